@@ -1,0 +1,499 @@
+"""Oracle solvers (test infrastructure only): NumPy/SciPy restatement of
+
+  src/errmeasure.jl:91-190                 Default/Residual/StandardSPMF error measures
+  src/LinSolvers.jl:109-159                FactorizeLinSolver, BackslashLinSolver, lin_solve
+  src/LinSolverCreators.jl:62-122          FactorizeLinSolverCreator (factorization reuse)
+  IterativeSolvers 0.9.2 (Manifest.toml:55-59) orthogonalize_and_normalize! DGKS/CGS/MGS
+       -- third-party, source not under /root/reference; published algorithm restated
+  src/method_iar.jl:47-184                 iar
+  src/method_tiar.jl:53-257                tiar
+  src/method_newton.jl:142-226,380-445,598-609   resinv, quasinewton, armijo_rule
+  src/compute_rf_wrapper.jl:25-54          compute_rf (ScalarNewtonInnerSolver)
+  src/method_beyncontour.jl:49-185         contour_beyn
+  src/method_contour_common.jl:61-94       integrate_interval (MatrixTrapezoidal)
+
+LU: SciPy's bundled SuperLU stands in for UMFPACK (SuiteSparse 5.10.1), which is not
+available in this image; differences appear at the 1e-13 level.
+"""
+import numpy as np
+import scipy.linalg as sla
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+EPS = np.finfo(float).eps
+
+
+class NoConvergenceException(Exception):
+    """NEPCore.jl:324-336."""
+
+    def __init__(self, lam, v, errmeasure, msg):
+        super().__init__(msg)
+        self.lam, self.v, self.errmeasure, self.msg = lam, v, errmeasure, msg
+
+
+class LostOrthogonalityException(Exception):
+    """NEPCore.jl:350."""
+
+
+# ----------------------------------------------------------------------------------
+# error measures
+class ResidualErrmeasure:
+    def __init__(self, nep):
+        self.nep = nep
+
+    def __call__(self, lam, v):
+        return np.linalg.norm(self.nep.compute_Mlincomb(lam, v)) / np.linalg.norm(v)
+
+
+def _fro(A):
+    return sla.norm(A.toarray() if sp.issparse(A) and A.shape[0] <= 64 else A.data) \
+        if sp.issparse(A) else np.linalg.norm(A)
+
+
+class StandardSPMFErrmeasure:
+    """errmeasure.jl:174-190 (Frobenius norms of the A_i)."""
+
+    def __init__(self, nep):
+        self.nep = nep
+        self.coeffs = [float(np.linalg.norm(A.data)) if sp.issparse(A) else float(np.linalg.norm(A))
+                       for A in nep.get_Av()]
+
+    def __call__(self, lam, v):
+        fv = self.nep.get_fv()
+        denom = sum(c * abs(f(lam)) for c, f in zip(self.coeffs, fv))
+        return np.linalg.norm(self.nep.compute_Mlincomb(lam, v)) / (np.linalg.norm(v) * denom)
+
+
+def DefaultErrmeasure(nep):
+    """errmeasure.jl:91-101."""
+    if hasattr(nep, "get_Av"):
+        return StandardSPMFErrmeasure(nep)
+    return ResidualErrmeasure(nep)
+
+
+# ----------------------------------------------------------------------------------
+# linear solvers
+class FactorizeLinSolver:
+    """LinSolvers.jl:109-137: factor M(lam) once, solve many."""
+
+    def __init__(self, nep, lam, permc_spec="COLAMD"):
+        A = nep.compute_Mder(lam)
+        self.sparse = sp.issparse(A)
+        if self.sparse:
+            self.Afact = spla.splu(sp.csc_matrix(A, dtype=complex), permc_spec=permc_spec)
+        else:
+            self.Afact = sla.lu_factor(np.asarray(A, dtype=complex))
+
+    def lin_solve(self, b, tol=0):
+        b = np.asarray(b, dtype=complex)
+        if self.sparse:
+            return self.Afact.solve(b)
+        return sla.lu_solve(self.Afact, b)
+
+
+class BackslashLinSolver:
+    """LinSolvers.jl:147-159: factor at every solve."""
+
+    def __init__(self, nep, lam):
+        self.A = nep.compute_Mder(lam)
+
+    def lin_solve(self, b, tol=0):
+        b = np.asarray(b, dtype=complex)
+        if sp.issparse(self.A):
+            return spla.splu(sp.csc_matrix(self.A, dtype=complex)).solve(b)
+        return np.linalg.solve(np.asarray(self.A, dtype=complex), b)
+
+
+class FactorizeLinSolverCreator:
+    """LinSolverCreators.jl:62-122."""
+
+    def __init__(self, max_factorizations=0, permc_spec="COLAMD"):
+        self.recycled = {}
+        self.max_factorizations = max_factorizations
+        self.permc_spec = permc_spec
+
+    def create_linsolver(self, nep, lam):
+        if lam in self.recycled:
+            return self.recycled[lam]
+        s = FactorizeLinSolver(nep, lam, self.permc_spec)
+        if len(self.recycled) < self.max_factorizations:
+            self.recycled[lam] = s
+        return s
+
+
+class BackslashLinSolverCreator:
+    def create_linsolver(self, nep, lam):
+        return BackslashLinSolver(nep, lam)
+
+
+DefaultLinSolverCreator = FactorizeLinSolverCreator
+
+
+# ----------------------------------------------------------------------------------
+# orthogonalisation (IterativeSolvers.orthogonalize_and_normalize!)
+def dgks(V, w, h):
+    """DGKS: h=V'w; w-=Vh; repeat while ||w|| < ||correction||/sqrt(2). In place on w,h.
+    Returns ||w|| before normalisation."""
+    h[:] = V.conj().T @ w
+    w -= V @ h
+    nrm = np.linalg.norm(w)
+    eta = 1.0 / np.sqrt(2.0)
+    projection_size = np.linalg.norm(h)
+    while nrm < eta * projection_size:
+        correction = V.conj().T @ w
+        projection_size = np.linalg.norm(correction)
+        w -= V @ correction
+        h += correction
+        nrm = np.linalg.norm(w)
+    w *= 1.0 / nrm
+    return nrm
+
+
+def cgs(V, w, h):
+    h[:] = V.conj().T @ w
+    w -= V @ h
+    nrm = np.linalg.norm(w)
+    w *= 1.0 / nrm
+    return nrm
+
+
+def mgs(V, w, h):
+    for i in range(V.shape[1]):
+        h[i] = np.vdot(V[:, i], w)
+        w -= h[i] * V[:, i]
+    nrm = np.linalg.norm(w)
+    w *= 1.0 / nrm
+    return nrm
+
+
+# ----------------------------------------------------------------------------------
+def _eig(H):
+    D, Z = sla.eig(H)
+    return D, Z
+
+
+def iar(nep, orthmethod=dgks, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
+        errmeasure=None, sigma=0.0, gamma=1.0, v=None, check_error_every=1, errhist=None,
+        timers=None):
+    """method_iar.jl:47-184 (proj_solve=false path).  F-ordered V so that
+    reshape(...) follows Julia's column-major semantics."""
+    import time
+    n = nep.size(1); m = maxit
+    sigma = complex(sigma)
+    if linsolvercreator is None:
+        linsolvercreator = DefaultLinSolverCreator()
+    if errmeasure is None:
+        errmeasure = DefaultErrmeasure(nep)
+    v = np.array(v, dtype=complex)
+    V = np.zeros((n * (m + 1), m + 1), dtype=complex, order="F")
+    H = np.zeros((m + 1, m), dtype=complex)
+    y = np.zeros((n, m + 1), dtype=complex, order="F")
+    alpha = (complex(gamma) ** np.arange(m + 1)).astype(complex); alpha[0] = 0
+    M0inv = linsolvercreator.create_linsolver(nep, sigma)
+    err = np.full((m, m), np.nan)
+    lam = np.zeros(m + 1, dtype=complex); Q = np.zeros((n, m + 1), dtype=complex)
+    V[:n, 0] = v / np.linalg.norm(v)
+    k = 1; conv_eig = 0
+    tm = timers if timers is not None else {}
+    for key in ("mlincomb", "solve", "orth", "ritz", "resid"):
+        tm.setdefault(key, 0.0)
+    while k <= m and conv_eig < neigs:
+        VV = V[:n * (k + 1), :k]
+        vv = V[:n * (k + 1), k]
+        y[:, 1:k + 1] = VV[:n * k, k - 1].reshape((n, k), order="F")
+        y[:, 1:k + 1] /= np.arange(1, k + 1)[None, :]
+        t0 = time.perf_counter()
+        y[:, 0] = nep.compute_Mlincomb(sigma, y[:, :k + 1], alpha[:k + 1])
+        t1 = time.perf_counter()
+        y[:, 0] = -M0inv.lin_solve(y[:, 0])
+        t2 = time.perf_counter()
+        vv[:] = y[:, :k + 1].reshape((k + 1) * n, order="F")
+        H[k, k - 1] = orthmethod(VV, vv, H[:k, k - 1])
+        t3 = time.perf_counter()
+        tm["mlincomb"] += t1 - t0; tm["solve"] += t2 - t1; tm["orth"] += t3 - t2
+        if (k % check_error_every == 0) or (k == m):
+            D, Z = _eig(H[:k, :k])
+            Q = V[:n, :k] @ Z
+            lam = sigma + gamma / D
+            t4 = time.perf_counter()
+            conv_eig = 0
+            err[k - 1, :k] = [errmeasure(lam[s], Q[:, s]) for s in range(k)]
+            t5 = time.perf_counter()
+            tm["ritz"] += t4 - t3; tm["resid"] += t5 - t4
+            if errhist is not None:
+                errhist.append(np.sort(err[k - 1, :k]).copy())
+            conv_eig = int(np.sum(err[k - 1, :k] < tol))
+            idx = np.argsort(err[k - 1, :k], kind="stable")
+            err[k - 1, :k] = err[k - 1, idx]
+            if k == m or conv_eig >= neigs:
+                nrof = int(min(len(lam), neigs))
+                lam = lam[idx[:nrof]]
+                Q = Q[:, idx[:len(lam)]]
+        k += 1
+    k -= 1
+    if conv_eig < neigs and neigs != np.inf:
+        raise NoConvergenceException(lam, Q, err[k - 1, :len(lam)],
+                                     "Number of iterations exceeded. maxit=%d." % maxit)
+    nc = min(len(lam), conv_eig)
+    return lam[:nc], Q[:, :nc], V[:, :k]
+
+
+def tiar(nep, orthmethod=dgks, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
+         errmeasure=None, sigma=0.0, gamma=1.0, v=None, check_error_every=1, errhist=None):
+    """method_tiar.jl:53-257 (proj_solve=false path). Note the Julia aliases f=g, ff=f
+    (:147,:164): updates of f also change g; g is rebuilt every step."""
+    n = nep.size(1); m = maxit
+    sigma = complex(sigma)
+    if n < m:
+        raise LostOrthogonalityException("Loss of orthogonality in the matrix Z. The problem size "
+                                         "is too small, use iar instead.")
+    if linsolvercreator is None:
+        linsolvercreator = DefaultLinSolverCreator()
+    if errmeasure is None:
+        errmeasure = DefaultErrmeasure(nep)
+    v = np.array(v, dtype=complex)
+    a = np.zeros((m + 1, m + 1, m + 1), dtype=complex)
+    Z = np.zeros((n, m + 1), dtype=complex, order="F")
+    t = np.zeros(m + 1, dtype=complex)
+    g = np.zeros((m + 1, m + 1), dtype=complex)
+    H = np.zeros((m + 1, m), dtype=complex)
+    y = np.zeros((n, m + 1), dtype=complex, order="F")
+    alpha = (complex(gamma) ** np.arange(m + 1)).astype(complex); alpha[0] = 0
+    M0inv = linsolvercreator.create_linsolver(nep, sigma)
+    err = np.full((m + 1, m + 1), np.nan)
+    lam = np.zeros(m + 1, dtype=complex); Q = np.zeros((n, m + 1), dtype=complex)
+    Z[:, 0] = v / np.linalg.norm(v)
+    a[0, 0, 0] = 1
+    conv_eig_hist = np.zeros(m + 1, dtype=int)
+    k = 1; conv_eig = 0
+    while k <= m and conv_eig < neigs:
+        y[:, 1:k + 1] = Z[:, :k] @ a[:k, k - 1, :k].T
+        y[:, 1:k + 1] /= np.arange(1, k + 1)[None, :]
+        y[:, 0] = nep.compute_Mlincomb(sigma, y[:, :k + 1], alpha[:k + 1])
+        y[:, 0] = -M0inv.lin_solve(y[:, 0])
+        Z[:, k] = y[:, 0]
+        t[k] = orthmethod(Z[:, :k], Z[:, k], t[:k])
+        # G
+        for l in range(k + 1):
+            for i in range(1, k + 1):
+                g[i, l] = a[i - 1, k - 1, l] / i
+            g[0, l] = t[l]
+        # h
+        h = np.zeros(m + 1, dtype=complex)
+        for l in range(k):
+            h[:k] += a[:k, :k, l].conj().T @ g[:k, l]
+        f = g  # alias, as in Julia
+        for l in range(k):
+            f[:k + 1, l] -= a[:k + 1, :k, l] @ h[:k]
+        hh = np.zeros(m + 1, dtype=complex)
+        for l in range(k):
+            hh[:k] += a[:k, :k, l].conj().T @ f[:k, l]
+        ff = f
+        for l in range(k):
+            ff[:k + 1, l] -= a[:k + 1, :k, l] @ hh[:k]
+        h = h + hh; f = ff
+        beta = np.linalg.norm(f[:k + 1, :k + 1])
+        H[:k, k - 1] = h[:k]; H[k, k - 1] = beta
+        a[:k + 1, k, :k + 1] = f[:k + 1, :k + 1] / beta
+        if (k % check_error_every == 0) or (k == m):
+            D, W = _eig(H[:k, :k])
+            VV = Z[:, :k] @ a[0, :k, :k].T
+            Q = VV @ W
+            lam = sigma + gamma / D
+            conv_eig = 0
+            err[k - 1, :k] = [errmeasure(lam[s], Q[:, s]) for s in range(k)]
+            if errhist is not None:
+                errhist.append(np.sort(err[k - 1, :k]).copy())
+            conv_eig = int(np.sum(err[k - 1, :k] < tol))
+            idx = np.argsort(err[k - 1, :k], kind="stable")
+            err[k - 1, :k] = err[k - 1, idx]
+            if k == m or conv_eig >= neigs:
+                nrof = int(min(len(lam), neigs))
+                lam = lam[idx[:nrof]]
+                Q = Q[:, idx[:nrof]]
+            conv_eig_hist[k - 1] = conv_eig
+        k += 1
+    k -= 1
+    if conv_eig < neigs and neigs != np.inf:
+        raise NoConvergenceException(lam, Q, None, "Number of iterations exceeded. maxit=%d." % maxit)
+    nc = min(len(lam), conv_eig)
+    return lam[:nc], Q[:, :nc], Z[:, :k], conv_eig_hist
+
+
+# ----------------------------------------------------------------------------------
+def compute_rf(nep, x, y=None, target=0.0, lam=None, tol=EPS * 100, maxit=80):
+    """compute_rf_wrapper.jl:25-54 (ScalarNewtonInnerSolver)."""
+    if y is None:
+        y = x
+    lam_iter = complex(target if lam is None else lam)
+    dlam = np.inf; count = 0
+    while abs(dlam) > tol and count < maxit:
+        count += 1
+        z1 = nep.compute_Mlincomb(lam_iter, x.reshape(-1, 1))
+        z2 = nep.compute_Mlincomb(lam_iter, x.reshape(-1, 1), [1.0], 1)
+        dlam = -np.vdot(y, z1) / np.vdot(y, z2)
+        lam_iter += dlam
+    return np.array([lam_iter])
+
+
+def armijo_rule(nep, errmeasure, err0, lam, v, dlam, dv, armijo_factor, armijo_max):
+    """method_newton.jl:598-609."""
+    j = 0
+    if armijo_factor < 1:
+        while errmeasure(lam + dlam, v + dv) > err0 and j < armijo_max:
+            j += 1
+            dv = dv * armijo_factor
+            dlam = dlam * armijo_factor
+    return dlam, dv, j, armijo_factor ** j
+
+
+def resinv(nep, errmeasure=None, tol=EPS * 100, maxit=100, lam=0.0, v=None, c=None,
+           linsolvercreator=None, armijo_factor=1, armijo_max=5, hist=None):
+    """method_newton.jl:142-226."""
+    lam = complex(lam)
+    v = np.array(v, dtype=complex)
+    c = v.copy() if c is None else np.array(c, dtype=complex)
+    n = len(v)
+    if errmeasure is None:
+        errmeasure = DefaultErrmeasure(nep)
+    if linsolvercreator is None:
+        linsolvercreator = DefaultLinSolverCreator()
+    linsolver = linsolvercreator.create_linsolver(nep, lam)
+    use_v_as_rf_vector = np.linalg.norm(c) == 0
+    sigma = lam
+    err = np.inf
+    for k in range(1, maxit + 1):
+        v = v / np.linalg.norm(v)
+        err = errmeasure(lam, v)
+        if use_v_as_rf_vector:
+            c = v.copy()
+        if hist is not None:
+            hist.append((k, err, lam))
+        if err < tol:
+            return lam, v
+        lam_vec = compute_rf(nep, v, y=c, lam=lam, target=sigma)
+        lam1 = lam_vec[np.argmin(abs(lam_vec - lam))]
+        dlam = lam1 - lam
+        dv = -linsolver.lin_solve(nep.compute_Mlincomb(lam1, v.reshape(n, 1)))
+        dlam, dv, j, scaling = armijo_rule(nep, errmeasure, err, lam, v, dlam, dv,
+                                           float(armijo_factor), armijo_max)
+        lam += dlam
+        v = v + dv
+    raise NoConvergenceException(lam, v, err, "Number of iterations exceeded. maxit=%d." % maxit)
+
+
+def quasinewton(nep, errmeasure=None, tol=EPS * 100, maxit=100, lam=0.0, v=None, ws=None,
+                linsolvercreator=None, armijo_factor=1, armijo_max=5, hist=None):
+    """method_newton.jl:380-445."""
+    lam = complex(lam)
+    v = np.array(v, dtype=complex)
+    ws = v.copy() if ws is None else np.array(ws, dtype=complex)
+    if errmeasure is None:
+        errmeasure = DefaultErrmeasure(nep)
+    if linsolvercreator is None:
+        linsolvercreator = DefaultLinSolverCreator()
+    linsolver = linsolvercreator.create_linsolver(nep, lam)
+    err = np.inf
+    for k in range(1, maxit + 1):
+        err = errmeasure(lam, v)
+        if hist is not None:
+            hist.append((k, err, lam))
+        if err < tol:
+            return lam, v
+        u = nep.compute_Mlincomb(lam, v, [1.0], 0)
+        w = nep.compute_Mlincomb(lam, v, [1.0], 1)
+        dlam = -np.vdot(ws, u) / np.vdot(ws, w)
+        z = dlam * w + u
+        dv = -linsolver.lin_solve(z, tol=tol)
+        dlam, dv, j, scaling = armijo_rule(nep, errmeasure, err, lam, v, dlam, dv,
+                                           float(armijo_factor), armijo_max)
+        lam += dlam
+        v = v + dv
+    raise NoConvergenceException(lam, v, err, "Number of iterations exceeded. maxit=%d." % maxit)
+
+
+# ----------------------------------------------------------------------------------
+def integrate_interval_trapezoidal(f, gv, a, b, N):
+    """method_contour_common.jl:61-94."""
+    h = (b - a) / N
+    t = a + h * np.arange(N)
+    f1 = f(t[0])
+    m = len(gv)
+    S = np.zeros(f1.shape + (m,), dtype=complex)
+    G = np.zeros((N, m), dtype=complex)
+    for i in range(m):
+        G[:, i] = [gv[i](tt) for tt in t]
+    for i in range(N):
+        temp = f1 if i == 0 else f(t[i])
+        for j in range(m):
+            S[:, :, j] += temp * G[i, j]
+    return S * h
+
+
+def probe_block(n, k, seed=10):
+    """Deterministic replacement of `Random.seed!(10); randn(n,k)` (method_beyncontour.jl:85-86);
+    Julia's stream is not reproducible outside Julia, so only counts/residuals are compared."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    return rng.standard_normal((n, k)).astype(complex)
+
+
+def contour_beyn(nep, tol=np.sqrt(EPS), sigma=0.0, linsolvercreator=None, neigs=2, k=None,
+                 radius=1, N=1000, errmeasure=None, sanity_check=True, rank_drop_tol=None,
+                 Vh=None, info=None):
+    """method_beyncontour.jl:49-185."""
+    if k is None:
+        k = neigs + 1
+    if rank_drop_tol is None:
+        rank_drop_tol = tol
+    if np.isscalar(radius):
+        radius = (radius, radius)
+    if linsolvercreator is None:
+        linsolvercreator = BackslashLinSolverCreator()
+    if errmeasure is None:
+        errmeasure = DefaultErrmeasure(nep)
+    g = lambda t: complex(radius[0] * np.cos(t), radius[1] * np.sin(t))
+    gp = lambda t: complex(-radius[0] * np.sin(t), radius[1] * np.cos(t))
+    n = nep.size(1)
+    if k > n:
+        raise ValueError("Cannot compute more eigenvalues than the size of the NEP with contour_beyn()")
+    if k <= 0:
+        raise ValueError("k must be positive")
+    if Vh is None:
+        Vh = probe_block(n, k)
+
+    def local_linsolve(lam):
+        return linsolvercreator.create_linsolver(nep, lam + sigma).lin_solve(Vh)
+
+    f = lambda t: local_linsolve(g(t)) * gp(t)
+    AA = integrate_interval_trapezoidal(f, [lambda s: 1.0 + 0j, g], 0, 2 * np.pi, N)
+    A0 = AA[:, :, 0] / (2j * np.pi)
+    A1 = AA[:, :, 1] / (2j * np.pi)
+    V, S, Wh = sla.svd(A0, full_matrices=False)
+    W = Wh.conj().T
+    p = int(np.sum(S / S[0] > rank_drop_tol))
+    V0 = V[:, :p]; W0 = W[:, :p]
+    B = (V0.conj().T @ A1 @ W0) @ np.diag(1.0 / S[:p])
+    lam, VB = sla.eig(B)
+    lam = lam + sigma
+    V = V0 @ VB
+    V = V / np.linalg.norm(V, axis=0)[None, :]
+    if info is not None:
+        info.update(p=p, S=S, A0=A0, A1=A1)
+
+    def inside(l):
+        return ((l - sigma).real / radius[0]) ** 2 + ((l - sigma).imag / radius[1]) ** 2 <= 1
+
+    if not sanity_check:
+        si = np.argsort(abs(sigma - lam), kind="stable")
+        ins = inside(lam[si])
+        perm = np.argsort(~ins, kind="stable")
+        return lam[si[perm]], V[:, si[perm]]
+    errs = np.array([errmeasure(lam[i], V[:, i]) for i in range(p)])
+    good = np.nonzero(errs < tol)[0]
+    sgi = good[np.argsort(abs(sigma - lam[good]), kind="stable")]
+    ins = inside(lam[sgi])
+    perm = np.argsort(~ins, kind="stable")
+    sel = sgi[perm]
+    if len(sel) > neigs:
+        sel = sel[:neigs]
+    return lam[sel], V[:, sel]

@@ -1,0 +1,179 @@
+"""Pins the CPU oracle against the known-answer values the reference publishes in its
+own docstrings and tests.  CPU only."""
+import numpy as np
+import pytest
+from oracle import gallery, neps, solvers
+
+EPS = np.finfo(float).eps
+
+
+def test_msws_dep0_mder():
+    # src/NEPTypes.jl:66-79
+    nep = gallery.dep0()
+    assert nep.compute_Mder(3.0)[0, 0] == pytest.approx(-2.942777908030041, abs=1e-15)
+
+
+def test_dep0_100_mlincomb_norm():
+    # src/Gallery.jl:172-176
+    nep = gallery.dep0(100)
+    z = nep.compute_Mlincomb(1.0 + 1.0j, np.ones(100))
+    assert np.linalg.norm(z) == pytest.approx(57.498446538064954, rel=1e-14)
+
+
+def test_dep0_mder_vs_mlincomb():
+    # src/NEPCore.jl:105-108
+    nep = gallery.dep0(); v = np.ones(5); lam = -1 + 1j
+    d = nep.compute_Mder(lam, 1) @ v - nep.compute_Mlincomb(lam, np.column_stack([v, v]), [0, 1])
+    assert np.linalg.norm(d) < 1e-14
+
+
+def test_dep0_fd_derivative():
+    # src/NEPCore.jl:81-86
+    nep = gallery.dep0(); lam = 2.25; e = 1e-5
+    fd = (nep.compute_Mder(lam + e) - nep.compute_Mder(lam - e)) / (2 * e)
+    assert np.linalg.norm(fd - nep.compute_Mder(lam, 1)) < 1e-9
+
+
+def test_gun_W_onenorms():
+    # test/rk_helper/gun_test_utils.jl:52-53
+    W1, W2 = gallery.gun_W()
+    assert abs(W1).sum(axis=0).max() == pytest.approx(2.328612251920476, rel=1e-15)
+    assert abs(W2).sum(axis=0).max() == pytest.approx(3.793375498194695, rel=1e-15)
+    assert W1.shape == (9956, 9956) and W1.nnz == 57 and W2.nnz == 293
+
+
+def test_gun_standin_norms():
+    K, M = gallery.gun_standin_KM()
+    assert K.shape == (9956, 9956)
+    assert abs(K).sum(axis=0).max() == pytest.approx(gallery.GUN_NK, rel=1e-14)
+    assert abs(M).sum(axis=0).max() == pytest.approx(gallery.GUN_NM, rel=1e-14)
+    assert K.nnz == 49366 and M.nnz == 88366
+
+
+def test_tiar_iar_docstring_eigs():
+    # src/method_tiar.jl:37-45
+    nep = gallery.dep0(100)
+    ref = np.array([-0.07708769561361105, 0.050462487743188206, 0.1503916927814904])
+    l, Q, _, _ = solvers.tiar(nep, v=np.ones(100), tol=1e-5, neigs=3)
+    assert np.allclose(np.sort(l.real), ref, atol=1e-13) and np.max(abs(l.imag)) < 1e-13
+    l, Q, _ = solvers.iar(nep, v=np.ones(100), tol=1e-5, neigs=3)
+    assert np.allclose(np.sort(l.real), ref, atol=1e-13)
+
+
+def test_iar_dep0_counts():
+    # test/iar.jl:23-39
+    nep = gallery.dep0()
+    R = solvers.ResidualErrmeasure(nep)
+    l, Q, V = solvers.iar(nep, sigma=1.1, v=np.ones(5), maxit=100, tol=EPS * 100, neigs=5, errmeasure=R)
+    assert len(l) == 5
+    assert all(R(l[i], Q[:, i]) < EPS * 100 for i in range(5))
+    l, Q, V = solvers.iar(nep, sigma=1.1, v=np.ones(5), maxit=38, tol=EPS * 100, neigs=np.inf)
+    assert len(l) == 6
+    assert np.linalg.norm(V.conj().T @ V - np.eye(V.shape[1]), 2) < 1e-6
+
+
+@pytest.mark.parametrize("orth", [solvers.dgks, solvers.cgs, solvers.mgs])
+def test_iar_orthogonality(orth):
+    # test/iar.jl:41-63
+    nep = gallery.dep0()
+    l, Q, V = solvers.iar(nep, orthmethod=orth, sigma=1.1, v=np.ones(5), maxit=100,
+                          tol=EPS * 100, neigs=5, errmeasure=solvers.ResidualErrmeasure(nep))
+    assert np.linalg.norm(V.conj().T @ V - np.eye(V.shape[1]), 2) < 1e-6
+
+
+def test_iar_noconvergence():
+    # test/iar.jl:65-70
+    nep = gallery.dep0(100)
+    with pytest.raises(solvers.NoConvergenceException):
+        solvers.iar(nep, sigma=1.1, v=np.ones(100), neigs=6, maxit=7, tol=EPS * 100)
+
+
+def test_tiar_counts_and_orth():
+    # test/tiar.jl:23-39, 86-90
+    nep = gallery.dep0(100)
+    R = solvers.ResidualErrmeasure(nep)
+    l, Q, Z, _ = solvers.tiar(nep, sigma=1.1, gamma=3, neigs=2, v=np.ones(100), maxit=50,
+                              tol=EPS * 100, errmeasure=R)
+    assert len(l) == 2
+    l, Q, Z, _ = solvers.tiar(nep, sigma=1.1, gamma=3, neigs=np.inf, v=np.ones(100), maxit=50,
+                              tol=EPS * 100, errmeasure=R)
+    assert len(l) == 7
+    assert max(R(l[i], Q[:, i]) for i in range(7)) < EPS * 100
+    assert np.linalg.norm(Z.conj().T @ Z - np.eye(Z.shape[1]), 2) < 1e-6
+    with pytest.raises(solvers.NoConvergenceException):
+        solvers.tiar(nep, sigma=2.0, gamma=3, neigs=4, v=np.ones(100), maxit=5, tol=EPS * 100)
+
+
+def test_tiar_equals_iar():
+    # test/tiar.jl:59-69
+    nep = gallery.dep0(100)
+    kw = dict(sigma=1.1, gamma=3, neigs=3, v=np.ones(100), maxit=50, tol=1e-10)
+    l1, Q1, _, _ = solvers.tiar(nep, **kw)
+    l2, Q2, _ = solvers.iar(nep, **kw)
+    assert np.allclose(np.sort_complex(l1), np.sort_complex(l2), atol=1e-6)
+
+
+def test_qdep0_quasinewton_history():
+    # src/errmeasure.jl:156-169
+    q = gallery.qdep0()
+    hist = []
+    solvers.quasinewton(q, lam=-1, v=np.ones(1000), errmeasure=solvers.StandardSPMFErrmeasure(q),
+                        tol=1e-10, hist=hist)
+    ref = [(0.022010375110869937, -1.0), (0.002515422247048546, -0.7063330111559607),
+           (0.000892354247568813, -0.8919579082730457), (5.445678793151584e-5, -1.0097584042560848),
+           (6.649967517409105e-7, -1.0023823873044), (1.0557281809769784e-8, -1.0024660870524031),
+           (6.420125566431444e-9, -1.0024677891861997), (3.181093707909799e-10, -1.0024669496893164),
+           (2.6368050026394416e-11, -1.0024669918249076)]
+    assert len(hist) == 9
+    for (k, err, lam), (eref, lref) in zip(hist, ref):
+        assert lam.real == pytest.approx(lref, rel=1e-11)
+        assert err == pytest.approx(eref, rel=1e-5)
+    assert hist[0][1] == pytest.approx(ref[0][0], rel=1e-14)   # pure sparse Mlincomb + Frobenius norms
+
+
+def test_beyn_dep0():
+    # test/beyn.jl:15-46
+    nep = gallery.dep0()
+    l, V = solvers.contour_beyn(nep, radius=1, neigs=1, sanity_check=False)
+    M = nep.compute_Mder(l[0])
+    assert np.linalg.svd(M, compute_uv=False).min() < EPS * 1000
+    assert np.linalg.norm(nep.compute_Mlincomb(l[0], V[:, 0])) < EPS * 500
+    l, V = solvers.contour_beyn(nep, sigma=0.2, radius=1.0, neigs=4, sanity_check=False)
+    assert len(l) == 3
+
+
+def test_resinv_dep0():
+    # SURVEY.md section 8d C1 (probe-derived expectation; reference has no resinv/dep0 KAT)
+    nep = gallery.dep0(); hist = []
+    l, v = solvers.resinv(nep, lam=0, v=np.ones(5), hist=hist)
+    assert l.real == pytest.approx(-0.1595539182329811, rel=1e-12)
+    assert len(hist) == 19
+
+
+def test_mlincomb_identities():
+    # test/core.jl:16-32, 99-128 ; test/spmf.jl:127-156
+    rng = np.random.default_rng(0)
+    nep = gallery.dep0()
+    V = rng.standard_normal((5, 3)) + 1j * rng.standard_normal((5, 3))
+    lam = 0.3 + 1j
+    z1 = nep.compute_Mlincomb(lam, V)
+    z2 = nep.compute_Mlincomb(lam, V, np.ones(3))
+    assert np.array_equal(z1, z2)
+    z3 = sum(nep.compute_Mder(lam, i) @ V[:, i] for i in range(3))
+    assert np.allclose(z1, z3)
+    a = nep.compute_Mlincomb(lam, V, [0, 0, 1]); b = nep.compute_Mlincomb(lam, V[:, 2], [1], 2)
+    assert np.allclose(a, b, rtol=1e-12)
+    assert np.allclose(z1, nep.compute_Mlincomb_from_MM(lam, V), rtol=1e-10)
+    # gun nonlinearities on random sparse 5x5
+    import scipy.sparse as sp
+    AA = [sp.random(5, 5, 0.6, random_state=i, format="csc") for i in range(4)]
+    fv = [neps.f_one(), neps.f_id(), neps.f_isqrt(0.0), neps.f_isqrt(-108.8774 ** 2)]
+    spmf = neps.SPMF_NEP(AA, fv)
+    lam = 120.0 ** 2 + 3j
+    der = neps.DerSPMF(spmf, lam, 3)
+    a = rng.standard_normal(3)
+    za = spmf.compute_Mlincomb(lam, V, a); zb = der.compute_Mlincomb(lam, V, a)
+    assert np.allclose(za, zb, rtol=1e-10)
+    assert np.allclose(za, spmf.compute_Mlincomb_from_MM(lam, V, a), rtol=1e-10)
+    zc = sum(a[i] * (spmf.compute_Mder(lam, i) @ V[:, i]) for i in range(3))
+    assert np.allclose(za, zc, rtol=1e-10)
