@@ -1,0 +1,170 @@
+/*
+ * nepmi355.h -- C ABI of libnepmi355.so, the MI355X (gfx950) inner linear-algebra backend
+ * for NEP-PACK-style nonlinear eigensolvers.
+ *
+ * The reference (nep-pack/NonlinearEigenproblems.jl, 100 % Julia) has no FFI; its plug-in
+ * seams are four small abstract types.  Every entry point below names
+ * the reference interface it replaces (file:line under /root/reference).  A Julia binding
+ * reaches these with `ccall((:nep_xxx, "libnepmi355"), Cint, (...), ...)` -- see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; no C++/torch types cross this boundary.
+ *   - every function returns int32 status: 0 = ok, <0 = error (nep_last_error() has text);
+ *     nothing throws.
+ *   - `d`-prefixed pointers are DEVICE pointers (from nep_dev_alloc, or any HIP allocation of
+ *     the same process, e.g. a torch tensor's data_ptr()); `h`-prefixed pointers are HOST.
+ *   - dense blocks are complex128 (re,im interleaved), COLUMN-MAJOR with explicit leading
+ *     dimension, i.e. exactly Julia's Matrix{ComplexF64} layout -- unless a parameter says
+ *     row-major.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Functions whose
+ *     results are written to host memory synchronise that stream before returning; all others
+ *     are asynchronous with respect to the host.
+ *   - a handle is used by one host thread at a time; distinct handles may be used concurrently.
+ */
+#ifndef NEPMI355_H
+#define NEPMI355_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct { double re, im; } nep_cdouble;
+typedef struct nep_spmf nep_spmf; /* device-resident SPMF: stacked CSR of A_1..A_mt */
+typedef struct nep_lu nep_lu;     /* device-resident sparse LU factors + solve schedule */
+typedef void* nep_stream;
+
+#define NEP_OK 0
+#define NEP_ERR_HIP -1      /* a HIP runtime call failed (no device, OOM, launch failure) */
+#define NEP_ERR_ARG -2      /* invalid argument */
+#define NEP_ERR_SINGULAR -3 /* zero pivot met in the triangular solve (SingularException analogue) */
+#define NEP_ERR_BREAKDOWN -4 /* orthogonalisation breakdown: ||w|| == 0 */
+
+/* ---- library / device ---------------------------------------------------------------- */
+int32_t nep_version(void);
+const char* nep_last_error(void);
+int32_t nep_device_count(int32_t* n);
+int32_t nep_set_device(int32_t dev);
+int32_t nep_device_name(char* buf, int32_t buflen);
+
+/* ---- raw device memory (for hosts without their own HIP allocator, e.g. Julia) ------- */
+int32_t nep_dev_alloc(void** dptr, size_t bytes);
+int32_t nep_dev_free(void* dptr);
+int32_t nep_dev_memset(void* dptr, int32_t value, size_t bytes, nep_stream stream);
+int32_t nep_upload(void* ddst, const void* hsrc, size_t bytes, nep_stream stream);   /* sync */
+int32_t nep_download(void* hdst, const void* dsrc, size_t bytes, nep_stream stream); /* sync */
+int32_t nep_dev_copy(void* ddst, const void* dsrc, size_t bytes, nep_stream stream);
+int32_t nep_stream_sync(nep_stream stream);
+
+/* ---- SPMF object: M(lambda) = sum_i f_i(lambda) A_i ------------------------------------
+ * replaces: struct SPMF_NEP  src/NEPTypes.jl:162-170 (+ get_Av :103, DEP :427-443,
+ *           PEP src/types_poly.jl:31-34, SPMFSumNEP src/NEPTypes.jl:845-847 -- all are
+ *           "a list of matrices" to the device).
+ * Input: mt matrices of size n x n in CSR (0-based, int32): rowptr[i] (n+1), colind[i], vals[i]
+ * (double if val_is_complex[i]==0 else nep_cdouble).  Julia's CSC of A is the CSR of A^T; the
+ * binding passes transpose(A_i) in CSC form, or uses nep_csc_to_csr below.
+ * The library builds ONE stacked CSR over all terms (entries sorted by (col,term) per row). */
+int32_t nep_spmf_create(int64_t n, int32_t mt, const int32_t* const* h_rowptr,
+                        const int32_t* const* h_colind, const void* const* h_vals,
+                        const int32_t* h_val_is_complex, nep_spmf** out);
+int32_t nep_spmf_destroy(nep_spmf* s);
+/* info[0]=n info[1]=mt info[2]=total nnz info[3]=value bytes (8|16) info[4]=lanes per row
+ * chosen for the SpMV info[5]=algorithmic matrix bytes of one pass over the stacked CSR */
+int32_t nep_spmf_info(const nep_spmf* s, int64_t info[6]);
+int32_t nep_csc_to_csr(int64_t n, const int64_t* colptr, const int64_t* rowval, const void* nzval,
+                       int32_t val_is_complex, int32_t one_based, int32_t* rowptr, int32_t* colind,
+                       void* vals);
+
+/* K1  z = sum_i A_i * (V * C[:,i])          V: n x k (ldv), C: k x mt (host, column-major)
+ * replaces: compute_Mlincomb!(::SPMF_NEP,...) src/NEPTypes.jl:972-1011 and
+ *           compute_Mlincomb(::DerSPMF,...)   src/NEPTypes.jl:1130-1160 (VafD=V*(a.*fD); z+=Av[j]*VafD[:,j]),
+ *           PEP :1016-1045, DEP :940-970, SumNEP :889-890 (all are this with other C).
+ * The host forms C[j,i] = a_j * f_i^(j-1)(lambda) (NEPCore.jl:218-228 identity). dV is not modified. */
+int32_t nep_mlincomb(nep_spmf* s, int32_t k, const nep_cdouble* hC, const nep_cdouble* dV,
+                     int64_t ldv, nep_cdouble* dz, nep_stream stream);
+
+/* K2  residual batch: r_s = sum_i F[i,s] A_i q_s, s=1..k; returns ||r_s||_2 and ||q_s||_2.
+ * replaces: k calls of estimate_error -> compute_Mlincomb(nep,lambda_s,q_s)
+ *           src/errmeasure.jl:128-130,186-190; call sites src/method_iar.jl:134-135,
+ *           src/method_tiar.jl:211-212, src/method_beyncontour.jl:142-144.
+ * dQT: the k vectors stored ROW-major (row r holds q_1[r]..q_k[r]; row stride ldq >= k), which is
+ * what nep_gemm_ts(..., y_rowmajor=1) produces.  hF: mt x k column-major host.  Synchronous. */
+int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT,
+                        int64_t ldq, double* h_rnorm, double* h_qnorm, nep_stream stream);
+
+/* compute_MM building block: ZT = sum_i A_i * XT[:, i*p:(i+1)*p]  (row-major in and out)
+ * replaces: compute_MM(::SPMF_NEP,S,V) src/NEPTypes.jl:276-319 (Z += AA[i]*(V*f_i(S))) after
+ *           XT = (V*[F_1..F_mt])^T has been formed with nep_gemm_ts. */
+int32_t nep_spmm_terms(nep_spmf* s, int32_t p, const nep_cdouble* dXT, int64_t ldx,
+                       nep_cdouble* dZT, int64_t ldz, nep_stream stream);
+
+/* ---- K6 Gram-Schmidt -------------------------------------------------------------------
+ * replaces: IterativeSolvers.orthogonalize_and_normalize!(V,w,h,method) (third-party,
+ *           IterativeSolvers 0.9.2) at src/method_iar.jl:107, src/method_tiar.jl:128,
+ *           src/method_nleigs.jl:293.
+ * h = V^H w; w -= V h; [DGKS: while ||w|| < ||corr||/sqrt(2): corr=V^H w; w-=V corr; h+=corr];
+ * beta=||w||; w/=beta.   dV: rows x k (ldv).  h_active_rows (nullable, k entries): number of
+ * leading rows of column j that can be non-zero (iar's block-triangular basis); rows beyond are
+ * skipped.  method: 0 = DGKS, 1 = classical GS (one pass), 2 = modified GS.  Synchronous. */
+int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
+                 const int64_t* h_active_rows, nep_cdouble* dw, nep_cdouble* h_h, double* h_beta,
+                 int32_t method, int32_t* h_npasses, nep_stream stream);
+
+/* ---- K7 tall-skinny GEMM on the FP64 matrix cores --------------------------------------
+ * Y = Z * B,  Z: rows x k (ldz, device), B: k x p (host, column-major, ldb), Y: rows x p.
+ * y_rowmajor=0: Y column-major (ldy >= rows); =1: Y row-major (ldy >= p).
+ * replaces: Q=VV*Z src/method_iar.jl:115; Z[:,1:k]*transpose(a[1:k,k,1:k]) src/method_tiar.jl:119,
+ *           :188-189; V*(H*S) src/method_nleigs.jl:318; V*(a.*fD) src/NEPTypes.jl:1154. */
+int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_t k,
+                    const nep_cdouble* hB, int64_t ldb, int32_t p, nep_cdouble* dY, int64_t ldy,
+                    int32_t y_rowmajor, nep_stream stream);
+
+/* ---- K5 fixed-shift solve with a host-computed sparse LU -------------------------------
+ * replaces: FactorizeLinSolver / lin_solve src/LinSolvers.jl:109-137 (Afact \ x) and
+ *           BackslashLinSolver :147-159; the factorisation (UMFPACK in the reference) stays on
+ *           the host, one-off per shift (BASELINE.json north_star).
+ * Factors satisfy Pr*A*Pc = L*U with L unit lower (diagonal stored or not), U upper.  L and U are
+ * given in CSR (0-based int32, complex128 values).  perm_r/perm_c follow SciPy/SuperLU:
+ * (Pr b)[perm_r[i]] = b[i],  x[i] = y[perm_c[i]].  NULL perms mean identity. */
+int32_t nep_lu_create(int64_t n, const int32_t* hLp, const int32_t* hLi, const nep_cdouble* hLx,
+                      const int32_t* hUp, const int32_t* hUi, const nep_cdouble* hUx,
+                      const int32_t* h_perm_r, const int32_t* h_perm_c, nep_lu** out);
+int32_t nep_lu_destroy(nep_lu* lu);
+/* info[0]=n info[1]=nnz(L) info[2]=nnz(U) info[3]=levels(L) info[4]=levels(U)
+ * info[5]=algorithmic bytes of one solve with one right-hand side */
+int32_t nep_lu_info(const nep_lu* lu, int64_t info[6]);
+/* X = A^{-1} B for nrhs right-hand sides; dB, dX: n x nrhs column-major; dX may alias dB.
+ * scale is applied to the result (iar/tiar use -1: y = -lin_solve(...), src/method_iar.jl:103). */
+int32_t nep_lu_solve(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_t ldb, nep_cdouble* dX,
+                     int64_t ldx, double scale, nep_stream stream);
+
+/* ---- small BLAS-1 style helpers used by the drivers ------------------------------------ */
+/* iar basis step (src/method_iar.jl:100-101,105): dst[(j+1)*n + r] = src[j*n + r]/(j+1), j=0..k-1 */
+int32_t nep_iar_shift_scale(int64_t n, int32_t k, const nep_cdouble* dsrc, nep_cdouble* ddst,
+                            nep_stream stream);
+/* y += alpha * x   (len complex entries); K8 quadrature accumulation
+ * src/method_contour_common.jl:88-90 (S[:,:,j] += temp*G[i,j]) */
+int32_t nep_axpy(int64_t len, nep_cdouble alpha, const nep_cdouble* dx, nep_cdouble* dy,
+                 nep_stream stream);
+/* x *= alpha */
+int32_t nep_scal(int64_t len, nep_cdouble alpha, nep_cdouble* dx, nep_stream stream);
+/* ||x||_2 of len complex entries (synchronous) */
+int32_t nep_nrm2(int64_t len, const nep_cdouble* dx, double* h_out, nep_stream stream);
+/* column norms of a column-major rows x k block (synchronous) */
+int32_t nep_colnorms(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx, double* h_out,
+                     nep_stream stream);
+/* dot products d_j = x_j^H y_j of the columns of two rows x k blocks (synchronous) */
+int32_t nep_coldots(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx,
+                    const nep_cdouble* dY, int64_t ldy, nep_cdouble* h_out, nep_stream stream);
+/* out-of-place transpose: row-major (rows x k, ld lds) -> column-major (ldd), selected columns
+ * cols[0..ncols) (host int32, NULL = all) */
+int32_t nep_rowmajor_to_colmajor(int64_t rows, int32_t k, const nep_cdouble* dsrc, int64_t lds,
+                                 const int32_t* h_cols, int32_t ncols, nep_cdouble* ddst,
+                                 int64_t ldd, nep_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NEPMI355_H */

@@ -1,0 +1,21 @@
+"""nep_amd -- MI355X-native inner linear-algebra backend for NEP-PACK-style nonlinear eigensolvers.
+
+Product package (directory `nonlineareigenproblems.jl_amd/`, import name `nep_amd`).  The compute
+path is libnepmi355.so (hand-written HIP for gfx950 behind the C ABI of include/nepmi355.h); this
+package is the host-side mirror of the reference's NEP / LinSolver / orthogonalisation interface.
+It never imports the CPU oracle and has no CPU fallback.
+"""
+from . import _lib, funcs, dense
+from ._lib import NepError, device_count, LIB_PATH
+from .exceptions import NoConvergenceException, LostOrthogonalityException
+from .nep import (NEP, AbstractSPMF, SPMF_NEP, DEP, PEP, SumNEP, DerSPMF, shift_and_scale, SPMFDevice,
+                  to_dev, to_host)
+from .linsolvers import (LinSolver, FactorizeLinSolver, BackslashLinSolver, FactorizeLinSolverCreator,
+                         BackslashLinSolverCreator, DefaultLinSolverCreator, create_linsolver, lin_solve,
+                         LinSolverCache, DeviceLU)
+from .errmeasure import (Errmeasure, ResidualErrmeasure, StandardSPMFErrmeasure, DefaultErrmeasure,
+                         estimate_error, estimate_errors)
+from .dense import gemm_ts, orthogonalize_and_normalize, DGKS, CGS, MGS
+from .iar import iar
+from . import gallery
+from .gallery import nep_gallery

@@ -1,0 +1,111 @@
+"""ctypes binding of libnepmi355.so (the C ABI declared in include/nepmi355.h).
+
+There is NO CPU fallback: if the library cannot be loaded the import fails, and if no GPU is
+visible every compute call fails with NepError (status NEP_ERR_HIP)."""
+import ctypes as C
+import os
+
+import numpy as np
+import torch  # noqa: F401  (loads the HIP runtime that the library binds to -- see build.py)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnepmi355.so")
+
+
+class NepError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("libnepmi355 status %d: %s" % (status, msg))
+        self.status = status
+
+
+NEP_OK, NEP_ERR_HIP, NEP_ERR_ARG, NEP_ERR_SINGULAR, NEP_ERR_BREAKDOWN = 0, -1, -2, -3, -4
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        # build in-tree (hipcc cross-compiles without a GPU); never falls back to a CPU path
+        from . import build
+        build.build_lib(verbose=False)
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+c_i32, c_i64, c_dbl, c_vp, c_sz = C.c_int32, C.c_int64, C.c_double, C.c_void_p, C.c_size_t
+P = C.POINTER
+
+
+class cdouble(C.Structure):
+    _fields_ = [("re", c_dbl), ("im", c_dbl)]
+
+
+# name -> argtypes (restype is always int32 unless listed)
+SIGNATURES = {
+    "nep_version": [],
+    "nep_last_error": [],
+    "nep_device_count": [P(c_i32)],
+    "nep_set_device": [c_i32],
+    "nep_device_name": [C.c_char_p, c_i32],
+    "nep_dev_alloc": [P(c_vp), c_sz],
+    "nep_dev_free": [c_vp],
+    "nep_dev_memset": [c_vp, c_i32, c_sz, c_vp],
+    "nep_upload": [c_vp, c_vp, c_sz, c_vp],
+    "nep_download": [c_vp, c_vp, c_sz, c_vp],
+    "nep_dev_copy": [c_vp, c_vp, c_sz, c_vp],
+    "nep_stream_sync": [c_vp],
+    "nep_spmf_create": [c_i64, c_i32, P(c_vp), P(c_vp), P(c_vp), P(c_i32), P(c_vp)],
+    "nep_spmf_destroy": [c_vp],
+    "nep_spmf_info": [c_vp, P(c_i64)],
+    "nep_csc_to_csr": [c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp],
+    "nep_mlincomb": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp],
+    "nep_resid_batch": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp],
+    "nep_spmm_terms": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp],
+    "nep_orth": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, P(c_dbl), c_i32, P(c_i32), c_vp],
+    "nep_gemm_ts": [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp],
+    "nep_lu_create": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, P(c_vp)],
+    "nep_lu_destroy": [c_vp],
+    "nep_lu_info": [c_vp, P(c_i64)],
+    "nep_lu_solve": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp],
+    "nep_iar_shift_scale": [c_i64, c_i32, c_vp, c_vp, c_vp],
+    "nep_axpy": [c_i64, cdouble, c_vp, c_vp, c_vp],
+    "nep_scal": [c_i64, cdouble, c_vp, c_vp],
+    "nep_nrm2": [c_i64, c_vp, P(c_dbl), c_vp],
+    "nep_colnorms": [c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],
+    "nep_coldots": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
+    "nep_rowmajor_to_colmajor": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp],
+}
+
+for _name, _args in SIGNATURES.items():
+    _f = getattr(lib, _name)  # AttributeError here = header/library mismatch
+    _f.argtypes = _args
+    _f.restype = C.c_char_p if _name == "nep_last_error" else c_i32
+
+
+def check(status):
+    if status != 0:
+        raise NepError(status, lib.nep_last_error().decode(errors="replace"))
+
+
+def hptr(a):
+    """host pointer of a C-contiguous/F-contiguous numpy array (caller keeps it alive)"""
+    return a.ctypes.data_as(c_vp)
+
+
+def cd(z):
+    z = complex(z)
+    return cdouble(z.real, z.imag)
+
+
+def device_count():
+    n = c_i32(0)
+    check(lib.nep_device_count(C.byref(n)))
+    return n.value
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise NepError(NEP_ERR_HIP, "no HIP device visible: the MI355X backend has no CPU fallback")
+
+
+def as_c128(a, order="F"):
+    return np.require(np.asarray(a, dtype=np.complex128), requirements=["A", "O", "F" if order == "F" else "C"])

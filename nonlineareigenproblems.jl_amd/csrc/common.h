@@ -1,0 +1,97 @@
+// Shared definitions for libnepmi355 (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdarg.h>
+#include "nepmi355.h"
+
+typedef double2 cplx;  // x = re, y = im  (same bytes as nep_cdouble / Julia ComplexF64)
+
+void nep_set_error(const char* fmt, ...);
+
+#define HIPCHK(call)                                                                       \
+    do {                                                                                   \
+        hipError_t e_ = (call);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            nep_set_error("%s:%d: %s failed: %s", __FILE__, __LINE__, #call,               \
+                          hipGetErrorString(e_));                                          \
+            return NEP_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define ARGCHK(cond)                                                                       \
+    do {                                                                                   \
+        if (!(cond)) {                                                                     \
+            nep_set_error("%s:%d: invalid argument: %s", __FILE__, __LINE__, #cond);       \
+            return NEP_ERR_ARG;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define LAUNCHCHK() HIPCHK(hipGetLastError())
+
+// ---- complex helpers ---------------------------------------------------------------------
+__device__ __forceinline__ cplx cmake(double re, double im) { cplx r; r.x = re; r.y = im; return r; }
+__device__ __forceinline__ cplx cadd(cplx a, cplx b) { return cmake(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ cplx csub(cplx a, cplx b) { return cmake(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ cplx cmul(cplx a, cplx b) {
+    return cmake(fma(a.x, b.x, -(a.y * b.y)), fma(a.x, b.y, a.y * b.x));
+}
+// acc += a*b
+__device__ __forceinline__ void cfma(cplx& acc, cplx a, cplx b) {
+    acc.x = fma(a.x, b.x, acc.x); acc.x = fma(-a.y, b.y, acc.x);
+    acc.y = fma(a.x, b.y, acc.y); acc.y = fma(a.y, b.x, acc.y);
+}
+// acc += conj(a)*b
+__device__ __forceinline__ void cfma_conj(cplx& acc, cplx a, cplx b) {
+    acc.x = fma(a.x, b.x, acc.x); acc.x = fma(a.y, b.y, acc.x);
+    acc.y = fma(a.x, b.y, acc.y); acc.y = fma(-a.y, b.x, acc.y);
+}
+// acc += s*b  (real s)
+__device__ __forceinline__ void cfma(cplx& acc, double s, cplx b) {
+    acc.x = fma(s, b.x, acc.x); acc.y = fma(s, b.y, acc.y);
+}
+__device__ __forceinline__ cplx cscale(double s, cplx b) { return cmake(s * b.x, s * b.y); }
+__device__ __forceinline__ cplx cscale(cplx s, cplx b) { return cmul(s, b); }
+
+// ---- wave-level helpers (wave = 64) -------------------------------------------------------
+__device__ __forceinline__ double shfl_xor_d(double v, int mask) { return __shfl_xor(v, mask, 64); }
+
+template <int W>
+__device__ __forceinline__ cplx group_reduce_sum(cplx v) {  // sum over aligned groups of W lanes
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1) {
+        v.x += shfl_xor_d(v.x, off);
+        v.y += shfl_xor_d(v.y, off);
+    }
+    return v;
+}
+__device__ __forceinline__ double wave_reduce_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += shfl_xor_d(v, off);
+    return v;
+}
+__device__ __forceinline__ int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], lane);
+    u.i[1] = __builtin_amdgcn_readlane(u.i[1], lane);
+    return u.d;
+}
+
+static inline hipStream_t as_stream(nep_stream s) { return (hipStream_t)s; }
+
+// stacked-CSR index packing: high bits = term, low bits = column
+#define NEP_TERM_SHIFT 27
+#define NEP_COL_MASK ((1u << NEP_TERM_SHIFT) - 1u)
+#define NEP_MAX_TERMS 32
+
+// small per-library scratch (device) helpers, defined in util.hip
+struct NepScratch {
+    void* dptr = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes);
+    void release();
+};

@@ -1,0 +1,182 @@
+// libnepmi355: K7 tall-skinny complex GEMM  Y = Z * B  on the gfx950 FP64 matrix cores.
+//
+// Complex arithmetic is mapped onto v_mfma_f64_16x16x4_f64 through the real embedding
+//   [Yre Yim] = [Zre Zim] * [[Bre Bim],[-Bim Bre]]
+// with a K-ordering chosen so that every lane loads ONE full complex128 (16 B) of Z per k-step:
+// MFMA #0 consumes the real parts of 4 complex columns of Z, MFMA #1 the imaginary parts.
+//   A operand (16 x 4): lane l -> row (l & 15), complex column 4*ks + (l >> 4)
+//   B operand (4 x 16): lane l -> k index (l >> 4), real output column n = l & 15
+//                       (complex output column 8*nt + n/2, part n & 1)
+//   C/D (16 x 16, 4 regs): reg i, lane l -> row (l >> 4) + 4 i, real column l & 15
+// The B operands are pre-expanded on the host into exactly this lane order, so a wave fetches a
+// fragment with one conflict-free 512-byte LDS read.  Z is streamed from HBM exactly once; the
+// accumulators for ALL p output columns of a 16-row strip live in registers.
+#include "common.h"
+#include <vector>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+#define GEMM_KCH 4  // k-steps (of 4 complex columns) staged in LDS per chunk
+
+template <int NT, bool ROWMAJOR>
+__global__ __launch_bounds__(512) void k_gemm_ts(const cplx* __restrict__ Z, int64_t ldz, int64_t rows, int k,
+                                                 const double* __restrict__ Bfrag, int nks, int p, int j0,
+                                                 cplx* __restrict__ Y, int64_t ldy) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* bs = (double*)smem_raw;  // [GEMM_KCH][NT][2][64]
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int64_t row0 = (blockIdx.x * 8LL + wv) * 16;
+    const int m = lane & 15, q = lane >> 4;
+    int64_t arow = row0 + m;
+    if (arow >= rows) arow = rows - 1;
+    d4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    constexpr int PER_KS = NT * 2 * 64;  // doubles per k-step
+    for (int ks0 = 0; ks0 < nks; ks0 += GEMM_KCH) {
+        const int nk = min(GEMM_KCH, nks - ks0);
+        // issue the A loads of this chunk first (latency hidden behind the LDS fill)
+        cplx a[GEMM_KCH];
+#pragma unroll
+        for (int s = 0; s < GEMM_KCH; ++s) {
+            int c = 4 * (ks0 + s) + q;
+            if (c >= k) c = k - 1;
+            a[s] = (s < nk) ? Z[(int64_t)c * ldz + arow] : cmake(0.0, 0.0);
+        }
+        __syncthreads();
+        {
+            const double2* src = (const double2*)(Bfrag + (int64_t)ks0 * PER_KS);
+            double2* dst = (double2*)bs;
+            const int n2 = nk * PER_KS / 2;
+            for (int t = threadIdx.x; t < n2; t += 512) dst[t] = src[t];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < GEMM_KCH; ++s) {
+            if (s < nk) {
+                const double* bk = bs + s * PER_KS + lane;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s].x, bk[(t * 2 + 0) * 64], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s].y, bk[(t * 2 + 1) * 64], acc[t], 0, 0, 0);
+            }
+        }
+    }
+    // ---- epilogue
+    const int n = lane & 15, g = lane >> 4;
+    if (ROWMAJOR) {
+        double* Yd = (double*)Y;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int jc = 8 * t + (n >> 1);
+            if (jc < p) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int64_t r = row0 + g + 4 * i;
+                    if (r < rows) Yd[(r * ldy + j0 + jc) * 2 + (n & 1)] = acc[t][i];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int jc = 8 * t + (n >> 1);
+            // even lanes keep regs {0,2}, odd lanes regs {1,3}; partner supplies the other part
+            const bool odd = n & 1;
+            const double s0 = odd ? acc[t][0] : acc[t][1];
+            const double s1 = odd ? acc[t][2] : acc[t][3];
+            const double r0 = shfl_xor_d(s0, 1);
+            const double r1 = shfl_xor_d(s1, 1);
+            cplx v0, v1;
+            int i0, i1;
+            if (!odd) { v0 = cmake(acc[t][0], r0); v1 = cmake(acc[t][2], r1); i0 = 0; i1 = 2; }
+            else      { v0 = cmake(r0, acc[t][1]); v1 = cmake(r1, acc[t][3]); i0 = 1; i1 = 3; }
+            if (jc < p) {
+                const int64_t ra = row0 + g + 4 * i0, rb = row0 + g + 4 * i1;
+                cplx* col = Y + (int64_t)(j0 + jc) * ldy;
+                if (ra < rows) col[ra] = v0;
+                if (rb < rows) col[rb] = v1;
+            }
+        }
+    }
+}
+
+static NepScratch g_gemm_scratch;
+
+template <int NT>
+static int gemm_launch(bool rowmajor, const cplx* Z, int64_t ldz, int64_t rows, int k, const double* dB, int nks,
+                       int p, int j0, cplx* Y, int64_t ldy, hipStream_t st) {
+    const dim3 grid((unsigned)((rows + 127) / 128)), block(512);
+    const size_t shm = (size_t)GEMM_KCH * NT * 2 * 64 * sizeof(double);
+    if (rowmajor)
+        hipLaunchKernelGGL((k_gemm_ts<NT, true>), grid, block, shm, st, Z, ldz, rows, k, dB, nks, p, j0, Y, ldy);
+    else
+        hipLaunchKernelGGL((k_gemm_ts<NT, false>), grid, block, shm, st, Z, ldz, rows, k, dB, nks, p, j0, Y, ldy);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+extern "C" int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_t k,
+                               const nep_cdouble* hB, int64_t ldb, int32_t p, nep_cdouble* dY, int64_t ldy,
+                               int32_t y_rowmajor, nep_stream stream) {
+    ARGCHK(dZ && hB && dY);
+    ARGCHK(rows > 0 && k >= 1 && p >= 1 && ldz >= rows && ldb >= k);
+    ARGCHK(y_rowmajor ? ldy >= p : ldy >= rows);
+    hipStream_t st = as_stream(stream);
+    const int nks = (k + 3) / 4;
+    // column panels of at most 104 complex output columns (13 N-tiles of 8)
+    int done = 0;
+    // total staging: sum over panels of nks*NT*128 doubles
+    size_t total = 0;
+    for (int j0 = 0; j0 < p; j0 += 104) {
+        const int pp = std::min(104, p - j0);
+        const int nt = pp <= 8 ? 1 : pp <= 16 ? 2 : pp <= 32 ? 4 : pp <= 56 ? 7 : 13;
+        total += (size_t)nks * nt * 128;
+    }
+    std::vector<double> frag(total, 0.0);
+    int rc = g_gemm_scratch.ensure(total * sizeof(double));
+    if (rc) return rc;
+    size_t off = 0;
+    std::vector<size_t> offs;
+    for (int j0 = 0; j0 < p; j0 += 104) {
+        const int pp = std::min(104, p - j0);
+        const int nt = pp <= 8 ? 1 : pp <= 16 ? 2 : pp <= 32 ? 4 : pp <= 56 ? 7 : 13;
+        offs.push_back(off);
+        for (int ks = 0; ks < nks; ++ks)
+            for (int t = 0; t < nt; ++t)
+                for (int l = 0; l < 64; ++l) {
+                    const int q = l >> 4, n = l & 15;
+                    const int c = 4 * ks + q, jc = 8 * t + (n >> 1);
+                    double b0 = 0.0, b1 = 0.0;
+                    if (c < k && jc < pp) {
+                        const nep_cdouble b = hB[(int64_t)(j0 + jc) * ldb + c];
+                        if ((n & 1) == 0) { b0 = b.re; b1 = -b.im; } else { b0 = b.im; b1 = b.re; }
+                    }
+                    double* f = frag.data() + off + ((size_t)(ks * nt + t) * 2) * 64;
+                    f[l] = b0;
+                    f[64 + l] = b1;
+                }
+        off += (size_t)nks * nt * 128;
+    }
+    HIPCHK(hipMemcpyAsync(g_gemm_scratch.dptr, frag.data(), total * sizeof(double), hipMemcpyHostToDevice, st));
+    // the staging vector is pageable: the runtime has copied it before returning
+    int pi = 0;
+    for (int j0 = 0; j0 < p; j0 += 104, ++pi) {
+        const int pp = std::min(104, p - j0);
+        const double* dB = (const double*)g_gemm_scratch.dptr + offs[pi];
+        const cplx* Z = (const cplx*)dZ;
+        cplx* Y = (cplx*)dY;
+        if (pp <= 8) rc = gemm_launch<1>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
+        else if (pp <= 16) rc = gemm_launch<2>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
+        else if (pp <= 32) rc = gemm_launch<4>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
+        else if (pp <= 56) rc = gemm_launch<7>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
+        else rc = gemm_launch<13>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
+        if (rc) return rc;
+        (void)done;
+    }
+    return NEP_OK;
+}

@@ -1,0 +1,217 @@
+// libnepmi355: K6 Gram-Schmidt orthogonalisation (DGKS / CGS / MGS) for gfx950.
+//
+// One DGKS pass = two streaming kernels over the basis V (rows x k, column-major):
+//   k_orth_dots   : partial[b][j] = sum_{r in row-chunk b} conj(V[r,j]) w[r]      (HBM-bound)
+//   k_orth_update : w[r] -= sum_j V[r,j] h[j];  partial norm of the new w          (HBM-bound)
+// plus two tiny fixed-order reductions (deterministic, no atomics).  The optional
+// `active` array (iar: column j is zero below row (j+1) n, src/method_iar.jl:76,97-98) lets both
+// kernels skip the structurally zero part of V, halving the traffic of iar's orthogonalisation.
+#include "common.h"
+#include <vector>
+#include <math.h>
+
+#define DOT_RPT 4
+#define DOT_CG 8
+#define DOT_RB (256 * DOT_RPT)
+
+__global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, int64_t ldv, int64_t rows,
+                                                   int k, const int64_t* __restrict__ active,
+                                                   const cplx* __restrict__ w, cplx* __restrict__ partial) {
+    __shared__ cplx sm[DOT_CG][4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * DOT_RB;
+    cplx wr[DOT_RPT];
+    int64_t rr[DOT_RPT];
+#pragma unroll
+    for (int i = 0; i < DOT_RPT; ++i) {
+        rr[i] = r0 + threadIdx.x + 256 * i;
+        wr[i] = rr[i] < rows ? w[rr[i]] : cmake(0.0, 0.0);
+    }
+    const int j0 = blockIdx.y * DOT_CG;
+#pragma unroll
+    for (int jj = 0; jj < DOT_CG; ++jj) {
+        const int j = j0 + jj;
+        cplx acc = cmake(0.0, 0.0);
+        if (j < k) {
+            int64_t act = active ? active[j] : rows;
+            if (act > rows) act = rows;
+            if (r0 < act) {
+                const cplx* vp = V + (int64_t)j * ldv;
+#pragma unroll
+                for (int i = 0; i < DOT_RPT; ++i)
+                    if (rr[i] < act) cfma_conj(acc, vp[rr[i]], wr[i]);
+                acc = group_reduce_sum<64>(acc);
+            }
+        }
+        if (lane == 0) sm[jj][wv] = acc;
+    }
+    __syncthreads();
+    if (threadIdx.x < DOT_CG) {
+        const int j = j0 + threadIdx.x;
+        if (j < k) {
+            cplx t = sm[threadIdx.x][0];
+            for (int q = 1; q < 4; ++q) t = cadd(t, sm[threadIdx.x][q]);
+            partial[(int64_t)blockIdx.x * k + j] = t;
+        }
+    }
+}
+
+// h[j] = sum_b partial[b*k + j]; one block per column, fixed summation tree -> deterministic
+__global__ __launch_bounds__(256) void k_orth_reduce_h(int nb, int k, const cplx* __restrict__ partial,
+                                                       cplx* __restrict__ h) {
+    __shared__ cplx sm[4];
+    const int j = blockIdx.x;
+    cplx acc = cmake(0.0, 0.0);
+    for (int b = threadIdx.x; b < nb; b += 256) acc = cadd(acc, partial[(int64_t)b * k + j]);
+    acc = group_reduce_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) h[j] = cadd(cadd(sm[0], sm[1]), cadd(sm[2], sm[3]));
+}
+
+__global__ __launch_bounds__(1024) void k_orth_reduce_n(int nb, const double* __restrict__ partial,
+                                                        double* __restrict__ out) {
+    __shared__ double sm[16];
+    double acc = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 1024) acc += partial[b];
+    acc = wave_reduce_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int q = 0; q < 16; ++q) t += sm[q];
+        out[0] = t;
+    }
+}
+
+// w[r] -= sum_j V[r,j] h[j];  block = 8 waves x 64 rows, wave q takes columns q, q+8, ...
+__global__ __launch_bounds__(512) void k_orth_update(const cplx* __restrict__ V, int64_t ldv, int64_t rows,
+                                                     int k, const int64_t* __restrict__ active,
+                                                     const cplx* __restrict__ h, cplx* __restrict__ w,
+                                                     double* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* hs = (cplx*)smem_raw;         // k
+    cplx* sm = hs + k;                  // [8][64]
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int t = threadIdx.x; t < k; t += 512) hs[t] = h[t];
+    __syncthreads();
+    const int64_t r0 = blockIdx.x * 64LL;
+    const int64_t row = r0 + lane;
+    const int64_t rowc = row < rows ? row : rows - 1;
+    cplx acc = cmake(0.0, 0.0);
+    const cplx* vp = V + rowc;
+#pragma unroll 4
+    for (int j = q; j < k; j += 8) {
+        const int64_t act = active ? active[j] : rows;
+        if (r0 < act) cfma(acc, vp[(int64_t)j * ldv], hs[j]);
+    }
+    sm[q * 64 + lane] = acc;
+    __syncthreads();
+    if (q == 0) {
+        cplx s = sm[lane];
+#pragma unroll
+        for (int t = 1; t < 8; ++t) s = cadd(s, sm[t * 64 + lane]);
+        double nn = 0.0;
+        if (row < rows) {
+            cplx wn = csub(w[row], s);
+            w[row] = wn;
+            nn = fma(wn.x, wn.x, wn.y * wn.y);
+        }
+        nn = wave_reduce_sum(nn);
+        if (lane == 0) partial[blockIdx.x] = nn;
+    }
+}
+
+static NepScratch g_orth_scratch;
+
+extern "C" int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
+                            const int64_t* h_active_rows, nep_cdouble* dw, nep_cdouble* h_h, double* h_beta,
+                            int32_t method, int32_t* h_npasses, nep_stream stream) {
+    ARGCHK(dV && dw && h_h && h_beta);
+    ARGCHK(rows > 0 && k >= 1 && ldv >= rows);
+    ARGCHK(method >= 0 && method <= 2);
+    hipStream_t st = as_stream(stream);
+    const int nchunks = (int)((rows + DOT_RB - 1) / DOT_RB);
+    const int nblk = (int)((rows + 63) / 64);
+    // scratch layout: [active k int64][partial_h nchunks*k cplx][h k cplx | nrm2 double pad][partial_n nblk dbl]
+    size_t off_act = 0;
+    size_t off_ph = off_act + (size_t)k * sizeof(int64_t);
+    off_ph = (off_ph + 15) & ~(size_t)15;
+    size_t off_h = off_ph + (size_t)nchunks * k * sizeof(cplx);
+    size_t off_pn = off_h + (size_t)(k + 1) * sizeof(cplx);
+    size_t total = off_pn + (size_t)nblk * sizeof(double);
+    int rc = g_orth_scratch.ensure(total);
+    if (rc) return rc;
+    char* base = (char*)g_orth_scratch.dptr;
+    int64_t* d_act = h_active_rows ? (int64_t*)(base + off_act) : nullptr;
+    cplx* d_ph = (cplx*)(base + off_ph);
+    cplx* d_h = (cplx*)(base + off_h);
+    double* d_n = (double*)(d_h + k);
+    double* d_pn = (double*)(base + off_pn);
+    if (h_active_rows)
+        HIPCHK(hipMemcpyAsync(d_act, h_active_rows, (size_t)k * sizeof(int64_t), hipMemcpyHostToDevice, st));
+    std::vector<nep_cdouble> corr(k + 1);
+    for (int j = 0; j < k; ++j) { h_h[j].re = 0.0; h_h[j].im = 0.0; }
+    const cplx* V = (const cplx*)dV;
+    cplx* w = (cplx*)dw;
+    double nrm = 0.0;
+    int passes = 0;
+    const size_t shm_upd = (size_t)(k + 8 * 64) * sizeof(cplx);
+
+    if (method == 2) {
+        // modified Gram-Schmidt: column by column (test/reference-comparison path; not tuned)
+        for (int j = 0; j < k; ++j) {
+            const int64_t* actj = d_act ? d_act + j : nullptr;
+            hipLaunchKernelGGL(k_orth_dots, dim3(nchunks, 1), dim3(256), 0, st, V + (int64_t)j * ldv, ldv, rows, 1,
+                               actj, (const cplx*)w, d_ph);
+            LAUNCHCHK();
+            hipLaunchKernelGGL(k_orth_reduce_h, dim3(1), dim3(256), 0, st, nchunks, 1, (const cplx*)d_ph, d_h + j);
+            LAUNCHCHK();
+            hipLaunchKernelGGL(k_orth_update, dim3(nblk), dim3(512), (1 + 8 * 64) * sizeof(cplx), st,
+                               V + (int64_t)j * ldv, ldv, rows, 1, actj, (const cplx*)(d_h + j), w, d_pn);
+            LAUNCHCHK();
+        }
+        hipLaunchKernelGGL(k_orth_reduce_n, dim3(1), dim3(1024), 0, st, nblk, (const double*)d_pn, d_n);
+        LAUNCHCHK();
+        HIPCHK(hipMemcpyAsync(corr.data(), d_h, (size_t)(k + 1) * sizeof(cplx), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int j = 0; j < k; ++j) h_h[j] = corr[j];
+        nrm = sqrt(corr[k].re);
+        passes = 1;
+    } else {
+        const double eta = 1.0 / sqrt(2.0);
+        while (true) {
+            hipLaunchKernelGGL(k_orth_dots, dim3(nchunks, (k + DOT_CG - 1) / DOT_CG), dim3(256), 0, st, V, ldv,
+                               rows, (int)k, (const int64_t*)d_act, (const cplx*)w, d_ph);
+            LAUNCHCHK();
+            hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_h);
+            LAUNCHCHK();
+            hipLaunchKernelGGL(k_orth_update, dim3(nblk), dim3(512), shm_upd, st, V, ldv, rows, (int)k,
+                               (const int64_t*)d_act, (const cplx*)d_h, w, d_pn);
+            LAUNCHCHK();
+            hipLaunchKernelGGL(k_orth_reduce_n, dim3(1), dim3(1024), 0, st, nblk, (const double*)d_pn, d_n);
+            LAUNCHCHK();
+            HIPCHK(hipMemcpyAsync(corr.data(), d_h, (size_t)(k + 1) * sizeof(cplx), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            ++passes;
+            double proj2 = 0.0;
+            for (int j = 0; j < k; ++j) {
+                h_h[j].re += corr[j].re; h_h[j].im += corr[j].im;
+                proj2 += corr[j].re * corr[j].re + corr[j].im * corr[j].im;
+            }
+            nrm = sqrt(corr[k].re);
+            if (method == 1) break;                       // classical GS: single pass
+            if (!(nrm < eta * sqrt(proj2))) break;        // DGKS criterion
+            if (passes >= 8) break;                       // safety net (never met in practice)
+        }
+    }
+    if (h_npasses) *h_npasses = passes;
+    *h_beta = nrm;
+    if (!(nrm > 0.0) || !isfinite(nrm)) {
+        nep_set_error("orthogonalisation breakdown: ||w|| = %g", nrm);
+        return NEP_ERR_BREAKDOWN;
+    }
+    nep_cdouble inv; inv.re = 1.0 / nrm; inv.im = 0.0;
+    return nep_scal(rows, inv, dw, stream);
+}

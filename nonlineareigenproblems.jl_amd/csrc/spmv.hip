@@ -1,0 +1,398 @@
+// libnepmi355: SPMF object (stacked CSR) and the kernels K1 (compute_Mlincomb) and
+// K2 (batched residuals / compute_MM SpMM) for gfx950.
+//
+// K1  z = sum_i A_i (V c_i) is executed as
+//   (a) k_vc:   WT[r, i] = sum_j V[r,j] C[j,i]      (tall-skinny, streams V once, HBM-bound)
+//   (b) k_spmv: z[r] = sum_{e in row r} val[e] * WT[col(e), term(e)]   (stacked CSR, G lanes/row)
+// The reference streams V once PER TERM (src/NEPTypes.jl:1006) and runs one CSC SpMV per term
+// (:1007); the DerSPMF formulation (:1154-1157) is the one realised here.
+#include "common.h"
+#include <vector>
+#include <algorithm>
+
+struct nep_spmf {
+    int64_t n = 0;
+    int32_t mt = 0;
+    int64_t nnz = 0;
+    int32_t valbytes = 8;  // 8: all terms real, 16: complex values
+    int32_t lanes = 16;    // lanes per row in k_spmv
+    int32_t* d_rowptr = nullptr;
+    uint32_t* d_idx = nullptr;
+    void* d_vals = nullptr;
+    cplx* d_WT = nullptr;     // n x mt row-major workspace
+    NepScratch coef;          // staged coefficient matrices
+    NepScratch part;          // per-block partials
+};
+
+// ------------------------------------------------------------------------------------------
+// (a) WT[r, i0+i] = sum_j V[r + j*ldv] * C[j + (i0+i)*k],  i < MT.
+// block = 512 threads = 8 waves; 64 rows per block; wave w takes columns j = w, w+8, ...
+template <int MT>
+__global__ __launch_bounds__(512) void k_vc(const cplx* __restrict__ V, int64_t ldv, int64_t n, int k,
+                                            const cplx* __restrict__ C, int i0, int mt_total,
+                                            cplx* __restrict__ WT) {
+    __shared__ cplx sm[8][MT][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t row = blockIdx.x * 64LL + lane;
+    const int64_t rowc = row < n ? row : n - 1;
+    cplx acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = cmake(0.0, 0.0);
+    const cplx* vp = V + rowc;
+#pragma unroll 4
+    for (int j = w; j < k; j += 8) {
+        const cplx v = vp[(int64_t)j * ldv];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) cfma(acc[i], v, C[j + (int64_t)(i0 + i) * k]);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) sm[w][i][lane] = acc[i];
+    __syncthreads();
+    // 64*MT outputs, written contiguously: t -> (row = t / MT, i = t % MT)
+    for (int t = threadIdx.x; t < 64 * MT; t += 512) {
+        const int rr = t / MT, i = t % MT;
+        cplx s = sm[0][i][rr];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) s = cadd(s, sm[q][i][rr]);
+        const int64_t r = blockIdx.x * 64LL + rr;
+        if (r < n) WT[r * mt_total + i0 + i] = s;
+    }
+}
+
+// (b) stacked-CSR SpMV, G lanes per row
+template <int G, typename VT>
+__global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ rowptr,
+                                              const uint32_t* __restrict__ idx,
+                                              const VT* __restrict__ vals, const cplx* __restrict__ WT,
+                                              int mt, int64_t n, cplx* __restrict__ z) {
+    constexpr int RPB = 256 / G;
+    const int sub = threadIdx.x % G;
+    const int64_t row = blockIdx.x * (int64_t)RPB + threadIdx.x / G;
+    cplx acc = cmake(0.0, 0.0);
+    if (row < n) {
+        const int e1 = rowptr[row + 1];
+        for (int e = rowptr[row] + sub; e < e1; e += G) {
+            const uint32_t id = idx[e];
+            const int64_t c = id & NEP_COL_MASK;
+            const int t = id >> NEP_TERM_SHIFT;
+            cfma(acc, vals[e], WT[c * mt + t]);
+        }
+    }
+    acc = group_reduce_sum<G>(acc);
+    if (row < n && sub == 0) z[row] = acc;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2 / compute_MM SpMM on ROW-major dense blocks.  One wave per row (grid-stride), lanes = columns.
+//   acc[s] = sum_e val[e] * coef(term(e), s) * XT[col(e)*ldx + term(e)*xoff + s]
+//   F != null: coef = F[t + s*mt] (K2, xoff = 0);  F == null: coef = 1 (MM, xoff = p)
+// Outputs (optional): ZT[row*ldz + s] = acc;  per-block partial sums of |acc|^2 and |XT[row,s]|^2.
+template <int NCH, typename VT>
+__global__ __launch_bounds__(256) void k_spmm_rm(const int32_t* __restrict__ rowptr,
+                                                 const uint32_t* __restrict__ idx,
+                                                 const VT* __restrict__ vals, int64_t n, int mt, int k,
+                                                 const cplx* __restrict__ F, const cplx* __restrict__ XT,
+                                                 int64_t ldx, int xoff, cplx* __restrict__ ZT, int64_t ldz,
+                                                 double* __restrict__ partial /* [grid][2][k] or null */) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* Fs = (cplx*)smem_raw;                       // mt*k coefficients (if F)
+    double* red = (double*)(Fs + (F ? mt * k : 0));   // [4][2][NCH*64]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (F) {
+        for (int t = threadIdx.x; t < mt * k; t += 256) Fs[t] = F[t];
+        __syncthreads();
+    }
+    double rn[NCH], qn[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { rn[c] = 0.0; qn[c] = 0.0; }
+
+    for (int64_t row = blockIdx.x * 4LL + w; row < n; row += gridDim.x * 4LL) {
+        cplx acc[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[c] = cmake(0.0, 0.0);
+        const int e0 = __builtin_amdgcn_readfirstlane(rowptr[row]);
+        const int e1 = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+        for (int base = e0; base < e1; base += 64) {
+            const int me = base + lane;
+            uint32_t id_l = 0;
+            VT a_l;
+            if constexpr (sizeof(VT) == 8) a_l = 0.0; else a_l = cmake(0.0, 0.0);
+            if (me < e1) { id_l = idx[me]; a_l = vals[me]; }
+            const int m = min(64, e1 - base);
+            for (int j = 0; j < m; ++j) {
+                const uint32_t id = (uint32_t)readlane_i((int)id_l, j);
+                const int64_t c = id & NEP_COL_MASK;
+                const int t = id >> NEP_TERM_SHIFT;
+                const cplx* xrow = XT + c * ldx + (int64_t)t * xoff;
+                if constexpr (sizeof(VT) == 8) {
+                    const double a = readlane_d(a_l, j);
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) {
+                        const int s = lane + 64 * ch;
+                        if (s < k) {
+                            cplx x = xrow[s];
+                            if (F) x = cmul(Fs[t + s * mt], x);
+                            cfma(acc[ch], a, x);
+                        }
+                    }
+                } else {
+                    cplx a; a.x = readlane_d(a_l.x, j); a.y = readlane_d(a_l.y, j);
+#pragma unroll
+                    for (int ch = 0; ch < NCH; ++ch) {
+                        const int s = lane + 64 * ch;
+                        if (s < k) {
+                            cplx x = xrow[s];
+                            if (F) x = cmul(Fs[t + s * mt], x);
+                            cfma(acc[ch], a, x);
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            const int s = lane + 64 * ch;
+            if (s < k) {
+                if (ZT) ZT[row * ldz + s] = acc[ch];
+                if (partial) {
+                    rn[ch] = fma(acc[ch].x, acc[ch].x, fma(acc[ch].y, acc[ch].y, rn[ch]));
+                    if (xoff == 0) {
+                        const cplx q = XT[row * ldx + s];
+                        qn[ch] = fma(q.x, q.x, fma(q.y, q.y, qn[ch]));
+                    }
+                }
+            }
+        }
+    }
+    if (partial) {
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            red[(w * 2 + 0) * (NCH * 64) + ch * 64 + lane] = rn[ch];
+            red[(w * 2 + 1) * (NCH * 64) + ch * 64 + lane] = qn[ch];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * k; t += 256) {
+            const int which = t / k, s = t % k;
+            double v = 0.0;
+            for (int q = 0; q < 4; ++q) v += red[(q * 2 + which) * (NCH * 64) + s];
+            partial[((int64_t)blockIdx.x * 2 + which) * k + s] = v;
+        }
+    }
+}
+
+__global__ void k_sum_partials_d(int nb, int len, const double* __restrict__ partial, double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= len) return;
+    double t = 0.0;
+    for (int b = 0; b < nb; ++b) t += partial[(int64_t)b * len + j];
+    out[j] = t;
+}
+
+// ------------------------------------------------------------------------------------------
+template <typename VT>
+static int launch_spmv(const nep_spmf* s, const cplx* WT, cplx* z, hipStream_t st) {
+    const VT* vals = (const VT*)s->d_vals;
+    const int64_t n = s->n;
+#define SPMV_CASE(G)                                                                               \
+    case G: {                                                                                      \
+        const int rpb = 256 / G;                                                                   \
+        hipLaunchKernelGGL((k_spmv<G, VT>), dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, st, \
+                           s->d_rowptr, s->d_idx, vals, WT, s->mt, n, z);                          \
+        break;                                                                                     \
+    }
+    switch (s->lanes) {
+        SPMV_CASE(2) SPMV_CASE(4) SPMV_CASE(8) SPMV_CASE(16) SPMV_CASE(32) SPMV_CASE(64)
+        default: nep_set_error("bad lanes %d", s->lanes); return NEP_ERR_ARG;
+    }
+#undef SPMV_CASE
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+static int launch_vc(const nep_spmf* s, int k, const cplx* dC, const cplx* V, int64_t ldv, hipStream_t st) {
+    const int64_t n = s->n;
+    const dim3 grid((unsigned)((n + 63) / 64)), block(512);
+    int i0 = 0;
+    while (i0 < s->mt) {
+        const int rem = s->mt - i0;
+        const int cnt = rem >= 4 ? 4 : rem;
+        switch (cnt) {
+            case 4: hipLaunchKernelGGL((k_vc<4>), grid, block, 0, st, V, ldv, n, k, dC, i0, s->mt, s->d_WT); break;
+            case 3: hipLaunchKernelGGL((k_vc<3>), grid, block, 0, st, V, ldv, n, k, dC, i0, s->mt, s->d_WT); break;
+            case 2: hipLaunchKernelGGL((k_vc<2>), grid, block, 0, st, V, ldv, n, k, dC, i0, s->mt, s->d_WT); break;
+            default: hipLaunchKernelGGL((k_vc<1>), grid, block, 0, st, V, ldv, n, k, dC, i0, s->mt, s->d_WT); break;
+        }
+        LAUNCHCHK();
+        i0 += cnt;
+    }
+    return NEP_OK;
+}
+
+template <typename VT>
+static int launch_spmm(const nep_spmf* s, int k, const cplx* dF, const cplx* XT, int64_t ldx, int xoff,
+                       cplx* ZT, int64_t ldz, double* partial, int grid, hipStream_t st) {
+    const int nch = (k + 63) / 64;
+    const size_t shm = (dF ? (size_t)s->mt * k * sizeof(cplx) : 0) + (size_t)4 * 2 * nch * 64 * sizeof(double);
+    const VT* vals = (const VT*)s->d_vals;
+#define SPMM_CASE(N)                                                                                   \
+    case N:                                                                                            \
+        hipLaunchKernelGGL((k_spmm_rm<N, VT>), dim3(grid), dim3(256), shm, st, s->d_rowptr, s->d_idx,  \
+                           vals, s->n, s->mt, k, dF, XT, ldx, xoff, ZT, ldz, partial);                 \
+        break;
+    switch (nch) {
+        SPMM_CASE(1) SPMM_CASE(2) SPMM_CASE(3) SPMM_CASE(4)
+        default: nep_set_error("k=%d too large for one spmm pass", k); return NEP_ERR_ARG;
+    }
+#undef SPMM_CASE
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+extern "C" {
+
+int32_t nep_spmf_create(int64_t n, int32_t mt, const int32_t* const* h_rowptr, const int32_t* const* h_colind,
+                        const void* const* h_vals, const int32_t* h_val_is_complex, nep_spmf** out) {
+    ARGCHK(out != nullptr);
+    *out = nullptr;
+    ARGCHK(n > 0 && n <= (int64_t)NEP_COL_MASK);
+    ARGCHK(mt > 0 && mt <= NEP_MAX_TERMS);
+    ARGCHK(h_rowptr && h_colind && h_vals && h_val_is_complex);
+    bool any_complex = false;
+    int64_t nnz = 0;
+    for (int i = 0; i < mt; ++i) {
+        ARGCHK(h_rowptr[i] && h_rowptr[i][0] == 0);
+        nnz += h_rowptr[i][n];
+        any_complex |= (h_val_is_complex[i] != 0);
+    }
+    ARGCHK(nnz < ((int64_t)1 << 31) - 64);
+    // ---- build the stacked CSR on the host: per row, entries of all terms sorted by (col, term)
+    std::vector<int32_t> rowptr(n + 1);
+    std::vector<uint32_t> idx(nnz);
+    std::vector<double> vr(any_complex ? 0 : nnz);
+    std::vector<nep_cdouble> vc(any_complex ? nnz : 0);
+    struct Ent { uint32_t col; uint32_t term; double re, im; };
+    std::vector<Ent> tmp;
+    int64_t pos = 0;
+    rowptr[0] = 0;
+    for (int64_t r = 0; r < n; ++r) {
+        tmp.clear();
+        for (int i = 0; i < mt; ++i) {
+            for (int32_t e = h_rowptr[i][r]; e < h_rowptr[i][r + 1]; ++e) {
+                const int32_t c = h_colind[i][e];
+                if (c < 0 || c >= n) { nep_set_error("column index out of range"); return NEP_ERR_ARG; }
+                Ent en; en.col = (uint32_t)c; en.term = (uint32_t)i;
+                if (h_val_is_complex[i]) {
+                    const nep_cdouble v = ((const nep_cdouble*)h_vals[i])[e]; en.re = v.re; en.im = v.im;
+                } else { en.re = ((const double*)h_vals[i])[e]; en.im = 0.0; }
+                tmp.push_back(en);
+            }
+        }
+        std::stable_sort(tmp.begin(), tmp.end(), [](const Ent& a, const Ent& b) {
+            return a.col != b.col ? a.col < b.col : a.term < b.term; });
+        for (const Ent& en : tmp) {
+            idx[pos] = (en.term << NEP_TERM_SHIFT) | en.col;
+            if (any_complex) { vc[pos].re = en.re; vc[pos].im = en.im; } else vr[pos] = en.re;
+            ++pos;
+        }
+        rowptr[r + 1] = (int32_t)pos;
+    }
+    nep_spmf* s = new nep_spmf();
+    s->n = n; s->mt = mt; s->nnz = nnz; s->valbytes = any_complex ? 16 : 8;
+    // lanes per row: power of two near the mean row length (env NEP_SPMV_LANES overrides)
+    {
+        const double mean = (double)nnz / (double)n;
+        int g = 2;
+        while (g < 64 && g < mean) g <<= 1;
+        if (const char* e = getenv("NEP_SPMV_LANES")) { int v = atoi(e); if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) g = v; }
+        s->lanes = g;
+    }
+#define CRCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { nep_set_error("%s:%d: %s: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); nep_spmf_destroy(s); return NEP_ERR_HIP; } } while (0)
+    CRCHK(hipMalloc((void**)&s->d_rowptr, (size_t)(n + 1) * sizeof(int32_t)));
+    CRCHK(hipMalloc((void**)&s->d_idx, (size_t)(nnz + 64) * sizeof(uint32_t)));
+    CRCHK(hipMalloc(&s->d_vals, (size_t)(nnz + 64) * s->valbytes));
+    CRCHK(hipMalloc((void**)&s->d_WT, (size_t)n * mt * sizeof(cplx)));
+    CRCHK(hipMemcpy(s->d_rowptr, rowptr.data(), (size_t)(n + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    CRCHK(hipMemcpy(s->d_idx, idx.data(), (size_t)nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (any_complex) CRCHK(hipMemcpy(s->d_vals, vc.data(), (size_t)nnz * 16, hipMemcpyHostToDevice));
+    else CRCHK(hipMemcpy(s->d_vals, vr.data(), (size_t)nnz * 8, hipMemcpyHostToDevice));
+#undef CRCHK
+    *out = s;
+    return NEP_OK;
+}
+
+int32_t nep_spmf_destroy(nep_spmf* s) {
+    if (!s) return NEP_OK;
+    if (s->d_rowptr) (void)hipFree(s->d_rowptr);
+    if (s->d_idx) (void)hipFree(s->d_idx);
+    if (s->d_vals) (void)hipFree(s->d_vals);
+    if (s->d_WT) (void)hipFree(s->d_WT);
+    s->coef.release();
+    s->part.release();
+    delete s;
+    return NEP_OK;
+}
+
+int32_t nep_spmf_info(const nep_spmf* s, int64_t info[6]) {
+    ARGCHK(s && info);
+    info[0] = s->n; info[1] = s->mt; info[2] = s->nnz; info[3] = s->valbytes; info[4] = s->lanes;
+    info[5] = s->nnz * (s->valbytes + 4) + 4 * (s->n + 1);
+    return NEP_OK;
+}
+
+int32_t nep_mlincomb(nep_spmf* s, int32_t k, const nep_cdouble* hC, const nep_cdouble* dV, int64_t ldv,
+                     nep_cdouble* dz, nep_stream stream) {
+    ARGCHK(s && hC && dV && dz);
+    ARGCHK(k >= 1 && ldv >= s->n);
+    hipStream_t st = as_stream(stream);
+    const size_t cbytes = (size_t)k * s->mt * sizeof(cplx);
+    int rc = s->coef.ensure(cbytes);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(s->coef.dptr, hC, cbytes, hipMemcpyHostToDevice, st));
+    rc = launch_vc(s, k, (const cplx*)s->coef.dptr, (const cplx*)dV, ldv, st);
+    if (rc) return rc;
+    if (s->valbytes == 8) return launch_spmv<double>(s, s->d_WT, (cplx*)dz, st);
+    return launch_spmv<cplx>(s, s->d_WT, (cplx*)dz, st);
+}
+
+int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
+                        double* h_rnorm, double* h_qnorm, nep_stream stream) {
+    ARGCHK(s && hF && dQT && h_rnorm && h_qnorm);
+    ARGCHK(k >= 1 && k <= 256 && ldq >= k);
+    hipStream_t st = as_stream(stream);
+    const size_t cbytes = (size_t)k * s->mt * sizeof(cplx);
+    int rc = s->coef.ensure(cbytes);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(s->coef.dptr, hF, cbytes, hipMemcpyHostToDevice, st));
+    int grid = (int)std::min<int64_t>((s->n + 3) / 4, 2048);
+    rc = s->part.ensure(((size_t)grid * 2 * k + 2 * k) * sizeof(double));
+    if (rc) return rc;
+    double* partial = (double*)s->part.dptr;
+    double* outd = partial + (size_t)grid * 2 * k;
+    if (s->valbytes == 8)
+        rc = launch_spmm<double>(s, k, (const cplx*)s->coef.dptr, (const cplx*)dQT, ldq, 0, nullptr, 0, partial, grid, st);
+    else
+        rc = launch_spmm<cplx>(s, k, (const cplx*)s->coef.dptr, (const cplx*)dQT, ldq, 0, nullptr, 0, partial, grid, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sum_partials_d, dim3((2 * k + 63) / 64), dim3(64), 0, st, grid, 2 * k, partial, outd);
+    LAUNCHCHK();
+    std::vector<double> h(2 * k);
+    HIPCHK(hipMemcpyAsync(h.data(), outd, (size_t)2 * k * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int j = 0; j < k; ++j) { h_rnorm[j] = sqrt(h[j]); h_qnorm[j] = sqrt(h[k + j]); }
+    return NEP_OK;
+}
+
+int32_t nep_spmm_terms(nep_spmf* s, int32_t p, const nep_cdouble* dXT, int64_t ldx, nep_cdouble* dZT,
+                       int64_t ldz, nep_stream stream) {
+    ARGCHK(s && dXT && dZT);
+    ARGCHK(p >= 1 && p <= 256 && ldx >= (int64_t)p * s->mt && ldz >= p);
+    hipStream_t st = as_stream(stream);
+    int grid = (int)std::min<int64_t>((s->n + 3) / 4, 4096);
+    if (s->valbytes == 8)
+        return launch_spmm<double>(s, p, nullptr, (const cplx*)dXT, ldx, p, (cplx*)dZT, ldz, nullptr, grid, st);
+    return launch_spmm<cplx>(s, p, nullptr, (const cplx*)dXT, ldx, p, (cplx*)dZT, ldz, nullptr, grid, st);
+}
+
+}  // extern "C"

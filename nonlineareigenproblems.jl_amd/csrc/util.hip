@@ -1,0 +1,291 @@
+// libnepmi355: error handling, device memory, BLAS-1 style helpers (gfx950).
+#include "common.h"
+#include <vector>
+
+static thread_local char g_err[1024] = "";
+
+void nep_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int NepScratch::ensure(size_t bytes) {
+    if (bytes <= cap) return NEP_OK;
+    if (dptr) { HIPCHK(hipFree(dptr)); dptr = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 4096;
+    HIPCHK(hipMalloc(&dptr, want));
+    cap = want;
+    return NEP_OK;
+}
+void NepScratch::release() {
+    if (dptr) (void)hipFree(dptr);
+    dptr = nullptr; cap = 0;
+}
+
+extern "C" {
+
+int32_t nep_version(void) { return 100; }
+const char* nep_last_error(void) { return g_err; }
+
+int32_t nep_device_count(int32_t* n) {
+    ARGCHK(n != nullptr);
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { c = 0; (void)hipGetLastError(); }
+    *n = c;
+    return NEP_OK;
+}
+int32_t nep_set_device(int32_t dev) { HIPCHK(hipSetDevice(dev)); return NEP_OK; }
+int32_t nep_device_name(char* buf, int32_t buflen) {
+    ARGCHK(buf && buflen > 0);
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    hipDeviceProp_t p;
+    HIPCHK(hipGetDeviceProperties(&p, dev));
+    snprintf(buf, buflen, "%s (%s, %d CUs)", p.name, p.gcnArchName, p.multiProcessorCount);
+    return NEP_OK;
+}
+
+int32_t nep_dev_alloc(void** dptr, size_t bytes) {
+    ARGCHK(dptr != nullptr);
+    HIPCHK(hipMalloc(dptr, bytes ? bytes : 16));
+    return NEP_OK;
+}
+int32_t nep_dev_free(void* dptr) {
+    if (dptr) HIPCHK(hipFree(dptr));
+    return NEP_OK;
+}
+int32_t nep_dev_memset(void* dptr, int32_t value, size_t bytes, nep_stream stream) {
+    HIPCHK(hipMemsetAsync(dptr, value, bytes, as_stream(stream)));
+    return NEP_OK;
+}
+int32_t nep_upload(void* ddst, const void* hsrc, size_t bytes, nep_stream stream) {
+    HIPCHK(hipMemcpyAsync(ddst, hsrc, bytes, hipMemcpyHostToDevice, as_stream(stream)));
+    HIPCHK(hipStreamSynchronize(as_stream(stream)));
+    return NEP_OK;
+}
+int32_t nep_download(void* hdst, const void* dsrc, size_t bytes, nep_stream stream) {
+    HIPCHK(hipMemcpyAsync(hdst, dsrc, bytes, hipMemcpyDeviceToHost, as_stream(stream)));
+    HIPCHK(hipStreamSynchronize(as_stream(stream)));
+    return NEP_OK;
+}
+int32_t nep_dev_copy(void* ddst, const void* dsrc, size_t bytes, nep_stream stream) {
+    HIPCHK(hipMemcpyAsync(ddst, dsrc, bytes, hipMemcpyDeviceToDevice, as_stream(stream)));
+    return NEP_OK;
+}
+int32_t nep_stream_sync(nep_stream stream) {
+    HIPCHK(hipStreamSynchronize(as_stream(stream)));
+    return NEP_OK;
+}
+
+int32_t nep_csc_to_csr(int64_t n, const int64_t* colptr, const int64_t* rowval, const void* nzval,
+                       int32_t val_is_complex, int32_t one_based, int32_t* rowptr, int32_t* colind,
+                       void* vals) {
+    ARGCHK(n >= 0 && colptr && rowptr);
+    const int64_t off = one_based ? 1 : 0;
+    const int64_t nnz = colptr[n] - off;
+    ARGCHK(nnz < (int64_t)1 << 31);
+    std::vector<int32_t> cnt(n + 1, 0);
+    for (int64_t e = 0; e < nnz; ++e) cnt[rowval[e] - off + 1]++;
+    rowptr[0] = 0;
+    for (int64_t i = 0; i < n; ++i) rowptr[i + 1] = rowptr[i] + cnt[i + 1];
+    std::vector<int32_t> pos(rowptr, rowptr + n);
+    for (int64_t c = 0; c < n; ++c)
+        for (int64_t e = colptr[c] - off; e < colptr[c + 1] - off; ++e) {
+            int64_t r = rowval[e] - off;
+            int32_t q = pos[r]++;
+            colind[q] = (int32_t)c;
+            if (val_is_complex) ((nep_cdouble*)vals)[q] = ((const nep_cdouble*)nzval)[e];
+            else ((double*)vals)[q] = ((const double*)nzval)[e];
+        }
+    return NEP_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// kernels
+__global__ void k_iar_shift_scale(int64_t n, int k, const cplx* __restrict__ src, cplx* __restrict__ dst) {
+    // dst[(j+1)*n + r] = src[j*n + r]/(j+1)   -- one pass over n*k contiguous complex entries
+    const int64_t total = n * (int64_t)k;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i / n);
+        const double s = 1.0 / (double)(j + 1);
+        cplx v = src[i];
+        dst[i + n] = cmake(v.x * s, v.y * s);
+    }
+}
+
+__global__ void k_axpy(int64_t len, cplx alpha, const cplx* __restrict__ x, cplx* __restrict__ y) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < len;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        cplx acc = y[i];
+        cfma(acc, alpha, x[i]);
+        y[i] = acc;
+    }
+}
+
+__global__ void k_scal(int64_t len, cplx alpha, cplx* __restrict__ x) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < len;
+         i += (int64_t)gridDim.x * blockDim.x)
+        x[i] = cmul(alpha, x[i]);
+}
+
+// per-block partial of sum conj(x_j) y_j for column j = blockIdx.y; partial[(j*gridDim.x + b)]
+__global__ __launch_bounds__(256) void k_coldots_partial(int64_t rows, const cplx* __restrict__ X,
+                                                         int64_t ldx, const cplx* __restrict__ Y,
+                                                         int64_t ldy, cplx* __restrict__ partial) {
+    const int j = blockIdx.y;
+    const cplx* x = X + (int64_t)j * ldx;
+    const cplx* y = Y + (int64_t)j * ldy;
+    cplx acc = cmake(0.0, 0.0);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows;
+         i += (int64_t)gridDim.x * blockDim.x)
+        cfma_conj(acc, x[i], y[i]);
+    acc = group_reduce_sum<64>(acc);
+    __shared__ cplx sm[4];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) sm[w] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cplx t = sm[0];
+        for (int q = 1; q < 4; ++q) t = cadd(t, sm[q]);
+        partial[(int64_t)j * gridDim.x + blockIdx.x] = t;
+    }
+}
+// out[j] = sum_b partial[j*nb + b]  (fixed order -> deterministic)
+__global__ void k_sum_partials(int nb, const cplx* __restrict__ partial, cplx* __restrict__ out, int k) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    cplx t = cmake(0.0, 0.0);
+    for (int b = 0; b < nb; ++b) t = cadd(t, partial[(int64_t)j * nb + b]);
+    out[j] = t;
+}
+
+// row-major (rows x k, ld lds) -> column-major selected columns
+__global__ __launch_bounds__(256) void k_rm2cm(int64_t rows, const cplx* __restrict__ src, int64_t lds,
+                                               const int* __restrict__ cols, int ncols,
+                                               cplx* __restrict__ dst, int64_t ldd) {
+    // tile 64 rows x 16 cols through LDS so that both sides are reasonably coalesced
+    __shared__ cplx tile[16][65];
+    const int64_t r0 = blockIdx.x * 64LL;
+    const int c0 = blockIdx.y * 16;
+    const int t = threadIdx.x;
+    // load: threads over (row = t/16 + 16*i, col = t%16)
+    for (int i = 0; i < 4; ++i) {
+        const int rr = (t >> 4) + 16 * i;
+        const int cc = t & 15;
+        const int64_t r = r0 + rr;
+        if (r < rows && c0 + cc < ncols) {
+            const int sc = cols ? cols[c0 + cc] : (c0 + cc);
+            tile[cc][rr] = src[r * lds + sc];
+        }
+    }
+    __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+        const int cc = (t >> 6) + 4 * i;
+        const int rr = t & 63;
+        const int64_t r = r0 + rr;
+        if (r < rows && c0 + cc < ncols) dst[(int64_t)(c0 + cc) * ldd + r] = tile[cc][rr];
+    }
+}
+
+static inline int grid_for(int64_t work, int block, int cap = 4096) {
+    int64_t g = (work + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+static NepScratch g_util_scratch;  // partial sums for nrm2/coldots (single host thread per process use)
+
+extern "C" {
+
+int32_t nep_iar_shift_scale(int64_t n, int32_t k, const nep_cdouble* dsrc, nep_cdouble* ddst,
+                            nep_stream stream) {
+    ARGCHK(n > 0 && k >= 0);
+    if (k == 0) return NEP_OK;
+    hipLaunchKernelGGL(k_iar_shift_scale, dim3(grid_for(n * k, 256)), dim3(256), 0, as_stream(stream), n,
+                       (int)k, (const cplx*)dsrc, (cplx*)ddst);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+int32_t nep_axpy(int64_t len, nep_cdouble alpha, const nep_cdouble* dx, nep_cdouble* dy, nep_stream stream) {
+    ARGCHK(len >= 0);
+    if (len == 0) return NEP_OK;
+    cplx a; a.x = alpha.re; a.y = alpha.im;
+    hipLaunchKernelGGL(k_axpy, dim3(grid_for(len, 256)), dim3(256), 0, as_stream(stream), len, a,
+                       (const cplx*)dx, (cplx*)dy);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+int32_t nep_scal(int64_t len, nep_cdouble alpha, nep_cdouble* dx, nep_stream stream) {
+    ARGCHK(len >= 0);
+    if (len == 0) return NEP_OK;
+    cplx a; a.x = alpha.re; a.y = alpha.im;
+    hipLaunchKernelGGL(k_scal, dim3(grid_for(len, 256)), dim3(256), 0, as_stream(stream), len, a, (cplx*)dx);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+int32_t nep_coldots(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx, const nep_cdouble* dY,
+                    int64_t ldy, nep_cdouble* h_out, nep_stream stream) {
+    ARGCHK(rows > 0 && k > 0 && h_out);
+    const int nb = grid_for(rows, 256 * 8, 512);
+    int rc = g_util_scratch.ensure(((size_t)k * nb + k) * sizeof(cplx));
+    if (rc) return rc;
+    cplx* partial = (cplx*)g_util_scratch.dptr;
+    cplx* out = partial + (size_t)k * nb;
+    hipLaunchKernelGGL(k_coldots_partial, dim3(nb, k), dim3(256), 0, as_stream(stream), rows, (const cplx*)dX,
+                       ldx, (const cplx*)dY, ldy, partial);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_sum_partials, dim3((k + 63) / 64), dim3(64), 0, as_stream(stream), nb, partial, out, (int)k);
+    LAUNCHCHK();
+    HIPCHK(hipMemcpyAsync(h_out, out, (size_t)k * sizeof(cplx), hipMemcpyDeviceToHost, as_stream(stream)));
+    HIPCHK(hipStreamSynchronize(as_stream(stream)));
+    return NEP_OK;
+}
+
+int32_t nep_colnorms(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx, double* h_out,
+                     nep_stream stream) {
+    ARGCHK(h_out != nullptr);
+    std::vector<nep_cdouble> tmp(k);
+    int rc = nep_coldots(rows, k, dX, ldx, dX, ldx, tmp.data(), stream);
+    if (rc) return rc;
+    for (int j = 0; j < k; ++j) h_out[j] = sqrt(tmp[j].re);
+    return NEP_OK;
+}
+
+int32_t nep_nrm2(int64_t len, const nep_cdouble* dx, double* h_out, nep_stream stream) {
+    return nep_colnorms(len, 1, dx, len, h_out, stream);
+}
+
+int32_t nep_rowmajor_to_colmajor(int64_t rows, int32_t k, const nep_cdouble* dsrc, int64_t lds,
+                                 const int32_t* h_cols, int32_t ncols, nep_cdouble* ddst, int64_t ldd,
+                                 nep_stream stream) {
+    ARGCHK(rows > 0 && k > 0 && lds >= k && ldd >= rows);
+    if (!h_cols) ncols = k;
+    ARGCHK(ncols >= 0);
+    if (ncols == 0) return NEP_OK;
+    int* dcols = nullptr;
+    if (h_cols) {
+        for (int i = 0; i < ncols; ++i) ARGCHK(h_cols[i] >= 0 && h_cols[i] < k);
+        int rc = g_util_scratch.ensure((size_t)ncols * sizeof(int));
+        if (rc) return rc;
+        dcols = (int*)g_util_scratch.dptr;
+        HIPCHK(hipMemcpyAsync(dcols, h_cols, (size_t)ncols * sizeof(int), hipMemcpyHostToDevice, as_stream(stream)));
+    }
+    dim3 grid((unsigned)((rows + 63) / 64), (unsigned)((ncols + 15) / 16));
+    hipLaunchKernelGGL(k_rm2cm, grid, dim3(256), 0, as_stream(stream), rows, (const cplx*)dsrc, lds,
+                       (const int*)dcols, (int)ncols, (cplx*)ddst, ldd);
+    LAUNCHCHK();
+    if (h_cols) HIPCHK(hipStreamSynchronize(as_stream(stream)));  // scratch reuse safety
+    return NEP_OK;
+}
+
+}  // extern "C"

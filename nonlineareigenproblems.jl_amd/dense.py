@@ -1,0 +1,98 @@
+"""Dense device helpers: tall-skinny GEMM (K7), Gram-Schmidt (K6), BLAS-1 wrappers."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, hptr, c_vp, c_i32, c_dbl
+from .nep import CDT, stream_ptr
+
+DGKS, CGS, MGS = 0, 1, 2
+
+
+class DGKS_:  # marker objects mirroring IterativeSolvers' DGKS()/ClassicalGramSchmidt()/ModifiedGramSchmidt()
+    code = DGKS
+
+
+class ClassicalGramSchmidt:
+    code = CGS
+
+
+class ModifiedGramSchmidt:
+    code = MGS
+
+
+def _orth_code(method):
+    if isinstance(method, int):
+        return method
+    return getattr(method, "code", DGKS)
+
+
+def gemm_ts(Z, B, rowmajor=False, out=None, k=None, rows=None, ldz=None):
+    """Y = Z[:, :k] * B on the FP64 matrix cores (nep_gemm_ts).
+    Z: device tensor (>=k, rows) holding a column-major block (ldz = Z.shape[1] unless given).
+    B: host k x p.  Returns device tensor: (p, rows) column-major block, or (rows, p) if rowmajor."""
+    Bm = _lib.as_c128(B, "F")
+    kk, p = Bm.shape
+    if k is None:
+        k = kk
+    assert kk == k
+    if rows is None:
+        rows = Z.shape[-1]
+    if ldz is None:
+        ldz = Z.shape[-1]
+    if out is None:
+        out = torch.empty((rows, p) if rowmajor else (p, rows), dtype=CDT, device="cuda")
+    ldy = out.shape[1]
+    check(lib.nep_gemm_ts(c_vp(Z.data_ptr()), ldz, rows, k, hptr(Bm), Bm.shape[0], p, c_vp(out.data_ptr()), ldy,
+                          1 if rowmajor else 0, stream_ptr()))
+    return out
+
+
+def orthogonalize_and_normalize(V, w, k, rows=None, ldv=None, active_rows=None, method=DGKS):
+    """IterativeSolvers.orthogonalize_and_normalize!(V, w, h, method): returns (h, beta, npasses);
+    w (device vector, `rows` entries) is orthogonalised against the first k columns of V and
+    normalised in place."""
+    if rows is None:
+        rows = w.numel()
+    if ldv is None:
+        ldv = V.shape[-1]
+    h = np.zeros(k, dtype=np.complex128)
+    beta = c_dbl(0.0)
+    npass = c_i32(0)
+    act = None
+    if active_rows is not None:
+        act = np.ascontiguousarray(active_rows, dtype=np.int64)
+        assert len(act) >= k
+    check(lib.nep_orth(c_vp(V.data_ptr()), ldv, rows, k, hptr(act) if act is not None else None,
+                       c_vp(w.data_ptr()), hptr(h), C.byref(beta), _orth_code(method), C.byref(npass), stream_ptr()))
+    return h, beta.value, npass.value
+
+
+def nrm2(x, length=None):
+    out = c_dbl(0.0)
+    check(lib.nep_nrm2(length if length is not None else x.numel(), c_vp(x.data_ptr()), C.byref(out), stream_ptr()))
+    return out.value
+
+
+def scal(x, alpha, length=None):
+    check(lib.nep_scal(length if length is not None else x.numel(), _lib.cd(alpha), c_vp(x.data_ptr()), stream_ptr()))
+
+
+def axpy(alpha, x, y, length=None):
+    check(lib.nep_axpy(length if length is not None else x.numel(), _lib.cd(alpha), c_vp(x.data_ptr()),
+                       c_vp(y.data_ptr()), stream_ptr()))
+
+
+def rowmajor_to_cols(QT, cols=None):
+    """(rows, k) row-major device block -> (ncols, rows) column-major tensor of the chosen columns"""
+    rows, k = QT.shape
+    if cols is None:
+        cols = np.arange(k)
+    cols = np.ascontiguousarray(cols, dtype=np.int32)
+    out = torch.empty((len(cols), rows), dtype=CDT, device="cuda")
+    if len(cols):
+        check(lib.nep_rowmajor_to_colmajor(rows, k, c_vp(QT.data_ptr()), k, hptr(cols), len(cols),
+                                           c_vp(out.data_ptr()), rows, stream_ptr()))
+    return out

@@ -1,0 +1,183 @@
+"""Problem gallery for the backend (inputs only): `nep_gallery(name, ...)` mirrors src/Gallery.jl:193-221
+for the problems on the hot path.
+
+  "dep0"              src/gallery_extra/basic_random_examples.jl:2-9 (MSWS RNG :73-105)
+  "qdep0"             src/gallery_extra/gallery_examples.jl:75-88 (matrices: data/qdep0.npz)
+  "nlevp_native_gun"  src/gallery_extra/NLEVP_native.jl:4-18.  gun_K/gun_M are missing from the
+                      reference checkout (.MISSING_LARGE_BLOBS); they are read from $NEPMI_GUN_DIR in
+                      the reference's text format (src/utils/Serialization.jl:20-31) when given,
+                      otherwise a deterministic gun-like stand-in with the reference's 1-norms is used
+                      (SURVEY.md section 8d C2).  W1, W2 are the reference's data (data/gun_W.npz).
+  "gun_spmf" / "gun_spmf_scaled"   the SPMF form used with Krylov methods (test/nlar.jl:26-27)
+"""
+import os
+
+import numpy as np
+import scipy.sparse as sp
+
+from . import funcs
+from .nep import DEP, PEP, SPMF_NEP, SumNEP, shift_and_scale
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+_M64 = (1 << 64) - 1
+_M128 = (1 << 128) - 1
+
+
+class MSWS_RNG:
+    """Middle Square Weyl Sequence RNG, UInt128 arithmetic (basic_random_examples.jl:73-91)."""
+
+    def __init__(self, seed=0):
+        self.s = ((seed << 1) + 0x9EF09A97AC0F9ECAEF01C4F2DB0958C9) & _M128
+        self.x = 0x1DE568E1A1CA1B593CBF13F7407CF43E
+        self.w = 0xD4AC5C288559E14A5FAFC1B7DF9F9E0E
+
+    def gen_rng_int(self):
+        self.x = (self.x * self.x) & _M128
+        self.w = (self.w + self.s) & _M128
+        self.x = (self.x + self.w) & _M128
+        self.x = ((self.x >> 64) | (self.x << 64)) & _M128
+        return self.x & _M64
+
+    def gen_rng_float(self):
+        return float(self.gen_rng_int()) / float(_M64)
+
+
+def gen_rng_mat(rng, n, m):
+    A = np.zeros((n, m))
+    for c in range(m):
+        for r in range(n):
+            A[r, c] = 1 - 2 * rng.gen_rng_float()
+    return A
+
+
+def read_sparse_matrix(filename):
+    """src/utils/Serialization.jl:20-31"""
+    with open(filename) as f:
+        data = f.read().split()
+    m = int(data[0]); n = int(data[1])
+    c = (len(data) - 2) // 3
+    I = np.array(data[2:2 + c], dtype=np.int64) - 1
+    J = np.array(data[2 + c:2 + 2 * c], dtype=np.int64) - 1
+    V = np.array(data[2 + 2 * c:2 + 3 * c], dtype=np.float64)
+    return sp.csc_matrix((V, (I, J)), shape=(m, n))
+
+
+def write_sparse_matrix(filename, M):
+    """src/utils/Serialization.jl:8-17"""
+    M = sp.coo_matrix(sp.csc_matrix(M))
+    order = np.lexsort((M.row, M.col))
+    with open(filename, "w") as f:
+        f.write("%d\n%d\n" % M.shape)
+        for x in M.row[order] + 1:
+            f.write("%d\n" % x)
+        for x in M.col[order] + 1:
+            f.write("%d\n" % x)
+        for x in M.data[order]:
+            f.write(repr(float(x)) + "\n")
+
+
+def _load_csc(path, key):
+    d = np.load(path)
+    return sp.csc_matrix((d[key + "_data"], d[key + "_indices"], d[key + "_indptr"]), shape=tuple(d[key + "_shape"]))
+
+
+GUN_NK = 1.474544889815002e+05   # test/rk_helper/gun_test_utils.jl:50
+GUN_NM = 2.726114618171165e-02   # :51
+GUN_SIGMA2 = 108.8774
+GUN_SHIFT = 250.0 ** 2           # test/nlar.jl:19-20
+GUN_SCALE = 330.0 ** 2 - 220.0 ** 2
+
+
+def _onenorm(A):
+    return abs(A).sum(axis=0).max()
+
+
+def gun_standin_KM(nx=76, ny=131):
+    def T(n):
+        return sp.diags([-np.ones(n - 1), 2 * np.ones(n), -np.ones(n - 1)], [-1, 0, 1])
+
+    def B(n):
+        return sp.diags([np.ones(n - 1), 4 * np.ones(n), np.ones(n - 1)], [-1, 0, 1]) / 6.0
+
+    K = sp.csc_matrix(sp.kron(sp.identity(nx), T(ny)) + sp.kron(T(nx), sp.identity(ny)))
+    M = sp.csc_matrix(sp.kron(B(nx), B(ny)))
+    K = sp.csc_matrix(K * (GUN_NK / _onenorm(K)))
+    M = sp.csc_matrix(M * (GUN_NM / _onenorm(M)))
+    return K, M
+
+
+def _twin_grid(n):
+    for ny in (131, 61, 31, 25, 20, 16, 10, 8, 5, 4, 2, 1):
+        if n % ny == 0:
+            return n // ny, ny
+    return n, 1
+
+
+def _fold(W, n, tail):
+    W = sp.coo_matrix(W)
+    N = W.shape[0]
+    r = W.row - (N - n) if tail else W.row
+    c = W.col - (N - n) if tail else W.col
+    keep = (r >= 0) & (r < n) & (c >= 0) & (c < n)
+    return sp.csc_matrix((W.data[keep], (r[keep], c[keep])), shape=(n, n))
+
+
+def gun_matrices(n=9956):
+    p = os.path.join(_DATA, "gun_W.npz")
+    W1 = _load_csc(p, "W1"); W2 = _load_csc(p, "W2")
+    d = os.environ.get("NEPMI_GUN_DIR")
+    if n == 9956 and d:
+        K = read_sparse_matrix(os.path.join(d, "gun_K.txt"))
+        M = read_sparse_matrix(os.path.join(d, "gun_M.txt"))
+        return K, M, W1, W2
+    if n == 9956:
+        K, M = gun_standin_KM()
+        return K, M, W1, W2
+    nx, ny = _twin_grid(n)
+    K, M = gun_standin_KM(nx, ny)
+    return K, M, _fold(W1, n, True), _fold(W2, n, False)
+
+
+def nlevp_native_gun(n=9956):
+    K, M, W1, W2 = gun_matrices(n)
+    pep = PEP([K, -M])
+    sqrtnep = SPMF_NEP([W1, W2], [funcs.ISqrt(1.0, 0.0), funcs.ISqrt(1.0, -GUN_SIGMA2 ** 2)])
+    return SumNEP(pep, sqrtnep)
+
+
+def gun_spmf(n=9956):
+    nep = nlevp_native_gun(n)
+    return SPMF_NEP(nep.get_Av(), nep.get_fv())
+
+
+def gun_spmf_scaled(n=9956):
+    return shift_and_scale(gun_spmf(n), shift=GUN_SHIFT, scale=GUN_SCALE)
+
+
+def dep0(n=5):
+    rng = MSWS_RNG()
+    A0 = gen_rng_mat(rng, n, n)
+    A1 = gen_rng_mat(rng, n, n)
+    return DEP([A0, A1], [0.0, 1.0])
+
+
+def qdep0():
+    p = os.path.join(_DATA, "qdep0.npz")
+    A0 = _load_csc(p, "A0"); A1 = _load_csc(p, "A1")
+    n = A0.shape[0]
+    return SPMF_NEP([-sp.identity(n, format="csc"), A0, A1], [funcs.Monomial(2), funcs.one(), funcs.Exp(-1.0)])
+
+
+GALLERY = {
+    "dep0": dep0,
+    "qdep0": qdep0,
+    "nlevp_native_gun": nlevp_native_gun,
+    "gun_spmf": gun_spmf,
+    "gun_spmf_scaled": gun_spmf_scaled,
+}
+
+
+def nep_gallery(name, *args, **kwargs):
+    if name not in GALLERY:
+        raise KeyError("unknown gallery problem %r (available: %s)" % (name, ", ".join(sorted(GALLERY))))
+    return GALLERY[name](*args, **kwargs)

@@ -1,0 +1,118 @@
+"""Infinite Arnoldi (iar) on the device backend -- same keyword surface as src/method_iar.jl:47-63.
+
+Device-resident state: the basis V (n(m+1) x (m+1), 1.6 GB for gun m=100), z/y work vectors and the
+Ritz block.  Per iteration only H's new column (k+1 numbers), the k x k eigenvector matrix of H, the
+coefficient block and 2k norms cross PCIe.
+
+Reference step (method_iar.jl:94-164)            device realisation
+  y[:,2:k+1]=reshape(VV[1:nk,k],n,k)./(1:k)'      none: column k of V *is* an n x k block (ld n); the
+                                                   1/j scaling is folded into the coefficient block
+  y[:,1]=compute_Mlincomb!(nep,s,y,alpha)         K1 nep_mlincomb on that block
+  y[:,1]=-lin_solve(M0inv,y[:,1])                 K5 nep_lu_solve(scale=-1) straight into V[0:n,k+1]
+  vv=reshape(y[:,1:k+1])                          nep_iar_shift_scale (one pass over n*k entries)
+  orthogonalize_and_normalize!(VV,vv,h,DGKS)      K6 nep_orth with the block-triangular row counts
+  D,Z=eigen(H[1:k,1:k])                           host LAPACK (k x k)
+  Q=VV[1:n,:]*Z                                   K7 nep_gemm_ts -> row-major Q^T
+  err[k,s]=estimate_error(...) for s=1:k          K2 nep_resid_batch (one pass for all k pairs)
+"""
+import time
+
+import numpy as np
+import scipy.linalg as sla
+import torch
+
+from . import dense
+from ._lib import lib, check, c_vp
+from .errmeasure import DefaultErrmeasure, estimate_errors
+from .exceptions import NoConvergenceException
+from .linsolvers import DefaultLinSolverCreator, create_linsolver, lin_solve
+from .nep import CDT, to_dev, to_host, stream_ptr
+
+EPS = np.finfo(float).eps
+
+
+def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
+        errmeasure=None, sigma=0.0, gamma=1.0, v=None, logger=0, check_error_every=1, proj_solve=False,
+        errhist=None, timers=None, return_device=False):
+    if proj_solve:
+        raise NotImplementedError("proj_solve=true (inner_solve on the projected NEP) is out of scope (SURVEY.md section 8f)")
+    n = nep.size(1); m = int(maxit)
+    sigma = complex(sigma); gamma = complex(gamma)
+    if linsolvercreator is None:
+        linsolvercreator = DefaultLinSolverCreator()
+    if errmeasure is None:
+        errmeasure = DefaultErrmeasure(nep)
+    if v is None:
+        v = np.random.randn(n)
+    tm = timers if timers is not None else {}
+    for key in ("mlincomb", "solve", "orth", "ritz", "resid", "host_eig"):
+        tm.setdefault(key, 0.0)
+    sync = torch.cuda.synchronize if timers is not None else (lambda: None)
+
+    # initialization (method_iar.jl:76-86)
+    ldv = n * (m + 1)
+    V = torch.zeros((m + 1, ldv), dtype=CDT, device="cuda")
+    H = np.zeros((m + 1, m), dtype=np.complex128)
+    alpha = gamma ** np.arange(m + 1); alpha[0] = 0
+    M0inv = create_linsolver(linsolvercreator, nep, sigma)
+    v0 = np.asarray(v, dtype=np.complex128)
+    V[0, :n] = torch.from_numpy(v0 / np.linalg.norm(v0)).to("cuda")
+    # derivative table at sigma: fD[j,i] = f_i^(j)(sigma)  (DerSPMF, NEPTypes.jl:1108-1128)
+    fv = nep.get_fv()
+    fD = np.column_stack([f.derivs(sigma, m + 1) for f in fv])
+    z = torch.empty(n, dtype=CDT, device="cuda")
+    active = (np.arange(1, m + 2) * n).astype(np.int64)   # column j has (j+1) non-zero blocks
+    err = np.full((m, m), np.nan)
+    lam = np.zeros(0, dtype=np.complex128); QT = None; idx = np.zeros(0, dtype=int)
+    k = 1; conv_eig = 0
+    while k <= m and conv_eig < neigs:
+        t0 = time.perf_counter()
+        # z = sum_{j=1..k} alpha_{j+1}/j * M^(j)(sigma) * V_k block j
+        jj = np.arange(1, k + 1)
+        Cm = (alpha[1:k + 1] / jj)[:, None] * fD[1:k + 1, :]
+        nep.dev.mlincomb(Cm, V.data_ptr() + 16 * (k - 1) * ldv, z, k=k, ldv=n)
+        sync(); t1 = time.perf_counter()
+        # new vector, block 0: -M(sigma)^{-1} z ; blocks 1..k: shifted/scaled old column
+        vv = V[k]
+        M0inv.lu.solve(z, out=vv[:n].reshape(1, n), scale=-1.0)
+        sync(); t2 = time.perf_counter()
+        check(lib.nep_iar_shift_scale(n, k, c_vp(V.data_ptr() + 16 * (k - 1) * ldv),
+                                      c_vp(vv.data_ptr()), stream_ptr()))
+        h, beta, _ = dense.orthogonalize_and_normalize(V, vv, k, rows=n * (k + 1), ldv=ldv,
+                                                       active_rows=active, method=orthmethod)
+        H[:k, k - 1] = h; H[k, k - 1] = beta
+        sync(); t3 = time.perf_counter()
+        tm["mlincomb"] += t1 - t0; tm["solve"] += t2 - t1; tm["orth"] += t3 - t2
+        if (k % check_error_every == 0) or (k == m):
+            D, Z = sla.eig(H[:k, :k])
+            t4 = time.perf_counter()
+            QT = dense.gemm_ts(V, Z, rowmajor=True, k=k, rows=n, ldz=ldv)       # (n, k) row-major
+            lam = sigma + gamma / D
+            sync(); t5 = time.perf_counter()
+            e = estimate_errors(errmeasure, lam, QT)
+            t6 = time.perf_counter()
+            tm["host_eig"] += t4 - t3; tm["ritz"] += t5 - t4; tm["resid"] += t6 - t5
+            err[k - 1, :k] = e
+            conv_eig = int(np.sum(e < tol))
+            idx = np.argsort(e, kind="stable")
+            err[k - 1, :k] = e[idx]
+            if errhist is not None:
+                errhist.append(err[k - 1, :k].copy())
+            if k == m or conv_eig >= neigs:
+                nrof = int(min(len(lam), neigs))
+                lam = lam[idx[:nrof]]
+                idx = idx[:nrof]
+        k += 1
+    k -= 1
+    if conv_eig < neigs and neigs != np.inf:
+        Q = to_host(dense.rowmajor_to_cols(QT, idx[:len(lam)])) if QT is not None else None
+        msg = "Number of iterations exceeded. maxit=%d." % maxit
+        if conv_eig < 3:
+            msg += "Try to change the inner_solver_method for better performance."
+        raise NoConvergenceException(lam, Q, err[k - 1, :len(lam)], msg)
+    nc = min(len(lam), conv_eig)
+    lam = lam[:nc]
+    Qd = dense.rowmajor_to_cols(QT, idx[:nc])          # (nc, n) = column-major n x nc
+    if return_device:
+        return lam, Qd, V[:k]
+    return lam, to_host(Qd), V[:k]

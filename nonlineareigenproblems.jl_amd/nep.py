@@ -1,0 +1,339 @@
+"""NEP types on the MI355X backend -- the host-side mirror of the reference's NEP interface.
+
+Same names and argument meaning as the reference (src/NEPCore.jl:89-194, src/NEPTypes.jl):
+`size`, `issparse`, `compute_Mlincomb(nep, lam, V[, a[, startder]])`, `compute_Mder(nep, lam, i)`,
+`compute_MM(nep, S, V)`, `get_Av`, `get_fv`; types `SPMF_NEP`, `DEP`, `PEP`, `SumNEP`, `DerSPMF`,
+`shift_and_scale`.  Every AbstractSPMF owns one device object (`nep_spmf`, a stacked CSR of all its
+A_i) and all compute_* calls run the HIP kernels behind the C ABI; the only host arithmetic is the
+O(k*m_t) coefficient block and compute_Mder (sparse linear combination for the one-off host LU,
+src/NEPTypes.jl:343-367).
+
+Dense blocks on the device are torch complex128 tensors used as raw memory: a column-major
+n x k block is a contiguous tensor of shape (k, n) (row i of the tensor = column i of the block).
+Inputs may be NumPy arrays (uploaded, result downloaded -> same semantics as the reference: a new
+vector is returned and V is never modified) or such tensors (result stays on the device).
+"""
+import ctypes as C
+
+import numpy as np
+import scipy.sparse as sp
+import torch
+
+from . import _lib, funcs
+from ._lib import lib, check, hptr, c_vp, c_i32, c_i64
+
+CDT = torch.complex128
+
+
+def stream_ptr():
+    return c_vp(torch.cuda.current_stream().cuda_stream)
+
+
+def dev_zeros(cols, rows):
+    return torch.zeros((cols, rows), dtype=CDT, device="cuda")
+
+
+def dev_empty(cols, rows):
+    return torch.empty((cols, rows), dtype=CDT, device="cuda")
+
+
+def to_dev(A):
+    """host column-major block (n x k ndarray or vector) -> device (k, n) tensor"""
+    _lib.require_gpu()
+    A = np.asarray(A, dtype=np.complex128)
+    if A.ndim == 1:
+        A = A.reshape(-1, 1)
+    return torch.from_numpy(np.ascontiguousarray(A.T)).to("cuda")
+
+
+def to_host(T):
+    """device (k, n) tensor -> host n x k ndarray"""
+    return T.cpu().numpy().T.copy()
+
+
+def is_dev(x):
+    return isinstance(x, torch.Tensor)
+
+
+def dptr(T, col=0, row=0):
+    assert T.dtype == CDT and T.is_contiguous()
+    return c_vp(T.data_ptr() + 16 * (col * T.shape[-1] + row))
+
+
+def _to_csr(A):
+    if sp.issparse(A):
+        M = sp.csr_matrix(A)
+        M.sum_duplicates()
+        M.sort_indices()
+    else:
+        M = sp.csr_matrix(np.asarray(A))
+        # keep explicit zeros out; dense matrices become full CSR rows
+    return M
+
+
+class SPMFDevice:
+    """Owns the device-side stacked CSR (nep_spmf handle)."""
+
+    def __init__(self, Av):
+        _lib.require_gpu()
+        self.n = Av[0].shape[0]
+        self.mt = len(Av)
+        csr = [_to_csr(A) for A in Av]
+        keep = []
+        rp = (c_vp * self.mt)(); ci = (c_vp * self.mt)(); vv = (c_vp * self.mt)()
+        isc = (c_i32 * self.mt)()
+        for i, M in enumerate(csr):
+            cplx = np.iscomplexobj(M.data)
+            ip = np.ascontiguousarray(M.indptr, dtype=np.int32)
+            ix = np.ascontiguousarray(M.indices, dtype=np.int32)
+            dv = np.ascontiguousarray(M.data, dtype=np.complex128 if cplx else np.float64)
+            keep += [ip, ix, dv]
+            rp[i] = ip.ctypes.data; ci[i] = ix.ctypes.data; vv[i] = dv.ctypes.data
+            isc[i] = 1 if cplx else 0
+        h = c_vp()
+        check(lib.nep_spmf_create(self.n, self.mt, rp, ci, vv, isc, C.byref(h)))
+        self.h = h
+        info = (c_i64 * 6)()
+        check(lib.nep_spmf_info(self.h, info))
+        self.nnz = int(info[2]); self.valbytes = int(info[3]); self.lanes = int(info[4])
+        self.matrix_bytes = int(info[5])
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib.nep_spmf_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def mlincomb(self, Cmat, V, z=None, k=None, ldv=None):
+        """z = sum_i A_i (V C[:,i]); V device tensor (k, n) (or any tensor + explicit k, ldv)."""
+        Cm = _lib.as_c128(Cmat, "F")
+        if k is None:
+            k = V.shape[0]; ldv = V.shape[1]
+        assert Cm.shape == (k, self.mt)
+        if z is None:
+            z = torch.empty(self.n, dtype=CDT, device="cuda")
+        check(lib.nep_mlincomb(self.h, k, hptr(Cm), c_vp(V.data_ptr() if is_dev(V) else V), ldv,
+                               c_vp(z.data_ptr()), stream_ptr()))
+        return z
+
+    def resid_batch(self, F, QT, k, ldq):
+        Fm = _lib.as_c128(F, "F")
+        assert Fm.shape == (self.mt, k)
+        rn = np.empty(k); qn = np.empty(k)
+        check(lib.nep_resid_batch(self.h, k, hptr(Fm), c_vp(QT.data_ptr()), ldq, hptr(rn), hptr(qn), stream_ptr()))
+        return rn, qn
+
+    def algorithmic_bytes(self, k):
+        """matrix bytes + 16 n k (read V) + 16 n (write z)."""
+        return self.matrix_bytes + 16 * self.n * k + 16 * self.n
+
+
+# ----------------------------------------------------------------------------------------------
+class NEP:
+    def size(self, d=None):
+        return (self.n, self.n) if d is None else self.n
+
+
+class AbstractSPMF(NEP):
+    """M(lam) = sum_i f_i(lam) A_i   (src/NEPTypes.jl:96-113)."""
+    _dev = None
+    _fro = None
+
+    def get_Av(self):
+        raise NotImplementedError
+
+    def get_fv(self):
+        raise NotImplementedError
+
+    def issparse(self):
+        return sp.issparse(self.get_Av()[0])
+
+    @property
+    def dev(self):
+        if self._dev is None:
+            self._dev = SPMFDevice(self.get_Av())
+        return self._dev
+
+    # ---- coefficient block C[j,i] = a_j f_i^(j)(lam) (Appendix A of SURVEY.md; NEPCore.jl:218-228)
+    def coeff_block(self, lam, a, startder=0):
+        a = np.asarray(a, dtype=np.complex128)
+        k = len(a)
+        fv = self.get_fv()
+        Cm = np.empty((k, len(fv)), dtype=np.complex128, order="F")
+        for i, f in enumerate(fv):
+            d = f.derivs(lam, k + startder)[startder:]
+            Cm[:, i] = np.where(a != 0, a * d, 0.0)   # a_j == 0 drops the column (NEPTypes.jl:982-983)
+        return Cm
+
+    def compute_Mlincomb(self, lam, V, a=None, startder=0):
+        """sum_j a_j M^(j-1+startder)(lam) v_j   (src/NEPCore.jl:111-160, src/NEPTypes.jl:972-1013).
+        NumPy in -> NumPy out; device tensor in -> device tensor out.  V is not modified."""
+        host = not is_dev(V)
+        Vd = to_dev(V) if host else (V if V.dim() == 2 else V.reshape(1, -1))
+        k = Vd.shape[0]
+        if a is None:
+            a = np.ones(k)
+        if len(a) != k:
+            raise ValueError("length of a must equal the number of columns of V")
+        z = self.dev.mlincomb(self.coeff_block(lam, a, startder), Vd)
+        return to_host(z.reshape(1, -1))[:, 0] if host else z
+
+    compute_Mlincomb_ = compute_Mlincomb  # the `!` variant may overwrite V; ours never needs to
+
+    def compute_Mder(self, lam, i=0):
+        """M^(i)(lam) as a host sparse/dense matrix (src/NEPTypes.jl:362-394); host-side, used once per
+        shift for the factorisation."""
+        Av = self.get_Av(); fv = self.get_fv()
+        Z = None
+        for A, f in zip(Av, fv):
+            c = f.derivs(lam, i + 1)[i]
+            T = A * c
+            Z = T if Z is None else Z + T
+        return Z
+
+    def compute_MM(self, S, V):
+        """sum_i A_i V f_i(S)   (src/NEPTypes.jl:276-319): host f_i(S), device GEMM + SpMM."""
+        from .dense import gemm_ts
+        S = np.atleast_2d(np.asarray(S, dtype=np.complex128))
+        p = S.shape[0]
+        host = not is_dev(V)
+        Vd = to_dev(V) if host else V
+        fv = self.get_fv()
+        isdiag = np.count_nonzero(S - np.diag(np.diag(S))) == 0
+        Fs = []
+        for f in fv:
+            if isdiag:
+                Fs.append(np.diag(np.array([f(s) for s in np.diag(S)], dtype=np.complex128)))
+            else:
+                Fs.append(np.asarray(f.matfun(S), dtype=np.complex128))
+        B = np.hstack(Fs)                                    # p x (p*mt)
+        mt = len(fv)
+        XT = gemm_ts(Vd, B, rowmajor=True)                   # (n, p*mt) row-major
+        ZT = torch.empty((self.n, p), dtype=CDT, device="cuda")
+        check(lib.nep_spmm_terms(self.dev.h, p, c_vp(XT.data_ptr()), p * mt, c_vp(ZT.data_ptr()), p, stream_ptr()))
+        if host:
+            return ZT.cpu().numpy()
+        return ZT.t().contiguous()
+
+    def fro_norms(self):
+        if self._fro is None:
+            self._fro = [float(np.linalg.norm(A.data)) if sp.issparse(A) else float(np.linalg.norm(A))
+                         for A in self.get_Av()]
+        return self._fro
+
+
+class SPMF_NEP(AbstractSPMF):
+    """src/NEPTypes.jl:162-237."""
+
+    def __init__(self, AA, fii, check_consistency=True):
+        if len(AA) != len(fii):
+            raise ValueError("Inconsistency: Number of supplied matrices = %d but the number of supplied "
+                             "functions are = %d" % (len(AA), len(fii)))
+        sps = [sp.issparse(A) for A in AA]
+        if not (all(sps) or not any(sps)):
+            raise ValueError("Mixing sparse and dense matrices is not allowed in SPMF_NEP. Either use a "
+                             "consistent format, or split your problem into a sparse and a dense part and "
+                             "use SumNEP.")
+        for i, A in enumerate(AA[1:]):
+            if A.shape != AA[0].shape:
+                raise ValueError("The dimensions of the matrices mismatch: size(AA[1]) != size(AA[%d])" % (i + 2))
+        fii = [f if isinstance(f, funcs.ScalarFun) else funcs.FromMatrixFunction(f) for f in fii]
+        self.A = [sp.csc_matrix(A) if sp.issparse(A) else np.asarray(A) for A in AA]
+        self.fi = list(fii)
+        self.n = AA[0].shape[0]
+
+    def get_Av(self):
+        return self.A
+
+    def get_fv(self):
+        return self.fi
+
+
+class DEP(AbstractSPMF):
+    """-lam I + sum_i A_i exp(-tau_i lam)   (src/NEPTypes.jl:427-513)."""
+
+    def __init__(self, AA, tauv=(0.0, 1.0)):
+        tauv = np.asarray(tauv)
+        if np.iscomplexobj(tauv):
+            raise ValueError("Incorrect construction of DEP. The delays need to be real.")
+        self.A = [sp.csc_matrix(A) if sp.issparse(A) else np.asarray(A) for A in AA]
+        self.tauv = np.array(tauv, dtype=float)
+        self.n = AA[0].shape[0]
+
+    def get_Av(self):
+        J = sp.identity(self.n, format="csc") if sp.issparse(self.A[0]) else np.eye(self.n)
+        return [J] + list(self.A)
+
+    def get_fv(self):
+        fv = [-funcs.ident()]
+        for tau in self.tauv:
+            fv.append(funcs.one() if tau == 0 else funcs.Exp(-tau))
+        return fv
+
+
+class PEP(AbstractSPMF):
+    """sum_i lam^i A_i   (src/types_poly.jl:31-98)."""
+
+    def __init__(self, AA):
+        self.A = [sp.csc_matrix(A) if sp.issparse(A) else np.asarray(A) for A in AA]
+        self.n = AA[0].shape[0]
+
+    def get_Av(self):
+        return self.A
+
+    def get_fv(self):
+        return [funcs.Monomial(i) for i in range(len(self.A))]
+
+
+class SumNEP(AbstractSPMF):
+    """SPMFSumNEP (src/NEPTypes.jl:845-898): the stacked CSR simply holds the terms of both halves."""
+
+    def __init__(self, nep1, nep2):
+        if nep1.size() != nep2.size():
+            raise ValueError("size mismatch in SumNEP")
+        self.nep1, self.nep2 = nep1, nep2
+        self.n = nep1.n
+
+    def get_Av(self):
+        return list(self.nep1.get_Av()) + list(self.nep2.get_Av())
+
+    def get_fv(self):
+        return list(self.nep1.get_fv()) + list(self.nep2.get_fv())
+
+
+class DerSPMF(AbstractSPMF):
+    """Derivative table precomputed at sigma (src/NEPTypes.jl:1055-1160).  Shares the device object
+    of the wrapped SPMF."""
+
+    def __init__(self, spmf, sigma, m):
+        self.spmf = spmf
+        self.sigma = complex(sigma)
+        self.n = spmf.n
+        self.fD = np.column_stack([f.derivs(self.sigma, 2 * m + 2) for f in spmf.get_fv()])
+
+    def get_Av(self):
+        return self.spmf.get_Av()
+
+    def get_fv(self):
+        return self.spmf.get_fv()
+
+    @property
+    def dev(self):
+        return self.spmf.dev
+
+    def coeff_block(self, lam, a, startder=0):
+        a = np.asarray(a, dtype=np.complex128)
+        k = len(a)
+        if complex(lam) != self.sigma or k + startder > self.fD.shape[0]:
+            return self.spmf.coeff_block(lam, a, startder)
+        return np.asfortranarray(np.where((a != 0)[:, None], a[:, None] * self.fD[startder:startder + k, :], 0.0))
+
+
+def shift_and_scale(orgnep, shift=0, scale=1):
+    """src/NEPTransformations.jl:92-105 (SPMF version: same matrices, composed functions)."""
+    fv = [f.affine(scale, shift) for f in orgnep.get_fv()]
+    new = SPMF_NEP(orgnep.get_Av(), fv)
+    new._dev = orgnep._dev  # same matrices -> share the device object
+    return new

@@ -1,0 +1,231 @@
+"""GPU parity tests: every HIP kernel behind the C ABI against the CPU oracle / NumPy on the same
+seeded inputs.  Tolerances are stated per test; all arithmetic is complex128."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def na():
+    import nep_amd
+    assert nep_amd.device_count() >= 1, "no GPU visible"
+    return nep_amd
+
+
+def _rand_spmf(n, mt, dens, seed, cplx_vals=False):
+    from oracle import neps as oneps
+    rng = np.random.default_rng(seed)
+    AA = []
+    for i in range(mt):
+        A = sp.random(n, n, dens, random_state=seed * 10 + i, format="csc")
+        if cplx_vals and i % 2 == 1:
+            A = A + 1j * sp.random(n, n, dens, random_state=seed * 10 + i + 100, format="csc")
+        AA.append(sp.csc_matrix(A))
+    ofv = [oneps.f_one(), oneps.f_id(), oneps.f_isqrt(0.0), oneps.f_isqrt(-108.8774 ** 2), oneps.f_exp(-0.001),
+           oneps.f_pow(2)][:mt]
+    return AA, ofv, rng
+
+
+def _pfv(na, mt):
+    f = na.funcs
+    return [f.one(), f.ident(), f.ISqrt(1.0, 0.0), f.ISqrt(1.0, -108.8774 ** 2), f.Exp(-0.001), f.Monomial(2)][:mt]
+
+
+@pytest.mark.parametrize("k", [1, 2, 7, 33])
+@pytest.mark.parametrize("cplx_vals", [False, True])
+def test_mlincomb_vs_oracle(na, k, cplx_vals):
+    from oracle import neps as oneps
+    n, mt = 203, 4
+    AA, ofv, rng = _rand_spmf(n, mt, 0.05, 3, cplx_vals)
+    onep = oneps.SPMF_NEP(AA, ofv)
+    pnep = na.SPMF_NEP(AA, _pfv(na, mt))
+    lam = 120.0 ** 2 + 3j
+    V = rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k))
+    a = rng.standard_normal(k) + 0j
+    if k >= 7:
+        a[2] = 0; a[5] = 0
+    V0 = V.copy()
+    z = pnep.compute_Mlincomb(lam, V, a)
+    zo = onep.compute_Mlincomb(lam, V, a)
+    assert np.array_equal(V, V0)                      # V must not be modified (test/spmf.jl:26-30)
+    assert np.linalg.norm(z - zo) <= 1e-10 * np.linalg.norm(zo)
+    # a = ones == no a  (test/core.jl:16-32)
+    z1 = pnep.compute_Mlincomb(lam, V); z2 = pnep.compute_Mlincomb(lam, V, np.ones(k))
+    assert np.array_equal(z1, z2)
+    # startder
+    if k <= 7:
+        zs = pnep.compute_Mlincomb(lam, V, a, 2)
+        zso = onep.compute_Mlincomb(lam, V, a, 2)
+        assert np.linalg.norm(zs - zso) <= 1e-9 * np.linalg.norm(zso)
+
+
+def test_mlincomb_dep_pep_sum(na):
+    from oracle import gallery as og, neps as oneps
+    rng = np.random.default_rng(1)
+    # DEP dense n=5 (config C1 plumbing) and n=100
+    for n in (5, 100):
+        o = og.dep0(n); p = na.nep_gallery("dep0", n)
+        V = rng.standard_normal((n, 4)) + 1j * rng.standard_normal((n, 4))
+        a = np.array([1.0, -2.0, 0.5, 3.0])
+        for lam in (1.0 + 1.0j, -0.3, 0.0):
+            zo = o.compute_Mlincomb(lam, V, a); z = p.compute_Mlincomb(lam, V, a)
+            assert np.linalg.norm(z - zo) <= 1e-13 * max(1.0, np.linalg.norm(zo))
+    # KAT src/Gallery.jl:172-176
+    p = na.nep_gallery("dep0", 100)
+    assert np.linalg.norm(p.compute_Mlincomb(1.0 + 1.0j, np.ones(100))) == pytest.approx(57.498446538064954, rel=1e-13)
+    # PEP + SPMF sum (native gun type) on a reduced twin
+    o = og.nlevp_native_gun(655); p = na.nep_gallery("nlevp_native_gun", 655)
+    V = rng.standard_normal((655, 3)) + 1j * rng.standard_normal((655, 3))
+    lam = 250.0 ** 2 + 10j
+    zo = o.compute_Mlincomb(lam, V); z = p.compute_Mlincomb(lam, V)
+    assert np.linalg.norm(z - zo) <= 1e-12 * np.linalg.norm(zo)
+
+
+def test_compute_MM_vs_oracle(na):
+    from oracle import neps as oneps
+    n, mt = 150, 4
+    AA, ofv, rng = _rand_spmf(n, mt, 0.06, 5)
+    onep = oneps.SPMF_NEP(AA, ofv); pnep = na.SPMF_NEP(AA, _pfv(na, mt))
+    V = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
+    S = rng.standard_normal((3, 3)) + 120.0 ** 2 * np.eye(3)        # test/spmf.jl:127-156
+    Zo = onep.compute_MM(S, V); Z = pnep.compute_MM(S, V)
+    assert np.linalg.norm(Z - Zo) <= 1e-10 * np.linalg.norm(Zo)
+    D = np.diag([1.0 + 2j, 3.0, -1.0])
+    assert np.linalg.norm(pnep.compute_MM(D, V) - onep.compute_MM(D, V)) <= 1e-12 * np.linalg.norm(Zo)
+
+
+@pytest.mark.parametrize("k", [1, 5, 64, 100, 130])
+def test_resid_batch(na, k):
+    n, mt = 317, 4
+    AA, ofv, rng = _rand_spmf(n, mt, 0.04, 7, cplx_vals=(k == 5))
+    pnep = na.SPMF_NEP(AA, _pfv(na, mt))
+    Q = rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k))
+    lams = 120.0 ** 2 + rng.standard_normal(k) * 100 + 1j * rng.standard_normal(k)
+    import torch
+    QT = torch.from_numpy(np.ascontiguousarray(Q)).to("cuda")
+    errm = na.ResidualErrmeasure(pnep)
+    e = errm.batch(list(lams), QT)
+    fv = _pfv(na, mt)
+    for s in range(k):
+        r = sum(fv[i](lams[s]) * (AA[i] @ Q[:, s]) for i in range(mt))
+        ref = np.linalg.norm(r) / np.linalg.norm(Q[:, s])
+        assert e[s] == pytest.approx(ref, rel=1e-11)
+
+
+@pytest.mark.parametrize("rows,k,p", [(16, 4, 8), (100, 3, 5), (1000, 37, 41), (333, 100, 100), (257, 61, 120),
+                                      (5, 2, 1), (4096, 16, 60)])
+@pytest.mark.parametrize("rowmajor", [False, True])
+def test_gemm_ts(na, rows, k, p, rowmajor):
+    rng = np.random.default_rng(rows + k + p)
+    Z = rng.standard_normal((rows, k)) + 1j * rng.standard_normal((rows, k))
+    B = rng.standard_normal((k, p)) + 1j * rng.standard_normal((k, p))   # asymmetric, complex
+    Y = na.gemm_ts(na.to_dev(Z), B, rowmajor=rowmajor)
+    Yh = Y.cpu().numpy() if rowmajor else na.to_host(Y)
+    ref = Z @ B
+    assert np.linalg.norm(Yh - ref) <= 1e-13 * np.linalg.norm(ref) * np.sqrt(k)
+
+
+def test_gemm_ts_ld(na):
+    """leading dimension larger than rows (iar: first block row of V)"""
+    rng = np.random.default_rng(0)
+    ld, rows, k = 500, 123, 9
+    Zfull = rng.standard_normal((ld, k)) + 1j * rng.standard_normal((ld, k))
+    B = rng.standard_normal((k, k)) + 1j * rng.standard_normal((k, k))
+    Y = na.gemm_ts(na.to_dev(Zfull), B, rowmajor=True, k=k, rows=rows, ldz=ld)
+    assert np.allclose(Y.cpu().numpy(), Zfull[:rows] @ B, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_orth_vs_oracle(na, method):
+    from oracle import solvers as osol
+    rng = np.random.default_rng(5)
+    rows, k = 5000, 13
+    V, _ = np.linalg.qr(rng.standard_normal((rows, k)) + 1j * rng.standard_normal((rows, k)))
+    w = rng.standard_normal(rows) + 1j * rng.standard_normal(rows)
+    ofun = [osol.dgks, osol.cgs, osol.mgs][method]
+    wo = w.copy(); ho = np.zeros(k, dtype=complex)
+    bo = ofun(V, wo, ho)
+    wd = na.to_dev(w)[0]
+    h, beta, npass = na.orthogonalize_and_normalize(na.to_dev(V), wd, k, method=method)
+    assert beta == pytest.approx(bo, rel=1e-12)
+    assert np.linalg.norm(h - ho) <= 1e-12 * np.linalg.norm(ho)
+    assert np.linalg.norm(wd.cpu().numpy() - wo) <= 1e-11
+    assert np.linalg.norm(V.conj().T @ wd.cpu().numpy()) < 1e-13
+
+
+def test_orth_dgks_forced_reorth_and_active(na):
+    from oracle import solvers as osol
+    rng = np.random.default_rng(6)
+    n, k = 700, 6
+    rows = n * (k + 1)
+    # block-triangular basis like iar's: column j non-zero in the first (j+1)*n rows
+    V = np.zeros((rows, k), dtype=complex)
+    for j in range(k):
+        V[:(j + 1) * n, j] = rng.standard_normal((j + 1) * n) + 1j * rng.standard_normal((j + 1) * n)
+    V, _ = np.linalg.qr(V)      # QR of a block upper-triangular-profile matrix keeps the profile
+    for j in range(k):
+        assert np.all(V[(j + 1) * n:, j] == 0)
+    # w almost inside span(V) -> DGKS must re-orthogonalise
+    w = V @ (rng.standard_normal(k) + 1j * rng.standard_normal(k)) + 1e-9 * (rng.standard_normal(rows) + 0j)
+    wo = w.copy(); ho = np.zeros(k, dtype=complex)
+    bo = osol.dgks(V, wo, ho)
+    wd = na.to_dev(w)[0]
+    active = (np.arange(1, k + 1) * n).astype(np.int64)
+    h, beta, npass = na.orthogonalize_and_normalize(na.to_dev(V), wd, k, active_rows=active)
+    assert npass >= 2
+    assert beta == pytest.approx(bo, rel=1e-6)
+    assert np.linalg.norm(h - ho) <= 1e-12 * np.linalg.norm(ho)
+    assert np.linalg.norm(V.conj().T @ wd.cpu().numpy()) < 1e-12
+    # determinism: bitwise equal across repeats
+    wd2 = na.to_dev(w)[0]
+    h2, beta2, _ = na.orthogonalize_and_normalize(na.to_dev(V), wd2, k, active_rows=active)
+    assert beta2 == beta and np.array_equal(h, h2) and np.array_equal(wd.cpu().numpy(), wd2.cpu().numpy())
+
+
+@pytest.mark.parametrize("nrhs", [1, 3, 32])
+def test_lu_solve_vs_host(na, nrhs):
+    from oracle import gallery as og
+    nep = og.nlevp_native_gun(1310)
+    A = sp.csc_matrix(nep.compute_Mder(250.0 ** 2 + 1j), dtype=complex)
+    rng = np.random.default_rng(2)
+    n = A.shape[0]
+    B = rng.standard_normal((n, nrhs)) + 1j * rng.standard_normal((n, nrhs))
+    lu = na.DeviceLU(A)
+    X = na.to_host(lu.solve(na.to_dev(B)))
+    Xo = spla.splu(A).solve(B)
+    assert np.linalg.norm(X - Xo) <= 1e-10 * np.linalg.norm(Xo)
+    nA = abs(A).sum(axis=0).max()
+    assert np.linalg.norm(A @ X - B) / (nA * np.linalg.norm(X)) < 1e-14      # test/linsolver.jl residual criterion
+    # scale = -1, in place
+    Bd = na.to_dev(B)
+    lu.solve(Bd, out=Bd, scale=-1.0)
+    assert np.linalg.norm(na.to_host(Bd) + Xo) <= 1e-10 * np.linalg.norm(Xo)
+
+
+def test_lin_solve_interfaces(na):
+    """Backslash == Factorize == host solve (test/linsolver.jl:11-69) on a gun twin; dense dep0 too."""
+    nep = na.nep_gallery("nlevp_native_gun", 655)
+    lam = 250.0 ** 2 + 1j
+    b = np.arange(1, 656) + 0j
+    x1 = na.lin_solve(na.create_linsolver(na.FactorizeLinSolverCreator(), nep, lam), b)
+    x2 = na.lin_solve(na.create_linsolver(na.BackslashLinSolverCreator(), nep, lam), b)
+    M = sp.csc_matrix(nep.compute_Mder(lam))
+    x3 = spla.spsolve(M, b)
+    assert np.linalg.norm(x1 - x3) <= 1e-10 * np.linalg.norm(x3)
+    assert np.linalg.norm(x2 - x3) <= 1e-10 * np.linalg.norm(x3)
+    B = np.column_stack([b, 2 * b[::-1]])
+    X = na.lin_solve(na.create_linsolver(na.FactorizeLinSolverCreator(), nep, lam), B)
+    assert X.shape == B.shape and np.linalg.norm(M @ X - B) <= 1e-9 * np.linalg.norm(B)
+    d = na.nep_gallery("dep0")
+    xs = na.lin_solve(na.create_linsolver(na.DefaultLinSolverCreator(), d, 0.3), np.ones(5))
+    assert np.allclose(d.compute_Mder(0.3) @ xs, np.ones(5))
+    # factorisation recycling: sizes 0 -> 1 -> 1 -> 2 (test/rk_helper/cached_lin_solver.jl)
+    cache = na.LinSolverCache(nep, na.FactorizeLinSolverCreator())
+    assert len(cache.solvers) == 0
+    cache.solve(lam, b, True); assert len(cache.solvers) == 1
+    cache.solve(lam, b, True); assert len(cache.solvers) == 1
+    cache.solve(lam + 1, b, False); assert len(cache.solvers) == 1
+    cache.solve(lam + 2, b, True); assert len(cache.solvers) == 2

@@ -1,0 +1,138 @@
+"""CPU tests of the product's host logic (no GPU compute): closed-form derivative tables against the
+oracle's matrix-function route, gallery equality, C-ABI symbol export, coefficient blocks."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+import nep_amd as na
+from oracle import gallery as og, neps as oneps
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    hdr = open(os.path.join(ROOT, "include", "nepmi355.h")).read()
+    names = set(re.findall(r"\b(nep_[a-z0-9_]+)\s*\(", hdr))
+    names -= {"nep_cdouble"}
+    assert len(names) >= 30
+    lib = ctypes.CDLL(na.LIB_PATH)
+    for nme in sorted(names):
+        assert hasattr(lib, nme), "missing export " + nme
+    assert set(na._lib.SIGNATURES) == names          # the ctypes binding covers the whole header
+    assert lib.nep_version() == 100
+
+
+def test_no_cpu_fallback_without_gpu():
+    if na.device_count() > 0:
+        pytest.skip("GPU present")
+    nep = na.nep_gallery("dep0")
+    with pytest.raises((na.NepError, RuntimeError)):
+        nep.compute_Mlincomb(1.0, np.ones(5))
+    with pytest.raises((na.NepError, RuntimeError)):
+        na.iar(nep, v=np.ones(5))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "nonlineareigenproblems.jl_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert "import oracle" not in src and "from oracle" not in src, f
+
+
+@pytest.mark.parametrize("lam", [0.0, 0.3 - 0.2j, 1.5])
+def test_gun_scaled_derivative_table_vs_matrix_function(lam):
+    """closed form (product) vs f(S)[:,1] of the bidiagonal matrix (oracle = reference route,
+    src/NEPTypes.jl:1108-1128) for the shifted/scaled gun functions, 42 derivatives."""
+    m = 20
+    o = oneps.DerSPMF(og.gun_spmf_scaled(655), lam, m)
+    p = na.nep_gallery("gun_spmf_scaled", 655)
+    fD = np.column_stack([f.derivs(lam, 2 * m + 2) for f in p.get_fv()])
+    assert fD.shape == o.fD.shape
+    rel = np.abs(fD - o.fD) / np.maximum(np.abs(o.fD), 1e-300)
+    rel[np.abs(o.fD) < 1e-250] = 0
+    assert rel.max() < 1e-9
+
+
+def test_derivative_table_dynamic_range():
+    p = na.nep_gallery("gun_spmf_scaled", 655)
+    d = np.column_stack([f.derivs(0.0, 101) for f in p.get_fv()])
+    assert np.all(np.isfinite(d))
+    assert 1e160 < np.abs(d).max() < 1e170          # 3.1e164 at order 100
+
+
+@pytest.mark.parametrize("name", ["Exp", "Monomial", "ISqrt", "Affine", "WEPSqrt"])
+def test_funcs_derivs_vs_numeric(name):
+    f = {"Exp": na.funcs.Exp(-0.7), "Monomial": na.funcs.Monomial(5), "ISqrt": na.funcs.ISqrt(2.0, -3.0 + 1j),
+         "Affine": na.funcs.ISqrt(1.0, 0.5).affine(3.0, 0.25 + 0.5j),
+         "WEPSqrt": na.funcs.WEPSqrt(0.3 + 0.1j, 2.0 + 0.7j, 0.4)}[name]
+    lam = 0.8 + 0.3j
+    d = f.derivs(lam, 4)
+    h = 0.05
+    # Cauchy-integral style numerical derivatives on a small circle
+    N = 64
+    th = 2 * np.pi * np.arange(N) / N
+    vals = np.array([f(lam + h * np.exp(1j * t)) for t in th])
+    import math
+    for j in range(4):
+        num = math.factorial(j) * np.mean(vals * np.exp(-1j * j * th)) / h ** j
+        assert abs(num - d[j]) <= 1e-6 * max(1.0, abs(d[j]))
+
+
+def test_gallery_matches_oracle():
+    a = na.nep_gallery("dep0"); b = og.dep0()
+    for X, Y in zip(a.A, b.A):
+        assert np.array_equal(X, Y)
+    assert a.compute_Mder(3.0)[0, 0].real == pytest.approx(-2.942777908030041, abs=1e-15)
+    ga = na.nep_gallery("nlevp_native_gun"); gb = og.nlevp_native_gun()
+    for X, Y in zip(ga.get_Av(), gb.get_Av()):
+        assert (sp.csc_matrix(X) != sp.csc_matrix(Y)).nnz == 0
+    lam = 250.0 ** 2 + 3j
+    D = sp.csc_matrix(ga.compute_Mder(lam)) - sp.csc_matrix(gb.compute_Mder(lam))
+    assert abs(D).max() <= 1e-12 * abs(sp.csc_matrix(gb.compute_Mder(lam))).max()
+    D1 = sp.csc_matrix(ga.compute_Mder(lam, 1)) - sp.csc_matrix(gb.compute_Mder(lam, 1))
+    assert abs(D1).max() <= 1e-12
+    q = na.nep_gallery("qdep0")
+    assert q.n == 1000 and [A.nnz for A in q.get_Av()] == [1000, 9945, 9963]
+
+
+def test_coeff_block_matches_reference_identity():
+    """C[j,i] = a_j f_i^(j-1)(lam) equals a_1 * f_i(S)[:,1] of the reference's bidiagonal S
+    (src/NEPTypes.jl:981-1010) wherever a has no zeros."""
+    p = na.nep_gallery("gun_spmf_scaled", 655)
+    o = og.gun_spmf_scaled(655)
+    rng = np.random.default_rng(0)
+    k = 6
+    a = rng.standard_normal(k) + 0j
+    lam = 0.2 + 0.1j
+    Cm = p.coeff_block(lam, a)
+    S = oneps._bidiag(lam, k, (a[1:k] / a[0:k - 1]) * np.arange(1, k))
+    for i, f in enumerate(o.get_fv()):
+        ref = a[0] * np.asarray(f(S))[:, 0]
+        assert np.allclose(Cm[:, i], ref, rtol=1e-10)
+    a[2] = 0
+    assert np.all(p.coeff_block(lam, a)[2] == 0)
+
+
+def test_serialization_roundtrip(tmp_path):
+    # test/serialization.jl:5-17
+    A = sp.random(30, 20, 0.2, random_state=1, format="csc")
+    fn = str(tmp_path / "m.txt")
+    na.gallery.write_sparse_matrix(fn, A)
+    B = na.gallery.read_sparse_matrix(fn)
+    assert (A != B).nnz == 0
+    assert (og.read_sparse_matrix(fn) != A).nnz == 0
+
+
+def test_spmf_constructor_errors():
+    A = sp.identity(3, format="csc")
+    with pytest.raises(ValueError):
+        na.SPMF_NEP([A, A], [na.funcs.one()])
+    with pytest.raises(ValueError):
+        na.SPMF_NEP([A, np.eye(3)], [na.funcs.one(), na.funcs.ident()])
+    with pytest.raises(ValueError):
+        na.SPMF_NEP([A, sp.identity(4, format="csc")], [na.funcs.one(), na.funcs.ident()])
