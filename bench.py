@@ -1,0 +1,212 @@
+#!/usr/bin/env python
+"""bench.py -- headline benchmark of the MI355X NEP backend (BASELINE.json metric:
+"eigenpairs/sec + compute_Mlincomb GB/s, gun SPMF iar m=100").
+
+One "step" = one complete `iar(gun_spmf_scaled, sigma=0, gamma=1, maxit=100, neigs=Inf, v=ones,
+tol=1e-10, check_error_every=1)` call on one GPU (config C2 of SURVEY.md section 8d, n = 9956), including
+the one-off host factorisation of M(sigma) and the upload of its factors.  The NEP's matrices are
+resident in HBM before the timed region.  iar is a sequential Krylov recurrence and does not shard
+("replicas only"), so with --gpus N every rank runs an independent replica of the same
+workload (weak scaling) and `value` is the whole-job rate: sum over ranks of converged eigenpairs
+divided by the max-over-ranks wall time.
+
+The JSON line also carries
+  roofline      compute_Mlincomb (k_vc + k_spmv, the kernel pair named by the metric) at k=100,
+                algorithmic bytes / HIP-event time, against the 8 TB/s HBM peak
+  kernels       per-phase GPU time of one instrumented iar run (so the time-dominant kernel is visible)
+  cpu_baseline  the CPU oracle (NumPy/SciPy restatement of the reference) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=9956)
+    ap.add_argument("--maxit", type=int, default=100)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-maxit", type=int, default=60)
+    ap.add_argument("--permc", default=None)
+    return ap.parse_args()
+
+
+def one_step(na, nep, args, timers=None, hist=None):
+    creator = na.FactorizeLinSolverCreator(permc_spec=args.permc, max_factorizations=0)
+    lam, Q, V = na.iar(nep, sigma=0.0, gamma=1.0, maxit=args.maxit, neigs=np.inf, v=np.ones(nep.n), tol=1e-10,
+                       linsolvercreator=creator, timers=timers, errhist=hist, return_device=True)
+    return lam, Q
+
+
+def mlincomb_roofline(na, nep, k, reps=50):
+    """algorithmic bytes / average HIP-event time of nep_mlincomb at k columns"""
+    n = nep.n
+    V = torch.randn((k, n), dtype=torch.float64, device="cuda").to(torch.complex128)
+    V = V + 1j * torch.randn((k, n), dtype=torch.float64, device="cuda")
+    fD = np.column_stack([f.derivs(0.0, k + 1) for f in nep.get_fv()])
+    Cm = fD[1:k + 1] / np.arange(1, k + 1)[:, None]
+    z = torch.empty(n, dtype=torch.complex128, device="cuda")
+    Cdev = na.to_dev(Cm)          # coefficient table resident on the device, as in iar (nep_mlincomb_dev)
+    for _ in range(5):
+        nep.dev.mlincomb_dev(Cdev, k, k, V, n, z)
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        nep.dev.mlincomb_dev(Cdev, k, k, V, n, z)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    byts = nep.dev.algorithmic_bytes(k)
+    return byts, ms
+
+
+def cpu_baseline(args):
+    """CPU oracle on a bounded sample of the same workload: iar with maxit=cpu_maxit (DGKS cost grows
+    ~ m^3, the full m=100 run needs ~1 min on 8 cores) + the C port of compute_Mlincomb at k=100."""
+    from oracle import gallery as og, solvers as osol, neps as oneps, cref
+    try:
+        from threadpoolctl import threadpool_info
+        nthreads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+    except Exception:
+        nthreads = os.cpu_count()
+    onep = og.gun_spmf_scaled(args.n)
+    m = args.cpu_maxit
+    t0 = time.perf_counter()
+    der = oneps.DerSPMF(onep, 0.0, m)
+    tm = {}
+    creator = osol.FactorizeLinSolverCreator(permc_spec=args.permc or "COLAMD")
+    lam, Q, _ = osol.iar(der, sigma=0.0, gamma=1.0, maxit=m, neigs=np.inf, v=np.ones(args.n), tol=1e-10,
+                         errmeasure=osol.StandardSPMFErrmeasure(onep), linsolvercreator=creator, timers=tm)
+    t_iar = time.perf_counter() - t0
+    # C port (single thread) of compute_Mlincomb, reference structure, k = 100
+    lib = cref.load()
+    terms = cref.CscTerms(onep.get_Av())
+    k = 100
+    rng = np.random.default_rng(0)
+    V = np.asfortranarray(rng.standard_normal((args.n, k)) + 1j * rng.standard_normal((args.n, k)))
+    Cm = np.asfortranarray(rng.standard_normal((k, terms.mt)) + 0j)
+    cref.mlincomb(lib, terms, Cm, V)
+    reps = 20
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cref.mlincomb(lib, terms, Cm, V)
+    t_ml = (time.perf_counter() - t0) / reps
+    nnz = sum(A.nnz for A in onep.get_Av())
+    byts = nnz * 12 + 4 * terms.mt * (args.n + 1) + 16 * args.n * k + 16 * args.n
+    return {
+        "value": len(lam) / t_iar, "unit": "eigenpairs/s", "cores": int(nthreads), "kind": "port",
+        "sample": "oracle (NumPy/SciPy restatement of the reference path, SuperLU for UMFPACK) iar on the same gun "
+                  "SPMF n=%d with maxit=%d instead of %d: %d eigenpairs in %.2f s (orth %.2f s, mlincomb %.2f s, "
+                  "solve %.2f s, residuals %.2f s)" % (args.n, m, args.maxit, len(lam), t_iar, tm.get("orth", 0),
+                                                       tm.get("mlincomb", 0), tm.get("solve", 0), tm.get("resid", 0)),
+        "mlincomb_GBps_k100": byts / t_ml / 1e9, "mlincomb_ms_k100": t_ml * 1e3,
+        "mlincomb_kind": "C port, 1 thread, per-term gemv + CSC scatter (src/NEPTypes.jl:1006-1007)",
+        "eigenpairs": int(len(lam)), "seconds": t_iar,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    import nep_amd as na
+    assert na.device_count() >= 1, "bench.py needs a GPU: the backend has no CPU fallback"
+
+    nep = na.nep_gallery("gun_spmf_scaled", args.n)
+    nep.dev  # build + upload the stacked CSR (inputs resident before the timed region)
+    torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step(na, nep, args)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    pairs = 0
+    for _ in range(args.steps):
+        lam, Q = one_step(na, nep, args)
+        pairs += len(lam)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt, float(pairs)], dtype=torch.float64, device="cuda")
+        tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        dt = float(tmax[0]); pairs = int(round(float(tsum[1])))
+
+    out = None
+    if rank == 0:
+        # independent parity check of the returned pairs (host FP64, reference residual criterion)
+        Qh = na.to_host(Q)
+        Av = nep.get_Av(); fv = nep.get_fv()
+        maxres = 0.0
+        fro = nep.fro_norms()
+        for s in range(len(lam)):
+            r = sum(f(lam[s]) * (A @ Qh[:, s]) for A, f in zip(Av, fv))
+            den = sum(c * abs(f(lam[s])) for c, f in zip(fro, fv)) * np.linalg.norm(Qh[:, s])
+            maxres = max(maxres, np.linalg.norm(r) / den)
+        # instrumented run: GPU time per phase
+        tm = {}
+        one_step(na, nep, args, timers=tm)
+        k = args.maxit
+        byts, ms = mlincomb_roofline(na, nep, k)
+        byts1, ms1 = mlincomb_roofline(na, nep, 1)
+        achieved = byts / (ms * 1e-3) / 1e9
+        out = {
+            "metric": "eigenpairs/sec (gun SPMF iar m=%d) + compute_Mlincomb GB/s" % args.maxit,
+            "value": pairs / dt, "unit": "eigenpairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
+            "config": {"workload": "nep_gallery gun SPMF (n=%d, 4 sparse terms, gun-like stand-in K,M + reference W1,W2), "
+                                   "shift_and_scale(250^2, 330^2-220^2), iar sigma=0 maxit=%d neigs=Inf tol=1e-10 "
+                                   "check_error_every=1 DGKS umfpack_refinements=10; host SuperLU factorisation "
+                                   "(UMFPACK-like symmetric strategy) inside the step" % (args.n, args.maxit),
+                       "parallelism": "replicas x%d (iar does not shard)" % world,
+                       "eigenpairs_per_step": pairs / (args.steps * world),
+                       "max_backward_error": maxres},
+            "compute_Mlincomb_GBps": achieved,
+            "roofline": {"bound": "hbm", "kernel": "nep_mlincomb = k_vc + k_spmv, k=%d columns" % k,
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": None, "algorithmic_bytes": byts, "ms_per_launch": ms,
+                         "single_vector": {"algorithmic_bytes": byts1, "ms_per_launch": ms1,
+                                           "achieved": byts1 / (ms1 * 1e-3) / 1e9}},
+            "kernels": {"note": "wall ms per phase of one instrumented iar run (torch.cuda.synchronize around each phase)",
+                        **{k_: round(v * 1e3, 3) for k_, v in tm.items()}},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -85,6 +85,12 @@ int32_t nep_csc_to_csr(int64_t n, const int64_t* colptr, const int64_t* rowval, 
 int32_t nep_mlincomb(nep_spmf* s, int32_t k, const nep_cdouble* hC, const nep_cdouble* dV,
                      int64_t ldv, nep_cdouble* dz, nep_stream stream);
 
+/* same with the coefficient block already resident on the device (column stride ldc >= k): a
+ * driver uploads the derivative table once (DerSPMF, src/NEPTypes.jl:1108-1128) and every iteration
+ * uses its first k rows -- no host-to-device copy on the critical path. */
+int32_t nep_mlincomb_dev(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t ldc, const nep_cdouble* dV,
+                         int64_t ldv, nep_cdouble* dz, nep_stream stream);
+
 /* K2  residual batch: r_s = sum_i F[i,s] A_i q_s, s=1..k; returns ||r_s||_2 and ||q_s||_2.
  * replaces: k calls of estimate_error -> compute_Mlincomb(nep,lambda_s,q_s)
  *           src/errmeasure.jl:128-130,186-190; call sites src/method_iar.jl:134-135,
@@ -135,6 +141,9 @@ int32_t nep_lu_destroy(nep_lu* lu);
 /* info[0]=n info[1]=nnz(L) info[2]=nnz(U) info[3]=levels(L) info[4]=levels(U)
  * info[5]=algorithmic bytes of one solve with one right-hand side */
 int32_t nep_lu_info(const nep_lu* lu, int64_t info[6]);
+/* schedule introspection: out[0]=dense tail size T, out[1]=kernel launches of the last solve,
+ * out[2]=levels(L), out[3]=levels(U) of the plain level schedule, out[4]=wide, out[5]=narrow segments */
+int32_t nep_lu_schedule(const nep_lu* lu, int64_t out[6]);
 /* X = A^{-1} B for nrhs right-hand sides; dB, dX: n x nrhs column-major; dX may alias dB.
  * scale is applied to the result (iar/tiar use -1: y = -lin_solve(...), src/method_iar.jl:103). */
 int32_t nep_lu_solve(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_t ldb, nep_cdouble* dX,

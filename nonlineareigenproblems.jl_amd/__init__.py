@@ -17,5 +17,9 @@ from .errmeasure import (Errmeasure, ResidualErrmeasure, StandardSPMFErrmeasure,
                          estimate_error, estimate_errors)
 from .dense import gemm_ts, orthogonalize_and_normalize, DGKS, CGS, MGS
 from .iar import iar
+from .tiar import tiar
+from .newton import resinv, quasinewton, compute_rf, armijo_rule, ScalarNewtonInnerSolver
+from .contour import (contour_beyn, integrate_interval, MatrixIntegrator, MatrixTrapezoidal,
+                      MatrixTrapezoidalSharded, probe_block)
 from . import gallery
 from .gallery import nep_gallery

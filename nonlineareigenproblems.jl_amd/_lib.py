@@ -58,6 +58,7 @@ SIGNATURES = {
     "nep_spmf_info": [c_vp, P(c_i64)],
     "nep_csc_to_csr": [c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp],
     "nep_mlincomb": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp],
+    "nep_mlincomb_dev": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "nep_resid_batch": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp],
     "nep_spmm_terms": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp],
     "nep_orth": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, P(c_dbl), c_i32, P(c_i32), c_vp],
@@ -65,6 +66,7 @@ SIGNATURES = {
     "nep_lu_create": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, P(c_vp)],
     "nep_lu_destroy": [c_vp],
     "nep_lu_info": [c_vp, P(c_i64)],
+    "nep_lu_schedule": [c_vp, P(c_i64)],
     "nep_lu_solve": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp],
     "nep_iar_shift_scale": [c_i64, c_i32, c_vp, c_vp, c_vp],
     "nep_axpy": [c_i64, cdouble, c_vp, c_vp, c_vp],

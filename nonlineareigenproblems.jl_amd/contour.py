@@ -1,0 +1,157 @@
+"""Beyn's contour-integral method on the device backend, with the quadrature nodes sharded over
+the GPUs of one node (one process per GPU, torch.distributed backend "nccl" = RCCL over xGMI).
+
+Mirrors src/method_beyncontour.jl:49-185 and the quadrature seam src/method_contour_common.jl:8-94:
+`contour_beyn(nep, MIntegrator; tol, sigma, linsolvercreator, neigs, k, radius, N, errmeasure,
+sanity_check, rank_drop_tol)` and `integrate_interval(::Type{<:MatrixIntegrator}, T, f, gv, a, b, N)`.
+
+Per quadrature node (method_beyncontour.jl:89-94): M(sigma+g(t_i)) is assembled and factorised on
+the host (new matrix per node -- BackslashLinSolverCreator is the reference default), its factors
+are uploaded, and the n x k block solve runs on the device (K5 with grid.y = k).  The two moment
+sums stay on the device (K8 = nep_axpy).  `MatrixTrapezoidalSharded` gives rank r the nodes
+i = r (mod P); the only exchange is ONE all-gather of the 2 n k partial block, followed by a
+fixed-order sum so that every rank holds bit-identical A0, A1.
+"""
+import numpy as np
+import scipy.linalg as sla
+import torch
+import torch.distributed as dist
+
+from . import dense
+from .errmeasure import DefaultErrmeasure, estimate_errors
+from .linsolvers import BackslashLinSolverCreator, create_linsolver, lin_solve
+from .nep import CDT, to_dev, to_host
+
+EPS = np.finfo(float).eps
+
+
+class MatrixIntegrator:
+    """src/method_contour_common.jl:46"""
+
+
+class MatrixTrapezoidal(MatrixIntegrator):
+    """trapezoidal rule on one GPU (src/method_contour_common.jl:55,61-94)"""
+    sharded = False
+
+
+class MatrixTrapezoidalSharded(MatrixIntegrator):
+    """trapezoidal rule with the N nodes sharded over torch.distributed ranks (RCCL all-gather)"""
+    sharded = True
+
+
+class _DeviceOps:
+    """accumulation primitives of the quadrature: the library's HIP kernels"""
+    axpy = staticmethod(dense.axpy)
+    scal = staticmethod(dense.scal)
+
+
+def integrate_interval(ST, f, gv, a, b, N, info=None, ops=_DeviceOps):
+    """returns S with S[j] ~ int f(t) g_j(t) dt  as a device tensor (m, k, n) (m = len(gv)).
+    f(t) returns (X, c): the integrand value is c*X with X a device (k, n) block.
+    `ops` exists so that the sharding / all-gather / fixed-order-sum logic can be exercised by the
+    world_size-2 gloo test on CPU tensors; the drivers always use the HIP kernels."""
+    h = (b - a) / N
+    t = a + h * np.arange(N)
+    m = len(gv)
+    G = np.array([[g(tt) for g in gv] for tt in t], dtype=np.complex128)    # N x m
+    world, rank = 1, 0
+    if getattr(ST, "sharded", False) and dist.is_available() and dist.is_initialized():
+        world, rank = dist.get_world_size(), dist.get_rank()
+    S = None
+    mine = range(rank, N, world)
+    for i in mine:
+        X, c = f(t[i])
+        if S is None:
+            S = torch.zeros((m,) + tuple(X.shape), dtype=CDT, device=X.device)
+        for j in range(m):
+            ops.axpy(c * G[i, j], X, S[j])
+    if S is None:
+        raise ValueError("rank %d owns no quadrature node (N=%d < world size %d)" % (rank, N, world))
+    if world > 1:
+        parts = [torch.empty_like(S) for _ in range(world)]
+        dist.all_gather(parts, S)                  # RCCL over xGMI: 2*n*k complex128 per rank
+        S = torch.zeros_like(S)
+        for p in parts:                            # fixed rank order -> identical on every rank
+            ops.axpy(1.0, p, S)
+    ops.scal(S, h)
+    if info is not None:
+        info.update(world=world, rank=rank, nodes=len(mine))
+    return S
+
+
+def probe_block(n, k, seed=10):
+    """deterministic standard-normal probe (the reference's `Random.seed!(10); randn(n,k)`,
+    method_beyncontour.jl:85-86, is Julia-RNG specific; counter-based Philox here)"""
+    rng = np.random.Generator(np.random.Philox(seed))
+    return rng.standard_normal((n, k)).astype(np.complex128)
+
+
+def contour_beyn(nep, MIntegrator=MatrixTrapezoidal, tol=np.sqrt(EPS), sigma=0.0, logger=0,
+                 linsolvercreator=None, neigs=2, k=None, radius=1, N=1000, errmeasure=None,
+                 sanity_check=True, rank_drop_tol=None, Vh=None, info=None):
+    if k is None:
+        if neigs >= np.iinfo(np.int64).max:
+            raise ValueError("k must be positive. The kwarg k must be set if you use neigs=typemax")
+        k = neigs + 1
+    if rank_drop_tol is None:
+        rank_drop_tol = tol
+    if np.isscalar(radius):
+        radius = (radius, radius)
+    if linsolvercreator is None:
+        linsolvercreator = BackslashLinSolverCreator()
+    if errmeasure is None:
+        errmeasure = DefaultErrmeasure(nep)
+    sigma = complex(sigma)
+    g = lambda t: complex(radius[0] * np.cos(t), radius[1] * np.sin(t))
+    gp = lambda t: complex(-radius[0] * np.sin(t), radius[1] * np.cos(t))
+    n = nep.size(1)
+    if k > n:
+        raise ValueError("Cannot compute more eigenvalues than the size of the NEP with contour_beyn() k=%d n=%d" % (k, n))
+    if k <= 0:
+        raise ValueError("k must be positive, k=%d." % k)
+    if Vh is None:
+        Vh = probe_block(n, k)
+    Vd = to_dev(Vh)
+
+    def f(t):
+        # method_beyncontour.jl:89-98: Tv(lam) = lin_solve(create_linsolver(creator, nep, lam+sigma), Vh)
+        M0inv = create_linsolver(linsolvercreator, nep, g(t) + sigma)
+        return lin_solve(M0inv, Vd), gp(t)
+
+    S = integrate_interval(MIntegrator, f, [lambda s: 1.0 + 0j, g], 0.0, 2 * np.pi, N, info=info)
+    A0 = to_host(S[0]) / (2j * np.pi)
+    A1 = to_host(S[1]) / (2j * np.pi)
+    V, Sv, Wh = sla.svd(A0, full_matrices=False)
+    W = Wh.conj().T
+    p = int(np.sum(Sv / Sv[0] > rank_drop_tol))
+    V0 = V[:, :p]; W0 = W[:, :p]
+    B = (V0.conj().T @ A1 @ W0) @ np.diag(1.0 / Sv[:p])
+    lam, VB = sla.eig(B)
+    lam = lam + sigma
+    # eigenvectors V0*VB on the device (K7), normalised
+    V0d = to_dev(V0)
+    QT = dense.gemm_ts(V0d, VB, rowmajor=True)                 # (n, p) row-major
+    if info is not None:
+        info.update(p=p, S=Sv)
+
+    def inside(l):
+        return ((l - sigma).real / radius[0]) ** 2 + ((l - sigma).imag / radius[1]) ** 2 <= 1
+
+    def cols(sel):
+        Q = to_host(dense.rowmajor_to_cols(QT, np.asarray(sel, dtype=np.int32)))
+        return Q / np.linalg.norm(Q, axis=0)[None, :] if Q.shape[1] else Q
+
+    if not sanity_check:
+        si = np.argsort(abs(sigma - lam), kind="stable")
+        perm = np.argsort(~inside(lam[si]), kind="stable")
+        return lam[si[perm]], cols(si[perm])
+    errs = estimate_errors(errmeasure, lam, QT)
+    good = np.nonzero(errs < tol)[0]
+    sgi = good[np.argsort(abs(sigma - lam[good]), kind="stable")]
+    perm = np.argsort(~inside(lam[sgi]), kind="stable")
+    sel = sgi[perm]
+    if len(sel) > neigs:
+        sel = sel[:neigs]
+    if info is not None:
+        info.update(errs=errs)
+    return lam[sel], cols(sel)

@@ -88,6 +88,22 @@ static inline hipStream_t as_stream(nep_stream s) { return (hipStream_t)s; }
 #define NEP_COL_MASK ((1u << NEP_TERM_SHIFT) - 1u)
 #define NEP_MAX_TERMS 32
 
+// Pinned host staging ring for small host->device parameter blocks (coefficient matrices, MFMA
+// B fragments).  hipMemcpyAsync from PAGEABLE memory may read the source after the call returns,
+// so caller-owned temporaries must never be handed to it directly: the block is first copied into
+// a pinned slot, the async copy is issued from there, and an event guards the slot's reuse.
+struct PinnedRing {
+    static const int NSLOT = 8;
+    void* slot[NSLOT] = {nullptr};
+    size_t cap[NSLOT] = {0};
+    hipEvent_t ev[NSLOT] = {nullptr};
+    bool used[NSLOT] = {false};
+    int next = 0;
+    // copies `bytes` from hsrc to ddst on `st`; hsrc may be freed by the caller right after return
+    int upload(void* ddst, const void* hsrc, size_t bytes, hipStream_t st);
+    void release();
+};
+
 // small per-library scratch (device) helpers, defined in util.hip
 struct NepScratch {
     void* dptr = nullptr;

@@ -106,6 +106,7 @@ __global__ __launch_bounds__(512) void k_gemm_ts(const cplx* __restrict__ Z, int
 }
 
 static NepScratch g_gemm_scratch;
+static PinnedRing g_gemm_ring;
 
 template <int NT>
 static int gemm_launch(bool rowmajor, const cplx* Z, int64_t ldz, int64_t rows, int k, const double* dB, int nks,
@@ -162,8 +163,8 @@ extern "C" int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows,
                 }
         off += (size_t)nks * nt * 128;
     }
-    HIPCHK(hipMemcpyAsync(g_gemm_scratch.dptr, frag.data(), total * sizeof(double), hipMemcpyHostToDevice, st));
-    // the staging vector is pageable: the runtime has copied it before returning
+    rc = g_gemm_ring.upload(g_gemm_scratch.dptr, frag.data(), total * sizeof(double), st);
+    if (rc) return rc;
     int pi = 0;
     for (int j0 = 0; j0 < p; j0 += 104, ++pi) {
         const int pp = std::min(104, p - j0);

@@ -22,40 +22,43 @@ struct nep_spmf {
     cplx* d_WT = nullptr;     // n x mt row-major workspace
     NepScratch coef;          // staged coefficient matrices
     NepScratch part;          // per-block partials
+    PinnedRing ring;          // pinned staging of host coefficient blocks
 };
 
 // ------------------------------------------------------------------------------------------
-// (a) WT[r, i0+i] = sum_j V[r + j*ldv] * C[j + (i0+i)*k],  i < MT.
-// block = 512 threads = 8 waves; 64 rows per block; wave w takes columns j = w, w+8, ...
+// (a) WT[r, i0+i] = sum_j V[r + j*ldv] * C[j + (i0+i)*ldc],  i < MT.
+// block = 512 threads = 8 waves covering 32 rows: each half-wave owns the same 32 rows and one of 16
+// column groups (columns j = g, g+16, ...), i.e. a wave reads two 512-byte row segments per step.
+// 32 rows per block keeps >= 2 blocks per CU even for n = 9956 (312 blocks on 256 CUs).
 template <int MT>
 __global__ __launch_bounds__(512) void k_vc(const cplx* __restrict__ V, int64_t ldv, int64_t n, int k,
-                                            const cplx* __restrict__ C, int i0, int mt_total,
+                                            const cplx* __restrict__ C, int64_t ldc, int i0, int mt_total,
                                             cplx* __restrict__ WT) {
-    __shared__ cplx sm[8][MT][64];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t row = blockIdx.x * 64LL + lane;
+    __shared__ cplx sm[16][MT][32];
+    const int r32 = threadIdx.x & 31;
+    const int g = threadIdx.x >> 5;          // column group 0..15
+    const int64_t row = blockIdx.x * 32LL + r32;
     const int64_t rowc = row < n ? row : n - 1;
     cplx acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = cmake(0.0, 0.0);
     const cplx* vp = V + rowc;
 #pragma unroll 4
-    for (int j = w; j < k; j += 8) {
+    for (int j = g; j < k; j += 16) {
         const cplx v = vp[(int64_t)j * ldv];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) cfma(acc[i], v, C[j + (int64_t)(i0 + i) * k]);
+        for (int i = 0; i < MT; ++i) cfma(acc[i], v, C[j + (int64_t)(i0 + i) * ldc]);
     }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) sm[w][i][lane] = acc[i];
+    for (int i = 0; i < MT; ++i) sm[g][i][r32] = acc[i];
     __syncthreads();
-    // 64*MT outputs, written contiguously: t -> (row = t / MT, i = t % MT)
-    for (int t = threadIdx.x; t < 64 * MT; t += 512) {
+    // 32*MT outputs, written contiguously: t -> (row = t / MT, i = t % MT)
+    for (int t = threadIdx.x; t < 32 * MT; t += 512) {
         const int rr = t / MT, i = t % MT;
         cplx s = sm[0][i][rr];
 #pragma unroll
-        for (int q = 1; q < 8; ++q) s = cadd(s, sm[q][i][rr]);
-        const int64_t r = blockIdx.x * 64LL + rr;
+        for (int q = 1; q < 16; ++q) s = cadd(s, sm[q][i][rr]);
+        const int64_t r = blockIdx.x * 32LL + rr;
         if (r < n) WT[r * mt_total + i0 + i] = s;
     }
 }
@@ -182,12 +185,17 @@ __global__ __launch_bounds__(256) void k_spmm_rm(const int32_t* __restrict__ row
     }
 }
 
-__global__ void k_sum_partials_d(int nb, int len, const double* __restrict__ partial, double* __restrict__ out) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= len) return;
+// out[j] = sum_b partial[b*len + j]: one block per output, fixed summation tree -> deterministic
+__global__ __launch_bounds__(256) void k_sum_partials_d(int nb, int len, const double* __restrict__ partial,
+                                                        double* __restrict__ out) {
+    __shared__ double sm[4];
+    const int j = blockIdx.x;
     double t = 0.0;
-    for (int b = 0; b < nb; ++b) t += partial[(int64_t)b * len + j];
-    out[j] = t;
+    for (int b = threadIdx.x; b < nb; b += 256) t += partial[(int64_t)b * len + j];
+    t = wave_reduce_sum(t);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) out[j] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -211,18 +219,18 @@ static int launch_spmv(const nep_spmf* s, const cplx* WT, cplx* z, hipStream_t s
     return NEP_OK;
 }
 
-static int launch_vc(const nep_spmf* s, int k, const cplx* dC, const cplx* V, int64_t ldv, hipStream_t st) {
+static int launch_vc(const nep_spmf* s, int k, const cplx* dC, int64_t ldc, const cplx* V, int64_t ldv, hipStream_t st) {
     const int64_t n = s->n;
-    const dim3 grid((unsigned)((n + 63) / 64)), block(512);
+    const dim3 grid((unsigned)((n + 31) / 32)), block(512);
     int i0 = 0;
     while (i0 < s->mt) {
         const int rem = s->mt - i0;
         const int cnt = rem >= 4 ? 4 : rem;
         switch (cnt) {
-            case 4: hipLaunchKernelGGL((k_vc<4>), grid, block, 0, st, V, ldv, n, k, dC, i0, s->mt, s->d_WT); break;
-            case 3: hipLaunchKernelGGL((k_vc<3>), grid, block, 0, st, V, ldv, n, k, dC, i0, s->mt, s->d_WT); break;
-            case 2: hipLaunchKernelGGL((k_vc<2>), grid, block, 0, st, V, ldv, n, k, dC, i0, s->mt, s->d_WT); break;
-            default: hipLaunchKernelGGL((k_vc<1>), grid, block, 0, st, V, ldv, n, k, dC, i0, s->mt, s->d_WT); break;
+            case 4: hipLaunchKernelGGL((k_vc<4>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
+            case 3: hipLaunchKernelGGL((k_vc<3>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
+            case 2: hipLaunchKernelGGL((k_vc<2>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
+            default: hipLaunchKernelGGL((k_vc<1>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
         }
         LAUNCHCHK();
         i0 += cnt;
@@ -330,6 +338,7 @@ int32_t nep_spmf_destroy(nep_spmf* s) {
     if (s->d_WT) (void)hipFree(s->d_WT);
     s->coef.release();
     s->part.release();
+    s->ring.release();
     delete s;
     return NEP_OK;
 }
@@ -349,8 +358,22 @@ int32_t nep_mlincomb(nep_spmf* s, int32_t k, const nep_cdouble* hC, const nep_cd
     const size_t cbytes = (size_t)k * s->mt * sizeof(cplx);
     int rc = s->coef.ensure(cbytes);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(s->coef.dptr, hC, cbytes, hipMemcpyHostToDevice, st));
-    rc = launch_vc(s, k, (const cplx*)s->coef.dptr, (const cplx*)dV, ldv, st);
+    // each call gets its own region of the device staging buffer? no: stream order protects dptr;
+    // the pinned ring protects the host side
+    rc = s->ring.upload(s->coef.dptr, hC, cbytes, st);
+    if (rc) return rc;
+    rc = launch_vc(s, k, (const cplx*)s->coef.dptr, k, (const cplx*)dV, ldv, st);
+    if (rc) return rc;
+    if (s->valbytes == 8) return launch_spmv<double>(s, s->d_WT, (cplx*)dz, st);
+    return launch_spmv<cplx>(s, s->d_WT, (cplx*)dz, st);
+}
+
+int32_t nep_mlincomb_dev(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t ldc, const nep_cdouble* dV,
+                         int64_t ldv, nep_cdouble* dz, nep_stream stream) {
+    ARGCHK(s && dC && dV && dz);
+    ARGCHK(k >= 1 && ldv >= s->n && ldc >= k);
+    hipStream_t st = as_stream(stream);
+    int rc = launch_vc(s, k, (const cplx*)dC, ldc, (const cplx*)dV, ldv, st);
     if (rc) return rc;
     if (s->valbytes == 8) return launch_spmv<double>(s, s->d_WT, (cplx*)dz, st);
     return launch_spmv<cplx>(s, s->d_WT, (cplx*)dz, st);
@@ -364,7 +387,8 @@ int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
     const size_t cbytes = (size_t)k * s->mt * sizeof(cplx);
     int rc = s->coef.ensure(cbytes);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(s->coef.dptr, hF, cbytes, hipMemcpyHostToDevice, st));
+    rc = s->ring.upload(s->coef.dptr, hF, cbytes, st);
+    if (rc) return rc;
     int grid = (int)std::min<int64_t>((s->n + 3) / 4, 2048);
     rc = s->part.ensure(((size_t)grid * 2 * k + 2 * k) * sizeof(double));
     if (rc) return rc;
@@ -375,7 +399,7 @@ int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
     else
         rc = launch_spmm<cplx>(s, k, (const cplx*)s->coef.dptr, (const cplx*)dQT, ldq, 0, nullptr, 0, partial, grid, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_sum_partials_d, dim3((2 * k + 63) / 64), dim3(64), 0, st, grid, 2 * k, partial, outd);
+    hipLaunchKernelGGL(k_sum_partials_d, dim3(2 * k), dim3(256), 0, st, grid, 2 * k, partial, outd);
     LAUNCHCHK();
     std::vector<double> h(2 * k);
     HIPCHK(hipMemcpyAsync(h.data(), outd, (size_t)2 * k * sizeof(double), hipMemcpyDeviceToHost, st));

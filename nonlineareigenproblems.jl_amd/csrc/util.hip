@@ -24,6 +24,32 @@ void NepScratch::release() {
     dptr = nullptr; cap = 0;
 }
 
+int PinnedRing::upload(void* ddst, const void* hsrc, size_t bytes, hipStream_t st) {
+    const int i = next;
+    next = (next + 1) % NSLOT;
+    if (!ev[i]) HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    if (used[i]) HIPCHK(hipEventSynchronize(ev[i]));     // slot's previous copy has been consumed
+    if (cap[i] < bytes) {
+        if (slot[i]) HIPCHK(hipHostFree(slot[i]));
+        slot[i] = nullptr; cap[i] = 0;
+        const size_t want = bytes + bytes / 2 + 256;
+        HIPCHK(hipHostMalloc(&slot[i], want, hipHostMallocDefault));
+        cap[i] = want;
+    }
+    memcpy(slot[i], hsrc, bytes);
+    HIPCHK(hipMemcpyAsync(ddst, slot[i], bytes, hipMemcpyHostToDevice, st));
+    HIPCHK(hipEventRecord(ev[i], st));
+    used[i] = true;
+    return NEP_OK;
+}
+void PinnedRing::release() {
+    for (int i = 0; i < NSLOT; ++i) {
+        if (slot[i]) (void)hipHostFree(slot[i]);
+        if (ev[i]) (void)hipEventDestroy(ev[i]);
+        slot[i] = nullptr; ev[i] = nullptr; cap[i] = 0; used[i] = false;
+    }
+}
+
 extern "C" {
 
 int32_t nep_version(void) { return 100; }

@@ -85,6 +85,10 @@ def axpy(alpha, x, y, length=None):
                        c_vp(y.data_ptr()), stream_ptr()))
 
 
+def copy(src, dst, length=None):
+    check(lib.nep_dev_copy(c_vp(dst.data_ptr()), c_vp(src.data_ptr()), 16 * (length if length is not None else src.numel()), stream_ptr()))
+
+
 def rowmajor_to_cols(QT, cols=None):
     """(rows, k) row-major device block -> (ncols, rows) column-major tensor of the chosen columns"""
     rows, k = QT.shape

@@ -17,10 +17,10 @@ class Errmeasure:
 
 def _fmat(nep, lams):
     fv = nep.get_fv()
-    F = np.empty((len(fv), len(lams)), dtype=np.complex128, order="F")
-    for s, lam in enumerate(lams):
-        for i, f in enumerate(fv):
-            F[i, s] = f(lam)
+    la = np.asarray(lams, dtype=np.complex128)
+    F = np.empty((len(fv), len(la)), dtype=np.complex128, order="F")
+    for i, f in enumerate(fv):
+        F[i, :] = f.values(la)
     return F
 
 

@@ -31,6 +31,10 @@ class ScalarFun:
         """f(S) for a square matrix S (host, small)."""
         raise NotImplementedError
 
+    def values(self, lams):
+        """vectorised f(lam) over an array of points"""
+        return np.array([self(l) for l in np.asarray(lams, dtype=np.complex128)], dtype=np.complex128)
+
     def affine(self, scale, shift):
         """g(lam) = f(scale*lam + shift)  (shift_and_scale, src/NEPTransformations.jl:92-105)"""
         return Affine(self, scale, shift)
@@ -60,6 +64,9 @@ class Monomial(ScalarFun):
     def matfun(self, S):
         return np.linalg.matrix_power(np.asarray(S, dtype=complex), self.p)
 
+    def values(self, lams):
+        return np.asarray(lams, dtype=np.complex128) ** self.p
+
 
 class Exp(ScalarFun):
     """exp(c*lam)   (DEP: c = -tau, src/NEPTypes.jl:505-509)"""
@@ -72,6 +79,9 @@ class Exp(ScalarFun):
 
     def matfun(self, S):
         return sla.expm(self.c * np.asarray(S, dtype=complex))
+
+    def values(self, lams):
+        return np.exp(self.c * np.asarray(lams, dtype=np.complex128))
 
 
 class ISqrt(ScalarFun):
@@ -96,6 +106,9 @@ class ISqrt(ScalarFun):
         S = np.asarray(S, dtype=complex)
         return 1j * sla.sqrtm(self.alpha * S + self.beta * np.eye(S.shape[0]))
 
+    def values(self, lams):
+        return 1j * np.sqrt(self.alpha * np.asarray(lams, dtype=np.complex128) + self.beta)
+
 
 class Scaled(ScalarFun):
     def __init__(self, c, f):
@@ -106,6 +119,9 @@ class Scaled(ScalarFun):
 
     def matfun(self, S):
         return self.c * self.f.matfun(S)
+
+    def values(self, lams):
+        return self.c * self.f.values(lams)
 
 
 class Affine(ScalarFun):
@@ -122,6 +138,9 @@ class Affine(ScalarFun):
         S = np.asarray(S, dtype=complex)
         return self.f.matfun(self.scale * S + self.shift * np.eye(S.shape[0]))
 
+    def values(self, lams):
+        return self.f.values(self.scale * np.asarray(lams, dtype=np.complex128) + self.shift)
+
 
 class Sum(ScalarFun):
     def __init__(self, *fs):
@@ -132,6 +151,9 @@ class Sum(ScalarFun):
 
     def matfun(self, S):
         return sum(f.matfun(S) for f in self.fs)
+
+    def values(self, lams):
+        return sum(f.values(lams) for f in self.fs)
 
 
 class WEPSqrt(ScalarFun):

@@ -54,27 +54,43 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     V = torch.zeros((m + 1, ldv), dtype=CDT, device="cuda")
     H = np.zeros((m + 1, m), dtype=np.complex128)
     alpha = gamma ** np.arange(m + 1); alpha[0] = 0
+    t_ls = time.perf_counter()
     M0inv = create_linsolver(linsolvercreator, nep, sigma)
+    sync(); tm["linsolver_setup"] = tm.get("linsolver_setup", 0.0) + time.perf_counter() - t_ls
+    if timers is not None and hasattr(M0inv, "lu"):
+        tm["host_factorization"] = tm.get("host_factorization", 0.0) + M0inv.lu.t_factor
     v0 = np.asarray(v, dtype=np.complex128)
     V[0, :n] = torch.from_numpy(v0 / np.linalg.norm(v0)).to("cuda")
     # derivative table at sigma: fD[j,i] = f_i^(j)(sigma)  (DerSPMF, NEPTypes.jl:1108-1128)
     fv = nep.get_fv()
     fD = np.column_stack([f.derivs(sigma, m + 1) for f in fv])
+    # coefficient rows C[j-1,:] = alpha_j/j * fD[j,:] do not depend on k: upload once, use the first k rows
+    Cfull = (alpha[1:m + 1] / np.arange(1, m + 1))[:, None] * fD[1:m + 1, :]
+    Cdev = to_dev(Cfull)                                   # (mt, m): column-major m x mt, ldc = m
     z = torch.empty(n, dtype=CDT, device="cuda")
     active = (np.arange(1, m + 2) * n).astype(np.int64)   # column j has (j+1) non-zero blocks
     err = np.full((m, m), np.nan)
     lam = np.zeros(0, dtype=np.complex128); QT = None; idx = np.zeros(0, dtype=int)
-    k = 1; conv_eig = 0
-    while k <= m and conv_eig < neigs:
+    # ---- main loop.  The small dense eigenproblem of step k (host LAPACK, method_iar.jl:112; 7.5 ms at
+    # k=100, ~190 ms summed over a run) is solved on worker threads WHILE the device runs the following
+    # Arnoldi steps (mlincomb, solve, DGKS); the Ritz extraction + residuals of step k are enqueued as soon
+    # as its decomposition is available, at most LAG steps late and always in order.  The arithmetic and
+    # the returned quantities are those of the sequential loop; when the convergence test of step k ends
+    # the iteration, the (at most LAG+1) speculative Arnoldi steps beyond k are simply dropped.
+    from collections import deque
+    from concurrent.futures import ThreadPoolExecutor
+    LAG = 3                        # host eig of up to LAG+1 consecutive steps in flight
+    pool = ThreadPoolExecutor(max_workers=LAG + 1)
+    state = {"lam": lam, "QT": QT, "idx": idx, "conv_eig": 0, "k_checked": 0}
+
+    def arnoldi_step(k):
         t0 = time.perf_counter()
         # z = sum_{j=1..k} alpha_{j+1}/j * M^(j)(sigma) * V_k block j
-        jj = np.arange(1, k + 1)
-        Cm = (alpha[1:k + 1] / jj)[:, None] * fD[1:k + 1, :]
-        nep.dev.mlincomb(Cm, V.data_ptr() + 16 * (k - 1) * ldv, z, k=k, ldv=n)
+        nep.dev.mlincomb_dev(Cdev, m, k, V.data_ptr() + 16 * (k - 1) * ldv, n, z)
         sync(); t1 = time.perf_counter()
         # new vector, block 0: -M(sigma)^{-1} z ; blocks 1..k: shifted/scaled old column
         vv = V[k]
-        M0inv.lu.solve(z, out=vv[:n].reshape(1, n), scale=-1.0)
+        M0inv.solve_dev(z, out=vv[:n].reshape(1, n), scale=-1.0)
         sync(); t2 = time.perf_counter()
         check(lib.nep_iar_shift_scale(n, k, c_vp(V.data_ptr() + 16 * (k - 1) * ldv),
                                       c_vp(vv.data_ptr()), stream_ptr()))
@@ -83,27 +99,53 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
         H[:k, k - 1] = h; H[k, k - 1] = beta
         sync(); t3 = time.perf_counter()
         tm["mlincomb"] += t1 - t0; tm["solve"] += t2 - t1; tm["orth"] += t3 - t2
-        if (k % check_error_every == 0) or (k == m):
-            D, Z = sla.eig(H[:k, :k])
-            t4 = time.perf_counter()
-            QT = dense.gemm_ts(V, Z, rowmajor=True, k=k, rows=n, ldz=ldv)       # (n, k) row-major
-            lam = sigma + gamma / D
-            sync(); t5 = time.perf_counter()
-            e = estimate_errors(errmeasure, lam, QT)
-            t6 = time.perf_counter()
-            tm["host_eig"] += t4 - t3; tm["ritz"] += t5 - t4; tm["resid"] += t6 - t5
-            err[k - 1, :k] = e
-            conv_eig = int(np.sum(e < tol))
-            idx = np.argsort(e, kind="stable")
-            err[k - 1, :k] = e[idx]
-            if errhist is not None:
-                errhist.append(err[k - 1, :k].copy())
-            if k == m or conv_eig >= neigs:
-                nrof = int(min(len(lam), neigs))
-                lam = lam[idx[:nrof]]
-                idx = idx[:nrof]
-        k += 1
-    k -= 1
+
+    def timed_eig(Hk):
+        t = time.perf_counter()
+        r = np.linalg.eig(Hk)      # numpy's LAPACK call releases the GIL (scipy's f2py wrapper does not)
+        return r, time.perf_counter() - t
+
+    def finish_check(kc, fut):
+        (D, Z), t_eig = fut.result()
+        tm["host_eig"] += t_eig
+        t4 = time.perf_counter()
+        QTl = dense.gemm_ts(V, Z, rowmajor=True, k=kc, rows=n, ldz=ldv)       # (n, kc) row-major
+        laml = sigma + gamma / D
+        sync(); t5 = time.perf_counter()
+        e = estimate_errors(errmeasure, laml, QTl)
+        t6 = time.perf_counter()
+        tm["ritz"] += t5 - t4; tm["resid"] += t6 - t5
+        err[kc - 1, :kc] = e
+        conv = int(np.sum(e < tol))
+        idxl = np.argsort(e, kind="stable")
+        err[kc - 1, :kc] = e[idxl]
+        if errhist is not None:
+            errhist.append(err[kc - 1, :kc].copy())
+        if kc == m or conv >= neigs:
+            nrof = int(min(len(laml), neigs))
+            laml = laml[idxl[:nrof]]
+            idxl = idxl[:nrof]
+        state.update(lam=laml, QT=QTl, idx=idxl, conv_eig=conv, k_checked=kc)
+
+    k = 1
+    pending = deque()              # (k, future) in increasing k; checks are always consumed in order
+    try:
+        while k <= m and state["conv_eig"] < neigs:
+            arnoldi_step(k)
+            if (k % check_error_every == 0) or (k == m):
+                pending.append((k, pool.submit(timed_eig, H[:k, :k].copy())))
+            # consume finished eigen-decompositions; never let the check lag more than LAG steps
+            while pending and state["conv_eig"] < neigs and (len(pending) > LAG or pending[0][1].done()):
+                finish_check(*pending.popleft())
+            k += 1
+        while pending and state["conv_eig"] < neigs:
+            finish_check(*pending.popleft())
+    finally:
+        for _, f in pending:
+            f.cancel()
+        pool.shutdown(wait=True)
+    lam, QT, idx, conv_eig = state["lam"], state["QT"], state["idx"], state["conv_eig"]
+    k = state["k_checked"] if state["k_checked"] > 0 else k - 1
     if conv_eig < neigs and neigs != np.inf:
         Q = to_host(dense.rowmajor_to_cols(QT, idx[:len(lam)])) if QT is not None else None
         msg = "Number of iterations exceeded. maxit=%d." % maxit

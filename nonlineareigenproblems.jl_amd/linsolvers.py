@@ -27,19 +27,41 @@ class LinSolver:
     pass
 
 
-class DeviceLU:
-    """nep_lu handle built from a host sparse LU of A (CSC/CSR/dense)."""
+def _pattern_symmetric(Ac):
+    P = sp.csc_matrix((np.ones(Ac.nnz, dtype=np.int8), Ac.indices, Ac.indptr), shape=Ac.shape)
+    return (P != P.T).nnz == 0 and np.all(Ac.diagonal() != 0)
 
-    def __init__(self, A, permc_spec="COLAMD", diag_pivot_thresh=None):
+
+class DeviceLU:
+    """nep_lu handle built from a host sparse LU of A (CSC/CSR/dense).
+
+    Pivoting strategy mirrors what UMFPACK (the reference's `factorize`, LinSolvers.jl:116) selects
+    automatically: for a structurally symmetric matrix with a zero-free diagonal the *symmetric strategy*
+    (fill-reducing ordering of A+A', diagonal pivots preferred with tolerance 0.001) -> SuperLU with
+    permc_spec=MMD_AT_PLUS_A, SymmetricMode, diag_pivot_thresh=0.001; otherwise the unsymmetric strategy
+    (column ordering, threshold partial pivoting) -> COLAMD with SuperLU's default threshold.  Explicit
+    arguments override the choice."""
+
+    def __init__(self, A, permc_spec=None, diag_pivot_thresh=None, symmetric_mode=None):
         _lib.require_gpu()
         t0 = time.perf_counter()
         n = A.shape[0]
         self.n = n
         Ac = sp.csc_matrix(A, dtype=np.complex128)
-        opts = {}
+        if permc_spec is None or symmetric_mode is None:
+            sym = _pattern_symmetric(Ac)
+            if permc_spec is None:
+                permc_spec = "MMD_AT_PLUS_A" if sym else "COLAMD"
+            if symmetric_mode is None:
+                symmetric_mode = sym and permc_spec == "MMD_AT_PLUS_A"
+        if diag_pivot_thresh is None and symmetric_mode:
+            diag_pivot_thresh = 0.001
+        self.strategy = dict(permc_spec=permc_spec, diag_pivot_thresh=diag_pivot_thresh, symmetric_mode=symmetric_mode)
         kw = dict(permc_spec=permc_spec)
         if diag_pivot_thresh is not None:
             kw["diag_pivot_thresh"] = diag_pivot_thresh
+        if symmetric_mode:
+            kw["options"] = dict(SymmetricMode=True)
         try:
             lu = spla.splu(Ac, **kw)
         except RuntimeError as e:  # "Factor is exactly singular"
@@ -60,7 +82,16 @@ class DeviceLU:
         check(lib.nep_lu_info(self.h, info))
         self.nnzL, self.nnzU, self.levL, self.levU, self.solve_bytes = (int(info[1]), int(info[2]), int(info[3]),
                                                                         int(info[4]), int(info[5]))
+        sch = (c_i64 * 6)()
+        check(lib.nep_lu_schedule(self.h, sch))
+        self.tail, self.levL_full, self.levU_full = int(sch[0]), int(sch[2]), int(sch[3])
+        self.wide_segments, self.narrow_segments = int(sch[4]), int(sch[5])
         self.t_setup = time.perf_counter() - t0
+
+    def launches_last_solve(self):
+        sch = (c_i64 * 6)()
+        check(lib.nep_lu_schedule(self.h, sch))
+        return int(sch[1])
 
     def __del__(self):
         try:
@@ -80,21 +111,82 @@ class DeviceLU:
         return X.reshape(B.shape)
 
 
-class FactorizeLinSolver(LinSolver):
-    """src/LinSolvers.jl:109-137: factor M(lam) once, solve many right-hand sides."""
+EPS = np.finfo(float).eps
 
-    def __init__(self, nep, lam, umfpack_refinements=0, permc_spec="COLAMD", _lu=None):
+
+class FactorizeLinSolver(LinSolver):
+    """src/LinSolvers.jl:109-137: factor M(lam) once, solve many right-hand sides.  Like UMFPACK's
+    solve (control[8] = umfpack_refinements, LinSolvers.jl:118-120) each single-vector solve is followed by
+    iterative refinement: r = b - M(lam) x is evaluated with the SPMF kernel K1 and the loop stops as soon
+    as the normwise backward error is at round-off level or stops halving."""
+
+    def __init__(self, nep, lam, umfpack_refinements=10, permc_spec=None, _lu=None, **lu_kw):
+        self.nep = nep
         self.lam = lam
         self.umfpack_refinements = umfpack_refinements
-        self.lu = _lu if _lu is not None else DeviceLU(nep.compute_Mder(lam), permc_spec=permc_spec)
+        self.lu = _lu if _lu is not None else DeviceLU(nep.compute_Mder(lam), permc_spec=permc_spec, **lu_kw)
+        self.refine_steps_taken = 0
+        self.solves = 0
+        self._C = None
+        self._normM = None
+        self._W = None
+
+    def _refine_setup(self):
+        if self._C is None:
+            fv = self.nep.get_fv()
+            self._C = np.array([[f(self.lam) for f in fv]], dtype=np.complex128)       # 1 x mt
+            self._normM = float(np.dot(self.nep.fro_norms(), np.abs(self._C[0])))       # >= ||M(lam)||_F
+            n = self.lu.n
+            self._W = torch.empty((4, n), dtype=CDT, device="cuda")                      # r, x, b, dx
+
+    def solve_dev(self, b, out=None, scale=1.0):
+        """device solve; b: (n,) or (nrhs, n) tensor"""
+        self.solves += 1
+        single = b.dim() == 1 or b.shape[0] == 1
+        if not single or self.umfpack_refinements <= 0 or not hasattr(self.nep, "dev"):
+            return self.lu.solve(b, out=out, scale=scale)
+        self._refine_setup()
+        n = self.lu.n
+        W = self._W
+        bd = b.reshape(1, n)
+        from . import dense
+        x = W[1]
+        dense.copy(bd, W[2], n)
+        self.lu.solve(bd, out=x.reshape(1, n))
+        w_prev = np.inf
+        for step in range(self.umfpack_refinements + 1):
+            # r = b - M x
+            self.nep.dev.mlincomb(self._C, x.reshape(1, n), W[0])
+            dense.scal(W[0], -1.0, n)
+            dense.axpy(1.0, W[2], W[0], n)
+            nr = np.empty(3)
+            check(lib.nep_colnorms(n, 3, c_vp(W.data_ptr()), n, hptr(nr), stream_ptr()))
+            omega = nr[0] / (self._normM * nr[1] + nr[2]) if (nr[1] > 0 or nr[2] > 0) else 0.0
+            if omega <= EPS or omega > 0.5 * w_prev or step == self.umfpack_refinements:
+                break
+            w_prev = omega
+            self.lu.solve(W[0].reshape(1, n), out=W[3].reshape(1, n))
+            dense.axpy(1.0, W[3], x, n)
+            self.refine_steps_taken += 1
+        X = torch.empty_like(b) if out is None else out
+        dense.copy(x, X, n)
+        if scale != 1.0:
+            dense.scal(X, scale, n)
+        return X.reshape(b.shape)
 
 
 class BackslashLinSolver(LinSolver):
     """src/LinSolvers.jl:147-159: `A \\ x`, i.e. a fresh factorisation at every lin_solve."""
 
-    def __init__(self, nep, lam, permc_spec="COLAMD"):
+    def __init__(self, nep, lam, permc_spec=None, **lu_kw):
         self.A = nep.compute_Mder(lam)
         self.permc_spec = permc_spec
+        self.lu_kw = lu_kw
+
+    def solve_dev(self, b, out=None, scale=1.0):
+        lu = DeviceLU(self.A, permc_spec=self.permc_spec, **self.lu_kw)
+        self.last_lu = lu
+        return lu.solve(b, out=out, scale=scale)
 
 
 def lin_solve(solver, b, tol=0, scale=1.0):
@@ -102,11 +194,7 @@ def lin_solve(solver, b, tol=0, scale=1.0):
     (nrhs, n) / (n,) (-> device result).  `scale` multiplies the result on the device."""
     host = not is_dev(b)
     bd = to_dev(b) if host else b
-    if isinstance(solver, BackslashLinSolver):
-        lu = DeviceLU(solver.A, permc_spec=solver.permc_spec)
-    else:
-        lu = solver.lu
-    x = lu.solve(bd, scale=scale)
+    x = solver.solve_dev(bd, scale=scale)
     if host:
         xh = to_host(x if x.dim() == 2 else x.reshape(1, -1))
         return xh[:, 0] if np.ndim(b) == 1 else xh
@@ -120,8 +208,8 @@ class LinSolverCreator:
 class FactorizeLinSolverCreator(LinSolverCreator):
     """src/LinSolverCreators.jl:62-122 (factorisation recycling keyed by lam)."""
 
-    def __init__(self, umfpack_refinements=0, max_factorizations=0, nep=None, precomp_values=(),
-                 permc_spec="COLAMD"):
+    def __init__(self, umfpack_refinements=10, max_factorizations=0, nep=None, precomp_values=(),
+                 permc_spec=None, **lu_kw):
         if np.isscalar(precomp_values):
             precomp_values = [precomp_values]
         if len(precomp_values) > 0 and nep is None:
@@ -130,14 +218,16 @@ class FactorizeLinSolverCreator(LinSolverCreator):
         self.umfpack_refinements = umfpack_refinements
         self.max_factorizations = max_factorizations
         self.permc_spec = permc_spec
+        self.lu_kw = lu_kw
         self.recycled_factorizations = {}
         for s in precomp_values:
-            self.recycled_factorizations[complex(s)] = DeviceLU(nep.compute_Mder(s), permc_spec=permc_spec)
+            self.recycled_factorizations[complex(s)] = DeviceLU(nep.compute_Mder(s), permc_spec=permc_spec, **lu_kw)
 
 
 class BackslashLinSolverCreator(LinSolverCreator):
-    def __init__(self, permc_spec="COLAMD"):
+    def __init__(self, permc_spec=None, **lu_kw):
         self.permc_spec = permc_spec
+        self.lu_kw = lu_kw
 
 
 DefaultLinSolverCreator = FactorizeLinSolverCreator
@@ -146,11 +236,11 @@ DefaultLinSolverCreator = FactorizeLinSolverCreator
 def create_linsolver(creator, nep, lam):
     """src/LinSolverCreators.jl:107-122,143."""
     if isinstance(creator, BackslashLinSolverCreator):
-        return BackslashLinSolver(nep, lam, creator.permc_spec)
+        return BackslashLinSolver(nep, lam, creator.permc_spec, **creator.lu_kw)
     key = complex(lam)
     if key in creator.recycled_factorizations:
         return FactorizeLinSolver(nep, lam, creator.umfpack_refinements, _lu=creator.recycled_factorizations[key])
-    solver = FactorizeLinSolver(nep, lam, creator.umfpack_refinements, permc_spec=creator.permc_spec)
+    solver = FactorizeLinSolver(nep, lam, creator.umfpack_refinements, permc_spec=creator.permc_spec, **creator.lu_kw)
     if len(creator.recycled_factorizations) < creator.max_factorizations:
         creator.recycled_factorizations[key] = solver.lu
     return solver

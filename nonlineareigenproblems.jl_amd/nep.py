@@ -118,6 +118,14 @@ class SPMFDevice:
                                c_vp(z.data_ptr()), stream_ptr()))
         return z
 
+    def mlincomb_dev(self, Cdev, ldc, k, V, ldv, z):
+        """same with the coefficient block resident on the device (nep_mlincomb_dev); V, z may be raw
+        device addresses (int) or tensors."""
+        va = V.data_ptr() if is_dev(V) else V
+        check(lib.nep_mlincomb_dev(self.h, k, c_vp(Cdev.data_ptr()), ldc, c_vp(va), ldv, c_vp(z.data_ptr()),
+                                   stream_ptr()))
+        return z
+
     def resid_batch(self, F, QT, k, ldq):
         Fm = _lib.as_c128(F, "F")
         assert Fm.shape == (self.mt, k)

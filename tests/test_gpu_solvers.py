@@ -77,3 +77,133 @@ def test_iar_gun_twin_vs_oracle(na):
         for a, b in zip(eo[:kk], eg[:kk]):
             if a > 1e-12 and b > 1e-12:
                 assert 0.1 < a / b < 10
+
+
+def test_tiar_dep0_kat(na):
+    # test/tiar.jl:23-39,59-69,86-90 ; src/method_tiar.jl:37-45
+    from oracle import gallery as og, solvers as osol
+    nep = na.nep_gallery("dep0", 100); onep = og.dep0(100)
+    R = na.ResidualErrmeasure(nep); oR = osol.ResidualErrmeasure(onep)
+    lam, Q, Z, _ = na.tiar(nep, sigma=1.1, gamma=3, neigs=2, v=np.ones(100), maxit=50, tol=EPS * 100, errmeasure=R)
+    assert len(lam) == 2
+    for fused in (True, False):
+        lam, Q, Z, _ = na.tiar(nep, sigma=1.1, gamma=3, neigs=np.inf, v=np.ones(100), maxit=50, tol=EPS * 100,
+                               errmeasure=R, fused=fused)
+        assert len(lam) == 7
+        assert max(oR(lam[i], Q[:, i]) for i in range(7)) < EPS * 100
+        Zh = na.to_host(Z)
+        assert np.linalg.norm(Zh.conj().T @ Zh - np.eye(Zh.shape[1]), 2) < 1e-6
+    lam, Q, _, _ = na.tiar(nep, v=np.ones(100), tol=1e-5, neigs=3)
+    ref = np.array([-0.07708769561361105, 0.050462487743188206, 0.1503916927814904])
+    assert np.allclose(np.sort(lam.real), ref, atol=1e-12)
+    # tiar == iar
+    kw = dict(sigma=1.1, gamma=3, neigs=3, v=np.ones(100), maxit=50, tol=1e-10)
+    l1 = na.tiar(nep, **kw)[0]; l2 = na.iar(nep, **kw)[0]
+    _match(l1, l2, 1e-6)
+    with pytest.raises(na.NoConvergenceException):
+        na.tiar(nep, sigma=2.0, gamma=3, neigs=4, v=np.ones(100), maxit=5, tol=EPS * 100)
+    with pytest.raises(na.LostOrthogonalityException):
+        na.tiar(na.nep_gallery("dep0"), maxit=30, v=np.ones(5))
+
+
+def test_tiar_gun_twin_vs_oracle(na):
+    from oracle import gallery as og, solvers as osol, neps as oneps
+    n, m = 1310, 30
+    onep = og.gun_spmf_scaled(n)
+    lo, Qo, _, _ = osol.tiar(oneps.DerSPMF(onep, 0.0, m), maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10,
+                             errmeasure=osol.StandardSPMFErrmeasure(onep))
+    nep = na.nep_gallery("gun_spmf_scaled", n)
+    lg, Qg, _, _ = na.tiar(nep, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10)
+    assert len(lg) == len(lo) and len(lg) >= 1
+    _match(lg, lo, 1e-8)
+    oE = osol.StandardSPMFErrmeasure(onep)
+    assert max(oE(lg[i], Qg[:, i]) for i in range(len(lg))) < 1e-10
+
+
+def test_resinv_dep0_c1(na):
+    """config C1: nep_gallery("dep0") n=5, resinv(lam=0, v=ones).  From this start the inner scalar
+    Newton iteration of compute_rf has no nearby root and wanders chaotically for its 80 allowed steps
+    (compute_rf_wrapper.jl:31-39, bad_solution_allowed=true), so iterates are not comparable between any
+    two floating-point implementations; the converged pair is."""
+    from oracle import gallery as og, solvers as osol
+    nep = na.nep_gallery("dep0"); onep = og.dep0()
+    lam, v = na.resinv(nep, lam=0, v=np.ones(5))
+    assert lam.real == pytest.approx(-0.1595539182329811, rel=1e-10) and abs(lam.imag) < 1e-12
+    assert osol.DefaultErrmeasure(onep)(lam, v) < EPS * 100
+    # well-conditioned start (near the eigenpair): iterate-by-iterate agreement with the oracle
+    lo, vo = osol.resinv(onep, lam=0, v=np.ones(5))
+    v0 = vo + 0.05 * np.arange(1, 6)
+    hg = []; ho = []
+    l1, v1 = na.resinv(nep, lam=lo + 0.05, v=v0, hist=hg)
+    l2, v2 = osol.resinv(onep, lam=lo + 0.05, v=v0, hist=ho)
+    assert len(hg) == len(ho) and len(hg) > 3
+    for (k1, e1, a), (k2, e2, b) in zip(hg, ho):
+        assert abs(a - b) <= 1e-9 * max(1, abs(b))
+        if e2 > 1e-12:
+            assert e1 == pytest.approx(e2, rel=1e-4)
+    assert abs(l1 - l2) < 1e-12
+    # armijo path (method_newton.jl:598-609)
+    lam2, v2 = na.resinv(nep, lam=lo + 0.05, v=v0, armijo_factor=0.5)
+    assert abs(lam2 - l1) < 1e-10
+
+
+def test_quasinewton_qdep0_history(na):
+    # src/errmeasure.jl:156-169: sparse compute_Mlincomb (startder 0 and 1), StandardSPMFErrmeasure and a reused
+    # sparse factorisation -- the reference's printed 9-step history
+    nep = na.nep_gallery("qdep0")
+    hist = []
+    lam, v = na.quasinewton(nep, lam=-1, v=np.ones(1000), errmeasure=na.StandardSPMFErrmeasure(nep), tol=1e-10,
+                            hist=hist)
+    ref = [(0.022010375110869937, -1.0), (0.002515422247048546, -0.7063330111559607),
+           (0.000892354247568813, -0.8919579082730457), (5.445678793151584e-5, -1.0097584042560848),
+           (6.649967517409105e-7, -1.0023823873044), (1.0557281809769784e-8, -1.0024660870524031),
+           (6.420125566431444e-9, -1.0024677891861997), (3.181093707909799e-10, -1.0024669496893164),
+           (2.6368050026394416e-11, -1.0024669918249076)]
+    assert len(hist) == 9
+    for (k, err, l), (eref, lref) in zip(hist, ref):
+        assert l.real == pytest.approx(lref, rel=1e-10)
+        assert err == pytest.approx(eref, rel=1e-4)
+    assert hist[0][1] == pytest.approx(ref[0][0], rel=1e-13)
+
+
+def test_lu_schedule_has_dense_tail(na):
+    from oracle import gallery as og
+    import scipy.sparse as sp
+    A = sp.csc_matrix(og.gun_spmf_scaled(2620).compute_Mder(0.0), dtype=complex)
+    lu = na.DeviceLU(A, permc_spec="MMD_AT_PLUS_A")
+    assert lu.tail >= 64 and lu.levL < lu.levL_full and lu.levU < lu.levU_full
+    rng = np.random.default_rng(0)
+    b = rng.standard_normal(2620) + 1j * rng.standard_normal(2620)
+    x = na.to_host(lu.solve(na.to_dev(b)))[:, 0]
+    assert np.linalg.norm(A @ x - b) <= 1e-12 * np.linalg.norm(b) * 10
+    assert lu.launches_last_solve() < 200
+
+
+def test_beyn_dep0_kat(na):
+    # test/beyn.jl:15-46 (N=1000 default)
+    from oracle import gallery as og
+    nep = na.nep_gallery("dep0"); onep = og.dep0()
+    lam, V = na.contour_beyn(nep, radius=1, neigs=1, sanity_check=False)
+    M = onep.compute_Mder(lam[0])
+    assert np.linalg.svd(M, compute_uv=False).min() < EPS * 1000
+    assert np.linalg.norm(onep.compute_Mlincomb(lam[0], V[:, 0])) < EPS * 500
+    lam, V = na.contour_beyn(nep, sigma=0.2, radius=1.0, neigs=4, sanity_check=False)
+    assert len(lam) == 3
+
+
+def test_beyn_gun_twin_vs_oracle(na):
+    """config C4 at reduced size: same probe block, same count, eigenvalues agree, residuals below tol."""
+    from oracle import gallery as og, solvers as osol
+    n, k, N = 1310, 16, 32
+    onep = og.gun_spmf(n)
+    nep = na.nep_gallery("gun_spmf", n)
+    Vh = na.probe_block(n, k)
+    kw = dict(sigma=250.0 ** 2, radius=1.2e4, N=N, k=k, neigs=10 ** 6, tol=1e-6, sanity_check=True)
+    io = {}; ig = {}
+    lo, Vo = osol.contour_beyn(onep, Vh=Vh, info=io, **kw)
+    lg, Vg = na.contour_beyn(nep, Vh=Vh, info=ig, **kw)
+    assert ig["p"] == io["p"]
+    assert len(lg) == len(lo) and len(lg) >= 1
+    _match(lg, lo, 1e-7)
+    oE = osol.StandardSPMFErrmeasure(onep)
+    assert max(oE(lg[i], Vg[:, i]) for i in range(len(lg))) < 1e-6
