@@ -105,6 +105,10 @@ __global__ __launch_bounds__(512) void k_gemm_ts(const cplx* __restrict__ Z, int
     }
 }
 
+static inline int gemm_nt(int pp) {   // N-tiles of 8 complex output columns
+    return pp <= 8 ? 1 : pp <= 16 ? 2 : pp <= 32 ? 4 : pp <= 48 ? 6 : pp <= 64 ? 8 : pp <= 80 ? 10 : 13;
+}
+
 static NepScratch g_gemm_scratch;
 static PinnedRing g_gemm_ring;
 
@@ -135,7 +139,7 @@ extern "C" int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows,
     size_t total = 0;
     for (int j0 = 0; j0 < p; j0 += 104) {
         const int pp = std::min(104, p - j0);
-        const int nt = pp <= 8 ? 1 : pp <= 16 ? 2 : pp <= 32 ? 4 : pp <= 56 ? 7 : 13;
+        const int nt = gemm_nt(pp);
         total += (size_t)nks * nt * 128;
     }
     std::vector<double> frag(total, 0.0);
@@ -145,7 +149,7 @@ extern "C" int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows,
     std::vector<size_t> offs;
     for (int j0 = 0; j0 < p; j0 += 104) {
         const int pp = std::min(104, p - j0);
-        const int nt = pp <= 8 ? 1 : pp <= 16 ? 2 : pp <= 32 ? 4 : pp <= 56 ? 7 : 13;
+        const int nt = gemm_nt(pp);
         offs.push_back(off);
         for (int ks = 0; ks < nks; ++ks)
             for (int t = 0; t < nt; ++t)
@@ -171,11 +175,15 @@ extern "C" int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows,
         const double* dB = (const double*)g_gemm_scratch.dptr + offs[pi];
         const cplx* Z = (const cplx*)dZ;
         cplx* Y = (cplx*)dY;
-        if (pp <= 8) rc = gemm_launch<1>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
-        else if (pp <= 16) rc = gemm_launch<2>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
-        else if (pp <= 32) rc = gemm_launch<4>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
-        else if (pp <= 56) rc = gemm_launch<7>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
-        else rc = gemm_launch<13>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
+        switch (gemm_nt(pp)) {
+            case 1: rc = gemm_launch<1>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
+            case 2: rc = gemm_launch<2>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
+            case 4: rc = gemm_launch<4>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
+            case 6: rc = gemm_launch<6>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
+            case 8: rc = gemm_launch<8>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
+            case 10: rc = gemm_launch<10>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
+            default: rc = gemm_launch<13>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
+        }
         if (rc) return rc;
         (void)done;
     }

@@ -20,6 +20,11 @@ struct nep_spmf {
     uint32_t* d_idx = nullptr;
     void* d_vals = nullptr;
     cplx* d_WT = nullptr;     // n x mt row-major workspace
+    // SELL-64 copy of the stacked matrix (large n only): lane = row, entries of 64 consecutive rows interleaved
+    int32_t* d_sell_ptr = nullptr;   // nslices+1, in units of 64-entry columns
+    uint32_t* d_sell_idx = nullptr;
+    void* d_sell_val = nullptr;
+    int64_t sell_cols = 0;           // padded entries / 64
     NepScratch coef;          // staged coefficient matrices
     NepScratch part;          // per-block partials
     PinnedRing ring;          // pinned staging of host coefficient blocks
@@ -27,38 +32,39 @@ struct nep_spmf {
 
 // ------------------------------------------------------------------------------------------
 // (a) WT[r, i0+i] = sum_j V[r + j*ldv] * C[j + (i0+i)*ldc],  i < MT.
-// block = 512 threads = 8 waves covering 32 rows: each half-wave owns the same 32 rows and one of 16
-// column groups (columns j = g, g+16, ...), i.e. a wave reads two 512-byte row segments per step.
-// 32 rows per block keeps >= 2 blocks per CU even for n = 9956 (312 blocks on 256 CUs).
-template <int MT>
+// block = 512 threads = 8 waves.  ROWS = 64: a wave owns 64 rows (1 KiB coalesced per load) and one of 8
+// column groups -- the streaming shape for large n.  ROWS = 32: each half-wave owns the same 32 rows and one
+// of 16 column groups, which doubles the number of workgroups for small n (gun: 312 blocks on 256 CUs).
+template <int MT, int ROWS>
 __global__ __launch_bounds__(512) void k_vc(const cplx* __restrict__ V, int64_t ldv, int64_t n, int k,
                                             const cplx* __restrict__ C, int64_t ldc, int i0, int mt_total,
                                             cplx* __restrict__ WT) {
-    __shared__ cplx sm[16][MT][32];
-    const int r32 = threadIdx.x & 31;
-    const int g = threadIdx.x >> 5;          // column group 0..15
-    const int64_t row = blockIdx.x * 32LL + r32;
+    constexpr int NG = 512 / ROWS;           // column groups
+    __shared__ cplx sm[NG][MT][ROWS];
+    const int rr0 = threadIdx.x % ROWS;
+    const int g = threadIdx.x / ROWS;
+    const int64_t row = blockIdx.x * (int64_t)ROWS + rr0;
     const int64_t rowc = row < n ? row : n - 1;
     cplx acc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = cmake(0.0, 0.0);
     const cplx* vp = V + rowc;
 #pragma unroll 4
-    for (int j = g; j < k; j += 16) {
+    for (int j = g; j < k; j += NG) {
         const cplx v = vp[(int64_t)j * ldv];
 #pragma unroll
         for (int i = 0; i < MT; ++i) cfma(acc[i], v, C[j + (int64_t)(i0 + i) * ldc]);
     }
 #pragma unroll
-    for (int i = 0; i < MT; ++i) sm[g][i][r32] = acc[i];
+    for (int i = 0; i < MT; ++i) sm[g][i][rr0] = acc[i];
     __syncthreads();
-    // 32*MT outputs, written contiguously: t -> (row = t / MT, i = t % MT)
-    for (int t = threadIdx.x; t < 32 * MT; t += 512) {
+    // ROWS*MT outputs, written contiguously: t -> (row = t / MT, i = t % MT)
+    for (int t = threadIdx.x; t < ROWS * MT; t += 512) {
         const int rr = t / MT, i = t % MT;
         cplx s = sm[0][i][rr];
 #pragma unroll
-        for (int q = 1; q < 16; ++q) s = cadd(s, sm[q][i][rr]);
-        const int64_t r = blockIdx.x * 32LL + rr;
+        for (int q = 1; q < NG; ++q) s = cadd(s, sm[q][i][rr]);
+        const int64_t r = blockIdx.x * (int64_t)ROWS + rr;
         if (r < n) WT[r * mt_total + i0 + i] = s;
     }
 }
@@ -80,6 +86,69 @@ __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ rowptr
             const int64_t c = id & NEP_COL_MASK;
             const int t = id >> NEP_TERM_SHIFT;
             cfma(acc, vals[e], WT[c * mt + t]);
+        }
+    }
+    acc = group_reduce_sum<G>(acc);
+    if (row < n && sub == 0) z[row] = acc;
+}
+
+typedef double d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double ntload(const double* p) { return __builtin_nontemporal_load(p); }
+__device__ __forceinline__ cplx ntload(const cplx* p) {
+    const d2v v = __builtin_nontemporal_load((const d2v*)p);
+    return cmake(v.x, v.y);
+}
+
+// (b') SELL-64 SpMV for large n: one lane per row, the entries of 64 consecutive rows are interleaved so that
+// every load of a wave is one contiguous 256-byte (idx) / 512-byte (val) segment; no cross-lane reduction.
+// FOLD: k == 1 -- the vector is used directly and the per-term coefficient is applied on the fly
+// (z = sum_e val[e] * C[term(e)] * v[col(e)]), which saves the k_vc launch and the W round trip.
+template <typename VT, bool FOLD>
+__global__ __launch_bounds__(256) void k_spmv_sell(const int32_t* __restrict__ sptr, const uint32_t* __restrict__ idx,
+                                                   const VT* __restrict__ vals, const cplx* __restrict__ X,
+                                                   const cplx* __restrict__ C, int64_t ldc, int mt, int64_t n,
+                                                   cplx* __restrict__ z) {
+    const int lane = threadIdx.x & 63;
+    const int64_t slice = blockIdx.x * 4LL + (threadIdx.x >> 6);
+    const int64_t row = slice * 64 + lane;
+    if (slice * 64 >= n) return;
+    cplx acc = cmake(0.0, 0.0);
+    const int64_t e0 = sptr[slice], e1 = sptr[slice + 1];
+    const uint32_t* ip = idx + e0 * 64 + lane;
+    const VT* vp = vals + e0 * 64 + lane;
+    const int cnt = (int)(e1 - e0);
+#pragma unroll 4
+    for (int e = 0; e < cnt; ++e) {
+        const uint32_t id = __builtin_nontemporal_load(ip + (int64_t)e * 64);
+        const VT a = ntload(vp + (int64_t)e * 64);
+        const int64_t c = id & NEP_COL_MASK;
+        const int t = id >> NEP_TERM_SHIFT;
+        if (FOLD) {
+            cfma(acc, cscale(a, C[(int64_t)t * ldc]), X[c]);
+        } else {
+            cfma(acc, a, X[c * mt + t]);
+        }
+    }
+    if (row < n) z[row] = acc;
+}
+
+// k == 1 fold for the CSR-vector kernel (small n)
+template <int G, typename VT>
+__global__ __launch_bounds__(256) void k_spmv_fold(const int32_t* __restrict__ rowptr, const uint32_t* __restrict__ idx,
+                                                   const VT* __restrict__ vals, const cplx* __restrict__ v,
+                                                   const cplx* __restrict__ C, int64_t ldc, int64_t n,
+                                                   cplx* __restrict__ z) {
+    constexpr int RPB = 256 / G;
+    const int sub = threadIdx.x % G;
+    const int64_t row = blockIdx.x * (int64_t)RPB + threadIdx.x / G;
+    cplx acc = cmake(0.0, 0.0);
+    if (row < n) {
+        const int e1 = rowptr[row + 1];
+        for (int e = rowptr[row] + sub; e < e1; e += G) {
+            const uint32_t id = idx[e];
+            const int64_t c = id & NEP_COL_MASK;
+            const int t = id >> NEP_TERM_SHIFT;
+            cfma(acc, cscale(vals[e], C[(int64_t)t * ldc]), v[c]);
         }
     }
     acc = group_reduce_sum<G>(acc);
@@ -203,6 +272,13 @@ template <typename VT>
 static int launch_spmv(const nep_spmf* s, const cplx* WT, cplx* z, hipStream_t st) {
     const VT* vals = (const VT*)s->d_vals;
     const int64_t n = s->n;
+    if (s->d_sell_ptr) {
+        const int64_t nsl = (n + 63) / 64;
+        hipLaunchKernelGGL((k_spmv_sell<VT, false>), dim3((unsigned)((nsl + 3) / 4)), dim3(256), 0, st, s->d_sell_ptr,
+                           s->d_sell_idx, (const VT*)s->d_sell_val, WT, (const cplx*)nullptr, (int64_t)0, s->mt, n, z);
+        LAUNCHCHK();
+        return NEP_OK;
+    }
 #define SPMV_CASE(G)                                                                               \
     case G: {                                                                                      \
         const int rpb = 256 / G;                                                                   \
@@ -219,23 +295,56 @@ static int launch_spmv(const nep_spmf* s, const cplx* WT, cplx* z, hipStream_t s
     return NEP_OK;
 }
 
-static int launch_vc(const nep_spmf* s, int k, const cplx* dC, int64_t ldc, const cplx* V, int64_t ldv, hipStream_t st) {
+// k == 1: z = sum_e val[e] * C[term] * v[col]  (one launch, no W)
+template <typename VT>
+static int launch_spmv_fold(const nep_spmf* s, const cplx* v, const cplx* dC, int64_t ldc, cplx* z, hipStream_t st) {
+    const VT* vals = (const VT*)s->d_vals;
     const int64_t n = s->n;
-    const dim3 grid((unsigned)((n + 31) / 32)), block(512);
+    if (s->d_sell_ptr) {
+        const int64_t nsl = (n + 63) / 64;
+        hipLaunchKernelGGL((k_spmv_sell<VT, true>), dim3((unsigned)((nsl + 3) / 4)), dim3(256), 0, st, s->d_sell_ptr,
+                           s->d_sell_idx, (const VT*)s->d_sell_val, v, dC, ldc, s->mt, n, z);
+        LAUNCHCHK();
+        return NEP_OK;
+    }
+#define FOLD_CASE(G)                                                                                    \
+    case G: {                                                                                           \
+        const int rpb = 256 / G;                                                                        \
+        hipLaunchKernelGGL((k_spmv_fold<G, VT>), dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, st, \
+                           s->d_rowptr, s->d_idx, vals, v, dC, ldc, n, z);                              \
+        break;                                                                                          \
+    }
+    switch (s->lanes) {
+        FOLD_CASE(2) FOLD_CASE(4) FOLD_CASE(8) FOLD_CASE(16) FOLD_CASE(32) FOLD_CASE(64)
+        default: nep_set_error("bad lanes %d", s->lanes); return NEP_ERR_ARG;
+    }
+#undef FOLD_CASE
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+template <int ROWS>
+static int launch_vc_rows(const nep_spmf* s, int k, const cplx* dC, int64_t ldc, const cplx* V, int64_t ldv, hipStream_t st) {
+    const int64_t n = s->n;
+    const dim3 grid((unsigned)((n + ROWS - 1) / ROWS)), block(512);
     int i0 = 0;
     while (i0 < s->mt) {
         const int rem = s->mt - i0;
         const int cnt = rem >= 4 ? 4 : rem;
         switch (cnt) {
-            case 4: hipLaunchKernelGGL((k_vc<4>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
-            case 3: hipLaunchKernelGGL((k_vc<3>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
-            case 2: hipLaunchKernelGGL((k_vc<2>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
-            default: hipLaunchKernelGGL((k_vc<1>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
+            case 4: hipLaunchKernelGGL((k_vc<4, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
+            case 3: hipLaunchKernelGGL((k_vc<3, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
+            case 2: hipLaunchKernelGGL((k_vc<2, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
+            default: hipLaunchKernelGGL((k_vc<1, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
         }
         LAUNCHCHK();
         i0 += cnt;
     }
     return NEP_OK;
+}
+static int launch_vc(const nep_spmf* s, int k, const cplx* dC, int64_t ldc, const cplx* V, int64_t ldv, hipStream_t st) {
+    if (s->n >= 65536) return launch_vc_rows<64>(s, k, dC, ldc, V, ldv, st);
+    return launch_vc_rows<32>(s, k, dC, ldc, V, ldv, st);
 }
 
 template <typename VT>
@@ -325,6 +434,44 @@ int32_t nep_spmf_create(int64_t n, int32_t mt, const int32_t* const* h_rowptr, c
     CRCHK(hipMemcpy(s->d_idx, idx.data(), (size_t)nnz * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (any_complex) CRCHK(hipMemcpy(s->d_vals, vc.data(), (size_t)nnz * 16, hipMemcpyHostToDevice));
     else CRCHK(hipMemcpy(s->d_vals, vr.data(), (size_t)nnz * 8, hipMemcpyHostToDevice));
+    // ---- SELL-64 copy for large n (lane-per-row SpMV); env NEP_SELL=0/1 overrides the size rule
+    {
+        bool want = n >= 32768;
+        if (const char* e = getenv("NEP_SELL")) want = atoi(e) != 0;
+        if (want) {
+            const int64_t nsl = (n + 63) / 64;
+            std::vector<int32_t> sptr(nsl + 1, 0);
+            for (int64_t sl = 0; sl < nsl; ++sl) {
+                int32_t mx = 0;
+                for (int64_t r = sl * 64; r < std::min<int64_t>(n, sl * 64 + 64); ++r) mx = std::max(mx, rowptr[r + 1] - rowptr[r]);
+                sptr[sl + 1] = sptr[sl] + mx;
+            }
+            const int64_t cols = sptr[nsl];
+            if (cols * 64 <= 4 * nnz + 4096) {          // refuse pathological padding (> 4x)
+                std::vector<uint32_t> sidx((size_t)cols * 64, 0u);
+                std::vector<double> sr(any_complex ? 0 : (size_t)cols * 64, 0.0);
+                std::vector<nep_cdouble> sc(any_complex ? (size_t)cols * 64 : 0);
+                for (int64_t sl = 0; sl < nsl; ++sl)
+                    for (int l = 0; l < 64; ++l) {
+                        const int64_t r = sl * 64 + l;
+                        if (r >= n) continue;
+                        for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+                            const size_t q = ((size_t)sptr[sl] + (e - rowptr[r])) * 64 + l;
+                            sidx[q] = idx[e];
+                            if (any_complex) sc[q] = vc[e]; else sr[q] = vr[e];
+                        }
+                    }
+                CRCHK(hipMalloc((void**)&s->d_sell_ptr, (size_t)(nsl + 1) * 4));
+                CRCHK(hipMalloc((void**)&s->d_sell_idx, (size_t)cols * 64 * 4 + 256));
+                CRCHK(hipMalloc(&s->d_sell_val, (size_t)cols * 64 * s->valbytes + 256));
+                CRCHK(hipMemcpy(s->d_sell_ptr, sptr.data(), (size_t)(nsl + 1) * 4, hipMemcpyHostToDevice));
+                CRCHK(hipMemcpy(s->d_sell_idx, sidx.data(), (size_t)cols * 64 * 4, hipMemcpyHostToDevice));
+                if (any_complex) CRCHK(hipMemcpy(s->d_sell_val, sc.data(), (size_t)cols * 64 * 16, hipMemcpyHostToDevice));
+                else CRCHK(hipMemcpy(s->d_sell_val, sr.data(), (size_t)cols * 64 * 8, hipMemcpyHostToDevice));
+                s->sell_cols = cols;
+            }
+        }
+    }
 #undef CRCHK
     *out = s;
     return NEP_OK;
@@ -336,6 +483,9 @@ int32_t nep_spmf_destroy(nep_spmf* s) {
     if (s->d_idx) (void)hipFree(s->d_idx);
     if (s->d_vals) (void)hipFree(s->d_vals);
     if (s->d_WT) (void)hipFree(s->d_WT);
+    if (s->d_sell_ptr) (void)hipFree(s->d_sell_ptr);
+    if (s->d_sell_idx) (void)hipFree(s->d_sell_idx);
+    if (s->d_sell_val) (void)hipFree(s->d_sell_val);
     s->coef.release();
     s->part.release();
     s->ring.release();
@@ -362,6 +512,10 @@ int32_t nep_mlincomb(nep_spmf* s, int32_t k, const nep_cdouble* hC, const nep_cd
     // the pinned ring protects the host side
     rc = s->ring.upload(s->coef.dptr, hC, cbytes, st);
     if (rc) return rc;
+    if (k == 1) {
+        if (s->valbytes == 8) return launch_spmv_fold<double>(s, (const cplx*)dV, (const cplx*)s->coef.dptr, 1, (cplx*)dz, st);
+        return launch_spmv_fold<cplx>(s, (const cplx*)dV, (const cplx*)s->coef.dptr, 1, (cplx*)dz, st);
+    }
     rc = launch_vc(s, k, (const cplx*)s->coef.dptr, k, (const cplx*)dV, ldv, st);
     if (rc) return rc;
     if (s->valbytes == 8) return launch_spmv<double>(s, s->d_WT, (cplx*)dz, st);
@@ -373,6 +527,10 @@ int32_t nep_mlincomb_dev(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t 
     ARGCHK(s && dC && dV && dz);
     ARGCHK(k >= 1 && ldv >= s->n && ldc >= k);
     hipStream_t st = as_stream(stream);
+    if (k == 1) {
+        if (s->valbytes == 8) return launch_spmv_fold<double>(s, (const cplx*)dV, (const cplx*)dC, ldc, (cplx*)dz, st);
+        return launch_spmv_fold<cplx>(s, (const cplx*)dV, (const cplx*)dC, ldc, (cplx*)dz, st);
+    }
     int rc = launch_vc(s, k, (const cplx*)dC, ldc, (const cplx*)dV, ldv, st);
     if (rc) return rc;
     if (s->valbytes == 8) return launch_spmv<double>(s, s->d_WT, (cplx*)dz, st);

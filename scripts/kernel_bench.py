@@ -1,0 +1,132 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of the individual HIP kernels at BASELINE sizes (HIP-event timing), meant to be run
+plain or under `rocprofv3 --kernel-trace --stats` / `rocprofv3 --pmc FETCH_SIZE` (separate passes).
+
+    python scripts/kernel_bench.py [gun|wep|all] [--reps N]
+
+Prints one JSON line per measurement: algorithmic bytes/flops (SURVEY.md section 8d formulas), ms per call,
+achieved GB/s or TFLOP/s and the fraction of the MI355X peak (HBM 8 TB/s, FP64 MFMA 78.6 TFLOP/s).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+HBM = 8000.0
+MFMA64 = 78.6
+
+
+def ev_time(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def crandn(*shape):
+    return torch.complex(torch.randn(*shape, dtype=torch.float64, device="cuda"),
+                         torch.randn(*shape, dtype=torch.float64, device="cuda"))
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def bench_mlincomb(na, dev, n, k, label, reps):
+    V = crandn(k, n)
+    Cm = np.random.default_rng(0).standard_normal((k, dev.mt)) + 0j
+    Cdev = na.to_dev(Cm)
+    z = torch.empty(n, dtype=torch.complex128, device="cuda")
+    ms = ev_time(lambda: dev.mlincomb_dev(Cdev, k, k, V, n, z), reps)
+    b = dev.algorithmic_bytes(k)
+    emit(kernel="K1 nep_mlincomb (k_vc+k_spmv)", case=label, n=n, k=k, nnz=dev.nnz, bytes=b, ms=ms,
+         GBps=b / ms / 1e6, frac_hbm=b / ms / 1e6 / HBM)
+
+
+def bench_resid(na, nep, n, k, label, reps):
+    QT = crandn(n, k)
+    lams = np.linspace(0.1, 0.2, k) + 0.01j
+    errm = na.ResidualErrmeasure(nep)
+    t0 = time.perf_counter(); errm.batch(list(lams), QT); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        errm.batch(list(lams), QT)
+    ms = (time.perf_counter() - t) / reps * 1e3
+    b = nep.dev.matrix_bytes + 16 * n * k
+    emit(kernel="K2 nep_resid_batch (wall incl. sync)", case=label, n=n, k=k, bytes=b, ms=ms, GBps=b / ms / 1e6,
+         frac_hbm=b / ms / 1e6 / HBM)
+
+
+def bench_orth(na, rows, k, label, reps, active=None):
+    V = crandn(k, rows)
+    w0 = crandn(rows)
+    w = w0.clone()
+
+    def run():
+        na.dense.copy(w0, w)
+        na.orthogonalize_and_normalize(V, w, k, active_rows=active, method=1)    # one CGS pass = dots + update
+    t0 = time.perf_counter(); run(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        run()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t) / reps * 1e3
+    if active is None:
+        b = 2 * 16 * rows * k + 3 * 16 * rows
+    else:
+        b = 2 * 16 * int(np.sum(np.minimum(active[:k], rows))) + 3 * 16 * rows
+    emit(kernel="K6 nep_orth one pass (wall incl. 1 sync + copy)", case=label, rows=rows, k=k, bytes=b, ms=ms,
+         GBps=b / ms / 1e6, frac_hbm=b / ms / 1e6 / HBM)
+
+
+def bench_gemm(na, rows, k, p, label, reps, rowmajor=True):
+    Z = crandn(k, rows)
+    B = np.random.default_rng(1).standard_normal((k, p)) + 1j * np.random.default_rng(2).standard_normal((k, p))
+    out = torch.empty((rows, p) if rowmajor else (p, rows), dtype=torch.complex128, device="cuda")
+    ms = ev_time(lambda: na.gemm_ts(Z, B, rowmajor=rowmajor, out=out), reps)
+    fl = 8.0 * rows * k * p
+    b = 16.0 * rows * (k + p)
+    emit(kernel="K7 nep_gemm_ts (incl. host B expansion + H2D)", case=label, rows=rows, k=k, p=p, flops=fl, bytes=b, ms=ms,
+         TFLOPs=fl / ms / 1e9, frac_mfma=fl / ms / 1e9 / MFMA64, GBps=b / ms / 1e6, frac_hbm=b / ms / 1e6 / HBM)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="?", default="all")
+    ap.add_argument("--reps", type=int, default=20)
+    args = ap.parse_args()
+    import nep_amd as na
+    if args.which in ("gun", "all"):
+        nep = na.nep_gallery("gun_spmf_scaled")
+        n = nep.n
+        for k in (1, 10, 100):
+            bench_mlincomb(na, nep.dev, n, k, "gun", args.reps)
+        bench_resid(na, nep, n, 100, "gun", args.reps)
+        bench_orth(na, n * 101, 100, "gun iar step 100 (block-triangular basis)", 5,
+                   active=(np.arange(1, 102) * n).astype(np.int64))
+        bench_orth(na, n, 100, "gun tiar step 100", args.reps)
+        bench_gemm(na, n, 100, 100, "gun Ritz block", args.reps)
+    if args.which in ("wep", "all"):
+        from nep_amd import wep
+        wd = wep.WaveguideData(1003, 999, "JARLEBRING")
+        dev = na.SPMFDevice(wd.big_matrices())
+        n = wd.n
+        for k in (1, 8, 60):
+            bench_mlincomb(na, dev, n, k, "wep 1003x999 (3 sparse terms)", max(3, args.reps // 2))
+        bench_orth(na, n, 60, "wep tiar step 60", 5)
+        bench_gemm(na, n, 60, 60, "wep Ritz block", 5)
+        bench_gemm(na, n, 60, 60, "wep basis block col-major", 5, rowmajor=False)
+
+
+if __name__ == "__main__":
+    main()

@@ -229,3 +229,27 @@ def test_lin_solve_interfaces(na):
     cache.solve(lam, b, True); assert len(cache.solvers) == 1
     cache.solve(lam + 1, b, False); assert len(cache.solvers) == 1
     cache.solve(lam + 2, b, True); assert len(cache.solvers) == 2
+
+
+def test_mlincomb_sell_and_fold_paths(na, monkeypatch):
+    """large-n SELL-64 SpMV and the k==1 folded SpMV agree with the CSR-vector path and with NumPy"""
+    from nep_amd import wep
+    wd = wep.WaveguideData(61, 57, "JARLEBRING")
+    Av = wd.big_matrices()
+    n = wd.n
+    rng = np.random.default_rng(4)
+    fv = [na.funcs.one(), na.funcs.ident(), na.funcs.Monomial(2)]
+    lam = -1.3 - 0.31j
+    Vs = {k: rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k)) for k in (1, 5)}
+    res = {}
+    for sell in ("0", "1"):
+        monkeypatch.setenv("NEP_SELL", sell)
+        nep = na.SPMF_NEP(Av, fv)
+        for k, V in Vs.items():
+            a = np.arange(1, k + 1) + 0.5j
+            z = nep.compute_Mlincomb(lam, V, a)
+            ref = sum(a[j] * sum(fv[i].derivs(lam, k)[j] * (Av[i] @ V[:, j]) for i in range(3)) for j in range(k))
+            assert np.linalg.norm(z - ref) <= 1e-12 * np.linalg.norm(ref)
+            if (k, "0") in res:
+                assert np.linalg.norm(z - res[(k, "0")]) <= 1e-13 * np.linalg.norm(ref)
+            res[(k, sell)] = z
