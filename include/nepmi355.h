@@ -100,6 +100,12 @@ int32_t nep_mlincomb_dev(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t 
 int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT,
                         int64_t ldq, double* h_rnorm, double* h_qnorm, nep_stream stream);
 
+/* same residuals, but the block R^T (row-major, row stride ldr >= k) is written instead of its norms --
+ * for NEPs with an extra non-SPMF term (the WEP corner, src/gallery_extra/waveguide/Waveguide.jl:351-374)
+ * whose contribution is added before the norms are taken.  Asynchronous. */
+int32_t nep_resid_block(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
+                        nep_cdouble* dRT, int64_t ldr, nep_stream stream);
+
 /* compute_MM building block: ZT = sum_i A_i * XT[:, i*p:(i+1)*p]  (row-major in and out)
  * replaces: compute_MM(::SPMF_NEP,S,V) src/NEPTypes.jl:276-319 (Z += AA[i]*(V*f_i(S))) after
  *           XT = (V*[F_1..F_mt])^T has been formed with nep_gemm_ts. */
@@ -126,6 +132,12 @@ int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
 int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_t k,
                     const nep_cdouble* hB, int64_t ldb, int32_t p, nep_cdouble* dY, int64_t ldy,
                     int32_t y_rowmajor, nep_stream stream);
+
+/* same with B resident on the device: B[c,j] = dB[j*ldb + c] (b_rowmajor=0) or dB[c*ldb + j] (=1).
+ * Used for the WEP corner term R*diag(s)*R^H (dense nz x nz scaled-DFT blocks, Waveguide.jl:53-65,351-374). */
+int32_t nep_gemm_ts_dev(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_t k,
+                        const nep_cdouble* dB, int64_t ldb, int32_t b_rowmajor, int32_t p,
+                        nep_cdouble* dY, int64_t ldy, int32_t y_rowmajor, nep_stream stream);
 
 /* ---- K5 fixed-shift solve with a host-computed sparse LU -------------------------------
  * replaces: FactorizeLinSolver / lin_solve src/LinSolvers.jl:109-137 (Afact \ x) and
@@ -167,6 +179,15 @@ int32_t nep_colnorms(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx
 /* dot products d_j = x_j^H y_j of the columns of two rows x k blocks (synchronous) */
 int32_t nep_coldots(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx,
                     const nep_cdouble* dY, int64_t ldy, nep_cdouble* h_out, nep_stream stream);
+/* out[r] = sum_j A[r,j]*B[r,j] (column-major blocks, no conjugation) */
+int32_t nep_rowdot(int64_t rows, int32_t k, const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb,
+                   nep_cdouble* dout, nep_stream stream);
+/* A[r,j] *= B[r,j] (column-major blocks) */
+int32_t nep_hadamard(int64_t rows, int32_t k, nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb,
+                     nep_stream stream);
+/* column 2-norms of a ROW-major rows x k block (row stride ld); synchronous */
+int32_t nep_rowmajor_colnorms(int64_t rows, int32_t k, const nep_cdouble* dXT, int64_t ld, double* h_out,
+                              nep_stream stream);
 /* out-of-place transpose: row-major (rows x k, ld lds) -> column-major (ldd), selected columns
  * cols[0..ncols) (host int32, NULL = all) */
 int32_t nep_rowmajor_to_colmajor(int64_t rows, int32_t k, const nep_cdouble* dsrc, int64_t lds,

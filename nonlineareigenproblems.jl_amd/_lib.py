@@ -60,9 +60,11 @@ SIGNATURES = {
     "nep_mlincomb": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp],
     "nep_mlincomb_dev": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "nep_resid_batch": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp],
+    "nep_resid_block": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp],
     "nep_spmm_terms": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp],
     "nep_orth": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, P(c_dbl), c_i32, P(c_i32), c_vp],
     "nep_gemm_ts": [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp],
+    "nep_gemm_ts_dev": [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp],
     "nep_lu_create": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, P(c_vp)],
     "nep_lu_destroy": [c_vp],
     "nep_lu_info": [c_vp, P(c_i64)],
@@ -74,6 +76,9 @@ SIGNATURES = {
     "nep_nrm2": [c_i64, c_vp, P(c_dbl), c_vp],
     "nep_colnorms": [c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],
     "nep_coldots": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
+    "nep_rowdot": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
+    "nep_hadamard": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp],
+    "nep_rowmajor_colnorms": [c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],
     "nep_rowmajor_to_colmajor": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i32, c_vp, c_i64, c_vp],
 }
 

@@ -125,6 +125,41 @@ static int gemm_launch(bool rowmajor, const cplx* Z, int64_t ldz, int64_t rows, 
     return NEP_OK;
 }
 
+// builds the lane-ordered B fragments of one column panel from a DEVICE matrix
+// B[c, j] = b_rowmajor ? dB[c*ldb + j] : dB[j*ldb + c]
+__global__ void k_expand_B(const cplx* __restrict__ B, int64_t ldb, int b_rowmajor, int k, int pp, int j0, int nks,
+                           int nt, double* __restrict__ frag) {
+    const int64_t total = (int64_t)nks * nt * 64;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int l = (int)(i & 63);
+        const int64_t kt = i >> 6;            // ks*nt + t
+        const int t = (int)(kt % nt), ks = (int)(kt / nt);
+        const int q = l >> 4, n = l & 15;
+        const int c = 4 * ks + q, jc = 8 * t + (n >> 1);
+        double b0 = 0.0, b1 = 0.0;
+        if (c < k && jc < pp) {
+            const cplx b = b_rowmajor ? B[(int64_t)c * ldb + (j0 + jc)] : B[(int64_t)(j0 + jc) * ldb + c];
+            if ((n & 1) == 0) { b0 = b.x; b1 = -b.y; } else { b0 = b.y; b1 = b.x; }
+        }
+        double* f = frag + kt * 128;
+        f[l] = b0;
+        f[64 + l] = b1;
+    }
+}
+
+static int gemm_dispatch(int nt, bool y_rowmajor, const cplx* Z, int64_t ldz, int64_t rows, int k, const double* dB,
+                         int nks, int pp, int j0, cplx* Y, int64_t ldy, hipStream_t st) {
+    switch (nt) {
+        case 1: return gemm_launch<1>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
+        case 2: return gemm_launch<2>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
+        case 4: return gemm_launch<4>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
+        case 6: return gemm_launch<6>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
+        case 8: return gemm_launch<8>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
+        case 10: return gemm_launch<10>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
+        default: return gemm_launch<13>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st);
+    }
+}
+
 extern "C" int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_t k,
                                const nep_cdouble* hB, int64_t ldb, int32_t p, nep_cdouble* dY, int64_t ldy,
                                int32_t y_rowmajor, nep_stream stream) {
@@ -134,14 +169,8 @@ extern "C" int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows,
     hipStream_t st = as_stream(stream);
     const int nks = (k + 3) / 4;
     // column panels of at most 104 complex output columns (13 N-tiles of 8)
-    int done = 0;
-    // total staging: sum over panels of nks*NT*128 doubles
     size_t total = 0;
-    for (int j0 = 0; j0 < p; j0 += 104) {
-        const int pp = std::min(104, p - j0);
-        const int nt = gemm_nt(pp);
-        total += (size_t)nks * nt * 128;
-    }
+    for (int j0 = 0; j0 < p; j0 += 104) total += (size_t)nks * gemm_nt(std::min(104, p - j0)) * 128;
     std::vector<double> frag(total, 0.0);
     int rc = g_gemm_scratch.ensure(total * sizeof(double));
     if (rc) return rc;
@@ -172,20 +201,40 @@ extern "C" int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows,
     int pi = 0;
     for (int j0 = 0; j0 < p; j0 += 104, ++pi) {
         const int pp = std::min(104, p - j0);
-        const double* dB = (const double*)g_gemm_scratch.dptr + offs[pi];
-        const cplx* Z = (const cplx*)dZ;
-        cplx* Y = (cplx*)dY;
-        switch (gemm_nt(pp)) {
-            case 1: rc = gemm_launch<1>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
-            case 2: rc = gemm_launch<2>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
-            case 4: rc = gemm_launch<4>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
-            case 6: rc = gemm_launch<6>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
-            case 8: rc = gemm_launch<8>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
-            case 10: rc = gemm_launch<10>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
-            default: rc = gemm_launch<13>(y_rowmajor, Z, ldz, rows, k, dB, nks, pp, j0, Y, ldy, st); break;
-        }
+        rc = gemm_dispatch(gemm_nt(pp), y_rowmajor != 0, (const cplx*)dZ, ldz, rows, k,
+                           (const double*)g_gemm_scratch.dptr + offs[pi], nks, pp, j0, (cplx*)dY, ldy, st);
         if (rc) return rc;
-        (void)done;
+    }
+    return NEP_OK;
+}
+
+static NepScratch g_gemm_scratch_dev;
+
+extern "C" int32_t nep_gemm_ts_dev(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_t k,
+                                   const nep_cdouble* dB, int64_t ldb, int32_t b_rowmajor, int32_t p,
+                                   nep_cdouble* dY, int64_t ldy, int32_t y_rowmajor, nep_stream stream) {
+    ARGCHK(dZ && dB && dY);
+    ARGCHK(rows > 0 && k >= 1 && p >= 1 && ldz >= rows);
+    ARGCHK(b_rowmajor ? ldb >= p : ldb >= k);
+    ARGCHK(y_rowmajor ? ldy >= p : ldy >= rows);
+    hipStream_t st = as_stream(stream);
+    const int nks = (k + 3) / 4;
+    size_t total = 0;
+    for (int j0 = 0; j0 < p; j0 += 104) total += (size_t)nks * gemm_nt(std::min(104, p - j0)) * 128;
+    int rc = g_gemm_scratch_dev.ensure(total * sizeof(double));
+    if (rc) return rc;
+    size_t off = 0;
+    for (int j0 = 0; j0 < p; j0 += 104) {
+        const int pp = std::min(104, p - j0);
+        const int nt = gemm_nt(pp);
+        double* frag = (double*)g_gemm_scratch_dev.dptr + off;
+        const int64_t work = (int64_t)nks * nt * 64;
+        hipLaunchKernelGGL(k_expand_B, dim3((unsigned)std::min<int64_t>((work + 255) / 256, 2048)), dim3(256), 0, st,
+                           (const cplx*)dB, ldb, (int)b_rowmajor, (int)k, pp, j0, nks, nt, frag);
+        LAUNCHCHK();
+        rc = gemm_dispatch(nt, y_rowmajor != 0, (const cplx*)dZ, ldz, rows, k, frag, nks, pp, j0, (cplx*)dY, ldy, st);
+        if (rc) return rc;
+        off += (size_t)nks * nt * 128;
     }
     return NEP_OK;
 }

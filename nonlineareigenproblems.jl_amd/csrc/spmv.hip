@@ -566,6 +566,22 @@ int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
     return NEP_OK;
 }
 
+int32_t nep_resid_block(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
+                        nep_cdouble* dRT, int64_t ldr, nep_stream stream) {
+    ARGCHK(s && hF && dQT && dRT);
+    ARGCHK(k >= 1 && k <= 256 && ldq >= k && ldr >= k);
+    hipStream_t st = as_stream(stream);
+    const size_t cbytes = (size_t)k * s->mt * sizeof(cplx);
+    int rc = s->coef.ensure(cbytes);
+    if (rc) return rc;
+    rc = s->ring.upload(s->coef.dptr, hF, cbytes, st);
+    if (rc) return rc;
+    int grid = (int)std::min<int64_t>((s->n + 3) / 4, 4096);
+    if (s->valbytes == 8)
+        return launch_spmm<double>(s, k, (const cplx*)s->coef.dptr, (const cplx*)dQT, ldq, 0, (cplx*)dRT, ldr, nullptr, grid, st);
+    return launch_spmm<cplx>(s, k, (const cplx*)s->coef.dptr, (const cplx*)dQT, ldq, 0, (cplx*)dRT, ldr, nullptr, grid, st);
+}
+
 int32_t nep_spmm_terms(nep_spmf* s, int32_t p, const nep_cdouble* dXT, int64_t ldx, nep_cdouble* dZT,
                        int64_t ldz, nep_stream stream) {
     ARGCHK(s && dXT && dZT);

@@ -1,6 +1,8 @@
 // libnepmi355: error handling, device memory, BLAS-1 style helpers (gfx950).
 #include "common.h"
 #include <vector>
+#include <algorithm>
+#include <math.h>
 
 static thread_local char g_err[1024] = "";
 
@@ -219,6 +221,58 @@ __global__ __launch_bounds__(256) void k_rm2cm(int64_t rows, const cplx* __restr
     }
 }
 
+// out[r] = sum_j A[r + j*lda] * B[r + j*ldb]   (no conjugation)
+__global__ void k_rowdot(int64_t rows, int k, const cplx* __restrict__ A, int64_t lda, const cplx* __restrict__ B,
+                         int64_t ldb, cplx* __restrict__ out) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < rows; r += (int64_t)gridDim.x * blockDim.x) {
+        cplx acc = cmake(0.0, 0.0);
+        for (int j = 0; j < k; ++j) cfma(acc, A[r + (int64_t)j * lda], B[r + (int64_t)j * ldb]);
+        out[r] = acc;
+    }
+}
+// A[r + j*lda] *= B[r + j*ldb]
+__global__ void k_hadamard(int64_t rows, int k, cplx* __restrict__ A, int64_t lda, const cplx* __restrict__ B,
+                           int64_t ldb) {
+    const int64_t total = rows * (int64_t)k;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i % rows, j = i / rows;
+        A[r + j * lda] = cmul(A[r + j * lda], B[r + j * ldb]);
+    }
+}
+// per-block partial column sums of |X[r*ld + s]|^2 of a row-major block; partial[b*k + s]
+__global__ __launch_bounds__(256) void k_rm_colnorm_partial(int64_t rows, int k, const cplx* __restrict__ XT, int64_t ld,
+                                                            double* __restrict__ partial) {
+    // thread t handles column s = t % kk-strided, rows strided by (256/ kpad)
+    extern __shared__ double red[];
+    const int s = threadIdx.x % 64;
+    const int sub = threadIdx.x / 64;       // 4 row phases
+    for (int s0 = 0; s0 < k; s0 += 64) {
+        const int col = s0 + s;
+        double acc = 0.0;
+        if (col < k)
+            for (int64_t r = blockIdx.x * 4LL + sub; r < rows; r += gridDim.x * 4LL) {
+                const cplx v = XT[r * ld + col];
+                acc = fma(v.x, v.x, fma(v.y, v.y, acc));
+            }
+        red[sub * 64 + s] = acc;
+        __syncthreads();
+        if (sub == 0 && col < k)
+            partial[(int64_t)blockIdx.x * k + col] = (red[s] + red[64 + s]) + (red[128 + s] + red[192 + s]);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void k_sum_partials_rows(int nb, int len, const double* __restrict__ partial,
+                                                           double* __restrict__ out) {
+    __shared__ double sm[4];
+    const int j = blockIdx.x;
+    double t = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 256) t += partial[(int64_t)b * len + j];
+    t = wave_reduce_sum(t);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) out[j] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+}
+
 static inline int grid_for(int64_t work, int block, int cap = 4096) {
     int64_t g = (work + block - 1) / block;
     if (g < 1) g = 1;
@@ -289,6 +343,44 @@ int32_t nep_colnorms(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx
 
 int32_t nep_nrm2(int64_t len, const nep_cdouble* dx, double* h_out, nep_stream stream) {
     return nep_colnorms(len, 1, dx, len, h_out, stream);
+}
+
+int32_t nep_rowdot(int64_t rows, int32_t k, const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb,
+                   nep_cdouble* dout, nep_stream stream) {
+    ARGCHK(rows > 0 && k >= 1 && dA && dB && dout);
+    hipLaunchKernelGGL(k_rowdot, dim3(grid_for(rows, 256)), dim3(256), 0, as_stream(stream), rows, (int)k,
+                       (const cplx*)dA, lda, (const cplx*)dB, ldb, (cplx*)dout);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+int32_t nep_hadamard(int64_t rows, int32_t k, nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb,
+                     nep_stream stream) {
+    ARGCHK(rows > 0 && k >= 1 && dA && dB);
+    hipLaunchKernelGGL(k_hadamard, dim3(grid_for(rows * k, 256)), dim3(256), 0, as_stream(stream), rows, (int)k,
+                       (cplx*)dA, lda, (const cplx*)dB, ldb);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+int32_t nep_rowmajor_colnorms(int64_t rows, int32_t k, const nep_cdouble* dXT, int64_t ld, double* h_out,
+                              nep_stream stream) {
+    ARGCHK(rows > 0 && k >= 1 && ld >= k && dXT && h_out);
+    hipStream_t st = as_stream(stream);
+    const int nb = (int)std::min<int64_t>((rows + 3) / 4, 1024);
+    int rc = g_util_scratch.ensure(((size_t)nb * k + k) * sizeof(double));
+    if (rc) return rc;
+    double* partial = (double*)g_util_scratch.dptr;
+    double* outd = partial + (size_t)nb * k;
+    hipLaunchKernelGGL(k_rm_colnorm_partial, dim3(nb), dim3(256), 256 * sizeof(double), st, rows, (int)k,
+                       (const cplx*)dXT, ld, partial);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_sum_partials_rows, dim3(k), dim3(256), 0, st, nb, (int)k, partial, outd);
+    LAUNCHCHK();
+    HIPCHK(hipMemcpyAsync(h_out, outd, (size_t)k * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int j = 0; j < k; ++j) h_out[j] = sqrt(h_out[j]);
+    return NEP_OK;
 }
 
 int32_t nep_rowmajor_to_colmajor(int64_t rows, int32_t k, const nep_cdouble* dsrc, int64_t lds,

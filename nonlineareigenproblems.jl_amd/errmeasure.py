@@ -15,19 +15,10 @@ class Errmeasure:
     pass
 
 
-def _fmat(nep, lams):
-    fv = nep.get_fv()
-    la = np.asarray(lams, dtype=np.complex128)
-    F = np.empty((len(fv), len(la)), dtype=np.complex128, order="F")
-    for i, f in enumerate(fv):
-        F[i, :] = f.values(la)
-    return F
-
-
 def _batch_norms(nep, lams, QT):
-    """QT: device (rows, k) row-major block of the k vectors. Returns (||M(lam_s) q_s||, ||q_s||)."""
-    F = _fmat(nep, lams)
-    return nep.dev.resid_batch(F, QT, len(lams), QT.shape[1]), F
+    """QT: device (rows, k) row-major block of the k vectors. Returns ((||M(lam_s) q_s||, ||q_s||), F)."""
+    rn, qn, F = nep.resid_norms(lams, QT)
+    return (rn, qn), F
 
 
 def _as_QT(v):
@@ -70,7 +61,9 @@ class DefaultErrmeasure(Errmeasure):
     """errmeasure.jl:91-101"""
 
     def __init__(self, nep):
-        self.errm = StandardSPMFErrmeasure(nep) if isinstance(nep, AbstractSPMF) else ResidualErrmeasure(nep)
+        from .wep import WEP
+        spmf = isinstance(nep, AbstractSPMF) and not isinstance(nep, WEP)     # reference: WEP <: NEP, not AbstractSPMF
+        self.errm = StandardSPMFErrmeasure(nep) if spmf else ResidualErrmeasure(nep)
 
     def batch(self, lams, QT):
         return self.errm.batch(lams, QT)

@@ -168,7 +168,13 @@ def qdep0():
     return SPMF_NEP([-sp.identity(n, format="csc"), A0, A1], [funcs.Monomial(2), funcs.one(), funcs.Exp(-1.0)])
 
 
+def _wep(**kw):
+    from .wep import WEP
+    return WEP(**kw)
+
+
 GALLERY = {
+    "WEP": _wep,
     "dep0": dep0,
     "qdep0": qdep0,
     "nlevp_native_gun": nlevp_native_gun,

@@ -61,12 +61,9 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
         tm["host_factorization"] = tm.get("host_factorization", 0.0) + M0inv.lu.t_factor
     v0 = np.asarray(v, dtype=np.complex128)
     V[0, :n] = torch.from_numpy(v0 / np.linalg.norm(v0)).to("cuda")
-    # derivative table at sigma: fD[j,i] = f_i^(j)(sigma)  (DerSPMF, NEPTypes.jl:1108-1128)
-    fv = nep.get_fv()
-    fD = np.column_stack([f.derivs(sigma, m + 1) for f in fv])
-    # coefficient rows C[j-1,:] = alpha_j/j * fD[j,:] do not depend on k: upload once, use the first k rows
-    Cfull = (alpha[1:m + 1] / np.arange(1, m + 1))[:, None] * fD[1:m + 1, :]
-    Cdev = to_dev(Cfull)                                   # (mt, m): column-major m x mt, ldc = m
+    # derivative table at sigma (DerSPMF, NEPTypes.jl:1108-1128).  The coefficient rows
+    # C[j-1,:] = alpha_j/j * f^(j)(sigma) do not depend on k: uploaded once, each step uses the first k rows
+    tab = nep.derivative_table(sigma, m, rowscale=alpha[1:m + 1] / np.arange(1, m + 1))
     z = torch.empty(n, dtype=CDT, device="cuda")
     active = (np.arange(1, m + 2) * n).astype(np.int64)   # column j has (j+1) non-zero blocks
     err = np.full((m, m), np.nan)
@@ -86,7 +83,7 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     def arnoldi_step(k):
         t0 = time.perf_counter()
         # z = sum_{j=1..k} alpha_{j+1}/j * M^(j)(sigma) * V_k block j
-        nep.dev.mlincomb_dev(Cdev, m, k, V.data_ptr() + 16 * (k - 1) * ldv, n, z)
+        nep.lincomb_rowscale(tab, k, V.data_ptr() + 16 * (k - 1) * ldv, n, z)
         sync(); t1 = time.perf_counter()
         # new vector, block 0: -M(sigma)^{-1} z ; blocks 1..k: shifted/scaled old column
         vv = V[k]

@@ -48,6 +48,7 @@ class DeviceLU:
         n = A.shape[0]
         self.n = n
         Ac = sp.csc_matrix(A, dtype=np.complex128)
+        self.normA = float(np.linalg.norm(Ac.data))          # ||A||_F, used by the refinement stopping test
         if permc_spec is None or symmetric_mode is None:
             sym = _pattern_symmetric(Ac)
             if permc_spec is None:
@@ -132,10 +133,8 @@ class FactorizeLinSolver(LinSolver):
         self._W = None
 
     def _refine_setup(self):
-        if self._C is None:
-            fv = self.nep.get_fv()
-            self._C = np.array([[f(self.lam) for f in fv]], dtype=np.complex128)       # 1 x mt
-            self._normM = float(np.dot(self.nep.fro_norms(), np.abs(self._C[0])))       # >= ||M(lam)||_F
+        if self._W is None:
+            self._normM = self.lu.normA
             n = self.lu.n
             self._W = torch.empty((4, n), dtype=CDT, device="cuda")                      # r, x, b, dx
 
@@ -143,7 +142,7 @@ class FactorizeLinSolver(LinSolver):
         """device solve; b: (n,) or (nrhs, n) tensor"""
         self.solves += 1
         single = b.dim() == 1 or b.shape[0] == 1
-        if not single or self.umfpack_refinements <= 0 or not hasattr(self.nep, "dev"):
+        if not single or self.umfpack_refinements <= 0 or not hasattr(self.nep, "compute_Mlincomb"):
             return self.lu.solve(b, out=out, scale=scale)
         self._refine_setup()
         n = self.lu.n
@@ -155,8 +154,8 @@ class FactorizeLinSolver(LinSolver):
         self.lu.solve(bd, out=x.reshape(1, n))
         w_prev = np.inf
         for step in range(self.umfpack_refinements + 1):
-            # r = b - M x
-            self.nep.dev.mlincomb(self._C, x.reshape(1, n), W[0])
+            # r = b - M(lam) x   (K1 through the NEP, so extra non-SPMF terms are included)
+            dense.copy(self.nep.compute_Mlincomb(self.lam, x.reshape(1, n)), W[0], n)
             dense.scal(W[0], -1.0, n)
             dense.axpy(1.0, W[2], W[0], n)
             nr = np.empty(3)

@@ -225,6 +225,36 @@ class AbstractSPMF(NEP):
             return ZT.cpu().numpy()
         return ZT.t().contiguous()
 
+    # ---- driver-facing hooks: every Krylov driver goes through these three, so a NEP type with extra
+    # non-SPMF structure (the WEP corner term) only overrides them
+    def derivative_table(self, sigma, m, rowscale=None):
+        """fD[j,i] = f_i^(j)(sigma), j = 0..m (DerSPMF, NEPTypes.jl:1108-1128).  With `rowscale` (length m) the
+        block C[j-1,:] = rowscale[j-1]*fD[j,:] is uploaded once; lincomb_rowscale then uses its first k rows."""
+        fD = np.column_stack([f.derivs(sigma, m + 1) for f in self.get_fv()])
+        tab = {"fD": fD, "m": m, "sigma": sigma}
+        if rowscale is not None:
+            tab["Cdev"] = to_dev(np.asarray(rowscale)[:, None] * fD[1:m + 1, :])      # (mt, m): ldc = m
+        return tab
+
+    def lincomb_rowscale(self, tab, k, V, ldv, z):
+        """z = sum_{j=1..k} rowscale_j M^(j)(sigma) V[:, j-1]   (V: device address or tensor, leading dim ldv)"""
+        return self.dev.mlincomb_dev(tab["Cdev"], tab["m"], k, V, ldv, z)
+
+    def lincomb_general(self, tab, G, V, k, ldv, z):
+        """z = sum_{j<k} sum_{q} G[j,q] M^(q+1)(sigma) V[:, j]   (G: k x q host matrix)"""
+        C = G @ tab["fD"][1:G.shape[1] + 1, :]
+        return self.dev.mlincomb(C, V, z, k=k, ldv=ldv)
+
+    def resid_norms(self, lams, QT):
+        """(||M(lam_s) q_s||, ||q_s||, F) for the k columns of the row-major block QT"""
+        fv = self.get_fv()
+        la = np.asarray(lams, dtype=np.complex128)
+        F = np.empty((len(fv), len(la)), dtype=np.complex128, order="F")
+        for i, f in enumerate(fv):
+            F[i, :] = f.values(la)
+        rn, qn = self.dev.resid_batch(F, QT, len(la), QT.shape[1])
+        return rn, qn, F
+
     def fro_norms(self):
         if self._fro is None:
             self._fro = [float(np.linalg.norm(A.data)) if sp.issparse(A) else float(np.linalg.norm(A))

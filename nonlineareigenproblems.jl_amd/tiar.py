@@ -64,7 +64,7 @@ def tiar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     v0 = np.asarray(v, dtype=np.complex128)
     Z[0] = torch.from_numpy(v0 / np.linalg.norm(v0)).to("cuda")
     a[0, 0, 0] = 1
-    fD = np.column_stack([f.derivs(sigma, m + 1) for f in nep.get_fv()])
+    tab = nep.derivative_table(sigma, m)
     z = torch.empty(n, dtype=CDT, device="cuda")
     conv_eig_hist = np.zeros(m + 1, dtype=int)
     lam = np.zeros(0, dtype=np.complex128); QT = None; idx = np.zeros(0, dtype=int)
@@ -72,12 +72,12 @@ def tiar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     while k <= m and conv_eig < neigs:
         t0 = time.perf_counter()
         Bs = a[:k, k - 1, :k].T / np.arange(1, k + 1)[None, :]          # k x k, column j scaled by 1/(j+1)
-        Cm = alpha[1:k + 1, None] * fD[1:k + 1, :]                       # k x mt
         if fused:
-            nep.dev.mlincomb(Bs @ Cm, Z, z, k=k, ldv=n)
+            # z = sum_i A_i Z (Bs diag(alpha) fD_i): coefficient matrix G = Bs * alpha (k x k), no GEMM on Z
+            nep.lincomb_general(tab, Bs * alpha[None, 1:k + 1], Z, k, n, z)
         else:
             Y = dense.gemm_ts(Z, Bs, k=k, rows=n, ldz=n)
-            nep.dev.mlincomb(Cm, Y, z)
+            nep.lincomb_general(tab, np.diag(alpha[1:k + 1]), Y, k, n, z)
         sync(); t1 = time.perf_counter()
         M0inv.solve_dev(z, out=Z[k].reshape(1, n), scale=-1.0)
         sync(); t2 = time.perf_counter()

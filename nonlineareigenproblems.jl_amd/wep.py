@@ -111,3 +111,167 @@ class WaveguideData:
         """the 2 nz corner functions s_j(lam) = 1im*sqrt(lam^2 + b_j lam + c_j) + d0 (branch Im sqrt >= 0)"""
         return ([funcs.WEPSqrt(self.b[j], self.cM[j], self.d0) for j in range(self.nz)] +
                 [funcs.WEPSqrt(self.b[j], self.cP[j], self.d0) for j in range(self.nz)])
+
+
+# =================================================================================================
+# device NEP
+import ctypes as C
+
+import torch
+
+from . import _lib, dense
+from ._lib import lib, check, hptr, c_vp
+from .nep import AbstractSPMF, CDT, to_dev, to_host, is_dev, stream_ptr
+
+
+def _corner_derivs(wd, lam, k, scale=1.0):
+    """D[r, j] = scale^j s_r^(j)(lam), r < 2 nz, j < k, vectorised over the 2 nz corner functions
+    (same Taylor-coefficient recurrence as funcs.WEPSqrt; Waveguide.jl:580-616 computes the same numbers)."""
+    lam = complex(lam)
+    b = np.concatenate([wd.b, wd.b]); c = np.concatenate([wd.cM, wd.cP]).astype(np.complex128)
+    q0 = lam * lam + b * lam + c
+    s0 = np.sqrt(q0)
+    sg = np.sign(q0.imag); sg[sg == 0] = 1.0
+    t = np.zeros((2 * wd.nz, max(k, 1)), dtype=np.complex128)
+    t[:, 0] = sg * s0
+    q1 = (2 * lam + b) * scale
+    q2 = scale * scale
+    for m in range(1, k):
+        qm = q1 if m == 1 else (q2 if m == 2 else 0.0)
+        acc = np.zeros(2 * wd.nz, dtype=np.complex128)
+        for i in range(1, m):
+            acc += t[:, i] * t[:, m - i]
+        t[:, m] = (qm - acc) / (2 * t[:, 0])
+    fact = np.cumprod(np.concatenate([[1.0], np.arange(1, max(k, 1))]))
+    D = 1j * t[:, :k] * fact[None, :k]
+    D[:, 0] += wd.d0
+    return D
+
+
+class WEP(AbstractSPMF):
+    """Waveguide eigenvalue problem on the device: 3 real sparse terms (stacked CSR / SELL) + factored corner.
+    Mirrors `nep_gallery(WEP, nx=, nz=, benchmark_problem=, neptype=, delta=)` (GalleryWaveguide.jl:60-94); both
+    reference formats ("SPMF" and "WEP") describe this same operator (test/wep_small.jl:13-22)."""
+
+    def __init__(self, nx=3 * 5 * 7, nz=3 * 5 * 7, benchmark_problem="TAUSCH", delta=0.1):
+        self.wd = WaveguideData(nx, nz, benchmark_problem, delta)
+        self.n = self.wd.n
+        self.nx, self.nz = self.wd.nx, self.wd.nz
+        self.N = self.nx * self.nz
+        self.A = self.wd.big_matrices()
+        self.fi = [funcs.one(), funcs.ident(), funcs.Monomial(2)]
+        self._Rm = None
+
+    def get_Av(self):
+        return self.A
+
+    def get_fv(self):
+        return self.fi
+
+    # ---- corner data on the device
+    def _corner_dev(self):
+        if self._Rm is None:
+            _lib.require_gpu()
+            Rm = self.wd.Rmat()
+            self._Rm = to_dev(Rm)                         # column-major nz x nz
+            self._RmH = to_dev(Rm.conj().T)
+        return self._Rm, self._RmH
+
+    def _corner_lincomb(self, Dtab, V, ldv, k, z):
+        """z[N:] += blkdiag(Rm,Rm) * sum_j Dtab[:, j] .* (blkdiag(Rm,Rm)^H V[N:, j]) / nz
+        Dtab: device tensor (k, 2nz) = column-major 2nz x k table (1/nz already folded in)."""
+        Rm, RmH = self._corner_dev()
+        nz, N = self.nz, self.N
+        va = V.data_ptr() if is_dev(V) else V
+        st = stream_ptr()
+        P = torch.empty((k, nz), dtype=CDT, device="cuda")
+        t = torch.empty(nz, dtype=CDT, device="cuda")
+        y = torch.empty(nz, dtype=CDT, device="cuda")
+        for half in (0, 1):
+            row0 = N + half * nz
+            check(lib.nep_gemm_ts_dev(c_vp(RmH.data_ptr()), nz, nz, nz, c_vp(va + 16 * row0), ldv, 0, k,
+                                      c_vp(P.data_ptr()), nz, 0, st))
+            check(lib.nep_rowdot(nz, k, c_vp(P.data_ptr()), nz, c_vp(Dtab.data_ptr() + 16 * half * nz), 2 * nz,
+                                 c_vp(t.data_ptr()), st))
+            check(lib.nep_gemm_ts_dev(c_vp(Rm.data_ptr()), nz, nz, nz, c_vp(t.data_ptr()), nz, 0, 1,
+                                      c_vp(y.data_ptr()), nz, 0, st))
+            check(lib.nep_axpy(nz, _lib.cd(1.0), c_vp(y.data_ptr()), c_vp(z.data_ptr() + 16 * row0), st))
+        return z
+
+    # ---- driver hooks
+    def derivative_table(self, sigma, m, rowscale=None):
+        tab = super().derivative_table(sigma, m, rowscale)
+        Dc = _corner_derivs(self.wd, sigma, m + 1) / self.nz          # 2nz x (m+1)
+        tab["Dc"] = Dc
+        if rowscale is not None:
+            tab["Dcdev"] = to_dev(Dc[:, 1:m + 1] * np.asarray(rowscale)[None, :])   # (m, 2nz)
+        return tab
+
+    def lincomb_rowscale(self, tab, k, V, ldv, z):
+        super().lincomb_rowscale(tab, k, V, ldv, z)
+        return self._corner_lincomb(tab["Dcdev"], V, ldv, k, z)
+
+    def lincomb_general(self, tab, G, V, k, ldv, z):
+        super().lincomb_general(tab, G, V, k, ldv, z)
+        Deff = tab["Dc"][:, 1:G.shape[1] + 1] @ G.T                      # 2nz x k
+        return self._corner_lincomb(to_dev(Deff), V, ldv, k, z)
+
+    def compute_Mlincomb(self, lam, V, a=None, startder=0):
+        host = not is_dev(V)
+        Vd = to_dev(V) if host else (V if V.dim() == 2 else V.reshape(1, -1))
+        k = Vd.shape[0]
+        a = np.ones(k) if a is None else np.asarray(a, dtype=np.complex128)
+        z = self.dev.mlincomb(self.coeff_block(lam, a, startder), Vd)
+        D = _corner_derivs(self.wd, lam, k + startder)[:, startder:] / self.nz
+        D = np.where((a != 0)[None, :], D * a[None, :], 0.0)
+        self._corner_lincomb(to_dev(D), Vd, Vd.shape[1], k, z)
+        return to_host(z.reshape(1, -1))[:, 0] if host else z
+
+    def corner_matrix(self, lam, i=0):
+        """dense 2nz x 2nz corner block of M^(i)(lam) (host)"""
+        Rm = self.wd.Rmat(); nz = self.nz
+        s = _corner_derivs(self.wd, lam, i + 1)[:, i]
+        Pm = np.zeros((2 * nz, 2 * nz), dtype=np.complex128)
+        Pm[:nz, :nz] = (Rm * s[:nz][None, :]) @ Rm.conj().T / nz
+        Pm[nz:, nz:] = (Rm * s[nz:][None, :]) @ Rm.conj().T / nz
+        return Pm
+
+    def compute_Mder(self, lam, i=0):
+        """explicit M^(i)(lam) (sparse with the dense corner) for the host factorisation.  The reference's WEP_FD has
+        no compute_Mder (Waveguide.jl:384-386) and solves through a Schur complement; the SPMF format does."""
+        M = sp.lil_matrix(super().compute_Mder(lam, i), dtype=np.complex128)
+        M[self.N:, self.N:] = self.corner_matrix(lam, i)
+        return sp.csc_matrix(M)
+
+    def resid_norms(self, lams, QT):
+        la = np.asarray(lams, dtype=np.complex128)
+        k = len(la)
+        F = np.empty((3, k), dtype=np.complex128, order="F")
+        for i, f in enumerate(self.fi):
+            F[i, :] = f.values(la)
+        n, nz, N = self.n, self.nz, self.N
+        ldq = QT.shape[1]
+        st = stream_ptr()
+        RT = torch.empty((n, k), dtype=CDT, device="cuda")
+        check(lib.nep_resid_block(self.dev.h, k, hptr(F), c_vp(QT.data_ptr()), ldq, c_vp(RT.data_ptr()), k, st))
+        # corner: R[N:, s] += Rfull diag(s(lam_s)) Rfull^H Q[N:, s] / nz
+        Rm, RmH = self._corner_dev()
+        S = np.column_stack([_corner_derivs(self.wd, l, 1)[:, 0] for l in la]) / nz      # 2nz x k
+        Sd = to_dev(S)
+        P = torch.empty((k, nz), dtype=CDT, device="cuda")
+        Y = torch.empty((nz, k), dtype=CDT, device="cuda")
+        for half in (0, 1):
+            row0 = N + half * nz
+            check(lib.nep_gemm_ts_dev(c_vp(RmH.data_ptr()), nz, nz, nz, c_vp(QT.data_ptr() + 16 * row0 * ldq), ldq, 1, k,
+                                      c_vp(P.data_ptr()), nz, 0, st))
+            check(lib.nep_hadamard(nz, k, c_vp(P.data_ptr()), nz, c_vp(Sd.data_ptr() + 16 * half * nz), 2 * nz, st))
+            check(lib.nep_gemm_ts_dev(c_vp(Rm.data_ptr()), nz, nz, nz, c_vp(P.data_ptr()), nz, 0, k,
+                                      c_vp(Y.data_ptr()), k, 1, st))
+            check(lib.nep_axpy(nz * k, _lib.cd(1.0), c_vp(Y.data_ptr()), c_vp(RT.data_ptr() + 16 * row0 * k), st))
+        rn = np.empty(k); qn = np.empty(k)
+        check(lib.nep_rowmajor_colnorms(n, k, c_vp(RT.data_ptr()), k, hptr(rn), st))
+        check(lib.nep_rowmajor_colnorms(n, k, c_vp(QT.data_ptr()), ldq, hptr(qn), st))
+        return rn, qn, F
+
+    def fro_norms(self):
+        raise TypeError("StandardSPMFErrmeasure is not defined for the WEP (use ResidualErrmeasure)")

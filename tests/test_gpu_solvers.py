@@ -207,3 +207,41 @@ def test_beyn_gun_twin_vs_oracle(na):
     _match(lg, lo, 1e-7)
     oE = osol.StandardSPMFErrmeasure(onep)
     assert max(oE(lg[i], Vg[:, i]) for i in range(len(lg))) < 1e-6
+
+
+def test_wep_mlincomb_vs_oracle(na):
+    # test/wep_small.jl:13-22 (SPMF == WEP_FD); here device WEP == oracle WEP_FD == oracle literal SPMF
+    from oracle import wep as ow
+    nep = na.nep_gallery("WEP", nx=11, nz=7, benchmark_problem="TAUSCH")
+    o = ow.WEP_FD(11, 7, "TAUSCH")
+    lam = -1.3 - 0.31j
+    v1 = nep.compute_Mlincomb(lam, np.ones(nep.n)); v2 = o.compute_Mlincomb(lam, np.ones(o.n))
+    assert np.linalg.norm(v1 - v2) / np.linalg.norm(v2) < 1e-13
+    rng = np.random.default_rng(0)
+    V = rng.standard_normal((nep.n, 5)) + 1j * rng.standard_normal((nep.n, 5))
+    a = np.array([1.0, 0.5, 0.0, -2.0, 0.3])
+    z1 = nep.compute_Mlincomb(lam, V, a); z2 = o.compute_Mlincomb(lam, V, a)
+    assert np.linalg.norm(z1 - z2) / np.linalg.norm(z2) < 1e-12
+    z1 = nep.compute_Mlincomb(lam, V[:, :2], a[:2], 1); z2 = o.compute_Mlincomb(lam, V[:, :2], a[:2], 1)
+    assert np.linalg.norm(z1 - z2) / np.linalg.norm(z2) < 1e-12
+    # residual error measure incl. corner term
+    e = na.estimate_error(na.ResidualErrmeasure(nep), lam, V[:, 0])
+    assert e == pytest.approx(np.linalg.norm(o.compute_Mlincomb(lam, V[:, 0])) / np.linalg.norm(V[:, 0]), rel=1e-11)
+
+
+def test_wep_reference_eigenvalue(na):
+    """test/wep_small.jl:31-36,73-76: JARLEBRING nx=109 nz=105, iar(sigma=-3-3.5i, neigs=3, maxit=100, tol=1e-8)
+    finds lambda_ref = -2.743228671961724-3.1439375599649972i to 1e-10; tiar finds it too."""
+    lref = -2.743228671961724 - 3.1439375599649972j
+    nep = na.nep_gallery("WEP", nx=109, nz=105, benchmark_problem="JARLEBRING")
+    n = nep.n
+    v0 = np.ones(n) / np.sqrt(n)
+    lam, Q, _ = na.iar(nep, sigma=-3 - 3.5j, neigs=3, maxit=100, v=v0, tol=1e-8)
+    assert len(lam) == 3 and min(abs(lref - lam)) < 1e-10
+    from oracle import wep as ow, solvers as osol
+    o = ow.WEP_FD(109, 105, "JARLEBRING")
+    R = osol.ResidualErrmeasure(o)
+    assert max(R(lam[i], Q[:, i]) for i in range(3)) < 1e-8          # independent host re-evaluation
+    lam2, Q2, _, _ = na.tiar(nep, sigma=-3 - 3.5j, neigs=3, maxit=100, v=v0, tol=1e-8)
+    assert len(lam2) == 3 and min(abs(lref - lam2)) < 1e-10
+    assert max(R(lam2[i], Q2[:, i]) for i in range(3)) < 1e-8
