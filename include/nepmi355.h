@@ -165,6 +165,14 @@ int32_t nep_lu_solve(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_t ld
 /* iar basis step (src/method_iar.jl:100-101,105): dst[(j+1)*n + r] = src[j*n + r]/(j+1), j=0..k-1 */
 int32_t nep_iar_shift_scale(int64_t n, int32_t k, const nep_cdouble* dsrc, nep_cdouble* ddst,
                             nep_stream stream);
+/* NLEIGS continuation-vector helpers (src/method_nleigs.jl:399-518, backslash):
+ *   nep_rk_bw:       Bw[0:n] = 0; Bw[i n + r] = wc[(i-1) n + r] + c[i-1]*wc[i n + r], i = 1..N     (:418-435)
+ *   nep_block_recur: x_i = a[i-1]*y_i + b[i-1]*x_{i-1}, i = 1..N, blocks of n entries, x_0 given   (:445-487, :496-515)
+ * h_c, h_a, h_b are host arrays of N complex coefficients. */
+int32_t nep_rk_bw(int64_t n, int32_t N, const nep_cdouble* dwc, const nep_cdouble* h_c, nep_cdouble* dBw,
+                  nep_stream stream);
+int32_t nep_block_recur(int64_t n, int32_t N, const nep_cdouble* h_a, const nep_cdouble* h_b, const nep_cdouble* dy,
+                        nep_cdouble* dx, nep_stream stream);
 /* y += alpha * x   (len complex entries); K8 quadrature accumulation
  * src/method_contour_common.jl:88-90 (S[:,:,j] += temp*G[i,j]) */
 int32_t nep_axpy(int64_t len, nep_cdouble alpha, const nep_cdouble* dx, nep_cdouble* dy,

@@ -19,6 +19,8 @@ from .dense import gemm_ts, orthogonalize_and_normalize, DGKS, CGS, MGS
 from .iar import iar
 from .tiar import tiar
 from .newton import resinv, quasinewton, compute_rf, armijo_rule, ScalarNewtonInnerSolver
+from .nleigs import nleigs
+from . import rk_helper
 from .contour import (contour_beyn, integrate_interval, MatrixIntegrator, MatrixTrapezoidal,
                       MatrixTrapezoidalSharded, probe_block)
 from . import gallery

@@ -71,6 +71,8 @@ SIGNATURES = {
     "nep_lu_schedule": [c_vp, P(c_i64)],
     "nep_lu_solve": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp],
     "nep_iar_shift_scale": [c_i64, c_i32, c_vp, c_vp, c_vp],
+    "nep_rk_bw": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "nep_block_recur": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "nep_axpy": [c_i64, cdouble, c_vp, c_vp, c_vp],
     "nep_scal": [c_i64, cdouble, c_vp, c_vp],
     "nep_nrm2": [c_i64, c_vp, P(c_dbl), c_vp],

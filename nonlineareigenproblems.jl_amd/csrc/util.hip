@@ -273,6 +273,33 @@ __global__ __launch_bounds__(256) void k_sum_partials_rows(int nb, int len, cons
     if (threadIdx.x == 0) out[j] = (sm[0] + sm[1]) + (sm[2] + sm[3]);
 }
 
+// NLEIGS continuation vector, block form (src/method_nleigs.jl:418-435):
+//   Bw[0:n] = 0 ;  Bw[i n + r] = wc[(i-1) n + r] + c[i-1] * wc[i n + r],  i = 1..N
+__global__ void k_rk_bw(int64_t n, int N, const cplx* __restrict__ wc, const cplx* __restrict__ c, cplx* __restrict__ Bw) {
+    const int64_t total = n * (int64_t)(N + 1);
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / n;
+        if (i == 0) { Bw[t] = cmake(0.0, 0.0); continue; }
+        cplx v = wc[t - n];
+        cfma(v, c[i - 1], wc[t]);
+        Bw[t] = v;
+    }
+}
+// block recurrence x_i = a[i-1]*y_i + b[i-1]*x_{i-1}, i = 1..N (blocks of n entries, x_0 given; y may alias x)
+// (src/method_nleigs.jl:445-487 for z, :496-515 for w); one thread per row, sequential over the blocks
+__global__ void k_block_recur(int64_t n, int N, const cplx* __restrict__ a, const cplx* __restrict__ b, const cplx* y,
+                              cplx* x) {
+    for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < n; r += (int64_t)gridDim.x * blockDim.x) {
+        cplx prev = x[r];
+        for (int i = 1; i <= N; ++i) {
+            cplx v = cmul(a[i - 1], y[(int64_t)i * n + r]);
+            cfma(v, b[i - 1], prev);
+            x[(int64_t)i * n + r] = v;
+            prev = v;
+        }
+    }
+}
+
 static inline int grid_for(int64_t work, int block, int cap = 4096) {
     int64_t g = (work + block - 1) / block;
     if (g < 1) g = 1;
@@ -343,6 +370,40 @@ int32_t nep_colnorms(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx
 
 int32_t nep_nrm2(int64_t len, const nep_cdouble* dx, double* h_out, nep_stream stream) {
     return nep_colnorms(len, 1, dx, len, h_out, stream);
+}
+
+static NepScratch g_rk_scratch;
+static PinnedRing g_rk_ring;
+
+int32_t nep_rk_bw(int64_t n, int32_t N, const nep_cdouble* dwc, const nep_cdouble* h_c, nep_cdouble* dBw, nep_stream stream) {
+    ARGCHK(n > 0 && N >= 0 && dwc && dBw && (N == 0 || h_c));
+    hipStream_t st = as_stream(stream);
+    int rc = g_rk_scratch.ensure((size_t)(2 * N + 2) * sizeof(cplx));
+    if (rc) return rc;
+    if (N > 0) { rc = g_rk_ring.upload(g_rk_scratch.dptr, h_c, (size_t)N * sizeof(cplx), st); if (rc) return rc; }
+    hipLaunchKernelGGL(k_rk_bw, dim3(grid_for(n * (N + 1), 256)), dim3(256), 0, st, n, (int)N, (const cplx*)dwc,
+                       (const cplx*)g_rk_scratch.dptr, (cplx*)dBw);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+int32_t nep_block_recur(int64_t n, int32_t N, const nep_cdouble* h_a, const nep_cdouble* h_b, const nep_cdouble* dy,
+                        nep_cdouble* dx, nep_stream stream) {
+    ARGCHK(n > 0 && N >= 0 && dy && dx);
+    if (N == 0) return NEP_OK;
+    ARGCHK(h_a && h_b);
+    hipStream_t st = as_stream(stream);
+    int rc = g_rk_scratch.ensure((size_t)(2 * N + 2) * sizeof(cplx));
+    if (rc) return rc;
+    std::vector<nep_cdouble> ab(2 * (size_t)N);
+    for (int i = 0; i < N; ++i) { ab[i] = h_a[i]; ab[N + i] = h_b[i]; }
+    rc = g_rk_ring.upload(g_rk_scratch.dptr, ab.data(), ab.size() * sizeof(cplx), st);
+    if (rc) return rc;
+    const cplx* da = (const cplx*)g_rk_scratch.dptr;
+    hipLaunchKernelGGL(k_block_recur, dim3(grid_for(n, 256)), dim3(256), 0, st, n, (int)N, da, da + N, (const cplx*)dy,
+                       (cplx*)dx);
+    LAUNCHCHK();
+    return NEP_OK;
 }
 
 int32_t nep_rowdot(int64_t rows, int32_t k, const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb,

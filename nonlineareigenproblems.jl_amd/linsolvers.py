@@ -253,11 +253,17 @@ class LinSolverCache:
         self.linsolvercreator = linsolvercreator
         self.solvers = {}
 
-    def solve(self, sigma, y, add_to_cache):
+    def _get(self, sigma, add_to_cache):
         key = complex(sigma)
         if key in self.solvers:
-            return lin_solve(self.solvers[key], y)
+            return self.solvers[key]
         solver = create_linsolver(self.linsolvercreator, self.nep, sigma)
         if add_to_cache:
             self.solvers[key] = solver
-        return lin_solve(solver, y)
+        return solver
+
+    def solve(self, sigma, y, add_to_cache):
+        return lin_solve(self._get(sigma, add_to_cache), y)
+
+    def solve_dev(self, sigma, y, add_to_cache, out=None, scale=1.0):
+        return self._get(sigma, add_to_cache).solve_dev(y, out=out, scale=scale)

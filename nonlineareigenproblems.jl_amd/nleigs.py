@@ -1,0 +1,196 @@
+"""NLEIGS (fully rational Krylov) on the device backend -- keyword surface of src/method_nleigs.jl:60-81.
+
+Supported: SPMF-type NEPs (PEP, SPMF_NEP, PEP+SPMF SumNEP, DEP), dynamic variant (static=false), matrix-function
+divided differences (isfunm=true), leja in {0,1,2}, reusefact in {0,1,2}; not supported: the LowRankFactorizedNEP
+compression (rk_nep.jl:59-67), static=true, return_details=true, non-SPMF NEPs.
+
+Device realisation of `backslash` (method_nleigs.jl:399-518).  The reference runs O(N) stacked SpMVs per step
+(`sum(reshape(BBCC*z_block,n,:) .* transpose(sgdd[:,ii+1]),dims=2)`, :462).  The block recurrence for z does not
+depend on z[1:n], so here
+   Bw          one pass            (nep_rk_bw)
+   z blocks    one pass, sequential over the N blocks inside each thread   (nep_block_recur)
+   z0          ONE K1 call with k = N columns:  sum_j A_j (Z_blocks * sgdd[j,2:N+1]^T)   (nep_mlincomb)
+   w0          K5 with the cached factorisation of the shift (LinSolverCache), scaled by -1/beta_1
+   w blocks    one pass            (nep_block_recur)
+followed by K6 DGKS on the (N+1) n-row basis with per-column active row counts, and -- every check_error_every
+steps -- host `eig(K,H)`, one K7 GEMM for the Ritz block and K2 for all residuals.
+"""
+import numpy as np
+import scipy.linalg as sla
+import torch
+
+from . import dense, rk_helper as rk
+from ._lib import lib, check, hptr, c_vp
+from .errmeasure import ResidualErrmeasure, estimate_errors
+from .linsolvers import DefaultLinSolverCreator, LinSolverCache, create_linsolver
+from .nep import CDT, to_dev, to_host, stream_ptr
+
+EPS = np.finfo(float).eps
+
+
+def _c128(x):
+    return np.ascontiguousarray(x, dtype=np.complex128)
+
+
+def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger=0, maxdgr=100, minit=20, maxit=200,
+           linsolvercreator=None, tol=1e-10, tollin=None, v=None, errmeasure=None, isfunm=True, static=False, leja=1,
+           nodes=(), reusefact=1, blksize=20, return_details=False, check_error_every=5, info=None):
+    if static or return_details or not isfunm:
+        raise NotImplementedError("nleigs on the device backend supports static=false, return_details=false, isfunm=true")
+    if tollin is None:
+        tollin = max(tol / 10, 100 * EPS)
+    if linsolvercreator is None:
+        linsolvercreator = DefaultLinSolverCreator()
+    if errmeasure is None:
+        errmeasure = ResidualErrmeasure(nep)
+    Sigma = np.asarray(Sigma, dtype=complex); Xi = np.asarray(Xi, dtype=float)
+    nodes = np.asarray(nodes, dtype=complex)
+    n = nep.size(1)
+    p, q = rk.rk_structure(nep)
+    mt = len(nep.get_Av())
+    if n == 1:
+        maxdgr = maxit + 1
+    if v is None:
+        v = np.random.randn(n) + 0j
+    cache = LinSolverCache(nep, linsolvercreator)
+
+    # ---- interpolation nodes, poles, scaling (method_nleigs.jl:121-146)
+    if leja == 0:
+        if len(nodes) == 0:
+            raise ValueError("Interpolation nodes must be provided via 'nodes' when no Leja-Bagby points ('leja' == 0) are used.")
+        gamma, _ = rk.discretizepolygon(Sigma)
+        max_count = max(maxit, maxdgr) + 2
+        sigma = np.tile(nodes, int(np.ceil(max_count / len(nodes))))
+        _, xi, beta = rk.lejabagby(sigma[:maxdgr + 2], Xi, gamma, maxdgr + 2, True, p)
+    elif leja == 1:
+        if len(nodes) == 0:
+            gamma, nodes = rk.discretizepolygon(Sigma, True)
+        else:
+            gamma, _ = rk.discretizepolygon(Sigma)
+        nodes = np.tile(nodes, int(np.ceil((maxit + 1) / len(nodes))))
+        sigma, xi, beta = rk.lejabagby(gamma, Xi, gamma, maxdgr + 2, False, p)
+    else:
+        gamma, _ = rk.discretizepolygon(Sigma)
+        max_count = max(maxit, maxdgr) + 2
+        sigma, xi, beta = rk.lejabagby(gamma, Xi, gamma, max_count, False, p)
+    sigma = np.array(sigma, dtype=complex); xi = np.array(xi, dtype=float); beta = np.array(beta, dtype=float)
+    xi[maxdgr + 1] = np.nan
+    rng_ = slice(0, maxdgr + 2)
+    sgdd = rk.scgendivdiffs(sigma[rng_], xi[rng_], beta[rng_], nep.get_fv())        # mt x (maxdgr+2)
+    nrmD = [float(np.max(abs(sgdd[:, 0])))]
+    if not np.isfinite(nrmD[0]):
+        raise ValueError("The generalized divided differences must be finite.")
+
+    # ---- device state: V ((kmax+2) n x (kmax+2)), work vectors of (kmax+2) n entries
+    kmax = maxit
+    ldv = (kmax + 2) * n
+    V = torch.zeros((kmax + 2, ldv), dtype=CDT, device="cuda")
+    Bw = torch.empty(ldv, dtype=CDT, device="cuda")
+    zb = torch.empty(ldv, dtype=CDT, device="cuda")
+    tmp = torch.empty(n, dtype=CDT, device="cuda")
+    H = np.zeros((kmax + 2, kmax + 1), dtype=complex); K = np.zeros((kmax + 2, kmax + 1), dtype=complex)
+    active = np.zeros(kmax + 2, dtype=np.int64)
+    st = stream_ptr
+
+    v0 = _c128(v) / np.linalg.norm(v)
+    x0 = cache.solve(sigma[0], to_dev(v0)[0], reusefact == 2)
+    nx0 = dense.nrm2(x0)
+    dense.copy(x0, V[0], n); dense.scal(V[0], 1.0 / nx0, n)
+    active[0] = n
+
+    expand = True
+    kconv = np.iinfo(np.int64).max // 2
+    kn = n; l = 0; N = 0; nbconv = 0; nblamin = 0
+    res_state = {"lam": np.zeros(0, dtype=complex), "QT": None, "ilam": np.zeros(0, dtype=int), "res": np.zeros(0),
+                 "conv": np.zeros(0, dtype=bool)}
+
+    def backslash(k, l):
+        """w = continuation solve for column l-1 of V; result in V[l][:kn]"""
+        shift = sigma[k]
+        wc = V[l - 1]
+        with np.errstate(all="ignore"):
+            cB = _c128(beta[1:N + 1] / xi[:N])                                    # beta[ii+1]/xi[ii]
+            check(lib.nep_rk_bw(n, N, c_vp(wc.data_ptr()), hptr(cB), c_vp(Bw.data_ptr()), st()))
+            # z blocks: z_1 = Bw_1/nu_1 ; z_i = Bw_i/nu_i + (mu_i/nu_i) z_{i-1}
+            nu = beta[1:N + 1] * (1 - shift / xi[:N])
+            a = _c128(1.0 / nu)
+            b = np.zeros(N, dtype=np.complex128)
+            if N > 1:
+                b[1:] = (shift - sigma[1:N]) / nu[1:]
+            dense.copy(Bw, zb, (N + 1) * n)
+            check(lib.nep_block_recur(n, N, hptr(a), hptr(b), c_vp(zb.data_ptr()), c_vp(zb.data_ptr()), st()))
+            # z0 = -sum_j A_j (Zblocks sgdd[j, 1:N+1]^T)   (Bw[0:n] = 0 without low-rank structure)
+            Cm = np.asfortranarray(sgdd[:, 1:N + 1].T)                             # N x mt
+            nep.dev.mlincomb(Cm, zb.data_ptr() + 16 * n, tmp, k=N, ldv=n)
+            add_to_cache = ((not expand or k > kconv) and reusefact == 1) or reusefact == 2
+            w = V[l]
+            w0 = cache.solve_dev(shift, tmp, add_to_cache, out=w[:n], scale=-1.0 / beta[0])
+            # w_i = (mu_i/nu_i) w_{i-1} + Bw_i/nu_i
+            mu = shift - sigma[:N]
+            bw = _c128(mu / nu)
+            check(lib.nep_block_recur(n, N, hptr(a), hptr(bw), c_vp(Bw.data_ptr()), c_vp(w.data_ptr()), st()))
+        return w
+
+    def check_convergence(k, l):
+        lambda_, S = sla.eig(K[:l, :l], H[:l, :l])
+        lamin = rk.in_Sigma(lambda_, Sigma, tol)
+        ilam = np.nonzero(lamin)[0]
+        lam = lambda_[ilam]
+        S = S.copy()
+        for i in ilam:
+            S[:, i] /= np.linalg.norm(H[:l + 1, :l] @ S[:, i])
+        if len(ilam):
+            QT = dense.gemm_ts(V, H[:l + 1, :l] @ S[:, ilam], rowmajor=True, k=l + 1, rows=n, ldz=ldv)
+            res = estimate_errors(errmeasure, lam, QT)
+        else:
+            QT = None; res = np.zeros(0)
+        conv = np.abs(res) < tol
+        res_state.update(lam=lam, QT=QT, ilam=ilam, res=res, conv=conv)
+        return int(np.sum(lamin)), int(np.sum(conv))
+
+    k = 1
+    while k <= kmax:
+        if expand:
+            kn += n
+            N += 1
+            nrmD.append(float(np.max(abs(sgdd[:, k]))))
+            if not np.isfinite(nrmD[k]):
+                raise ValueError("The generalized divided differences must be finite.")
+            if n > 1 and k >= 5 and k < kconv:
+                frozen = False
+                if sum(nrmD[k - 4:k + 1]) < 5 * tollin:
+                    kconv = k - 1
+                    frozen = True
+                    xi = xi[:k]; beta = beta[:k]; nrmD = nrmD[:k]
+                elif k == maxdgr + 1:
+                    kconv = k
+                    frozen = True
+                if frozen:
+                    expand = False
+                    if leja == 1:
+                        if len(sigma) < kmax + 1:
+                            sigma = np.concatenate([sigma, np.zeros(kmax + 1 - len(sigma), dtype=complex)])
+                        sigma[k:kmax + 1] = nodes[:kmax - k + 1]
+                    N -= 1
+        l = k
+        w = backslash(k, l)
+        active[l] = kn
+        h, hb, _ = dense.orthogonalize_and_normalize(V, w, l, rows=kn, ldv=ldv, active_rows=active, method=dense.DGKS)
+        H[:l, l - 1] = h; H[l, l - 1] = hb
+        K[:l, l - 1] = H[:l, l - 1] * sigma[k]
+        K[l - 1, l - 1] += 1.0
+        K[l, l - 1] = hb * sigma[k]
+        if ((not expand and k >= N + minit and (k - (N + minit)) % check_error_every == 0) or
+                (k >= kconv + minit and (k - (kconv + minit)) % check_error_every == 0) or k == kmax):
+            nblamin, nbconv = check_convergence(k, l)
+        if ((not expand and k >= N + minit) or k >= kconv + minit) and nblamin == nbconv:
+            break
+        k += 1
+    lam = res_state["lam"]; conv = res_state["conv"]; res = res_state["res"]
+    if info is not None:
+        info.update(kconv=kconv, N=N, k=min(k, kmax), nfact=len(cache.solvers), nrmD=nrmD, nblamin=nblamin)
+    if res_state["QT"] is None or not np.any(conv):
+        return lam[conv], np.zeros((n, 0), dtype=complex), res[conv]
+    X = to_host(dense.rowmajor_to_cols(res_state["QT"], np.nonzero(conv)[0]))
+    X = X / np.linalg.norm(X, axis=0)[None, :]
+    return lam[conv], X, res[conv]

@@ -1,0 +1,159 @@
+"""Rational-Krylov host utilities for nleigs (tiny, setup only): src/rk_helper/rk_utils.jl:14-128 (lejabagby,
+scgendivdiffs, ratnewtoncoeffsm), src/rk_helper/discretizepolygon.jl, src/rk_helper/inpolygon.jl and the
+structure discovery of src/rk_helper/rk_nep.jl:102-153 (p, q; the stacked matrix BBCC is the device's
+stacked CSR).  Pure host arithmetic on O(maxdgr) points -- not a kernel."""
+import numpy as np
+
+from .nep import PEP, SumNEP
+
+
+def _det3p(q1x, q1y, q2x, q2y, px, py):
+    return (q1x - px) * (q2y - py) - (q2x - px) * (q1y - py)
+
+
+def _approx0(det):
+    return det == 0.0          # isapprox(0, det) with default rtol and atol=0 is true only for det == 0
+
+
+def inpolygon(px, py, polyx, polyy):
+    if not (np.isfinite(px) and np.isfinite(py)):
+        return False
+    c = False
+    m = len(polyx)
+    for idx in range(m):
+        q1x, q1y = polyx[idx], polyy[idx]
+        q2x, q2y = polyx[(idx + 1) % m], polyy[(idx + 1) % m]
+        if q1x == px and q1y == py:
+            return True
+        if q2y == py:
+            if q2x == px:
+                return True
+            if q1y == py and (q2x > px) == (q1x < px):
+                return True
+        if (q1y < py) != (q2y < py):
+            if q1x >= px:
+                if q2x > px:
+                    c = not c
+                else:
+                    det = _det3p(q1x, q1y, q2x, q2y, px, py)
+                    if _approx0(det):
+                        return True
+                    if (det > 0) == (q2y > q1y):
+                        c = not c
+            elif q2x > px:
+                det = _det3p(q1x, q1y, q2x, q2y, px, py)
+                if _approx0(det):
+                    return True
+                if (det > 0) == (q2y > q1y):
+                    c = not c
+    return c
+
+
+def in_Sigma(z, Sigma, tol):
+    """src/method_nleigs.jl:521-531"""
+    Sigma = np.asarray(Sigma)
+    if len(Sigma) == 2 and np.all(Sigma.imag == 0):
+        rx = np.array([Sigma[0].real, Sigma[0].real, Sigma[1].real, Sigma[1].real]); iy = np.array([-tol, tol, tol, -tol])
+    else:
+        rx, iy = Sigma.real, Sigma.imag
+    return np.array([inpolygon(p.real, p.imag, rx, iy) for p in np.atleast_1d(z)], dtype=bool)
+
+
+def discretizepolygon(z, include_interior_points=False, npts=10000, nptsint=5):
+    z = np.asarray(z, dtype=complex)
+    if len(z) == 0:
+        z = np.array([0j])
+    if len(z) == 1:
+        zz = z[0] + np.exp(2j * np.pi * np.arange(1, npts + 1) / npts)
+    elif len(z) == 2:
+        zz = (z[1] - z[0]) / 2 * (np.cos(np.pi * np.arange(npts - 1, -1, -1) / (npts - 1)) + 1) + z[0]
+    else:
+        z = np.concatenate([z, z[:1]])
+        L = np.sum(abs(np.diff(z)))
+        ind = 0; alph = 0.0
+        pts = [z[0]]
+        remL = L / npts
+        while len(pts) < npts:
+            d = abs(z[ind + 1] - z[ind])
+            if (1 - alph) * d < remL:
+                ind += 1
+                remL -= (1 - alph) * d
+                alph = 0.0
+            else:
+                alph += remL / d
+                remL = L / npts
+                pts.append(z[ind] + alph * (z[ind + 1] - z[ind]))
+        zz = np.asarray(pts, dtype=complex)
+    zz = np.concatenate([zz, z])
+    Z = np.zeros(0, dtype=complex)
+    if include_interior_points:
+        if len(z) == 2:
+            xnr = 2 * nptsint
+            xnr += (xnr % 2 == 0)
+            return zz, np.linspace(z[0], z[1], xnr)[1::2]
+        points = zz if len(z) == 1 else z
+        rx, iy = points.real, points.imag
+        rmin, rmax, imin, imax = rx.min(), rx.max(), iy.min(), iy.max()
+        it = 0
+        spacing = (rmax - rmin) / 2.0001 / np.sqrt(nptsint)
+        eps = np.finfo(float).eps
+        while len(Z) < nptsint:
+            it += 1
+            if it > 10:
+                raise RuntimeError("Failed to find interior polygon points. Polygon too narrow? (Note that intervals "
+                                   "should be given by their two endpoints only.)")
+            xnr = int((rmax - rmin) / (2 * spacing)); ynr = int((imax - imin) / (2 * spacing))
+            spacing /= np.sqrt(np.sqrt(2))
+            if xnr <= 1 or ynr <= 1:
+                continue
+            xpts = np.linspace(rmin, rmax, xnr)[1::2]
+            ypts = np.linspace(imin - eps, imax + eps, ynr)[1::2]
+            Z = np.array([x + 1j * y for x in xpts for y in ypts if inpolygon(x, y, rx, iy)], dtype=complex)
+    return zz, Z
+
+
+def lejabagby(A, B, C, m, keepA=False, forceInf=0):
+    A = np.asarray(A, dtype=complex); B = np.asarray(B, dtype=float); C = np.asarray(C, dtype=complex)
+    a = [A[0]]; b = [np.inf if forceInf > 0 else B[0]]; beta = [1.0]
+    sA = np.ones(len(A), dtype=complex); sB = np.ones(len(B), dtype=complex); sC = np.ones(len(C), dtype=complex)
+    with np.errstate(all="ignore"):
+        for j in range(m - 1):
+            binv = 1 / b[j]; betainv = 1 / beta[j]
+            sA = sA * betainv * (A - a[j]) / (1 - A * binv)
+            sB = sB * betainv * (B - a[j]) / (1 - B * binv)
+            sC = sC * betainv * (C - a[j]) / (1 - C * binv)
+            a.append(A[j + 1] if keepA else A[int(np.argmax(np.where(np.isnan(sA), -np.inf, abs(sA))))])
+            b.append(np.inf if forceInf > j + 1 else B[int(np.argmin(np.where(np.isnan(sB), np.inf, abs(sB))))])
+            beta.append(float(np.max(abs(sC))))
+            if beta[j + 1] < np.finfo(float).eps:
+                beta[j + 1] = 1.0
+    return np.array(a, dtype=complex), np.array(b, dtype=float), np.array(beta, dtype=float)
+
+
+def ratnewtoncoeffsm(fun, sigma, xi, beta):
+    """scalar generalized divided differences through the matrix function of H K^{-1} (rk_utils.jl:99-119);
+    `fun` is a funcs.ScalarFun (its matfun is used)"""
+    m = len(sigma) - 1
+    K = np.eye(m + 1, dtype=complex)
+    H = np.diag(np.asarray(sigma[:m + 1], dtype=complex))
+    with np.errstate(all="ignore"):
+        K[np.arange(1, m + 1), np.arange(m)] = np.asarray(beta[1:m + 1]) / np.asarray(xi[:m])
+    H[np.arange(1, m + 1), np.arange(m)] = beta[1:m + 1]
+    Pd = 1.0 / np.max(abs(K), axis=0)
+    K = K * Pd[None, :]; H = H * Pd[None, :]
+    M = np.linalg.solve(K.T, H.T).T
+    return np.asarray(fun.matfun(M), dtype=complex)[:, 0] * beta[0]
+
+
+def scgendivdiffs(sigma, xi, beta, pff):
+    return np.vstack([ratnewtoncoeffsm(f, sigma, xi, beta) for f in pff])
+
+
+def rk_structure(nep):
+    """(p, q) of rk_nep.jl:102-125: degree of the polynomial part and number of nonlinear terms"""
+    Av = nep.get_Av()
+    if isinstance(nep, PEP):
+        return len(Av) - 1, 0
+    if isinstance(nep, SumNEP) and isinstance(nep.nep1, PEP):
+        return len(nep.nep1.get_Av()) - 1, len(nep.nep2.get_Av())
+    return -1, len(Av)

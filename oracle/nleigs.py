@@ -1,0 +1,371 @@
+"""Oracle NLEIGS (test infrastructure only): NumPy/SciPy restatement of
+
+  src/method_nleigs.jl:60-377     main loop (dynamic variant, static=false, return_details=false)
+  src/method_nleigs.jl:380-396    constructD
+  src/method_nleigs.jl:399-518    backslash (continuation-vector solve; non-low-rank branches)
+  src/method_nleigs.jl:521-531    in_Sigma
+  src/rk_helper/rk_utils.jl:14-128    lejabagby, scgendivdiffs, ratnewtoncoeffsm, evalrat
+  src/rk_helper/rk_nep.jl:102-153     get_rk_nep (p, q, BBCC; without the low-rank factorisation)
+  src/rk_helper/discretizepolygon.jl, inpolygon.jl
+  src/rk_helper/linsolvercache.jl:7-26
+
+Restrictions (documented in DESIGN.md): SPMF-type NEPs only, no LowRankFactorizedNEP structure, dynamic variant.
+"""
+import numpy as np
+import scipy.linalg as sla
+import scipy.sparse as sp
+
+from . import neps, solvers
+
+
+# ------------------------------------------------------------------------------------------------
+def det3p(q1x, q1y, q2x, q2y, px, py):
+    return (q1x - px) * (q2y - py) - (q2x - px) * (q1y - py)
+
+
+def inpolygon(px, py, polyx, polyy):
+    """Hormann-Agathos point-in-polygon (rk_helper/inpolygon.jl)."""
+    if not (np.isfinite(px) and np.isfinite(py)):
+        return False
+    c = False
+    n = len(polyx)
+    for idx in range(n):
+        q1x, q1y = polyx[idx], polyy[idx]
+        q2x, q2y = polyx[(idx + 1) % n], polyy[(idx + 1) % n]
+        if q1x == px and q1y == py:
+            return True
+        if q2y == py:
+            if q2x == px:
+                return True
+            elif q1y == py and (q2x > px) == (q1x < px):
+                return True
+        if (q1y < py) != (q2y < py):
+            if q1x >= px:
+                if q2x > px:
+                    c = not c
+                else:
+                    det = det3p(q1x, q1y, q2x, q2y, px, py)
+                    if np.isclose(0, det, rtol=np.sqrt(np.finfo(float).eps), atol=0):
+                        return True
+                    elif (det > 0) == (q2y > q1y):
+                        c = not c
+            elif q2x > px:
+                det = det3p(q1x, q1y, q2x, q2y, px, py)
+                if np.isclose(0, det, rtol=np.sqrt(np.finfo(float).eps), atol=0):
+                    return True
+                elif (det > 0) == (q2y > q1y):
+                    c = not c
+    return c
+
+
+def in_Sigma(z, Sigma, tol):
+    Sigma = np.asarray(Sigma)
+    if len(Sigma) == 2 and np.all(Sigma.imag == 0):
+        rx = np.array([Sigma[0].real, Sigma[0].real, Sigma[1].real, Sigma[1].real]); iy = np.array([-tol, tol, tol, -tol])
+    else:
+        rx = Sigma.real; iy = Sigma.imag
+    return np.array([inpolygon(p.real, p.imag, rx, iy) for p in np.atleast_1d(z)], dtype=bool)
+
+
+def discretizepolygon(z, include_interior_points=False, npts=10000, nptsint=5):
+    z = np.asarray(z, dtype=complex)
+    if len(z) == 0:
+        z = np.array([0j])
+    if len(z) == 1:
+        zz = list(z[0] + np.exp(2j * np.pi * np.arange(1, npts + 1) / npts))
+    elif len(z) == 2:
+        zz = list((z[1] - z[0]) / 2 * (np.cos(np.pi * np.arange(npts - 1, -1, -1) / (npts - 1)) + 1) + z[0])
+    else:
+        z = np.concatenate([z, z[:1]])
+        L = np.sum(abs(np.diff(z)))
+        ind = 0; alph = 0.0
+        zz = [z[0]]
+        remL = L / npts
+        while len(zz) < npts:
+            d = abs(z[ind + 1] - z[ind])
+            if (1 - alph) * d < remL:
+                ind += 1
+                remL -= (1 - alph) * d
+                alph = 0.0
+            else:
+                alph += remL / d
+                remL = L / npts
+                zz.append(z[ind] + alph * (z[ind + 1] - z[ind]))
+    zz = np.concatenate([np.asarray(zz, dtype=complex), z])
+    Z = np.zeros(0, dtype=complex)
+    if include_interior_points:
+        if len(z) == 2:
+            xnr = 2 * nptsint
+            if xnr % 2 == 0:
+                xnr += 1
+            xpts = np.linspace(z[0], z[1], xnr)
+            return zz, xpts[1::2]
+        points = zz if len(z) == 1 else z
+        rx, iy = points.real, points.imag
+        rmin, rmax = rx.min(), rx.max(); imin, imax = iy.min(), iy.max()
+        it = 0
+        spacing = (rmax - rmin) / 2.0001 / np.sqrt(nptsint)
+        while len(Z) < nptsint:
+            it += 1
+            if it > 10:
+                raise RuntimeError("Failed to find interior polygon points. Polygon too narrow?")
+            xnr = int((rmax - rmin) / (2 * spacing)); ynr = int((imax - imin) / (2 * spacing))
+            spacing /= np.sqrt(np.sqrt(2))
+            if xnr <= 1 or ynr <= 1:
+                continue
+            xpts = np.linspace(rmin, rmax, xnr)[1::2]
+            eps = np.finfo(float).eps
+            ypts = np.linspace(imin - eps, imax + eps, ynr)[1::2]
+            Z = np.array([x + 1j * y for x in xpts for y in ypts], dtype=complex)
+            Z = np.array([p for p in Z if inpolygon(p.real, p.imag, rx, iy)], dtype=complex)
+    return zz, Z
+
+
+def lejabagby(A, B, C, m, keepA=False, forceInf=0):
+    """rk_utils.jl:14-46"""
+    A = np.asarray(A, dtype=complex); B = np.asarray(B, dtype=float); C = np.asarray(C, dtype=complex)
+    a = [A[0]]
+    b = [np.inf if forceInf > 0 else B[0]]
+    beta = [1.0]
+    sA = np.ones(len(A), dtype=complex); sB = np.ones(len(B), dtype=complex); sC = np.ones(len(C), dtype=complex)
+    with np.errstate(all="ignore"):
+        for j in range(m - 1):
+            binv = 1 / b[j]; betainv = 1 / beta[j]
+            sA = sA * betainv * (A - a[j]) / (1 - A * binv)
+            sB = sB * betainv * (B - a[j]) / (1 - B * binv)
+            sC = sC * betainv * (C - a[j]) / (1 - C * binv)
+            if keepA:
+                a.append(A[j + 1])
+            else:
+                t = np.where(np.isnan(sA), -np.inf, abs(sA))
+                a.append(A[int(np.argmax(t))])
+            if forceInf > j + 1:
+                b.append(np.inf)
+            else:
+                t = np.where(np.isnan(sB), np.inf, abs(sB))
+                b.append(B[int(np.argmin(t))])
+            beta.append(float(np.max(abs(sC))))
+            if beta[j + 1] < np.finfo(float).eps:
+                beta[j + 1] = 1.0
+    return np.array(a, dtype=complex), np.array(b, dtype=float), np.array(beta, dtype=float)
+
+
+def ratnewtoncoeffsm(fm, sigma, xi, beta):
+    """rk_utils.jl:99-119: rational divided differences via a matrix function of H K^{-1}"""
+    m = len(sigma) - 1
+    sigma = np.asarray(sigma, dtype=complex); xi = np.asarray(xi, dtype=float); beta = np.asarray(beta, dtype=float)
+    K = np.diag(np.ones(m + 1)).astype(complex)
+    H = np.diag(sigma[:m + 1]).astype(complex)
+    with np.errstate(all="ignore"):
+        sub = beta[1:m + 1] / xi[:m]
+    K[np.arange(1, m + 1), np.arange(m)] = sub
+    H[np.arange(1, m + 1), np.arange(m)] = beta[1:m + 1]
+    Pd = 1.0 / np.max(abs(K), axis=0)
+    K = K * Pd[None, :]; H = H * Pd[None, :]
+    M = np.linalg.solve(K.T, H.T).T          # H / K
+    return np.asarray(fm(M), dtype=complex)[:, 0] * beta[0]
+
+
+def scgendivdiffs(sigma, xi, beta, maxdgr, pff):
+    return np.vstack([ratnewtoncoeffsm(f, sigma, xi, beta) for f in pff])
+
+
+class RKNEP:
+    """rk_nep.jl:19-32,102-153 without low-rank structure"""
+
+    def __init__(self, nep):
+        self.nep = nep
+        Av = nep.get_Av()
+        self.BC = Av
+        if isinstance(nep, neps.PEP):
+            self.p, self.q = len(Av) - 1, 0
+        elif isinstance(nep, neps.SumNEP) and isinstance(nep.nep1, neps.PEP):
+            self.p = len(nep.nep1.get_Av()) - 1; self.q = len(nep.nep2.get_Av())
+        else:
+            self.p, self.q = -1, len(Av)
+
+
+def constructD(nb, P, sgdd):
+    D = None
+    for ii in range(P.p + 1 + P.q):
+        T = sgdd[ii, nb] * P.BC[ii]
+        D = T if D is None else D + T
+    return D
+
+
+class LinSolverCache:
+    def __init__(self, nep, creator):
+        self.nep, self.creator, self.solvers = nep, creator, {}
+
+    def solve(self, sigma, y, add_to_cache):
+        key = complex(sigma)
+        if key in self.solvers:
+            return self.solvers[key].lin_solve(y)
+        s = self.creator.create_linsolver(self.nep, sigma)
+        if add_to_cache:
+            self.solvers[key] = s
+        return s.lin_solve(y)
+
+
+def backslash(wc, P, cache, reusefact, computeD, sigma, k, D, beta, N, xi, expand, kconv, sgdd):
+    """method_nleigs.jl:399-518 (non-low-rank branches); k is the 1-based iteration counter"""
+    n = P.nep.size(1)
+    shift = sigma[k]                      # sigma[k+1] in 1-based numbering
+    with np.errstate(all="ignore"):
+        Bw = np.zeros(len(wc), dtype=complex)
+        for ii in range(1, N + 1):
+            i0 = slice((ii - 1) * n, ii * n); i1 = slice(ii * n, (ii + 1) * n)
+            Bw[i1] = wc[i0] + beta[ii] / xi[ii - 1] * wc[i1]
+        z = Bw.copy()
+        nu = beta[1] * (1 - shift / xi[0])
+        z[n:2 * n] = 1 / nu * z[n:2 * n]
+        for ii in range(1, N + 1):
+            i1 = slice(ii * n, (ii + 1) * n); i2 = slice((ii + 1) * n, (ii + 2) * n)
+            if computeD:
+                z[:n] -= D[ii] @ z[i1]
+            else:
+                acc = np.zeros(n, dtype=complex)
+                for j, A in enumerate(P.BC):
+                    acc += sgdd[j, ii] * (A @ z[i1])
+                z[:n] -= acc
+            if ii < N:
+                mu = shift - sigma[ii]
+                nu = beta[ii + 1] * (1 - shift / xi[ii])
+                z[i2] = 1 / nu * z[i2] + mu / nu * z[i1]
+        w = np.zeros(len(wc), dtype=complex)
+        add_to_cache = ((not expand or k > kconv) and reusefact == 1) or reusefact == 2
+        w[:n] = cache.solve(shift, z[:n] / beta[0], add_to_cache)
+        for ii in range(1, N + 1):
+            i0 = slice((ii - 1) * n, ii * n); i1 = slice(ii * n, (ii + 1) * n)
+            mu = shift - sigma[ii - 1]
+            nu = beta[ii] * (1 - shift / xi[ii - 1])
+            w[i1] = mu / nu * w[i0] + 1 / nu * Bw[i1]
+    return w
+
+
+def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolvercreator=None, tol=1e-10,
+           tollin=None, v=None, errmeasure=None, leja=1, nodes=(), reusefact=1, blksize=20, check_error_every=5,
+           info=None):
+    """method_nleigs.jl:60-377 (static=false, return_details=false, isfunm=true)."""
+    eps = np.finfo(float).eps
+    if tollin is None:
+        tollin = max(tol / 10, 100 * eps)
+    if linsolvercreator is None:
+        linsolvercreator = solvers.DefaultLinSolverCreator()
+    if errmeasure is None:
+        errmeasure = solvers.ResidualErrmeasure(nep)
+    Sigma = np.asarray(Sigma, dtype=complex); Xi = np.asarray(Xi, dtype=float)
+    nodes = np.asarray(nodes, dtype=complex)
+    P = RKNEP(nep)
+    n = nep.size(1)
+    if n == 1:
+        maxdgr = maxit + 1
+    computeD = n <= 400
+    cache = LinSolverCache(nep, linsolvercreator)
+    v = np.array(v, dtype=complex)
+
+    if leja == 0:
+        if len(nodes) == 0:
+            raise ValueError("Interpolation nodes must be provided via 'nodes' when no Leja-Bagby points ('leja' == 0) are used.")
+        gamma, _ = discretizepolygon(Sigma)
+        max_count = max(maxit, maxdgr) + 2
+        sigma = np.tile(nodes, int(np.ceil(max_count / len(nodes))))
+        _, xi, beta = lejabagby(sigma[:maxdgr + 2], Xi, gamma, maxdgr + 2, True, P.p)
+    elif leja == 1:
+        if len(nodes) == 0:
+            gamma, nodes = discretizepolygon(Sigma, True)
+        else:
+            gamma, _ = discretizepolygon(Sigma)
+        nodes = np.tile(nodes, int(np.ceil((maxit + 1) / len(nodes))))
+        sigma, xi, beta = lejabagby(gamma, Xi, gamma, maxdgr + 2, False, P.p)
+    else:
+        gamma, _ = discretizepolygon(Sigma)
+        max_count = max(maxit, maxdgr) + 2
+        sigma, xi, beta = lejabagby(gamma, Xi, gamma, max_count, False, P.p)
+    sigma = np.array(sigma, dtype=complex); xi = np.array(xi, dtype=float); beta = np.array(beta, dtype=float)
+    xi[maxdgr + 1] = np.nan
+
+    rng_ = slice(0, maxdgr + 2)
+    sgdd = scgendivdiffs(sigma[rng_], xi[rng_], beta[rng_], maxdgr, nep.get_fv())
+    D = []
+    if computeD:
+        D.append(constructD(0, P, sgdd))
+    nrmD = [float(np.max(abs(sgdd[:, 0])))]
+    if not np.isfinite(nrmD[0]):
+        raise ValueError("The generalized divided differences must be finite.")
+
+    kmax = maxit
+    V = np.zeros(((kmax + 2) * n, kmax + 2), dtype=complex, order="F")
+    H = np.zeros((kmax + 2, kmax + 1), dtype=complex); K = np.zeros((kmax + 2, kmax + 1), dtype=complex)
+    v = cache.solve(sigma[0], v / np.linalg.norm(v), reusefact == 2)
+    V[:n, 0] = v / np.linalg.norm(v)
+    expand = True
+    kconv = np.iinfo(np.int64).max // 2
+    kn = n; l = 0; N = 0; nbconv = 0; nblamin = 0
+    lam = np.zeros(0, dtype=complex); X = np.zeros((n, 0), dtype=complex); res = np.zeros(0); conv = np.zeros(0, dtype=bool)
+    k = 1
+    nfact = 0
+    while k <= kmax:
+        if expand:
+            kn += n
+            if computeD:
+                D.append(constructD(k, P, sgdd))
+            N += 1
+            nrmD.append(float(np.max(abs(sgdd[:, k]))))
+            if not np.isfinite(nrmD[k]):
+                raise ValueError("The generalized divided differences must be finite.")
+            if n > 1 and k >= 5 and k < kconv:
+                if sum(nrmD[k - 4:k + 1]) < 5 * tollin:
+                    kconv = k - 1
+                    expand = False
+                    if leja == 1:
+                        if len(sigma) < kmax + 1:
+                            sigma = np.concatenate([sigma, np.zeros(kmax + 1 - len(sigma), dtype=complex)])
+                        sigma[k:kmax + 1] = nodes[:kmax - k + 1]
+                    if computeD:
+                        D = D[:k]
+                    xi = xi[:k]; beta = beta[:k]; nrmD = nrmD[:k]
+                    N -= 1
+                elif k == maxdgr + 1:
+                    kconv = k
+                    expand = False
+                    if leja == 1:
+                        if len(sigma) < kmax + 1:
+                            sigma = np.concatenate([sigma, np.zeros(kmax + 1 - len(sigma), dtype=complex)])
+                        sigma[k:kmax + 1] = nodes[:kmax - k + 1]
+                    N -= 1
+        l = k
+        t = np.zeros(l); t[l - 1] = 1
+        wc = V[:kn, l - 1].copy()
+        w = backslash(wc, P, cache, reusefact, computeD, sigma, k, D, beta, N, xi, expand, kconv, sgdd)
+        H[l, l - 1] = solvers.dgks(V[:kn, :l], w, H[:l, l - 1])
+        K[:l, l - 1] = H[:l, l - 1] * sigma[k] + t
+        K[l, l - 1] = H[l, l - 1] * sigma[k]
+        V[:kn, l] = w
+
+        def check_convergence():
+            nonlocal lam, X, res, conv, nbconv, nblamin
+            lambda_, S = sla.eig(K[:l, :l], H[:l, :l])
+            lamin = in_Sigma(lambda_, Sigma, tol)
+            ilam = np.nonzero(lamin)[0]
+            lam = lambda_[ilam]
+            nblamin = int(np.sum(lamin))
+            S = S.copy()
+            for i in ilam:
+                S[:, i] /= np.linalg.norm(H[:l + 1, :l] @ S[:, i])
+            X = V[:n, :l + 1] @ (H[:l + 1, :l] @ S[:, ilam])
+            if X.shape[1]:
+                X = X / np.linalg.norm(X, axis=0)[None, :]
+            res = np.array([errmeasure(lam[i], X[:, i]) for i in range(len(lam))])
+            conv = abs(res) < tol
+            nbconv = int(np.sum(conv)) if len(conv) else 0
+
+        if ((not expand and k >= N + minit and (k - (N + minit)) % check_error_every == 0) or
+                (k >= kconv + minit and (k - (kconv + minit)) % check_error_every == 0) or k == kmax):
+            check_convergence()
+        if ((not expand and k >= N + minit) or k >= kconv + minit) and nblamin == nbconv:
+            break
+        k += 1
+    if info is not None:
+        info.update(kconv=kconv, N=N, k=min(k, kmax), nfact=len(cache.solvers), nrmD=nrmD, nblamin=nblamin)
+    return lam[conv], X[:, conv], res[conv]

@@ -245,3 +245,59 @@ def test_wep_reference_eigenvalue(na):
     lam2, Q2, _, _ = na.tiar(nep, sigma=-3 - 3.5j, neigs=3, maxit=100, v=v0, tol=1e-8)
     assert len(lam2) == 3 and min(abs(lref - lam2)) < 1e-10
     assert max(R(lam2[i], Q2[:, i]) for i in range(3)) < 1e-8
+
+
+def _gun_r1_setup(n):
+    """test/rk_helper/gun_test_utils.jl:6-32 (target set, nodes, pole candidates) for the gun problem"""
+    gam = 300.0 ** 2 - 200.0 ** 2; mu = 250.0 ** 2; sigma2 = 108.8774
+    xmin = gam * (-1) + mu; xmax = gam * 1 + mu
+    npts = 1000
+    th = np.linspace(0, np.pi, int(round(np.pi / 2 * npts)) + 2)
+    halfcircle = xmin + (xmax - xmin) * (np.exp(1j * th) / 2 + .5)
+    Sigma = np.concatenate([halfcircle, [xmin]])
+    Z = np.array([2 / 3, (1 + 1j) / 3, 0, (-1 + 1j) / 3, -2 / 3])
+    nodes = gam * Z + mu
+    Xi = -10.0 ** np.linspace(-8, 8, 10000) + sigma2 ** 2
+    v = np.random.Generator(np.random.Philox(1)).standard_normal(n) + 0j
+    return Sigma, Xi, nodes, v
+
+
+def test_nleigs_basic_kat(na):
+    # test/nleigs/nleigs_basic.jl:11-19,42-47 ; src/method_nleigs.jl:44-50
+    from oracle import neps as oneps, nleigs as onl, gallery as og
+    B = [np.array([[1., 3], [5, 6]]), np.array([[3., 4], [6, 6]]), np.eye(2)]
+    Sigma = np.array([-10 - 2j, 10 - 2j, 10 + 2j, -10 + 2j])
+    info = {}
+    lam, X, res = na.nleigs(na.PEP(B), Sigma, maxit=10, v=np.ones(2) + 0j, blksize=5, info=info)
+    lo, Xo, ro = onl.nleigs(oneps.PEP(B), Sigma, maxit=10, v=np.ones(2) + 0j, blksize=5)
+    assert len(lam) == 4 and len(lo) == 4
+    _match(lam, lo, 1e-9)
+    o = oneps.PEP(B)
+    assert max(np.linalg.norm(o.compute_Mlincomb(lam[i], X[:, i])) for i in range(4)) < 1e-5
+    assert info["kconv"] == 6 and info["nfact"] == 4
+    cB = [b + 1j * np.eye(2) for b in B]
+    lam, X, res = na.nleigs(na.PEP(cB), Sigma, maxit=10, v=np.ones(2) + 0j, blksize=5)
+    assert len(lam) == 3
+    d = na.nep_gallery("dep0"); od = og.dep0()
+    lam, X, res = na.nleigs(d, np.array([1 + 1j, 1 - 1j, -1 - 1j, -1 + 1j]), v=np.ones(5) + 0j)
+    assert len(lam) >= 2
+    assert max(np.linalg.norm(od.compute_Mlincomb(lam[i], X[:, i])) for i in range(len(lam))) < 1e-10
+
+
+def test_nleigs_gun_twin_r1_vs_oracle(na):
+    """config C3 at reduced size: gun in native PEP+SPMF form, variant R1 (leja=0, 5 cyclic nodes, reusefact=2)"""
+    from oracle import gallery as og, nleigs as onl, solvers as osol
+    n, maxit = 1310, 40
+    Sigma, Xi, nodes, v = _gun_r1_setup(n)
+    onep = og.nlevp_native_gun(n)
+    io = {}; ig = {}
+    oE = osol.StandardSPMFErrmeasure(onep)
+    lo, Xo, ro = onl.nleigs(onep, Sigma, Xi=Xi, maxit=maxit, v=v, leja=0, nodes=nodes, reusefact=2, errmeasure=oE,
+                            tol=1e-10, info=io)
+    nep = na.nep_gallery("nlevp_native_gun", n)
+    lg, Xg, rg = na.nleigs(nep, Sigma, Xi=Xi, maxit=maxit, v=v, leja=0, nodes=nodes, reusefact=2,
+                           errmeasure=na.StandardSPMFErrmeasure(nep), tol=1e-10, info=ig)
+    assert ig["nfact"] == io["nfact"] == 5                    # 5 cached factorisations (linsolvercache.jl)
+    assert len(lg) == len(lo) and len(lg) >= 1
+    _match(lg, lo, 1e-8)
+    assert max(oE(lg[i], Xg[:, i]) for i in range(len(lg))) < 1e-10

@@ -177,3 +177,42 @@ def test_mlincomb_identities():
     assert np.allclose(za, spmf.compute_Mlincomb_from_MM(lam, V, a), rtol=1e-10)
     zc = sum(a[i] * (spmf.compute_Mder(lam, i) @ V[:, i]) for i in range(3))
     assert np.allclose(za, zc, rtol=1e-10)
+
+
+def test_wep_oracle_kats():
+    # test/wep_small.jl:13-22 (SPMF == WEP_FD) and :31-36,73-76 (reference eigenvalue through iar)
+    from oracle import wep
+    w = wep.WEP_FD(11, 7, "TAUSCH")
+    spmf = wep.assemble_waveguide_spmf_fd(w.wd)
+    lam = -1.3 - 0.31j
+    v1 = spmf.compute_Mlincomb(lam, np.ones(w.n)); v2 = w.compute_Mlincomb(lam, np.ones(w.n))
+    assert np.linalg.norm(v1 - v2) / np.linalg.norm(v1) < 1e-14
+    assert np.linalg.norm(w.compute_Mder(lam) @ np.ones(w.n) - v2) / np.linalg.norm(v2) < 1e-14
+    nep = wep.WEP_FD(109, 105, "JARLEBRING")
+    n = nep.n
+    lam, Q, _ = solvers.iar(nep, sigma=-3 - 3.5j, neigs=3, maxit=100, v=np.ones(n) / np.sqrt(n), tol=1e-8,
+                            errmeasure=solvers.ResidualErrmeasure(nep))
+    lref = -2.743228671961724 - 3.1439375599649972j
+    assert min(abs(lref - lam)) < 1e-10
+
+
+def test_nleigs_oracle_kats():
+    # test/nleigs/nleigs_basic.jl:11-19,42-47 ; src/method_nleigs.jl:44-50
+    from oracle import nleigs as onl
+    B = [np.array([[1., 3], [5, 6]]), np.array([[3., 4], [6, 6]]), np.eye(2)]
+    pep = neps.PEP(B)
+    Sigma = np.array([-10 - 2j, 10 - 2j, 10 + 2j, -10 + 2j])
+    info = {}
+    lam, X, res = onl.nleigs(pep, Sigma, maxit=10, v=np.ones(2) + 0j, blksize=5, info=info)
+    assert len(lam) == 4 and max(res) < 1e-5
+    exact = np.sort_complex(np.roots(np.poly1d([1]))) if False else None
+    # exact spectrum of the quadratic PEP via its companion form
+    C = np.block([[np.zeros((2, 2)), np.eye(2)], [-B[0], -B[1]]])
+    ex = np.linalg.eigvals(C)
+    for l in lam:
+        assert min(abs(ex - l)) < 1e-9
+    lam, X, res = onl.nleigs(neps.PEP([b + 1j * np.eye(2) for b in B]), Sigma, maxit=10, v=np.ones(2) + 0j)
+    assert len(lam) == 3
+    d = gallery.dep0()
+    lam, X, res = onl.nleigs(d, np.array([1 + 1j, 1 - 1j, -1 - 1j, -1 + 1j]), v=np.ones(5) + 0j)
+    assert len(lam) >= 2 and max(np.linalg.norm(d.compute_Mlincomb(lam[i], X[:, i])) for i in range(len(lam))) < 2e-13
