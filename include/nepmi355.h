@@ -150,6 +150,11 @@ int32_t nep_lu_create(int64_t n, const int32_t* hLp, const int32_t* hLi, const n
                       const int32_t* hUp, const int32_t* hUi, const nep_cdouble* hUx,
                       const int32_t* h_perm_r, const int32_t* h_perm_c, nep_lu** out);
 int32_t nep_lu_destroy(nep_lu* lu);
+/* hint for the NEXT nep_lu_create of the calling thread: how many solves the factorisation will serve (default 50).
+ * It sizes the dense tail block whose inverse is built at creation time (one-off ~T^2/256 us vs a shorter
+ * dependency chain per solve): FactorizeLinSolver (iar/tiar: maxit solves) passes a large number,
+ * BackslashLinSolver (one block solve per factorisation, src/LinSolvers.jl:157-159) passes 1. */
+int32_t nep_lu_set_expected_solves(int32_t nsolves);
 /* info[0]=n info[1]=nnz(L) info[2]=nnz(U) info[3]=levels(L) info[4]=levels(U)
  * info[5]=algorithmic bytes of one solve with one right-hand side */
 int32_t nep_lu_info(const nep_lu* lu, int64_t info[6]);

@@ -67,6 +67,7 @@ SIGNATURES = {
     "nep_gemm_ts_dev": [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp],
     "nep_lu_create": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, P(c_vp)],
     "nep_lu_destroy": [c_vp],
+    "nep_lu_set_expected_solves": [c_i32],
     "nep_lu_info": [c_vp, P(c_i64)],
     "nep_lu_schedule": [c_vp, P(c_i64)],
     "nep_lu_solve": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp],

@@ -1,0 +1,72 @@
+"""Host sparse LU (SuperLU via SciPy) as a plain function of arrays, importable WITHOUT torch/HIP so that it can run
+in worker processes (Beyn: one new matrix per quadrature node, src/method_beyncontour.jl:89-94; SciPy's splu holds
+the GIL, so concurrency needs processes).  Returns the factors in the CSR form nep_lu_create expects."""
+import time
+
+import numpy as np
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+
+_CTL = [False]
+
+
+def blas_controller():
+    """one cached threadpoolctl controller (constructing one scans every loaded shared library: ~50-100 ms in a
+    process that has torch loaded, so never do it per call)"""
+    if _CTL[0] is False:
+        try:
+            from threadpoolctl import ThreadpoolController
+            _CTL[0] = ThreadpoolController()
+        except Exception:
+            _CTL[0] = None
+    return _CTL[0]
+
+
+def ping(i):
+    time.sleep(0.02)      # keeps the first tasks from all landing on one worker while the others still start
+    return i
+
+
+def pattern_symmetric(Ac):
+    P = sp.csc_matrix((np.ones(Ac.nnz, dtype=np.int8), Ac.indices, Ac.indptr), shape=Ac.shape)
+    return (P != P.T).nnz == 0 and bool(np.all(Ac.diagonal() != 0))
+
+
+def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None, symmetric_mode=None):
+    """UMFPACK-like strategy selection (see linsolvers.DeviceLU) + SuperLU factorisation."""
+    t0 = time.perf_counter()
+    Ac = sp.csc_matrix((np.asarray(data, dtype=np.complex128), indices, indptr), shape=shape)
+    if permc_spec is None or symmetric_mode is None:
+        sym = pattern_symmetric(Ac)
+        if permc_spec is None:
+            permc_spec = "MMD_AT_PLUS_A" if sym else "COLAMD"
+        if symmetric_mode is None:
+            symmetric_mode = sym and permc_spec == "MMD_AT_PLUS_A"
+    if diag_pivot_thresh is None and symmetric_mode:
+        diag_pivot_thresh = 0.001
+    kw = dict(permc_spec=permc_spec)
+    if diag_pivot_thresh is not None:
+        kw["diag_pivot_thresh"] = diag_pivot_thresh
+    if symmetric_mode:
+        kw["options"] = dict(SymmetricMode=True)
+    # SuperLU is sequential and calls small BLAS-2/3 kernels: a many-thread OpenBLAS only adds spinning threads
+    # (measured 40 -> 230 ms jitter on a 128-core host); pin BLAS to one thread for the duration of the call
+    ctl = blas_controller()
+    if ctl is not None:
+        with ctl.limit(limits=1):
+            lu = spla.splu(Ac, **kw)  # RuntimeError("Factor is exactly singular") propagates to the caller
+    else:
+        lu = spla.splu(Ac, **kw)
+    t_factor = time.perf_counter() - t0
+    L = sp.csr_matrix(lu.L); U = sp.csr_matrix(lu.U)
+    L.sort_indices(); U.sort_indices()
+    return dict(
+        n=shape[0],
+        Lp=np.ascontiguousarray(L.indptr, dtype=np.int32), Li=np.ascontiguousarray(L.indices, dtype=np.int32),
+        Lx=np.ascontiguousarray(L.data, dtype=np.complex128),
+        Up=np.ascontiguousarray(U.indptr, dtype=np.int32), Ui=np.ascontiguousarray(U.indices, dtype=np.int32),
+        Ux=np.ascontiguousarray(U.data, dtype=np.complex128),
+        perm_r=np.ascontiguousarray(lu.perm_r, dtype=np.int32), perm_c=np.ascontiguousarray(lu.perm_c, dtype=np.int32),
+        normA=float(np.linalg.norm(Ac.data)), t_factor=t_factor, t_total=time.perf_counter() - t0,
+        strategy=dict(permc_spec=permc_spec, diag_pivot_thresh=diag_pivot_thresh, symmetric_mode=bool(symmetric_mode)))

@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 from . import dense
 from .errmeasure import DefaultErrmeasure, estimate_errors
-from .linsolvers import BackslashLinSolverCreator, create_linsolver, lin_solve
+from .linsolvers import BackslashLinSolverCreator, DeviceLU, HostLUPool, create_linsolver, lin_solve
 from .nep import CDT, to_dev, to_host
 
 EPS = np.finfo(float).eps
@@ -59,6 +59,8 @@ def integrate_interval(ST, f, gv, a, b, N, info=None, ops=_DeviceOps):
         world, rank = dist.get_world_size(), dist.get_rank()
     S = None
     mine = range(rank, N, world)
+    if hasattr(f, "prefetch"):
+        f.prefetch([t[i] for i in mine])
     for i in mine:
         X, c = f(t[i])
         if S is None:
@@ -113,10 +115,34 @@ def contour_beyn(nep, MIntegrator=MatrixTrapezoidal, tol=np.sqrt(EPS), sigma=0.0
         Vh = probe_block(n, k)
     Vd = to_dev(Vh)
 
-    def f(t):
-        # method_beyncontour.jl:89-98: Tv(lam) = lin_solve(create_linsolver(creator, nep, lam+sigma), Vh)
-        M0inv = create_linsolver(linsolvercreator, nep, g(t) + sigma)
-        return lin_solve(M0inv, Vd), gp(t)
+    class _NodeSolve:
+        """f(t) = Tv(g(t)) * gp(t), Tv(lam) = lin_solve(create_linsolver(creator, nep, lam+sigma), Vh)
+        (method_beyncontour.jl:89-98).  With the default BackslashLinSolverCreator every node needs a NEW host
+        factorisation; `prefetch` starts all factorisations of this rank's nodes in worker processes so that they run
+        concurrently with each other and with the device solves of the nodes already factored."""
+
+        def __init__(self):
+            self.futs = {}
+
+        def prefetch(self, ts):
+            workers = getattr(linsolvercreator, "workers", None)
+            if not isinstance(linsolvercreator, BackslashLinSolverCreator) or workers == 0 or len(ts) < 2:
+                return
+            for t in ts:
+                A = nep.compute_Mder(g(t) + sigma)
+                self.futs[t] = HostLUPool.submit(A, permc_spec=linsolvercreator.permc_spec, **linsolvercreator.lu_kw)
+
+        def __call__(self, t):
+            if t in self.futs:
+                try:
+                    F = self.futs.pop(t).result()
+                except RuntimeError as e:
+                    raise np.linalg.LinAlgError("SingularException: " + str(e))
+                return DeviceLU(factors=F, expected_solves=1).solve(Vd), gp(t)
+            M0inv = create_linsolver(linsolvercreator, nep, g(t) + sigma)
+            return lin_solve(M0inv, Vd), gp(t)
+
+    f = _NodeSolve()
 
     S = integrate_interval(MIntegrator, f, [lambda s: 1.0 + 0j, g], 0.0, 2 * np.pi, N, info=info)
     A0 = to_host(S[0]) / (2j * np.pi)

@@ -104,6 +104,14 @@ struct PinnedRing {
     void release();
 };
 
+// Caching device allocator for objects that are created and destroyed repeatedly (one LU per quadrature node in
+// Beyn, one per iar call): hipMalloc/hipFree of 100 MB blocks cost 10-100 ms each and fluctuate; freed blocks are
+// kept (up to a cap) and handed out again.  Reuse is stream-ordered: the library issues all its work on the
+// caller's stream, so a block is never reused before the kernels that read it have been enqueued ahead of its
+// next writer.
+int nep_pool_alloc(void** p, size_t bytes);
+void nep_pool_free(void* p);
+
 // small per-library scratch (device) helpers, defined in util.hip
 struct NepScratch {
     void* dptr = nullptr;

@@ -25,7 +25,7 @@
 
 #define TRSV_WIDE_MIN 48      // a level with at least this many rows gets its own multi-WG launch
 #define TRSV_TAIL_SMALL 4     // levels with <= this many rows are "chain" levels (dense tail)
-#define TRSV_TAIL_MAX 3072    // cap on the dense tail size (16*T^2 bytes = 151 MB at 3072)
+#define TRSV_TAIL_MAX 4096    // cap on the dense tail size (16*T^2 bytes = 268 MB at 4096)
 #define TRSV_TAIL_MIN 64
 
 struct Seg { int wide; int lev_lo, lev_hi; int slot_lo, slot_hi; int G; };
@@ -55,6 +55,13 @@ struct nep_lu {
     int64_t nnzL_in = 0, nnzU_in = 0;
     int32_t levL_full = 0, levU_full = 0;
     int32_t launches = 0;
+    // the level sweep between the two permutation kernels as an instantiated hipGraph (one per nrhs in use):
+    // ~90 small dependent launches per solve are host-launch-bound when issued eagerly
+    hipGraphExec_t graph_exec = nullptr;
+    int32_t graph_nrhs = 0;
+    void* graph_work = nullptr;
+    hipStream_t cap_stream = nullptr;
+    int32_t use_graph = 1;
 };
 
 __device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
@@ -215,12 +222,12 @@ __global__ __launch_bounds__(512) void k_tail_inverse(int T, int i0,
 
 // ------------------------------------------------------------------------------------------------
 static void free_tri(TriFactor& t) {
-    if (t.d_levptr) (void)hipFree(t.d_levptr);
-    if (t.d_rowid) (void)hipFree(t.d_rowid);
-    if (t.d_rowptr) (void)hipFree(t.d_rowptr);
-    if (t.d_col) (void)hipFree(t.d_col);
-    if (t.d_val) (void)hipFree(t.d_val);
-    if (t.d_diag) (void)hipFree(t.d_diag);
+    if (t.d_levptr) nep_pool_free(t.d_levptr);
+    if (t.d_rowid) nep_pool_free(t.d_rowid);
+    if (t.d_rowptr) nep_pool_free(t.d_rowptr);
+    if (t.d_col) nep_pool_free(t.d_col);
+    if (t.d_val) nep_pool_free(t.d_val);
+    if (t.d_diag) nep_pool_free(t.d_diag);
     t = TriFactor();
 }
 
@@ -303,11 +310,11 @@ static int build_tri(int64_t n, const int32_t* P, const int32_t* I, const nep_cd
         }
     }
     const size_t nnz = col.size();
-    HIPCHK(hipMalloc((void**)&out.d_levptr, (size_t)(nlev + 1) * 4));
-    HIPCHK(hipMalloc((void**)&out.d_rowid, (size_t)nr * 4));
-    HIPCHK(hipMalloc((void**)&out.d_rowptr, (size_t)(nr + 1) * 4));
-    HIPCHK(hipMalloc((void**)&out.d_col, (nnz + 1) * 4));
-    HIPCHK(hipMalloc((void**)&out.d_val, (nnz + 1) * 16));
+    { int prc_ = nep_pool_alloc((void**)&out.d_levptr, (size_t)(nlev + 1) * 4); if (prc_) return prc_; }
+    { int prc_ = nep_pool_alloc((void**)&out.d_rowid, (size_t)nr * 4); if (prc_) return prc_; }
+    { int prc_ = nep_pool_alloc((void**)&out.d_rowptr, (size_t)(nr + 1) * 4); if (prc_) return prc_; }
+    { int prc_ = nep_pool_alloc((void**)&out.d_col, (nnz + 1) * 4); if (prc_) return prc_; }
+    { int prc_ = nep_pool_alloc((void**)&out.d_val, (nnz + 1) * 16); if (prc_) return prc_; }
     HIPCHK(hipMemcpy(out.d_levptr, levptr.data(), (size_t)(nlev + 1) * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(out.d_rowid, rowid.data(), (size_t)nr * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(out.d_rowptr, rowptr.data(), (size_t)(nr + 1) * 4, hipMemcpyHostToDevice));
@@ -316,7 +323,7 @@ static int build_tri(int64_t n, const int32_t* P, const int32_t* I, const nep_cd
         HIPCHK(hipMemcpy(out.d_val, val.data(), nnz * 16, hipMemcpyHostToDevice));
     }
     if (upper) {
-        HIPCHK(hipMalloc((void**)&out.d_diag, (size_t)nr * 16));
+        { int prc_ = nep_pool_alloc((void**)&out.d_diag, (size_t)nr * 16); if (prc_) return prc_; }
         HIPCHK(hipMemcpy(out.d_diag, diag.data(), (size_t)nr * 16, hipMemcpyHostToDevice));
     }
     return NEP_OK;
@@ -354,16 +361,20 @@ int32_t nep_lu_destroy(nep_lu* lu) {
     if (!lu) return NEP_OK;
     free_tri(lu->L11);
     free_tri(lu->U11);
-    if (lu->d_L21p) (void)hipFree(lu->d_L21p);
-    if (lu->d_L21i) (void)hipFree(lu->d_L21i);
-    if (lu->d_L21x) (void)hipFree(lu->d_L21x);
-    if (lu->d_Sinv) (void)hipFree(lu->d_Sinv);
-    if (lu->d_perm_r) (void)hipFree(lu->d_perm_r);
-    if (lu->d_perm_c) (void)hipFree(lu->d_perm_c);
+    if (lu->d_L21p) nep_pool_free(lu->d_L21p);
+    if (lu->d_L21i) nep_pool_free(lu->d_L21i);
+    if (lu->d_L21x) nep_pool_free(lu->d_L21x);
+    if (lu->d_Sinv) nep_pool_free(lu->d_Sinv);
+    if (lu->d_perm_r) nep_pool_free(lu->d_perm_r);
+    if (lu->d_perm_c) nep_pool_free(lu->d_perm_c);
+    if (lu->graph_exec) (void)hipGraphExecDestroy(lu->graph_exec);
+    if (lu->cap_stream) (void)hipStreamDestroy(lu->cap_stream);
     lu->work.release();
     delete lu;
     return NEP_OK;
 }
+
+static thread_local int g_expected_solves = 50;
 
 static double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -389,16 +400,53 @@ static int lu_build(nep_lu* lu, int64_t n, const int32_t* hLp, const int32_t* hL
     int32_t nlevL = 0, nlevU = 0;
     compute_levels(n, hLp, hLi, false, 0, n, level, nlevL);
     lu->levL_full = nlevL;
-    // tail start: rows of the trailing run of "chain" levels (<= TRSV_TAIL_SMALL rows per level)
+    // tail start.  Seed: rows of the trailing run of "chain" levels (<= TRSV_TAIL_SMALL rows per level).  Then the
+    // tail is grown while a cost model of one solve improves: every head level costs a dependent step (a launch
+    // for a wide level, a workgroup barrier for a narrow one) while the dense tail costs 16 T^2 bytes of streaming.
+    // Measured on gun (n=9956): T=1067 -> 0.76 ms, 2000 -> 0.42 ms, 2500 -> 0.25 ms per solve.
     int64_t i0 = n;
     {
         std::vector<int32_t> cnt(nlevL, 0);
         for (int64_t i = 0; i < n; ++i) cnt[level[i]]++;
         int t0 = nlevL;
         while (t0 > 0 && cnt[t0 - 1] <= TRSV_TAIL_SMALL) --t0;
+        int64_t Tseed = 0;
         if (nlevL - t0 >= TRSV_TAIL_MIN) {
-            for (int64_t i = 0; i < n; ++i) if (level[i] >= t0) { i0 = i; break; }
-            if (n - i0 > TRSV_TAIL_MAX) i0 = n - TRSV_TAIL_MAX;
+            for (int64_t i = 0; i < n; ++i) if (level[i] >= t0) { Tseed = n - i; break; }
+        }
+        if (Tseed > 0) {
+            auto cost_us = [&](int64_t T) -> double {
+                const int64_t h = n - T;
+                std::vector<int32_t> lv(n, 0);
+                double c = 16.0 * (double)T * (double)T / 3.0e6 + 10.0;       // dense GEMV at ~3 TB/s + tail SpMV
+                for (int pass = 0; pass < 2; ++pass) {
+                    int32_t nl = 0;
+                    compute_levels(n, pass ? hUp : hLp, pass ? hUi : hLi, pass == 1, 0, h, lv, nl);
+                    std::vector<int32_t> cn(nl, 0);
+                    for (int64_t i = 0; i < h; ++i) cn[lv[i]]++;
+                    bool in_narrow = false;
+                    for (int32_t l = pass ? 0 : 1; l < nl; ++l) {
+                        if (cn[l] >= TRSV_WIDE_MIN) { c += 4.5; in_narrow = false; }
+                        else { c += 3.0; if (!in_narrow) { c += 5.0; in_narrow = true; } }
+                    }
+                }
+                return c;
+            };
+            // one-off cost of building S22^{-1} on the device (T workgroups x 2T levels): ~T^2/256 us, amortised over
+            // the number of solves the caller expects from this factorisation (nep_lu_set_expected_solves)
+            const double nsolve = (double)std::max(1, g_expected_solves);
+            auto total_us = [&](int64_t T) { return cost_us(T) + (double)T * (double)T / 256.0 / nsolve; };
+            const int64_t Tcap = std::min<int64_t>(TRSV_TAIL_MAX, n / 2);
+            int64_t best = std::min(Tseed, Tcap);
+            double bestc = total_us(best);
+            const double mult[] = {1.25, 1.5, 1.75, 2.0, 2.5, 3.0, 4.0};
+            for (double m : mult) {
+                int64_t T = std::min<int64_t>((int64_t)(Tseed * m), Tcap);
+                if (T <= best) continue;
+                const double c = total_us(T);
+                if (c < bestc * 0.97) { bestc = c; best = T; }
+            }
+            i0 = n - best;
         }
         if (const char* e = getenv("NEP_LU_TAIL")) {   // experiment knob: force the tail size
             long v = atol(e);
@@ -435,9 +483,9 @@ static int lu_build(nep_lu* lu, int64_t n, const int32_t* hLp, const int32_t* hL
             rp[r + 1] = (int32_t)ci.size();
         }
         lu->nnzL21 = (int64_t)ci.size();
-        HIPCHK(hipMalloc((void**)&lu->d_L21p, (size_t)(T + 1) * 4));
-        HIPCHK(hipMalloc((void**)&lu->d_L21i, (ci.size() + 1) * 4));
-        HIPCHK(hipMalloc((void**)&lu->d_L21x, (ci.size() + 1) * 16));
+        { int prc_ = nep_pool_alloc((void**)&lu->d_L21p, (size_t)(T + 1) * 4); if (prc_) return prc_; }
+        { int prc_ = nep_pool_alloc((void**)&lu->d_L21i, (ci.size() + 1) * 4); if (prc_) return prc_; }
+        { int prc_ = nep_pool_alloc((void**)&lu->d_L21x, (ci.size() + 1) * 16); if (prc_) return prc_; }
         HIPCHK(hipMemcpy(lu->d_L21p, rp.data(), (size_t)(T + 1) * 4, hipMemcpyHostToDevice));
         if (!ci.empty()) {
             HIPCHK(hipMemcpy(lu->d_L21i, ci.data(), ci.size() * 4, hipMemcpyHostToDevice));
@@ -454,8 +502,7 @@ static int lu_build(nep_lu* lu, int64_t n, const int32_t* hLp, const int32_t* hL
         rc = build_tri(n, hUp, hUi, hUx, true, i0, n, i0, n, level, nl, U22);
     }
     if (rc == NEP_OK) {
-        hipError_t e = hipMalloc((void**)&lu->d_Sinv, (size_t)T * T * sizeof(cplx));
-        if (e != hipSuccess) { nep_set_error("hipMalloc(Sinv) failed: %s", hipGetErrorString(e)); rc = NEP_ERR_HIP; }
+        rc = nep_pool_alloc((void**)&lu->d_Sinv, (size_t)T * T * sizeof(cplx));
     }
     TSTAMP("tail factors");
     if (rc == NEP_OK) {
@@ -476,6 +523,11 @@ static int lu_build(nep_lu* lu, int64_t n, const int32_t* hLp, const int32_t* hL
     return rc;
 }
 
+int32_t nep_lu_set_expected_solves(int32_t nsolves) {
+    g_expected_solves = nsolves < 1 ? 1 : nsolves;
+    return NEP_OK;
+}
+
 int32_t nep_lu_create(int64_t n, const int32_t* hLp, const int32_t* hLi, const nep_cdouble* hLx, const int32_t* hUp,
                       const int32_t* hUi, const nep_cdouble* hUx, const int32_t* h_perm_r, const int32_t* h_perm_c,
                       nep_lu** out) {
@@ -483,10 +535,13 @@ int32_t nep_lu_create(int64_t n, const int32_t* hLp, const int32_t* hLi, const n
     *out = nullptr;
     ARGCHK(n > 0 && n < ((int64_t)1 << 31));
     ARGCHK(hLp && hLi && hLx && hUp && hUi && hUx);
+    const bool timing = getenv("NEP_TIMING") != nullptr;
+    double tlast = now_ms();
     nep_lu* lu = new nep_lu();
     lu->n = n;
     lu->nnzL_in = hLp[n]; lu->nnzU_in = hUp[n];
     int rc = lu_build(lu, n, hLp, hLi, hLx, hUp, hUi, hUx);
+    TSTAMP("lu_build total");
     if (rc != NEP_OK) { nep_lu_destroy(lu); return rc; }
     auto up_perm = [&](const int32_t* hp, int32_t** dp) -> int {
         if (!hp) return NEP_OK;
@@ -495,13 +550,14 @@ int32_t nep_lu_create(int64_t n, const int32_t* hLp, const int32_t* hLi, const n
             if (hp[i] < 0 || hp[i] >= n || seen[hp[i]]) { nep_set_error("invalid permutation"); return NEP_ERR_ARG; }
             seen[hp[i]] = 1;
         }
-        HIPCHK(hipMalloc((void**)dp, (size_t)n * 4));
+        { int prc_ = nep_pool_alloc((void**)dp, (size_t)n * 4); if (prc_) return prc_; }
         HIPCHK(hipMemcpy(*dp, hp, (size_t)n * 4, hipMemcpyHostToDevice));
         return NEP_OK;
     };
     rc = up_perm(h_perm_r, &lu->d_perm_r);
     if (rc == NEP_OK) rc = up_perm(h_perm_c, &lu->d_perm_c);
     if (rc != NEP_OK) { nep_lu_destroy(lu); return rc; }
+    TSTAMP("perms");
     *out = lu;
     return NEP_OK;
 }
@@ -529,22 +585,10 @@ int32_t nep_lu_schedule(const nep_lu* lu, int64_t out[6]) {
     return NEP_OK;
 }
 
-int32_t nep_lu_solve(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_t ldb, nep_cdouble* dX, int64_t ldx,
-                     double scale, nep_stream stream) {
-    ARGCHK(lu && dB && dX);
-    ARGCHK(nrhs >= 1 && nrhs <= 65535 && ldb >= lu->n && ldx >= lu->n);
-    hipStream_t st = as_stream(stream);
+// enqueues the level sweep (L head, tail, U head) on `st`
+static int lu_sweep(nep_lu* lu, int nrhs, cplx* work, cplx* tmp, hipStream_t st, int* launches) {
     const int64_t n = lu->n, T = lu->T, i0 = lu->i0;
-    int rc = lu->work.ensure((size_t)(n + T) * nrhs * sizeof(cplx));
-    if (rc) return rc;
-    cplx* work = (cplx*)lu->work.dptr;
-    cplx* tmp = work + (size_t)n * nrhs;
-    int launches = 0;
-    const int pg = (int)std::min<int64_t>((n + 255) / 256, 1024);
-    hipLaunchKernelGGL(k_perm_in, dim3(pg, nrhs), dim3(256), 0, st, n, (const int32_t*)lu->d_perm_r, (const cplx*)dB, ldb,
-                       work, n);
-    LAUNCHCHK(); ++launches;
-    rc = run_head<false>(lu->L11, work, n, nrhs, st, &launches);
+    int rc = run_head<false>(lu->L11, work, n, nrhs, st, launches);
     if (rc) return rc;
     if (T > 0) {
         hipLaunchKernelGGL(k_tail_spmv, dim3((unsigned)((T + 3) / 4), nrhs), dim3(256), 0, st, T, i0,
@@ -554,10 +598,60 @@ int32_t nep_lu_solve(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_t ld
         hipLaunchKernelGGL(k_tail_gemv, dim3((unsigned)((T + 3) / 4), nrhs), dim3(256), 0, st, T, i0,
                            (const cplx*)lu->d_Sinv, (const cplx*)tmp, T, work, n);
         LAUNCHCHK();
-        launches += 2;
+        if (launches) *launches += 2;
     }
-    rc = run_head<true>(lu->U11, work, n, nrhs, st, &launches);
+    return run_head<true>(lu->U11, work, n, nrhs, st, launches);
+}
+
+int32_t nep_lu_solve(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_t ldb, nep_cdouble* dX, int64_t ldx,
+                     double scale, nep_stream stream) {
+    ARGCHK(lu && dB && dX);
+    ARGCHK(nrhs >= 1 && nrhs <= 65535 && ldb >= lu->n && ldx >= lu->n);
+    hipStream_t st = as_stream(stream);
+    const int64_t n = lu->n, T = lu->T;
+    int rc = lu->work.ensure((size_t)(n + T) * nrhs * sizeof(cplx));
     if (rc) return rc;
+    cplx* work = (cplx*)lu->work.dptr;
+    cplx* tmp = work + (size_t)n * nrhs;
+    int launches = 0;
+    const int pg = (int)std::min<int64_t>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_perm_in, dim3(pg, nrhs), dim3(256), 0, st, n, (const int32_t*)lu->d_perm_r, (const cplx*)dB, ldb,
+                       work, n);
+    LAUNCHCHK(); ++launches;
+    const int nseg = (int)(lu->L11.segs.size() + lu->U11.segs.size());
+    bool graphed = false;
+    if (lu->use_graph && nseg >= 8 && !getenv("NEP_NO_GRAPH")) {
+        if (!lu->graph_exec || lu->graph_nrhs != nrhs || lu->graph_work != (void*)work) {
+            // (re)capture: same kernels, recorded on a private stream in thread-local capture mode
+            if (lu->graph_exec) { (void)hipGraphExecDestroy(lu->graph_exec); lu->graph_exec = nullptr; }
+            if (!lu->cap_stream) HIPCHK(hipStreamCreateWithFlags(&lu->cap_stream, hipStreamNonBlocking));
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamBeginCapture(lu->cap_stream, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                int rcs = lu_sweep(lu, nrhs, work, tmp, lu->cap_stream, nullptr);
+                e = hipStreamEndCapture(lu->cap_stream, &g);
+                if (rcs == NEP_OK && e == hipSuccess && g) e = hipGraphInstantiate(&lu->graph_exec, g, nullptr, nullptr, 0);
+                else if (e == hipSuccess) e = hipErrorUnknown;
+                if (g) (void)hipGraphDestroy(g);
+            }
+            if (e != hipSuccess || !lu->graph_exec) {
+                (void)hipGetLastError();
+                lu->graph_exec = nullptr;
+                lu->use_graph = 0;              // fall back to eager launches for this factorisation
+            } else {
+                lu->graph_nrhs = nrhs; lu->graph_work = (void*)work;
+            }
+        }
+        if (lu->graph_exec) {
+            HIPCHK(hipGraphLaunch(lu->graph_exec, st));
+            launches += nseg + (T > 0 ? 2 : 0);
+            graphed = true;
+        }
+    }
+    if (!graphed) {
+        rc = lu_sweep(lu, nrhs, work, tmp, st, &launches);
+        if (rc) return rc;
+    }
     hipLaunchKernelGGL(k_perm_out, dim3(pg, nrhs), dim3(256), 0, st, n, (const int32_t*)lu->d_perm_c, (const cplx*)work, n,
                        (cplx*)dX, ldx, scale);
     LAUNCHCHK(); ++launches;

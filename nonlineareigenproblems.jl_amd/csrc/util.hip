@@ -15,15 +15,76 @@ void nep_set_error(const char* fmt, ...) {
 
 int NepScratch::ensure(size_t bytes) {
     if (bytes <= cap) return NEP_OK;
-    if (dptr) { HIPCHK(hipFree(dptr)); dptr = nullptr; cap = 0; }
+    if (dptr) { nep_pool_free(dptr); dptr = nullptr; cap = 0; }
     size_t want = bytes + bytes / 4 + 4096;
-    HIPCHK(hipMalloc(&dptr, want));
+    int rc = nep_pool_alloc(&dptr, want);
+    if (rc) return rc;
     cap = want;
     return NEP_OK;
 }
 void NepScratch::release() {
-    if (dptr) (void)hipFree(dptr);
+    if (dptr) nep_pool_free(dptr);
     dptr = nullptr; cap = 0;
+}
+
+// ---- caching device allocator ---------------------------------------------------------------------
+#include <map>
+#include <mutex>
+#include <unordered_map>
+namespace {
+std::mutex g_pool_mu;
+std::multimap<size_t, void*> g_pool_free;        // size -> block
+std::unordered_map<void*, size_t> g_pool_live;   // block -> size
+size_t g_pool_cached = 0;
+const size_t POOL_CAP = (size_t)4 << 30;         // at most 4 GiB of idle blocks
+size_t pool_round(size_t b) {
+    if (b < 4096) return 4096;
+    size_t p = 4096;
+    while (p < b) p <<= 1;                        // next power of two ...
+    const size_t q = p >> 3;                      // ... in steps of an eighth
+    return ((b + q - 1) / q) * q;
+}
+}  // namespace
+
+int nep_pool_alloc(void** p, size_t bytes) {
+    const size_t want = pool_round(bytes);
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_free.lower_bound(want);
+        if (it != g_pool_free.end() && it->first <= want + want / 4) {
+            *p = it->second;
+            g_pool_live[*p] = it->first;
+            g_pool_cached -= it->first;
+            g_pool_free.erase(it);
+            return NEP_OK;
+        }
+    }
+    HIPCHK(hipMalloc(p, want));
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    g_pool_live[*p] = want;
+    return NEP_OK;
+}
+
+void nep_pool_free(void* p) {
+    if (!p) return;
+    std::vector<void*> to_free;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        auto it = g_pool_live.find(p);
+        if (it == g_pool_live.end()) { to_free.push_back(p); }
+        else {
+            g_pool_free.emplace(it->second, p);
+            g_pool_cached += it->second;
+            g_pool_live.erase(it);
+            while (g_pool_cached > POOL_CAP && !g_pool_free.empty()) {
+                auto big = std::prev(g_pool_free.end());
+                to_free.push_back(big->second);
+                g_pool_cached -= big->first;
+                g_pool_free.erase(big);
+            }
+        }
+    }
+    for (void* q : to_free) (void)hipFree(q);
 }
 
 int PinnedRing::upload(void* ddst, const void* hsrc, size_t bytes, hipStream_t st) {
@@ -34,7 +95,10 @@ int PinnedRing::upload(void* ddst, const void* hsrc, size_t bytes, hipStream_t s
     if (cap[i] < bytes) {
         if (slot[i]) HIPCHK(hipHostFree(slot[i]));
         slot[i] = nullptr; cap[i] = 0;
-        const size_t want = bytes + bytes / 2 + 256;
+        // pinned allocations cost ~1 ms each: start at 1 MiB and double, so a growing parameter block (the B
+        // fragments of iar's Ritz GEMM grow every step) does not reallocate every few calls
+        size_t want = (size_t)1 << 20;
+        while (want < bytes) want <<= 1;
         HIPCHK(hipHostMalloc(&slot[i], want, hipHostMallocDefault));
         cap[i] = want;
     }

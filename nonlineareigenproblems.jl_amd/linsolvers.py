@@ -11,6 +11,8 @@ host step is SuperLU (SciPy's bundled copy -- the only sparse LU in this image) 
 are uploaded once; every lin_solve is the HIP kernel k_lu_solve (csrc/trsv.hip).
 """
 import ctypes as C
+import os
+import sys
 import time
 
 import numpy as np
@@ -27,9 +29,63 @@ class LinSolver:
     pass
 
 
-def _pattern_symmetric(Ac):
-    P = sp.csc_matrix((np.ones(Ac.nnz, dtype=np.int8), Ac.indices, Ac.indptr), shape=Ac.shape)
-    return (P != P.T).nnz == 0 and np.all(Ac.diagonal() != 0)
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+if _PKG_DIR not in sys.path:
+    sys.path.insert(0, _PKG_DIR)          # makes the torch-free worker module importable by name (also in spawned workers)
+import _nep_hostlu  # noqa: E402
+
+
+class HostLUPool:
+    """process pool for concurrent host factorisations (SciPy's splu holds the GIL).  Workers are spawned (never forked
+    from a process with a live HIP context) and import only NumPy/SciPy."""
+    _pool = None
+    _workers = 0
+
+    @classmethod
+    def get(cls, workers=None):
+        if workers is None:
+            workers = int(os.environ.get("NEP_HOSTLU_WORKERS", min(16, max(1, (os.cpu_count() or 2) // 2))))
+        if cls._pool is None or cls._workers != workers:
+            cls.shutdown()
+            import multiprocessing as mp
+            from concurrent.futures import ProcessPoolExecutor
+            # SuperLU is sequential: one BLAS thread per worker (the children read these variables when they load
+            # NumPy; 16 workers x 64 spinning OpenBLAS threads made a factorisation 10x slower)
+            keys = ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS")
+            saved = {k: os.environ.get(k) for k in keys}
+            for k in keys:
+                os.environ[k] = "1"
+            try:
+                cls._pool = ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn"))
+                cls._workers = workers
+                list(cls._pool.map(_nep_hostlu.ping, range(4 * workers)))     # forces all workers to start now
+            finally:
+                for k, v in saved.items():
+                    if v is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = v
+        return cls._pool
+
+    @classmethod
+    def shutdown(cls):
+        if cls._pool is not None:
+            cls._pool.shutdown(wait=False, cancel_futures=True)
+            cls._pool = None
+
+    @classmethod
+    def warm(cls, workers=None):
+        """start the workers and wait until each has imported SciPy (keeps the start-up out of timed regions)"""
+        cls.get(workers)
+
+    @classmethod
+    def submit(cls, A, **kw):
+        Ac = sp.csc_matrix(A, dtype=np.complex128)
+        return cls.get().submit(_nep_hostlu.factor, Ac.data, Ac.indices, Ac.indptr, Ac.shape, **kw)
+
+
+import atexit  # noqa: E402
+atexit.register(HostLUPool.shutdown)
 
 
 class DeviceLU:
@@ -40,45 +96,36 @@ class DeviceLU:
     (fill-reducing ordering of A+A', diagonal pivots preferred with tolerance 0.001) -> SuperLU with
     permc_spec=MMD_AT_PLUS_A, SymmetricMode, diag_pivot_thresh=0.001; otherwise the unsymmetric strategy
     (column ordering, threshold partial pivoting) -> COLAMD with SuperLU's default threshold.  Explicit
-    arguments override the choice."""
+    arguments override the choice.  `factors` (the dict returned by _nep_hostlu.factor, e.g. from a HostLUPool
+    worker) skips the host factorisation."""
 
-    def __init__(self, A, permc_spec=None, diag_pivot_thresh=None, symmetric_mode=None):
+    def __init__(self, A=None, permc_spec=None, diag_pivot_thresh=None, symmetric_mode=None, expected_solves=50,
+                 factors=None):
         _lib.require_gpu()
         t0 = time.perf_counter()
-        n = A.shape[0]
+        if factors is None:
+            Ac = sp.csc_matrix(A, dtype=np.complex128)
+            try:
+                factors = _nep_hostlu.factor(Ac.data, Ac.indices, Ac.indptr, Ac.shape, permc_spec=permc_spec,
+                                             diag_pivot_thresh=diag_pivot_thresh, symmetric_mode=symmetric_mode)
+            except RuntimeError as e:  # "Factor is exactly singular"
+                raise np.linalg.LinAlgError("SingularException: " + str(e))
+        F = factors
+        n = int(F["n"])
         self.n = n
-        Ac = sp.csc_matrix(A, dtype=np.complex128)
-        self.normA = float(np.linalg.norm(Ac.data))          # ||A||_F, used by the refinement stopping test
-        if permc_spec is None or symmetric_mode is None:
-            sym = _pattern_symmetric(Ac)
-            if permc_spec is None:
-                permc_spec = "MMD_AT_PLUS_A" if sym else "COLAMD"
-            if symmetric_mode is None:
-                symmetric_mode = sym and permc_spec == "MMD_AT_PLUS_A"
-        if diag_pivot_thresh is None and symmetric_mode:
-            diag_pivot_thresh = 0.001
-        self.strategy = dict(permc_spec=permc_spec, diag_pivot_thresh=diag_pivot_thresh, symmetric_mode=symmetric_mode)
-        kw = dict(permc_spec=permc_spec)
-        if diag_pivot_thresh is not None:
-            kw["diag_pivot_thresh"] = diag_pivot_thresh
-        if symmetric_mode:
-            kw["options"] = dict(SymmetricMode=True)
-        try:
-            lu = spla.splu(Ac, **kw)
-        except RuntimeError as e:  # "Factor is exactly singular"
-            raise np.linalg.LinAlgError("SingularException: " + str(e))
-        self.t_factor = time.perf_counter() - t0
-        L = sp.csr_matrix(lu.L); U = sp.csr_matrix(lu.U)
-        L.sort_indices(); U.sort_indices()
-        Lp = np.ascontiguousarray(L.indptr, dtype=np.int32); Li = np.ascontiguousarray(L.indices, dtype=np.int32)
-        Lx = np.ascontiguousarray(L.data, dtype=np.complex128)
-        Up = np.ascontiguousarray(U.indptr, dtype=np.int32); Ui = np.ascontiguousarray(U.indices, dtype=np.int32)
-        Ux = np.ascontiguousarray(U.data, dtype=np.complex128)
-        pr = np.ascontiguousarray(lu.perm_r, dtype=np.int32); pc = np.ascontiguousarray(lu.perm_c, dtype=np.int32)
+        self.normA = F["normA"]          # ||A||_F, used by the refinement stopping test
+        self.strategy = F["strategy"]
+        self.t_factor = F["t_factor"]
+        t_a = time.perf_counter()
+        Lp, Li, Lx, Up, Ui, Ux, pr, pc = (F[k] for k in ("Lp", "Li", "Lx", "Up", "Ui", "Ux", "perm_r", "perm_c"))
+        self.t_convert = time.perf_counter() - t_a
+        t_b = time.perf_counter()
+        check(lib.nep_lu_set_expected_solves(int(expected_solves)))
         h = c_vp()
         check(lib.nep_lu_create(n, hptr(Lp), hptr(Li), hptr(Lx), hptr(Up), hptr(Ui), hptr(Ux), hptr(pr), hptr(pc),
                                 C.byref(h)))
         self.h = h
+        self.t_create = time.perf_counter() - t_b
         info = (c_i64 * 6)()
         check(lib.nep_lu_info(self.h, info))
         self.nnzL, self.nnzU, self.levL, self.levU, self.solve_bytes = (int(info[1]), int(info[2]), int(info[3]),
@@ -125,6 +172,7 @@ class FactorizeLinSolver(LinSolver):
         self.nep = nep
         self.lam = lam
         self.umfpack_refinements = umfpack_refinements
+        lu_kw.setdefault("expected_solves", 200)      # a FactorizeLinSolver exists to be reused (iar/tiar: maxit solves)
         self.lu = _lu if _lu is not None else DeviceLU(nep.compute_Mder(lam), permc_spec=permc_spec, **lu_kw)
         self.refine_steps_taken = 0
         self.solves = 0
@@ -183,7 +231,7 @@ class BackslashLinSolver(LinSolver):
         self.lu_kw = lu_kw
 
     def solve_dev(self, b, out=None, scale=1.0):
-        lu = DeviceLU(self.A, permc_spec=self.permc_spec, **self.lu_kw)
+        lu = DeviceLU(self.A, permc_spec=self.permc_spec, expected_solves=1, **self.lu_kw)
         self.last_lu = lu
         return lu.solve(b, out=out, scale=scale)
 
@@ -224,8 +272,12 @@ class FactorizeLinSolverCreator(LinSolverCreator):
 
 
 class BackslashLinSolverCreator(LinSolverCreator):
-    def __init__(self, permc_spec=None, **lu_kw):
+    """`workers`: host processes used by drivers that know several shifts in advance (contour_beyn); None = auto,
+    0 = factor in-process one node at a time."""
+
+    def __init__(self, permc_spec=None, workers=None, **lu_kw):
         self.permc_spec = permc_spec
+        self.workers = workers
         self.lu_kw = lu_kw
 
 

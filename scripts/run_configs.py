@@ -1,0 +1,141 @@
+#!/usr/bin/env python
+"""Runs the five BASELINE.json configurations on the device backend and, where cheap
+enough, through the CPU oracle on the same inputs; prints one JSON line per configuration with eigenpair counts,
+residuals, wall times and parity against the oracle.  Usage:  python scripts/run_configs.py [c1 c2 c3 c4 c5] [--oracle]
+[--wep-nx NX --wep-nz NZ]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+EPS = np.finfo(float).eps
+
+
+def emit(**kw):
+    print(json.dumps(kw, default=lambda o: float(o) if isinstance(o, (np.floating,)) else str(o)), flush=True)
+
+
+def match(l1, l2, rtol):
+    l2 = list(l2); worst = 0.0
+    if len(l1) != len(l2):
+        return False, None
+    for x in l1:
+        j = int(np.argmin([abs(x - y) for y in l2])); worst = max(worst, abs(x - l2[j]) / max(1.0, abs(x))); l2.pop(j)
+    return worst <= rtol, worst
+
+
+def gun_r1():
+    gam = 300.0 ** 2 - 200.0 ** 2; mu = 250.0 ** 2; sigma2 = 108.8774
+    xmin = gam * (-1) + mu; xmax = gam + mu
+    th = np.linspace(0, np.pi, int(round(np.pi / 2 * 1000)) + 2)
+    Sigma = np.concatenate([xmin + (xmax - xmin) * (np.exp(1j * th) / 2 + .5), [xmin]])
+    nodes = gam * np.array([2 / 3, (1 + 1j) / 3, 0, (-1 + 1j) / 3, -2 / 3]) + mu
+    Xi = -10.0 ** np.linspace(-8, 8, 10000) + sigma2 ** 2
+    return Sigma, Xi, nodes
+
+
+def timed(f):
+    torch.cuda.synchronize(); t = time.perf_counter(); r = f(); torch.cuda.synchronize()
+    return r, time.perf_counter() - t
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("which", nargs="*", default=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("--oracle", action="store_true", help="also run the (slow) CPU oracle for C2/C3")
+    ap.add_argument("--wep-nx", type=int, default=303)
+    ap.add_argument("--wep-nz", type=int, default=299)
+    args = ap.parse_args()
+    import nep_amd as na
+    from oracle import gallery as og, solvers as osol, neps as oneps
+
+    if "c1" in args.which:
+        nep = na.nep_gallery("dep0"); onep = og.dep0()
+        (lam, v), t = timed(lambda: na.resinv(nep, lam=0, v=np.ones(5)))
+        t0 = time.perf_counter(); lo, vo = osol.resinv(onep, lam=0, v=np.ones(5)); to = time.perf_counter() - t0
+        emit(config="C1 dep0 n=5 resinv", gpu_lambda=[lam.real, lam.imag], cpu_lambda=[lo.real, lo.imag],
+             backward_error=osol.DefaultErrmeasure(onep)(lam, v), gpu_s=t, cpu_s=to, parity=bool(abs(lam - lo) < 1e-10))
+
+    if "c2" in args.which:
+        nep = na.nep_gallery("gun_spmf_scaled"); n = nep.n; nep.dev
+        run = lambda: na.iar(nep, maxit=100, neigs=np.inf, v=np.ones(n), tol=1e-10)
+        run()
+        (lam, Q, _), t = timed(run)
+        onep = og.gun_spmf_scaled()
+        oE = osol.StandardSPMFErrmeasure(onep)
+        res = max(oE(lam[i], Q[:, i]) for i in range(len(lam)))
+        out = dict(config="C2 gun SPMF iar m=100", n=n, eigenpairs=len(lam), max_backward_error=res, gpu_s=t,
+                   eigenpairs_per_s=len(lam) / t)
+        if args.oracle:
+            t0 = time.perf_counter()
+            lo, Qo, _ = osol.iar(oneps.DerSPMF(onep, 0.0, 100), maxit=100, neigs=np.inf, v=np.ones(n), tol=1e-10, errmeasure=oE,
+                                 linsolvercreator=osol.FactorizeLinSolverCreator(permc_spec="MMD_AT_PLUS_A"))
+            to = time.perf_counter() - t0
+            ok, worst = match(lam, lo, 1e-8)
+            out.update(cpu_eigenpairs=len(lo), cpu_s=to, cpu_eigenpairs_per_s=len(lo) / to, parity=ok, max_rel_eig_diff=worst)
+        emit(**out)
+
+    if "c3" in args.which:
+        Sigma, Xi, nodes = gun_r1()
+        nep = na.nep_gallery("nlevp_native_gun"); n = nep.n; nep.dev
+        v = np.random.Generator(np.random.Philox(1)).standard_normal(n) + 0j
+        info = {}
+        run = lambda: na.nleigs(nep, Sigma, Xi=Xi, maxit=100, v=v, leja=0, nodes=nodes, reusefact=2, tol=1e-10,
+                                errmeasure=na.StandardSPMFErrmeasure(nep), info=info)
+        (lam, X, res), t = timed(run)
+        onep = og.nlevp_native_gun()
+        oE = osol.StandardSPMFErrmeasure(onep)
+        out = dict(config="C3 gun nleigs variant R1 maxit=100", n=n, eigenpairs=len(lam), factorizations=info["nfact"],
+                   max_backward_error=max([oE(lam[i], X[:, i]) for i in range(len(lam))] + [0.0]), gpu_s=t,
+                   eigenpairs_per_s=len(lam) / t, ritz_in_sigma=info["nblamin"])
+        if args.oracle:
+            from oracle import nleigs as onl
+            t0 = time.perf_counter()
+            lo, Xo, ro = onl.nleigs(onep, Sigma, Xi=Xi, maxit=100, v=v, leja=0, nodes=nodes, reusefact=2, tol=1e-10, errmeasure=oE)
+            to = time.perf_counter() - t0
+            ok, worst = match(lam, lo, 1e-8)
+            out.update(cpu_eigenpairs=len(lo), cpu_s=to, parity=ok, max_rel_eig_diff=worst)
+        emit(**out)
+
+    if "c4" in args.which:
+        nep = na.nep_gallery("gun_spmf"); n = nep.n; nep.dev
+        onep = og.gun_spmf()
+        Vh = na.probe_block(n, 32)
+        kw = dict(sigma=250.0 ** 2, radius=1e4, N=64, k=32, neigs=10 ** 6, tol=1e-6, sanity_check=True)
+        ig = {}
+        run = lambda: na.contour_beyn(nep, Vh=Vh, info=ig, **kw)
+        (lam, V), t = timed(run)
+        oE = osol.StandardSPMFErrmeasure(onep)
+        t0 = time.perf_counter(); io = {}
+        lo, Vo = osol.contour_beyn(onep, Vh=Vh, info=io, **kw)
+        to = time.perf_counter() - t0
+        ok, worst = match(lam, lo, 1e-7)
+        emit(config="C4 gun contour_beyn N=64 k=32 radius=1e4 (1 GPU)", n=n, eigenpairs=len(lam), rank_p=ig["p"],
+             cpu_rank_p=io["p"], max_backward_error=max([oE(lam[i], V[:, i]) for i in range(len(lam))] + [0.0]), gpu_s=t,
+             eigenpairs_per_s=len(lam) / t, cpu_eigenpairs=len(lo), cpu_s=to, cpu_eigenpairs_per_s=len(lo) / to, parity=ok,
+             max_rel_eig_diff=worst)
+
+    if "c5" in args.which:
+        nx, nz = args.wep_nx, args.wep_nz
+        t0 = time.perf_counter()
+        nep = na.nep_gallery("WEP", nx=nx, nz=nz, benchmark_problem="JARLEBRING"); n = nep.n; nep.dev
+        tgen = time.perf_counter() - t0
+        v0 = np.ones(n) / np.sqrt(n)
+        tm = {}
+        run = lambda: na.tiar(nep, sigma=-3 - 3.5j, gamma=1.0, maxit=60, neigs=np.inf, v=v0, tol=1e-8, timers=tm)
+        (out4, t) = timed(run)
+        lam, Q = out4[0], out4[1]
+        R = na.ResidualErrmeasure(nep)
+        res = [na.estimate_error(R, lam[i], Q[:, i]) for i in range(len(lam))]
+        emit(config="C5 WEP JARLEBRING tiar m=60", nx=nx, nz=nz, n=n, eigenpairs=len(lam), max_residual=max(res + [0.0]),
+             gpu_s=t, eigenpairs_per_s=len(lam) / t, generate_s=tgen, phases_s={k_: round(v_, 4) for k_, v_ in tm.items()},
+             eigenvalues=[[l.real, l.imag] for l in lam[:6]])
+
+
+if __name__ == "__main__":
+    main()
