@@ -178,6 +178,20 @@ def main():
         byts, ms = mlincomb_roofline(na, nep, k)
         byts1, ms1 = mlincomb_roofline(na, nep, 1)
         achieved = byts / (ms * 1e-3) / 1e9
+        # HBM traffic of the same two kernels from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and
+        # --pmc WRITE_SIZE runs of scratch/pmc_k1.py; FETCH_SIZE doubled per the gfx950 correction of
+        # MI355X_MICROARCH.md).  Recorded measurement, not live: PMC collection needs rocprofv3 around the process.
+        traffic = None; traffic_src = None
+        try:
+            pj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_k1_traffic.json")))["gun"]
+            kb = 0.0
+            for name, d in pj.items():
+                if name.startswith("k_vc") or name.startswith("k_spmv grid"):
+                    kb += 2 * d["FETCH_SIZE"]["avg_KB"] + d["WRITE_SIZE"]["avg_KB"]
+            traffic = kb * 1024.0
+            traffic_src = "profiles/r1_pmc_k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, k=100, FETCH x2 gfx950 correction)"
+        except Exception:
+            pass
         out = {
             "metric": "eigenpairs/sec (gun SPMF iar m=%d) + compute_Mlincomb GB/s" % args.maxit,
             "value": pairs / dt, "unit": "eigenpairs/s", "n_gpus": world, "steps": args.steps,
@@ -193,7 +207,7 @@ def main():
             "compute_Mlincomb_GBps": achieved,
             "roofline": {"bound": "hbm", "kernel": "nep_mlincomb = k_vc + k_spmv, k=%d columns" % k,
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "algorithmic_bytes": byts, "ms_per_launch": ms,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": byts, "ms_per_launch": ms,
                          "single_vector": {"algorithmic_bytes": byts1, "ms_per_launch": ms1,
                                            "achieved": byts1 / (ms1 * 1e-3) / 1e9}},
             "kernels": {"note": "wall ms per phase of one instrumented iar run (torch.cuda.synchronize around each phase)",
