@@ -241,7 +241,10 @@ def lin_solve(solver, b, tol=0, scale=1.0):
     (nrhs, n) / (n,) (-> device result).  `scale` multiplies the result on the device."""
     host = not is_dev(b)
     bd = to_dev(b) if host else b
-    x = solver.solve_dev(bd, scale=scale)
+    if isinstance(solver, GMRESLinSolver):
+        x = solver.solve_dev(bd, scale=scale, tol=tol)          # `tol` is a hint for iterative solvers (LinSolvers.jl:184)
+    else:
+        x = solver.solve_dev(bd, scale=scale)
     if host:
         xh = to_host(x if x.dim() == 2 else x.reshape(1, -1))
         return xh[:, 0] if np.ndim(b) == 1 else xh
@@ -288,6 +291,8 @@ def create_linsolver(creator, nep, lam):
     """src/LinSolverCreators.jl:107-122,143."""
     if isinstance(creator, BackslashLinSolverCreator):
         return BackslashLinSolver(nep, lam, creator.permc_spec, **creator.lu_kw)
+    if isinstance(creator, GMRESLinSolverCreator):
+        return GMRESLinSolver(nep, lam, creator.kwargs)
     key = complex(lam)
     if key in creator.recycled_factorizations:
         return FactorizeLinSolver(nep, lam, creator.umfpack_refinements, _lu=creator.recycled_factorizations[key])
@@ -319,3 +324,104 @@ class LinSolverCache:
 
     def solve_dev(self, sigma, y, add_to_cache, out=None, scale=1.0):
         return self._get(sigma, add_to_cache).solve_dev(y, out=out, scale=scale)
+
+
+class GMRESLinSolver(LinSolver):
+    """src/LinSolvers.jl:171-188: matrix-free restarted GMRES on v -> compute_Mlincomb(nep, lam, v), i.e. every
+    iteration is one K1 call (folded single-vector SpMV) + one K6 orthogonalisation (IterativeSolvers' default
+    ModifiedGramSchmidt) on the device; only the (restart+1) x restart Hessenberg / Givens data live on the host.
+    kwargs mirror IterativeSolvers.gmres!: Pl (left preconditioner: a vector/diagonal matrix d meaning Pl \\ r = r ./ d,
+    or a callable acting on a device vector), reltol (alias tol), abstol, restart, maxiter."""
+
+    def __init__(self, nep, lam, kwargs=None):
+        kwargs = dict(kwargs or {})
+        self.nep, self.lam = nep, lam
+        self.n = nep.size(1)
+        self.restart = int(kwargs.get("restart", min(20, self.n)))
+        self.maxiter = int(kwargs.get("maxiter", self.n))
+        self.reltol = kwargs.get("reltol", kwargs.get("tol", None))
+        self.abstol = float(kwargs.get("abstol", 0.0))
+        Pl = kwargs.get("Pl", None)
+        self._Pl_call = None
+        self._Pl_inv = None
+        if Pl is not None:
+            if callable(Pl):
+                self._Pl_call = Pl
+            else:
+                d = np.asarray(Pl) if np.ndim(Pl) == 1 else (Pl.diagonal() if hasattr(Pl, "diagonal") else np.diag(np.asarray(Pl)))
+                self._Pl_inv = to_dev(1.0 / np.asarray(d, dtype=np.complex128))[0]
+        self.iterations = 0
+
+    def _prec(self, r):
+        if self._Pl_inv is not None:
+            check(lib.nep_hadamard(self.n, 1, c_vp(r.data_ptr()), self.n, c_vp(self._Pl_inv.data_ptr()), self.n, stream_ptr()))
+        elif self._Pl_call is not None:
+            out = self._Pl_call(r)
+            if out is not None and out.data_ptr() != r.data_ptr():
+                from . import dense
+                dense.copy(out, r, self.n)
+        return r
+
+    def solve_dev(self, b, out=None, scale=1.0, tol=None):
+        from . import dense
+        n, m = self.n, self.restart
+        if b.dim() == 2 and b.shape[0] > 1:
+            X = torch.empty_like(b) if out is None else out
+            for j in range(b.shape[0]):
+                self.solve_dev(b[j], out=X[j], scale=scale, tol=tol)
+            return X
+        reltol = tol if tol else (self.reltol if self.reltol is not None else np.sqrt(np.finfo(float).eps))
+        bvec = b.reshape(n)
+        x = torch.zeros(n, dtype=CDT, device="cuda")
+        V = torch.empty((m + 1, n), dtype=CDT, device="cuda")
+        r = torch.empty(n, dtype=CDT, device="cuda")
+        dense.copy(bvec, r, n); self._prec(r)
+        beta = dense.nrm2(r)
+        tolabs = max(reltol * beta, self.abstol)
+        its = 0
+        while beta > tolabs and its < self.maxiter:
+            dense.copy(r, V[0], n); dense.scal(V[0], 1.0 / beta, n)
+            H = np.zeros((m + 1, m), dtype=np.complex128)
+            cs = np.zeros(m, dtype=np.complex128); sn = np.zeros(m, dtype=np.complex128)
+            g = np.zeros(m + 1, dtype=np.complex128); g[0] = beta
+            j_done = 0
+            for j in range(m):
+                w = V[j + 1]
+                dense.copy(self.nep.compute_Mlincomb(self.lam, V[j].reshape(1, n)), w, n)
+                self._prec(w)
+                h, hb, _ = dense.orthogonalize_and_normalize(V, w, j + 1, rows=n, ldv=n, method=dense.MGS)
+                H[:j + 1, j] = h; H[j + 1, j] = hb
+                for i in range(j):                       # apply previous Givens rotations
+                    t = cs[i] * H[i, j] + sn[i] * H[i + 1, j]
+                    H[i + 1, j] = -np.conj(sn[i]) * H[i, j] + np.conj(cs[i]) * H[i + 1, j]
+                    H[i, j] = t
+                a_, b_ = H[j, j], H[j + 1, j]
+                d = np.sqrt(abs(a_) ** 2 + abs(b_) ** 2)
+                cs[j] = a_ / d; sn[j] = b_ / d
+                cs[j] = np.conj(cs[j]); sn[j] = np.conj(sn[j])
+                H[j, j] = d; H[j + 1, j] = 0.0
+                g[j + 1] = -np.conj(sn[j]) * g[j]
+                g[j] = cs[j] * g[j]
+                its += 1; j_done = j + 1
+                if abs(g[j + 1]) <= tolabs or its >= self.maxiter:
+                    break
+            y = np.linalg.solve(np.triu(H[:j_done, :j_done]), g[:j_done])
+            dx = dense.gemm_ts(V, y.reshape(-1, 1), k=j_done, rows=n, ldz=n)          # (1, n)
+            dense.axpy(1.0, dx, x, n)
+            # true (preconditioned) residual for the restart
+            dense.copy(self.nep.compute_Mlincomb(self.lam, x.reshape(1, n)), r, n)
+            dense.scal(r, -1.0, n); dense.axpy(1.0, bvec, r, n); self._prec(r)
+            beta = dense.nrm2(r)
+        self.iterations = its
+        X = torch.empty_like(b) if out is None else out
+        dense.copy(x, X, n)
+        if scale != 1.0:
+            dense.scal(X, scale, n)
+        return X.reshape(b.shape)
+
+
+class GMRESLinSolverCreator(LinSolverCreator):
+    """src/LinSolverCreators.jl:124-145"""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs

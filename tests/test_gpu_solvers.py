@@ -301,3 +301,32 @@ def test_nleigs_gun_twin_r1_vs_oracle(na):
     assert len(lg) == len(lo) and len(lg) >= 1
     _match(lg, lo, 1e-8)
     assert max(oE(lg[i], Xg[:, i]) for i in range(len(lg))) < 1e-10
+
+
+def test_gmres_linsolver(na):
+    """docs/src/tutorial_linsolve.md / test/newlinsolve.jl: tridiagonal SPMF n=100, GMRES with the diagonal of M(lam0)
+    as left preconditioner vs the factorised solver."""
+    import scipy.sparse as sp
+    n = 100; alpha = 0.01
+    A = sp.diags([np.ones(n), alpha * np.ones(n - 1), alpha * np.ones(n - 1)], [0, 1, -1], format="csc")
+    B = sp.identity(n, format="csc"); Cm = sp.diags(np.arange(1, n + 1) / n, format="csc")
+    nep = na.SPMF_NEP([A, B, Cm], [na.funcs.one(), na.funcs.ident(), na.funcs.Exp(1.0)])
+    lam0 = -1.02
+    M = sp.csc_matrix(nep.compute_Mder(lam0))
+    b = np.arange(1, n + 1) + 1j
+    creator = na.GMRESLinSolverCreator(Pl=M.diagonal(), tol=1e-12)
+    s = na.create_linsolver(creator, nep, lam0)
+    x = na.lin_solve(s, b)
+    assert np.linalg.norm(M @ x - b) <= 1e-10 * np.linalg.norm(b)
+    assert 0 < s.iterations <= n
+    # no preconditioner: full GMRES at the (nearly singular) shift, restarted GMRES(5) at a well-conditioned one
+    x2 = na.lin_solve(na.create_linsolver(na.GMRESLinSolverCreator(tol=1e-12, restart=n), nep, lam0), b)
+    assert np.linalg.norm(M @ x2 - b) <= 1e-8 * np.linalg.norm(b)
+    M3 = sp.csc_matrix(nep.compute_Mder(3.0))
+    s3 = na.create_linsolver(na.GMRESLinSolverCreator(tol=1e-12, restart=5), nep, 3.0)
+    x3 = na.lin_solve(s3, b)
+    assert np.linalg.norm(M3 @ x3 - b) <= 1e-10 * np.linalg.norm(b) and s3.iterations > 5
+    # as the linear solver of a NEP driver
+    l1, v1 = na.quasinewton(nep, lam=lam0, v=np.ones(n), tol=1e-12)
+    l2, v2 = na.quasinewton(nep, lam=lam0, v=np.ones(n), tol=1e-12, linsolvercreator=na.GMRESLinSolverCreator(Pl=M.diagonal(), tol=1e-12))
+    assert abs(l1 - l2) < 1e-10
