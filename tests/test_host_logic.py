@@ -136,3 +136,40 @@ def test_spmf_constructor_errors():
         na.SPMF_NEP([A, np.eye(3)], [na.funcs.one(), na.funcs.ident()])
     with pytest.raises(ValueError):
         na.SPMF_NEP([A, sp.identity(4, format="csc")], [na.funcs.one(), na.funcs.ident()])
+
+
+def test_rk_helper_matches_oracle():
+    """host setup of nleigs (polygon discretisation, Leja-Bagby points, scalar divided differences, point-in-polygon)"""
+    from oracle import nleigs as onl
+    rk = na.rk_helper
+    Sigma = np.array([-10 - 2j, 10 - 2j, 10 + 2j, -10 + 2j])
+    g1, z1 = rk.discretizepolygon(Sigma, True); g2, z2 = onl.discretizepolygon(Sigma, True)
+    assert np.array_equal(g1, g2) and np.array_equal(z1, z2)
+    a1, b1, c1 = rk.lejabagby(g1, np.array([np.inf]), g1, 12, False, 2); a2, b2, c2 = onl.lejabagby(g2, np.array([np.inf]), g2, 12, False, 2)
+    assert np.array_equal(a1, a2) and np.array_equal(b1, b2) and np.array_equal(c1, c2)
+    fv_p = [na.funcs.one(), na.funcs.ident(), na.funcs.ISqrt(1.0, 0.0)]
+    fv_o = [oneps.f_one(), oneps.f_id(), oneps.f_isqrt(0.0)]
+    sig = 62500 + 1e4 * np.exp(2j * np.pi * np.arange(8) / 8); xi = -np.logspace(0, 3, 8); be = np.linspace(1, 2, 8)
+    s1 = rk.scgendivdiffs(sig, xi, be, fv_p); s2 = onl.scgendivdiffs(sig, xi, be, 6, fv_o)
+    assert np.allclose(s1, s2, rtol=1e-10, atol=1e-14 * abs(s2).max())
+    pts = np.array([0, 9.99 + 1.99j, 10 + 2j, 10.01, -10 - 2j, 3 - 2j, 3 - 2.0001j])
+    assert list(rk.in_Sigma(pts, Sigma, 1e-10)) == list(onl.in_Sigma(pts, Sigma, 1e-10)) == [True, True, True, False, True, True, False]
+    assert rk.rk_structure(na.nep_gallery("nlevp_native_gun", 655)) == (1, 2)
+    assert rk.rk_structure(na.PEP([np.eye(2)] * 3)) == (2, 0)
+    assert rk.rk_structure(na.nep_gallery("dep0")) == (-1, 3)
+
+
+def test_hostlu_factor_strategy():
+    """UMFPACK-like strategy selection and factor layout (torch-free worker module)"""
+    import _nep_hostlu as hl
+    import scipy.sparse.linalg as spla
+    A = sp.csc_matrix(og.gun_spmf(655).compute_Mder(250.0 ** 2 + 1j), dtype=complex)
+    F = hl.factor(A.data, A.indices, A.indptr, A.shape)
+    assert F["strategy"]["symmetric_mode"] and F["strategy"]["permc_spec"] == "MMD_AT_PLUS_A"
+    n = A.shape[0]
+    L = sp.csr_matrix((F["Lx"], F["Li"], F["Lp"]), shape=(n, n)); U = sp.csr_matrix((F["Ux"], F["Ui"], F["Up"]), shape=(n, n))
+    Pr = sp.csc_matrix((np.ones(n), (F["perm_r"], np.arange(n)))); Pc = sp.csc_matrix((np.ones(n), (np.arange(n), F["perm_c"])))
+    assert abs(Pr @ A @ Pc - L @ U).max() <= 1e-10 * abs(A).max()
+    B = A.copy().tolil(); B[0, 5] = 1.0; B = sp.csc_matrix(B)            # break structural symmetry
+    F2 = hl.factor(B.data, B.indices, B.indptr, B.shape)
+    assert not F2["strategy"]["symmetric_mode"] and F2["strategy"]["permc_spec"] == "COLAMD"
