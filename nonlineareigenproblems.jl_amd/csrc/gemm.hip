@@ -109,8 +109,8 @@ static inline int gemm_nt(int pp) {   // N-tiles of 8 complex output columns
     return pp <= 8 ? 1 : pp <= 16 ? 2 : pp <= 32 ? 4 : pp <= 48 ? 6 : pp <= 64 ? 8 : pp <= 80 ? 10 : 13;
 }
 
-static NepScratch g_gemm_scratch;
-static PinnedRing g_gemm_ring;
+static thread_local NepScratch g_gemm_scratch;
+static thread_local PinnedRing g_gemm_ring;
 
 template <int NT>
 static int gemm_launch(bool rowmajor, const cplx* Z, int64_t ldz, int64_t rows, int k, const double* dB, int nks,
@@ -208,7 +208,7 @@ extern "C" int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows,
     return NEP_OK;
 }
 
-static NepScratch g_gemm_scratch_dev;
+static thread_local NepScratch g_gemm_scratch_dev;
 
 extern "C" int32_t nep_gemm_ts_dev(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_t k,
                                    const nep_cdouble* dB, int64_t ldb, int32_t b_rowmajor, int32_t p,

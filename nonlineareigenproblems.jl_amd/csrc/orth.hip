@@ -123,7 +123,7 @@ __global__ __launch_bounds__(512) void k_orth_update(const cplx* __restrict__ V,
     }
 }
 
-static NepScratch g_orth_scratch;
+static thread_local NepScratch g_orth_scratch;
 
 extern "C" int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
                             const int64_t* h_active_rows, nep_cdouble* dw, nep_cdouble* h_h, double* h_beta,

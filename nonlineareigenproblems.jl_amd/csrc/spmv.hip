@@ -540,29 +540,34 @@ int32_t nep_mlincomb_dev(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t 
 int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
                         double* h_rnorm, double* h_qnorm, nep_stream stream) {
     ARGCHK(s && hF && dQT && h_rnorm && h_qnorm);
-    ARGCHK(k >= 1 && k <= 256 && ldq >= k);
+    ARGCHK(k >= 1 && ldq >= k);
     hipStream_t st = as_stream(stream);
-    const size_t cbytes = (size_t)k * s->mt * sizeof(cplx);
-    int rc = s->coef.ensure(cbytes);
-    if (rc) return rc;
-    rc = s->ring.upload(s->coef.dptr, hF, cbytes, st);
-    if (rc) return rc;
-    int grid = (int)std::min<int64_t>((s->n + 3) / 4, 2048);
-    rc = s->part.ensure(((size_t)grid * 2 * k + 2 * k) * sizeof(double));
-    if (rc) return rc;
-    double* partial = (double*)s->part.dptr;
-    double* outd = partial + (size_t)grid * 2 * k;
-    if (s->valbytes == 8)
-        rc = launch_spmm<double>(s, k, (const cplx*)s->coef.dptr, (const cplx*)dQT, ldq, 0, nullptr, 0, partial, grid, st);
-    else
-        rc = launch_spmm<cplx>(s, k, (const cplx*)s->coef.dptr, (const cplx*)dQT, ldq, 0, nullptr, 0, partial, grid, st);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_sum_partials_d, dim3(2 * k), dim3(256), 0, st, grid, 2 * k, partial, outd);
-    LAUNCHCHK();
-    std::vector<double> h(2 * k);
-    HIPCHK(hipMemcpyAsync(h.data(), outd, (size_t)2 * k * sizeof(double), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    for (int j = 0; j < k; ++j) { h_rnorm[j] = sqrt(h[j]); h_qnorm[j] = sqrt(h[k + j]); }
+    // panels of at most 256 Ritz vectors per pass over the matrix
+    for (int32_t j0 = 0; j0 < k; j0 += 256) {
+        const int32_t kk = std::min(256, k - j0);
+        const size_t cbytes = (size_t)kk * s->mt * sizeof(cplx);
+        int rc = s->coef.ensure(cbytes);
+        if (rc) return rc;
+        rc = s->ring.upload(s->coef.dptr, hF + (size_t)j0 * s->mt, cbytes, st);
+        if (rc) return rc;
+        int grid = (int)std::min<int64_t>((s->n + 3) / 4, 2048);
+        rc = s->part.ensure(((size_t)grid * 2 * kk + 2 * kk) * sizeof(double));
+        if (rc) return rc;
+        double* partial = (double*)s->part.dptr;
+        double* outd = partial + (size_t)grid * 2 * kk;
+        const cplx* Q = (const cplx*)dQT + j0;
+        if (s->valbytes == 8)
+            rc = launch_spmm<double>(s, kk, (const cplx*)s->coef.dptr, Q, ldq, 0, nullptr, 0, partial, grid, st);
+        else
+            rc = launch_spmm<cplx>(s, kk, (const cplx*)s->coef.dptr, Q, ldq, 0, nullptr, 0, partial, grid, st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_sum_partials_d, dim3(2 * kk), dim3(256), 0, st, grid, 2 * kk, partial, outd);
+        LAUNCHCHK();
+        std::vector<double> h(2 * kk);
+        HIPCHK(hipMemcpyAsync(h.data(), outd, (size_t)2 * kk * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        for (int j = 0; j < kk; ++j) { h_rnorm[j0 + j] = sqrt(h[j]); h_qnorm[j0 + j] = sqrt(h[kk + j]); }
+    }
     return NEP_OK;
 }
 

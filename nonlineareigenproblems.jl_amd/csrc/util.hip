@@ -371,7 +371,7 @@ static inline int grid_for(int64_t work, int block, int cap = 4096) {
     return (int)g;
 }
 
-static NepScratch g_util_scratch;  // partial sums for nrm2/coldots (single host thread per process use)
+static thread_local NepScratch g_util_scratch;  // partial sums for nrm2/coldots (single host thread per process use)
 
 extern "C" {
 
@@ -436,8 +436,8 @@ int32_t nep_nrm2(int64_t len, const nep_cdouble* dx, double* h_out, nep_stream s
     return nep_colnorms(len, 1, dx, len, h_out, stream);
 }
 
-static NepScratch g_rk_scratch;
-static PinnedRing g_rk_ring;
+static thread_local NepScratch g_rk_scratch;
+static thread_local PinnedRing g_rk_ring;
 
 int32_t nep_rk_bw(int64_t n, int32_t N, const nep_cdouble* dwc, const nep_cdouble* h_c, nep_cdouble* dBw, nep_stream stream) {
     ARGCHK(n > 0 && N >= 0 && dwc && dBw && (N == 0 || h_c));

@@ -1,0 +1,75 @@
+"""Full-size (BASELINE.json configs) GPU checks: eigenpair counts + independently re-evaluated residuals, and
+size-independent properties of the kernels (linearity, orthogonality, agreement with host SciPy where the host
+finishes in seconds)."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def na():
+    import nep_amd
+    assert nep_amd.device_count() >= 1
+    return nep_amd
+
+
+def test_c2_gun_iar_m100_fullsize(na):
+    """config C2: 46 eigenpairs with backward error < 1e-10 (SURVEY.md Appendix B.1 probe: 46 at k=100)"""
+    nep = na.nep_gallery("gun_spmf_scaled"); n = nep.n
+    hist = []
+    lam, Q, V = na.iar(nep, sigma=0.0, gamma=1.0, maxit=100, neigs=np.inf, v=np.ones(n), tol=1e-10, errhist=hist)
+    assert len(lam) == 46
+    Av = nep.get_Av(); fv = nep.get_fv(); fro = nep.fro_norms()
+    for s in range(len(lam)):                                     # host FP64 re-evaluation, reference criterion
+        r = sum(f(lam[s]) * (A @ Q[:, s]) for A, f in zip(Av, fv))
+        den = sum(c * abs(f(lam[s])) for c, f in zip(fro, fv)) * np.linalg.norm(Q[:, s])
+        assert np.linalg.norm(r) / den < 1e-10
+    # eigenvalues of the scaled problem map into the physical gun window (Re lam in [4.1e4, 8.5e4], Im > 0)
+    phys = 250.0 ** 2 + (330.0 ** 2 - 220.0 ** 2) * lam
+    assert np.all((phys.real > 4.0e4) & (phys.real < 8.6e4) & (phys.imag > 0))
+    # Krylov basis orthonormal (test/iar.jl:41-47 criterion) -- checked on the device-resident V through host download of V^H V
+    Vh = na.to_host(V[:20, :21 * n])[:21 * n]
+    assert np.linalg.norm(Vh.conj().T @ Vh - np.eye(20), 2) < 1e-10
+    # error history is monotone in the number of converged pairs
+    conv = [int(np.sum(h < 1e-10)) for h in hist]
+    assert conv[-1] == 46 and all(b >= a - 2 for a, b in zip(conv, conv[1:]))
+
+
+def test_c5_wep_fullsize_kernels_vs_host(na):
+    """config C5 size (nx=1003, nz=999, n=1 003 995): K1 against host SciPy SpMV, linearity, DGKS orthogonality"""
+    from nep_amd import wep
+    import torch
+    wd = wep.WaveguideData(1003, 999, "JARLEBRING")
+    Av = wd.big_matrices()
+    fv = [na.funcs.one(), na.funcs.ident(), na.funcs.Monomial(2)]
+    nep = na.SPMF_NEP(Av, fv)
+    n = wd.n
+    assert n == 1003995 and sum(A.nnz for A in Av) == 8019972
+    rng = np.random.default_rng(0)
+    lam = -3 - 3.5j
+    v = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    z = nep.compute_Mlincomb(lam, v)                                # SELL-64 folded SpMV
+    ref = Av[0] @ v + lam * (Av[1] @ v) + lam ** 2 * (Av[2] @ v)
+    assert np.linalg.norm(z - ref) <= 1e-13 * np.linalg.norm(ref)
+    k = 6
+    V = rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k))
+    a = rng.standard_normal(k); b = rng.standard_normal(k)
+    Vd = na.to_dev(V)
+    za = na.to_host(nep.compute_Mlincomb(lam, Vd, a).reshape(1, -1))[:, 0]
+    zb = na.to_host(nep.compute_Mlincomb(lam, Vd, b).reshape(1, -1))[:, 0]
+    zab = na.to_host(nep.compute_Mlincomb(lam, Vd, a + b).reshape(1, -1))[:, 0]
+    assert np.linalg.norm(zab - za - zb) <= 1e-13 * np.linalg.norm(zab)          # linearity in a
+    refa = sum(a[j] * sum(fv[i].derivs(lam, k)[j] * (Av[i] @ V[:, j]) for i in range(3)) for j in range(k))
+    assert np.linalg.norm(za - refa) <= 1e-12 * np.linalg.norm(refa)
+    # DGKS at tiar shape: orthogonalise 8 vectors one after another, check Z^H Z = I
+    Z = torch.zeros((8, n), dtype=torch.complex128, device="cuda")
+    for j in range(8):
+        Z[j] = torch.from_numpy(rng.standard_normal(n) + 1j * rng.standard_normal(n)).to("cuda")
+        if j == 0:
+            na.dense.scal(Z[0], 1.0 / na.dense.nrm2(Z[0]))
+        else:
+            na.orthogonalize_and_normalize(Z, Z[j], j)
+    G = na.to_host(na.gemm_ts(Z, np.eye(8), rowmajor=False))                  # identity GEMM = copy through the MFMA path
+    assert np.linalg.norm(G.conj().T @ G - np.eye(8), 2) < 1e-12

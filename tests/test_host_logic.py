@@ -173,3 +173,27 @@ def test_hostlu_factor_strategy():
     B = A.copy().tolil(); B[0, 5] = 1.0; B = sp.csc_matrix(B)            # break structural symmetry
     F2 = hl.factor(B.data, B.indices, B.indptr, B.shape)
     assert not F2["strategy"]["symmetric_mode"] and F2["strategy"]["permc_spec"] == "COLAMD"
+
+
+def test_c_abi_argument_errors_without_gpu():
+    """every entry point validates its arguments before touching the device: status NEP_ERR_ARG (-2) + message"""
+    import ctypes as C
+    L = na._lib.lib
+    assert L.nep_mlincomb(None, 1, None, None, 1, None, None) == -2
+    assert b"invalid argument" in L.nep_last_error()
+    assert L.nep_orth(None, 1, 1, 1, None, None, None, None, 0, None, None) == -2
+    assert L.nep_gemm_ts(None, 1, 1, 1, None, 1, 1, None, 1, 0, None) == -2
+    assert L.nep_lu_solve(None, 1, None, 1, None, 1, 1.0, None) == -2
+    h = C.c_void_p()
+    assert L.nep_spmf_create(0, 1, None, None, None, None, C.byref(h)) == -2 and not h.value
+    assert L.nep_lu_create(0, None, None, None, None, None, None, None, None, C.byref(h)) == -2
+    assert L.nep_resid_batch(None, 0, None, None, 0, None, None, None) == -2
+    # CSC -> CSR helper is pure host code
+    A = sp.random(7, 7, 0.4, random_state=0, format="csc")
+    rp = np.zeros(8, dtype=np.int32); ci = np.zeros(A.nnz, dtype=np.int32); vv = np.zeros(A.nnz)
+    cp = A.indptr.astype(np.int64) + 1; rv = A.indices.astype(np.int64) + 1        # Julia's 1-based Int64 CSC
+    st = L.nep_csc_to_csr(7, cp.ctypes.data_as(C.c_void_p), rv.ctypes.data_as(C.c_void_p), A.data.ctypes.data_as(C.c_void_p), 0, 1,
+                          rp.ctypes.data_as(C.c_void_p), ci.ctypes.data_as(C.c_void_p), vv.ctypes.data_as(C.c_void_p))
+    assert st == 0
+    R = sp.csr_matrix((vv, ci, rp), shape=(7, 7))
+    assert (R != A).nnz == 0
