@@ -40,7 +40,9 @@ __global__ __launch_bounds__(512) void k_vc(const cplx* __restrict__ V, int64_t 
                                             const cplx* __restrict__ C, int64_t ldc, int i0, int mt_total,
                                             cplx* __restrict__ WT) {
     constexpr int NG = 512 / ROWS;           // column groups
+    constexpr int KC = 128;                  // coefficient rows staged in LDS per chunk
     __shared__ cplx sm[NG][MT][ROWS];
+    __shared__ cplx cs[MT][KC];
     const int rr0 = threadIdx.x % ROWS;
     const int g = threadIdx.x / ROWS;
     const int64_t row = blockIdx.x * (int64_t)ROWS + rr0;
@@ -49,11 +51,20 @@ __global__ __launch_bounds__(512) void k_vc(const cplx* __restrict__ V, int64_t 
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i] = cmake(0.0, 0.0);
     const cplx* vp = V + rowc;
+    for (int j0 = 0; j0 < k; j0 += KC) {
+        const int kc = min(KC, k - j0);
+        if (j0 > 0) __syncthreads();
+        for (int t = threadIdx.x; t < kc * MT; t += 512) {
+            const int i = t / kc, j = t % kc;
+            cs[i][j] = C[j0 + j + (int64_t)(i0 + i) * ldc];
+        }
+        __syncthreads();
 #pragma unroll 4
-    for (int j = g; j < k; j += NG) {
-        const cplx v = vp[(int64_t)j * ldv];
+        for (int j = g; j < kc; j += NG) {
+            const cplx v = vp[(int64_t)(j0 + j) * ldv];
 #pragma unroll
-        for (int i = 0; i < MT; ++i) cfma(acc[i], v, C[j + (int64_t)(i0 + i) * ldc]);
+            for (int i = 0; i < MT; ++i) cfma(acc[i], v, cs[i][j]);
+        }
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) sm[g][i][rr0] = acc[i];
