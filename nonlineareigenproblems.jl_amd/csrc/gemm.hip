@@ -23,7 +23,10 @@ __global__ __launch_bounds__(512) void k_gemm_ts(const cplx* __restrict__ Z, int
                                                  const double* __restrict__ Bfrag, int nks, int p, int j0,
                                                  cplx* __restrict__ Y, int64_t ldy) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    double* bs = (double*)smem_raw;  // [GEMM_KCH][NT][2][64]
+    constexpr int PER_KS = NT * 2 * 64;               // doubles per k-step
+    constexpr int CH = GEMM_KCH * PER_KS;             // doubles per LDS stage
+    constexpr int BPT = (CH / 2 + 511) / 512;         // double2 per thread per stage (NT*2*64*4/2/512 = NT/2 rounded up)
+    double* bs = (double*)smem_raw;                   // [2][GEMM_KCH][NT][2][64]  (double buffered)
     const int lane = threadIdx.x & 63;
     const int wv = threadIdx.x >> 6;
     const int64_t row0 = (blockIdx.x * 8LL + wv) * 16;
@@ -34,29 +37,52 @@ __global__ __launch_bounds__(512) void k_gemm_ts(const cplx* __restrict__ Z, int
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
 
-    constexpr int PER_KS = NT * 2 * 64;  // doubles per k-step
-    for (int ks0 = 0; ks0 < nks; ks0 += GEMM_KCH) {
-        const int nk = min(GEMM_KCH, nks - ks0);
-        // issue the A loads of this chunk first (latency hidden behind the LDS fill)
-        cplx a[GEMM_KCH];
+    const int nch = (nks + GEMM_KCH - 1) / GEMM_KCH;
+    cplx a[GEMM_KCH], an[GEMM_KCH];
+    double2 bn[BPT];
+
+    auto load_a = [&](int c, cplx* dst) {
 #pragma unroll
         for (int s = 0; s < GEMM_KCH; ++s) {
-            int c = 4 * (ks0 + s) + q;
-            if (c >= k) c = k - 1;
-            a[s] = (s < nk) ? Z[(int64_t)c * ldz + arow] : cmake(0.0, 0.0);
+            const int ks = c * GEMM_KCH + s;
+            int col = 4 * ks + q;
+            if (col >= k) col = k - 1;
+            dst[s] = (ks < nks) ? Z[(int64_t)col * ldz + arow] : cmake(0.0, 0.0);
         }
-        __syncthreads();
-        {
-            const double2* src = (const double2*)(Bfrag + (int64_t)ks0 * PER_KS);
-            double2* dst = (double2*)bs;
-            const int n2 = nk * PER_KS / 2;
-            for (int t = threadIdx.x; t < n2; t += 512) dst[t] = src[t];
+    };
+    auto load_b = [&](int c) {
+        const int nk = min(GEMM_KCH, nks - c * GEMM_KCH);
+        const double2* src = (const double2*)(Bfrag + (int64_t)c * CH);
+        const int n2 = nk * PER_KS / 2;
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int t = threadIdx.x + 512 * i;
+            bn[i] = (t < n2) ? src[t] : make_double2(0.0, 0.0);
         }
-        __syncthreads();
+    };
+    auto store_b = [&](int buf) {
+        double2* dst = (double2*)(bs + (size_t)buf * CH);
+#pragma unroll
+        for (int i = 0; i < BPT; ++i) {
+            const int t = threadIdx.x + 512 * i;
+            if (t < CH / 2) dst[t] = bn[i];
+        }
+    };
+
+    // prologue: stage chunk 0
+    load_a(0, a);
+    load_b(0);
+    store_b(0);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+        const bool more = c + 1 < nch;
+        if (more) { load_a(c + 1, an); load_b(c + 1); }        // global loads in flight during the MFMAs below
+        const int nk = min(GEMM_KCH, nks - c * GEMM_KCH);
+        const double* bk0 = bs + (size_t)(c & 1) * CH + lane;
 #pragma unroll
         for (int s = 0; s < GEMM_KCH; ++s) {
             if (s < nk) {
-                const double* bk = bs + s * PER_KS + lane;
+                const double* bk = bk0 + s * PER_KS;
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
                     acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s].x, bk[(t * 2 + 0) * 64], acc[t], 0, 0, 0);
@@ -65,6 +91,12 @@ __global__ __launch_bounds__(512) void k_gemm_ts(const cplx* __restrict__ Z, int
                     acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s].y, bk[(t * 2 + 1) * 64], acc[t], 0, 0, 0);
             }
         }
+        if (more) {
+            store_b((c + 1) & 1);                               // the other stage: nobody reads it during chunk c
+#pragma unroll
+            for (int s = 0; s < GEMM_KCH; ++s) a[s] = an[s];
+        }
+        __syncthreads();
     }
     // ---- epilogue
     const int n = lane & 15, g = lane >> 4;
@@ -116,7 +148,7 @@ template <int NT>
 static int gemm_launch(bool rowmajor, const cplx* Z, int64_t ldz, int64_t rows, int k, const double* dB, int nks,
                        int p, int j0, cplx* Y, int64_t ldy, hipStream_t st) {
     const dim3 grid((unsigned)((rows + 127) / 128)), block(512);
-    const size_t shm = (size_t)GEMM_KCH * NT * 2 * 64 * sizeof(double);
+    const size_t shm = (size_t)2 * GEMM_KCH * NT * 2 * 64 * sizeof(double);      // double-buffered B stage
     if (rowmajor)
         hipLaunchKernelGGL((k_gemm_ts<NT, true>), grid, block, shm, st, Z, ldz, rows, k, dB, nks, p, j0, Y, ldy);
     else
