@@ -13,6 +13,7 @@
 // accumulators for ALL p output columns of a 16-row strip live in registers.
 #include "common.h"
 #include <vector>
+#include <algorithm>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -203,7 +204,11 @@ extern "C" int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows,
     // column panels of at most 104 complex output columns (13 N-tiles of 8)
     size_t total = 0;
     for (int j0 = 0; j0 < p; j0 += 104) total += (size_t)nks * gemm_nt(std::min(104, p - j0)) * 128;
-    std::vector<double> frag(total, 0.0);
+    // persistent staging (a fresh 300 KB vector per call means mmap/munmap + TLB shootdowns across all the
+    // process' threads: measured 0.7 ms per call while the eig worker threads are running)
+    static thread_local std::vector<double> frag;
+    if (frag.size() < total) frag.resize(total + total / 2);
+    std::fill(frag.begin(), frag.begin() + total, 0.0);
     int rc = g_gemm_scratch.ensure(total * sizeof(double));
     if (rc) return rc;
     size_t off = 0;

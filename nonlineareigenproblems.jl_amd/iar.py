@@ -21,7 +21,7 @@ import numpy as np
 import scipy.linalg as sla
 import torch
 
-from . import dense
+from . import dense, _hosteig
 from ._lib import lib, check, c_vp
 from .errmeasure import DefaultErrmeasure, estimate_errors
 from .exceptions import NoConvergenceException
@@ -99,7 +99,7 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
 
     def timed_eig(Hk):
         t = time.perf_counter()
-        r = np.linalg.eig(Hk)      # numpy's LAPACK call releases the GIL (scipy's f2py wrapper does not)
+        r = _hosteig.eig(Hk)       # zgeev through ctypes: runs without the GIL (numpy/scipy hold it)
         return r, time.perf_counter() - t
 
     def finish_check(kc, fut):
