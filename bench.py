@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--cpu-maxit", type=int, default=60)
     ap.add_argument("--permc", default=None)
     ap.add_argument("--no-beyn", action="store_true", help="skip the sharded contour_beyn extra")
+    ap.add_argument("--no-wep-roofline", action="store_true", help="skip the waveguide-scale K1 roofline extra")
     return ap.parse_args()
 
 
@@ -105,6 +106,34 @@ def beyn_sharded(na, args, world, rank):
             "eigenpairs": int(len(lam)), "seconds": dt, "eigenpairs_per_s": len(lam) / dt, "rank_p": int(info.get("p", -1)),
             "nodes_per_rank": int(info.get("nodes", 64)), "scaling": "strong",
             "exchange": "one all_gather of 2*n*k complex128 per rank (%.1f MB)" % (2 * nep.n * 32 * 16 / 1e6) if world > 1 else "none"}
+
+
+def wep_scale_roofline(na):
+    """K1 on the waveguide (config C5) matrices, nx=1003 nz=999 (n = 1 003 995, 8.02 M non-zeros): the HBM-bound size
+    at which the >= 60 % target of BASELINE.json is meaningful (the gun call moves 2-18 MB and is launch-bound)."""
+    from nep_amd import wep
+    wd = wep.WaveguideData(1003, 999, "JARLEBRING")
+    dev = na.SPMFDevice(wd.big_matrices())
+    n = wd.n
+    out = {"workload": "WEP JARLEBRING nx=1003 nz=999: 3 real sparse terms, n=%d, nnz=%d" % (n, dev.nnz), "peak": HBM_PEAK_GBS,
+           "unit": "GB/s"}
+    for k in (1, 60):
+        V = torch.randn((k, n), dtype=torch.float64, device="cuda").to(torch.complex128)
+        Cdev = na.to_dev(np.random.default_rng(0).standard_normal((k, dev.mt)) + 0j)
+        z = torch.empty(n, dtype=torch.complex128, device="cuda")
+        for _ in range(3):
+            dev.mlincomb_dev(Cdev, k, k, V, n, z)
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            dev.mlincomb_dev(Cdev, k, k, V, n, z)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 10
+        b = dev.algorithmic_bytes(k)
+        out["k=%d" % k] = {"algorithmic_bytes": b, "ms_per_launch": ms, "achieved": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS}
+        del V
+    return out
 
 
 def cpu_baseline(args):
@@ -245,6 +274,11 @@ def main():
             "kernels": {"note": "wall ms per phase of one instrumented iar run (torch.cuda.synchronize around each phase)",
                         **{k_: round(v * 1e3, 3) for k_, v in tm.items()}},
         }
+        if world == 1 and not args.no_wep_roofline:
+            try:
+                out["roofline_wep_scale"] = wep_scale_roofline(na)
+            except Exception as e:
+                out["roofline_wep_scale"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
     # extra (outside the headline timed region): the path that DOES shard -- Beyn's quadrature nodes over the ranks

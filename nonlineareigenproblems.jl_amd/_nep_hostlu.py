@@ -28,9 +28,17 @@ def ping(i):
     return i
 
 
-def pattern_symmetric(Ac):
+def pattern_symmetric(Ac, threshold=0.5):
+    """UMFPACK's strategy test: the symmetric strategy is chosen when the non-zero pattern is (nearly) symmetric and
+    the diagonal is zero-free.  Symmetry = fraction of off-diagonal entries whose transposed position is also stored
+    (1.0 for gun, 0.997 for the WEP whose C1 / C2^T coupling blocks differ by one stencil point)."""
     P = sp.csc_matrix((np.ones(Ac.nnz, dtype=np.int8), Ac.indices, Ac.indptr), shape=Ac.shape)
-    return (P != P.T).nnz == 0 and bool(np.all(Ac.diagonal() != 0))
+    if not bool(np.all(Ac.diagonal() != 0)):
+        return False
+    both = P.multiply(P.T)
+    nd = P.nnz - Ac.shape[0]
+    sym = 1.0 if nd <= 0 else (both.nnz - Ac.shape[0]) / nd
+    return sym >= threshold
 
 
 def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None, symmetric_mode=None):

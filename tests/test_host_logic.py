@@ -170,9 +170,11 @@ def test_hostlu_factor_strategy():
     L = sp.csr_matrix((F["Lx"], F["Li"], F["Lp"]), shape=(n, n)); U = sp.csr_matrix((F["Ux"], F["Ui"], F["Up"]), shape=(n, n))
     Pr = sp.csc_matrix((np.ones(n), (F["perm_r"], np.arange(n)))); Pc = sp.csc_matrix((np.ones(n), (np.arange(n), F["perm_c"])))
     assert abs(Pr @ A @ Pc - L @ U).max() <= 1e-10 * abs(A).max()
-    B = A.copy().tolil(); B[0, 5] = 1.0; B = sp.csc_matrix(B)            # break structural symmetry
+    B = sp.csc_matrix(sp.triu(A, 0) + sp.identity(n))                     # upper triangular pattern: symmetry 0
     F2 = hl.factor(B.data, B.indices, B.indptr, B.shape)
     assert not F2["strategy"]["symmetric_mode"] and F2["strategy"]["permc_spec"] == "COLAMD"
+    Bz = A.copy().tolil(); Bz[3, 3] = 0.0; Bz = sp.csc_matrix(Bz); Bz.eliminate_zeros()   # zero on the diagonal
+    assert not hl.pattern_symmetric(Bz)
 
 
 def test_c_abi_argument_errors_without_gpu():
