@@ -139,6 +139,17 @@ int32_t nep_gemm_ts_dev(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_
                         const nep_cdouble* dB, int64_t ldb, int32_t b_rowmajor, int32_t p,
                         nep_cdouble* dY, int64_t ldy, int32_t y_rowmajor, nep_stream stream);
 
+/* Refinement criterion of the fixed-shift solve (replaces UMFPACK's internal iterative refinement behind
+ * `Afact \ x`, src/LinSolvers.jl:114-122 with control[8] = umfpack_refinements): writes r = b - M(lam) x and, if
+ * h_omega != NULL, returns the componentwise backward error
+ *     max_i |r_i| / (sum_t h_cabs[t] * (|A_t| |x|)_i + |b_i|)          (Arioli/Demmel/Duff), h_cabs[t] = |f_t(lam)|
+ * after a stream synchronisation; with h_omega == NULL nothing is read back (blind refinement step).  M(lam) x is
+ * either given (dMx, e.g. from a NEP-specific compute_Mlincomb with non-SPMF terms; h_c == NULL) or formed in the same
+ * pass over the matrices from the host coefficients h_c[t] = f_t(lam) (dMx == NULL). */
+int32_t nep_cw_backward_error(nep_spmf* s, const double* h_cabs, const nep_cdouble* h_c, const nep_cdouble* dx,
+                              const nep_cdouble* db, const nep_cdouble* dMx, nep_cdouble* dr, double* h_omega,
+                              nep_stream stream);
+
 /* ---- K5 fixed-shift solve with a host-computed sparse LU -------------------------------
  * replaces: FactorizeLinSolver / lin_solve src/LinSolvers.jl:109-137 (Afact \ x) and
  *           BackslashLinSolver :147-159; the factorisation (UMFPACK in the reference) stays on
@@ -159,12 +170,18 @@ int32_t nep_lu_set_expected_solves(int32_t nsolves);
  * info[5]=algorithmic bytes of one solve with one right-hand side */
 int32_t nep_lu_info(const nep_lu* lu, int64_t info[6]);
 /* schedule introspection: out[0]=dense tail size T, out[1]=kernel launches of the last solve,
- * out[2]=levels(L), out[3]=levels(U) of the plain level schedule, out[4]=wide, out[5]=narrow segments */
-int32_t nep_lu_schedule(const nep_lu* lu, int64_t out[6]);
+ * out[2]=levels(L), out[3]=levels(U) of the plain level schedule, out[4]=wide, out[5]=narrow segments,
+ * out[6]=rows of the blocked mid region (explicitly inverted diagonal blocks), out[7]=its block size */
+int32_t nep_lu_schedule(const nep_lu* lu, int64_t out[8]);
 /* X = A^{-1} B for nrhs right-hand sides; dB, dX: n x nrhs column-major; dX may alias dB.
  * scale is applied to the result (iar/tiar use -1: y = -lin_solve(...), src/method_iar.jl:103). */
 int32_t nep_lu_solve(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_t ldb, nep_cdouble* dX,
                      int64_t ldx, double scale, nep_stream stream);
+
+/* X = scale * (Add + A^{-1} B): the update step of the iterative refinement (x + A^{-1} r, UMFPACK's solve behind
+ * src/LinSolvers.jl:114-122) fused into the output permutation; dAdd may alias dX, NULL means zero. */
+int32_t nep_lu_solve_add(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_t ldb, const nep_cdouble* dAdd,
+                         int64_t ldadd, nep_cdouble* dX, int64_t ldx, double scale, nep_stream stream);
 
 /* ---- small BLAS-1 style helpers used by the drivers ------------------------------------ */
 /* iar basis step (src/method_iar.jl:100-101,105): dst[(j+1)*n + r] = src[j*n + r]/(j+1), j=0..k-1 */

@@ -68,6 +68,12 @@ __device__ __forceinline__ cplx group_reduce_sum(cplx v) {  // sum over aligned 
     }
     return v;
 }
+template <int W>
+__device__ __forceinline__ double group_reduce_sum(double v) {
+#pragma unroll
+    for (int off = W / 2; off > 0; off >>= 1) v += shfl_xor_d(v, off);
+    return v;
+}
 __device__ __forceinline__ double wave_reduce_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += shfl_xor_d(v, off);

@@ -7,6 +7,7 @@
 // The reference streams V once PER TERM (src/NEPTypes.jl:1006) and runs one CSC SpMV per term
 // (:1007); the DerSPMF formulation (:1154-1157) is the one realised here.
 #include "common.h"
+#include <cstring>
 #include <vector>
 #include <algorithm>
 
@@ -334,6 +335,83 @@ static int launch_spmv_fold(const nep_spmf* s, const cplx* v, const cplx* dC, in
     return NEP_OK;
 }
 
+// ------------------------------------------------------------------------------------------
+// Componentwise backward error of an approximate solution of M x = b (the refinement criterion of UMFPACK's solve,
+// Arioli/Demmel/Duff):  r = b - Mx,  omega = max_i |r_i| / ( sum_t |c_t| sum_j |A_t[i,j]| |x_j| + |b_i| ).
+// One pass over the stacked CSR; the maximum lands in *omega_bits (non-negative doubles order like their bit patterns).
+__device__ __forceinline__ double absval(double v) { return fabs(v); }
+__device__ __forceinline__ double absval(cplx v) { return hypot(v.x, v.y); }
+
+// FUSED: Mx is not given but accumulated in the same pass with the complex coefficients ccf (pure SPMF operators).
+template <int G, typename VT, bool FUSED>
+__global__ __launch_bounds__(256) void k_cw_resid(const int32_t* __restrict__ rowptr, const uint32_t* __restrict__ idx,
+                                                  const VT* __restrict__ vals, const double* __restrict__ cabs,
+                                                  const cplx* __restrict__ ccf,
+                                                  const cplx* __restrict__ x, const cplx* __restrict__ b,
+                                                  const cplx* __restrict__ Mx, int64_t n, cplx* __restrict__ r,
+                                                  unsigned long long* omega_bits) {
+    constexpr int RPB = 256 / G;
+    __shared__ double wmax[4];
+    const int sub = threadIdx.x % G;
+    const int64_t row = blockIdx.x * (int64_t)RPB + threadIdx.x / G;
+    double d = 0.0;
+    cplx acc = cmake(0.0, 0.0);
+    if (row < n) {
+        const int e1 = rowptr[row + 1];
+        for (int e = rowptr[row] + sub; e < e1; e += G) {
+            const uint32_t id = idx[e];
+            const int t = id >> NEP_TERM_SHIFT;
+            const cplx xv = x[id & NEP_COL_MASK];
+            const VT v = vals[e];
+            d += absval(v) * cabs[t] * absval(xv);
+            if (FUSED) cfma(acc, cscale(v, ccf[t]), xv);
+        }
+    }
+    d = group_reduce_sum<G>(d);
+    if (FUSED) acc = group_reduce_sum<G>(acc);
+    double ratio = 0.0;
+    if (row < n && sub == 0) {
+        const cplx rr = csub(b[row], FUSED ? acc : Mx[row]);
+        r[row] = rr;
+        const double num = absval(rr), den = d + absval(b[row]);
+        ratio = den > 0.0 ? num / den : (num > 0.0 ? 1.0e300 : 0.0);
+        if (!(ratio == ratio)) ratio = 1.0e300;     // NaN -> "not converged"
+    }
+    // workgroup maximum, one atomic per workgroup
+    for (int off = 32; off > 0; off >>= 1) ratio = fmax(ratio, __shfl_xor(ratio, off, 64));
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = ratio;
+    __syncthreads();
+    if (threadIdx.x == 0 && omega_bits) {
+        const double m = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
+        if (m > 0.0) atomicMax(omega_bits, (unsigned long long)__double_as_longlong(m));
+    }
+}
+
+template <typename VT>
+static int launch_cw_resid(const nep_spmf* s, const double* cabs, const cplx* ccf, const cplx* x, const cplx* b,
+                           const cplx* Mx, cplx* r, unsigned long long* omega_bits, hipStream_t st) {
+    const int64_t n = s->n;
+    const VT* vals = (const VT*)s->d_vals;
+#define CW_CASE(G)                                                                                      \
+    case G: {                                                                                           \
+        const int rpb = 256 / G;                                                                        \
+        if (Mx)                                                                                         \
+            hipLaunchKernelGGL((k_cw_resid<G, VT, false>), dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, st, \
+                               s->d_rowptr, s->d_idx, vals, cabs, ccf, x, b, Mx, n, r, omega_bits);     \
+        else                                                                                            \
+            hipLaunchKernelGGL((k_cw_resid<G, VT, true>), dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, st, \
+                               s->d_rowptr, s->d_idx, vals, cabs, ccf, x, b, Mx, n, r, omega_bits);     \
+        break;                                                                                          \
+    }
+    switch (s->lanes) {
+        CW_CASE(2) CW_CASE(4) CW_CASE(8) CW_CASE(16) CW_CASE(32) CW_CASE(64)
+        default: nep_set_error("bad lanes %d", s->lanes); return NEP_ERR_ARG;
+    }
+#undef CW_CASE
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
 template <int ROWS>
 static int launch_vc_rows(const nep_spmf* s, int k, const cplx* dC, int64_t ldc, const cplx* V, int64_t ldv, hipStream_t st) {
     const int64_t n = s->n;
@@ -546,6 +624,41 @@ int32_t nep_mlincomb_dev(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t 
     if (rc) return rc;
     if (s->valbytes == 8) return launch_spmv<double>(s, s->d_WT, (cplx*)dz, st);
     return launch_spmv<cplx>(s, s->d_WT, (cplx*)dz, st);
+}
+
+int32_t nep_cw_backward_error(nep_spmf* s, const double* h_cabs, const nep_cdouble* h_c, const nep_cdouble* dx,
+                              const nep_cdouble* db, const nep_cdouble* dMx, nep_cdouble* dr, double* h_omega,
+                              nep_stream stream) {
+    ARGCHK(s && h_cabs && dx && db && dr);
+    ARGCHK((dMx != nullptr) != (h_c != nullptr));     // exactly one of: M x given, or coefficients to form it
+    ARGCHK(s->mt <= 64);
+    hipStream_t st = as_stream(stream);
+    const size_t mt = (size_t)s->mt;
+    int rc = s->part.ensure(64 + mt * 24);
+    if (rc) return rc;
+    unsigned long long* bits = (unsigned long long*)s->part.dptr;
+    double* cabs = (double*)((char*)s->part.dptr + 64);
+    cplx* ccf = (cplx*)((char*)s->part.dptr + 64 + mt * 8);
+    double stage[64 * 3];
+    memcpy(stage, h_cabs, mt * 8);
+    if (h_c) memcpy(stage + mt, h_c, mt * 16);
+    rc = s->ring.upload(cabs, stage, mt * (h_c ? 24 : 8), st);
+    if (rc) return rc;
+    if (h_omega) HIPCHK(hipMemsetAsync(bits, 0, 8, st));
+    if (s->valbytes == 8)
+        rc = launch_cw_resid<double>(s, cabs, ccf, (const cplx*)dx, (const cplx*)db, (const cplx*)dMx, (cplx*)dr, h_omega ? bits : nullptr, st);
+    else
+        rc = launch_cw_resid<cplx>(s, cabs, ccf, (const cplx*)dx, (const cplx*)db, (const cplx*)dMx, (cplx*)dr, h_omega ? bits : nullptr, st);
+    if (rc) return rc;
+    if (h_omega) {
+        unsigned long long hb = 0;
+        HIPCHK(hipMemcpyAsync(&hb, bits, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        double v;
+        memcpy(&v, &hb, 8);
+        *h_omega = v;
+    }
+    return NEP_OK;
 }
 
 int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,

@@ -12,6 +12,12 @@
 //   head  L11 / U11 : level-scheduled.  Wide levels (many independent rows) run as ONE multi-
 //                     workgroup launch each (G lanes per row); runs of consecutive narrow levels
 //                     run inside ONE persistent workgroup with a workgroup barrier per level.
+//   mid   (blocked) : rows [h0, i0) between head and tail, where levels hold a handful of long rows (the fronts of
+//                     the top separators: n = 1e6 waveguide -> 8500 levels, 200 ms per solve level-scheduled).
+//                     Cut into blocks of b rows; per block ONE multi-workgroup SpMV with everything outside the
+//                     block (r_B = c_B - L[B,<B] x) and ONE dense GEMV with the explicitly inverted b x b diagonal
+//                     block (x_B = inv(L_BB) r_B): b dependent levels become 2 launches.  The inverses are built once
+//                     per factorisation on the device (one workgroup per column, x in LDS).
 //   tail            : t = c2 - L21*y1 (SpMV) ; x2 = S22^{-1} t as ONE dense GEMV.  S22^{-1} is built
 //                     once per factorisation ON THE DEVICE by T independent tail solves (one
 //                     workgroup per unit vector, x in LDS), turning ~2T dependent steps per solve
@@ -25,8 +31,9 @@
 
 #define TRSV_WIDE_MIN 48      // a level with at least this many rows gets its own multi-WG launch
 #define TRSV_TAIL_SMALL 4     // levels with <= this many rows are "chain" levels (dense tail)
-#define TRSV_TAIL_MAX 4096    // cap on the dense tail size (16*T^2 bytes = 268 MB at 4096)
+#define TRSV_TAIL_MAX 2048    // cap on the dense tail size (16*T^2 bytes = 67 MB); beyond it the blocked mid region is cheaper to build
 #define TRSV_TAIL_MIN 64
+#define TRSV_MID_MAX 131072   // cap on the rows of the blocked mid region (2 * 16*b bytes of inverse per row)
 
 struct Seg { int wide; int lev_lo, lev_hi; int slot_lo, slot_hi; int G; };
 
@@ -43,15 +50,28 @@ struct TriFactor {
     std::vector<Seg> segs;
 };
 
+// blocked mid region of one triangular factor: rows [h0, h0 + nblk*b)
+struct MidFactor {
+    int32_t* d_rp = nullptr;       // CSR over mid rows: entries OUTSIDE the row's diagonal block
+    int32_t* d_ci = nullptr;       //   (lower: col < block start; upper: col >= block end)
+    cplx* d_vx = nullptr;
+    cplx* d_inv = nullptr;         // nblk dense b x b row-major inverses of the diagonal blocks
+    int64_t nnz = 0;
+    std::vector<int> wpr;          // waves per row of the block's SpMV launch (1 or 4)
+};
+
 struct nep_lu {
     int64_t n = 0, i0 = 0, T = 0;
+    int64_t h0 = 0;                // heads cover rows [0,h0), mid [h0,i0), tail [i0,n)
+    int32_t nblk = 0, bsz = 0;
+    MidFactor Lm, Um;
     TriFactor L11, U11;
     // L21 as CSR over tail rows
     int32_t* d_L21p = nullptr; int32_t* d_L21i = nullptr; cplx* d_L21x = nullptr; int64_t nnzL21 = 0;
     cplx* d_Sinv = nullptr;        // T x T row-major
     int32_t* d_perm_r = nullptr;
     int32_t* d_perm_c = nullptr;
-    NepScratch work;               // (n + T) x nrhs
+    NepScratch work;               // (n + (n - h0)) x nrhs
     int64_t nnzL_in = 0, nnzU_in = 0;
     int32_t levL_full = 0, levU_full = 0;
     int32_t launches = 0;
@@ -84,11 +104,13 @@ __global__ void k_perm_in(int64_t n, const int32_t* __restrict__ perm_r, const c
         x[perm_r ? perm_r[i] : i] = b[i];
 }
 __global__ void k_perm_out(int64_t n, const int32_t* __restrict__ perm_c, const cplx* __restrict__ work, int64_t ldw,
-                           cplx* __restrict__ X, int64_t ldx, double scale) {
+                           cplx* __restrict__ X, int64_t ldx, double scale, const cplx* __restrict__ add, int64_t lda) {
     const cplx* x = work + (int64_t)blockIdx.y * ldw;
     cplx* xo = X + (int64_t)blockIdx.y * ldx;
+    const cplx* ad = add ? add + (int64_t)blockIdx.y * lda : nullptr;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const cplx v = x[perm_c ? perm_c[i] : i];
+        cplx v = x[perm_c ? perm_c[i] : i];
+        if (ad) { v.x += ad[i].x; v.y += ad[i].y; }
         xo[i] = cmake(scale * v.x, scale * v.y);
     }
 }
@@ -144,23 +166,6 @@ __global__ __launch_bounds__(512) void k_levels_narrow(int lev_lo, int lev_hi, c
     }
 }
 
-// ---- tail: tmp = x[i0:] - L21 * x[:i0]  (wave per tail row) --------------------------------------
-__global__ __launch_bounds__(256) void k_tail_spmv(int64_t T, int64_t i0, const int32_t* __restrict__ rp,
-                                                   const int32_t* __restrict__ ci, const cplx* __restrict__ vx,
-                                                   const cplx* __restrict__ work, int64_t ldw, cplx* __restrict__ tmp,
-                                                   int64_t ldt) {
-    const cplx* x = work + (int64_t)blockIdx.y * ldw;
-    cplx* t = tmp + (int64_t)blockIdx.y * ldt;
-    const int lane = threadIdx.x & 63;
-    const int64_t r = blockIdx.x * 4LL + (threadIdx.x >> 6);
-    if (r >= T) return;
-    cplx acc = cmake(0.0, 0.0);
-    const int e1 = rp[r + 1];
-    for (int e = rp[r] + lane; e < e1; e += 64) cfma(acc, vx[e], x[ci[e]]);
-    acc = group_reduce_sum<64>(acc);
-    if (lane == 0) t[r] = csub(x[i0 + r], acc);
-}
-
 // ---- tail: x[i0:] = Sinv * tmp   (dense row-major GEMV, wave per row, HBM/L2-bound) --------------
 __global__ __launch_bounds__(256) void k_tail_gemv(int64_t T, int64_t i0, const cplx* __restrict__ Sinv,
                                                    const cplx* __restrict__ tmp, int64_t ldt, cplx* __restrict__ work,
@@ -176,6 +181,121 @@ __global__ __launch_bounds__(256) void k_tail_gemv(int64_t T, int64_t i0, const 
     for (int64_t c = lane; c < T; c += 64) cfma(acc, row[c], t[c]);
     acc = group_reduce_sum<64>(acc);
     if (lane == 0) x[i0 + r] = acc;
+}
+
+// ---- mid: tmp[B] = x[B] - (off-block part of rows B) * x   (WPR waves per row; WPR=16 -> 1024 threads) ------------
+template <int WPR>
+__global__ __launch_bounds__(WPR == 16 ? 1024 : 256) void k_mid_spmv(int64_t r0, int nrows, int64_t h0,
+                                                                      const int32_t* __restrict__ rp,
+                                                                      const int32_t* __restrict__ ci,
+                                                                      const cplx* __restrict__ vx,
+                                                                      const cplx* __restrict__ work, int64_t ldw,
+                                                                      cplx* __restrict__ tmp, int64_t ldt) {
+    constexpr int NW = WPR == 16 ? 16 : 4;               // waves per workgroup
+    constexpr int RPB = NW / WPR;
+    __shared__ cplx part[NW];
+    const cplx* x = work + (int64_t)blockIdx.y * ldw;
+    cplx* t = tmp + (int64_t)blockIdx.y * ldt;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lr = blockIdx.x * RPB + wv / WPR;          // uniform per wave
+    const bool live = lr < nrows;
+    const int64_t row = r0 + lr;
+    cplx acc = cmake(0.0, 0.0);
+    if (live) {
+        const int e1 = rp[row - h0 + 1];
+        for (int e = rp[row - h0] + (wv % WPR) * 64 + lane; e < e1; e += 64 * WPR) cfma(acc, vx[e], x[ci[e]]);
+    }
+    acc = group_reduce_sum<64>(acc);
+    if (WPR == 1) {
+        if (live && lane == 0) t[row - h0] = csub(x[row], acc);
+    } else {
+        if (lane == 0) part[wv] = acc;
+        __syncthreads();
+        if (live && threadIdx.x == 0) {
+            cplx a = part[0];
+            for (int w = 1; w < NW; ++w) { a.x += part[w].x; a.y += part[w].y; }
+            t[row - h0] = csub(x[row], a);
+        }
+    }
+}
+
+static int pick_wpr(double avg_row_nnz) { return avg_row_nnz > 6144.0 ? 16 : (avg_row_nnz > 768.0 ? 4 : 1); }
+
+static void launch_mid_spmv(int wpr, int64_t r0, int nrows, int64_t h0, const int32_t* rp, const int32_t* ci,
+                            const cplx* vx, const cplx* work, int64_t ldw, cplx* tmp, int64_t ldt, int nrhs,
+                            hipStream_t st) {
+    if (wpr == 16)
+        hipLaunchKernelGGL((k_mid_spmv<16>), dim3(nrows, nrhs), dim3(1024), 0, st, r0, nrows, h0, rp, ci, vx, work, ldw, tmp, ldt);
+    else if (wpr == 4)
+        hipLaunchKernelGGL((k_mid_spmv<4>), dim3(nrows, nrhs), dim3(256), 0, st, r0, nrows, h0, rp, ci, vx, work, ldw, tmp, ldt);
+    else
+        hipLaunchKernelGGL((k_mid_spmv<1>), dim3((nrows + 3) / 4, nrhs), dim3(256), 0, st, r0, nrows, h0, rp, ci, vx, work, ldw, tmp, ldt);
+}
+
+// ---- mid: x[B] = inv(D_B) * tmp[B]   (triangular dense GEMV, WPR waves per row) -----------------------------------
+template <bool UPPER, int WPR>
+__global__ __launch_bounds__(256) void k_mid_gemv(int64_t r0, int b, int64_t h0, const cplx* __restrict__ inv,
+                                                  const cplx* __restrict__ tmp, int64_t ldt, cplx* __restrict__ work,
+                                                  int64_t ldw) {
+    __shared__ cplx part[4];
+    const cplx* t = tmp + (int64_t)blockIdx.y * ldt + (r0 - h0);
+    cplx* x = work + (int64_t)blockIdx.y * ldw;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    constexpr int RPB = 4 / WPR;
+    const int r = blockIdx.x * RPB + wv / WPR;
+    const bool live = r < b;
+    cplx acc = cmake(0.0, 0.0);
+    if (live) {
+        const cplx* row = inv + (int64_t)r * b;
+        const int c0 = UPPER ? r : 0, c1 = UPPER ? b : r + 1;
+        for (int c = (c0 & ~63) + (wv % WPR) * 64 + lane; c < c1; c += 64 * WPR)
+            if (c >= c0) cfma(acc, row[c], t[c]);
+    }
+    acc = group_reduce_sum<64>(acc);
+    if (WPR == 1) {
+        if (live && lane == 0) x[r0 + r] = acc;
+    } else {
+        if (lane == 0) part[wv] = acc;
+        __syncthreads();
+        if (live && threadIdx.x == 0) {
+            cplx a = part[0];
+            for (int w = 1; w < 4; ++w) { a.x += part[w].x; a.y += part[w].y; }
+            x[r0 + r] = a;
+        }
+    }
+}
+
+// ---- setup: column j of inv(D_B) for every diagonal block B (grid = b x nblk), x in LDS --------------------------
+// In-block level schedule: blkoff[k] indexes `levptr`, which holds nlev_k + 1 slot positions for block k.
+template <bool UPPER>
+__global__ __launch_bounds__(256) void k_mid_inverse(int b, int64_t h0, const int32_t* __restrict__ blkoff,
+                                                     const int32_t* __restrict__ levptr,
+                                                     const int32_t* __restrict__ rowid, const int32_t* __restrict__ rowptr,
+                                                     const int32_t* __restrict__ col, const cplx* __restrict__ val,
+                                                     const cplx* __restrict__ diag, cplx* __restrict__ inv) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* x = (cplx*)smem_raw;
+    const int j = blockIdx.x, k = blockIdx.y;
+    const int64_t s0row = h0 + (int64_t)k * b;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int t = threadIdx.x; t < b; t += 256) x[t] = cmake(t == j ? 1.0 : 0.0, 0.0);
+    __syncthreads();
+    const int l0 = blkoff[k], nlev = blkoff[k + 1] - l0 - 1;
+    for (int lev = UPPER ? 0 : 1; lev < nlev; ++lev) {
+        const int s0 = levptr[l0 + lev], s1 = levptr[l0 + lev + 1];
+        for (int s = s0 + wv; s < s1; s += 4) {
+            const int i = (int)(rowid[s] - s0row);
+            if (UPPER ? (i <= j) : (i > j)) {        // the other rows of the column stay zero (uniform per wave)
+                cplx acc = cmake(0.0, 0.0);
+                for (int e = rowptr[s] + lane; e < rowptr[s + 1]; e += 64) cfma(acc, val[e], x[col[e] - s0row]);
+                acc = group_reduce_sum<64>(acc);
+                if (lane == 0) x[i] = UPPER ? cdiv(csub(x[i], acc), diag[s]) : csub(x[i], acc);
+            }
+        }
+        __syncthreads();
+    }
+    cplx* out = inv + (int64_t)k * b * b;
+    for (int t = threadIdx.x; t < b; t += 256) out[(int64_t)t * b + j] = x[t];
 }
 
 // ---- setup: column j of S22^{-1} = U22^{-1} L22^{-1} e_j, one workgroup per column, x in LDS -------
@@ -329,6 +449,145 @@ static int build_tri(int64_t n, const int32_t* P, const int32_t* I, const nep_cd
     return NEP_OK;
 }
 
+static void free_mid(MidFactor& m) {
+    if (m.d_rp) nep_pool_free(m.d_rp);
+    if (m.d_ci) nep_pool_free(m.d_ci);
+    if (m.d_vx) nep_pool_free(m.d_vx);
+    if (m.d_inv) nep_pool_free(m.d_inv);
+    m = MidFactor();
+}
+
+// blocked mid region rows [h0, h0 + nblk*b) of one factor: off-block CSR + device-built inverses of the diagonal blocks
+static int build_mid(const int32_t* P, const int32_t* I, const nep_cdouble* X, bool upper, int64_t h0, int nblk, int b,
+                     MidFactor& out) {
+    const int64_t M = (int64_t)nblk * b;
+    std::vector<int32_t> rp(M + 1, 0), ci, blkoff(nblk + 1, 0), levptr, rowid(M), rowptr(M + 1, 0), col, lvl(b), cnt;
+    std::vector<nep_cdouble> vx, val, diag(upper ? M : 0);
+    {   // sizes first (the mid rows are the long ones: avoid vector regrowth)
+        size_t noff = 0, nin = 0;
+        for (int64_t r = 0; r < M; ++r) {
+            const int64_t i = h0 + r, s = h0 + (r / b) * b, e = s + b;
+            for (int32_t q = P[i]; q < P[i + 1]; ++q) {
+                const int32_t j = I[q];
+                if (j == i) continue;
+                if (j >= s && j < e) ++nin; else ++noff;
+            }
+        }
+        ci.reserve(noff); vx.reserve(noff); col.reserve(nin); val.reserve(nin);
+    }
+    out.wpr.assign(nblk, 1);
+    for (int k = 0; k < nblk; ++k) {
+        const int64_t s = h0 + (int64_t)k * b, e = s + b;
+        // ---- off-block part, row order
+        for (int64_t i = s; i < e; ++i) {
+            for (int32_t q = P[i]; q < P[i + 1]; ++q) {
+                const int32_t j = I[q];
+                if (upper ? (j >= e) : (j < s)) { ci.push_back(j); vx.push_back(X[q]); }
+            }
+            rp[i - h0 + 1] = (int32_t)ci.size();
+        }
+        out.wpr[k] = pick_wpr((double)(rp[e - h0] - rp[s - h0]) / b);
+        // ---- in-block levels
+        int nlev = 0;
+        if (!upper) {
+            for (int64_t i = s; i < e; ++i) {
+                int lv = 0;
+                for (int32_t q = P[i]; q < P[i + 1]; ++q) { const int32_t j = I[q]; if (j >= s && j < i) lv = std::max(lv, lvl[j - s] + 1); }
+                lvl[i - s] = lv; nlev = std::max(nlev, lv + 1);
+            }
+        } else {
+            for (int64_t i = e - 1; i >= s; --i) {
+                int lv = 0;
+                for (int32_t q = P[i]; q < P[i + 1]; ++q) { const int32_t j = I[q]; if (j > i && j < e) lv = std::max(lv, lvl[j - s] + 1); }
+                lvl[i - s] = lv; nlev = std::max(nlev, lv + 1);
+            }
+        }
+        cnt.assign(nlev + 1, 0);
+        for (int t = 0; t < b; ++t) cnt[lvl[t] + 1]++;
+        for (int l = 0; l < nlev; ++l) cnt[l + 1] += cnt[l];
+        blkoff[k] = (int32_t)levptr.size();
+        const int32_t base = (int32_t)((int64_t)k * b);
+        for (int l = 0; l <= nlev; ++l) levptr.push_back(base + cnt[l]);
+        {
+            std::vector<int32_t> pos(cnt.begin(), cnt.end() - 1);
+            for (int t = 0; t < b; ++t) rowid[base + pos[lvl[t]]++] = (int32_t)(s + t);
+        }
+        for (int t = 0; t < b; ++t) {
+            const int32_t slot = base + t, i = rowid[slot];
+            bool have_diag = false;
+            for (int32_t q = P[i]; q < P[i + 1]; ++q) {
+                const int32_t j = I[q];
+                if (j == i) { have_diag = true; if (upper) diag[slot] = X[q]; continue; }
+                if (j >= s && j < e) { col.push_back(j); val.push_back(X[q]); }
+            }
+            if (upper && (!have_diag || (diag[slot].re == 0.0 && diag[slot].im == 0.0))) {
+                nep_set_error("U has a zero pivot in row %d (matrix is singular)", i);
+                return NEP_ERR_SINGULAR;
+            }
+            rowptr[slot + 1] = (int32_t)col.size();
+        }
+    }
+    blkoff[nblk] = (int32_t)levptr.size();
+    out.nnz = (int64_t)ci.size();
+    // ---- upload the off-block CSR
+    { int prc_ = nep_pool_alloc((void**)&out.d_rp, (size_t)(M + 1) * 4); if (prc_) return prc_; }
+    { int prc_ = nep_pool_alloc((void**)&out.d_ci, (ci.size() + 1) * 4); if (prc_) return prc_; }
+    { int prc_ = nep_pool_alloc((void**)&out.d_vx, (vx.size() + 1) * 16); if (prc_) return prc_; }
+    HIPCHK(hipMemcpy(out.d_rp, rp.data(), (size_t)(M + 1) * 4, hipMemcpyHostToDevice));
+    if (!ci.empty()) {
+        HIPCHK(hipMemcpy(out.d_ci, ci.data(), ci.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(out.d_vx, vx.data(), vx.size() * 16, hipMemcpyHostToDevice));
+    }
+    // ---- diagonal-block inverses on the device
+    int32_t *d_blkoff = nullptr, *d_levptr = nullptr, *d_rowid = nullptr, *d_rowptr = nullptr, *d_col = nullptr;
+    cplx *d_val = nullptr, *d_diag = nullptr;
+    int rc = nep_pool_alloc((void**)&out.d_inv, (size_t)M * b * sizeof(cplx));
+    if (!rc) rc = nep_pool_alloc((void**)&d_blkoff, (size_t)(nblk + 1) * 4);
+    if (!rc) rc = nep_pool_alloc((void**)&d_levptr, levptr.size() * 4);
+    if (!rc) rc = nep_pool_alloc((void**)&d_rowid, (size_t)M * 4);
+    if (!rc) rc = nep_pool_alloc((void**)&d_rowptr, (size_t)(M + 1) * 4);
+    if (!rc) rc = nep_pool_alloc((void**)&d_col, (col.size() + 1) * 4);
+    if (!rc) rc = nep_pool_alloc((void**)&d_val, (val.size() + 1) * 16);
+    if (!rc && upper) rc = nep_pool_alloc((void**)&d_diag, (size_t)M * 16);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpy(d_blkoff, blkoff.data(), (size_t)(nblk + 1) * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_levptr, levptr.data(), levptr.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_rowid, rowid.data(), (size_t)M * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(d_rowptr, rowptr.data(), (size_t)(M + 1) * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !col.empty()) e = hipMemcpy(d_col, col.data(), col.size() * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess && !val.empty()) e = hipMemcpy(d_val, val.data(), val.size() * 16, hipMemcpyHostToDevice);
+        if (e == hipSuccess && upper) e = hipMemcpy(d_diag, diag.data(), (size_t)M * 16, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            if (upper)
+                hipLaunchKernelGGL((k_mid_inverse<true>), dim3(b, nblk), dim3(256), (size_t)b * sizeof(cplx), 0, b, h0,
+                                   (const int32_t*)d_blkoff, (const int32_t*)d_levptr, (const int32_t*)d_rowid,
+                                   (const int32_t*)d_rowptr, (const int32_t*)d_col, (const cplx*)d_val,
+                                   (const cplx*)d_diag, out.d_inv);
+            else
+                hipLaunchKernelGGL((k_mid_inverse<false>), dim3(b, nblk), dim3(256), (size_t)b * sizeof(cplx), 0, b, h0,
+                                   (const int32_t*)d_blkoff, (const int32_t*)d_levptr, (const int32_t*)d_rowid,
+                                   (const int32_t*)d_rowptr, (const int32_t*)d_col, (const cplx*)d_val,
+                                   (const cplx*)d_diag, out.d_inv);
+            e = hipGetLastError();
+            if (e == hipSuccess) e = hipDeviceSynchronize();
+        }
+        if (e != hipSuccess) { nep_set_error("mid inverse build failed: %s", hipGetErrorString(e)); rc = NEP_ERR_HIP; }
+    }
+    if (d_blkoff) nep_pool_free(d_blkoff);
+    if (d_levptr) nep_pool_free(d_levptr);
+    if (d_rowid) nep_pool_free(d_rowid);
+    if (d_rowptr) nep_pool_free(d_rowptr);
+    if (d_col) nep_pool_free(d_col);
+    if (d_val) nep_pool_free(d_val);
+    if (d_diag) nep_pool_free(d_diag);
+    return rc;
+}
+
+template <bool UPPER>
+static int run_mid(const nep_lu* lu, const MidFactor& m, cplx* work, int64_t ldw, cplx* tmp, int64_t ldt, int nrhs,
+                   hipStream_t st, int* launches);
+
 template <bool UPPER>
 static int run_head(const TriFactor& f, cplx* work, int64_t ldw, int nrhs, hipStream_t st, int* launches) {
     for (const Seg& sg : f.segs) {
@@ -355,12 +614,36 @@ static int run_head(const TriFactor& f, cplx* work, int64_t ldw, int nrhs, hipSt
     return NEP_OK;
 }
 
+template <bool UPPER>
+static int run_mid(const nep_lu* lu, const MidFactor& m, cplx* work, int64_t ldw, cplx* tmp, int64_t ldt, int nrhs,
+                   hipStream_t st, int* launches) {
+    const int b = lu->bsz, nblk = lu->nblk;
+    for (int q = 0; q < nblk; ++q) {
+        const int k = UPPER ? nblk - 1 - q : q;
+        const int64_t r0 = lu->h0 + (int64_t)k * b;
+        launch_mid_spmv(m.wpr[k], r0, b, lu->h0, (const int32_t*)m.d_rp, (const int32_t*)m.d_ci, (const cplx*)m.d_vx,
+                        (const cplx*)work, ldw, tmp, ldt, nrhs, st);
+        LAUNCHCHK();
+        if (b >= 1024)
+            hipLaunchKernelGGL((k_mid_gemv<UPPER, 4>), dim3(b, nrhs), dim3(256), 0, st, r0, b, lu->h0,
+                               (const cplx*)(m.d_inv + (int64_t)k * b * b), (const cplx*)tmp, ldt, work, ldw);
+        else
+            hipLaunchKernelGGL((k_mid_gemv<UPPER, 1>), dim3((b + 3) / 4, nrhs), dim3(256), 0, st, r0, b, lu->h0,
+                               (const cplx*)(m.d_inv + (int64_t)k * b * b), (const cplx*)tmp, ldt, work, ldw);
+        LAUNCHCHK();
+        if (launches) *launches += 2;
+    }
+    return NEP_OK;
+}
+
 extern "C" {
 
 int32_t nep_lu_destroy(nep_lu* lu) {
     if (!lu) return NEP_OK;
     free_tri(lu->L11);
     free_tri(lu->U11);
+    free_mid(lu->Lm);
+    free_mid(lu->Um);
     if (lu->d_L21p) nep_pool_free(lu->d_L21p);
     if (lu->d_L21i) nep_pool_free(lu->d_L21i);
     if (lu->d_L21x) nep_pool_free(lu->d_L21x);
@@ -460,17 +743,55 @@ static int lu_build(nep_lu* lu, int64_t n, const int32_t* hLp, const int32_t* hL
     }
     lu->i0 = i0; lu->T = n - i0;
     const int64_t T = lu->T;
+    // blocked mid region [h0, i0): nblk blocks of b rows.  A head level costs a dependent launch (~4.5 us), a block two
+    // (~8 us + GEMV) plus a one-off inverse build (~b^2/2048 us, amortised over the expected solves).  level[] of the FULL
+    // L is also the level of a row inside any leading sub-triangle, so head levels(h) = 1 + max(level[0:h)); U is
+    // taken to behave alike (exact for the symmetric strategy).
+    int64_t h0 = i0;
+    {
+        int b = n >= 8192 ? 2048 : (n >= 4096 ? 1024 : (n >= 2048 ? 512 : 256));   // measured: gun 0.35 -> 0.14 ms, n=1e6 203 -> 2.4 ms
+        if (const char* e = getenv("NEP_LU_BLOCK")) { int v = atoi(e); if (v >= 64 && v <= 2048 && v % 64 == 0) b = v; }
+        const int64_t kmax = std::min<int64_t>(i0 / b, std::min<int64_t>(n / 2, TRSV_MID_MAX) / b);
+        if (kmax > 0) {
+            std::vector<int32_t> headlev(kmax + 1, 0);
+            int32_t run = 0;
+            for (int64_t i = 0; i <= i0; ++i) {
+                const int64_t d = i0 - i;
+                if (d % b == 0 && d / b <= kmax) headlev[d / b] = run;
+                if (i < i0) run = std::max(run, level[i] + 1);
+            }
+            const double nsolve = (double)std::max(1, g_expected_solves);
+            const double cblk = 8.0 + 8.0 * (double)b * b / 3.0e6;   // two launches + the triangular GEMV at ~3 TB/s
+            int64_t bestk = 0;
+            double bestc = 2.0 * headlev[0] * 4.5;
+            for (int64_t k = 1; k <= kmax; ++k) {
+                const double c = 2.0 * (headlev[k] * 4.5 + k * cblk) + k * ((double)b * b / 2048.0) / nsolve;
+                if (c < bestc * 0.98) { bestc = c; bestk = k; }
+            }
+            if (const char* e = getenv("NEP_LU_MID")) { long v = atol(e); if (v >= 0) bestk = std::min<int64_t>(v / b, kmax); }
+            lu->nblk = (int32_t)bestk; lu->bsz = b;
+            h0 = i0 - bestk * b;
+        }
+    }
+    lu->h0 = h0;
     int rc;
     TSTAMP("validate+levels");
     // ---- heads
     int32_t nl = 0;
-    compute_levels(n, hLp, hLi, false, 0, i0, level, nl);
-    rc = build_tri(n, hLp, hLi, hLx, false, 0, i0, 0, i0, level, nl, lu->L11);
+    compute_levels(n, hLp, hLi, false, 0, h0, level, nl);
+    rc = build_tri(n, hLp, hLi, hLx, false, 0, h0, 0, h0, level, nl, lu->L11);
     if (rc) return rc;
-    compute_levels(n, hUp, hUi, true, 0, i0, level, nl);
-    rc = build_tri(n, hUp, hUi, hUx, true, 0, i0, 0, n, level, nl, lu->U11);   // keeps U12 entries (tail is final)
+    compute_levels(n, hUp, hUi, true, 0, h0, level, nl);
+    rc = build_tri(n, hUp, hUi, hUx, true, 0, h0, 0, n, level, nl, lu->U11);   // keeps the columns >= h0 (final by then)
     if (rc) return rc;
     TSTAMP("heads build+upload");
+    if (lu->nblk > 0) {
+        rc = build_mid(hLp, hLi, hLx, false, h0, lu->nblk, lu->bsz, lu->Lm);
+        if (rc) return rc;
+        rc = build_mid(hUp, hUi, hUx, true, h0, lu->nblk, lu->bsz, lu->Um);
+        if (rc) return rc;
+        TSTAMP("mid blocks");
+    }
     if (T == 0) return NEP_OK;
     // ---- L21 (tail rows, head columns)
     {
@@ -566,50 +887,61 @@ int32_t nep_lu_info(const nep_lu* lu, int64_t info[6]) {
     ARGCHK(lu && info);
     info[0] = lu->n; info[1] = lu->nnzL_in; info[2] = lu->nnzU_in;
     // levels actually traversed per solve (head levels; the dense tail counts as one step each way)
-    info[3] = lu->L11.nlev + (lu->T ? 1 : 0); info[4] = lu->U11.nlev + (lu->T ? 1 : 0);
+    info[3] = lu->L11.nlev + lu->nblk + (lu->T ? 1 : 0); info[4] = lu->U11.nlev + lu->nblk + (lu->T ? 1 : 0);
     // algorithmic bytes of one single-RHS solve: sparse heads + L21 (val 16 + idx 4) + dense tail + vectors
-    info[5] = (lu->L11.nnz + lu->U11.nnz + lu->nnzL21) * 20 + 16 * lu->T * lu->T + 8 * (lu->n + 1) + 16 * lu->n +
+    info[5] = (lu->L11.nnz + lu->U11.nnz + lu->nnzL21 + lu->Lm.nnz + lu->Um.nnz) * 20 + 16 * lu->T * lu->T +
+              16 * (int64_t)lu->nblk * lu->bsz * lu->bsz /* two triangular halves */ + 8 * (lu->n + 1) + 16 * lu->n +
               3 * 16 * lu->n;
     return NEP_OK;
 }
 
 /* extra introspection used by tests/bench: out[0]=tail size T, out[1]=kernel launches of the last
- * solve, out[2]=full levels(L), out[3]=full levels(U), out[4]=wide segments, out[5]=narrow segments */
-int32_t nep_lu_schedule(const nep_lu* lu, int64_t out[6]) {
+ * solve, out[2]=full levels(L), out[3]=full levels(U), out[4]=wide segments, out[5]=narrow segments,
+ * out[6]=rows of the blocked mid region, out[7]=its block size */
+int32_t nep_lu_schedule(const nep_lu* lu, int64_t out[8]) {
     ARGCHK(lu && out);
     out[0] = lu->T; out[1] = lu->launches; out[2] = lu->levL_full; out[3] = lu->levU_full;
     int64_t w = 0, nn = 0;
     for (const Seg& s : lu->L11.segs) (s.wide ? w : nn)++;
     for (const Seg& s : lu->U11.segs) (s.wide ? w : nn)++;
     out[4] = w; out[5] = nn;
+    out[6] = (int64_t)lu->nblk * lu->bsz; out[7] = lu->bsz;
     return NEP_OK;
 }
 
 // enqueues the level sweep (L head, tail, U head) on `st`
 static int lu_sweep(nep_lu* lu, int nrhs, cplx* work, cplx* tmp, hipStream_t st, int* launches) {
-    const int64_t n = lu->n, T = lu->T, i0 = lu->i0;
+    const int64_t n = lu->n, T = lu->T, i0 = lu->i0, ldt = n - lu->h0;
+    cplx* tmp_tail = tmp + (i0 - lu->h0);
     int rc = run_head<false>(lu->L11, work, n, nrhs, st, launches);
     if (rc) return rc;
+    if (lu->nblk > 0) { rc = run_mid<false>(lu, lu->Lm, work, n, tmp, ldt, nrhs, st, launches); if (rc) return rc; }
     if (T > 0) {
-        hipLaunchKernelGGL(k_tail_spmv, dim3((unsigned)((T + 3) / 4), nrhs), dim3(256), 0, st, T, i0,
-                           (const int32_t*)lu->d_L21p, (const int32_t*)lu->d_L21i, (const cplx*)lu->d_L21x,
-                           (const cplx*)work, n, tmp, T);
+        launch_mid_spmv(pick_wpr((double)lu->nnzL21 / (double)T), i0, (int)T, i0, (const int32_t*)lu->d_L21p,
+                        (const int32_t*)lu->d_L21i, (const cplx*)lu->d_L21x, (const cplx*)work, n, tmp_tail, ldt, nrhs, st);
         LAUNCHCHK();
         hipLaunchKernelGGL(k_tail_gemv, dim3((unsigned)((T + 3) / 4), nrhs), dim3(256), 0, st, T, i0,
-                           (const cplx*)lu->d_Sinv, (const cplx*)tmp, T, work, n);
+                           (const cplx*)lu->d_Sinv, (const cplx*)tmp_tail, ldt, work, n);
         LAUNCHCHK();
         if (launches) *launches += 2;
     }
+    if (lu->nblk > 0) { rc = run_mid<true>(lu, lu->Um, work, n, tmp, ldt, nrhs, st, launches); if (rc) return rc; }
     return run_head<true>(lu->U11, work, n, nrhs, st, launches);
 }
 
 int32_t nep_lu_solve(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_t ldb, nep_cdouble* dX, int64_t ldx,
                      double scale, nep_stream stream) {
+    return nep_lu_solve_add(lu, nrhs, dB, ldb, nullptr, 0, dX, ldx, scale, stream);
+}
+
+int32_t nep_lu_solve_add(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_t ldb, const nep_cdouble* dAdd,
+                         int64_t ldadd, nep_cdouble* dX, int64_t ldx, double scale, nep_stream stream) {
     ARGCHK(lu && dB && dX);
     ARGCHK(nrhs >= 1 && nrhs <= 65535 && ldb >= lu->n && ldx >= lu->n);
+    ARGCHK(dAdd == nullptr || ldadd >= lu->n);
     hipStream_t st = as_stream(stream);
     const int64_t n = lu->n, T = lu->T;
-    int rc = lu->work.ensure((size_t)(n + T) * nrhs * sizeof(cplx));
+    int rc = lu->work.ensure((size_t)(2 * n - lu->h0) * nrhs * sizeof(cplx));
     if (rc) return rc;
     cplx* work = (cplx*)lu->work.dptr;
     cplx* tmp = work + (size_t)n * nrhs;
@@ -618,7 +950,7 @@ int32_t nep_lu_solve(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_t ld
     hipLaunchKernelGGL(k_perm_in, dim3(pg, nrhs), dim3(256), 0, st, n, (const int32_t*)lu->d_perm_r, (const cplx*)dB, ldb,
                        work, n);
     LAUNCHCHK(); ++launches;
-    const int nseg = (int)(lu->L11.segs.size() + lu->U11.segs.size());
+    const int nseg = (int)(lu->L11.segs.size() + lu->U11.segs.size()) + 4 * lu->nblk;
     bool graphed = false;
     if (lu->use_graph && nseg >= 8 && !getenv("NEP_NO_GRAPH")) {
         if (!lu->graph_exec || lu->graph_nrhs != nrhs || lu->graph_work != (void*)work) {
@@ -653,7 +985,7 @@ int32_t nep_lu_solve(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_t ld
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_perm_out, dim3(pg, nrhs), dim3(256), 0, st, n, (const int32_t*)lu->d_perm_c, (const cplx*)work, n,
-                       (cplx*)dX, ldx, scale);
+                       (cplx*)dX, ldx, scale, (const cplx*)dAdd, ldadd);
     LAUNCHCHK(); ++launches;
     lu->launches = launches;
     return NEP_OK;

@@ -205,6 +205,80 @@ def test_lu_solve_vs_host(na, nrhs):
     assert np.linalg.norm(na.to_host(Bd) + Xo) <= 1e-10 * np.linalg.norm(Xo)
 
 
+@pytest.mark.parametrize("spec", [dict(), dict(NEP_LU_BLOCK="64", NEP_LU_MID="512", NEP_LU_TAIL="0"),
+                                  dict(NEP_LU_BLOCK="128", NEP_LU_MID="384", NEP_LU_TAIL="100"), dict(NEP_LU_MID="0")])
+def test_lu_blocked_mid_region(na, spec, monkeypatch):
+    """every schedule shape of the hybrid solve (level heads / blocked mid with inverted diagonal blocks / dense tail)
+    returns the host solution; nrhs 1 and 5; tolerance 1e-9 relative (explicit block inverses)"""
+    for k_, v_ in spec.items():
+        monkeypatch.setenv(k_, v_)
+    from oracle import gallery as og
+    nep = og.nlevp_native_gun(1310)
+    A = sp.csc_matrix(nep.compute_Mder(250.0 ** 2 + 1j), dtype=complex)
+    n = A.shape[0]
+    rng = np.random.default_rng(5)
+    lu = na.DeviceLU(A, expected_solves=200)
+    if "NEP_LU_MID" in spec and "NEP_LU_BLOCK" in spec:
+        assert lu.mid_block == int(spec["NEP_LU_BLOCK"]) and lu.mid_rows == int(spec["NEP_LU_MID"])
+        assert lu.tail == int(spec["NEP_LU_TAIL"])
+    if spec.get("NEP_LU_MID") == "0":
+        assert lu.mid_rows == 0
+    host = spla.splu(A)
+    for nrhs in (1, 5):
+        B = rng.standard_normal((n, nrhs)) + 1j * rng.standard_normal((n, nrhs))
+        X = na.to_host(lu.solve(na.to_dev(B)))
+        Xo = host.solve(B)
+        assert np.linalg.norm(X - Xo) <= 1e-9 * np.linalg.norm(Xo)
+
+
+def test_cw_backward_error_and_refinement(na):
+    """nep_cw_backward_error against NumPy (r exact to round-off, omega to 1e-12 relative) and the UMFPACK-style
+    refinement loop of FactorizeLinSolver: final componentwise backward error < 10 eps, and refinement never makes the
+    residual worse (test/linsolver.jl:77-94)."""
+    import ctypes as C
+    from nep_amd import _lib
+    AA, ofv, rng = _rand_spmf(400, 3, 0.02, 11, cplx_vals=True)
+    AA[0] = sp.csc_matrix(AA[0] + 5 * sp.eye(400))
+    nep = na.SPMF_NEP(AA, _pfv(na, 3))
+    lam = 0.7 + 0.2j
+    n = 400
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    cabs = np.array([abs(f.derivs(lam, 1)[0]) for f in nep.get_fv()])
+    xd, bd = na.to_dev(x), na.to_dev(b)
+    Mx = nep.compute_Mlincomb(lam, xd)
+    import torch
+    r = torch.empty_like(xd)
+    om = np.zeros(1)
+    st = __import__("nep_amd").nep.stream_ptr()
+    _lib.check(_lib.lib.nep_cw_backward_error(nep.dev.h, _lib.hptr(cabs), None, C.c_void_p(xd.data_ptr()),
+                                              C.c_void_p(bd.data_ptr()), C.c_void_p(Mx.data_ptr()),
+                                              C.c_void_p(r.data_ptr()), _lib.hptr(om), st))
+    # fused variant: M x formed inside the kernel from the complex coefficients
+    cf = np.array([f.derivs(lam, 1)[0] for f in nep.get_fv()], dtype=complex)
+    r2 = torch.empty_like(xd)
+    om2 = np.zeros(1)
+    _lib.check(_lib.lib.nep_cw_backward_error(nep.dev.h, _lib.hptr(cabs), _lib.hptr(cf), C.c_void_p(xd.data_ptr()),
+                                              C.c_void_p(bd.data_ptr()), None, C.c_void_p(r2.data_ptr()),
+                                              _lib.hptr(om2), st))
+    assert np.linalg.norm(na.to_host(r2) - na.to_host(r)) <= 1e-13 * np.linalg.norm(na.to_host(r))
+    assert abs(om2[0] - om[0]) <= 1e-12 * om[0]
+    M = sum(f.derivs(lam, 1)[0] * A for f, A in zip(nep.get_fv(), AA))
+    r_ref = b - M @ x
+    den = sum(c * (abs(A) @ abs(x)) for c, A in zip(cabs, AA)) + abs(b)
+    assert np.linalg.norm(na.to_host(r)[:, 0] - r_ref) <= 1e-13 * np.linalg.norm(r_ref)
+    assert abs(om[0] - np.max(abs(r_ref) / den)) <= 1e-12 * om[0]
+    # refinement
+    res = []
+    for steps in (0, 1, 10):
+        ls = na.create_linsolver(na.FactorizeLinSolverCreator(umfpack_refinements=steps), nep, lam)
+        xs = na.lin_solve(ls, b)
+        res.append(np.linalg.norm(M @ xs - b))
+        if steps == 10:
+            assert ls.last_omega < 10 * np.finfo(float).eps
+    assert res[1] <= res[0] * 1.5 and res[2] <= res[0] * 1.5
+
+
 def test_lin_solve_interfaces(na):
     """Backslash == Factorize == host solve (test/linsolver.jl:11-69) on a gun twin; dense dep0 too."""
     nep = na.nep_gallery("nlevp_native_gun", 655)
