@@ -2,7 +2,7 @@
 """Micro-benchmarks of the individual HIP kernels at BASELINE sizes (HIP-event timing), meant to be run
 plain or under `rocprofv3 --kernel-trace --stats` / `rocprofv3 --pmc FETCH_SIZE` (separate passes).
 
-    python scripts/kernel_bench.py [gun|wep|all] [--reps N]
+    python scripts/kernel_bench.py [gun|wep|lu|all] [--reps N]
 
 Prints one JSON line per measurement: algorithmic bytes/flops (SURVEY.md section 8d formulas), ms per call,
 achieved GB/s or TFLOP/s and the fraction of the MI355X peak (HBM 8 TB/s, FP64 MFMA 78.6 TFLOP/s).
@@ -100,6 +100,26 @@ def bench_gemm(na, rows, k, p, label, reps, rowmajor=True):
          TFLOPs=fl / ms / 1e9, frac_mfma=fl / ms / 1e9 / MFMA64, GBps=b / ms / 1e6, frac_hbm=b / ms / 1e6 / HBM)
 
 
+def bench_lu(na, A, label, reps, nrhs=1):
+    import scipy.sparse as sp
+    t = time.perf_counter()
+    lu = na.DeviceLU(sp.csc_matrix(A, dtype=np.complex128), expected_solves=200)
+    torch.cuda.synchronize()
+    tsetup = time.perf_counter() - t
+    n = lu.n
+    B = crandn(nrhs, n)
+    X = torch.empty_like(B)
+    ms = ev_time(lambda: lu.solve(B, out=X), reps)
+    xh = na.to_host(X)[:, 0]; bh = na.to_host(B)[:, 0]
+    res = float(np.linalg.norm(A @ xh - bh) / np.linalg.norm(bh))
+    b = lu.solve_bytes + (nrhs - 1) * 4 * 16 * n
+    emit(kernel="K5 nep_lu_solve (hipGraph level sweep + blocked mid + dense tail)", case=label, n=n, nrhs=nrhs,
+         nnzL=lu.nnzL, nnzU=lu.nnzU, levels_plain=[lu.levL_full, lu.levU_full], dependent_steps=[lu.levL, lu.levU],
+         tail=lu.tail, mid_rows=lu.mid_rows, mid_block=lu.mid_block, launches=lu.launches_last_solve(), bytes=b, ms=ms,
+         GBps=b / ms / 1e6, frac_hbm=b / ms / 1e6 / HBM, rel_residual=res, host_factor_s=lu.t_factor,
+         device_setup_s=lu.t_create, setup_s=tsetup)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="?", default="all")
@@ -116,6 +136,9 @@ def main():
                    active=(np.arange(1, 102) * n).astype(np.int64))
         bench_orth(na, n, 100, "gun tiar step 100", args.reps)
         bench_gemm(na, n, 100, 100, "gun Ritz block", args.reps)
+        A0 = nep.compute_Mder(0.0)
+        bench_lu(na, A0, "gun M(sigma)", args.reps)
+        bench_lu(na, A0, "gun M(sigma), Beyn block", args.reps, nrhs=32)
     if args.which in ("wep", "all"):
         from nep_amd import wep
         wd = wep.WaveguideData(1003, 999, "JARLEBRING")
@@ -126,6 +149,11 @@ def main():
         bench_orth(na, n, 60, "wep tiar step 60", 5)
         bench_gemm(na, n, 60, 60, "wep Ritz block", 5)
         bench_gemm(na, n, 60, 60, "wep basis block col-major", 5, rowmajor=False)
+    if args.which in ("lu", "all"):
+        for nx, nz in ((303, 299), (1003, 999)):
+            nepw = na.nep_gallery("WEP", nx=nx, nz=nz, benchmark_problem="JARLEBRING")
+            bench_lu(na, nepw.compute_Mder(-3 - 3.5j), "wep %dx%d M(sigma)" % (nx, nz), 10)
+            del nepw
 
 
 if __name__ == "__main__":
