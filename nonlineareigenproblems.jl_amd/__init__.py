@@ -21,7 +21,7 @@ from .tiar import tiar
 from .newton import resinv, quasinewton, compute_rf, armijo_rule, ScalarNewtonInnerSolver
 from .nleigs import nleigs
 from . import rk_helper
-from .contour import (contour_beyn, integrate_interval, MatrixIntegrator, MatrixTrapezoidal,
+from .contour import (contour_beyn, contour_block_SS, integrate_interval, MatrixIntegrator, MatrixTrapezoidal,
                       MatrixTrapezoidalSharded, probe_block)
 from . import gallery
 from .gallery import nep_gallery

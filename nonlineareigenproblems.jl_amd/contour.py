@@ -81,6 +81,36 @@ def integrate_interval(ST, f, gv, a, b, N, info=None, ops=_DeviceOps):
     return S
 
 
+class _NodeSolve:
+    """f(t) = Tv(g(t)) * weight(t), Tv(lam) = lin_solve(create_linsolver(creator, nep, lam+sigma), Vh)
+    (method_beyncontour.jl:89-98, method_block_SS.jl:81-86,129-132).  With the default BackslashLinSolverCreator every
+    node needs a NEW host factorisation; `prefetch` starts all factorisations of this rank's nodes in worker processes
+    so that they run concurrently with each other and with the device solves of the nodes already factored."""
+
+    def __init__(self, nep, linsolvercreator, sigma, g, Vd, weight):
+        self.nep, self.creator, self.sigma, self.g, self.Vd, self.weight = nep, linsolvercreator, sigma, g, Vd, weight
+        self.futs = {}
+
+    def prefetch(self, ts):
+        c = self.creator
+        workers = getattr(c, "workers", None)
+        if not isinstance(c, BackslashLinSolverCreator) or workers == 0 or len(ts) < 2:
+            return
+        for t in ts:
+            A = self.nep.compute_Mder(self.g(t) + self.sigma)
+            self.futs[t] = HostLUPool.submit(A, permc_spec=c.permc_spec, **c.lu_kw)
+
+    def __call__(self, t):
+        if t in self.futs:
+            try:
+                F = self.futs.pop(t).result()
+            except RuntimeError as e:
+                raise np.linalg.LinAlgError("SingularException: " + str(e))
+            return DeviceLU(factors=F, expected_solves=1).solve(self.Vd), self.weight(t)
+        M0inv = create_linsolver(self.creator, self.nep, self.g(t) + self.sigma)
+        return lin_solve(M0inv, self.Vd), self.weight(t)
+
+
 def probe_block(n, k, seed=10):
     """deterministic standard-normal probe (the reference's `Random.seed!(10); randn(n,k)`,
     method_beyncontour.jl:85-86, is Julia-RNG specific; counter-based Philox here)"""
@@ -115,34 +145,7 @@ def contour_beyn(nep, MIntegrator=MatrixTrapezoidal, tol=np.sqrt(EPS), sigma=0.0
         Vh = probe_block(n, k)
     Vd = to_dev(Vh)
 
-    class _NodeSolve:
-        """f(t) = Tv(g(t)) * gp(t), Tv(lam) = lin_solve(create_linsolver(creator, nep, lam+sigma), Vh)
-        (method_beyncontour.jl:89-98).  With the default BackslashLinSolverCreator every node needs a NEW host
-        factorisation; `prefetch` starts all factorisations of this rank's nodes in worker processes so that they run
-        concurrently with each other and with the device solves of the nodes already factored."""
-
-        def __init__(self):
-            self.futs = {}
-
-        def prefetch(self, ts):
-            workers = getattr(linsolvercreator, "workers", None)
-            if not isinstance(linsolvercreator, BackslashLinSolverCreator) or workers == 0 or len(ts) < 2:
-                return
-            for t in ts:
-                A = nep.compute_Mder(g(t) + sigma)
-                self.futs[t] = HostLUPool.submit(A, permc_spec=linsolvercreator.permc_spec, **linsolvercreator.lu_kw)
-
-        def __call__(self, t):
-            if t in self.futs:
-                try:
-                    F = self.futs.pop(t).result()
-                except RuntimeError as e:
-                    raise np.linalg.LinAlgError("SingularException: " + str(e))
-                return DeviceLU(factors=F, expected_solves=1).solve(Vd), gp(t)
-            M0inv = create_linsolver(linsolvercreator, nep, g(t) + sigma)
-            return lin_solve(M0inv, Vd), gp(t)
-
-    f = _NodeSolve()
+    f = _NodeSolve(nep, linsolvercreator, sigma, g, Vd, gp)
 
     S = integrate_interval(MIntegrator, f, [lambda s: 1.0 + 0j, g], 0.0, 2 * np.pi, N, info=info)
     A0 = to_host(S[0]) / (2j * np.pi)
@@ -181,3 +184,73 @@ def contour_beyn(nep, MIntegrator=MatrixTrapezoidal, tol=np.sqrt(EPS), sigma=0.0
     if info is not None:
         info.update(errs=errs)
     return lam[sel], cols(sel)
+
+
+def probe_block_uniform(n, L, seed=10):
+    """deterministic stand-in for `Random.seed!(10); U = rand(T,n,L); V = rand(T,n,L)` (method_block_SS.jl:77-79):
+    real and imaginary parts uniform in [0,1), U drawn before V (counter-based Philox)"""
+    rng = np.random.Generator(np.random.Philox(seed))
+    U = rng.random((n, L)) + 1j * rng.random((n, L))
+    V = rng.random((n, L)) + 1j * rng.random((n, L))
+    return U, V
+
+
+def contour_block_SS(nep, MIntegrator=MatrixTrapezoidal, tol=np.sqrt(EPS), sigma=0.0, logger=0, linsolvercreator=None,
+                     neigs=np.inf, k=3, radius=1, N=1000, K=3, errmeasure=None, sanity_check=True, Shat_mode="native",
+                     rank_drop_tol=None, U=None, V=None, info=None):
+    """Block SS (Asakura/Sakurai/Tadano/Ikegami/Kimura) contour method, src/method_block_SS.jl:47-214: the same
+    node solves as contour_beyn (host factorisation per node, n x L block solve on the device, K5 with grid.y = L), but
+    2K moment blocks accumulated on the device (K8) through the same `integrate_interval` seam -- so
+    `MatrixTrapezoidalSharded` shards it over GPUs exactly like Beyn.  The small Hankel
+    SVD / generalised eigenproblem run on the host; the eigenvector block S*(VV1*X) on the device (K7).
+    `neigs`, `errmeasure`, `sanity_check` are accepted and unused, as in the reference (:57,:62-63)."""
+    if rank_drop_tol is None:
+        rank_drop_tol = tol
+    if linsolvercreator is None:
+        linsolvercreator = BackslashLinSolverCreator()
+    sigma = complex(sigma)
+    n = nep.size(1)
+    L = int(k)
+    if U is None or V is None:
+        U, V = probe_block_uniform(n, L)
+    Vd = to_dev(V)
+    if Shat_mode == "JSIAM":
+        if not np.isscalar(radius):
+            raise ValueError("JSIAM Shat_mode does not support ellipses")
+        # nodes omega_j = radius*exp(i t_j), t_j = 2 pi (j + 1/2)/N; Shat_k = (1/N) sum_j (omega_j/radius)^(k+1) F(omega_j)^-1 V
+        g = lambda t: radius * np.exp(1j * t)
+        f = _NodeSolve(nep, linsolvercreator, sigma, g, Vd, lambda t: 1.0 / (2 * np.pi))
+        gv = [(lambda s, kk=kk: np.exp(1j * (kk + 1) * s)) for kk in range(2 * K)]
+        a = np.pi / N
+        factor = radius
+    elif Shat_mode == "native":
+        r1 = (radius, radius) if np.isscalar(radius) else tuple(radius)
+        g = lambda t: complex(r1[0] * np.cos(t), r1[1] * np.sin(t))
+        gp = lambda t: complex(-r1[0] * np.sin(t), r1[1] * np.cos(t))
+        f = _NodeSolve(nep, linsolvercreator, sigma, g, Vd, lambda t: gp(t) / (2j * np.pi))
+        gv = [(lambda s, kk=kk: g(s) ** kk) for kk in range(2 * K)]
+        a = 0.0
+        factor = 1.0
+    else:
+        raise ValueError("Unknown Shat_mode: %s" % Shat_mode)
+    Sd = integrate_interval(MIntegrator, f, gv, a, a + 2 * np.pi, N, info=info)       # device (2K, L, n)
+    Sh = [to_host(Sd[j]) for j in range(2 * K)]                                         # n x L each
+    UH = np.asarray(U).conj().T
+    Mhat = [UH @ Sh[j] for j in range(2 * K)]                                           # :151-153
+    m = K * L
+    Hhat = np.zeros((m, m), dtype=np.complex128); Hhat2 = np.zeros((m, m), dtype=np.complex128)   # :157-167
+    for i in range(K):
+        for j in range(K):
+            Hhat[i * L:(i + 1) * L, j * L:(j + 1) * L] = Mhat[i + j]
+            Hhat2[i * L:(i + 1) * L, j * L:(j + 1) * L] = Mhat[i + j + 1]
+    UU, SS, VVh = sla.svd(Hhat)                                                        # :172-188
+    VV = VVh.conj().T
+    mprime = int(np.sum(SS / SS[0] > rank_drop_tol))
+    UU1 = UU[:, :mprime]; VV1 = VV[:, :mprime]
+    xi, X = sla.eig(UU1.conj().T @ Hhat2 @ VV1, UU1.conj().T @ Hhat @ VV1)             # :191-197
+    # eigenvector block S * (VV1 X), S = [Shat_0 ... Shat_{K-1}] (n x KL) = the first K moment blocks, already contiguous
+    S = Sd[:K].reshape(K * L, n)
+    Vout = to_host(dense.gemm_ts(S, VV1 @ X, rowmajor=False))                           # :202-207
+    if info is not None:
+        info.update(mprime=mprime, SS=SS)
+    return sigma + factor * xi, Vout

@@ -497,3 +497,68 @@ def contour_beyn(nep, tol=np.sqrt(EPS), sigma=0.0, linsolvercreator=None, neigs=
     if len(sel) > neigs:
         sel = sel[:neigs]
     return lam[sel], V[:, sel]
+
+
+# ----------------------------------------------------------------------------------
+def probe_block_uniform(n, L, seed=10):
+    """Deterministic replacement of `Random.seed!(10); U = rand(T,n,L); V = rand(T,n,L)` (method_block_SS.jl:77-79):
+    real and imaginary parts uniform in [0,1), U drawn before V."""
+    rng = np.random.Generator(np.random.Philox(seed))
+    U = rng.random((n, L)) + 1j * rng.random((n, L))
+    V = rng.random((n, L)) + 1j * rng.random((n, L))
+    return U, V
+
+
+def contour_block_SS(nep, tol=np.sqrt(EPS), sigma=0.0, linsolvercreator=None, neigs=np.inf, k=3, radius=1, N=1000,
+                     K=3, Shat_mode="native", rank_drop_tol=None, U=None, V=None, info=None):
+    """method_block_SS.jl:47-214 (Asakura/Sakurai/Tadano/Ikegami/Kimura block SS; L probe columns = k, 2K moments)."""
+    if rank_drop_tol is None:
+        rank_drop_tol = tol
+    if linsolvercreator is None:
+        linsolvercreator = BackslashLinSolverCreator()
+    n = nep.size(1)
+    L = k
+    if U is None or V is None:
+        U, V = probe_block_uniform(n, L)
+
+    def local_linsolve(lam):                       # :81-86
+        return linsolvercreator.create_linsolver(nep, lam + sigma).lin_solve(V)
+
+    if Shat_mode == "JSIAM":                       # :96-122 (circle only; omega_j = radius*exp(2 pi i (j+1/2)/N))
+        if not np.isscalar(radius):
+            raise ValueError("JSIAM Shat_mode does not support ellipses")
+        w = np.exp(2j * np.pi * (0.5 + np.arange(N)) / N)
+        Shat = np.zeros((n, L, 2 * K), dtype=complex)
+        for j in range(N):
+            X = local_linsolve(radius * w[j])
+            for kk in range(2 * K):
+                Shat[:, :, kk] += w[j] ** (kk + 1) * X / N
+    elif Shat_mode == "native":                    # :124-145
+        r1 = (radius, radius) if np.isscalar(radius) else tuple(radius)
+        g = lambda t: complex(r1[0] * np.cos(t), r1[1] * np.sin(t))
+        gp = lambda t: complex(-r1[0] * np.sin(t), r1[1] * np.cos(t))
+        f = lambda t: local_linsolve(g(t)) * gp(t) / (2j * np.pi)
+        gv = [(lambda s, kk=kk: g(s) ** kk) for kk in range(2 * K)]
+        Shat = integrate_interval_trapezoidal(f, gv, 0, 2 * np.pi, N)
+    else:
+        raise ValueError("Unknown Shat_mode: %s" % Shat_mode)
+    Mhat = np.stack([U.conj().T @ Shat[:, :, kk] for kk in range(2 * K)], axis=2)      # :151-153
+    m = K * L
+    Hhat = np.zeros((m, m), dtype=complex); Hhat2 = np.zeros((m, m), dtype=complex)    # :157-167
+    for i in range(K):
+        for j in range(K):
+            Hhat[i * L:(i + 1) * L, j * L:(j + 1) * L] = Mhat[:, :, i + j]
+            Hhat2[i * L:(i + 1) * L, j * L:(j + 1) * L] = Mhat[:, :, i + j + 1]
+    UU, SS, VVh = sla.svd(Hhat)                                                       # :172-188
+    VV = VVh.conj().T
+    mprime = int(np.sum(SS / SS[0] > rank_drop_tol))
+    UU1 = UU[:, :mprime]; VV1 = VV[:, :mprime]
+    H1 = UU1.conj().T @ Hhat @ VV1                                                     # :191-193
+    H2 = UU1.conj().T @ Hhat2 @ VV1
+    xi, X = sla.eig(H2, H1)                                                            # :196-197
+    S = np.concatenate([Shat[:, :, j] for j in range(K)], axis=1)                      # :202-206
+    Vout = S @ VV1 @ X
+    factor = radius if Shat_mode == "JSIAM" else 1.0                                   # :210-211
+    if info is not None:
+        info.update(mprime=mprime, SS=SS, Mhat=Mhat)
+    return sigma + factor * xi, Vout

@@ -209,6 +209,32 @@ def test_beyn_gun_twin_vs_oracle(na):
     assert max(oE(lg[i], Vg[:, i]) for i in range(len(lg))) < 1e-6
 
 
+def test_block_SS_dep0_kat_and_gun_twin(na):
+    """test/contour_block_SS.jl:9-24 on the device path (three variants), then a sparse gun twin against the oracle with
+    the same probe blocks: same numerical rank, eigenvalues inside the contour agree to 1e-7 relative."""
+    from oracle import gallery as og, solvers as osol
+    nep = na.nep_gallery("dep0", 3); onep = og.dep0(3)
+    for kw in (dict(radius=1.0, K=3), dict(radius=[1.0, 2.0], K=3), dict(radius=1.0, K=4, Shat_mode="JSIAM")):
+        lam, V = na.contour_block_SS(nep, N=1000, sigma=0.1, k=3, **kw)
+        assert np.linalg.norm(onep.compute_Mlincomb(lam[0], V[:, 0])) < np.sqrt(EPS)
+        lo, Vo = osol.contour_block_SS(onep, N=1000, sigma=0.1, k=3, **kw)
+        _match(np.sort_complex(lam), np.sort_complex(lo), 1e-9)
+    # radius-normalised moments (JSIAM mode): the rank gap of the Hankel matrix is 1e-4 -> 1e-14 on this problem
+    n, L, K, N = 1310, 8, 4, 64
+    onep = og.gun_spmf(n); nep = na.nep_gallery("gun_spmf", n)
+    U, V = na.contour.probe_block_uniform(n, L)
+    kw = dict(sigma=250.0 ** 2, radius=1.2e4, N=N, k=L, K=K, rank_drop_tol=1e-10, Shat_mode="JSIAM")
+    io = {}; ig = {}
+    lo, Vo = osol.contour_block_SS(onep, U=U, V=V, info=io, **kw)
+    lg, Vg = na.contour_block_SS(nep, U=U, V=V, info=ig, **kw)
+    assert ig["mprime"] == io["mprime"] and len(lg) == len(lo)
+    oE = osol.StandardSPMFErrmeasure(onep)
+    eg = np.array([oE(lg[i], Vg[:, i]) for i in range(len(lg))])
+    eo = np.array([oE(lo[i], Vo[:, i]) for i in range(len(lo))])
+    assert io["mprime"] == 7 and eg.max() < 1e-12 and eo.max() < 1e-12
+    _match(lg, lo, 1e-10)
+
+
 def test_wep_mlincomb_vs_oracle(na):
     # test/wep_small.jl:13-22 (SPMF == WEP_FD); here device WEP == oracle WEP_FD == oracle literal SPMF
     from oracle import wep as ow

@@ -131,6 +131,18 @@ def test_qdep0_quasinewton_history():
     assert hist[0][1] == pytest.approx(ref[0][0], rel=1e-14)   # pure sparse Mlincomb + Frobenius norms
 
 
+def test_block_SS_dep0():
+    # test/contour_block_SS.jl:9-24: circle, ellipse, JSIAM mode on dep0(3); ||M(lam_1) v_1|| < sqrt(eps)
+    nep = gallery.dep0(3)
+    for kw in (dict(radius=1.0, K=3), dict(radius=[1.0, 2.0], K=3), dict(radius=1.0, K=4, Shat_mode="JSIAM")):
+        info = {}
+        l, V = solvers.contour_block_SS(nep, N=1000, sigma=0.1, k=3, info=info, **kw)
+        assert info["mprime"] == 3
+        assert np.linalg.norm(nep.compute_Mlincomb(l[0], V[:, 0])) < np.sqrt(EPS)
+        # all three returned pairs are eigenpairs inside the contour, identical across the three variants
+        assert np.allclose(np.sort(l.real), [-0.21424660, 0.14278532, 0.52044939], atol=1e-7)
+
+
 def test_beyn_dep0():
     # test/beyn.jl:15-46
     nep = gallery.dep0()
