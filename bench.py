@@ -19,6 +19,8 @@ The JSON line also carries
 import argparse
 import json
 import os
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):   # small host BLAS only; big pools stall the launch thread
+    os.environ.setdefault(_v, "8")
 import sys
 import time
 

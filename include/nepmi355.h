@@ -99,6 +99,10 @@ int32_t nep_mlincomb_dev(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t 
  * what nep_gemm_ts(..., y_rowmajor=1) produces.  hF: mt x k column-major host.  Synchronous. */
 int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT,
                         int64_t ldq, double* h_rnorm, double* h_qnorm, nep_stream stream);
+/* asynchronous variant: no host synchronisation, SQUARED norms stay on the device.  d_out (2k doubles), per panel of
+ * kk <= 256 columns starting at column j0: d_out[2*j0 + j] = ||M(lam_j) q_j||^2, d_out[2*j0 + kk + j] = ||q_j||^2. */
+int32_t nep_resid_batch_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
+                            double* d_out, nep_stream stream);
 
 /* same residuals, but the block R^T (row-major, row stride ldr >= k) is written instead of its norms --
  * for NEPs with an extra non-SPMF term (the WEP corner, src/gallery_extra/waveguide/Waveguide.jl:351-374)
@@ -123,6 +127,12 @@ int32_t nep_spmm_terms(nep_spmf* s, int32_t p, const nep_cdouble* dXT, int64_t l
 int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
                  const int64_t* h_active_rows, nep_cdouble* dw, nep_cdouble* h_h, double* h_beta,
                  int32_t method, int32_t* h_npasses, nep_stream stream);
+/* asynchronous DGKS (method 0) / CGS (method 1): no host synchronisation.  The re-orthogonalisation passes are
+ * always enqueued and gate themselves on the device with the same criterion (at most 3 passes); w is normalised on the
+ * device.  d_active_rows: DEVICE array (or NULL).  d_out (k+2 complex, device): h[0..k), (beta, 0),
+ * (passes, 2*breakdown + another_pass_wanted). */
+int32_t nep_orth_dev(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, const int64_t* d_active_rows,
+                     nep_cdouble* dw, nep_cdouble* d_out, int32_t method, nep_stream stream);
 
 /* ---- K7 tall-skinny GEMM on the FP64 matrix cores --------------------------------------
  * Y = Z * B,  Z: rows x k (ldz, device), B: k x p (host, column-major, ldb), Y: rows x p.

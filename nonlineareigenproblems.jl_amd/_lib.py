@@ -60,9 +60,11 @@ SIGNATURES = {
     "nep_mlincomb": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp],
     "nep_mlincomb_dev": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "nep_resid_batch": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp],
+    "nep_resid_batch_dev": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp],
     "nep_resid_block": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp],
     "nep_spmm_terms": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp],
     "nep_orth": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, P(c_dbl), c_i32, P(c_i32), c_vp],
+    "nep_orth_dev": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp],
     "nep_gemm_ts": [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp],
     "nep_gemm_ts_dev": [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp],
     "nep_lu_create": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, P(c_vp)],
@@ -114,9 +116,25 @@ def device_count():
     return n.value
 
 
+_pinned = [False]
+
+
 def require_gpu():
     if device_count() < 1:
         raise NepError(NEP_ERR_HIP, "no HIP device visible: the MI355X backend has no CPU fallback")
+    if not _pinned[0]:
+        _pinned[0] = True
+        from . import _affinity          # host side of this rank -> CPUs of the GPU's NUMA node (NEP_NO_PIN=1 disables)
+        try:
+            _affinity.pin_to_gpu_numa(torch.cuda.current_device())
+        except Exception:
+            pass
+        import sys
+        pkg = os.path.dirname(os.path.abspath(__file__))
+        if pkg not in sys.path:
+            sys.path.insert(0, pkg)
+        import _nep_hostlu               # big BLAS thread pools make the host side stall at random (see there)
+        _nep_hostlu.cap_blas_threads()
 
 
 def as_c128(a, order="F"):

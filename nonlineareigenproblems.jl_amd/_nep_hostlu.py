@@ -23,6 +23,36 @@ def blas_controller():
     return _CTL[0]
 
 
+_CAP = [None]
+
+
+def cap_blas_threads(nmax=8):
+    """Permanently caps the BLAS thread pools of this process at `nmax` threads (NEP_BLAS_THREADS overrides, 0 = leave
+    alone).  Measured on a 2 x 64-core host: with the default 64-128 thread OpenBLAS pools, every change of the
+    thread count (threadpoolctl around SuperLU / the k x k LAPACK calls) and every large allocation stalls the
+    launching thread for 50-100 ms at random places (splu 22 -> 99 ms, CSR conversion 5 -> 70 ms); with <= 8 threads
+    the same code is stable at 26-28 ms.  All host BLAS in this backend is small (k <= a few hundred)."""
+    import os
+    if _CAP[0] is not None:
+        return
+    try:
+        nmax = int(os.environ.get("NEP_BLAS_THREADS", nmax))
+    except ValueError:
+        pass
+    _CAP[0] = False
+    if nmax <= 0:
+        return
+    ctl = blas_controller()
+    if ctl is None:
+        return
+    try:
+        cur = max([lib.num_threads for lib in ctl.lib_controllers if lib.user_api == "blas"] + [0])
+        if cur > nmax:
+            _CAP[0] = ctl.limit(limits=nmax, user_api="blas")     # kept alive: never restored
+    except Exception:
+        pass
+
+
 def ping(i):
     time.sleep(0.02)      # keeps the first tasks from all landing on one worker while the others still start
     return i

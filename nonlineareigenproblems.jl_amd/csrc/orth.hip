@@ -8,6 +8,7 @@
 // kernels skip the structurally zero part of V, halving the traffic of iar's orthogonalisation.
 #include "common.h"
 #include <vector>
+#include <algorithm>
 #include <math.h>
 
 #define DOT_RPT 4
@@ -16,8 +17,10 @@
 
 __global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, int64_t ldv, int64_t rows,
                                                    int k, const int64_t* __restrict__ active,
-                                                   const cplx* __restrict__ w, cplx* __restrict__ partial) {
+                                                   const cplx* __restrict__ w, cplx* __restrict__ partial,
+                                                   const int* __restrict__ gate = nullptr) {
     __shared__ cplx sm[DOT_CG][4];
+    if (gate && *gate == 0) return;          // device-side DGKS decision: this pass is not needed
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * DOT_RB;
     cplx wr[DOT_RPT];
@@ -58,15 +61,21 @@ __global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, i
 
 // h[j] = sum_b partial[b*k + j]; one block per column, fixed summation tree -> deterministic
 __global__ __launch_bounds__(256) void k_orth_reduce_h(int nb, int k, const cplx* __restrict__ partial,
-                                                       cplx* __restrict__ h) {
+                                                       cplx* __restrict__ h, const int* __restrict__ gate = nullptr,
+                                                       cplx* __restrict__ hacc = nullptr, int first = 1) {
     __shared__ cplx sm[4];
+    if (gate && *gate == 0) return;
     const int j = blockIdx.x;
     cplx acc = cmake(0.0, 0.0);
     for (int b = threadIdx.x; b < nb; b += 256) acc = cadd(acc, partial[(int64_t)b * k + j]);
     acc = group_reduce_sum<64>(acc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) h[j] = cadd(cadd(sm[0], sm[1]), cadd(sm[2], sm[3]));
+    if (threadIdx.x == 0) {
+        const cplx c = cadd(cadd(sm[0], sm[1]), cadd(sm[2], sm[3]));
+        h[j] = c;
+        if (hacc) hacc[j] = first ? c : cadd(hacc[j], c);     // accumulated projection coefficients (device path)
+    }
 }
 
 __global__ __launch_bounds__(1024) void k_orth_reduce_n(int nb, const double* __restrict__ partial,
@@ -88,8 +97,10 @@ __global__ __launch_bounds__(1024) void k_orth_reduce_n(int nb, const double* __
 __global__ __launch_bounds__(512) void k_orth_update(const cplx* __restrict__ V, int64_t ldv, int64_t rows,
                                                      int k, const int64_t* __restrict__ active,
                                                      const cplx* __restrict__ h, cplx* __restrict__ w,
-                                                     double* __restrict__ partial) {
+                                                     double* __restrict__ partial,
+                                                     const int* __restrict__ gate = nullptr) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    if (gate && *gate == 0) return;
     cplx* hs = (cplx*)smem_raw;         // k
     cplx* sm = hs + k;                  // [8][64]
     const int lane = threadIdx.x & 63;
@@ -121,6 +132,43 @@ __global__ __launch_bounds__(512) void k_orth_update(const cplx* __restrict__ V,
         nn = wave_reduce_sum(nn);
         if (lane == 0) partial[blockIdx.x] = nn;
     }
+}
+
+
+// device-side end of a pass: ||w||^2 from the update partials, ||c||^2 of this pass' coefficients, DGKS criterion.
+// state: [0] = gate of the NEXT pass (1 = run), [1] = passes done, [2] = breakdown flag.  out[k] = (beta, 0).
+__global__ __launch_bounds__(1024) void k_orth_decide(int nb, const double* __restrict__ partial, int k,
+                                                      const cplx* __restrict__ c, int method, int* __restrict__ state,
+                                                      const int* __restrict__ gate, cplx* __restrict__ out_beta) {
+    __shared__ double sm[16], sp[16];
+    if (gate && *gate == 0) { if (threadIdx.x == 0) state[0] = 0; return; }
+    double acc = 0.0, pj = 0.0;
+    for (int b = threadIdx.x; b < nb; b += 1024) acc += partial[b];
+    for (int j = threadIdx.x; j < k; j += 1024) pj += c[j].x * c[j].x + c[j].y * c[j].y;
+    acc = wave_reduce_sum(acc); pj = wave_reduce_sum(pj);
+    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = acc; sp[threadIdx.x >> 6] = pj; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0, p2 = 0.0;
+        for (int q = 0; q < 16; ++q) { t += sm[q]; p2 += sp[q]; }
+        const double nrm = sqrt(t);
+        out_beta[0] = cmake(nrm, 0.0);
+        state[1] += 1;
+        state[0] = (method == 0 && nrm < 0.70710678118654752440 * sqrt(p2)) ? 1 : 0;
+        if (!(nrm > 0.0) || !isfinite(nrm)) state[2] = 1;
+    }
+}
+
+// w /= beta (beta on the device); records passes / flags behind beta: out[k+1] = (passes, 2*breakdown + more_needed)
+__global__ __launch_bounds__(256) void k_orth_finish(int64_t rows, cplx* __restrict__ w, cplx* __restrict__ out_beta,
+                                                     const int* __restrict__ state) {
+    const double beta = out_beta[0].x;
+    const double inv = (beta > 0.0 && isfinite(beta)) ? 1.0 / beta : 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
+        cplx v = w[i];
+        w[i] = cmake(v.x * inv, v.y * inv);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_beta[1] = cmake((double)state[1], (double)(2 * state[2] + state[0]));
 }
 
 static thread_local NepScratch g_orth_scratch;
@@ -214,4 +262,56 @@ extern "C" int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, in
     }
     nep_cdouble inv; inv.re = 1.0 / nrm; inv.im = 0.0;
     return nep_scal(rows, inv, dw, stream);
+}
+
+// Fully asynchronous DGKS/CGS: no host synchronisation.  The re-orthogonalisation passes are always enqueued and
+// switch themselves off through a device flag (criterion ||w|| < ||c||/sqrt(2) evaluated by k_orth_decide), at most
+// NEP_ORTH_DEV_PASSES passes.  d_out (k+2 complex, device): h[0..k), (beta,0), (passes, 2*breakdown + more_needed).
+#define NEP_ORTH_DEV_PASSES 3
+extern "C" int32_t nep_orth_dev(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
+                                const int64_t* d_active_rows, nep_cdouble* dw, nep_cdouble* d_out, int32_t method,
+                                nep_stream stream) {
+    ARGCHK(dV && dw && d_out);
+    ARGCHK(rows > 0 && k >= 1 && ldv >= rows);
+    ARGCHK(method == 0 || method == 1);
+    hipStream_t st = as_stream(stream);
+    const int nchunks = (int)((rows + DOT_RB - 1) / DOT_RB);
+    const int nblk = (int)((rows + 63) / 64);
+    // scratch: [state 4 int][partial_h nchunks*k cplx][c k cplx][partial_n nblk dbl]
+    size_t off_ph = 16;
+    size_t off_c = off_ph + (size_t)nchunks * k * sizeof(cplx);
+    size_t off_pn = off_c + (size_t)k * sizeof(cplx);
+    size_t total = off_pn + (size_t)nblk * sizeof(double);
+    int rc = g_orth_scratch.ensure(total);
+    if (rc) return rc;
+    char* base = (char*)g_orth_scratch.dptr;
+    int* d_state = (int*)base;
+    cplx* d_ph = (cplx*)(base + off_ph);
+    cplx* d_c = (cplx*)(base + off_c);
+    double* d_pn = (double*)(base + off_pn);
+    const cplx* V = (const cplx*)dV;
+    cplx* w = (cplx*)dw;
+    cplx* out = (cplx*)d_out;
+    const size_t shm_upd = (size_t)(k + 8 * 64) * sizeof(cplx);
+    HIPCHK(hipMemsetAsync(d_state, 0, 16, st));
+    const int npass = method == 1 ? 1 : NEP_ORTH_DEV_PASSES;
+    for (int p = 0; p < npass; ++p) {
+        const int* gate = p == 0 ? nullptr : d_state;
+        hipLaunchKernelGGL(k_orth_dots, dim3(nchunks, (k + DOT_CG - 1) / DOT_CG), dim3(256), 0, st, V, ldv, rows, (int)k,
+                           d_active_rows, (const cplx*)w, d_ph, gate);
+        LAUNCHCHK();
+        hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_c, gate, out,
+                           p == 0 ? 1 : 0);
+        LAUNCHCHK();
+        hipLaunchKernelGGL(k_orth_update, dim3(nblk), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
+                           (const cplx*)d_c, w, d_pn, gate);
+        LAUNCHCHK();
+        hipLaunchKernelGGL(k_orth_decide, dim3(1), dim3(1024), 0, st, nblk, (const double*)d_pn, (int)k, (const cplx*)d_c,
+                           (int)method, d_state, gate, out + k);
+        LAUNCHCHK();
+    }
+    const int g = (int)std::min<int64_t>((rows + 255) / 256, 2048);
+    hipLaunchKernelGGL(k_orth_finish, dim3(g), dim3(256), 0, st, rows, w, out + k, (const int*)d_state);
+    LAUNCHCHK();
+    return NEP_OK;
 }

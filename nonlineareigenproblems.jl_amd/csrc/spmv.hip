@@ -661,11 +661,9 @@ int32_t nep_cw_backward_error(nep_spmf* s, const double* h_cabs, const nep_cdoub
     return NEP_OK;
 }
 
-int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
-                        double* h_rnorm, double* h_qnorm, nep_stream stream) {
-    ARGCHK(s && hF && dQT && h_rnorm && h_qnorm);
-    ARGCHK(k >= 1 && ldq >= k);
-    hipStream_t st = as_stream(stream);
+// shared body: d_out != NULL -> squared norms stay on the device (no synchronisation); else host results
+static int resid_panels(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
+                        double* d_out, double* h_rnorm, double* h_qnorm, hipStream_t st) {
     // panels of at most 256 Ritz vectors per pass over the matrix
     for (int32_t j0 = 0; j0 < k; j0 += 256) {
         const int32_t kk = std::min(256, k - j0);
@@ -678,7 +676,7 @@ int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
         rc = s->part.ensure(((size_t)grid * 2 * kk + 2 * kk) * sizeof(double));
         if (rc) return rc;
         double* partial = (double*)s->part.dptr;
-        double* outd = partial + (size_t)grid * 2 * kk;
+        double* outd = d_out ? d_out + 2 * (size_t)j0 : partial + (size_t)grid * 2 * kk;
         const cplx* Q = (const cplx*)dQT + j0;
         if (s->valbytes == 8)
             rc = launch_spmm<double>(s, kk, (const cplx*)s->coef.dptr, Q, ldq, 0, nullptr, 0, partial, grid, st);
@@ -687,12 +685,28 @@ int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
         if (rc) return rc;
         hipLaunchKernelGGL(k_sum_partials_d, dim3(2 * kk), dim3(256), 0, st, grid, 2 * kk, partial, outd);
         LAUNCHCHK();
-        std::vector<double> h(2 * kk);
-        HIPCHK(hipMemcpyAsync(h.data(), outd, (size_t)2 * kk * sizeof(double), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        for (int j = 0; j < kk; ++j) { h_rnorm[j0 + j] = sqrt(h[j]); h_qnorm[j0 + j] = sqrt(h[kk + j]); }
+        if (!d_out) {
+            std::vector<double> h(2 * kk);
+            HIPCHK(hipMemcpyAsync(h.data(), outd, (size_t)2 * kk * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (int j = 0; j < kk; ++j) { h_rnorm[j0 + j] = sqrt(h[j]); h_qnorm[j0 + j] = sqrt(h[kk + j]); }
+        }
     }
     return NEP_OK;
+}
+
+int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
+                        double* h_rnorm, double* h_qnorm, nep_stream stream) {
+    ARGCHK(s && hF && dQT && h_rnorm && h_qnorm);
+    ARGCHK(k >= 1 && ldq >= k);
+    return resid_panels(s, k, hF, dQT, ldq, nullptr, h_rnorm, h_qnorm, as_stream(stream));
+}
+
+int32_t nep_resid_batch_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
+                            double* d_out, nep_stream stream) {
+    ARGCHK(s && hF && dQT && d_out);
+    ARGCHK(k >= 1 && ldq >= k);
+    return resid_panels(s, k, hF, dQT, ldq, d_out, nullptr, nullptr, as_stream(stream));
 }
 
 int32_t nep_resid_block(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,

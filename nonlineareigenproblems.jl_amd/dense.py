@@ -70,6 +70,17 @@ def orthogonalize_and_normalize(V, w, k, rows=None, ldv=None, active_rows=None, 
     return h, beta.value, npass.value
 
 
+def orthogonalize_and_normalize_dev(V, w, k, out, rows=None, ldv=None, active_dev=None, method=DGKS):
+    """asynchronous variant (nep_orth_dev): nothing is read back.  `out` (device, >= k+2 complex) receives h[0..k),
+    (beta,0), (passes, 2*breakdown + another_pass_wanted); `active_dev` is a DEVICE int64 tensor or None."""
+    if rows is None:
+        rows = w.numel()
+    if ldv is None:
+        ldv = V.shape[-1]
+    check(lib.nep_orth_dev(c_vp(V.data_ptr()), ldv, rows, k, c_vp(active_dev.data_ptr()) if active_dev is not None else None,
+                           c_vp(w.data_ptr()), c_vp(out.data_ptr()), _orth_code(method), stream_ptr()))
+
+
 def nrm2(x, length=None):
     out = c_dbl(0.0)
     check(lib.nep_nrm2(length if length is not None else x.numel(), c_vp(x.data_ptr()), C.byref(out), stream_ptr()))

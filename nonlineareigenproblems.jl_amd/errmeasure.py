@@ -15,6 +15,21 @@ class Errmeasure:
     pass
 
 
+class _PendingErrs:
+    """errors of an asynchronous residual batch (see AbstractSPMF.resid_norms_async)"""
+
+    def __init__(self, pending, fn, value=None):
+        self.pending, self.fn, self.value = pending, fn, value
+
+    def ready(self):
+        return self.value is not None or self.pending.ready()
+
+    def get(self):
+        if self.value is None:
+            self.value = self.fn(*self.pending.get())
+        return self.value
+
+
 def _batch_norms(nep, lams, QT):
     """QT: device (rows, k) row-major block of the k vectors. Returns ((||M(lam_s) q_s||, ||q_s||), F)."""
     rn, qn, F = nep.resid_norms(lams, QT)
@@ -41,6 +56,10 @@ class ResidualErrmeasure(Errmeasure):
         (rn, qn), _ = _batch_norms(self.nep, lams, QT)
         return rn / qn
 
+    def batch_async(self, lams, QT):
+        p = self.nep.resid_norms_async(lams, QT)
+        return _PendingErrs(p, lambda rn, qn, F: rn / qn)
+
 
 class StandardSPMFErrmeasure(Errmeasure):
     """backward error ||M(lam)v|| / (||v|| sum_i ||A_i||_F |f_i(lam)|)   (errmeasure.jl:174-190)"""
@@ -56,6 +75,10 @@ class StandardSPMFErrmeasure(Errmeasure):
         denom = self.coeffs @ np.abs(F)
         return rn / (qn * denom)
 
+    def batch_async(self, lams, QT):
+        p = self.nep.resid_norms_async(lams, QT)
+        return _PendingErrs(p, lambda rn, qn, F: rn / (qn * (self.coeffs @ np.abs(F))))
+
 
 class DefaultErrmeasure(Errmeasure):
     """errmeasure.jl:91-101"""
@@ -67,6 +90,9 @@ class DefaultErrmeasure(Errmeasure):
 
     def batch(self, lams, QT):
         return self.errm.batch(lams, QT)
+
+    def batch_async(self, lams, QT):
+        return self.errm.batch_async(lams, QT)
 
 
 def estimate_error(errm, lam, v):
@@ -82,3 +108,10 @@ def estimate_errors(errm, lams, QT):
         Q = QT.cpu().numpy()
         return np.array([errm(l, Q[:, s]) for s, l in enumerate(lams)])
     return errm.batch(list(lams), QT)
+
+
+def estimate_errors_async(errm, lams, QT):
+    """like estimate_errors, but only enqueues the device work; returns an object with ready() / get()"""
+    if isinstance(errm, Errmeasure) and hasattr(errm, "batch_async") and hasattr(getattr(errm, "nep", getattr(getattr(errm, "errm", None), "nep", None)), "resid_norms_async"):
+        return errm.batch_async(list(lams), QT)
+    return _PendingErrs(None, None, value=estimate_errors(errm, lams, QT))

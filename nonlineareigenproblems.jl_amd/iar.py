@@ -15,6 +15,7 @@ Reference step (method_iar.jl:94-164)            device realisation
   Q=VV[1:n,:]*Z                                   K7 nep_gemm_ts -> row-major Q^T
   err[k,s]=estimate_error(...) for s=1:k          K2 nep_resid_batch (one pass for all k pairs)
 """
+import os
 import time
 
 import numpy as np
@@ -22,8 +23,8 @@ import scipy.linalg as sla
 import torch
 
 from . import dense, _hosteig
-from ._lib import lib, check, c_vp
-from .errmeasure import DefaultErrmeasure, estimate_errors
+from ._lib import lib, check, c_vp, NepError, NEP_ERR_BREAKDOWN
+from .errmeasure import DefaultErrmeasure, estimate_errors, estimate_errors_async
 from .exceptions import NoConvergenceException
 from .linsolvers import DefaultLinSolverCreator, create_linsolver, lin_solve
 from .nep import CDT, to_dev, to_host, stream_ptr
@@ -51,7 +52,7 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
 
     # initialization (method_iar.jl:76-86)
     ldv = n * (m + 1)
-    V = torch.zeros((m + 1, ldv), dtype=CDT, device="cuda")
+    V = torch.zeros((m + 1, ldv), dtype=CDT, device="cuda")     # the fill overlaps with the host factorisation below
     H = np.zeros((m + 1, m), dtype=np.complex128)
     alpha = gamma ** np.arange(m + 1); alpha[0] = 0
     t_ls = time.perf_counter()
@@ -66,6 +67,19 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     tab = nep.derivative_table(sigma, m, rowscale=alpha[1:m + 1] / np.arange(1, m + 1))
     z = torch.empty(n, dtype=CDT, device="cuda")
     active = (np.arange(1, m + 2) * n).astype(np.int64)   # column j has (j+1) non-zero blocks
+    # Asynchronous pipeline (default): nothing on the Arnoldi critical path waits for the device.  The DGKS decision
+    # is taken on the device (nep_orth_dev), H's new column travels to pinned host memory behind an event that the eigen
+    # worker waits for, the residual norms of the Ritz pairs come back the same way (nep_resid_batch_dev) -- the host
+    # enqueues step k+1.. while the device is still executing step k.  `timers` (instrumented run), MGS and
+    # NEP_IAR_SYNC=1 use the step-synchronous loop; both produce the same iterates.
+    use_async = timers is None and dense._orth_code(orthmethod) in (0, 1) and not os.environ.get("NEP_IAR_SYNC")
+    if use_async:
+        active_d = torch.from_numpy(active).to("cuda")
+        Hdev = torch.zeros((m, m + 2), dtype=CDT, device="cuda")
+        Hpin = torch.zeros((m, m + 2), dtype=CDT).pin_memory()
+        Hnp = Hpin.numpy()
+        evs = [None] * (m + 1)
+        filled = [False] * (m + 1)
     err = np.full((m, m), np.nan)
     lam = np.zeros(0, dtype=np.complex128); QT = None; idx = np.zeros(0, dtype=int)
     # ---- main loop.  The small dense eigenproblem of step k (host LAPACK, method_iar.jl:112; 7.5 ms at
@@ -91,6 +105,13 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
         sync(); t2 = time.perf_counter()
         check(lib.nep_iar_shift_scale(n, k, c_vp(V.data_ptr() + 16 * (k - 1) * ldv),
                                       c_vp(vv.data_ptr()), stream_ptr()))
+        if use_async:
+            dense.orthogonalize_and_normalize_dev(V, vv, k, Hdev[k - 1], rows=n * (k + 1), ldv=ldv, active_dev=active_d,
+                                                  method=orthmethod)
+            Hpin[k - 1, :k + 2].copy_(Hdev[k - 1, :k + 2], non_blocking=True)
+            evs[k] = torch.cuda.Event()
+            evs[k].record()
+            return
         h, beta, _ = dense.orthogonalize_and_normalize(V, vv, k, rows=n * (k + 1), ldv=ldv,
                                                        active_rows=active, method=orthmethod)
         H[:k, k - 1] = h; H[k, k - 1] = beta
@@ -101,6 +122,22 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
         t = time.perf_counter()
         r = _hosteig.eig(Hk)       # zgeev through ctypes: runs without the GIL (numpy/scipy hold it)
         return r, time.perf_counter() - t
+
+    def fill_H(kk):
+        """columns 1..kk of H from the pinned buffer (their copies are complete once evs[kk] is)"""
+        for j in range(1, kk + 1):
+            if not filled[j]:
+                row = Hnp[j - 1]
+                if int(row[j + 1].imag) & 2:
+                    raise NepError(NEP_ERR_BREAKDOWN, "orthogonalisation breakdown in step %d: ||w|| = %g" % (j, row[j].real))
+                H[:j, j - 1] = row[:j]
+                H[j, j - 1] = row[j].real
+                filled[j] = True
+
+    def timed_eig_async(kk):
+        evs[kk].synchronize()          # releases the GIL; H's columns <= kk are in pinned memory afterwards
+        fill_H(kk)
+        return timed_eig(H[:kk, :kk].copy())
 
     def finish_check(kc, fut):
         (D, Z), t_eig = fut.result()
@@ -124,6 +161,26 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
             idxl = idxl[:nrof]
         state.update(lam=laml, QT=QTl, idx=idxl, conv_eig=conv, k_checked=kc)
 
+    def launch_check(kc, fut):
+        """eigen-decomposition of step kc is available: enqueue Ritz block (K7) + residual batch (K2), no waiting"""
+        (D, Z), t_eig = fut.result()
+        QTl = dense.gemm_ts(V, Z, rowmajor=True, k=kc, rows=n, ldz=ldv)
+        laml = sigma + gamma / D
+        return kc, laml, QTl, estimate_errors_async(errmeasure, laml, QTl)
+
+    def consume_check(kc, laml, QTl, perr):
+        e = perr.get()
+        conv = int(np.sum(e < tol))
+        idxl = np.argsort(e, kind="stable")
+        err[kc - 1, :kc] = e[idxl]
+        if errhist is not None:
+            errhist.append(err[kc - 1, :kc].copy())
+        if kc == m or conv >= neigs:
+            nrof = int(min(len(laml), neigs))
+            laml = laml[idxl[:nrof]]
+            idxl = idxl[:nrof]
+        state.update(lam=laml, QT=QTl, idx=idxl, conv_eig=conv, k_checked=kc)
+
     k = 1
     pending = deque()              # (k, future) in increasing k; checks are always consumed in order
     # the k x k eigenproblems gain nothing from a threaded BLAS (7.5 ms at k=100 with 1 or 64 threads) while its
@@ -134,16 +191,35 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     if blas_guard is not None:
         blas_guard.__enter__()
     try:
-        while k <= m and state["conv_eig"] < neigs:
-            arnoldi_step(k)
-            if (k % check_error_every == 0) or (k == m):
-                pending.append((k, pool.submit(timed_eig, H[:k, :k].copy())))
-            # consume finished eigen-decompositions; never let the check lag more than LAG steps
-            while pending and state["conv_eig"] < neigs and (len(pending) > LAG or pending[0][1].done()):
+        if use_async:
+            pend_err = deque()         # checks whose device work is enqueued, in increasing k
+            while k <= m and state["conv_eig"] < neigs:
+                arnoldi_step(k)
+                if (k % check_error_every == 0) or (k == m):
+                    pending.append((k, pool.submit(timed_eig_async, k)))
+                # waiting for the oldest decomposition when more than LAG are in flight is what bounds how far the
+                # host runs ahead of the device
+                while pending and (len(pending) > LAG or pending[0][1].done()):
+                    pend_err.append(launch_check(*pending.popleft()))
+                while pend_err and state["conv_eig"] < neigs and (len(pend_err) > LAG or pend_err[0][3].ready()):
+                    consume_check(*pend_err.popleft())
+                k += 1
+            while (pending or pend_err) and state["conv_eig"] < neigs:
+                if pend_err:
+                    consume_check(*pend_err.popleft())
+                else:
+                    pend_err.append(launch_check(*pending.popleft()))
+        else:
+            while k <= m and state["conv_eig"] < neigs:
+                arnoldi_step(k)
+                if (k % check_error_every == 0) or (k == m):
+                    pending.append((k, pool.submit(timed_eig, H[:k, :k].copy())))
+                # consume finished eigen-decompositions; never let the check lag more than LAG steps
+                while pending and state["conv_eig"] < neigs and (len(pending) > LAG or pending[0][1].done()):
+                    finish_check(*pending.popleft())
+                k += 1
+            while pending and state["conv_eig"] < neigs:
                 finish_check(*pending.popleft())
-            k += 1
-        while pending and state["conv_eig"] < neigs:
-            finish_check(*pending.popleft())
     finally:
         for _, f in pending:
             f.cancel()

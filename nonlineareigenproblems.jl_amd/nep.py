@@ -133,9 +133,39 @@ class SPMFDevice:
         check(lib.nep_resid_batch(self.h, k, hptr(Fm), c_vp(QT.data_ptr()), ldq, hptr(rn), hptr(qn), stream_ptr()))
         return rn, qn
 
+    def resid_batch_dev(self, F, QT, k, ldq, out_dev):
+        """asynchronous K2: squared norms into the device tensor out_dev (2k float64), layout of nep_resid_batch_dev"""
+        Fm = _lib.as_c128(F, "F")
+        assert Fm.shape == (self.mt, k)
+        check(lib.nep_resid_batch_dev(self.h, k, hptr(Fm), c_vp(QT.data_ptr()), ldq, c_vp(out_dev.data_ptr()), stream_ptr()))
+
     def algorithmic_bytes(self, k):
         """matrix bytes + 16 n k (read V) + 16 n (write z)."""
         return self.matrix_bytes + 16 * self.n * k + 16 * self.n
+
+
+class PendingNorms:
+    """result of an asynchronous residual batch: ready() polls the event, get() waits and unpacks"""
+
+    def __init__(self, pin=None, ev=None, k=0, F=None, keep=None, result=None):
+        self.pin, self.ev, self.k, self.F, self.keep, self.result = pin, ev, k, F, keep, result
+
+    def ready(self):
+        return self.result is not None or self.ev.query()
+
+    def get(self):
+        if self.result is None:
+            self.ev.synchronize()
+            sq = self.pin.numpy()
+            k = self.k
+            rn = np.empty(k); qn = np.empty(k)
+            for j0 in range(0, k, 256):
+                kk = min(256, k - j0)
+                rn[j0:j0 + kk] = np.sqrt(sq[2 * j0:2 * j0 + kk])
+                qn[j0:j0 + kk] = np.sqrt(sq[2 * j0 + kk:2 * j0 + 2 * kk])
+            self.result = (rn, qn, self.F)
+            self.keep = None
+        return self.result
 
 
 # ----------------------------------------------------------------------------------------------
@@ -254,6 +284,25 @@ class AbstractSPMF(NEP):
             F[i, :] = f.values(la)
         rn, qn = self.dev.resid_batch(F, QT, len(la), QT.shape[1])
         return rn, qn, F
+
+    def resid_norms_async(self, lams, QT):
+        """enqueues K2 and the device->pinned-host copy of the squared norms; returns a PendingNorms whose get() gives
+        (rn, qn, F) like resid_norms.  Only for pure SPMF operators (subclasses with extra terms fall back to sync)."""
+        if type(self).resid_norms is not AbstractSPMF.resid_norms:
+            return PendingNorms(result=self.resid_norms(lams, QT))
+        fv = self.get_fv()
+        la = np.asarray(lams, dtype=np.complex128)
+        k = len(la)
+        F = np.empty((len(fv), k), dtype=np.complex128, order="F")
+        for i, f in enumerate(fv):
+            F[i, :] = f.values(la)
+        out = torch.empty(2 * k, dtype=torch.float64, device="cuda")
+        self.dev.resid_batch_dev(F, QT, k, QT.shape[1], out)
+        pin = torch.empty(2 * k, dtype=torch.float64, pin_memory=True)
+        pin.copy_(out, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return PendingNorms(pin=pin, ev=ev, k=k, F=F, keep=(out, QT))
 
     def fro_norms(self):
         if self._fro is None:

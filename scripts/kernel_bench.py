@@ -10,6 +10,8 @@ achieved GB/s or TFLOP/s and the fraction of the MI355X peak (HBM 8 TB/s, FP64 M
 import argparse
 import json
 import os
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):   # small host BLAS only; big pools stall the launch thread
+    os.environ.setdefault(_v, "8")
 import sys
 import time
 

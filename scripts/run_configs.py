@@ -6,6 +6,8 @@ residuals, wall times and parity against the oracle.  Usage:  python scripts/run
 import argparse
 import json
 import os
+for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):   # small host BLAS only; big pools stall the launch thread
+    os.environ.setdefault(_v, "8")
 import sys
 import time
 
