@@ -87,26 +87,69 @@ class _NodeSolve:
     node needs a NEW host factorisation; `prefetch` starts all factorisations of this rank's nodes in worker processes
     so that they run concurrently with each other and with the device solves of the nodes already factored."""
 
+    BUILDERS = 4          # threads turning host factors into device schedules (nep_lu_create releases the GIL)
+    AHEAD = 8             # device factorisations built (or being built) ahead of the node being solved
+
     def __init__(self, nep, linsolvercreator, sigma, g, Vd, weight):
         self.nep, self.creator, self.sigma, self.g, self.Vd, self.weight = nep, linsolvercreator, sigma, g, Vd, weight
-        self.futs = {}
+        self.host = {}        # t -> future of the host factorisation (worker process)
+        self.built = {}       # t -> future of the DeviceLU (builder thread)
+        self.order = []
+        self.next = 0
+        self.pool = None
+
+    def _build(self, host_future, dev):
+        # host factors -> level analysis, upload, tail inverse (6 ms for gun): off the main thread, which only issues the
+        # block solves and the moment updates
+        torch.cuda.set_device(dev)
+        try:
+            F = host_future.result()
+        except RuntimeError as e:
+            raise np.linalg.LinAlgError("SingularException: " + str(e))
+        return DeviceLU(factors=F, expected_solves=1)
+
+    def _submit_builds(self):
+        # never more than AHEAD builds outstanding; submitted in node order by the consuming thread (no blocking
+        # primitives in the builders, so an exception in the consumer cannot leave a thread waiting)
+        dev = torch.cuda.current_device()
+        while self.next < len(self.order) and len(self.built) < self.AHEAD:
+            t = self.order[self.next]
+            self.built[t] = self.pool.submit(self._build, self.host.pop(t), dev)
+            self.next += 1
 
     def prefetch(self, ts):
         c = self.creator
         workers = getattr(c, "workers", None)
         if not isinstance(c, BackslashLinSolverCreator) or workers == 0 or len(ts) < 2:
             return
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=self.BUILDERS)
+        self.order = list(ts)
         for t in ts:
             A = self.nep.compute_Mder(self.g(t) + self.sigma)
-            self.futs[t] = HostLUPool.submit(A, permc_spec=c.permc_spec, **c.lu_kw)
+            self.host[t] = HostLUPool.submit(A, permc_spec=c.permc_spec, **c.lu_kw)
+        self._submit_builds()
+
+    def close(self):
+        if self.pool is not None:
+            for f in list(self.built.values()) + list(self.host.values()):
+                f.cancel()
+            self.pool.shutdown(wait=True)
+            self.pool = None
+            self.built.clear(); self.host.clear()
 
     def __call__(self, t):
-        if t in self.futs:
+        if t in self.built:
             try:
-                F = self.futs.pop(t).result()
-            except RuntimeError as e:
-                raise np.linalg.LinAlgError("SingularException: " + str(e))
-            return DeviceLU(factors=F, expected_solves=1).solve(self.Vd), self.weight(t)
+                lu = self.built.pop(t).result()
+                self._submit_builds()
+                X = lu.solve(self.Vd)
+            except BaseException:
+                self.close()
+                raise
+            if not self.built and self.next >= len(self.order):
+                self.close()
+            return X, self.weight(t)
         M0inv = create_linsolver(self.creator, self.nep, self.g(t) + self.sigma)
         return lin_solve(M0inv, self.Vd), self.weight(t)
 

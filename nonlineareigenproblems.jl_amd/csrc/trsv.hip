@@ -860,6 +860,10 @@ int32_t nep_lu_create(int64_t n, const int32_t* hLp, const int32_t* hLi, const n
     double tlast = now_ms();
     nep_lu* lu = new nep_lu();
     lu->n = n;
+    // a graph pays off from the second solve on; one-shot factorisations (BackslashLinSolver: Beyn builds them on
+    // worker threads while the main thread solves) launch eagerly -- stream capture in one thread makes synchronous
+    // HIP calls of the other threads fail on this runtime
+    lu->use_graph = g_expected_solves >= 3 ? 1 : 0;
     lu->nnzL_in = hLp[n]; lu->nnzU_in = hUp[n];
     int rc = lu_build(lu, n, hLp, hLi, hLx, hUp, hUi, hUx);
     TSTAMP("lu_build total");

@@ -55,16 +55,30 @@ class HostLUPool:
             saved = {k: os.environ.get(k) for k in keys}
             for k in keys:
                 os.environ[k] = "1"
+            # spawn re-imports the parent's __main__ in every child (multiprocessing.spawn.get_preparation_data); a user
+            # script without an `if __name__ == "__main__":` guard would run again inside each worker.  The workers only
+            # need _nep_hostlu (importable by name), so __main__ is hidden from the preparation data while they start.
+            main = sys.modules.get("__main__")
+            hidden = {}
+            for attr in ("__file__", "__spec__"):
+                if main is not None and getattr(main, attr, None) is not None:
+                    hidden[attr] = getattr(main, attr)
+                    try:
+                        setattr(main, attr, None)
+                    except Exception:
+                        hidden.pop(attr)
             try:
                 cls._pool = ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn"))
                 cls._workers = workers
                 list(cls._pool.map(_nep_hostlu.ping, range(4 * workers)))     # forces all workers to start now
             finally:
-                for k, v in saved.items():
-                    if v is None:
-                        os.environ.pop(k, None)
+                for attr, val in hidden.items():
+                    setattr(main, attr, val)
+                for k_, v_ in saved.items():
+                    if v_ is None:
+                        os.environ.pop(k_, None)
                     else:
-                        os.environ[k] = v
+                        os.environ[k_] = v_
         return cls._pool
 
     @classmethod
@@ -80,8 +94,10 @@ class HostLUPool:
 
     @classmethod
     def submit(cls, A, **kw):
+        """future of the factor METADATA; the arrays sit in a shared-memory block: DeviceLU(factors=meta) maps, uploads
+        and unlinks it (a result that is never consumed leaves its block to the resource tracker at exit)"""
         Ac = sp.csc_matrix(A, dtype=np.complex128)
-        return cls.get().submit(_nep_hostlu.factor, Ac.data, Ac.indices, Ac.indptr, Ac.shape, **kw)
+        return cls.get().submit(_nep_hostlu.factor_shm, Ac.data, Ac.indices, Ac.indptr, Ac.shape, **kw)
 
 
 import atexit  # noqa: E402
@@ -111,6 +127,9 @@ class DeviceLU:
             except RuntimeError as e:  # "Factor is exactly singular"
                 raise np.linalg.LinAlgError("SingularException: " + str(e))
         F = factors
+        shm_backed = "shm_name" in F
+        if shm_backed:
+            F = _nep_hostlu.attach_shm(F)
         n = int(F["n"])
         self.n = n
         self.normA = F["normA"]          # ||A||_F, used by the refinement stopping test
@@ -122,8 +141,13 @@ class DeviceLU:
         t_b = time.perf_counter()
         check(lib.nep_lu_set_expected_solves(int(expected_solves)))
         h = c_vp()
-        check(lib.nep_lu_create(n, hptr(Lp), hptr(Li), hptr(Lx), hptr(Up), hptr(Ui), hptr(Ux), hptr(pr), hptr(pc),
-                                C.byref(h)))
+        try:
+            check(lib.nep_lu_create(n, hptr(Lp), hptr(Li), hptr(Lx), hptr(Up), hptr(Ui), hptr(Ux), hptr(pr), hptr(pc),
+                                    C.byref(h)))
+        finally:
+            if shm_backed:
+                del Lp, Li, Lx, Up, Ui, Ux, pr, pc
+                _nep_hostlu.release_shm(F)
         self.h = h
         self.t_create = time.perf_counter() - t_b
         info = (c_i64 * 6)()
