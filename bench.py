@@ -87,27 +87,28 @@ def beyn_sharded(na, args, world, rank):
     nep.dev
     Vh = na.probe_block(nep.n, 32)
     na.HostLUPool.warm()
-    integ = na.MatrixTrapezoidalSharded if world > 1 else na.MatrixTrapezoidal
+    distd = dist.is_available() and dist.is_initialized()
+    integ = na.MatrixTrapezoidalSharded if distd else na.MatrixTrapezoidal
     kw = dict(sigma=250.0 ** 2, radius=1e4, N=64, k=32, neigs=10 ** 6, tol=1e-6, sanity_check=True, Vh=Vh)
     na.contour_beyn(nep, integ, **dict(kw, N=8 * world))          # warm-up (graph capture, allocator pools)
-    if world > 1:
+    if distd:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     info = {}
     lam, V = na.contour_beyn(nep, integ, info=info, **kw)
-    if world > 1:
+    if distd:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if distd:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     return {"workload": "contour_beyn gun SPMF n=%d N=64 k=32 radius=1e4 sigma=250^2 tol=1e-6" % nep.n,
             "eigenpairs": int(len(lam)), "seconds": dt, "eigenpairs_per_s": len(lam) / dt, "rank_p": int(info.get("p", -1)),
             "nodes_per_rank": int(info.get("nodes", 64)), "scaling": "strong",
-            "exchange": "one all_gather of 2*n*k complex128 per rank (%.1f MB)" % (2 * nep.n * 32 * 16 / 1e6) if world > 1 else "none"}
+            "exchange": "one all_gather of 2*n*k complex128 per rank (%.1f MB)" % (2 * nep.n * 32 * 16 / 1e6) if distd else "none"}
 
 
 def wep_scale_roofline(na):
@@ -186,9 +187,10 @@ def cpu_baseline(args):
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    use_dist = world > 1 or bool(os.environ.get("NEP_FORCE_DIST") and "RANK" in os.environ)   # forced: 1-rank RCCL smoke test
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
@@ -205,7 +207,7 @@ def main():
         one_step(na, nep, args)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -217,7 +219,7 @@ def main():
         pairs += len(lam)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt, float(pairs)], dtype=torch.float64, device="cuda")
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
@@ -290,7 +292,7 @@ def main():
             beyn = beyn_sharded(na, args, world, rank)
         except Exception as e:                       # never lose the headline line because of the extra
             beyn = {"error": repr(e)[:300]}
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
