@@ -79,6 +79,35 @@ def mlincomb_roofline(na, nep, k, reps=50):
     return byts, ms
 
 
+def orth_roofline(na, n, k, reps=10):
+    """K6 at the shape of iar step k (block-triangular basis, rows = n(k+1)): one classical Gram-Schmidt pass =
+    k_orth_dots + k_orth_update, the two kernels with the largest share of device time in the timed region
+    (profiles/r1_iar_kernel_stats_v4.csv).  Algorithmic bytes: SURVEY.md section 8d K6 restricted to the non-zero
+    blocks: 2*16*sum_j active_j + 3*16*rows.  Timed with HIP events around asynchronous nep_orth_dev launches."""
+    from nep_amd import dense
+    rows = n * (k + 1)
+    active = (np.arange(1, k + 1) * n).astype(np.int64)
+    V = torch.randn((k, rows), dtype=torch.float64, device="cuda").to(torch.complex128)
+    w0 = torch.randn(rows, dtype=torch.float64, device="cuda").to(torch.complex128)
+    w = w0.clone()
+    act_d = torch.from_numpy(active).to("cuda")
+    out = torch.zeros(k + 2, dtype=torch.complex128, device="cuda")
+    for _ in range(2):
+        dense.orthogonalize_and_normalize_dev(V, w, k, out, rows=rows, ldv=rows, active_dev=act_d, method=dense.CGS)
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        dense.orthogonalize_and_normalize_dev(V, w, k, out, rows=rows, ldv=rows, active_dev=act_d, method=dense.CGS)
+    ev1.record()
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    byts = 2 * 16 * int(active.sum()) + 3 * 16 * rows
+    return {"bound": "hbm", "kernel": "K6 nep_orth_dev, one Gram-Schmidt pass (k_orth_dots + k_orth_update + 3 small "
+            "kernels) at iar step k=%d: rows=%d, block-triangular basis" % (k, rows), "algorithmic_bytes": byts,
+            "ms_per_pass": ms, "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS}
+
+
 def beyn_sharded(na, args, world, rank):
     """config C4: contour_beyn on the unscaled gun SPMF, N=64 nodes sharded i = r (mod P) over the ranks, one RCCL
     all-gather of the 2 n k partial moment block.  Strong scaling (total work fixed).  Timed with barriers."""
@@ -278,6 +307,10 @@ def main():
             "kernels": {"note": "wall ms per phase of one instrumented iar run (torch.cuda.synchronize around each phase)",
                         **{k_: round(v * 1e3, 3) for k_, v in tm.items()}},
         }
+        try:
+            out["roofline_time_dominant"] = orth_roofline(na, nep.n, args.maxit)
+        except Exception as e:
+            out["roofline_time_dominant"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_wep_roofline:
             try:
                 out["roofline_wep_scale"] = wep_scale_roofline(na)
