@@ -239,9 +239,21 @@ class WEP(AbstractSPMF):
     def compute_Mder(self, lam, i=0):
         """explicit M^(i)(lam) (sparse with the dense corner) for the host factorisation.  The reference's WEP_FD has
         no compute_Mder (Waveguide.jl:384-386) and solves through a Schur complement; the SPMF format does."""
-        M = sp.lil_matrix(super().compute_Mder(lam, i), dtype=np.complex128)
-        M[self.N:, self.N:] = self.corner_matrix(lam, i)
-        return sp.csc_matrix(M)
+        # the SPMF part has no entries in the corner block (the three big matrices are zero there), so the dense
+        # 2nz x 2nz corner is simply added as a second sparse matrix (block-diagonal: two nz x nz blocks)
+        M = sp.csc_matrix(super().compute_Mder(lam, i), dtype=np.complex128)
+        nz, N, n = self.nz, self.N, self.n
+        Pm = self.corner_matrix(lam, i)
+        ii, jj = np.meshgrid(np.arange(nz), np.arange(nz), indexing="ij")
+        rows = np.concatenate([(N + ii).ravel(), (N + nz + ii).ravel()])
+        cols = np.concatenate([(N + jj).ravel(), (N + nz + jj).ravel()])
+        vals = np.concatenate([Pm[:nz, :nz].ravel(), Pm[nz:, nz:].ravel()])
+        Cn = sp.csc_matrix((vals, (rows, cols)), shape=(n, n))
+        corner_spmf = M[N:, N:]
+        if corner_spmf.nnz:
+            # general case: entries of the SPMF part inside the corner block are overwritten, as the assignment did
+            M = M - sp.bmat([[sp.csc_matrix((N, N)), None], [None, corner_spmf]], format="csc")
+        return sp.csc_matrix(M + Cn)
 
     def resid_norms(self, lams, QT):
         la = np.asarray(lams, dtype=np.complex128)
