@@ -167,20 +167,35 @@ __global__ __launch_bounds__(512) void k_levels_narrow(int lev_lo, int lev_hi, c
 }
 
 // ---- tail: x[i0:] = Sinv * tmp   (dense row-major GEMV, wave per row, HBM/L2-bound) --------------
+// RB right-hand sides share one pass over the matrix row (PMC: with one launch row per right-hand side the 32-column
+// block solve of Beyn re-read Sinv 32 times, 1.86 GB of HBM traffic for a 67 MB matrix)
+template <int RB>
 __global__ __launch_bounds__(256) void k_tail_gemv(int64_t T, int64_t i0, const cplx* __restrict__ Sinv,
                                                    const cplx* __restrict__ tmp, int64_t ldt, cplx* __restrict__ work,
-                                                   int64_t ldw) {
-    const cplx* t = tmp + (int64_t)blockIdx.y * ldt;
-    cplx* x = work + (int64_t)blockIdx.y * ldw;
+                                                   int64_t ldw, int nrhs) {
+    const int rhs0 = blockIdx.y * RB;
+    const int nb = min(RB, nrhs - rhs0);
+    const cplx* t = tmp + (int64_t)rhs0 * ldt;
+    cplx* x = work + (int64_t)rhs0 * ldw;
     const int lane = threadIdx.x & 63;
     const int64_t r = blockIdx.x * 4LL + (threadIdx.x >> 6);
     if (r >= T) return;
     const cplx* row = Sinv + r * T;
-    cplx acc = cmake(0.0, 0.0);
-#pragma unroll 4
-    for (int64_t c = lane; c < T; c += 64) cfma(acc, row[c], t[c]);
-    acc = group_reduce_sum<64>(acc);
-    if (lane == 0) x[i0 + r] = acc;
+    cplx acc[RB];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) acc[q] = cmake(0.0, 0.0);
+#pragma unroll 2
+    for (int64_t c = lane; c < T; c += 64) {
+        const cplx m = row[c];
+#pragma unroll
+        for (int q = 0; q < RB; ++q)
+            if (q < nb) cfma(acc[q], m, t[(int64_t)q * ldt + c]);
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+        const cplx a = group_reduce_sum<64>(acc[q]);
+        if (lane == 0 && q < nb) x[(int64_t)q * ldw + i0 + r] = a;
+    }
 }
 
 // ---- mid: tmp[B] = x[B] - (off-block part of rows B) * x   (WPR waves per row; WPR=16 -> 1024 threads) ------------
@@ -232,35 +247,48 @@ static void launch_mid_spmv(int wpr, int64_t r0, int nrows, int64_t h0, const in
         hipLaunchKernelGGL((k_mid_spmv<1>), dim3((nrows + 3) / 4, nrhs), dim3(256), 0, st, r0, nrows, h0, rp, ci, vx, work, ldw, tmp, ldt);
 }
 
-// ---- mid: x[B] = inv(D_B) * tmp[B]   (triangular dense GEMV, WPR waves per row) -----------------------------------
-template <bool UPPER, int WPR>
+// ---- mid: x[B] = inv(D_B) * tmp[B]   (triangular dense GEMV, WPR waves per row, RB right-hand sides per pass) ------
+template <bool UPPER, int WPR, int RB>
 __global__ __launch_bounds__(256) void k_mid_gemv(int64_t r0, int b, int64_t h0, const cplx* __restrict__ inv,
                                                   const cplx* __restrict__ tmp, int64_t ldt, cplx* __restrict__ work,
-                                                  int64_t ldw) {
-    __shared__ cplx part[4];
-    const cplx* t = tmp + (int64_t)blockIdx.y * ldt + (r0 - h0);
-    cplx* x = work + (int64_t)blockIdx.y * ldw;
+                                                  int64_t ldw, int nrhs) {
+    __shared__ cplx part[4][RB];
+    const int rhs0 = blockIdx.y * RB;
+    const int nb = min(RB, nrhs - rhs0);
+    const cplx* t = tmp + (int64_t)rhs0 * ldt + (r0 - h0);
+    cplx* x = work + (int64_t)rhs0 * ldw;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     constexpr int RPB = 4 / WPR;
     const int r = blockIdx.x * RPB + wv / WPR;
     const bool live = r < b;
-    cplx acc = cmake(0.0, 0.0);
+    cplx acc[RB];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) acc[q] = cmake(0.0, 0.0);
     if (live) {
         const cplx* row = inv + (int64_t)r * b;
         const int c0 = UPPER ? r : 0, c1 = UPPER ? b : r + 1;
         for (int c = (c0 & ~63) + (wv % WPR) * 64 + lane; c < c1; c += 64 * WPR)
-            if (c >= c0) cfma(acc, row[c], t[c]);
+            if (c >= c0) {
+                const cplx m = row[c];
+#pragma unroll
+                for (int q = 0; q < RB; ++q)
+                    if (q < nb) cfma(acc[q], m, t[(int64_t)q * ldt + c]);
+            }
     }
-    acc = group_reduce_sum<64>(acc);
+#pragma unroll
+    for (int q = 0; q < RB; ++q) acc[q] = group_reduce_sum<64>(acc[q]);
     if (WPR == 1) {
-        if (live && lane == 0) x[r0 + r] = acc;
+        if (live && lane == 0)
+            for (int q = 0; q < nb; ++q) x[(int64_t)q * ldw + r0 + r] = acc[q];
     } else {
-        if (lane == 0) part[wv] = acc;
+        if (lane == 0)
+            for (int q = 0; q < RB; ++q) part[wv][q] = acc[q];
         __syncthreads();
-        if (live && threadIdx.x == 0) {
-            cplx a = part[0];
-            for (int w = 1; w < 4; ++w) { a.x += part[w].x; a.y += part[w].y; }
-            x[r0 + r] = a;
+        if (live && threadIdx.x < nb) {
+            const int q = threadIdx.x;
+            cplx a = part[0][q];
+            for (int w = 1; w < 4; ++w) { a.x += part[w][q].x; a.y += part[w][q].y; }
+            x[(int64_t)q * ldw + r0 + r] = a;
         }
     }
 }
@@ -624,12 +652,13 @@ static int run_mid(const nep_lu* lu, const MidFactor& m, cplx* work, int64_t ldw
         launch_mid_spmv(m.wpr[k], r0, b, lu->h0, (const int32_t*)m.d_rp, (const int32_t*)m.d_ci, (const cplx*)m.d_vx,
                         (const cplx*)work, ldw, tmp, ldt, nrhs, st);
         LAUNCHCHK();
-        if (b >= 1024)
-            hipLaunchKernelGGL((k_mid_gemv<UPPER, 4>), dim3(b, nrhs), dim3(256), 0, st, r0, b, lu->h0,
-                               (const cplx*)(m.d_inv + (int64_t)k * b * b), (const cplx*)tmp, ldt, work, ldw);
-        else
-            hipLaunchKernelGGL((k_mid_gemv<UPPER, 1>), dim3((b + 3) / 4, nrhs), dim3(256), 0, st, r0, b, lu->h0,
-                               (const cplx*)(m.d_inv + (int64_t)k * b * b), (const cplx*)tmp, ldt, work, ldw);
+        const cplx* invk = (const cplx*)(m.d_inv + (int64_t)k * b * b);
+#define MID_GEMV(WPR_, RB_)                                                                                          \
+    hipLaunchKernelGGL((k_mid_gemv<UPPER, WPR_, RB_>), dim3(WPR_ == 4 ? b : (b + 3) / 4, (nrhs + RB_ - 1) / RB_),     \
+                       dim3(256), 0, st, r0, b, lu->h0, invk, (const cplx*)tmp, ldt, work, ldw, nrhs)
+        if (b >= 1024) { if (nrhs >= 8) MID_GEMV(4, 8); else if (nrhs >= 2) MID_GEMV(4, 4); else MID_GEMV(4, 1); }
+        else           { if (nrhs >= 8) MID_GEMV(1, 8); else if (nrhs >= 2) MID_GEMV(1, 4); else MID_GEMV(1, 1); }
+#undef MID_GEMV
         LAUNCHCHK();
         if (launches) *launches += 2;
     }
@@ -924,8 +953,11 @@ static int lu_sweep(nep_lu* lu, int nrhs, cplx* work, cplx* tmp, hipStream_t st,
         launch_mid_spmv(pick_wpr((double)lu->nnzL21 / (double)T), i0, (int)T, i0, (const int32_t*)lu->d_L21p,
                         (const int32_t*)lu->d_L21i, (const cplx*)lu->d_L21x, (const cplx*)work, n, tmp_tail, ldt, nrhs, st);
         LAUNCHCHK();
-        hipLaunchKernelGGL(k_tail_gemv, dim3((unsigned)((T + 3) / 4), nrhs), dim3(256), 0, st, T, i0,
-                           (const cplx*)lu->d_Sinv, (const cplx*)tmp_tail, ldt, work, n);
+#define TAIL_GEMV(RB_)                                                                                              \
+    hipLaunchKernelGGL((k_tail_gemv<RB_>), dim3((unsigned)((T + 3) / 4), (nrhs + RB_ - 1) / RB_), dim3(256), 0, st, T, \
+                       i0, (const cplx*)lu->d_Sinv, (const cplx*)tmp_tail, ldt, work, n, nrhs)
+        if (nrhs >= 8) TAIL_GEMV(8); else if (nrhs >= 2) TAIL_GEMV(4); else TAIL_GEMV(1);
+#undef TAIL_GEMV
         LAUNCHCHK();
         if (launches) *launches += 2;
     }

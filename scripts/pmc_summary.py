@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Summarises the rocprofv3 --pmc passes of scripts/pmc_collect.sh: average FETCH_SIZE / WRITE_SIZE (KB) per kernel and
+launch grid.  HBM bytes of a launch = 2*FETCH_SIZE + WRITE_SIZE kilobytes (gfx950: FETCH_SIZE counts 64-byte units where
+the tool assumes 32, MI355X_MICROARCH.md HBM section).   python scripts/pmc_summary.py <dir> <tag>"""
+import csv
+import glob
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+
+def main():
+    d, tag = sys.argv[1], sys.argv[2]
+    acc = defaultdict(lambda: defaultdict(list))
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        for f in glob.glob(os.path.join(d, "%s_%s" % (tag, c), "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(f)):
+                name = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void ", "")
+                if not name.startswith("k_"):
+                    continue
+                key = "%s grid=%s" % (name, r["Grid_Size"])
+                acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    out = {}
+    for key, cs in sorted(acc.items()):
+        e = {c: {"n": len(v), "avg_KB": sum(v) / len(v)} for c, v in cs.items()}
+        if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
+            e["hbm_MB_per_launch"] = (2 * e["FETCH_SIZE"]["avg_KB"] + e["WRITE_SIZE"]["avg_KB"]) / 1024.0
+        out[key] = e
+    json.dump(out, open(os.path.join(d, "%s_traffic.json" % tag), "w"), indent=1)
+    for key, e in out.items():
+        print("%-60s %s" % (key[:60], {k: (round(v["avg_KB"] / 1024, 2) if isinstance(v, dict) else round(v, 2)) for k, v in e.items()}))
+
+
+if __name__ == "__main__":
+    main()
