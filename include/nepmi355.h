@@ -155,10 +155,14 @@ int32_t nep_gemm_ts_dev(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_
  *     max_i |r_i| / (sum_t h_cabs[t] * (|A_t| |x|)_i + |b_i|)          (Arioli/Demmel/Duff), h_cabs[t] = |f_t(lam)|
  * after a stream synchronisation; with h_omega == NULL nothing is read back (blind refinement step).  M(lam) x is
  * either given (dMx, e.g. from a NEP-specific compute_Mlincomb with non-SPMF terms; h_c == NULL) or formed in the same
- * pass over the matrices from the host coefficients h_c[t] = f_t(lam) (dMx == NULL). */
+ * pass over the matrices from the host coefficients h_c[t] = f_t(lam) (dMx == NULL).  d_den_extra (device, n complex,
+ * real parts used, may be NULL) is added to the denominator: (|P||x|)_i of operator parts outside the SPMF terms (the
+ * dense corner block of the waveguide problem). */
 int32_t nep_cw_backward_error(nep_spmf* s, const double* h_cabs, const nep_cdouble* h_c, const nep_cdouble* dx,
-                              const nep_cdouble* db, const nep_cdouble* dMx, nep_cdouble* dr, double* h_omega,
-                              nep_stream stream);
+                              const nep_cdouble* db, const nep_cdouble* dMx, const nep_cdouble* d_den_extra,
+                              nep_cdouble* dr, double* h_omega, nep_stream stream);
+/* out[i] = (|x[i]|, 0): feeds the non-SPMF part of the denominator above */
+int32_t nep_absvec(int64_t len, const nep_cdouble* dx, nep_cdouble* dout, nep_stream stream);
 
 /* ---- K5 fixed-shift solve with a host-computed sparse LU -------------------------------
  * replaces: FactorizeLinSolver / lin_solve src/LinSolvers.jl:109-137 (Afact \ x) and

@@ -70,7 +70,8 @@ SIGNATURES = {
     "nep_lu_create": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, P(c_vp)],
     "nep_lu_destroy": [c_vp],
     "nep_lu_set_expected_solves": [c_i32],
-    "nep_cw_backward_error": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "nep_cw_backward_error": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "nep_absvec": [c_i64, c_vp, c_vp, c_vp],
     "nep_lu_info": [c_vp, P(c_i64)],
     "nep_lu_schedule": [c_vp, P(c_i64)],
     "nep_lu_solve": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp],

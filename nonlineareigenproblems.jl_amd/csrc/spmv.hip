@@ -349,7 +349,8 @@ __global__ __launch_bounds__(256) void k_cw_resid(const int32_t* __restrict__ ro
                                                   const cplx* __restrict__ ccf,
                                                   const cplx* __restrict__ x, const cplx* __restrict__ b,
                                                   const cplx* __restrict__ Mx, int64_t n, cplx* __restrict__ r,
-                                                  unsigned long long* omega_bits) {
+                                                  unsigned long long* omega_bits,
+                                                  const cplx* __restrict__ den_extra) {
     constexpr int RPB = 256 / G;
     __shared__ double wmax[4];
     const int sub = threadIdx.x % G;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void k_cw_resid(const int32_t* __restrict__ ro
     if (row < n && sub == 0) {
         const cplx rr = csub(b[row], FUSED ? acc : Mx[row]);
         r[row] = rr;
-        const double num = absval(rr), den = d + absval(b[row]);
+        const double num = absval(rr), den = d + absval(b[row]) + (den_extra ? den_extra[row].x : 0.0);
         ratio = den > 0.0 ? num / den : (num > 0.0 ? 1.0e300 : 0.0);
         if (!(ratio == ratio)) ratio = 1.0e300;     // NaN -> "not converged"
     }
@@ -389,7 +390,8 @@ __global__ __launch_bounds__(256) void k_cw_resid(const int32_t* __restrict__ ro
 
 template <typename VT>
 static int launch_cw_resid(const nep_spmf* s, const double* cabs, const cplx* ccf, const cplx* x, const cplx* b,
-                           const cplx* Mx, cplx* r, unsigned long long* omega_bits, hipStream_t st) {
+                           const cplx* Mx, cplx* r, unsigned long long* omega_bits, const cplx* den_extra,
+                           hipStream_t st) {
     const int64_t n = s->n;
     const VT* vals = (const VT*)s->d_vals;
 #define CW_CASE(G)                                                                                      \
@@ -397,10 +399,10 @@ static int launch_cw_resid(const nep_spmf* s, const double* cabs, const cplx* cc
         const int rpb = 256 / G;                                                                        \
         if (Mx)                                                                                         \
             hipLaunchKernelGGL((k_cw_resid<G, VT, false>), dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, st, \
-                               s->d_rowptr, s->d_idx, vals, cabs, ccf, x, b, Mx, n, r, omega_bits);     \
+                               s->d_rowptr, s->d_idx, vals, cabs, ccf, x, b, Mx, n, r, omega_bits, den_extra); \
         else                                                                                            \
             hipLaunchKernelGGL((k_cw_resid<G, VT, true>), dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, st, \
-                               s->d_rowptr, s->d_idx, vals, cabs, ccf, x, b, Mx, n, r, omega_bits);     \
+                               s->d_rowptr, s->d_idx, vals, cabs, ccf, x, b, Mx, n, r, omega_bits, den_extra); \
         break;                                                                                          \
     }
     switch (s->lanes) {
@@ -627,8 +629,8 @@ int32_t nep_mlincomb_dev(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t 
 }
 
 int32_t nep_cw_backward_error(nep_spmf* s, const double* h_cabs, const nep_cdouble* h_c, const nep_cdouble* dx,
-                              const nep_cdouble* db, const nep_cdouble* dMx, nep_cdouble* dr, double* h_omega,
-                              nep_stream stream) {
+                              const nep_cdouble* db, const nep_cdouble* dMx, const nep_cdouble* d_den_extra,
+                              nep_cdouble* dr, double* h_omega, nep_stream stream) {
     ARGCHK(s && h_cabs && dx && db && dr);
     ARGCHK((dMx != nullptr) != (h_c != nullptr));     // exactly one of: M x given, or coefficients to form it
     ARGCHK(s->mt <= 64);
@@ -646,9 +648,9 @@ int32_t nep_cw_backward_error(nep_spmf* s, const double* h_cabs, const nep_cdoub
     if (rc) return rc;
     if (h_omega) HIPCHK(hipMemsetAsync(bits, 0, 8, st));
     if (s->valbytes == 8)
-        rc = launch_cw_resid<double>(s, cabs, ccf, (const cplx*)dx, (const cplx*)db, (const cplx*)dMx, (cplx*)dr, h_omega ? bits : nullptr, st);
+        rc = launch_cw_resid<double>(s, cabs, ccf, (const cplx*)dx, (const cplx*)db, (const cplx*)dMx, (cplx*)dr, h_omega ? bits : nullptr, (const cplx*)d_den_extra, st);
     else
-        rc = launch_cw_resid<cplx>(s, cabs, ccf, (const cplx*)dx, (const cplx*)db, (const cplx*)dMx, (cplx*)dr, h_omega ? bits : nullptr, st);
+        rc = launch_cw_resid<cplx>(s, cabs, ccf, (const cplx*)dx, (const cplx*)db, (const cplx*)dMx, (cplx*)dr, h_omega ? bits : nullptr, (const cplx*)d_den_extra, st);
     if (rc) return rc;
     if (h_omega) {
         unsigned long long hb = 0;

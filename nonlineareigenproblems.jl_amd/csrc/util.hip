@@ -306,6 +306,11 @@ __global__ void k_hadamard(int64_t rows, int k, cplx* __restrict__ A, int64_t ld
         A[r + j * lda] = cmul(A[r + j * lda], B[r + j * ldb]);
     }
 }
+// out[i] = (|x[i]|, 0)
+__global__ void k_absvec(int64_t len, const cplx* __restrict__ x, cplx* __restrict__ out) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = cmake(hypot(x[i].x, x[i].y), 0.0);
+}
 // per-block partial column sums of |X[r*ld + s]|^2 of a row-major block; partial[b*k + s]
 __global__ __launch_bounds__(256) void k_rm_colnorm_partial(int64_t rows, int k, const cplx* __restrict__ XT, int64_t ld,
                                                             double* __restrict__ partial) {
@@ -500,6 +505,13 @@ int32_t nep_hadamard(int64_t rows, int32_t k, nep_cdouble* dA, int64_t lda, cons
     ARGCHK(rows > 0 && k >= 1 && dA && dB);
     hipLaunchKernelGGL(k_hadamard, dim3(grid_for(rows * k, 256)), dim3(256), 0, as_stream(stream), rows, (int)k,
                        (cplx*)dA, lda, (const cplx*)dB, ldb);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+int32_t nep_absvec(int64_t len, const nep_cdouble* dx, nep_cdouble* dout, nep_stream stream) {
+    ARGCHK(len > 0 && dx && dout);
+    hipLaunchKernelGGL(k_absvec, dim3(grid_for(len, 256)), dim3(256), 0, as_stream(stream), len, (const cplx*)dx, (cplx*)dout);
     LAUNCHCHK();
     return NEP_OK;
 }

@@ -243,9 +243,13 @@ class FactorizeLinSolver(LinSolver):
             om = np.zeros(1)
             fused = self._cf is not None
             Mx = None if fused else self.nep.compute_Mlincomb(self.lam, W[1].reshape(1, n))
+            extra = None
+            if want_omega and hasattr(self.nep, "refine_denominator_extra"):
+                extra = self.nep.refine_denominator_extra(self.lam, W[1])          # (|P||x|) of non-SPMF operator parts
             check(lib.nep_cw_backward_error(self._spmf, hptr(self._cabs), hptr(self._cf) if fused else None,
                                             c_vp(W[1].data_ptr()), c_vp(b.data_ptr()),
-                                            None if fused else c_vp(Mx.data_ptr()), c_vp(W[0].data_ptr()),
+                                            None if fused else c_vp(Mx.data_ptr()),
+                                            c_vp(extra.data_ptr()) if extra is not None else None, c_vp(W[0].data_ptr()),
                                             hptr(om) if want_omega else None, stream_ptr()))
             return float(om[0]) if want_omega else None
         # NEP without an SPMF device handle: normwise backward error ||r|| / (||M||_F ||x|| + ||b||)

@@ -227,6 +227,25 @@ class WEP(AbstractSPMF):
         self._corner_lincomb(to_dev(D), Vd, Vd.shape[1], k, z)
         return to_host(z.reshape(1, -1))[:, 0] if host else z
 
+    def refine_denominator_extra(self, lam, x):
+        """device vector d (n complex, real parts used) with d[N:] = |P(lam)| |x[N:]| for the dense corner block P: the
+        part of (|M||x|) that the SPMF terms do not see in the refinement criterion (linsolvers.FactorizeLinSolver)"""
+        key = complex(lam)
+        if getattr(self, "_Pabs_key", None) != key:
+            Pm = np.abs(self.corner_matrix(lam))
+            nz = self.nz
+            self._Pabs = (to_dev(Pm[:nz, :nz].astype(np.complex128)), to_dev(Pm[nz:, nz:].astype(np.complex128)))
+            self._Pabs_key = key
+            self._den = torch.zeros(self.n, dtype=CDT, device="cuda")
+            self._absx = torch.empty(2 * nz, dtype=CDT, device="cuda")
+        nz, N = self.nz, self.N
+        st = stream_ptr()
+        check(lib.nep_absvec(2 * nz, c_vp(x.data_ptr() + 16 * N), c_vp(self._absx.data_ptr()), st))
+        for half in (0, 1):
+            check(lib.nep_gemm_ts_dev(c_vp(self._Pabs[half].data_ptr()), nz, nz, nz, c_vp(self._absx.data_ptr() + 16 * half * nz),
+                                      nz, 0, 1, c_vp(self._den.data_ptr() + 16 * (N + half * nz)), nz, 0, st))
+        return self._den
+
     def corner_matrix(self, lam, i=0):
         """dense 2nz x 2nz corner block of M^(i)(lam) (host)"""
         Rm = self.wd.Rmat(); nz = self.nz

@@ -37,6 +37,49 @@ def test_c2_gun_iar_m100_fullsize(na):
     assert conv[-1] == 46 and all(b >= a - 2 for a, b in zip(conv, conv[1:]))
 
 
+def test_c2_pipelined_iar_equals_step_synchronous(na, monkeypatch):
+    """the asynchronous pipeline (device-side DGKS decision, event-ordered transfers) and the step-synchronous loop
+    (NEP_IAR_SYNC=1) run the same arithmetic: same eigenpair count, eigenvalues to 1e-11 relative, same error history
+    length; also with check_error_every=7 and with a finite neigs that stops the iteration early"""
+    nep = na.nep_gallery("gun_spmf_scaled"); n = nep.n
+    for kw in (dict(maxit=60, neigs=np.inf), dict(maxit=60, neigs=np.inf, check_error_every=7), dict(maxit=100, neigs=12)):
+        out = []
+        for sync in ("", "1"):
+            if sync:
+                monkeypatch.setenv("NEP_IAR_SYNC", "1")
+            else:
+                monkeypatch.delenv("NEP_IAR_SYNC", raising=False)
+            hist = []
+            lam, Q, _ = na.iar(nep, sigma=0.0, gamma=1.0, v=np.ones(n), tol=1e-10, errhist=hist, **kw)
+            out.append((lam, hist))
+        (la, ha), (ls, hs) = out
+        assert len(la) == len(ls) and len(la) >= 12
+        d = [np.min(abs(ls - x)) / max(1.0, abs(x)) for x in la]
+        assert max(d) < 1e-11
+        if kw["neigs"] == np.inf:
+            assert len(ha) == len(hs)
+
+
+def test_k5_blocked_solve_waveguide_91k(na):
+    """K5 at n = 91 195 (WEP 303x299, 2610 plain levels): blocked mid region + dense tail; raw solve relative residual
+    < 1e-9, after the UMFPACK-style refinement the componentwise backward error is at round-off (< 10 eps)"""
+    import scipy.sparse as sp
+    nep = na.nep_gallery("WEP", nx=303, nz=299, benchmark_problem="JARLEBRING")
+    lam = -3 - 3.5j
+    A = sp.csc_matrix(nep.compute_Mder(lam))
+    n = nep.n
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    ls = na.create_linsolver(na.FactorizeLinSolverCreator(), nep, lam)
+    lu = ls.lu
+    assert lu.mid_rows > 0 and lu.levL < 100 and lu.levL_full > 2000
+    x0 = na.to_host(lu.solve(na.to_dev(b)))[:, 0]
+    assert np.linalg.norm(A @ x0 - b) <= 1e-9 * np.linalg.norm(b)
+    x = na.lin_solve(ls, b)
+    assert ls.last_omega < 10 * np.finfo(float).eps and ls.refine_steps_taken <= 2
+    assert np.linalg.norm(A @ x - b) <= np.linalg.norm(A @ x0 - b) * 1.01
+
+
 def test_c5_wep_fullsize_kernels_vs_host(na):
     """config C5 size (nx=1003, nz=999, n=1 003 995): K1 against host SciPy SpMV, linearity, DGKS orthogonality"""
     from nep_amd import wep

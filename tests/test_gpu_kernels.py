@@ -252,14 +252,14 @@ def test_cw_backward_error_and_refinement(na):
     om = np.zeros(1)
     st = __import__("nep_amd").nep.stream_ptr()
     _lib.check(_lib.lib.nep_cw_backward_error(nep.dev.h, _lib.hptr(cabs), None, C.c_void_p(xd.data_ptr()),
-                                              C.c_void_p(bd.data_ptr()), C.c_void_p(Mx.data_ptr()),
+                                              C.c_void_p(bd.data_ptr()), C.c_void_p(Mx.data_ptr()), None,
                                               C.c_void_p(r.data_ptr()), _lib.hptr(om), st))
     # fused variant: M x formed inside the kernel from the complex coefficients
     cf = np.array([f.derivs(lam, 1)[0] for f in nep.get_fv()], dtype=complex)
     r2 = torch.empty_like(xd)
     om2 = np.zeros(1)
     _lib.check(_lib.lib.nep_cw_backward_error(nep.dev.h, _lib.hptr(cabs), _lib.hptr(cf), C.c_void_p(xd.data_ptr()),
-                                              C.c_void_p(bd.data_ptr()), None, C.c_void_p(r2.data_ptr()),
+                                              C.c_void_p(bd.data_ptr()), None, None, C.c_void_p(r2.data_ptr()),
                                               _lib.hptr(om2), st))
     assert np.linalg.norm(na.to_host(r2) - na.to_host(r)) <= 1e-13 * np.linalg.norm(na.to_host(r))
     assert abs(om2[0] - om[0]) <= 1e-12 * om[0]
