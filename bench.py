@@ -273,7 +273,7 @@ def main():
         byts1, ms1 = mlincomb_roofline(na, nep, 1)
         achieved = byts / (ms * 1e-3) / 1e9
         # HBM traffic of the same two kernels from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and
-        # --pmc WRITE_SIZE runs of scratch/pmc_k1.py; FETCH_SIZE doubled per the gfx950 correction of
+        # --pmc WRITE_SIZE runs of scripts/pmc_k1.py; FETCH_SIZE doubled per the gfx950 correction of
         # MI355X_MICROARCH.md).  Recorded measurement, not live: PMC collection needs rocprofv3 around the process.
         traffic = None; traffic_src = None
         try:

@@ -1,4 +1,4 @@
-import sys, os, time, cProfile, pstats; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os, time, cProfile, pstats; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS"): os.environ.setdefault(_v, "8")
 import numpy as np, torch, nep_amd as na
 nep = na.nep_gallery("gun_spmf"); nep.dev

@@ -1,4 +1,4 @@
-import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, nep_amd as na
 nx,nz=int(sys.argv[1]),int(sys.argv[2])
 nep=na.nep_gallery("WEP",nx=nx,nz=nz,benchmark_problem="JARLEBRING"); n=nep.n

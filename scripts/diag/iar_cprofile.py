@@ -1,4 +1,4 @@
-import sys, os, time, cProfile, pstats; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import sys, os, time, cProfile, pstats; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, nep_amd as na
 nep = na.nep_gallery("gun_spmf_scaled"); nep.dev
 kw=dict(maxit=100,neigs=np.inf,v=np.ones(nep.n),tol=1e-10)
