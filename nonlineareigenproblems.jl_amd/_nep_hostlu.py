@@ -71,8 +71,12 @@ def pattern_symmetric(Ac, threshold=0.5):
     return sym >= threshold
 
 
-def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None, symmetric_mode=None):
-    """UMFPACK-like strategy selection (see linsolvers.DeviceLU) + SuperLU factorisation."""
+def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None, symmetric_mode=None, panel_size=8,
+           relax=4):
+    """UMFPACK-like strategy selection (see linsolvers.DeviceLU) + SuperLU factorisation.
+    panel_size / relax: SuperLU's panel width and relaxed-supernode size.  With single-threaded BLAS on these complex
+    sparse matrices the defaults (20 / 10) are slower: measured on the bench host gun (n=9956) 20.4 -> 15.5 ms,
+    waveguide n=91k 411 -> 348 ms, n=1e6 13.7 -> 13.5 s (scripts/diag/superlu_params.py); same fill, same pivots."""
     t0 = time.perf_counter()
     Ac = sp.csc_matrix((np.asarray(data, dtype=np.complex128), indices, indptr), shape=shape)
     if permc_spec is None or symmetric_mode is None:
@@ -84,6 +88,10 @@ def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None
     if diag_pivot_thresh is None and symmetric_mode:
         diag_pivot_thresh = 0.001
     kw = dict(permc_spec=permc_spec)
+    if panel_size:
+        kw["panel_size"] = int(panel_size)
+    if relax:
+        kw["relax"] = int(relax)
     if diag_pivot_thresh is not None:
         kw["diag_pivot_thresh"] = diag_pivot_thresh
     if symmetric_mode:
