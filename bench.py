@@ -82,7 +82,7 @@ def mlincomb_roofline(na, nep, k, reps=50):
 def orth_roofline(na, n, k, reps=10):
     """K6 at the shape of iar step k (block-triangular basis, rows = n(k+1)): one classical Gram-Schmidt pass =
     k_orth_dots + k_orth_update, the two kernels with the largest share of device time in the timed region
-    (profiles/r1_iar_kernel_stats_v4.csv).  Algorithmic bytes: SURVEY.md section 8d K6 restricted to the non-zero
+    (profiles/r1_iar_kernel_stats_v5.csv).  Algorithmic bytes: SURVEY.md section 8d K6 restricted to the non-zero
     blocks: 2*16*sum_j active_j + 3*16*rows.  Timed with HIP events around asynchronous nep_orth_dev launches."""
     from nep_amd import dense
     rows = n * (k + 1)
