@@ -19,7 +19,7 @@ from .dense import gemm_ts, orthogonalize_and_normalize, DGKS, CGS, MGS
 from .iar import iar
 from .tiar import tiar
 from .newton import resinv, quasinewton, compute_rf, armijo_rule, ScalarNewtonInnerSolver
-from .nleigs import nleigs
+from .nleigs import nleigs, NleigsSolutionDetails
 from . import rk_helper
 from .contour import (contour_beyn, contour_block_SS, integrate_interval, MatrixIntegrator, MatrixTrapezoidal,
                       MatrixTrapezoidalSharded, probe_block)

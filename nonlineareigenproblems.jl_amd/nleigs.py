@@ -1,8 +1,9 @@
 """NLEIGS (fully rational Krylov) on the device backend -- keyword surface of src/method_nleigs.jl:60-81.
 
-Supported: SPMF-type NEPs (PEP, SPMF_NEP, PEP+SPMF SumNEP, DEP), dynamic variant (static=false), matrix-function
-divided differences (isfunm=true), leja in {0,1,2}, reusefact in {0,1,2}; not supported: the LowRankFactorizedNEP
-compression (rk_nep.jl:59-67), static=true, return_details=true, non-SPMF NEPs.
+Supported: SPMF-type NEPs (PEP, SPMF_NEP, PEP+SPMF SumNEP, DEP), dynamic and static variants, return_details
+(NleigsSolutionDetails), matrix-function divided differences (isfunm=true), leja in {0,1,2}, reusefact in {0,1,2};
+not supported: the LowRankFactorizedNEP compression (rk_nep.jl:59-67; low-rank terms are treated as general sparse
+matrices, same result), isfunm=false, non-SPMF NEPs.
 
 Device realisation of `backslash` (method_nleigs.jl:399-518).  The reference runs O(N) stacked SpMVs per step
 (`sum(reshape(BBCC*z_block,n,:) .* transpose(sgdd[:,ii+1]),dims=2)`, :462).  The block recurrence for z does not
@@ -32,11 +33,20 @@ def _c128(x):
     return np.ascontiguousarray(x, dtype=np.complex128)
 
 
+class NleigsSolutionDetails:
+    """src/method_nleigs.jl:538-561: Ritz values / residuals per iteration, nodes, poles, scaling, divided-difference
+    norms and the iteration at which the linearisation converged"""
+
+    def __init__(self, Lam, Res, sigma, xi, beta, nrmD, kconv):
+        self.Lam, self.Res, self.sigma, self.xi, self.beta, self.nrmD, self.kconv = Lam, Res, sigma, xi, beta, nrmD, kconv
+
+
 def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger=0, maxdgr=100, minit=20, maxit=200,
            linsolvercreator=None, tol=1e-10, tollin=None, v=None, errmeasure=None, isfunm=True, static=False, leja=1,
            nodes=(), reusefact=1, blksize=20, return_details=False, check_error_every=5, info=None):
-    if static or return_details or not isfunm:
-        raise NotImplementedError("nleigs on the device backend supports static=false, return_details=false, isfunm=true")
+    if not isfunm:
+        raise NotImplementedError("nleigs on the device backend computes the divided differences with matrix functions (isfunm=true)")
+    import warnings
     if tollin is None:
         tollin = max(tol / 10, 100 * EPS)
     if linsolvercreator is None:
@@ -59,7 +69,7 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
         if len(nodes) == 0:
             raise ValueError("Interpolation nodes must be provided via 'nodes' when no Leja-Bagby points ('leja' == 0) are used.")
         gamma, _ = rk.discretizepolygon(Sigma)
-        max_count = max(maxit, maxdgr) + 2
+        max_count = (maxit + maxdgr + 2) if static else max(maxit, maxdgr) + 2
         sigma = np.tile(nodes, int(np.ceil(max_count / len(nodes))))
         _, xi, beta = rk.lejabagby(sigma[:maxdgr + 2], Xi, gamma, maxdgr + 2, True, p)
     elif leja == 1:
@@ -71,7 +81,7 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
         sigma, xi, beta = rk.lejabagby(gamma, Xi, gamma, maxdgr + 2, False, p)
     else:
         gamma, _ = rk.discretizepolygon(Sigma)
-        max_count = max(maxit, maxdgr) + 2
+        max_count = (maxit + maxdgr + 2) if static else max(maxit, maxdgr) + 2
         sigma, xi, beta = rk.lejabagby(gamma, Xi, gamma, max_count, False, p)
     sigma = np.array(sigma, dtype=complex); xi = np.array(xi, dtype=float); beta = np.array(beta, dtype=float)
     xi[maxdgr + 1] = np.nan
@@ -82,14 +92,19 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
         raise ValueError("The generalized divided differences must be finite.")
 
     # ---- device state: V ((kmax+2) n x (kmax+2)), work vectors of (kmax+2) n entries
-    kmax = maxit
-    ldv = (kmax + 2) * n
-    V = torch.zeros((kmax + 2, ldv), dtype=CDT, device="cuda")
+    # static variant (method_nleigs.jl:101-102,176,250-257): the linearisation is built first (no Krylov steps), then
+    # maxit steps run on vectors of the frozen length (N+1) n; the start vector is zero-padded, which the zero-initialised V
+    # provides for free.  At most maxdgr+1 blocks.
+    kmax = maxit + maxdgr if static else maxit
+    ldv = (min(kmax, maxdgr + 1) + 2) * n if static else (kmax + 2) * n
+    ncol = maxit + 2
+    V = torch.zeros((ncol, ldv), dtype=CDT, device="cuda")
     Bw = torch.empty(ldv, dtype=CDT, device="cuda")
     zb = torch.empty(ldv, dtype=CDT, device="cuda")
     tmp = torch.empty(n, dtype=CDT, device="cuda")
-    H = np.zeros((kmax + 2, kmax + 1), dtype=complex); K = np.zeros((kmax + 2, kmax + 1), dtype=complex)
-    active = np.zeros(kmax + 2, dtype=np.int64)
+    H = np.zeros((ncol, ncol - 1), dtype=complex); K = np.zeros((ncol, ncol - 1), dtype=complex)
+    Lam = np.zeros((ncol - 1, ncol - 1), dtype=complex); Res = np.zeros((ncol - 1, ncol - 1))
+    active = np.zeros(ncol, dtype=np.int64)
     st = stream_ptr
 
     v0 = _c128(v) / np.linalg.norm(v)
@@ -131,11 +146,16 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
             check(lib.nep_block_recur(n, N, hptr(a), hptr(bw), c_vp(Bw.data_ptr()), c_vp(w.data_ptr()), st()))
         return w
 
-    def check_convergence(k, l):
+    def check_convergence(k, l, all_=False):
         lambda_, S = sla.eig(K[:l, :l], H[:l, :l])
-        lamin = rk.in_Sigma(lambda_, Sigma, tol)
-        ilam = np.nonzero(lamin)[0]
-        lam = lambda_[ilam]
+        if not all_:
+            lamin = rk.in_Sigma(lambda_, Sigma, tol)
+            ilam = np.nonzero(lamin)[0]
+            lam = lambda_[ilam]
+        else:                                                   # method_nleigs.jl:309-313: every finite Ritz value
+            ilam = np.nonzero(np.isfinite(lambda_))[0]
+            lam = lambda_[ilam]
+            lamin = rk.in_Sigma(lam, Sigma, tol)
         S = S.copy()
         for i in ilam:
             S[:, i] /= np.linalg.norm(H[:l + 1, :l] @ S[:, i])
@@ -145,6 +165,13 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
         else:
             QT = None; res = np.zeros(0)
         conv = np.abs(res) < tol
+        if all_:                                                # :328-336 history of all Ritz values / residuals
+            resall = np.full(l, np.nan)
+            resall[ilam] = res
+            si = sorted(range(l), key=lambda i: (abs(lambda_[i]), np.angle(lambda_[i])))
+            Res[:l, l - 1] = resall[si]
+            Lam[:l, l - 1] = lambda_[si]
+            conv = conv & lamin
         res_state.update(lam=lam, QT=QT, ilam=ilam, res=res, conv=conv)
         return int(np.sum(lamin)), int(np.sum(conv))
 
@@ -162,9 +189,13 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
                     kconv = k - 1
                     frozen = True
                     xi = xi[:k]; beta = beta[:k]; nrmD = nrmD[:k]
+                    if static:
+                        kmax = maxit + kconv
+                        kn -= n
                 elif k == maxdgr + 1:
                     kconv = k
                     frozen = True
+                    warnings.warn("NLEIGS: Linearization not converged after %d iterations" % maxdgr)
                 if frozen:
                     expand = False
                     if leja == 1:
@@ -172,17 +203,21 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
                             sigma = np.concatenate([sigma, np.zeros(kmax + 1 - len(sigma), dtype=complex)])
                         sigma[k:kmax + 1] = nodes[:kmax - k + 1]
                     N -= 1
-        l = k
-        w = backslash(k, l)
-        active[l] = kn
-        h, hb, _ = dense.orthogonalize_and_normalize(V, w, l, rows=kn, ldv=ldv, active_rows=active, method=dense.DGKS)
-        H[:l, l - 1] = h; H[l, l - 1] = hb
-        K[:l, l - 1] = H[:l, l - 1] * sigma[k]
-        K[l - 1, l - 1] += 1.0
-        K[l, l - 1] = hb * sigma[k]
-        if ((not expand and k >= N + minit and (k - (N + minit)) % check_error_every == 0) or
+        l = k - N if static else k
+        if not static or not expand:
+            w = backslash(k, l)
+            active[l] = kn
+            h, hb, _ = dense.orthogonalize_and_normalize(V, w, l, rows=kn, ldv=ldv, active_rows=active, method=dense.DGKS)
+            H[:l, l - 1] = h; H[l, l - 1] = hb
+            K[:l, l - 1] = H[:l, l - 1] * sigma[k]
+            K[l - 1, l - 1] += 1.0
+            K[l, l - 1] = hb * sigma[k]
+        if not return_details and (
+                (not expand and k >= N + minit and (k - (N + minit)) % check_error_every == 0) or
                 (k >= kconv + minit and (k - (kconv + minit)) % check_error_every == 0) or k == kmax):
             nblamin, nbconv = check_convergence(k, l)
+        elif return_details and (not static or not expand):
+            nblamin, nbconv = check_convergence(k, l, True)
         if ((not expand and k >= N + minit) or k >= kconv + minit) and nblamin == nbconv:
             break
         k += 1
@@ -190,7 +225,14 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
     if info is not None:
         info.update(kconv=kconv, N=N, k=min(k, kmax), nfact=len(cache.solvers), nrmD=nrmD, nblamin=nblamin)
     if res_state["QT"] is None or not np.any(conv):
-        return lam[conv], np.zeros((n, 0), dtype=complex), res[conv]
-    X = to_host(dense.rowmajor_to_cols(res_state["QT"], np.nonzero(conv)[0]))
-    X = X / np.linalg.norm(X, axis=0)[None, :]
+        X = np.zeros((n, 0), dtype=complex)
+    else:
+        X = to_host(dense.rowmajor_to_cols(res_state["QT"], np.nonzero(conv)[0]))
+        X = X / np.linalg.norm(X, axis=0)[None, :]
+    if return_details:                                          # method_nleigs.jl:363-374
+        kk = min(k, kmax)
+        if expand:
+            xi = xi[:kk]; beta = beta[:kk]; nrmD = nrmD[:kk]
+            warnings.warn("NLEIGS: Linearization not converged after %d iterations" % maxdgr)
+        return lam[conv], X, res[conv], NleigsSolutionDetails(Lam[:l, :l], Res[:l, :l], sigma[:kk], xi, beta, nrmD, kconv)
     return lam[conv], X, res[conv]

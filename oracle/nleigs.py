@@ -243,10 +243,19 @@ def backslash(wc, P, cache, reusefact, computeD, sigma, k, D, beta, N, xi, expan
     return w
 
 
+class NleigsSolutionDetails:
+    """method_nleigs.jl:538-561"""
+
+    def __init__(self, Lam, Res, sigma, xi, beta, nrmD, kconv):
+        self.Lam, self.Res, self.sigma, self.xi, self.beta, self.nrmD, self.kconv = Lam, Res, sigma, xi, beta, nrmD, kconv
+
+
 def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolvercreator=None, tol=1e-10,
            tollin=None, v=None, errmeasure=None, leja=1, nodes=(), reusefact=1, blksize=20, check_error_every=5,
-           info=None):
-    """method_nleigs.jl:60-377 (static=false, return_details=false, isfunm=true)."""
+           info=None, static=False, return_details=False):
+    """method_nleigs.jl:60-377 (isfunm=true; dynamic and static variants, optional solution details).
+    With return_details=True the return value is (lam, X, res, NleigsSolutionDetails) as in the reference."""
+    import warnings
     eps = np.finfo(float).eps
     if tollin is None:
         tollin = max(tol / 10, 100 * eps)
@@ -268,7 +277,7 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
         if len(nodes) == 0:
             raise ValueError("Interpolation nodes must be provided via 'nodes' when no Leja-Bagby points ('leja' == 0) are used.")
         gamma, _ = discretizepolygon(Sigma)
-        max_count = max(maxit, maxdgr) + 2
+        max_count = (maxit + maxdgr + 2) if static else max(maxit, maxdgr) + 2
         sigma = np.tile(nodes, int(np.ceil(max_count / len(nodes))))
         _, xi, beta = lejabagby(sigma[:maxdgr + 2], Xi, gamma, maxdgr + 2, True, P.p)
     elif leja == 1:
@@ -280,7 +289,7 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
         sigma, xi, beta = lejabagby(gamma, Xi, gamma, maxdgr + 2, False, P.p)
     else:
         gamma, _ = discretizepolygon(Sigma)
-        max_count = max(maxit, maxdgr) + 2
+        max_count = (maxit + maxdgr + 2) if static else max(maxit, maxdgr) + 2
         sigma, xi, beta = lejabagby(gamma, Xi, gamma, max_count, False, P.p)
     sigma = np.array(sigma, dtype=complex); xi = np.array(xi, dtype=float); beta = np.array(beta, dtype=float)
     xi[maxdgr + 1] = np.nan
@@ -294,9 +303,11 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
     if not np.isfinite(nrmD[0]):
         raise ValueError("The generalized divided differences must be finite.")
 
-    kmax = maxit
-    V = np.zeros(((kmax + 2) * n, kmax + 2), dtype=complex, order="F")
-    H = np.zeros((kmax + 2, kmax + 1), dtype=complex); K = np.zeros((kmax + 2, kmax + 1), dtype=complex)
+    kmax = maxit + maxdgr if static else maxit                                      # :176
+    vrows = (min(kmax, maxdgr + 1) + 2) * n if static else (kmax + 2) * n         # static: N <= maxdgr+1 blocks, zero padded
+    V = np.zeros((vrows, maxit + 2), dtype=complex, order="F")
+    H = np.zeros((maxit + 2, maxit + 1), dtype=complex); K = np.zeros((maxit + 2, maxit + 1), dtype=complex)
+    Lam = np.zeros((maxit + 1, maxit + 1), dtype=complex); Res = np.zeros((maxit + 1, maxit + 1))
     v = cache.solve(sigma[0], v / np.linalg.norm(v), reusefact == 2)
     V[:n, 0] = v / np.linalg.norm(v)
     expand = True
@@ -317,6 +328,8 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
             if n > 1 and k >= 5 and k < kconv:
                 if sum(nrmD[k - 4:k + 1]) < 5 * tollin:
                     kconv = k - 1
+                    if static:
+                        kmax = maxit + kconv                                        # :236-238
                     expand = False
                     if leja == 1:
                         if len(sigma) < kmax + 1:
@@ -325,30 +338,39 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
                     if computeD:
                         D = D[:k]
                     xi = xi[:k]; beta = beta[:k]; nrmD = nrmD[:k]
+                    if static:
+                        kn -= n                                                     # :250-257 (V is zero padded already)
                     N -= 1
                 elif k == maxdgr + 1:
                     kconv = k
                     expand = False
+                    warnings.warn("NLEIGS: Linearization not converged after %d iterations" % maxdgr)
                     if leja == 1:
                         if len(sigma) < kmax + 1:
                             sigma = np.concatenate([sigma, np.zeros(kmax + 1 - len(sigma), dtype=complex)])
                         sigma[k:kmax + 1] = nodes[:kmax - k + 1]
                     N -= 1
-        l = k
-        t = np.zeros(l); t[l - 1] = 1
-        wc = V[:kn, l - 1].copy()
-        w = backslash(wc, P, cache, reusefact, computeD, sigma, k, D, beta, N, xi, expand, kconv, sgdd)
-        H[l, l - 1] = solvers.dgks(V[:kn, :l], w, H[:l, l - 1])
-        K[:l, l - 1] = H[:l, l - 1] * sigma[k] + t
-        K[l, l - 1] = H[l, l - 1] * sigma[k]
-        V[:kn, l] = w
+        l = k - N if static else k                                                 # :283
+        if not static or not expand:                                                # :285-298
+            t = np.zeros(l); t[l - 1] = 1
+            wc = V[:kn, l - 1].copy()
+            w = backslash(wc, P, cache, reusefact, computeD, sigma, k, D, beta, N, xi, expand, kconv, sgdd)
+            H[l, l - 1] = solvers.dgks(V[:kn, :l], w, H[:l, l - 1])
+            K[:l, l - 1] = H[:l, l - 1] * sigma[k] + t
+            K[l, l - 1] = H[l, l - 1] * sigma[k]
+            V[:kn, l] = w
 
-        def check_convergence():
+        def check_convergence(all_):
             nonlocal lam, X, res, conv, nbconv, nblamin
             lambda_, S = sla.eig(K[:l, :l], H[:l, :l])
-            lamin = in_Sigma(lambda_, Sigma, tol)
-            ilam = np.nonzero(lamin)[0]
-            lam = lambda_[ilam]
+            if not all_:
+                lamin = in_Sigma(lambda_, Sigma, tol)
+                ilam = np.nonzero(lamin)[0]
+                lam = lambda_[ilam]
+            else:                                                                   # :309-313
+                ilam = np.nonzero(np.isfinite(lambda_))[0]
+                lam = lambda_[ilam]
+                lamin = in_Sigma(lam, Sigma, tol)
             nblamin = int(np.sum(lamin))
             S = S.copy()
             for i in ilam:
@@ -358,14 +380,31 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
                 X = X / np.linalg.norm(X, axis=0)[None, :]
             res = np.array([errmeasure(lam[i], X[:, i]) for i in range(len(lam))])
             conv = abs(res) < tol
+            if all_:                                                                # :328-336
+                resall = np.full(l, np.nan)
+                resall[ilam] = res
+                si = sorted(range(l), key=lambda i: (abs(lambda_[i]), np.angle(lambda_[i])))
+                Res[:l, l - 1] = resall[si]
+                Lam[:l, l - 1] = lambda_[si]
+                conv = conv & lamin
             nbconv = int(np.sum(conv)) if len(conv) else 0
 
-        if ((not expand and k >= N + minit and (k - (N + minit)) % check_error_every == 0) or
+        if not return_details and (
+                (not expand and k >= N + minit and (k - (N + minit)) % check_error_every == 0) or
                 (k >= kconv + minit and (k - (kconv + minit)) % check_error_every == 0) or k == kmax):
-            check_convergence()
+            check_convergence(False)
+        elif return_details and (not static or not expand):
+            check_convergence(True)
         if ((not expand and k >= N + minit) or k >= kconv + minit) and nblamin == nbconv:
             break
         k += 1
     if info is not None:
         info.update(kconv=kconv, N=N, k=min(k, kmax), nfact=len(cache.solvers), nrmD=nrmD, nblamin=nblamin)
+    if return_details:                                                              # :363-374
+        kk = min(k, kmax)
+        if expand:
+            xi = xi[:kk]; beta = beta[:kk]; nrmD = nrmD[:kk]
+            warnings.warn("NLEIGS: Linearization not converged after %d iterations" % maxdgr)
+        details = NleigsSolutionDetails(Lam[:l, :l], Res[:l, :l], sigma[:kk], xi, beta, nrmD, kconv)
+        return lam[conv], X[:, conv], res[conv], details
     return lam[conv], X[:, conv], res[conv]

@@ -310,6 +310,55 @@ def test_nleigs_basic_kat(na):
     assert max(np.linalg.norm(od.compute_Mlincomb(lam[i], X[:, i])) for i in range(len(lam))) < 1e-10
 
 
+def test_nleigs_static_and_details_vs_oracle(na):
+    """test/nleigs/nleigs_basic.jl:28-73 on the device path: static variant (warning + 4 eigenvalues), return_details
+    (0 / 3 / 4 eigenvalues, history consistent with the returned values); each case against the oracle (1e-9); then the
+    static variant on a sparse gun twin against the oracle."""
+    import warnings
+    from oracle import nleigs as onl, neps as oneps, gallery as og
+    B = [np.array([[1.0, 3], [5, 6]]), np.array([[3.0, 4], [6, 6]]), np.eye(2)]
+    Sig = [-10.0 - 2j, 10 - 2j, 10 + 2j, -10 + 2j]
+    pep = na.PEP(B); opep = oneps.PEP(B)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        lam, X, _ = na.nleigs(pep, Sig, maxit=10, v=np.ones(2) + 0j, maxdgr=5, blksize=5, static=True)
+        assert any("Linearization not converged" in str(x.message) for x in w)
+    lo, Xo, _ = onl.nleigs(opep, Sig, maxit=10, v=np.ones(2) + 0j, maxdgr=5, blksize=5, static=True)
+    assert len(lam) == 4
+    _match(lam, lo, 1e-9)
+    with warnings.catch_warnings(record=True):
+        warnings.simplefilter("always")
+        lam, X, _, d = na.nleigs(pep, Sig, maxit=5, v=np.ones(2) + 0j, blksize=5, return_details=True)
+    assert len(lam) == 0
+    Bc = [b + 1j * np.eye(2) for b in B]
+    lam, X, _, d = na.nleigs(na.PEP(Bc), Sig, maxit=10, v=np.ones(2) + 0j, blksize=5, return_details=True)
+    lo, Xo, _, do = onl.nleigs(oneps.PEP(Bc), Sig, maxit=10, v=np.ones(2) + 0j, blksize=5, return_details=True)
+    assert len(lam) == 3
+    _match(lam, lo, 1e-9)
+    lam, X, res, d = na.nleigs(pep, Sig, maxit=10, v=np.ones(2) + 0j, blksize=5, return_details=True)
+    lo, Xo, reso, do = onl.nleigs(opep, Sig, maxit=10, v=np.ones(2) + 0j, blksize=5, return_details=True)
+    assert len(lam) == 4 and d.Lam.shape == do.Lam.shape and d.kconv == do.kconv
+    l2 = d.Lam[:, -1]; r2 = d.Res[:, -1]
+    conv = (r2 < 1e-12) & onl.in_Sigma(l2, np.asarray(Sig, dtype=complex), 0)
+    assert conv.sum() == 4 and len(set(np.round(np.concatenate([lam, l2[conv]]), 8))) == 4
+    # static variant on a sparse gun twin (leja nodes in both phases are replaced by given nodes: variant S set-up)
+    n = 400
+    onep = og.nlevp_native_gun(n); nep = na.nep_gallery("nlevp_native_gun", n)
+    gam, mu = 300.0 ** 2 - 200.0 ** 2, 250.0 ** 2
+    xmin, xmax = mu - gam, mu + gam
+    half = xmin + (xmax - xmin) * (np.exp(1j * np.linspace(0, np.pi, 202)) / 2 + 0.5)
+    Sg = np.concatenate([half, [xmin]])
+    nodes = gam * np.array([2 / 3, (1 + 1j) / 3, 0, (-1 + 1j) / 3, -2 / 3]) + mu
+    Xi = -np.logspace(-8, 8, 2000) + 108.8774 ** 2
+    v0 = np.cos(np.arange(n)) + 0j
+    kw = dict(Xi=Xi, minit=30, maxit=50, v=v0, nodes=nodes, static=True, tol=1e-8)
+    io = {}; ig = {}
+    lo, Xo, ro = onl.nleigs(onep, Sg, info=io, **kw)
+    lg, Xg, rg = na.nleigs(nep, Sg, info=ig, **kw)
+    assert ig["kconv"] == io["kconv"] and len(lg) == len(lo) and len(lg) >= 1
+    _match(lg, lo, 1e-7)
+
+
 def test_nleigs_gun_twin_r1_vs_oracle(na):
     """config C3 at reduced size: gun in native PEP+SPMF form, variant R1 (leja=0, 5 cyclic nodes, reusefact=2)"""
     from oracle import gallery as og, nleigs as onl, solvers as osol

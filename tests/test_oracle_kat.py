@@ -131,6 +131,33 @@ def test_qdep0_quasinewton_history():
     assert hist[0][1] == pytest.approx(ref[0][0], rel=1e-14)   # pure sparse Mlincomb + Frobenius norms
 
 
+def test_nleigs_basic_static_and_details():
+    # test/nleigs/nleigs_basic.jl:28-73: static variant, return_details, complex matrices / start vector
+    import warnings
+    from oracle import nleigs as onl
+    B = [np.array([[1.0, 3], [5, 6]]), np.array([[3.0, 4], [6, 6]]), np.eye(2)]
+    pep = neps.PEP(B)
+    Sig = [-10.0 - 2j, 10 - 2j, 10 + 2j, -10 + 2j]
+    ok = lambda nep, lam, X: sum(np.linalg.norm(nep.compute_Mlincomb(l, X[:, i])) < 1e-5 for i, l in enumerate(lam))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        lam, X, _ = onl.nleigs(pep, Sig, maxit=10, v=np.ones(2) + 0j, maxdgr=5, blksize=5, static=True)
+        assert len(lam) == 4 and ok(pep, lam, X) == 4 and any("Linearization not converged" in str(x.message) for x in w)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        lam, X, _, d = onl.nleigs(pep, Sig, maxit=5, v=np.ones(2) + 0j, blksize=5, return_details=True)
+        assert len(lam) == 0 and any("Linearization not converged" in str(x.message) for x in w)
+    cpep = neps.PEP([b + 1j * np.eye(2) for b in B])
+    lam, X, _, d = onl.nleigs(cpep, Sig, maxit=10, v=np.ones(2) + 0j, blksize=5, return_details=True)
+    assert len(lam) == 3 and ok(cpep, lam, X) == 3
+    lam, X, _, d = onl.nleigs(pep, Sig, maxit=10, v=np.ones(2) * (1 + 0.1j), blksize=5, return_details=True)
+    assert len(lam) == 4 and ok(pep, lam, X) == 4
+    lam, X, res, d = onl.nleigs(pep, Sig, maxit=10, v=np.ones(2) + 0j, blksize=5, return_details=True)
+    l2 = d.Lam[:, -1]; r2 = d.Res[:, -1]
+    conv = (r2 < 1e-12) & onl.in_Sigma(l2, np.asarray(Sig, dtype=complex), 0)
+    assert len(lam) == 4 and conv.sum() == 4 and len(set(np.round(np.concatenate([lam, l2[conv]]), 8))) == 4
+
+
 def test_block_SS_dep0():
     # test/contour_block_SS.jl:9-24: circle, ellipse, JSIAM mode on dep0(3); ||M(lam_1) v_1|| < sqrt(eps)
     nep = gallery.dep0(3)
