@@ -327,3 +327,48 @@ def test_mlincomb_sell_and_fold_paths(na, monkeypatch):
             if (k, "0") in res:
                 assert np.linalg.norm(z - res[(k, "0")]) <= 1e-13 * np.linalg.norm(ref)
             res[(k, sell)] = z
+
+
+def test_error_paths_through_the_c_abi(na):
+    """status codes instead of crashes: singular factorisation (SingularException like `lu` in the reference, hence
+    LinAlgError), structurally singular U handed to nep_lu_create (NEP_ERR_SINGULAR), non-triangular factors and bad
+    leading dimensions (NEP_ERR_ARG), orthogonalisation breakdown on a zero vector (NEP_ERR_BREAKDOWN), and the
+    asynchronous DGKS reporting the same breakdown through its status word"""
+    import ctypes as C
+    import torch
+    from nep_amd import _lib
+    from nep_amd._lib import lib, hptr, c_vp
+    st = __import__("nep_amd").nep.stream_ptr()
+    # numerically singular matrix: the host factorisation raises, surfaced as LinAlgError("SingularException...")
+    A = sp.csc_matrix(np.array([[1.0, 2.0, 0], [2.0, 4.0, 0], [0, 0, 1.0]]), dtype=complex)
+    with pytest.raises(np.linalg.LinAlgError):
+        na.DeviceLU(A)
+    # zero pivot in U passed directly to the library
+    n = 4
+    Lp = np.arange(n + 1, dtype=np.int32); Li = np.arange(n, dtype=np.int32); Lx = np.ones(n, dtype=complex)
+    Ux = np.ones(n, dtype=complex); Ux[2] = 0.0
+    h = C.c_void_p()
+    rc = lib.nep_lu_create(n, hptr(Lp), hptr(Li), hptr(Lx), hptr(Lp), hptr(Li), hptr(Ux), None, None, C.byref(h))
+    assert rc == _lib.NEP_ERR_SINGULAR and not h.value
+    # L with an entry above the diagonal
+    Lp2 = np.array([0, 2, 3, 4, 5], dtype=np.int32); Li2 = np.array([0, 3, 1, 2, 3], dtype=np.int32); Lx2 = np.ones(5, dtype=complex)
+    rc = lib.nep_lu_create(n, hptr(Lp2), hptr(Li2), hptr(Lx2), hptr(Lp), hptr(Li), hptr(Lx), None, None, C.byref(h))
+    assert rc == _lib.NEP_ERR_ARG
+    with pytest.raises(na.NepError):
+        _lib.check(rc)
+    # gemm with a leading dimension smaller than the row count
+    Z = torch.zeros((3, 10), dtype=torch.complex128, device="cuda")
+    B = np.ones((3, 2), dtype=complex, order="F")
+    Y = torch.zeros((2, 10), dtype=torch.complex128, device="cuda")
+    rc = lib.nep_gemm_ts(c_vp(Z.data_ptr()), 5, 10, 3, hptr(B), 3, 2, c_vp(Y.data_ptr()), 10, 0, st)
+    assert rc == _lib.NEP_ERR_ARG
+    # orthogonalising the zero vector: breakdown, synchronous and asynchronous flavour
+    V = torch.zeros((2, 64), dtype=torch.complex128, device="cuda"); V[0, 0] = 1; V[1, 1] = 1
+    w = torch.zeros(64, dtype=torch.complex128, device="cuda")
+    with pytest.raises(na.NepError) as ei:
+        na.orthogonalize_and_normalize(V, w, 2)
+    assert ei.value.status == _lib.NEP_ERR_BREAKDOWN
+    out = torch.zeros(4, dtype=torch.complex128, device="cuda")
+    na.dense.orthogonalize_and_normalize_dev(V, w, 2, out)
+    flags = na.to_host(out.reshape(1, -1))[:, 0][3]
+    assert int(flags.imag) & 2
