@@ -11,8 +11,11 @@ workload (weak scaling) and `value` is the whole-job rate: sum over ranks of con
 divided by the max-over-ranks wall time.
 
 The JSON line also carries
-  roofline      compute_Mlincomb (k_vc + k_spmv, the kernel pair named by the metric) at k=100,
-                algorithmic bytes / HIP-event time, against the 8 TB/s HBM peak
+  roofline      the kernels that dominate the device time of the timed region: K6, one Gram-Schmidt pass
+                (k_orth_dots + k_orth_update) at the shape of the last Arnoldi step; algorithmic bytes / HIP-event
+                time against the 8 TB/s HBM peak, HBM traffic from the committed PMC passes
+  roofline_compute_Mlincomb   the kernel the metric names (k_vc + k_spmv) at k=100 and k=1 on the gun matrices
+                (launch-bound at this size); roofline_wep_scale: the same kernels on the n = 1e6 waveguide matrices
   kernels       per-phase GPU time of one instrumented iar run (so the time-dominant kernel is visible)
   cpu_baseline  the CPU oracle (NumPy/SciPy restatement of the reference) on a bounded sample
 """
@@ -299,7 +302,10 @@ def main():
                        "eigenpairs_per_step": pairs / (args.steps * world),
                        "max_backward_error": maxres},
             "compute_Mlincomb_GBps": achieved,
-            "roofline": {"bound": "hbm", "kernel": "nep_mlincomb = k_vc + k_spmv, k=%d columns" % k,
+            "roofline_compute_Mlincomb": {"bound": "hbm", "kernel": "nep_mlincomb = k_vc + k_spmv, k=%d columns" % k,
+                         "note": "the kernel BASELINE's metric names; at gun size one call moves 17.8 MB (2.2 us at 8 TB/s) "
+                                 "behind two kernel boundaries, i.e. launch-bound by construction; the HBM-bound size is "
+                                 "roofline_wep_scale",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": byts, "ms_per_launch": ms,
                          "single_vector": {"algorithmic_bytes": byts1, "ms_per_launch": ms1,
@@ -307,10 +313,24 @@ def main():
             "kernels": {"note": "wall ms per phase of one instrumented iar run (torch.cuda.synchronize around each phase)",
                         **{k_: round(v * 1e3, 3) for k_, v in tm.items()}},
         }
+        # `roofline` = the dominant kernels of the timed region: K6 (k_orth_dots + k_orth_update hold the largest share
+        # of device time, profiles/r1_iar_kernel_stats_v5.csv), measured live at the shape of the last step
         try:
-            out["roofline_time_dominant"] = orth_roofline(na, nep.n, args.maxit)
+            rf = orth_roofline(na, nep.n, args.maxit)
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc2", "gun_traffic.json")))
+                kb = 0.0
+                for name, d in pj.items():
+                    if (name.startswith("k_orth_dots") or name.startswith("k_orth_update")) and d.get("hbm_MB_per_launch", 0) > 100:
+                        kb += d["hbm_MB_per_launch"] * 1024.0
+                rf["traffic"] = kb * 1024.0
+                rf["traffic_source"] = ("profiles/pmc2/gun_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                                        "scripts/kernel_bench.py gun, same shape; 2*FETCH + WRITE per the gfx950 note)")
+            except Exception:
+                rf["traffic"] = None
+            out["roofline"] = rf
         except Exception as e:
-            out["roofline_time_dominant"] = {"error": repr(e)[:200]}
+            out["roofline"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_wep_roofline:
             try:
                 out["roofline_wep_scale"] = wep_scale_roofline(na)
