@@ -33,15 +33,22 @@ def _f_factory(n, k):
     return f
 
 
-def _run(rank, world, port, N, out):
+def _moments(K):
+    """gv of the quadrature: K = 0 -> Beyn's two moments (1, g); K > 0 -> the 2K moments of contour_block_SS"""
+    g = lambda t: complex(np.cos(t), np.sin(t))
+    if K == 0:
+        return [lambda s: 1.0 + 0j, g]
+    return [(lambda s, kk=kk: g(s) ** kk) for kk in range(2 * K)]
+
+
+def _run(rank, world, port, N, out, K=0, a=0.0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import nep_amd as na
-    g = lambda t: complex(np.cos(t), np.sin(t))
     info = {}
-    S = na.integrate_interval(na.MatrixTrapezoidalSharded, _f_factory(50, 3), [lambda s: 1.0 + 0j, g], 0.0,
-                              2 * np.pi, N, info=info, ops=_CpuOps)
+    S = na.integrate_interval(na.MatrixTrapezoidalSharded, _f_factory(50, 3), _moments(K), a,
+                              a + 2 * np.pi, N, info=info, ops=_CpuOps)
     np.save(os.path.join(out, "S%d.npy" % rank), S.numpy())
     np.save(os.path.join(out, "nodes%d.npy" % rank), np.array([info["nodes"], info["world"]]))
     dist.destroy_process_group()
@@ -52,18 +59,20 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("N", [64, 7])
-def test_sharded_quadrature_world2(tmp_path, N):
+@pytest.mark.parametrize("N,K,a", [(64, 0, 0.0), (7, 0, 0.0), (32, 3, np.pi / 32)])
+def test_sharded_quadrature_world2(tmp_path, N, K, a):
+    """Beyn's two moments, and the 2K = 6 moment blocks of contour_block_SS on the half-step-shifted nodes of its JSIAM
+    mode, through the same seam"""
     import nep_amd as na
     world = 2
-    mp.spawn(_run, args=(world, _free_port(), N, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_run, args=(world, _free_port(), N, str(tmp_path), K, a), nprocs=world, join=True)
     S0 = np.load(tmp_path / "S0.npy"); S1 = np.load(tmp_path / "S1.npy")
     assert np.array_equal(S0, S1)                                   # bit-identical on all ranks
     n0 = np.load(tmp_path / "nodes0.npy"); n1 = np.load(tmp_path / "nodes1.npy")
     assert n0[1] == 2 and n0[0] + n1[0] == N and n0[0] == (N + 1) // 2
-    g = lambda t: complex(np.cos(t), np.sin(t))
-    Sref = na.integrate_interval(na.MatrixTrapezoidal, _f_factory(50, 3), [lambda s: 1.0 + 0j, g], 0.0, 2 * np.pi,
+    Sref = na.integrate_interval(na.MatrixTrapezoidal, _f_factory(50, 3), _moments(K), a, a + 2 * np.pi,
                                  N, ops=_CpuOps).numpy()
+    assert Sref.shape[0] == (2 if K == 0 else 2 * K)
     assert np.linalg.norm(S0 - Sref) <= 1e-13 * np.linalg.norm(Sref)
 
 
