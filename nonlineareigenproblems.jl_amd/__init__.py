@@ -9,6 +9,7 @@ from . import _lib, funcs, dense
 from ._lib import NepError, device_count, LIB_PATH
 from .exceptions import NoConvergenceException, LostOrthogonalityException
 from .nep import (NEP, AbstractSPMF, SPMF_NEP, DEP, PEP, SumNEP, DerSPMF, shift_and_scale, SPMFDevice,
+                  LowRankMatrixAndFunction, LowRankFactorizedNEP,
                   to_dev, to_host)
 from .linsolvers import (LinSolver, FactorizeLinSolver, BackslashLinSolver, FactorizeLinSolverCreator,
                          BackslashLinSolverCreator, DefaultLinSolverCreator, create_linsolver, lin_solve,

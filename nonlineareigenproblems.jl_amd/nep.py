@@ -338,6 +338,51 @@ class SPMF_NEP(AbstractSPMF):
         return self.fi
 
 
+class LowRankMatrixAndFunction:
+    """src/rk_helper/rk_nep.jl:41-53: a matrix A = L U^H of low rank with its function f.  The factors come from a
+    rank-revealing (column-pivoted QR) factorisation of the block of A that holds its non-zeros; `L`, `U` are sparse
+    n x r.  (The reference takes L, U from an unpivoted reading of `lu`, :71-83; only A = L U^H is relied upon.)"""
+
+    def __init__(self, A, f, L=None, U=None, tol=1e-13):
+        import scipy.linalg as sla
+        self.f = f
+        if L is not None and U is not None:
+            self.L, self.U = sp.csc_matrix(L), sp.csc_matrix(U)
+            self.A = sp.csc_matrix(A) if A is not None and getattr(A, "nnz", 1) else sp.csc_matrix(self.L @ self.U.conj().T)
+            return
+        A = sp.csc_matrix(A)
+        self.A = A
+        n = A.shape[0]
+        coo = A.tocoo()
+        if coo.nnz == 0:
+            self.L = sp.csc_matrix((n, 0)); self.U = sp.csc_matrix((n, 0))
+            return
+        r0, r1 = coo.row.min(), coo.row.max() + 1
+        c0, c1 = coo.col.min(), coo.col.max() + 1
+        B = A[r0:r1, c0:c1].toarray()
+        Q, R, piv = sla.qr(B, mode="economic", pivoting=True)
+        d = np.abs(np.diag(R))
+        r = int(np.sum(d > tol * max(d[0], 1e-300))) if len(d) else 0
+        Ru = np.zeros((r, c1 - c0), dtype=R.dtype)
+        Ru[:, piv] = R[:r, :]
+        Lf = sp.lil_matrix((n, r), dtype=Q.dtype); Lf[r0:r1, :] = Q[:, :r]
+        Uf = sp.lil_matrix((n, r), dtype=R.dtype); Uf[c0:c1, :] = Ru.conj().T
+        self.L, self.U = sp.csc_matrix(Lf), sp.csc_matrix(Uf)
+
+
+class LowRankFactorizedNEP(SPMF_NEP):
+    """src/NEPTypes.jl (LowRankFactorizedNEP) + rk_nep.jl:59-67: an SPMF whose matrices carry low-rank factors
+    A_i = L_i U_i^H.  On this backend the terms run through the same stacked-CSR kernels as any sparse SPMF term; the
+    compression of the Krylov vectors that the reference's nleigs derives from the factors (method_nleigs.jl:406-414) is
+    not applied -- same eigenpairs, more memory."""
+
+    def __init__(self, Amf):
+        super().__init__([M.A for M in Amf], [M.f for M in Amf])
+        self.L = [M.L for M in Amf]
+        self.U = [M.U for M in Amf]
+        self.rank = int(sum(M.U.shape[1] for M in Amf))
+
+
 class DEP(AbstractSPMF):
     """-lam I + sum_i A_i exp(-tau_i lam)   (src/NEPTypes.jl:427-513)."""
 

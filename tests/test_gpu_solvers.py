@@ -310,6 +310,30 @@ def test_nleigs_basic_kat(na):
     assert max(np.linalg.norm(od.compute_Mlincomb(lam[i], X[:, i])) for i in range(len(lam))) < 1e-10
 
 
+def test_nleigs_nep_types(na):
+    """test/nleigs/nleigs_nep_types.jl:31-46: the same quadratic problem as SPMF_NEP, PEP, PEP + SPMF and
+    PEP + LowRankFactorizedNEP -> 4 eigenvalues each, all equal (the custom non-SPMF NEP type is out of scope)"""
+    import scipy.sparse as sp
+    f = na.funcs
+    B = [np.array([[1.0, 3], [5, 6]]), np.array([[3.0, 4], [6, 6]])]; Cm = [np.eye(2)]
+    Sig = [-10.0 - 2j, 10 - 2j, 10 + 2j, -10 + 2j]
+    problems = [
+        na.SPMF_NEP(B + Cm, [f.one(), f.ident(), f.Monomial(2)]),
+        na.PEP(B + Cm),
+        na.SumNEP(na.PEP(B), na.SPMF_NEP(Cm, [f.Monomial(2)])),
+        na.SumNEP(na.PEP(B), na.LowRankFactorizedNEP([na.LowRankMatrixAndFunction(sp.csc_matrix(Cm[0]), f.Monomial(2))])),
+    ]
+    ref = None
+    for nep in problems:
+        lam, X, res = na.nleigs(nep, Sig, maxit=10, v=np.ones(2) + 0j, blksize=5)
+        assert len(lam) == 4
+        M = lambda l: B[0] + l * B[1] + l * l * Cm[0]
+        assert max(np.linalg.norm(M(lam[i]) @ X[:, i]) for i in range(4)) < 1e-5
+        if ref is None:
+            ref = lam
+        _match(lam, ref, 1e-9)
+
+
 def test_nleigs_static_and_details_vs_oracle(na):
     """test/nleigs/nleigs_basic.jl:28-73 on the device path: static variant (warning + 4 eigenvalues), return_details
     (0 / 3 / 4 eigenvalues, history consistent with the returned values); each case against the oracle (1e-9); then the

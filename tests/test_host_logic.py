@@ -199,3 +199,23 @@ def test_c_abi_argument_errors_without_gpu():
     assert st == 0
     R = sp.csr_matrix((vv, ci, rp), shape=(7, 7))
     assert (R != A).nnz == 0
+
+
+def test_low_rank_types_host_side():
+    """LowRankMatrixAndFunction / LowRankFactorizedNEP (rk_nep.jl:41-67): A = L U^H on the reference's gun W1, W2
+    (ranks 19 and 65, test/rk_helper/gun_test_utils.jl) and the PEP + LowRankFactorizedNEP composition of
+    test/nleigs/nleigs_nep_types.jl:40"""
+    import scipy.sparse as sp
+    import nep_amd as na
+    d = np.load(os.path.join(ROOT, "nonlineareigenproblems.jl_amd", "data", "gun_W.npz"))
+    ranks = []
+    for nm in ("W1", "W2"):
+        W = sp.csc_matrix((d[nm + "_data"], d[nm + "_indices"], d[nm + "_indptr"]), shape=tuple(d[nm + "_shape"]))
+        c = na.LowRankMatrixAndFunction(W, na.funcs.ident())
+        assert abs(c.L @ c.U.conj().T - W).max() < 1e-13 and c.L.shape == (W.shape[0], c.U.shape[1])
+        ranks.append(c.U.shape[1])
+    assert ranks == [19, 65]
+    B = [np.array([[1.0, 3], [5, 6]]), np.array([[3.0, 4], [6, 6]])]
+    lr = na.LowRankFactorizedNEP([na.LowRankMatrixAndFunction(sp.csc_matrix(np.eye(2)), na.funcs.Monomial(2))])
+    nep = na.SumNEP(na.PEP(B), lr)
+    assert lr.rank == 2 and len(nep.get_Av()) == 3 and na.rk_helper.rk_structure(nep) == (1, 1)
