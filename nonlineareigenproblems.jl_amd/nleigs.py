@@ -1,9 +1,9 @@
 """NLEIGS (fully rational Krylov) on the device backend -- keyword surface of src/method_nleigs.jl:60-81.
 
 Supported: SPMF-type NEPs (PEP, SPMF_NEP, PEP+SPMF SumNEP, DEP), dynamic and static variants, return_details
-(NleigsSolutionDetails), matrix-function divided differences (isfunm=true), leja in {0,1,2}, reusefact in {0,1,2};
-not supported: the LowRankFactorizedNEP compression (rk_nep.jl:59-67; low-rank terms are treated as general sparse
-matrices, same result), isfunm=false, non-SPMF NEPs.
+(NleigsSolutionDetails), divided differences by matrix functions (isfunm=true) or by differencing (isfunm=false),
+leja in {0,1,2}, reusefact in {0,1,2}; not supported: the LowRankFactorizedNEP compression (rk_nep.jl:59-67; low-rank
+terms are treated as general sparse matrices, same result) and non-SPMF NEP types.
 
 Device realisation of `backslash` (method_nleigs.jl:399-518).  The reference runs O(N) stacked SpMVs per step
 (`sum(reshape(BBCC*z_block,n,:) .* transpose(sgdd[:,ii+1]),dims=2)`, :462).  The block recurrence for z does not
@@ -44,8 +44,6 @@ class NleigsSolutionDetails:
 def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger=0, maxdgr=100, minit=20, maxit=200,
            linsolvercreator=None, tol=1e-10, tollin=None, v=None, errmeasure=None, isfunm=True, static=False, leja=1,
            nodes=(), reusefact=1, blksize=20, return_details=False, check_error_every=5, info=None):
-    if not isfunm:
-        raise NotImplementedError("nleigs on the device backend computes the divided differences with matrix functions (isfunm=true)")
     import warnings
     if tollin is None:
         tollin = max(tol / 10, 100 * EPS)
@@ -86,7 +84,10 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
     sigma = np.array(sigma, dtype=complex); xi = np.array(xi, dtype=float); beta = np.array(beta, dtype=float)
     xi[maxdgr + 1] = np.nan
     rng_ = slice(0, maxdgr + 2)
-    sgdd = rk.scgendivdiffs(sigma[rng_], xi[rng_], beta[rng_], nep.get_fv())        # mt x (maxdgr+2)
+    if not isfunm and len(np.unique(sigma)) != len(sigma):                          # method_nleigs.jl:142-145
+        raise ValueError("All interpolation nodes must be distinct when no matrix functions are used for computing "
+                         "the generalized divided differences.")
+    sgdd = rk.scgendivdiffs(sigma[rng_], xi[rng_], beta[rng_], nep.get_fv(), isfunm)   # mt x (maxdgr+2)
     nrmD = [float(np.max(abs(sgdd[:, 0])))]
     if not np.isfinite(nrmD[0]):
         raise ValueError("The generalized divided differences must be finite.")

@@ -145,8 +145,33 @@ def ratnewtoncoeffsm(fun, sigma, xi, beta):
     return np.asarray(fun.matfun(M), dtype=complex)[:, 0] * beta[0]
 
 
-def scgendivdiffs(sigma, xi, beta, pff):
-    return np.vstack([ratnewtoncoeffsm(f, sigma, xi, beta) for f in pff])
+def evalrat(sigma, xi, beta, z):
+    """nodal rational function at the point z (rk_utils.jl:121-128)"""
+    r = 1.0 / beta[0] + 0j
+    with np.errstate(all="ignore"):
+        for j in range(len(sigma)):
+            r = r * (z - sigma[j]) / (1 - z / xi[j]) / beta[j + 1]
+    return r
+
+
+def ratnewtoncoeffs_scalar(fun, sigma, xi, beta):
+    """rational divided differences of a scalar function by differencing (rk_utils.jl:73-93); distinct sigma required.
+    `fun` is a funcs.ScalarFun (its value derivs(z, 1)[0] is used)"""
+    m = len(sigma)
+    fv = lambda z: complex(fun.derivs(complex(z), 1)[0])
+    D = np.zeros(m, dtype=complex)
+    D[0] = fv(sigma[0]) * beta[0]
+    for j in range(1, m):
+        Qj = sum(D[k] * evalrat(sigma[:k], xi[:k], beta[:k + 1], sigma[j]) for k in range(j))
+        D[j] = (fv(sigma[j]) - Qj) / evalrat(sigma[:j], xi[:j], beta[:j + 1], sigma[j])
+    return D
+
+
+def scgendivdiffs(sigma, xi, beta, pff, isfunm=True):
+    """rk_utils.jl:56-66"""
+    if isfunm:
+        return np.vstack([ratnewtoncoeffsm(f, sigma, xi, beta) for f in pff])
+    return np.vstack([ratnewtoncoeffs_scalar(f, sigma, xi, beta) for f in pff])
 
 
 def rk_structure(nep):

@@ -166,8 +166,33 @@ def ratnewtoncoeffsm(fm, sigma, xi, beta):
     return np.asarray(fm(M), dtype=complex)[:, 0] * beta[0]
 
 
-def scgendivdiffs(sigma, xi, beta, maxdgr, pff):
-    return np.vstack([ratnewtoncoeffsm(f, sigma, xi, beta) for f in pff])
+def evalrat(sigma, xi, beta, z):
+    """rk_utils.jl:121-128: nodal rational function at the point z"""
+    r = 1.0 / beta[0] + 0j
+    with np.errstate(all="ignore"):
+        for j in range(len(sigma)):
+            r = r * (z - sigma[j]) / (1 - z / xi[j]) / beta[j + 1]
+    return r
+
+
+def ratnewtoncoeffs_scalar(f, sigma, xi, beta):
+    """rk_utils.jl:73-93 for a scalar function (evaluated on 1 x 1 matrices): divided differences by differencing;
+    the sigma must be distinct"""
+    m = len(sigma)
+    fv = lambda z: complex(np.asarray(f(np.array([[z]], dtype=complex))).ravel()[0])
+    D = np.zeros(m, dtype=complex)
+    D[0] = fv(sigma[0]) * beta[0]
+    for j in range(1, m):
+        Qj = sum(D[k] * evalrat(sigma[:k], xi[:k], beta[:k + 1], sigma[j]) for k in range(j))
+        D[j] = (fv(sigma[j]) - Qj) / evalrat(sigma[:j], xi[:j], beta[:j + 1], sigma[j])
+    return D
+
+
+def scgendivdiffs(sigma, xi, beta, maxdgr, pff, isfunm=True):
+    """rk_utils.jl:56-66"""
+    if isfunm:
+        return np.vstack([ratnewtoncoeffsm(f, sigma, xi, beta) for f in pff])
+    return np.vstack([ratnewtoncoeffs_scalar(f, sigma, xi, beta) for f in pff])
 
 
 class RKNEP:
@@ -252,7 +277,7 @@ class NleigsSolutionDetails:
 
 def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolvercreator=None, tol=1e-10,
            tollin=None, v=None, errmeasure=None, leja=1, nodes=(), reusefact=1, blksize=20, check_error_every=5,
-           info=None, static=False, return_details=False):
+           info=None, static=False, return_details=False, isfunm=True):
     """method_nleigs.jl:60-377 (isfunm=true; dynamic and static variants, optional solution details).
     With return_details=True the return value is (lam, X, res, NleigsSolutionDetails) as in the reference."""
     import warnings
@@ -295,7 +320,10 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
     xi[maxdgr + 1] = np.nan
 
     rng_ = slice(0, maxdgr + 2)
-    sgdd = scgendivdiffs(sigma[rng_], xi[rng_], beta[rng_], maxdgr, nep.get_fv())
+    if not isfunm and len(np.unique(sigma)) != len(sigma):                          # :142-145
+        raise ValueError("All interpolation nodes must be distinct when no matrix functions are used for computing "
+                         "the generalized divided differences.")
+    sgdd = scgendivdiffs(sigma[rng_], xi[rng_], beta[rng_], maxdgr, nep.get_fv(), isfunm)
     D = []
     if computeD:
         D.append(constructD(0, P, sgdd))

@@ -310,6 +310,21 @@ def test_nleigs_basic_kat(na):
     assert max(np.linalg.norm(od.compute_Mlincomb(lam[i], X[:, i])) for i in range(len(lam))) < 1e-10
 
 
+def test_nleigs_scalar_isfunm_false(na):
+    """test/nleigs/nleigs_scalar.jl:9-34 on the device path (n = 1, user functions given as callables, divided
+    differences by differencing): 1 eigenvalue with the polynomial approach, 3 with poles; values against the oracle KAT"""
+    import scipy.linalg as sla
+    fsqrt = lambda S: np.sqrt(S + 0j) if np.ndim(S) == 0 else sla.sqrtm(np.asarray(S, dtype=complex))
+    fsin = lambda S: np.sin(2 * (S + 0j)) if np.ndim(S) == 0 else sla.sinm(2 * np.asarray(S, dtype=complex))
+    nep = na.SPMF_NEP([np.array([[0.2]]), np.array([[-0.6]])], [fsqrt, fsin])
+    Sig = np.array([0.01, 4], dtype=complex)
+    lam, X, res = na.nleigs(nep, Sig, maxit=100, v=np.ones(1) + 0j, leja=2, isfunm=False)
+    assert len(lam) == 1 and abs(lam[0] - 1.37036708) < 1e-7
+    lam, X, res = na.nleigs(nep, Sig, Xi=-np.logspace(-6, 5, 10000), maxit=100, v=np.ones(1) + 0j, leja=2, isfunm=False)
+    assert len(lam) == 3 and np.allclose(np.sort(lam.real), [0.02780643, 1.37036708, 3.47695453], atol=1e-7)
+    assert max(abs(0.2 * np.sqrt(l) - 0.6 * np.sin(2 * l)) for l in lam) < 1e-10
+
+
 def test_nleigs_nep_types(na):
     """test/nleigs/nleigs_nep_types.jl:31-46: the same quadratic problem as SPMF_NEP, PEP, PEP + SPMF and
     PEP + LowRankFactorizedNEP -> 4 eigenvalues each, all equal (the custom non-SPMF NEP type is out of scope)"""

@@ -158,6 +158,22 @@ def test_nleigs_basic_static_and_details():
     assert len(lam) == 4 and conv.sum() == 4 and len(set(np.round(np.concatenate([lam, l2[conv]]), 8))) == 4
 
 
+def test_nleigs_scalar_isfunm_false():
+    # test/nleigs/nleigs_scalar.jl:9-34: A(lam) = 0.2 sqrt(lam) - 0.6 sin(2 lam) on [0.01, 4], leja=2, isfunm=false:
+    # polynomial approach -> 1 eigenvalue, fully rational (poles on the negative axis) -> 3 eigenvalues
+    import scipy.linalg as sla
+    from oracle import nleigs as onl
+    fsqrt = lambda S: np.sqrt(S + 0j) if np.ndim(S) == 0 else sla.sqrtm(np.asarray(S, dtype=complex))
+    fsin = lambda S: np.sin(2 * (S + 0j)) if np.ndim(S) == 0 else sla.sinm(2 * np.asarray(S, dtype=complex))
+    nep = neps.SPMF_NEP([np.array([[0.2]]), np.array([[-0.6]])], [fsqrt, fsin])
+    Sig = np.array([0.01, 4], dtype=complex)
+    lam, X, res = onl.nleigs(nep, Sig, maxit=100, v=np.ones(1) + 0j, leja=2, isfunm=False)
+    assert len(lam) == 1 and abs(0.2 * np.sqrt(lam[0]) - 0.6 * np.sin(2 * lam[0])) < 1e-9
+    lam, X, res = onl.nleigs(nep, Sig, Xi=-np.logspace(-6, 5, 10000), maxit=100, v=np.ones(1) + 0j, leja=2, isfunm=False)
+    assert len(lam) == 3 and max(abs(0.2 * np.sqrt(l) - 0.6 * np.sin(2 * l)) for l in lam) < 1e-12
+    assert np.allclose(np.sort(lam.real), [0.02780643, 1.37036708, 3.47695453], atol=1e-7)
+
+
 def test_block_SS_dep0():
     # test/contour_block_SS.jl:9-24: circle, ellipse, JSIAM mode on dep0(3); ||M(lam_1) v_1|| < sqrt(eps)
     nep = gallery.dep0(3)
