@@ -79,6 +79,20 @@ def test_iar_gun_twin_vs_oracle(na):
                 assert 0.1 < a / b < 10
 
 
+def test_transf_shift_and_scale_iar_qdep0(na):
+    """test/transf.jl:44-52 on the device path: the recipe of config C2 (shift_and_scale + iar) on the in-tree sparse SPMF
+    qdep0; residuals evaluated by the ORACLE on the original problem < sqrt(eps); eigenvalues equal the oracle's"""
+    from oracle import gallery as og, neps as oneps, solvers as osol
+    nep3 = na.nep_gallery("qdep0"); o3 = og.qdep0(); n = nep3.n
+    sig, al = -3 + 0.3j, 0.9
+    tr = na.shift_and_scale(nep3, shift=sig, scale=al)
+    lam, V, _ = na.iar(tr, sigma=0, neigs=2, maxit=60, v=np.ones(n))
+    for i in range(2):
+        assert np.linalg.norm(o3.compute_Mlincomb(al * lam[i] + sig, V[:, i])) < np.sqrt(EPS)
+    lo, Vo = osol.iar(oneps.shift_and_scale(o3, shift=sig, scale=al), sigma=0, neigs=2, maxit=60, v=np.ones(n))[:2]
+    _match(lam, lo, 1e-9)
+
+
 def test_tiar_dep0_kat(na):
     # test/tiar.jl:23-39,59-69,86-90 ; src/method_tiar.jl:37-45
     from oracle import gallery as og, solvers as osol

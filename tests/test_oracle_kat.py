@@ -131,6 +131,17 @@ def test_qdep0_quasinewton_history():
     assert hist[0][1] == pytest.approx(ref[0][0], rel=1e-14)   # pure sparse Mlincomb + Frobenius norms
 
 
+def test_transf_shift_and_scale_iar_qdep0():
+    # test/transf.jl:44-52: iar on shift_and_scale(qdep0, shift=-3+0.3i, scale=0.9); the pairs mapped back,
+    # (0.9 lam - 3 + 0.3i, v), are eigenpairs of the ORIGINAL sparse SPMF to sqrt(eps)
+    nep3 = gallery.qdep0(); n = nep3.size(1)
+    sig, al = -3 + 0.3j, 0.9
+    tr = neps.shift_and_scale(nep3, shift=sig, scale=al)
+    lam, V = solvers.iar(tr, sigma=0, neigs=2, maxit=60, v=np.ones(n))[:2]
+    for i in range(2):
+        assert np.linalg.norm(nep3.compute_Mlincomb(al * lam[i] + sig, V[:, i])) < np.sqrt(EPS)
+
+
 def test_nleigs_basic_static_and_details():
     # test/nleigs/nleigs_basic.jl:28-73: static variant, return_details, complex matrices / start vector
     import warnings
