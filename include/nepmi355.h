@@ -133,6 +133,10 @@ int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
  * (passes, 2*breakdown + another_pass_wanted). */
 int32_t nep_orth_dev(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, const int64_t* d_active_rows,
                      nep_cdouble* dw, nep_cdouble* d_out, int32_t method, nep_stream stream);
+/* h = V^H w for a rows x k block (w untouched, k host results, synchronous): the products W^H (A_i v) behind
+ * set_projectmatrices! / expand_projectmatrices! of Proj_SPMF_NEP (src/NEPTypes.jl:724-790) and Gram matrices. */
+int32_t nep_gemv_h(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, const nep_cdouble* dw,
+                   nep_cdouble* h_h, nep_stream stream);
 
 /* ---- K7 tall-skinny GEMM on the FP64 matrix cores --------------------------------------
  * Y = Z * B,  Z: rows x k (ldz, device), B: k x p (host, column-major, ldb), Y: rows x p.

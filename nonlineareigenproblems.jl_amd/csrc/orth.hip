@@ -329,3 +329,28 @@ extern "C" int32_t nep_orth_dev(const nep_cdouble* dV, int64_t ldv, int64_t rows
     LAUNCHCHK();
     return NEP_OK;
 }
+
+// h = V^H w  (rows x k block, no update of w): the projection products W^H (A_i v) of Proj_SPMF_NEP
+// (src/NEPTypes.jl:724-790) and Gram matrices.  Synchronous (k host results).
+extern "C" int32_t nep_gemv_h(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, const nep_cdouble* dw,
+                              nep_cdouble* h_h, nep_stream stream) {
+    ARGCHK(dV && dw && h_h);
+    ARGCHK(rows > 0 && k >= 1 && ldv >= rows);
+    hipStream_t st = as_stream(stream);
+    const int nchunks = (int)((rows + DOT_RB - 1) / DOT_RB);
+    size_t off_h = (size_t)nchunks * k * sizeof(cplx);
+    int rc = g_orth_scratch.ensure(off_h + (size_t)k * sizeof(cplx));
+    if (rc) return rc;
+    cplx* d_ph = (cplx*)g_orth_scratch.dptr;
+    cplx* d_h = (cplx*)((char*)g_orth_scratch.dptr + off_h);
+    hipLaunchKernelGGL(k_orth_dots, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, (const cplx*)dV, ldv, rows,
+                       (int)k, (const int64_t*)nullptr, (const cplx*)dw, d_ph);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_h);
+    LAUNCHCHK();
+    std::vector<nep_cdouble> tmp(k);
+    HIPCHK(hipMemcpyAsync(tmp.data(), d_h, (size_t)k * sizeof(cplx), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int j = 0; j < k; ++j) h_h[j] = tmp[j];
+    return NEP_OK;
+}

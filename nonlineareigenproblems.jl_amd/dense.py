@@ -81,6 +81,26 @@ def orthogonalize_and_normalize_dev(V, w, k, out, rows=None, ldv=None, active_de
                            c_vp(w.data_ptr()), c_vp(out.data_ptr()), _orth_code(method), stream_ptr()))
 
 
+def gemv_h(V, w, k, rows=None, ldv=None):
+    """h = V[:, :k]^H w (host result); V: device (cols, ldv) tensor = column-major block, w: device vector"""
+    if rows is None:
+        rows = w.numel()
+    if ldv is None:
+        ldv = V.shape[-1]
+    h = np.empty(k, dtype=np.complex128)
+    check(lib.nep_gemv_h(c_vp(V.data_ptr()), ldv, rows, k, c_vp(w.data_ptr()), hptr(h), stream_ptr()))
+    return h
+
+
+def gram_h(W, Y, k, p, rows, ldw=None, ldy=None):
+    """G = W[:, :k]^H Y[:, :p] (k x p, host) column by column with gemv_h (W is streamed once per column of Y)"""
+    ldy = Y.shape[-1] if ldy is None else ldy
+    G = np.empty((k, p), dtype=np.complex128)
+    for j in range(p):
+        G[:, j] = gemv_h(W, Y[j], k, rows=rows, ldv=ldw)
+    return G
+
+
 def nrm2(x, length=None):
     out = c_dbl(0.0)
     check(lib.nep_nrm2(length if length is not None else x.numel(), c_vp(x.data_ptr()), C.byref(out), stream_ptr()))

@@ -34,9 +34,7 @@ EPS = np.finfo(float).eps
 
 def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
         errmeasure=None, sigma=0.0, gamma=1.0, v=None, logger=0, check_error_every=1, proj_solve=False,
-        errhist=None, timers=None, return_device=False):
-    if proj_solve:
-        raise NotImplementedError("proj_solve=true (inner_solve on the projected NEP) is out of scope (SURVEY.md section 8f)")
+        errhist=None, timers=None, return_device=False, inner_solver_method=None):
     n = nep.size(1); m = int(maxit)
     sigma = complex(sigma); gamma = complex(gamma)
     if linsolvercreator is None:
@@ -72,7 +70,14 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     # worker waits for, the residual norms of the Ritz pairs come back the same way (nep_resid_batch_dev) -- the host
     # enqueues step k+1.. while the device is still executing step k.  `timers` (instrumented run), MGS and
     # NEP_IAR_SYNC=1 use the step-synchronous loop; both produce the same iterates.
-    use_async = timers is None and dense._orth_code(orthmethod) in (0, 1) and not os.environ.get("NEP_IAR_SYNC")
+    use_async = (timers is None and dense._orth_code(orthmethod) in (0, 1) and not os.environ.get("NEP_IAR_SYNC")
+                 and not proj_solve)
+    pnep = None
+    if proj_solve:                                       # method_iar.jl:89-92
+        from .projection import create_proj_NEP, inner_solve, DefaultInnerSolver
+        pnep = create_proj_NEP(nep, maxsize=min(n, m + 1))
+        if inner_solver_method is None:
+            inner_solver_method = DefaultInnerSolver()
     if use_async:
         active_d = torch.from_numpy(active).to("cuda")
         Hdev = torch.zeros((m, m + 2), dtype=CDT, device="cuda")
@@ -143,18 +148,39 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
         (D, Z), t_eig = fut.result()
         tm["host_eig"] += t_eig
         t4 = time.perf_counter()
-        QTl = dense.gemm_ts(V, Z, rowmajor=True, k=kc, rows=n, ldz=ldv)       # (n, kc) row-major
         laml = sigma + gamma / D
+        if proj_solve:
+            # method_iar.jl:118-131: orthonormal basis QQ of span(V[0:n, 0:kc]) (CholQR2 on the device: Gram matrix by
+            # the K6 dots kernel, triangular scaling by K7), Galerkin projection, inner solve started from RR*Z
+            # (rank revealing: eigen-decomposition of the Gram matrix, directions below 1e-13 of the largest are dropped
+            # -- the first-block rows of the Krylov basis become numerically dependent, and kc may exceed n)
+            R_tot = np.eye(kc, dtype=complex)
+            Qd = V; ldq = ldv; kq = kc
+            for _ in range(2):
+                G = dense.gram_h(Qd, Qd, kq, kq, rows=n, ldw=ldq, ldy=ldq)
+                wg, Ug = np.linalg.eigh((G + G.conj().T) / 2)
+                keep = wg > 1e-13 * wg[-1]
+                T = Ug[:, keep] / np.sqrt(wg[keep])[None, :]                       # kq x r
+                Rc = (np.sqrt(wg[keep])[:, None] * Ug[:, keep].conj().T)           # r x kq,  block = Q Rc
+                Qd = dense.gemm_ts(Qd, T, k=kq, rows=n, ldz=ldq)                   # (r, n) column-major
+                ldq = n; kq = int(np.sum(keep))
+                R_tot = Rc @ R_tot
+            pnep.set_projectmatrices(Qd, Qd)
+            lamp, Qp = inner_solve(inner_solver_method, pnep, V=R_tot @ Z, lamv=laml.copy(), neigs=kc, sigma=np.mean(laml))
+            laml = np.asarray(lamp); Qp = np.asarray(Qp)
+            QTl = dense.gemm_ts(Qd, Qp, rowmajor=True, k=kq, rows=n, ldz=n)
+        else:
+            QTl = dense.gemm_ts(V, Z, rowmajor=True, k=kc, rows=n, ldz=ldv)       # (n, kc) row-major
         sync(); t5 = time.perf_counter()
-        e = estimate_errors(errmeasure, laml, QTl)
+        e = estimate_errors(errmeasure, laml, QTl) if len(laml) else np.zeros(0)
         t6 = time.perf_counter()
         tm["ritz"] += t5 - t4; tm["resid"] += t6 - t5
-        err[kc - 1, :kc] = e
+        ne = min(len(e), m)
         conv = int(np.sum(e < tol))
         idxl = np.argsort(e, kind="stable")
-        err[kc - 1, :kc] = e[idxl]
+        err[kc - 1, :ne] = e[idxl][:ne]
         if errhist is not None:
-            errhist.append(err[kc - 1, :kc].copy())
+            errhist.append(err[kc - 1, :ne].copy())
         if kc == m or conv >= neigs:
             nrof = int(min(len(laml), neigs))
             laml = laml[idxl[:nrof]]

@@ -154,3 +154,49 @@ def quasinewton(nep, errmeasure=None, tol=EPS * 100, maxit=100, lam=0.0, v=None,
         dense.axpy(1.0, dv, vd)
     raise NoConvergenceException(lam, to_host(vd.reshape(1, n))[:, 0], err,
                                  "Number of iterations exceeded. maxit=%d." % maxit)
+
+
+def augnewton(nep, errmeasure=None, tol=EPS * 100, maxit=30, lam=0.0, v=None, c=None, logger=0, linsolvercreator=None,
+              armijo_factor=1, armijo_max=5):
+    """Augmented Newton (method_newton.jl:262-345): a NEW factorisation of M(lam_k) every step (BackslashLinSolver
+    semantics through create_linsolver), vectors of length n only.  c = 0 selects v/||v||^2 as normalisation vector."""
+    n = nep.size(1)
+    lam = complex(lam)
+    if v is None:
+        v = np.random.randn(n)
+    vh = np.asarray(v, dtype=np.complex128).copy()
+    ch = vh.copy() if c is None else np.asarray(c, dtype=np.complex128).copy()
+    if errmeasure is None:
+        errmeasure = DefaultErrmeasure(nep)
+    if linsolvercreator is None:
+        linsolvercreator = DefaultLinSolverCreator()
+    use_v = False
+    if np.linalg.norm(ch) == 0:
+        use_v = True
+        ch = vh / np.linalg.norm(vh) ** 2
+    vh = vh / np.vdot(ch, vh)
+    vd = to_dev(vh)[0]
+    cd = to_dev(ch)[0]
+    one = np.ones(1)
+    z = torch.empty(n, dtype=CDT, device="cuda")
+    tv = torch.empty(n, dtype=CDT, device="cuda")
+    err = np.inf
+    for k in range(1, maxit + 1):
+        err = estimate_error(errmeasure, lam, vd)
+        if err < tol:
+            return lam, to_host(vd.reshape(1, n))[:, 0]
+        nep.dev.mlincomb(nep.coeff_block(lam, one, 1), vd.reshape(1, n), z)          # z = M'(lam) v
+        linsolver = create_linsolver(linsolvercreator, nep, lam)
+        linsolver.solve_dev(z, out=tv.reshape(1, n))
+        if use_v:
+            nv = dense.nrm2(vd)
+            dense.copy(vd, cd, n); dense.scal(cd, 1.0 / nv ** 2, n)
+        alpha = 1.0 / _dots2(cd, torch.stack([tv, tv]), n)[0]
+        dlam = -alpha
+        dv = tv                                                                        # dv = alpha*tempvec - v
+        dense.scal(dv, alpha, n); dense.axpy(-1.0, vd, dv, n)
+        dlam, dv, j, scaling = armijo_rule(nep, errmeasure, err, lam, vd, dlam, dv, float(armijo_factor), armijo_max)
+        lam += dlam
+        dense.axpy(1.0, dv, vd)
+    raise NoConvergenceException(lam, to_host(vd.reshape(1, n))[:, 0], err,
+                                 "Number of iterations exceeded. maxit=%d." % maxit)

@@ -30,9 +30,7 @@ EPS = np.finfo(float).eps
 
 def tiar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
          errmeasure=None, sigma=0.0, gamma=1.0, v=None, logger=0, check_error_every=1, proj_solve=False,
-         errhist=None, timers=None, fused=True, return_device=False):
-    if proj_solve:
-        raise NotImplementedError("proj_solve=true is out of scope (SURVEY.md section 8f)")
+         errhist=None, timers=None, fused=True, return_device=False, inner_solver_method=None):
     n = nep.size(1); m = int(maxit)
     sigma = complex(sigma); gamma = complex(gamma)
     if n < m:
@@ -68,6 +66,13 @@ def tiar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     z = torch.empty(n, dtype=CDT, device="cuda")
     conv_eig_hist = np.zeros(m + 1, dtype=int)
     lam = np.zeros(0, dtype=np.complex128); QT = None; idx = np.zeros(0, dtype=int)
+    pnep = None
+    if proj_solve:                                           # method_tiar.jl:104-106
+        from .projection import create_proj_NEP, inner_solve, DefaultInnerSolver
+        pnep = create_proj_NEP(nep, maxsize=min(n, m + 1))
+        if inner_solver_method is None:
+            inner_solver_method = DefaultInnerSolver()
+        err = np.full((m + 1, m + 4), np.nan)
     k = 1; conv_eig = 0
     while k <= m and conv_eig < neigs:
         t0 = time.perf_counter()
@@ -108,18 +113,28 @@ def tiar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
         if (k % check_error_every == 0) or (k == m):
             D, W = sla.eig(H[:k, :k])
             t5 = time.perf_counter()
-            QT = dense.gemm_ts(Z, a[0, :k, :k].T @ W, rowmajor=True, k=k, rows=n, ldz=n)
             lam = sigma + gamma / D
+            if proj_solve:
+                # method_tiar.jl:192-207: Galerkin projection on span(Z_k) (Z is orthonormal), inner solve, lift back
+                pnep.set_projectmatrices(Z[:k], Z[:k])
+                lamp, Qp = inner_solve(inner_solver_method, pnep, lamv=lam.copy(), neigs=len(lam) + 3, sigma=sigma,
+                                       tol=tol / 10)
+                II = np.argsort(abs(lamp - sigma), kind="stable")
+                lam = np.asarray(lamp)[II]; Qp = np.asarray(Qp)[:, II]
+                QT = dense.gemm_ts(Z, Qp, rowmajor=True, k=k, rows=n, ldz=n)
+            else:
+                QT = dense.gemm_ts(Z, a[0, :k, :k].T @ W, rowmajor=True, k=k, rows=n, ldz=n)
             sync(); t6 = time.perf_counter()
-            e = estimate_errors(errmeasure, lam, QT)
+            e = estimate_errors(errmeasure, lam, QT) if len(lam) else np.zeros(0)
             t7 = time.perf_counter()
             tm["host_eig"] += t5 - t4; tm["ritz"] += t6 - t5; tm["resid"] += t7 - t6
-            err[k - 1, :k] = e
+            ne = len(e)
+            err[k - 1, :ne] = e
             conv_eig = int(np.sum(e < tol))
             idx = np.argsort(e, kind="stable")
-            err[k - 1, :k] = e[idx]
+            err[k - 1, :ne] = e[idx]
             if errhist is not None:
-                errhist.append(err[k - 1, :k].copy())
+                errhist.append(err[k - 1, :ne].copy())
             if k == m or conv_eig >= neigs:
                 nrof = int(min(len(lam), neigs))
                 lam = lam[idx[:nrof]]

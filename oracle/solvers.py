@@ -174,9 +174,8 @@ def _eig(H):
 
 def iar(nep, orthmethod=dgks, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
         errmeasure=None, sigma=0.0, gamma=1.0, v=None, check_error_every=1, errhist=None,
-        timers=None):
-    """method_iar.jl:47-184 (proj_solve=false path).  F-ordered V so that
-    reshape(...) follows Julia's column-major semantics."""
+        timers=None, proj_solve=False, inner_solver_method=None):
+    """method_iar.jl:47-184.  F-ordered V so that reshape(...) follows Julia's column-major semantics."""
     import time
     n = nep.size(1); m = maxit
     sigma = complex(sigma)
@@ -215,16 +214,24 @@ def iar(nep, orthmethod=dgks, maxit=30, linsolvercreator=None, tol=EPS * 10000, 
             D, Z = _eig(H[:k, :k])
             Q = V[:n, :k] @ Z
             lam = sigma + gamma / D
+            if proj_solve:                                    # method_iar.jl:118-131
+                QQ, RR = np.linalg.qr(V[:n, :k])
+                pnep = Proj_SPMF_NEP(nep)
+                pnep.set_projectmatrices(QQ, QQ)
+                lam, Qproj = inner_solve(inner_solver_method, pnep, V=RR @ Z, lamv=lam.copy(), neigs=k,
+                                         sigma=np.mean(lam))
+                Q = QQ @ Qproj
             t4 = time.perf_counter()
             conv_eig = 0
-            err[k - 1, :k] = [errmeasure(lam[s], Q[:, s]) for s in range(k)]
+            ne = min(len(lam), m)
+            err[k - 1, :ne] = [errmeasure(lam[s], Q[:, s]) for s in range(ne)]
             t5 = time.perf_counter()
             tm["ritz"] += t4 - t3; tm["resid"] += t5 - t4
             if errhist is not None:
-                errhist.append(np.sort(err[k - 1, :k]).copy())
-            conv_eig = int(np.sum(err[k - 1, :k] < tol))
-            idx = np.argsort(err[k - 1, :k], kind="stable")
-            err[k - 1, :k] = err[k - 1, idx]
+                errhist.append(np.sort(err[k - 1, :ne]).copy())
+            conv_eig = int(np.sum(err[k - 1, :ne] < tol))
+            idx = np.argsort(err[k - 1, :ne], kind="stable")
+            err[k - 1, :ne] = err[k - 1, idx]
             if k == m or conv_eig >= neigs:
                 nrof = int(min(len(lam), neigs))
                 lam = lam[idx[:nrof]]
@@ -239,8 +246,9 @@ def iar(nep, orthmethod=dgks, maxit=30, linsolvercreator=None, tol=EPS * 10000, 
 
 
 def tiar(nep, orthmethod=dgks, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
-         errmeasure=None, sigma=0.0, gamma=1.0, v=None, check_error_every=1, errhist=None):
-    """method_tiar.jl:53-257 (proj_solve=false path). Note the Julia aliases f=g, ff=f
+         errmeasure=None, sigma=0.0, gamma=1.0, v=None, check_error_every=1, errhist=None, proj_solve=False,
+         inner_solver_method=None):
+    """method_tiar.jl:53-257. Note the Julia aliases f=g, ff=f
     (:147,:164): updates of f also change g; g is rebuilt every step."""
     n = nep.size(1); m = maxit
     sigma = complex(sigma)
@@ -260,7 +268,7 @@ def tiar(nep, orthmethod=dgks, maxit=30, linsolvercreator=None, tol=EPS * 10000,
     y = np.zeros((n, m + 1), dtype=complex, order="F")
     alpha = (complex(gamma) ** np.arange(m + 1)).astype(complex); alpha[0] = 0
     M0inv = linsolvercreator.create_linsolver(nep, sigma)
-    err = np.full((m + 1, m + 1), np.nan)
+    err = np.full((m + 1, m + 4), np.nan)
     lam = np.zeros(m + 1, dtype=complex); Q = np.zeros((n, m + 1), dtype=complex)
     Z[:, 0] = v / np.linalg.norm(v)
     a[0, 0, 0] = 1
@@ -300,13 +308,22 @@ def tiar(nep, orthmethod=dgks, maxit=30, linsolvercreator=None, tol=EPS * 10000,
             VV = Z[:, :k] @ a[0, :k, :k].T
             Q = VV @ W
             lam = sigma + gamma / D
+            if proj_solve:                                    # method_tiar.jl:192-207
+                pnep = Proj_SPMF_NEP(nep)
+                pnep.set_projectmatrices(Z[:, :k], Z[:, :k])
+                lamp, Qproj = inner_solve(inner_solver_method, pnep, lamv=lam.copy(), neigs=len(lam) + 3, sigma=sigma,
+                                          tol=tol / 10)
+                II = np.argsort(abs(lamp - sigma), kind="stable")
+                lam = lamp[II]; Qproj = Qproj[:, II]
+                Q = Z[:, :k] @ Qproj
             conv_eig = 0
-            err[k - 1, :k] = [errmeasure(lam[s], Q[:, s]) for s in range(k)]
+            ne = len(lam)
+            err[k - 1, :ne] = [errmeasure(lam[s], Q[:, s]) for s in range(ne)]
             if errhist is not None:
-                errhist.append(np.sort(err[k - 1, :k]).copy())
-            conv_eig = int(np.sum(err[k - 1, :k] < tol))
-            idx = np.argsort(err[k - 1, :k], kind="stable")
-            err[k - 1, :k] = err[k - 1, idx]
+                errhist.append(np.sort(err[k - 1, :ne]).copy())
+            conv_eig = int(np.sum(err[k - 1, :ne] < tol))
+            idx = np.argsort(err[k - 1, :ne], kind="stable")
+            err[k - 1, :ne] = err[k - 1, idx]
             if k == m or conv_eig >= neigs:
                 nrof = int(min(len(lam), neigs))
                 lam = lam[idx[:nrof]]
@@ -562,3 +579,45 @@ def contour_block_SS(nep, tol=np.sqrt(EPS), sigma=0.0, linsolvercreator=None, ne
     if info is not None:
         info.update(mprime=mprime, SS=SS, Mhat=Mhat)
     return sigma + factor * xi, Vout
+
+
+# ----------------------------------------------------------------------------------
+class Proj_SPMF_NEP:
+    """src/NEPTypes.jl:647-800: N(lam) = W^H M(lam) V as the SPMF with B_i = W^H A_i V"""
+
+    def __init__(self, orgnep):
+        self.orgnep = orgnep
+        self.nep_proj = None
+
+    def set_projectmatrices(self, W, V):
+        from . import neps
+        WH = np.asarray(W).conj().T
+        self.nep_proj = neps.SPMF_NEP([np.asarray(WH @ (A @ V)) for A in self.orgnep.get_Av()], self.orgnep.get_fv())
+
+    def size(self, d=None):
+        return self.nep_proj.size(d)
+
+
+class IARInnerSolver:
+    """src/inner_solver.jl:133-144,308-347"""
+
+    def __init__(self, tol=1e-13, maxit=80, normalize_DEPs=False):
+        self.tol, self.maxit, self.normalize_DEPs = tol, maxit, normalize_DEPs
+
+
+def inner_solve(solver, pnep, lamv=None, V=None, neigs=10, sigma=0.0, tol=None):
+    """src/inner_solver.jl:308-347 (IARInnerSolver with iar, starting vector ones; partial results on NoConvergence)"""
+    from . import neps
+    if solver is None:
+        solver = IARInnerSolver()
+    nep = pnep.nep_proj
+    k = nep.size(1)
+    if isinstance(pnep.orgnep, neps.DEP) and solver.normalize_DEPs:
+        AA = nep.get_Av()
+        nep = neps.DEP([np.linalg.solve(AA[0], AA[1 + i]) for i in range(len(AA) - 1)], pnep.orgnep.tauv)
+    try:
+        out = iar(nep, sigma=sigma, neigs=neigs, tol=solver.tol, maxit=solver.maxit, v=np.ones(k))
+        return out[0], out[1]
+    except NoConvergenceException as e:
+        Q = np.zeros((k, 0), dtype=complex) if e.v is None else np.asarray(e.v).reshape(k, -1)
+        return np.asarray(e.lam, dtype=complex).reshape(-1), Q

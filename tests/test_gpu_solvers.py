@@ -93,6 +93,62 @@ def test_transf_shift_and_scale_iar_qdep0(na):
     _match(lam, lo, 1e-9)
 
 
+def test_augnewton_and_newton_inner_solver(na):
+    """augnewton (method_newton.jl:262-345) from the start of test/newton.jl:16-17 reaches the dep0 eigenvalue that resinv
+    finds; NewtonInnerSolver on a projected problem (test/inner_solves.jl:31) returns eigenpairs of the projected NEP"""
+    from oracle import gallery as og
+    dep = na.nep_gallery("dep0"); od = og.dep0()
+    lam, v = na.augnewton(dep, lam=0.0, v=np.ones(5), maxit=30)
+    assert abs(lam - (-0.15955391823299253)) < 1e-10
+    assert np.linalg.norm(od.compute_Mlincomb(lam, v)) / np.linalg.norm(v) < 1e-12
+    nep = na.nep_gallery("dep0", 50)
+    pnep = na.create_proj_NEP(nep)
+    rng = np.random.default_rng(0)
+    Q, _ = np.linalg.qr(rng.standard_normal((50, 6)))
+    pnep.set_projectmatrices(Q, Q)
+    lamv, Vp = na.inner_solve(na.NewtonInnerSolver(), pnep, lamv=np.array([0.0, 1.0]) + 0j, V=np.ones((6, 2)), tol=EPS * 100)
+    Mp = lambda l: pnep.compute_Mder(l)
+    assert min(np.linalg.norm(Mp(lamv[j]) @ Vp[:, j]) / np.linalg.norm(Vp[:, j]) for j in range(2)) < 1e-9
+
+
+def test_projection_and_proj_solve(na):
+    """Proj_SPMF_NEP (NEPTypes.jl:724-790): set / expand project matrices against NumPy on a sparse SPMF; then
+    proj_solve=true in tiar (test/tiar.jl:70-84 at n=200) and iar (test/iar.jl:29-33) with IARInnerSolver: same eigenvalues
+    as the oracle, residuals below the reference's thresholds"""
+    from oracle import gallery as og, solvers as osol
+    nep = na.nep_gallery("qdep0"); n = nep.n
+    rng = np.random.default_rng(1)
+    V = rng.standard_normal((n, 4)) + 1j * rng.standard_normal((n, 4)); W = rng.standard_normal((n, 4)) + 0j
+    pnep = na.create_proj_NEP(nep)
+    pnep.set_projectmatrices(W[:, :3], V[:, :3])
+    Bref = [W[:, :3].conj().T @ (A @ V[:, :3]) for A in nep.get_Av()]
+    for B, Br in zip(pnep.get_Av(), Bref):
+        assert np.linalg.norm(B - Br) <= 1e-12 * np.linalg.norm(Br)
+    pnep.expand_projectmatrices(W, V)
+    Bref = [W.conj().T @ (A @ V) for A in nep.get_Av()]
+    for B, Br in zip(pnep.get_Av(), Bref):
+        assert B.shape == (4, 4) and np.linalg.norm(B - Br) <= 1e-12 * np.linalg.norm(Br)
+    lam0 = 0.3 + 0.1j
+    M = sum(f.derivs(lam0, 1)[0] * A for f, A in zip(nep.get_fv(), nep.get_Av()))
+    assert np.linalg.norm(pnep.compute_Mder(lam0) - W.conj().T @ (M @ V)) <= 1e-11 * np.linalg.norm(M.toarray() if hasattr(M, "toarray") else M)
+    # tiar with projected extraction
+    m = 200
+    depp = na.nep_gallery("dep0", m); odep = og.dep0(m)
+    nn = np.linalg.norm(odep.compute_Mder(0), 2)
+    errm = lambda l, v: np.linalg.norm(odep.compute_Mlincomb(l, np.asarray(v))) / nn
+    kw = dict(sigma=0, gamma=3, neigs=3, v=np.ones(m), maxit=50, tol=np.sqrt(EPS), check_error_every=3, proj_solve=True)
+    lam, Q = na.tiar(depp, inner_solver_method=na.IARInnerSolver(), errmeasure=errm, **kw)[:2]
+    lo, Qo = osol.tiar(odep, inner_solver_method=osol.IARInnerSolver(), errmeasure=errm, **kw)[:2]
+    assert len(lam) == 3 and errm(lam[0], Q[:, 0]) < np.sqrt(EPS) * 10
+    _match(lam, lo, 1e-8)
+    # iar with projected extraction
+    dep = na.nep_gallery("dep0"); od = og.dep0()
+    lam, Q, _ = na.iar(dep, sigma=1.1, neigs=5, v=np.ones(5), maxit=100, tol=EPS * 100, errmeasure=na.ResidualErrmeasure(dep),
+                       proj_solve=True, inner_solver_method=na.IARInnerSolver())
+    assert len(lam) == 5
+    assert max(np.linalg.norm(od.compute_Mlincomb(lam[i], Q[:, i])) / np.linalg.norm(Q[:, i]) for i in range(5)) < EPS * 100
+
+
 def test_tiar_dep0_kat(na):
     # test/tiar.jl:23-39,59-69,86-90 ; src/method_tiar.jl:37-45
     from oracle import gallery as og, solvers as osol

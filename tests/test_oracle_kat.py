@@ -142,6 +142,24 @@ def test_transf_shift_and_scale_iar_qdep0():
         assert np.linalg.norm(nep3.compute_Mlincomb(al * lam[i] + sig, V[:, i])) < np.sqrt(EPS)
 
 
+def test_tiar_iar_proj_solve():
+    # test/tiar.jl:70-84 (dep0 of reduced size 200 instead of 1000) and test/iar.jl:29-33: Ritz extraction by projection +
+    # inner solve (IARInnerSolver; the reference's default for a DEP is iar_chebyshev, which is not restated)
+    n = 200
+    depp = gallery.dep0(n)
+    nn = np.linalg.norm(depp.compute_Mder(0), 2)
+    errm = lambda l, v: np.linalg.norm(depp.compute_Mlincomb(l, v)) / nn
+    lam, Q = solvers.tiar(depp, sigma=0, gamma=3, neigs=3, v=np.ones(n), maxit=50, tol=np.sqrt(EPS), check_error_every=3,
+                          proj_solve=True, inner_solver_method=solvers.IARInnerSolver(), errmeasure=errm)[:2]
+    assert len(lam) == 3 and errm(lam[0], Q[:, 0]) < np.sqrt(EPS) * 10
+    dep = gallery.dep0()
+    lam, Q = solvers.iar(dep, sigma=1.1, neigs=5, v=np.ones(5), maxit=100, tol=EPS * 100,
+                         errmeasure=solvers.ResidualErrmeasure(dep), proj_solve=True,
+                         inner_solver_method=solvers.IARInnerSolver())[:2]
+    assert len(lam) == 5
+    assert max(np.linalg.norm(dep.compute_Mlincomb(lam[i], Q[:, i])) / np.linalg.norm(Q[:, i]) for i in range(5)) < EPS * 100
+
+
 def test_nleigs_basic_static_and_details():
     # test/nleigs/nleigs_basic.jl:28-73: static variant, return_details, complex matrices / start vector
     import warnings
