@@ -137,6 +137,11 @@ int32_t nep_orth_dev(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k
  * set_projectmatrices! / expand_projectmatrices! of Proj_SPMF_NEP (src/NEPTypes.jl:724-790) and Gram matrices. */
 int32_t nep_gemv_h(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, const nep_cdouble* dw,
                    nep_cdouble* h_h, nep_stream stream);
+/* K9  C = W^H Y (k x p, host, column-major) for two ROW-major device blocks WT (rows x k), YT (rows x p), k, p <= 256:
+ * all of B_i = W^H (A_i V) at once (YT from nep_resid_block with F = e_i 1^T), FP64 MFMA with the row index as contraction
+ * index, per-workgroup partial tiles summed in a fixed order.  Synchronous. */
+int32_t nep_gemm_h_rm(const nep_cdouble* dWT, int64_t ldw, const nep_cdouble* dYT, int64_t ldy, int64_t rows,
+                      int32_t k, int32_t p, nep_cdouble* h_C, nep_stream stream);
 
 /* ---- K7 tall-skinny GEMM on the FP64 matrix cores --------------------------------------
  * Y = Z * B,  Z: rows x k (ldz, device), B: k x p (host, column-major, ldb), Y: rows x p.

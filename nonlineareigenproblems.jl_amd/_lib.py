@@ -66,6 +66,7 @@ SIGNATURES = {
     "nep_orth": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, P(c_dbl), c_i32, P(c_i32), c_vp],
     "nep_orth_dev": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp],
     "nep_gemv_h": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp],
+    "nep_gemm_h_rm": [c_vp, c_i64, c_vp, c_i64, c_i64, c_i32, c_i32, c_vp, c_vp],
     "nep_gemm_ts": [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp],
     "nep_gemm_ts_dev": [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp],
     "nep_lu_create": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, P(c_vp)],

@@ -12,6 +12,7 @@
 // fragment with one conflict-free 512-byte LDS read.  Z is streamed from HBM exactly once; the
 // accumulators for ALL p output columns of a 16-row strip live in registers.
 #include "common.h"
+#include <cstring>
 #include <vector>
 #include <algorithm>
 
@@ -273,5 +274,120 @@ extern "C" int32_t nep_gemm_ts_dev(const nep_cdouble* dZ, int64_t ldz, int64_t r
         if (rc) return rc;
         off += (size_t)nks * nt * 128;
     }
+    return NEP_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K9  C = W^H Y  (k x p) for two tall row-major blocks WT (rows x k), YT (rows x p): the reduction GEMM behind
+// B_i = W^H (A_i V) of Proj_SPMF_NEP (src/NEPTypes.jl:733) and Gram matrices.  Row-major operands ARE the MFMA
+// operand layout of v_mfma_f64_16x16x4_f64 with the row index as contraction index: lane l loads
+// WT[r0 + (l>>4)][i0 + (l&15)] (A operand, 16 contiguous complex per row) and YT[r0 + (l>>4)][j0 + (l&15)] (B operand),
+// no LDS staging.  conj(a) b = (ar br + ai bi) + i (ar bi - ai br): four real MFMAs per 4-row step and 16 x 16 tile.
+// One wave per tile, the waves of a workgroup share the rows through L1/L2; per-workgroup partial tiles are summed
+// in a fixed order by k_gemm_h_reduce (deterministic).  Bound: HBM (16 rows (k+p) bytes) for k, p <~ 64, MFMA above.
+__global__ __launch_bounds__(1024) void k_gemm_h_rm(const cplx* __restrict__ WT, int64_t ldw, const cplx* __restrict__ YT,
+                                                    int64_t ldy, int64_t rows, int k, int p, int rows_per_wg,
+                                                    cplx* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int ti = (k + 15) / 16, tj = (p + 15) / 16;
+    const int64_t rbeg = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t rend = rbeg + rows_per_wg < rows ? rbeg + rows_per_wg : rows;
+    const int li = lane & 15, lk = lane >> 4;
+    cplx* out = partial + (int64_t)blockIdx.x * ti * tj * 256;
+    for (int t = wv; t < ti * tj; t += nw) {
+        const int i0 = (t / tj) * 16, j0 = (t % tj) * 16;
+        const bool ia = i0 + li < k, jb = j0 + li < p;
+        d4 cre = {0.0, 0.0, 0.0, 0.0}, cim = {0.0, 0.0, 0.0, 0.0};
+        // 16 rows per trip: the 8 operand loads are issued before the 16 MFMAs that consume them
+        for (int64_t r = rbeg; r < rend; r += 16) {
+            cplx a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int64_t rr = r + 4 * u + lk;
+                a[u] = cmake(0.0, 0.0); b[u] = cmake(0.0, 0.0);
+                if (rr < rend) {
+                    if (ia) a[u] = WT[rr * ldw + i0 + li];
+                    if (jb) b[u] = YT[rr * ldy + j0 + li];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                cre = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b[u].x, cre, 0, 0, 0);
+                cim = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].x, b[u].y, cim, 0, 0, 0);
+                cre = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u].y, b[u].y, cre, 0, 0, 0);
+                cim = __builtin_amdgcn_mfma_f64_16x16x4f64(-a[u].y, b[u].x, cim, 0, 0, 0);
+            }
+        }
+        // D[row = (l>>4) + 4q][col = l&15]
+        cplx* tile = out + (int64_t)t * 256;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tile[(lk + 4 * q) * 16 + li] = cmake(cre[q], cim[q]);
+    }
+}
+
+// C[i + j*k] = sum_b partial[b][tile(i,j)][i%16][j%16]   (column-major k x p).  One workgroup per 16 x 16 tile and
+// split of the partial range: 4 groups of 256 threads (one per tile element, coalesced 4 KB reads per partial), fixed
+// summation order; the splits are summed by the same kernel in a second call (nsplit = 1).
+__global__ __launch_bounds__(1024) void k_gemm_h_reduce(int nb, int ntile, int k, int p, int tj,
+                                                        const cplx* __restrict__ partial, int64_t pstride,
+                                                        cplx* __restrict__ out, int final_layout) {
+    __shared__ cplx sm[4][256];
+    const int t = blockIdx.x, sp = blockIdx.y, nsp = gridDim.y;
+    const int e = threadIdx.x & 255, g = threadIdx.x >> 8;
+    const int b0 = (int)((int64_t)nb * sp / nsp), b1 = (int)((int64_t)nb * (sp + 1) / nsp);
+    cplx acc = cmake(0.0, 0.0);
+    for (int b = b0 + g; b < b1; b += 4) acc = cadd(acc, partial[(int64_t)b * pstride + (int64_t)t * 256 + e]);
+    sm[g][e] = acc;
+    __syncthreads();
+    if (g == 0) {
+        const cplx v = cadd(cadd(sm[0][e], sm[1][e]), cadd(sm[2][e], sm[3][e]));
+        if (!final_layout) {
+            out[((int64_t)sp * ntile + t) * 256 + e] = v;
+        } else {
+            const int i = (t / tj) * 16 + e / 16, j = (t % tj) * 16 + e % 16;
+            if (i < k && j < p) out[i + (int64_t)j * k] = v;
+        }
+    }
+}
+
+static thread_local NepScratch g_gemmh_scratch;
+
+extern "C" int32_t nep_gemm_h_rm(const nep_cdouble* dWT, int64_t ldw, const nep_cdouble* dYT, int64_t ldy, int64_t rows,
+                                 int32_t k, int32_t p, nep_cdouble* h_C, nep_stream stream) {
+    ARGCHK(dWT && dYT && h_C);
+    ARGCHK(rows > 0 && k >= 1 && p >= 1 && k <= 256 && p <= 256 && ldw >= k && ldy >= p);
+    hipStream_t st = as_stream(stream);
+    const int ti = (k + 15) / 16, tj = (p + 15) / 16;
+    int rows_per_wg = rows >= 262144 ? 1024 : (rows >= 16384 ? 128 : 64);
+    const int nb = (int)((rows + rows_per_wg - 1) / rows_per_wg);
+    const int ntile = ti * tj;
+    const int nsplit = nb >= 64 ? 16 : 1;
+    const size_t pbytes = (size_t)nb * ntile * 256 * sizeof(cplx);
+    const size_t p2bytes = (size_t)nsplit * ntile * 256 * sizeof(cplx);
+    int rc = g_gemmh_scratch.ensure(pbytes + p2bytes + (size_t)k * p * sizeof(cplx));
+    if (rc) return rc;
+    cplx* partial = (cplx*)g_gemmh_scratch.dptr;
+    cplx* partial2 = (cplx*)((char*)g_gemmh_scratch.dptr + pbytes);
+    cplx* dC = (cplx*)((char*)g_gemmh_scratch.dptr + pbytes + p2bytes);
+    const int nw = std::min(16, ntile);
+    hipLaunchKernelGGL(k_gemm_h_rm, dim3(nb), dim3(64 * nw), 0, st, (const cplx*)dWT, ldw, (const cplx*)dYT, ldy, rows,
+                       (int)k, (int)p, rows_per_wg, partial);
+    LAUNCHCHK();
+    if (nsplit > 1) {
+        hipLaunchKernelGGL(k_gemm_h_reduce, dim3(ntile, nsplit), dim3(1024), 0, st, nb, ntile, (int)k, (int)p, tj,
+                           (const cplx*)partial, (int64_t)ntile * 256, partial2, 0);
+        LAUNCHCHK();
+        hipLaunchKernelGGL(k_gemm_h_reduce, dim3(ntile, 1), dim3(1024), 0, st, nsplit, ntile, (int)k, (int)p, tj,
+                           (const cplx*)partial2, (int64_t)ntile * 256, dC, 1);
+    } else {
+        hipLaunchKernelGGL(k_gemm_h_reduce, dim3(ntile, 1), dim3(1024), 0, st, nb, ntile, (int)k, (int)p, tj,
+                           (const cplx*)partial, (int64_t)ntile * 256, dC, 1);
+    }
+    LAUNCHCHK();
+    std::vector<nep_cdouble> tmp((size_t)k * p);
+    HIPCHK(hipMemcpyAsync(tmp.data(), dC, (size_t)k * p * sizeof(cplx), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    memcpy(h_C, tmp.data(), (size_t)k * p * sizeof(cplx));
     return NEP_OK;
 }

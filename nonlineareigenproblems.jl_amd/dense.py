@@ -101,6 +101,15 @@ def gram_h(W, Y, k, p, rows, ldw=None, ldy=None):
     return G
 
 
+def gemm_h_rm(WT, YT, rows, k, p, ldw=None, ldy=None):
+    """C = W^H Y (k x p, host) for ROW-major device blocks WT (rows, k), YT (rows, p): K9, FP64 MFMA"""
+    ldw = WT.shape[-1] if ldw is None else ldw
+    ldy = YT.shape[-1] if ldy is None else ldy
+    Cm = np.empty((k, p), dtype=np.complex128, order="F")
+    check(lib.nep_gemm_h_rm(c_vp(WT.data_ptr()), ldw, c_vp(YT.data_ptr()), ldy, rows, k, p, hptr(Cm), stream_ptr()))
+    return Cm
+
+
 def nrm2(x, length=None):
     out = c_dbl(0.0)
     check(lib.nep_nrm2(length if length is not None else x.numel(), c_vp(x.data_ptr()), C.byref(out), stream_ptr()))

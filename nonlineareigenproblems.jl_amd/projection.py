@@ -4,10 +4,12 @@ Mirrors `create_proj_NEP`, `Proj_SPMF_NEP`, `set_projectmatrices!`, `expand_proj
 (src/NEPTypes.jl:600-800) and `inner_solve` with `IARInnerSolver` / `NewtonInnerSolver` / `DefaultInnerSolver`
 (src/inner_solver.jl:9-350): N(lam) = W^H M(lam) V = sum_i f_i(lam) B_i with B_i = W^H A_i V.
 
-Device work of a projection: one folded SpMV per (term, basis column) for y = A_i v_j (K1, k = 1) and one
-`nep_gemv_h` (the K6 dots kernel) for the column W^H y of B_i; the k x k matrices B_i come back to the host, where the
-projected problem is an ordinary (dense) SPMF_NEP of this backend.  (A batched W^H (A_i V) = SpMM + MFMA GEMM^H is the
-planned replacement)
+Device work of `set_projectmatrices`: V and W are brought into row-major form once (K7 with B = I), then per term i
+one SpMM Y_i = A_i V over the stacked CSR (`nep_resid_block` with the coefficient block e_i 1^T, the K2 kernel) and one
+reduction GEMM B_i = W^H Y_i on the FP64 matrix cores (K9 `nep_gemm_h_rm`: row-major operands are the MFMA operand
+layout with the row index as contraction index).  `expand_projectmatrices` adds one row and one column with folded
+SpMVs (K1, k = 1) and `nep_gemv_h` (the K6 dots kernel).  The k x k matrices B_i come back to the host, where the
+projected problem is an ordinary (dense) SPMF_NEP of this backend.
 """
 import numpy as np
 import torch
@@ -38,6 +40,8 @@ class Proj_SPMF_NEP:
     def __init__(self, orgnep, maxsize=None):
         if not isinstance(orgnep, AbstractSPMF):
             raise TypeError("create_proj_NEP needs an AbstractSPMF")
+        if type(orgnep).compute_Mlincomb is not AbstractSPMF.compute_Mlincomb:
+            raise NotImplementedError("the operator has terms outside its SPMF matrices (e.g. the waveguide corner block)")
         self.orgnep = orgnep
         self.orgnep_Av = orgnep.get_Av()
         self.orgnep_fv = orgnep.get_fv()
@@ -69,10 +73,22 @@ class Proj_SPMF_NEP:
         if k > self.maxsize:
             raise ValueError("projection larger than the preallocated size (maxsize=%d)" % self.maxsize)
         n = self.orgnep.size(1)
-        for i in range(len(self.orgnep_fv)):
-            for j in range(k):
-                y = self._term_times(i, Vd[j])
-                self.projnep_B_mem[i][:k, j] = dense.gemv_h(Wd, y, k, rows=n, ldv=Wd.shape[1])
+        if k == 0:
+            self._rebuild(0)
+            return
+        from ._lib import lib, check, hptr, c_vp
+        from .nep import stream_ptr
+        mt = len(self.orgnep_fv)
+        eye = np.eye(k, dtype=np.complex128)
+        VT = dense.gemm_ts(Vd, eye, rowmajor=True, k=k, rows=n, ldz=Vd.shape[1])          # (n, k) row-major
+        WT = VT if Wd.data_ptr() == Vd.data_ptr() else dense.gemm_ts(Wd, eye, rowmajor=True, k=k, rows=n, ldz=Wd.shape[1])
+        YT = torch.empty((n, k), dtype=CDT, device="cuda")
+        for i in range(mt):
+            F = np.zeros((mt, k), dtype=np.complex128, order="F")
+            F[i, :] = 1.0
+            check(lib.nep_resid_block(self.orgnep.dev.h, k, hptr(F), c_vp(VT.data_ptr()), k, c_vp(YT.data_ptr()), k,
+                                      stream_ptr()))                                       # Y_i = A_i V
+            self.projnep_B_mem[i][:k, :k] = dense.gemm_h_rm(WT, YT, n, k, k)                # B_i = W^H Y_i
         self._rebuild(k)
 
     def expand_projectmatrices(self, Wnew, Vnew):

@@ -102,6 +102,19 @@ def bench_gemm(na, rows, k, p, label, reps, rowmajor=True):
          TFLOPs=fl / ms / 1e9, frac_mfma=fl / ms / 1e9 / MFMA64, GBps=b / ms / 1e6, frac_hbm=b / ms / 1e6 / HBM)
 
 
+def bench_gemm_h(na, rows, k, p, label, reps):
+    WT = crandn(rows, k); YT = crandn(rows, p)
+    t0 = time.perf_counter(); na.dense.gemm_h_rm(WT, YT, rows, k, p)
+    t = time.perf_counter()
+    for _ in range(reps):
+        na.dense.gemm_h_rm(WT, YT, rows, k, p)
+    ms = (time.perf_counter() - t) / reps * 1e3
+    fl = 8.0 * rows * k * p
+    b = 16.0 * rows * (k + p)
+    emit(kernel="K9 nep_gemm_h_rm C = W^H Y (wall incl. reduction, D2H, sync)", case=label, rows=rows, k=k, p=p, flops=fl,
+         bytes=b, ms=ms, TFLOPs=fl / ms / 1e9, frac_mfma=fl / ms / 1e9 / MFMA64, GBps=b / ms / 1e6, frac_hbm=b / ms / 1e6 / HBM)
+
+
 def bench_lu(na, A, label, reps, nrhs=1):
     import scipy.sparse as sp
     t = time.perf_counter()
@@ -138,6 +151,7 @@ def main():
                    active=(np.arange(1, 102) * n).astype(np.int64))
         bench_orth(na, n, 100, "gun tiar step 100", args.reps)
         bench_gemm(na, n, 100, 100, "gun Ritz block", args.reps)
+        bench_gemm_h(na, n, 100, 100, "gun projection block", args.reps)
         A0 = nep.compute_Mder(0.0)
         bench_lu(na, A0, "gun M(sigma)", args.reps)
         bench_lu(na, A0, "gun M(sigma), Beyn block", args.reps, nrhs=32)
@@ -151,6 +165,7 @@ def main():
         bench_orth(na, n, 60, "wep tiar step 60", 5)
         bench_gemm(na, n, 60, 60, "wep Ritz block", 5)
         bench_gemm(na, n, 60, 60, "wep basis block col-major", 5, rowmajor=False)
+        bench_gemm_h(na, n, 60, 60, "wep projection block", 5)
     if args.which in ("lu", "all"):
         for nx, nz in ((303, 299), (1003, 999)):
             nepw = na.nep_gallery("WEP", nx=nx, nz=nz, benchmark_problem="JARLEBRING")
