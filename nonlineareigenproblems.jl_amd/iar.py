@@ -150,14 +150,15 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
         t4 = time.perf_counter()
         laml = sigma + gamma / D
         if proj_solve:
-            # method_iar.jl:118-131: orthonormal basis QQ of span(V[0:n, 0:kc]) (CholQR2 on the device: Gram matrix by
-            # the K6 dots kernel, triangular scaling by K7), Galerkin projection, inner solve started from RR*Z
+            # method_iar.jl:118-131: orthonormal basis QQ of span(V[0:n, 0:kc]) (on the device: Gram matrix by K9,
+            # scaling by K7, twice), Galerkin projection, inner solve started from RR*Z
             # (rank revealing: eigen-decomposition of the Gram matrix, directions below 1e-13 of the largest are dropped
             # -- the first-block rows of the Krylov basis become numerically dependent, and kc may exceed n)
             R_tot = np.eye(kc, dtype=complex)
             Qd = V; ldq = ldv; kq = kc
             for _ in range(2):
-                G = dense.gram_h(Qd, Qd, kq, kq, rows=n, ldw=ldq, ldy=ldq)
+                QTm = dense.gemm_ts(Qd, np.eye(kq, dtype=complex), rowmajor=True, k=kq, rows=n, ldz=ldq)
+                G = dense.gemm_h_rm(QTm, QTm, n, kq, kq)                             # K9 Gram matrix
                 wg, Ug = np.linalg.eigh((G + G.conj().T) / 2)
                 keep = wg > 1e-13 * wg[-1]
                 T = Ug[:, keep] / np.sqrt(wg[keep])[None, :]                       # kq x r
