@@ -19,9 +19,10 @@ from .errmeasure import (Errmeasure, ResidualErrmeasure, StandardSPMFErrmeasure,
 from .dense import gemm_ts, orthogonalize_and_normalize, DGKS, CGS, MGS
 from .iar import iar
 from .tiar import tiar
+from .iar_chebyshev import iar_chebyshev
 from .newton import resinv, quasinewton, augnewton, compute_rf, armijo_rule, ScalarNewtonInnerSolver
 from .projection import (Proj_SPMF_NEP, create_proj_NEP, inner_solve, InnerSolver, DefaultInnerSolver, IARInnerSolver,
-                         NewtonInnerSolver)
+                         NewtonInnerSolver, IARChebInnerSolver, PolyeigInnerSolver, polyeig)
 from .nleigs import nleigs, NleigsSolutionDetails
 from . import rk_helper
 from .contour import (contour_beyn, contour_block_SS, integrate_interval, MatrixIntegrator, MatrixTrapezoidal,

@@ -156,6 +156,38 @@ class IARInnerSolver(InnerSolver):
         self.normalize_DEPs, self.iar_function = bool(normalize_DEPs), iar_function
 
 
+def IARChebInnerSolver(tol=1e-13, maxit=80, starting_vector="ones", normalize_DEPs=True):
+    """src/inner_solver.jl:158-163"""
+    from .iar_chebyshev import iar_chebyshev
+    return IARInnerSolver(tol=tol, maxit=maxit, starting_vector=starting_vector, normalize_DEPs=normalize_DEPs,
+                          iar_function=iar_chebyshev)
+
+
+class PolyeigInnerSolver(InnerSolver):
+    """src/inner_solver.jl:104,298-304: companion linearisation of the projected PEP (host LAPACK, k*d x k*d)"""
+
+
+def polyeig(Bv):
+    """eigenpairs of sum_i lam^i B_i through the first companion form (src/method_companion.jl); returns (lam, V) with
+    the leading-block eigenvectors normalised"""
+    import scipy.linalg as sla
+    d = len(Bv) - 1
+    k = Bv[0].shape[0]
+    if d == 1:
+        lam, X = sla.eig(-np.asarray(Bv[0]), np.asarray(Bv[1]))
+        return lam, X
+    A = np.zeros((k * d, k * d), dtype=complex); E = np.eye(k * d, dtype=complex)
+    A[:k * (d - 1), k:] = np.eye(k * (d - 1))
+    for i in range(d):
+        A[k * (d - 1):, k * i:k * (i + 1)] = -np.asarray(Bv[i])
+    E[k * (d - 1):, k * (d - 1):] = np.asarray(Bv[d])
+    lam, X = sla.eig(A, E)
+    X = X[:k, :]
+    nrm = np.linalg.norm(X, axis=0)
+    X = X / np.where(nrm > 0, nrm, 1.0)[None, :]
+    return lam, X
+
+
 def inner_solve(solver, pnep, lamv=None, V=None, neigs=10, sigma=0.0, tol=None, **kwargs):
     """src/inner_solver.jl:243-350.  Returns (lambdas, eigenvector matrix of the PROJECTED problem, k x #lambdas)."""
     from .iar import iar as _iar
@@ -163,11 +195,16 @@ def inner_solve(solver, pnep, lamv=None, V=None, neigs=10, sigma=0.0, tol=None, 
     k = pnep.size(1)
     if isinstance(solver, DefaultInnerSolver):
         org = pnep.orgnep
-        if isinstance(org, PEP) or isinstance(org, DEP):
-            raise NotImplementedError("DefaultInnerSolver dispatches PEPs to polyeig and DEPs to iar_chebyshev "
-                                      "(inner_solver.jl:244-249), which this backend does not provide; pass IARInnerSolver() "
-                                      "or NewtonInnerSolver()")
-        solver = IARInnerSolver() if isinstance(org, SPMF_NEP) else NewtonInnerSolver()
+        if isinstance(org, PEP):                                 # inner_solver.jl:244-245
+            solver = PolyeigInnerSolver()
+        elif isinstance(org, DEP):                               # :246-248
+            solver = IARChebInnerSolver()
+        else:
+            solver = IARInnerSolver() if isinstance(org, SPMF_NEP) else NewtonInnerSolver()
+    if isinstance(solver, PolyeigInnerSolver):
+        if not isinstance(pnep.orgnep, PEP):
+            raise TypeError("Wrong type. PolyeigInnerSolver only handles the PEP type.")
+        return polyeig(pnep.get_Av())
     if isinstance(solver, IARInnerSolver):
         nep = pnep.nep_proj
         if isinstance(pnep.orgnep, DEP) and solver.normalize_DEPs:          # :312-324

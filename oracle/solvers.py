@@ -621,3 +621,115 @@ def inner_solve(solver, pnep, lamv=None, V=None, neigs=10, sigma=0.0, tol=None):
     except NoConvergenceException as e:
         Q = np.zeros((k, 0), dtype=complex) if e.v is None else np.asarray(e.v).reshape(k, -1)
         return np.asarray(e.lam, dtype=complex).reshape(-1), Q
+
+
+# ----------------------------------------------------------------------------------
+def _cheb_L(m, a, b):
+    """method_iar_chebyshev.jl:129-131: integration map in the Chebyshev basis of [a, b]"""
+    L = np.diag(np.concatenate([[2.0], 1.0 / np.arange(2, m + 1)])) + np.diag(-1.0 / np.arange(1, m - 1), -2)
+    return L * (b - a) / 4
+
+
+def _cheb_T_at(x, idx):
+    """T_i(x) for real x outside or inside [-1, 1]  (method_iar_chebyshev.jl:245-253)"""
+    idx = np.asarray(idx, dtype=float)
+    if abs(x) <= 1:
+        return np.cos(idx * np.arccos(x))
+    if x >= 1:
+        return np.cosh(idx * np.arccosh(x))
+    return ((-1.0) ** idx) * np.cosh(idx * np.arccosh(-x))
+
+
+def _dd0_mat_fun(f, S, sigma):
+    """method_iar_chebyshev.jl:474-497: f[S, sigma I] through f([[S, I], [0, sigma I]])"""
+    n = S.shape[0]
+    A = np.zeros((2 * n, 2 * n), dtype=complex)
+    A[:n, :n] = S; A[:n, n:] = np.eye(n); A[n:, n:] = sigma * np.eye(n)
+    return np.asarray(f(A))[:n, n:]
+
+
+def iar_chebyshev(nep, orthmethod=dgks, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6, errmeasure=None,
+                  sigma=0.0, gamma=1.0, v=None, check_error_every=1, a=None, b=None, compute_y0_method="auto"):
+    """method_iar_chebyshev.jl:66-218 with the DEP / PEP / SPMF versions of compute_y0_cheb (:309-370).  A DEP or PEP
+    with sigma != 0 or gamma != 1 is handled by the SPMF version (which carries shift and scale in its divided
+    differences) instead of the reference's explicit shift_and_scale -- same spectrum."""
+    from . import neps
+    n = nep.size(1); m = maxit
+    sigma = complex(sigma); gamma = complex(gamma)
+    isdep = isinstance(nep, neps.DEP); ispep = isinstance(nep, neps.PEP)
+    if a is None:
+        a = -float(np.max(nep.tauv)) if isdep else -1.0
+    if b is None:
+        b = 0.0 if isdep else 1.0
+    if compute_y0_method == "auto":
+        compute_y0_method = "DEP" if isdep else ("PEP" if ispep else "SPMF")
+    if (sigma != 0 or gamma != 1) and compute_y0_method in ("DEP", "PEP"):
+        compute_y0_method = "SPMF"
+    if linsolvercreator is None:
+        linsolvercreator = DefaultLinSolverCreator()
+    if errmeasure is None:
+        errmeasure = DefaultErrmeasure(nep)
+    cc = (a + b) / (a - b); kk = 2 / (b - a)
+    Av = nep.get_Av(); fv = nep.get_fv()
+    L = _cheb_L(m, a, b)
+    Tc = np.cos(np.arange(m + 1) * np.arccos(cc))
+    if compute_y0_method == "DEP":
+        Ttau = np.array([_cheb_T_at(-kk * tau + cc, np.arange(m + 2)) for tau in nep.tauv])
+    else:
+        Li = np.linalg.inv(L[:m, :m])
+        D = np.vstack([np.zeros((1, m)), Li[:m - 1, :]])
+        if compute_y0_method == "SPMF":
+            DDf = [gamma * _dd0_mat_fun(f, sigma * np.eye(m) + gamma * D, sigma) for f in fv]
+    v = np.array(v, dtype=complex)
+    V = np.zeros((n * (m + 1), m + 1), dtype=complex, order="F")
+    H = np.zeros((m + 1, m), dtype=complex)
+    M0inv = linsolvercreator.create_linsolver(nep, sigma)
+    err = np.ones((m, m))
+    lam = np.zeros(m + 1, dtype=complex); Q = np.zeros((n, m + 1), dtype=complex)
+    V[:n, 0] = v / np.linalg.norm(v)
+    k = 1; conv_eig = 0
+    while k <= m and conv_eig < neigs:
+        X = V[:n * k, k - 1].reshape((n, k), order="F")
+        y = np.zeros((n, k + 1), dtype=complex, order="F")
+        y[:, 1:k + 1] = X @ L[:k, :k]
+        N = k
+        if compute_y0_method == "DEP":                                    # :309-321
+            y0 = X @ Tc[:N]
+            for j in range(len(nep.tauv)):
+                y0 = y0 - Av[j + 1] @ (y @ Ttau[j, :N + 1])
+            y0 = M0inv.lin_solve(y0)
+        elif compute_y0_method == "PEP":                                  # :331-343
+            d = len(Av) - 1
+            vv_ = Tc[:N].astype(complex)
+            y0 = np.zeros(n, dtype=complex)
+            for j in range(d):
+                y0 = y0 + Av[j + 1] @ (X @ vv_)
+                vv_ = D[:N, :N] @ vv_
+            y0 = -M0inv.lin_solve(y0) - y @ Tc[:N + 1]
+        else:                                                             # :355-366
+            y0 = np.zeros(n, dtype=complex)
+            for i in range(len(fv)):
+                y0 = y0 + Av[i] @ (X @ (DDf[i][:N, :N] @ Tc[:N]))
+            y0 = -M0inv.lin_solve(y0) - y @ Tc[:N + 1]
+        y[:, 0] = y0
+        vv = y.reshape(-1, order="F").copy()
+        H[k, k - 1] = orthmethod(V[:n * (k + 1), :k], vv, H[:k, k - 1])
+        V[:n * (k + 1), k] = vv
+        if ((k % check_error_every == 0) or (k == m)) and k > 2:
+            Dv, Z = _eig(H[:k, :k])
+            Q = V[:n, :k] @ Z
+            lam = sigma + gamma / Dv
+            err[k - 1, :k] = [errmeasure(lam[s], Q[:, s]) for s in range(k)]
+            conv_eig = int(np.sum(err[k - 1, :k] < tol))
+            idx = np.argsort(err[k - 1, :k], kind="stable")
+            err[k - 1, :k] = err[k - 1, idx]
+            if k == m or conv_eig >= neigs:
+                nrof = int(min(len(lam), neigs))
+                lam = lam[idx[:nrof]]
+                Q = Q[:, idx[:nrof]]
+        k += 1
+    k -= 1
+    if conv_eig < neigs and neigs != np.inf:
+        raise NoConvergenceException(lam, Q, err[k - 1, :len(lam)], "Number of iterations exceeded. maxit=%d." % maxit)
+    nc = min(len(lam), conv_eig)
+    return lam[:nc], Q[:, :nc], V[:, :k]

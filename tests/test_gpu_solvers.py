@@ -111,6 +111,45 @@ def test_augnewton_and_newton_inner_solver(na):
     assert min(np.linalg.norm(Mp(lamv[j]) @ Vp[:, j]) / np.linalg.norm(Vp[:, j]) for j in range(2)) < 1e-9
 
 
+def test_iar_chebyshev_and_default_inner_solver(na):
+    """iar_chebyshev on the device: the docstring eigenvalues of method_iar_chebyshev.jl:45-56 (1e-12), the SPMF and PEP
+    versions of compute_y0_cheb against the oracle, a shifted / scaled run; then test/iar.jl:29-33 exactly: iar(dep0,
+    proj_solve=true) with the DEFAULT inner solver (DEP -> iar_chebyshev on the normalised projected DEP), and the
+    PEP default (polyeig of the projected problem)"""
+    from oracle import gallery as og, solvers as osol, neps as oneps
+    nep = na.nep_gallery("dep0", 100); onep = og.dep0(100)
+    lam, V, _ = na.iar_chebyshev(nep, v=np.ones(100), tol=1e-5, neigs=3)
+    ref = np.array([0.050462487848960284, -0.07708779190301127, 0.1503856540695659])
+    assert np.max(abs(lam.real - ref)) < 1e-12 and np.max(abs(lam.imag)) < 1e-13
+    lam2, V2, _ = na.iar_chebyshev(nep, v=np.ones(100), tol=1e-9, neigs=3, compute_y0_method="SPMF", a=-1.0, b=0.0)
+    lo2 = osol.iar_chebyshev(onep, v=np.ones(100), tol=1e-9, neigs=3, compute_y0_method="SPMF", a=-1.0, b=0.0)[0]
+    _match(lam2, lo2, 1e-9)
+    lam4, V4, _ = na.iar_chebyshev(nep, v=np.ones(100), tol=1e-9, neigs=2, sigma=0.1, gamma=0.5, maxit=40)
+    assert max(np.linalg.norm(onep.compute_Mlincomb(lam4[i], V4[:, i])) / np.linalg.norm(V4[:, i]) for i in range(2)) < 1e-7
+    B = [np.array([[1.0, 3], [5, 6]]), np.array([[3.0, 4], [6, 6]]), np.eye(2)]
+    lam3, V3, _ = na.iar_chebyshev(na.PEP(B), v=np.ones(2), tol=1e-10, neigs=2, maxit=20)
+    lo3 = osol.iar_chebyshev(oneps.PEP(B), v=np.ones(2), tol=1e-10, neigs=2, maxit=20)[0]
+    _match(lam3, lo3, 1e-8)
+    # proj_solve with the default inner solver
+    dep = na.nep_gallery("dep0"); od = og.dep0()
+    lam, Q, _ = na.iar(dep, sigma=1.1, neigs=5, v=np.ones(5), maxit=100, tol=EPS * 100, errmeasure=na.ResidualErrmeasure(dep),
+                       proj_solve=True)
+    assert len(lam) == 5
+    assert max(np.linalg.norm(od.compute_Mlincomb(lam[i], Q[:, i])) / np.linalg.norm(Q[:, i]) for i in range(5)) < EPS * 100
+    # PEP original -> polyeig of the projected PEP
+    rng = np.random.default_rng(4)
+    Bp = [rng.standard_normal((30, 30)) for _ in range(3)]
+    pep = na.PEP(Bp)
+    pnep = na.create_proj_NEP(pep)
+    Qb, _ = np.linalg.qr(rng.standard_normal((30, 4)))
+    pnep.set_projectmatrices(Qb, Qb)
+    lamp, Xp = na.inner_solve(na.DefaultInnerSolver(), pnep)
+    Bq = [Qb.T @ Bi @ Qb for Bi in Bp]
+    fin = np.isfinite(lamp)
+    assert fin.sum() >= 6
+    assert max(np.linalg.norm((Bq[0] + l * Bq[1] + l * l * Bq[2]) @ Xp[:, j]) for j, l in enumerate(lamp) if np.isfinite(l) and abs(l) < 1e3) < 1e-8
+
+
 def test_projection_and_proj_solve(na):
     """Proj_SPMF_NEP (NEPTypes.jl:724-790): set / expand project matrices against NumPy on a sparse SPMF; then
     proj_solve=true in tiar (test/tiar.jl:70-84 at n=200) and iar (test/iar.jl:29-33) with IARInnerSolver: same eigenvalues

@@ -142,6 +142,21 @@ def test_transf_shift_and_scale_iar_qdep0():
         assert np.linalg.norm(nep3.compute_Mlincomb(al * lam[i] + sig, V[:, i])) < np.sqrt(EPS)
 
 
+def test_iar_chebyshev_docstring():
+    # src/method_iar_chebyshev.jl:45-56: iar_chebyshev(dep0(100), v=ones, tol=1e-5, neigs=3) prints these eigenvalues
+    nep = gallery.dep0(100)
+    lam, V = solvers.iar_chebyshev(nep, v=np.ones(100), tol=1e-5, neigs=3)[:2]
+    ref = np.array([0.050462487848960284, -0.07708779190301127, 0.1503856540695659])
+    assert np.max(abs(lam.real - ref)) < 1e-13 and np.max(abs(lam.imag)) < 1e-14
+    # the general SPMF version of compute_y0_cheb gives the same spectrum; PEP version on the quadratic of nleigs_basic
+    lam2 = solvers.iar_chebyshev(nep, v=np.ones(100), tol=1e-5, neigs=3, compute_y0_method="SPMF", a=-1.0, b=0.0)[0]
+    assert np.max(abs(np.sort(lam2.real) - np.sort(ref))) < 1e-9
+    B = [np.array([[1.0, 3], [5, 6]]), np.array([[3.0, 4], [6, 6]]), np.eye(2)]
+    pep = neps.PEP(B)
+    lam3, V3 = solvers.iar_chebyshev(pep, v=np.ones(2), tol=1e-10, neigs=2, maxit=20)[:2]
+    assert max(np.linalg.norm(pep.compute_Mlincomb(lam3[i], V3[:, i])) for i in range(2)) < 1e-8
+
+
 def test_tiar_iar_proj_solve():
     # test/tiar.jl:70-84 (dep0 of reduced size 200 instead of 1000) and test/iar.jl:29-33: Ritz extraction by projection +
     # inner solve (IARInnerSolver; the reference's default for a DEP is iar_chebyshev, which is not restated)
