@@ -97,10 +97,13 @@ def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None
     if symmetric_mode:
         kw["options"] = dict(SymmetricMode=True)
     # SuperLU is sequential and calls small BLAS-2/3 kernels: a many-thread OpenBLAS only adds spinning threads
-    # (measured 40 -> 230 ms jitter on a 128-core host); pin BLAS to one thread for the duration of the call
+    # (measured 40 -> 230 ms jitter on a 128-core host), so BLAS is pinned to one thread for the call -- except for
+    # large problems whose supernodes are big enough for threaded zgemm/ztrsm to pay (measured: n = 91k 0.36 -> 0.40 s,
+    # n = 251k 1.90 -> 1.71 s, n = 1e6 13.5 -> 10.4 s with 8 threads; scripts/diag/superlu_threads.py)
+    nthreads = 1 if shape[0] < 200000 else 8
     ctl = blas_controller()
     if ctl is not None:
-        with ctl.limit(limits=1):
+        with ctl.limit(limits=nthreads, user_api="blas"):
             lu = spla.splu(Ac, **kw)  # RuntimeError("Factor is exactly singular") propagates to the caller
     else:
         lu = spla.splu(Ac, **kw)
