@@ -232,6 +232,10 @@ int32_t nep_colnorms(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx
 /* dot products d_j = x_j^H y_j of the columns of two rows x k blocks (synchronous) */
 int32_t nep_coldots(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx,
                     const nep_cdouble* dY, int64_t ldy, nep_cdouble* h_out, nep_stream stream);
+/* same without conjugation, d_j = x_j^T y_j: the bilinear sums `mat_sum` of the infinite Lanczos three-term recurrence
+ * for symmetric NEPs (src/method_ilan.jl:299-308) */
+int32_t nep_coldotsu(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx,
+                     const nep_cdouble* dY, int64_t ldy, nep_cdouble* h_out, nep_stream stream);
 /* out[r] = sum_j A[r,j]*B[r,j] (column-major blocks, no conjugation) */
 int32_t nep_rowdot(int64_t rows, int32_t k, const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb,
                    nep_cdouble* dout, nep_stream stream);

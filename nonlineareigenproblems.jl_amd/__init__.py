@@ -20,6 +20,7 @@ from .dense import gemm_ts, orthogonalize_and_normalize, DGKS, CGS, MGS
 from .iar import iar
 from .tiar import tiar
 from .iar_chebyshev import iar_chebyshev
+from .ilan import ilan
 from .newton import resinv, quasinewton, augnewton, compute_rf, armijo_rule, ScalarNewtonInnerSolver
 from .projection import (Proj_SPMF_NEP, create_proj_NEP, inner_solve, InnerSolver, DefaultInnerSolver, IARInnerSolver,
                          NewtonInnerSolver, IARChebInnerSolver, PolyeigInnerSolver, polyeig)

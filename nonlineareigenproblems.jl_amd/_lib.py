@@ -86,6 +86,7 @@ SIGNATURES = {
     "nep_nrm2": [c_i64, c_vp, P(c_dbl), c_vp],
     "nep_colnorms": [c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],
     "nep_coldots": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
+    "nep_coldotsu": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "nep_rowdot": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "nep_hadamard": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp],
     "nep_rowmajor_colnorms": [c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],

@@ -230,6 +230,7 @@ __global__ void k_scal(int64_t len, cplx alpha, cplx* __restrict__ x) {
 }
 
 // per-block partial of sum conj(x_j) y_j for column j = blockIdx.y; partial[(j*gridDim.x + b)]
+template <bool CONJ>
 __global__ __launch_bounds__(256) void k_coldots_partial(int64_t rows, const cplx* __restrict__ X,
                                                          int64_t ldx, const cplx* __restrict__ Y,
                                                          int64_t ldy, cplx* __restrict__ partial) {
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void k_coldots_partial(int64_t rows, const cpl
     cplx acc = cmake(0.0, 0.0);
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows;
          i += (int64_t)gridDim.x * blockDim.x)
-        cfma_conj(acc, x[i], y[i]);
+        if (CONJ) cfma_conj(acc, x[i], y[i]); else cfma(acc, x[i], y[i]);
     acc = group_reduce_sum<64>(acc);
     __shared__ cplx sm[4];
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -425,16 +426,33 @@ int32_t nep_scal(int64_t len, nep_cdouble alpha, nep_cdouble* dx, nep_stream str
     return NEP_OK;
 }
 
+static int coldots_impl(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx, const nep_cdouble* dY,
+                        int64_t ldy, nep_cdouble* h_out, nep_stream stream, bool conj);
+
 int32_t nep_coldots(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx, const nep_cdouble* dY,
                     int64_t ldy, nep_cdouble* h_out, nep_stream stream) {
+    return coldots_impl(rows, k, dX, ldx, dY, ldy, h_out, stream, true);
+}
+
+int32_t nep_coldotsu(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx, const nep_cdouble* dY,
+                     int64_t ldy, nep_cdouble* h_out, nep_stream stream) {
+    return coldots_impl(rows, k, dX, ldx, dY, ldy, h_out, stream, false);
+}
+
+static int coldots_impl(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx, const nep_cdouble* dY,
+                        int64_t ldy, nep_cdouble* h_out, nep_stream stream, bool conj) {
     ARGCHK(rows > 0 && k > 0 && h_out);
     const int nb = grid_for(rows, 256 * 8, 512);
     int rc = g_util_scratch.ensure(((size_t)k * nb + k) * sizeof(cplx));
     if (rc) return rc;
     cplx* partial = (cplx*)g_util_scratch.dptr;
     cplx* out = partial + (size_t)k * nb;
-    hipLaunchKernelGGL(k_coldots_partial, dim3(nb, k), dim3(256), 0, as_stream(stream), rows, (const cplx*)dX,
-                       ldx, (const cplx*)dY, ldy, partial);
+    if (conj)
+        hipLaunchKernelGGL((k_coldots_partial<true>), dim3(nb, k), dim3(256), 0, as_stream(stream), rows, (const cplx*)dX,
+                           ldx, (const cplx*)dY, ldy, partial);
+    else
+        hipLaunchKernelGGL((k_coldots_partial<false>), dim3(nb, k), dim3(256), 0, as_stream(stream), rows, (const cplx*)dX,
+                           ldx, (const cplx*)dY, ldy, partial);
     LAUNCHCHK();
     hipLaunchKernelGGL(k_sum_partials, dim3((k + 63) / 64), dim3(64), 0, as_stream(stream), nb, partial, out, (int)k);
     LAUNCHCHK();

@@ -183,6 +183,22 @@ GALLERY = {
 }
 
 
+def dep_symm_double(n=100):
+    """src/gallery_extra/gallery_examples.jl:15-30: DEP with sparse symmetric matrices, double eigenvalues, tau = 2"""
+    LL = -sp.diags(2 * np.ones(n)) + sp.diags(np.ones(n - 1), -1) + sp.diags(np.ones(n - 1), 1)
+    x = np.linspace(0, np.pi, n)
+    h = x[1] - x[0]
+    LL = sp.kron(LL / h ** 2, LL / h ** 2)
+    bb = -100 * np.abs(np.sin(x[:, None] + x[None, :]))
+    aa = 8 * np.sin(x)[:, None] * np.sin(x)[None, :]
+    B = sp.diags(bb.reshape(-1, order="F"))
+    A = LL + sp.diags(aa.reshape(-1, order="F"))
+    return DEP([sp.csc_matrix(A), sp.csc_matrix(B)], [0.0, 2.0])
+
+
+GALLERY["dep_symm_double"] = dep_symm_double
+
+
 def nep_gallery(name, *args, **kwargs):
     if name not in GALLERY:
         raise KeyError("unknown gallery problem %r (available: %s)" % (name, ", ".join(sorted(GALLERY))))

@@ -197,3 +197,18 @@ def qdep0():
     AA = [-sp.identity(n, format="csc"), A0, A1]
     fi = [neps.f_pow(2), neps.f_one(), neps.f_exp(-1.0)]
     return neps.SPMF_NEP(AA, fi)
+
+
+def dep_symm_double(n=100):
+    """src/gallery_extra/gallery_examples.jl:15-30: DEP with sparse symmetric matrices, double eigenvalues, tau = 2"""
+    import scipy.sparse as sp
+    from . import neps
+    LL = -sp.diags(2 * np.ones(n)) + sp.diags(np.ones(n - 1), -1) + sp.diags(np.ones(n - 1), 1)
+    x = np.linspace(0, np.pi, n)
+    h = x[1] - x[0]
+    LL = sp.kron(LL / h ** 2, LL / h ** 2)
+    bb = -100 * np.abs(np.sin(x[:, None] + x[None, :]))
+    aa = 8 * np.sin(x)[:, None] * np.sin(x)[None, :]
+    B = sp.diags(bb.reshape(-1, order="F"))
+    A = LL + sp.diags(aa.reshape(-1, order="F"))
+    return neps.DEP([sp.csc_matrix(A), sp.csc_matrix(B)], [0.0, 2.0])

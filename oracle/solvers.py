@@ -608,15 +608,21 @@ class IARInnerSolver:
 def inner_solve(solver, pnep, lamv=None, V=None, neigs=10, sigma=0.0, tol=None):
     """src/inner_solver.jl:308-347 (IARInnerSolver with iar, starting vector ones; partial results on NoConvergence)"""
     from . import neps
-    if solver is None:
-        solver = IARInnerSolver()
+    cheb = False
+    if solver is None:                               # DefaultInnerSolver (inner_solver.jl:243-256)
+        if isinstance(pnep.orgnep, neps.DEP):
+            solver = IARInnerSolver(normalize_DEPs=True); cheb = True
+        else:
+            solver = IARInnerSolver()
+    cheb = cheb or getattr(solver, "cheb", False)
     nep = pnep.nep_proj
     k = nep.size(1)
     if isinstance(pnep.orgnep, neps.DEP) and solver.normalize_DEPs:
         AA = nep.get_Av()
         nep = neps.DEP([np.linalg.solve(AA[0], AA[1 + i]) for i in range(len(AA) - 1)], pnep.orgnep.tauv)
     try:
-        out = iar(nep, sigma=sigma, neigs=neigs, tol=solver.tol, maxit=solver.maxit, v=np.ones(k))
+        fn = iar_chebyshev if cheb else iar
+        out = fn(nep, sigma=sigma, neigs=neigs, tol=solver.tol, maxit=solver.maxit, v=np.ones(k))
         return out[0], out[1]
     except NoConvergenceException as e:
         Q = np.zeros((k, 0), dtype=complex) if e.v is None else np.asarray(e.v).reshape(k, -1)
@@ -733,3 +739,105 @@ def iar_chebyshev(nep, orthmethod=dgks, maxit=30, linsolvercreator=None, tol=EPS
         raise NoConvergenceException(lam, Q, err[k - 1, :len(lam)], "Number of iterations exceeded. maxit=%d." % maxit)
     nc = min(len(lam), conv_eig)
     return lam[:nc], Q[:, :nc], V[:, :k]
+
+
+# ----------------------------------------------------------------------------------
+def _symmetrizer_coefficients(m):
+    """method_ilan.jl:419-427"""
+    G = np.zeros((m + 1, m + 1), dtype=complex)
+    G[:, 0] = 1.0 / np.arange(1, m + 2)
+    for j in range(m):
+        for i in range(m + 1):
+            G[i, j + 1] = G[i, j] * (j + 1) / (i + j + 2)
+    return G
+
+
+def ilan(nep, orthmethod=dgks, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6, errmeasure=None, sigma=0.0,
+         gamma=1.0, v=None, check_error_every=30, inner_solver_method=None, proj_solve=True):
+    """method_ilan.jl:56-258 (infinite Lanczos for symmetric NEPs) with the SPMF version of Bmult (:370-378) for every
+    SPMF-type NEP -- the reference's DEP version (:384-405) is the same product in factored form (test/ilan.jl:45-62)."""
+    n = nep.size(1); m = maxit
+    sigma = complex(sigma); gamma = complex(gamma)
+    if linsolvercreator is None:
+        linsolvercreator = DefaultLinSolverCreator()
+    if errmeasure is None:
+        errmeasure = DefaultErrmeasure(nep)
+    Av = nep.get_Av(); fv = nep.get_fv(); p = len(fv)
+    v = np.array(v, dtype=complex)
+    V = np.zeros((n, m + 1), dtype=complex); Q = np.zeros((n, m + 1), dtype=complex)
+    Qp = np.zeros_like(Q); Qn = np.zeros_like(Q); Z = np.zeros_like(Q); W = np.zeros_like(Q)
+    H = np.zeros((m + 1, m), dtype=complex); HH = np.zeros((m + 1, m), dtype=complex)
+    om = np.zeros(m + 1, dtype=complex)
+    a = gamma ** np.arange(2 * m + 3); a[0] = 0
+    M0inv = linsolvercreator.create_linsolver(nep, sigma)
+    err = np.full((m, m + 1), np.nan)
+    QQ = np.zeros((n, m + 1), dtype=complex)
+    # precompute_data (:322-343): FDH_t[i,j] = fD[i+j+1, t], fD[:, t] = f_t(SS)[:, 0], SS = sigma I + gamma subdiag(1..)
+    SS = np.diag(sigma * np.ones(2 * m + 2)) + np.diag(gamma * np.arange(1, 2 * m + 2), -1)
+    fD = np.column_stack([np.asarray(f(SS))[:, 0] for f in fv])
+    FDH = [np.array([[fD[i + j + 1, t] for j in range(m + 1)] for i in range(m + 1)]) for t in range(p)]
+    G = _symmetrizer_coefficients(m)
+    msum = lambda X, Y: np.sum(X * Y)                                     # mat_sum (:299-308): no conjugation
+    Q[:, 0] = v / np.linalg.norm(v)
+    om[0] = np.vdot(Q[:, 0], nep.compute_Mlincomb(0, np.column_stack([Q[:, 0], Q[:, 0]]), [0, 1]))
+    V[:, 0] = Q[:, 0]
+    lam = np.zeros(0, dtype=complex)
+    k = 1; conv_eig = 0
+    while k <= m and conv_eig < neigs:
+        if not proj_solve:
+            QQ[:, k - 1] = Q[:, 0]
+        Qn[:, 1:k + 1] = Q[:, :k] / np.arange(1, k + 1)[None, :]
+        Qn[:, 0] = nep.compute_Mlincomb(sigma, Qn[:, :k + 1].copy(), a[:k + 1])
+        Qn[:, 0] = -M0inv.lin_solve(Qn[:, 0])
+        Z[:] = 0                                                           # Bmult (:370-378)
+        for t in range(p):
+            Z[:, :k + 1] += Av[t] @ (Qn[:, :k + 1] @ (G[:k + 1, :k + 1] * FDH[t][:k + 1, :k + 1]))
+        if k > 1:
+            beta = msum(Z[:, :k], Qp[:, :k])
+        alpha = msum(Z[:, :k], Q[:, :k])
+        eta = msum(Z[:, :k + 1], Qn[:, :k + 1])
+        H[k - 1, k - 1] = alpha / om[k - 1]
+        if k > 1:
+            H[k - 2, k - 1] = beta / om[k - 2]
+        Qn[:, :k] -= H[k - 1, k - 1] * Q[:, :k]
+        if k > 1:
+            Qn[:, :k] -= H[k - 2, k - 1] * Qp[:, :k]
+        H[k, k - 1] = np.linalg.norm(Qn)
+        Qn[:, :k + 1] /= H[k, k - 1]
+        om[k] = eta - 2 * alpha * H[k - 1, k - 1] + om[k - 1] * H[k - 1, k - 1] ** 2
+        if k > 1:
+            om[k] = om[k] - 2 * beta * H[k - 2, k - 1] + om[k - 2] * H[k - 2, k - 1] ** 2
+        om[k] = om[k] / H[k, k - 1] ** 2
+        V[:, k] = Qn[:, 0]
+        vk = V[:, k].copy()
+        orthmethod(V[:, :k], vk, HH[:k, k - 1])
+        V[:, k] = vk
+        if (check_error_every != np.inf and k % check_error_every == 0) or k == m:
+            if not proj_solve:
+                D, WR = _eig(H[:k, :k])
+                W[:, :k] = QQ[:, :k] @ WR
+                lam = sigma + gamma / D
+            else:
+                VV = V[:, :k + 1]
+                pnep = Proj_SPMF_NEP(nep)
+                pnep.set_projectmatrices(VV, VV)
+                lamp, Wp = inner_solve(inner_solver_method, pnep, neigs=m, tol=tol)
+                q = len(lamp)
+                lam = lamp[:q]
+                q = min(q, m)
+                W[:, :q] = VV @ Wp[:, :q]
+            ne = min(len(lam), m + 1)
+            err[k - 1, :ne] = [errmeasure(lam[s], W[:, s]) for s in range(ne)]
+            conv_eig = int(np.sum(err[k - 1, :ne] < tol))
+            idx = np.argsort(err[k - 1, :k], kind="stable")
+            err[k - 1, :k] = err[k - 1, idx]
+            if k == m or conv_eig >= neigs:
+                nrof = int(min(conv_eig, neigs))
+                lam = lam[idx[:nrof]]
+                W = W[:, idx[:len(lam)]]
+        k += 1
+        Qp[:] = Q; Q[:] = Qn; Qn[:] = 0
+    k -= 1
+    if conv_eig < neigs and neigs != np.inf:
+        raise NoConvergenceException(lam, W, None, "Number of iterations exceeded. maxit=%d." % maxit)
+    return lam, W[:, :len(lam)], V[:, :k + 1], H[:k, :k - 1], om[:k]

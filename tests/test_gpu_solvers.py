@@ -2,6 +2,7 @@
 acceptance = the reference's own criterion verify_lambdas (test/runtests.jl:80-89): eigenpair count
 + residual below tol, plus eigenvalue agreement with the oracle run."""
 import numpy as np
+import scipy.sparse as sp
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -148,6 +149,44 @@ def test_iar_chebyshev_and_default_inner_solver(na):
     fin = np.isfinite(lamp)
     assert fin.sum() >= 6
     assert max(np.linalg.norm((Bq[0] + l * Bq[1] + l * l * Bq[2]) @ Xp[:, j]) for j, l in enumerate(lamp) if np.isfinite(l) and abs(l) < 1e3) < 1e-8
+
+
+def test_ilan_vs_oracle(na):
+    """infinite Lanczos on the device: the docstring eigenvalues of method_ilan.jl:41-52 are among the converged ones
+    (1e-10), the Lanczos coefficients H and omega of the first 8 steps equal the oracle's (1e-8; later steps amplify
+    round-off in both), Ritz extraction path, DEP == equivalent SPMF_NEP (test/ilan.jl:45-62), NoConvergence (:33-43)"""
+    import warnings
+    from oracle import gallery as og, solvers as osol
+    nep = na.nep_gallery("dep_symm_double", 10); n = nep.n
+    onep = og.dep_symm_double(10)
+    out = na.ilan(nep, v=np.ones(n), tol=1e-5, neigs=12)
+    lam, W = out[0], out[1]
+    ref = np.array([0.03409997385842267, -0.03100798730589012, -0.0367653644764646])
+    assert len(lam) == 12 and max(np.min(abs(lam - r)) for r in ref) < 1e-10
+    assert max(np.linalg.norm(onep.compute_Mlincomb(lam[i], W[:, i])) / np.linalg.norm(W[:, i]) for i in range(12)) < 1e-2
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        oo = osol.ilan(onep, v=np.ones(n), tol=1e-5, neigs=12)
+    assert np.linalg.norm(out[3][:9, :8] - oo[3][:9, :8]) <= 1e-8 * np.linalg.norm(oo[3][:9, :8])
+    assert np.linalg.norm(out[4][:8] - oo[4][:8]) <= 1e-8 * np.linalg.norm(oo[4][:8])
+    lam2 = na.ilan(nep, v=np.ones(n), tol=1e-5, neigs=3, proj_solve=False)[0]
+    assert len(lam2) == 3 and np.min(abs(lam2 - ref[0])) < 1e-8
+    # same problem as DEP and as SPMF_NEP: same Lanczos coefficients
+    rng = np.random.default_rng(1)
+    m = 60
+    def symtri():
+        d = rng.random(m); e = rng.random(m - 1)
+        A = sp.diags([e, d, e], [-1, 0, 1]); return sp.csc_matrix(A + A.T)
+    A1, A2 = symtri(), symtri()
+    f = na.funcs
+    nep1 = na.DEP([A1, A2], [0.0, 1.0])
+    nep2 = na.SPMF_NEP([sp.identity(m, format="csc"), A1, A2], [f.Monomial(1) * (-1.0), f.one(), f.Exp(-1.0)])
+    v0 = rng.random(m)
+    o1 = na.ilan(nep1, neigs=np.inf, maxit=10, tol=EPS * 100, check_error_every=np.inf, v=v0)
+    o2 = na.ilan(nep2, neigs=np.inf, maxit=10, tol=EPS * 100, check_error_every=np.inf, v=v0)
+    assert np.linalg.norm(o1[3] - o2[3]) < 1e-6 and np.linalg.norm(o1[2] - o2[2]) < 1e-6
+    with pytest.raises(na.NoConvergenceException):
+        na.ilan(nep1, neigs=2, maxit=3, tol=EPS * 100, check_error_every=np.inf, v=v0, errmeasure=na.ResidualErrmeasure(nep1))
 
 
 def test_projection_and_proj_solve(na):

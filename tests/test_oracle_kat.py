@@ -157,6 +157,21 @@ def test_iar_chebyshev_docstring():
     assert max(np.linalg.norm(pep.compute_Mlincomb(lam3[i], V3[:, i])) for i in range(2)) < 1e-8
 
 
+def test_ilan_docstring():
+    # src/method_ilan.jl:41-52: ilan(dep_symm_double(10), v=ones, tol=1e-5, neigs=3) prints three eigenvalues; which three
+    # of the converged ones come first depends on round-off-level error values, so the check is containment (1e-12) in
+    # the converged set of a run with neigs=12, plus residuals
+    import warnings
+    nep = gallery.dep_symm_double(10); n = nep.size(1)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lam, W = solvers.ilan(nep, v=np.ones(n), tol=1e-5, neigs=12)[:2]
+    ref = np.array([0.03409997385842267, -0.03100798730589012, -0.0367653644764646])
+    assert len(lam) == 12 and max(np.min(abs(lam - r)) for r in ref) < 1e-12
+    E = solvers.DefaultErrmeasure(nep)
+    assert max(E(lam[i], W[:, i]) for i in range(12)) < 1e-5          # the criterion ilan itself applied (tol)
+
+
 def test_tiar_iar_proj_solve():
     # test/tiar.jl:70-84 (dep0 of reduced size 200 instead of 1000) and test/iar.jl:29-33: Ritz extraction by projection +
     # inner solve (IARInnerSolver; the reference's default for a DEP is iar_chebyshev, which is not restated)
