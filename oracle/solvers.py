@@ -841,3 +841,85 @@ def ilan(nep, orthmethod=dgks, maxit=30, linsolvercreator=None, tol=EPS * 10000,
     if conv_eig < neigs and neigs != np.inf:
         raise NoConvergenceException(lam, W, None, "Number of iterations exceeded. maxit=%d." % maxit)
     return lam, W[:, :len(lam)], V[:, :k + 1], H[:k, :k - 1], om[:k]
+
+
+# ----------------------------------------------------------------------------------
+def _discard_ritz_values(dd, D, R):
+    dd = np.array(dd, dtype=complex)
+    for j in range(len(D)):
+        dd[np.abs(dd - D[j]) < R] = np.inf
+    return dd
+
+
+def residual_eigval_sorter(nep, dd, vv, sigma, D, R, Vk, errmeasure=None):
+    """method_nlar.jl:185-196"""
+    if errmeasure is None:
+        errmeasure = DefaultErrmeasure(nep)
+    dd = np.asarray(dd, dtype=complex)
+    dd2 = _discard_ritz_values(dd, D, R)
+    eig_res = np.array([errmeasure(dd[i], Vk @ vv[:, i]) for i in range(len(dd))])
+    with np.errstate(all="ignore"):
+        key = eig_res * np.abs(dd2 - sigma)
+    key = np.where(np.isnan(key), np.inf, key)
+    ii = np.argsort(key, kind="stable")
+    return dd[ii], vv[:, ii]
+
+
+def nlar(nep, neigs=10, errmeasure=None, tol=EPS * 100, maxit=100, lam=0.0, v=None, linsolvercreator=None, R=0.01,
+         eigval_sorter=residual_eigval_sorter, max_subspace=100, num_restart_ritz_vecs=8, inner_solver_method=None,
+         orthmethod=mgs):
+    """method_nlar.jl:30-164 (qrfact_orth=false); after a restart the projected matrices are rebuilt in full (the
+    reference only refreshes the last row and column)."""
+    n = nep.size(1)
+    maxit = min(maxit, n)
+    num_restart_ritz_vecs = min(num_restart_ritz_vecs, neigs)
+    if max_subspace < num_restart_ritz_vecs:
+        max_subspace = num_restart_ritz_vecs + 20
+    if errmeasure is None:
+        errmeasure = DefaultErrmeasure(nep)
+    if linsolvercreator is None:
+        linsolvercreator = DefaultLinSolverCreator()
+    sigma = complex(lam); nu = sigma
+    V = np.zeros((n, max_subspace + 1), dtype=complex)
+    X = np.zeros((n, neigs), dtype=complex)
+    v = np.array(v, dtype=complex)
+    V[:, 0] = v / np.linalg.norm(v)
+    cbs = 1
+    D = np.zeros(neigs, dtype=complex)
+    m = 0; k = 1
+    linsolver = linsolvercreator.create_linsolver(nep, sigma)
+    err = np.inf; u = None
+    while m < neigs and k < maxit:
+        Vk = V[:, :cbs]
+        pnep = Proj_SPMF_NEP(nep)
+        pnep.set_projectmatrices(Vk, Vk)
+        dd, vv = inner_solve(inner_solver_method, pnep, neigs=neigs, sigma=sigma)
+        dd = np.asarray(dd, dtype=complex).reshape(-1); vv = np.asarray(vv, dtype=complex).reshape(cbs, -1)
+        nuv, yv = eigval_sorter(nep, dd, vv, sigma, D[:m], R, Vk)
+        nu = nuv[0]
+        u = Vk @ yv[:, 0]; u = u / np.linalg.norm(u)
+        res = nep.compute_Mlincomb(nu, u)
+        err = errmeasure(nu, u)
+        if err < tol:
+            D[m] = nu; X[:, m] = u; m += 1
+            if m >= neigs:
+                break
+            nuv, yv = eigval_sorter(nep, dd, vv, sigma, D[:m], R, Vk)
+            u1 = Vk @ yv[:, 0]; u1 = u1 / np.linalg.norm(u1)
+            res = nep.compute_Mlincomb(nuv[0], u1)
+        if cbs >= max_subspace:
+            nr = min(num_restart_ritz_vecs, yv.shape[1])
+            Qh, _ = np.linalg.qr(np.column_stack([X[:, :m], Vk @ yv[:, :nr]]))
+            cbs = Qh.shape[1]
+            V[:, :cbs] = Qh
+        else:
+            dv = linsolver.lin_solve(res)
+            h = np.zeros(cbs, dtype=complex)
+            orthmethod(Vk, dv, h)
+            V[:, cbs] = dv
+            cbs += 1
+        k += 1
+    if k >= maxit and m < neigs:
+        raise NoConvergenceException(nu, u, err, "Number of iterations exceeded. maxit=%d and only %d eigenvalues "
+                                                 "converged out of %d." % (maxit, m, neigs))
+    return D, X

@@ -189,6 +189,32 @@ def test_ilan_vs_oracle(na):
         na.ilan(nep1, neigs=2, maxit=3, tol=EPS * 100, check_error_every=np.inf, v=v0, errmeasure=na.ResidualErrmeasure(nep1))
 
 
+def test_nlar_gun_twin_vs_oracle(na):
+    """test/nlar.jl:12-44 on the device (400-row gun twin, shift_and_scale SPMF, IARInnerSolver, residual sorter): the two
+    eigenvalues equal the oracle's (1e-7), residual thresholds of the reference test; default sorter; NoConvergence (:66)"""
+    import warnings
+    from oracle import gallery as og, solvers as osol, neps as oneps
+    n = 400
+    onep = og.nlevp_native_gun(n)
+    shift, scale = 250.0 ** 2, 330.0 ** 2 - 220.0 ** 2
+    o1 = oneps.shift_and_scale(oneps.SPMF_NEP(onep.get_Av(), onep.get_fv()), shift=shift, scale=scale)
+    nep1 = na.nep_gallery("gun_spmf_scaled", n)
+    TOL = 1e-10
+    kw = dict(tol=TOL, lam=0, maxit=100, neigs=2, R=0.01, v=np.ones(n), max_subspace=150, num_restart_ritz_vecs=8)
+    D, X, hist = na.nlar(nep1, inner_solver_method=na.IARInnerSolver(), **kw)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        Do, Xo = osol.nlar(o1, inner_solver_method=osol.IARInnerSolver(), **kw)
+    _match(D, Do, 1e-7)
+    for i in range(2):
+        lo = shift + scale * D[i]
+        assert np.linalg.norm(onep.compute_Mlincomb(lo, X[:, i])) < np.sqrt(TOL) * 50
+    D2, X2, _ = na.nlar(nep1, inner_solver_method=na.IARInnerSolver(), eigval_sorter=na.default_eigval_sorter, **dict(kw, neigs=1))
+    assert np.linalg.norm(onep.compute_Mlincomb(shift + scale * D2[0], X2[:, 0])) < np.sqrt(TOL) * 50
+    with pytest.raises(na.NoConvergenceException):
+        na.nlar(nep1, tol=1e-20, maxit=3, neigs=3, v=np.ones(n), inner_solver_method=na.IARInnerSolver())
+
+
 def test_projection_and_proj_solve(na):
     """Proj_SPMF_NEP (NEPTypes.jl:724-790): set / expand project matrices against NumPy on a sparse SPMF; then
     proj_solve=true in tiar (test/tiar.jl:70-84 at n=200) and iar (test/iar.jl:29-33) with IARInnerSolver: same eigenvalues

@@ -172,6 +172,25 @@ def test_ilan_docstring():
     assert max(E(lam[i], W[:, i]) for i in range(12)) < 1e-5          # the criterion ilan itself applied (tol)
 
 
+def test_nlar_gun_twin():
+    # test/nlar.jl:12-44 on a 400-row gun twin: nlar on the shifted / scaled SPMF (the recipe of config C2), IARInnerSolver,
+    # residual sorter; residual thresholds of the reference test
+    import warnings
+    n = 400
+    nep = gallery.nlevp_native_gun(n)
+    shift, scale = 250.0 ** 2, 330.0 ** 2 - 220.0 ** 2
+    nep1 = neps.shift_and_scale(neps.SPMF_NEP(nep.get_Av(), nep.get_fv()), shift=shift, scale=scale)
+    TOL = 1e-10
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        D, X = solvers.nlar(nep1, tol=TOL, lam=0, maxit=100, neigs=2, R=0.01, v=np.ones(n),
+                            inner_solver_method=solvers.IARInnerSolver(), max_subspace=150, num_restart_ritz_vecs=8)
+    for i in range(2):
+        lo = shift + scale * D[i]
+        assert np.linalg.norm(nep.compute_Mlincomb(lo, X[:, i])) < np.sqrt(TOL) * 50
+        assert np.linalg.norm(nep.compute_Mder(lo) @ X[:, i]) < np.sqrt(TOL) * 50
+
+
 def test_tiar_iar_proj_solve():
     # test/tiar.jl:70-84 (dep0 of reduced size 200 instead of 1000) and test/iar.jl:29-33: Ritz extraction by projection +
     # inner solve (IARInnerSolver; the reference's default for a DEP is iar_chebyshev, which is not restated)
