@@ -48,13 +48,16 @@ def timed(f):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("which", nargs="*", default=["c1", "c2", "c3", "c4", "c5"])
+    ap.add_argument("which", nargs="*", default=["c1", "c2", "c3", "c4", "c5"], help="c1..c5 and/or x (widened drivers)")
     ap.add_argument("--oracle", action="store_true", help="also run the (slow) CPU oracle for C2/C3")
     ap.add_argument("--wep-nx", type=int, default=303)
     ap.add_argument("--wep-nz", type=int, default=299)
     args = ap.parse_args()
     import nep_amd as na
     from oracle import gallery as og, solvers as osol, neps as oneps
+
+    if "x" in args.which:
+        extras(na)
 
     if "c1" in args.which:
         nep = na.nep_gallery("dep0"); onep = og.dep0()
@@ -138,6 +141,41 @@ def main():
         emit(config="C5 WEP JARLEBRING tiar m=60", nx=nx, nz=nz, n=n, eigenpairs=len(lam), max_residual=max(res + [0.0]),
              gpu_s=t, eigenpairs_per_s=len(lam) / t, generate_s=tgen, phases_s={k_: round(v_, 4) for k_, v_ in tm.items()},
              eigenvalues=[[l.real, l.imag] for l in lam[:6]])
+
+
+def extras(na):
+    """the widened drivers on their reference examples: wall time and the reference's own check"""
+    import warnings
+    shift, scale = 250.0 ** 2, 330.0 ** 2 - 220.0 ** 2
+    gun = na.nep_gallery("nlevp_native_gun"); n = gun.n
+    nep1 = na.nep_gallery("gun_spmf_scaled"); nep1.dev
+    Av, fv = gun.get_Av(), gun.get_fv()
+    res = lambda lo, x: float(np.linalg.norm(sum(f.derivs(lo, 1)[0] * (A @ x) for f, A in zip(fv, Av))))
+    (D, X, _), t = timed(lambda: na.nlar(nep1, tol=1e-10, lam=0, maxit=100, neigs=2, R=0.01, v=np.ones(n),
+                                         inner_solver_method=na.IARInnerSolver(), num_restart_ritz_vecs=8, max_subspace=150))
+    emit(config="X1 gun nlar (test/nlar.jl:28-31)", n=n, eigenpairs=2, gpu_s=t,
+         residuals=[res(shift + scale * D[i], X[:, i]) for i in range(2)], threshold=float(np.sqrt(1e-10) * 50))
+    (lam, Q, _), t = timed(lambda: na.iar(nep1, maxit=40, neigs=np.inf, v=np.ones(n), tol=1e-10, check_error_every=10,
+                                          proj_solve=True, inner_solver_method=na.IARInnerSolver(maxit=60)))
+    emit(config="X2 gun iar m=40 proj_solve=true (checks every 10)", n=n, eigenpairs=len(lam), gpu_s=t)
+    d100 = na.nep_gallery("dep0", 100)
+    (lam, V, _), t = timed(lambda: na.iar_chebyshev(d100, v=np.ones(100), tol=1e-5, neigs=3))
+    ref = np.array([0.050462487848960284, -0.07708779190301127, 0.1503856540695659])
+    emit(config="X3 dep0(100) iar_chebyshev docstring (method_iar_chebyshev.jl:45-56)", eigenpairs=len(lam), gpu_s=t,
+         max_abs_diff_to_docstring=float(np.max(np.abs(lam.real - ref))))
+    ds = na.nep_gallery("dep_symm_double", 10)
+    out, t = timed(lambda: na.ilan(ds, v=np.ones(100), tol=1e-5, neigs=12))
+    refl = np.array([0.03409997385842267, -0.03100798730589012, -0.0367653644764646])
+    emit(config="X4 dep_symm_double(10) ilan docstring (method_ilan.jl:41-52)", eigenpairs=len(out[0]), gpu_s=t,
+         max_dist_docstring_eigs=float(max(np.min(np.abs(out[0] - r)) for r in refl)))
+    g = na.nep_gallery("gun_spmf"); g.dev
+    na.HostLUPool.warm()
+    (lam, V), t = timed(lambda: na.contour_block_SS(g, sigma=250.0 ** 2, radius=1e4, N=64, k=8, K=4, rank_drop_tol=1e-10,
+                                                    Shat_mode="JSIAM"))
+    E = na.StandardSPMFErrmeasure(g)
+    errs = np.array([na.estimate_error(E, lam[i], V[:, i]) for i in range(len(lam))])
+    emit(config="X5 gun contour_block_SS N=64 L=8 K=4 (JSIAM moments)", ritz_values=len(lam),
+         eigenpairs_backward_error_below_1em6=int(np.sum(errs < 1e-6)), gpu_s=t)
 
 
 if __name__ == "__main__":
