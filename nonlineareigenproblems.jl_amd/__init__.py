@@ -22,6 +22,7 @@ from .tiar import tiar
 from .iar_chebyshev import iar_chebyshev
 from .ilan import ilan
 from .nlar import nlar, residual_eigval_sorter, default_eigval_sorter
+from .jd import jd_betcke, jd_eig_sorter
 from .newton import resinv, quasinewton, augnewton, compute_rf, armijo_rule, ScalarNewtonInnerSolver
 from .projection import (Proj_SPMF_NEP, create_proj_NEP, inner_solve, InnerSolver, DefaultInnerSolver, IARInnerSolver,
                          NewtonInnerSolver, IARChebInnerSolver, PolyeigInnerSolver, polyeig)

@@ -197,7 +197,8 @@ class DEP(AbstractSPMF):
     """NEPTypes.jl:427-443."""
 
     def __init__(self, AA, tauv=(0.0, 1.0)):
-        self.A = [sp.csc_matrix(A) if _issparse(A) else np.asarray(A, dtype=float) for A in AA]
+        self.A = [sp.csc_matrix(A) if _issparse(A) else
+                  np.asarray(A, dtype=complex if np.iscomplexobj(A) else float) for A in AA]   # projected DEPs are complex
         self.tauv = np.array(tauv, dtype=float)
         self.n = AA[0].shape[0]
 

@@ -923,3 +923,60 @@ def nlar(nep, neigs=10, errmeasure=None, tol=EPS * 100, maxit=100, lam=0.0, v=No
         raise NoConvergenceException(nu, u, err, "Number of iterations exceeded. maxit=%d and only %d eigenvalues "
                                                  "converged out of %d." % (maxit, m, neigs))
     return D, X
+
+
+# ----------------------------------------------------------------------------------
+def jd_betcke(nep, maxit=100, neigs=1, projtype="PetrovGalerkin", inner_solver_method=None, orthmethod=dgks,
+              errmeasure=None, linsolvercreator=None, tol=EPS * 100, lam=0.0, v=None, target=0.0):
+    """method_jd.jl:52-175"""
+    n = nep.size(1)
+    if maxit > n:
+        raise ValueError("maxit = %d is larger than size of NEP = %d." % (maxit, n))
+    if errmeasure is None:
+        errmeasure = DefaultErrmeasure(nep)
+    if linsolvercreator is None:
+        linsolvercreator = DefaultLinSolverCreator()
+    lam = complex(lam); target = complex(target)
+    lam_vec = np.zeros(neigs, dtype=complex); u_vec = np.zeros((n, neigs), dtype=complex)
+    u = np.array(v, dtype=complex); u = u / np.linalg.norm(u)
+    conveig = 0
+    err = errmeasure(lam, u)
+    if err < tol:
+        lam_vec[conveig] = lam; u_vec[:, conveig] = u; conveig += 1
+    if conveig == neigs:
+        return lam_vec, u_vec
+    Vm = np.zeros((n, maxit + 1), dtype=complex); Vm[:, 0] = u
+    pg = projtype == "PetrovGalerkin"
+    if pg:
+        Wm = np.zeros((n, maxit + 1), dtype=complex)
+        w0 = nep.compute_Mlincomb(lam, u); Wm[:, 0] = w0 / np.linalg.norm(w0)
+    else:
+        Wm = Vm
+    for k in range(1, maxit + 1):
+        V = Vm[:, :k]; W = Wm[:, :k]
+        pnep = Proj_SPMF_NEP(nep)
+        pnep.set_projectmatrices(W, V)
+        lamv, sv = inner_solve(inner_solver_method, pnep, lamv=lam * np.ones(conveig + 1, dtype=complex), sigma=target,
+                               neigs=conveig + 1)
+        lamv = np.asarray(lamv, dtype=complex).reshape(-1); sv = np.asarray(sv).reshape(k, -1)
+        NN = min(conveig + 1, len(lamv))
+        c = np.argsort(abs(lamv - target), kind="stable")
+        lam = lamv[c[NN - 1]]; s = sv[:, c[NN - 1]]; s = s / np.linalg.norm(s)
+        u = V @ s
+        err = errmeasure(lam, u)
+        if err < tol and (conveig == 0 or np.all(abs(lam - lam_vec[:conveig]) / abs(lam_vec[:conveig]) > np.sqrt(np.sqrt(EPS)))):
+            lam_vec[conveig] = lam; u_vec[:, conveig] = u; conveig += 1
+        if conveig == neigs:
+            return lam_vec, u_vec
+        pk = nep.compute_Mlincomb(lam, u.reshape(-1, 1), [1.0], 1)
+        vnew = linsolvercreator.create_linsolver(nep, lam).lin_solve(pk)
+        h = np.zeros(k, dtype=complex)
+        orthmethod(V, vnew, h)
+        Vm[:, k] = vnew
+        if pg:
+            wnew = nep.compute_Mlincomb(lam, u)
+            orthmethod(W, wnew, h)
+            Wm[:, k] = wnew
+    raise NoConvergenceException(np.concatenate([lam_vec[:conveig], [lam]]), np.column_stack([u_vec[:, :conveig], u]), err,
+                                 "Number of iterations exceeded. maxit=%d and only %d eigenvalues converged out of %d."
+                                 % (maxit, conveig, neigs))

@@ -215,6 +215,38 @@ def test_nlar_gun_twin_vs_oracle(na):
         na.nlar(nep1, tol=1e-20, maxit=3, neigs=3, v=np.ones(n), inner_solver_method=na.IARInnerSolver())
 
 
+def test_jd_betcke_vs_oracle(na):
+    """test/jd.jl:15-60 on the device with in-tree problems: random quadratic PEP (n=60, default inner solver = polyeig of
+    the projected PEP), dep0(40) with the default (Chebyshev) inner solver, Galerkin projection, restart from a converged
+    pair, the error cases; eigenvalues against the oracle"""
+    import warnings
+    from oracle import gallery as og, solvers as osol, neps as oneps
+    rng = np.random.default_rng(0)
+    n = 60
+    B = [rng.standard_normal((n, n)) for _ in range(3)]
+    pep = na.PEP(B); opep = oneps.PEP(B)
+    lam, u = na.jd_betcke(pep, tol=1e-11, maxit=55, neigs=2, v=np.ones(n), lam=0, errmeasure=na.ResidualErrmeasure(pep))
+    assert max(np.linalg.norm(opep.compute_Mlincomb(lam[i], u[:, i])) / np.linalg.norm(u[:, i]) for i in range(2)) < 1e-10
+    dep = na.nep_gallery("dep0", 40); odep = og.dep0(40)
+    lam, u = na.jd_betcke(dep, tol=1e-10, maxit=30, v=np.ones(40), lam=0)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lo, uo = osol.jd_betcke(odep, tol=1e-10, maxit=30, v=np.ones(40), lam=0)
+    assert osol.DefaultErrmeasure(odep)(lam[0], u[:, 0]) < 1e-10
+    _match(lam, lo, 1e-7)
+    lam2, u2 = na.jd_betcke(dep, tol=1e-10, maxit=25, neigs=1, lam=lam[0], v=u[:, 0])          # converged before starting
+    assert abs(lam2[0] - lam[0]) < 1e-12
+    lam3, u3 = na.jd_betcke(dep, tol=1e-10, maxit=30, v=np.ones(40), lam=0, projtype="Galerkin", inner_solver_method=na.IARInnerSolver())
+    assert osol.DefaultErrmeasure(odep)(lam3[0], u3[:, 0]) < 1e-10
+    small = na.PEP([b[:10, :10] for b in B])
+    with pytest.raises(ValueError):
+        na.jd_betcke(small, tol=1e-10, maxit=60, v=np.ones(10))
+    with pytest.raises(ValueError):
+        na.jd_betcke(small, tol=1e-10, maxit=4, projtype="MYNOTDEFINED", v=np.ones(10))
+    with pytest.raises(na.NoConvergenceException):
+        na.jd_betcke(small, tol=1e-10, maxit=4, lam=10.0, neigs=1000, v=np.ones(10))
+
+
 def test_projection_and_proj_solve(na):
     """Proj_SPMF_NEP (NEPTypes.jl:724-790): set / expand project matrices against NumPy on a sparse SPMF; then
     proj_solve=true in tiar (test/tiar.jl:70-84 at n=200) and iar (test/iar.jl:29-33) with IARInnerSolver: same eigenvalues

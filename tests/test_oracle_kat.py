@@ -191,6 +191,23 @@ def test_nlar_gun_twin():
         assert np.linalg.norm(nep.compute_Mder(lo) @ X[:, i]) < np.sqrt(TOL) * 50
 
 
+def test_jd_betcke():
+    # test/jd.jl:15-37 with in-tree problems: a random quadratic PEP of size 60 (pep0 stand-in), 2 eigenpairs to 1e-11;
+    # dep0(40) with the default inner solver (DEP -> iar_chebyshev on the normalised projected DEP), 1 eigenpair to 1e-10
+    import warnings
+    rng = np.random.default_rng(0)
+    n = 60
+    pep = neps.PEP([rng.standard_normal((n, n)) for _ in range(3)])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lam, u = solvers.jd_betcke(pep, tol=1e-11, maxit=55, neigs=2, v=np.ones(n), lam=0,
+                                   errmeasure=solvers.ResidualErrmeasure(pep), inner_solver_method=solvers.IARInnerSolver())
+        assert max(np.linalg.norm(pep.compute_Mlincomb(lam[i], u[:, i])) / np.linalg.norm(u[:, i]) for i in range(2)) < 1e-11
+        dep = gallery.dep0(40)
+        lam, u = solvers.jd_betcke(dep, tol=1e-10, maxit=30, v=np.ones(40), lam=0)
+        assert solvers.DefaultErrmeasure(dep)(lam[0], u[:, 0]) < 1e-10
+
+
 def test_tiar_iar_proj_solve():
     # test/tiar.jl:70-84 (dep0 of reduced size 200 instead of 1000) and test/iar.jl:29-33: Ritz extraction by projection +
     # inner solve (IARInnerSolver; the reference's default for a DEP is iar_chebyshev, which is not restated)
