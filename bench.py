@@ -118,7 +118,8 @@ def beyn_sharded(na, args, world, rank):
     nep = na.nep_gallery("gun_spmf", args.n)
     nep.dev
     Vh = na.probe_block(nep.n, 32)
-    na.HostLUPool.warm()
+    # worker processes for the host factorisations of THIS rank's nodes (64/world of them): no more workers than nodes
+    na.HostLUPool.warm(max(2, min(16, -(-64 // max(world, 1)))))
     distd = dist.is_available() and dist.is_initialized()
     integ = na.MatrixTrapezoidalSharded if distd else na.MatrixTrapezoidal
     kw = dict(sigma=250.0 ** 2, radius=1e4, N=64, k=32, neigs=10 ** 6, tol=1e-6, sanity_check=True, Vh=Vh)

@@ -43,6 +43,8 @@ class HostLUPool:
 
     @classmethod
     def get(cls, workers=None):
+        if workers is None and cls._pool is not None:
+            return cls._pool                    # whatever size it was started with
         if workers is None:
             workers = int(os.environ.get("NEP_HOSTLU_WORKERS", min(16, max(1, (os.cpu_count() or 2) // 2))))
         if cls._pool is None or cls._workers != workers:
