@@ -97,6 +97,11 @@ class Proj_SPMF_NEP:
         k = Vd.shape[0] - 1
         if k + 1 > self.maxsize:
             raise ValueError("projection larger than the preallocated size (maxsize=%d)" % self.maxsize)
+        if k + 1 > 4:
+            # the new row needs A_i v_j for every old column again (k+1 SpMVs and as many synchronising dot calls per
+            # term); from a handful of columns on, one batched pass (K2 SpMM + K9) over the whole basis is cheaper and
+            # gives the same matrices
+            return self.set_projectmatrices(Wd, Vd)
         n = self.orgnep.size(1)
         for i in range(len(self.orgnep_fv)):
             B = self.projnep_B_mem[i]
