@@ -28,6 +28,8 @@
 #include <vector>
 #include <algorithm>
 #include <chrono>
+#include <thread>
+#include <cstring>
 
 #define TRSV_WIDE_MIN 48      // a level with at least this many rows gets its own multi-WG launch
 #define TRSV_TAIL_SMALL 4     // levels with <= this many rows are "chain" levels (dense tail)
@@ -805,22 +807,29 @@ static int lu_build(nep_lu* lu, int64_t n, const int32_t* hLp, const int32_t* hL
     lu->h0 = h0;
     int rc;
     TSTAMP("validate+levels");
-    // ---- heads
+    // ---- heads and mid blocks: the L side and the U side are independent (host analysis, uploads, inverse kernels),
+    // so the U side runs on a second host thread
     int32_t nl = 0;
+    int rcU = NEP_OK;
+    char errU[512] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::thread side([&]() {
+        (void)hipSetDevice(dev);
+        std::vector<int32_t> levU(n, 0);
+        int32_t nlU = 0;
+        compute_levels(n, hUp, hUi, true, 0, h0, levU, nlU);
+        rcU = build_tri(n, hUp, hUi, hUx, true, 0, h0, 0, n, levU, nlU, lu->U11);   // keeps the columns >= h0 (final by then)
+        if (rcU == NEP_OK && lu->nblk > 0) rcU = build_mid(hUp, hUi, hUx, true, h0, lu->nblk, lu->bsz, lu->Um);
+        if (rcU != NEP_OK) { strncpy(errU, nep_last_error(), sizeof(errU) - 1); }
+    });
     compute_levels(n, hLp, hLi, false, 0, h0, level, nl);
     rc = build_tri(n, hLp, hLi, hLx, false, 0, h0, 0, h0, level, nl, lu->L11);
+    if (rc == NEP_OK && lu->nblk > 0) rc = build_mid(hLp, hLi, hLx, false, h0, lu->nblk, lu->bsz, lu->Lm);
+    side.join();
     if (rc) return rc;
-    compute_levels(n, hUp, hUi, true, 0, h0, level, nl);
-    rc = build_tri(n, hUp, hUi, hUx, true, 0, h0, 0, n, level, nl, lu->U11);   // keeps the columns >= h0 (final by then)
-    if (rc) return rc;
-    TSTAMP("heads build+upload");
-    if (lu->nblk > 0) {
-        rc = build_mid(hLp, hLi, hLx, false, h0, lu->nblk, lu->bsz, lu->Lm);
-        if (rc) return rc;
-        rc = build_mid(hUp, hUi, hUx, true, h0, lu->nblk, lu->bsz, lu->Um);
-        if (rc) return rc;
-        TSTAMP("mid blocks");
-    }
+    if (rcU) { nep_set_error("%s", errU); return rcU; }
+    TSTAMP("heads + mid blocks (L || U)");
     if (T == 0) return NEP_OK;
     // ---- L21 (tail rows, head columns)
     {
