@@ -77,6 +77,18 @@ int32_t nep_csc_to_csr(int64_t n, const int64_t* colptr, const int64_t* rowval, 
                        int32_t val_is_complex, int32_t one_based, int32_t* rowptr, int32_t* colind,
                        void* vals);
 
+/* ---- rectangular CSR operator (complex values, 0-based int32 indices) ----------------------
+ * replaces: the low-rank factors held by RKNEP, src/rk_helper/rk_nep.jl:19-32,128-152 -- UU (hcat of the U_i,
+ *           applied as UU' at src/method_nleigs.jl:430,480,510) and the rows LL / iLr of [L_1 ... L_q]
+ *           (scalar loop at :464-471).  nep_csr_mv:  y = alpha*A*x + beta*z   (x: cols entries, y, z: rows
+ *           entries; z may alias y and is not read when beta == 0). */
+typedef struct nep_csr nep_csr;
+int32_t nep_csr_create(int64_t rows, int64_t cols, const int32_t* h_rowptr, const int32_t* h_colind,
+                       const nep_cdouble* h_vals, nep_csr** out);
+int32_t nep_csr_destroy(nep_csr* a);
+int32_t nep_csr_mv(const nep_csr* a, nep_cdouble alpha, const nep_cdouble* dx, nep_cdouble beta,
+                   const nep_cdouble* dz, nep_cdouble* dy, nep_stream stream);
+
 /* K1  z = sum_i A_i * (V * C[:,i])          V: n x k (ldv), C: k x mt (host, column-major)
  * replaces: compute_Mlincomb!(::SPMF_NEP,...) src/NEPTypes.jl:972-1011 and
  *           compute_Mlincomb(::DerSPMF,...)   src/NEPTypes.jl:1130-1160 (VafD=V*(a.*fD); z+=Av[j]*VafD[:,j]),

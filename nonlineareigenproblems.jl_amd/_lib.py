@@ -63,6 +63,9 @@ SIGNATURES = {
     "nep_resid_batch_dev": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp],
     "nep_resid_block": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_i64, c_vp],
     "nep_spmm_terms": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp],
+    "nep_csr_create": [c_i64, c_i64, c_vp, c_vp, c_vp, P(c_vp)],
+    "nep_csr_destroy": [c_vp],
+    "nep_csr_mv": [c_vp, cdouble, c_vp, cdouble, c_vp, c_vp, c_vp],
     "nep_orth": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, P(c_dbl), c_i32, P(c_i32), c_vp],
     "nep_orth_dev": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp],
     "nep_gemv_h": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp],

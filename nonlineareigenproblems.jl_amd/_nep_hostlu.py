@@ -1,6 +1,10 @@
 """Host sparse LU (SuperLU via SciPy) as a plain function of arrays, importable WITHOUT torch/HIP so that it can run
-in worker processes (Beyn: one new matrix per quadrature node, src/method_beyncontour.jl:89-94; SciPy's splu holds
-the GIL, so concurrency needs processes).  Returns the factors in the CSR form nep_lu_create expects."""
+in worker processes (Beyn: one new matrix per quadrature node, src/method_beyncontour.jl:89-94; SciPy's splu releases
+the GIL for other Python threads but two splu calls of one process do not overlap -- measured: 4 threads take as long
+as 4 sequential calls -- so concurrent factorisations need processes, while ONE background thread is enough to overlap a
+factorisation with device work, see linsolvers.LinSolverCache.prefetch).  Returns the factors in the CSR form
+nep_lu_create expects."""
+import threading
 import time
 
 import numpy as np
@@ -71,6 +75,40 @@ def pattern_symmetric(Ac, threshold=0.5):
     return sym >= threshold
 
 
+class _blas_limit:
+    """`with _blas_limit(n)`: process-wide BLAS thread limit for the duration of a factorisation.  Re-entrant across
+    threads (several factorisations may run on worker threads at once): the first one in sets the limit, the last one
+    out restores it, so an interleaved exit cannot leave the process at the inner value."""
+    _lock = threading.Lock()
+    _depth = 0
+    _ctx = None
+
+    def __init__(self, nthreads):
+        self.nthreads = nthreads
+
+    def __enter__(self):
+        ctl = blas_controller()
+        if ctl is None:
+            return self
+        cls = _blas_limit
+        with cls._lock:
+            if cls._depth == 0:
+                cls._ctx = ctl.limit(limits=self.nthreads, user_api="blas")
+            cls._depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        if blas_controller() is None:
+            return False
+        cls = _blas_limit
+        with cls._lock:
+            cls._depth -= 1
+            if cls._depth == 0 and cls._ctx is not None:
+                cls._ctx.restore_original_limits()
+                cls._ctx = None
+        return False
+
+
 def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None, symmetric_mode=None, panel_size=8,
            relax=4):
     """UMFPACK-like strategy selection (see linsolvers.DeviceLU) + SuperLU factorisation.
@@ -101,12 +139,8 @@ def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None
     # large problems whose supernodes are big enough for threaded zgemm/ztrsm to pay (measured: n = 91k 0.36 -> 0.40 s,
     # n = 251k 1.90 -> 1.71 s, n = 1e6 13.5 -> 10.4 s with 8 threads; scripts/diag/superlu_threads.py)
     nthreads = 1 if shape[0] < 200000 else 8
-    ctl = blas_controller()
-    if ctl is not None:
-        with ctl.limit(limits=nthreads, user_api="blas"):
-            lu = spla.splu(Ac, **kw)  # RuntimeError("Factor is exactly singular") propagates to the caller
-    else:
-        lu = spla.splu(Ac, **kw)
+    with _blas_limit(nthreads):
+        lu = spla.splu(Ac, **kw)  # RuntimeError("Factor is exactly singular") propagates to the caller
     t_factor = time.perf_counter() - t0
     L = sp.csr_matrix(lu.L); U = sp.csr_matrix(lu.U)
     L.sort_indices(); U.sort_indices()

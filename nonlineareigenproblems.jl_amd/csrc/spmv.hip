@@ -739,3 +739,96 @@ int32_t nep_spmm_terms(nep_spmf* s, int32_t p, const nep_cdouble* dXT, int64_t l
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------
+// Rectangular CSR operator (low-rank factors of NLEIGS: UU^H is r x n, [L_1 ... L_q] is n x r;
+// src/rk_helper/rk_nep.jl:128-152, used at src/method_nleigs.jl:430,464-471,480,510).
+//   y = alpha * A * x + beta * z      (z may alias y; z is not read when beta == 0)
+// LANES lanes cooperate on a row; rows are few or short here, so the kernel is latency-bound by design.
+struct nep_csr {
+    int64_t rows = 0, cols = 0, nnz = 0;
+    int32_t lanes = 8;
+    int32_t* d_rowptr = nullptr;
+    int32_t* d_col = nullptr;
+    cplx* d_val = nullptr;
+};
+
+template <int LANES>
+__global__ __launch_bounds__(256) void k_csr_mv(int64_t rows, const int32_t* __restrict__ rowptr,
+                                                const int32_t* __restrict__ col, const cplx* __restrict__ val,
+                                                cplx alpha, const cplx* __restrict__ x, cplx beta, const cplx* z,
+                                                cplx* y) {
+    constexpr int RPB = 256 / LANES;
+    const int lane = threadIdx.x % LANES;
+    const bool use_z = (beta.x != 0.0 || beta.y != 0.0);
+    for (int64_t r = blockIdx.x * (int64_t)RPB + threadIdx.x / LANES; r < rows; r += (int64_t)gridDim.x * RPB) {
+        cplx acc = cmake(0.0, 0.0);
+        const int32_t e0 = rowptr[r], e1 = rowptr[r + 1];
+        for (int32_t e = e0 + lane; e < e1; e += LANES) cfma(acc, val[e], x[col[e]]);
+        acc = group_reduce_sum<LANES>(acc);
+        if (lane == 0) {
+            cplx out = cmul(alpha, acc);
+            if (use_z) cfma(out, beta, z[r]);
+            y[r] = out;
+        }
+    }
+}
+
+extern "C" {
+
+int32_t nep_csr_create(int64_t rows, int64_t cols, const int32_t* h_rowptr, const int32_t* h_colind,
+                       const nep_cdouble* h_vals, nep_csr** out) {
+    ARGCHK(out && h_rowptr && rows >= 1 && cols >= 1);
+    *out = nullptr;
+    const int64_t nnz = h_rowptr[rows];
+    ARGCHK(h_rowptr[0] == 0 && nnz >= 0 && (nnz == 0 || (h_colind && h_vals)));
+    for (int64_t r = 0; r < rows; ++r) ARGCHK(h_rowptr[r + 1] >= h_rowptr[r]);
+    for (int64_t e = 0; e < nnz; ++e) ARGCHK(h_colind[e] >= 0 && h_colind[e] < cols);
+    nep_csr* a = new nep_csr();
+    a->rows = rows; a->cols = cols; a->nnz = nnz;
+    const double avg = (double)nnz / (double)rows;
+    a->lanes = avg >= 48 ? 64 : (avg >= 6 ? 16 : 4);
+#define CSRCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { nep_set_error("%s:%d: %s: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); nep_csr_destroy(a); return NEP_ERR_HIP; } } while (0)
+    CSRCHK(hipMalloc((void**)&a->d_rowptr, (size_t)(rows + 1) * sizeof(int32_t)));
+    CSRCHK(hipMalloc((void**)&a->d_col, (size_t)(nnz + 1) * sizeof(int32_t)));
+    CSRCHK(hipMalloc((void**)&a->d_val, (size_t)(nnz + 1) * sizeof(cplx)));
+    CSRCHK(hipMemcpy(a->d_rowptr, h_rowptr, (size_t)(rows + 1) * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (nnz) {
+        CSRCHK(hipMemcpy(a->d_col, h_colind, (size_t)nnz * sizeof(int32_t), hipMemcpyHostToDevice));
+        CSRCHK(hipMemcpy(a->d_val, h_vals, (size_t)nnz * sizeof(cplx), hipMemcpyHostToDevice));
+    }
+#undef CSRCHK
+    *out = a;
+    return NEP_OK;
+}
+
+int32_t nep_csr_destroy(nep_csr* a) {
+    if (!a) return NEP_OK;
+    if (a->d_rowptr) (void)hipFree(a->d_rowptr);
+    if (a->d_col) (void)hipFree(a->d_col);
+    if (a->d_val) (void)hipFree(a->d_val);
+    delete a;
+    return NEP_OK;
+}
+
+int32_t nep_csr_mv(const nep_csr* a, nep_cdouble alpha, const nep_cdouble* dx, nep_cdouble beta,
+                   const nep_cdouble* dz, nep_cdouble* dy, nep_stream stream) {
+    ARGCHK(a && dx && dy);
+    ARGCHK((beta.re == 0.0 && beta.im == 0.0) || dz);
+    hipStream_t st = as_stream(stream);
+    cplx al, be;
+    al.x = alpha.re; al.y = alpha.im; be.x = beta.re; be.y = beta.im;
+    const int64_t rows = a->rows;
+#define CSR_LAUNCH(L)                                                                                         \
+    hipLaunchKernelGGL(k_csr_mv<L>, dim3((unsigned)std::min<int64_t>((rows + 256 / L - 1) / (256 / L), 8192)), \
+                       dim3(256), 0, st, rows, a->d_rowptr, a->d_col, a->d_val, al, (const cplx*)dx, be,      \
+                       (const cplx*)dz, (cplx*)dy)
+    if (a->lanes == 64) CSR_LAUNCH(64);
+    else if (a->lanes == 16) CSR_LAUNCH(16);
+    else CSR_LAUNCH(4);
+#undef CSR_LAUNCH
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+}  // extern "C"

@@ -406,21 +406,80 @@ def create_linsolver(creator, nep, lam):
 
 
 class LinSolverCache:
-    """src/rk_helper/linsolvercache.jl:7-26."""
+    """src/rk_helper/linsolvercache.jl:7-26.
 
-    def __init__(self, nep, linsolvercreator):
+    `prefetch(shifts)`: a driver that knows its next shifts (nleigs: the node sequence sigma) announces them; their host
+    factorisations (compute_Mder + SuperLU, which releases the GIL) then run on one background thread while the device
+    works on the current step, and `_get` only builds the device schedule from the finished factors.  Only for the
+    factorising creator; at most `ahead` factorisations are in flight or waiting to be used."""
+
+    def __init__(self, nep, linsolvercreator, ahead=2):
         self.nep = nep
         self.linsolvercreator = linsolvercreator
         self.solvers = {}
+        self.ahead = ahead
+        self._pending = {}
+        self._pool = None
+
+    def _host_factors(self, sigma):
+        c = self.linsolvercreator
+        Ac = sp.csc_matrix(self.nep.compute_Mder(sigma), dtype=np.complex128)
+        kw = {k: v for k, v in c.lu_kw.items() if k in ("diag_pivot_thresh", "symmetric_mode")}
+        return _nep_hostlu.factor(Ac.data, Ac.indices, Ac.indptr, Ac.shape, permc_spec=c.permc_spec, **kw)
+
+    def prefetch(self, shifts):
+        c = self.linsolvercreator
+        if type(c) is not FactorizeLinSolverCreator or os.environ.get("NEP_LU_PREFETCH", "1") == "0":
+            return
+        for s in shifts:
+            key = complex(s)
+            if len(self._pending) >= self.ahead:
+                break
+            if not np.isfinite(key) or key in self.solvers or key in self._pending or key in c.recycled_factorizations:
+                continue
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="nep-lu-prefetch")
+            self._pending[key] = self._pool.submit(self._host_factors, key)
 
     def _get(self, sigma, add_to_cache):
         key = complex(sigma)
         if key in self.solvers:
             return self.solvers[key]
-        solver = create_linsolver(self.linsolvercreator, self.nep, sigma)
+        c = self.linsolvercreator
+        if key in self._pending:
+            try:
+                factors = self._pending.pop(key).result()
+            except RuntimeError as e:  # "Factor is exactly singular"
+                raise np.linalg.LinAlgError("SingularException: " + str(e))
+            lu_kw = dict(c.lu_kw); lu_kw.setdefault("expected_solves", 200)
+            lu = DeviceLU(factors=factors, **{k: v for k, v in lu_kw.items() if k == "expected_solves"})
+            solver = FactorizeLinSolver(self.nep, sigma, c.umfpack_refinements, _lu=lu)
+            if len(c.recycled_factorizations) < c.max_factorizations:
+                c.recycled_factorizations[key] = lu
+        elif self._pool is not None:
+            # keep host factorisations on the one worker thread (they toggle the process-wide BLAS thread count)
+            self._pending[key] = self._pool.submit(self._host_factors, key)
+            return self._get(sigma, add_to_cache)
+        else:
+            solver = create_linsolver(c, self.nep, sigma)
         if add_to_cache:
             self.solvers[key] = solver
         return solver
+
+    def close(self):
+        if self._pool is not None:
+            for f in self._pending.values():
+                f.cancel()
+            self._pool.shutdown(wait=True)
+            self._pool = None
+            self._pending = {}
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def solve(self, sigma, y, add_to_cache):
         return lin_solve(self._get(sigma, add_to_cache), y)

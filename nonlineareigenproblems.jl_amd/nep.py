@@ -144,6 +144,35 @@ class SPMFDevice:
         return self.matrix_bytes + 16 * self.n * k + 16 * self.n
 
 
+class DeviceCSR:
+    """Rectangular complex CSR operator on the device (nep_csr handle): y = alpha A x + beta z."""
+
+    def __init__(self, A):
+        _lib.require_gpu()
+        M = sp.csr_matrix(A)
+        M.sum_duplicates(); M.sort_indices()
+        self.shape = M.shape
+        ip = np.ascontiguousarray(M.indptr, dtype=np.int32)
+        ix = np.ascontiguousarray(M.indices, dtype=np.int32)
+        dv = np.ascontiguousarray(M.data, dtype=np.complex128)
+        h = c_vp()
+        check(lib.nep_csr_create(M.shape[0], M.shape[1], hptr(ip), hptr(ix), hptr(dv), C.byref(h)))
+        self.h = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib.nep_csr_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    def mv(self, alpha, x, beta, z, y):
+        """x, z, y: raw device addresses (int) or tensors; z may be None when beta == 0"""
+        a = lambda t: c_vp(t.data_ptr() if is_dev(t) else t) if t is not None else c_vp(0)
+        check(lib.nep_csr_mv(self.h, _lib.cd(alpha), a(x), _lib.cd(beta), a(z), a(y), stream_ptr()))
+
+
 class PendingNorms:
     """result of an asynchronous residual batch: ready() polls the event, get() waits and unpacks"""
 
@@ -339,11 +368,12 @@ class SPMF_NEP(AbstractSPMF):
 
 
 class LowRankMatrixAndFunction:
-    """src/rk_helper/rk_nep.jl:41-53: a matrix A = L U^H of low rank with its function f.  The factors come from a
-    rank-revealing (column-pivoted QR) factorisation of the block of A that holds its non-zeros; `L`, `U` are sparse
-    n x r.  (The reference takes L, U from an unpivoted reading of `lu`, :71-83; only A = L U^H is relied upon.)"""
+    """src/rk_helper/rk_nep.jl:41-53: a matrix A = L U^H of low rank with its function f.  As in the reference (:70-100)
+    the factors are the LU factors of the dense block that holds the non-zeros of A, compacted to the columns of L / rows of
+    U that carry anything; `L`, `U` are sparse n x r.  The row permutation of the LU (which the reference drops, relying
+    on no interchange taking place) is folded into L, so A = L U^H holds for every input."""
 
-    def __init__(self, A, f, L=None, U=None, tol=1e-13):
+    def __init__(self, A, f, L=None, U=None):
         import scipy.linalg as sla
         self.f = f
         if L is not None and U is not None:
@@ -354,27 +384,25 @@ class LowRankMatrixAndFunction:
         self.A = A
         n = A.shape[0]
         coo = A.tocoo()
-        if coo.nnz == 0:
+        nz = coo.data != 0
+        if not np.any(nz):
             self.L = sp.csc_matrix((n, 0)); self.U = sp.csc_matrix((n, 0))
             return
-        r0, r1 = coo.row.min(), coo.row.max() + 1
-        c0, c1 = coo.col.min(), coo.col.max() + 1
-        B = A[r0:r1, c0:c1].toarray()
-        Q, R, piv = sla.qr(B, mode="economic", pivoting=True)
-        d = np.abs(np.diag(R))
-        r = int(np.sum(d > tol * max(d[0], 1e-300))) if len(d) else 0
-        Ru = np.zeros((r, c1 - c0), dtype=R.dtype)
-        Ru[:, piv] = R[:r, :]
-        Lf = sp.lil_matrix((n, r), dtype=Q.dtype); Lf[r0:r1, :] = Q[:, :r]
-        Uf = sp.lil_matrix((n, r), dtype=R.dtype); Uf[c0:c1, :] = Ru.conj().T
+        r0, r1 = coo.row[nz].min(), coo.row[nz].max() + 1
+        c0, c1 = coo.col[nz].min(), coo.col[nz].max() + 1
+        Pm, Lb, Ub = sla.lu(A[r0:r1, c0:c1].toarray())
+        sel = [i for i in range(min(Lb.shape[1], Ub.shape[0]))
+               if np.count_nonzero(Lb[i:, i]) > 1 or np.count_nonzero(Ub[i, i:]) > 0]
+        Lf = sp.lil_matrix((n, len(sel)), dtype=Lb.dtype); Lf[r0:r1, :] = (Pm @ Lb)[:, sel]
+        Uf = sp.lil_matrix((n, len(sel)), dtype=Ub.dtype); Uf[c0:c1, :] = Ub[sel, :].conj().T
         self.L, self.U = sp.csc_matrix(Lf), sp.csc_matrix(Uf)
 
 
 class LowRankFactorizedNEP(SPMF_NEP):
     """src/NEPTypes.jl (LowRankFactorizedNEP) + rk_nep.jl:59-67: an SPMF whose matrices carry low-rank factors
-    A_i = L_i U_i^H.  On this backend the terms run through the same stacked-CSR kernels as any sparse SPMF term; the
-    compression of the Krylov vectors that the reference's nleigs derives from the factors (method_nleigs.jl:406-414) is
-    not applied -- same eigenpairs, more memory."""
+    A_i = L_i U_i^H.  The terms run through the same stacked-CSR kernels as any sparse SPMF term; `nleigs` uses the factors
+    to shrink the blocks of its Krylov vectors beyond the polynomial degree from n to r = sum r_i rows
+    (method_nleigs.jl:206-211,406-414)."""
 
     def __init__(self, Amf):
         super().__init__([M.A for M in Amf], [M.f for M in Amf])

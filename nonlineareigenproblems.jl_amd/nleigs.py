@@ -2,8 +2,9 @@
 
 Supported: SPMF-type NEPs (PEP, SPMF_NEP, PEP+SPMF SumNEP, DEP), dynamic and static variants, return_details
 (NleigsSolutionDetails), divided differences by matrix functions (isfunm=true) or by differencing (isfunm=false),
-leja in {0,1,2}, reusefact in {0,1,2}; not supported: the LowRankFactorizedNEP compression (rk_nep.jl:59-67; low-rank
-terms are treated as general sparse matrices, same result) and non-SPMF NEP types.
+leja in {0,1,2}, reusefact in {0,1,2}, and the low-rank compression of PEP + LowRankFactorizedNEP problems
+(rk_nep.jl:128-152; method_nleigs.jl:206-211,406-414,424-430,464-471,480,510: the blocks of the Krylov vectors beyond the
+polynomial degree p hold r = sum rank(C_i) rows instead of n -- gun: 84 instead of 9956).  Not supported: non-SPMF NEP types.
 
 Device realisation of `backslash` (method_nleigs.jl:399-518).  The reference runs O(N) stacked SpMVs per step
 (`sum(reshape(BBCC*z_block,n,:) .* transpose(sgdd[:,ii+1]),dims=2)`, :462).  The block recurrence for z does not
@@ -13,6 +14,9 @@ depend on z[1:n], so here
    z0          ONE K1 call with k = N columns:  sum_j A_j (Z_blocks * sgdd[j,2:N+1]^T)   (nep_mlincomb)
    w0          K5 with the cached factorisation of the shift (LinSolverCache), scaled by -1/beta_1
    w blocks    one pass            (nep_block_recur)
+With low-rank structure the same steps run over p blocks of n rows and N-p+1 blocks of r rows; the three seams
+(Bw_p, z_p, w_p) apply UU^H and the tail of z0 applies [L_1 ... L_q] through the rectangular CSR operator (nep_csr_mv),
+the weighted block sum in between is one nep_rowdot.
 followed by K6 DGKS on the (N+1) n-row basis with per-column active row counts, and -- every check_error_every
 steps -- host `eig(K,H)`, one K7 GEMM for the Ritz block and K2 for all residuals.
 """
@@ -56,6 +60,13 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
     n = nep.size(1)
     p, q = rk.rk_structure(nep)
     mt = len(nep.get_Av())
+    LR = rk.low_rank_structure(nep)
+    if LR is not None and not 1 <= p <= 2:
+        # the reference reads block p-1 of a two-block vector in its first step (method_nleigs.jl:408-414)
+        raise ValueError("nleigs with low-rank structure needs a polynomial part of degree 1 or 2")
+    r = LR.r if LR is not None else n
+    blk = lambda j: n if (LR is None or j < p) else r                    # rows of block j (method_nleigs.jl:206-211)
+    off = lambda j: j * n if (LR is None or j <= p) else p * n + (j - p) * r
     if n == 1:
         maxdgr = maxit + 1
     if v is None:
@@ -97,18 +108,22 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
     # maxit steps run on vectors of the frozen length (N+1) n; the start vector is zero-padded, which the zero-initialised V
     # provides for free.  At most maxdgr+1 blocks.
     kmax = maxit + maxdgr if static else maxit
-    ldv = (min(kmax, maxdgr + 1) + 2) * n if static else (kmax + 2) * n
+    ldv = off(min(kmax, maxdgr + 1) + 2) if static else off(kmax + 2)
     ncol = maxit + 2
     V = torch.zeros((ncol, ldv), dtype=CDT, device="cuda")
     Bw = torch.empty(ldv, dtype=CDT, device="cuda")
     zb = torch.empty(ldv, dtype=CDT, device="cuda")
     tmp = torch.empty(n, dtype=CDT, device="cuda")
+    if LR is not None:
+        ylr = torch.empty(r, dtype=CDT, device="cuda")
+        Wlr = to_dev(sgdd[p + 1 + LR.iL, :])          # (maxdgr+2, r): column ii holds dd[iL] of method_nleigs.jl:464
     H = np.zeros((ncol, ncol - 1), dtype=complex); K = np.zeros((ncol, ncol - 1), dtype=complex)
     Lam = np.zeros((ncol - 1, ncol - 1), dtype=complex); Res = np.zeros((ncol - 1, ncol - 1))
     active = np.zeros(ncol, dtype=np.int64)
     st = stream_ptr
 
     v0 = _c128(v) / np.linalg.norm(v)
+    cache.prefetch(sigma[:3])                   # host factorisations of the next shifts run ahead on a worker thread
     x0 = cache.solve(sigma[0], to_dev(v0)[0], reusefact == 2)
     nx0 = dense.nrm2(x0)
     dense.copy(x0, V[0], n); dense.scal(V[0], 1.0 / nx0, n)
@@ -147,6 +162,70 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
             check(lib.nep_block_recur(n, N, hptr(a), hptr(bw), c_vp(Bw.data_ptr()), c_vp(w.data_ptr()), st()))
         return w
 
+    def backslash_lowrank(k, l):
+        """the same solve over p blocks of n rows and N-p+1 blocks of r rows (low-rank branches of method_nleigs.jl:399-518);
+        needs N >= p-1, which p <= 2 guarantees"""
+        shift = sigma[k]
+        wc = V[l - 1]; w = V[l]
+        at = lambda T, j: T.data_ptr() + 16 * off(j)
+        with np.errstate(all="ignore"):
+            cB = _c128(beta[1:N + 1] / xi[:N])
+            nu = beta[1:N + 1] * (1 - shift / xi[:N])
+            a = _c128(1.0 / nu)
+            b = np.zeros(N, dtype=np.complex128)
+            if N > 1:
+                b[1:] = (shift - sigma[1:N]) / nu[1:]
+            bw = _c128((shift - sigma[:N]) / nu)
+            nh = min(N, p - 1)                 # n-row blocks 1..p-1 follow the plain recurrences
+            nr = N - p                         # r-row blocks p+1..N
+            # ---- Bw (:417-436); its first block (:407-415) goes straight into the K1 call below
+            if nh > 0:
+                check(lib.nep_rk_bw(n, nh, c_vp(wc.data_ptr()), hptr(_c128(cB[:nh])), c_vp(Bw.data_ptr()), st()))
+            if nr > 0:
+                check(lib.nep_rk_bw(r, nr, c_vp(at(wc, p)), hptr(_c128(cB[p:])), c_vp(at(Bw, p)), st()))
+            if nr >= 0:                        # seam: Bw_p = UU^H wc_{p-1} + beta_p/xi_{p-1} wc_p
+                LR.UUH.mv(1.0, at(wc, p - 1), cB[p - 1], at(wc, p), at(Bw, p))
+            # ---- z blocks (:438-491); block 0 of zb carries wc_{p-1} for the K1 call
+            check(lib.nep_dev_copy(c_vp(zb.data_ptr()), c_vp(at(wc, p - 1)), 16 * n, st()))
+            check(lib.nep_dev_copy(c_vp(at(zb, 1)), c_vp(at(Bw, 1)), 16 * (off(N + 1) - n), st()))
+            if nh > 0:
+                check(lib.nep_block_recur(n, nh, hptr(_c128(a[:nh])), hptr(_c128(b[:nh])), c_vp(zb.data_ptr()),
+                                          c_vp(zb.data_ptr()), st()))
+            if nr >= 0:                        # seam: z_p = Bw_p/nu_p + mu_p/nu_p UU^H z_{p-1}   (mu_1/nu_1 := 0)
+                LR.UUH.mv(b[p - 1], at(zb, p - 1), a[p - 1], at(zb, p), at(zb, p))
+            if nr > 0:
+                check(lib.nep_block_recur(r, nr, hptr(_c128(a[p:])), hptr(_c128(b[p:])), c_vp(at(zb, p)),
+                                          c_vp(at(zb, p)), st()))
+            # ---- -z0 = D_p wc_{p-1}/beta_p + sum_{j<p} D_j z_j + [L_1..L_q] (sum_{j>p} dd_j o z_j)   (:407-415,455-471)
+            Cm = np.zeros((p, mt), dtype=np.complex128, order="F")
+            Cm[0, :] = sgdd[:, p] / beta[p]
+            for j in range(1, p):
+                Cm[j, :] = sgdd[:, j]
+            if p >= 2 and N >= p:
+                # (shift - sigma_{p-1})/beta_p D_p z_{p-1}: the elimination of block p-1 of the first block row leaves this
+                # term; the reference omits it (its low-rank tests all have p = 1, where z_0 = 0) -- see oracle/nleigs.py
+                Cm[p - 1, :] += b[p - 1] * sgdd[:, p]
+            nep.dev.mlincomb(Cm, zb.data_ptr(), tmp, k=p, ldv=n)
+            if nr > 0:
+                check(lib.nep_rowdot(r, nr, c_vp(at(zb, p + 1)), r, c_vp(Wlr.data_ptr() + 16 * r * (p + 1)), r,
+                                     c_vp(ylr.data_ptr()), st()))
+                LR.Lall.mv(1.0, ylr, 1.0, tmp, tmp)
+            add_to_cache = ((not expand or k > kconv) and reusefact == 1) or reusefact == 2
+            cache.solve_dev(shift, tmp, add_to_cache, out=w[:n], scale=-1.0 / beta[0])
+            # ---- w blocks (:496-515)
+            if nh > 0:
+                check(lib.nep_block_recur(n, nh, hptr(_c128(a[:nh])), hptr(_c128(bw[:nh])), c_vp(Bw.data_ptr()),
+                                          c_vp(w.data_ptr()), st()))
+            if nr >= 0:                        # seam: w_p = mu_p/nu_p UU^H w_{p-1} + Bw_p/nu_p
+                LR.UUH.mv(bw[p - 1], at(w, p - 1), a[p - 1], at(Bw, p), at(w, p))
+            if nr > 0:
+                check(lib.nep_block_recur(r, nr, hptr(_c128(a[p:])), hptr(_c128(bw[p:])), c_vp(at(Bw, p)),
+                                          c_vp(at(w, p)), st()))
+        return w
+
+    if LR is not None:
+        backslash = backslash_lowrank
+
     def check_convergence(k, l, all_=False):
         lambda_, S = sla.eig(K[:l, :l], H[:l, :l])
         if not all_:
@@ -179,7 +258,7 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
     k = 1
     while k <= kmax:
         if expand:
-            kn += n
+            kn += blk(k)
             N += 1
             nrmD.append(float(np.max(abs(sgdd[:, k]))))
             if not np.isfinite(nrmD[k]):
@@ -192,7 +271,7 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
                     xi = xi[:k]; beta = beta[:k]; nrmD = nrmD[:k]
                     if static:
                         kmax = maxit + kconv
-                        kn -= n
+                        kn -= blk(k)
                 elif k == maxdgr + 1:
                     kconv = k
                     frozen = True
@@ -206,6 +285,7 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
                     N -= 1
         l = k - N if static else k
         if not static or not expand:
+            cache.prefetch(sigma[k:k + 3])
             w = backslash(k, l)
             active[l] = kn
             h, hb, _ = dense.orthogonalize_and_normalize(V, w, l, rows=kn, ldv=ldv, active_rows=active, method=dense.DGKS)
@@ -223,8 +303,10 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
             break
         k += 1
     lam = res_state["lam"]; conv = res_state["conv"]; res = res_state["res"]
+    cache.close()
     if info is not None:
-        info.update(kconv=kconv, N=N, k=min(k, kmax), nfact=len(cache.solvers), nrmD=nrmD, nblamin=nblamin)
+        info.update(kconv=kconv, N=N, k=min(k, kmax), nfact=len(cache.solvers), nrmD=nrmD, nblamin=nblamin, vrows=ldv,
+                    lowrank_r=(r if LR is not None else 0))
     if res_state["QT"] is None or not np.any(conv):
         X = np.zeros((n, 0), dtype=complex)
     else:

@@ -193,6 +193,53 @@ class SPMF_NEP(AbstractSPMF):
         return a[0] * z
 
 
+def low_rank_lu_factors(A):
+    """rk_nep.jl:70-83 + compactlu :96-100: LU of the dense block that holds the non-zeros of A, keeping only the columns of
+    L / rows of U that carry anything; returns L (n x r), U (n x r) with A = L U^H.  The reference destructures
+    `L, U = lu(B)` and drops the row permutation (it relies on no interchange taking place, true for the gun W1, W2 and
+    for diagonal blocks); here the permutation is applied to L so that A = L U^H always holds."""
+    import scipy.linalg as sla
+    A = sp.csc_matrix(A)
+    n = A.shape[0]
+    coo = A.tocoo()
+    keep = coo.data != 0
+    if not np.any(keep):
+        return sp.csc_matrix((n, 0)), sp.csc_matrix((n, 0))
+    r0, r1 = coo.row[keep].min(), coo.row[keep].max() + 1
+    c0, c1 = coo.col[keep].min(), coo.col[keep].max() + 1
+    B = A[r0:r1, c0:c1].toarray()
+    Pm, L, U = sla.lu(B)
+    m = min(B.shape)
+    sel = [i for i in range(m) if np.count_nonzero(L[i:, i]) > 1 or np.count_nonzero(U[i, i:]) > 0]
+    Lc = (Pm @ L)[:, sel]; Uc = U[sel, :]
+    Lf = sp.lil_matrix((n, len(sel)), dtype=B.dtype); Lf[r0:r1, :] = Lc
+    Uf = sp.lil_matrix((n, len(sel)), dtype=B.dtype); Uf[c0:c1, :] = Uc.conj().T
+    return sp.csc_matrix(Lf), sp.csc_matrix(Uf)
+
+
+class LowRankMatrixAndFunction:
+    """rk_nep.jl:41-53"""
+
+    def __init__(self, A, f, L=None, U=None):
+        self.f = f
+        if L is not None and U is not None:
+            self.L, self.U = sp.csc_matrix(L), sp.csc_matrix(U)
+            self.A = sp.csc_matrix(A) if A is not None and A.shape[0] else sp.csc_matrix(self.L @ self.U.conj().T)
+        else:
+            self.A = sp.csc_matrix(A)
+            self.L, self.U = low_rank_lu_factors(self.A)
+
+
+class LowRankFactorizedNEP(SPMF_NEP):
+    """rk_nep.jl:58-67 (NEPTypes.jl LowRankFactorizedNEP): SPMF whose matrices carry A_i = L_i U_i^H, rank = sum r_i"""
+
+    def __init__(self, Amf):
+        super().__init__([M.A for M in Amf], [M.f for M in Amf])
+        self.L = [M.L for M in Amf]
+        self.U = [M.U for M in Amf]
+        self.rank = int(sum(M.U.shape[1] for M in Amf))
+
+
 class DEP(AbstractSPMF):
     """NEPTypes.jl:427-443."""
 

@@ -2,14 +2,14 @@
 
   src/method_nleigs.jl:60-377     main loop (dynamic variant, static=false, return_details=false)
   src/method_nleigs.jl:380-396    constructD
-  src/method_nleigs.jl:399-518    backslash (continuation-vector solve; non-low-rank branches)
+  src/method_nleigs.jl:399-518    backslash (continuation-vector solve; full and low-rank branches)
   src/method_nleigs.jl:521-531    in_Sigma
   src/rk_helper/rk_utils.jl:14-128    lejabagby, scgendivdiffs, ratnewtoncoeffsm, evalrat
-  src/rk_helper/rk_nep.jl:102-153     get_rk_nep (p, q, BBCC; without the low-rank factorisation)
+  src/rk_helper/rk_nep.jl:102-153     get_rk_nep (p, q, BBCC, low-rank factors L, UU, iL)
   src/rk_helper/discretizepolygon.jl, inpolygon.jl
   src/rk_helper/linsolvercache.jl:7-26
 
-Restrictions (documented in DESIGN.md): SPMF-type NEPs only, no LowRankFactorizedNEP structure, dynamic variant.
+Restrictions (documented in DESIGN.md): SPMF-type NEPs only.
 """
 import numpy as np
 import scipy.linalg as sla
@@ -196,26 +196,43 @@ def scgendivdiffs(sigma, xi, beta, maxdgr, pff, isfunm=True):
 
 
 class RKNEP:
-    """rk_nep.jl:19-32,102-153 without low-rank structure"""
+    """rk_nep.jl:19-32,102-153"""
 
     def __init__(self, nep):
         self.nep = nep
         Av = nep.get_Av()
         self.BC = Av
+        self.is_low_rank = False
+        self.r = 0
         if isinstance(nep, neps.PEP):
             self.p, self.q = len(Av) - 1, 0
         elif isinstance(nep, neps.SumNEP) and isinstance(nep.nep1, neps.PEP):
             self.p = len(nep.nep1.get_Av()) - 1; self.q = len(nep.nep2.get_Av())
+            if self.q > 0 and isinstance(nep.nep2, neps.LowRankFactorizedNEP):       # :128-152
+                self.is_low_rank = True
+                self.L = nep.nep2.L
+                self.UU = sp.csc_matrix(sp.hstack(nep.nep2.U))
+                self.r = nep.nep2.rank
+                self.iL = np.concatenate([np.full(L.shape[1], i, dtype=int) for i, L in enumerate(self.L)])
+                self.Lall = sp.csc_matrix(sp.hstack(self.L))                          # the rows LL / iLr of :141-150, as one matrix
         else:
             self.p, self.q = -1, len(Av)
 
+    def blk(self, j):
+        """rows of block j (0-based) of the linearisation vectors: n for j < p, r from there on (method_nleigs.jl:206-211)"""
+        n = self.nep.size(1)
+        return n if (not self.is_low_rank or j < self.p) else self.r
+
 
 def constructD(nb, P, sgdd):
-    D = None
-    for ii in range(P.p + 1 + P.q):
-        T = sgdd[ii, nb] * P.BC[ii]
-        D = T if D is None else D + T
-    return D
+    """method_nleigs.jl:380-396"""
+    if not P.is_low_rank or nb <= P.p:
+        D = None
+        for ii in range(P.p + 1 + P.q):
+            T = sgdd[ii, nb] * P.BC[ii]
+            D = T if D is None else D + T
+        return D
+    return sp.csc_matrix(sp.hstack([sgdd[P.p + 1 + ii, nb] * P.L[ii] for ii in range(P.q)]))
 
 
 class LinSolverCache:
@@ -233,38 +250,69 @@ class LinSolverCache:
 
 
 def backslash(wc, P, cache, reusefact, computeD, sigma, k, D, beta, N, xi, expand, kconv, sgdd):
-    """method_nleigs.jl:399-518 (non-low-rank branches); k is the 1-based iteration counter"""
+    """method_nleigs.jl:399-518; k is the 1-based iteration counter.  Block j of a vector has P.blk(j) rows."""
     n = P.nep.size(1)
+    p = P.p
+    lr = P.is_low_rank
     shift = sigma[k]                      # sigma[k+1] in 1-based numbering
+    off = np.concatenate([[0], np.cumsum([P.blk(j) for j in range(N + 2)])])
+    B = lambda j: slice(off[j], off[j + 1])
+
+    def Dmul(ii, x):
+        if computeD:
+            # (low rank, p = 2, first step: the reference indexes D[p+1] before it exists, :410 -- a BoundsError there;
+            # the matrix is formed on the spot here, which is what its BBCC branch :412 computes)
+            Dii = D[ii] if ii < len(D) else constructD(ii, P, sgdd)
+            return np.asarray(Dii @ x).ravel()
+        acc = np.zeros(n, dtype=complex)
+        for j, A in enumerate(P.BC):
+            acc += sgdd[j, ii] * (A @ x)
+        return acc
+
     with np.errstate(all="ignore"):
         Bw = np.zeros(len(wc), dtype=complex)
-        for ii in range(1, N + 1):
-            i0 = slice((ii - 1) * n, ii * n); i1 = slice(ii * n, (ii + 1) * n)
-            Bw[i1] = wc[i0] + beta[ii] / xi[ii - 1] * wc[i1]
-        z = Bw.copy()
-        nu = beta[1] * (1 - shift / xi[0])
-        z[n:2 * n] = 1 / nu * z[n:2 * n]
-        for ii in range(1, N + 1):
-            i1 = slice(ii * n, (ii + 1) * n); i2 = slice((ii + 1) * n, (ii + 2) * n)
-            if computeD:
-                z[:n] -= D[ii] @ z[i1]
+        if lr:                                                                      # :407-415 first block
+            Bw[:n] = -Dmul(p, wc[B(p - 1)]) / beta[p]
+        for ii in range(1, N + 1):                                                  # :417-436
+            if not lr or ii != p:
+                Bw[B(ii)] = wc[B(ii - 1)] + beta[ii] / xi[ii - 1] * wc[B(ii)]
             else:
-                acc = np.zeros(n, dtype=complex)
-                for j, A in enumerate(P.BC):
-                    acc += sgdd[j, ii] * (A @ z[i1])
-                z[:n] -= acc
+                Bw[B(ii)] = P.UU.conj().T @ wc[B(ii - 1)] + beta[ii] / xi[ii - 1] * wc[B(ii)]
+        z = Bw.copy()                                                               # :438-491
+        nu = beta[1] * (1 - shift / xi[0])
+        z[B(1)] = 1 / nu * z[B(1)]
+        for ii in range(1, N + 1):
+            if not lr or ii < p:
+                z[:n] -= Dmul(ii, z[B(ii)])
+            elif ii == p and p >= 2:
+                # Not in the reference, which skips ii == p altogether (:455-463).  The first block row of the low-rank
+                # pencil holds D_{p-1} - sigma_{p-1} D_p / beta_p in A and -D_p / beta_p in B at block p-1 (that B entry is
+                # the first block of Bw above), so eliminating it leaves (shift - sigma_{p-1})/beta_p D_p z_{p-1} on the
+                # right-hand side.  For p = 1 this is D_1 z_0 = 0 -- every low-rank test of the reference has p = 1; for
+                # p = 2 the Ritz values do not approach eigenvalues of the NEP without it (tests/test_oracle_kat.py).
+                z[:n] -= Dmul(p, (shift - sigma[p - 1]) / (beta[p] * (1 - shift / xi[p - 1])) * z[B(p - 1)])
+            elif ii > p:
+                if computeD:
+                    z[:n] -= np.asarray(D[ii] @ z[B(ii)]).ravel()
+                else:
+                    z[:n] -= P.Lall @ (sgdd[p + 1 + P.iL, ii] * z[B(ii)])           # :464-471
             if ii < N:
                 mu = shift - sigma[ii]
                 nu = beta[ii + 1] * (1 - shift / xi[ii])
-                z[i2] = 1 / nu * z[i2] + mu / nu * z[i1]
+                if not lr or ii != p - 1:
+                    z[B(ii + 1)] = 1 / nu * z[B(ii + 1)] + mu / nu * z[B(ii)]
+                else:
+                    z[B(ii + 1)] = 1 / nu * z[B(ii + 1)] + mu / nu * (P.UU.conj().T @ z[B(ii)])
         w = np.zeros(len(wc), dtype=complex)
         add_to_cache = ((not expand or k > kconv) and reusefact == 1) or reusefact == 2
         w[:n] = cache.solve(shift, z[:n] / beta[0], add_to_cache)
-        for ii in range(1, N + 1):
-            i0 = slice((ii - 1) * n, ii * n); i1 = slice(ii * n, (ii + 1) * n)
+        for ii in range(1, N + 1):                                                  # :498-515
             mu = shift - sigma[ii - 1]
             nu = beta[ii] * (1 - shift / xi[ii - 1])
-            w[i1] = mu / nu * w[i0] + 1 / nu * Bw[i1]
+            if not lr or ii != p:
+                w[B(ii)] = mu / nu * w[B(ii - 1)] + 1 / nu * Bw[B(ii)]
+            else:
+                w[B(ii)] = mu / nu * (P.UU.conj().T @ w[B(ii - 1)]) + 1 / nu * Bw[B(ii)]
     return w
 
 
@@ -346,7 +394,7 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
     nfact = 0
     while k <= kmax:
         if expand:
-            kn += n
+            kn += P.blk(k)                                                          # :206-211
             if computeD:
                 D.append(constructD(k, P, sgdd))
             N += 1
@@ -367,7 +415,7 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
                         D = D[:k]
                     xi = xi[:k]; beta = beta[:k]; nrmD = nrmD[:k]
                     if static:
-                        kn -= n                                                     # :250-257 (V is zero padded already)
+                        kn -= P.blk(k)                                              # :250-257 (V is zero padded already)
                     N -= 1
                 elif k == maxdgr + 1:
                     kconv = k

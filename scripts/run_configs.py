@@ -87,22 +87,35 @@ def main():
         emit(**out)
 
     if "c3" in args.which:
+        # gun_nep() of test/rk_helper/gun_test_utils.jl:37-43: PEP + LowRankFactorizedNEP (ranks 19 + 65), as the
+        # reference's variant R1 runs it; the same problem with full blocks (PEP + SPMF) is timed beside it
         Sigma, Xi, nodes = gun_r1()
-        nep = na.nep_gallery("nlevp_native_gun"); n = nep.n; nep.dev
+        Kg, Mg, W1, W2 = na.gallery.gun_matrices()
+        fv = [na.funcs.ISqrt(1.0, 0.0), na.funcs.ISqrt(1.0, -na.gallery.GUN_SIGMA2 ** 2)]
+        nep = na.SumNEP(na.PEP([Kg, -Mg]), na.LowRankFactorizedNEP([na.LowRankMatrixAndFunction(W1, fv[0]),
+                                                                      na.LowRankMatrixAndFunction(W2, fv[1])]))
+        nep_full = na.nep_gallery("nlevp_native_gun"); n = nep.n; nep.dev; nep_full.dev
         v = np.random.Generator(np.random.Philox(1)).standard_normal(n) + 0j
         info = {}
-        run = lambda: na.nleigs(nep, Sigma, Xi=Xi, maxit=100, v=v, leja=0, nodes=nodes, reusefact=2, tol=1e-10,
-                                errmeasure=na.StandardSPMFErrmeasure(nep), info=info)
+        kw = dict(Xi=Xi, maxit=100, v=v, leja=0, nodes=nodes, reusefact=2, tol=1e-10)
+        run = lambda: na.nleigs(nep, Sigma, errmeasure=na.StandardSPMFErrmeasure(nep), info=info, **kw)
+        run()
         (lam, X, res), t = timed(run)
+        (lamf, Xf, resf), tf = timed(lambda: na.nleigs(nep_full, Sigma, errmeasure=na.StandardSPMFErrmeasure(nep_full), **kw))
         onep = og.nlevp_native_gun()
         oE = osol.StandardSPMFErrmeasure(onep)
-        out = dict(config="C3 gun nleigs variant R1 maxit=100", n=n, eigenpairs=len(lam), factorizations=info["nfact"],
+        out = dict(config="C3 gun nleigs variant R1 maxit=100 (PEP + LowRankFactorizedNEP, r = %d)" % info["lowrank_r"], n=n,
+                   eigenpairs=len(lam), factorizations=info["nfact"], krylov_rows=info["vrows"],
                    max_backward_error=max([oE(lam[i], X[:, i]) for i in range(len(lam))] + [0.0]), gpu_s=t,
-                   eigenpairs_per_s=len(lam) / t, ritz_in_sigma=info["nblamin"])
+                   eigenpairs_per_s=len(lam) / t, ritz_in_sigma=info["nblamin"], full_blocks_gpu_s=tf,
+                   full_blocks_same_eigenvalues=bool(match(lam, lamf, 1e-8)[0]))
         if args.oracle:
-            from oracle import nleigs as onl
+            from oracle import neps as on, nleigs as onl
+            ofv = [on.f_isqrt(0.0), on.f_isqrt(-na.gallery.GUN_SIGMA2 ** 2)]
+            olr = on.SumNEP(on.PEP([Kg, -Mg]), on.LowRankFactorizedNEP([on.LowRankMatrixAndFunction(W1, ofv[0]),
+                                                                         on.LowRankMatrixAndFunction(W2, ofv[1])]))
             t0 = time.perf_counter()
-            lo, Xo, ro = onl.nleigs(onep, Sigma, Xi=Xi, maxit=100, v=v, leja=0, nodes=nodes, reusefact=2, tol=1e-10, errmeasure=oE)
+            lo, Xo, ro = onl.nleigs(olr, Sigma, errmeasure=osol.StandardSPMFErrmeasure(olr), **kw)
             to = time.perf_counter() - t0
             ok, worst = match(lam, lo, 1e-8)
             out.update(cpu_eigenpairs=len(lo), cpu_s=to, parity=ok, max_rel_eig_diff=worst)

@@ -400,3 +400,29 @@ def test_randomized_sweep_small(na):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert "done, failures: 0" in out.stdout, out.stdout[-2000:]
+
+
+@pytest.mark.parametrize("rows,cols,dens", [(84, 9956, 0.01), (9956, 84, 0.01), (500, 300, 0.3), (64, 64, 1.0), (3, 1000, 0.9),
+                                            (1, 1, 1.0), (40, 7, 0.0)])
+def test_csr_mv_vs_scipy(na, rows, cols, dens):
+    """nep_csr_mv: y = alpha A x + beta z on rectangular complex CSR operators (the UU^H / [L_1..L_q] factors of the
+    low-rank NLEIGS, rk_nep.jl:128-152): every lanes-per-row variant (4 / 16 / 64), empty rows, an empty matrix, aliasing
+    of z and y, and beta = 0 with NaN in y (must not be read).  Tolerance 4 eps * nnz-per-row growth -> 1e-14 relative."""
+    import torch
+    from nep_amd import nep as nn
+    rng = np.random.default_rng(rows + cols)
+    A = sp.random(rows, cols, density=dens, random_state=1, format="csr") + 1j * sp.random(rows, cols, density=dens, random_state=2, format="csr")
+    op = nn.DeviceCSR(A)
+    x = rng.standard_normal(cols) + 1j * rng.standard_normal(cols)
+    z = rng.standard_normal(rows) + 1j * rng.standard_normal(rows)
+    xd = nn.to_dev(x)[0]; zd = nn.to_dev(z)[0]
+    yd = torch.full((rows,), float("nan"), dtype=torch.complex128, device="cuda")
+    op.mv(0.3 - 0.2j, xd, 0.0, yd, yd)
+    ref = (0.3 - 0.2j) * (A @ x)
+    assert np.abs(yd.cpu().numpy() - ref).max() <= 1e-14 * max(1.0, np.abs(ref).max())
+    op.mv(1.5, xd, -0.5j, zd, zd)
+    ref2 = 1.5 * (A @ x) - 0.5j * z
+    assert np.abs(zd.cpu().numpy() - ref2).max() <= 1e-14 * np.abs(ref2).max()
+    out = torch.empty(rows, dtype=torch.complex128, device="cuda")
+    op.mv(1.0, xd.data_ptr(), 2.0, nn.to_dev(z)[0], out)          # raw device addresses are accepted
+    assert np.abs(out.cpu().numpy() - (A @ x + 2 * z)).max() <= 1e-14 * max(1.0, np.abs(A @ x + 2 * z).max())

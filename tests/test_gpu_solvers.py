@@ -650,3 +650,64 @@ def test_gmres_linsolver(na):
     l1, v1 = na.quasinewton(nep, lam=lam0, v=np.ones(n), tol=1e-12)
     l2, v2 = na.quasinewton(nep, lam=lam0, v=np.ones(n), tol=1e-12, linsolvercreator=na.GMRESLinSolverCreator(Pl=M.diagonal(), tol=1e-12))
     assert abs(l1 - l2) < 1e-10
+
+
+def test_nleigs_lowrank_gun_vs_oracle(na):
+    """gun_nep() of test/rk_helper/gun_test_utils.jl:37-43 (PEP + LowRankFactorizedNEP, ranks 19 + 65) through variant
+    R1 (test/nleigs/nleigs_gun_variant_r1.jl:15) on a reduced gun problem: the compressed device run (Krylov vectors of
+    n + 84 N rows) against the compressed oracle run (eigenvalues 1e-8 relative) and against the device run with full blocks"""
+    from oracle import neps as on, nleigs as onl, solvers as osol
+    n = 1310
+    K, M, W1, W2 = na.gallery.gun_matrices(n)
+    s2 = na.gallery.GUN_SIGMA2
+    fv = [na.funcs.ISqrt(1.0, 0.0), na.funcs.ISqrt(1.0, -s2 ** 2)]
+    ofv = [on.f_isqrt(0.0), on.f_isqrt(-s2 ** 2)]
+    full = na.SumNEP(na.PEP([K, -M]), na.SPMF_NEP([W1, W2], fv))
+    lowr = na.SumNEP(na.PEP([K, -M]), na.LowRankFactorizedNEP([na.LowRankMatrixAndFunction(W1, fv[0]), na.LowRankMatrixAndFunction(W2, fv[1])]))
+    olr = on.SumNEP(on.PEP([K, -M]), on.LowRankFactorizedNEP([on.LowRankMatrixAndFunction(W1, ofv[0]), on.LowRankMatrixAndFunction(W2, ofv[1])]))
+    assert lowr.nep2.rank == 84 and olr.nep2.rank == 84
+    gam = 300.0 ** 2 - 200.0 ** 2; mu = 250.0 ** 2
+    th = np.linspace(0, np.pi, int(round(np.pi / 2 * 1000)) + 2)
+    Sig = np.concatenate([(mu - gam) + 2 * gam * (np.exp(1j * th) / 2 + .5), [mu - gam]])
+    nodes = gam * np.array([2 / 3, (1 + 1j) / 3, 0, (-1 + 1j) / 3, -2 / 3]) + mu
+    Xi = -10.0 ** np.linspace(-8, 8, 10000) + s2 ** 2
+    v = np.random.default_rng(1).standard_normal(n) + 0j
+    kw = dict(Xi=Xi, maxit=60, v=v, leja=0, nodes=nodes, reusefact=2)
+    info = {}
+    lam, X, res = na.nleigs(lowr, Sig, errmeasure=na.StandardSPMFErrmeasure(lowr), info=info, **kw)
+    assert info["vrows"] == n + 84 * 61 and info["nfact"] == 5
+    lo, Xo, ro = onl.nleigs(olr, Sig, errmeasure=osol.StandardSPMFErrmeasure(olr), **kw)
+    assert len(lam) >= 5
+    _match(lam, lo, 1e-8)
+    lf, Xf, rf = na.nleigs(full, Sig, errmeasure=na.StandardSPMFErrmeasure(full), **kw)
+    _match(lam, lf, 1e-8)
+    E = osol.StandardSPMFErrmeasure(olr)
+    assert max(E(lam[i], X[:, i]) for i in range(len(lam))) < 1e-10
+
+
+def test_nleigs_lowrank_degree2_vs_oracle(na):
+    """polynomial part of degree 2 + two low-rank exponential terms: the n-row recurrences of blocks 1..p-1, the UU^H seams
+    at block p and the corrected first-block-row term (oracle/nleigs.py backslash) on the device; dynamic and static
+    variants against the oracle (1e-8) and against the full-block device run"""
+    import warnings
+    from oracle import neps as on, nleigs as onl
+    try:
+        from test_oracle_kat import _lowrank_p2_problem
+    except ImportError:
+        from tests.test_oracle_kat import _lowrank_p2_problem
+    n, B, C, Sigma = _lowrank_p2_problem(None)
+    fv = [na.funcs.Exp(-1.0), na.funcs.Exp(-0.5)]; ofv = [on.f_exp(-1.0), on.f_exp(-0.5)]
+    full = na.SumNEP(na.PEP(B), na.SPMF_NEP(C, fv))
+    lowr = na.SumNEP(na.PEP(B), na.LowRankFactorizedNEP([na.LowRankMatrixAndFunction(C[i], fv[i]) for i in range(2)]))
+    olr = on.SumNEP(on.PEP(B), on.LowRankFactorizedNEP([on.LowRankMatrixAndFunction(C[i], ofv[i]) for i in range(2)]))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref, _, _ = na.nleigs(full, Sigma, maxit=60, v=np.ones(n) + 0j)
+        assert len(ref) == 8
+        for static in (False, True):
+            lam, X, res = na.nleigs(lowr, Sigma, maxit=60, v=np.ones(n) + 0j, static=static)
+            lo, Xo, ro = onl.nleigs(olr, Sigma, maxit=60, v=np.ones(n) + 0j, static=static)
+            _match(lam, lo, 1e-8)
+            _match(lam, ref, 1e-7)
+    with pytest.raises(ValueError):                     # p = 3: the reference reads a block that does not exist yet
+        na.nleigs(na.SumNEP(na.PEP(B + [0.01 * np.eye(n)]), lowr.nep2), Sigma, maxit=10, v=np.ones(n) + 0j)

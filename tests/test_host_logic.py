@@ -219,3 +219,28 @@ def test_low_rank_types_host_side():
     lr = na.LowRankFactorizedNEP([na.LowRankMatrixAndFunction(sp.csc_matrix(np.eye(2)), na.funcs.Monomial(2))])
     nep = na.SumNEP(na.PEP(B), lr)
     assert lr.rank == 2 and len(nep.get_Av()) == 3 and na.rk_helper.rk_structure(nep) == (1, 1)
+
+
+def test_inpolygon_reference_kat_and_vectorised_form():
+    """test/rk_helper/inpolygon.jl:6-31: 96 of the 13 x 13 lattice points lie in or on the M-shaped polygon, either
+    orientation, non-finite points are outside; and the all-edges-at-once form of the package equals the scalar
+    restatement of the oracle on vertices, edge points, horizontal edges and random points of several polygons"""
+    from oracle import nleigs as onl
+    inp = na.rk_helper.inpolygon
+    px = [0, 0, 5, 10, 10]; py = [0, 10, 5, 10, 0]
+    pts = [(x, y) for x in range(-1, 12) for y in range(-1, 12)]
+    for f in (inp, onl.inpolygon):
+        assert sum(bool(f(x, y, px, py)) for x, y in pts) == 96
+        assert sum(bool(f(x, y, px[::-1], py[::-1])) for x, y in pts) == 96
+        assert not any(f(x, y, px, py) for x, y in ((np.nan, 0.0), (0.0, np.nan), (np.inf, 0.0), (0.0, np.inf)))
+    rng = np.random.default_rng(0)
+    th = np.linspace(0, np.pi, 200)
+    a = np.sort(rng.uniform(0, 2 * np.pi, 37)); rr = rng.uniform(.5, 1.5, 37)
+    polys = [(np.array([-1, 1, 1, -1.]), np.array([-1, -1, 1, 1.])), (np.r_[np.cos(th), -1.0], np.r_[np.sin(th), 0.0]),
+             (rr * np.cos(a), rr * np.sin(a)), (np.array([0, 2, 2, 1, 1, 0.]), np.array([0, 0, 2, 2, 1, 1.]))]
+    for qx, qy in polys:
+        m = len(qx)
+        P = [(x, y) for x in np.linspace(-1.6, 2.1, 24) for y in np.linspace(-1.6, 2.1, 24)]
+        P += list(zip(qx, qy)) + [((qx[i] + qx[(i + 1) % m]) / 2, (qy[i] + qy[(i + 1) % m]) / 2) for i in range(m)]
+        P += [(0.5, 0.0), (1.0, 1.5), (1.5, 1.0), (0.0, 0.0)]
+        assert all(bool(inp(x, y, qx, qy)) == bool(onl.inpolygon(x, y, qx, qy)) for x, y in P)

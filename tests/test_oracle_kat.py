@@ -366,3 +366,83 @@ def test_nleigs_oracle_kats():
     d = gallery.dep0()
     lam, X, res = onl.nleigs(d, np.array([1 + 1j, 1 - 1j, -1 - 1j, -1 + 1j]), v=np.ones(5) + 0j)
     assert len(lam) >= 2 and max(np.linalg.norm(d.compute_Mlincomb(lam[i], X[:, i])) for i in range(len(lam))) < 2e-13
+
+
+def test_nleigs_lowrank_oracle():
+    """Low-rank branches of NLEIGS (method_nleigs.jl:206-211,406-414,424-430,464-471,480,510; rk_nep.jl:58-153):
+    test/nleigs/nleigs_nep_types.jl:31-46 -- PEP, PEP + SPMF and PEP + LowRankFactorizedNEP give the same 4 eigenvalues;
+    gun_nep() of test/rk_helper/gun_test_utils.jl:37-43 on the reference's W1, W2: factor ranks 19 + 65, and variant R1
+    (nleigs_gun_variant_r1.jl) on a reduced gun problem finds the same eigenvalues with compressed and with full blocks"""
+    import scipy.sparse as sp
+    from oracle import nleigs as onl
+    B = [np.array([[1., 3], [5, 6]]), np.array([[3., 4], [6, 6]])]; C = [np.eye(2)]
+    Sigma = np.array([-10 - 2j, 10 - 2j, 10 + 2j, -10 + 2j])
+    f2 = neps.f_pow(2)
+    probs = [neps.PEP(B + C), neps.SumNEP(neps.PEP(B), neps.SPMF_NEP(C, [f2])),
+             neps.SumNEP(neps.PEP(B), neps.LowRankFactorizedNEP([neps.LowRankMatrixAndFunction(sp.csc_matrix(C[0]), f2)]))]
+    ref = None
+    for pr in probs:
+        lam, X, res = onl.nleigs(pr, Sigma, maxit=10, v=np.ones(2) + 0j, blksize=5)
+        assert len(lam) == 4
+        lam = np.sort_complex(np.round(lam, 9))
+        ref = lam if ref is None else ref
+        assert np.allclose(lam, ref, atol=1e-8)
+    n = 1310
+    K, M, W1, W2 = gallery.gun_matrices(n)
+    Kf, Mf, W1f, W2f = gallery.gun_matrices()
+    for W, rk_ in ((W1f, 19), (W2f, 65)):
+        L, U = neps.low_rank_lu_factors(W)
+        assert L.shape == (9956, rk_) and abs(L @ U.conj().T - W).max() < 1e-14
+    s2 = 108.8774
+    fv = [neps.f_isqrt(0.0), neps.f_isqrt(-s2 ** 2)]
+    full = neps.SumNEP(neps.PEP([K, -M]), neps.SPMF_NEP([W1, W2], fv))
+    lowr = neps.SumNEP(neps.PEP([K, -M]), neps.LowRankFactorizedNEP([neps.LowRankMatrixAndFunction(W1, fv[0]),
+                                                                      neps.LowRankMatrixAndFunction(W2, fv[1])]))
+    P = onl.RKNEP(lowr)
+    assert P.is_low_rank and (P.p, P.q, P.r) == (1, 2, 84) and [P.blk(j) for j in range(3)] == [n, 84, 84]
+    gam = 300.0 ** 2 - 200.0 ** 2; mu = 250.0 ** 2
+    th = np.linspace(0, np.pi, int(round(np.pi / 2 * 1000)) + 2)
+    Sig = np.concatenate([(mu - gam) + 2 * gam * (np.exp(1j * th) / 2 + .5), [mu - gam]])
+    nodes = gam * np.array([2 / 3, (1 + 1j) / 3, 0, (-1 + 1j) / 3, -2 / 3]) + mu
+    Xi = -10.0 ** np.linspace(-8, 8, 10000) + s2 ** 2
+    v = np.random.default_rng(1).standard_normal(n) + 0j
+    out = []
+    for nep in (lowr, full):
+        E = solvers.StandardSPMFErrmeasure(nep)
+        lam, X, res = onl.nleigs(nep, Sig, Xi=Xi, maxit=60, v=v, leja=0, nodes=nodes, reusefact=2, errmeasure=E)
+        assert len(lam) >= 5 and max(res) < 1e-10
+        out.append(np.sort_complex(lam))
+    assert len(out[0]) == len(out[1]) and np.allclose(out[0], out[1], rtol=1e-8)
+
+
+def _lowrank_p2_problem(N):
+    """quadratic polynomial part + two low-rank exponential terms (n = 8); N = module with PEP / SPMF_NEP / SumNEP / LowRank* types"""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(3)
+    n = 8
+    B = [np.diag(0.3 * np.arange(1, n + 1)) + 0.05 * rng.standard_normal((n, n)), -np.eye(n),
+         -0.2 * np.eye(n) + 0.05 * rng.standard_normal((n, n))]
+    u = rng.standard_normal((n, 2)); w = rng.standard_normal((n, 2))
+    C1 = np.zeros((n, n)); C1[2:6, 1:5] = 0.1 * (u[2:6] @ w[1:5].T)
+    C2 = np.zeros((n, n)); C2[5:8, 5:8] = 0.1 * np.outer(u[5:8, 0], w[5:8, 1])
+    return n, B, [sp.csc_matrix(C1), sp.csc_matrix(C2)], np.array([-1 - 1j, 3 - 1j, 3 + 1j, -1 + 1j])
+
+
+def test_nleigs_lowrank_degree2_oracle():
+    """PEP of degree 2 + LowRankFactorizedNEP: compressed blocks start at block 2, so the seam z_p = ... UU^H z_{p-1}
+    (method_nleigs.jl:477-481) is exercised; with the first-block-row term that the reference leaves out (see
+    oracle/nleigs.py backslash) the compressed run finds the 8 eigenvalues of the full run, dynamic and static"""
+    from oracle import nleigs as onl
+    n, B, C, Sigma = _lowrank_p2_problem(neps)
+    fv = [neps.f_exp(-1.0), neps.f_exp(-0.5)]
+    full = neps.SumNEP(neps.PEP(B), neps.SPMF_NEP(C, fv))
+    lowr = neps.SumNEP(neps.PEP(B), neps.LowRankFactorizedNEP([neps.LowRankMatrixAndFunction(C[i], fv[i]) for i in range(2)]))
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref, _, _ = onl.nleigs(full, Sigma, maxit=60, v=np.ones(n) + 0j)
+        assert len(ref) == 8
+        for static in (False, True):
+            lam, X, res = onl.nleigs(lowr, Sigma, maxit=60, v=np.ones(n) + 0j, static=static)
+            assert len(lam) == 8 and np.allclose(np.sort_complex(np.round(lam, 9)), np.sort_complex(np.round(ref, 9)), atol=1e-7)
+            assert max(np.linalg.norm(full.compute_Mlincomb(lam[i], X[:, i])) for i in range(8)) < 1e-9
