@@ -711,3 +711,37 @@ def test_nleigs_lowrank_degree2_vs_oracle(na):
             _match(lam, ref, 1e-7)
     with pytest.raises(ValueError):                     # p = 3: the reference reads a block that does not exist yet
         na.nleigs(na.SumNEP(na.PEP(B + [0.01 * np.eye(n)]), lowr.nep2), Sigma, maxit=10, v=np.ones(n) + 0j)
+
+
+@pytest.mark.parametrize("variant", ["P", "R2", "S", "naive"])
+def test_nleigs_gun_variants_lowrank_vs_oracle(na, variant):
+    """the other gun variants of test/nleigs (nleigs_gun_variant_p.jl: polynomial, no poles; _r2.jl: Leja-Bagby nodes +
+    cyclic shifts after convergence, minit=60; _s.jl: static, minit=70; nleigs_gun_naive.jl: defaults on a square) on the
+    reduced low-rank gun problem, device against oracle: same eigenvalue count, eigenvalues to 1e-7 relative"""
+    import warnings
+    from oracle import neps as on, nleigs as onl, solvers as osol
+    n = 1310
+    K, M, W1, W2 = na.gallery.gun_matrices(n)
+    s2 = na.gallery.GUN_SIGMA2
+    fv = [na.funcs.ISqrt(1.0, 0.0), na.funcs.ISqrt(1.0, -s2 ** 2)]
+    ofv = [on.f_isqrt(0.0), on.f_isqrt(-s2 ** 2)]
+    lowr = na.SumNEP(na.PEP([K, -M]), na.LowRankFactorizedNEP([na.LowRankMatrixAndFunction(W1, fv[0]), na.LowRankMatrixAndFunction(W2, fv[1])]))
+    olr = on.SumNEP(on.PEP([K, -M]), on.LowRankFactorizedNEP([on.LowRankMatrixAndFunction(W1, ofv[0]), on.LowRankMatrixAndFunction(W2, ofv[1])]))
+    gam = 300.0 ** 2 - 200.0 ** 2; mu = 250.0 ** 2
+    th = np.linspace(0, np.pi, int(round(np.pi / 2 * 1000)) + 2)
+    Sig = np.concatenate([(mu - gam) + 2 * gam * (np.exp(1j * th) / 2 + .5), [mu - gam]])
+    nodes = gam * np.array([2 / 3, (1 + 1j) / 3, 0, (-1 + 1j) / 3, -2 / 3]) + mu
+    Xi = -10.0 ** np.linspace(-8, 8, 10000) + s2 ** 2
+    v = np.random.default_rng(1).standard_normal(n) + 0j
+    kw = {"P": dict(maxit=100, v=v, leja=0, nodes=nodes, reusefact=2),
+          "R2": dict(Xi=Xi, minit=60, maxit=100, v=v, nodes=nodes),
+          "S": dict(Xi=Xi, minit=70, maxit=100, v=v, nodes=nodes, static=True),
+          "naive": dict(v=v, maxit=60)}[variant]
+    if variant == "naive":
+        Sig = 150.0 ** 2 + 200.0 * np.array([-1 - 1j, -1 + 1j, 1 + 1j, 1 - 1j])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        lam, X, res = na.nleigs(lowr, Sig, errmeasure=na.StandardSPMFErrmeasure(lowr), **kw)
+        lo, Xo, ro = onl.nleigs(olr, Sig, errmeasure=osol.StandardSPMFErrmeasure(olr), **kw)
+    assert len(lam) >= 1 or variant == "naive"       # the stand-in has no eigenvalue in the naive square; counts must agree
+    _match(lam, lo, 1e-7)
