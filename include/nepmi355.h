@@ -112,7 +112,8 @@ int32_t nep_mlincomb_dev(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t 
 int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT,
                         int64_t ldq, double* h_rnorm, double* h_qnorm, nep_stream stream);
 /* asynchronous variant: no host synchronisation, SQUARED norms stay on the device.  d_out (2k doubles), per panel of
- * kk <= 256 columns starting at column j0: d_out[2*j0 + j] = ||M(lam_j) q_j||^2, d_out[2*j0 + kk + j] = ||q_j||^2. */
+ * kk <= P columns starting at column j0: d_out[2*j0 + j] = ||M(lam_j) q_j||^2, d_out[2*j0 + kk + j] = ||q_j||^2, where the
+ * panel width is P = min(256, max(1, 3072 / mt)) (the mt x P coefficient block has to fit 48 KiB of LDS). */
 int32_t nep_resid_batch_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
                             double* d_out, nep_stream stream);
 

@@ -89,10 +89,11 @@ __device__ __forceinline__ double readlane_d(double v, int lane) {
 
 static inline hipStream_t as_stream(nep_stream s) { return (hipStream_t)s; }
 
-// stacked-CSR index packing: high bits = term, low bits = column
-#define NEP_TERM_SHIFT 27
+// stacked-CSR index packing: high 7 bits = term (<= 128 terms: the particle example of test/nleigs has 83),
+// low 25 bits = column (n <= 33.5 M)
+#define NEP_TERM_SHIFT 25
 #define NEP_COL_MASK ((1u << NEP_TERM_SHIFT) - 1u)
-#define NEP_MAX_TERMS 32
+#define NEP_MAX_TERMS 128
 
 // Pinned host staging ring for small host->device parameter blocks (coefficient matrices, MFMA
 // B fragments).  hipMemcpyAsync from PAGEABLE memory may read the source after the call returns,

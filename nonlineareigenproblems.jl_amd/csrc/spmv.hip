@@ -633,7 +633,7 @@ int32_t nep_cw_backward_error(nep_spmf* s, const double* h_cabs, const nep_cdoub
                               nep_cdouble* dr, double* h_omega, nep_stream stream) {
     ARGCHK(s && h_cabs && dx && db && dr);
     ARGCHK((dMx != nullptr) != (h_c != nullptr));     // exactly one of: M x given, or coefficients to form it
-    ARGCHK(s->mt <= 64);
+    ARGCHK(s->mt <= NEP_MAX_TERMS);
     hipStream_t st = as_stream(stream);
     const size_t mt = (size_t)s->mt;
     int rc = s->part.ensure(64 + mt * 24);
@@ -641,7 +641,7 @@ int32_t nep_cw_backward_error(nep_spmf* s, const double* h_cabs, const nep_cdoub
     unsigned long long* bits = (unsigned long long*)s->part.dptr;
     double* cabs = (double*)((char*)s->part.dptr + 64);
     cplx* ccf = (cplx*)((char*)s->part.dptr + 64 + mt * 8);
-    double stage[64 * 3];
+    double stage[NEP_MAX_TERMS * 3];
     memcpy(stage, h_cabs, mt * 8);
     if (h_c) memcpy(stage + mt, h_c, mt * 16);
     rc = s->ring.upload(cabs, stage, mt * (h_c ? 24 : 8), st);
@@ -663,12 +663,17 @@ int32_t nep_cw_backward_error(nep_spmf* s, const double* h_cabs, const nep_cdoub
     return NEP_OK;
 }
 
+// widest column panel whose mt x kk complex coefficient block fits 48 KiB of LDS (256 for mt <= 12)
+static inline int32_t resid_panel_width(int32_t mt) { return std::min(256, std::max(1, 3072 / mt)); }
+
 // shared body: d_out != NULL -> squared norms stay on the device (no synchronisation); else host results
 static int resid_panels(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
                         double* d_out, double* h_rnorm, double* h_qnorm, hipStream_t st) {
-    // panels of at most 256 Ritz vectors per pass over the matrix
-    for (int32_t j0 = 0; j0 < k; j0 += 256) {
-        const int32_t kk = std::min(256, k - j0);
+    // panels of at most 256 Ritz vectors per pass over the matrix (fewer when the mt x kk coefficient block would not
+    // fit the 48 KiB LDS budget of k_spmm_rm)
+    const int32_t P = resid_panel_width(s->mt);
+    for (int32_t j0 = 0; j0 < k; j0 += P) {
+        const int32_t kk = std::min(P, k - j0);
         const size_t cbytes = (size_t)kk * s->mt * sizeof(cplx);
         int rc = s->coef.ensure(cbytes);
         if (rc) return rc;
@@ -722,9 +727,17 @@ int32_t nep_resid_block(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
     rc = s->ring.upload(s->coef.dptr, hF, cbytes, st);
     if (rc) return rc;
     int grid = (int)std::min<int64_t>((s->n + 3) / 4, 4096);
-    if (s->valbytes == 8)
-        return launch_spmm<double>(s, k, (const cplx*)s->coef.dptr, (const cplx*)dQT, ldq, 0, (cplx*)dRT, ldr, nullptr, grid, st);
-    return launch_spmm<cplx>(s, k, (const cplx*)s->coef.dptr, (const cplx*)dQT, ldq, 0, (cplx*)dRT, ldr, nullptr, grid, st);
+    const int32_t P = resid_panel_width(s->mt);
+    for (int32_t j0 = 0; j0 < k; j0 += P) {
+        const int32_t kk = std::min(P, k - j0);
+        const cplx* F = (const cplx*)s->coef.dptr + (size_t)j0 * s->mt;
+        const cplx* Q = (const cplx*)dQT + j0;
+        cplx* R = (cplx*)dRT + j0;
+        if (s->valbytes == 8) rc = launch_spmm<double>(s, kk, F, Q, ldq, 0, R, ldr, nullptr, grid, st);
+        else rc = launch_spmm<cplx>(s, kk, F, Q, ldq, 0, R, ldr, nullptr, grid, st);
+        if (rc) return rc;
+    }
+    return NEP_OK;
 }
 
 int32_t nep_spmm_terms(nep_spmf* s, int32_t p, const nep_cdouble* dXT, int64_t ldx, nep_cdouble* dZT,

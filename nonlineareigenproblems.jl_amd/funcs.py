@@ -220,6 +220,26 @@ class FromMatrixFunction(ScalarFun):
         return np.asarray(self.fun(np.asarray(S, dtype=complex)))
 
 
+class ExpSqrt(FromMatrixFunction):
+    """lam -> exp(gamma * sqrt(alpha * lam + beta)): the wave-number functions of the "particle in a canyon" example,
+    test/nleigs/particle_test_utils.jl:148-155 -- exp(i sqrt(m (lam - c))) for branch points c below the interval of
+    interest (gamma = i, alpha = m, beta = -m c) and exp(-sqrt(m (c - lam))) from there on (gamma = -1, alpha = -m,
+    beta = m c).  Value and matrix function in closed form (principal square root), higher derivatives through the
+    Jordan-block evaluation of the base class."""
+
+    def __init__(self, gamma, alpha, beta):
+        self.gamma, self.alpha, self.beta = complex(gamma), float(alpha), float(beta)
+        super().__init__(self._eval)
+
+    def _eval(self, S):
+        if isinstance(S, np.ndarray) and S.ndim == 2:
+            return sla.expm(self.gamma * sla.sqrtm(self.alpha * S.astype(complex) + self.beta * np.eye(S.shape[0])))
+        return np.exp(self.gamma * np.sqrt(self.alpha * complex(S) + self.beta))
+
+    def values(self, lams):
+        return np.exp(self.gamma * np.sqrt(self.alpha * np.asarray(lams, dtype=np.complex128) + self.beta))
+
+
 def one():
     return Monomial(0)
 

@@ -16,7 +16,7 @@ import numpy as np
 import scipy.sparse as sp
 
 from . import funcs
-from .nep import DEP, PEP, SPMF_NEP, SumNEP, shift_and_scale
+from .nep import DEP, PEP, SPMF_NEP, SumNEP, LowRankMatrixAndFunction, LowRankFactorizedNEP, shift_and_scale
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 _M64 = (1 << 64) - 1
@@ -197,6 +197,80 @@ def dep_symm_double(n=100):
 
 
 GALLERY["dep_symm_double"] = dep_symm_double
+
+
+def pep0(n=200):
+    """src/gallery_extra/basic_random_examples.jl:36-44"""
+    rng = MSWS_RNG()
+    return PEP([gen_rng_mat(rng, n, n) for _ in range(3)])
+
+
+GALLERY["pep0"] = pep0
+
+
+def particle_nep(interval):
+    """The "particle in a canyon" problem of test/nleigs/particle_test_utils.jl:37-165 (after W. Vandenberghe): a 2-D
+    Schroedinger operator H - lam I on a 201 x 81 grid plus, per branch point (eigenvalue of the lead Hamiltonian), a
+    rank-2 boundary term with the wave-number function exp(+-sqrt(...)) -- 83 terms, the nonlinear ones given by their
+    factors L_k, U_k only.  Returns (nep, brpts, U0); nep = PEP + LowRankFactorizedNEP (n = 16281, r = 162)."""
+    meter = 1 / 5.2917725e-11
+    nm = 1e-9 * meter
+    eV = 1 / 13.6
+    xmax, zmax, xstep, zstep = 5, 2, 0.05, 0.05
+    x_x = np.arange(-xmax, xmax + xstep / 2, xstep) * nm
+    z_z = np.arange(-zmax, zmax + zstep / 2, zstep) * nm
+    nx, nz = len(x_x), len(z_z)
+    dx = np.min(np.diff(x_x)); dz = np.min(np.diff(z_z))
+    xg = np.kron(x_x, np.ones(nz)); zg = np.kron(np.ones(nx), z_z)
+    w1, w2, ell, U0 = 1 * nm, 1.1 * nm, 4 * nm, 3 * eV
+    U = np.zeros(len(xg))
+    U[np.abs(zg) < w1] = -U0
+    U[(np.abs(zg) < w2) & (np.abs(xg) < ell / 2)] = -U0
+    m = 0.2
+    n = nx * nz
+    tri = lambda k, d0, d1: sp.diags([np.full(k - 1, d1), np.full(k, d0), np.full(k - 1, d1)], [-1, 0, 1], format="csc")
+    Dxx = tri(nx, -2 / dx ** 2, 1 / dx ** 2)
+    Dzz = tri(nz, -2 / dx ** 2, 1 / dz ** 2)            # (the reference scales the diagonal with dx, :80)
+    H_L = (-1 / m * Dzz + sp.diags(U[:nz])).toarray()
+    H_R = (-1 / m * Dzz + sp.diags(U[-nz:])).toarray()
+    if np.linalg.norm(H_L - H_R, 2) != 0:
+        raise NotImplementedError("asymmetric lead potential (not reached with the reference's parameters)")
+    d, V = np.linalg.eigh(H_L)
+    order = np.argsort(d, kind="stable")
+    d = d[order]; V = V[:, order]
+    H = -1 / m * (sp.kron(Dxx, sp.identity(nz)) + sp.kron(sp.identity(nx), Dzz)) + sp.diags(U)
+    brpts, SL = [], []
+    for j in range(len(d)):                                 # symmetric leads: a left and a right column per lead mode
+        cols = np.zeros((n, 2)); cols[:nz, 0] = V[:, j]; cols[n - nz:, 1] = V[:, j]
+        if j > 0 and d[j - 1] == d[j]:
+            SL[-1] = np.hstack([SL[-1], cols])
+        else:
+            SL.append(cols); brpts.append(d[j])
+    brpts = np.array(brpts)
+    fv = [funcs.ExpSqrt(1j, m, -m * c) if j < interval - 1 else funcs.ExpSqrt(-1.0, -m, m * c) for j, c in enumerate(brpts)]
+    C = [LowRankMatrixAndFunction(None, fv[k], L=sp.csc_matrix(-1 / m / dx ** 2 * SL[k]), U=sp.csc_matrix(SL[k]))
+         for k in range(len(fv))]
+    nep = SumNEP(PEP([sp.csc_matrix(H), -sp.identity(n, format="csc")]), LowRankFactorizedNEP(C))
+    return nep, brpts, U0
+
+
+def particle_init(interval):
+    """test/nleigs/particle_test_utils.jl:7-35: (nep, Sigma, Xi, v, nodes, xmin, xmax)"""
+    nep, brpts, U0 = particle_nep(interval)
+    sep = 1e-4
+    if interval == 1:
+        xmin = -U0; xmax = brpts[0] - sep
+        Xi = 10.0 ** np.linspace(-6, 6, 10000) + brpts[0]
+    elif interval > 1:
+        xmin = brpts[interval - 2] + sep; xmax = brpts[interval - 1] - sep
+        Xi = np.concatenate([-10.0 ** np.linspace(-6, 6, 5000) + brpts[interval - 2],
+                             10.0 ** np.linspace(-6, 6, 5000) + brpts[interval - 1]])
+    else:
+        raise ValueError("Invalid interval: %d" % interval)
+    A0 = pep0(200).get_Av()[0]
+    v = np.concatenate([A0[:, :81].reshape(-1, order="F"), A0[:81, 81]]).astype(complex)
+    nodes = np.linspace(xmin, xmax, 11)[1::2] + 0j
+    return nep, np.array([xmin + 0j, xmax + 0j]), Xi, v, nodes, xmin, xmax
 
 
 def nep_gallery(name, *args, **kwargs):

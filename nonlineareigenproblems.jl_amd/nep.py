@@ -176,8 +176,9 @@ class DeviceCSR:
 class PendingNorms:
     """result of an asynchronous residual batch: ready() polls the event, get() waits and unpacks"""
 
-    def __init__(self, pin=None, ev=None, k=0, F=None, keep=None, result=None):
+    def __init__(self, pin=None, ev=None, k=0, F=None, keep=None, result=None, panel=256):
         self.pin, self.ev, self.k, self.F, self.keep, self.result = pin, ev, k, F, keep, result
+        self.panel = panel            # column panel width of nep_resid_batch_dev's output layout
 
     def ready(self):
         return self.result is not None or self.ev.query()
@@ -188,8 +189,9 @@ class PendingNorms:
             sq = self.pin.numpy()
             k = self.k
             rn = np.empty(k); qn = np.empty(k)
-            for j0 in range(0, k, 256):
-                kk = min(256, k - j0)
+            P = self.panel
+            for j0 in range(0, k, P):
+                kk = min(P, k - j0)
                 rn[j0:j0 + kk] = np.sqrt(sq[2 * j0:2 * j0 + kk])
                 qn[j0:j0 + kk] = np.sqrt(sq[2 * j0 + kk:2 * j0 + 2 * kk])
             self.result = (rn, qn, self.F)
@@ -331,7 +333,7 @@ class AbstractSPMF(NEP):
         pin.copy_(out, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return PendingNorms(pin=pin, ev=ev, k=k, F=F, keep=(out, QT))
+        return PendingNorms(pin=pin, ev=ev, k=k, F=F, keep=(out, QT), panel=min(256, max(1, 3072 // len(fv))))
 
     def fro_norms(self):
         if self._fro is None:

@@ -212,3 +212,90 @@ def dep_symm_double(n=100):
     B = sp.diags(bb.reshape(-1, order="F"))
     A = LL + sp.diags(aa.reshape(-1, order="F"))
     return neps.DEP([sp.csc_matrix(A), sp.csc_matrix(B)], [0.0, 2.0])
+
+
+def pep0(n=200):
+    """basic_random_examples.jl:36-44"""
+    rng = MSWS_RNG()
+    return neps.PEP([gen_rng_mat(rng, n, n) for _ in range(3)])
+
+
+def _f_exp_sqrt(m, coeff, below):
+    """test/nleigs/particle_test_utils.jl:148-155: exp(i sqrt(m (lam - c)))  (branch points below the interval) or
+    exp(-sqrt(m (c - lam)))  (from the interval on)"""
+    import scipy.linalg as sla
+
+    def f(S):
+        if neps._ismat(S):
+            I = np.eye(S.shape[0])
+            if below:
+                return sla.expm(1j * sla.sqrtm((m * (S.astype(complex) - coeff * I))))
+            return sla.expm(-sla.sqrtm((m * (-S.astype(complex) + coeff * I))))
+        z = complex(S)
+        return np.exp(1j * np.sqrt(m * (z - coeff))) if below else np.exp(-np.sqrt(m * (-z + coeff)))
+    return f
+
+
+def particle_nep(interval):
+    """test/nleigs/particle_test_utils.jl:37-165 ("particle in a canyon", after W. Vandenberghe): H - lam I plus one
+    rank-2 term per branch point, given by its factors only; returns (nep, brpts, U0)"""
+    meter = 1 / 5.2917725e-11
+    nm = 1e-9 * meter
+    eV = 1 / 13.6
+    xmax, zmax, xstep, zstep = 5, 2, 0.05, 0.05
+    x_x = np.arange(-xmax, xmax + xstep / 2, xstep) * nm
+    z_z = np.arange(-zmax, zmax + zstep / 2, zstep) * nm
+    nx, nz = len(x_x), len(z_z)
+    dx = np.min(np.diff(x_x)); dz = np.min(np.diff(z_z))
+    x = np.kron(x_x, np.ones(nz)); z = np.kron(np.ones(nx), z_z)
+    w1, w2, l, U0 = 1 * nm, 1.1 * nm, 4 * nm, 3 * eV
+    U = np.zeros(len(x))
+    U[np.abs(z) < w1] = -U0
+    U[(np.abs(z) < w2) & (np.abs(x) < l / 2)] = -U0
+    m = 0.2
+    n = nx * nz
+    tri = lambda k, d0, d1: np.diag(np.full(k, d0)) + np.diag(np.full(k - 1, d1), 1) + np.diag(np.full(k - 1, d1), -1)
+    Dxx_x = tri(nx, -2 / dx ** 2, 1 / dx ** 2)
+    Dzz_z = tri(nz, -2 / dx ** 2, 1 / dz ** 2)
+    H_L = -1 / m * Dzz_z + np.diag(U[:nz])
+    H_R = -1 / m * Dzz_z + np.diag(U[-nz:])
+    if np.linalg.norm(H_L - H_R, 2) != 0:
+        raise NotImplementedError("asymmetric potential (not reached by the reference's parameters)")
+    D, V = np.linalg.eigh(H_L)
+    i = np.argsort(D, kind="stable")
+    d = D[i]; V = V[:, i]
+    H = -1 / m * (sp.kron(sp.csc_matrix(Dxx_x), sp.identity(nz)) + sp.kron(sp.identity(nx), sp.csc_matrix(Dzz_z))) + sp.diags(U)
+    brpts = []
+    SL = []
+    for j in range(len(d)):                                   # p[j] == 0: left and right column for every eigenvector
+        cols = np.zeros((n, 2)); cols[:nz, 0] = V[:, j]; cols[n - nz:, 1] = V[:, j]
+        if j > 0 and d[j - 1] == d[j]:
+            SL[-1] = np.hstack([SL[-1], cols])
+        else:
+            SL.append(cols); brpts.append(d[j])
+    brpts = np.array(brpts)
+    SU = [sp.csc_matrix(S) for S in SL]
+    SL = [sp.csc_matrix(-1 / m / dx ** 2 * S) for S in SL]
+    f = [_f_exp_sqrt(m, brpts[j], j < interval - 1) for j in range(len(brpts))]
+    C = [neps.LowRankMatrixAndFunction(None, f[k], L=SL[k], U=SU[k]) for k in range(len(f))]
+    nep = neps.SumNEP(neps.PEP([sp.csc_matrix(H), -sp.identity(n, format="csc")]), neps.LowRankFactorizedNEP(C))
+    return nep, brpts, U0
+
+
+def particle_init(interval):
+    """test/nleigs/particle_test_utils.jl:7-35: (nep, Sigma, Xi, v, nodes, xmin, xmax)"""
+    nep, brpts, U0 = particle_nep(interval)
+    sep = 1e-4
+    if interval == 1:
+        xmin = -U0; xmax = brpts[0] - sep
+        Xi = 10.0 ** np.linspace(-6, 6, 10000) + brpts[0]
+    elif interval > 1:
+        xmin = brpts[interval - 2] + sep; xmax = brpts[interval - 1] - sep
+        Xi = np.concatenate([-10.0 ** np.linspace(-6, 6, 5000) + brpts[interval - 2], 10.0 ** np.linspace(-6, 6, 5000) + brpts[interval - 1]])
+    else:
+        raise ValueError("Invalid interval: %d" % interval)
+    Sigma = np.array([xmin + 0j, xmax + 0j])
+    A0 = pep0(200).get_Av()[0]
+    v = np.concatenate([A0[:, :81].reshape(-1, order="F"), A0[:81, 81]]).astype(complex)
+    nodes = np.linspace(xmin, xmax, 11)[1::2] + 0j
+    return nep, Sigma, Xi, v, nodes, xmin, xmax

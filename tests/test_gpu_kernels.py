@@ -426,3 +426,46 @@ def test_csr_mv_vs_scipy(na, rows, cols, dens):
     out = torch.empty(rows, dtype=torch.complex128, device="cuda")
     op.mv(1.0, xd.data_ptr(), 2.0, nn.to_dev(z)[0], out)          # raw device addresses are accepted
     assert np.abs(out.cpu().numpy() - (A @ x + 2 * z)).max() <= 1e-14 * max(1.0, np.abs(A @ x + 2 * z).max())
+
+
+@pytest.mark.parametrize("mt", [33, 83, 128])
+def test_many_terms(na, mt):
+    """stacked CSR with more than 32 terms (7 term bits, <= 128; the particle example of test/nleigs has 83): K1 for
+    k = 1 (fold) and k = 5, K2 norms over 100 vectors -- several column panels, since the mt x panel coefficient block must
+    fit the LDS budget -- synchronous and asynchronous, the residual block, and the refinement criterion of a solve"""
+    import torch
+    n = 257
+    rng = np.random.default_rng(mt)
+    AA = [sp.random(n, n, 0.02, random_state=mt * 7 + i, format="csc") + (sp.identity(n) * (1.0 + i) if i == 0 else 0 * sp.identity(n))
+          for i in range(mt)]
+    AA = [sp.csc_matrix(A) for A in AA]
+    fv = [na.funcs.Exp(-0.01 * (i + 1)) if i % 2 else na.funcs.Monomial(i % 3) for i in range(mt)]
+    nep = na.SPMF_NEP(AA, fv)
+    lam = 0.3 + 0.1j
+    for k in (1, 5):
+        V = rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k))
+        a = rng.standard_normal(k)
+        z = nep.compute_Mlincomb(lam, V, a)
+        ref = sum(sum(a[j] * fv[i].derivs(lam, k)[j] * (AA[i] @ V[:, j]) for j in range(k)) for i in range(mt))
+        assert np.linalg.norm(z - ref) <= 1e-12 * np.linalg.norm(ref)
+    k = 100
+    Q = rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k))
+    lams = 0.2 + 0.3 * rng.standard_normal(k) + 0.1j * rng.standard_normal(k)
+    QT = torch.from_numpy(np.ascontiguousarray(Q)).to("cuda")
+    R = np.stack([sum(fv[i](lams[s]) * (AA[i] @ Q[:, s]) for i in range(mt)) for s in range(k)], axis=1)
+    refn = np.linalg.norm(R, axis=0) / np.linalg.norm(Q, axis=0)
+    e = na.ResidualErrmeasure(nep).batch(list(lams), QT)
+    assert np.allclose(e, refn, rtol=1e-11)
+    rn, qn, _ = nep.resid_norms_async(lams, QT).get()
+    assert np.allclose(rn / qn, refn, rtol=1e-11)
+    from nep_amd._lib import lib, check, hptr, c_vp
+    F = np.asfortranarray(np.array([[fv[i](lams[s_]) for s_ in range(k)] for i in range(mt)], dtype=np.complex128))
+    RT = torch.empty((n, k), dtype=torch.complex128, device="cuda")
+    check(lib.nep_resid_block(nep.dev.h, k, hptr(F), c_vp(QT.data_ptr()), k, c_vp(RT.data_ptr()), k, None))
+    torch.cuda.synchronize()
+    assert np.linalg.norm(RT.cpu().numpy() - R) <= 1e-12 * np.linalg.norm(R)
+    solver = na.create_linsolver(na.FactorizeLinSolverCreator(), nep, lam)
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    x = na.lin_solve(solver, b)
+    M = sum(fv[i](lam) * AA[i] for i in range(mt))
+    assert np.linalg.norm(M @ x - b) <= 1e-12 * np.linalg.norm(b) and solver.last_omega is not None and solver.last_omega < 1e-14

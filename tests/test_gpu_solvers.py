@@ -745,3 +745,23 @@ def test_nleigs_gun_variants_lowrank_vs_oracle(na, variant):
         lo, Xo, ro = onl.nleigs(olr, Sig, errmeasure=osol.StandardSPMFErrmeasure(olr), **kw)
     assert len(lam) >= 1 or variant == "naive"       # the stand-in has no eigenvalue in the naive square; counts must agree
     _match(lam, lo, 1e-7)
+
+
+def test_nleigs_particle_lowrank_static(na):
+    """test/nleigs/nleigs_particle_variant_s.jl on the device: 83 terms (the stacked CSR carries up to 128), low-rank
+    blocks of r = 162 rows, static variant with the reference's settings and start vector -> the 2 eigenvalues the
+    reference's verify_lambdas(2, ...) expects, equal to the oracle's to 1e-9, residuals below 1e-5"""
+    import warnings
+    from oracle import gallery as og, nleigs as onl, solvers as osol
+    nep, Sigma, Xi, v, nodes, xmin, xmax = na.gallery.particle_init(2)
+    onep = og.particle_init(2)[0]
+    kw = dict(Xi=Xi, maxdgr=50, minit=120, maxit=200, v=v, nodes=nodes, static=True)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        info = {}
+        lam, X, res = na.nleigs(nep, Sigma, info=info, **kw)
+        lo, Xo, ro = onl.nleigs(onep, Sigma, **kw)
+    assert len(lam) == 2 and info["lowrank_r"] == 162
+    _match(lam, lo, 1e-9)
+    E = osol.ResidualErrmeasure(onep)
+    assert max(E(lam[i], X[:, i]) for i in range(2)) < 1e-5
