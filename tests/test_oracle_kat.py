@@ -467,3 +467,49 @@ def test_nleigs_particle_lowrank_oracle():
         assert np.allclose(np.sort(lam.real), [-0.14339765648, -0.13573256070], atol=1e-9) and max(abs(lam.imag)) < 1e-10
         lam2, X2, res2 = onl.nleigs(nep, Sigma, Xi=Xi, maxdgr=50, minit=30, maxit=100, v=v, nodes=nodes, tol=1e-7)
         assert len(lam2) == 2 and np.allclose(np.sort(lam2.real), np.sort(lam.real), atol=1e-8)
+
+
+def test_wep_linsolvers_oracle_small():
+    """test/wep_small.jl:24-28: the Sylvester-SMW preconditioner with one grid point per region (N = nz) inverts the
+    Schur complement exactly (1e-14); plus the pieces it is made of: FFT Sylvester solver (Ringh 5.3), assembled Schur
+    complement (Prop. 3.1) == SchurMatVec, and the Schur-complement lin_solve (Prop. 2.1) == M(lam)^{-1} for the
+    backslash / factorized / gmres inner solvers"""
+    from oracle import wep as ow, wep_linsolvers as wl
+    nep = ow.WEP_FD(11, 7, "TAUSCH")
+    lam = -1.3 - 0.31j
+    rng = np.random.default_rng(0)
+    b1 = rng.random(77) + 1j * rng.random(77)
+    S = wl.SchurMatVec(nep, lam)
+    P = wl.wep_generate_preconditioner(nep, 7, lam)
+    assert np.linalg.norm(b1 - P(S(b1))) / np.linalg.norm(b1) < 1e-14
+    assert np.linalg.norm(wl.construct_WEP_schur_complement(nep, lam) @ b1 - S(b1)) < 1e-14 * np.linalg.norm(S(b1))
+    X = rng.random((7, 11)) + 1j * rng.random((7, 11))
+    C = nep._A(lam) @ X + (nep.wd.Dxx.T @ X.T).T
+    assert np.linalg.norm(wl.solve_wg_sylvester_fft(C, lam, nep.k_bar, nep.wd.hx, nep.wd.hz) - X) < 1e-13 * np.linalg.norm(X)
+    x = rng.random(nep.n) + 1j * rng.random(nep.n)
+    M = nep.compute_Mder(lam)
+    for st in ("backslash", "factorized", "gmres"):
+        kw = (("Pl", P), ("reltol", 1e-12)) if st == "gmres" else ()
+        y = wl.WEPLinSolverCreator(st, kwargs=kw).create_linsolver(nep, lam).lin_solve(x)
+        assert np.linalg.norm(M @ y - x) < 1e-12 * np.linalg.norm(x)
+    with pytest.raises(ValueError):
+        wl.wep_generate_preconditioner(ow.WEP_FD(11, 9, "TAUSCH"), 3, lam)            # nx != nz + 4
+    with pytest.raises(ValueError):
+        wl.wep_generate_preconditioner(nep, 2, lam)                                    # nz / N not an integer
+    with pytest.raises(ValueError):
+        wl.WEPLinSolverCreator("qr").create_linsolver(nep, lam)
+
+
+@pytest.mark.parametrize("solver_type", ["factorized", "gmres"])
+def test_wep_linsolvers_oracle_resinv(solver_type):
+    """test/wep_small.jl:30-61: resinv on the 109 x 105 JARLEBRING waveguide with the WEP linear solvers (default
+    = factorized Schur complement; gmres with the N = 21 preconditioner and reltol 1e-7) ends with
+    ||M(lam) v|| / ||v|| < 1e-10 at the reference eigenvalue"""
+    from oracle import wep as ow, wep_linsolvers as wl
+    nep = ow.WEP_FD(109, 105, "JARLEBRING")
+    n = nep.n; lam0 = -3 - 3.5j; v0 = np.ones(n) / np.sqrt(n)
+    lref = -2.743228671961724 - 3.1439375599649972j
+    E = lambda l, v: abs(l - lref) / abs(lref)
+    kw = (("Pl", wl.wep_generate_preconditioner(nep, 21, lam0)), ("reltol", 1e-7)) if solver_type == "gmres" else ()
+    lam, v = solvers.resinv(nep, lam=lam0, v=v0, errmeasure=E, tol=1e-12, linsolvercreator=wl.WEPLinSolverCreator(solver_type, kwargs=kw))
+    assert np.linalg.norm(nep.compute_Mlincomb(lam, v)) / np.linalg.norm(v) < 1e-10 and abs(lam - lref) < 1e-10
