@@ -171,6 +171,15 @@ int32_t nep_gemm_ts_dev(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_
                         const nep_cdouble* dB, int64_t ldb, int32_t b_rowmajor, int32_t p,
                         nep_cdouble* dY, int64_t ldy, int32_t y_rowmajor, nep_stream stream);
 
+/* plain dense complex GEMM, column-major:  C = alpha op(A) op(B) + beta C,  op = 0 none | 1 transpose | 2 conjugate
+ * transpose; A: m x k after op, B: k x n after op.  Runs rocBLAS zgemm (loaded on first use).
+ * replaces: the FFTW transforms of the waveguide Sylvester solver, src/gallery_extra/waveguide/waveguide_preconditioner.jl:
+ *           120-219 (V!, Vh!, W, Wh as dense DFT / sine-transform matrices), and the small dense products of the
+ *           Sylvester-SMW preconditioner (:221-421). */
+int32_t nep_zgemm(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t k, nep_cdouble alpha,
+                  const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb, nep_cdouble beta,
+                  nep_cdouble* dC, int64_t ldc, nep_stream stream);
+
 /* Refinement criterion of the fixed-shift solve (replaces UMFPACK's internal iterative refinement behind
  * `Afact \ x`, src/LinSolvers.jl:114-122 with control[8] = umfpack_refinements): writes r = b - M(lam) x and, if
  * h_omega != NULL, returns the componentwise backward error

@@ -31,4 +31,7 @@ from . import rk_helper
 from .contour import (contour_beyn, contour_block_SS, integrate_interval, MatrixIntegrator, MatrixTrapezoidal,
                       MatrixTrapezoidalSharded, probe_block)
 from . import gallery
+from . import wep_linsolvers
+from .wep_linsolvers import (WEPLinSolverCreator, WEPFactorizedLinSolver, WEPBackslashLinSolver, WEPGMRESLinSolver,
+                             wep_generate_preconditioner, construct_WEP_schur_complement)
 from .gallery import nep_gallery

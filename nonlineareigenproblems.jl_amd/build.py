@@ -65,7 +65,7 @@ def build_lib(force=False, verbose=True):
     link = [os.environ.get("CXX", "g++"), "-shared", "-fPIC", "-o", LIB] + objs
     if tl:
         link += ["-L" + tl, "-Wl,-rpath," + tl]
-    link += ["-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"]
+    link += ["-L/opt/rocm/lib", "-lamdhip64", "-ldl", "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)

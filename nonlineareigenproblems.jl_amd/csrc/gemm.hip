@@ -391,3 +391,57 @@ extern "C" int32_t nep_gemm_h_rm(const nep_cdouble* dWT, int64_t ldw, const nep_
     memcpy(h_C, tmp.data(), (size_t)k * p * sizeof(cplx));
     return NEP_OK;
 }
+
+
+// ------------------------------------------------------------------------------------------------
+// Plain dense complex GEMM  C = alpha op(A) op(B) + beta C  (column-major) through rocBLAS: the DFT / sine-transform
+// products of the waveguide Sylvester solver (waveguide_preconditioner.jl:120-219 does them with FFTW; nz = 999 = 27*37 and
+// 2(nx+1) = 2008 = 8*251 are poor FFT lengths, while a 1000^3 complex GEMM is 8 GFLOP on the FP64 matrix cores).  These are
+// ordinary square library GEMMs, not a fused hot op, so the vendor library is the right tool; it is loaded on first use
+// (dlopen) so that the rest of the library does not depend on it.
+#include <dlfcn.h>
+namespace {
+typedef void* rb_handle;
+typedef int (*rb_create_t)(rb_handle*);
+typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);
+typedef int (*rb_zgemm_t)(rb_handle, int, int, int, int, int, const void*, const void*, int, const void*, int, const void*,
+                          void*, int);
+struct RocblasApi {
+    void* lib = nullptr;
+    rb_create_t create = nullptr;
+    rb_set_stream_t set_stream = nullptr;
+    rb_zgemm_t zgemm = nullptr;
+    rb_handle handle = nullptr;
+    bool tried = false;
+};
+static RocblasApi g_rb;
+static int rocblas_ready() {
+    if (g_rb.handle) return NEP_OK;
+    if (g_rb.tried) { nep_set_error("rocBLAS is not available (librocblas.so could not be loaded)"); return NEP_ERR_HIP; }
+    g_rb.tried = true;
+    const char* names[] = {"librocblas.so", "librocblas.so.5", "librocblas.so.4", "/opt/rocm/lib/librocblas.so"};
+    for (const char* nm : names) { g_rb.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (g_rb.lib) break; }
+    if (!g_rb.lib) { nep_set_error("dlopen(librocblas.so): %s", dlerror()); return NEP_ERR_HIP; }
+    g_rb.create = (rb_create_t)dlsym(g_rb.lib, "rocblas_create_handle");
+    g_rb.set_stream = (rb_set_stream_t)dlsym(g_rb.lib, "rocblas_set_stream");
+    g_rb.zgemm = (rb_zgemm_t)dlsym(g_rb.lib, "rocblas_zgemm");
+    if (!g_rb.create || !g_rb.set_stream || !g_rb.zgemm) { nep_set_error("rocBLAS symbols missing"); return NEP_ERR_HIP; }
+    if (g_rb.create(&g_rb.handle) != 0 || !g_rb.handle) { g_rb.handle = nullptr; nep_set_error("rocblas_create_handle failed"); return NEP_ERR_HIP; }
+    return NEP_OK;
+}
+}  // namespace
+
+extern "C" int32_t nep_zgemm(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t k, nep_cdouble alpha,
+                             const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb, nep_cdouble beta,
+                             nep_cdouble* dC, int64_t ldc, nep_stream stream) {
+    ARGCHK(dA && dB && dC && m >= 1 && n >= 1 && k >= 1);
+    ARGCHK(transa >= 0 && transa <= 2 && transb >= 0 && transb <= 2);
+    ARGCHK(lda >= (transa ? k : m) && ldb >= (transb ? n : k) && ldc >= m);
+    int rc = rocblas_ready();
+    if (rc) return rc;
+    if (g_rb.set_stream(g_rb.handle, as_stream(stream)) != 0) { nep_set_error("rocblas_set_stream failed"); return NEP_ERR_HIP; }
+    static const int op[3] = {111, 112, 113};      // rocblas_operation_none / transpose / conjugate_transpose
+    const int st = g_rb.zgemm(g_rb.handle, op[transa], op[transb], m, n, k, &alpha, dA, (int)lda, dB, (int)ldb, &beta, dC, (int)ldc);
+    if (st != 0) { nep_set_error("rocblas_zgemm failed with status %d", st); return NEP_ERR_HIP; }
+    return NEP_OK;
+}

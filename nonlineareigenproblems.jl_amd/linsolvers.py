@@ -344,7 +344,7 @@ def lin_solve(solver, b, tol=0, scale=1.0):
     (nrhs, n) / (n,) (-> device result).  `scale` multiplies the result on the device."""
     host = not is_dev(b)
     bd = to_dev(b) if host else b
-    if isinstance(solver, GMRESLinSolver):
+    if isinstance(solver, GMRESLinSolver) or getattr(solver, "accepts_tol", False):
         x = solver.solve_dev(bd, scale=scale, tol=tol)          # `tol` is a hint for iterative solvers (LinSolvers.jl:184)
     else:
         x = solver.solve_dev(bd, scale=scale)
@@ -392,6 +392,8 @@ DefaultLinSolverCreator = FactorizeLinSolverCreator
 
 def create_linsolver(creator, nep, lam):
     """src/LinSolverCreators.jl:107-122,143."""
+    if hasattr(creator, "create_linsolver"):            # problem-specific creators (WEPLinSolverCreator, Waveguide.jl:504-519)
+        return creator.create_linsolver(nep, lam)
     if isinstance(creator, BackslashLinSolverCreator):
         return BackslashLinSolver(nep, lam, creator.permc_spec, **creator.lu_kw)
     if isinstance(creator, GMRESLinSolverCreator):

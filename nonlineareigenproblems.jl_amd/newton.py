@@ -33,6 +33,18 @@ class ScalarNewtonInnerSolver:
         self.tol, self.maxit, self.bad_solution_allowed = tol, maxit, bad_solution_allowed
 
 
+def _mder_times(nep, lam, vb, out, der):
+    """out = M^(der)(lam) v on the device: the stacked-CSR kernel K1 directly for pure SPMF operators, the NEP's own
+    compute_Mlincomb for types with extra terms (the dense corner of the waveguide problem)"""
+    from .nep import AbstractSPMF
+    one = np.ones(1)
+    if type(nep).compute_Mlincomb is AbstractSPMF.compute_Mlincomb:
+        nep.dev.mlincomb(nep.coeff_block(lam, one, der), vb, out)
+    else:
+        dense.copy(nep.compute_Mlincomb(lam, vb, a=one, startder=der), out, vb.shape[-1])
+    return out
+
+
 def compute_rf(nep, x, inner_solver=None, y=None, target=0.0, lam=None):
     """Rayleigh functional by scalar Newton: y^H M(lam) x = 0  (compute_rf_wrapper.jl:25-54).
     x, y: device vectors (n,) or NumPy vectors.  Returns a length-1 complex array."""
@@ -48,8 +60,8 @@ def compute_rf(nep, x, inner_solver=None, y=None, target=0.0, lam=None):
     one = np.ones(1)
     while abs(dlam) > inner_solver.tol and count < inner_solver.maxit:
         count += 1
-        nep.dev.mlincomb(nep.coeff_block(lam_iter, one, 0), xb, Z2[0])
-        nep.dev.mlincomb(nep.coeff_block(lam_iter, one, 1), xb, Z2[1])
+        _mder_times(nep, lam_iter, xb, Z2[0], 0)
+        _mder_times(nep, lam_iter, xb, Z2[1], 1)
         d = _dots2(yd, Z2, n)
         dlam = -d[0] / d[1]
         lam_iter += dlam
@@ -108,7 +120,7 @@ def resinv(nep, errmeasure=None, tol=EPS * 100, maxit=100, lam=0.0, v=None, c=No
         lam_vec = compute_rf(nep, vd, inner_solver, y=cd, lam=lam, target=sigma)
         lam1 = lam_vec[np.argmin(abs(lam_vec - lam))]
         dlam = lam1 - lam
-        nep.dev.mlincomb(nep.coeff_block(lam1, one, 0), vd.reshape(1, n), z)
+        _mder_times(nep, lam1, vd.reshape(1, n), z, 0)
         linsolver.solve_dev(z, out=dv.reshape(1, n), scale=-1.0)
         dlam, dv, j, scaling = armijo_rule(nep, errmeasure, err, lam, vd, dlam, dv, float(armijo_factor), armijo_max)
         lam += dlam
@@ -142,8 +154,8 @@ def quasinewton(nep, errmeasure=None, tol=EPS * 100, maxit=100, lam=0.0, v=None,
         if err < tol:
             return lam, to_host(vd.reshape(1, n))[:, 0]
         vb = vd.reshape(1, n)
-        nep.dev.mlincomb(nep.coeff_block(lam, one, 0), vb, UW[0])
-        nep.dev.mlincomb(nep.coeff_block(lam, one, 1), vb, UW[1])
+        _mder_times(nep, lam, vb, UW[0], 0)
+        _mder_times(nep, lam, vb, UW[1], 1)
         d = _dots2(wsd, UW, n)
         dlam = -d[0] / d[1]
         # z = dlam*w + u  (in place in u)
@@ -185,7 +197,7 @@ def augnewton(nep, errmeasure=None, tol=EPS * 100, maxit=30, lam=0.0, v=None, c=
         err = estimate_error(errmeasure, lam, vd)
         if err < tol:
             return lam, to_host(vd.reshape(1, n))[:, 0]
-        nep.dev.mlincomb(nep.coeff_block(lam, one, 1), vd.reshape(1, n), z)          # z = M'(lam) v
+        _mder_times(nep, lam, vd.reshape(1, n), z, 1)          # z = M'(lam) v
         linsolver = create_linsolver(linsolvercreator, nep, lam)
         linsolver.solve_dev(z, out=tv.reshape(1, n))
         if use_v:

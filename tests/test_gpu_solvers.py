@@ -765,3 +765,63 @@ def test_nleigs_particle_lowrank_static(na):
     _match(lam, lo, 1e-9)
     E = osol.ResidualErrmeasure(onep)
     assert max(E(lam[i], X[:, i]) for i in range(2)) < 1e-5
+
+
+def test_wep_linsolvers_small(na):
+    """test/wep_small.jl:24-28 on the device: the Sylvester-SMW preconditioner with one grid point per region (N = nz)
+    inverts SchurMatVec exactly; device SchurMatVec / assembled Schur complement / dense-transform Sylvester solve against
+    the oracle (1e-13); the Schur-complement lin_solve == M(lam)^{-1} for the three inner solvers; error behaviour"""
+    import torch
+    from oracle import wep as ow, wep_linsolvers as owl
+    nep = na.nep_gallery("WEP", nx=11, nz=7, benchmark_problem="TAUSCH")
+    onep = ow.WEP_FD(11, 7, "TAUSCH")
+    lam = -1.3 - 0.31j
+    rng = np.random.default_rng(0)
+    b1 = rng.random(77) + 1j * rng.random(77)
+    wl = na.wep_linsolvers
+    ops = wl.SchurOps(nep, lam)
+    out = torch.empty(77, dtype=torch.complex128, device="cuda")
+    Sb = ops.matvec(na.to_dev(b1)[0], out).cpu().numpy().copy()
+    So = owl.SchurMatVec(onep, lam)(b1)
+    assert np.linalg.norm(Sb - So) < 1e-13 * np.linalg.norm(So)
+    assert np.linalg.norm(na.construct_WEP_schur_complement(nep, lam) @ b1 - So) < 1e-13 * np.linalg.norm(So)
+    P = na.wep_generate_preconditioner(nep, 7, lam)
+    r = na.to_dev(Sb)[0]
+    b2 = P(r).cpu().numpy()
+    assert np.linalg.norm(b1 - b2) / np.linalg.norm(b1) < 1e-13
+    X = rng.random((7, 11)) + 1j * rng.random((7, 11))
+    C = onep._A(lam) @ X + (onep.wd.Dxx.T @ X.T).T
+    Cd = na.to_dev(C)
+    assert np.linalg.norm(na.to_host(P.linv(Cd)) - X) < 1e-12 * np.linalg.norm(X)
+    x = rng.random(nep.n) + 1j * rng.random(nep.n)
+    M = onep.compute_Mder(lam)
+    for st in ("backslash", "factorized", "gmres"):
+        kw = (("Pl", P), ("reltol", 1e-12)) if st == "gmres" else ()
+        solver = na.create_linsolver(na.WEPLinSolverCreator(solver_type=st, kwargs=kw), nep, lam)
+        y = na.lin_solve(solver, x)
+        assert np.linalg.norm(M @ y - x) < 1e-11 * np.linalg.norm(x), st
+    with pytest.raises(ValueError):
+        na.wep_generate_preconditioner(na.nep_gallery("WEP", nx=11, nz=9), 3, lam)
+    with pytest.raises(ValueError):
+        na.wep_generate_preconditioner(nep, 2, lam)
+    with pytest.raises(ValueError):
+        na.create_linsolver(na.WEPLinSolverCreator(solver_type="qr"), nep, lam)
+    with pytest.raises(TypeError):
+        na.create_linsolver(na.WEPLinSolverCreator(), na.nep_gallery("dep0"), lam)
+
+
+@pytest.mark.parametrize("solver_type", ["factorized", "backslash", "gmres"])
+def test_wep_linsolvers_resinv(na, solver_type):
+    """test/wep_small.jl:30-61 on the device: resinv on the 109 x 105 JARLEBRING waveguide with WEPLinSolverCreator()
+    (factorized Schur complement), :backslash and :gmres (N = 21 preconditioner, reltol 1e-7) -> residual < 1e-10 at the
+    reference eigenvalue"""
+    from oracle import wep as ow
+    nep = na.nep_gallery("WEP", nx=109, nz=105, benchmark_problem="JARLEBRING")
+    onep = ow.WEP_FD(109, 105, "JARLEBRING")
+    n = nep.n; lam0 = -3 - 3.5j; v0 = np.ones(n) / np.sqrt(n)
+    lref = -2.743228671961724 - 3.1439375599649972j
+    E = lambda l, v: abs(l - lref) / abs(lref)
+    kw = (("Pl", na.wep_generate_preconditioner(nep, 21, lam0)), ("reltol", 1e-7)) if solver_type == "gmres" else ()
+    cr = na.WEPLinSolverCreator(solver_type=solver_type, kwargs=kw)
+    lam, v = na.resinv(nep, lam=lam0, v=v0, errmeasure=E, tol=1e-12, linsolvercreator=cr)
+    assert np.linalg.norm(onep.compute_Mlincomb(lam, v)) / np.linalg.norm(v) < 1e-10 and abs(lam - lref) < 1e-10
