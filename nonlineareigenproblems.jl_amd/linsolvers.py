@@ -505,6 +505,9 @@ class GMRESLinSolver(LinSolver):
         self.maxiter = int(kwargs.get("maxiter", self.n))
         self.reltol = kwargs.get("reltol", kwargs.get("tol", None))
         self.abstol = float(kwargs.get("abstol", 0.0))
+        from . import dense as _d
+        # IterativeSolvers' gmres orthogonalises with ModifiedGramSchmidt by default (orth_meth keyword)
+        self.orth = {"mgs": _d.MGS, "cgs": _d.CGS, "dgks": _d.DGKS}[str(kwargs.get("orth_meth", os.environ.get("NEP_GMRES_ORTH", "mgs"))).lower()]
         Pl = kwargs.get("Pl", None)
         self._Pl_call = None
         self._Pl_inv = None
@@ -553,7 +556,7 @@ class GMRESLinSolver(LinSolver):
                 w = V[j + 1]
                 dense.copy(self.nep.compute_Mlincomb(self.lam, V[j].reshape(1, n)), w, n)
                 self._prec(w)
-                h, hb, _ = dense.orthogonalize_and_normalize(V, w, j + 1, rows=n, ldv=n, method=dense.MGS)
+                h, hb, _ = dense.orthogonalize_and_normalize(V, w, j + 1, rows=n, ldv=n, method=self.orth)
                 H[:j + 1, j] = h; H[j + 1, j] = hb
                 for i in range(j):                       # apply previous Givens rotations
                     t = cs[i] * H[i, j] + sn[i] * H[i + 1, j]

@@ -50,6 +50,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("which", nargs="*", default=["c1", "c2", "c3", "c4", "c5"], help="c1..c5 and/or x (widened drivers)")
     ap.add_argument("--oracle", action="store_true", help="also run the (slow) CPU oracle for C2/C3")
+    ap.add_argument("--wep-solver", default="lu", choices=["lu", "factorized", "backslash", "gmres"],
+                    help="c5: lu = FactorizeLinSolver on the assembled M(sigma); others = WEPLinSolverCreator types")
+    ap.add_argument("--wep-N", type=int, default=27, help="c5 gmres: regions per direction of the Sylvester-SMW preconditioner")
+    ap.add_argument("--wep-reltol", type=float, default=1e-6)
+    ap.add_argument("--wep-refine", type=int, default=10, help="c5 gmres: refinement sweeps around the GMRES solve (0 = reference behaviour)")
     ap.add_argument("--wep-nx", type=int, default=303)
     ap.add_argument("--wep-nz", type=int, default=299)
     args = ap.parse_args()
@@ -146,14 +151,30 @@ def main():
         tgen = time.perf_counter() - t0
         v0 = np.ones(n) / np.sqrt(n)
         tm = {}
-        run = lambda: na.tiar(nep, sigma=-3 - 3.5j, gamma=1.0, maxit=60, neigs=np.inf, v=v0, tol=1e-8, timers=tm)
+        kw = {}
+        extra = {}
+        if args.wep_solver != "lu":
+            # the reference's own solver for this problem: Schur complement of the boundary block (Waveguide.jl:552-567),
+            # optionally matrix-free GMRES with the Sylvester-SMW preconditioner (waveguide_preconditioner.jl)
+            skw = ()
+            if args.wep_solver == "gmres":
+                tp = time.perf_counter()
+                P = na.wep_generate_preconditioner(nep, args.wep_N, -3 - 3.5j)
+                torch.cuda.synchronize()
+                extra = dict(preconditioner_N=args.wep_N, preconditioner_setup_s=time.perf_counter() - tp, smw_cond=P.cond)
+                skw = (("Pl", P), ("reltol", args.wep_reltol), ("restart", 60), ("maxiter", 300), ("orth_meth", "dgks"))
+            kw["linsolvercreator"] = na.WEPLinSolverCreator(solver_type=args.wep_solver, kwargs=skw, refinements=args.wep_refine)
+            extra["refinements"] = args.wep_refine
+        run = lambda: na.tiar(nep, sigma=-3 - 3.5j, gamma=1.0, maxit=60, neigs=np.inf, v=v0, tol=1e-8, timers=tm, **kw)
         (out4, t) = timed(run)
+        t += extra.get("preconditioner_setup_s", 0.0)
+        extra["linsolver"] = args.wep_solver
         lam, Q = out4[0], out4[1]
         R = na.ResidualErrmeasure(nep)
         res = [na.estimate_error(R, lam[i], Q[:, i]) for i in range(len(lam))]
         emit(config="C5 WEP JARLEBRING tiar m=60", nx=nx, nz=nz, n=n, eigenpairs=len(lam), max_residual=max(res + [0.0]),
              gpu_s=t, eigenpairs_per_s=len(lam) / t, generate_s=tgen, phases_s={k_: round(v_, 4) for k_, v_ in tm.items()},
-             eigenvalues=[[l.real, l.imag] for l in lam[:6]])
+             eigenvalues=[[l.real, l.imag] for l in lam[:6]], **extra)
 
 
 def extras(na):
