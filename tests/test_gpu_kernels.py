@@ -469,3 +469,24 @@ def test_many_terms(na, mt):
     x = na.lin_solve(solver, b)
     M = sum(fv[i](lam) * AA[i] for i in range(mt))
     assert np.linalg.norm(M @ x - b) <= 1e-12 * np.linalg.norm(b) and solver.last_omega is not None and solver.last_omega < 1e-14
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 0), (2, 0), (0, 1), (1, 2)])
+def test_zgemm_vs_numpy(na, ta, tb):
+    """nep_zgemm (rocBLAS zgemm behind the C ABI): C = alpha op(A) op(B) + beta C with none / transpose / conjugate
+    transpose, leading dimensions larger than the matrices; 1e-13 relative (k = 77 products per entry)"""
+    import torch
+    from nep_amd.wep_linsolvers import zgemm
+    rng = np.random.default_rng(10 * ta + tb)
+    m, n, k = 53, 41, 77
+    op = lambda X, t: X if t == 0 else (X.T if t == 1 else X.conj().T)
+    A = rng.standard_normal((m, k) if ta == 0 else (k, m)) + 1j * rng.standard_normal((m, k) if ta == 0 else (k, m))
+    B = rng.standard_normal((k, n) if tb == 0 else (n, k)) + 1j * rng.standard_normal((k, n) if tb == 0 else (n, k))
+    C0 = rng.standard_normal((m + 3, n)) + 1j * rng.standard_normal((m + 3, n))
+    Ad, Bd, Cd = na.to_dev(A), na.to_dev(B), na.to_dev(C0)
+    alpha, beta = 0.7 - 0.2j, -0.3 + 1.1j
+    zgemm(ta, tb, m, n, k, alpha, Ad, A.shape[0], Bd, B.shape[0], beta, Cd, m + 3)
+    ref = C0.copy(); ref[:m] = alpha * (op(A, ta) @ op(B, tb)) + beta * C0[:m]
+    assert np.linalg.norm(na.to_host(Cd) - ref) <= 1e-13 * np.linalg.norm(ref)
+    with pytest.raises(na.NepError):
+        zgemm(0, 0, m, n, k, 1.0, Ad, m - 1 if ta == 0 else 1, Bd, B.shape[0], 0.0, Cd, m + 3)      # lda too small
