@@ -434,6 +434,10 @@ static int launch_vc_rows(const nep_spmf* s, int k, const cplx* dC, int64_t ldc,
     return NEP_OK;
 }
 static int launch_vc(const nep_spmf* s, int k, const cplx* dC, int64_t ldc, const cplx* V, int64_t ldv, hipStream_t st) {
+    static const int force = getenv("NEP_VC_ROWS") ? atoi(getenv("NEP_VC_ROWS")) : 0;
+    if (force == 16) return launch_vc_rows<16>(s, k, dC, ldc, V, ldv, st);
+    if (force == 32) return launch_vc_rows<32>(s, k, dC, ldc, V, ldv, st);
+    if (force == 64) return launch_vc_rows<64>(s, k, dC, ldc, V, ldv, st);
     if (s->n >= 65536) return launch_vc_rows<64>(s, k, dC, ldc, V, ldv, st);
     return launch_vc_rows<32>(s, k, dC, ldc, V, ldv, st);
 }
