@@ -116,3 +116,27 @@ def test_c5_wep_fullsize_kernels_vs_host(na):
             na.orthogonalize_and_normalize(Z, Z[j], j)
     G = na.to_host(na.gemm_ts(Z, np.eye(8), rowmajor=False))                  # identity GEMM = copy through the MFMA path
     assert np.linalg.norm(G.conj().T @ G - np.eye(8), 2) < 1e-12
+
+
+def test_c5_wep_fullsize_schur_gmres_round_trip(na):
+    """config C5 size, the reference's own solver (Waveguide.jl:428-446,552-567 + waveguide_preconditioner.jl): solve
+    M(sigma) x = b through the Schur complement with preconditioned GMRES (27 x 31 regions) and refinement sweeps, then
+    apply M(sigma): ||M x - b|| <= 1e-11 ||b|| (size-independent round-trip property; no factorisation at n = 10^6), and the
+    solve is linear in b"""
+    import torch
+    nep = na.nep_gallery("WEP", nx=1003, nz=999, benchmark_problem="JARLEBRING")
+    n = nep.n
+    sigma = -3 - 3.5j
+    P = na.wep_generate_preconditioner(nep, 27, sigma)
+    assert P.mm == 27 * 27 + 4 * 27
+    cr = na.WEPLinSolverCreator(solver_type="gmres", kwargs=(("Pl", P), ("reltol", 1e-6), ("restart", 60), ("maxiter", 300)),
+                                refinements=10)
+    solver = na.create_linsolver(cr, nep, sigma)
+    rng = np.random.default_rng(0)
+    b1 = na.to_dev(rng.standard_normal(n) + 1j * rng.standard_normal(n))[0]
+    b2 = na.to_dev(rng.standard_normal(n) + 1j * rng.standard_normal(n))[0]
+    x1 = solver.solve_dev(b1).clone(); x2 = solver.solve_dev(b2).clone()
+    r = nep.compute_Mlincomb(sigma, x1.reshape(1, n)).reshape(-1) - b1
+    assert float(torch.linalg.norm(r) / torch.linalg.norm(b1)) <= 1e-11
+    x12 = solver.solve_dev(b1 + 2.0 * b2)
+    assert float(torch.linalg.norm(x12 - x1 - 2.0 * x2) / torch.linalg.norm(x12)) <= 1e-9
