@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--oracle", action="store_true", help="also run the (slow) CPU oracle for C2/C3")
     ap.add_argument("--wep-solver", default="lu", choices=["lu", "factorized", "backslash", "gmres"],
                     help="c5: lu = FactorizeLinSolver on the assembled M(sigma); others = WEPLinSolverCreator types")
-    ap.add_argument("--wep-N", type=int, default=27, help="c5 gmres: regions per direction of the Sylvester-SMW preconditioner")
+    ap.add_argument("--wep-N", type=int, default=37, help="c5 gmres: regions per direction of the Sylvester-SMW preconditioner")
     ap.add_argument("--wep-reltol", type=float, default=1e-6)
     ap.add_argument("--wep-refine", type=int, default=10, help="c5 gmres: refinement sweeps around the GMRES solve (0 = reference behaviour)")
     ap.add_argument("--wep-nx", type=int, default=303)

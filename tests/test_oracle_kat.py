@@ -355,7 +355,6 @@ def test_nleigs_oracle_kats():
     info = {}
     lam, X, res = onl.nleigs(pep, Sigma, maxit=10, v=np.ones(2) + 0j, blksize=5, info=info)
     assert len(lam) == 4 and max(res) < 1e-5
-    exact = np.sort_complex(np.roots(np.poly1d([1]))) if False else None
     # exact spectrum of the quadratic PEP via its companion form
     C = np.block([[np.zeros((2, 2)), np.eye(2)], [-B[0], -B[1]]])
     ex = np.linalg.eigvals(C)
