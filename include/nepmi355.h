@@ -258,6 +258,12 @@ int32_t nep_coldots(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx,
  * for symmetric NEPs (src/method_ilan.jl:299-308) */
 int32_t nep_coldotsu(int64_t rows, int32_t k, const nep_cdouble* dX, int64_t ldx,
                      const nep_cdouble* dY, int64_t ldy, nep_cdouble* h_out, nep_stream stream);
+/* y = d .* (A^H x), result on the device (no synchronisation); A: rows x k column-major, d: k entries or NULL.
+ * replaces: R(nep, Rinv(nep, v) ./ coeffs) -- the boundary-operator inverse of the waveguide problem,
+ *           src/gallery_extra/waveguide/Waveguide.jl:159-170,270-294 (dense scaled-DFT matrix instead of FFTs), and
+ *           `alpha = M\b` of the Sylvester-SMW preconditioner, waveguide_preconditioner.jl:378 (M^{-1} precomputed). */
+int32_t nep_gemv_hd(const nep_cdouble* dA, int64_t lda, int64_t rows, int32_t k, const nep_cdouble* dx,
+                    const nep_cdouble* dd, nep_cdouble* dy, nep_stream stream);
 /* out[r] = sum_j A[r,j]*B[r,j] (column-major blocks, no conjugation) */
 int32_t nep_rowdot(int64_t rows, int32_t k, const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb,
                    nep_cdouble* dout, nep_stream stream);

@@ -91,6 +91,7 @@ SIGNATURES = {
     "nep_colnorms": [c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],
     "nep_coldots": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "nep_coldotsu": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
+    "nep_gemv_hd": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
     "nep_rowdot": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],
     "nep_hadamard": [c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp],
     "nep_rowmajor_colnorms": [c_i64, c_i32, c_vp, c_i64, c_vp, c_vp],

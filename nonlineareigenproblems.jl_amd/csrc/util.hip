@@ -373,6 +373,21 @@ __global__ void k_block_recur(int64_t n, int N, const cplx* __restrict__ a, cons
     }
 }
 
+// y[j] = d[j] * sum_i conj(A[i + j*lda]) x[i]   (d optional): small dense A^H x with the result on the device -- the
+// scaled-DFT products of the waveguide boundary operator P(lam)^{-1} = R diag(1/s) R^H / nz (Waveguide.jl:159-170) and the
+// SMW coefficient solve alpha = M^{-1} f.  One wave per column, 16-byte coalesced reads down the column.
+__global__ __launch_bounds__(256) void k_gemv_hd(const cplx* __restrict__ A, int64_t lda, int64_t rows, int k,
+                                                 const cplx* __restrict__ x, const cplx* __restrict__ d, cplx* __restrict__ y) {
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= k) return;
+    const cplx* a = A + (int64_t)j * lda;
+    cplx acc = cmake(0.0, 0.0);
+    for (int64_t i = lane; i < rows; i += 64) cfma_conj(acc, a[i], x[i]);
+    acc = group_reduce_sum<64>(acc);
+    if (lane == 0) y[j] = d ? cmul(d[j], acc) : acc;
+}
+
 static inline int grid_for(int64_t work, int block, int cap = 4096) {
     int64_t g = (work + block - 1) / block;
     if (g < 1) g = 1;
@@ -505,6 +520,15 @@ int32_t nep_block_recur(int64_t n, int32_t N, const nep_cdouble* h_a, const nep_
     const cplx* da = (const cplx*)g_rk_scratch.dptr;
     hipLaunchKernelGGL(k_block_recur, dim3(grid_for(n, 256)), dim3(256), 0, st, n, (int)N, da, da + N, (const cplx*)dy,
                        (cplx*)dx);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+int32_t nep_gemv_hd(const nep_cdouble* dA, int64_t lda, int64_t rows, int32_t k, const nep_cdouble* dx,
+                    const nep_cdouble* dd, nep_cdouble* dy, nep_stream stream) {
+    ARGCHK(dA && dx && dy && rows > 0 && k >= 1 && lda >= rows);
+    hipLaunchKernelGGL(k_gemv_hd, dim3((unsigned)((k + 3) / 4)), dim3(256), 0, as_stream(stream), (const cplx*)dA, lda, rows,
+                       (int)k, (const cplx*)dx, (const cplx*)dd, (cplx*)dy);
     LAUNCHCHK();
     return NEP_OK;
 }

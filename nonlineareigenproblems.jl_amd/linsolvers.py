@@ -518,6 +518,7 @@ class GMRESLinSolver(LinSolver):
                 d = np.asarray(Pl) if np.ndim(Pl) == 1 else (Pl.diagonal() if hasattr(Pl, "diagonal") else np.diag(np.asarray(Pl)))
                 self._Pl_inv = to_dev(1.0 / np.asarray(d, dtype=np.complex128))[0]
         self.iterations = 0
+        self.fused_step = None          # optional callable (v, w): w = Pl^{-1} A v  (e.g. a captured hipGraph)
 
     def _prec(self, r):
         if self._Pl_inv is not None:
@@ -554,8 +555,11 @@ class GMRESLinSolver(LinSolver):
             j_done = 0
             for j in range(m):
                 w = V[j + 1]
-                dense.copy(self.nep.compute_Mlincomb(self.lam, V[j].reshape(1, n)), w, n)
-                self._prec(w)
+                if self.fused_step is not None:            # w = Pl^{-1} A v as one pre-recorded launch sequence
+                    self.fused_step(V[j], w)
+                else:
+                    dense.copy(self.nep.compute_Mlincomb(self.lam, V[j].reshape(1, n)), w, n)
+                    self._prec(w)
                 h, hb, _ = dense.orthogonalize_and_normalize(V, w, j + 1, rows=n, ldv=n, method=self.orth)
                 H[:j + 1, j] = h; H[j + 1, j] = hb
                 for i in range(j):                       # apply previous Givens rotations

@@ -17,6 +17,8 @@ matrices applied as complex GEMMs (nep_zgemm), 4 GEMMs of nz * nx * (nz | nx) pe
 region sums / expansions of the SMW correction are products with 0/1 indicator matrices (small GEMMs), the mm x mm SMW
 matrix is inverted once on the host and applied as a GEMV, so one preconditioner application never synchronises.
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 import torch
@@ -58,35 +60,35 @@ class SchurOps:
         self.nep, self.lam = nep, complex(lam)
         self.n, self.N, self.nz, self.nx = nep.n, nep.N, nep.nz, nep.nx
         self.C1, self.C2T = _boundary_csr(nep)
-        self.Rm, _ = nep._corner_dev()
+        self.Rm, self.RmH = nep._corner_dev()
         s = _corner_derivs(nep.wd, self.lam, 1)[:, 0]
         self.sinv = to_dev(1.0 / (s * self.nz))[0]                     # 1 / (nz s_j(lam)), 2 nz entries
-        self.coef = np.asfortranarray(np.array([[1.0, self.lam, self.lam ** 2]], dtype=np.complex128))
+        self.coef = to_dev(np.array([[1.0, self.lam, self.lam ** 2]], dtype=np.complex128))    # 1 x 3, device resident
         self.pad = torch.zeros(self.n, dtype=CDT, device="cuda")
         self.z = torch.empty(self.n, dtype=CDT, device="cuda")
         self.t = torch.empty(2 * self.nz, dtype=CDT, device="cuda")
         self.u = torch.empty(2 * self.nz, dtype=CDT, device="cuda")
         self.w = torch.empty(2 * self.nz, dtype=CDT, device="cuda")
 
-    def pinv(self, x, out, ncol=1):
+    def pinv(self, x, out):
         """out = blkdiag(R, R) diag(1/s(lam)) blkdiag(R, R)^H x / nz   (Waveguide.jl:159-162); x, out: device addresses of
-        2 nz entries (minus block, plus block); the work vector self.w is used"""
+        2 nz entries (minus block, plus block); two A^H x products per block (nep_gemv_hd), the diagonal scaling fused into
+        the first one; the work vector self.w is used"""
         nz = self.nz
         xa = x.data_ptr() if is_dev(x) else x
         oa = out.data_ptr() if is_dev(out) else out
+        st = stream_ptr()
         for half in (0, 1):
             o = 16 * half * nz
-            zgemm(C_, N_, nz, 1, nz, 1.0, self.Rm, nz, xa + o, nz, 0.0, self.w.data_ptr() + o, nz)
-        check(lib.nep_hadamard(2 * nz, 1, c_vp(self.w.data_ptr()), 2 * nz, c_vp(self.sinv.data_ptr()), 2 * nz, stream_ptr()))
-        for half in (0, 1):
-            o = 16 * half * nz
-            zgemm(N_, N_, nz, 1, nz, 1.0, self.Rm, nz, self.w.data_ptr() + o, nz, 0.0, oa + o, nz)
+            check(lib.nep_gemv_hd(c_vp(self.Rm.data_ptr()), nz, nz, nz, c_vp(xa + o), c_vp(self.sinv.data_ptr() + o),
+                                  c_vp(self.w.data_ptr() + o), st))                         # w = (1/(nz s)) .* (R^H x)
+            check(lib.nep_gemv_hd(c_vp(self.RmH.data_ptr()), nz, nz, nz, c_vp(self.w.data_ptr() + o), None, c_vp(oa + o), st))   # (R^H)^H w
 
     def matvec(self, v, out):
         """out = vec(A(lam) X + X B + K .* X) - C1 P(lam)^{-1} C2T v   (SchurMatVec, Waveguide.jl:398-406)"""
         N, n = self.N, self.n
         check(lib.nep_dev_copy(c_vp(self.pad.data_ptr()), _p(v), 16 * N, stream_ptr()))
-        self.nep.dev.mlincomb(self.coef, self.pad.data_ptr(), self.z, k=1, ldv=n)
+        self.nep.dev.mlincomb_dev(self.coef, 1, 1, self.pad.data_ptr(), n, self.z)      # no host->device copy: graph-safe
         self.pinv(self.z.data_ptr() + 16 * N, self.t)
         self.C1.mv(-1.0, self.t, 1.0, self.z, out)
         return out
@@ -219,11 +221,47 @@ class WEPGMRESLinSolver(LinSolver):
         self.gmres = GMRESLinSolver(_SchurOperator(self.ops), self.lam, kw)
         self.iterations = []
 
+        self._graph = None
+        if self.gmres._Pl_call is not None and os.environ.get("NEP_WEP_GRAPH", "1") != "0":
+            self._capture_step()
+
         def inner(rhs, q, tol):
             self.gmres.solve_dev(rhs, out=q, tol=tol if self.gmres.reltol is None else None)
             self.iterations.append(self.gmres.iterations)
         self.schur = _SchurSolve(self.ops, inner)
         self.refined = FactorizeLinSolver(nep, lam, refinements, _lu=self.schur) if refinements > 0 else None
+
+    def _capture_step(self):
+        """one GMRES operator step w = Pl^{-1} S v (1 K1 call, ~12 GEMMs, ~15 small kernels) recorded once as a hipGraph on
+        fixed buffers; per iteration: copy in, replay, copy out.  Falls back to the eager sequence if capture fails."""
+        N = self.ops.N
+        vin = torch.empty(N, dtype=CDT, device="cuda"); wout = torch.empty(N, dtype=CDT, device="cuda")
+        prec = self.gmres._Pl_call
+
+        def step():
+            self.ops.matvec(vin, wout)
+            prec(wout)
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                vin.zero_(); step()                      # warm-up outside the capture (rocBLAS handle, lazy kernel loads)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                step()
+            torch.cuda.synchronize()
+        except Exception as e:                           # keep the eager path
+            self._graph_error = repr(e)
+            return
+        self._graph, self._vin, self._wout = g, vin, wout
+
+        def fused(v, w):
+            dense.copy(v, vin, N)
+            g.replay()
+            dense.copy(wout, w, N)
+        self.gmres.fused_step = fused
 
     def solve_dev(self, b, out=None, scale=1.0, tol=None):
         if self.refined is not None:
@@ -304,7 +342,7 @@ class WEPPreconditioner:
         self.al = e(N + 4, N)
         self.eb = e(2, nz)                     # nz x 2 = [e_minus, e_plus]
         self.pb = e(2 * nz)
-        self.Minv = None
+        self.MinvH = None
         self._generate()
 
     # -- pieces
@@ -353,14 +391,15 @@ class WEPPreconditioner:
             self.functionals(self.Y, Mdev[kappa])
         M = to_host(Mdev) + np.eye(mm)
         self.cond = float(np.linalg.cond(M))
-        self.Minv = to_dev(np.linalg.inv(M))
+        self.MinvH = to_dev(np.linalg.inv(M).conj().T)           # alpha = (Minv^H)^H f through nep_gemv_hd
 
     def __call__(self, r):
         """solve_smw (waveguide_preconditioner.jl:323-421), in place on the device vector r"""
         nz, nx, N, mm = self.nep.nz, self.nep.nx, self.N, self.mm
         self.linv(r)                                                           # C = Linv r
         self.functionals(r, self.fb)
-        zgemm(N_, N_, mm, 1, mm, 1.0, self.Minv, mm, self.fb, mm, 0.0, self.al, mm)
+        check(lib.nep_gemv_hd(c_vp(self.MinvH.data_ptr()), mm, mm, mm, c_vp(self.fb.data_ptr()), None, c_vp(self.al.data_ptr()),
+                              stream_ptr()))
         self.expand(self.al, self.Y)
         self.linv(self.Y)
         dense.axpy(-1.0, self.Y, r, nz * nx)

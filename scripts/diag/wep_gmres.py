@@ -22,12 +22,16 @@ for rep in range(2):
     x = s.solve_dev(b)
     torch.cuda.synchronize(); dt = time.perf_counter() - t
 r = nep.compute_Mlincomb(sigma, x.reshape(1, n)).reshape(-1) - b
+print("graph step:", s.gmres.fused_step is not None, getattr(s, "_graph_error", None))
 print(json.dumps(dict(nx=nx, nz=nz, n=n, N=N, mm=P.mm, smw_cond=P.cond, precond_setup_s=tp, reltol=reltol, gmres_iterations=s.iterations[-1],
                       solve_s=dt, true_rel_residual=float(torch.linalg.norm(r) / torch.linalg.norm(b)))))
 # cost of the pieces
 ops = s.ops
 v = torch.randn(nep.N, dtype=torch.complex128, device="cuda"); out = torch.empty_like(v)
-for name, f in (("SchurMatVec", lambda: ops.matvec(v, out)), ("preconditioner", lambda: P(out)), ("Sylvester solve", lambda: P.linv(out))):
+cand = [("SchurMatVec", lambda: ops.matvec(v, out)), ("preconditioner", lambda: P(out)), ("Sylvester solve", lambda: P.linv(out))]
+if s.gmres.fused_step is not None:
+    cand.append(("graph step", lambda: s.gmres.fused_step(v, out)))
+for name, f in cand:
     f(); torch.cuda.synchronize(); t = time.perf_counter()
     for _ in range(10): f()
     torch.cuda.synchronize(); print("%-16s %.3f ms" % (name, 1e2 * (time.perf_counter() - t)))
