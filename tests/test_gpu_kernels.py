@@ -490,3 +490,25 @@ def test_zgemm_vs_numpy(na, ta, tb):
     assert np.linalg.norm(na.to_host(Cd) - ref) <= 1e-13 * np.linalg.norm(ref)
     with pytest.raises(na.NepError):
         zgemm(0, 0, m, n, k, 1.0, Ad, m - 1 if ta == 0 else 1, Bd, B.shape[0], 0.0, Cd, m + 3)      # lda too small
+
+
+@pytest.mark.parametrize("rows,k", [(999, 999), (7, 7), (1517, 1517), (65, 3), (1, 1)])
+def test_gemv_hd_vs_numpy(na, rows, k):
+    """nep_gemv_hd: y = d .* (A^H x) with the result on the device (boundary operator P^{-1} of the waveguide problem and
+    the SMW coefficient solve), with and without the diagonal factor, lda > rows; 1e-13 relative"""
+    import torch
+    from nep_amd._lib import lib, check, c_vp
+    rng = np.random.default_rng(rows * 7 + k)
+    lda = rows + 5
+    A = rng.standard_normal((lda, k)) + 1j * rng.standard_normal((lda, k))
+    x = rng.standard_normal(rows) + 1j * rng.standard_normal(rows)
+    d = rng.standard_normal(k) + 1j * rng.standard_normal(k)
+    Ad, xd, dd = na.to_dev(A), na.to_dev(x)[0], na.to_dev(d)[0]
+    y = torch.full((k,), float("nan"), dtype=torch.complex128, device="cuda")
+    ref = A[:rows].conj().T @ x
+    check(lib.nep_gemv_hd(c_vp(Ad.data_ptr()), lda, rows, k, c_vp(xd.data_ptr()), None, c_vp(y.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.linalg.norm(y.cpu().numpy() - ref) <= 1e-13 * np.linalg.norm(ref)
+    check(lib.nep_gemv_hd(c_vp(Ad.data_ptr()), lda, rows, k, c_vp(xd.data_ptr()), c_vp(dd.data_ptr()), c_vp(y.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert np.linalg.norm(y.cpu().numpy() - d * ref) <= 1e-13 * np.linalg.norm(d * ref)
