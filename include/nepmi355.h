@@ -180,6 +180,12 @@ int32_t nep_zgemm(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t 
                   const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb, nep_cdouble beta,
                   nep_cdouble* dC, int64_t ldc, nep_stream stream);
 
+/* real GEMM (rocBLAS dgemm), op = 0 none | 1 transpose.  A complex column-major m x n block is a real 2m x n block, so
+ * products X * W with a real W (the sine transform W of waveguide_preconditioner.jl:176-199) run at half the flops. */
+int32_t nep_dgemm(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t k, double alpha,
+                  const double* dA, int64_t lda, const double* dB, int64_t ldb, double beta,
+                  double* dC, int64_t ldc, nep_stream stream);
+
 /* Refinement criterion of the fixed-shift solve (replaces UMFPACK's internal iterative refinement behind
  * `Afact \ x`, src/LinSolvers.jl:114-122 with control[8] = umfpack_refinements): writes r = b - M(lam) x and, if
  * h_omega != NULL, returns the componentwise backward error

@@ -406,11 +406,13 @@ typedef int (*rb_create_t)(rb_handle*);
 typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);
 typedef int (*rb_zgemm_t)(rb_handle, int, int, int, int, int, const void*, const void*, int, const void*, int, const void*,
                           void*, int);
+typedef rb_zgemm_t rb_dgemm_t;
 struct RocblasApi {
     void* lib = nullptr;
     rb_create_t create = nullptr;
     rb_set_stream_t set_stream = nullptr;
     rb_zgemm_t zgemm = nullptr;
+    rb_dgemm_t dgemm = nullptr;
     rb_handle handle = nullptr;
     bool tried = false;
 };
@@ -425,7 +427,8 @@ static int rocblas_ready() {
     g_rb.create = (rb_create_t)dlsym(g_rb.lib, "rocblas_create_handle");
     g_rb.set_stream = (rb_set_stream_t)dlsym(g_rb.lib, "rocblas_set_stream");
     g_rb.zgemm = (rb_zgemm_t)dlsym(g_rb.lib, "rocblas_zgemm");
-    if (!g_rb.create || !g_rb.set_stream || !g_rb.zgemm) { nep_set_error("rocBLAS symbols missing"); return NEP_ERR_HIP; }
+    g_rb.dgemm = (rb_dgemm_t)dlsym(g_rb.lib, "rocblas_dgemm");
+    if (!g_rb.create || !g_rb.set_stream || !g_rb.zgemm || !g_rb.dgemm) { nep_set_error("rocBLAS symbols missing"); return NEP_ERR_HIP; }
     if (g_rb.create(&g_rb.handle) != 0 || !g_rb.handle) { g_rb.handle = nullptr; nep_set_error("rocblas_create_handle failed"); return NEP_ERR_HIP; }
     return NEP_OK;
 }
@@ -443,5 +446,22 @@ extern "C" int32_t nep_zgemm(int32_t transa, int32_t transb, int32_t m, int32_t 
     static const int op[3] = {111, 112, 113};      // rocblas_operation_none / transpose / conjugate_transpose
     const int st = g_rb.zgemm(g_rb.handle, op[transa], op[transb], m, n, k, &alpha, dA, (int)lda, dB, (int)ldb, &beta, dC, (int)ldc);
     if (st != 0) { nep_set_error("rocblas_zgemm failed with status %d", st); return NEP_ERR_HIP; }
+    return NEP_OK;
+}
+
+// real counterpart (rocBLAS dgemm): a complex column-major m x n block IS a real 2m x n block (re / im interleaved along the
+// rows), so X * W with a REAL W -- the sine transform of the waveguide Sylvester solver -- costs half the flops of a zgemm.
+extern "C" int32_t nep_dgemm(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t k, double alpha,
+                             const double* dA, int64_t lda, const double* dB, int64_t ldb, double beta,
+                             double* dC, int64_t ldc, nep_stream stream) {
+    ARGCHK(dA && dB && dC && m >= 1 && n >= 1 && k >= 1);
+    ARGCHK(transa >= 0 && transa <= 1 && transb >= 0 && transb <= 1);
+    ARGCHK(lda >= (transa ? k : m) && ldb >= (transb ? n : k) && ldc >= m);
+    int rc = rocblas_ready();
+    if (rc) return rc;
+    if (g_rb.set_stream(g_rb.handle, as_stream(stream)) != 0) { nep_set_error("rocblas_set_stream failed"); return NEP_ERR_HIP; }
+    static const int op[2] = {111, 112};
+    const int st = g_rb.dgemm(g_rb.handle, op[transa], op[transb], m, n, k, &alpha, dA, (int)lda, dB, (int)ldb, &beta, dC, (int)ldc);
+    if (st != 0) { nep_set_error("rocblas_dgemm failed with status %d", st); return NEP_ERR_HIP; }
     return NEP_OK;
 }

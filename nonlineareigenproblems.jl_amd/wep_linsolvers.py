@@ -12,8 +12,9 @@ so SchurMatVec is ONE K1 call on the zero-padded vector (its last 2 nz rows are 
 entries + one rectangular CSR product with C1 (nep_csr_mv).  P(lam)^{-1} = R diag(1/s(lam)) R^H / nz with the dense
 scaled-DFT matrix R (two nz x nz GEMVs).  The reference diagonalises the Sylvester operator with FFTs along z (length nz)
 and sine transforms along x (FFT length 2 (nx + 1)); here both are dense transforms -- nz x nz DFT and nx x nx sine
-matrices applied as complex GEMMs (nep_zgemm), 4 GEMMs of nz * nx * (nz | nx) per Sylvester solve: at nz = 999 = 27 * 37 and
-2 (nx + 1) = 2008 = 8 * 251 a 8 GFLOP GEMM on the FP64 matrix cores costs less than a mixed-radix FFT would save.  The
+matrices applied as GEMMs (nep_zgemm for the DFT, nep_dgemm on the re/im-interleaved block for the real sine matrix), 4 GEMMs
+per Sylvester solve: at nz = 999 = 27 * 37 and 2 (nx + 1) = 2008 = 8 * 251 a 4-8 GFLOP GEMM on the FP64 matrix cores (0.1 ms)
+costs less than a mixed-radix FFT would save.  The
 region sums / expansions of the SMW correction are products with 0/1 indicator matrices (small GEMMs), the mm x mm SMW
 matrix is inverted once on the host and applied as a GEMV, so one preconditioner application never synchronises.
 """
@@ -319,7 +320,7 @@ class WEPPreconditioner:
         self.G = to_dev(1.0 / (D[:, None] + S[None, :]))                                   # nz x nx
         self.Fs = to_dev(np.fft.fft(np.eye(nz), axis=0) / np.sqrt(nz))                     # unitary DFT, symmetric
         jx = np.arange(1, nx + 1)
-        self.Wm = to_dev(np.sqrt(2.0 / (nx + 1)) * np.sin(np.pi * np.outer(jx, jx) / (nx + 1)))
+        self.Wr = torch.from_numpy(np.ascontiguousarray(np.sqrt(2.0 / (nx + 1)) * np.sin(np.pi * np.outer(jx, jx) / (nx + 1)))).to("cuda")
         self.Ksc = to_dev(Kmat - k_bar)                                                    # K_scaled (Waveguide.jl:229-230)
         # ---- regions: indicator matrices (z: nz x N; x: nx x (N+4)), kappa = i + N j
         Bz = np.kron(np.eye(N), np.ones((L, 1)))
@@ -347,14 +348,21 @@ class WEPPreconditioner:
 
     # -- pieces
     def linv(self, X):
-        """in place Sylvester solve on a device nz x nx matrix (column-major): X <- F (G .* (F^H X W)) W"""
+        """in place Sylvester solve on a device nz x nx matrix (column-major): X <- F (G .* (F^H X W)) W; the two products
+        with the real W run as real GEMMs"""
         nz, nx = self.nep.nz, self.nep.nx
-        zgemm(N_, N_, nz, nx, nx, 1.0, X, nz, self.Wm, nx, 0.0, self.T1, nz)
+        self._xw(X, self.T1)
         zgemm(C_, N_, nz, nx, nz, 1.0, self.Fs, nz, self.T1, nz, 0.0, self.T2, nz)
         check(lib.nep_hadamard(nz * nx, 1, c_vp(self.T2.data_ptr()), nz * nx, c_vp(self.G.data_ptr()), nz * nx, stream_ptr()))
-        zgemm(N_, N_, nz, nx, nx, 1.0, self.T2, nz, self.Wm, nx, 0.0, self.T1, nz)
+        self._xw(self.T2, self.T1)
         zgemm(N_, N_, nz, nx, nz, 1.0, self.Fs, nz, self.T1, nz, 0.0, X, nz)
         return X
+
+    def _xw(self, X, out):
+        """out = X W for the real symmetric sine-transform matrix W: the complex nz x nx block as a real 2 nz x nx block"""
+        nz, nx = self.nep.nz, self.nep.nx
+        check(lib.nep_dgemm(0, 0, 2 * nz, nx, nx, 1.0, _p(X), 2 * nz, c_vp(self.Wr.data_ptr()), nx, 0.0, _p(out), 2 * nz,
+                            stream_ptr()))
 
     def functionals(self, X, out):
         """out (N x (N+4)) = region means of X (waveguide_preconditioner.jl:297-304)"""
