@@ -51,6 +51,8 @@ def _dd0_mat_fun(f, S, sigma):
 def iar_chebyshev(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6, errmeasure=None,
                   sigma=0.0, gamma=1.0, v=None, logger=0, check_error_every=1, compute_y0_method="auto", a=None, b=None,
                   errhist=None, return_device=False):
+    from .nep import require_pure_spmf
+    require_pure_spmf(nep, "iar_chebyshev")
     n = nep.size(1); m = int(maxit)
     sigma = complex(sigma); gamma = complex(gamma)
     isdep = isinstance(nep, DEP); ispep = isinstance(nep, PEP)

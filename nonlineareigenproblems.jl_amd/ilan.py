@@ -46,6 +46,8 @@ def _dotu(x, y, length):
 
 def ilan(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6, errmeasure=None, sigma=0.0,
          gamma=1.0, v=None, logger=0, check_error_every=30, inner_solver_method=None, proj_solve=True, inner_logger=0):
+    from .nep import require_pure_spmf
+    require_pure_spmf(nep, "ilan")
     n = nep.size(1); m = int(maxit)
     sigma = complex(sigma); gamma = complex(gamma)
     if linsolvercreator is None:

@@ -350,6 +350,15 @@ class AbstractSPMF(NEP):
         return self._fro
 
 
+def require_pure_spmf(nep, who):
+    """drivers that feed their own coefficient blocks to the stacked-CSR kernels (nleigs, iar_chebyshev, ilan) are only
+    correct when M(lam) is exactly its SPMF sum; NEP types with extra terms (the dense corner of the waveguide problem) are
+    refused loudly instead of being solved without them"""
+    if not isinstance(nep, AbstractSPMF) or type(nep).compute_Mlincomb is not AbstractSPMF.compute_Mlincomb:
+        raise NotImplementedError("%s: the operator has terms outside its SPMF matrices (type %s); use iar / tiar / resinv / "
+                                  "quasinewton / augnewton, which go through the NEP's own compute_Mlincomb" % (who, type(nep).__name__))
+
+
 class SPMF_NEP(AbstractSPMF):
     """src/NEPTypes.jl:162-237."""
 

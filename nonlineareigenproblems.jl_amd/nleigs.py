@@ -57,6 +57,8 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
         errmeasure = ResidualErrmeasure(nep)
     Sigma = np.asarray(Sigma, dtype=complex); Xi = np.asarray(Xi, dtype=float)
     nodes = np.asarray(nodes, dtype=complex)
+    from .nep import require_pure_spmf
+    require_pure_spmf(nep, "nleigs")
     n = nep.size(1)
     p, q = rk.rk_structure(nep)
     mt = len(nep.get_Av())

@@ -808,6 +808,9 @@ def test_wep_linsolvers_small(na):
         na.create_linsolver(na.WEPLinSolverCreator(solver_type="qr"), nep, lam)
     with pytest.raises(TypeError):
         na.create_linsolver(na.WEPLinSolverCreator(), na.nep_gallery("dep0"), lam)
+    for drv in (na.nleigs, na.iar_chebyshev, na.ilan):               # drivers that bypass the NEP's own operator refuse the corner term
+        with pytest.raises(NotImplementedError):
+            drv(nep)
 
 
 @pytest.mark.parametrize("solver_type", ["factorized", "backslash", "gmres"])
