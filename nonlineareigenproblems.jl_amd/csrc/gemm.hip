@@ -139,6 +139,110 @@ __global__ __launch_bounds__(512) void k_gemm_ts(const cplx* __restrict__ Z, int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// B-resident persistent variant: when ALL B fragments of a column panel fit in LDS (nks * NT KiB <= 144 KiB, e.g. k = p = 60:
+// 120 KiB) they are loaded once per workgroup and every wave walks 16-row strips on its own -- no __syncthreads in the main
+// loop, each Z register is refilled with the NEXT strip's value right after its MFMAs are issued, so a whole strip of loads is
+// in flight behind the 2 * NT * nks MFMAs of the current one.  One workgroup
+// per CU (LDS-bound), 2 waves per SIMD.
+#define GEMM_RES_MAXKS 20
+template <int NT, bool ROWMAJOR>
+__global__ __launch_bounds__(512) void k_gemm_ts_res(const cplx* __restrict__ Z, int64_t ldz, int64_t rows, int k,
+                                                     const double* __restrict__ Bfrag, int nks, int p, int j0,
+                                                     cplx* __restrict__ Y, int64_t ldy) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int PER_KS = NT * 2 * 64;
+    double* bs = (double*)smem_raw;                       // [nks][NT][2][64]
+    {
+        const double2* src = (const double2*)Bfrag;
+        double2* dst = (double2*)bs;
+        const int n2 = nks * PER_KS / 2;
+        for (int t = threadIdx.x; t < n2; t += 512) dst[t] = src[t];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int64_t nstrips = (rows + 15) / 16;
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    cplx a[GEMM_RES_MAXKS];
+    int64_t strip = blockIdx.x * 8LL + wv;
+    if (strip < nstrips) {
+        int64_t arow = strip * 16 + m;
+        if (arow >= rows) arow = rows - 1;
+#pragma unroll
+        for (int ks = 0; ks < GEMM_RES_MAXKS; ++ks) {
+            if (ks < nks) {
+                int col = 4 * ks + q;
+                if (col >= k) col = k - 1;          // the matching B rows are zero
+                a[ks] = Z[(int64_t)col * ldz + arow];
+            }
+        }
+    }
+    for (; strip < nstrips; strip += stride) {
+        const int64_t next = strip + stride;
+        int64_t nrow = next * 16 + m;
+        if (nrow >= rows) nrow = rows - 1;
+        d4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < GEMM_RES_MAXKS; ++ks) {
+            if (ks < nks) {
+                const double* bk = bs + (size_t)ks * PER_KS + lane;
+                const cplx av = a[ks];
+                if (next < nstrips) {               // the register is free once its value is copied: refill it for the next strip
+                    int col = 4 * ks + q;
+                    if (col >= k) col = k - 1;
+                    a[ks] = Z[(int64_t)col * ldz + nrow];
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bk[(t * 2 + 0) * 64], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bk[(t * 2 + 1) * 64], acc[t], 0, 0, 0);
+            }
+        }
+        const int64_t row0 = strip * 16;
+        const int n = lane & 15, g = lane >> 4;
+        if (ROWMAJOR) {
+            double* Yd = (double*)Y;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int jc = 8 * t + (n >> 1);
+                if (jc < p) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int64_t r = row0 + g + 4 * i;
+                        if (r < rows) Yd[(r * ldy + j0 + jc) * 2 + (n & 1)] = acc[t][i];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int jc = 8 * t + (n >> 1);
+                const bool odd = n & 1;
+                const double s0 = odd ? acc[t][0] : acc[t][1];
+                const double s1 = odd ? acc[t][2] : acc[t][3];
+                const double r0 = shfl_xor_d(s0, 1);
+                const double r1 = shfl_xor_d(s1, 1);
+                cplx v0, v1;
+                int i0, i1;
+                if (!odd) { v0 = cmake(acc[t][0], r0); v1 = cmake(acc[t][2], r1); i0 = 0; i1 = 2; }
+                else      { v0 = cmake(r0, acc[t][1]); v1 = cmake(r1, acc[t][3]); i0 = 1; i1 = 3; }
+                if (jc < p) {
+                    const int64_t ra = row0 + g + 4 * i0, rb = row0 + g + 4 * i1;
+                    cplx* col = Y + (int64_t)(j0 + jc) * ldy;
+                    if (ra < rows) col[ra] = v0;
+                    if (rb < rows) col[rb] = v1;
+                }
+            }
+        }
+    }
+}
+
 static inline int gemm_nt(int pp) {   // N-tiles of 8 complex output columns
     return pp <= 8 ? 1 : pp <= 16 ? 2 : pp <= 32 ? 4 : pp <= 48 ? 6 : pp <= 64 ? 8 : pp <= 80 ? 10 : 13;
 }
@@ -149,6 +253,25 @@ static thread_local PinnedRing g_gemm_ring;
 template <int NT>
 static int gemm_launch(bool rowmajor, const cplx* Z, int64_t ldz, int64_t rows, int k, const double* dB, int nks,
                        int p, int j0, cplx* Y, int64_t ldy, hipStream_t st) {
+    // B-resident persistent kernel: all fragments in LDS (<= 144 KiB), tall blocks only (>= 16 strips per wave)
+    static const int res_mode = getenv("NEP_GEMM_RES") ? atoi(getenv("NEP_GEMM_RES")) : 1;
+    const size_t res_bytes = (size_t)nks * NT * 2 * 64 * sizeof(double);
+    if (NT <= 8 && res_mode && nks <= GEMM_RES_MAXKS && res_bytes <= 147456 && rows >= 16LL * 16 * 8 * 256) {   // NT > 8 would spill
+        static thread_local int ncu = 0;
+        if (!ncu) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
+        const dim3 grid((unsigned)ncu), block(512);
+        if (rowmajor) {
+            static thread_local bool set_t = false;
+            if (!set_t) { HIPCHK(hipFuncSetAttribute((const void*)k_gemm_ts_res<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456)); set_t = true; }
+            hipLaunchKernelGGL((k_gemm_ts_res<NT, true>), grid, block, res_bytes, st, Z, ldz, rows, k, dB, nks, p, j0, Y, ldy);
+        } else {
+            static thread_local bool set_f = false;
+            if (!set_f) { HIPCHK(hipFuncSetAttribute((const void*)k_gemm_ts_res<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456)); set_f = true; }
+            hipLaunchKernelGGL((k_gemm_ts_res<NT, false>), grid, block, res_bytes, st, Z, ldz, rows, k, dB, nks, p, j0, Y, ldy);
+        }
+        LAUNCHCHK();
+        return NEP_OK;
+    }
     const dim3 grid((unsigned)((rows + 127) / 128)), block(512);
     const size_t shm = (size_t)2 * GEMM_KCH * NT * 2 * 64 * sizeof(double);      // double-buffered B stage
     if (rowmajor)

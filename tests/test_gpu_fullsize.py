@@ -140,3 +140,17 @@ def test_c5_wep_fullsize_schur_gmres_round_trip(na):
     assert float(torch.linalg.norm(r) / torch.linalg.norm(b1)) <= 1e-11
     x12 = solver.solve_dev(b1 + 2.0 * b2)
     assert float(torch.linalg.norm(x12 - x1 - 2.0 * x2) / torch.linalg.norm(x12)) <= 1e-9
+
+
+@pytest.mark.parametrize("k,p,rowmajor", [(60, 60, True), (60, 60, False), (37, 64, True), (80, 13, False)])
+def test_k7_resident_variant_tall_blocks(na, k, p, rowmajor):
+    """K7 on blocks tall enough for the B-resident persistent kernel (rows >= 524 288, all B fragments in LDS): against NumPy,
+    1e-13 relative per entry scale; both output layouts, k not a multiple of 4, p not a multiple of 8"""
+    rows = 600_003
+    rng = np.random.default_rng(k * 100 + p)
+    Z = rng.standard_normal((rows, k)) + 1j * rng.standard_normal((rows, k))
+    B = rng.standard_normal((k, p)) + 1j * rng.standard_normal((k, p))
+    Y = na.gemm_ts(na.to_dev(Z), B, rowmajor=rowmajor)
+    Yh = Y.cpu().numpy() if rowmajor else na.to_host(Y)
+    ref = Z @ B
+    assert np.linalg.norm(Yh - ref) <= 1e-13 * np.linalg.norm(ref) * np.sqrt(k)
