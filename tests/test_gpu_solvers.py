@@ -828,3 +828,25 @@ def test_wep_linsolvers_resinv(na, solver_type):
     cr = na.WEPLinSolverCreator(solver_type=solver_type, kwargs=kw)
     lam, v = na.resinv(nep, lam=lam0, v=v0, errmeasure=E, tol=1e-12, linsolvercreator=cr)
     assert np.linalg.norm(onep.compute_Mlincomb(lam, v)) / np.linalg.norm(v) < 1e-10 and abs(lam - lref) < 1e-10
+
+
+def test_wep_nep_solvers_with_schur_linsolver(na):
+    """test/wep_small.jl:63-77: quasinewton and iar on the 109 x 105 JARLEBRING waveguide with
+    WEPLinSolverCreator(solver_type=:factorized) -- residual < 1e-10, resp. the reference eigenvalue to 1e-10; and tiar with
+    the matrix-free GMRES solver + refinement sweeps finds it too"""
+    from oracle import wep as ow
+    nep = na.nep_gallery("WEP", nx=109, nz=105, benchmark_problem="JARLEBRING")
+    onep = ow.WEP_FD(109, 105, "JARLEBRING")
+    n = nep.n; lam0 = -3 - 3.5j; v0 = np.ones(n) / np.sqrt(n)
+    lref = -2.743228671961724 - 3.1439375599649972j
+    E = lambda l, v: abs(l - lref) / abs(lref)
+    cr = na.WEPLinSolverCreator(solver_type="factorized")
+    lam, v = na.quasinewton(nep, lam=lam0, v=v0, errmeasure=E, tol=1e-12, linsolvercreator=cr)
+    assert np.linalg.norm(onep.compute_Mlincomb(lam, v)) / np.linalg.norm(v) < 1e-10
+    lams, Q, _ = na.iar(nep, sigma=lam0, neigs=3, maxit=100, v=v0, tol=1e-8, linsolvercreator=cr)
+    assert min(abs(lref - lams)) < 1e-10
+    P = na.wep_generate_preconditioner(nep, 21, lam0)
+    crg = na.WEPLinSolverCreator(solver_type="gmres", kwargs=(("Pl", P), ("reltol", 1e-6), ("restart", 60), ("maxiter", 300)),
+                                 refinements=10)
+    lam2, Q2, _, _ = na.tiar(nep, sigma=lam0, neigs=3, maxit=100, v=v0, tol=1e-8, linsolvercreator=crg)
+    assert min(abs(lref - lam2)) < 1e-10
