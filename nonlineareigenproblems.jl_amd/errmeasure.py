@@ -6,7 +6,7 @@ issues k separate compute_Mlincomb calls, src/method_iar.jl:134-135)."""
 import numpy as np
 import torch
 
-from .nep import AbstractSPMF, is_dev, to_dev, CDT
+from .nep import AbstractSPMF, is_dev
 
 EPS = np.finfo(float).eps
 

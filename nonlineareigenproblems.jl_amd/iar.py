@@ -19,15 +19,14 @@ import os
 import time
 
 import numpy as np
-import scipy.linalg as sla
 import torch
 
 from . import dense, _hosteig
 from ._lib import lib, check, c_vp, NepError, NEP_ERR_BREAKDOWN
 from .errmeasure import DefaultErrmeasure, estimate_errors, estimate_errors_async
 from .exceptions import NoConvergenceException
-from .linsolvers import DefaultLinSolverCreator, create_linsolver, lin_solve
-from .nep import CDT, to_dev, to_host, stream_ptr
+from .linsolvers import DefaultLinSolverCreator, create_linsolver
+from .nep import CDT, to_host, stream_ptr
 
 EPS = np.finfo(float).eps
 

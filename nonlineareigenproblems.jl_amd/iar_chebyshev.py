@@ -14,12 +14,11 @@ import numpy as np
 import torch
 
 from . import dense
-from ._lib import lib, check, c_vp
 from .errmeasure import DefaultErrmeasure, estimate_errors
 from .exceptions import NoConvergenceException
 from .iar import _hosteig
 from .linsolvers import DefaultLinSolverCreator, create_linsolver
-from .nep import CDT, DEP, PEP, to_dev, to_host, stream_ptr
+from .nep import CDT, DEP, PEP, to_dev, to_host
 
 EPS = np.finfo(float).eps
 

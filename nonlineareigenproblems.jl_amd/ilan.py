@@ -12,7 +12,6 @@ Extraction by Galerkin projection on span(V) + inner solve (proj_solve=true, the
 The reference's DEP version of Bmult is the same product in factored form (test/ilan.jl:45-62 checks that the two give the
 same iterates); the SPMF version is used for every SPMF-type NEP here.
 """
-import ctypes as C
 
 import numpy as np
 import torch

@@ -17,7 +17,6 @@ import time
 
 import numpy as np
 import scipy.sparse as sp
-import scipy.sparse.linalg as spla
 import torch
 
 from . import _lib

@@ -4,12 +4,11 @@ Mirrors src/method_newton.jl:142-226 (resinv), :380-445 (quasinewton), :598-609 
 src/compute_rf_wrapper.jl:25-54 (compute_rf).  The eigenvector iterate lives on the device; per
 iteration only scalars (lambda, error, two dot products) cross PCIe.
 """
-import ctypes as C
 
 import numpy as np
 import torch
 
-from . import dense, _lib
+from . import dense
 from ._lib import lib, check, hptr, c_vp
 from .errmeasure import DefaultErrmeasure, estimate_error
 from .exceptions import NoConvergenceException

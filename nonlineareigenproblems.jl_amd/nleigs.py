@@ -27,7 +27,7 @@ import torch
 from . import dense, rk_helper as rk
 from ._lib import lib, check, hptr, c_vp
 from .errmeasure import ResidualErrmeasure, estimate_errors
-from .linsolvers import DefaultLinSolverCreator, LinSolverCache, create_linsolver
+from .linsolvers import DefaultLinSolverCreator, LinSolverCache
 from .nep import CDT, to_dev, to_host, stream_ptr
 
 EPS = np.finfo(float).eps

@@ -115,11 +115,10 @@ class WaveguideData:
 
 # =================================================================================================
 # device NEP
-import ctypes as C
 
 import torch
 
-from . import _lib, dense
+from . import _lib
 from ._lib import lib, check, hptr, c_vp
 from .nep import AbstractSPMF, CDT, to_dev, to_host, is_dev, stream_ptr
 

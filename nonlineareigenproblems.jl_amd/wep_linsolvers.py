@@ -25,7 +25,7 @@ import scipy.sparse as sp
 import torch
 
 from . import _lib, dense
-from ._lib import lib, check, hptr, c_vp
+from ._lib import lib, check, c_vp
 from .linsolvers import DeviceLU, FactorizeLinSolver, GMRESLinSolver, LinSolver, LinSolverCreator
 from .nep import CDT, DeviceCSR, to_dev, to_host, is_dev, stream_ptr
 from .wep import WEP, _corner_derivs
