@@ -142,10 +142,17 @@ __global__ __launch_bounds__(512) void k_gemm_ts(const cplx* __restrict__ Z, int
 // ------------------------------------------------------------------------------------------------
 // B-resident persistent variant: when ALL B fragments of a column panel fit in LDS (nks * NT KiB <= 144 KiB, e.g. k = p = 60:
 // 120 KiB) they are loaded once per workgroup and every wave walks 16-row strips on its own -- no __syncthreads in the main
-// loop, each Z register is refilled with the NEXT strip's value right after its MFMAs are issued, so a whole strip of loads is
-// in flight behind the 2 * NT * nks MFMAs of the current one.  One workgroup
+// loop, the Z values are prefetched four k-steps (64 MFMAs) ahead through a small register ring, across strip boundaries.  One workgroup
 // per CU (LDS-bound), 2 waves per SIMD.
-#define GEMM_RES_MAXKS 20
+#define GEMM_RES_MAXKS 24
+#define GEMM_TALL_ROWS (16LL * 16 * 8 * 256)   // >= 16 strips per wave of a full grid: the resident kernel is worth its set-up
+// k-steps for a block of `rows` rows: padded to a multiple of 8 for tall blocks so that the resident kernel can take them
+// (the extra k-steps multiply zero B rows)
+static inline int gemm_nks(int k, int64_t rows) {
+    int nks = (k + 3) / 4;
+    if (rows >= GEMM_TALL_ROWS) { const int np = (nks + 7) & ~7; if (np <= GEMM_RES_MAXKS) nks = np; }
+    return nks;
+}
 template <int NT, bool ROWMAJOR>
 __global__ __launch_bounds__(512) void k_gemm_ts_res(const cplx* __restrict__ Z, int64_t ldz, int64_t rows, int k,
                                                      const double* __restrict__ Bfrag, int nks, int p, int j0,
@@ -165,44 +172,62 @@ __global__ __launch_bounds__(512) void k_gemm_ts_res(const cplx* __restrict__ Z,
     const int m = lane & 15, q = lane >> 4;
     const int64_t nstrips = (rows + 15) / 16;
     const int64_t stride = (int64_t)gridDim.x * 8;
-    cplx a[GEMM_RES_MAXKS];
+    // Z values travel through two rings of RES_D registers used alternately (ping-pong, so no register copies and the
+    // only waits are at the first use of a ring): while the MFMAs of k-steps kb .. kb+RES_D-1 consume ring A, the loads for
+    // kb+RES_D .. kb+2*RES_D-1 go into ring B -- of this strip, or of the wave's next strip once the index runs past nks.
+    // The loads are unconditional (clamped addresses) and pinned in front of the MFMAs with scheduling barriers.
+    constexpr int RES_D = 4;
+    cplx ra[RES_D], rb[RES_D];
     int64_t strip = blockIdx.x * 8LL + wv;
-    if (strip < nstrips) {
-        int64_t arow = strip * 16 + m;
+    auto zload = [&](int ks, int64_t arow, int64_t nrow) -> cplx {      // k-step ks of this strip, or ks - nks of the next one
+        const bool same = ks < nks;
+        int col = 4 * (same ? ks : ks - nks) + q;
+        if (col >= k) col = k - 1;                  // the matching B rows are zero
+        return Z[(int64_t)col * ldz + (same ? arow : nrow)];
+    };
+    {
+        int64_t arow = (strip < nstrips ? strip : nstrips - 1) * 16 + m;
         if (arow >= rows) arow = rows - 1;
 #pragma unroll
-        for (int ks = 0; ks < GEMM_RES_MAXKS; ++ks) {
-            if (ks < nks) {
-                int col = 4 * ks + q;
-                if (col >= k) col = k - 1;          // the matching B rows are zero
-                a[ks] = Z[(int64_t)col * ldz + arow];
-            }
-        }
+        for (int j = 0; j < RES_D; ++j) ra[j] = zload(j, arow, arow);
     }
     for (; strip < nstrips; strip += stride) {
-        const int64_t next = strip + stride;
-        int64_t nrow = next * 16 + m;
+        const int64_t next = strip + stride < nstrips ? strip + stride : strip;
+        int64_t arow = strip * 16 + m, nrow = next * 16 + m;
+        if (arow >= rows) arow = rows - 1;
         if (nrow >= rows) nrow = rows - 1;
         d4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+        for (int kb = 0; kb < nks; kb += 2 * RES_D) {      // nks is a multiple of 2 * RES_D (padded by the host side)
 #pragma unroll
-        for (int ks = 0; ks < GEMM_RES_MAXKS; ++ks) {
-            if (ks < nks) {
-                const double* bk = bs + (size_t)ks * PER_KS + lane;
-                const cplx av = a[ks];
-                if (next < nstrips) {               // the register is free once its value is copied: refill it for the next strip
-                    int col = 4 * ks + q;
-                    if (col >= k) col = k - 1;
-                    a[ks] = Z[(int64_t)col * ldz + nrow];
-                }
+            for (int j = 0; j < RES_D; ++j) rb[j] = zload(kb + RES_D + j, arow, nrow);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < RES_D; ++j) {
+                const double* bk = bs + (size_t)(kb + j) * PER_KS + lane;
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.x, bk[(t * 2 + 0) * 64], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[j].x, bk[(t * 2 + 0) * 64], acc[t], 0, 0, 0);
 #pragma unroll
                 for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av.y, bk[(t * 2 + 1) * 64], acc[t], 0, 0, 0);
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[j].y, bk[(t * 2 + 1) * 64], acc[t], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < RES_D; ++j) ra[j] = zload(kb + 2 * RES_D + j, arow, nrow);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < RES_D; ++j) {
+                const double* bk = bs + (size_t)(kb + RES_D + j) * PER_KS + lane;
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rb[j].x, bk[(t * 2 + 0) * 64], acc[t], 0, 0, 0);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rb[j].y, bk[(t * 2 + 1) * 64], acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
         const int64_t row0 = strip * 16;
         const int n = lane & 15, g = lane >> 4;
@@ -256,7 +281,8 @@ static int gemm_launch(bool rowmajor, const cplx* Z, int64_t ldz, int64_t rows, 
     // B-resident persistent kernel: all fragments in LDS (<= 144 KiB), tall blocks only (>= 16 strips per wave)
     static const int res_mode = getenv("NEP_GEMM_RES") ? atoi(getenv("NEP_GEMM_RES")) : 1;
     const size_t res_bytes = (size_t)nks * NT * 2 * 64 * sizeof(double);
-    if (NT <= 8 && res_mode && nks <= GEMM_RES_MAXKS && res_bytes <= 147456 && rows >= 16LL * 16 * 8 * 256) {   // NT > 8 would spill
+    // (the ping-pong rings of the resident kernel need nks to be a multiple of 8: the entry points pad it for tall blocks)
+    if (NT <= 8 && res_mode && nks <= GEMM_RES_MAXKS && nks % 8 == 0 && res_bytes <= 147456 && rows >= GEMM_TALL_ROWS) {   // NT > 8 would spill
         static thread_local int ncu = 0;
         if (!ncu) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
         const dim3 grid((unsigned)ncu), block(512);
@@ -324,7 +350,7 @@ extern "C" int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows,
     ARGCHK(rows > 0 && k >= 1 && p >= 1 && ldz >= rows && ldb >= k);
     ARGCHK(y_rowmajor ? ldy >= p : ldy >= rows);
     hipStream_t st = as_stream(stream);
-    const int nks = (k + 3) / 4;
+    const int nks = gemm_nks(k, rows);
     // column panels of at most 104 complex output columns (13 N-tiles of 8)
     size_t total = 0;
     for (int j0 = 0; j0 < p; j0 += 104) total += (size_t)nks * gemm_nt(std::min(104, p - j0)) * 128;
@@ -379,7 +405,7 @@ extern "C" int32_t nep_gemm_ts_dev(const nep_cdouble* dZ, int64_t ldz, int64_t r
     ARGCHK(b_rowmajor ? ldb >= p : ldb >= k);
     ARGCHK(y_rowmajor ? ldy >= p : ldy >= rows);
     hipStream_t st = as_stream(stream);
-    const int nks = (k + 3) / 4;
+    const int nks = gemm_nks(k, rows);
     size_t total = 0;
     for (int j0 = 0; j0 < p; j0 += 104) total += (size_t)nks * gemm_nt(std::min(104, p - j0)) * 128;
     int rc = g_gemm_scratch_dev.ensure(total * sizeof(double));
