@@ -329,6 +329,18 @@ def main():
                                         "scripts/kernel_bench.py gun, same shape; 2*FETCH + WRITE per the gfx950 note)")
             except Exception:
                 rf["traffic"] = None
+            try:                                      # context: what a plain streaming read reaches on this box, same run
+                xs = torch.rand(1 << 26, dtype=torch.float64, device="cuda")          # 512 MiB
+                xs.sum(); torch.cuda.synchronize()
+                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(20):
+                    xs.sum()
+                e1.record(); torch.cuda.synchronize()
+                rf["stream_read_reference"] = {"kernel": "torch.sum over 512 MiB float64", "GB/s": 8.0 * (1 << 26) * 20 / e0.elapsed_time(e1) / 1e6}
+                del xs
+            except Exception:
+                pass
             out["roofline"] = rf
         except Exception as e:
             out["roofline"] = {"error": repr(e)[:200]}
