@@ -263,12 +263,46 @@ class AbstractSPMF(NEP):
         """M^(i)(lam) as a host sparse/dense matrix (src/NEPTypes.jl:362-394); host-side, used once per
         shift for the factorisation."""
         Av = self.get_Av(); fv = self.get_fv()
+        coef = np.array([f.derivs(lam, i + 1)[i] for f in fv], dtype=np.complex128)
+        al = self._aligned_terms()
+        if al is not None:
+            # all terms on ONE union sparsity pattern (built once, like the reference's align_sparsity_patterns option of
+            # SPMF_NEP): the matrix of a shift is a 1 x m_t by m_t x nnz product instead of m_t sparse additions
+            # (contour_beyn assembles 64 of them: 1.6 ms -> 0.7 ms each on gun)
+            indptr, indices, D = al
+            # (einsum, not `D @ coef`: OpenBLAS' threaded zgemv takes 24 ms for this 88 598 x 4 product, einsum 0.6 ms)
+            return sp.csc_matrix((np.einsum("ij,j->i", D, coef), indices, indptr), shape=Av[0].shape)
         Z = None
-        for A, f in zip(Av, fv):
-            c = f.derivs(lam, i + 1)[i]
+        for A, c in zip(Av, coef):
             T = A * c
             Z = T if Z is None else Z + T
         return Z
+
+    def _aligned_terms(self):
+        """(indptr, indices, D) with D[:, t] = values of A_t scattered onto the union CSC pattern of all terms, or None if a
+        term is dense"""
+        if getattr(self, "_aligned", False) is not False:
+            return self._aligned
+        Av = self.get_Av()
+        self._aligned = None
+        if all(sp.issparse(A) for A in Av) and len(Av) > 0:
+            n = Av[0].shape[0]
+            cs = [sp.csc_matrix(A) for A in Av]
+            for M in cs:
+                M.sum_duplicates(); M.sort_indices()
+            U = cs[0].astype(bool).astype(np.int8)
+            for M in cs[1:]:
+                U = U + M.astype(bool).astype(np.int8)
+            U = sp.csc_matrix(U); U.sort_indices()
+            colU = np.repeat(np.arange(U.shape[1], dtype=np.int64), np.diff(U.indptr))
+            keyU = colU * n + U.indices                                    # increasing: columns ascending, rows sorted inside
+            D = np.zeros((U.nnz, len(cs)), dtype=np.complex128)           # nnz x m_t: a tall matrix-vector product per shift
+            for t, M in enumerate(cs):
+                colM = np.repeat(np.arange(M.shape[1], dtype=np.int64), np.diff(M.indptr))
+                pos = np.searchsorted(keyU, colM * n + M.indices)
+                D[pos, t] = M.data
+            self._aligned = (U.indptr.copy(), U.indices.copy(), D)
+        return self._aligned
 
     def compute_MM(self, S, V):
         """sum_i A_i V f_i(S)   (src/NEPTypes.jl:276-319): host f_i(S), device GEMM + SpMM."""
