@@ -12,6 +12,8 @@ sums stay on the device (K8 = nep_axpy).  `MatrixTrapezoidalSharded` gives rank 
 i = r (mod P); the only exchange is ONE all-gather of the 2 n k partial block, followed by a
 fixed-order sum so that every rank holds bit-identical A0, A1.
 """
+import os
+
 import numpy as np
 import scipy.linalg as sla
 import torch
@@ -87,8 +89,8 @@ class _NodeSolve:
     node needs a NEW host factorisation; `prefetch` starts all factorisations of this rank's nodes in worker processes
     so that they run concurrently with each other and with the device solves of the nodes already factored."""
 
-    BUILDERS = 4          # threads turning host factors into device schedules (nep_lu_create releases the GIL)
-    AHEAD = 8             # device factorisations built (or being built) ahead of the node being solved
+    BUILDERS = int(os.environ.get("NEP_BEYN_BUILDERS", "4"))   # threads turning host factors into device schedules (nep_lu_create releases the GIL)
+    AHEAD = int(os.environ.get("NEP_BEYN_AHEAD", "8"))         # device factorisations built (or being built) ahead of the node being solved
 
     def __init__(self, nep, linsolvercreator, sigma, g, Vd, weight):
         self.nep, self.creator, self.sigma, self.g, self.Vd, self.weight = nep, linsolvercreator, sigma, g, Vd, weight
