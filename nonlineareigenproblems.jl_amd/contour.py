@@ -127,9 +127,17 @@ class _NodeSolve:
         from concurrent.futures import ThreadPoolExecutor
         self.pool = ThreadPoolExecutor(max_workers=self.BUILDERS)
         self.order = list(ts)
+        trace = os.environ.get("NEP_BEYN_TRACE")
+        if trace:
+            import time as _t
+            self._t0 = _t.perf_counter(); self._host_done = []
         for t in ts:
             A = self.nep.compute_Mder(self.g(t) + self.sigma)
             self.host[t] = HostLUPool.submit(A, permc_spec=c.permc_spec, **c.lu_kw)
+            if trace:
+                self.host[t].add_done_callback(lambda f, s=self: s._host_done.append(_t.perf_counter() - s._t0))
+        if trace:
+            self._t_submitted = _t.perf_counter() - self._t0
         self._submit_builds()
 
     def close(self):
@@ -150,6 +158,12 @@ class _NodeSolve:
                 self.close()
                 raise
             if not self.built and self.next >= len(self.order):
+                if os.environ.get("NEP_BEYN_TRACE"):
+                    import time as _t
+                    hd = sorted(self._host_done)
+                    print("[beyn trace] submitted all at %.0f ms; host factorisations done: first %.0f ms, half %.0f ms, last %.0f ms; "
+                          "last block solve issued at %.0f ms" % (1e3 * self._t_submitted, 1e3 * hd[0], 1e3 * hd[len(hd) // 2], 1e3 * hd[-1],
+                                                                  1e3 * (_t.perf_counter() - self._t0)), flush=True)
                 self.close()
             return X, self.weight(t)
         M0inv = create_linsolver(self.creator, self.nep, self.g(t) + self.sigma)

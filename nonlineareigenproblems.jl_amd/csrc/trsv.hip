@@ -489,7 +489,7 @@ static void free_mid(MidFactor& m) {
 
 // blocked mid region rows [h0, h0 + nblk*b) of one factor: off-block CSR + device-built inverses of the diagonal blocks
 static int build_mid(const int32_t* P, const int32_t* I, const nep_cdouble* X, bool upper, int64_t h0, int nblk, int b,
-                     MidFactor& out) {
+                     MidFactor& out, hipStream_t bst) {
     const int64_t M = (int64_t)nblk * b;
     std::vector<int32_t> rp(M + 1, 0), ci, blkoff(nblk + 1, 0), levptr, rowid(M), rowptr(M + 1, 0), col, lvl(b), cnt;
     std::vector<nep_cdouble> vx, val, diag(upper ? M : 0);
@@ -590,17 +590,17 @@ static int build_mid(const int32_t* P, const int32_t* I, const nep_cdouble* X, b
         if (e == hipSuccess && upper) e = hipMemcpy(d_diag, diag.data(), (size_t)M * 16, hipMemcpyHostToDevice);
         if (e == hipSuccess) {
             if (upper)
-                hipLaunchKernelGGL((k_mid_inverse<true>), dim3(b, nblk), dim3(256), (size_t)b * sizeof(cplx), 0, b, h0,
+                hipLaunchKernelGGL((k_mid_inverse<true>), dim3(b, nblk), dim3(256), (size_t)b * sizeof(cplx), bst, b, h0,
                                    (const int32_t*)d_blkoff, (const int32_t*)d_levptr, (const int32_t*)d_rowid,
                                    (const int32_t*)d_rowptr, (const int32_t*)d_col, (const cplx*)d_val,
                                    (const cplx*)d_diag, out.d_inv);
             else
-                hipLaunchKernelGGL((k_mid_inverse<false>), dim3(b, nblk), dim3(256), (size_t)b * sizeof(cplx), 0, b, h0,
+                hipLaunchKernelGGL((k_mid_inverse<false>), dim3(b, nblk), dim3(256), (size_t)b * sizeof(cplx), bst, b, h0,
                                    (const int32_t*)d_blkoff, (const int32_t*)d_levptr, (const int32_t*)d_rowid,
                                    (const int32_t*)d_rowptr, (const int32_t*)d_col, (const cplx*)d_val,
                                    (const cplx*)d_diag, out.d_inv);
             e = hipGetLastError();
-            if (e == hipSuccess) e = hipDeviceSynchronize();
+            if (e == hipSuccess) e = hipStreamSynchronize(bst);     // only this build's work: other threads' builds and solves go on
         }
         if (e != hipSuccess) { nep_set_error("mid inverse build failed: %s", hipGetErrorString(e)); rc = NEP_ERR_HIP; }
     }
@@ -814,18 +814,26 @@ static int lu_build(nep_lu* lu, int64_t n, const int32_t* hLp, const int32_t* hL
     char errU[512] = {0};
     int dev = 0;
     (void)hipGetDevice(&dev);
+    // the inverse-block kernels of this build run on private non-blocking streams and are waited for individually (they
+    // used to be followed by hipDeviceSynchronize, which serialised concurrent builds -- Beyn builds several
+    // factorisations at once -- against each other and against the solves of the launching thread)
+    static thread_local hipStream_t bst = nullptr;
+    if (!bst) HIPCHK(hipStreamCreateWithFlags(&bst, hipStreamNonBlocking));
     std::thread side([&]() {
         (void)hipSetDevice(dev);
+        hipStream_t sst = nullptr;
+        if (hipStreamCreateWithFlags(&sst, hipStreamNonBlocking) != hipSuccess) sst = nullptr;
         std::vector<int32_t> levU(n, 0);
         int32_t nlU = 0;
         compute_levels(n, hUp, hUi, true, 0, h0, levU, nlU);
         rcU = build_tri(n, hUp, hUi, hUx, true, 0, h0, 0, n, levU, nlU, lu->U11);   // keeps the columns >= h0 (final by then)
-        if (rcU == NEP_OK && lu->nblk > 0) rcU = build_mid(hUp, hUi, hUx, true, h0, lu->nblk, lu->bsz, lu->Um);
+        if (rcU == NEP_OK && lu->nblk > 0) rcU = build_mid(hUp, hUi, hUx, true, h0, lu->nblk, lu->bsz, lu->Um, sst);
+        if (sst) (void)hipStreamDestroy(sst);
         if (rcU != NEP_OK) { strncpy(errU, nep_last_error(), sizeof(errU) - 1); }
     });
     compute_levels(n, hLp, hLi, false, 0, h0, level, nl);
     rc = build_tri(n, hLp, hLi, hLx, false, 0, h0, 0, h0, level, nl, lu->L11);
-    if (rc == NEP_OK && lu->nblk > 0) rc = build_mid(hLp, hLi, hLx, false, h0, lu->nblk, lu->bsz, lu->Lm);
+    if (rc == NEP_OK && lu->nblk > 0) rc = build_mid(hLp, hLi, hLx, false, h0, lu->nblk, lu->bsz, lu->Lm, bst);
     side.join();
     if (rc) return rc;
     if (rcU) { nep_set_error("%s", errU); return rcU; }
@@ -865,14 +873,14 @@ static int lu_build(nep_lu* lu, int64_t n, const int32_t* hLp, const int32_t* hL
     }
     TSTAMP("tail factors");
     if (rc == NEP_OK) {
-        hipLaunchKernelGGL(k_tail_inverse, dim3((unsigned)T), dim3(512), (size_t)T * sizeof(cplx), 0, (int)T, (int)i0,
+        hipLaunchKernelGGL(k_tail_inverse, dim3((unsigned)T), dim3(512), (size_t)T * sizeof(cplx), bst, (int)T, (int)i0,
                            (const int32_t*)L22.d_levptr, L22.nlev, (const int32_t*)L22.d_rowid,
                            (const int32_t*)L22.d_rowptr, (const int32_t*)L22.d_col, (const cplx*)L22.d_val,
                            (const int32_t*)U22.d_levptr, U22.nlev, (const int32_t*)U22.d_rowid,
                            (const int32_t*)U22.d_rowptr, (const int32_t*)U22.d_col, (const cplx*)U22.d_val,
                            (const cplx*)U22.d_diag, lu->d_Sinv);
         hipError_t e = hipGetLastError();
-        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = hipStreamSynchronize(bst);
         if (e != hipSuccess) { nep_set_error("tail inverse kernel failed: %s", hipGetErrorString(e)); rc = NEP_ERR_HIP; }
     }
     TSTAMP("tail inverse");
