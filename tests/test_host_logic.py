@@ -244,3 +244,32 @@ def test_inpolygon_reference_kat_and_vectorised_form():
         P += list(zip(qx, qy)) + [((qx[i] + qx[(i + 1) % m]) / 2, (qy[i] + qy[(i + 1) % m]) / 2) for i in range(m)]
         P += [(0.5, 0.0), (1.0, 1.5), (1.5, 1.0), (0.0, 0.0)]
         assert all(bool(inp(x, y, qx, qy)) == bool(onl.inpolygon(x, y, qx, qy)) for x, y in P)
+
+
+def test_compute_Mder_union_pattern_equals_term_by_term_sum():
+    """compute_Mder (src/NEPTypes.jl:343-394) assembles M^(i)(lam) on a cached union sparsity pattern: same matrix as the
+    term-by-term sparse sum for gun (disjoint and overlapping patterns), qdep0, a random SPMF with unsorted / duplicate
+    entries, the waveguide problem (whose dense corner is added on top), and dense NEPs fall back to the plain sum"""
+    rng = np.random.default_rng(0)
+    def naive(nep, lam, i):
+        Z = None
+        for A, f in zip(nep.get_Av(), nep.get_fv()):
+            T = A * f.derivs(lam, i + 1)[i]
+            Z = T if Z is None else Z + T
+        return Z
+    rows = rng.integers(0, 30, 200); cols = rng.integers(0, 30, 200)
+    A0 = sp.coo_matrix((rng.standard_normal(200), (rows, cols)), shape=(30, 30))            # duplicates, unsorted
+    A1 = sp.random(30, 30, 0.1, random_state=1, format="csr") + 1j * sp.random(30, 30, 0.1, random_state=2, format="csr")
+    cases = [(na.nep_gallery("gun_spmf", 655), 62500.0 + 300j), (na.nep_gallery("nlevp_native_gun", 655), 5e4 - 20j),
+             (na.nep_gallery("qdep0"), 0.3 + 0.1j),
+             (na.SPMF_NEP([A0, A1, sp.identity(30, format="csc")], [na.funcs.one(), na.funcs.Exp(-0.5), na.funcs.Monomial(2)]), -0.7 + 0.2j)]
+    for nep, lam in cases:
+        for i in (0, 1, 2):
+            Z = nep.compute_Mder(lam, i); R = naive(nep, lam, i)
+            assert sp.issparse(Z) and abs(Z - R).max() <= 1e-15 * max(abs(R).max(), 1e-300)
+    d = na.nep_gallery("dep0")
+    assert isinstance(d.compute_Mder(0.2), np.ndarray) and np.allclose(d.compute_Mder(0.2), naive(d, 0.2, 0))
+    w = na.nep_gallery("WEP", nx=11, nz=7)
+    from oracle import wep as ow
+    lam = -1.3 - 0.31j
+    assert abs(w.compute_Mder(lam) - ow.WEP_FD(11, 7, "TAUSCH").compute_Mder(lam)).max() < 1e-12
