@@ -41,6 +41,7 @@ typedef void* nep_stream;
 #define NEP_ERR_ARG -2      /* invalid argument */
 #define NEP_ERR_SINGULAR -3 /* zero pivot met in the triangular solve (SingularException analogue) */
 #define NEP_ERR_BREAKDOWN -4 /* orthogonalisation breakdown: ||w|| == 0 */
+#define NEP_ERR_UNSUPPORTED -5 /* the request does not fit this code path (internal: callers fall back) */
 
 /* ---- library / device ---------------------------------------------------------------- */
 int32_t nep_version(void);
@@ -211,19 +212,45 @@ int32_t nep_absvec(int64_t len, const nep_cdouble* dx, nep_cdouble* dout, nep_st
 int32_t nep_lu_create(int64_t n, const int32_t* hLp, const int32_t* hLi, const nep_cdouble* hLx,
                       const int32_t* hUp, const int32_t* hUi, const nep_cdouble* hUx,
                       const int32_t* h_perm_r, const int32_t* h_perm_c, nep_lu** out);
+/* The same with L and U in CSC (compressed columns: colptr, rowidx, values) -- the layout UMFPACK (Julia's `F.L`, `F.U`,
+ * SparseMatrixCSC) and SuperLU (SciPy's `lu.L`, `lu.U`) hand out, so the host never converts.  Row indices inside a
+ * column need not be sorted. */
+int32_t nep_lu_create_csc(int64_t n, const int32_t* hLp, const int32_t* hLi, const nep_cdouble* hLx,
+                          const int32_t* hUp, const int32_t* hUi, const nep_cdouble* hUx,
+                          const int32_t* h_perm_r, const int32_t* h_perm_c, nep_lu** out);
+/* Same-pattern refactorisation (src/method_beyncontour.jl:89-94 factors N matrices M(sigma + g(t_i)) of one sparsity
+ * pattern; src/LinSolverCreators.jl:62-122 recycles by lambda): new values for the factors `lu` was created with, in the
+ * same entry order (and the same CSR/CSC layout).  Only the numeric part runs: value upload + the device kernels that
+ * invert the diagonal blocks.  The symbolic analysis (elimination tree, block partition, index arrays) is also shared
+ * automatically between nep_lu_create[_csc] calls whose L/U patterns and permutations coincide (pattern-hash cache). */
+int32_t nep_lu_refactor(nep_lu* lu, const nep_cdouble* hLx, const nep_cdouble* hUx);
+/* Row scaling of the factorised matrix: the factors are those of Pr*diag(rs)*A*Pc (UMFPACK's `F.Rs`: L*U = P*(Rs.\A)*Q
+ * has rs = 1 ./ Rs), so every right-hand side is multiplied by rs on the way in.  h_rs: n doubles, NULL removes it. */
+int32_t nep_lu_set_row_scale(nep_lu* lu, const double* h_rs);
 int32_t nep_lu_destroy(nep_lu* lu);
 /* hint for the NEXT nep_lu_create of the calling thread: how many solves the factorisation will serve (default 50).
  * It sizes the dense tail block whose inverse is built at creation time (one-off ~T^2/256 us vs a shorter
  * dependency chain per solve): FactorizeLinSolver (iar/tiar: maxit solves) passes a large number,
  * BackslashLinSolver (one block solve per factorisation, src/LinSolvers.jl:157-159) passes 1. */
 int32_t nep_lu_set_expected_solves(int32_t nsolves);
-/* info[0]=n info[1]=nnz(L) info[2]=nnz(U) info[3]=levels(L) info[4]=levels(U)
- * info[5]=algorithmic bytes of one solve with one right-hand side */
+/* info[0]=n info[1]=nnz(L) info[2]=nnz(U) info[3]=dependent steps(L) info[4]=dependent steps(U)
+ * info[5]=bytes one solve with one right-hand side moves under the schedule in use (the ALGORITHMIC bytes of SURVEY.md
+ * section 8d are (nnz(L)+nnz(U))*20 + 8(n+1) + 48n, computable from info[0..2]) */
 int32_t nep_lu_info(const nep_lu* lu, int64_t info[6]);
-/* schedule introspection: out[0]=dense tail size T, out[1]=kernel launches of the last solve,
- * out[2]=levels(L), out[3]=levels(U) of the plain level schedule, out[4]=wide, out[5]=narrow segments,
- * out[6]=rows of the blocked mid region (explicitly inverted diagonal blocks), out[7]=its block size */
+/* schedule introspection.  Block schedule (default, trsv_ml.hip): out[0]=0, out[1]=kernel launches of the last solve,
+ * out[2]=out[3]=levels of the block partition, out[4]=levels whose coupling product is a separate launch (L+U),
+ * out[5]=number of diagonal blocks, out[6]=rows covered by inverted blocks (= n), out[7]=largest block size.
+ * Level schedule (NEP_LU_SCHED=old, and the fallback): out[0]=dense tail size T, out[1]=launches, out[2]=levels(L),
+ * out[3]=levels(U) of the plain level schedule, out[4]=wide, out[5]=narrow segments, out[6]=rows of the blocked mid
+ * region, out[7]=its block size.  nep_lu_is_block_schedule tells which one a handle uses. */
 int32_t nep_lu_schedule(const nep_lu* lu, int64_t out[8]);
+int32_t nep_lu_is_block_schedule(const nep_lu* lu, int32_t* out);
+/* host-only symbolic analysis of the block schedule for a pair of factor patterns (csc = 0: CSR, 1: CSC); touches no
+ * device.  out[0]=levels, out[1]=diagonal blocks, out[2]=largest block, out[3]/out[4]=coupling non-zeros / packed inverse
+ * entries of L, out[5]/out[6] the same for U, out[7]=levels with a separate coupling launch.  NEP_ERR_UNSUPPORTED when the
+ * patterns have a dependency outside the elimination tree (the level schedule is used then). */
+int32_t nep_lu_analyze(int64_t n, int32_t csc, const int32_t* hLp, const int32_t* hLi, const int32_t* hUp,
+                       const int32_t* hUi, int64_t out[8]);
 /* X = A^{-1} B for nrhs right-hand sides; dB, dX: n x nrhs column-major; dX may alias dB.
  * scale is applied to the result (iar/tiar use -1: y = -lin_solve(...), src/method_iar.jl:103). */
 int32_t nep_lu_solve(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_t ldb, nep_cdouble* dX,

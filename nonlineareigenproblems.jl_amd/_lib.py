@@ -18,14 +18,18 @@ class NepError(RuntimeError):
         self.status = status
 
 
-NEP_OK, NEP_ERR_HIP, NEP_ERR_ARG, NEP_ERR_SINGULAR, NEP_ERR_BREAKDOWN = 0, -1, -2, -3, -4
+NEP_OK, NEP_ERR_HIP, NEP_ERR_ARG, NEP_ERR_SINGULAR, NEP_ERR_BREAKDOWN, NEP_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
 
 
 def _load():
-    if not os.path.exists(LIB_PATH):
-        # build in-tree (hipcc cross-compiles without a GPU); never falls back to a CPU path
-        from . import build
-        build.build_lib(verbose=False)
+    # build in-tree (hipcc cross-compiles without a GPU) when the library is missing OR older than its sources: a stale
+    # .so with changed argument lists would corrupt memory through ctypes.  Never falls back to a CPU path.
+    from . import build
+    if build.needs_build():
+        if os.path.exists("/opt/rocm/bin/hipcc") or os.environ.get("HIPCC"):
+            build.build_lib(verbose=False)
+        elif not os.path.exists(LIB_PATH):
+            raise ImportError("libnepmi355.so is missing and hipcc is not available to build it")
     return C.CDLL(LIB_PATH)
 
 
@@ -75,6 +79,11 @@ SIGNATURES = {
     "nep_gemm_ts": [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp],
     "nep_gemm_ts_dev": [c_vp, c_i64, c_i64, c_i32, c_vp, c_i64, c_i32, c_i32, c_vp, c_i64, c_i32, c_vp],
     "nep_lu_create": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, P(c_vp)],
+    "nep_lu_create_csc": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, P(c_vp)],
+    "nep_lu_refactor": [c_vp, c_vp, c_vp],
+    "nep_lu_set_row_scale": [c_vp, c_vp],
+    "nep_lu_is_block_schedule": [c_vp, P(c_i32)],
+    "nep_lu_analyze": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, P(c_i64)],
     "nep_lu_destroy": [c_vp],
     "nep_lu_set_expected_solves": [c_i32],
     "nep_cw_backward_error": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],

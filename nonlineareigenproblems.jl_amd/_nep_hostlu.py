@@ -2,8 +2,8 @@
 in worker processes (Beyn: one new matrix per quadrature node, src/method_beyncontour.jl:89-94; SciPy's splu releases
 the GIL for other Python threads but two splu calls of one process do not overlap -- measured: 4 threads take as long
 as 4 sequential calls -- so concurrent factorisations need processes, while ONE background thread is enough to overlap a
-factorisation with device work, see linsolvers.LinSolverCache.prefetch).  Returns the factors in the CSR form
-nep_lu_create expects."""
+factorisation with device work, see linsolvers.LinSolverCache.prefetch).  Returns the factors in the compressed-column form
+SuperLU produces (nep_lu_create_csc; csr=True converts to the CSR form of nep_lu_create)."""
 import threading
 import time
 
@@ -110,7 +110,7 @@ class _blas_limit:
 
 
 def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None, symmetric_mode=None, panel_size=8,
-           relax=4):
+           relax=4, csr=False):
     """UMFPACK-like strategy selection (see linsolvers.DeviceLU) + SuperLU factorisation.
     panel_size / relax: SuperLU's panel width and relaxed-supernode size.  With single-threaded BLAS on these complex
     sparse matrices the defaults (20 / 10) are slower: measured on the bench host gun (n=9956) 20.4 -> 15.5 ms,
@@ -142,10 +142,14 @@ def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None
     with _blas_limit(nthreads):
         lu = spla.splu(Ac, **kw)  # RuntimeError("Factor is exactly singular") propagates to the caller
     t_factor = time.perf_counter() - t0
-    L = sp.csr_matrix(lu.L); U = sp.csr_matrix(lu.U)
-    L.sort_indices(); U.sort_indices()
+    # SuperLU hands L and U out in compressed columns; nep_lu_create_csc takes them as they are (the former CSC -> CSR
+    # conversion + index sort cost 3-6 ms per gun factorisation on the host)
+    L = lu.L; U = lu.U
+    if csr:
+        L = sp.csr_matrix(L); U = sp.csr_matrix(U)
+        L.sort_indices(); U.sort_indices()
     return dict(
-        n=shape[0],
+        n=shape[0], fmt="csr" if csr else "csc",
         Lp=np.ascontiguousarray(L.indptr, dtype=np.int32), Li=np.ascontiguousarray(L.indices, dtype=np.int32),
         Lx=np.ascontiguousarray(L.data, dtype=np.complex128),
         Up=np.ascontiguousarray(U.indptr, dtype=np.int32), Ui=np.ascontiguousarray(U.indices, dtype=np.int32),

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnepmi355.so")
-SOURCES = ["util.hip", "spmv.hip", "orth.hip", "gemm.hip", "trsv.hip"]
+SOURCES = ["util.hip", "spmv.hip", "orth.hip", "gemm.hip", "trsv.hip", "trsv_ml.hip"]
 
 
 def _torch_lib_dir():
@@ -31,7 +31,7 @@ def needs_build():
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h"]] + [os.path.join(ROOT, "include", "nepmi355.h")]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + ["common.h", "trsv_ml.h"]] + [os.path.join(ROOT, "include", "nepmi355.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

@@ -118,6 +118,10 @@ struct PinnedRing {
 // next writer.
 int nep_pool_alloc(void** p, size_t bytes);
 void nep_pool_free(void* p);
+// free a block that work already enqueued on `st` may still read or write: an event recorded on st travels with the
+// block and the next nep_pool_alloc that picks it waits for it (blocks whose event has completed are preferred).
+// in_flight = false degrades to nep_pool_free.
+void nep_pool_free_on(void* p, hipStream_t st, bool in_flight);
 
 // small per-library scratch (device) helpers, defined in util.hip
 struct NepScratch {

@@ -25,6 +25,7 @@
 // All kernels take grid.y = right-hand side index, so Beyn's n x k block solve
 // (src/method_beyncontour.jl:91-93) fills the chip.
 #include "common.h"
+#include "trsv_ml.h"
 #include <vector>
 #include <algorithm>
 #include <chrono>
@@ -84,6 +85,10 @@ struct nep_lu {
     void* graph_work = nullptr;
     hipStream_t cap_stream = nullptr;
     int32_t use_graph = 1;
+    MLFactor* ml = nullptr;        // elimination-tree block schedule (trsv_ml.hip); when set, the fields above are unused
+    int32_t csc = 0;               // layout the caller's factors came in (nep_lu_refactor expects the same)
+    hipStream_t last = nullptr;    // stream of the last solve: frees are ordered behind it
+    bool used = false;
 };
 
 __device__ __forceinline__ cplx cdiv(cplx a, cplx b) {
@@ -671,19 +676,26 @@ extern "C" {
 
 int32_t nep_lu_destroy(nep_lu* lu) {
     if (!lu) return NEP_OK;
-    free_tri(lu->L11);
-    free_tri(lu->U11);
-    free_mid(lu->Lm);
-    free_mid(lu->Um);
-    if (lu->d_L21p) nep_pool_free(lu->d_L21p);
-    if (lu->d_L21i) nep_pool_free(lu->d_L21i);
-    if (lu->d_L21x) nep_pool_free(lu->d_L21x);
-    if (lu->d_Sinv) nep_pool_free(lu->d_Sinv);
-    if (lu->d_perm_r) nep_pool_free(lu->d_perm_r);
-    if (lu->d_perm_c) nep_pool_free(lu->d_perm_c);
+    if (lu->ml) { ml_destroy(lu->ml); lu->ml = nullptr; }
+    // a solve enqueued on lu->last may still read these blocks (Beyn drops the factorisation right after the asynchronous
+    // block solve): the pool hands them out again only behind that work
+    hipStream_t st = lu->last; const bool fl = lu->used;
+    auto rel_tri = [&](TriFactor& t) {
+        nep_pool_free_on(t.d_levptr, st, fl); nep_pool_free_on(t.d_rowid, st, fl); nep_pool_free_on(t.d_rowptr, st, fl);
+        nep_pool_free_on(t.d_col, st, fl); nep_pool_free_on(t.d_val, st, fl); nep_pool_free_on(t.d_diag, st, fl);
+        t = TriFactor();
+    };
+    auto rel_mid = [&](MidFactor& m) {
+        nep_pool_free_on(m.d_rp, st, fl); nep_pool_free_on(m.d_ci, st, fl); nep_pool_free_on(m.d_vx, st, fl);
+        nep_pool_free_on(m.d_inv, st, fl);
+        m = MidFactor();
+    };
+    rel_tri(lu->L11); rel_tri(lu->U11); rel_mid(lu->Lm); rel_mid(lu->Um);
+    nep_pool_free_on(lu->d_L21p, st, fl); nep_pool_free_on(lu->d_L21i, st, fl); nep_pool_free_on(lu->d_L21x, st, fl);
+    nep_pool_free_on(lu->d_Sinv, st, fl); nep_pool_free_on(lu->d_perm_r, st, fl); nep_pool_free_on(lu->d_perm_c, st, fl);
     if (lu->graph_exec) (void)hipGraphExecDestroy(lu->graph_exec);
     if (lu->cap_stream) (void)hipStreamDestroy(lu->cap_stream);
-    lu->work.release();
+    if (lu->work.dptr) { nep_pool_free_on(lu->work.dptr, st, fl); lu->work.dptr = nullptr; lu->work.cap = 0; }
     delete lu;
     return NEP_OK;
 }
@@ -817,8 +829,9 @@ static int lu_build(nep_lu* lu, int64_t n, const int32_t* hLp, const int32_t* hL
     // the inverse-block kernels of this build run on private non-blocking streams and are waited for individually (they
     // used to be followed by hipDeviceSynchronize, which serialised concurrent builds -- Beyn builds several
     // factorisations at once -- against each other and against the solves of the launching thread)
-    static thread_local hipStream_t bst = nullptr;
-    if (!bst) HIPCHK(hipStreamCreateWithFlags(&bst, hipStreamNonBlocking));
+    hipStream_t bst = nullptr;     // per-build stream, destroyed at the end of the build (a thread_local one leaked per builder thread)
+    HIPCHK(hipStreamCreateWithFlags(&bst, hipStreamNonBlocking));
+    struct StreamGuard { hipStream_t s; ~StreamGuard() { if (s) (void)hipStreamDestroy(s); } } bst_guard{bst};
     std::thread side([&]() {
         (void)hipSetDevice(dev);
         hipStream_t sst = nullptr;
@@ -895,25 +908,23 @@ int32_t nep_lu_set_expected_solves(int32_t nsolves) {
     return NEP_OK;
 }
 
-int32_t nep_lu_create(int64_t n, const int32_t* hLp, const int32_t* hLi, const nep_cdouble* hLx, const int32_t* hUp,
-                      const int32_t* hUi, const nep_cdouble* hUx, const int32_t* h_perm_r, const int32_t* h_perm_c,
-                      nep_lu** out) {
-    ARGCHK(out != nullptr);
-    *out = nullptr;
-    ARGCHK(n > 0 && n < ((int64_t)1 << 31));
-    ARGCHK(hLp && hLi && hLx && hUp && hUi && hUx);
+static bool use_block_schedule() {
+    const char* e = getenv("NEP_LU_SCHED");
+    return !(e && (!strcmp(e, "old") || !strcmp(e, "levels")));
+}
+
+static int lu_create_levels(int64_t n, const int32_t* hLp, const int32_t* hLi, const nep_cdouble* hLx, const int32_t* hUp,
+                            const int32_t* hUi, const nep_cdouble* hUx, const int32_t* h_perm_r, const int32_t* h_perm_c,
+                            nep_lu* lu) {
     const bool timing = getenv("NEP_TIMING") != nullptr;
     double tlast = now_ms();
-    nep_lu* lu = new nep_lu();
-    lu->n = n;
     // a graph pays off from the second solve on; one-shot factorisations (BackslashLinSolver: Beyn builds them on
     // worker threads while the main thread solves) launch eagerly -- stream capture in one thread makes synchronous
     // HIP calls of the other threads fail on this runtime
     lu->use_graph = g_expected_solves >= 3 ? 1 : 0;
-    lu->nnzL_in = hLp[n]; lu->nnzU_in = hUp[n];
     int rc = lu_build(lu, n, hLp, hLi, hLx, hUp, hUi, hUx);
     TSTAMP("lu_build total");
-    if (rc != NEP_OK) { nep_lu_destroy(lu); return rc; }
+    if (rc != NEP_OK) return rc;
     auto up_perm = [&](const int32_t* hp, int32_t** dp) -> int {
         if (!hp) return NEP_OK;
         std::vector<char> seen(n, 0);
@@ -927,14 +938,98 @@ int32_t nep_lu_create(int64_t n, const int32_t* hLp, const int32_t* hLi, const n
     };
     rc = up_perm(h_perm_r, &lu->d_perm_r);
     if (rc == NEP_OK) rc = up_perm(h_perm_c, &lu->d_perm_c);
-    if (rc != NEP_OK) { nep_lu_destroy(lu); return rc; }
     TSTAMP("perms");
+    return rc;
+}
+
+// CSC -> CSR for the level schedule (the block schedule reads CSC directly)
+static void csc_to_csr_c(int64_t n, const int32_t* cp, const int32_t* ri, const nep_cdouble* vx, std::vector<int32_t>& rp,
+                         std::vector<int32_t>& ci, std::vector<nep_cdouble>& rv) {
+    const int64_t nnz = cp[n];
+    rp.assign(n + 1, 0);
+    for (int64_t e = 0; e < nnz; ++e) rp[ri[e] + 1]++;
+    for (int64_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
+    ci.resize(nnz); rv.resize(nnz);
+    std::vector<int32_t> pos(rp.begin(), rp.end() - 1);
+    for (int64_t c = 0; c < n; ++c)
+        for (int32_t e = cp[c]; e < cp[c + 1]; ++e) { const int32_t q = pos[ri[e]]++; ci[q] = (int32_t)c; rv[q] = vx[e]; }
+}
+
+static int32_t lu_create_any(int64_t n, int csc, const int32_t* hLp, const int32_t* hLi, const nep_cdouble* hLx,
+                             const int32_t* hUp, const int32_t* hUi, const nep_cdouble* hUx, const int32_t* h_perm_r,
+                             const int32_t* h_perm_c, nep_lu** out) {
+    ARGCHK(out != nullptr);
+    *out = nullptr;
+    ARGCHK(n > 0 && n < ((int64_t)1 << 31));
+    ARGCHK(hLp && hLi && hLx && hUp && hUi && hUx);
+    ARGCHK(hLp[0] == 0 && hUp[0] == 0 && hLp[n] >= 0 && hUp[n] >= 0);
+    nep_lu* lu = new nep_lu();
+    lu->n = n; lu->csc = csc;
+    lu->nnzL_in = hLp[n]; lu->nnzU_in = hUp[n];
+    int rc = NEP_ERR_UNSUPPORTED;
+    if (use_block_schedule()) {
+        if (csc) {      // CSC index sanity before the pattern is transposed
+            for (int64_t e = 0; e < hLp[n]; ++e) if (hLi[e] < 0 || hLi[e] >= n) { delete lu; nep_set_error("L: row out of range"); return NEP_ERR_ARG; }
+            for (int64_t e = 0; e < hUp[n]; ++e) if (hUi[e] < 0 || hUi[e] >= n) { delete lu; nep_set_error("U: row out of range"); return NEP_ERR_ARG; }
+        }
+        rc = ml_create(n, csc, hLp, hLi, hLx, hUp, hUi, hUx, h_perm_r, h_perm_c, g_expected_solves, &lu->ml);
+    }
+    if (rc == NEP_ERR_UNSUPPORTED) {
+        if (csc) {
+            std::vector<int32_t> Lrp, Lci, Urp, Uci; std::vector<nep_cdouble> Lrv, Urv;
+            csc_to_csr_c(n, hLp, hLi, hLx, Lrp, Lci, Lrv);
+            csc_to_csr_c(n, hUp, hUi, hUx, Urp, Uci, Urv);
+            rc = lu_create_levels(n, Lrp.data(), Lci.data(), Lrv.data(), Urp.data(), Uci.data(), Urv.data(), h_perm_r, h_perm_c, lu);
+        } else
+            rc = lu_create_levels(n, hLp, hLi, hLx, hUp, hUi, hUx, h_perm_r, h_perm_c, lu);
+    }
+    if (rc != NEP_OK) { nep_lu_destroy(lu); return rc; }
     *out = lu;
+    return NEP_OK;
+}
+
+int32_t nep_lu_create(int64_t n, const int32_t* hLp, const int32_t* hLi, const nep_cdouble* hLx, const int32_t* hUp,
+                      const int32_t* hUi, const nep_cdouble* hUx, const int32_t* h_perm_r, const int32_t* h_perm_c,
+                      nep_lu** out) {
+    return lu_create_any(n, 0, hLp, hLi, hLx, hUp, hUi, hUx, h_perm_r, h_perm_c, out);
+}
+
+int32_t nep_lu_create_csc(int64_t n, const int32_t* hLp, const int32_t* hLi, const nep_cdouble* hLx, const int32_t* hUp,
+                          const int32_t* hUi, const nep_cdouble* hUx, const int32_t* h_perm_r, const int32_t* h_perm_c,
+                          nep_lu** out) {
+    return lu_create_any(n, 1, hLp, hLi, hLx, hUp, hUi, hUx, h_perm_r, h_perm_c, out);
+}
+
+int32_t nep_lu_refactor(nep_lu* lu, const nep_cdouble* hLx, const nep_cdouble* hUx) {
+    ARGCHK(lu && hLx && hUx);
+    if (!lu->ml) { nep_set_error("nep_lu_refactor needs the block schedule (this handle uses the level schedule)"); return NEP_ERR_UNSUPPORTED; }
+    return ml_refactor(lu->ml, hLx, hUx);
+}
+
+int32_t nep_lu_set_row_scale(nep_lu* lu, const double* h_rs) {
+    ARGCHK(lu != nullptr);
+    if (!lu->ml) { nep_set_error("nep_lu_set_row_scale needs the block schedule"); return NEP_ERR_UNSUPPORTED; }
+    return ml_set_row_scale(lu->ml, h_rs);
+}
+
+int32_t nep_lu_analyze(int64_t n, int32_t csc, const int32_t* hLp, const int32_t* hLi, const int32_t* hUp, const int32_t* hUi,
+                       int64_t out[8]) {
+    ARGCHK(n > 0 && n < ((int64_t)1 << 31) && hLp && hLi && hUp && hUi && out);
+    ARGCHK(hLp[0] == 0 && hUp[0] == 0);
+    for (int64_t e = 0; e < hLp[n]; ++e) ARGCHK(hLi[e] >= 0 && hLi[e] < n);
+    for (int64_t e = 0; e < hUp[n]; ++e) ARGCHK(hUi[e] >= 0 && hUi[e] < n);
+    return ml_analyze(n, csc, hLp, hLi, hUp, hUi, out);
+}
+
+int32_t nep_lu_is_block_schedule(const nep_lu* lu, int32_t* out) {
+    ARGCHK(lu && out);
+    *out = lu->ml ? 1 : 0;
     return NEP_OK;
 }
 
 int32_t nep_lu_info(const nep_lu* lu, int64_t info[6]) {
     ARGCHK(lu && info);
+    if (lu->ml) { ml_info(lu->ml, info, nullptr); return NEP_OK; }
     info[0] = lu->n; info[1] = lu->nnzL_in; info[2] = lu->nnzU_in;
     // levels actually traversed per solve (head levels; the dense tail counts as one step each way)
     info[3] = lu->L11.nlev + lu->nblk + (lu->T ? 1 : 0); info[4] = lu->U11.nlev + lu->nblk + (lu->T ? 1 : 0);
@@ -950,6 +1045,7 @@ int32_t nep_lu_info(const nep_lu* lu, int64_t info[6]) {
  * out[6]=rows of the blocked mid region, out[7]=its block size */
 int32_t nep_lu_schedule(const nep_lu* lu, int64_t out[8]) {
     ARGCHK(lu && out);
+    if (lu->ml) { ml_info(lu->ml, nullptr, out); return NEP_OK; }
     out[0] = lu->T; out[1] = lu->launches; out[2] = lu->levL_full; out[3] = lu->levU_full;
     int64_t w = 0, nn = 0;
     for (const Seg& s : lu->L11.segs) (s.wide ? w : nn)++;
@@ -993,6 +1089,8 @@ int32_t nep_lu_solve_add(nep_lu* lu, int32_t nrhs, const nep_cdouble* dB, int64_
     ARGCHK(nrhs >= 1 && nrhs <= 65535 && ldb >= lu->n && ldx >= lu->n);
     ARGCHK(dAdd == nullptr || ldadd >= lu->n);
     hipStream_t st = as_stream(stream);
+    if (lu->ml) return ml_solve(lu->ml, nrhs, dB, ldb, dAdd, ldadd, dX, ldx, scale, st);
+    lu->last = st; lu->used = true;
     const int64_t n = lu->n, T = lu->T;
     int rc = lu->work.ensure((size_t)(2 * n - lu->h0) * nrhs * sizeof(cplx));
     if (rc) return rc;

@@ -1,0 +1,18 @@
+// K5 elimination-tree block schedule (trsv_ml.hip): internal interface used by the C ABI in trsv.hip
+#pragma once
+#include "common.h"
+
+struct MLFactor;
+
+// csc = 0: L and U in CSR; 1: in CSC.  NEP_ERR_UNSUPPORTED: the factors do not fit the block schedule (caller falls back
+// to the level schedule).
+int ml_create(int64_t n, int csc, const int32_t* Lp, const int32_t* Li, const nep_cdouble* Lx, const int32_t* Up,
+              const int32_t* Ui, const nep_cdouble* Ux, const int32_t* perm_r, const int32_t* perm_c, int expected_solves,
+              MLFactor** out);
+int ml_analyze(int64_t n, int csc, const int32_t* Lp, const int32_t* Li, const int32_t* Up, const int32_t* Ui, int64_t out[8]);
+int ml_refactor(MLFactor* F, const nep_cdouble* Lx, const nep_cdouble* Ux);
+int ml_set_row_scale(MLFactor* F, const double* h_rs);
+void ml_destroy(MLFactor* F);
+void ml_info(const MLFactor* F, int64_t info[6], int64_t sched[8]);
+int ml_solve(MLFactor* F, int nrhs, const nep_cdouble* dB, int64_t ldb, const nep_cdouble* dAdd, int64_t ldadd,
+             nep_cdouble* dX, int64_t ldx, double scale, hipStream_t st);

@@ -1,0 +1,1186 @@
+// libnepmi355: K5 fixed-shift solve, elimination-tree block schedule (gfx950).
+//
+// Replaces the dependent level sweep of a sparse triangular solve (gun: 515 levels per factor; src/LinSolvers.jl:125-137,
+// `Afact \ x`) by a handful of bandwidth-bound launches.  Pr*A*Pc = L*U comes from the host (one-off per shift,
+// src/LinSolvers.jl:114-116).  Symbolic part, once per sparsity pattern (cached, see MLCache):
+//
+//   1. elimination tree of the symmetrised pattern struct(L) + struct(U)^T (Liu's algorithm): every dependency of the
+//      forward and of the backward substitution points from a node to one of its ancestors;
+//   2. multilevel partition of the tree: level 0 = the maximal subtrees with at most `bmax` nodes, level 1 = the maximal
+//      subtrees of what is left, ... (gun, n = 9956, bmax = 256: 51 + 10 + 2 + 1 blocks in 4 levels).  Blocks of one
+//      level are independent of each other and depend on earlier levels only (L) / later levels only (U);
+//   3. a symmetric permutation that makes every block a contiguous row range, levels in order.
+//
+// Numeric part, per factorisation: the diagonal blocks L_BB, U_BB (at most bmax x bmax, sparse) are inverted explicitly on
+// the device (k_ml_inverse: one workgroup per column, x in LDS, in-block level schedule) and stored as packed dense
+// triangular rows; everything outside the diagonal blocks stays sparse ("coupling" CSR).  One solve is then, per level,
+//
+//      L:  y_B = inv(L_BB) (b_B - L[B, earlier] y)          U:  x_B = inv(U_BB) (y_B - U[B, later] x)
+//
+// i.e. ONE launch per level and factor (k_ml_level; the coupling product is formed redundantly per row chunk in LDS) or
+// two when the coupling rows are long (k_ml_coupling + k_ml_level<MODE 1>).  The input permutation is folded into the
+// first launch and the output permutation / scaling / refinement update into the last one.  Dependent steps per solve:
+// gun 23 launches (0.139 ms) -> 2 * nlev (+ split levels).
+#include "common.h"
+#include "trsv_ml.h"
+#include <vector>
+#include <algorithm>
+#include <mutex>
+#include <list>
+#include <chrono>
+#include <cstring>
+
+#define ML_BMAX 256            // largest diagonal block (rows): LDS staging of the fused level kernel is sized for it
+
+struct MLChunk { int32_t a, b, s, e; int64_t ipa; };   // rows [a,b) of the block with rows [s,e); ipa = offset of row a's packed inverse row
+
+struct MLFacSym {
+    // device, symbolic
+    int32_t* d_cp = nullptr;       // n+1  coupling CSR (new row order; columns in new numbering)
+    int32_t* d_ci = nullptr;
+    int64_t* d_ip = nullptr;       // n+1  offsets of the packed inverse rows
+    int32_t* d_bp = nullptr;       // n+1  in-block CSR over slots (rows of a block sorted by in-block level)
+    int32_t* d_bi = nullptr;       //      local column (col - block start)
+    int32_t* d_slotrow = nullptr;  // n    slot -> local row
+    int32_t* d_lvp = nullptr;      //      in-block level pointers (slot positions), block k: [lvo[k], lvo[k+1])
+    int32_t* d_lvo = nullptr;      // nblk+1
+    // host
+    std::vector<int32_t> map;      // input entry -> slot*4 + kind   (kind 0 skip, 1 coupling, 2 in-block, 3 diagonal)
+    int64_t ncoup = 0, nin = 0, ninv = 0;
+    MLChunk* d_chunks = nullptr;   // row chunks of the level kernels (chunk size depends on the level's mode)
+    std::vector<int32_t> lev_chunk;    // nlev+1
+    std::vector<int> lev_ch;       // per level: rows per chunk (4, 16 or 32)
+    std::vector<uint8_t> split;    // per level: coupling product as its own launch
+    std::vector<int> cpl_lanes;    // per level: lanes per row of that launch (8, 64, 256)
+    std::vector<int64_t> lev_coup; // per level: coupling non-zeros
+};
+
+struct MLSym {
+    int64_t n = 0;
+    int nlev = 0, nblk = 0;
+    std::vector<int32_t> lev_row, lev_blk;       // nlev+1 each: row / block range of a level
+    int32_t* d_blk_se = nullptr;   // 2*nblk
+    int32_t* d_rowblk = nullptr;   // n
+    int32_t* d_pin = nullptr;      // n: new row q reads b[pin[q]]
+    int32_t* d_pout = nullptr;     // n: new row q writes X[pout[q]]
+    MLFacSym L, U;
+    uint64_t key0 = 0, key1 = 0;
+    int64_t nnzL = 0, nnzU = 0;
+    int refs = 0;
+    int csc = 0;
+    int max_block = 0;
+    double t_build_ms = 0.0;
+};
+
+struct MLFactor {
+    MLSym* sym = nullptr;
+    cplx* d_vals = nullptr;        // [cxL | bxL | cxU | bxU | diagU]
+    cplx* d_ixL = nullptr;
+    cplx* d_ixU = nullptr;
+    cplx* d_Sinv = nullptr;        // apex: dense row-major inverse of the rows of levels >= apex_la (0 = no apex)
+    int apex_la = 0;
+    double* d_rscale = nullptr;    // optional row scaling (UMFPACK's Rs): b is multiplied by it on the way in
+    NepScratch work;               // bw | y | x | tmp, each n*nrhs
+    hipEvent_t ready = nullptr;    // numeric build complete (recorded on the build stream)
+    hipStream_t synced = nullptr;  // stream that has already waited for `ready`
+    bool synced_valid = false;
+    hipStream_t last = nullptr;    // stream of the last solve (frees are ordered behind it)
+    bool used = false;
+    hipGraphExec_t graph = nullptr;
+    int graph_nrhs = 0; void* graph_work = nullptr;
+    hipStream_t cap_stream = nullptr;
+    int use_graph = 1;
+    int launches = 0;
+    void* pinned = nullptr; size_t pinned_cap = 0;
+};
+
+static double ml_now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+__device__ __forceinline__ cplx ml_cdiv(cplx a, cplx b) {
+    if (fabs(b.x) >= fabs(b.y)) {
+        const double r = b.y / b.x, d = b.x + b.y * r;
+        return cmake((a.x + a.y * r) / d, (a.y - a.x * r) / d);
+    } else {
+        const double r = b.x / b.y, d = b.x * r + b.y;
+        return cmake((a.x * r + a.y) / d, (a.y * r - a.x) / d);
+    }
+}
+
+// ---- numeric set-up: column j of inv(L_BB) / inv(U_BB) for every diagonal block --------------------------------------
+// grid.x = n (one workgroup per column of the block-diagonal inverse), 16 lanes per row, x in LDS
+template <bool UPPER>
+__global__ __launch_bounds__(256) void k_ml_inverse(const int32_t* __restrict__ rowblk, const int32_t* __restrict__ blk_se,
+                                                    const int32_t* __restrict__ lvo, const int32_t* __restrict__ lvp,
+                                                    const int32_t* __restrict__ slotrow, const int32_t* __restrict__ bp,
+                                                    const int32_t* __restrict__ bi, const cplx* __restrict__ bx,
+                                                    const cplx* __restrict__ diag, const int64_t* __restrict__ ip,
+                                                    cplx* __restrict__ ix) {
+    __shared__ cplx x[ML_BMAX];
+    const int q = blockIdx.x;
+    const int k = rowblk[q];
+    const int s = blk_se[2 * k], e = blk_se[2 * k + 1];
+    const int j = q - s, bsz = e - s;
+    for (int t = threadIdx.x; t < bsz; t += 256) x[t] = cmake(t == j ? 1.0 : 0.0, 0.0);
+    __syncthreads();
+    const int l0 = lvo[k], nlev = lvo[k + 1] - l0 - 1;
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    for (int lev = UPPER ? 0 : 1; lev < nlev; ++lev) {          // level 0 of a unit-lower block needs no work
+        const int s0 = lvp[l0 + lev], s1 = lvp[l0 + lev + 1];
+        for (int sl0 = s0; sl0 < s1; sl0 += 16) {
+            const int sl = sl0 + grp;
+            int i = -1;
+            cplx acc = cmake(0.0, 0.0);
+            if (sl < s1) {
+                i = slotrow[sl];
+                if (UPPER ? (i <= j) : (i > j)) {               // the other rows of the column stay zero
+                    const int e1 = bp[sl + 1];
+                    for (int p = bp[sl] + sub; p < e1; p += 16) cfma(acc, bx[p], x[bi[p]]);
+                } else i = -1;
+            }
+            acc = group_reduce_sum<16>(acc);
+            if (i >= 0 && sub == 0) x[i] = UPPER ? ml_cdiv(csub(x[i], acc), diag[s + i]) : csub(x[i], acc);
+        }
+        __syncthreads();
+    }
+    if (UPPER) { for (int t = threadIdx.x; t <= j; t += 256) ix[ip[s + t] + (j - t)] = x[t]; }
+    else       { for (int t = j + threadIdx.x; t < bsz; t += 256) ix[ip[s + t] + j] = x[t]; }
+}
+
+// ---- solve kernels ------------------------------------------------------------------------------------------------
+struct MLArgs {
+    const MLChunk* chunks; int nchunks;
+    const int32_t* cp; const int32_t* ci; const cplx* cx;          // coupling CSR
+    const cplx* ix;                                                // packed inverse rows (offsets in the chunk records)
+    int has_coupling;
+    const cplx* src; int64_t ldsrc; const int32_t* gat; const double* rs;   // right-hand side of the level: [rs]*src[gat[c]]
+    int ident_row0;                                                // >= 0: the right-hand sides are unit vectors, rhs j = e_(ident_row0 + j)
+    int col_lo;                                                    // coupling entries with column < col_lo are skipped (apex build)
+    const cplx* xin; int64_t ldxin;                                // solved rows of the other levels
+    cplx* xout; int64_t ldxout;
+    const cplx* tmp; int64_t ldtmp;                                // MODE 1: r precomputed by k_ml_coupling
+    cplx* outX; int64_t ldX; const int32_t* pout; double scale; const cplx* add; int64_t ldadd;   // final output (optional)
+    // side job of extra workgroups, rows [side_lo, side_hi): LOWER copies the right-hand side of the other levels into
+    // side_dst (new order); UPPER scatters the finished rows of the other levels (side_src) to outX
+    int64_t side_lo, side_hi; cplx* side_dst; int64_t ldside; const cplx* side_src; int64_t ldsidesrc;
+    int nrhs;
+};
+
+// G2 lanes per row, CH = 256 / G2 rows per chunk: all rows of a chunk are processed concurrently
+template <bool UPPER, int RB, int MODE, int G2>
+__global__ __launch_bounds__(256) void k_ml_level(const MLArgs A) {
+    const int rhs0 = blockIdx.y * RB;
+    const int nb = min(RB, A.nrhs - rhs0);
+    if ((int)blockIdx.x >= A.nchunks) {                            // ---- side job
+        const int64_t q = A.side_lo + ((int64_t)blockIdx.x - A.nchunks) * 256 + threadIdx.x;
+        if (q < A.side_hi) {
+            if (!UPPER) {
+                const int64_t g = A.gat ? A.gat[q] : q;
+                const double sc = A.rs ? A.rs[g] : 1.0;
+                for (int r = 0; r < nb; ++r) {
+                    const cplx v = A.src[(int64_t)(rhs0 + r) * A.ldsrc + g];
+                    A.side_dst[(int64_t)(rhs0 + r) * A.ldside + q] = cmake(sc * v.x, sc * v.y);
+                }
+            } else {
+                const int64_t g = A.pout ? A.pout[q] : q;
+                for (int r = 0; r < nb; ++r) {
+                    cplx v = A.side_src[(int64_t)(rhs0 + r) * A.ldsidesrc + q];
+                    if (A.add) { const cplx ad = A.add[(int64_t)(rhs0 + r) * A.ldadd + g]; v.x += ad.x; v.y += ad.y; }
+                    A.outX[(int64_t)(rhs0 + r) * A.ldX + g] = cmake(A.scale * v.x, A.scale * v.y);
+                }
+            }
+        }
+        return;
+    }
+    __shared__ cplx rbuf[MODE == 0 ? RB * ML_BMAX : 1];
+    const MLChunk ch = A.chunks[blockIdx.x];
+    const int base = UPPER ? ch.a : ch.s;                           // first row whose r is needed
+    if (MODE == 0) {
+        // r_c = rhs_c - C[c,:] xin for the rows the chunk's dot products read: one thread per row (at most ML_BMAX rows;
+        // levels whose coupling rows are long run the product as its own launch instead, MODE 1)
+        const int cnt = UPPER ? ch.e - ch.a : ch.b - ch.s;
+        const int t = threadIdx.x;
+        if (t < cnt) {
+            const int c = base + t;
+            cplx acc[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] = cmake(0.0, 0.0);
+            if (A.has_coupling) {
+                const int e1 = A.cp[c + 1];
+                for (int p = A.cp[c]; p < e1; ++p) {
+                    const cplx v = A.cx[p];
+                    const int64_t col = A.ci[p];
+                    if (col < A.col_lo) continue;
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+                        if (r < nb) cfma(acc[r], v, A.xin[(int64_t)(rhs0 + r) * A.ldxin + col]);
+                }
+            }
+            const int64_t g = A.gat ? A.gat[c] : c;
+            const double sc = A.rs ? A.rs[g] : 1.0;
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (r < nb) {
+                    const cplx v = A.ident_row0 >= 0 ? cmake(c - A.ident_row0 == rhs0 + r ? 1.0 : 0.0, 0.0)
+                                                     : A.src[(int64_t)(rhs0 + r) * A.ldsrc + g];
+                    rbuf[r * ML_BMAX + t] = cmake(sc * v.x - acc[r].x, sc * v.y - acc[r].y);
+                }
+        }
+        __syncthreads();
+    }
+    const int sub = threadIdx.x % G2;
+    const int rho = ch.a + threadIdx.x / G2;
+    const bool live = rho < ch.b;
+    const int d = rho - ch.a;
+    // packed rows: LOWER row r holds columns [s, r], UPPER row r holds [r, e)
+    const int len = !live ? 0 : (UPPER ? ch.e - rho : rho - ch.s + 1);
+    const int c0 = UPPER ? rho : ch.s;
+    const int64_t off = UPPER ? ch.ipa + (int64_t)d * (ch.e - ch.a) - (int64_t)d * (d - 1) / 2
+                              : ch.ipa + (int64_t)d * (ch.a - ch.s + 1) + (int64_t)d * (d - 1) / 2;
+    const cplx* row = A.ix + off;
+    cplx acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = cmake(0.0, 0.0);
+    for (int t = sub; t < len; t += G2) {
+        const cplx m = row[t];
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+            if (r < nb) {
+                const cplx rv = MODE == 0 ? rbuf[r * ML_BMAX + (c0 - base) + t]
+                                          : A.tmp[(int64_t)(rhs0 + r) * A.ldtmp + c0 + t];
+                cfma(acc[r], m, rv);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = group_reduce_sum<G2>(acc[r]);
+    if (live && sub == 0) {
+        for (int r = 0; r < nb; ++r) {
+            A.xout[(int64_t)(rhs0 + r) * A.ldxout + rho] = acc[r];
+            if (UPPER && A.outX) {
+                const int64_t g = A.pout ? A.pout[rho] : rho;
+                cplx v = acc[r];
+                if (A.add) { const cplx ad = A.add[(int64_t)(rhs0 + r) * A.ldadd + g]; v.x += ad.x; v.y += ad.y; }
+                A.outX[(int64_t)(rhs0 + r) * A.ldX + g] = cmake(A.scale * v.x, A.scale * v.y);
+            }
+        }
+    }
+}
+
+// tmp[q] = src[q] - sum_{col_lo <= col < col_hi} C[q,col] xin[col]   for the rows [r0, r1) of one level; G lanes per row
+// (G = 256: one workgroup per row); ident_row0 >= 0: src is the identity block (rhs j = e_(ident_row0 + j))
+template <int G, int RB>
+__global__ __launch_bounds__(256) void k_ml_coupling(int r0, int r1, const int32_t* __restrict__ cp,
+                                                     const int32_t* __restrict__ ci, const cplx* __restrict__ cx,
+                                                     const cplx* __restrict__ src, int64_t ldsrc,
+                                                     const cplx* __restrict__ xin, int64_t ldxin, cplx* __restrict__ tmp,
+                                                     int64_t ldtmp, int nrhs, int col_lo, int col_hi, int ident_row0) {
+    constexpr int GG = G == 256 ? 64 : G;
+    constexpr int RPB = G == 256 ? 1 : 256 / G;
+    const int rhs0 = blockIdx.y * RB;
+    const int nb = min(RB, nrhs - rhs0);
+    const int sub = G == 256 ? threadIdx.x : (threadIdx.x % GG);
+    const int q = r0 + blockIdx.x * RPB + (G == 256 ? 0 : threadIdx.x / GG);
+    cplx acc[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = cmake(0.0, 0.0);
+    if (q < r1) {
+        const int e1 = cp[q + 1];
+        for (int p = cp[q] + sub; p < e1; p += G) {
+            const int col = ci[p];
+            if (col < col_lo || col >= col_hi) continue;
+            const cplx v = cx[p];
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (r < nb) cfma(acc[r], v, xin[(int64_t)(rhs0 + r) * ldxin + col]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) acc[r] = group_reduce_sum<GG>(acc[r]);
+    if (G == 256) {
+        __shared__ cplx part[4][RB];
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0)
+            for (int r = 0; r < RB; ++r) part[wv][r] = acc[r];
+        __syncthreads();
+        if (threadIdx.x < nb && q < r1) {
+            const int r = threadIdx.x;
+            cplx a = part[0][r];
+            for (int w = 1; w < 4; ++w) { a.x += part[w][r].x; a.y += part[w][r].y; }
+            const cplx v = ident_row0 >= 0 ? cmake(q - ident_row0 == rhs0 + r ? 1.0 : 0.0, 0.0) : src[(int64_t)(rhs0 + r) * ldsrc + q];
+            tmp[(int64_t)(rhs0 + r) * ldtmp + q] = csub(v, a);
+        }
+    } else if (q < r1 && sub == 0) {
+        for (int r = 0; r < nb; ++r) {
+            const cplx v = ident_row0 >= 0 ? cmake(q - ident_row0 == rhs0 + r ? 1.0 : 0.0, 0.0) : src[(int64_t)(rhs0 + r) * ldsrc + q];
+            tmp[(int64_t)(rhs0 + r) * ldtmp + q] = csub(v, acc[r]);
+        }
+    }
+}
+
+// ---- apex: the last levels as ONE dense inverse S^{-1} = inv(U_TT) inv(L_TT) (T x T, row-major) ---------------------------
+// out (row-major T x T) = transpose of the column-major block `in` (ld = T)
+__global__ __launch_bounds__(256) void k_apex_transpose(int T, const cplx* __restrict__ in, cplx* __restrict__ out) {
+    __shared__ cplx tile[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int r = blockIdx.x * 16 + tx, c = blockIdx.y * 16 + ty;        // in[(c)*T + r]: r fastest
+    if (r < T && c < T) tile[ty][tx] = in[(int64_t)c * T + r];
+    __syncthreads();
+    const int c2 = blockIdx.y * 16 + tx, r2 = blockIdx.x * 16 + ty;
+    if (r2 < T && c2 < T) out[(int64_t)r2 * T + c2] = tile[tx][ty];
+}
+// x[R0 + r] = sum_c Sinv[r, c] t[R0 + c]: wave per row, RB right-hand sides share one pass over the row
+template <int RB>
+__global__ __launch_bounds__(256) void k_apex_gemv(int T, int R0, const cplx* __restrict__ Sinv, const cplx* __restrict__ t,
+                                                   int64_t ldt, cplx* __restrict__ x, int64_t ldx, int nrhs) {
+    const int rhs0 = blockIdx.y * RB;
+    const int nb = min(RB, nrhs - rhs0);
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= T) return;
+    const cplx* row = Sinv + (int64_t)r * T;
+    cplx acc[RB];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) acc[q] = cmake(0.0, 0.0);
+#pragma unroll 4
+    for (int c = lane; c < T; c += 64) {
+        const cplx m = row[c];
+#pragma unroll
+        for (int q = 0; q < RB; ++q)
+            if (q < nb) cfma(acc[q], m, t[(int64_t)(rhs0 + q) * ldt + R0 + c]);
+    }
+#pragma unroll
+    for (int q = 0; q < RB; ++q) {
+        const cplx a = group_reduce_sum<64>(acc[q]);
+        if (lane == 0 && q < nb) x[(int64_t)(rhs0 + q) * ldx + R0 + r] = a;
+    }
+}
+
+// =====================================================================================================================
+// host side
+// =====================================================================================================================
+namespace {
+
+struct PinnedPool {           // pinned staging buffers for the value upload (hipHostMalloc costs ~1 ms per call)
+    struct Buf { void* p; size_t cap; hipEvent_t ev; bool busy; };
+    std::mutex mu;
+    std::vector<Buf> bufs;
+    int acquire(size_t bytes, int* idx) {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < bufs.size(); ++i) {
+            Buf& b = bufs[i];
+            if (!b.busy && b.cap >= bytes && b.cap <= 2 * bytes + (1 << 20)) {
+                if (b.ev && hipEventQuery(b.ev) != hipSuccess) continue;
+                b.busy = true; *idx = (int)i; return NEP_OK;
+            }
+        }
+        Buf nb; nb.p = nullptr; nb.cap = bytes + bytes / 8 + 4096; nb.ev = nullptr; nb.busy = true;
+        HIPCHK(hipHostMalloc(&nb.p, nb.cap, hipHostMallocDefault));
+        HIPCHK(hipEventCreateWithFlags(&nb.ev, hipEventDisableTiming));
+        if (bufs.size() >= 24) {                  // bounded: drop an idle one
+            for (size_t i = 0; i < bufs.size(); ++i)
+                if (!bufs[i].busy && (!bufs[i].ev || hipEventQuery(bufs[i].ev) == hipSuccess)) {
+                    (void)hipHostFree(bufs[i].p); (void)hipEventDestroy(bufs[i].ev);
+                    bufs[i] = nb; *idx = (int)i; return NEP_OK;
+                }
+        }
+        bufs.push_back(nb); *idx = (int)bufs.size() - 1;
+        return NEP_OK;
+    }
+    void* ptr(int idx) { std::lock_guard<std::mutex> lk(mu); return bufs[idx].p; }
+    void release(int idx, hipStream_t st) {       // reusable once the copies enqueued on st have completed
+        std::lock_guard<std::mutex> lk(mu);
+        (void)hipEventRecord(bufs[idx].ev, st);
+        bufs[idx].busy = false;
+    }
+};
+PinnedPool g_pinned;
+
+struct BuildStreams {          // a fixed set of non-blocking streams for the numeric builds (never destroyed: process-wide)
+    std::mutex mu; hipStream_t st[4] = {nullptr, nullptr, nullptr, nullptr}; unsigned next = 0;
+    hipStream_t get() {
+        std::lock_guard<std::mutex> lk(mu);
+        const unsigned i = next++ % 4;
+        if (!st[i] && hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) st[i] = nullptr;
+        return st[i];
+    }
+};
+BuildStreams g_bstreams;
+
+std::mutex g_cache_mu;
+std::list<MLSym*> g_cache;       // most recently used first
+const size_t ML_CACHE_MAX = 8;
+
+void hash_words(uint64_t& h0, uint64_t& h1, const void* p, size_t bytes) {
+    const uint8_t* b = (const uint8_t*)p;
+    size_t i = 0;
+    for (; i + 8 <= bytes; i += 8) {
+        uint64_t w; memcpy(&w, b + i, 8);
+        h0 = (h0 ^ w) * 0x9E3779B97F4A7C15ull; h0 ^= h0 >> 29;
+        h1 = (h1 + w) * 0xC2B2AE3D27D4EB4Full; h1 ^= h1 >> 31;
+    }
+    uint64_t w = 0;
+    if (i < bytes) memcpy(&w, b + i, bytes - i);
+    h0 = (h0 ^ w ^ bytes) * 0x9E3779B97F4A7C15ull;
+    h1 = (h1 + w + bytes) * 0xC2B2AE3D27D4EB4Full;
+}
+
+thread_local bool g_ml_dry = false;     // ml_analyze: host analysis only, nothing is uploaded
+
+template <class T>
+int up(T** d, const std::vector<T>& h, size_t min_count = 1) {
+    if (g_ml_dry) { *d = nullptr; return NEP_OK; }
+    const size_t cnt = std::max(h.size(), min_count);
+    int rc = nep_pool_alloc((void**)d, cnt * sizeof(T));
+    if (rc) return rc;
+    if (!h.empty()) HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return NEP_OK;
+}
+
+void free_fac(MLFacSym& f) {
+    nep_pool_free(f.d_cp); nep_pool_free(f.d_ci); nep_pool_free(f.d_ip); nep_pool_free(f.d_bp); nep_pool_free(f.d_bi);
+    nep_pool_free(f.d_slotrow); nep_pool_free(f.d_lvp); nep_pool_free(f.d_lvo); nep_pool_free(f.d_chunks);
+}
+void free_sym(MLSym* s) {
+    if (!s) return;
+    free_fac(s->L); free_fac(s->U);
+    nep_pool_free(s->d_blk_se); nep_pool_free(s->d_rowblk);
+    nep_pool_free(s->d_pin); nep_pool_free(s->d_pout);
+    delete s;
+}
+
+// CSR pattern (rowptr, colidx) + source index of every entry in the caller's arrays, from a CSC pattern
+void transpose_pattern(int64_t n, const int32_t* cp, const int32_t* ri, std::vector<int32_t>& rp, std::vector<int32_t>& ci,
+                       std::vector<int32_t>* srcidx) {
+    const int64_t nnz = cp[n];
+    rp.assign(n + 1, 0);
+    for (int64_t e = 0; e < nnz; ++e) rp[ri[e] + 1]++;
+    for (int64_t i = 0; i < n; ++i) rp[i + 1] += rp[i];
+    ci.resize(nnz);
+    if (srcidx) srcidx->resize(nnz);
+    std::vector<int32_t> pos(rp.begin(), rp.end() - 1);
+    for (int64_t c = 0; c < n; ++c)
+        for (int32_t e = cp[c]; e < cp[c + 1]; ++e) {
+            const int32_t q = pos[ri[e]]++;
+            ci[q] = (int32_t)c;
+            if (srcidx) (*srcidx)[q] = e;
+        }
+}
+
+int bmax_env() { const char* e = getenv("NEP_ML_BMAX"); const int v = e ? atoi(e) : -1; return (v >= 8 && v <= ML_BMAX) ? v : -1; }
+int bmax_of_level(int lev, int64_t n, int forced) {
+    if (forced > 0) return forced;
+    if (n > 200000 && lev == 0) return 64;          // most rows sit in level 0: 16*b/2 bytes of inverse per row
+    if (n > 200000 && lev == 1) return 128;
+    return ML_BMAX;
+}
+
+// one triangular factor in the new order.  rp/ci: CSR pattern in the ORIGINAL factor numbering, src: index of each CSR
+// entry in the caller's value array (nullptr = identity)
+int build_factor(const MLSym& S, bool upper, const int32_t* rp, const int32_t* ci, const int32_t* src,
+                 const std::vector<int32_t>& newpos, const std::vector<int32_t>& oldof, const std::vector<int32_t>& rowblk,
+                 const std::vector<int32_t>& blk_se, const std::vector<int32_t>& rowlev, MLFacSym& F) {
+    const int64_t n = S.n;
+    const int64_t nnz = rp[n];
+    F.map.assign(nnz, 0);
+    std::vector<int32_t> cp(n + 1, 0), bcnt(n + 1, 0), lvl_in(n, 0);
+    // pass 1: classify, count, in-block levels
+    auto classify = [&](int64_t q, int32_t c, int& kind) -> int {
+        if (c == q) { kind = upper ? 3 : 0; return NEP_OK; }
+        if (rowblk[c] == rowblk[q]) {
+            if (upper ? (c < q) : (c > q)) return NEP_ERR_ARG;
+            kind = 2; return NEP_OK;
+        }
+        if (upper ? (rowlev[c] <= rowlev[q]) : (rowlev[c] >= rowlev[q])) return NEP_ERR_ARG;
+        kind = 1; return NEP_OK;
+    };
+    int bad = 0;
+    auto row_pass1 = [&](int64_t q) {
+        const int32_t i = oldof[q];
+        int lv = 0, ncp = 0, nbk = 0;
+        for (int32_t e = rp[i]; e < rp[i + 1]; ++e) {
+            const int32_t c = newpos[ci[e]];
+            int kind = 0;
+            if (classify(q, c, kind)) { bad = 1; continue; }
+            if (kind == 1) ++ncp;
+            else if (kind == 2) { ++nbk; lv = std::max(lv, lvl_in[c] + 1); }
+        }
+        lvl_in[q] = lv; cp[q + 1] = ncp; bcnt[q + 1] = nbk;
+    };
+    if (!upper) for (int64_t q = 0; q < n; ++q) row_pass1(q);
+    else for (int64_t q = n - 1; q >= 0; --q) row_pass1(q);
+    if (bad) return NEP_ERR_ARG;
+    for (int64_t q = 0; q < n; ++q) cp[q + 1] += cp[q];
+    F.ncoup = cp[n];
+    // slots: rows of each block sorted by in-block level
+    std::vector<int32_t> slot_of(n), slotrow(n), lvo(S.nblk + 1, 0), lvp;
+    lvp.reserve(S.nblk * 8);
+    {
+        std::vector<int32_t> cnt;
+        for (int k = 0; k < S.nblk; ++k) {
+            const int32_t s = blk_se[2 * k], e = blk_se[2 * k + 1];
+            int nl = 0;
+            for (int32_t q = s; q < e; ++q) nl = std::max(nl, lvl_in[q] + 1);
+            cnt.assign(nl + 1, 0);
+            for (int32_t q = s; q < e; ++q) cnt[lvl_in[q] + 1]++;
+            for (int l = 0; l < nl; ++l) cnt[l + 1] += cnt[l];
+            lvo[k] = (int32_t)lvp.size();
+            for (int l = 0; l <= nl; ++l) lvp.push_back(s + cnt[l]);
+            for (int32_t q = s; q < e; ++q) { const int32_t sl = s + cnt[lvl_in[q]]++; slot_of[q] = sl; slotrow[sl] = q - s; }
+        }
+        lvo[S.nblk] = (int32_t)lvp.size();
+    }
+    std::vector<int32_t> bp(n + 1, 0);
+    for (int64_t q = 0; q < n; ++q) bp[slot_of[q] + 1] = bcnt[q + 1];
+    for (int64_t q = 0; q < n; ++q) bp[q + 1] += bp[q];
+    F.nin = bp[n];
+    std::vector<int64_t> ip(n + 1, 0);
+    for (int64_t q = 0; q < n; ++q) {
+        const int k = rowblk[q];
+        ip[q + 1] = ip[q] + (upper ? blk_se[2 * k + 1] - q : q - blk_se[2 * k] + 1);
+    }
+    F.ninv = ip[n];
+    // pass 2: fill
+    std::vector<int32_t> cci(std::max<int64_t>(F.ncoup, 1)), bi(std::max<int64_t>(F.nin, 1));
+    for (int64_t q = 0; q < n; ++q) {
+        const int32_t i = oldof[q];
+        int32_t pc = cp[q], pb = bp[slot_of[q]];
+        const int32_t s = blk_se[2 * rowblk[q]];
+        for (int32_t e = rp[i]; e < rp[i + 1]; ++e) {
+            const int32_t c = newpos[ci[e]];
+            const int32_t se = src ? src[e] : e;
+            if (c == q) { F.map[se] = upper ? (int32_t)(q * 4 + 3) : 0; continue; }
+            if (rowblk[c] == rowblk[q]) { bi[pb] = c - s; F.map[se] = pb * 4 + 2; ++pb; }
+            else { cci[pc] = c; F.map[se] = pc * 4 + 1; ++pc; }
+        }
+    }
+    if (F.ncoup >= ((int64_t)1 << 29) || F.nin >= ((int64_t)1 << 29)) { nep_set_error("factor too large for the 32-bit slot map"); return NEP_ERR_ARG; }
+    // per level: coupling non-zeros; whether the coupling product runs inside the level kernel (one thread per row, formed
+    // redundantly by every chunk of a block) or as its own launch; rows per chunk
+    F.split.assign(S.nlev, 0); F.cpl_lanes.assign(S.nlev, 8); F.lev_coup.assign(S.nlev, 0); F.lev_ch.assign(S.nlev, 4);
+    F.lev_chunk.assign(S.nlev + 1, 0);
+    std::vector<MLChunk> chunks;
+    const char* fs = getenv("NEP_ML_SPLIT");       // experiment knobs: 0 = always fused, 1 = always split; rows per chunk
+    int ch_env = 0;
+    if (const char* e = getenv("NEP_ML_CHUNK")) { const int v = atoi(e); if (v == 4 || v == 16 || v == 32) ch_env = v; }
+    for (int l = 0; l < S.nlev; ++l) {
+        const int32_t r0 = S.lev_row[l], r1 = S.lev_row[l + 1];
+        const int64_t nz = cp[r1] - cp[r0];
+        F.lev_coup[l] = nz;
+        const double avg = nz / (double)std::max(1, r1 - r0);
+        int32_t maxrow = 0;
+        for (int32_t q = r0; q < r1; ++q) maxrow = std::max(maxrow, cp[q + 1] - cp[q]);
+        F.cpl_lanes[l] = avg > 2048.0 ? 256 : (avg > 24.0 ? 64 : 8);
+        // fused: 16 rows per chunk (the chunk recomputes r for up to a whole block); split or no coupling: 4 rows per chunk
+        int64_t redundant = 0;
+        for (int k = S.lev_blk[l]; k < S.lev_blk[l + 1]; ++k) {
+            const int32_t s = blk_se[2 * k], e = blk_se[2 * k + 1];
+            const int64_t nch = (e - s + 15) / 16;
+            redundant += (int64_t)(cp[e] - cp[s]) * (nch + 1) / 2;
+        }
+        // measured on gun (U level 0: 10 non-zeros per row on average, 60 at most): fused 37 us (the thread with the longest
+        // row walks it alone, one dependent gather per entry) against 4.5 + 4.5 us for the two launches
+        bool split = nz > 0 && (maxrow > 8 || redundant > 1500000);
+        if (fs && nz > 0) split = atoi(fs) != 0;
+        F.split[l] = split ? 1 : 0;
+        int CH = (nz == 0 || split) ? 4 : 16;
+        if (ch_env) CH = ch_env;
+        F.lev_ch[l] = CH;
+        F.lev_chunk[l] = (int32_t)chunks.size();
+        for (int k = S.lev_blk[l]; k < S.lev_blk[l + 1]; ++k) {
+            const int32_t s = blk_se[2 * k], e = blk_se[2 * k + 1];
+            for (int32_t a = s; a < e; a += CH) chunks.push_back(MLChunk{a, std::min(a + CH, e), s, e, ip[a]});
+        }
+    }
+    F.lev_chunk[S.nlev] = (int32_t)chunks.size();
+    int rc;
+    if ((rc = up(&F.d_cp, cp))) return rc;
+    if ((rc = up(&F.d_ci, cci))) return rc;
+    if ((rc = up(&F.d_ip, ip))) return rc;
+    if ((rc = up(&F.d_bp, bp))) return rc;
+    if ((rc = up(&F.d_bi, bi))) return rc;
+    if ((rc = up(&F.d_slotrow, slotrow))) return rc;
+    if ((rc = up(&F.d_lvp, lvp))) return rc;
+    if ((rc = up(&F.d_lvo, lvo))) return rc;
+    if ((rc = up(&F.d_chunks, chunks))) return rc;
+    return NEP_OK;
+}
+
+// symbolic analysis.  Lrp/Lci and Urp/Uci: CSR patterns of L and U; UTp/UTi: CSR pattern of U^T (= CSC of U);
+// Lsrc/Usrc: source index per CSR entry (nullptr = identity)
+int build_symbolic(MLSym* S, int64_t n, const int32_t* Lrp, const int32_t* Lci, const int32_t* Lsrc, const int32_t* Urp,
+                   const int32_t* Uci, const int32_t* Usrc, const int32_t* UTp, const int32_t* UTi,
+                   const int32_t* perm_r, const int32_t* perm_c) {
+    S->n = n;
+    // ---- validate triangularity
+    for (int64_t i = 0; i < n; ++i) {
+        for (int32_t e = Lrp[i]; e < Lrp[i + 1]; ++e) {
+            if (Lci[e] < 0 || Lci[e] >= n) { nep_set_error("L: column out of range"); return NEP_ERR_ARG; }
+            if (Lci[e] > i) { nep_set_error("L is not lower triangular (row %lld col %d)", (long long)i, Lci[e]); return NEP_ERR_ARG; }
+        }
+        for (int32_t e = Urp[i]; e < Urp[i + 1]; ++e) {
+            if (Uci[e] < 0 || Uci[e] >= n) { nep_set_error("U: column out of range"); return NEP_ERR_ARG; }
+            if (Uci[e] < i) { nep_set_error("U is not upper triangular (row %lld col %d)", (long long)i, Uci[e]); return NEP_ERR_ARG; }
+        }
+    }
+    // ---- elimination tree of struct(L) + struct(U)^T (Liu, path compression)
+    std::vector<int32_t> parent(n, -1), anc(n, -1);
+    for (int64_t i = 0; i < n; ++i) {
+        for (int pass = 0; pass < 2; ++pass) {
+            const int32_t* P = pass ? UTp : Lrp; const int32_t* I = pass ? UTi : Lci;
+            for (int32_t e = P[i]; e < P[i + 1]; ++e) {
+                int32_t k = I[e];
+                while (k >= 0 && k < i) {
+                    const int32_t nx = anc[k];
+                    anc[k] = (int32_t)i;
+                    if (nx < 0) { parent[k] = (int32_t)i; break; }
+                    k = nx;
+                }
+            }
+        }
+    }
+    // ---- multilevel partition in ONE ascending pass: lvl[j] = level, rsz[j] = nodes of j's subtree in j's level
+    std::vector<int32_t> lvl(n, 0), rsz(n, 1), pmax(n, -1), psum(n, 0);
+    int nlev = 0;
+    const int forced_bmax = bmax_env();
+    for (int64_t j = 0; j < n; ++j) {
+        const int M = std::max(pmax[j], 0);
+        const int s = pmax[j] >= 0 ? psum[j] : 0;
+        if (s + 1 <= bmax_of_level(M, n, forced_bmax)) { lvl[j] = M; rsz[j] = s + 1; }
+        else { lvl[j] = M + 1; rsz[j] = 1; }
+        nlev = std::max(nlev, lvl[j] + 1);
+        const int32_t p = parent[j];
+        if (p >= 0) {
+            if (lvl[j] > pmax[p]) { pmax[p] = lvl[j]; psum[p] = rsz[j]; }
+            else if (lvl[j] == pmax[p]) psum[p] += rsz[j];
+        }
+    }
+    std::vector<int32_t> bid(n);
+    for (int64_t j = n - 1; j >= 0; --j) {
+        const int32_t p = parent[j];
+        bid[j] = (p >= 0 && lvl[p] == lvl[j]) ? bid[p] : (int32_t)j;
+    }
+    // ---- new order: levels in sequence, blocks of a level by root index, rows of a block by original index
+    S->nlev = nlev;
+    std::vector<int32_t> lev_nblk(nlev + 1, 0);
+    for (int64_t j = 0; j < n; ++j) if (bid[j] == j) lev_nblk[lvl[j] + 1]++;
+    for (int l = 0; l < nlev; ++l) lev_nblk[l + 1] += lev_nblk[l];
+    const int nblk = lev_nblk[nlev];
+    S->nblk = nblk;
+    std::vector<int32_t> blkid(n, -1), blk_root(nblk), pos(lev_nblk.begin(), lev_nblk.end() - 1);
+    for (int64_t j = 0; j < n; ++j) if (bid[j] == j) { const int k = pos[lvl[j]]++; blkid[j] = k; blk_root[k] = (int32_t)j; }
+    std::vector<int32_t> blk_se(2 * (size_t)nblk), fill(nblk, 0);
+    S->lev_row.assign(nlev + 1, 0);
+    {
+        int32_t cur = 0;
+        for (int l = 0; l < nlev; ++l) {
+            S->lev_row[l] = cur;
+            for (int k = lev_nblk[l]; k < lev_nblk[l + 1]; ++k) { blk_se[2 * k] = cur; cur += rsz[blk_root[k]]; blk_se[2 * k + 1] = cur; }
+        }
+        S->lev_row[nlev] = cur;
+        if (cur != n) { nep_set_error("internal: block sizes do not add up"); return NEP_ERR_ARG; }
+    }
+    std::vector<int32_t> newpos(n), oldof(n), rowblk(n), rowlev(n);
+    for (int64_t j = 0; j < n; ++j) {
+        const int k = blkid[bid[j]];
+        const int32_t q = blk_se[2 * k] + fill[k]++;
+        newpos[j] = q; oldof[q] = (int32_t)j; rowblk[q] = k; rowlev[q] = lvl[j];
+    }
+    S->lev_blk = lev_nblk;
+    for (int k = 0; k < nblk; ++k) S->max_block = std::max(S->max_block, blk_se[2 * k + 1] - blk_se[2 * k]);
+    // ---- permutations folded into the first and last launch
+    std::vector<int32_t> pin(n), pout(n);
+    {
+        std::vector<int32_t> ipr, ipc;
+        auto invert = [&](const int32_t* p, std::vector<int32_t>& ip) -> int {
+            ip.assign(n, -1);
+            for (int64_t i = 0; i < n; ++i) {
+                if (p[i] < 0 || p[i] >= n || ip[p[i]] >= 0) { nep_set_error("invalid permutation"); return NEP_ERR_ARG; }
+                ip[p[i]] = (int32_t)i;
+            }
+            return NEP_OK;
+        };
+        if (perm_r) { int rc = invert(perm_r, ipr); if (rc) return rc; }
+        if (perm_c) { int rc = invert(perm_c, ipc); if (rc) return rc; }
+        for (int64_t q = 0; q < n; ++q) {
+            pin[q] = perm_r ? ipr[oldof[q]] : oldof[q];        // (Pr b)[perm_r[i]] = b[i]
+            pout[q] = perm_c ? ipc[oldof[q]] : oldof[q];       // x[i] = y[perm_c[i]]
+        }
+    }
+    int rc;
+    if ((rc = up(&S->d_blk_se, blk_se))) return rc;
+    if ((rc = up(&S->d_rowblk, rowblk))) return rc;
+    if ((rc = up(&S->d_pin, pin))) return rc;
+    if ((rc = up(&S->d_pout, pout))) return rc;
+    rc = build_factor(*S, false, Lrp, Lci, Lsrc, newpos, oldof, rowblk, blk_se, rowlev, S->L);
+    if (rc == NEP_ERR_ARG) { nep_set_error("block schedule: L has a dependency outside the elimination tree"); return NEP_ERR_UNSUPPORTED; }
+    if (rc) return rc;
+    rc = build_factor(*S, true, Urp, Uci, Usrc, newpos, oldof, rowblk, blk_se, rowlev, S->U);
+    if (rc == NEP_ERR_ARG) { nep_set_error("block schedule: U has a dependency outside the elimination tree"); return NEP_ERR_UNSUPPORTED; }
+    return rc;
+}
+
+}  // namespace
+
+static int ml_build_apex(MLFactor* F, hipStream_t bst);
+static int choose_apex(const MLSym* S, int expected_solves);
+
+// ---- numeric part: gather the values into the schedule's order, upload, invert the diagonal blocks -----------------------
+static int ml_numeric(MLFactor* F, const nep_cdouble* Lx, const nep_cdouble* Ux) {
+    MLSym* S = F->sym;
+    const int64_t n = S->n;
+    const int64_t oL = 0, oLb = oL + S->L.ncoup, oU = oLb + S->L.nin, oUb = oU + S->U.ncoup, oD = oUb + S->U.nin;
+    const int64_t ntot = oD + n;
+    int pidx = -1;
+    int rc = g_pinned.acquire((size_t)ntot * sizeof(cplx), &pidx);
+    if (rc) return rc;
+    nep_cdouble* h = (nep_cdouble*)g_pinned.ptr(pidx);
+    for (int64_t q = 0; q < n; ++q) { h[oD + q].re = 0.0; h[oD + q].im = 0.0; }
+    {
+        const int32_t* m = S->L.map.data();
+        for (int64_t e = 0; e < S->nnzL; ++e) {
+            const int32_t v = m[e];
+            const int kind = v & 3;
+            if (kind == 1) h[oL + (v >> 2)] = Lx[e];
+            else if (kind == 2) h[oLb + (v >> 2)] = Lx[e];
+        }
+        m = S->U.map.data();
+        for (int64_t e = 0; e < S->nnzU; ++e) {
+            const int32_t v = m[e];
+            const int kind = v & 3;
+            if (kind == 1) h[oU + (v >> 2)] = Ux[e];
+            else if (kind == 2) h[oUb + (v >> 2)] = Ux[e];
+            else if (kind == 3) h[oD + (v >> 2)] = Ux[e];
+        }
+    }
+    for (int64_t q = 0; q < n; ++q)
+        if (h[oD + q].re == 0.0 && h[oD + q].im == 0.0) {
+            g_pinned.release(pidx, nullptr);
+            nep_set_error("U has a zero pivot (matrix is singular)");
+            return NEP_ERR_SINGULAR;
+        }
+    hipStream_t bst = g_bstreams.get();
+    if (!F->d_vals) {
+        if ((rc = nep_pool_alloc((void**)&F->d_vals, (size_t)ntot * sizeof(cplx)))) { g_pinned.release(pidx, nullptr); return rc; }
+        if ((rc = nep_pool_alloc((void**)&F->d_ixL, (size_t)std::max<int64_t>(S->L.ninv, 1) * sizeof(cplx)))) { g_pinned.release(pidx, nullptr); return rc; }
+        if ((rc = nep_pool_alloc((void**)&F->d_ixU, (size_t)std::max<int64_t>(S->U.ninv, 1) * sizeof(cplx)))) { g_pinned.release(pidx, nullptr); return rc; }
+        HIPCHK(hipEventCreateWithFlags(&F->ready, hipEventDisableTiming));
+    } else if (F->used && F->last != bst) {
+        // refactorisation: the solves in flight read the old values
+        hipEvent_t ev; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev, F->last));
+        HIPCHK(hipStreamWaitEvent(bst, ev, 0));
+        (void)hipEventDestroy(ev);
+    }
+    HIPCHK(hipMemcpyAsync(F->d_vals, h, (size_t)ntot * sizeof(cplx), hipMemcpyHostToDevice, bst));
+    g_pinned.release(pidx, bst);
+    hipLaunchKernelGGL((k_ml_inverse<false>), dim3((unsigned)n), dim3(256), 0, bst, (const int32_t*)S->d_rowblk,
+                       (const int32_t*)S->d_blk_se, (const int32_t*)S->L.d_lvo, (const int32_t*)S->L.d_lvp,
+                       (const int32_t*)S->L.d_slotrow, (const int32_t*)S->L.d_bp, (const int32_t*)S->L.d_bi,
+                       (const cplx*)(F->d_vals + oLb), (const cplx*)nullptr, (const int64_t*)S->L.d_ip, F->d_ixL);
+    LAUNCHCHK();
+    hipLaunchKernelGGL((k_ml_inverse<true>), dim3((unsigned)n), dim3(256), 0, bst, (const int32_t*)S->d_rowblk,
+                       (const int32_t*)S->d_blk_se, (const int32_t*)S->U.d_lvo, (const int32_t*)S->U.d_lvp,
+                       (const int32_t*)S->U.d_slotrow, (const int32_t*)S->U.d_bp, (const int32_t*)S->U.d_bi,
+                       (const cplx*)(F->d_vals + oUb), (const cplx*)(F->d_vals + oD), (const int64_t*)S->U.d_ip, F->d_ixU);
+    LAUNCHCHK();
+    if (F->apex_la > 0 && (rc = ml_build_apex(F, bst))) return rc;
+    HIPCHK(hipEventRecord(F->ready, bst));
+    F->synced_valid = false;
+    return NEP_OK;
+}
+
+static void sym_release(MLSym* s) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    if (--s->refs > 0) return;
+    // unreferenced patterns stay cached (LRU) up to ML_CACHE_MAX entries
+    size_t idle = 0;
+    for (MLSym* t : g_cache) if (t->refs == 0) ++idle;
+    while (idle > ML_CACHE_MAX) {
+        for (auto it = g_cache.rbegin(); it != g_cache.rend(); ++it)
+            if ((*it)->refs == 0) { MLSym* dead = *it; g_cache.erase(std::next(it).base()); free_sym(dead); --idle; break; }
+    }
+}
+
+int ml_create(int64_t n, int csc, const int32_t* Lp, const int32_t* Li, const nep_cdouble* Lx, const int32_t* Up,
+              const int32_t* Ui, const nep_cdouble* Ux, const int32_t* perm_r, const int32_t* perm_c, int expected_solves,
+              MLFactor** out) {
+    *out = nullptr;
+    const bool timing = getenv("NEP_TIMING") != nullptr;
+    const double t0 = ml_now_ms();
+    uint64_t h0 = 0x243F6A8885A308D3ull ^ (uint64_t)n, h1 = 0x13198A2E03707344ull + (uint64_t)csc;
+    hash_words(h0, h1, Lp, (size_t)(n + 1) * 4); hash_words(h0, h1, Li, (size_t)Lp[n] * 4);
+    hash_words(h0, h1, Up, (size_t)(n + 1) * 4); hash_words(h0, h1, Ui, (size_t)Up[n] * 4);
+    if (perm_r) hash_words(h0, h1, perm_r, (size_t)n * 4);
+    if (perm_c) hash_words(h0, h1, perm_c, (size_t)n * 4);
+    h1 += (perm_r ? 1 : 0) + (perm_c ? 2 : 0);
+    for (const char* kn : {"NEP_ML_BMAX", "NEP_ML_SPLIT", "NEP_ML_CHUNK"}) {     // experiment knobs change the schedule
+        const char* e = getenv(kn);
+        h0 = (h0 ^ (uint64_t)(e ? atoi(e) + 7 : 3)) * 0x9E3779B97F4A7C15ull;
+    }
+    const double t1 = ml_now_ms();
+    MLSym* S = nullptr;
+    bool hit = false;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);      // held during the symbolic build: concurrent creators of one
+        const bool nocache = getenv("NEP_ML_NOCACHE") != nullptr;   // pattern (Beyn) wait instead of duplicating it
+        if (!nocache)
+            for (auto it = g_cache.begin(); it != g_cache.end(); ++it)
+                if ((*it)->key0 == h0 && (*it)->key1 == h1 && (*it)->n == n && (*it)->nnzL == Lp[n] && (*it)->nnzU == Up[n]) {
+                    S = *it; g_cache.erase(it); g_cache.push_front(S); hit = true; break;
+                }
+        if (!S) {
+            S = new MLSym();
+            S->key0 = h0; S->key1 = h1; S->nnzL = Lp[n]; S->nnzU = Up[n]; S->csc = csc;
+            int rc;
+            if (csc) {
+                std::vector<int32_t> Lrp, Lci, Lsrc, Urp, Uci, Usrc;
+                transpose_pattern(n, Lp, Li, Lrp, Lci, &Lsrc);
+                transpose_pattern(n, Up, Ui, Urp, Uci, &Usrc);
+                rc = build_symbolic(S, n, Lrp.data(), Lci.data(), Lsrc.data(), Urp.data(), Uci.data(), Usrc.data(), Up, Ui,
+                                    perm_r, perm_c);
+            } else {
+                std::vector<int32_t> UTp, UTi;
+                transpose_pattern(n, Up, Ui, UTp, UTi, nullptr);
+                rc = build_symbolic(S, n, Lp, Li, nullptr, Up, Ui, nullptr, UTp.data(), UTi.data(), perm_r, perm_c);
+            }
+            if (rc) { free_sym(S); return rc; }
+            S->t_build_ms = ml_now_ms() - t1;
+            g_cache.push_front(S);
+        }
+        S->refs++;
+    }
+    const double t2 = ml_now_ms();
+    MLFactor* F = new MLFactor();
+    F->sym = S;
+    F->use_graph = expected_solves >= 3 ? 1 : 0;
+    F->apex_la = choose_apex(S, expected_solves);
+    int rc = ml_numeric(F, Lx, Ux);
+    if (rc) { ml_destroy(F); return rc; }
+    if (timing) {
+        fprintf(stderr, "[ml_create] n=%lld levels=%d blocks=%d hash %.3f ms, symbolic %s %.3f ms, numeric (host) %.3f ms\n",
+                (long long)n, S->nlev, S->nblk, t1 - t0, hit ? "hit" : "built", t2 - t1, ml_now_ms() - t2);
+        if (!hit)
+            for (int l = 0; l < S->nlev; ++l)
+                fprintf(stderr, "[ml_create]   level %d: rows %d blocks %d | L coupling %lld %s ch %d | U coupling %lld %s ch %d\n", l,
+                        S->lev_row[l + 1] - S->lev_row[l], S->lev_blk[l + 1] - S->lev_blk[l], (long long)S->L.lev_coup[l],
+                        S->L.split[l] ? "split" : "fused", S->L.lev_ch[l], (long long)S->U.lev_coup[l],
+                        S->U.split[l] ? "split" : "fused", S->U.lev_ch[l]);
+    }
+    *out = F;
+    return NEP_OK;
+}
+
+int ml_refactor(MLFactor* F, const nep_cdouble* Lx, const nep_cdouble* Ux) { return ml_numeric(F, Lx, Ux); }
+
+// host-only analysis (no device): out[0]=levels, out[1]=blocks, out[2]=largest block, out[3]/[4]=coupling non-zeros and
+// packed inverse entries of L, out[5]/[6] of U, out[7]=levels with a separate coupling launch (L+U)
+int ml_analyze(int64_t n, int csc, const int32_t* Lp, const int32_t* Li, const int32_t* Up, const int32_t* Ui, int64_t out[8]) {
+    MLSym* S = new MLSym();
+    g_ml_dry = true;
+    int rc;
+    if (csc) {
+        std::vector<int32_t> Lrp, Lci, Lsrc, Urp, Uci, Usrc;
+        transpose_pattern(n, Lp, Li, Lrp, Lci, &Lsrc);
+        transpose_pattern(n, Up, Ui, Urp, Uci, &Usrc);
+        rc = build_symbolic(S, n, Lrp.data(), Lci.data(), Lsrc.data(), Urp.data(), Uci.data(), Usrc.data(), Up, Ui, nullptr, nullptr);
+    } else {
+        std::vector<int32_t> UTp, UTi;
+        transpose_pattern(n, Up, Ui, UTp, UTi, nullptr);
+        rc = build_symbolic(S, n, Lp, Li, nullptr, Up, Ui, nullptr, UTp.data(), UTi.data(), nullptr, nullptr);
+    }
+    g_ml_dry = false;
+    if (rc == NEP_OK) {
+        out[0] = S->nlev; out[1] = S->nblk; out[2] = S->max_block;
+        out[3] = S->L.ncoup; out[4] = S->L.ninv; out[5] = S->U.ncoup; out[6] = S->U.ninv;
+        int64_t sp = 0;
+        for (int l = 0; l < S->nlev; ++l) sp += S->L.split[l] + S->U.split[l];
+        out[7] = sp;
+    }
+    delete S;
+    return rc;
+}
+
+int ml_set_row_scale(MLFactor* F, const double* h_rs) {
+    const int64_t n = F->sym->n;
+    if (!h_rs) { if (F->d_rscale) nep_pool_free(F->d_rscale); F->d_rscale = nullptr; return NEP_OK; }
+    if (!F->d_rscale) { int rc = nep_pool_alloc((void**)&F->d_rscale, (size_t)n * sizeof(double)); if (rc) return rc; }
+    HIPCHK(hipMemcpy(F->d_rscale, h_rs, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    return NEP_OK;
+}
+
+void ml_destroy(MLFactor* F) {
+    if (!F) return;
+    // the solves enqueued on F->last may still read these blocks: the pool hands them out again only behind that work
+    hipStream_t st = F->used ? F->last : nullptr;
+    if (F->ready) { (void)hipEventSynchronize(F->ready); (void)hipEventDestroy(F->ready); }   // numeric build done (cheap: long past)
+    nep_pool_free_on(F->d_vals, st, F->used); nep_pool_free_on(F->d_ixL, st, F->used); nep_pool_free_on(F->d_ixU, st, F->used);
+    nep_pool_free_on(F->d_rscale, st, F->used); nep_pool_free_on(F->d_Sinv, st, F->used);
+    if (F->work.dptr) { nep_pool_free_on(F->work.dptr, st, F->used); F->work.dptr = nullptr; F->work.cap = 0; }
+    if (F->graph) (void)hipGraphExecDestroy(F->graph);
+    if (F->cap_stream) (void)hipStreamDestroy(F->cap_stream);
+    if (F->sym) sym_release(F->sym);
+    delete F;
+}
+
+void ml_info(const MLFactor* F, int64_t info[6], int64_t sched[8]) {
+    const MLSym* S = F->sym;
+    if (info) {
+        info[0] = S->n; info[1] = S->nnzL; info[2] = S->nnzU;
+        const int top = F->apex_la > 0 ? F->apex_la : S->nlev;
+        info[3] = top + (F->apex_la > 0 ? 1 : 0); info[4] = info[3];
+        // bytes one single-RHS solve moves: coupling (16 + 4 per non-zero), packed inverses, index arrays, vectors
+        // (with an apex, the inverses / in-apex coupling of its levels are replaced by the dense T x T block: upper bound)
+        const int64_t T = F->apex_la > 0 ? S->n - S->lev_row[F->apex_la] : 0;
+        info[5] = (S->L.ncoup + S->U.ncoup) * 20 + (S->L.ninv + S->U.ninv) * 16 + 16 * T * T + 2 * (8 + 4) * (S->n + 1) + 6 * 16 * S->n;
+    }
+    if (sched) {
+        sched[0] = F->apex_la > 0 ? S->n - S->lev_row[F->apex_la] : 0; sched[1] = F->launches; sched[2] = S->nlev; sched[3] = S->nlev;
+        int64_t sp = 0;
+        for (int l = 0; l < S->nlev; ++l) sp += S->L.split[l] + S->U.split[l];
+        sched[4] = sp; sched[5] = S->nblk; sched[6] = S->n; sched[7] = S->max_block;
+    }
+}
+
+// ---- launches ---------------------------------------------------------------------------------------------------------
+template <bool UPPER, int MODE, int G2>
+static void launch_level_g(const MLArgs& a, int nside_wg, int nrhs, hipStream_t st) {
+    const unsigned gx = (unsigned)(a.nchunks + nside_wg);
+    const dim3 b(256);
+    if (nrhs >= 8) hipLaunchKernelGGL((k_ml_level<UPPER, 8, MODE, G2>), dim3(gx, (nrhs + 7) / 8), b, 0, st, a);
+    else if (nrhs >= 2) hipLaunchKernelGGL((k_ml_level<UPPER, 4, MODE, G2>), dim3(gx, (nrhs + 3) / 4), b, 0, st, a);
+    else hipLaunchKernelGGL((k_ml_level<UPPER, 1, MODE, G2>), dim3(gx, 1), b, 0, st, a);
+}
+template <bool UPPER, int MODE>
+static void launch_level(const MLArgs& a, int ch, int nside_wg, int nrhs, hipStream_t st) {
+    if (ch == 4) launch_level_g<UPPER, MODE, 64>(a, nside_wg, nrhs, st);
+    else if (ch == 16) launch_level_g<UPPER, MODE, 16>(a, nside_wg, nrhs, st);
+    else launch_level_g<UPPER, MODE, 8>(a, nside_wg, nrhs, st);
+}
+
+static void launch_coupling(int lanes, int r0, int r1, const int32_t* cp, const int32_t* ci, const cplx* cx, const cplx* src,
+                            int64_t ldsrc, const cplx* xin, int64_t ldxin, cplx* tmp, int64_t ldtmp, int nrhs, hipStream_t st,
+                            int col_lo = 0, int col_hi = 0x7fffffff, int ident_row0 = -1) {
+    const int rows = r1 - r0;
+#define CPL(G_, RB_)                                                                                                       \
+    hipLaunchKernelGGL((k_ml_coupling<G_, RB_>), dim3((unsigned)(G_ == 256 ? rows : (rows + 256 / G_ - 1) / (256 / G_)),    \
+                                                      (nrhs + RB_ - 1) / RB_), dim3(256), 0, st, r0, r1, cp, ci, cx, src,  \
+                       ldsrc, xin, ldxin, tmp, ldtmp, nrhs, col_lo, col_hi, ident_row0)
+#define CPLG(G_) do { if (nrhs >= 8) CPL(G_, 8); else if (nrhs >= 2) CPL(G_, 4); else CPL(G_, 1); } while (0)
+    if (lanes == 256) CPLG(256); else if (lanes == 64) CPLG(64); else CPLG(8);
+#undef CPLG
+#undef CPL
+}
+
+struct MLSolveCtx {
+    MLFactor* F; int nrhs; cplx *bw, *y, *x, *tmp; int64_t ld;     // work vectors (ld = n; apex build: T, pointers offset by -R0)
+    const cplx* dB; int64_t ldb; cplx* dX; int64_t ldx; const cplx* dAdd; int64_t ldadd; double scale;
+    int ident_row0 = -1;      // >= 0: right-hand sides are unit vectors (apex build)
+    int col_lo = 0;           // coupling columns below it are skipped (apex build)
+};
+
+// L level l.  first = the level reads the caller's B through the input permutation (and copies the rest of B to bw)
+static int run_L(const MLSolveCtx& c, int l, bool first, hipStream_t st, int* launches) {
+    const MLSym* S = c.F->sym;
+    const MLFacSym& f = S->L;
+    const int64_t n = S->n;
+    const cplx* cx = c.F->d_vals;
+    const cplx* src = first ? c.dB : c.bw;
+    const int64_t ldsrc = first ? c.ldb : c.ld;
+    const bool split = f.split[l] != 0;          // level 0 has no coupling, so `first` is never split
+    if (split) {
+        launch_coupling(f.cpl_lanes[l], S->lev_row[l], S->lev_row[l + 1], f.d_cp, f.d_ci, cx, src, ldsrc, c.y, c.ld, c.tmp, c.ld,
+                        c.nrhs, st, c.col_lo, 0x7fffffff, c.ident_row0);
+        LAUNCHCHK(); if (launches) ++*launches;
+    }
+    MLArgs a; memset(&a, 0, sizeof(a));
+    a.chunks = f.d_chunks + f.lev_chunk[l]; a.nchunks = f.lev_chunk[l + 1] - f.lev_chunk[l];
+    a.cp = f.d_cp; a.ci = f.d_ci; a.cx = cx; a.ix = c.F->d_ixL; a.has_coupling = f.lev_coup[l] > 0 ? 1 : 0;
+    a.src = src; a.ldsrc = ldsrc; a.gat = first ? S->d_pin : nullptr; a.rs = first ? c.F->d_rscale : nullptr;
+    a.ident_row0 = c.ident_row0; a.col_lo = c.col_lo;
+    a.xin = c.y; a.ldxin = c.ld; a.xout = c.y; a.ldxout = c.ld; a.tmp = c.tmp; a.ldtmp = c.ld;
+    a.nrhs = c.nrhs;
+    int nside = 0;
+    if (first && S->nlev > 1) {
+        a.side_lo = S->lev_row[1]; a.side_hi = n; a.side_dst = c.bw; a.ldside = c.ld;
+        nside = (int)((a.side_hi - a.side_lo + 255) / 256);
+    }
+    if (split) launch_level<false, 1>(a, f.lev_ch[l], nside, c.nrhs, st); else launch_level<false, 0>(a, f.lev_ch[l], nside, c.nrhs, st);
+    LAUNCHCHK(); if (launches) ++*launches;
+    return NEP_OK;
+}
+
+static int run_U_coupling(const MLSolveCtx& c, int l, hipStream_t st, int* launches) {
+    const MLSym* S = c.F->sym;
+    const MLFacSym& f = S->U;
+    if (!f.split[l]) return NEP_OK;
+    const cplx* cx = c.F->d_vals + (S->L.ncoup + S->L.nin);
+    launch_coupling(f.cpl_lanes[l], S->lev_row[l], S->lev_row[l + 1], f.d_cp, f.d_ci, cx, c.y, c.ld, c.x, c.ld, c.tmp, c.ld, c.nrhs, st);
+    LAUNCHCHK(); if (launches) ++*launches;
+    return NEP_OK;
+}
+// U level l; `final` = the launch that also produces the caller's X
+static int run_U_level(const MLSolveCtx& c, int l, bool final, hipStream_t st, int* launches) {
+    const MLSym* S = c.F->sym;
+    const MLFacSym& f = S->U;
+    const int64_t n = S->n;
+    const cplx* cx = c.F->d_vals + (S->L.ncoup + S->L.nin);
+    MLArgs a; memset(&a, 0, sizeof(a));
+    a.chunks = f.d_chunks + f.lev_chunk[l]; a.nchunks = f.lev_chunk[l + 1] - f.lev_chunk[l];
+    a.cp = f.d_cp; a.ci = f.d_ci; a.cx = cx; a.ix = c.F->d_ixU; a.has_coupling = f.lev_coup[l] > 0 ? 1 : 0;
+    a.src = c.y; a.ldsrc = c.ld; a.xin = c.x; a.ldxin = c.ld; a.xout = c.x; a.ldxout = c.ld; a.tmp = c.tmp; a.ldtmp = c.ld;
+    a.ident_row0 = -1; a.col_lo = 0;
+    a.nrhs = c.nrhs;
+    int nside = 0;
+    if (final) {
+        a.outX = c.dX; a.ldX = c.ldx; a.pout = S->d_pout; a.scale = c.scale; a.add = c.dAdd; a.ldadd = c.ldadd;
+        if (S->nlev > 1) {
+            a.side_lo = S->lev_row[1]; a.side_hi = n; a.side_src = c.x; a.ldsidesrc = c.ld;
+            nside = (int)((a.side_hi - a.side_lo + 255) / 256);
+        }
+    }
+    if (f.split[l]) launch_level<true, 1>(a, f.lev_ch[l], nside, c.nrhs, st); else launch_level<true, 0>(a, f.lev_ch[l], nside, c.nrhs, st);
+    LAUNCHCHK(); if (launches) ++*launches;
+    return NEP_OK;
+}
+
+// apex of one solve: t = b_T - L[T, <R0] y (coupling restricted to the columns below the apex), x_T = S^{-1} t
+static int run_apex(const MLSolveCtx& c, hipStream_t st, int* launches) {
+    MLFactor* F = c.F;
+    const MLSym* S = F->sym;
+    const int la = F->apex_la;
+    const int R0 = S->lev_row[la], T = (int)(S->n - R0);
+    const MLFacSym& f = S->L;
+    int lanes = 8;
+    { int64_t nz = 0; for (int l = la; l < S->nlev; ++l) nz += f.lev_coup[l]; const double avg = nz / (double)T; lanes = avg > 2048.0 ? 256 : (avg > 24.0 ? 64 : 8); }
+    launch_coupling(lanes, R0, (int)S->n, f.d_cp, f.d_ci, F->d_vals, c.bw, c.ld, c.y, c.ld, c.tmp, c.ld, c.nrhs, st, 0, R0, -1);
+    LAUNCHCHK();
+#define APEX_GEMV(RB_)                                                                                                  \
+    hipLaunchKernelGGL((k_apex_gemv<RB_>), dim3((unsigned)((T + 3) / 4), (c.nrhs + RB_ - 1) / RB_), dim3(256), 0, st, T, R0,  \
+                       (const cplx*)F->d_Sinv, (const cplx*)c.tmp, c.ld, c.x, c.ld, c.nrhs)
+    if (c.nrhs >= 8) APEX_GEMV(8); else if (c.nrhs >= 2) APEX_GEMV(4); else APEX_GEMV(1);
+#undef APEX_GEMV
+    LAUNCHCHK();
+    if (launches) *launches += 2;
+    return NEP_OK;
+}
+
+// everything between the first (L level 0) and the last (U level 0) launch: fixed buffers only -> one hipGraph
+static int ml_middle(const MLSolveCtx& c, hipStream_t st, int* launches) {
+    const MLSym* S = c.F->sym;
+    const int top = c.F->apex_la > 0 ? c.F->apex_la : S->nlev;      // levels [top, nlev) are handled by the apex
+    int rc;
+    for (int l = 1; l < top; ++l) if ((rc = run_L(c, l, false, st, launches))) return rc;
+    if (c.F->apex_la > 0 && (rc = run_apex(c, st, launches))) return rc;
+    for (int l = top - 1; l >= 1; --l) {
+        if ((rc = run_U_coupling(c, l, st, launches))) return rc;
+        if ((rc = run_U_level(c, l, false, st, launches))) return rc;
+    }
+    return run_U_coupling(c, 0, st, launches);
+}
+static int ml_middle_count(const MLFactor* F) {
+    const MLSym* S = F->sym;
+    const int top = F->apex_la > 0 ? F->apex_la : S->nlev;
+    int nmid = 0;
+    for (int l = 1; l < top; ++l) nmid += 2 + S->L.split[l] + S->U.split[l];
+    if (F->apex_la > 0) nmid += 2;
+    return nmid + S->U.split[0];
+}
+
+// numeric build of the apex: S^{-1} e_j for all T unit vectors = the block solve of levels >= la restricted to the apex
+// rows, T right-hand sides at once (work vectors T x T, addressed with the global row index through pointers offset by -R0)
+static int ml_build_apex(MLFactor* F, hipStream_t bst) {
+    MLSym* S = F->sym;
+    const int la = F->apex_la;
+    const int R0 = S->lev_row[la];
+    const int64_t T = S->n - R0;
+    int rc;
+    if (!F->d_Sinv && (rc = nep_pool_alloc((void**)&F->d_Sinv, (size_t)T * T * sizeof(cplx)))) return rc;
+    cplx* wk = nullptr;
+    if ((rc = nep_pool_alloc((void**)&wk, (size_t)3 * T * T * sizeof(cplx)))) return rc;
+    MLSolveCtx c;
+    c.F = F; c.nrhs = (int)T; c.ld = T;
+    c.y = wk - R0; c.x = wk + (size_t)T * T - R0; c.tmp = wk + (size_t)2 * T * T - R0; c.bw = nullptr;
+    c.dB = nullptr; c.ldb = 0; c.dX = nullptr; c.ldx = 0; c.dAdd = nullptr; c.ldadd = 0; c.scale = 1.0;
+    c.ident_row0 = R0; c.col_lo = R0;
+    for (int l = la; l < S->nlev; ++l) if ((rc = run_L(c, l, false, bst, nullptr))) { nep_pool_free_on(wk, bst, true); return rc; }
+    for (int l = S->nlev - 1; l >= la; --l) {
+        if ((rc = run_U_coupling(c, l, bst, nullptr)) || (rc = run_U_level(c, l, false, bst, nullptr))) { nep_pool_free_on(wk, bst, true); return rc; }
+    }
+    hipLaunchKernelGGL(k_apex_transpose, dim3((unsigned)((T + 15) / 16), (unsigned)((T + 15) / 16)), dim3(256), 0, bst, (int)T,
+                       (const cplx*)(wk + (size_t)T * T), F->d_Sinv);
+    hipError_t e = hipGetLastError();
+    nep_pool_free_on(wk, bst, true);
+    if (e != hipSuccess) { nep_set_error("apex build failed: %s", hipGetErrorString(e)); return NEP_ERR_HIP; }
+    return NEP_OK;
+}
+
+// which levels to merge into the dense apex: launches saved (about 4.5 us each) against 16 T^2 bytes of extra streaming
+static int choose_apex(const MLSym* S, int expected_solves) {
+    if (const char* e = getenv("NEP_ML_APEX")) { const int v = atoi(e); return (v >= 1 && v < S->nlev && S->n - S->lev_row[v] <= 4096) ? v : 0; }
+    if (expected_solves < 8 || S->nlev < 2) return 0;
+    int best = 0; double bestgain = 2.0;              // at least 2 us per solve
+    for (int la = 1; la < S->nlev; ++la) {
+        const double T = (double)(S->n - S->lev_row[la]);
+        if (T > 2048.0) continue;
+        int saved = -2;
+        double bytes_now = 0.0;
+        for (int l = la; l < S->nlev; ++l) {
+            saved += 2 + S->L.split[l] + S->U.split[l];
+            bytes_now += 20.0 * (S->L.lev_coup[l] + S->U.lev_coup[l]);
+        }
+        const double gain = 4.5 * saved - (16.0 * T * T - bytes_now) / 3.5e6;      // us
+        if (gain > bestgain) { bestgain = gain; best = la; }
+    }
+    return best;
+}
+
+int ml_solve(MLFactor* F, int nrhs, const nep_cdouble* dB, int64_t ldb, const nep_cdouble* dAdd, int64_t ldadd,
+             nep_cdouble* dX, int64_t ldx, double scale, hipStream_t st) {
+    MLSym* S = F->sym;
+    const int64_t n = S->n;
+    // the previous users of these buffers ran on F->last; a different stream must queue behind them
+    if (F->used && F->last != st) {
+        hipEvent_t ev; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev, F->last)); HIPCHK(hipStreamWaitEvent(st, ev, 0)); (void)hipEventDestroy(ev);
+    }
+    if (!F->synced_valid || F->synced != st) { HIPCHK(hipStreamWaitEvent(st, F->ready, 0)); F->synced = st; F->synced_valid = true; }
+    int rc;
+    const size_t need = (size_t)4 * n * nrhs * sizeof(cplx);
+    if (F->work.cap < need) {          // the old block may still be in use by solves in flight on F->last
+        if (F->work.dptr) { nep_pool_free_on(F->work.dptr, F->last, F->used); F->work.dptr = nullptr; F->work.cap = 0; }
+        if ((rc = nep_pool_alloc(&F->work.dptr, need))) return rc;
+        F->work.cap = need;
+    }
+    MLSolveCtx c;
+    c.F = F; c.nrhs = nrhs; c.ld = n;
+    c.bw = (cplx*)F->work.dptr; c.y = c.bw + (size_t)n * nrhs; c.x = c.y + (size_t)n * nrhs; c.tmp = c.x + (size_t)n * nrhs;
+    c.dB = (const cplx*)dB; c.ldb = ldb; c.dX = (cplx*)dX; c.ldx = ldx; c.dAdd = (const cplx*)dAdd; c.ldadd = ldadd; c.scale = scale;
+    int launches = 0;
+    if ((rc = run_L(c, 0, true, st, &launches))) return rc;
+    const int nmid = ml_middle_count(F);
+    bool graphed = false;
+    if (F->use_graph && nmid >= 4 && !getenv("NEP_NO_GRAPH")) {
+        if (!F->graph || F->graph_nrhs != nrhs || F->graph_work != F->work.dptr) {
+            if (F->graph) { (void)hipGraphExecDestroy(F->graph); F->graph = nullptr; }
+            if (!F->cap_stream) HIPCHK(hipStreamCreateWithFlags(&F->cap_stream, hipStreamNonBlocking));
+            hipGraph_t g = nullptr;
+            hipError_t e = hipStreamBeginCapture(F->cap_stream, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                const int rcs = ml_middle(c, F->cap_stream, nullptr);
+                e = hipStreamEndCapture(F->cap_stream, &g);
+                if (rcs == NEP_OK && e == hipSuccess && g) e = hipGraphInstantiate(&F->graph, g, nullptr, nullptr, 0);
+                else if (e == hipSuccess) e = hipErrorUnknown;
+                if (g) (void)hipGraphDestroy(g);
+            }
+            if (e != hipSuccess || !F->graph) { (void)hipGetLastError(); F->graph = nullptr; F->use_graph = 0; }
+            else { F->graph_nrhs = nrhs; F->graph_work = F->work.dptr; }
+        }
+        if (F->graph) { HIPCHK(hipGraphLaunch(F->graph, st)); launches += nmid; graphed = true; }
+    }
+    if (!graphed && (rc = ml_middle(c, st, &launches))) return rc;
+    if ((rc = run_U_level(c, 0, true, st, &launches))) return rc;
+    F->launches = launches;
+    F->last = st; F->used = true;
+    return NEP_OK;
+}

@@ -32,8 +32,9 @@ void NepScratch::release() {
 #include <mutex>
 #include <unordered_map>
 namespace {
+struct PoolBlock { void* p; hipEvent_t ev; };      // ev != nullptr: work that may still touch the block (nep_pool_free_on)
 std::mutex g_pool_mu;
-std::multimap<size_t, void*> g_pool_free;        // size -> block
+std::multimap<size_t, PoolBlock> g_pool_free;    // size -> block
 std::unordered_map<void*, size_t> g_pool_live;   // block -> size
 size_t g_pool_cached = 0;
 const size_t POOL_CAP = (size_t)4 << 30;         // at most 4 GiB of idle blocks
@@ -44,20 +45,51 @@ size_t pool_round(size_t b) {
     const size_t q = p >> 3;                      // ... in steps of an eighth
     return ((b + q - 1) / q) * q;
 }
+void pool_put(void* p, hipEvent_t ev, std::vector<PoolBlock>& to_free) {   // g_pool_mu held
+    auto it = g_pool_live.find(p);
+    if (it == g_pool_live.end()) { to_free.push_back(PoolBlock{p, ev}); return; }
+    g_pool_free.emplace(it->second, PoolBlock{p, ev});
+    g_pool_cached += it->second;
+    g_pool_live.erase(it);
+    while (g_pool_cached > POOL_CAP && !g_pool_free.empty()) {
+        auto big = std::prev(g_pool_free.end());
+        to_free.push_back(big->second);
+        g_pool_cached -= big->first;
+        g_pool_free.erase(big);
+    }
+}
+void pool_drop(std::vector<PoolBlock>& v) {
+    for (PoolBlock& b : v) {
+        if (b.ev) { (void)hipEventSynchronize(b.ev); (void)hipEventDestroy(b.ev); }
+        (void)hipFree(b.p);
+    }
+}
 }  // namespace
 
 int nep_pool_alloc(void** p, size_t bytes) {
     const size_t want = pool_round(bytes);
+    hipEvent_t wait_ev = nullptr;
+    bool found = false;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        auto it = g_pool_free.lower_bound(want);
-        if (it != g_pool_free.end() && it->first <= want + want / 4) {
-            *p = it->second;
-            g_pool_live[*p] = it->first;
-            g_pool_cached -= it->first;
-            g_pool_free.erase(it);
-            return NEP_OK;
+        auto lo = g_pool_free.lower_bound(want);
+        auto pick = g_pool_free.end();
+        for (auto it = lo; it != g_pool_free.end() && it->first <= want + want / 4; ++it) {
+            if (!it->second.ev || hipEventQuery(it->second.ev) == hipSuccess) { pick = it; break; }
+            if (pick == g_pool_free.end()) pick = it;           // all candidates busy: take the first and wait
         }
+        if (pick != g_pool_free.end()) {
+            *p = pick->second.p;
+            wait_ev = pick->second.ev;
+            g_pool_live[*p] = pick->first;
+            g_pool_cached -= pick->first;
+            g_pool_free.erase(pick);
+            found = true;
+        }
+    }
+    if (found) {
+        if (wait_ev) { (void)hipEventSynchronize(wait_ev); (void)hipEventDestroy(wait_ev); }
+        return NEP_OK;
     }
     HIPCHK(hipMalloc(p, want));
     std::lock_guard<std::mutex> lk(g_pool_mu);
@@ -67,24 +99,30 @@ int nep_pool_alloc(void** p, size_t bytes) {
 
 void nep_pool_free(void* p) {
     if (!p) return;
-    std::vector<void*> to_free;
+    std::vector<PoolBlock> to_free;
     {
         std::lock_guard<std::mutex> lk(g_pool_mu);
-        auto it = g_pool_live.find(p);
-        if (it == g_pool_live.end()) { to_free.push_back(p); }
-        else {
-            g_pool_free.emplace(it->second, p);
-            g_pool_cached += it->second;
-            g_pool_live.erase(it);
-            while (g_pool_cached > POOL_CAP && !g_pool_free.empty()) {
-                auto big = std::prev(g_pool_free.end());
-                to_free.push_back(big->second);
-                g_pool_cached -= big->first;
-                g_pool_free.erase(big);
-            }
+        pool_put(p, nullptr, to_free);
+    }
+    pool_drop(to_free);
+}
+
+void nep_pool_free_on(void* p, hipStream_t st, bool in_flight) {
+    if (!p) return;
+    hipEvent_t ev = nullptr;
+    if (in_flight) {
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, st) != hipSuccess) {
+            (void)hipGetLastError();
+            if (ev) { (void)hipEventDestroy(ev); ev = nullptr; }
+            (void)hipStreamSynchronize(st);               // no event available: be safe
         }
     }
-    for (void* q : to_free) (void)hipFree(q);
+    std::vector<PoolBlock> to_free;
+    {
+        std::lock_guard<std::mutex> lk(g_pool_mu);
+        pool_put(p, ev, to_free);
+    }
+    pool_drop(to_free);
 }
 
 int PinnedRing::upload(void* ddst, const void* hsrc, size_t bytes, hipStream_t st) {

@@ -143,8 +143,8 @@ class DeviceLU:
         check(lib.nep_lu_set_expected_solves(int(expected_solves)))
         h = c_vp()
         try:
-            check(lib.nep_lu_create(n, hptr(Lp), hptr(Li), hptr(Lx), hptr(Up), hptr(Ui), hptr(Ux), hptr(pr), hptr(pc),
-                                    C.byref(h)))
+            create = lib.nep_lu_create_csc if F.get("fmt", "csr") == "csc" else lib.nep_lu_create
+            check(create(n, hptr(Lp), hptr(Li), hptr(Lx), hptr(Up), hptr(Ui), hptr(Ux), hptr(pr), hptr(pc), C.byref(h)))
         finally:
             if shm_backed:
                 del Lp, Li, Lx, Up, Ui, Ux, pr, pc
@@ -160,7 +160,25 @@ class DeviceLU:
         self.tail, self.levL_full, self.levU_full = int(sch[0]), int(sch[2]), int(sch[3])
         self.wide_segments, self.narrow_segments = int(sch[4]), int(sch[5])
         self.mid_rows, self.mid_block = int(sch[6]), int(sch[7])
+        ib = C.c_int32(0)
+        check(lib.nep_lu_is_block_schedule(self.h, C.byref(ib)))
+        self.block_schedule = bool(ib.value)          # elimination-tree block schedule (trsv_ml.hip) vs level schedule
+        if self.block_schedule:
+            self.levels, self.split_levels, self.blocks = int(sch[2]), int(sch[4]), int(sch[5])
+        # (nnz L + nnz U)(16 + 4) + 8(n + 1) + 3*16 n for one right-hand side
+        self.algorithmic_bytes = (self.nnzL + self.nnzU) * 20 + 8 * (n + 1) + 48 * n
         self.t_setup = time.perf_counter() - t0
+
+    def refactor(self, Lx, Ux):
+        """same-pattern refactorisation (nep_lu_refactor): new values in the entry order of the factors this handle
+        was created with"""
+        Lx = np.ascontiguousarray(Lx, dtype=np.complex128); Ux = np.ascontiguousarray(Ux, dtype=np.complex128)
+        assert Lx.shape[0] == self.nnzL and Ux.shape[0] == self.nnzU
+        check(lib.nep_lu_refactor(self.h, hptr(Lx), hptr(Ux)))
+
+    def set_row_scale(self, rs):
+        rs = None if rs is None else np.ascontiguousarray(rs, dtype=np.float64)
+        check(lib.nep_lu_set_row_scale(self.h, hptr(rs) if rs is not None else None))
 
     def launches_last_solve(self):
         sch = (c_i64 * 8)()

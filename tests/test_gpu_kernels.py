@@ -210,6 +210,7 @@ def test_lu_solve_vs_host(na, nrhs):
 def test_lu_blocked_mid_region(na, spec, monkeypatch):
     """every schedule shape of the hybrid solve (level heads / blocked mid with inverted diagonal blocks / dense tail)
     returns the host solution; nrhs 1 and 5; tolerance 1e-9 relative (explicit block inverses)"""
+    monkeypatch.setenv("NEP_LU_SCHED", "old")             # the level schedule stays as the fallback of the block schedule
     for k_, v_ in spec.items():
         monkeypatch.setenv(k_, v_)
     from oracle import gallery as og
@@ -218,6 +219,7 @@ def test_lu_blocked_mid_region(na, spec, monkeypatch):
     n = A.shape[0]
     rng = np.random.default_rng(5)
     lu = na.DeviceLU(A, expected_solves=200)
+    assert not lu.block_schedule
     if "NEP_LU_MID" in spec and "NEP_LU_BLOCK" in spec:
         assert lu.mid_block == int(spec["NEP_LU_BLOCK"]) and lu.mid_rows == int(spec["NEP_LU_MID"])
         assert lu.tail == int(spec["NEP_LU_TAIL"])
@@ -229,6 +231,98 @@ def test_lu_blocked_mid_region(na, spec, monkeypatch):
         X = na.to_host(lu.solve(na.to_dev(B)))
         Xo = host.solve(B)
         assert np.linalg.norm(X - Xo) <= 1e-9 * np.linalg.norm(Xo)
+
+
+@pytest.mark.parametrize("spec", [dict(), dict(NEP_ML_BMAX="64"), dict(NEP_ML_BMAX="32", NEP_ML_CHUNK="32"),
+                                  dict(NEP_ML_SPLIT="1"), dict(NEP_ML_SPLIT="0", NEP_ML_CHUNK="4"), dict(NEP_NO_GRAPH="1"),
+                                  dict(NEP_ML_NOCACHE="1"), dict(NEP_ML_APEX="0"), dict(NEP_ML_APEX="1", NEP_ML_SPLIT="0"),
+                                  dict(NEP_ML_APEX="2", NEP_ML_BMAX="64")])
+def test_lu_block_schedule(na, spec, monkeypatch):
+    """K5 block schedule (csrc/trsv_ml.hip): every shape of the schedule (block size, chunking, fused / split coupling
+    product, graph / eager) returns SuperLU's solution; CSR and CSC input; nrhs 1, 5, 32; in-place, scale, fused update"""
+    for k_, v_ in spec.items():
+        monkeypatch.setenv(k_, v_)
+    import _nep_hostlu as hl
+    from oracle import gallery as og
+    nep = og.nlevp_native_gun(1310)
+    A = sp.csc_matrix(nep.compute_Mder(250.0 ** 2 + 1j), dtype=complex)
+    n = A.shape[0]
+    rng = np.random.default_rng(5)
+    host = spla.splu(A)
+    for csr in (False, True):
+        F = hl.factor(A.data, A.indices, A.indptr, A.shape, csr=csr)
+        lu = na.DeviceLU(factors=F, expected_solves=200)
+        assert lu.block_schedule and lu.mid_block <= int(spec.get("NEP_ML_BMAX", 256))
+        for nrhs in (1, 5, 32):
+            B = rng.standard_normal((n, nrhs)) + 1j * rng.standard_normal((n, nrhs))
+            Xo = host.solve(B)
+            for rep in range(2):                       # second call replays the captured graph
+                X = na.to_host(lu.solve(na.to_dev(B)))
+                assert np.linalg.norm(X - Xo) <= 1e-9 * np.linalg.norm(Xo)
+            Bd = na.to_dev(B)
+            lu.solve(Bd, out=Bd, scale=-1.0)           # in place
+            assert np.linalg.norm(na.to_host(Bd) + Xo) <= 1e-9 * np.linalg.norm(Xo)
+            Add = rng.standard_normal((n, nrhs)) + 1j * rng.standard_normal((n, nrhs))
+            Ad = na.to_dev(Add)
+            lu.solve_add(na.to_dev(B), Ad, Ad, 2.0)    # out aliases add
+            assert np.linalg.norm(na.to_host(Ad) - 2.0 * (Add + Xo)) <= 1e-9 * np.linalg.norm(Xo)
+        assert lu.launches_last_solve() <= 2 * lu.levels + lu.split_levels
+        if spec.get("NEP_ML_APEX", "0") != "0":
+            assert lu.tail > 0                             # the last levels are one dense inverse
+
+
+def test_lu_refactor_rowscale_and_pattern_cache(na, monkeypatch):
+    """nep_lu_refactor (same pattern, new values: src/method_beyncontour.jl:89-94), nep_lu_set_row_scale (UMFPACK's Rs) and
+    the pattern-hash cache of the symbolic analysis; destroying a factorisation right after an asynchronous solve is safe
+    (stream-ordered frees)"""
+    import _nep_hostlu as hl
+    from oracle import gallery as og
+    nep = og.nlevp_native_gun(1310)
+    n = nep.n
+    rng = np.random.default_rng(11)
+    A1 = sp.csc_matrix(nep.compute_Mder(250.0 ** 2 + 1j), dtype=complex)
+    A2 = sp.csc_matrix(nep.compute_Mder(260.0 ** 2 + 5j), dtype=complex)
+    F1 = hl.factor(A1.data, A1.indices, A1.indptr, A1.shape)
+    F2 = hl.factor(A2.data, A2.indices, A2.indptr, A2.shape)
+    same = all(np.array_equal(F1[k], F2[k]) for k in ("Lp", "Li", "Up", "Ui", "perm_r", "perm_c"))
+    B = rng.standard_normal((n, 3)) + 1j * rng.standard_normal((n, 3))
+    lu = na.DeviceLU(factors=F1)
+    X1 = na.to_host(lu.solve(na.to_dev(B)))
+    assert np.linalg.norm(A1 @ X1 - B) <= 1e-9 * np.linalg.norm(B)
+    if same:                                             # diagonal pivoting: the two shifts share the factor pattern
+        lu.refactor(F2["Lx"], F2["Ux"])
+        X2 = na.to_host(lu.solve(na.to_dev(B)))
+        assert np.linalg.norm(A2 @ X2 - B) <= 1e-9 * np.linalg.norm(B)
+        lu.refactor(F1["Lx"], F1["Ux"])
+        assert np.array_equal(na.to_host(lu.solve(na.to_dev(B))), X1)        # deterministic kernels
+    # row scaling: factors of diag(rs) A  ->  solve multiplies b by rs
+    rs = 0.5 + rng.random(n)
+    As = sp.csc_matrix(sp.diags(rs) @ A1)
+    Fs = hl.factor(As.data, As.indices, As.indptr, As.shape)
+    lus = na.DeviceLU(factors=Fs)
+    lus.set_row_scale(rs)
+    Xs = na.to_host(lus.solve(na.to_dev(B)))
+    assert np.linalg.norm(A1 @ Xs - B) <= 1e-9 * np.linalg.norm(B)
+    lus.set_row_scale(None)
+    Xn = na.to_host(lus.solve(na.to_dev(B)))
+    assert np.linalg.norm(As @ Xn - B) <= 1e-9 * np.linalg.norm(B)
+    # create / solve / drop in a loop: blocks return to the pool while their solve may still be running
+    outs = []
+    for i in range(6):
+        t = na.DeviceLU(factors=F1 if i % 2 == 0 else F2, expected_solves=1)
+        outs.append((i, t.solve(na.to_dev(B))))
+        del t
+    for i, Xd in outs:
+        Aref = A1 if i % 2 == 0 else A2
+        assert np.linalg.norm(Aref @ na.to_host(Xd) - B) <= 1e-9 * np.linalg.norm(B)
+    # singular U is reported at the numeric stage
+    Fz = dict(F1); Ux = F1["Ux"].copy()
+    Uc = sp.csc_matrix((np.arange(len(Ux)), F1["Ui"], F1["Up"]), shape=(n, n))
+    Ux[int(Uc[5, 5])] = 0.0
+    Fz["Ux"] = Ux
+    with pytest.raises(na.NepError) as ei:
+        na.DeviceLU(factors=Fz)
+    assert ei.value.status == -3
 
 
 def test_cw_backward_error_and_refinement(na):

@@ -372,17 +372,23 @@ def test_quasinewton_qdep0_history(na):
     assert hist[0][1] == pytest.approx(ref[0][0], rel=1e-13)
 
 
-def test_lu_schedule_has_dense_tail(na):
+@pytest.mark.parametrize("sched", ["block", "old"])
+def test_lu_schedule_shortens_the_dependency_chain(na, sched, monkeypatch):
     from oracle import gallery as og
     import scipy.sparse as sp
+    if sched == "old":
+        monkeypatch.setenv("NEP_LU_SCHED", "old")
     A = sp.csc_matrix(og.gun_spmf_scaled(2620).compute_Mder(0.0), dtype=complex)
     lu = na.DeviceLU(A, permc_spec="MMD_AT_PLUS_A")
-    assert lu.tail >= 64 and lu.levL < lu.levL_full and lu.levU < lu.levU_full
+    if sched == "old":
+        assert not lu.block_schedule and lu.tail >= 64 and lu.levL < lu.levL_full and lu.levU < lu.levU_full
+    else:
+        assert lu.block_schedule and lu.levels <= 6 and lu.blocks >= 10 and lu.mid_block <= 256
     rng = np.random.default_rng(0)
     b = rng.standard_normal(2620) + 1j * rng.standard_normal(2620)
     x = na.to_host(lu.solve(na.to_dev(b)))[:, 0]
     assert np.linalg.norm(A @ x - b) <= 1e-12 * np.linalg.norm(b) * 10
-    assert lu.launches_last_solve() < 200
+    assert lu.launches_last_solve() < (200 if sched == "old" else 20)
 
 
 def test_beyn_dep0_kat(na):

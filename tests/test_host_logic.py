@@ -167,14 +167,112 @@ def test_hostlu_factor_strategy():
     F = hl.factor(A.data, A.indices, A.indptr, A.shape)
     assert F["strategy"]["symmetric_mode"] and F["strategy"]["permc_spec"] == "MMD_AT_PLUS_A"
     n = A.shape[0]
-    L = sp.csr_matrix((F["Lx"], F["Li"], F["Lp"]), shape=(n, n)); U = sp.csr_matrix((F["Ux"], F["Ui"], F["Up"]), shape=(n, n))
+    assert F["fmt"] == "csc"                      # SuperLU's own layout goes to nep_lu_create_csc unconverted
+    L = sp.csc_matrix((F["Lx"], F["Li"], F["Lp"]), shape=(n, n)); U = sp.csc_matrix((F["Ux"], F["Ui"], F["Up"]), shape=(n, n))
     Pr = sp.csc_matrix((np.ones(n), (F["perm_r"], np.arange(n)))); Pc = sp.csc_matrix((np.ones(n), (np.arange(n), F["perm_c"])))
     assert abs(Pr @ A @ Pc - L @ U).max() <= 1e-10 * abs(A).max()
+    Fr = hl.factor(A.data, A.indices, A.indptr, A.shape, csr=True)
+    Lr = sp.csr_matrix((Fr["Lx"], Fr["Li"], Fr["Lp"]), shape=(n, n)); Ur = sp.csr_matrix((Fr["Ux"], Fr["Ui"], Fr["Up"]), shape=(n, n))
+    assert Fr["fmt"] == "csr" and abs(Lr - L).max() == 0 and abs(Ur - U).max() == 0
     B = sp.csc_matrix(sp.triu(A, 0) + sp.identity(n))                     # upper triangular pattern: symmetry 0
     F2 = hl.factor(B.data, B.indices, B.indptr, B.shape)
     assert not F2["strategy"]["symmetric_mode"] and F2["strategy"]["permc_spec"] == "COLAMD"
     Bz = A.copy().tolil(); Bz[3, 3] = 0.0; Bz = sp.csc_matrix(Bz); Bz.eliminate_zeros()   # zero on the diagonal
     assert not hl.pattern_symmetric(Bz)
+
+
+def _ml_reference_partition(n, L, U, bmax):
+    """NumPy restatement of the symbolic analysis of csrc/trsv_ml.hip (elimination tree of struct(L)+struct(U)^T by
+    Liu's algorithm, multilevel partition into subtrees of at most bmax nodes): levels, block ids"""
+    Lr = sp.csr_matrix(L); UT = sp.csr_matrix(sp.csc_matrix(U).T)
+    parent = np.full(n, -1); anc = np.full(n, -1)
+    for i in range(n):
+        for M in (Lr, UT):
+            for k in M.indices[M.indptr[i]:M.indptr[i + 1]]:
+                while 0 <= k < i:
+                    nx = anc[k]; anc[k] = i
+                    if nx < 0:
+                        parent[k] = i
+                        break
+                    k = nx
+    lvl = np.zeros(n, int); rsz = np.ones(n, int); pmax = np.full(n, -1); psum = np.zeros(n, int)
+    for j in range(n):
+        M = max(pmax[j], 0); s_ = psum[j] if pmax[j] >= 0 else 0
+        if s_ + 1 <= bmax:
+            lvl[j], rsz[j] = M, s_ + 1
+        else:
+            lvl[j], rsz[j] = M + 1, 1
+        p = parent[j]
+        if p >= 0:
+            if lvl[j] > pmax[p]:
+                pmax[p], psum[p] = lvl[j], rsz[j]
+            elif lvl[j] == pmax[p]:
+                psum[p] += rsz[j]
+    bid = np.arange(n)
+    for j in range(n - 1, -1, -1):
+        if parent[j] >= 0 and lvl[parent[j]] == lvl[j]:
+            bid[j] = bid[parent[j]]
+    return parent, lvl, bid
+
+
+@pytest.mark.parametrize("case", ["gun_sym", "random_unsym", "chain"])
+def test_lu_block_schedule_analysis(case, monkeypatch):
+    """host-only symbolic analysis of the K5 block schedule (nep_lu_analyze, no device): level / block counts equal the
+    NumPy restatement; every dependency of L (U) stays inside its diagonal block or points to an earlier (later) level;
+    the block solve built from that partition reproduces the direct solution"""
+    import ctypes as C
+    import _nep_hostlu as hl
+    monkeypatch.setenv("NEP_ML_BMAX", "128")
+    rng = np.random.default_rng(3)
+    if case == "gun_sym":
+        A = sp.csc_matrix(og.gun_spmf(1310).compute_Mder(250.0 ** 2 + 1j), dtype=complex)
+    elif case == "random_unsym":
+        n0 = 900
+        A = (sp.random(n0, n0, 0.004, random_state=rng, format="csc") + sp.diags(0.05 + rng.random(n0))
+             + 1j * sp.random(n0, n0, 0.002, random_state=rng, format="csc")).tocsc()
+    else:
+        A = sp.diags([np.ones(699), 4 * np.ones(700), np.ones(699)], [-1, 0, 1], format="csc").astype(complex)
+    F = hl.factor(A.data, A.indices, A.indptr, A.shape)
+    n = F["n"]
+    out = (C.c_int64 * 8)()
+    L_ = na._lib.lib
+    hp = na._lib.hptr
+    assert L_.nep_lu_analyze(n, 1, hp(F["Lp"]), hp(F["Li"]), hp(F["Up"]), hp(F["Ui"]), out) == 0
+    L = sp.csc_matrix((F["Lx"], F["Li"], F["Lp"]), shape=(n, n)); U = sp.csc_matrix((F["Ux"], F["Ui"], F["Up"]), shape=(n, n))
+    parent, lvl, bid = _ml_reference_partition(n, L, U, 128)
+    assert out[0] == lvl.max() + 1 and out[1] == len(np.unique(bid)) and out[2] == np.bincount(bid).max() <= 128
+    # CSR input gives the same partition
+    Lr = sp.csr_matrix(L); Ur = sp.csr_matrix(U); Lr.sort_indices(); Ur.sort_indices()
+    out2 = (C.c_int64 * 8)()
+    assert L_.nep_lu_analyze(n, 0, hp(Lr.indptr.astype(np.int32)), hp(Lr.indices.astype(np.int32)), hp(Ur.indptr.astype(np.int32)),
+                             hp(Ur.indices.astype(np.int32)), out2) == 0
+    assert list(out2) == list(out)
+    # dependencies respect the partition
+    Lc = sp.coo_matrix(sp.tril(L, -1)); Uc = sp.coo_matrix(sp.triu(U, 1))
+    same = bid[Lc.row] == bid[Lc.col]
+    assert np.all(same | (lvl[Lc.col] < lvl[Lc.row]))
+    same = bid[Uc.row] == bid[Uc.col]
+    assert np.all(same | (lvl[Uc.col] > lvl[Uc.row]))
+    assert out[3] == int(np.sum(bid[Lc.row] != bid[Lc.col])) and out[5] == int(np.sum(bid[Uc.row] != bid[Uc.col]))
+    # block solve with explicitly inverted diagonal blocks (what the device kernels do), level by level
+    order = np.lexsort((np.arange(n), bid, lvl))
+    Ld = L.toarray()[np.ix_(order, order)]; Ud = U.toarray()[np.ix_(order, order)]
+    assert np.allclose(np.triu(Ld, 1), 0) and np.allclose(np.tril(Ud, -1), 0)
+    bnew = bid[order]
+    starts = np.flatnonzero(np.r_[True, bnew[1:] != bnew[:-1]]); ends = np.r_[starts[1:], n]
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    bw = np.empty(n, complex); bw[F["perm_r"]] = b
+    bn = bw[order]; y = np.zeros(n, complex); x = np.zeros(n, complex)
+    for s_, e_ in zip(starts, ends):                       # blocks come level by level in the new order
+        y[s_:e_] = np.linalg.inv(Ld[s_:e_, s_:e_]) @ (bn[s_:e_] - Ld[s_:e_, :s_] @ y[:s_])
+    for s_, e_ in zip(starts[::-1], ends[::-1]):
+        x[s_:e_] = np.linalg.inv(Ud[s_:e_, s_:e_]) @ (y[s_:e_] - Ud[s_:e_, e_:] @ x[e_:])
+    xw = np.empty(n, complex); xw[order] = x
+    xo = xw[F["perm_c"]]
+    assert np.linalg.norm(A @ xo - b) <= 1e-9 * np.linalg.norm(b)
+    # a pattern that is not triangular is rejected
+    bad = F["Li"].copy(); bad[:] = bad[::-1]
+    assert L_.nep_lu_analyze(n, 1, hp(F["Lp"]), hp(bad), hp(F["Up"]), hp(F["Ui"]), out) in (-2, -5)
 
 
 def test_c_abi_argument_errors_without_gpu():
