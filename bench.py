@@ -11,13 +11,20 @@ workload (weak scaling) and `value` is the whole-job rate: sum over ranks of con
 divided by the max-over-ranks wall time.
 
 The JSON line also carries
-  roofline      the kernels that dominate the device time of the timed region: K6, one Gram-Schmidt pass
-                (k_orth_dots + k_orth_update) at the shape of the last Arnoldi step; algorithmic bytes / HIP-event
-                time against the 8 TB/s HBM peak, HBM traffic from the committed PMC passes
-  roofline_compute_Mlincomb   the kernel the metric names (k_vc + k_spmv) at k=100 and k=1 on the gun matrices
-                (launch-bound at this size); roofline_wep_scale: the same kernels on the n = 1e6 waveguide matrices
-  kernels       per-phase GPU time of one instrumented iar run (so the time-dominant kernel is visible)
-  cpu_baseline  the CPU oracle (NumPy/SciPy restatement of the reference) on a bounded sample
+  value_excl_setup   the same rate with the linear-solver set-up (host SuperLU + factor upload + device-built block inverses)
+                     taken out of every step (set-up time from the instrumented run)
+  kernels / phase_share   per-phase time of one instrumented iar run and each phase's share of it
+  roofline      the kernel pair with the largest share of device time (K6: k_orth_dots + k_orth_update), ONE Gram-Schmidt
+                pass at a FIXED shape (iar step k = maxit), algorithmic bytes / average HIP-event time per pass; the committed
+                rocprofv3 summary of exactly this loop (`python bench.py --only orth`, profiles/r2_orth_kernel_stats.csv) gives the
+                same average
+  roofline_k5   the fixed-shift solve (time-dominant phase of round 1) against SURVEY.md section 8d ALGORITHMIC bytes
+  roofline_compute_Mlincomb   the kernel the metric names at k = maxit and k = 1 on the gun matrices;
+                roofline_wep_scale: the same kernels on the n = 1e6 waveguide matrices (the HBM-bound size)
+  cpu_baseline  the CPU oracle on the SAME configuration (maxit = 100), host core count and threads used, plus the
+                single-thread C port and the OpenMP all-cores variant of compute_Mlincomb
+  beyn_sharded  config C4 (the path that shards over ranks) with parity against the CPU oracle
+  c3_nleigs, c5_wep   the other BASELINE configurations (rank 0, one run each)
 """
 import argparse
 import json
@@ -29,6 +36,7 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 import numpy as np
 import torch
@@ -45,18 +53,33 @@ def parse():
     ap.add_argument("--n", type=int, default=9956)
     ap.add_argument("--maxit", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-maxit", type=int, default=60)
+    ap.add_argument("--cpu-maxit", type=int, default=0, help="CPU oracle iterations (0 = the benchmark's own maxit)")
     ap.add_argument("--permc", default=None)
-    ap.add_argument("--no-beyn", action="store_true", help="skip the sharded contour_beyn extra")
+    ap.add_argument("--no-beyn", action="store_true", help="skip the sharded contour_beyn extra (C4)")
+    ap.add_argument("--no-beyn-parity", action="store_true", help="skip the CPU-oracle twin of C4 (about 5 s)")
     ap.add_argument("--no-wep-roofline", action="store_true", help="skip the waveguide-scale K1 roofline extra")
+    ap.add_argument("--no-c3", action="store_true", help="skip the C3 (nleigs) summary")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 (waveguide tiar, n = 1e6) summary")
+    ap.add_argument("--c5-nx", type=int, default=1003)
+    ap.add_argument("--c5-nz", type=int, default=999)
+    ap.add_argument("--only", default=None, choices=["orth", "k5", "mlincomb"],
+                    help="run only one fixed-shape kernel loop (the command the committed rocprofv3 summaries come from)")
+    ap.add_argument("--reps", type=int, default=50)
     return ap.parse_args()
 
 
-def one_step(na, nep, args, timers=None, hist=None):
-    creator = na.FactorizeLinSolverCreator(permc_spec=args.permc, max_factorizations=0)
-    lam, Q, V = na.iar(nep, sigma=0.0, gamma=1.0, maxit=args.maxit, neigs=np.inf, v=np.ones(nep.n), tol=1e-10,
-                       linsolvercreator=creator, timers=timers, errhist=hist, return_device=True)
-    return lam, Q
+def event_loop(fn, reps, warm=5):
+    """average ms per call of fn, HIP events on the current stream around `reps` back-to-back calls"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
+    ev0.record()
+    for _ in range(reps):
+        fn()
+    ev1.record()
+    torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / reps
 
 
 def mlincomb_roofline(na, nep, k, reps=50):
@@ -68,53 +91,53 @@ def mlincomb_roofline(na, nep, k, reps=50):
     Cm = fD[1:k + 1] / np.arange(1, k + 1)[:, None]
     z = torch.empty(n, dtype=torch.complex128, device="cuda")
     Cdev = na.to_dev(Cm)          # coefficient table resident on the device, as in iar (nep_mlincomb_dev)
-    for _ in range(5):
-        nep.dev.mlincomb_dev(Cdev, k, k, V, n, z)
-    torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for _ in range(reps):
-        nep.dev.mlincomb_dev(Cdev, k, k, V, n, z)
-    ev1.record()
-    torch.cuda.synchronize()
-    ms = ev0.elapsed_time(ev1) / reps
-    byts = nep.dev.algorithmic_bytes(k)
-    return byts, ms
+    ms = event_loop(lambda: nep.dev.mlincomb_dev(Cdev, k, k, V, n, z), reps)
+    return nep.dev.algorithmic_bytes(k), ms
 
 
-def orth_roofline(na, n, k, reps=10):
-    """K6 at the shape of iar step k (block-triangular basis, rows = n(k+1)): one classical Gram-Schmidt pass =
-    k_orth_dots + k_orth_update, the two kernels with the largest share of device time in the timed region
-    (profiles/r1_iar_kernel_stats_v5.csv).  Algorithmic bytes: SURVEY.md section 8d K6 restricted to the non-zero
-    blocks: 2*16*sum_j active_j + 3*16*rows.  Timed with HIP events around asynchronous nep_orth_dev launches."""
+def orth_roofline(na, n, k, reps=20):
+    """K6 at the FIXED shape of iar step k (block-triangular basis, rows = n(k+1)): one classical Gram-Schmidt pass =
+    k_orth_dots + k_orth_update (+ 3 small kernels).  Algorithmic bytes: SURVEY.md section 8d K6 restricted to the non-zero
+    blocks: 2*16*sum_j active_j + 3*16*rows.  Average over `reps` identical asynchronous nep_orth_dev launches."""
     from nep_amd import dense
     rows = n * (k + 1)
     active = (np.arange(1, k + 1) * n).astype(np.int64)
     V = torch.randn((k, rows), dtype=torch.float64, device="cuda").to(torch.complex128)
-    w0 = torch.randn(rows, dtype=torch.float64, device="cuda").to(torch.complex128)
-    w = w0.clone()
+    w = torch.randn(rows, dtype=torch.float64, device="cuda").to(torch.complex128)
     act_d = torch.from_numpy(active).to("cuda")
     out = torch.zeros(k + 2, dtype=torch.complex128, device="cuda")
-    for _ in range(2):
-        dense.orthogonalize_and_normalize_dev(V, w, k, out, rows=rows, ldv=rows, active_dev=act_d, method=dense.CGS)
-    torch.cuda.synchronize()
-    ev0 = torch.cuda.Event(enable_timing=True); ev1 = torch.cuda.Event(enable_timing=True)
-    ev0.record()
-    for _ in range(reps):
-        dense.orthogonalize_and_normalize_dev(V, w, k, out, rows=rows, ldv=rows, active_dev=act_d, method=dense.CGS)
-    ev1.record()
-    torch.cuda.synchronize()
-    ms = ev0.elapsed_time(ev1) / reps
+    ms = event_loop(lambda: dense.orthogonalize_and_normalize_dev(V, w, k, out, rows=rows, ldv=rows, active_dev=act_d,
+                                                                  method=dense.CGS), reps, warm=2)
     byts = 2 * 16 * int(active.sum()) + 3 * 16 * rows
     return {"bound": "hbm", "kernel": "K6 nep_orth_dev, one Gram-Schmidt pass (k_orth_dots + k_orth_update + 3 small "
-            "kernels) at iar step k=%d: rows=%d, block-triangular basis" % (k, rows), "algorithmic_bytes": byts,
-            "ms_per_pass": ms, "achieved": byts / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS}
+            "kernels) at the fixed shape of iar step k=%d: rows=%d, block-triangular basis" % (k, rows),
+            "algorithmic_bytes": byts, "ms_per_pass": ms, "launches_timed": reps, "achieved": byts / ms / 1e6,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS}
+
+
+def k5_roofline(na, nep, args, reps=100):
+    """K5: one fixed-shift solve M(sigma) x = b on the gun matrices; bytes = SURVEY.md section 8d K5
+    (nnz L + nnz U)(16 + 4) + 8(n + 1) + 3*16 n; the schedule itself moves `moved_bytes` (explicit block inverses)"""
+    import scipy.sparse as sp
+    lu = na.DeviceLU(sp.csc_matrix(nep.compute_Mder(0.0), dtype=np.complex128), permc_spec=args.permc, expected_solves=200)
+    n = lu.n
+    B = torch.randn(n, dtype=torch.float64, device="cuda").to(torch.complex128)
+    X = torch.empty_like(B)
+    ms = event_loop(lambda: lu.solve(B, out=X), reps)
+    ba = lu.algorithmic_bytes
+    return {"bound": "hbm (dependent-launch latency in practice)", "kernel": "K5 nep_lu_solve, one right-hand side, gun M(sigma): "
+            "%s" % ("elimination-tree block schedule, %d levels, %d blocks" % (lu.levels, lu.blocks) if lu.block_schedule
+                    else "level schedule"),
+            "launches_per_solve": lu.launches_last_solve(), "nnz_L_plus_U": lu.nnzL + lu.nnzU, "algorithmic_bytes": ba,
+            "moved_bytes": lu.solve_bytes, "ms_per_solve": ms, "achieved": ba / ms / 1e6, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": ba / ms / 1e6 / HBM_PEAK_GBS, "moved_GBps": lu.solve_bytes / ms / 1e6}
 
 
 def beyn_sharded(na, args, world, rank):
     """config C4: contour_beyn on the unscaled gun SPMF, N=64 nodes sharded i = r (mod P) over the ranks, one RCCL
-    all-gather of the 2 n k partial moment block.  Strong scaling (total work fixed).  Timed with barriers."""
-    import torch.distributed as dist
+    all-gather of the 2 n k partial moment block.  Strong scaling (total work fixed).  Timed with barriers.  Parity on rank
+    0: count and eigenvalues against the CPU oracle on the same probe block, backward errors re-evaluated on the host."""
+    import baseline_configs as bc
     nep = na.nep_gallery("gun_spmf", args.n)
     nep.dev
     Vh = na.probe_block(nep.n, 32)
@@ -122,14 +145,13 @@ def beyn_sharded(na, args, world, rank):
     na.HostLUPool.warm(max(2, min(16, -(-64 // max(world, 1)))))
     distd = dist.is_available() and dist.is_initialized()
     integ = na.MatrixTrapezoidalSharded if distd else na.MatrixTrapezoidal
-    kw = dict(sigma=250.0 ** 2, radius=1e4, N=64, k=32, neigs=10 ** 6, tol=1e-6, sanity_check=True, Vh=Vh)
-    na.contour_beyn(nep, integ, **dict(kw, N=8 * world))          # warm-up (graph capture, allocator pools)
+    bc.c4_device(na, nep, integ, Vh=Vh, N=8 * world)          # warm-up (graph capture, allocator pools)
     if distd:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     info = {}
-    lam, V = na.contour_beyn(nep, integ, info=info, **kw)
+    lam, V = bc.c4_device(na, nep, integ, Vh=Vh, info=info)
     if distd:
         dist.barrier()
     torch.cuda.synchronize()
@@ -138,10 +160,58 @@ def beyn_sharded(na, args, world, rank):
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
-    return {"workload": "contour_beyn gun SPMF n=%d N=64 k=32 radius=1e4 sigma=250^2 tol=1e-6" % nep.n,
-            "eigenpairs": int(len(lam)), "seconds": dt, "eigenpairs_per_s": len(lam) / dt, "rank_p": int(info.get("p", -1)),
-            "nodes_per_rank": int(info.get("nodes", 64)), "scaling": "strong",
-            "exchange": "one all_gather of 2*n*k complex128 per rank (%.1f MB)" % (2 * nep.n * 32 * 16 / 1e6) if distd else "none"}
+    out = {"workload": "contour_beyn gun SPMF n=%d N=64 k=32 radius=1e4 sigma=250^2 tol=1e-6" % nep.n,
+           "eigenpairs": int(len(lam)), "seconds": dt, "eigenpairs_per_s": len(lam) / dt, "rank_p": int(info.get("p", -1)),
+           "nodes_per_rank": int(info.get("nodes", 64)), "scaling": "strong",
+           "exchange": "one all_gather of 2*n*k complex128 per rank (%.1f MB)" % (2 * nep.n * 32 * 16 / 1e6) if distd else "none"}
+    if rank == 0:
+        errs = bc.c4_host_errors(nep.n, lam, V)
+        out["max_backward_error"] = max(errs + [0.0])
+        out["inside_contour"] = int(np.sum(abs(np.asarray(lam) - 250.0 ** 2) <= 1e4))   # the rest: accurate pairs just outside, kept last (method_beyncontour.jl:153-163)
+        if not args.no_beyn_parity:
+            t0 = time.perf_counter(); io = {}
+            lo, Vo = bc.c4_oracle(na, nep.n, info=io)
+            to = time.perf_counter() - t0
+            ok, worst = bc.match(lam, lo, 1e-8)
+            out["parity"] = {"oracle_eigenpairs": int(len(lo)), "oracle_rank_p": int(io.get("p", -1)), "oracle_seconds": to,
+                             "same_count": len(lo) == len(lam), "eigenvalues_match_1e-8": bool(ok), "max_rel_eig_diff": worst}
+    return out
+
+
+def c3_summary(na, args):
+    import baseline_configs as bc
+    nep = bc.c3_device_nep(na, args.n)
+    info = {}
+    bc.c3_device(na, nep, info=info)                       # warm-up
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    lam, X, res = bc.c3_device(na, nep, info=info)
+    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    errs = bc.c3_host_errors(args.n, lam, X)
+    out = {"workload": "gun nleigs variant R1 (PEP + LowRankFactorizedNEP, r = %d), maxit=100, leja=0, reusefact=2" % info.get("lowrank_r", -1),
+           "eigenpairs": int(len(lam)), "seconds": dt, "eigenpairs_per_s": len(lam) / dt, "factorizations": int(info.get("nfact", -1)),
+           "max_backward_error": max(errs + [0.0])}
+    t0 = time.perf_counter()
+    lo, Xo, ro = bc.c3_oracle(na, args.n)
+    to = time.perf_counter() - t0
+    ok, worst = bc.match(lam, lo, 1e-8)
+    out["parity"] = {"oracle_eigenpairs": int(len(lo)), "oracle_seconds": to, "same_count": len(lo) == len(lam),
+                     "eigenvalues_match_1e-8": bool(ok), "max_rel_eig_diff": worst}
+    return out
+
+
+def c5_summary(na, args):
+    import baseline_configs as bc
+    tm = {}
+    t0 = time.perf_counter()
+    lam, Q, res, info = bc.c5_device(na, nx=args.c5_nx, nz=args.c5_nz, solver="gmres", timers=tm)
+    dt = time.perf_counter() - t0
+    return {"workload": "WEP JARLEBRING nx=%d nz=%d (n=%d) tiar sigma=-3-3.5i maxit=60 tol=1e-8, Schur complement + "
+                        "Sylvester-SMW preconditioned GMRES (the reference's solver for this problem)" % (args.c5_nx, args.c5_nz, info["n"]),
+            "eigenpairs": int(len(lam)), "max_residual": max(res + [0.0]), "seconds_incl_generation": dt,
+            "seconds_solver": info["solve_s"], "eigenpairs_per_s": len(lam) / info["solve_s"],
+            "generate_s": info["generate_s"], "preconditioner_setup_s": info.get("preconditioner_setup_s"),
+            "phases_s": {k_: round(v_, 4) for k_, v_ in tm.items()},
+            "eigenvalues": [[float(l.real), float(l.imag)] for l in lam[:8]]}
 
 
 def wep_scale_roofline(na):
@@ -153,67 +223,74 @@ def wep_scale_roofline(na):
     n = wd.n
     out = {"workload": "WEP JARLEBRING nx=1003 nz=999: 3 real sparse terms, n=%d, nnz=%d" % (n, dev.nnz), "peak": HBM_PEAK_GBS,
            "unit": "GB/s"}
-    for k in (1, 60):
+    for k in (1, 8, 60):
         V = torch.randn((k, n), dtype=torch.float64, device="cuda").to(torch.complex128)
         Cdev = na.to_dev(np.random.default_rng(0).standard_normal((k, dev.mt)) + 0j)
         z = torch.empty(n, dtype=torch.complex128, device="cuda")
-        for _ in range(3):
-            dev.mlincomb_dev(Cdev, k, k, V, n, z)
-        torch.cuda.synchronize()
-        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            dev.mlincomb_dev(Cdev, k, k, V, n, z)
-        e1.record(); torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / 10
+        ms = event_loop(lambda: dev.mlincomb_dev(Cdev, k, k, V, n, z), 10, warm=3)
         b = dev.algorithmic_bytes(k)
         out["k=%d" % k] = {"algorithmic_bytes": b, "ms_per_launch": ms, "achieved": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS}
         del V
     return out
 
 
+def host_cores():
+    try:
+        import subprocess
+        return int(subprocess.check_output(["nproc", "--all"]).decode().strip())
+    except Exception:
+        return int(os.cpu_count() or 1)
+
+
 def cpu_baseline(args):
-    """CPU oracle on a bounded sample of the same workload: iar with maxit=cpu_maxit (DGKS cost grows
-    ~ m^3, the full m=100 run needs ~1 min on 8 cores) + the C port of compute_Mlincomb at k=100."""
-    from oracle import gallery as og, solvers as osol, neps as oneps, cref
+    """CPU oracle (NumPy/SciPy restatement of the reference path, SuperLU for UMFPACK) on the SAME configuration as the
+    timed GPU step (maxit = args.maxit unless --cpu-maxit bounds it), BLAS threads as set for this process; plus
+    compute_Mlincomb at k = 100 through the C port (1 thread, the reference's per-term gemv + CSC scatter structure) and its
+    OpenMP all-cores variant."""
+    import baseline_configs as bc
+    from oracle import gallery as og, cref
     try:
         from threadpoolctl import threadpool_info
-        nthreads = max([p.get("num_threads", 1) for p in threadpool_info()] + [1])
+        nthreads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] + [1])
     except Exception:
-        nthreads = os.cpu_count()
-    onep = og.gun_spmf_scaled(args.n)
-    m = args.cpu_maxit
-    t0 = time.perf_counter()
-    der = oneps.DerSPMF(onep, 0.0, m)
+        nthreads = int(os.environ.get("OPENBLAS_NUM_THREADS", "1"))
+    m = args.cpu_maxit if args.cpu_maxit > 0 else args.maxit
     tm = {}
-    creator = osol.FactorizeLinSolverCreator(permc_spec=args.permc or "COLAMD")
-    lam, Q, _ = osol.iar(der, sigma=0.0, gamma=1.0, maxit=m, neigs=np.inf, v=np.ones(args.n), tol=1e-10,
-                         errmeasure=osol.StandardSPMFErrmeasure(onep), linsolvercreator=creator, timers=tm)
+    t0 = time.perf_counter()
+    lam, Q = bc.c2_oracle(args.n, maxit=m, permc=args.permc or "MMD_AT_PLUS_A", timers=tm)
     t_iar = time.perf_counter() - t0
-    # C port (single thread) of compute_Mlincomb, reference structure, k = 100
+    onep = og.gun_spmf_scaled(args.n)
     lib = cref.load()
     terms = cref.CscTerms(onep.get_Av())
     k = 100
     rng = np.random.default_rng(0)
     V = np.asfortranarray(rng.standard_normal((args.n, k)) + 1j * rng.standard_normal((args.n, k)))
     Cm = np.asfortranarray(rng.standard_normal((k, terms.mt)) + 0j)
-    cref.mlincomb(lib, terms, Cm, V)
-    reps = 20
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        cref.mlincomb(lib, terms, Cm, V)
-    t_ml = (time.perf_counter() - t0) / reps
     nnz = sum(A.nnz for A in onep.get_Av())
     byts = nnz * 12 + 4 * terms.mt * (args.n + 1) + 16 * args.n * k + 16 * args.n
+
+    def tloop(f, reps):
+        f()
+        t = time.perf_counter()
+        for _ in range(reps):
+            f()
+        return (time.perf_counter() - t) / reps
+    t_ml = tloop(lambda: cref.mlincomb(lib, terms, Cm, V), 20)
+    W = np.empty((args.n, terms.mt), dtype=np.complex128, order="F")
+    t_omp = tloop(lambda: cref.mlincomb_omp(lib, terms, Cm, V, W), 50)
     return {
-        "value": len(lam) / t_iar, "unit": "eigenpairs/s", "cores": int(nthreads), "kind": "port",
-        "sample": "oracle (NumPy/SciPy restatement of the reference path, SuperLU for UMFPACK) iar on the same gun "
-                  "SPMF n=%d with maxit=%d instead of %d: %d eigenpairs in %.2f s (orth %.2f s, mlincomb %.2f s, "
-                  "solve %.2f s, residuals %.2f s)" % (args.n, m, args.maxit, len(lam), t_iar, tm.get("orth", 0),
-                                                       tm.get("mlincomb", 0), tm.get("solve", 0), tm.get("resid", 0)),
-        "mlincomb_GBps_k100": byts / t_ml / 1e9, "mlincomb_ms_k100": t_ml * 1e3,
-        "mlincomb_kind": "C port, 1 thread, per-term gemv + CSC scatter (src/NEPTypes.jl:1006-1007)",
+        "value": len(lam) / t_iar, "unit": "eigenpairs/s", "cores": int(nthreads), "host_cores": host_cores(), "kind": "port",
+        "sample": "oracle (NumPy/SciPy restatement of the reference path, SuperLU for UMFPACK, %d BLAS threads on a %d-core host) "
+                  "iar on the same gun SPMF n=%d, maxit=%d%s: %d eigenpairs in %.2f s (orth %.2f s, mlincomb %.2f s, solve %.2f s, "
+                  "residuals %.2f s)" % (nthreads, host_cores(), args.n, m, "" if m == args.maxit else " instead of %d" % args.maxit,
+                                         len(lam), t_iar, tm.get("orth", 0), tm.get("mlincomb", 0), tm.get("solve", 0), tm.get("resid", 0)),
+        "same_config_as_value": bool(m == args.maxit),
         "eigenpairs": int(len(lam)), "seconds": t_iar,
+        "mlincomb_k100": {"algorithmic_bytes": byts,
+                          "c_port_1_thread": {"ms": t_ml * 1e3, "GBps": byts / t_ml / 1e9,
+                                              "structure": "per-term gemv + CSC scatter (src/NEPTypes.jl:1006-1007)"},
+                          "c_openmp_all_cores": {"ms": t_omp * 1e3, "GBps": byts / t_omp / 1e9, "threads": int(lib.ref_omp_threads()),
+                                                 "structure": "row-parallel: per-thread gemv block + CSR products"}},
     }
 
 
@@ -230,14 +307,27 @@ def main():
     else:
         torch.cuda.set_device(0)
     import nep_amd as na
+    import baseline_configs as bc
     assert na.device_count() >= 1, "bench.py needs a GPU: the backend has no CPU fallback"
 
     nep = na.nep_gallery("gun_spmf_scaled", args.n)
     nep.dev  # build + upload the stacked CSR (inputs resident before the timed region)
     torch.cuda.synchronize()
 
+    if args.only:         # fixed-shape kernel loops: the commands behind profiles/r2_*_kernel_stats.csv
+        if args.only == "orth":
+            print(json.dumps(orth_roofline(na, nep.n, args.maxit, reps=args.reps)))
+        elif args.only == "k5":
+            print(json.dumps(k5_roofline(na, nep, args, reps=args.reps)))
+        else:
+            for k in (args.maxit, 1):
+                b, ms = mlincomb_roofline(na, nep, k, reps=args.reps)
+                print(json.dumps({"kernel": "K1 nep_mlincomb k=%d" % k, "algorithmic_bytes": b, "ms_per_launch": ms,
+                                  "achieved": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS}))
+        return
+
     for _ in range(args.warmup):
-        one_step(na, nep, args)
+        bc.c2_device(na, nep, args.maxit, args.permc)
 
     def barrier():
         if use_dist:
@@ -248,7 +338,7 @@ def main():
     t0 = time.perf_counter()
     pairs = 0
     for _ in range(args.steps):
-        lam, Q = one_step(na, nep, args)
+        lam, Q = bc.c2_device(na, nep, args.maxit, args.permc)
         pairs += len(lam)
     barrier()
     dt = time.perf_counter() - t0
@@ -262,60 +352,56 @@ def main():
     if rank == 0:
         # independent parity check of the returned pairs (host FP64, reference residual criterion)
         Qh = na.to_host(Q)
-        Av = nep.get_Av(); fv = nep.get_fv()
-        maxres = 0.0
-        fro = nep.fro_norms()
-        for s in range(len(lam)):
-            r = sum(f(lam[s]) * (A @ Qh[:, s]) for A, f in zip(Av, fv))
-            den = sum(c * abs(f(lam[s])) for c, f in zip(fro, fv)) * np.linalg.norm(Qh[:, s])
-            maxres = max(maxres, np.linalg.norm(r) / den)
-        # instrumented run: GPU time per phase
+        errs = bc.host_backward_errors(nep.get_Av(), nep.get_fv(), lam, Qh)
+        maxres = max(errs + [0.0])
+        # set-up share: median of 5 separately timed create_linsolver calls (host factorisation + device schedule; the
+        # device-side block inverses run asynchronously behind it and are waited for here)
+        ts = []
+        for _ in range(5):
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            ls = na.create_linsolver(na.FactorizeLinSolverCreator(permc_spec=args.permc, max_factorizations=0), nep, 0.0)
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t1)
+            del ls
+        t_setup = float(np.median(ts))
+        # instrumented run: time per phase (step-synchronous loop)
         tm = {}
-        one_step(na, nep, args, timers=tm)
+        bc.c2_device(na, nep, args.maxit, args.permc, timers=tm)
         k = args.maxit
         byts, ms = mlincomb_roofline(na, nep, k)
         byts1, ms1 = mlincomb_roofline(na, nep, 1)
         achieved = byts / (ms * 1e-3) / 1e9
-        # HBM traffic of the same two kernels from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE and
-        # --pmc WRITE_SIZE runs of scripts/pmc_k1.py; FETCH_SIZE doubled per the gfx950 correction of
-        # MI355X_MICROARCH.md).  Recorded measurement, not live: PMC collection needs rocprofv3 around the process.
-        traffic = None; traffic_src = None
-        try:
-            pj = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_k1_traffic.json")))["gun"]
-            kb = 0.0
-            for name, d in pj.items():
-                if name.startswith("k_vc") or name.startswith("k_spmv grid"):
-                    kb += 2 * d["FETCH_SIZE"]["avg_KB"] + d["WRITE_SIZE"]["avg_KB"]
-            traffic = kb * 1024.0
-            traffic_src = "profiles/r1_pmc_k1_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, k=100, FETCH x2 gfx950 correction)"
-        except Exception:
-            pass
+        ms_step = dt / args.steps * 1e3
+        per_step_pairs = pairs / (args.steps * world)
         out = {
             "metric": "eigenpairs/sec (gun SPMF iar m=%d) + compute_Mlincomb GB/s" % args.maxit,
             "value": pairs / dt, "unit": "eigenpairs/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
             "config": {"workload": "nep_gallery gun SPMF (n=%d, 4 sparse terms, gun-like stand-in K,M + reference W1,W2), "
                                    "shift_and_scale(250^2, 330^2-220^2), iar sigma=0 maxit=%d neigs=Inf tol=1e-10 "
                                    "check_error_every=1 DGKS umfpack_refinements=10; host SuperLU factorisation "
                                    "(UMFPACK-like symmetric strategy) inside the step" % (args.n, args.maxit),
                        "parallelism": "replicas x%d (iar does not shard)" % world,
-                       "eigenpairs_per_step": pairs / (args.steps * world),
+                       "eigenpairs_per_step": per_step_pairs,
                        "max_backward_error": maxres},
+            "value_excl_setup": world * per_step_pairs / max(ms_step * 1e-3 - t_setup, 1e-9),
+            "linsolver_setup_ms": t_setup * 1e3,
             "compute_Mlincomb_GBps": achieved,
-            "roofline_compute_Mlincomb": {"bound": "hbm", "kernel": "nep_mlincomb = k_vc + k_spmv, k=%d columns" % k,
-                         "note": "the kernel BASELINE's metric names; at gun size one call moves 17.8 MB (2.2 us at 8 TB/s) "
-                                 "behind two kernel boundaries, i.e. launch-bound by construction; the HBM-bound size is "
-                                 "roofline_wep_scale",
+            "roofline_compute_Mlincomb": {"bound": "hbm", "kernel": "nep_mlincomb, k=%d columns" % k,
+                         "note": "the kernel BASELINE's metric names; at gun size one call moves 17.8 MB (2.2 us at 8 TB/s), "
+                                 "i.e. launch-bound by construction; the HBM-bound size is roofline_wep_scale",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes": byts, "ms_per_launch": ms,
+                         "algorithmic_bytes": byts, "ms_per_launch": ms,
                          "single_vector": {"algorithmic_bytes": byts1, "ms_per_launch": ms1,
                                            "achieved": byts1 / (ms1 * 1e-3) / 1e9}},
-            "kernels": {"note": "wall ms per phase of one instrumented iar run (torch.cuda.synchronize around each phase)",
+            "kernels": {"note": "wall ms per phase of one instrumented (step-synchronous) iar run",
                         **{k_: round(v * 1e3, 3) for k_, v in tm.items()}},
         }
-        # `roofline` = the dominant kernels of the timed region: K6 (k_orth_dots + k_orth_update hold the largest share
-        # of device time, profiles/r1_iar_kernel_stats_v5.csv), measured live at the shape of the last step
+        dev_phases = ("linsolver_setup", "mlincomb", "solve", "orth", "ritz", "resid")
+        tot = sum(tm.get(p, 0.0) for p in dev_phases)
+        out["phase_share"] = {p: round(tm.get(p, 0.0) / tot, 3) for p in dev_phases} if tot > 0 else {}
+        # `roofline` = the kernel pair with the largest share of device time (rocprofv3: k_orth_dots + k_orth_update,
+        # profiles/r2_iar_kernel_stats.csv), one pass at a fixed shape, averaged
         try:
             rf = orth_roofline(na, nep.n, args.maxit)
             try:
@@ -329,21 +415,22 @@ def main():
                                         "scripts/kernel_bench.py gun, same shape; 2*FETCH + WRITE per the gfx950 note)")
             except Exception:
                 rf["traffic"] = None
-            try:                                      # context: what a plain streaming read reaches on this box, same run
-                xs = torch.rand(1 << 26, dtype=torch.float64, device="cuda")          # 512 MiB
-                xs.sum(); torch.cuda.synchronize()
-                e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
-                e0.record()
-                for _ in range(20):
-                    xs.sum()
-                e1.record(); torch.cuda.synchronize()
-                rf["stream_read_reference"] = {"kernel": "torch.sum over 512 MiB float64", "GB/s": 8.0 * (1 << 26) * 20 / e0.elapsed_time(e1) / 1e6}
-                del xs
-            except Exception:
-                pass
+            rf["share_of_step"] = out["phase_share"].get("orth")
             out["roofline"] = rf
         except Exception as e:
             out["roofline"] = {"error": repr(e)[:200]}
+        try:
+            out["roofline_k5"] = k5_roofline(na, nep, args)
+            out["roofline_k5"]["share_of_step"] = out["phase_share"].get("solve")
+        except Exception as e:
+            out["roofline_k5"] = {"error": repr(e)[:200]}
+        try:                                      # context: what a plain streaming read reaches on this box, same run
+            xs = torch.rand(1 << 26, dtype=torch.float64, device="cuda")          # 512 MiB
+            ms_s = event_loop(lambda: xs.sum(), 20, warm=2)
+            out["stream_read_reference"] = {"kernel": "torch.sum over 512 MiB float64", "GB/s": 8.0 * (1 << 26) / ms_s / 1e6}
+            del xs
+        except Exception:
+            pass
         if world == 1 and not args.no_wep_roofline:
             try:
                 out["roofline_wep_scale"] = wep_scale_roofline(na)
@@ -351,6 +438,11 @@ def main():
                 out["roofline_wep_scale"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
+        if world == 1 and not args.no_c3:
+            try:
+                out["c3_nleigs"] = c3_summary(na, args)
+            except Exception as e:
+                out["c3_nleigs"] = {"error": repr(e)[:300]}
     # extra (outside the headline timed region): the path that DOES shard -- Beyn's quadrature nodes over the ranks
     beyn = None
     if not args.no_beyn:
@@ -358,6 +450,11 @@ def main():
             beyn = beyn_sharded(na, args, world, rank)
         except Exception as e:                       # never lose the headline line because of the extra
             beyn = {"error": repr(e)[:300]}
+    if rank == 0 and world == 1 and not args.no_c5:
+        try:
+            out["c5_wep"] = c5_summary(na, args)
+        except Exception as e:
+            out["c5_wep"] = {"error": repr(e)[:300]}
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

@@ -94,7 +94,7 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     # the iteration, the (at most LAG+1) speculative Arnoldi steps beyond k are simply dropped.
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
-    LAG = 3                        # host eig of up to LAG+1 consecutive steps in flight
+    LAG = int(os.environ.get("NEP_IAR_LAG", "9"))      # host eig of up to LAG+1 consecutive steps in flight
     pool = ThreadPoolExecutor(max_workers=LAG + 1)
     state = {"lam": lam, "QT": QT, "idx": idx, "conv_eig": 0, "k_checked": 0}
 

@@ -513,3 +513,22 @@ def test_wep_linsolvers_oracle_resinv(solver_type):
     kw = (("Pl", wl.wep_generate_preconditioner(nep, 21, lam0)), ("reltol", 1e-7)) if solver_type == "gmres" else ()
     lam, v = solvers.resinv(nep, lam=lam0, v=v0, errmeasure=E, tol=1e-12, linsolvercreator=wl.WEPLinSolverCreator(solver_type, kwargs=kw))
     assert np.linalg.norm(nep.compute_Mlincomb(lam, v)) / np.linalg.norm(v) < 1e-10 and abs(lam - lref) < 1e-10
+
+
+def test_c_port_of_compute_Mlincomb():
+    """oracle/c/nep_cpu.c (single-thread reference structure and the OpenMP all-cores variant, both timed by bench.py's
+    cpu_baseline) against the NumPy oracle on the gun stand-in with the four gun functions"""
+    from oracle import cref
+    onep = gallery.gun_spmf_scaled(1310)
+    lib = cref.load()
+    terms = cref.CscTerms(onep.get_Av())
+    rng = np.random.default_rng(4)
+    for k in (1, 2, 7, 33):
+        V = rng.standard_normal((1310, k)) + 1j * rng.standard_normal((1310, k))
+        Cm = rng.standard_normal((k, terms.mt)) + 1j * rng.standard_normal((k, terms.mt))
+        ref = sum(A @ (V @ Cm[:, i]) for i, A in enumerate(onep.get_Av()))
+        z1 = cref.mlincomb(lib, terms, Cm, V)
+        z2 = cref.mlincomb_omp(lib, terms, Cm, V)
+        assert np.linalg.norm(z1 - ref) <= 1e-13 * np.linalg.norm(ref)
+        assert np.linalg.norm(z2 - ref) <= 1e-13 * np.linalg.norm(ref)
+    assert lib.ref_omp_threads() >= 1
