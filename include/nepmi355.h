@@ -34,6 +34,7 @@ extern "C" {
 typedef struct { double re, im; } nep_cdouble;
 typedef struct nep_spmf nep_spmf; /* device-resident SPMF: stacked CSR of A_1..A_mt */
 typedef struct nep_lu nep_lu;     /* device-resident sparse LU factors + solve schedule */
+typedef struct nep_comm nep_comm; /* one rank of the multi-GPU exchange (RCCL communicator) */
 typedef void* nep_stream;
 
 #define NEP_OK 0
@@ -311,6 +312,24 @@ int32_t nep_rowmajor_colnorms(int64_t rows, int32_t k, const nep_cdouble* dXT, i
 int32_t nep_rowmajor_to_colmajor(int64_t rows, int32_t k, const nep_cdouble* dsrc, int64_t lds,
                                  const int32_t* h_cols, int32_t ncols, nep_cdouble* ddst,
                                  int64_t ldd, nep_stream stream);
+
+/* ---- multi-GPU exchange of the contour integrators ----------------------------------------
+ * replaces: the reduction inside `integrate_interval(::Type{<:MatrixIntegrator}, ...)` src/method_contour_common.jl:46,61-94
+ *           when the N quadrature nodes of contour_beyn / contour_block_SS (src/method_beyncontour.jl:89-104,
+ *           src/method_block_SS.jl:81-86,129-135) are sharded over the GPUs of one node: rank r owns the nodes
+ *           i = r (mod P) and accumulates their moments locally; the only exchange is one all-gather of the partial
+ *           moment block followed by a sum in fixed rank order (bit-identical result on every rank).
+ * One process per GPU.  Rank 0 obtains a 128-byte unique id and hands it to the other ranks out of band (MPI.jl bcast,
+ * torch.distributed, a shared file); every rank then creates its communicator on ITS current device (collective call).
+ * RCCL (librccl.so) is loaded on first use. */
+int32_t nep_comm_unique_id(void* h_out128);
+int32_t nep_comm_create(int32_t rank, int32_t world, const void* h_unique_id128, nep_comm** out);
+int32_t nep_comm_destroy(nep_comm* c);
+int32_t nep_comm_info(const nep_comm* c, int32_t out[2]);     /* out[0] = rank, out[1] = world */
+/* d_total[i] = sum_{r=0}^{world-1} partial_r[i], i < len (complex128), on every rank; ncclAllGather over xGMI into a
+ * library-owned world x len block + one summation kernel, all on `stream` (asynchronous).  d_total may alias
+ * d_partial. */
+int32_t nep_allgather_sum(nep_comm* c, const nep_cdouble* d_partial, int64_t len, nep_cdouble* d_total, nep_stream stream);
 
 #ifdef __cplusplus
 }

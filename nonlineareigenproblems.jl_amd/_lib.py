@@ -92,6 +92,11 @@ SIGNATURES = {
     "nep_lu_schedule": [c_vp, P(c_i64)],
     "nep_lu_solve": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp],
     "nep_lu_solve_add": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp],
+    "nep_comm_unique_id": [c_vp],
+    "nep_comm_create": [c_i32, c_i32, c_vp, P(c_vp)],
+    "nep_comm_destroy": [c_vp],
+    "nep_comm_info": [c_vp, P(c_i32)],
+    "nep_allgather_sum": [c_vp, c_vp, c_i64, c_vp, c_vp],
     "nep_iar_shift_scale": [c_i64, c_i32, c_vp, c_vp, c_vp],
     "nep_rk_bw": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
     "nep_block_recur": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],

@@ -1,0 +1,58 @@
+"""The multi-GPU exchange of the contour integrators through the C ABI (nep_comm_create / nep_allgather_sum, csrc/comm.hip):
+one RCCL communicator per process (= per GPU), an all-gather of the partial moment block over xGMI and a sum in fixed rank
+order.  The 128-byte unique id reaches the ranks out of band -- here through torch.distributed's process group (any backend),
+in a Julia host through MPI.jl."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import lib, check, c_vp, hptr
+from .nep import stream_ptr
+
+
+class DeviceComm:
+    def __init__(self, rank, world, unique_id):
+        assert len(unique_id) == 128
+        self.rank, self.world = int(rank), int(world)
+        self._uid = np.frombuffer(bytes(unique_id), dtype=np.uint8).copy()
+        h = c_vp()
+        check(lib.nep_comm_create(self.rank, self.world, hptr(self._uid), C.byref(h)))
+        self.h = h
+
+    @staticmethod
+    def unique_id():
+        uid = np.zeros(128, dtype=np.uint8)
+        check(lib.nep_comm_unique_id(hptr(uid)))
+        return uid.tobytes()
+
+    _from_dist = None
+
+    @classmethod
+    def from_torch_distributed(cls):
+        """communicator spanning the default torch.distributed group (created once per process)"""
+        import torch.distributed as dist
+        if cls._from_dist is None:
+            rank, world = dist.get_rank(), dist.get_world_size()
+            box = [cls.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            cls._from_dist = cls(rank, world, box[0])
+        return cls._from_dist
+
+    def allgather_sum(self, S, out=None):
+        """out = sum over ranks of S (device complex128 tensor, same shape on every rank), identical on every rank"""
+        out = S if out is None else out
+        check(lib.nep_allgather_sum(self.h, c_vp(S.data_ptr()), S.numel(), c_vp(out.data_ptr()), stream_ptr()))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.nep_comm_destroy(self.h)
+            self.h = None
+            if DeviceComm._from_dist is self:
+                DeviceComm._from_dist = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -37,8 +37,12 @@ class MatrixTrapezoidal(MatrixIntegrator):
 
 
 class MatrixTrapezoidalSharded(MatrixIntegrator):
-    """trapezoidal rule with the N nodes sharded over torch.distributed ranks (RCCL all-gather)"""
+    """trapezoidal rule with the N nodes sharded over the ranks (one process per GPU): rank r owns the nodes i = r (mod P);
+    the exchange is nep_allgather_sum of the C ABI (RCCL all-gather over xGMI + fixed-order sum, csrc/comm.hip).  `comm`: a
+    comm.DeviceComm; None = the communicator spanning torch.distributed's default group (created on first use).  CPU
+    tensors (the gloo test of the sharding logic) are exchanged through torch.distributed itself."""
     sharded = True
+    comm = None
 
 
 class _DeviceOps:
@@ -57,7 +61,10 @@ def integrate_interval(ST, f, gv, a, b, N, info=None, ops=_DeviceOps):
     m = len(gv)
     G = np.array([[g(tt) for g in gv] for tt in t], dtype=np.complex128)    # N x m
     world, rank = 1, 0
-    if getattr(ST, "sharded", False) and dist.is_available() and dist.is_initialized():
+    comm = getattr(ST, "comm", None) if getattr(ST, "sharded", False) else None
+    if comm is not None:
+        world, rank = comm.world, comm.rank
+    elif getattr(ST, "sharded", False) and dist.is_available() and dist.is_initialized():
         world, rank = dist.get_world_size(), dist.get_rank()
     S = None
     mine = range(rank, N, world)
@@ -71,9 +78,14 @@ def integrate_interval(ST, f, gv, a, b, N, info=None, ops=_DeviceOps):
             ops.axpy(c * G[i, j], X, S[j])
     if S is None:
         raise ValueError("rank %d owns no quadrature node (N=%d < world size %d)" % (rank, N, world))
-    if world > 1:
+    if getattr(ST, "sharded", False) and S.is_cuda and (comm is not None or (dist.is_available() and dist.is_initialized())):
+        if comm is None:
+            from .comm import DeviceComm
+            comm = DeviceComm.from_torch_distributed()
+        comm.allgather_sum(S)                      # C ABI: RCCL all-gather over xGMI (2*n*k complex128 per rank) + fixed-order sum
+    elif world > 1:
         parts = [torch.empty_like(S) for _ in range(world)]
-        dist.all_gather(parts, S)                  # RCCL over xGMI: 2*n*k complex128 per rank
+        dist.all_gather(parts, S)                  # CPU tensors (gloo test of the sharding logic)
         S = torch.zeros_like(S)
         for p in parts:                            # fixed rank order -> identical on every rank
             ops.axpy(1.0, p, S)

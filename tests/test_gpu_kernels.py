@@ -606,3 +606,19 @@ def test_gemv_hd_vs_numpy(na, rows, k):
     check(lib.nep_gemv_hd(c_vp(Ad.data_ptr()), lda, rows, k, c_vp(xd.data_ptr()), c_vp(dd.data_ptr()), c_vp(y.data_ptr()), None))
     torch.cuda.synchronize()
     assert np.linalg.norm(y.cpu().numpy() - d * ref) <= 1e-13 * np.linalg.norm(d * ref)
+
+
+def test_plain_c_smoke_program():
+    """examples/smoke_c.c: the C ABI driven from a plain C process (no Python, no torch): nep_spmf_create -> nep_mlincomb ->
+    nep_lu_create_csc / nep_lu_solve -> nep_orth -> nep_gemm_ts, each checked against host arithmetic inside the program"""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "smoke_c")
+    if not os.path.exists(exe):
+        subprocess.check_call(["gcc", "-O2", "-I", os.path.join(root, "include"), os.path.join(root, "examples", "smoke_c.c"), "-o", exe,
+                               "-L", os.path.join(root, "nonlineareigenproblems.jl_amd"), "-lnepmi355", "-lm",
+                               "-Wl,-rpath,$ORIGIN/../nonlineareigenproblems.jl_amd"])
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "smoke_c ok" in p.stdout

@@ -856,3 +856,38 @@ def test_wep_nep_solvers_with_schur_linsolver(na):
                                  refinements=10)
     lam2, Q2, _, _ = na.tiar(nep, sigma=lam0, neigs=3, maxit=100, v=v0, tol=1e-8, linsolvercreator=crg)
     assert min(abs(lref - lam2)) < 1e-10
+
+
+def test_sharded_beyn_through_the_c_abi_one_rank_rccl(na):
+    """the multi-rank exchange of the C ABI (nep_comm_unique_id / nep_comm_create / nep_allgather_sum, csrc/comm.hip) with a
+    real RCCL communicator of one rank: the all-gather + fixed-order sum is the identity, in place and out of place, and
+    contour_beyn through MatrixTrapezoidalSharded (nodes i = r mod P) returns the eigenpairs of the unsharded integrator
+    bit for bit"""
+    import torch
+    uid = na.DeviceComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = na.DeviceComm(0, 1, uid)
+    try:
+        import ctypes as C
+        info = (C.c_int32 * 2)()
+        assert na._lib.lib.nep_comm_info(comm.h, info) == 0 and list(info) == [0, 1]
+        S = torch.randn(3, 7, 129, dtype=torch.float64, device="cuda").to(torch.complex128)
+        ref = S.clone()
+        out = torch.empty_like(S)
+        comm.allgather_sum(S, out)
+        comm.allgather_sum(S)                              # in place
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref) and torch.equal(S, ref)
+        nep = na.nep_gallery("dep0")
+        lam0, V0 = na.contour_beyn(nep, na.MatrixTrapezoidal, sigma=0.2, radius=1.0, neigs=4, N=200, sanity_check=False)
+        na.MatrixTrapezoidalSharded.comm = comm
+        info = {}
+        lam1, V1 = na.contour_beyn(nep, na.MatrixTrapezoidalSharded, sigma=0.2, radius=1.0, neigs=4, N=200, sanity_check=False, info=info)
+        assert info["world"] == 1 and info["nodes"] == 200
+        assert np.array_equal(lam0, lam1) and np.array_equal(V0, V1)
+        # argument errors never reach RCCL
+        assert na._lib.lib.nep_allgather_sum(comm.h, None, 5, None, None) == -2
+        assert na._lib.lib.nep_comm_create(2, 2, None, None) == -2
+    finally:
+        na.MatrixTrapezoidalSharded.comm = None
+        comm.close()
