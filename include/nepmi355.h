@@ -225,8 +225,9 @@ int32_t nep_lu_create_csc(int64_t n, const int32_t* hLp, const int32_t* hLi, con
  * invert the diagonal blocks.  The symbolic analysis (elimination tree, block partition, index arrays) is also shared
  * automatically between nep_lu_create[_csc] calls whose L/U patterns and permutations coincide (pattern-hash cache). */
 int32_t nep_lu_refactor(nep_lu* lu, const nep_cdouble* hLx, const nep_cdouble* hUx);
-/* Row scaling of the factorised matrix: the factors are those of Pr*diag(rs)*A*Pc (UMFPACK's `F.Rs`: L*U = P*(Rs.\A)*Q
- * has rs = 1 ./ Rs), so every right-hand side is multiplied by rs on the way in.  h_rs: n doubles, NULL removes it. */
+/* Row scaling of the factorised matrix: the factors are those of Pr*diag(rs)*A*Pc (Julia's UMFPACK wrapper:
+ * F.L*F.U == (F.Rs .* A)[F.p, F.q], i.e. rs = F.Rs), so every right-hand side is multiplied by rs on the way in (inside the
+ * first kernel of the solve).  h_rs: n doubles, NULL removes it. */
 int32_t nep_lu_set_row_scale(nep_lu* lu, const double* h_rs);
 int32_t nep_lu_destroy(nep_lu* lu);
 /* hint for the NEXT nep_lu_create of the calling thread: how many solves the factorisation will serve (default 50).
