@@ -232,7 +232,7 @@ def contour_beyn(nep, MIntegrator=MatrixTrapezoidal, tol=np.sqrt(EPS), sigma=0.0
     V0d = to_dev(V0)
     QT = dense.gemm_ts(V0d, VB, rowmajor=True)                 # (n, p) row-major
     if info is not None:
-        info.update(p=p, S=Sv)
+        info.update(p=p, S=Sv, A0=A0, A1=A1)
 
     def inside(l):
         return ((l - sigma).real / radius[0]) ** 2 + ((l - sigma).imag / radius[1]) ** 2 <= 1

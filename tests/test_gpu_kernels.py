@@ -622,3 +622,51 @@ def test_plain_c_smoke_program():
     p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "smoke_c ok" in p.stdout
+
+
+def test_concurrent_lu_create_solve_stress(na):
+    """the path Beyn uses: several host threads create, solve with and drop factorisations at the same time (shared pattern
+    -> shared symbolic analysis from the cache, different values; per-build streams; stream-ordered pool frees) while the
+    main thread keeps solving with a long-lived factorisation.  Every result is checked."""
+    import threading
+    import _nep_hostlu as hl
+    from oracle import gallery as og
+    nep = og.nlevp_native_gun(1310)
+    n = nep.n
+    rng = np.random.default_rng(17)
+    shifts = [250.0 ** 2 + 1j, 255.0 ** 2 + 3j, 245.0 ** 2 + 0.5j, 262.0 ** 2 + 2j]
+    mats = [sp.csc_matrix(nep.compute_Mder(s), dtype=complex) for s in shifts]
+    facs = [hl.factor(A.data, A.indices, A.indptr, A.shape) for A in mats]
+    B = rng.standard_normal((n, 4)) + 1j * rng.standard_normal((n, 4))
+    Bd = na.to_dev(B)
+    errors = []
+
+    def worker(tid):
+        try:
+            import torch
+            torch.cuda.set_device(0)
+            for it in range(12):
+                i = (tid + it) % len(facs)
+                lu = na.DeviceLU(factors=facs[i], expected_solves=1 if it % 2 else 200)
+                X = lu.solve(Bd)
+                if it % 3 == 0:
+                    lu.refactor(facs[i]["Lx"], facs[i]["Ux"])
+                    X = lu.solve(Bd)
+                Xh = na.to_host(X)
+                del lu
+                r = np.linalg.norm(mats[i] @ Xh - B) / np.linalg.norm(B)
+                if not r < 1e-9:
+                    errors.append((tid, it, r))
+        except Exception as e:                      # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    main_lu = na.DeviceLU(factors=facs[0], expected_solves=200)
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for t in th:
+        t.start()
+    for _ in range(200):
+        Xm = main_lu.solve(Bd)
+    for t in th:
+        t.join()
+    assert not errors, errors[:3]
+    assert np.linalg.norm(mats[0] @ na.to_host(Xm) - B) <= 1e-9 * np.linalg.norm(B)

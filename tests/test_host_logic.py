@@ -371,3 +371,16 @@ def test_compute_Mder_union_pattern_equals_term_by_term_sum():
     from oracle import wep as ow
     lam = -1.3 - 0.31j
     assert abs(w.compute_Mder(lam) - ow.WEP_FD(11, 7, "TAUSCH").compute_Mder(lam)).max() < 1e-12
+
+
+def test_asan_host_analysis():
+    """AddressSanitizer + UBSan build of the library's host side (tests/sanitize/Makefile) running the K5 symbolic analysis
+    on random patterns from 4 threads: no report, no leak (sanitizer target)"""
+    import shutil
+    import subprocess
+    if not os.path.exists("/opt/rocm/bin/hipcc") or shutil.which("make") is None:
+        pytest.skip("needs hipcc + make")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(["make", "-C", os.path.join(root, "tests", "sanitize"), "run"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
+    assert "asan_driver ok" in p.stdout
