@@ -154,10 +154,10 @@ def require_gpu():
         except Exception:
             pass
         import sys
-        pkg = os.path.dirname(os.path.abspath(__file__))
-        if pkg not in sys.path:
-            sys.path.insert(0, pkg)
-        import _nep_hostlu               # big BLAS thread pools make the host side stall at random (see there)
+        wdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_workers")
+        if wdir not in sys.path:
+            sys.path.insert(0, wdir)
+        import nep_amd_hostlu as _nep_hostlu               # big BLAS thread pools make the host side stall at random (see there)
         _nep_hostlu.cap_blas_threads()
 
 

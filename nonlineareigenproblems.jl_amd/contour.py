@@ -145,7 +145,7 @@ class _NodeSolve:
             self._t0 = _t.perf_counter(); self._host_done = []
         for t in ts:
             A = self.nep.compute_Mder(self.g(t) + self.sigma)
-            self.host[t] = HostLUPool.submit(A, permc_spec=c.permc_spec, **c.lu_kw)
+            self.host[t] = HostLUPool.submit(A, workers=workers, permc_spec=c.permc_spec, **c.lu_kw)
             if trace:
                 self.host[t].add_done_callback(lambda f, s=self: s._host_done.append(_t.perf_counter() - s._t0))
         if trace:
@@ -158,6 +158,22 @@ class _NodeSolve:
                 f.cancel()
             self.pool.shutdown(wait=True)
             self.pool = None
+            # host factorisations that finished (or still finish) but were never turned into a DeviceLU own a shared-memory
+            # block nobody else will unlink (the worker handed ownership to this process): release it
+            import nep_amd_hostlu as hl
+
+            def _release(fut):
+                try:
+                    meta = fut.result()
+                    if isinstance(meta, dict) and "shm_name" in meta:
+                        hl.release_shm(hl.attach_shm(meta))
+                except BaseException:
+                    pass
+            for f in self.host.values():
+                if f.done():
+                    _release(f)
+                else:
+                    f.add_done_callback(_release)
             self.built.clear(); self.host.clear()
 
     def __call__(self, t):

@@ -211,7 +211,7 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     pending = deque()              # (k, future) in increasing k; checks are always consumed in order
     # the k x k eigenproblems gain nothing from a threaded BLAS (7.5 ms at k=100 with 1 or 64 threads) while its
     # spinning worker threads slow the launching thread down: pin BLAS to one thread for the duration of the loop
-    import _nep_hostlu
+    import nep_amd_hostlu as _nep_hostlu
     ctl = _nep_hostlu.blas_controller()
     blas_guard = ctl.limit(limits=1) if ctl is not None else None
     if blas_guard is not None:

@@ -28,10 +28,12 @@ class LinSolver:
     pass
 
 
-_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-if _PKG_DIR not in sys.path:
-    sys.path.insert(0, _PKG_DIR)          # makes the torch-free worker module importable by name (also in spawned workers)
-import _nep_hostlu  # noqa: E402
+# the torch-free worker module lives alone in _workers/ under a unique top-level name: only that directory goes on
+# sys.path (spawned workers import it by name), so no module of this package can shadow a user's `build`, `nep`, ...
+_WORKERS_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_workers")
+if _WORKERS_DIR not in sys.path:
+    sys.path.insert(0, _WORKERS_DIR)
+import nep_amd_hostlu as _nep_hostlu  # noqa: E402
 
 
 class HostLUPool:
@@ -94,11 +96,13 @@ class HostLUPool:
         cls.get(workers)
 
     @classmethod
-    def submit(cls, A, **kw):
+    def submit(cls, A, workers=None, **kw):
         """future of the factor METADATA; the arrays sit in a shared-memory block: DeviceLU(factors=meta) maps, uploads
-        and unlinks it (a result that is never consumed leaves its block to the resource tracker at exit)"""
+        and unlinks it; a result that is never consumed must be released by its holder (contour._NodeSolve.close does)"""
         Ac = sp.csc_matrix(A, dtype=np.complex128)
-        return cls.get().submit(_nep_hostlu.factor_shm, Ac.data, Ac.indices, Ac.indptr, Ac.shape, **kw)
+        # `workers` (BackslashLinSolverCreator(workers=N)) sizes the pool when it has to be started; a running pool is kept
+        pool = cls._pool if cls._pool is not None else cls.get(workers)
+        return pool.submit(_nep_hostlu.factor_shm, Ac.data, Ac.indices, Ac.indptr, Ac.shape, **kw)
 
 
 import atexit  # noqa: E402

@@ -290,17 +290,29 @@ class AbstractSPMF(NEP):
             cs = [sp.csc_matrix(A) for A in Av]
             for M in cs:
                 M.sum_duplicates(); M.sort_indices()
-            U = cs[0].astype(bool).astype(np.int8)
-            for M in cs[1:]:
-                U = U + M.astype(bool).astype(np.int8)
-            U = sp.csc_matrix(U); U.sort_indices()
-            colU = np.repeat(np.arange(U.shape[1], dtype=np.int64), np.diff(U.indptr))
-            keyU = colU * n + U.indices                                    # increasing: columns ascending, rows sorted inside
-            D = np.zeros((U.nnz, len(cs)), dtype=np.complex128)           # nnz x m_t: a tall matrix-vector product per shift
-            for t, M in enumerate(cs):
+            # union pattern from the entry KEYS (column * n + row), stored zeros included: a sparse add of pattern matrices
+            # would drop explicitly stored zeros (their slot would then be missing below) and wraps at 256 overlapping terms
+            keys = []
+            for M in cs:
                 colM = np.repeat(np.arange(M.shape[1], dtype=np.int64), np.diff(M.indptr))
-                pos = np.searchsorted(keyU, colM * n + M.indices)
+                keys.append(colM * n + M.indices)
+            keyU = np.unique(np.concatenate(keys))                         # increasing: columns ascending, rows sorted inside
+            nnz_sum = sum(len(k_) for k_ in keys)
+            if len(keyU) * len(cs) > 8 * max(nnz_sum, 1) and len(keyU) * len(cs) > (1 << 22):
+                return None                                                # many disjoint (low-rank) terms: the dense nnz_union x m_t
+            D = np.zeros((len(keyU), len(cs)), dtype=np.complex128)       #   block would dwarf sum(nnz); compute_Mder sums term by term
+            for t, (M, key) in enumerate(zip(cs, keys)):
+                pos = np.searchsorted(keyU, key)
+                assert np.array_equal(keyU[pos], key)
                 D[pos, t] = M.data
+            indices = (keyU % n).astype(np.int32)
+            indptr = np.zeros(n + 1, dtype=np.int32)
+            np.add.at(indptr, (keyU // n) + 1, 1)
+            indptr = np.cumsum(indptr).astype(np.int32)
+
+            class _U:                                                      # the three attributes the caller reads
+                pass
+            U = _U(); U.indptr = indptr; U.indices = indices
             self._aligned = (U.indptr.copy(), U.indices.copy(), D)
         return self._aligned
 

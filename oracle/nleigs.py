@@ -476,6 +476,9 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
         k += 1
     if info is not None:
         info.update(kconv=kconv, N=N, k=min(k, kmax), nfact=len(cache.solvers), nrmD=nrmD, nblamin=nblamin)
+        if info.get("_debug"):          # diagnostic hook (scripts/diag): the Krylov relation of the final run
+            info.update(V=V, H=H, K=K, sigma=sigma, xi=xi, beta=beta, kn=kn, l=l, P=P, sgdd=sgdd, D=D, cache=cache,
+                        computeD=computeD)
     if return_details:                                                              # :363-374
         kk = min(k, kmax)
         if expand:

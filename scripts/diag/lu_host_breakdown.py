@@ -1,6 +1,6 @@
 import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla, torch, nep_amd as na
-from nep_amd import _nep_hostlu
+from nep_amd import nep_amd_hostlu as _nep_hostlu
 nep = na.nep_gallery("gun_spmf_scaled"); nep.dev
 A = nep.compute_Mder(0.0)
 T=time.perf_counter

@@ -1,6 +1,6 @@
 import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch, nep_amd as na
-from nep_amd import _nep_hostlu
+from nep_amd import nep_amd_hostlu as _nep_hostlu
 import scipy.sparse as sp
 if sys.argv[1]=="gun":
     nep=na.nep_gallery("gun_spmf_scaled"); n=nep.n

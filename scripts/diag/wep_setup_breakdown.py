@@ -1,7 +1,7 @@
 import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS"): os.environ.setdefault(_v, "8")
 import numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla, torch, nep_amd as na
-from nep_amd import _nep_hostlu
+from nep_amd import nep_amd_hostlu as _nep_hostlu
 nx, nz = int(sys.argv[1]), int(sys.argv[2])
 T = time.perf_counter
 t0 = T(); nep = na.nep_gallery("WEP", nx=nx, nz=nz, benchmark_problem="JARLEBRING"); nep.dev; t1 = T()

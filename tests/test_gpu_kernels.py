@@ -242,7 +242,7 @@ def test_lu_block_schedule(na, spec, monkeypatch):
     product, graph / eager) returns SuperLU's solution; CSR and CSC input; nrhs 1, 5, 32; in-place, scale, fused update"""
     for k_, v_ in spec.items():
         monkeypatch.setenv(k_, v_)
-    import _nep_hostlu as hl
+    import nep_amd_hostlu as hl
     from oracle import gallery as og
     nep = og.nlevp_native_gun(1310)
     A = sp.csc_matrix(nep.compute_Mder(250.0 ** 2 + 1j), dtype=complex)
@@ -275,7 +275,7 @@ def test_lu_refactor_rowscale_and_pattern_cache(na, monkeypatch):
     """nep_lu_refactor (same pattern, new values: src/method_beyncontour.jl:89-94), nep_lu_set_row_scale (UMFPACK's Rs) and
     the pattern-hash cache of the symbolic analysis; destroying a factorisation right after an asynchronous solve is safe
     (stream-ordered frees)"""
-    import _nep_hostlu as hl
+    import nep_amd_hostlu as hl
     from oracle import gallery as og
     nep = og.nlevp_native_gun(1310)
     n = nep.n
@@ -629,7 +629,7 @@ def test_concurrent_lu_create_solve_stress(na):
     -> shared symbolic analysis from the cache, different values; per-build streams; stream-ordered pool frees) while the
     main thread keeps solving with a long-lived factorisation.  Every result is checked."""
     import threading
-    import _nep_hostlu as hl
+    import nep_amd_hostlu as hl
     from oracle import gallery as og
     nep = og.nlevp_native_gun(1310)
     n = nep.n

@@ -161,7 +161,7 @@ def test_rk_helper_matches_oracle():
 
 def test_hostlu_factor_strategy():
     """UMFPACK-like strategy selection and factor layout (torch-free worker module)"""
-    import _nep_hostlu as hl
+    import nep_amd_hostlu as hl
     import scipy.sparse.linalg as spla
     A = sp.csc_matrix(og.gun_spmf(655).compute_Mder(250.0 ** 2 + 1j), dtype=complex)
     F = hl.factor(A.data, A.indices, A.indptr, A.shape)
@@ -221,7 +221,7 @@ def test_lu_block_schedule_analysis(case, monkeypatch):
     NumPy restatement; every dependency of L (U) stays inside its diagonal block or points to an earlier (later) level;
     the block solve built from that partition reproduces the direct solution"""
     import ctypes as C
-    import _nep_hostlu as hl
+    import nep_amd_hostlu as hl
     monkeypatch.setenv("NEP_ML_BMAX", "128")
     rng = np.random.default_rng(3)
     if case == "gun_sym":
@@ -384,3 +384,22 @@ def test_asan_host_analysis():
     p = subprocess.run(["make", "-C", os.path.join(root, "tests", "sanitize"), "run"], capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-4000:]
     assert "asan_driver ok" in p.stdout
+
+
+def test_compute_Mder_union_pattern_with_stored_zeros_and_many_terms():
+    """the union pattern of compute_Mder is built from entry keys: explicitly stored zeros keep their slot (a sparse add of
+    pattern matrices dropped them -> IndexError when the entry had the largest key), and 300 overlapping terms do not wrap"""
+    n = 40
+    rng = np.random.default_rng(8)
+    A0 = sp.random(n, n, 0.1, random_state=rng, format="csc") + sp.identity(n, format="csc")
+    A1 = sp.csc_matrix(([0.0, 2.0], ([n - 1, 3], [n - 1, 5])), shape=(n, n))     # stored zero at the largest key, no eliminate_zeros
+    A1 = sp.csc_matrix((np.array([2.0, 0.0]), np.array([3, n - 2]), np.r_[np.zeros(6), np.ones(n - 6), 2].astype(int)), shape=(n, n))
+    assert A1.nnz == 2 and 0.0 in A1.data
+    nep = na.SPMF_NEP([A0, A1], [na.funcs.one(), na.funcs.ident()])
+    lam = 0.3 + 0.1j
+    M = nep.compute_Mder(lam)
+    ref = A0 + lam * A1
+    assert abs(M - ref).max() < 1e-15
+    many = [sp.identity(n, format="csc") * (i + 1.0) for i in range(300)]
+    nep2 = na.SPMF_NEP(many, [na.funcs.one()] * 300)
+    assert abs(nep2.compute_Mder(0.0) - sp.identity(n) * sum(range(1, 301))).max() < 1e-9
