@@ -314,6 +314,26 @@ int32_t nep_rowmajor_to_colmajor(int64_t rows, int32_t k, const nep_cdouble* dsr
                                  const int32_t* h_cols, int32_t ncols, nep_cdouble* ddst,
                                  int64_t ldd, nep_stream stream);
 
+/* ---- one infinite-Arnoldi step as one call ------------------------------------------------------
+ * replaces: the loop body of iar between two eigenvalue checks, src/method_iar.jl:94-109
+ *           (compute_Mlincomb! at sigma through the DerSPMF table :1130-1160, lin_solve, the 1/j shift of the block
+ *           structure, orthogonalize_and_normalize!).  Sequences nep_mlincomb_dev, nep_lu_solve[_add] (+ refine_steps blind
+ *           refinement steps on nep_cw_backward_error's residual), nep_iar_shift_scale and nep_orth_dev, then copies row k-1 of
+ *           the device H block ((m+2) complex per row: h[0..k), beta, flags) to the caller's PINNED host block behind an
+ *           event.  Nothing waits for the device; nep_iar_wait(k) blocks until H's column k has arrived.
+ * dV: the basis, column j at dV + j*ldv (ldv >= n(m+1), zero-initialised, column 0 = start vector); dCtab: the DerSPMF
+ * coefficient table (mt columns of ldc >= m entries, row j-1 = alpha_j/j f^(j)(sigma)); d_active: device int64[m+1], active
+ * rows per basis column; dwork3n: 3n complex of scratch; h_cabs / h_cf: |f_t(sigma)| and f_t(sigma) for the refinement
+ * (may be NULL when refine_steps is always 0); orth_method: 0 DGKS, 1 CGS. */
+typedef struct nep_iar nep_iar;
+int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdouble* dV, int64_t ldv,
+                       const nep_cdouble* dCtab, int64_t ldc, const int64_t* d_active, nep_cdouble* dwork3n,
+                       const double* h_cabs, const nep_cdouble* h_cf, int32_t mt, nep_cdouble* dH, nep_cdouble* h_pinnedH,
+                       int32_t orth_method, nep_iar** out);
+int32_t nep_iar_destroy(nep_iar* s);
+int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream stream);
+int32_t nep_iar_wait(nep_iar* s, int32_t k);
+
 /* ---- multi-GPU exchange of the contour integrators ----------------------------------------
  * replaces: the reduction inside `integrate_interval(::Type{<:MatrixIntegrator}, ...)` src/method_contour_common.jl:46,61-94
  *           when the N quadrature nodes of contour_beyn / contour_block_SS (src/method_beyncontour.jl:89-104,

@@ -92,6 +92,10 @@ SIGNATURES = {
     "nep_lu_schedule": [c_vp, P(c_i64)],
     "nep_lu_solve": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp],
     "nep_lu_solve_add": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp],
+    "nep_iar_create": [c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, P(c_vp)],
+    "nep_iar_destroy": [c_vp],
+    "nep_iar_step": [c_vp, c_i32, c_i32, c_vp],
+    "nep_iar_wait": [c_vp, c_i32],
     "nep_comm_unique_id": [c_vp],
     "nep_comm_create": [c_i32, c_i32, c_vp, P(c_vp)],
     "nep_comm_destroy": [c_vp],

@@ -1,0 +1,97 @@
+// libnepmi355: one infinite-Arnoldi step as ONE call (the inner statements of src/method_iar.jl:94-109 between two
+// eigenvalue checks).  Every piece is an entry point of this library already; this file only sequences them natively so
+// that the host language issues one foreign call per Arnoldi step instead of a dozen (a Python host spends ~0.25 ms per
+// step in ctypes marshalling at gun size, as much as the device needs for the step itself).
+//
+//   y[:,1]  = compute_Mlincomb!(nep, sigma, y[:,1:k], a[1:k], 1)      K1  nep_mlincomb_dev on column k of the basis
+//   y[:,1]  = -lin_solve(M0inv, y[:,1])                                K5  nep_lu_solve [+ UMFPACK-style refinement, blind plan]
+//   vv      = reshape(y[:,1:k+1])  with  y[:,2:k+1] ./ (1:k)'          nep_iar_shift_scale
+//   h, beta = orthogonalize_and_normalize!(VV, vv, h, DGKS)            K6  nep_orth_dev (decision on the device)
+//   H[:,k]  -> pinned host memory behind an event                      (the host reads it when it needs eig(H_k))
+#include "common.h"
+#include <vector>
+
+struct nep_iar {
+    nep_spmf* spmf; nep_lu* lu;
+    int64_t n, ldv; int32_t m, mt;
+    cplx* dV; const cplx* dCtab; int64_t ldc; const int64_t* d_active;
+    cplx* dz; cplx* dW;                      // z (n) ; refinement work r, x (2n)
+    std::vector<double> cabs; std::vector<nep_cdouble> cf;
+    cplx* dH; nep_cdouble* hH;               // m rows of (m+2): device / pinned host
+    int32_t method;
+    std::vector<hipEvent_t> ev;              // ev[k]: H column k is in pinned memory
+};
+
+extern "C" {
+
+int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdouble* dV, int64_t ldv,
+                       const nep_cdouble* dCtab, int64_t ldc, const int64_t* d_active, nep_cdouble* dwork3n,
+                       const double* h_cabs, const nep_cdouble* h_cf, int32_t mt, nep_cdouble* dH, nep_cdouble* h_pinnedH,
+                       int32_t orth_method, nep_iar** out) {
+    ARGCHK(out != nullptr);
+    *out = nullptr;
+    ARGCHK(spmf && lu && dV && dCtab && dwork3n && dH && h_pinnedH);
+    ARGCHK(n > 0 && m >= 1 && ldv >= n * (int64_t)(m + 1) && ldc >= m && mt >= 1 && (orth_method == 0 || orth_method == 1));
+    nep_iar* s = new nep_iar();
+    s->spmf = spmf; s->lu = lu; s->n = n; s->ldv = ldv; s->m = m; s->mt = mt;
+    s->dV = (cplx*)dV; s->dCtab = (const cplx*)dCtab; s->ldc = ldc; s->d_active = d_active;
+    s->dz = (cplx*)dwork3n; s->dW = (cplx*)dwork3n + n;
+    if (h_cabs && h_cf) { s->cabs.assign(h_cabs, h_cabs + mt); s->cf.assign(h_cf, h_cf + mt); }
+    s->dH = (cplx*)dH; s->hH = h_pinnedH; s->method = orth_method;
+    s->ev.assign(m + 1, nullptr);
+    *out = s;
+    return NEP_OK;
+}
+
+int32_t nep_iar_destroy(nep_iar* s) {
+    if (!s) return NEP_OK;
+    for (hipEvent_t e : s->ev) if (e) (void)hipEventDestroy(e);
+    delete s;
+    return NEP_OK;
+}
+
+int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream stream) {
+    ARGCHK(s && k >= 1 && k <= s->m && refine_steps >= 0);
+    ARGCHK(refine_steps == 0 || !s->cabs.empty());
+    hipStream_t st = as_stream(stream);
+    const int64_t n = s->n;
+    cplx* col = s->dV + (int64_t)(k - 1) * s->ldv;      // column k-1: the n x k block of the reference's reshape
+    cplx* vv = s->dV + (int64_t)k * s->ldv;
+    int rc = nep_mlincomb_dev(s->spmf, k, (const nep_cdouble*)s->dCtab, s->ldc, (const nep_cdouble*)col, n, (nep_cdouble*)s->dz, stream);
+    if (rc) return rc;
+    if (refine_steps == 0) {
+        rc = nep_lu_solve(s->lu, 1, (const nep_cdouble*)s->dz, n, (nep_cdouble*)vv, n, -1.0, stream);
+        if (rc) return rc;
+    } else {
+        cplx* r = s->dW; cplx* x = s->dW + n;
+        rc = nep_lu_solve(s->lu, 1, (const nep_cdouble*)s->dz, n, (nep_cdouble*)x, n, 1.0, stream);
+        for (int i = 0; i < refine_steps && !rc; ++i) {
+            rc = nep_cw_backward_error(s->spmf, s->cabs.data(), s->cf.data(), (const nep_cdouble*)x, (const nep_cdouble*)s->dz, nullptr,
+                                       nullptr, (nep_cdouble*)r, nullptr, stream);
+            if (rc) break;
+            if (i == refine_steps - 1)
+                rc = nep_lu_solve_add(s->lu, 1, (const nep_cdouble*)r, n, (const nep_cdouble*)x, n, (nep_cdouble*)vv, n, -1.0, stream);
+            else
+                rc = nep_lu_solve_add(s->lu, 1, (const nep_cdouble*)r, n, (const nep_cdouble*)x, n, (nep_cdouble*)x, n, 1.0, stream);
+        }
+        if (rc) return rc;
+    }
+    rc = nep_iar_shift_scale(n, k, (const nep_cdouble*)col, (nep_cdouble*)vv, stream);
+    if (rc) return rc;
+    cplx* hrow = s->dH + (int64_t)(k - 1) * (s->m + 2);
+    rc = nep_orth_dev((const nep_cdouble*)s->dV, s->ldv, n * (int64_t)(k + 1), k, s->d_active, (nep_cdouble*)vv, (nep_cdouble*)hrow, s->method, stream);
+    if (rc) return rc;
+    HIPCHK(hipMemcpyAsync(s->hH + (int64_t)(k - 1) * (s->m + 2), hrow, (size_t)(k + 2) * sizeof(cplx), hipMemcpyDeviceToHost, st));
+    if (!s->ev[k]) HIPCHK(hipEventCreateWithFlags(&s->ev[k], hipEventDisableTiming | hipEventBlockingSync));
+    HIPCHK(hipEventRecord(s->ev[k], st));
+    return NEP_OK;
+}
+
+// blocks the calling thread until column k of H has reached the pinned buffer
+int32_t nep_iar_wait(nep_iar* s, int32_t k) {
+    ARGCHK(s && k >= 1 && k <= s->m && s->ev[k]);
+    HIPCHK(hipEventSynchronize(s->ev[k]));
+    return NEP_OK;
+}
+
+}  // extern "C"

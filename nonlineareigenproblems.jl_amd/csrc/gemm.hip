@@ -343,6 +343,13 @@ static int gemm_dispatch(int nt, bool y_rowmajor, const cplx* Z, int64_t ldz, in
     }
 }
 
+extern "C" int32_t nep_gemm_ts_dev(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_t k,
+                                   const nep_cdouble* dB, int64_t ldb, int32_t b_rowmajor, int32_t p,
+                                   nep_cdouble* dY, int64_t ldy, int32_t y_rowmajor, nep_stream stream);
+
+// B arrives from the host: the k x p block itself is staged through the pinned ring (16 k p bytes; iar's Ritz block at
+// k = p = 100: 160 KB) and the lane-ordered MFMA fragments are built on the device by k_expand_B.  (Round 1 expanded the
+// fragments on the host: a 20 800-iteration triple loop + 333 KB upload per call cost more than the GEMM at gun size.)
 extern "C" int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_t k,
                                const nep_cdouble* hB, int64_t ldb, int32_t p, nep_cdouble* dY, int64_t ldy,
                                int32_t y_rowmajor, nep_stream stream) {
@@ -350,49 +357,19 @@ extern "C" int32_t nep_gemm_ts(const nep_cdouble* dZ, int64_t ldz, int64_t rows,
     ARGCHK(rows > 0 && k >= 1 && p >= 1 && ldz >= rows && ldb >= k);
     ARGCHK(y_rowmajor ? ldy >= p : ldy >= rows);
     hipStream_t st = as_stream(stream);
-    const int nks = gemm_nks(k, rows);
-    // column panels of at most 104 complex output columns (13 N-tiles of 8)
-    size_t total = 0;
-    for (int j0 = 0; j0 < p; j0 += 104) total += (size_t)nks * gemm_nt(std::min(104, p - j0)) * 128;
-    // persistent staging (a fresh 300 KB vector per call means mmap/munmap + TLB shootdowns across all the
-    // process' threads: measured 0.7 ms per call while the eig worker threads are running)
-    static thread_local std::vector<double> frag;
-    if (frag.size() < total) frag.resize(total + total / 2);
-    std::fill(frag.begin(), frag.begin() + total, 0.0);
-    int rc = g_gemm_scratch.ensure(total * sizeof(double));
+    const size_t bytes = (size_t)k * p * sizeof(cplx);
+    int rc = g_gemm_scratch.ensure(bytes);
     if (rc) return rc;
-    size_t off = 0;
-    std::vector<size_t> offs;
-    for (int j0 = 0; j0 < p; j0 += 104) {
-        const int pp = std::min(104, p - j0);
-        const int nt = gemm_nt(pp);
-        offs.push_back(off);
-        for (int ks = 0; ks < nks; ++ks)
-            for (int t = 0; t < nt; ++t)
-                for (int l = 0; l < 64; ++l) {
-                    const int q = l >> 4, n = l & 15;
-                    const int c = 4 * ks + q, jc = 8 * t + (n >> 1);
-                    double b0 = 0.0, b1 = 0.0;
-                    if (c < k && jc < pp) {
-                        const nep_cdouble b = hB[(int64_t)(j0 + jc) * ldb + c];
-                        if ((n & 1) == 0) { b0 = b.re; b1 = -b.im; } else { b0 = b.im; b1 = b.re; }
-                    }
-                    double* f = frag.data() + off + ((size_t)(ks * nt + t) * 2) * 64;
-                    f[l] = b0;
-                    f[64 + l] = b1;
-                }
-        off += (size_t)nks * nt * 128;
+    if (ldb == k) {
+        rc = g_gemm_ring.upload(g_gemm_scratch.dptr, hB, bytes, st);
+    } else {                                  // pack the columns (leading dimension > k)
+        static thread_local std::vector<nep_cdouble> pack;
+        pack.resize((size_t)k * p);
+        for (int j = 0; j < p; ++j) memcpy(pack.data() + (size_t)j * k, hB + (size_t)j * ldb, (size_t)k * sizeof(nep_cdouble));
+        rc = g_gemm_ring.upload(g_gemm_scratch.dptr, pack.data(), bytes, st);
     }
-    rc = g_gemm_ring.upload(g_gemm_scratch.dptr, frag.data(), total * sizeof(double), st);
     if (rc) return rc;
-    int pi = 0;
-    for (int j0 = 0; j0 < p; j0 += 104, ++pi) {
-        const int pp = std::min(104, p - j0);
-        rc = gemm_dispatch(gemm_nt(pp), y_rowmajor != 0, (const cplx*)dZ, ldz, rows, k,
-                           (const double*)g_gemm_scratch.dptr + offs[pi], nks, pp, j0, (cplx*)dY, ldy, st);
-        if (rc) return rc;
-    }
-    return NEP_OK;
+    return nep_gemm_ts_dev(dZ, ldz, rows, k, (const nep_cdouble*)g_gemm_scratch.dptr, k, 0, p, dY, ldy, y_rowmajor, stream);
 }
 
 static thread_local NepScratch g_gemm_scratch_dev;

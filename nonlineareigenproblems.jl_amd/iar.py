@@ -84,6 +84,27 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
         Hnp = Hpin.numpy()
         evs = [None] * (m + 1)
         filled = [False] * (m + 1)
+    # native step (csrc/driver.hip nep_iar_step): K1 -> K5 (+ blind refinement) -> shift -> K6 -> H row to pinned memory as
+    # ONE foreign call per Arnoldi step.  Needs a pure SPMF operator and a device LU; solves whose refinement criterion
+    # must be read back (every 8th, and until the step count has settled) take the statement-by-statement path below.
+    cstep = None
+    if use_async and not os.environ.get("NEP_IAR_PYSTEP"):
+        from .linsolvers import FactorizeLinSolver
+        from .nep import AbstractSPMF
+        import ctypes as _C
+        pure = (isinstance(nep, AbstractSPMF) and type(nep).lincomb_rowscale is AbstractSPMF.lincomb_rowscale
+                and type(nep).compute_Mlincomb is AbstractSPMF.compute_Mlincomb and "Cdev" in tab)
+        if pure and type(M0inv) is FactorizeLinSolver and getattr(M0inv.lu, "h", None):
+            rc_ = M0inv.refine_coefficients() if M0inv.umfpack_refinements > 0 else None
+            if M0inv.umfpack_refinements <= 0 or rc_ is not None:
+                from ._lib import hptr
+                work3 = torch.empty(3 * n, dtype=CDT, device="cuda")
+                hh = c_vp()
+                check(lib.nep_iar_create(nep.dev.h, M0inv.lu.h, n, m, c_vp(V.data_ptr()), ldv, c_vp(tab["Cdev"].data_ptr()), tab["m"],
+                                         c_vp(active_d.data_ptr()), c_vp(work3.data_ptr()),
+                                         hptr(rc_[0]) if rc_ else None, hptr(rc_[1]) if rc_ else None, len(nep.get_fv()),
+                                         c_vp(Hdev.data_ptr()), c_vp(Hpin.data_ptr()), dense._orth_code(orthmethod), _C.byref(hh)))
+                cstep = hh
     err = np.full((m, m), np.nan)
     lam = np.zeros(0, dtype=np.complex128); QT = None; idx = np.zeros(0, dtype=int)
     # ---- main loop.  The small dense eigenproblem of step k (host LAPACK, method_iar.jl:112; 7.5 ms at
@@ -99,6 +120,13 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     state = {"lam": lam, "QT": QT, "idx": idx, "conv_eig": 0, "k_checked": 0}
 
     def arnoldi_step(k):
+        if cstep is not None:
+            plan = M0inv.blind_plan()
+            if plan is not None:
+                check(lib.nep_iar_step(cstep, k, plan, stream_ptr()))
+                M0inv.note_blind_solve(plan)
+                evs[k] = "native"
+                return
         t0 = time.perf_counter()
         # z = sum_{j=1..k} alpha_{j+1}/j * M^(j)(sigma) * V_k block j
         nep.lincomb_rowscale(tab, k, V.data_ptr() + 16 * (k - 1) * ldv, n, z)
@@ -139,7 +167,10 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
                 filled[j] = True
 
     def timed_eig_async(kk):
-        evs[kk].synchronize()          # releases the GIL; H's columns <= kk are in pinned memory afterwards
+        if evs[kk] == "native":
+            check(lib.nep_iar_wait(cstep, kk))      # ctypes releases the GIL
+        else:
+            evs[kk].synchronize()      # releases the GIL; H's columns <= kk are in pinned memory afterwards
         fill_H(kk)
         return timed_eig(H[:kk, :kk].copy())
 
@@ -250,6 +281,8 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
         for _, f in pending:
             f.cancel()
         pool.shutdown(wait=True)
+        if cstep is not None:
+            lib.nep_iar_destroy(cstep)
         if blas_guard is not None:
             blas_guard.__exit__(None, None, None)
     lam, QT, idx, conv_eig = state["lam"], state["QT"], state["idx"], state["conv_eig"]

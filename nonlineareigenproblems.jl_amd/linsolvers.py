@@ -287,6 +287,24 @@ class FactorizeLinSolver(LinSolver):
         check(lib.nep_colnorms(n, 3, c_vp(W.data_ptr()), n, hptr(nr), stream_ptr()))
         return nr[0] / (self.lu.normA * nr[1] + nr[2]) if (nr[1] > 0 or nr[2] > 0) else 0.0
 
+    def blind_plan(self):
+        """refinement steps of the NEXT single-vector solve if it can be issued without reading omega back (None = that solve
+        evaluates the criterion on the host).  Used by drivers that hand a whole step to the library (nep_iar_step)."""
+        if self.umfpack_refinements <= 0:
+            return 0
+        if self._stable >= 4 and ((self.solves + 1) % 8) != 0:
+            return self._plan
+        return None
+
+    def note_blind_solve(self, plan):
+        self.solves += 1
+        self.refine_steps_taken += plan
+
+    def refine_coefficients(self):
+        """(|f_t(lam)|, f_t(lam)) of a pure SPMF operator, or None when M x needs the NEP's own compute_Mlincomb"""
+        self._refine_setup()
+        return (self._cabs, self._cf) if (self._cabs is not None and self._cf is not None) else None
+
     def solve_dev(self, b, out=None, scale=1.0):
         """device solve; b: (n,) or (nrhs, n) tensor; out may alias b"""
         self.solves += 1
