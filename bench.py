@@ -142,7 +142,8 @@ def beyn_sharded(na, args, world, rank):
     nep.dev
     Vh = na.probe_block(nep.n, 32)
     # worker processes for the host factorisations of THIS rank's nodes (64/world of them): no more workers than nodes
-    na.HostLUPool.warm(max(2, min(16, -(-64 // max(world, 1)))))
+    from nep_amd._affinity import cpu_budget
+    na.HostLUPool.warm(max(1, min(16, -(-64 // max(world, 1)), cpu_budget() - 2)))
     distd = dist.is_available() and dist.is_initialized()
     integ = na.MatrixTrapezoidalSharded if distd else na.MatrixTrapezoidal
     bc.c4_device(na, nep, integ, Vh=Vh, N=8 * world)          # warm-up (graph capture, allocator pools)

@@ -143,7 +143,7 @@ int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
                  const int64_t* h_active_rows, nep_cdouble* dw, nep_cdouble* h_h, double* h_beta,
                  int32_t method, int32_t* h_npasses, nep_stream stream);
 /* asynchronous DGKS (method 0) / CGS (method 1): no host synchronisation.  The re-orthogonalisation passes are
- * always enqueued and gate themselves on the device with the same criterion (at most 3 passes); w is normalised on the
+ * always enqueued and gate themselves on the device with the same criterion (at most 2 passes, NEP_ORTH_DEV_PASSES); w is normalised on the
  * device.  d_active_rows: DEVICE array (or NULL).  d_out (k+2 complex, device): h[0..k), (beta, 0),
  * (passes, 2*breakdown + another_pass_wanted). */
 int32_t nep_orth_dev(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, const int64_t* d_active_rows,

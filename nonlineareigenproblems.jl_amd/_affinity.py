@@ -57,3 +57,35 @@ def pin_to_gpu_numa(device_index=0):
         res = None
     _done[device_index] = res
     return res
+
+
+def cpu_budget():
+    """CPUs this process may actually use: the smaller of its affinity mask and the cgroup CPU quota (cpu.max), divided
+    by the number of ranks sharing the node (LOCAL_WORLD_SIZE / WORLD_SIZE).  Host-side thread and worker counts (eig
+    workers of iar, SuperLU processes of contour_beyn) are sized from it: on the benchmark box the container is limited to
+    16 CPUs' worth of time although 256 are visible, and oversubscribed workers only get throttled."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = int(f.read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    ranks = 1
+    for key in ("LOCAL_WORLD_SIZE", "WORLD_SIZE"):
+        if os.environ.get(key, "").isdigit():
+            ranks = max(1, int(os.environ[key]))
+            break
+    return max(1, n // ranks)

@@ -53,3 +53,4 @@ def eig(H):
     if info != 0:
         return np.linalg.eig(H)
     return w, V
+

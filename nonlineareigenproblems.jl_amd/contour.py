@@ -142,12 +142,24 @@ class _NodeSolve:
         trace = os.environ.get("NEP_BEYN_TRACE")
         if trace:
             import time as _t
-            self._t0 = _t.perf_counter(); self._host_done = []
+            self._t0 = _t.perf_counter(); self._host_done = []; self._host_meta = []
+        strat = None
         for t in ts:
             A = self.nep.compute_Mder(self.g(t) + self.sigma)
-            self.host[t] = HostLUPool.submit(A, workers=workers, permc_spec=c.permc_spec, **c.lu_kw)
+            if strat is None:
+                # UMFPACK-like strategy (symmetric pattern + zero-free diagonal?) decided ONCE: all nodes share one pattern
+                import nep_amd_hostlu as hl
+                import scipy.sparse as sp_
+                kw0 = dict(c.lu_kw)
+                if c.permc_spec is None and "symmetric_mode" not in kw0:
+                    sym = hl.pattern_symmetric(sp_.csc_matrix(A))
+                    strat = dict(permc_spec="MMD_AT_PLUS_A" if sym else "COLAMD", symmetric_mode=bool(sym))
+                else:
+                    strat = dict(permc_spec=c.permc_spec)
+            self.host[t] = HostLUPool.submit(A, workers=workers, **dict(c.lu_kw, **strat))
             if trace:
-                self.host[t].add_done_callback(lambda f, s=self: s._host_done.append(_t.perf_counter() - s._t0))
+                self.host[t].add_done_callback(lambda f, s=self: (s._host_done.append(_t.perf_counter() - s._t0),
+                                                                   s._host_meta.append(f.result() if not f.exception() else {})))
         if trace:
             self._t_submitted = _t.perf_counter() - self._t0
         self._submit_builds()
@@ -189,6 +201,11 @@ class _NodeSolve:
                 if os.environ.get("NEP_BEYN_TRACE"):
                     import time as _t
                     hd = sorted(self._host_done)
+                    mt_ = [m_ for m_ in self._host_meta if "t_worker" in m_]
+                    if mt_:
+                        print("[beyn trace] per factorisation in the worker: splu %.1f ms, factor() %.1f ms, whole task %.1f ms (means over %d)"
+                              % (1e3 * np.mean([m_["t_factor"] for m_ in mt_]), 1e3 * np.mean([m_["t_worker_factor_call"] for m_ in mt_]),
+                                 1e3 * np.mean([m_["t_worker"] for m_ in mt_]), len(mt_)), flush=True)
                     print("[beyn trace] submitted all at %.0f ms; host factorisations done: first %.0f ms, half %.0f ms, last %.0f ms; "
                           "last block solve issued at %.0f ms" % (1e3 * self._t_submitted, 1e3 * hd[0], 1e3 * hd[len(hd) // 2], 1e3 * hd[-1],
                                                                   1e3 * (_t.perf_counter() - self._t0)), flush=True)

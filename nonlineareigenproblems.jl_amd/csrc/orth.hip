@@ -280,8 +280,17 @@ extern "C" int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, in
 
 // Fully asynchronous DGKS/CGS: no host synchronisation.  The re-orthogonalisation passes are always enqueued and
 // switch themselves off through a device flag (criterion ||w|| < ||c||/sqrt(2) evaluated by k_orth_decide), at most
-// NEP_ORTH_DEV_PASSES passes.  d_out (k+2 complex, device): h[0..k), (beta,0), (passes, 2*breakdown + more_needed).
-#define NEP_ORTH_DEV_PASSES 3
+// orth_dev_passes() passes.  d_out (k+2 complex, device): h[0..k), (beta,0), (passes, 2*breakdown + more_needed).
+// "Twice is enough" (Kahan/Parlett): after the second pass w is orthogonal to machine precision unless it lies
+// numerically inside span(V), which the breakdown flag reports.  The default therefore enqueues 2 passes (every enqueued
+// pass costs four launches even when its gate is closed: 3 -> 2 passes took 1.4 ms off the 100 steps of the gun run);
+// NEP_ORTH_DEV_PASSES=3.. restores the longer chain; the `another_pass_wanted` flag in d_out tells if the criterion still
+// held after the last enqueued pass.
+static int orth_dev_passes() {
+    static int np = 0;
+    if (!np) { const char* e = getenv("NEP_ORTH_DEV_PASSES"); np = e ? atoi(e) : 2; if (np < 1 || np > 8) np = 2; }
+    return np;
+}
 extern "C" int32_t nep_orth_dev(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
                                 const int64_t* d_active_rows, nep_cdouble* dw, nep_cdouble* d_out, int32_t method,
                                 nep_stream stream) {
@@ -308,7 +317,7 @@ extern "C" int32_t nep_orth_dev(const nep_cdouble* dV, int64_t ldv, int64_t rows
     cplx* out = (cplx*)d_out;
     const size_t shm_upd = (size_t)(k + 8 * 64) * sizeof(cplx);
     HIPCHK(hipMemsetAsync(d_state, 0, 16, st));
-    const int npass = method == 1 ? 1 : NEP_ORTH_DEV_PASSES;
+    const int npass = method == 1 ? 1 : orth_dev_passes();
     for (int p = 0; p < npass; ++p) {
         const int* gate = p == 0 ? nullptr : d_state;
         hipLaunchKernelGGL(k_orth_dots, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv, rows, (int)k,

@@ -115,7 +115,10 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     # the iteration, the (at most LAG+1) speculative Arnoldi steps beyond k are simply dropped.
     from collections import deque
     from concurrent.futures import ThreadPoolExecutor
-    LAG = int(os.environ.get("NEP_IAR_LAG", "9"))      # host eig of up to LAG+1 consecutive steps in flight
+    from ._affinity import cpu_budget
+    # host eig of up to LAG+1 consecutive steps in flight: as many workers as the CPU budget of this rank allows (measured on
+    # gun, 16-CPU budget: LAG 3 -> 86 ms per run, 5 -> 75, 9 -> 72, 15 -> 73)
+    LAG = int(os.environ.get("NEP_IAR_LAG", str(max(1, min(9, cpu_budget() - 2)))))
     pool = ThreadPoolExecutor(max_workers=LAG + 1)
     state = {"lam": lam, "QT": QT, "idx": idx, "conv_eig": 0, "k_checked": 0}
 

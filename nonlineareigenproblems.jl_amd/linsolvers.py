@@ -47,7 +47,8 @@ class HostLUPool:
         if workers is None and cls._pool is not None:
             return cls._pool                    # whatever size it was started with
         if workers is None:
-            workers = int(os.environ.get("NEP_HOSTLU_WORKERS", min(16, max(1, (os.cpu_count() or 2) // 2))))
+            from ._affinity import cpu_budget
+            workers = int(os.environ.get("NEP_HOSTLU_WORKERS", min(16, max(1, cpu_budget() - 2))))
         if cls._pool is None or cls._workers != workers:
             cls.shutdown()
             import multiprocessing as mp
@@ -71,7 +72,13 @@ class HostLUPool:
                     except Exception:
                         hidden.pop(attr)
             try:
-                cls._pool = ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn"))
+                ctx = mp.get_context("spawn")
+                # one physical core per worker, taken from the END of the allowed set (the launching thread, the eig and
+                # builder threads of this process stay on the first cores); NEP_HOSTLU_PIN=0 leaves placement to the scheduler
+                cores = _nep_hostlu.physical_cores() if os.environ.get("NEP_HOSTLU_PIN", "1") != "0" else []
+                cores = cores[::-1][:max(workers, 1)] if len(cores) >= 2 * workers else []
+                cls._pool = ProcessPoolExecutor(max_workers=workers, mp_context=ctx, initializer=_nep_hostlu.pin_worker,
+                                                initargs=(ctx.Value("i", 0), cores))
                 cls._workers = workers
                 list(cls._pool.map(_nep_hostlu.ping, range(4 * workers)))     # forces all workers to start now
             finally:
