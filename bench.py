@@ -235,6 +235,14 @@ def wep_scale_roofline(na):
     return out
 
 
+def _cpu_budget():
+    try:
+        from nep_amd._affinity import cpu_budget
+        return int(cpu_budget())
+    except Exception:
+        return None
+
+
 def host_cores():
     try:
         import subprocess
@@ -278,9 +286,16 @@ def cpu_baseline(args):
         return (time.perf_counter() - t) / reps
     t_ml = tloop(lambda: cref.mlincomb(lib, terms, Cm, V), 20)
     W = np.empty((args.n, terms.mt), dtype=np.complex128, order="F")
+    try:                                   # "all cores" = the CPU budget of this process (cgroup quota), not OMP_NUM_THREADS
+        import ctypes
+        from nep_amd._affinity import cpu_budget
+        ctypes.CDLL("libgomp.so.1").omp_set_num_threads(int(cpu_budget()))
+    except Exception:
+        pass
     t_omp = tloop(lambda: cref.mlincomb_omp(lib, terms, Cm, V, W), 50)
     return {
-        "value": len(lam) / t_iar, "unit": "eigenpairs/s", "cores": int(nthreads), "host_cores": host_cores(), "kind": "port",
+        "value": len(lam) / t_iar, "unit": "eigenpairs/s", "cores": int(nthreads), "host_cores": host_cores(),
+        "cpu_budget": _cpu_budget(), "kind": "port",
         "sample": "oracle (NumPy/SciPy restatement of the reference path, SuperLU for UMFPACK, %d BLAS threads on a %d-core host) "
                   "iar on the same gun SPMF n=%d, maxit=%d%s: %d eigenpairs in %.2f s (orth %.2f s, mlincomb %.2f s, solve %.2f s, "
                   "residuals %.2f s)" % (nthreads, host_cores(), args.n, m, "" if m == args.maxit else " instead of %d" % args.maxit,
