@@ -314,6 +314,31 @@ int32_t nep_rowmajor_to_colmajor(int64_t rows, int32_t k, const nep_cdouble* dsr
                                  const int32_t* h_cols, int32_t ncols, nep_cdouble* ddst,
                                  int64_t ldd, nep_stream stream);
 
+/* ---- waveguide preconditioner: Sylvester solve and region operators --------------------------------------
+ * replaces: solve_wg_sylvester_fft! src/gallery_extra/waveguide/waveguide_preconditioner.jl:120-219 (FFT along z, sine
+ *           transform along x) and the region means / expansions of solve_smw :263-304,:382-412.
+ * nep_wep_sylv: X <- solution of A(sigma) X + X B = X in place (nz x nx, column-major): prime-factor DFT along z (dense small
+ * DFTs out of LDS), one tridiagonal solve along x per z-mode (d_i I + B, B = tridiag(1,-2,1)*b) by in-wave scans, inverse
+ * DFT.  h_d: the nz eigenvalues d_i of the z-operator in the basis F^H X (including sigma^2 + k_bar).  nx <= 2048. */
+typedef struct nep_wep_sylv nep_wep_sylv;
+int32_t nep_wep_sylv_create(int32_t nz, int32_t nx, const nep_cdouble* h_d, double b, nep_wep_sylv** out);
+int32_t nep_wep_sylv_destroy(nep_wep_sylv* s);
+int32_t nep_wep_sylv_info(const nep_wep_sylv* s, int32_t out[4]);   /* N1, N2 (nz = N1 N2 coprime), columns per workgroup, x per lane */
+int32_t nep_wep_sylv_solve(nep_wep_sylv* s, nep_cdouble* dX, nep_stream stream);
+/* boundary operator of the waveguide: dOut (2 nz) = blkdiag(R, R) diag(d_sinv) blkdiag(R, R)^H dX with R x = reverse(bb .* fft(x))
+ * (Waveguide.jl:53-65) and d_sinv = 1 / (nz s_j(lam)) (P_inv_m / P_inv_p, Waveguide.jl:159-170): two prime-factor DFTs per half
+ * in ONE launch (replaces four dense nz x nz GEMVs).  dOut may alias dX. */
+typedef struct nep_wep_pinv nep_wep_pinv;
+int32_t nep_wep_pinv_create(int32_t nz, const nep_cdouble* h_bb, nep_wep_pinv** out);
+int32_t nep_wep_pinv_destroy(nep_wep_pinv* p);
+int32_t nep_wep_pinv_apply(nep_wep_pinv* p, const nep_cdouble* d_sinv, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream);
+/* dOut (N x (N+4), column-major) = means of X over the N x (N+4) regions (interior regions L x L with L = nz/N, the four
+ * boundary columns of X are regions of their own); needs nx = nz + 4 */
+int32_t nep_wep_region_means(int32_t nz, int32_t nx, int32_t N, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream);
+/* dY[z, x] = alpha[region(z), region(x)] * Ksc[z, x];  dEb (nz x 2): dd1/dd2 combinations of the boundary region columns */
+int32_t nep_wep_region_expand(int32_t nz, int32_t nx, int32_t N, const nep_cdouble* dAlpha, const nep_cdouble* dKsc, double dd1,
+                              double dd2, nep_cdouble* dY, nep_cdouble* dEb, nep_stream stream);
+
 /* ---- one infinite-Arnoldi step as one call ------------------------------------------------------
  * replaces: the loop body of iar between two eigenvalue checks, src/method_iar.jl:94-109
  *           (compute_Mlincomb! at sigma through the DerSPMF table :1130-1160, lin_solve, the 1/j shift of the block

@@ -92,6 +92,15 @@ SIGNATURES = {
     "nep_lu_schedule": [c_vp, P(c_i64)],
     "nep_lu_solve": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp],
     "nep_lu_solve_add": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_dbl, c_vp],
+    "nep_wep_sylv_create": [c_i32, c_i32, c_vp, c_dbl, P(c_vp)],
+    "nep_wep_sylv_destroy": [c_vp],
+    "nep_wep_sylv_info": [c_vp, P(c_i32)],
+    "nep_wep_sylv_solve": [c_vp, c_vp, c_vp],
+    "nep_wep_pinv_create": [c_i32, c_vp, P(c_vp)],
+    "nep_wep_pinv_destroy": [c_vp],
+    "nep_wep_pinv_apply": [c_vp, c_vp, c_vp, c_vp, c_vp],
+    "nep_wep_region_means": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
+    "nep_wep_region_expand": [c_i32, c_i32, c_i32, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp],
     "nep_iar_create": [c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, P(c_vp)],
     "nep_iar_destroy": [c_vp],
     "nep_iar_step": [c_vp, c_i32, c_i32, c_vp],

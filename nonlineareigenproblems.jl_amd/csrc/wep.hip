@@ -1,0 +1,484 @@
+// libnepmi355: the Sylvester solve of the waveguide preconditioner (config C5) without any library GEMM or FFT.
+//
+// replaces: solve_wg_sylvester_fft! src/gallery_extra/waveguide/waveguide_preconditioner.jl:120-219 -- the reference
+//           diagonalises A(sigma) X + X B = C with an FFT along z (circulant A, length nz) and a sine transform along x
+//           (tridiagonal Toeplitz B, realised there as an FFT of length 2(nx+1)).  Round 1 of this backend applied both transforms as
+//           dense GEMMs (4 x 4-8 GFLOP per solve on rocBLAS, 0.41 ms at nz = 999, nx = 1003).
+//
+// Here only the z direction is diagonalised; what is left is, for every z-mode i, the TRIDIAGONAL system
+//           (d_i I + B) x_i = c_i,        B = tridiag(1, -2, 1) / hx^2,   d_i = eigenvalue i of A(sigma) + (sigma^2 + k_bar)
+// which is mathematically the same operator as W diag(1 / (d_i + s_j)) W with the sine matrix W (s_j = eigenvalues of B).
+//   1. k_dft_cols<forward>   DFT along z of every column with the Good-Thomas prime-factor algorithm: nz = N1 N2 with
+//      gcd(N1, N2) = 1 (999 = 27 * 37, 299 = 13 * 23, 105 = 15 * 7) is a TWIDDLE-FREE N1 x N2 two-dimensional DFT under the
+//      Ruritanian / CRT index maps; both small DFTs are dense matrix products out of LDS (27 + 37 = 64 complex multiplies per
+//      entry instead of 999).  A workgroup takes 4 columns and writes the result transposed (x fastest), 64 bytes per mode.
+//   2. k_tridiag_modes       one wave per mode: Thomas forward / backward substitution with precomputed pivots as two
+//      first-order affine recurrences, each evaluated by a segmented scan inside the wave (16 consecutive x per lane).
+//   3. k_dft_cols<inverse>   reads the transposed block back, inverse DFT, writes z fastest.
+// Data moved per solve: about 10 passes over the 16 nx nz byte block (HBM/L2-bound, ~0.03 ms) instead of 24 GFLOP.
+#include "common.h"
+#include <vector>
+#include <cmath>
+#include <numeric>
+
+struct nep_wep_sylv {
+    int nz = 0, nx = 0, N1 = 0, N2 = 0, cols = 4;
+    int32_t* d_in = nullptr;      // nz: input position of (n1, n2)
+    int32_t* d_out = nullptr;     // nz: output position of (k1, k2)
+    cplx* d_w1 = nullptr;         // N1 roots exp(-2 pi i j / N1)
+    cplx* d_w2 = nullptr;         // N2 roots
+    cplx* d_m = nullptr;          // nz x nx (x fastest): forward multipliers m_j = b / dtilde_{j-1}
+    cplx* d_dinv = nullptr;       // nz x nx: 1 / dtilde_j
+    cplx* d_T = nullptr;          // nz x nx work (x fastest)
+    double b = 0.0;
+};
+
+// ---- prime-factor DFT of COLS columns per workgroup ---------------------------------------------------------------------
+// FWD = true : in  X (z fastest, column x at X + x*nz), out T (x fastest, mode i at T + i*nx), exponent sign `sgn`
+// FWD = false: in  T (x fastest), out X (z fastest)
+template <bool FWD, int COLS>
+__global__ __launch_bounds__(1024) void k_dft_cols(int nz, int nx, int N1, int N2, const int32_t* __restrict__ in_idx,
+                                                   const int32_t* __restrict__ out_idx, const cplx* __restrict__ w1,
+                                                   const cplx* __restrict__ w2, double sgn, double scale,
+                                                   const cplx* __restrict__ src, cplx* __restrict__ dst) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* xs = (cplx*)smem_raw;                 // [q][COLS], natural (n1, n2) order q = n1 N2 + n2
+    cplx* ts = xs + (size_t)COLS * nz;          // [q][COLS], q = k1 N2 + n2
+    cplx* r1 = ts + (size_t)COLS * nz;          // N1 roots
+    cplx* r2 = r1 + N1;                         // N2 roots
+    const int x0 = blockIdx.x * COLS;
+    const int nc = min(COLS, nx - x0);
+    const int nt = blockDim.x;
+    for (int t = threadIdx.x; t < N1; t += nt) r1[t] = cmake(w1[t].x, sgn * w1[t].y);
+    for (int t = threadIdx.x; t < N2; t += nt) r2[t] = cmake(w2[t].x, sgn * w2[t].y);
+    // load element (n1, n2) of the COLS columns (the COLS values of one q sit side by side: one root read serves COLS MACs)
+    if (FWD) {
+        for (int t = threadIdx.x; t < COLS * nz; t += nt) {
+            const int c = t / nz, q = t - c * nz;
+            xs[q * COLS + c] = c < nc ? src[(int64_t)(x0 + c) * nz + in_idx[q]] : cmake(0.0, 0.0);
+        }
+    } else {
+        for (int t = threadIdx.x; t < COLS * nz; t += nt) {      // consecutive threads -> consecutive x of one mode
+            const int q = t / COLS, c = t - q * COLS;
+            xs[t] = c < nc ? src[(int64_t)in_idx[q] * nx + (x0 + c)] : cmake(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+    // stage 1: ts[k1, n2] = sum_n1 xs[n1, n2] r1^(n1 k1)
+    for (int q = threadIdx.x; q < nz; q += nt) {
+        const int k1 = q / N2, n2 = q - k1 * N2;
+        const cplx* xc = xs + (size_t)n2 * COLS;
+        cplx acc[COLS];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) acc[c] = cmake(0.0, 0.0);
+        int e = 0;
+        for (int n1 = 0; n1 < N1; ++n1) {
+            const cplx w = r1[e];
+            const cplx* xp = xc + (size_t)n1 * N2 * COLS;
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) cfma(acc[c], xp[c], w);
+            e += k1; if (e >= N1) e -= N1;
+        }
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) ts[(size_t)q * COLS + c] = acc[c];
+    }
+    __syncthreads();
+    // stage 2: out[k1, k2] = sum_n2 ts[k1, n2] r2^(n2 k2)
+    for (int q = threadIdx.x; q < nz; q += nt) {
+        const int k1 = q / N2, k2 = q - k1 * N2;
+        const cplx* tc = ts + (size_t)k1 * N2 * COLS;
+        cplx acc[COLS];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) acc[c] = cmake(0.0, 0.0);
+        int e = 0;
+        for (int n2 = 0; n2 < N2; ++n2) {
+            const cplx w = r2[e];
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) cfma(acc[c], tc[(size_t)n2 * COLS + c], w);
+            e += k2; if (e >= N2) e -= N2;
+        }
+        const int o = out_idx[q];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c)
+            if (c < nc) {
+                const cplx v = cmake(scale * acc[c].x, scale * acc[c].y);
+                if (FWD) dst[(int64_t)o * nx + (x0 + c)] = v;          // COLS consecutive x of one mode: COLS * 16 bytes
+                else dst[(int64_t)(x0 + c) * nz + o] = v;
+            }
+    }
+}
+
+// ---- Thomas pivots of (d_i I + B), one thread per mode (one-off per shift) -------------------------------------------------------
+__global__ void k_tridiag_factor(int nz, int nx, const cplx* __restrict__ d, double b, cplx* __restrict__ mfac,
+                                 cplx* __restrict__ dinv) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nz) return;
+    const cplx a = cmake(d[i].x - 2.0 * b, d[i].y);
+    cplx piv = a;
+    auto inv = [](cplx z) { const double s = 1.0 / (z.x * z.x + z.y * z.y); return cmake(z.x * s, -z.y * s); };
+    cplx pinv = inv(piv);
+    mfac[(int64_t)i * nx] = cmake(0.0, 0.0);
+    dinv[(int64_t)i * nx] = pinv;
+    for (int j = 1; j < nx; ++j) {
+        const cplx m = cmake(b * pinv.x, b * pinv.y);            // m_j = b / dtilde_{j-1}
+        piv = cmake(a.x - b * m.x, a.y - b * m.y);               // dtilde_j = a - b m_j
+        pinv = inv(piv);
+        mfac[(int64_t)i * nx + j] = m;
+        dinv[(int64_t)i * nx + j] = pinv;
+    }
+}
+
+// affine map v -> A v + B ; composition "first f then g": (g.A f.A, g.A f.B + g.B)
+struct Aff { cplx A, B; };
+__device__ __forceinline__ Aff aff_then(const Aff f, const Aff g) {
+    Aff r; r.A = cmul(g.A, f.A); r.B = cmul(g.A, f.B); r.B.x += g.B.x; r.B.y += g.B.y; return r;
+}
+__device__ __forceinline__ cplx shfl_c(cplx v, int src) { return cmake(__shfl(v.x, src, 64), __shfl(v.y, src, 64)); }
+
+// ---- (d_i I + B) x = c for every mode i: one wave per mode, SEG consecutive x per lane -----------------------------------------
+// forward  y_j = c_j - m_j y_{j-1}            (y_{-1} = 0)
+// backward x_j = (y_j - b x_{j+1}) dinv_j     (x_{nx} = 0)
+template <int SEG>
+__global__ __launch_bounds__(256) void k_tridiag_modes(int nz, int nx, const cplx* __restrict__ mfac, const cplx* __restrict__ dinv,
+                                                       double b, cplx* __restrict__ T) {
+    const int lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nz) return;
+    const int64_t base = (int64_t)i * nx;
+    const int j0 = lane * SEG;
+    cplx c[SEG], al[SEG];           // c: right-hand side, then y, then h;  al: forward multipliers, then g
+#pragma unroll
+    for (int t = 0; t < SEG; ++t) {
+        const int j = j0 + t;
+        if (j < nx) { c[t] = T[base + j]; const cplx m = mfac[base + j]; al[t] = cmake(-m.x, -m.y); }
+        else { c[t] = cmake(0.0, 0.0); al[t] = cmake(0.0, 0.0); }     // padding maps everything to 0 (never used downstream)
+    }
+    // ---- forward: segment composite, inclusive scan over lanes, apply
+    Aff seg; seg.A = cmake(1.0, 0.0); seg.B = cmake(0.0, 0.0);
+#pragma unroll
+    for (int t = 0; t < SEG; ++t) { Aff e; e.A = al[t]; e.B = c[t]; seg = aff_then(seg, e); }
+    Aff inc = seg;                                   // Hillis-Steele: inc(l) = seg(0) then ... then seg(l)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int srcl = lane >= off ? lane - off : 0;
+        Aff o; o.A = shfl_c(inc.A, srcl); o.B = shfl_c(inc.B, srcl);
+        if (lane >= off) inc = aff_then(o, inc);
+    }
+    cplx carry = shfl_c(inc.B, lane > 0 ? lane - 1 : 0);   // y at the end of the previous lane's segment (start value 0: only B counts)
+    if (lane == 0) carry = cmake(0.0, 0.0);
+#pragma unroll
+    for (int t = 0; t < SEG; ++t) { cplx v = c[t]; cfma(v, al[t], carry); c[t] = v; carry = v; }      // c = y
+    // ---- backward: x_j = g_j x_{j+1} + h_j,  g_j = -b dinv_j, h_j = y_j dinv_j ; scan from the high end
+#pragma unroll
+    for (int t = 0; t < SEG; ++t) {
+        const int j = j0 + t;
+        if (j < nx) { const cplx di = dinv[base + j]; al[t] = cmake(-b * di.x, -b * di.y); c[t] = cmul(c[t], di); }
+        else { al[t] = cmake(0.0, 0.0); c[t] = cmake(0.0, 0.0); }      // beyond the end: x = 0
+    }
+    Aff segb; segb.A = cmake(1.0, 0.0); segb.B = cmake(0.0, 0.0);      // maps x_{j0+SEG} to x_{j0}: entry SEG-1 acts first
+#pragma unroll
+    for (int t = SEG - 1; t >= 0; --t) { Aff e; e.A = al[t]; e.B = c[t]; segb = aff_then(segb, e); }
+    Aff incb = segb;                                  // inclusive scan from lane 63 downwards
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int srcl = lane + off < 64 ? lane + off : 63;
+        Aff o; o.A = shfl_c(incb.A, srcl); o.B = shfl_c(incb.B, srcl);
+        if (lane + off < 64) incb = aff_then(o, incb);
+    }
+    cplx carryb = shfl_c(incb.B, lane < 63 ? lane + 1 : 63);          // x at the start of the next lane's segment
+    if (lane == 63) carryb = cmake(0.0, 0.0);
+#pragma unroll
+    for (int t = SEG - 1; t >= 0; --t) {
+        cplx v = c[t]; cfma(v, al[t], carryb); carryb = v;
+        const int j = j0 + t;
+        if (j < nx) T[base + j] = v;
+    }
+}
+
+// ---- region means / expansion of the SMW correction (waveguide_preconditioner.jl:263-304) -------------------------------------
+// out (N x (N+4), column-major): mean over the region (zi, xk) of X (nz x nx, z fastest).  x regions: columns 0, 1, nx-2, nx-1 are
+// single-column regions 0, 1, N+2, N+3; region 2+j covers columns 2 + jL .. 2 + (j+1)L - 1.  z regions: L consecutive rows.
+__global__ __launch_bounds__(256) void k_region_means(int nz, int nx, int N, int L, const cplx* __restrict__ X, cplx* __restrict__ out) {
+    __shared__ cplx sm[4];
+    const int zi = blockIdx.x, xk = blockIdx.y;
+    int c0, c1; double wx;
+    if (xk < 2) { c0 = xk; c1 = xk + 1; wx = 1.0; }
+    else if (xk >= N + 2) { c0 = nx - 2 + (xk - (N + 2)); c1 = c0 + 1; wx = 1.0; }
+    else { c0 = 2 + (xk - 2) * L; c1 = c0 + L; wx = 1.0 / L; }
+    const int nrow = L, ncol = c1 - c0;
+    cplx acc = cmake(0.0, 0.0);
+    for (int t = threadIdx.x; t < nrow * ncol; t += 256) {
+        const int cc = t / nrow, rr = t - cc * nrow;
+        const cplx v = X[(int64_t)(c0 + cc) * nz + zi * L + rr];
+        acc.x += v.x; acc.y += v.y;
+    }
+    acc = group_reduce_sum<64>(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        cplx s = sm[0];
+        for (int q = 1; q < 4; ++q) { s.x += sm[q].x; s.y += sm[q].y; }
+        const double w = wx / L;
+        out[(int64_t)xk * N + zi] = cmake(w * s.x, w * s.y);
+    }
+}
+// Y[z, x] = alpha[region_z(z), region_x(x)] * Ksc[z, x];  eb (nz x 2) = the boundary pieces
+//   eb[:, 0] = dd1 * alpha[rz, 0] + dd2 * alpha[rz, 1],  eb[:, 1] = dd2 * alpha[rz, N+2] + dd1 * alpha[rz, N+3]
+__global__ void k_region_expand(int nz, int nx, int N, int L, const cplx* __restrict__ alpha, const cplx* __restrict__ Ksc,
+                                double dd1, double dd2, cplx* __restrict__ Y, cplx* __restrict__ eb) {
+    const int64_t total = (int64_t)nz * nx;
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int x = (int)(t / nz), z = (int)(t - (int64_t)x * nz);
+        const int rz = z / L;
+        const int rx = x < 2 ? x : (x >= nx - 2 ? N + 2 + (x - (nx - 2)) : 2 + (x - 2) / L);
+        Y[t] = cmul(alpha[(int64_t)rx * N + rz], Ksc[t]);
+        if (x == 0) {
+            const cplx a0 = alpha[rz], a1 = alpha[(int64_t)N + rz], a2 = alpha[(int64_t)(N + 2) * N + rz], a3 = alpha[(int64_t)(N + 3) * N + rz];
+            eb[z] = cmake(dd1 * a0.x + dd2 * a1.x, dd1 * a0.y + dd2 * a1.y);
+            eb[nz + z] = cmake(dd2 * a2.x + dd1 * a3.x, dd2 * a2.y + dd1 * a3.y);
+        }
+    }
+}
+
+// ---- boundary operator P(lam)^{-1} = R diag(1 / s(lam)) R^H / nz,  R x = reverse(bb .* fft(x))  (Waveguide.jl:53-65,159-162) ------
+// one workgroup per half (minus / plus block): x -> reverse -> conj(bb) .* -> inverse-direction DFT -> scale by sinv = 1/(nz s) ->
+// DFT -> bb .* -> reverse, both DFTs by the same prime-factor scheme out of LDS.  Replaces four nz x nz dense GEMVs per application.
+__global__ __launch_bounds__(1024) void k_wep_pinv(int nz, int N1, int N2, const int32_t* __restrict__ in_idx,
+                                                   const int32_t* __restrict__ out_idx, const cplx* __restrict__ w1,
+                                                   const cplx* __restrict__ w2, const cplx* __restrict__ bb,
+                                                   const cplx* __restrict__ sinv, const cplx* __restrict__ x, cplx* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* a = (cplx*)smem_raw;        // nz
+    cplx* t = a + nz;                 // nz
+    cplx* v = t + nz;                 // nz (natural order)
+    cplx* r1 = v + nz; cplx* r2 = r1 + N1;
+    const int half = blockIdx.x;
+    const cplx* xh = x + (int64_t)half * nz;
+    const cplx* sh = sinv + (int64_t)half * nz;
+    cplx* oh = out + (int64_t)half * nz;
+    const int nt = blockDim.x;
+    for (int pass = 0; pass < 2; ++pass) {
+        const double sgn = pass == 0 ? -1.0 : 1.0;           // pass 0: F^H (exponent +), pass 1: F
+        __syncthreads();
+        for (int q = threadIdx.x; q < N1; q += nt) r1[q] = cmake(w1[q].x, sgn * w1[q].y);
+        for (int q = threadIdx.x; q < N2; q += nt) r2[q] = cmake(w2[q].x, sgn * w2[q].y);
+        for (int q = threadIdx.x; q < nz; q += nt) {
+            const int m = in_idx[q];
+            if (pass == 0) { const cplx b = bb[m]; a[q] = cmul(cmake(b.x, -b.y), xh[nz - 1 - m]); }
+            else a[q] = v[m];
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < nz; q += nt) {
+            const int k1 = q / N2, n2 = q - k1 * N2;
+            cplx acc = cmake(0.0, 0.0);
+            int e = 0;
+            for (int n1 = 0; n1 < N1; ++n1) { cfma(acc, a[n1 * N2 + n2], r1[e]); e += k1; if (e >= N1) e -= N1; }
+            t[q] = acc;
+        }
+        __syncthreads();
+        for (int q = threadIdx.x; q < nz; q += nt) {
+            const int k1 = q / N2, k2 = q - k1 * N2;
+            cplx acc = cmake(0.0, 0.0);
+            int e = 0;
+            for (int n2 = 0; n2 < N2; ++n2) { cfma(acc, t[k1 * N2 + n2], r2[e]); e += k2; if (e >= N2) e -= N2; }
+            const int k = out_idx[q];
+            if (pass == 0) v[k] = cmul(acc, sh[k]);
+            else oh[nz - 1 - k] = cmul(bb[k], acc);
+        }
+    }
+}
+
+static int egcd_inv(int a, int m) {            // a^{-1} mod m (gcd = 1)
+    int t = 0, nt = 1, r = m, nr = a % m;
+    while (nr) { const int q = r / nr; int tmp = t - q * nt; t = nt; nt = tmp; tmp = r - q * nr; r = nr; nr = tmp; }
+    return t < 0 ? t + m : t;
+}
+
+extern "C" {
+
+int32_t nep_wep_sylv_destroy(nep_wep_sylv* s) {
+    if (!s) return NEP_OK;
+    nep_pool_free(s->d_in); nep_pool_free(s->d_out); nep_pool_free(s->d_w1); nep_pool_free(s->d_w2);
+    nep_pool_free(s->d_m); nep_pool_free(s->d_dinv); nep_pool_free(s->d_T);
+    delete s;
+    return NEP_OK;
+}
+
+int32_t nep_wep_sylv_create(int32_t nz, int32_t nx, const nep_cdouble* h_d, double b, nep_wep_sylv** out) {
+    ARGCHK(out != nullptr);
+    *out = nullptr;
+    ARGCHK(nz >= 1 && nx >= 2 && h_d != nullptr && nx <= 64 * 32);
+    // coprime factorisation with the smallest N1 + N2 (N2 = 1: plain dense DFT of length nz)
+    int N1 = nz, N2 = 1;
+    for (int a = 2; a * a <= nz; ++a)
+        if (nz % a == 0 && std::gcd(a, nz / a) == 1 && a + nz / a < N1 + N2) { N1 = nz / a; N2 = a; }
+    int cols = 4;
+    while (cols > 1 && ((size_t)2 * cols * nz + N1 + N2) * sizeof(cplx) > 150 * 1024) cols >>= 1;
+    if (((size_t)2 * cols * nz + N1 + N2) * sizeof(cplx) > 150 * 1024) {
+        nep_set_error("nep_wep_sylv_create: nz = %d does not fit the LDS staging of the DFT kernel", nz);
+        return NEP_ERR_UNSUPPORTED;
+    }
+    nep_wep_sylv* s = new nep_wep_sylv();
+    s->nz = nz; s->nx = nx; s->N1 = N1; s->N2 = N2; s->cols = cols; s->b = b;
+    std::vector<int32_t> in_idx(nz), out_idx(nz);
+    const int i2 = N1 > 1 && N2 > 1 ? egcd_inv(N2 % N1, N1) : 0, i1 = N1 > 1 && N2 > 1 ? egcd_inv(N1 % N2, N2) : 0;
+    for (int a = 0; a < N1; ++a)
+        for (int c = 0; c < N2; ++c) {
+            if (N2 == 1) { in_idx[a] = a; out_idx[a] = a; continue; }
+            in_idx[a * N2 + c] = (int32_t)(((int64_t)N2 * a + (int64_t)N1 * c) % nz);
+            out_idx[a * N2 + c] = (int32_t)(((int64_t)N2 * i2 % nz * a + (int64_t)N1 * i1 % nz * c) % nz);
+        }
+    std::vector<nep_cdouble> w1(N1), w2(N2);
+    for (int j = 0; j < N1; ++j) { const double th = -2.0 * M_PI * j / N1; w1[j].re = cos(th); w1[j].im = sin(th); }
+    for (int j = 0; j < N2; ++j) { const double th = -2.0 * M_PI * j / N2; w2[j].re = cos(th); w2[j].im = sin(th); }
+    int rc = nep_pool_alloc((void**)&s->d_in, (size_t)nz * 4);
+    if (!rc) rc = nep_pool_alloc((void**)&s->d_out, (size_t)nz * 4);
+    if (!rc) rc = nep_pool_alloc((void**)&s->d_w1, (size_t)N1 * 16);
+    if (!rc) rc = nep_pool_alloc((void**)&s->d_w2, (size_t)N2 * 16);
+    if (!rc) rc = nep_pool_alloc((void**)&s->d_m, (size_t)nz * nx * 16);
+    if (!rc) rc = nep_pool_alloc((void**)&s->d_dinv, (size_t)nz * nx * 16);
+    if (!rc) rc = nep_pool_alloc((void**)&s->d_T, (size_t)nz * nx * 16);
+    cplx* d_d = nullptr;
+    if (!rc) rc = nep_pool_alloc((void**)&d_d, (size_t)nz * 16);
+    if (rc) { nep_wep_sylv_destroy(s); return rc; }
+    hipError_t e = hipMemcpy(s->d_in, in_idx.data(), (size_t)nz * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->d_out, out_idx.data(), (size_t)nz * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->d_w1, w1.data(), (size_t)N1 * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(s->d_w2, w2.data(), (size_t)N2 * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d_d, h_d, (size_t)nz * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_tridiag_factor, dim3((nz + 63) / 64), dim3(64), 0, nullptr, (int)nz, (int)nx, (const cplx*)d_d, b, s->d_m, s->d_dinv);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+    }
+    nep_pool_free(d_d);
+    if (e != hipSuccess) { nep_set_error("nep_wep_sylv_create: %s", hipGetErrorString(e)); nep_wep_sylv_destroy(s); return NEP_ERR_HIP; }
+    *out = s;
+    return NEP_OK;
+}
+
+// ---- P(lam)^{-1}: plan (depends on nz and bb only) ----------------------------------------------------------------------------
+struct nep_wep_pinv { int nz = 0, N1 = 0, N2 = 0; int32_t *d_in = nullptr, *d_out = nullptr; cplx *d_w1 = nullptr, *d_w2 = nullptr, *d_bb = nullptr; };
+
+int32_t nep_wep_pinv_destroy(nep_wep_pinv* p) {
+    if (!p) return NEP_OK;
+    nep_pool_free(p->d_in); nep_pool_free(p->d_out); nep_pool_free(p->d_w1); nep_pool_free(p->d_w2); nep_pool_free(p->d_bb);
+    delete p;
+    return NEP_OK;
+}
+
+int32_t nep_wep_pinv_create(int32_t nz, const nep_cdouble* h_bb, nep_wep_pinv** out) {
+    ARGCHK(out != nullptr);
+    *out = nullptr;
+    ARGCHK(nz >= 1 && h_bb != nullptr);
+    if (((size_t)3 * nz + 2 * (size_t)nz) * sizeof(cplx) > 150 * 1024) { nep_set_error("nep_wep_pinv_create: nz = %d too large for the LDS staging", nz); return NEP_ERR_UNSUPPORTED; }
+    int N1 = nz, N2 = 1;
+    for (int a = 2; a * a <= nz; ++a)
+        if (nz % a == 0 && std::gcd(a, nz / a) == 1 && a + nz / a < N1 + N2) { N1 = nz / a; N2 = a; }
+    nep_wep_pinv* p = new nep_wep_pinv();
+    p->nz = nz; p->N1 = N1; p->N2 = N2;
+    std::vector<int32_t> in_idx(nz), out_idx(nz);
+    const int i2 = N2 > 1 ? egcd_inv(N2 % N1, N1) : 0, i1 = N2 > 1 ? egcd_inv(N1 % N2, N2) : 0;
+    for (int a = 0; a < N1; ++a)
+        for (int c = 0; c < N2; ++c) {
+            if (N2 == 1) { in_idx[a] = a; out_idx[a] = a; continue; }
+            in_idx[a * N2 + c] = (int32_t)(((int64_t)N2 * a + (int64_t)N1 * c) % nz);
+            out_idx[a * N2 + c] = (int32_t)(((int64_t)N2 * i2 % nz * a + (int64_t)N1 * i1 % nz * c) % nz);
+        }
+    std::vector<nep_cdouble> w1(N1), w2(N2);
+    for (int j = 0; j < N1; ++j) { const double th = -2.0 * M_PI * j / N1; w1[j].re = cos(th); w1[j].im = sin(th); }
+    for (int j = 0; j < N2; ++j) { const double th = -2.0 * M_PI * j / N2; w2[j].re = cos(th); w2[j].im = sin(th); }
+    int rc = nep_pool_alloc((void**)&p->d_in, (size_t)nz * 4);
+    if (!rc) rc = nep_pool_alloc((void**)&p->d_out, (size_t)nz * 4);
+    if (!rc) rc = nep_pool_alloc((void**)&p->d_w1, (size_t)N1 * 16);
+    if (!rc) rc = nep_pool_alloc((void**)&p->d_w2, (size_t)N2 * 16);
+    if (!rc) rc = nep_pool_alloc((void**)&p->d_bb, (size_t)nz * 16);
+    if (rc) { nep_wep_pinv_destroy(p); return rc; }
+    hipError_t e = hipMemcpy(p->d_in, in_idx.data(), (size_t)nz * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_out, out_idx.data(), (size_t)nz * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_w1, w1.data(), (size_t)N1 * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_w2, w2.data(), (size_t)N2 * 16, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p->d_bb, h_bb, (size_t)nz * 16, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { nep_set_error("nep_wep_pinv_create: %s", hipGetErrorString(e)); nep_wep_pinv_destroy(p); return NEP_ERR_HIP; }
+    *out = p;
+    return NEP_OK;
+}
+
+// dOut (2 nz) = blkdiag(R, R) diag(d_sinv) blkdiag(R, R)^H dX, d_sinv = 1 / (nz s_j(lam)) (2 nz device entries); dOut may alias dX
+int32_t nep_wep_pinv_apply(nep_wep_pinv* p, const nep_cdouble* d_sinv, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream) {
+    ARGCHK(p && d_sinv && dX && dOut);
+    static thread_local bool attr_set = false;
+    if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_wep_pinv, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+    const size_t shm = ((size_t)3 * p->nz + p->N1 + p->N2) * sizeof(cplx);
+    const int threads = p->nz >= 768 ? 1024 : (p->nz >= 256 ? 512 : 256);
+    hipLaunchKernelGGL(k_wep_pinv, dim3(2), dim3(threads), shm, as_stream(stream), p->nz, p->N1, p->N2, (const int32_t*)p->d_in,
+                       (const int32_t*)p->d_out, (const cplx*)p->d_w1, (const cplx*)p->d_w2, (const cplx*)p->d_bb, (const cplx*)d_sinv,
+                       (const cplx*)dX, (cplx*)dOut);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+int32_t nep_wep_sylv_info(const nep_wep_sylv* s, int32_t out[4]) {
+    ARGCHK(s && out);
+    out[0] = s->N1; out[1] = s->N2; out[2] = s->cols; out[3] = (s->nx + 63) / 64;
+    return NEP_OK;
+}
+
+// X (nz x nx, column-major = z fastest, device) <- solution of A(sigma) X + X B = X, in place
+int32_t nep_wep_sylv_solve(nep_wep_sylv* s, nep_cdouble* dX, nep_stream stream) {
+    ARGCHK(s && dX);
+    hipStream_t st = as_stream(stream);
+    const int nz = s->nz, nx = s->nx;
+    const size_t shm = ((size_t)2 * s->cols * nz + s->N1 + s->N2) * sizeof(cplx);
+    static thread_local bool attr_set = false;
+    if (!attr_set) {
+#define DFT_ATTR(F_, C_) HIPCHK(hipFuncSetAttribute((const void*)k_dft_cols<F_, C_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+        DFT_ATTR(true, 4); DFT_ATTR(false, 4); DFT_ATTR(true, 2); DFT_ATTR(false, 2); DFT_ATTR(true, 1); DFT_ATTR(false, 1);
+#undef DFT_ATTR
+        attr_set = true;
+    }
+    const double scale = 1.0 / sqrt((double)nz);
+    const dim3 grid((unsigned)((nx + s->cols - 1) / s->cols));
+    const int threads = nz >= 768 ? 1024 : (nz >= 384 ? 512 : 256);
+#define DFT_LAUNCH(F_, C_, SGN_, SRC_, DST_)                                                                               \
+    hipLaunchKernelGGL((k_dft_cols<F_, C_>), grid, dim3(threads), shm, st, nz, nx, s->N1, s->N2, (const int32_t*)s->d_in,    \
+                       (const int32_t*)s->d_out, (const cplx*)s->d_w1, (const cplx*)s->d_w2, SGN_, scale, SRC_, DST_)
+#define DFT_BY_COLS(F_, SGN_, SRC_, DST_)                                                                                  \
+    do { if (s->cols == 4) DFT_LAUNCH(F_, 4, SGN_, SRC_, DST_); else if (s->cols == 2) DFT_LAUNCH(F_, 2, SGN_, SRC_, DST_);  \
+         else DFT_LAUNCH(F_, 1, SGN_, SRC_, DST_); } while (0)
+    // F^H X : exponent +, result transposed into T
+    DFT_BY_COLS(true, -1.0, (const cplx*)dX, s->d_T);
+    LAUNCHCHK();
+    const int seg = (nx + 63) / 64;
+    const dim3 g2((unsigned)((nz + 3) / 4));
+#define TRI(S_) hipLaunchKernelGGL((k_tridiag_modes<S_>), g2, dim3(256), 0, st, nz, nx, (const cplx*)s->d_m, (const cplx*)s->d_dinv, s->b, s->d_T)
+    if (seg <= 1) TRI(1); else if (seg <= 2) TRI(2); else if (seg <= 4) TRI(4); else if (seg <= 8) TRI(8); else if (seg <= 16) TRI(16); else TRI(32);
+#undef TRI
+    LAUNCHCHK();
+    // F T : exponent -, back to z fastest
+    DFT_BY_COLS(false, 1.0, (const cplx*)s->d_T, (cplx*)dX);
+    LAUNCHCHK();
+#undef DFT_BY_COLS
+#undef DFT_LAUNCH
+    return NEP_OK;
+}
+
+int32_t nep_wep_region_means(int32_t nz, int32_t nx, int32_t N, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream) {
+    ARGCHK(dX && dOut && N >= 1 && nz % N == 0 && nx == nz + 4);
+    hipLaunchKernelGGL(k_region_means, dim3((unsigned)N, (unsigned)(N + 4)), dim3(256), 0, as_stream(stream), (int)nz, (int)nx, (int)N,
+                       (int)(nz / N), (const cplx*)dX, (cplx*)dOut);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+int32_t nep_wep_region_expand(int32_t nz, int32_t nx, int32_t N, const nep_cdouble* dAlpha, const nep_cdouble* dKsc, double dd1,
+                              double dd2, nep_cdouble* dY, nep_cdouble* dEb, nep_stream stream) {
+    ARGCHK(dAlpha && dKsc && dY && dEb && N >= 1 && nz % N == 0 && nx == nz + 4);
+    const int64_t total = (int64_t)nz * nx;
+    hipLaunchKernelGGL(k_region_expand, dim3((unsigned)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, as_stream(stream),
+                       (int)nz, (int)nx, (int)N, (int)(nz / N), (const cplx*)dAlpha, (const cplx*)dKsc, dd1, dd2, (cplx*)dY, (cplx*)dEb);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+}  // extern "C"

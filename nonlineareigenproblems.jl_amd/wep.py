@@ -168,6 +168,21 @@ class WEP(AbstractSPMF):
         return self.fi
 
     # ---- corner data on the device
+    def _pinv_plan(self):
+        """nep_wep_pinv handle (prime-factor DFT plan + bb on the device) for P(lam)^{-1}, or None (NEP_WEP_GEMM=1 / nz too large:
+        the dense R matrices are used instead)"""
+        if getattr(self, "_pinv_h", False) is False:
+            self._pinv_h = None
+            import os
+            if not os.environ.get("NEP_WEP_GEMM"):
+                import ctypes as C
+                _lib.require_gpu()
+                h = c_vp()
+                bb = np.ascontiguousarray(self.wd.bb, dtype=np.complex128)
+                if lib.nep_wep_pinv_create(self.nz, hptr(bb), C.byref(h)) == 0:
+                    self._pinv_h = h
+        return self._pinv_h
+
     def _corner_dev(self):
         if self._Rm is None:
             _lib.require_gpu()

@@ -79,6 +79,10 @@ class SchurOps:
         xa = x.data_ptr() if is_dev(x) else x
         oa = out.data_ptr() if is_dev(out) else out
         st = stream_ptr()
+        plan = self.nep._pinv_plan()
+        if plan is not None:
+            check(lib.nep_wep_pinv_apply(plan, c_vp(self.sinv.data_ptr()), c_vp(xa), c_vp(oa), st))
+            return
         for half in (0, 1):
             o = 16 * half * nz
             check(lib.nep_gemv_hd(c_vp(self.Rm.data_ptr()), nz, nz, nz, c_vp(xa + o), c_vp(self.sinv.data_ptr() + o),
@@ -316,11 +320,25 @@ class WEPPreconditioner:
         v = np.zeros(nz, dtype=complex); v[0] = -2; v[1] = 1; v[nz - 1] = 1; v /= wd.hz ** 2
         w = np.zeros(nz, dtype=complex); w[1] = 1; w[nz - 1] = -1; w *= self.sigma / wd.hz
         D = np.fft.fft(v + w) + (self.sigma ** 2 + k_bar)
-        S = -(4.0 / wd.hx ** 2) * np.sin(np.pi * np.arange(1, nx + 1) / (2 * (nx + 1))) ** 2
-        self.G = to_dev(1.0 / (D[:, None] + S[None, :]))                                   # nz x nx
-        self.Fs = to_dev(np.fft.fft(np.eye(nz), axis=0) / np.sqrt(nz))                     # unitary DFT, symmetric
-        jx = np.arange(1, nx + 1)
-        self.Wr = torch.from_numpy(np.ascontiguousarray(np.sqrt(2.0 / (nx + 1)) * np.sin(np.pi * np.outer(jx, jx) / (nx + 1)))).to("cuda")
+        # Sylvester solve: prime-factor DFT along z + one tridiagonal solve per z-mode along x (csrc/wep.hip); the dense
+        # transform matrices of round 1 (rocBLAS GEMMs) remain as the A/B reference behind NEP_WEP_GEMM=1
+        self.sylv = None
+        self.dd1 = (2 / wd.hx) / wd.hx ** 2; self.dd2 = (-1 / (2 * wd.hx)) / wd.hx ** 2
+        if not os.environ.get("NEP_WEP_GEMM"):
+            import ctypes as C
+            h = c_vp()
+            Dc = np.ascontiguousarray(D, dtype=np.complex128)
+            st = lib.nep_wep_sylv_create(nz, nx, _lib.hptr(Dc), 1.0 / wd.hx ** 2, C.byref(h))
+            if st == 0:
+                self.sylv = h
+            elif st != _lib.NEP_ERR_UNSUPPORTED:
+                check(st)
+        if self.sylv is None:
+            S = -(4.0 / wd.hx ** 2) * np.sin(np.pi * np.arange(1, nx + 1) / (2 * (nx + 1))) ** 2
+            self.G = to_dev(1.0 / (D[:, None] + S[None, :]))                                   # nz x nx
+            self.Fs = to_dev(np.fft.fft(np.eye(nz), axis=0) / np.sqrt(nz))                     # unitary DFT, symmetric
+            jx = np.arange(1, nx + 1)
+            self.Wr = torch.from_numpy(np.ascontiguousarray(np.sqrt(2.0 / (nx + 1)) * np.sin(np.pi * np.outer(jx, jx) / (nx + 1)))).to("cuda")
         self.Ksc = to_dev(Kmat - k_bar)                                                    # K_scaled (Waveguide.jl:229-230)
         # ---- regions: indicator matrices (z: nz x N; x: nx x (N+4)), kappa = i + N j
         Bz = np.kron(np.eye(N), np.ones((L, 1)))
@@ -346,11 +364,22 @@ class WEPPreconditioner:
         self.MinvH = None
         self._generate()
 
+    def __del__(self):
+        try:
+            if getattr(self, "sylv", None):
+                lib.nep_wep_sylv_destroy(self.sylv)
+                self.sylv = None
+        except Exception:
+            pass
+
     # -- pieces
     def linv(self, X):
         """in place Sylvester solve on a device nz x nx matrix (column-major): X <- F (G .* (F^H X W)) W; the two products
         with the real W run as real GEMMs"""
         nz, nx = self.nep.nz, self.nep.nx
+        if self.sylv is not None:
+            check(lib.nep_wep_sylv_solve(self.sylv, _p(X), stream_ptr()))
+            return X
         self._xw(X, self.T1)
         zgemm(C_, N_, nz, nx, nz, 1.0, self.Fs, nz, self.T1, nz, 0.0, self.T2, nz)
         check(lib.nep_hadamard(nz * nx, 1, c_vp(self.T2.data_ptr()), nz * nx, c_vp(self.G.data_ptr()), nz * nx, stream_ptr()))
@@ -367,6 +396,9 @@ class WEPPreconditioner:
     def functionals(self, X, out):
         """out (N x (N+4)) = region means of X (waveguide_preconditioner.jl:297-304)"""
         nz, nx, N = self.nep.nz, self.nep.nx, self.N
+        if self.sylv is not None:
+            check(lib.nep_wep_region_means(nz, nx, N, _p(X), _p(out), stream_ptr()))
+            return out
         zgemm(N_, N_, nz, N + 4, nx, 1.0, X, nz, self.Ax, nx, 0.0, self.tz, nz)
         zgemm(N_, N_, N, N + 4, nz, 1.0, self.Az, N, self.tz, nz, 0.0, out, N)
         return out
@@ -375,10 +407,13 @@ class WEPPreconditioner:
         """Y (nz x nx) = sum_k alpha_k E_k  (waveguide_preconditioner.jl:263-288, :382-412): K_scaled restricted to the regions,
         plus -P^{-1}(sigma) of the boundary pieces in the first and last column"""
         nz, nx, N = self.nep.nz, self.nep.nx, self.N
-        zgemm(N_, N_, nz, N + 4, N, 1.0, self.Bz, nz, alpha, N, 0.0, self.tz, nz)            # Bz A
-        zgemm(N_, T_, nz, nx, N + 4, 1.0, self.tz, nz, self.Bx, nx, 0.0, Y, nz)               # (Bz A) Bx^T
-        check(lib.nep_hadamard(nz * nx, 1, c_vp(Y.data_ptr()), nz * nx, c_vp(self.Ksc.data_ptr()), nz * nx, stream_ptr()))
-        zgemm(N_, N_, nz, 2, N + 4, 1.0, self.tz, nz, self.cb, N + 4, 0.0, self.eb, nz)       # [e_-, e_+]
+        if self.sylv is not None:
+            check(lib.nep_wep_region_expand(nz, nx, N, _p(alpha), _p(self.Ksc), self.dd1, self.dd2, _p(Y), _p(self.eb), stream_ptr()))
+        else:
+            zgemm(N_, N_, nz, N + 4, N, 1.0, self.Bz, nz, alpha, N, 0.0, self.tz, nz)            # Bz A
+            zgemm(N_, T_, nz, nx, N + 4, 1.0, self.tz, nz, self.Bx, nx, 0.0, Y, nz)               # (Bz A) Bx^T
+            check(lib.nep_hadamard(nz * nx, 1, c_vp(Y.data_ptr()), nz * nx, c_vp(self.Ksc.data_ptr()), nz * nx, stream_ptr()))
+            zgemm(N_, N_, nz, 2, N + 4, 1.0, self.tz, nz, self.cb, N + 4, 0.0, self.eb, nz)       # [e_-, e_+]
         self.ops.pinv(self.eb, self.pb)
         dense.axpy(-1.0, self.pb, Y, nz)                                                     # column 1       -= P_-^{-1} e_-
         check(lib.nep_axpy(nz, _lib.cd(-1.0), c_vp(self.pb.data_ptr() + 16 * nz), c_vp(Y.data_ptr() + 16 * nz * (nx - 1)),

@@ -891,3 +891,82 @@ def test_sharded_beyn_through_the_c_abi_one_rank_rccl(na):
     finally:
         na.MatrixTrapezoidalSharded.comm = None
         comm.close()
+
+
+@pytest.mark.parametrize("nz,nx", [(7, 11), (105, 109), (299, 303), (60, 64)])
+def test_wep_sylvester_solve_pfa_vs_numpy(na, nz, nx):
+    """nep_wep_sylv_solve (prime-factor DFT along z + per-mode tridiagonal scans along x, csrc/wep.hip) against the dense
+    diagonalisation it replaces, X = F (G .* (F^H C W)) W with the DFT matrix F and the sine matrix W
+    (waveguide_preconditioner.jl:120-219): sizes with N2 = 1 (7 prime), 105 = 15 * 7, 299 = 13 * 23, 60 = 15 * 4; also the
+    region means / expansion kernels against their indicator-matrix products"""
+    import ctypes as C
+    import torch
+    L_ = na._lib.lib
+    rng = np.random.default_rng(nz)
+    hx, hz, sigma, kbar = 0.37, 0.21, -3 - 3.5j, 2.1 + 0.3j
+    v = np.zeros(nz, dtype=complex); v[0] = -2; v[1 % nz] += 1; v[nz - 1] += 1; v /= hz ** 2
+    w = np.zeros(nz, dtype=complex); w[1 % nz] += 1; w[nz - 1] += -1; w *= sigma / hz
+    D = np.fft.fft(v + w) + (sigma ** 2 + kbar)
+    S = -(4.0 / hx ** 2) * np.sin(np.pi * np.arange(1, nx + 1) / (2 * (nx + 1))) ** 2
+    F = np.fft.fft(np.eye(nz), axis=0) / np.sqrt(nz)
+    jx = np.arange(1, nx + 1)
+    W = np.sqrt(2.0 / (nx + 1)) * np.sin(np.pi * np.outer(jx, jx) / (nx + 1))
+    Cm = rng.standard_normal((nz, nx)) + 1j * rng.standard_normal((nz, nx))
+    ref = F @ ((F.conj().T @ Cm @ W) / (D[:, None] + S[None, :])) @ W
+    h = C.c_void_p()
+    Dc = np.ascontiguousarray(D)
+    assert L_.nep_wep_sylv_create(nz, nx, na._lib.hptr(Dc), 1.0 / hx ** 2, C.byref(h)) == 0
+    info = (C.c_int32 * 4)()
+    assert L_.nep_wep_sylv_info(h, info) == 0 and info[0] * info[1] == nz and np.gcd(info[0], info[1]) == 1
+    Xd = na.to_dev(Cm)                                   # (nx, nz) tensor = column-major nz x nx
+    for _ in range(2):                                   # the work block is reused: repeatable
+        Xd = na.to_dev(Cm)
+        assert L_.nep_wep_sylv_solve(h, C.c_void_p(Xd.data_ptr()), None) == 0
+    X = na.to_host(Xd)
+    assert np.linalg.norm(X - ref) <= 1e-12 * np.linalg.norm(ref)
+    assert L_.nep_wep_sylv_destroy(h) == 0
+    if nx == nz + 4:
+        for N in [d for d in (1, 3, 5, 7, 13) if nz % d == 0][:3]:
+            Lr = nz // N
+            Bz = np.kron(np.eye(N), np.ones((Lr, 1)))
+            Bx = np.zeros((nx, N + 4)); Bx[0, 0] = Bx[1, 1] = Bx[nx - 2, N + 2] = Bx[nx - 1, N + 3] = 1.0
+            for j in range(N):
+                Bx[2 + j * Lr:2 + (j + 1) * Lr, 2 + j] = 1.0
+            wx = np.ones(N + 4); wx[2:N + 2] = 1.0 / Lr
+            means_ref = (Bz.T / Lr) @ Cm @ (Bx * wx[None, :])
+            out = torch.empty((N + 4, N), dtype=torch.complex128, device="cuda")
+            assert L_.nep_wep_region_means(nz, nx, N, C.c_void_p(na.to_dev(Cm).data_ptr()), C.c_void_p(out.data_ptr()), None) == 0
+            assert np.linalg.norm(na.to_host(out) - means_ref) <= 1e-13 * np.linalg.norm(means_ref)
+            al = rng.standard_normal((N, N + 4)) + 1j * rng.standard_normal((N, N + 4))
+            K = rng.standard_normal((nz, nx)) + 1j * rng.standard_normal((nz, nx))
+            Y = torch.empty((nx, nz), dtype=torch.complex128, device="cuda"); eb = torch.empty((2, nz), dtype=torch.complex128, device="cuda")
+            assert L_.nep_wep_region_expand(nz, nx, N, C.c_void_p(na.to_dev(al).data_ptr()), C.c_void_p(na.to_dev(K).data_ptr()), 0.7, -0.3,
+                                            C.c_void_p(Y.data_ptr()), C.c_void_p(eb.data_ptr()), None) == 0
+            tz = Bz @ al
+            assert np.linalg.norm(na.to_host(Y) - (tz @ Bx.T) * K) <= 1e-13 * np.linalg.norm(K)
+            cb = np.zeros((N + 4, 2)); cb[0, 0] = 0.7; cb[1, 0] = -0.3; cb[N + 2, 1] = -0.3; cb[N + 3, 1] = 0.7
+            assert np.linalg.norm(na.to_host(eb) - tz @ cb) <= 1e-13 * np.linalg.norm(tz)
+
+
+@pytest.mark.parametrize("nz", [7, 105, 299])
+def test_wep_pinv_dft_vs_dense(na, nz):
+    """nep_wep_pinv_apply (two prime-factor DFTs per half in one launch) against blkdiag(R, R) diag(sinv) blkdiag(R, R)^H x with
+    the dense R = reverse(bb .* fft(.)) of Waveguide.jl:53-65"""
+    import ctypes as C
+    L_ = na._lib.lib
+    rng = np.random.default_rng(nz + 1)
+    p = 0.37
+    bb = np.exp(-2j * np.pi * np.arange(nz) * (-p) / nz)
+    R = (bb[:, None] * np.fft.fft(np.eye(nz), axis=0))[::-1, :]
+    sinv = rng.standard_normal(2 * nz) + 1j * rng.standard_normal(2 * nz)
+    x = rng.standard_normal(2 * nz) + 1j * rng.standard_normal(2 * nz)
+    ref = np.concatenate([R @ (sinv[:nz] * (R.conj().T @ x[:nz])), R @ (sinv[nz:] * (R.conj().T @ x[nz:]))])
+    h = C.c_void_p()
+    assert L_.nep_wep_pinv_create(nz, na._lib.hptr(np.ascontiguousarray(bb)), C.byref(h)) == 0
+    xd = na.to_dev(x)[0]; sd = na.to_dev(sinv)[0]; od = na.to_dev(np.zeros(2 * nz, dtype=complex))[0]
+    assert L_.nep_wep_pinv_apply(h, C.c_void_p(sd.data_ptr()), C.c_void_p(xd.data_ptr()), C.c_void_p(od.data_ptr()), None) == 0
+    out = na.to_host(od.reshape(1, -1))[:, 0]
+    assert np.linalg.norm(out - ref) <= 1e-12 * np.linalg.norm(ref)
+    assert L_.nep_wep_pinv_apply(h, C.c_void_p(sd.data_ptr()), C.c_void_p(xd.data_ptr()), C.c_void_p(xd.data_ptr()), None) == 0   # in place
+    assert np.linalg.norm(na.to_host(xd.reshape(1, -1))[:, 0] - ref) <= 1e-12 * np.linalg.norm(ref)
+    assert L_.nep_wep_pinv_destroy(h) == 0
