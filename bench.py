@@ -207,7 +207,8 @@ def c5_summary(na, args):
     lam, Q, res, info = bc.c5_device(na, nx=args.c5_nx, nz=args.c5_nz, solver="gmres", timers=tm)
     dt = time.perf_counter() - t0
     return {"workload": "WEP JARLEBRING nx=%d nz=%d (n=%d) tiar sigma=-3-3.5i maxit=60 tol=1e-8, Schur complement + "
-                        "Sylvester-SMW preconditioned GMRES (the reference's solver for this problem)" % (args.c5_nx, args.c5_nz, info["n"]),
+                        "Sylvester-SMW preconditioned GMRES (the reference's solver for this problem; 37 x 41 regions, inner reltol 1e-9, one "
+                        "refinement sweep)" % (args.c5_nx, args.c5_nz, info["n"]),
             "eigenpairs": int(len(lam)), "max_residual": max(res + [0.0]), "seconds_incl_generation": dt,
             "seconds_solver": info["solve_s"], "eigenpairs_per_s": len(lam) / info["solve_s"],
             "generate_s": info["generate_s"], "preconditioner_setup_s": info.get("preconditioner_setup_s"),

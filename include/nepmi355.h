@@ -332,6 +332,11 @@ typedef struct nep_wep_pinv nep_wep_pinv;
 int32_t nep_wep_pinv_create(int32_t nz, const nep_cdouble* h_bb, nep_wep_pinv** out);
 int32_t nep_wep_pinv_destroy(nep_wep_pinv* p);
 int32_t nep_wep_pinv_apply(nep_wep_pinv* p, const nep_cdouble* d_sinv, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream);
+/* Sylvester-SMW matrix (generate_smw_matrix, waveguide_preconditioner.jl:221-313): column kappa of dM (mm x mm column-major,
+ * mm = N (N+4)) = region means of Linv(E_kappa); the caller adds the identity and inverts.  All mm columns in one call (1517
+ * Sylvester solves at N = 37).  dWork: nz*nx + 4 nz + mm complex. */
+int32_t nep_wep_smw_matrix(nep_wep_sylv* s, nep_wep_pinv* p, int32_t N, const nep_cdouble* dKsc, double dd1, double dd2,
+                           const nep_cdouble* d_sinv, nep_cdouble* dWork, nep_cdouble* dM, nep_stream stream);
 /* dOut (N x (N+4), column-major) = means of X over the N x (N+4) regions (interior regions L x L with L = nz/N, the four
  * boundary columns of X are regions of their own); needs nx = nz + 4 */
 int32_t nep_wep_region_means(int32_t nz, int32_t nx, int32_t N, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream);

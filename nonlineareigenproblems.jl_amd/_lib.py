@@ -99,6 +99,7 @@ SIGNATURES = {
     "nep_wep_pinv_create": [c_i32, c_vp, P(c_vp)],
     "nep_wep_pinv_destroy": [c_vp],
     "nep_wep_pinv_apply": [c_vp, c_vp, c_vp, c_vp, c_vp],
+    "nep_wep_smw_matrix": [c_vp, c_vp, c_i32, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp],
     "nep_wep_region_means": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "nep_wep_region_expand": [c_i32, c_i32, c_i32, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp],
     "nep_iar_create": [c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, P(c_vp)],

@@ -463,6 +463,47 @@ int32_t nep_wep_sylv_solve(nep_wep_sylv* s, nep_cdouble* dX, nep_stream stream) 
     return NEP_OK;
 }
 
+// alpha <- e_kappa (N x (N+4) block as a vector of mm entries)
+__global__ void k_unit_vector(int mm, int kappa, cplx* __restrict__ a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < mm) a[i] = cmake(i == kappa ? 1.0 : 0.0, 0.0);
+}
+// Y[:, 0] -= pb[0:nz], Y[:, nx-1] -= pb[nz:2nz]
+__global__ void k_sub_boundary(int nz, int nx, const cplx* __restrict__ pb, cplx* __restrict__ Y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nz) { Y[i].x -= pb[i].x; Y[i].y -= pb[i].y; }
+    else if (i < 2 * nz) { cplx* y = Y + (int64_t)nz * (nx - 1) + (i - nz); y->x -= pb[i].x; y->y -= pb[i].y; }
+}
+
+int32_t nep_wep_region_means(int32_t nz, int32_t nx, int32_t N, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream);
+int32_t nep_wep_region_expand(int32_t nz, int32_t nx, int32_t N, const nep_cdouble* dAlpha, const nep_cdouble* dKsc, double dd1,
+                              double dd2, nep_cdouble* dY, nep_cdouble* dEb, nep_stream stream);
+
+// Sylvester-SMW matrix, all mm = N (N+4) columns in one call (generate_smw_matrix, waveguide_preconditioner.jl:221-313):
+//   column kappa of dM (mm x mm, column-major) = region means of Linv(E_kappa),  E_kappa = expansion of the unit vector e_kappa
+//   (K_scaled on region kappa, minus P^{-1}(sigma) of the boundary pieces in the first / last grid column).
+// The caller adds the identity and inverts (host, mm x mm).  dWork: nz*nx + 4 nz + mm complex of scratch.
+int32_t nep_wep_smw_matrix(nep_wep_sylv* s, nep_wep_pinv* p, int32_t N, const nep_cdouble* dKsc, double dd1, double dd2,
+                           const nep_cdouble* d_sinv, nep_cdouble* dWork, nep_cdouble* dM, nep_stream stream) {
+    ARGCHK(s && p && dKsc && d_sinv && dWork && dM && N >= 1 && s->nz % N == 0 && s->nx == s->nz + 4 && p->nz == s->nz);
+    hipStream_t st = as_stream(stream);
+    const int nz = s->nz, nx = s->nx, mm = N * (N + 4);
+    cplx* Y = (cplx*)dWork; cplx* eb = Y + (size_t)nz * nx; cplx* pb = eb + 2 * (size_t)nz; cplx* alpha = pb + 2 * (size_t)nz;
+    for (int kappa = 0; kappa < mm; ++kappa) {
+        hipLaunchKernelGGL(k_unit_vector, dim3((mm + 255) / 256), dim3(256), 0, st, mm, kappa, alpha);
+        LAUNCHCHK();
+        int rc = nep_wep_region_expand(nz, nx, N, (const nep_cdouble*)alpha, dKsc, dd1, dd2, (nep_cdouble*)Y, (nep_cdouble*)eb, stream);
+        if (!rc) rc = nep_wep_pinv_apply(p, d_sinv, (const nep_cdouble*)eb, (nep_cdouble*)pb, stream);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_sub_boundary, dim3((2 * nz + 255) / 256), dim3(256), 0, st, nz, nx, (const cplx*)pb, Y);
+        LAUNCHCHK();
+        rc = nep_wep_sylv_solve(s, (nep_cdouble*)Y, stream);
+        if (!rc) rc = nep_wep_region_means(nz, nx, N, (const nep_cdouble*)Y, dM + (size_t)kappa * mm, stream);
+        if (rc) return rc;
+    }
+    return NEP_OK;
+}
+
 int32_t nep_wep_region_means(int32_t nz, int32_t nx, int32_t N, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream) {
     ARGCHK(dX && dOut && N >= 1 && nz % N == 0 && nx == nz + 4);
     hipLaunchKernelGGL(k_region_means, dim3((unsigned)N, (unsigned)(N + 4)), dim3(256), 0, as_stream(stream), (int)nz, (int)nx, (int)N,

@@ -593,20 +593,25 @@ class GMRESLinSolver(LinSolver):
         beta = dense.nrm2(r)
         tolabs = max(reltol * beta, self.abstol)
         its = 0
+        # Arnoldi columns are orthogonalised on the device without reading anything back (nep_orth_dev: DGKS / CGS); the
+        # Givens update of column j runs on the host while the device already works on column j+1, so the only cost of the
+        # convergence test is ONE speculative iteration at the end of a cycle instead of a device stall in every iteration
+        # (waveguide, n = 1e6: 3300 stalls of 50-100 us per tiar run).  MGS keeps the step-synchronous loop.
+        pipelined = self.orth in (dense.DGKS, dense.CGS) and not os.environ.get("NEP_GMRES_SYNC")
+        if pipelined:
+            Hdev = torch.zeros((m, m + 3), dtype=CDT, device="cuda")
+            Hpin = torch.zeros((m, m + 3), dtype=CDT).pin_memory()
+            Hnp = Hpin.numpy()
         while beta > tolabs and its < self.maxiter:
             dense.copy(r, V[0], n); dense.scal(V[0], 1.0 / beta, n)
             H = np.zeros((m + 1, m), dtype=np.complex128)
             cs = np.zeros(m, dtype=np.complex128); sn = np.zeros(m, dtype=np.complex128)
             g = np.zeros(m + 1, dtype=np.complex128); g[0] = beta
             j_done = 0
-            for j in range(m):
-                w = V[j + 1]
-                if self.fused_step is not None:            # w = Pl^{-1} A v as one pre-recorded launch sequence
-                    self.fused_step(V[j], w)
-                else:
-                    dense.copy(self.nep.compute_Mlincomb(self.lam, V[j].reshape(1, n)), w, n)
-                    self._prec(w)
-                h, hb, _ = dense.orthogonalize_and_normalize(V, w, j + 1, rows=n, ldv=n, method=self.orth)
+
+            def givens(j, h, hb):
+                """column j of H (h: j+1 entries, hb: the subdiagonal) through the rotations; True = cycle finished"""
+                nonlocal its, j_done
                 H[:j + 1, j] = h; H[j + 1, j] = hb
                 for i in range(j):                       # apply previous Givens rotations
                     t = cs[i] * H[i, j] + sn[i] * H[i + 1, j]
@@ -620,8 +625,42 @@ class GMRESLinSolver(LinSolver):
                 g[j + 1] = -np.conj(sn[j]) * g[j]
                 g[j] = cs[j] * g[j]
                 its += 1; j_done = j + 1
-                if abs(g[j + 1]) <= tolabs or its >= self.maxiter:
-                    break
+                return abs(g[j + 1]) <= tolabs or its >= self.maxiter
+
+            def apply_op(j):
+                w = V[j + 1]
+                if self.fused_step is not None:            # w = Pl^{-1} A v as one pre-recorded launch sequence
+                    self.fused_step(V[j], w)
+                else:
+                    dense.copy(self.nep.compute_Mlincomb(self.lam, V[j].reshape(1, n)), w, n)
+                    self._prec(w)
+                return w
+
+            if pipelined:
+                evs = [None] * m
+                done = False
+                for j in range(m):
+                    w = apply_op(j)
+                    dense.orthogonalize_and_normalize_dev(V, w, j + 1, Hdev[j], rows=n, ldv=n, method=self.orth)
+                    Hpin[j, :j + 3].copy_(Hdev[j, :j + 3], non_blocking=True)
+                    evs[j] = torch.cuda.Event(); evs[j].record()
+                    if j >= 1:                             # column j-1 while the device computes column j
+                        evs[j - 1].synchronize()
+                        row = Hnp[j - 1]
+                        if givens(j - 1, row[:j].copy(), row[j].real):
+                            done = True
+                            break
+                if not done and j_done < m and its < self.maxiter:
+                    jl = j_done
+                    evs[jl].synchronize()
+                    row = Hnp[jl]
+                    givens(jl, row[:jl + 1].copy(), row[jl + 1].real)
+            else:
+                for j in range(m):
+                    w = apply_op(j)
+                    h, hb, _ = dense.orthogonalize_and_normalize(V, w, j + 1, rows=n, ldv=n, method=self.orth)
+                    if givens(j, h, hb):
+                        break
             y = np.linalg.solve(np.triu(H[:j_done, :j_done]), g[:j_done])
             dx = dense.gemm_ts(V, y.reshape(-1, 1), k=j_done, rows=n, ldz=n)          # (1, n)
             dense.axpy(1.0, dx, x, n)
