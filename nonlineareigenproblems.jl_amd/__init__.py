@@ -8,7 +8,7 @@ It never imports the CPU oracle and has no CPU fallback.
 from . import _lib, funcs, dense
 from ._lib import NepError, device_count, LIB_PATH
 from .exceptions import NoConvergenceException, LostOrthogonalityException
-from .nep import (NEP, AbstractSPMF, SPMF_NEP, DEP, PEP, SumNEP, DerSPMF, shift_and_scale, SPMFDevice,
+from .nep import (NEP, AbstractSPMF, SPMF_NEP, DEP, PEP, SumNEP, DerSPMF, shift_and_scale, SPMFDevice, Mder_NEP,
                   LowRankMatrixAndFunction, LowRankFactorizedNEP,
                   to_dev, to_host)
 from .linsolvers import (LinSolver, FactorizeLinSolver, BackslashLinSolver, FactorizeLinSolverCreator,

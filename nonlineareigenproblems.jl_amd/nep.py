@@ -213,6 +213,60 @@ class NEP:
         return (self.n, self.n) if d is None else self.n
 
 
+class Mder_NEP(NEP):
+    """A NEP known only through a function lam -> M(lam) (and optionally its derivatives i <= maxder): the reference's
+    `Mder_NEP` (src/nep_type_helpers.jl:6-12,106-146) and the "Custom NEP type" of test/nleigs/nleigs_nep_types.jl.  The
+    matrices come from the user's host function; every product with them runs on the device (a rectangular-CSR operator per
+    evaluation point, nep_csr_mv).  `nleigs` accepts it through matrix-valued divided differences."""
+
+    def __init__(self, n, Mder_fun, maxder=0):
+        self.n = int(n)
+        self.Mder_fun = Mder_fun
+        self.maxder = int(maxder)
+        self._ops = {}                                  # (lam, i) -> DeviceCSR, small LRU
+
+    def compute_Mder(self, lam, i=0):
+        if i > self.maxder:
+            raise ValueError("Derivatives higher than %d are not available" % self.maxder)
+        return self.Mder_fun(lam) if self.maxder == 0 else self.Mder_fun(lam, i)
+
+    def _op(self, lam, i=0):
+        key = (complex(lam), int(i))
+        op = self._ops.pop(key, None)
+        if op is None:
+            op = DeviceCSR(sp.csr_matrix(self.compute_Mder(lam, i), dtype=np.complex128))
+            while len(self._ops) >= 8:
+                self._ops.pop(next(iter(self._ops)))
+        self._ops[key] = op
+        return op
+
+    def compute_Mlincomb(self, lam, V, a=None, startder=0):
+        """sum_j a_j M^(j-1+startder)(lam) v_j  (NEPCore.jl:164-172, compute_Mlincomb_from_Mder) on the device"""
+        host = not is_dev(V)
+        Vd = to_dev(V) if host else (V if V.dim() == 2 else V.reshape(1, -1))
+        k = Vd.shape[0]
+        a = np.ones(k) if a is None else np.asarray(a)
+        z = torch.zeros(self.n, dtype=CDT, device="cuda")
+        for j in range(k):
+            if a[j] != 0:
+                self._op(lam, j + startder).mv(complex(a[j]), Vd[j], 1.0, z, z)
+        return to_host(z.reshape(1, -1))[:, 0] if host else z
+
+    def resid_norms(self, lams, QT):
+        """(||M(lam_s) q_s||, ||q_s||, None) for the columns of the row-major block QT (one matrix assembly + upload per
+        Ritz value: the price of a NEP that is only a function handle)"""
+        from . import dense
+        k = len(lams)
+        cols = dense.rowmajor_to_cols(QT, np.arange(k, dtype=np.int32))          # (k, n) column-major n x k
+        Y = torch.empty_like(cols)
+        for s_ in range(k):
+            self._op(lams[s_], 0).mv(1.0, cols[s_], 0.0, None, Y[s_])
+        nr = np.empty(k); nq = np.empty(k)
+        check(lib.nep_colnorms(self.n, k, c_vp(Y.data_ptr()), self.n, hptr(nr), stream_ptr()))
+        check(lib.nep_colnorms(self.n, k, c_vp(cols.data_ptr()), self.n, hptr(nq), stream_ptr()))
+        return nr, nq, None
+
+
 class AbstractSPMF(NEP):
     """M(lam) = sum_i f_i(lam) A_i   (src/NEPTypes.jl:96-113)."""
     _dev = None

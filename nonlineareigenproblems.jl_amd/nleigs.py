@@ -2,9 +2,10 @@
 
 Supported: SPMF-type NEPs (PEP, SPMF_NEP, PEP+SPMF SumNEP, DEP), dynamic and static variants, return_details
 (NleigsSolutionDetails), divided differences by matrix functions (isfunm=true) or by differencing (isfunm=false),
-leja in {0,1,2}, reusefact in {0,1,2}, and the low-rank compression of PEP + LowRankFactorizedNEP problems
+leja in {0,1,2}, reusefact in {0,1,2}, non-SPMF NEP types through matrix-valued divided differences (`Mder_NEP`: the D_j become the
+terms of an SPMF in the rational Newton basis), and the low-rank compression of PEP + LowRankFactorizedNEP problems
 (rk_nep.jl:128-152; method_nleigs.jl:206-211,406-414,424-430,464-471,480,510: the blocks of the Krylov vectors beyond the
-polynomial degree p hold r = sum rank(C_i) rows instead of n -- gun: 84 instead of 9956).  Not supported: non-SPMF NEP types.
+polynomial degree p hold r = sum rank(C_i) rows instead of n -- gun: 84 instead of 9956).
 
 Device realisation of `backslash` (method_nleigs.jl:399-518).  The reference runs O(N) stacked SpMVs per step
 (`sum(reshape(BBCC*z_block,n,:) .* transpose(sgdd[:,ii+1]),dims=2)`, :462).  The block recurrence for z does not
@@ -57,12 +58,23 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
         errmeasure = ResidualErrmeasure(nep)
     Sigma = np.asarray(Sigma, dtype=complex); Xi = np.asarray(Xi, dtype=float)
     nodes = np.asarray(nodes, dtype=complex)
-    from .nep import require_pure_spmf
-    require_pure_spmf(nep, "nleigs")
+    from .nep import require_pure_spmf, AbstractSPMF, SPMFDevice
     n = nep.size(1)
-    p, q = rk.rk_structure(nep)
-    mt = len(nep.get_Av())
-    LR = rk.low_rank_structure(nep)
+    newton_basis = not isinstance(nep, AbstractSPMF)
+    if newton_basis:
+        # non-SPMF NEP type (method_nleigs.jl:149-153: `D = ratnewtoncoeffs(lam -> compute_Mder(nep, lam), ...)`): the
+        # matrix-valued divided differences D_0..D_{maxdgr+1} ARE an SPMF in the rational Newton basis, M ~ sum_j b_j(lam) D_j,
+        # whose scalar divided differences are the identity -- so the stacked-CSR kernels below run unchanged on the D_j
+        if not hasattr(nep, "compute_Mder"):
+            raise TypeError("nleigs needs an SPMF-type NEP or one that provides compute_Mder")
+        if maxdgr + 2 > 128:
+            raise ValueError("nleigs on a non-SPMF NEP keeps maxdgr+2 divided-difference matrices on the device: maxdgr <= 126")
+        p, q, mt, LR = 0, 0, maxdgr + 2, None
+    else:
+        require_pure_spmf(nep, "nleigs")
+        p, q = rk.rk_structure(nep)
+        mt = len(nep.get_Av())
+        LR = rk.low_rank_structure(nep)
     if LR is not None and not 1 <= p <= 2:
         # the reference reads block p-1 of a two-block vector in its first step (method_nleigs.jl:408-414)
         raise ValueError("nleigs with low-rank structure needs a polynomial part of degree 1 or 2")
@@ -100,8 +112,20 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
     if not isfunm and len(np.unique(sigma)) != len(sigma):                          # method_nleigs.jl:142-145
         raise ValueError("All interpolation nodes must be distinct when no matrix functions are used for computing "
                          "the generalized divided differences.")
-    sgdd = rk.scgendivdiffs(sigma[rng_], xi[rng_], beta[rng_], nep.get_fv(), isfunm)   # mt x (maxdgr+2)
-    nrmD = [float(np.max(abs(sgdd[:, 0])))]
+    if newton_basis:
+        if len(np.unique(sigma[rng_])) != len(sigma[rng_]):
+            raise ValueError("All interpolation nodes must be distinct when no matrix functions are used for computing "
+                             "the generalized divided differences.")
+        import scipy.sparse as sp
+        Dall = rk.ratnewtoncoeffs(lambda lam_: sp.csr_matrix(nep.compute_Mder(lam_), dtype=np.complex128), sigma[rng_], xi[rng_], beta[rng_])
+        nrmD_all = [float(np.sqrt(abs(Dj.multiply(Dj.conj()).sum()))) for Dj in Dall]        # Frobenius norms (:152,225)
+        newton_dev = SPMFDevice(Dall)
+        sgdd = np.eye(mt, dtype=np.complex128)
+        nrmD = [nrmD_all[0]]
+    else:
+        sgdd = rk.scgendivdiffs(sigma[rng_], xi[rng_], beta[rng_], nep.get_fv(), isfunm)   # mt x (maxdgr+2)
+        nrmD = [float(np.max(abs(sgdd[:, 0])))]
+    kdev = newton_dev if newton_basis else nep.dev                                          # the operator of the z0 sum
     if not np.isfinite(nrmD[0]):
         raise ValueError("The generalized divided differences must be finite.")
 
@@ -154,7 +178,7 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
             check(lib.nep_block_recur(n, N, hptr(a), hptr(b), c_vp(zb.data_ptr()), c_vp(zb.data_ptr()), st()))
             # z0 = -sum_j A_j (Zblocks sgdd[j, 1:N+1]^T)   (Bw[0:n] = 0 without low-rank structure)
             Cm = np.asfortranarray(sgdd[:, 1:N + 1].T)                             # N x mt
-            nep.dev.mlincomb(Cm, zb.data_ptr() + 16 * n, tmp, k=N, ldv=n)
+            kdev.mlincomb(Cm, zb.data_ptr() + 16 * n, tmp, k=N, ldv=n)
             add_to_cache = ((not expand or k > kconv) and reusefact == 1) or reusefact == 2
             w = V[l]
             w0 = cache.solve_dev(shift, tmp, add_to_cache, out=w[:n], scale=-1.0 / beta[0])
@@ -262,7 +286,7 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
         if expand:
             kn += blk(k)
             N += 1
-            nrmD.append(float(np.max(abs(sgdd[:, k]))))
+            nrmD.append(nrmD_all[k] if newton_basis else float(np.max(abs(sgdd[:, k]))))
             if not np.isfinite(nrmD[k]):
                 raise ValueError("The generalized divided differences must be finite.")
             if n > 1 and k >= 5 and k < kconv:

@@ -154,6 +154,21 @@ def ratnewtoncoeffs_scalar(fun, sigma, xi, beta):
     return D
 
 
+def ratnewtoncoeffs(fun, sigma, xi, beta):
+    """src/rk_helper/rk_utils.jl:73-93 for a matrix-valued function lam -> M(lam) (SciPy sparse): rational divided
+    differences D_0..D_{m-1} by differencing (host: m evaluations of the user's function + sparse linear combinations);
+    the sigma must be distinct"""
+    m = len(sigma)
+    D = [fun(sigma[0]) * beta[0]]
+    for j in range(1, m):
+        Qj = None
+        for k in range(j):
+            T = D[k] * evalrat(sigma[:k], xi[:k], beta[:k + 1], sigma[j])
+            Qj = T if Qj is None else Qj + T
+        D.append((fun(sigma[j]) - Qj) * (1.0 / evalrat(sigma[:j], xi[:j], beta[:j + 1], sigma[j])))
+    return D
+
+
 def scgendivdiffs(sigma, xi, beta, pff, isfunm=True):
     """rk_utils.jl:56-66"""
     if isfunm:

@@ -116,6 +116,29 @@ class NEP:
         return a[0] * z
 
 
+class Mder_NEP(NEP):
+    """nep_type_helpers.jl:6-12,106-146 (Mder_NEP): a NEP known only through a function lam -> M(lam) (and, optionally,
+    derivatives i <= maxder); what test/nleigs/nleigs_nep_types.jl calls "Custom NEP type"."""
+
+    def __init__(self, n, Mder_fun, maxder=0):
+        self.n = n
+        self.Mder_fun = Mder_fun
+        self.maxder = maxder
+
+    def compute_Mder(self, lam, i=0):
+        if i > self.maxder:
+            raise ValueError("Derivatives higher than %d are not available" % self.maxder)
+        return self.Mder_fun(lam) if self.maxder == 0 else self.Mder_fun(lam, i)
+
+    def _mlincomb(self, lam, V, a):
+        """NEPCore.jl:164-172 compute_Mlincomb_from_Mder"""
+        z = np.zeros(self.n, dtype=complex)
+        for j in range(V.shape[1]):
+            if a[j] != 0:
+                z = z + a[j] * (self.compute_Mder(lam, j) @ V[:, j])
+        return np.asarray(z).ravel()
+
+
 class AbstractSPMF(NEP):
     def compute_Mder(self, lam, i=0):
         """NEPTypes.jl:362-394 (generic AbstractSPMF route)."""

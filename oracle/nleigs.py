@@ -188,6 +188,24 @@ def ratnewtoncoeffs_scalar(f, sigma, xi, beta):
     return D
 
 
+def ratnewtoncoeffs(fun, sigma, xi, beta):
+    """rk_utils.jl:73-93 for a MATRIX-valued function (lam -> M(lam), sparse or dense): rational divided differences
+    D_0..D_{m-1} by differencing; the sigma must be distinct"""
+    m = len(sigma)
+    D = [fun(sigma[0]) * beta[0]]
+    for j in range(1, m):
+        Qj = None
+        for k in range(j):
+            T = D[k] * evalrat(sigma[:k], xi[:k], beta[:k + 1], sigma[j])
+            Qj = T if Qj is None else Qj + T
+        D.append((fun(sigma[j]) - Qj) * (1.0 / evalrat(sigma[:j], xi[:j], beta[:j + 1], sigma[j])))
+    return D
+
+
+def _fro(A):
+    return float(np.sqrt(abs(A.multiply(A.conj()).sum()))) if sp.issparse(A) else float(np.linalg.norm(A))
+
+
 def scgendivdiffs(sigma, xi, beta, maxdgr, pff, isfunm=True):
     """rk_utils.jl:56-66"""
     if isfunm:
@@ -200,10 +218,14 @@ class RKNEP:
 
     def __init__(self, nep):
         self.nep = nep
-        Av = nep.get_Av()
-        self.BC = Av
         self.is_low_rank = False
         self.r = 0
+        self.spmf = hasattr(nep, "get_Av")
+        if not self.spmf:                      # RKNEP(::Type{T}, nep::NEP), rk_nep.jl:34-35: no structure known
+            self.p, self.q, self.BC = 0, 0, []
+            return
+        Av = nep.get_Av()
+        self.BC = Av
         if isinstance(nep, neps.PEP):
             self.p, self.q = len(Av) - 1, 0
         elif isinstance(nep, neps.SumNEP) and isinstance(nep.nep1, neps.PEP):
@@ -342,7 +364,7 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
     n = nep.size(1)
     if n == 1:
         maxdgr = maxit + 1
-    computeD = n <= 400
+    computeD = n <= 400 or not P.spmf           # `!P.spmf || computeD` in every branch of the reference
     cache = LinSolverCache(nep, linsolvercreator)
     v = np.array(v, dtype=complex)
 
@@ -371,11 +393,20 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
     if not isfunm and len(np.unique(sigma)) != len(sigma):                          # :142-145
         raise ValueError("All interpolation nodes must be distinct when no matrix functions are used for computing "
                          "the generalized divided differences.")
-    sgdd = scgendivdiffs(sigma[rng_], xi[rng_], beta[rng_], maxdgr, nep.get_fv(), isfunm)
-    D = []
-    if computeD:
-        D.append(constructD(0, P, sgdd))
-    nrmD = [float(np.max(abs(sgdd[:, 0])))]
+    if not P.spmf:                                                                  # :149-153
+        if len(np.unique(sigma[rng_])) != len(sigma[rng_]):
+            raise ValueError("All interpolation nodes must be distinct when no matrix functions are used for computing "
+                             "the generalized divided differences.")
+        Dall = ratnewtoncoeffs(lambda lam_: nep.compute_Mder(lam_), sigma[rng_], xi[rng_], beta[rng_])
+        D = [Dall[0]]
+        nrmD = [_fro(Dall[0])]
+        sgdd = None
+    else:
+        sgdd = scgendivdiffs(sigma[rng_], xi[rng_], beta[rng_], maxdgr, nep.get_fv(), isfunm)
+        D = []
+        if computeD:
+            D.append(constructD(0, P, sgdd))
+        nrmD = [float(np.max(abs(sgdd[:, 0])))]
     if not np.isfinite(nrmD[0]):
         raise ValueError("The generalized divided differences must be finite.")
 
@@ -395,10 +426,12 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
     while k <= kmax:
         if expand:
             kn += P.blk(k)                                                          # :206-211
-            if computeD:
+            if not P.spmf:
+                D.append(Dall[k])
+            elif computeD:
                 D.append(constructD(k, P, sgdd))
             N += 1
-            nrmD.append(float(np.max(abs(sgdd[:, k]))))
+            nrmD.append(_fro(D[k]) if not P.spmf else float(np.max(abs(sgdd[:, k]))))
             if not np.isfinite(nrmD[k]):
                 raise ValueError("The generalized divided differences must be finite.")
             if n > 1 and k >= 5 and k < kconv:

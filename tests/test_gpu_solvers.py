@@ -970,3 +970,43 @@ def test_wep_pinv_dft_vs_dense(na, nz):
     assert L_.nep_wep_pinv_apply(h, C.c_void_p(sd.data_ptr()), C.c_void_p(xd.data_ptr()), C.c_void_p(xd.data_ptr()), None) == 0   # in place
     assert np.linalg.norm(na.to_host(xd.reshape(1, -1))[:, 0] - ref) <= 1e-12 * np.linalg.norm(ref)
     assert L_.nep_wep_pinv_destroy(h) == 0
+
+
+def test_nleigs_custom_nep_type(na):
+    """test/nleigs/nleigs_nep_types.jl "Custom NEP type": a NEP given only by lam -> M(lam) (na.Mder_NEP) through nleigs with
+    matrix-valued divided differences (the D_j become the terms of an SPMF in the rational Newton basis on the device): the 4
+    eigenvalues of the underlying PEP, equal to the oracle's run and to the PEP run; plus a sparse n = 655 case against the
+    SPMF formulation of the same problem"""
+    from oracle import neps as on, nleigs as onl
+    B = [np.array([[1.0, 3], [5, 6]]), np.array([[3.0, 4], [6, 6]])]
+    opep = on.PEP(B + [np.eye(2)])
+    Sigma = np.array([-10.0 - 2j, 10 - 2j, 10 + 2j, -10 + 2j])
+    custom = na.Mder_NEP(2, lambda lam: opep.compute_Mder(lam))
+    lam, X, res = na.nleigs(custom, Sigma, maxit=10, v=np.ones(2) + 0j, blksize=5)
+    lo, Xo, ro = onl.nleigs(on.Mder_NEP(2, lambda lam: opep.compute_Mder(lam)), Sigma, maxit=10, v=np.ones(2) + 0j, blksize=5)
+    assert len(lam) == len(lo) == 4
+    assert max(np.min(abs(lo - l)) for l in lam) < 1e-9
+    for i in range(4):                                           # verify_lambdas tolerance of the reference test
+        assert np.linalg.norm(opep.compute_Mlincomb(lam[i], X[:, i])) / np.linalg.norm(X[:, i]) < 1e-5
+    # compute_Mlincomb of the function-handle NEP runs on the device
+    v = np.array([1.0 + 2j, -0.5j])
+    assert np.linalg.norm(custom.compute_Mlincomb(0.3 + 0.1j, v) - opep.compute_Mder(0.3 + 0.1j) @ v) < 1e-13
+    # sparse problem (n = 300 quadratic PEP) as a function handle against its PEP form
+    import scipy.sparse as sp
+    rng = np.random.default_rng(12)
+    n = 300
+    A0 = sp.csr_matrix(0.2 * sp.random(n, n, 0.02, random_state=rng) + sp.diags(np.linspace(-40.0, 40.0, n)))
+    A1 = sp.csr_matrix(0.3 * sp.random(n, n, 0.02, random_state=rng))
+    A2 = sp.csr_matrix(-sp.identity(n))
+    pep = na.PEP([A0, A1, A2])
+    fun = na.Mder_NEP(n, lambda lam: A0 + lam * A1 + lam ** 2 * A2)
+    Sig = np.array([-0.6 - 0.6j, 0.6 - 0.6j, 0.6 + 0.6j, -0.6 + 0.6j])
+    v0 = np.random.Generator(np.random.Philox(3)).standard_normal(n) + 0j
+    kw = dict(maxit=60, v=v0, tol=1e-9)
+    l1, _, _ = na.nleigs(pep, Sig, **kw)
+    l2, X2, _ = na.nleigs(fun, Sig, **kw)
+    assert len(l1) == len(l2) >= 2
+    assert max(np.min(abs(l1 - l)) for l in l2) < 1e-8
+    for i in range(len(l2)):
+        M = A0 + l2[i] * A1 + l2[i] ** 2 * A2
+        assert np.linalg.norm(M @ X2[:, i]) / np.linalg.norm(X2[:, i]) < 1e-8

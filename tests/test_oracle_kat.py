@@ -532,3 +532,23 @@ def test_c_port_of_compute_Mlincomb():
         assert np.linalg.norm(z1 - ref) <= 1e-13 * np.linalg.norm(ref)
         assert np.linalg.norm(z2 - ref) <= 1e-13 * np.linalg.norm(ref)
     assert lib.ref_omp_threads() >= 1
+
+
+def test_nleigs_custom_nep_type_kat():
+    """test/nleigs/nleigs_nep_types.jl ("Custom NEP type": a NEP known only through compute_Mder / compute_Mlincomb): NLEIGS with
+    matrix-valued rational divided differences (ratnewtoncoeffs, rk_utils.jl:73-93; the non-SPMF branches of
+    method_nleigs.jl:149-153,225-227,410,457) returns the 4 eigenvalues of the underlying PEP, residual < 1e-5"""
+    from oracle import nleigs as onl
+    B = [np.array([[1.0, 3], [5, 6]]), np.array([[3.0, 4], [6, 6]])]
+    pep = neps.PEP(B + [np.eye(2)])
+    custom = neps.Mder_NEP(2, lambda lam: pep.compute_Mder(lam))
+    Sigma = np.array([-10.0 - 2j, 10 - 2j, 10 + 2j, -10 + 2j])
+    lam, X, res = onl.nleigs(custom, Sigma, maxit=10, v=np.ones(2) + 0j, blksize=5)
+    assert len(lam) == 4
+    ref = np.array([-8.71449789, -0.82408444 - 0.28068189j, -0.82408444 + 0.28068189j, 1.36266678])
+    for l in lam:
+        assert np.min(abs(ref - l)) < 1e-7
+    for i in range(4):
+        assert np.linalg.norm(pep.compute_Mlincomb(lam[i], X[:, i])) / np.linalg.norm(X[:, i]) < 1e-5
+    lam2, _, _ = onl.nleigs(pep, Sigma, maxit=10, v=np.ones(2) + 0j, blksize=5)
+    assert len(lam2) == 4 and max(np.min(abs(lam2 - l)) for l in lam) < 1e-9
