@@ -349,8 +349,11 @@ int32_t nep_wep_region_expand(int32_t nz, int32_t nx, int32_t N, const nep_cdoub
  *           (compute_Mlincomb! at sigma through the DerSPMF table :1130-1160, lin_solve, the 1/j shift of the block
  *           structure, orthogonalize_and_normalize!).  Sequences nep_mlincomb_dev, nep_lu_solve[_add] (+ refine_steps blind
  *           refinement steps on nep_cw_backward_error's residual), nep_iar_shift_scale and nep_orth_dev, then copies row k-1 of
- *           the device H block ((m+2) complex per row: h[0..k), beta, flags) to the caller's PINNED host block behind an
- *           event.  Nothing waits for the device; nep_iar_wait(k) blocks until H's column k has arrived.
+ *           the device H block ((m+4) complex per row: h[0..k), beta, flags, then 4 doubles = UMFPACK's componentwise backward
+ *           error omega of the refinement iterates x_0..x_refine_steps when h_cabs/h_cf were given) to the caller's PINNED host
+ *           block behind an event.  Nothing waits for the device; nep_iar_wait(k) blocks until H's column k has arrived; the
+ *           host replays UMFPACK's stopping rule on the recorded omegas instead of reading them back inside the step.
+ *           dH must be zero-filled by the caller (m rows of m+4).
  * dV: the basis, column j at dV + j*ldv (ldv >= n(m+1), zero-initialised, column 0 = start vector); dCtab: the DerSPMF
  * coefficient table (mt columns of ldc >= m entries, row j-1 = alpha_j/j f^(j)(sigma)); d_active: device int64[m+1], active
  * rows per basis column; dwork3n: 3n complex of scratch; h_cabs / h_cf: |f_t(sigma)| and f_t(sigma) for the refinement
@@ -362,6 +365,8 @@ int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdo
                        int32_t orth_method, nep_iar** out);
 int32_t nep_iar_destroy(nep_iar* s);
 int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream stream);
+/* steps k0 .. k0+count-1 (same refine_steps) in one foreign call */
+int32_t nep_iar_steps(nep_iar* s, int32_t k0, int32_t count, int32_t refine_steps, nep_stream stream);
 int32_t nep_iar_wait(nep_iar* s, int32_t k);
 
 /* ---- multi-GPU exchange of the contour integrators ----------------------------------------

@@ -105,6 +105,7 @@ SIGNATURES = {
     "nep_iar_create": [c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, P(c_vp)],
     "nep_iar_destroy": [c_vp],
     "nep_iar_step": [c_vp, c_i32, c_i32, c_vp],
+    "nep_iar_steps": [c_vp, c_i32, c_i32, c_i32, c_vp],
     "nep_iar_wait": [c_vp, c_i32],
     "nep_comm_unique_id": [c_vp],
     "nep_comm_create": [c_i32, c_i32, c_vp, P(c_vp)],

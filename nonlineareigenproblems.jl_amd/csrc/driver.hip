@@ -8,8 +8,17 @@
 //   vv      = reshape(y[:,1:k+1])  with  y[:,2:k+1] ./ (1:k)'          nep_iar_shift_scale
 //   h, beta = orthogonalize_and_normalize!(VV, vv, h, DGKS)            K6  nep_orth_dev (decision on the device)
 //   H[:,k]  -> pinned host memory behind an event                      (the host reads it when it needs eig(H_k))
+//
+// Refinement without read-backs: the step takes `refine_steps` correction sweeps blindly and RECORDS UMFPACK's componentwise
+// backward error omega of every iterate x_0 .. x_r behind the H row (4 doubles at entries k+2, k+3 of the row).  The host
+// replays UMFPACK's stopping rule on the recorded values when the row arrives and re-runs the call with checked solves in
+// the (never yet observed) case that the rule would have asked for more sweeps than were taken -- no step of the
+// recurrence waits for the device (the checked form drained the queue on 17 of the 100 gun solves).
 #include "common.h"
 #include <vector>
+
+extern "C" int nep_cw_resid_dev(nep_spmf* s, const double* d_cabs, const nep_cdouble* d_ccf, const nep_cdouble* dx, const nep_cdouble* db,
+                                nep_cdouble* dr, unsigned long long* d_bits, double xsign, hipStream_t st);
 
 struct nep_iar {
     nep_spmf* spmf; nep_lu* lu;
@@ -17,7 +26,8 @@ struct nep_iar {
     cplx* dV; const cplx* dCtab; int64_t ldc; const int64_t* d_active;
     cplx* dz; cplx* dW;                      // z (n) ; refinement work r, x (2n)
     std::vector<double> cabs; std::vector<nep_cdouble> cf;
-    cplx* dH; nep_cdouble* hH;               // m rows of (m+2): device / pinned host
+    cplx* dH; nep_cdouble* hH;               // m rows of (m+4): device / pinned host; row k-1 = h[0..k), beta, flags, omegas
+    double* d_cabs; cplx* d_ccf;             // |f_t(sigma)|, f_t(sigma) resident on the device (refinement residuals)
     int32_t method;
     std::vector<hipEvent_t> ev;              // ev[k]: H column k is in pinned memory
 };
@@ -36,7 +46,15 @@ int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdo
     s->spmf = spmf; s->lu = lu; s->n = n; s->ldv = ldv; s->m = m; s->mt = mt;
     s->dV = (cplx*)dV; s->dCtab = (const cplx*)dCtab; s->ldc = ldc; s->d_active = d_active;
     s->dz = (cplx*)dwork3n; s->dW = (cplx*)dwork3n + n;
-    if (h_cabs && h_cf) { s->cabs.assign(h_cabs, h_cabs + mt); s->cf.assign(h_cf, h_cf + mt); }
+    s->d_cabs = nullptr; s->d_ccf = nullptr;
+    if (h_cabs && h_cf) {
+        s->cabs.assign(h_cabs, h_cabs + mt); s->cf.assign(h_cf, h_cf + mt);
+        void* p = nullptr;
+        if (nep_pool_alloc(&p, (size_t)mt * 24 + 64)) { delete s; return NEP_ERR_HIP; }
+        s->d_cabs = (double*)p; s->d_ccf = (cplx*)((char*)p + (((size_t)mt * 8 + 15) & ~(size_t)15));
+        HIPCHK(hipMemcpy(s->d_cabs, h_cabs, (size_t)mt * 8, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(s->d_ccf, h_cf, (size_t)mt * 16, hipMemcpyHostToDevice));
+    }
     s->dH = (cplx*)dH; s->hH = h_pinnedH; s->method = orth_method;
     s->ev.assign(m + 1, nullptr);
     *out = s;
@@ -46,12 +64,13 @@ int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdo
 int32_t nep_iar_destroy(nep_iar* s) {
     if (!s) return NEP_OK;
     for (hipEvent_t e : s->ev) if (e) (void)hipEventDestroy(e);
+    if (s->d_cabs) nep_pool_free(s->d_cabs);
     delete s;
     return NEP_OK;
 }
 
 int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream stream) {
-    ARGCHK(s && k >= 1 && k <= s->m && refine_steps >= 0);
+    ARGCHK(s && k >= 1 && k <= s->m && refine_steps >= 0 && refine_steps <= 3);
     ARGCHK(refine_steps == 0 || !s->cabs.empty());
     hipStream_t st = as_stream(stream);
     const int64_t n = s->n;
@@ -59,6 +78,9 @@ int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream str
     cplx* vv = s->dV + (int64_t)k * s->ldv;
     int rc = nep_mlincomb_dev(s->spmf, k, (const nep_cdouble*)s->dCtab, s->ldc, (const nep_cdouble*)col, n, (nep_cdouble*)s->dz, stream);
     if (rc) return rc;
+    cplx* hrow = s->dH + (int64_t)(k - 1) * (s->m + 4);
+    unsigned long long* bits = (unsigned long long*)(hrow + k + 2);      // zero: dH is zero-filled by the caller, a row is used once
+    const bool record = !s->cabs.empty();
     if (refine_steps == 0) {
         rc = nep_lu_solve(s->lu, 1, (const nep_cdouble*)s->dz, n, (nep_cdouble*)vv, n, -1.0, stream);
         if (rc) return rc;
@@ -66,8 +88,8 @@ int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream str
         cplx* r = s->dW; cplx* x = s->dW + n;
         rc = nep_lu_solve(s->lu, 1, (const nep_cdouble*)s->dz, n, (nep_cdouble*)x, n, 1.0, stream);
         for (int i = 0; i < refine_steps && !rc; ++i) {
-            rc = nep_cw_backward_error(s->spmf, s->cabs.data(), s->cf.data(), (const nep_cdouble*)x, (const nep_cdouble*)s->dz, nullptr,
-                                       nullptr, (nep_cdouble*)r, nullptr, stream);
+            rc = nep_cw_resid_dev(s->spmf, s->d_cabs, (const nep_cdouble*)s->d_ccf, (const nep_cdouble*)x, (const nep_cdouble*)s->dz,
+                                  (nep_cdouble*)r, bits + i, 1.0, st);
             if (rc) break;
             if (i == refine_steps - 1)
                 rc = nep_lu_solve_add(s->lu, 1, (const nep_cdouble*)r, n, (const nep_cdouble*)x, n, (nep_cdouble*)vv, n, -1.0, stream);
@@ -76,14 +98,29 @@ int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream str
         }
         if (rc) return rc;
     }
+    if (record) {       // omega of the iterate that is kept (stored negated in vv)
+        rc = nep_cw_resid_dev(s->spmf, s->d_cabs, (const nep_cdouble*)s->d_ccf, (const nep_cdouble*)vv, (const nep_cdouble*)s->dz,
+                              (nep_cdouble*)s->dW, bits + refine_steps, -1.0, st);
+        if (rc) return rc;
+    }
     rc = nep_iar_shift_scale(n, k, (const nep_cdouble*)col, (nep_cdouble*)vv, stream);
     if (rc) return rc;
-    cplx* hrow = s->dH + (int64_t)(k - 1) * (s->m + 2);
     rc = nep_orth_dev((const nep_cdouble*)s->dV, s->ldv, n * (int64_t)(k + 1), k, s->d_active, (nep_cdouble*)vv, (nep_cdouble*)hrow, s->method, stream);
     if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(s->hH + (int64_t)(k - 1) * (s->m + 2), hrow, (size_t)(k + 2) * sizeof(cplx), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(s->hH + (int64_t)(k - 1) * (s->m + 4), hrow, (size_t)(k + 4) * sizeof(cplx), hipMemcpyDeviceToHost, st));
     if (!s->ev[k]) HIPCHK(hipEventCreateWithFlags(&s->ev[k], hipEventDisableTiming | hipEventBlockingSync));
     HIPCHK(hipEventRecord(s->ev[k], st));
+    return NEP_OK;
+}
+
+// steps k0 .. k0+count-1 in one call: a host language with a global interpreter lock hands the lock to its other threads
+// (eigen workers, convergence checks) for the duration instead of fighting for it after every step
+int32_t nep_iar_steps(nep_iar* s, int32_t k0, int32_t count, int32_t refine_steps, nep_stream stream) {
+    ARGCHK(s && count >= 1);
+    for (int32_t k = k0; k < k0 + count; ++k) {
+        int rc = nep_iar_step(s, k, refine_steps, stream);
+        if (rc) return rc;
+    }
     return NEP_OK;
 }
 

@@ -28,7 +28,10 @@ struct nep_spmf {
     int64_t sell_cols = 0;           // padded entries / 64
     NepScratch coef;          // staged coefficient matrices
     NepScratch part;          // per-block partials
+    NepScratch cwpart;        // nep_cw_backward_error's own scratch: it runs on the solve stream while a residual batch
+                              // (coef, part) may be in flight on another stream (iar's convergence checks)
     PinnedRing ring;          // pinned staging of host coefficient blocks
+    PinnedRing cwring;        // ... of nep_cw_backward_error (may be called from another host thread than the residual batches)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -111,6 +114,16 @@ __device__ __forceinline__ cplx ntload(const cplx* p) {
     return cmake(v.x, v.y);
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs (private L2 each).  Remapped so that XCD x streams one contiguous range of
+// slices: the stencil neighbours of a row (+-1, +-nz rows away) then sit in the same L2 instead of being fetched by
+// several XCDs (measured at n = 1e6, k = 8 fused: see DESIGN.md K1).
+__device__ __forceinline__ int64_t xcd_block(int swz) {
+    const int64_t b = blockIdx.x, nb = gridDim.x;
+    if (!swz) return b;
+    const int64_t x = b & 7, i = b >> 3, per = nb >> 3, rem = nb & 7;
+    return x * per + (x < rem ? x : rem) + i;
+}
+
 // (b') SELL-64 SpMV for large n: one lane per row, the entries of 64 consecutive rows are interleaved so that
 // every load of a wave is one contiguous 256-byte (idx) / 512-byte (val) segment; no cross-lane reduction.
 // FOLD: k == 1 -- the vector is used directly and the per-term coefficient is applied on the fly
@@ -119,9 +132,9 @@ template <typename VT, bool FOLD>
 __global__ __launch_bounds__(256) void k_spmv_sell(const int32_t* __restrict__ sptr, const uint32_t* __restrict__ idx,
                                                    const VT* __restrict__ vals, const cplx* __restrict__ X,
                                                    const cplx* __restrict__ C, int64_t ldc, int mt, int64_t n,
-                                                   cplx* __restrict__ z) {
+                                                   cplx* __restrict__ z, int swz) {
     const int lane = threadIdx.x & 63;
-    const int64_t slice = blockIdx.x * 4LL + (threadIdx.x >> 6);
+    const int64_t slice = xcd_block(swz) * 4LL + (threadIdx.x >> 6);
     const int64_t row = slice * 64 + lane;
     if (slice * 64 >= n) return;
     cplx acc = cmake(0.0, 0.0);
@@ -142,6 +155,88 @@ __global__ __launch_bounds__(256) void k_spmv_sell(const int32_t* __restrict__ s
         }
     }
     if (row < n) z[row] = acc;
+}
+
+// (b'') 2 <= k <= NEP_K1_FUSE_MAX: the coefficient product is folded into the SpMV -- for every entry the k-term inner
+// product w = sum_j C[j,term] V[col,j] is formed on the fly (the k loads of a wave are k contiguous 1 KiB segments, and the
+// stencil neighbours of a row hit in L1/L2), so neither the k_vc launch nor the n x mt round trip of W through HBM happens:
+// the kernel's HBM traffic is the algorithmic minimum (matrix + V + z).  C is staged in LDS as cs[term][j].
+__device__ __forceinline__ cplx kdot(const cplx* __restrict__ vp, int64_t ldv, const cplx* cp, int k) {
+    cplx w0 = cmake(0.0, 0.0), w1 = cmake(0.0, 0.0);
+    int j = 0;
+    for (; j + 4 <= k; j += 4) {
+        const cplx v0 = vp[(int64_t)j * ldv], v1 = vp[(int64_t)(j + 1) * ldv];
+        const cplx v2 = vp[(int64_t)(j + 2) * ldv], v3 = vp[(int64_t)(j + 3) * ldv];
+        cfma(w0, cp[j], v0); cfma(w1, cp[j + 1], v1); cfma(w0, cp[j + 2], v2); cfma(w1, cp[j + 3], v3);
+    }
+    for (; j < k; ++j) cfma(w0, cp[j], vp[(int64_t)j * ldv]);
+    return cadd(w0, w1);
+}
+__device__ __forceinline__ void stage_coef(cplx* cs, const cplx* __restrict__ C, int64_t ldc, int k, int mt) {
+    for (int i = threadIdx.x; i < mt * k; i += blockDim.x) cs[i] = C[(i % k) + (int64_t)(i / k) * ldc];
+    __syncthreads();
+}
+
+// K is a compile-time constant so that the K gathers of an entry (and of the next, unroll 2) are all in flight together:
+// with a run-time k the compiler waits after every few loads and the kernel is latency-bound (measured 122 us vs the
+// two-launch form's 64 us at n = 1e6, k = 8).
+template <typename VT, int K>
+__global__ __launch_bounds__(256) void k_spmv_sell_kfused(const int32_t* __restrict__ sptr, const uint32_t* __restrict__ idx,
+                                                          const VT* __restrict__ vals, const cplx* __restrict__ V,
+                                                          int64_t ldv, const cplx* __restrict__ C, int64_t ldc,
+                                                          int mt, int64_t n, cplx* __restrict__ z, int swz) {
+    extern __shared__ cplx cs[];
+    stage_coef(cs, C, ldc, K, mt);
+    const int lane = threadIdx.x & 63;
+    const int64_t slice = xcd_block(swz) * 4LL + (threadIdx.x >> 6);
+    const int64_t row = slice * 64 + lane;
+    if (slice * 64 >= n) return;
+    cplx acc = cmake(0.0, 0.0);
+    const int64_t e0 = sptr[slice], e1 = sptr[slice + 1];
+    const uint32_t* ip = idx + e0 * 64 + lane;
+    const VT* vp = vals + e0 * 64 + lane;
+    const int cnt = (int)(e1 - e0);
+#pragma unroll 2
+    for (int e = 0; e < cnt; ++e) {
+        const uint32_t id = __builtin_nontemporal_load(ip + (int64_t)e * 64);
+        const VT a = ntload(vp + (int64_t)e * 64);
+        const cplx* xp = V + (id & NEP_COL_MASK);
+        const cplx* cp = cs + (id >> NEP_TERM_SHIFT) * K;
+        cplx v[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) v[j] = xp[(int64_t)j * ldv];
+        cplx w0 = cmake(0.0, 0.0), w1 = cmake(0.0, 0.0);
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            if (j & 1) cfma(w1, cp[j], v[j]); else cfma(w0, cp[j], v[j]);
+        }
+        cfma(acc, a, cadd(w0, w1));
+    }
+    if (row < n) z[row] = acc;
+}
+
+template <int G, typename VT>
+__global__ __launch_bounds__(256) void k_spmv_kfused(const int32_t* __restrict__ rowptr, const uint32_t* __restrict__ idx,
+                                                     const VT* __restrict__ vals, const cplx* __restrict__ V, int64_t ldv,
+                                                     int k, const cplx* __restrict__ C, int64_t ldc, int mt, int64_t n,
+                                                     cplx* __restrict__ z) {
+    extern __shared__ cplx cs[];
+    stage_coef(cs, C, ldc, k, mt);
+    constexpr int RPB = 256 / G;
+    const int sub = threadIdx.x % G;
+    const int64_t row = blockIdx.x * (int64_t)RPB + threadIdx.x / G;
+    cplx acc = cmake(0.0, 0.0);
+    if (row < n) {
+        const int e1 = rowptr[row + 1];
+        for (int e = rowptr[row] + sub; e < e1; e += G) {
+            const uint32_t id = idx[e];
+            const int64_t c = id & NEP_COL_MASK;
+            const int t = id >> NEP_TERM_SHIFT;
+            cfma(acc, vals[e], kdot(V + c, ldv, cs + t * k, k));
+        }
+    }
+    acc = group_reduce_sum<G>(acc);
+    if (row < n && sub == 0) z[row] = acc;
 }
 
 // k == 1 fold for the CSR-vector kernel (small n)
@@ -280,6 +375,10 @@ __global__ __launch_bounds__(256) void k_sum_partials_d(int nb, int len, const d
 }
 
 // ------------------------------------------------------------------------------------------
+static int xcd_swizzle() {
+    static const int v = getenv("NEP_XCD_SWIZZLE") ? atoi(getenv("NEP_XCD_SWIZZLE")) : 1;
+    return v;
+}
 template <typename VT>
 static int launch_spmv(const nep_spmf* s, const cplx* WT, cplx* z, hipStream_t st) {
     const VT* vals = (const VT*)s->d_vals;
@@ -287,7 +386,7 @@ static int launch_spmv(const nep_spmf* s, const cplx* WT, cplx* z, hipStream_t s
     if (s->d_sell_ptr) {
         const int64_t nsl = (n + 63) / 64;
         hipLaunchKernelGGL((k_spmv_sell<VT, false>), dim3((unsigned)((nsl + 3) / 4)), dim3(256), 0, st, s->d_sell_ptr,
-                           s->d_sell_idx, (const VT*)s->d_sell_val, WT, (const cplx*)nullptr, (int64_t)0, s->mt, n, z);
+                           s->d_sell_idx, (const VT*)s->d_sell_val, WT, (const cplx*)nullptr, (int64_t)0, s->mt, n, z, xcd_swizzle());
         LAUNCHCHK();
         return NEP_OK;
     }
@@ -315,7 +414,7 @@ static int launch_spmv_fold(const nep_spmf* s, const cplx* v, const cplx* dC, in
     if (s->d_sell_ptr) {
         const int64_t nsl = (n + 63) / 64;
         hipLaunchKernelGGL((k_spmv_sell<VT, true>), dim3((unsigned)((nsl + 3) / 4)), dim3(256), 0, st, s->d_sell_ptr,
-                           s->d_sell_idx, (const VT*)s->d_sell_val, v, dC, ldc, s->mt, n, z);
+                           s->d_sell_idx, (const VT*)s->d_sell_val, v, dC, ldc, s->mt, n, z, xcd_swizzle());
         LAUNCHCHK();
         return NEP_OK;
     }
@@ -335,6 +434,52 @@ static int launch_spmv_fold(const nep_spmf* s, const cplx* v, const cplx* dC, in
     return NEP_OK;
 }
 
+// 2 <= k <= fuse_max(): one launch, no W (see k_spmv_sell_kfused)
+static int fuse_max(const nep_spmf* s) {
+    static const int env = getenv("NEP_K1_FUSE_MAX") ? atoi(getenv("NEP_K1_FUSE_MAX")) : -1;
+    if (env >= 0) return env < 16 ? env : 16;
+    // small n (CSR-vector path) is launch-bound: one launch instead of two (gun k = 10: 6.8 -> 4.8 us).  At n = 1e6 the
+    // k gathers per entry miss L1 and the kernel is L2-bandwidth-bound (k = 8: 90 us fused vs 64 us for k_vc + SpMV,
+    // whose extra W round trip costs less than the 8x gather traffic), so the SELL path keeps the two-launch form.
+    return s->d_sell_ptr ? 0 : 16;
+}
+template <typename VT>
+static int launch_spmv_kfused(const nep_spmf* s, int k, const cplx* V, int64_t ldv, const cplx* dC, int64_t ldc, cplx* z,
+                              hipStream_t st) {
+    const VT* vals = (const VT*)s->d_vals;
+    const int64_t n = s->n;
+    const size_t shm = (size_t)s->mt * k * sizeof(cplx);
+    if (s->d_sell_ptr) {
+        const int64_t nsl = (n + 63) / 64;
+#define SKF(K)                                                                                                  \
+    case K:                                                                                                     \
+        hipLaunchKernelGGL((k_spmv_sell_kfused<VT, K>), dim3((unsigned)((nsl + 3) / 4)), dim3(256), shm, st, s->d_sell_ptr, \
+                           s->d_sell_idx, (const VT*)s->d_sell_val, V, ldv, dC, ldc, s->mt, n, z, xcd_swizzle()); \
+        break;
+        switch (k) {
+            SKF(2) SKF(3) SKF(4) SKF(5) SKF(6) SKF(7) SKF(8) SKF(9) SKF(10) SKF(11) SKF(12) SKF(13) SKF(14) SKF(15) SKF(16)
+            default: nep_set_error("fused K1: k=%d out of range", k); return NEP_ERR_ARG;
+        }
+#undef SKF
+        LAUNCHCHK();
+        return NEP_OK;
+    }
+#define KF_CASE(G)                                                                                        \
+    case G: {                                                                                             \
+        const int rpb = 256 / G;                                                                          \
+        hipLaunchKernelGGL((k_spmv_kfused<G, VT>), dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), shm, st, \
+                           s->d_rowptr, s->d_idx, vals, V, ldv, k, dC, ldc, s->mt, n, z);                 \
+        break;                                                                                            \
+    }
+    switch (s->lanes) {
+        KF_CASE(2) KF_CASE(4) KF_CASE(8) KF_CASE(16) KF_CASE(32) KF_CASE(64)
+        default: nep_set_error("bad lanes %d", s->lanes); return NEP_ERR_ARG;
+    }
+#undef KF_CASE
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // Componentwise backward error of an approximate solution of M x = b (the refinement criterion of UMFPACK's solve,
 // Arioli/Demmel/Duff):  r = b - Mx,  omega = max_i |r_i| / ( sum_t |c_t| sum_j |A_t[i,j]| |x_j| + |b_i| ).
@@ -350,7 +495,7 @@ __global__ __launch_bounds__(256) void k_cw_resid(const int32_t* __restrict__ ro
                                                   const cplx* __restrict__ x, const cplx* __restrict__ b,
                                                   const cplx* __restrict__ Mx, int64_t n, cplx* __restrict__ r,
                                                   unsigned long long* omega_bits,
-                                                  const cplx* __restrict__ den_extra) {
+                                                  const cplx* __restrict__ den_extra, double xsign) {
     constexpr int RPB = 256 / G;
     __shared__ double wmax[4];
     const int sub = threadIdx.x % G;
@@ -372,7 +517,8 @@ __global__ __launch_bounds__(256) void k_cw_resid(const int32_t* __restrict__ ro
     if (FUSED) acc = group_reduce_sum<G>(acc);
     double ratio = 0.0;
     if (row < n && sub == 0) {
-        const cplx rr = csub(b[row], FUSED ? acc : Mx[row]);
+        const cplx mx = FUSED ? cmake(xsign * acc.x, xsign * acc.y) : Mx[row];      // xsign = -1: the iterate is stored as -x
+        const cplx rr = csub(b[row], mx);
         r[row] = rr;
         const double num = absval(rr), den = d + absval(b[row]) + (den_extra ? den_extra[row].x : 0.0);
         ratio = den > 0.0 ? num / den : (num > 0.0 ? 1.0e300 : 0.0);
@@ -391,7 +537,7 @@ __global__ __launch_bounds__(256) void k_cw_resid(const int32_t* __restrict__ ro
 template <typename VT>
 static int launch_cw_resid(const nep_spmf* s, const double* cabs, const cplx* ccf, const cplx* x, const cplx* b,
                            const cplx* Mx, cplx* r, unsigned long long* omega_bits, const cplx* den_extra,
-                           hipStream_t st) {
+                           hipStream_t st, double xsign = 1.0) {
     const int64_t n = s->n;
     const VT* vals = (const VT*)s->d_vals;
 #define CW_CASE(G)                                                                                      \
@@ -399,10 +545,10 @@ static int launch_cw_resid(const nep_spmf* s, const double* cabs, const cplx* cc
         const int rpb = 256 / G;                                                                        \
         if (Mx)                                                                                         \
             hipLaunchKernelGGL((k_cw_resid<G, VT, false>), dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, st, \
-                               s->d_rowptr, s->d_idx, vals, cabs, ccf, x, b, Mx, n, r, omega_bits, den_extra); \
+                               s->d_rowptr, s->d_idx, vals, cabs, ccf, x, b, Mx, n, r, omega_bits, den_extra, xsign); \
         else                                                                                            \
             hipLaunchKernelGGL((k_cw_resid<G, VT, true>), dim3((unsigned)((n + rpb - 1) / rpb)), dim3(256), 0, st, \
-                               s->d_rowptr, s->d_idx, vals, cabs, ccf, x, b, Mx, n, r, omega_bits, den_extra); \
+                               s->d_rowptr, s->d_idx, vals, cabs, ccf, x, b, Mx, n, r, omega_bits, den_extra, xsign); \
         break;                                                                                          \
     }
     switch (s->lanes) {
@@ -583,7 +729,9 @@ int32_t nep_spmf_destroy(nep_spmf* s) {
     if (s->d_sell_val) (void)hipFree(s->d_sell_val);
     s->coef.release();
     s->part.release();
+    s->cwpart.release();
     s->ring.release();
+    s->cwring.release();
     delete s;
     return NEP_OK;
 }
@@ -611,6 +759,10 @@ int32_t nep_mlincomb(nep_spmf* s, int32_t k, const nep_cdouble* hC, const nep_cd
         if (s->valbytes == 8) return launch_spmv_fold<double>(s, (const cplx*)dV, (const cplx*)s->coef.dptr, 1, (cplx*)dz, st);
         return launch_spmv_fold<cplx>(s, (const cplx*)dV, (const cplx*)s->coef.dptr, 1, (cplx*)dz, st);
     }
+    if (k <= fuse_max(s) && (size_t)s->mt * k * sizeof(cplx) <= 48 * 1024) {
+        if (s->valbytes == 8) return launch_spmv_kfused<double>(s, k, (const cplx*)dV, ldv, (const cplx*)s->coef.dptr, k, (cplx*)dz, st);
+        return launch_spmv_kfused<cplx>(s, k, (const cplx*)dV, ldv, (const cplx*)s->coef.dptr, k, (cplx*)dz, st);
+    }
     rc = launch_vc(s, k, (const cplx*)s->coef.dptr, k, (const cplx*)dV, ldv, st);
     if (rc) return rc;
     if (s->valbytes == 8) return launch_spmv<double>(s, s->d_WT, (cplx*)dz, st);
@@ -626,6 +778,10 @@ int32_t nep_mlincomb_dev(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t 
         if (s->valbytes == 8) return launch_spmv_fold<double>(s, (const cplx*)dV, (const cplx*)dC, ldc, (cplx*)dz, st);
         return launch_spmv_fold<cplx>(s, (const cplx*)dV, (const cplx*)dC, ldc, (cplx*)dz, st);
     }
+    if (k <= fuse_max(s) && (size_t)s->mt * k * sizeof(cplx) <= 48 * 1024) {
+        if (s->valbytes == 8) return launch_spmv_kfused<double>(s, k, (const cplx*)dV, ldv, (const cplx*)dC, ldc, (cplx*)dz, st);
+        return launch_spmv_kfused<cplx>(s, k, (const cplx*)dV, ldv, (const cplx*)dC, ldc, (cplx*)dz, st);
+    }
     int rc = launch_vc(s, k, (const cplx*)dC, ldc, (const cplx*)dV, ldv, st);
     if (rc) return rc;
     if (s->valbytes == 8) return launch_spmv<double>(s, s->d_WT, (cplx*)dz, st);
@@ -640,15 +796,15 @@ int32_t nep_cw_backward_error(nep_spmf* s, const double* h_cabs, const nep_cdoub
     ARGCHK(s->mt <= NEP_MAX_TERMS);
     hipStream_t st = as_stream(stream);
     const size_t mt = (size_t)s->mt;
-    int rc = s->part.ensure(64 + mt * 24);
+    int rc = s->cwpart.ensure(64 + mt * 24);
     if (rc) return rc;
-    unsigned long long* bits = (unsigned long long*)s->part.dptr;
-    double* cabs = (double*)((char*)s->part.dptr + 64);
-    cplx* ccf = (cplx*)((char*)s->part.dptr + 64 + mt * 8);
+    unsigned long long* bits = (unsigned long long*)s->cwpart.dptr;
+    double* cabs = (double*)((char*)s->cwpart.dptr + 64);
+    cplx* ccf = (cplx*)((char*)s->cwpart.dptr + 64 + mt * 8);
     double stage[NEP_MAX_TERMS * 3];
     memcpy(stage, h_cabs, mt * 8);
     if (h_c) memcpy(stage + mt, h_c, mt * 16);
-    rc = s->ring.upload(cabs, stage, mt * (h_c ? 24 : 8), st);
+    rc = s->cwring.upload(cabs, stage, mt * (h_c ? 24 : 8), st);
     if (rc) return rc;
     if (h_omega) HIPCHK(hipMemsetAsync(bits, 0, 8, st));
     if (s->valbytes == 8)
@@ -665,6 +821,15 @@ int32_t nep_cw_backward_error(nep_spmf* s, const double* h_cabs, const nep_cdoub
         *h_omega = v;
     }
     return NEP_OK;
+}
+
+// Device-only form for callers that keep |f_t|, f_t resident (nep_iar_step): no upload, no memset, no synchronisation.
+// d_bits (may be NULL) must hold 0 on entry; afterwards it holds the bit pattern of omega.  xsign = -1: dx stores -x.
+int nep_cw_resid_dev(nep_spmf* s, const double* d_cabs, const nep_cdouble* d_ccf, const nep_cdouble* dx, const nep_cdouble* db,
+                     nep_cdouble* dr, unsigned long long* d_bits, double xsign, hipStream_t st) {
+    if (s->valbytes == 8)
+        return launch_cw_resid<double>(s, d_cabs, (const cplx*)d_ccf, (const cplx*)dx, (const cplx*)db, nullptr, (cplx*)dr, d_bits, nullptr, st, xsign);
+    return launch_cw_resid<cplx>(s, d_cabs, (const cplx*)d_ccf, (const cplx*)dx, (const cplx*)db, nullptr, (cplx*)dr, d_bits, nullptr, st, xsign);
 }
 
 // widest column panel whose mt x kk complex coefficient block fits 48 KiB of LDS (256 for mt <= 12)

@@ -31,9 +31,31 @@ from .nep import CDT, to_host, stream_ptr
 EPS = np.finfo(float).eps
 
 
+class _RefinementMiss(Exception):
+    """a step's recorded backward errors show that UMFPACK's rule wanted more refinement than the step took"""
+
+
 def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
         errmeasure=None, sigma=0.0, gamma=1.0, v=None, logger=0, check_error_every=1, proj_solve=False,
         errhist=None, timers=None, return_device=False, inner_solver_method=None):
+    """src/method_iar.jl:56-141"""
+    if v is None:
+        v = np.random.randn(nep.size(1))
+    kw = dict(orthmethod=orthmethod, maxit=maxit, linsolvercreator=linsolvercreator, tol=tol, neigs=neigs, errmeasure=errmeasure,
+              sigma=sigma, gamma=gamma, v=v, logger=logger, check_error_every=check_error_every, proj_solve=proj_solve,
+              errhist=errhist, timers=timers, return_device=return_device, inner_solver_method=inner_solver_method)
+    try:
+        return _iar(nep, **kw)
+    except _RefinementMiss:          # never observed; the checked path decides every refinement on the host
+        if errhist is not None:
+            del errhist[:]
+        return _iar(nep, _native_step=False, **kw)
+
+
+def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
+         errmeasure=None, sigma=0.0, gamma=1.0, v=None, logger=0, check_error_every=1, proj_solve=False,
+         errhist=None, timers=None, return_device=False, inner_solver_method=None, _native_step=True):
+    t_entry = time.perf_counter()
     n = nep.size(1); m = int(maxit)
     sigma = complex(sigma); gamma = complex(gamma)
     if linsolvercreator is None:
@@ -55,6 +77,7 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     t_ls = time.perf_counter()
     M0inv = create_linsolver(linsolvercreator, nep, sigma)
     sync(); tm["linsolver_setup"] = tm.get("linsolver_setup", 0.0) + time.perf_counter() - t_ls
+    t_setup_done = time.perf_counter()
     if timers is not None and hasattr(M0inv, "lu"):
         tm["host_factorization"] = tm.get("host_factorization", 0.0) + M0inv.lu.t_factor
     v0 = np.asarray(v, dtype=np.complex128)
@@ -79,16 +102,17 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
             inner_solver_method = DefaultInnerSolver()
     if use_async:
         active_d = torch.from_numpy(active).to("cuda")
-        Hdev = torch.zeros((m, m + 2), dtype=CDT, device="cuda")
-        Hpin = torch.zeros((m, m + 2), dtype=CDT).pin_memory()
+        Hdev = torch.zeros((m, m + 4), dtype=CDT, device="cuda")     # row k-1: h[0..k), beta, flags, 4 recorded omegas
+        Hpin = torch.zeros((m, m + 4), dtype=CDT).pin_memory()
         Hnp = Hpin.numpy()
         evs = [None] * (m + 1)
         filled = [False] * (m + 1)
-    # native step (csrc/driver.hip nep_iar_step): K1 -> K5 (+ blind refinement) -> shift -> K6 -> H row to pinned memory as
-    # ONE foreign call per Arnoldi step.  Needs a pure SPMF operator and a device LU; solves whose refinement criterion
-    # must be read back (every 8th, and until the step count has settled) take the statement-by-statement path below.
+    # native step (csrc/driver.hip nep_iar_step): K1 -> K5 (+ refinement) -> shift -> K6 -> H row to pinned memory as
+    # ONE foreign call per Arnoldi step.  Needs a pure SPMF operator and a device LU.  The refinement criterion is never
+    # read back inside a step: the step records omega of every iterate behind the H row and fill_H replays UMFPACK's
+    # stopping rule on the record (FactorizeLinSolver.review_recorded); a miss re-runs the call with checked solves.
     cstep = None
-    if use_async and not os.environ.get("NEP_IAR_PYSTEP"):
+    if use_async and _native_step and not os.environ.get("NEP_IAR_PYSTEP"):
         from .linsolvers import FactorizeLinSolver
         from .nep import AbstractSPMF
         import ctypes as _C
@@ -122,14 +146,21 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     pool = ThreadPoolExecutor(max_workers=LAG + 1)
     state = {"lam": lam, "QT": QT, "idx": idx, "conv_eig": 0, "k_checked": 0}
 
+    trace = {} if os.environ.get("NEP_IAR_TRACE") else None
+    plans = [0] * (m + 1)
+
     def arnoldi_step(k):
         if cstep is not None:
-            plan = M0inv.blind_plan()
-            if plan is not None:
-                check(lib.nep_iar_step(cstep, k, plan, stream_ptr()))
-                M0inv.note_blind_solve(plan)
-                evs[k] = "native"
-                return
+            plan = M0inv.blind_plan_recorded()
+            plans[k] = plan
+            t0 = time.perf_counter()
+            check(lib.nep_iar_step(cstep, k, plan, stream_ptr()))
+            if trace is not None:
+                trace["native_s"] = trace.get("native_s", 0.0) + time.perf_counter() - t0
+                trace["native_n"] = trace.get("native_n", 0) + 1
+            M0inv.note_blind_solve(plan)
+            evs[k] = "native"
+            return
         t0 = time.perf_counter()
         # z = sum_{j=1..k} alpha_{j+1}/j * M^(j)(sigma) * V_k block j
         nep.lincomb_rowscale(tab, k, V.data_ptr() + 16 * (k - 1) * ldv, n, z)
@@ -165,6 +196,9 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
                 row = Hnp[j - 1]
                 if int(row[j + 1].imag) & 2:
                     raise NepError(NEP_ERR_BREAKDOWN, "orthogonalisation breakdown in step %d: ||w|| = %g" % (j, row[j].real))
+                if cstep is not None and M0inv.umfpack_refinements > 0:
+                    if not M0inv.review_recorded(row[j + 2:j + 4].view(np.float64), plans[j]):
+                        raise _RefinementMiss(j)
                 H[:j, j - 1] = row[:j]
                 H[j, j - 1] = row[j].real
                 filled[j] = True
@@ -174,6 +208,8 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
             check(lib.nep_iar_wait(cstep, kk))      # ctypes releases the GIL
         else:
             evs[kk].synchronize()      # releases the GIL; H's columns <= kk are in pinned memory afterwards
+        if trace is not None:
+            trace["dev_done_%d" % kk] = time.perf_counter()
         fill_H(kk)
         return timed_eig(H[:kk, :kk].copy())
 
@@ -221,12 +257,24 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
             idxl = idxl[:nrof]
         state.update(lam=laml, QT=QTl, idx=idxl, conv_eig=conv, k_checked=kc)
 
+    # The convergence checks (Ritz block K7 + residual batch K2 of step kc) read columns of V that are final by the time
+    # eig(H_kc) exists -- the eigen worker waited for step kc's event -- and write only their own buffers, so they run on a
+    # second stream next to the Arnoldi recurrence (latency-bound small kernels at gun size) instead of in line with it.
+    # Only with the native step: there this thread touches none of the scratch the checks use (csrc/spmv.hip: coef / part /
+    # ring belong to the residual batch, cwpart / cwring to the refinement inside the step).
+    check_thread = cstep is not None and not os.environ.get("NEP_IAR_ONE_STREAM") and hasattr(errmeasure, "batch_async")
+    check_stream = torch.cuda.Stream() if check_thread else None
+
     def launch_check(kc, fut):
         """eigen-decomposition of step kc is available: enqueue Ritz block (K7) + residual batch (K2), no waiting"""
         (D, Z), t_eig = fut.result()
-        QTl = dense.gemm_ts(V, Z, rowmajor=True, k=kc, rows=n, ldz=ldv)
         laml = sigma + gamma / D
-        return kc, laml, QTl, estimate_errors_async(errmeasure, laml, QTl)
+        if check_stream is None:
+            QTl = dense.gemm_ts(V, Z, rowmajor=True, k=kc, rows=n, ldz=ldv)
+            return kc, laml, QTl, estimate_errors_async(errmeasure, laml, QTl)
+        with torch.cuda.stream(check_stream):
+            QTl = dense.gemm_ts(V, Z, rowmajor=True, k=kc, rows=n, ldz=ldv)
+            return kc, laml, QTl, estimate_errors_async(errmeasure, laml, QTl)
 
     def consume_check(kc, laml, QTl, perr):
         e = perr.get()
@@ -251,7 +299,83 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     if blas_guard is not None:
         blas_guard.__enter__()
     try:
-        if use_async:
+        if use_async and check_thread:
+            # native step: this thread only issues nep_iar_step (one foreign call per step, GIL released); the checker thread
+            # waits for the eigen-decompositions in order, enqueues their checks on check_stream and consumes the results.
+            # `slots` bounds how far the recurrence runs ahead of the checks (LAG + 1 decompositions in flight, as before).
+            import queue, threading
+            todo = queue.Queue(); failure = []
+            slots = threading.Semaphore(LAG + 1)
+
+            def checker():
+                inflight = deque()
+                try:
+                    while True:
+                        item = todo.get()
+                        if item is None:
+                            break
+                        if state["conv_eig"] >= neigs:
+                            slots.release(); continue
+                        t0 = time.perf_counter()
+                        fut_ = item[1]; fut_.result(); t1 = time.perf_counter()
+                        inflight.append(launch_check(*item))
+                        slots.release()
+                        t2 = time.perf_counter()
+                        while inflight and state["conv_eig"] < neigs and (len(inflight) > LAG or inflight[0][3].ready()):
+                            consume_check(*inflight.popleft())
+                        if trace is not None:
+                            t3 = time.perf_counter()
+                            trace["chk_wait"] = trace.get("chk_wait", 0.0) + t1 - t0
+                            trace["chk_launch"] = trace.get("chk_launch", 0.0) + t2 - t1
+                            trace["chk_consume"] = trace.get("chk_consume", 0.0) + t3 - t2
+                    while inflight and state["conv_eig"] < neigs:
+                        consume_check(*inflight.popleft())
+                except BaseException as exc:          # re-raised on the calling thread
+                    failure.append(exc)
+                    slots.release()
+
+            th = threading.Thread(target=checker, name="nep-iar-check", daemon=True)
+            th.start()
+            try:
+                BATCH = max(1, min(4, LAG // 2))
+                while k <= m and state["conv_eig"] < neigs and not failure:
+                    # as many steps as there are free check slots (at most BATCH) go to the device in ONE foreign call: the
+                    # interpreter lock is released for all of it and re-acquired once (with one call per step this thread
+                    # queued for the lock behind the checker after every step: 330 us per step instead of 120)
+                    nb = 0
+                    while nb < BATCH and k + nb <= m:
+                        due = ((k + nb) % check_error_every == 0) or (k + nb == m)
+                        if due:
+                            if nb == 0:
+                                while not slots.acquire(timeout=0.05):
+                                    if failure or not th.is_alive():
+                                        break
+                            elif not slots.acquire(blocking=False):
+                                break
+                        nb += 1
+                    if failure:
+                        break
+                    plan = M0inv.blind_plan_recorded()
+                    t0 = time.perf_counter()
+                    check(lib.nep_iar_steps(cstep, k, nb, plan, stream_ptr()))
+                    if trace is not None:
+                        trace["native_s"] = trace.get("native_s", 0.0) + time.perf_counter() - t0
+                        trace["native_n"] = trace.get("native_n", 0) + nb
+                    for kk in range(k, k + nb):
+                        plans[kk] = plan
+                        M0inv.note_blind_solve(plan)
+                        evs[kk] = "native"
+                        if trace is not None:
+                            trace["enq_%d" % kk] = time.perf_counter()
+                        if (kk % check_error_every == 0) or (kk == m):
+                            todo.put((kk, pool.submit(timed_eig_async, kk)))
+                    k += nb
+            finally:
+                todo.put(None)
+                th.join()
+            if failure:
+                raise failure[0]
+        elif use_async:
             pend_err = deque()         # checks whose device work is enqueued, in increasing k
             while k <= m and state["conv_eig"] < neigs:
                 arnoldi_step(k)
@@ -284,8 +408,20 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
         for _, f in pending:
             f.cancel()
         pool.shutdown(wait=True)
+        if check_stream is not None:
+            check_stream.synchronize()       # dropped speculative checks may still read V / write their blocks
         if cstep is not None:
             lib.nep_iar_destroy(cstep)
+        if trace is not None:
+            t_end = time.perf_counter()
+            ks = [kk for kk in (1, 10, 25, 50, 75, 100) if "enq_%d" % kk in trace and "dev_done_%d" % kk in trace]
+            print("iar trace (ms after entry): setup %.1f | " % ((t_setup_done - t_entry) * 1e3)
+                  + " ".join("k=%d enq %.1f dev %.1f" % (kk, (trace["enq_%d" % kk] - t_entry) * 1e3, (trace["dev_done_%d" % kk] - t_entry) * 1e3) for kk in ks)
+                  + " | end %.1f | native steps %d, %.1f ms inside nep_iar_step; checker: wait eig %.1f launch %.1f consume %.1f ms" % ((t_end - t_entry) * 1e3, trace.get("native_n", 0), trace.get("native_s", 0.0) * 1e3, trace.get("chk_wait", 0) * 1e3, trace.get("chk_launch", 0) * 1e3, trace.get("chk_consume", 0) * 1e3))
+        if use_async and os.environ.get("NEP_IAR_PASSES"):
+            torch.cuda.synchronize()
+            print("orth passes per step:", [int(Hnp[j - 1][j + 1].real) for j in range(1, m + 1)], "flags",
+                  [int(Hnp[j - 1][j + 1].imag) for j in range(1, m + 1)])
         if blas_guard is not None:
             blas_guard.__exit__(None, None, None)
     lam, QT, idx, conv_eig = state["lam"], state["QT"], state["idx"], state["conv_eig"]

@@ -246,6 +246,7 @@ class FactorizeLinSolver(LinSolver):
         self.last_omega = None
         self._plan = 0                  # refinement steps the last checked solve needed
         self._stable = 0                # consecutive checked solves that needed exactly _plan steps
+        self._recorded_plan = None      # sweeps the stopping rule asked for on the last reviewed record (nep_iar_step)
         self.solves = 0
         self._W = None
         self._cabs = None
@@ -302,6 +303,41 @@ class FactorizeLinSolver(LinSolver):
         if self._stable >= 4 and ((self.solves + 1) % 8) != 0:
             return self._plan
         return None
+
+    def blind_plan_recorded(self):
+        """refinement sweeps of the next solve of a step that RECORDS omega of every iterate (nep_iar_step): the settled
+        count once a record has been reviewed, the maximum before"""
+        if self.umfpack_refinements <= 0:
+            return 0
+        # the record holds omega of x_0..x_3; two sweeps to start with (gun needs one), a rule that asks for more is a miss
+        return min(self.umfpack_refinements, 2) if self._recorded_plan is None else self._recorded_plan
+
+    def review_recorded(self, w, plan):
+        """UMFPACK's stopping rule (the loop of solve_dev) replayed on the recorded omegas w[0..plan] of a solve that took
+        `plan` sweeps without looking.  True: what was returned is what the checked loop returns, or an iterate at least as
+        good; False: the checked loop would have continued, or would have taken a worsening sweep back."""
+        umf = self.umfpack_refinements
+        w = [float(x) for x in w[:plan + 1]]
+        w_prev = np.inf; ret = None
+        for step in range(umf + 1):
+            if step > plan:
+                return False
+            omega = w[step]
+            if omega <= 2.0 * EPS:
+                ret = step
+                break
+            if omega > 0.5 * w_prev:
+                ret = step - 1 if omega > w_prev else step
+                break
+            if step == umf:
+                ret = step
+                break
+            w_prev = omega
+        self.last_omega = w[plan]
+        self._recorded_plan = ret
+        if not np.isfinite(w[plan]):
+            return False
+        return ret == plan or w[plan] <= max(4.0 * EPS, w[ret])
 
     def note_blind_solve(self, plan):
         self.solves += 1

@@ -34,7 +34,7 @@ def _pfv(na, mt):
     return [f.one(), f.ident(), f.ISqrt(1.0, 0.0), f.ISqrt(1.0, -108.8774 ** 2), f.Exp(-0.001), f.Monomial(2)][:mt]
 
 
-@pytest.mark.parametrize("k", [1, 2, 7, 33])
+@pytest.mark.parametrize("k", [1, 2, 7, 8, 9, 33])      # 1: folded, 2..8: coefficient product fused, >8: k_vc + SpMV
 @pytest.mark.parametrize("cplx_vals", [False, True])
 def test_mlincomb_vs_oracle(na, k, cplx_vals):
     from oracle import neps as oneps
@@ -400,7 +400,7 @@ def test_lin_solve_interfaces(na):
 
 
 def test_mlincomb_sell_and_fold_paths(na, monkeypatch):
-    """large-n SELL-64 SpMV and the k==1 folded SpMV agree with the CSR-vector path and with NumPy"""
+    """large-n SELL-64 SpMV, the k==1 folded and the 2<=k<=16 fused forms agree with the CSR-vector path and with NumPy"""
     from nep_amd import wep
     wd = wep.WaveguideData(61, 57, "JARLEBRING")
     Av = wd.big_matrices()
@@ -408,7 +408,7 @@ def test_mlincomb_sell_and_fold_paths(na, monkeypatch):
     rng = np.random.default_rng(4)
     fv = [na.funcs.one(), na.funcs.ident(), na.funcs.Monomial(2)]
     lam = -1.3 - 0.31j
-    Vs = {k: rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k)) for k in (1, 5)}
+    Vs = {k: rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k)) for k in (1, 5, 16, 17)}
     res = {}
     for sell in ("0", "1"):
         monkeypatch.setenv("NEP_SELL", sell)

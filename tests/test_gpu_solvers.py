@@ -112,6 +112,44 @@ def test_augnewton_and_newton_inner_solver(na):
     assert min(np.linalg.norm(Mp(lamv[j]) @ Vp[:, j]) / np.linalg.norm(Vp[:, j]) for j in range(2)) < 1e-9
 
 
+def test_iar_recorded_refinement_and_miss_fallback(na, monkeypatch):
+    """the native iar step refines without reading omega back and records it; (i) the record is reviewed for every step and
+    the settled sweep count is what the checked solves find, (ii) a review miss re-runs the call with checked solves and
+    returns the same eigenpairs and error history"""
+    from nep_amd.linsolvers import FactorizeLinSolver
+    n, m = 1310, 30
+    nep = na.nep_gallery("gun_spmf_scaled", n)
+    seen = []
+    orig = FactorizeLinSolver.review_recorded
+
+    def spy(self, w, plan):
+        ok = orig(self, w, plan)
+        seen.append((plan, [float(x) for x in w[:plan + 1]], ok))
+        return ok
+    monkeypatch.setattr(FactorizeLinSolver, "review_recorded", spy)
+    h1 = []
+    l1, Q1, _ = na.iar(nep, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10, errhist=h1)
+    assert len(seen) == m and all(ok for _, _, ok in seen)
+    assert all(w[-1] <= 4 * np.finfo(float).eps for _, w, _ in seen)          # every kept iterate is converged
+    assert seen[0][0] == 2 and seen[-1][0] <= 1                                 # two sweeps to start, then the settled count
+    # (ii) force a miss on the 7th review
+    count = [0]
+
+    def miss(self, w, plan):
+        count[0] += 1
+        return orig(self, w, plan) and count[0] != 7
+    monkeypatch.setattr(FactorizeLinSolver, "review_recorded", miss)
+    h2 = []
+    l2, Q2, _ = na.iar(nep, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10, errhist=h2)
+    assert count[0] >= 7 and len(h2) == len(h1) == m
+    assert len(l2) == len(l1)
+    _match(l2, l1, 1e-10)
+    for a, b in zip(h1, h2):
+        for x, y in zip(a[:3], b[:3]):
+            if x > 1e-12 and y > 1e-12:
+                assert 0.2 < x / y < 5
+
+
 def test_iar_chebyshev_and_default_inner_solver(na):
     """iar_chebyshev on the device: the docstring eigenvalues of method_iar_chebyshev.jl:45-56 (1e-12), the SPMF and PEP
     versions of compute_y0_cheb against the oracle, a shifted / scaled run; then test/iar.jl:29-33 exactly: iar(dep0,

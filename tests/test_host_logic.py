@@ -403,3 +403,26 @@ def test_compute_Mder_union_pattern_with_stored_zeros_and_many_terms():
     many = [sp.identity(n, format="csc") * (i + 1.0) for i in range(300)]
     nep2 = na.SPMF_NEP(many, [na.funcs.one()] * 300)
     assert abs(nep2.compute_Mder(0.0) - sp.identity(n) * sum(range(1, 301))).max() < 1e-9
+
+
+def test_recorded_refinement_rule_replay():
+    """FactorizeLinSolver.review_recorded replays UMFPACK's stopping rule (the checked loop of solve_dev) on the omegas a
+    native iar step records: accepted when the iterate kept is the one the rule returns (or at least as good), a miss when
+    the rule would have continued or taken a worsening sweep back"""
+    from nep_amd.linsolvers import FactorizeLinSolver
+    eps = np.finfo(float).eps
+    s = FactorizeLinSolver.__new__(FactorizeLinSolver)
+    s.umfpack_refinements = 10; s._recorded_plan = None; s.last_omega = None
+    assert s.blind_plan_recorded() == 2                       # before any record: two sweeps
+    assert s.review_recorded(np.array([1e-13, 1e-16, 5e-17, 0.0]), 2)     # rule stops after 1 sweep, x_2 is as good
+    assert s._recorded_plan == 1 and s.blind_plan_recorded() == 1
+    assert s.review_recorded(np.array([1e-13, 1e-16, 0.0, 0.0]), 1)       # exactly what the rule does
+    assert s.review_recorded(np.array([1e-17, 0.0, 0.0, 0.0]), 0) and s._recorded_plan == 0
+    assert not s.review_recorded(np.array([1e-13, 0.0, 0.0, 0.0]), 0)     # omega_0 > 2 eps and no sweep taken: miss
+    assert not s.review_recorded(np.array([1e-9, 1e-12, 0.0, 0.0]), 1)    # still halving after the sweeps taken: miss
+    assert s.review_recorded(np.array([1e-13, 8e-14, 0.0, 0.0]), 1)       # stagnation (> half): the rule stops there too
+    assert not s.review_recorded(np.array([1e-13, 5e-13, 0.0, 0.0]), 1)   # the sweep made it worse: rule takes it back
+    assert s.review_recorded(np.array([3e-16, 3.5e-16, 0.0, 0.0]), 1) == (3.5e-16 <= 4 * eps)   # ... unless at noise level
+    assert not s.review_recorded(np.array([1e-13, np.nan, 0.0, 0.0]), 1)
+    s.umfpack_refinements = 0
+    assert s.blind_plan_recorded() == 0
