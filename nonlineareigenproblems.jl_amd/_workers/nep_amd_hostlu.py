@@ -5,6 +5,7 @@ as 4 sequential calls -- so concurrent factorisations need processes, while ONE 
 factorisation with device work, see linsolvers.LinSolverCache.prefetch).  Returns the factors in the compressed-column form
 SuperLU produces (nep_lu_create_csc; csr=True converts to the CSR form of nep_lu_create)."""
 import threading
+import os
 import time
 
 import numpy as np
@@ -140,6 +141,37 @@ class _blas_limit:
         return False
 
 
+_SYMMETRY = {}        # pattern digest -> UMFPACK-style symmetry verdict
+_ORDERS = {}          # (pattern digest, permc_spec, symmetric) -> (ip, indices, indptr, data map) of the permuted matrix
+
+
+def _pattern_key(Ac, permc_spec, symmetric):
+    import hashlib
+    h = hashlib.blake2b(digest_size=16)
+    h.update(np.ascontiguousarray(Ac.indptr)); h.update(np.ascontiguousarray(Ac.indices))
+    return (h.digest(), Ac.shape, permc_spec, symmetric)
+
+
+def _cached_order(Ac, permc_spec, symmetric):
+    if permc_spec == "NATURAL":
+        return None
+    return _ORDERS.get(_pattern_key(Ac, permc_spec, symmetric))
+
+
+def _store_order(Ac, permc_spec, symmetric, perm_c):
+    """perm_c: SuperLU's column permutation (column j of A sits at position perm_c[j] of the factored matrix).  Symmetric
+    strategy: rows are permuted alike, so that the diagonal stays the diagonal (SymmetricMode prefers diagonal pivots)."""
+    if permc_spec == "NATURAL":
+        return
+    ip = np.argsort(perm_c).astype(np.int64)
+    T = sp.csc_matrix((np.arange(1, Ac.nnz + 1, dtype=np.float64), Ac.indices, Ac.indptr), shape=Ac.shape)
+    T = (T[ip][:, ip] if symmetric else T[:, ip]).tocsc()
+    T.sort_indices()
+    if len(_ORDERS) >= 8:
+        _ORDERS.pop(next(iter(_ORDERS)))
+    _ORDERS[_pattern_key(Ac, permc_spec, symmetric)] = (ip, T.indices.copy(), T.indptr.copy(), (T.data - 1).astype(np.int64))
+
+
 def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None, symmetric_mode=None, panel_size=8,
            relax=4, csr=False):
     """UMFPACK-like strategy selection (see linsolvers.DeviceLU) + SuperLU factorisation.
@@ -149,7 +181,15 @@ def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None
     t0 = time.perf_counter()
     Ac = sp.csc_matrix((np.asarray(data, dtype=np.complex128), indices, indptr), shape=shape)
     if permc_spec is None or symmetric_mode is None:
-        sym = pattern_symmetric(Ac)
+        dkey = _pattern_key(Ac, None, None)
+        sym = _SYMMETRY.get(dkey)
+        if sym is None:
+            sym = pattern_symmetric(Ac)               # 1 ms at gun size; a property of the pattern (and a zero-free diagonal)
+            if len(_SYMMETRY) >= 64:
+                _SYMMETRY.clear()
+            _SYMMETRY[dkey] = sym
+        elif sym and not bool(np.all(Ac.diagonal() != 0)):
+            sym = False
         if permc_spec is None:
             permc_spec = "MMD_AT_PLUS_A" if sym else "COLAMD"
         if symmetric_mode is None:
@@ -170,8 +210,26 @@ def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None
     # large problems whose supernodes are big enough for threaded zgemm/ztrsm to pay (measured: n = 91k 0.36 -> 0.40 s,
     # n = 251k 1.90 -> 1.71 s, n = 1e6 13.5 -> 10.4 s with 8 threads; scripts/diag/superlu_threads.py)
     nthreads = 1 if shape[0] < 200000 else 8
+    # The fill-reducing column ordering (MMD / COLAMD + etree postorder) is a function of the sparsity pattern alone.  It is
+    # kept per pattern (the 64 nodes of a contour, the factorisations of nleigs, repeated solves of one problem) and the
+    # next matrix with that pattern is handed to SuperLU already permuted with permc_spec = "NATURAL": identical pivots and
+    # factors, without the ordering pass (gun: 16 -> 13 ms per factorisation).
+    order = _cached_order(Ac, permc_spec, bool(symmetric_mode)) if not os.environ.get("NEP_NO_ORDER_CACHE") else None
     with _blas_limit(nthreads):
-        lu = spla.splu(Ac, **kw)  # RuntimeError("Factor is exactly singular") propagates to the caller
+        if order is None:
+            lu = spla.splu(Ac, **kw)  # RuntimeError("Factor is exactly singular") propagates to the caller
+            perm_r, perm_c = lu.perm_r, lu.perm_c
+            _store_order(Ac, permc_spec, bool(symmetric_mode), perm_c)
+        else:
+            ip, Bi, Bp, dmap = order
+            B = sp.csc_matrix((Ac.data[dmap], Bi, Bp), shape=shape)
+            kw["permc_spec"] = "NATURAL"
+            lu = spla.splu(B, **kw)
+            perm_c = np.empty(shape[0], dtype=np.int32); perm_c[ip] = lu.perm_c
+            if symmetric_mode:
+                perm_r = np.empty(shape[0], dtype=np.int32); perm_r[ip] = lu.perm_r
+            else:
+                perm_r = lu.perm_r
     t_factor = time.perf_counter() - t0
     # SuperLU hands L and U out in compressed columns; nep_lu_create_csc takes them as they are (the former CSC -> CSR
     # conversion + index sort cost 3-6 ms per gun factorisation on the host)
@@ -185,7 +243,7 @@ def factor(data, indices, indptr, shape, permc_spec=None, diag_pivot_thresh=None
         Lx=np.ascontiguousarray(L.data, dtype=np.complex128),
         Up=np.ascontiguousarray(U.indptr, dtype=np.int32), Ui=np.ascontiguousarray(U.indices, dtype=np.int32),
         Ux=np.ascontiguousarray(U.data, dtype=np.complex128),
-        perm_r=np.ascontiguousarray(lu.perm_r, dtype=np.int32), perm_c=np.ascontiguousarray(lu.perm_c, dtype=np.int32),
+        perm_r=np.ascontiguousarray(perm_r, dtype=np.int32), perm_c=np.ascontiguousarray(perm_c, dtype=np.int32),
         normA=float(np.linalg.norm(Ac.data)), t_factor=t_factor, t_total=time.perf_counter() - t0,
         strategy=dict(permc_spec=permc_spec, diag_pivot_thresh=diag_pivot_thresh, symmetric_mode=bool(symmetric_mode)))
 
