@@ -92,6 +92,8 @@ struct MLFactor {
     int use_graph = 1;
     int launches = 0;
     void* pinned = nullptr; size_t pinned_cap = 0;
+    // single-launch form (k_ml_fused): phase counters on the device, launches issued so far, device-mapped error flag
+    unsigned long long* d_fctr = nullptr; unsigned long long fuse_epoch = 0; int* h_ferr = nullptr; int* d_ferr = nullptr; int fuse_off = 0;
 };
 
 static double ml_now_ms() {
@@ -169,11 +171,11 @@ struct MLArgs {
 
 // G2 lanes per row, CH = 256 / G2 rows per chunk: all rows of a chunk are processed concurrently
 template <bool UPPER, int RB, int MODE, int G2>
-__global__ __launch_bounds__(256) void k_ml_level(const MLArgs A) {
-    const int rhs0 = blockIdx.y * RB;
+__device__ __forceinline__ void ml_level_body(const MLArgs& A, const int bx, const int by) {
+    const int rhs0 = by * RB;
     const int nb = min(RB, A.nrhs - rhs0);
-    if ((int)blockIdx.x >= A.nchunks) {                            // ---- side job
-        const int64_t q = A.side_lo + ((int64_t)blockIdx.x - A.nchunks) * 256 + threadIdx.x;
+    if (bx >= A.nchunks) {                            // ---- side job
+        const int64_t q = A.side_lo + ((int64_t)bx - A.nchunks) * 256 + threadIdx.x;
         if (q < A.side_hi) {
             if (!UPPER) {
                 const int64_t g = A.gat ? A.gat[q] : q;
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(256) void k_ml_level(const MLArgs A) {
         return;
     }
     __shared__ cplx rbuf[MODE == 0 ? RB * ML_BMAX : 1];
-    const MLChunk ch = A.chunks[blockIdx.x];
+    const MLChunk ch = A.chunks[bx];
     const int base = UPPER ? ch.a : ch.s;                           // first row whose r is needed
     if (MODE == 0) {
         // r_c = rhs_c - C[c,:] xin for the rows the chunk's dot products read: one thread per row (at most ML_BMAX rows;
@@ -267,20 +269,27 @@ __global__ __launch_bounds__(256) void k_ml_level(const MLArgs A) {
     }
 }
 
+template <bool UPPER, int RB, int MODE, int G2>
+__global__ __launch_bounds__(256) void k_ml_level(const MLArgs A) { ml_level_body<UPPER, RB, MODE, G2>(A, (int)blockIdx.x, (int)blockIdx.y); }
+
 // tmp[q] = src[q] - sum_{col_lo <= col < col_hi} C[q,col] xin[col]   for the rows [r0, r1) of one level; G lanes per row
 // (G = 256: one workgroup per row); ident_row0 >= 0: src is the identity block (rhs j = e_(ident_row0 + j))
+struct MLCplArgs {
+    int r0, r1; const int32_t* cp; const int32_t* ci; const cplx* cx; const cplx* src; int64_t ldsrc; const cplx* xin; int64_t ldxin;
+    cplx* tmp; int64_t ldtmp; int nrhs, col_lo, col_hi, ident_row0;
+};
 template <int G, int RB>
-__global__ __launch_bounds__(256) void k_ml_coupling(int r0, int r1, const int32_t* __restrict__ cp,
-                                                     const int32_t* __restrict__ ci, const cplx* __restrict__ cx,
-                                                     const cplx* __restrict__ src, int64_t ldsrc,
-                                                     const cplx* __restrict__ xin, int64_t ldxin, cplx* __restrict__ tmp,
-                                                     int64_t ldtmp, int nrhs, int col_lo, int col_hi, int ident_row0) {
+__device__ __forceinline__ void ml_coupling_body(const MLCplArgs& C, const int bx, const int by) {
+    const int r0 = C.r0, r1 = C.r1, nrhs = C.nrhs, col_lo = C.col_lo, col_hi = C.col_hi, ident_row0 = C.ident_row0;
+    const int32_t* __restrict__ cp = C.cp; const int32_t* __restrict__ ci = C.ci; const cplx* __restrict__ cx = C.cx;
+    const cplx* __restrict__ src = C.src; const cplx* __restrict__ xin = C.xin; cplx* __restrict__ tmp = C.tmp;
+    const int64_t ldsrc = C.ldsrc, ldxin = C.ldxin, ldtmp = C.ldtmp;
     constexpr int GG = G == 256 ? 64 : G;
     constexpr int RPB = G == 256 ? 1 : 256 / G;
-    const int rhs0 = blockIdx.y * RB;
+    const int rhs0 = by * RB;
     const int nb = min(RB, nrhs - rhs0);
     const int sub = G == 256 ? threadIdx.x : (threadIdx.x % GG);
-    const int q = r0 + blockIdx.x * RPB + (G == 256 ? 0 : threadIdx.x / GG);
+    const int q = r0 + bx * RPB + (G == 256 ? 0 : threadIdx.x / GG);
     cplx acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = cmake(0.0, 0.0);
@@ -318,6 +327,9 @@ __global__ __launch_bounds__(256) void k_ml_coupling(int r0, int r1, const int32
     }
 }
 
+template <int G, int RB>
+__global__ __launch_bounds__(256) void k_ml_coupling(const MLCplArgs C) { ml_coupling_body<G, RB>(C, (int)blockIdx.x, (int)blockIdx.y); }
+
 // ---- apex: the last levels as ONE dense inverse S^{-1} = inv(U_TT) inv(L_TT) (T x T, row-major) ---------------------------
 // out (row-major T x T) = transpose of the column-major block `in` (ld = T)
 __global__ __launch_bounds__(256) void k_apex_transpose(int T, const cplx* __restrict__ in, cplx* __restrict__ out) {
@@ -330,13 +342,16 @@ __global__ __launch_bounds__(256) void k_apex_transpose(int T, const cplx* __res
     if (r2 < T && c2 < T) out[(int64_t)r2 * T + c2] = tile[tx][ty];
 }
 // x[R0 + r] = sum_c Sinv[r, c] t[R0 + c]: wave per row, RB right-hand sides share one pass over the row
+struct MLApexArgs { int T, R0; const cplx* Sinv; const cplx* t; int64_t ldt; cplx* x; int64_t ldx; int nrhs; };
 template <int RB>
-__global__ __launch_bounds__(256) void k_apex_gemv(int T, int R0, const cplx* __restrict__ Sinv, const cplx* __restrict__ t,
-                                                   int64_t ldt, cplx* __restrict__ x, int64_t ldx, int nrhs) {
-    const int rhs0 = blockIdx.y * RB;
+__device__ __forceinline__ void apex_gemv_body(const MLApexArgs& P, const int bx, const int by) {
+    const int T = P.T, R0 = P.R0, nrhs = P.nrhs;
+    const cplx* __restrict__ Sinv = P.Sinv; const cplx* __restrict__ t = P.t; cplx* __restrict__ x = P.x;
+    const int64_t ldt = P.ldt, ldx = P.ldx;
+    const int rhs0 = by * RB;
     const int nb = min(RB, nrhs - rhs0);
     const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r = bx * 4 + (threadIdx.x >> 6);
     if (r >= T) return;
     const cplx* row = Sinv + (int64_t)r * T;
     cplx acc[RB];
@@ -355,6 +370,9 @@ __global__ __launch_bounds__(256) void k_apex_gemv(int T, int R0, const cplx* __
         if (lane == 0 && q < nb) x[(int64_t)(rhs0 + q) * ldx + R0 + r] = a;
     }
 }
+
+template <int RB>
+__global__ __launch_bounds__(256) void k_apex_gemv(const MLApexArgs P) { apex_gemv_body<RB>(P, (int)blockIdx.x, (int)blockIdx.y); }
 
 // =====================================================================================================================
 // host side
@@ -919,6 +937,8 @@ void ml_destroy(MLFactor* F) {
     if (F->work.dptr) { nep_pool_free_on(F->work.dptr, st, F->used); F->work.dptr = nullptr; F->work.cap = 0; }
     if (F->graph) (void)hipGraphExecDestroy(F->graph);
     if (F->cap_stream) (void)hipStreamDestroy(F->cap_stream);
+    if (F->d_fctr) nep_pool_free_on(F->d_fctr, st, F->used);
+    if (F->h_ferr) { if (st) (void)hipStreamSynchronize(st); (void)hipHostFree(F->h_ferr); }
     if (F->sym) sym_release(F->sym);
     delete F;
 }
@@ -943,10 +963,104 @@ void ml_info(const MLFactor* F, int64_t info[6], int64_t sched[8]) {
 }
 
 // ---- launches ---------------------------------------------------------------------------------------------------------
+// ---- single-launch form (one right-hand side): the launch helpers below append a phase record instead of launching when a
+// recorder is active, and ml_solve issues ONE k_ml_fused launch that runs the phases back to back (see k_ml_fused)
+enum { PH_LEVEL = 0, PH_COUPLING = 1, PH_APEX = 2 };
+struct MLFusedPhase {
+    int type, sel, nwg, pad;                 // PH_LEVEL: sel = UPPER*6 + MODE*3 + {0: G2 64, 1: G2 16, 2: G2 8}; PH_COUPLING: sel = lanes
+    union U { MLArgs lv; MLCplArgs cp; MLApexArgs ax; __host__ __device__ U() {} } u;
+};
+#define ML_FUSE_MAXP 8
+struct MLFusedArgs {
+    int nph, total, mode, pad0;
+    unsigned long long* ctr;                 // [0] ticket counter, [1 + p] workgroups of phase p that have finished (monotonic over solves)
+    unsigned long long epoch;                // fused launches issued on this factor before this one
+    int* err;                                // device-mapped host flag: set when a wait ran into its bound
+    MLFusedPhase ph[ML_FUSE_MAXP];
+};
+struct MLRecorder { MLFusedArgs a; bool overflow; };
+static thread_local MLRecorder* g_rec = nullptr;
+static bool rec_push(MLFusedPhase** out, int type, int sel, int nwg) {
+    MLRecorder* r = g_rec;
+    if (r->a.nph >= ML_FUSE_MAXP) { r->overflow = true; return false; }
+    MLFusedPhase* p = &r->a.ph[r->a.nph++];
+    p->type = type; p->sel = sel; p->nwg = nwg; p->pad = 0;
+    r->a.total += nwg;
+    *out = p;
+    return true;
+}
+
+// All phases of a single-vector solve as ONE launch.  Workgroups take a ticket (start order); the ticket decides phase and
+// block index, so a workgroup only ever waits for workgroups that started before it -- no co-residency assumption, no
+// deadlock.  A phase starts when every workgroup of the previous one has published its results: results are written, the
+// wave executes an agent-scope release fence (L2 write-back: the 8 XCDs do not share an L2), one thread bumps the phase
+// counter; the consumer polls the counter, then every wave executes an acquire fence (L1/L2 invalidate) before its first
+// read.  The counters are monotonic over solves (target = (epoch + 1) * workgroups of the phase), so nothing is reset
+// between launches.  Every wait is bounded: a bound hit sets *err (device-mapped host memory) and the workgroup leaves.
+__global__ __launch_bounds__(256) void k_ml_fused(const MLFusedArgs F) {
+    __shared__ int s_ticket;
+    int t;
+    if (F.mode & 1) {                                                  // experiment: trust in-order dispatch, no ticket atomics
+        t = (int)blockIdx.x;
+    } else {
+        if (threadIdx.x == 0)
+            s_ticket = (int)(atomicAdd(&F.ctr[0], 1ULL) - F.epoch * (unsigned long long)F.total);
+        __syncthreads();
+        t = __builtin_amdgcn_readfirstlane(s_ticket);                  // uniform: the phase record is read with scalar loads
+    }
+    int p = 0;
+    while (p < F.nph - 1 && t >= F.ph[p].nwg) { t -= F.ph[p].nwg; ++p; }
+    if (p > 0) {
+        if (threadIdx.x == 0) {
+            const unsigned long long target = (F.epoch + 1ULL) * (unsigned long long)F.ph[p - 1].nwg;
+            int it = 0;
+            while (__hip_atomic_load(&F.ctr[p], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (++it > (1 << 21)) { *F.err = 1; break; }
+                if (F.mode & 2) __builtin_amdgcn_s_sleep(64); else __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    const MLFusedPhase& ph = F.ph[p];
+    if (ph.type == PH_LEVEL) {
+        switch (ph.sel) {
+            case 0:  ml_level_body<false, 1, 0, 64>(ph.u.lv, t, 0); break;
+            case 1:  ml_level_body<false, 1, 0, 16>(ph.u.lv, t, 0); break;
+            case 2:  ml_level_body<false, 1, 0, 8>(ph.u.lv, t, 0); break;
+            case 3:  ml_level_body<false, 1, 1, 64>(ph.u.lv, t, 0); break;
+            case 4:  ml_level_body<false, 1, 1, 16>(ph.u.lv, t, 0); break;
+            case 5:  ml_level_body<false, 1, 1, 8>(ph.u.lv, t, 0); break;
+            case 6:  ml_level_body<true, 1, 0, 64>(ph.u.lv, t, 0); break;
+            case 7:  ml_level_body<true, 1, 0, 16>(ph.u.lv, t, 0); break;
+            case 8:  ml_level_body<true, 1, 0, 8>(ph.u.lv, t, 0); break;
+            case 9:  ml_level_body<true, 1, 1, 64>(ph.u.lv, t, 0); break;
+            case 10: ml_level_body<true, 1, 1, 16>(ph.u.lv, t, 0); break;
+            default: ml_level_body<true, 1, 1, 8>(ph.u.lv, t, 0); break;
+        }
+    } else if (ph.type == PH_COUPLING) {
+        if (ph.sel == 256) ml_coupling_body<256, 1>(ph.u.cp, t, 0);
+        else if (ph.sel == 64) ml_coupling_body<64, 1>(ph.u.cp, t, 0);
+        else ml_coupling_body<8, 1>(ph.u.cp, t, 0);
+    } else {
+        apex_gemv_body<1>(ph.u.ax, t, 0);
+    }
+    if (p < F.nph - 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(&F.ctr[1 + p], 1ULL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <bool UPPER, int MODE, int G2>
 static void launch_level_g(const MLArgs& a, int nside_wg, int nrhs, hipStream_t st) {
     const unsigned gx = (unsigned)(a.nchunks + nside_wg);
     const dim3 b(256);
+    if (g_rec) {
+        MLFusedPhase* p;
+        if (rec_push(&p, PH_LEVEL, (UPPER ? 6 : 0) + MODE * 3 + (G2 == 64 ? 0 : (G2 == 16 ? 1 : 2)), (int)gx)) p->u.lv = a;
+        return;
+    }
     if (nrhs >= 8) hipLaunchKernelGGL((k_ml_level<UPPER, 8, MODE, G2>), dim3(gx, (nrhs + 7) / 8), b, 0, st, a);
     else if (nrhs >= 2) hipLaunchKernelGGL((k_ml_level<UPPER, 4, MODE, G2>), dim3(gx, (nrhs + 3) / 4), b, 0, st, a);
     else hipLaunchKernelGGL((k_ml_level<UPPER, 1, MODE, G2>), dim3(gx, 1), b, 0, st, a);
@@ -962,10 +1076,17 @@ static void launch_coupling(int lanes, int r0, int r1, const int32_t* cp, const 
                             int64_t ldsrc, const cplx* xin, int64_t ldxin, cplx* tmp, int64_t ldtmp, int nrhs, hipStream_t st,
                             int col_lo = 0, int col_hi = 0x7fffffff, int ident_row0 = -1) {
     const int rows = r1 - r0;
-#define CPL(G_, RB_)                                                                                                       \
-    hipLaunchKernelGGL((k_ml_coupling<G_, RB_>), dim3((unsigned)(G_ == 256 ? rows : (rows + 256 / G_ - 1) / (256 / G_)),    \
-                                                      (nrhs + RB_ - 1) / RB_), dim3(256), 0, st, r0, r1, cp, ci, cx, src,  \
-                       ldsrc, xin, ldxin, tmp, ldtmp, nrhs, col_lo, col_hi, ident_row0)
+    MLCplArgs C;
+    C.r0 = r0; C.r1 = r1; C.cp = cp; C.ci = ci; C.cx = cx; C.src = src; C.ldsrc = ldsrc; C.xin = xin; C.ldxin = ldxin; C.tmp = tmp;
+    C.ldtmp = ldtmp; C.nrhs = nrhs; C.col_lo = col_lo; C.col_hi = col_hi; C.ident_row0 = ident_row0;
+    if (lanes != 256 && lanes != 64) lanes = 8;
+    const unsigned gx = (unsigned)(lanes == 256 ? rows : (rows + 256 / lanes - 1) / (256 / lanes));
+    if (g_rec) {
+        MLFusedPhase* p;
+        if (rec_push(&p, PH_COUPLING, lanes, (int)gx)) p->u.cp = C;
+        return;
+    }
+#define CPL(G_, RB_) hipLaunchKernelGGL((k_ml_coupling<G_, RB_>), dim3(gx, (nrhs + RB_ - 1) / RB_), dim3(256), 0, st, C)
 #define CPLG(G_) do { if (nrhs >= 8) CPL(G_, 8); else if (nrhs >= 2) CPL(G_, 4); else CPL(G_, 1); } while (0)
     if (lanes == 256) CPLG(256); else if (lanes == 64) CPLG(64); else CPLG(8);
 #undef CPLG
@@ -1055,9 +1176,15 @@ static int run_apex(const MLSolveCtx& c, hipStream_t st, int* launches) {
     { int64_t nz = 0; for (int l = la; l < S->nlev; ++l) nz += f.lev_coup[l]; const double avg = nz / (double)T; lanes = avg > 2048.0 ? 256 : (avg > 24.0 ? 64 : 8); }
     launch_coupling(lanes, R0, (int)S->n, f.d_cp, f.d_ci, F->d_vals, c.bw, c.ld, c.y, c.ld, c.tmp, c.ld, c.nrhs, st, 0, R0, -1);
     LAUNCHCHK();
-#define APEX_GEMV(RB_)                                                                                                  \
-    hipLaunchKernelGGL((k_apex_gemv<RB_>), dim3((unsigned)((T + 3) / 4), (c.nrhs + RB_ - 1) / RB_), dim3(256), 0, st, T, R0,  \
-                       (const cplx*)F->d_Sinv, (const cplx*)c.tmp, c.ld, c.x, c.ld, c.nrhs)
+    MLApexArgs P;
+    P.T = T; P.R0 = R0; P.Sinv = (const cplx*)F->d_Sinv; P.t = (const cplx*)c.tmp; P.ldt = c.ld; P.x = c.x; P.ldx = c.ld; P.nrhs = c.nrhs;
+    if (g_rec) {
+        MLFusedPhase* p;
+        if (rec_push(&p, PH_APEX, 0, (T + 3) / 4)) p->u.ax = P;
+        if (launches) *launches += 2;
+        return NEP_OK;
+    }
+#define APEX_GEMV(RB_) hipLaunchKernelGGL((k_apex_gemv<RB_>), dim3((unsigned)((T + 3) / 4), (c.nrhs + RB_ - 1) / RB_), dim3(256), 0, st, P)
     if (c.nrhs >= 8) APEX_GEMV(8); else if (c.nrhs >= 2) APEX_GEMV(4); else APEX_GEMV(1);
 #undef APEX_GEMV
     LAUNCHCHK();
@@ -1157,6 +1284,43 @@ int ml_solve(MLFactor* F, int nrhs, const nep_cdouble* dB, int64_t ldb, const ne
     c.bw = (cplx*)F->work.dptr; c.y = c.bw + (size_t)n * nrhs; c.x = c.y + (size_t)n * nrhs; c.tmp = c.x + (size_t)n * nrhs;
     c.dB = (const cplx*)dB; c.ldb = ldb; c.dX = (cplx*)dX; c.ldx = ldx; c.dAdd = (const cplx*)dAdd; c.ldadd = ldadd; c.scale = scale;
     int launches = 0;
+    if (F->h_ferr && *F->h_ferr) {
+        nep_set_error("block-schedule solve: a phase wait of the single-launch kernel hit its bound (earlier solve incomplete)");
+        return NEP_ERR_HIP;
+    }
+    // MEASURED NEGATIVE (kept opt-in, NEP_ML_FUSE=1, so that it can be reproduced): on the gun factors the one-launch form
+    // takes 770 us per solve against 38 us for the five launches (470 us without the ticket atomics, NEP_ML_FUSE_MODE=1).
+    // The 8 XCDs have no common L2, so every agent-scope atomic on the phase counters is performed memory-side; ~3000
+    // same-address increments per solve serialise at ~150 ns each, and the release/acquire fences are the same L2
+    // write-back/invalidate a kernel boundary performs.  A kernel boundary (~2.5 us on this part) IS the cheap grid barrier.
+    const char* fuse_env = nrhs == 1 ? getenv("NEP_ML_FUSE") : nullptr;
+    if (nrhs == 1 && !F->fuse_off && fuse_env && atoi(fuse_env)) {
+        // record the launches of the multi-launch path as phases and issue them as one kernel
+        MLRecorder rec; rec.a.nph = 0; rec.a.total = 0; rec.overflow = false;
+        g_rec = &rec;
+        rc = run_L(c, 0, true, st, nullptr);
+        if (!rc) rc = ml_middle(c, st, nullptr);
+        if (!rc) rc = run_U_level(c, 0, true, st, nullptr);
+        g_rec = nullptr;
+        if (rc) return rc;
+        if (!rec.overflow && rec.a.nph >= 2) {
+            if (!F->d_fctr) {
+                if ((rc = nep_pool_alloc((void**)&F->d_fctr, 16 * sizeof(unsigned long long)))) return rc;
+                HIPCHK(hipMemsetAsync(F->d_fctr, 0, 16 * sizeof(unsigned long long), st));
+                HIPCHK(hipHostMalloc((void**)&F->h_ferr, 64, hipHostMallocMapped));
+                HIPCHK(hipHostGetDevicePointer((void**)&F->d_ferr, F->h_ferr, 0));
+                *F->h_ferr = 0; F->fuse_epoch = 0;
+            }
+            rec.a.mode = getenv("NEP_ML_FUSE_MODE") ? atoi(getenv("NEP_ML_FUSE_MODE")) : 0; rec.a.pad0 = 0;
+            rec.a.ctr = F->d_fctr; rec.a.epoch = F->fuse_epoch++; rec.a.err = F->d_ferr;
+            hipLaunchKernelGGL(k_ml_fused, dim3((unsigned)rec.a.total), dim3(256), 0, st, rec.a);
+            LAUNCHCHK();
+            F->launches = 1;
+            F->last = st; F->used = true;
+            return NEP_OK;
+        }
+        F->fuse_off = 1;          // too many phases for one kernel-argument block: multi-launch path from now on
+    }
     if ((rc = run_L(c, 0, true, st, &launches))) return rc;
     const int nmid = ml_middle_count(F);
     bool graphed = false;

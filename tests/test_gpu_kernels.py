@@ -423,6 +423,27 @@ def test_mlincomb_sell_and_fold_paths(na, monkeypatch):
             res[(k, sell)] = z
 
 
+def test_lu_single_launch_form_opt_in(na, monkeypatch):
+    """NEP_ML_FUSE=1: all phases of a single-vector solve as one kernel (tickets + phase counters); same solution as the
+    multi-launch schedule.  Kept opt-in because it is 20x slower on this part -- the test keeps it correct."""
+    import scipy.sparse as sp
+    from oracle import gallery as og
+    A = sp.csc_matrix(og.gun_spmf_scaled(1310).compute_Mder(0.1 + 0.02j))
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal(A.shape[0]) + 1j * rng.standard_normal(A.shape[0])
+    import torch
+    lu = na.DeviceLU(A)
+    bd = torch.from_numpy(b).to("cuda")
+    x0 = lu.solve(bd).cpu().numpy()
+    assert lu.launches_last_solve() > 1
+    monkeypatch.setenv("NEP_ML_FUSE", "1")
+    for _ in range(3):                       # counters are monotonic over solves
+        x1 = lu.solve(bd).cpu().numpy()
+        assert lu.launches_last_solve() == 1
+        assert np.linalg.norm(x1 - x0) <= 1e-12 * np.linalg.norm(x0)
+    assert np.linalg.norm(A @ x1 - b) <= 1e-9 * np.linalg.norm(b)
+
+
 def test_error_paths_through_the_c_abi(na):
     """status codes instead of crashes: singular factorisation (SingularException like `lu` in the reference, hence
     LinAlgError), structurally singular U handed to nep_lu_create (NEP_ERR_SINGULAR), non-triangular factors and bad
