@@ -16,9 +16,15 @@
 // recurrence waits for the device (the checked form drained the queue on 17 of the 100 gun solves).
 #include "common.h"
 #include <vector>
+#include <stdlib.h>
 
 extern "C" int nep_cw_resid_dev(nep_spmf* s, const double* d_cabs, const nep_cdouble* d_ccf, const nep_cdouble* dx, const nep_cdouble* db,
                                 nep_cdouble* dr, unsigned long long* d_bits, double xsign, hipStream_t st);
+extern "C" int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, const int64_t* d_active_rows,
+                                       nep_cdouble* dw, nep_cdouble* d_out, int32_t method, nep_cdouble* d_mirror, int32_t nmirror,
+                                       nep_stream stream);
+extern "C" int nep_mlincomb_dev_shift(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t ldc, const nep_cdouble* dV, int64_t ldv,
+                                      nep_cdouble* dz, nep_cdouble* d_shift, int32_t* folded, hipStream_t st);
 
 struct nep_iar {
     nep_spmf* spmf; nep_lu* lu;
@@ -28,6 +34,7 @@ struct nep_iar {
     std::vector<double> cabs; std::vector<nep_cdouble> cf;
     cplx* dH; nep_cdouble* hH;               // m rows of (m+4): device / pinned host; row k-1 = h[0..k), beta, flags, omegas
     double* d_cabs; cplx* d_ccf;             // |f_t(sigma)|, f_t(sigma) resident on the device (refinement residuals)
+    cplx* hH_dev;                            // device address of the pinned block (NULL: not mapped, rows travel by memcpy)
     int32_t method;
     std::vector<hipEvent_t> ev;              // ev[k]: H column k is in pinned memory
 };
@@ -57,6 +64,11 @@ int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdo
     }
     s->dH = (cplx*)dH; s->hH = h_pinnedH; s->method = orth_method;
     s->ev.assign(m + 1, nullptr);
+    s->hH_dev = nullptr;
+    if (!getenv("NEP_IAR_NO_MIRROR")) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, h_pinnedH, 0) == hipSuccess) s->hH_dev = (cplx*)dp; else (void)hipGetLastError();
+    }
     *out = s;
     return NEP_OK;
 }
@@ -76,7 +88,9 @@ int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream str
     const int64_t n = s->n;
     cplx* col = s->dV + (int64_t)(k - 1) * s->ldv;      // column k-1: the n x k block of the reference's reshape
     cplx* vv = s->dV + (int64_t)k * s->ldv;
-    int rc = nep_mlincomb_dev(s->spmf, k, (const nep_cdouble*)s->dCtab, s->ldc, (const nep_cdouble*)col, n, (nep_cdouble*)s->dz, stream);
+    int32_t shifted = 0;
+    int rc = nep_mlincomb_dev_shift(s->spmf, k, (const nep_cdouble*)s->dCtab, s->ldc, (const nep_cdouble*)col, n, (nep_cdouble*)s->dz,
+                                    (nep_cdouble*)(vv + n), &shifted, st);
     if (rc) return rc;
     cplx* hrow = s->dH + (int64_t)(k - 1) * (s->m + 4);
     unsigned long long* bits = (unsigned long long*)(hrow + k + 2);      // zero: dH is zero-filled by the caller, a row is used once
@@ -103,11 +117,16 @@ int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream str
                               (nep_cdouble*)s->dW, bits + refine_steps, -1.0, st);
         if (rc) return rc;
     }
-    rc = nep_iar_shift_scale(n, k, (const nep_cdouble*)col, (nep_cdouble*)vv, stream);
+    if (!shifted) {
+        rc = nep_iar_shift_scale(n, k, (const nep_cdouble*)col, (nep_cdouble*)vv, stream);
+        if (rc) return rc;
+    }
+    cplx* mirror = s->hH_dev ? s->hH_dev + (int64_t)(k - 1) * (s->m + 4) : nullptr;
+    rc = nep_orth_dev_mirror((const nep_cdouble*)s->dV, s->ldv, n * (int64_t)(k + 1), k, s->d_active, (nep_cdouble*)vv, (nep_cdouble*)hrow,
+                             s->method, (nep_cdouble*)mirror, k + 4, stream);
     if (rc) return rc;
-    rc = nep_orth_dev((const nep_cdouble*)s->dV, s->ldv, n * (int64_t)(k + 1), k, s->d_active, (nep_cdouble*)vv, (nep_cdouble*)hrow, s->method, stream);
-    if (rc) return rc;
-    HIPCHK(hipMemcpyAsync(s->hH + (int64_t)(k - 1) * (s->m + 4), hrow, (size_t)(k + 4) * sizeof(cplx), hipMemcpyDeviceToHost, st));
+    if (!mirror)
+        HIPCHK(hipMemcpyAsync(s->hH + (int64_t)(k - 1) * (s->m + 4), hrow, (size_t)(k + 4) * sizeof(cplx), hipMemcpyDeviceToHost, st));
     if (!s->ev[k]) HIPCHK(hipEventCreateWithFlags(&s->ev[k], hipEventDisableTiming | hipEventBlockingSync));
     HIPCHK(hipEventRecord(s->ev[k], st));
     return NEP_OK;

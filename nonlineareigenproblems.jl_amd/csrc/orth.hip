@@ -166,15 +166,25 @@ __global__ __launch_bounds__(1024) void k_orth_decide(int nb, const double* __re
 }
 
 // w /= beta (beta on the device); records passes / flags behind beta: out[k+1] = (passes, 2*breakdown + more_needed)
+// mirror (optional): device-mapped pinned host copy of the caller's row [row, row + nmirror) -- h, beta, flags and whatever the
+// caller keeps behind them -- written by block 0, which saves the separate device-to-host copy command of every Arnoldi step
 __global__ __launch_bounds__(256) void k_orth_finish(int64_t rows, cplx* __restrict__ w, cplx* __restrict__ out_beta,
-                                                     const int* __restrict__ state) {
+                                                     const int* __restrict__ state, const cplx* __restrict__ row,
+                                                     cplx* __restrict__ mirror, int nmirror) {
     const double beta = out_beta[0].x;
     const double inv = (beta > 0.0 && isfinite(beta)) ? 1.0 / beta : 0.0;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
         cplx v = w[i];
         w[i] = cmake(v.x * inv, v.y * inv);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out_beta[1] = cmake((double)state[1], (double)(2 * state[2] + state[0]));
+    if (blockIdx.x == 0) {
+        const cplx flags = cmake((double)state[1], (double)(2 * state[2] + state[0]));
+        if (threadIdx.x == 0) out_beta[1] = flags;
+        if (mirror) {
+            const int iflag = (int)(out_beta + 1 - row);
+            for (int i = threadIdx.x; i < nmirror; i += blockDim.x) mirror[i] = i == iflag ? flags : row[i];
+        }
+    }
 }
 
 // column groups per launch: enough workgroups to fill 256 CUs a few times over, otherwise as few as possible
@@ -291,9 +301,18 @@ static int orth_dev_passes() {
     if (!np) { const char* e = getenv("NEP_ORTH_DEV_PASSES"); np = e ? atoi(e) : 2; if (np < 1 || np > 8) np = 2; }
     return np;
 }
+extern "C" int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
+                                       const int64_t* d_active_rows, nep_cdouble* dw, nep_cdouble* d_out, int32_t method,
+                                       nep_cdouble* d_mirror, int32_t nmirror, nep_stream stream);
 extern "C" int32_t nep_orth_dev(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
                                 const int64_t* d_active_rows, nep_cdouble* dw, nep_cdouble* d_out, int32_t method,
                                 nep_stream stream) {
+    return nep_orth_dev_mirror(dV, ldv, rows, k, d_active_rows, dw, d_out, method, nullptr, 0, stream);
+}
+// d_mirror / nmirror: see k_orth_finish (internal: nep_iar_step)
+extern "C" int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
+                                       const int64_t* d_active_rows, nep_cdouble* dw, nep_cdouble* d_out, int32_t method,
+                                       nep_cdouble* d_mirror, int32_t nmirror, nep_stream stream) {
     ARGCHK(dV && dw && d_out);
     ARGCHK(rows > 0 && k >= 1 && ldv >= rows);
     ARGCHK(method == 0 || method == 1);
@@ -334,7 +353,8 @@ extern "C" int32_t nep_orth_dev(const nep_cdouble* dV, int64_t ldv, int64_t rows
         LAUNCHCHK();
     }
     const int g = (int)std::min<int64_t>((rows + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_orth_finish, dim3(g), dim3(256), 0, st, rows, w, out + k, (const int*)d_state);
+    hipLaunchKernelGGL(k_orth_finish, dim3(g), dim3(256), 0, st, rows, w, out + k, (const int*)d_state, (const cplx*)out,
+                       (cplx*)d_mirror, (int)nmirror);
     LAUNCHCHK();
     return NEP_OK;
 }

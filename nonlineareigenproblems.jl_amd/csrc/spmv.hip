@@ -42,7 +42,7 @@ struct nep_spmf {
 template <int MT, int ROWS>
 __global__ __launch_bounds__(512) void k_vc(const cplx* __restrict__ V, int64_t ldv, int64_t n, int k,
                                             const cplx* __restrict__ C, int64_t ldc, int i0, int mt_total,
-                                            cplx* __restrict__ WT) {
+                                            cplx* __restrict__ WT, cplx* __restrict__ shift_dst) {
     constexpr int NG = 512 / ROWS;           // column groups
     constexpr int KC = 128;                  // coefficient rows staged in LDS per chunk
     __shared__ cplx sm[NG][MT][ROWS];
@@ -66,6 +66,11 @@ __global__ __launch_bounds__(512) void k_vc(const cplx* __restrict__ V, int64_t 
 #pragma unroll 4
         for (int j = g; j < kc; j += NG) {
             const cplx v = vp[(int64_t)(j0 + j) * ldv];
+            // iar: the block shift of the basis column rides along (dst block j+1 = src block j / (j+1), method_iar.jl:97-98)
+            if (shift_dst && row < n) {
+                const double sc = 1.0 / (double)(j0 + j + 1);
+                shift_dst[row + (int64_t)(j0 + j) * ldv] = cmake(v.x * sc, v.y * sc);
+            }
 #pragma unroll
             for (int i = 0; i < MT; ++i) cfma(acc[i], v, cs[i][j]);
         }
@@ -561,7 +566,7 @@ static int launch_cw_resid(const nep_spmf* s, const double* cabs, const cplx* cc
 }
 
 template <int ROWS>
-static int launch_vc_rows(const nep_spmf* s, int k, const cplx* dC, int64_t ldc, const cplx* V, int64_t ldv, hipStream_t st) {
+static int launch_vc_rows(const nep_spmf* s, int k, const cplx* dC, int64_t ldc, const cplx* V, int64_t ldv, hipStream_t st, cplx* shift_dst) {
     const int64_t n = s->n;
     const dim3 grid((unsigned)((n + ROWS - 1) / ROWS)), block(512);
     int i0 = 0;
@@ -569,23 +574,23 @@ static int launch_vc_rows(const nep_spmf* s, int k, const cplx* dC, int64_t ldc,
         const int rem = s->mt - i0;
         const int cnt = rem >= 4 ? 4 : rem;
         switch (cnt) {
-            case 4: hipLaunchKernelGGL((k_vc<4, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
-            case 3: hipLaunchKernelGGL((k_vc<3, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
-            case 2: hipLaunchKernelGGL((k_vc<2, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
-            default: hipLaunchKernelGGL((k_vc<1, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT); break;
+            case 4: hipLaunchKernelGGL((k_vc<4, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, i0 == 0 ? shift_dst : nullptr); break;
+            case 3: hipLaunchKernelGGL((k_vc<3, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, i0 == 0 ? shift_dst : nullptr); break;
+            case 2: hipLaunchKernelGGL((k_vc<2, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, i0 == 0 ? shift_dst : nullptr); break;
+            default: hipLaunchKernelGGL((k_vc<1, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, i0 == 0 ? shift_dst : nullptr); break;
         }
         LAUNCHCHK();
         i0 += cnt;
     }
     return NEP_OK;
 }
-static int launch_vc(const nep_spmf* s, int k, const cplx* dC, int64_t ldc, const cplx* V, int64_t ldv, hipStream_t st) {
+static int launch_vc(const nep_spmf* s, int k, const cplx* dC, int64_t ldc, const cplx* V, int64_t ldv, hipStream_t st, cplx* shift_dst = nullptr) {
     static const int force = getenv("NEP_VC_ROWS") ? atoi(getenv("NEP_VC_ROWS")) : 0;
-    if (force == 16) return launch_vc_rows<16>(s, k, dC, ldc, V, ldv, st);
-    if (force == 32) return launch_vc_rows<32>(s, k, dC, ldc, V, ldv, st);
-    if (force == 64) return launch_vc_rows<64>(s, k, dC, ldc, V, ldv, st);
-    if (s->n >= 65536) return launch_vc_rows<64>(s, k, dC, ldc, V, ldv, st);
-    return launch_vc_rows<32>(s, k, dC, ldc, V, ldv, st);
+    if (force == 16) return launch_vc_rows<16>(s, k, dC, ldc, V, ldv, st, shift_dst);
+    if (force == 32) return launch_vc_rows<32>(s, k, dC, ldc, V, ldv, st, shift_dst);
+    if (force == 64) return launch_vc_rows<64>(s, k, dC, ldc, V, ldv, st, shift_dst);
+    if (s->n >= 65536) return launch_vc_rows<64>(s, k, dC, ldc, V, ldv, st, shift_dst);
+    return launch_vc_rows<32>(s, k, dC, ldc, V, ldv, st, shift_dst);
 }
 
 template <typename VT>
@@ -784,6 +789,20 @@ int32_t nep_mlincomb_dev(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t 
     }
     int rc = launch_vc(s, k, (const cplx*)dC, ldc, (const cplx*)dV, ldv, st);
     if (rc) return rc;
+    if (s->valbytes == 8) return launch_spmv<double>(s, s->d_WT, (cplx*)dz, st);
+    return launch_spmv<cplx>(s, s->d_WT, (cplx*)dz, st);
+}
+
+// nep_mlincomb_dev for iar's step: when the coefficient product runs as its own kernel (k_vc) the block shift of the basis
+// column is folded into it (d_shift = destination of block 1; *folded = 1), otherwise the caller issues nep_iar_shift_scale
+int nep_mlincomb_dev_shift(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t ldc, const nep_cdouble* dV, int64_t ldv,
+                           nep_cdouble* dz, nep_cdouble* d_shift, int32_t* folded, hipStream_t st) {
+    *folded = 0;
+    if (k == 1 || (k <= fuse_max(s) && (size_t)s->mt * k * sizeof(cplx) <= 48 * 1024) || getenv("NEP_NO_SHIFT_FOLD"))
+        return nep_mlincomb_dev(s, k, dC, ldc, dV, ldv, dz, (nep_stream)st);
+    int rc = launch_vc(s, k, (const cplx*)dC, ldc, (const cplx*)dV, ldv, st, (cplx*)d_shift);
+    if (rc) return rc;
+    *folded = 1;
     if (s->valbytes == 8) return launch_spmv<double>(s, s->d_WT, (cplx*)dz, st);
     return launch_spmv<cplx>(s, s->d_WT, (cplx*)dz, st);
 }
