@@ -39,7 +39,7 @@ struct nep_spmf {
 // block = 512 threads = 8 waves.  ROWS = 64: a wave owns 64 rows (1 KiB coalesced per load) and one of 8
 // column groups -- the streaming shape for large n.  ROWS = 32: each half-wave owns the same 32 rows and one
 // of 16 column groups, which doubles the number of workgroups for small n (gun: 312 blocks on 256 CUs).
-template <int MT, int ROWS>
+template <int MT, int ROWS, bool SHIFT>
 __global__ __launch_bounds__(512) void k_vc(const cplx* __restrict__ V, int64_t ldv, int64_t n, int k,
                                             const cplx* __restrict__ C, int64_t ldc, int i0, int mt_total,
                                             cplx* __restrict__ WT, cplx* __restrict__ shift_dst) {
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(512) void k_vc(const cplx* __restrict__ V, int64_t 
         for (int j = g; j < kc; j += NG) {
             const cplx v = vp[(int64_t)(j0 + j) * ldv];
             // iar: the block shift of the basis column rides along (dst block j+1 = src block j / (j+1), method_iar.jl:97-98)
-            if (shift_dst && row < n) {
+            if (SHIFT && row < n) {
                 const double sc = 1.0 / (double)(j0 + j + 1);
                 shift_dst[row + (int64_t)(j0 + j) * ldv] = cmake(v.x * sc, v.y * sc);
             }
@@ -574,10 +574,10 @@ static int launch_vc_rows(const nep_spmf* s, int k, const cplx* dC, int64_t ldc,
         const int rem = s->mt - i0;
         const int cnt = rem >= 4 ? 4 : rem;
         switch (cnt) {
-            case 4: hipLaunchKernelGGL((k_vc<4, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, i0 == 0 ? shift_dst : nullptr); break;
-            case 3: hipLaunchKernelGGL((k_vc<3, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, i0 == 0 ? shift_dst : nullptr); break;
-            case 2: hipLaunchKernelGGL((k_vc<2, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, i0 == 0 ? shift_dst : nullptr); break;
-            default: hipLaunchKernelGGL((k_vc<1, ROWS>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, i0 == 0 ? shift_dst : nullptr); break;
+            case 4: if (i0 == 0 && shift_dst) hipLaunchKernelGGL((k_vc<4, ROWS, true>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, shift_dst); else hipLaunchKernelGGL((k_vc<4, ROWS, false>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, (cplx*)nullptr); break;
+            case 3: if (i0 == 0 && shift_dst) hipLaunchKernelGGL((k_vc<3, ROWS, true>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, shift_dst); else hipLaunchKernelGGL((k_vc<3, ROWS, false>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, (cplx*)nullptr); break;
+            case 2: if (i0 == 0 && shift_dst) hipLaunchKernelGGL((k_vc<2, ROWS, true>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, shift_dst); else hipLaunchKernelGGL((k_vc<2, ROWS, false>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, (cplx*)nullptr); break;
+            default: if (i0 == 0 && shift_dst) hipLaunchKernelGGL((k_vc<1, ROWS, true>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, shift_dst); else hipLaunchKernelGGL((k_vc<1, ROWS, false>), grid, block, 0, st, V, ldv, n, k, dC, ldc, i0, s->mt, s->d_WT, (cplx*)nullptr); break;
         }
         LAUNCHCHK();
         i0 += cnt;
