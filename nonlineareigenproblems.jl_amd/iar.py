@@ -186,7 +186,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
 
     def timed_eig(Hk):
         t = time.perf_counter()
-        r = _hosteig.eig(Hk)       # zgeev through ctypes: runs without the GIL (numpy/scipy hold it)
+        r = _hosteig.eig(Hk, hessenberg=True)       # LAPACK through ctypes: runs without the GIL (numpy/scipy hold it)
         return r, time.perf_counter() - t
 
     def fill_H(kk):

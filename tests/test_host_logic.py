@@ -429,3 +429,22 @@ def test_recorded_refinement_rule_replay():
     assert not s.review_recorded(np.array([1e-13, np.nan, 0.0, 0.0]), 1)
     s.umfpack_refinements = 0
     assert s.blind_plan_recorded() == 0
+
+
+def test_hosteig_hessenberg_route():
+    """_hosteig.eig(H, hessenberg=True): eigenvalues without Schur vectors + inverse iteration on the Hessenberg matrix give
+    the same decomposition as zgeev (unit 2-norm columns, residual at round-off level); small n and failures fall back"""
+    import scipy.linalg as sl
+    from nep_amd import _hosteig
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((160, 160)) + 1j * rng.standard_normal((160, 160))
+    for n in (6, 60, 100):
+        H = np.triu(sl.hessenberg(A)[:n, :n], -1)
+        w, V = _hosteig.eig(H, hessenberg=True)
+        w0, V0 = _hosteig.eig(H)
+        assert np.abs(H @ V - V * w[None, :]).max() <= 1e-10 * np.linalg.norm(H, 2)
+        assert np.allclose(np.linalg.norm(V, axis=0), 1.0, atol=1e-12)
+        order = [int(np.argmin(abs(w - x))) for x in w0]
+        assert sorted(order) == list(range(n)) and np.abs(w[order] - w0).max() <= 1e-10 * np.abs(w0).max()
+        for j, i in enumerate(order):                      # same eigenvector up to a phase
+            assert 1 - abs(np.vdot(V0[:, j], V[:, i])) <= 1e-8
