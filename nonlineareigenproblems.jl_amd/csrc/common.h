@@ -123,6 +123,22 @@ void nep_pool_free(void* p);
 // in_flight = false degrades to nep_pool_free.
 void nep_pool_free_on(void* p, hipStream_t st, bool in_flight);
 
+// ---- internal cross-file entry points (exported with C linkage, NOT part of include/nepmi355.h) -------------------------
+struct nep_spmf;
+extern "C" {
+// spmv.hip: UMFPACK's componentwise residual with the coefficients resident on the device (no upload, no memset, no sync);
+// d_bits (may be NULL, must hold 0) receives the bit pattern of omega; xsign = -1: dx stores -x
+int nep_cw_resid_dev(nep_spmf* s, const double* d_cabs, const nep_cdouble* d_ccf, const nep_cdouble* dx, const nep_cdouble* db,
+                     nep_cdouble* dr, unsigned long long* d_bits, double xsign, hipStream_t st);
+// spmv.hip: nep_mlincomb_dev with iar's block shift folded into k_vc when that kernel runs (*folded = 1)
+int nep_mlincomb_dev_shift(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t ldc, const nep_cdouble* dV, int64_t ldv,
+                           nep_cdouble* dz, nep_cdouble* d_shift, int32_t* folded, hipStream_t st);
+// orth.hip: nep_orth_dev whose last kernel also writes the caller's row (h, beta, flags, ...) to device-mapped host memory
+int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, const int64_t* d_active_rows,
+                            nep_cdouble* dw, nep_cdouble* d_out, int32_t method, nep_cdouble* d_mirror, int32_t nmirror,
+                            nep_stream stream);
+}
+
 // small per-library scratch (device) helpers, defined in util.hip
 struct NepScratch {
     void* dptr = nullptr;

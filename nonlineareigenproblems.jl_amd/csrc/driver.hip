@@ -18,14 +18,6 @@
 #include <vector>
 #include <stdlib.h>
 
-extern "C" int nep_cw_resid_dev(nep_spmf* s, const double* d_cabs, const nep_cdouble* d_ccf, const nep_cdouble* dx, const nep_cdouble* db,
-                                nep_cdouble* dr, unsigned long long* d_bits, double xsign, hipStream_t st);
-extern "C" int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, const int64_t* d_active_rows,
-                                       nep_cdouble* dw, nep_cdouble* d_out, int32_t method, nep_cdouble* d_mirror, int32_t nmirror,
-                                       nep_stream stream);
-extern "C" int nep_mlincomb_dev_shift(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t ldc, const nep_cdouble* dV, int64_t ldv,
-                                      nep_cdouble* dz, nep_cdouble* d_shift, int32_t* folded, hipStream_t st);
-
 struct nep_iar {
     nep_spmf* spmf; nep_lu* lu;
     int64_t n, ldv; int32_t m, mt;

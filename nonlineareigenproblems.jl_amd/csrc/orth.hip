@@ -301,9 +301,6 @@ static int orth_dev_passes() {
     if (!np) { const char* e = getenv("NEP_ORTH_DEV_PASSES"); np = e ? atoi(e) : 2; if (np < 1 || np > 8) np = 2; }
     return np;
 }
-extern "C" int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
-                                       const int64_t* d_active_rows, nep_cdouble* dw, nep_cdouble* d_out, int32_t method,
-                                       nep_cdouble* d_mirror, int32_t nmirror, nep_stream stream);
 extern "C" int32_t nep_orth_dev(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
                                 const int64_t* d_active_rows, nep_cdouble* dw, nep_cdouble* d_out, int32_t method,
                                 nep_stream stream) {
