@@ -463,10 +463,27 @@ def main():
     # extra (outside the headline timed region): the path that DOES shard -- Beyn's quadrature nodes over the ranks
     beyn = None
     if not args.no_beyn:
+        # never lose the headline line because of the extra: an exception is recorded, and with several ranks a watchdog
+        # covers the case of a rank stuck in the collective (the multi-rank RCCL exchange cannot be exercised on the 1-GPU
+        # development box): after 120 s rank 0 prints the line without the extra and every rank leaves
+        watchdog = None
+        if world > 1:
+            import threading
+
+            def bail():
+                if rank == 0:
+                    out["beyn_sharded"] = {"error": "sharded contour_beyn extra did not finish within 120 s"}
+                    os.write(1, (json.dumps(out) + "\n").encode())
+                os._exit(0)
+            watchdog = threading.Timer(120.0, bail)
+            watchdog.daemon = True
+            watchdog.start()
         try:
             beyn = beyn_sharded(na, args, world, rank)
-        except Exception as e:                       # never lose the headline line because of the extra
+        except Exception as e:
             beyn = {"error": repr(e)[:300]}
+        if watchdog is not None:
+            watchdog.cancel()
     if rank == 0 and world == 1 and not args.no_c5:
         try:
             out["c5_wep"] = c5_summary(na, args)

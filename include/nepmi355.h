@@ -344,6 +344,30 @@ int32_t nep_wep_region_means(int32_t nz, int32_t nx, int32_t N, const nep_cdoubl
 int32_t nep_wep_region_expand(int32_t nz, int32_t nx, int32_t N, const nep_cdouble* dAlpha, const nep_cdouble* dKsc, double dd1,
                               double dd2, nep_cdouble* dY, nep_cdouble* dEb, nep_stream stream);
 
+/* ---- numeric LU factorisation on the device for a known pattern ----------------------------------------------
+ * replaces: the numeric phase of `lu(A)` / `factorize` behind FactorizeLinSolver (src/LinSolvers.jl:109-122) for the second
+ *           and later matrices of one sparsity pattern: the N same-pattern factorisations of contour_beyn
+ *           (src/method_beyncontour.jl:89-94), the shifts of nleigs, repeated solves of one problem.  The first matrix of a
+ *           pattern is factorised on the host (ordering, pivot sequence, fill pattern); nep_lu_refac_create enumerates the
+ *           updates of the right-looking factorisation for that pivot sequence once, nep_lu_factor_dev computes the values of
+ *           L and U on the GPU (static pivoting, as KLU / PARDISO refactorisation) and returns an ordinary nep_lu handle.
+ * ref: a handle created by nep_lu_create_csc from (Lp, Li, Up, Ui, perm_r, perm_c); Ap / Ai: CSC pattern of the matrices to
+ * come (caller's numbering), perm_r[i] / perm_c[j]: position of row i / column j of A in the factored matrix.
+ * NEP_ERR_UNSUPPORTED: level-schedule handle, or the stored pattern is not closed under the elimination.
+ * nep_lu_factor_dev: h_Ax = the nnz(A) values in the order of (Ap, Ai); growth_limit: largest |Re|+|Im| of an entry of L
+ * that is accepted (a diagonally pivoted factor stays near 1; the stored pivot sequence may not suit the new values);
+ * h_health[3] (may be NULL): [0] pivot breakdown flag, [1] that largest entry; h_LUx_out (may be NULL): the nnz(L) + nnz(U)
+ * computed values in the input entry order (tests).  NEP_ERR_SINGULAR: breakdown / growth -- factorise on the host instead. */
+typedef struct nep_lu_refac nep_lu_refac;
+int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int32_t* Li, const int32_t* Up, const int32_t* Ui,
+                            const int32_t* perm_r, const int32_t* perm_c, const int32_t* Ap, const int32_t* Ai,
+                            nep_lu_refac** out);
+int32_t nep_lu_refac_destroy(nep_lu_refac* r);
+/* out[0..5] = n, products, internal products, external products, external destination segments, symbolic time in ms */
+int32_t nep_lu_refac_info(const nep_lu_refac* r, int64_t out[6]);
+int32_t nep_lu_factor_dev(nep_lu_refac* r, const nep_cdouble* h_Ax, int32_t expected_solves, double growth_limit,
+                          double* h_health, nep_cdouble* h_LUx_out, nep_lu** out, nep_stream stream);
+
 /* ---- one infinite-Arnoldi step as one call ------------------------------------------------------
  * replaces: the loop body of iar between two eigenvalue checks, src/method_iar.jl:94-109
  *           (compute_Mlincomb! at sigma through the DerSPMF table :1130-1160, lin_solve, the 1/j shift of the block

@@ -104,6 +104,10 @@ SIGNATURES = {
     "nep_wep_region_expand": [c_i32, c_i32, c_i32, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp],
     "nep_iar_create": [c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, P(c_vp)],
     "nep_iar_destroy": [c_vp],
+    "nep_lu_refac_create": [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
+    "nep_lu_refac_destroy": [c_vp],
+    "nep_lu_refac_info": [c_vp, c_vp],
+    "nep_lu_factor_dev": [c_vp, c_vp, c_i32, C.c_double, c_vp, c_vp, c_vp, c_vp],
     "nep_iar_step": [c_vp, c_i32, c_i32, c_vp],
     "nep_iar_steps": [c_vp, c_i32, c_i32, c_i32, c_vp],
     "nep_iar_wait": [c_vp, c_i32],

@@ -1,0 +1,489 @@
+// libnepmi355: numeric LU factorisation ON THE DEVICE for a sparsity pattern whose symbolic factorisation is known.
+//
+// replaces: the numeric phase of `lu(A)` / `factorize` (UMFPACK) behind FactorizeLinSolver, src/LinSolvers.jl:109-122, for the
+//           second and later matrices of one sparsity pattern -- the N same-pattern factorisations of
+//           src/method_beyncontour.jl:89-94, the shifts of nleigs, repeated solves of one problem.  The first matrix of a
+//           pattern is factorised on the host (SuperLU: ordering, pivot sequence, fill pattern); this file re-uses that
+//           pivot sequence and fill pattern (static pivoting, as KLU / PARDISO refactorisation do) and computes the VALUES of
+//           L and U on the GPU:  L U = Pr A Pc  with the stored patterns of L and U.
+//
+// Algorithm: right-looking LU in the elimination-tree block partition the solve schedule already has (trsv_ml.hip).  Every
+// update  F(i,j) -= L(i,k) U(k,j)  of the factorisation is enumerated ONCE per pattern on the host (22 M products for the gun
+// matrix, three int32 each); its destination pivot p = min(i,j) lies either in the block of k ("internal") or in an ancestor
+// block on a higher level ("external"):
+//   level l:  k_lu_ext   every entry that belongs to a pivot of level l receives the sum of its external products from the
+//                        levels below, one thread per entry, products in fixed (ascending k) order -> deterministic
+//             k_lu_int   one workgroup per block of the level, pivots in order: divide the column of L by the pivot, then
+//                        apply the pivot's internal products (distinct destinations, no atomics)
+// Blocks of a level are independent (that is what the partition guarantees), so a level is two launches.  The values land
+// in arrays laid out exactly like the host factor's L and U, and the solve schedule is built from them by the same kernels
+// as after a host factorisation (ml_create_from_sym).  A health word (zero / non-finite pivot, element growth) is read back
+// once after the factorisation kernels; the caller falls back to the host factorisation when it is set.
+#include "common.h"
+#include "trsv_ml.h"
+#include <vector>
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <math.h>
+
+struct nep_lu;
+// trsv.hip
+extern "C" int32_t nep_lu_destroy(nep_lu* lu);
+MLFactor* nep_lu_ml(nep_lu* lu);
+nep_lu* nep_lu_wrap_ml(MLFactor* F, int64_t n, int64_t nnzL, int64_t nnzU);
+
+struct nep_lu_refac {
+    MLSym* S = nullptr;
+    int64_t n = 0, nnzL = 0, nnzU = 0, nnzA = 0, nprod = 0;
+    int nlev = 0, nblk = 0;
+    std::vector<int32_t> lev_blk;        // nlev+1
+    std::vector<int64_t> ext_seg0;       // nlev+1: first external segment of a level
+    std::vector<int32_t> h_blk_se;       // 2 nblk (schedule positions)
+    // device, symbolic
+    int32_t* d_amap = nullptr;           // nnzA: entry of A (CSC order of the caller) -> position in F
+    int32_t* d_ldiag = nullptr;          // n: position of L(k,k) (unit) in F
+    int32_t* d_udiag = nullptr;          // n: position of U(k,k)
+    int32_t* d_Lp = nullptr;             // n+1 (CSC of L as given)
+    int32_t* d_Li = nullptr;             // nnzL
+    int32_t* d_oldof = nullptr;          // n: pivot at schedule position q
+    int32_t* d_blk_se = nullptr;         // 2 nblk
+    int64_t* d_piv_ptr = nullptr;        // n+1 (schedule order): internal products of the pivot at position q
+    int32_t* d_int = nullptr;            // 3 per internal product: gL, gU, gdst
+    int64_t* d_ext_ptr = nullptr;        // nseg+1
+    int32_t* d_ext_dst = nullptr;        // nseg
+    int32_t* d_ext_src = nullptr;        // 2 per external product: gL, gU
+    int64_t nint = 0, next_ = 0, nseg = 0;
+    // "wide" levels (few, large blocks: the top of the elimination tree): one launch per pivot step, all products of the
+    // step's pivots (one per block of the level) spread over the whole device
+    std::vector<uint8_t> wide;           // nlev
+    std::vector<int64_t> wstep0;         // nlev+1: first step of a level in wide_ptr
+    std::vector<int64_t> wide_ptr;       // nsteps+1 (host: launch bounds)
+    int32_t* d_wide = nullptr;           // 4 per product: gL, gU, gdst, position of the pivot U(k,k)
+    int64_t nwide = 0;
+    double t_symbolic_ms = 0.0;
+};
+
+// ---- kernels ---------------------------------------------------------------------------------------------------------------
+__global__ void k_lu_init(int64_t nF, int64_t n, int64_t nnzA, const int32_t* __restrict__ amap, const cplx* __restrict__ Ax,
+                          const int32_t* __restrict__ ldiag, cplx* __restrict__ F, double* __restrict__ health) {
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    // F was zeroed by a memset; scatter A, unit diagonal of L
+    if (i < nnzA) F[amap[i]] = Ax[i];
+    if (i < n) F[ldiag[i]] = cmake(1.0, 0.0);
+    if (i == 0) { health[0] = 0.0; health[1] = 0.0; health[2] = 0.0; }
+}
+
+// one thread per destination entry of the level: F[dst] -= sum_products L * U   (sources final: lower levels are done)
+__global__ __launch_bounds__(256) void k_lu_ext(int64_t seg0, int64_t seg1, const int64_t* __restrict__ ptr,
+                                                const int32_t* __restrict__ dst, const int32_t* __restrict__ src,
+                                                cplx* __restrict__ F) {
+    const int64_t sidx = seg0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (sidx >= seg1) return;
+    const int64_t p0 = ptr[sidx], p1 = ptr[sidx + 1];
+    cplx acc = cmake(0.0, 0.0);
+    for (int64_t p = p0; p < p1; ++p) cfma(acc, F[src[2 * p]], F[src[2 * p + 1]]);
+    const int32_t d = dst[sidx];
+    F[d] = csub(F[d], acc);
+}
+
+__device__ __forceinline__ cplx lu_cdiv(cplx a, cplx b);
+
+// wide level, one pivot step: F[dst] -= (F[gL] / pivot) * F[gU], one product per thread (distinct destinations within a pivot;
+// the column of L stays unscaled until k_lu_scale at the end of the level)
+__global__ __launch_bounds__(256) void k_lu_wide(int64_t t0, int64_t t1, const int4* __restrict__ prod, cplx* __restrict__ F) {
+    const int64_t t = t0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= t1) return;
+    const int4 q = prod[t];
+    const cplx l = lu_cdiv(F[q.x], F[q.w]), u = F[q.y];
+    cplx f = F[q.z];
+    f.x -= l.x * u.x - l.y * u.y;
+    f.y -= l.x * u.y + l.y * u.x;
+    F[q.z] = f;
+}
+
+// end of a wide level: divide the columns of L of the level's pivots (schedule positions [q0, q1)), one wave per pivot
+__global__ __launch_bounds__(256) void k_lu_scale(int q0, int q1, const int32_t* __restrict__ oldof, const int32_t* __restrict__ Lp,
+                                                  const int32_t* __restrict__ Li, const int32_t* __restrict__ udiag,
+                                                  cplx* __restrict__ F, double* __restrict__ health) {
+    const int q = q0 + blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (q >= q1) return;
+    const int k = oldof[q];
+    const cplx piv = F[udiag[k]];
+    const double ap = fabs(piv.x) + fabs(piv.y);
+    if (!(ap > 0.0) || !isfinite(ap)) { if (lane == 0) health[0] = 1.0; return; }
+    double maxabs = 0.0;
+    for (int e = Lp[k] + lane; e < Lp[k + 1]; e += 64)
+        if (Li[e] != k) {
+            const cplx v = lu_cdiv(F[e], piv);
+            F[e] = v;
+            maxabs = fmax(maxabs, fabs(v.x) + fabs(v.y));
+        }
+    for (int off = 32; off > 0; off >>= 1) maxabs = fmax(maxabs, __shfl_xor(maxabs, off, 64));
+    if (lane == 0 && maxabs > 0.0) atomicMax((unsigned long long*)&health[1], (unsigned long long)__double_as_longlong(maxabs));
+}
+
+__device__ __forceinline__ cplx lu_cdiv(cplx a, cplx b) {
+    if (fabs(b.x) >= fabs(b.y)) {
+        const double r = b.y / b.x, d = b.x + b.y * r;
+        return cmake((a.x + a.y * r) / d, (a.y - a.x * r) / d);
+    }
+    const double r = b.x / b.y, d = b.x * r + b.y;
+    return cmake((a.x * r + a.y) / d, (a.y * r - a.x) / d);
+}
+
+// one workgroup per block of the level, pivots in schedule order
+__global__ __launch_bounds__(512) void k_lu_int(int blk0, const int32_t* __restrict__ blk_se, const int32_t* __restrict__ oldof,
+                                                const int32_t* __restrict__ Lp, const int32_t* __restrict__ Li,
+                                                const int32_t* __restrict__ udiag, const int64_t* __restrict__ piv_ptr,
+                                                const int32_t* __restrict__ tri, cplx* __restrict__ F, double* __restrict__ health) {
+    const int b = blk0 + blockIdx.x;
+    const int q0 = blk_se[2 * b], q1 = blk_se[2 * b + 1];
+    double minpiv = 1.0e300, maxabs = 0.0;
+    for (int q = q0; q < q1; ++q) {
+        const int k = oldof[q];
+        const cplx piv = F[udiag[k]];
+        const double ap = fabs(piv.x) + fabs(piv.y);
+        if (threadIdx.x == 0) { if (!(ap > 0.0) || !isfinite(ap)) minpiv = -1.0; else if (minpiv >= 0.0 && ap < minpiv) minpiv = ap; }
+        const int e0 = Lp[k], e1 = Lp[k + 1];
+        for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x)
+            if (Li[e] != k) {
+                const cplx v = lu_cdiv(F[e], piv);
+                F[e] = v;
+                maxabs = fmax(maxabs, fabs(v.x) + fabs(v.y));
+            }
+        __syncthreads();
+        const int64_t t0 = piv_ptr[q], t1 = piv_ptr[q + 1];
+        for (int64_t t = t0 + threadIdx.x; t < t1; t += blockDim.x) {
+            const int32_t d = tri[3 * t + 2];
+            cplx f = F[d];
+            const cplx l = F[tri[3 * t]], u = F[tri[3 * t + 1]];
+            f.x -= l.x * u.x - l.y * u.y;
+            f.y -= l.x * u.y + l.y * u.x;
+            F[d] = f;
+        }
+        __syncthreads();
+    }
+    // health: [0] = 1 when a pivot was zero / non-finite, [1] = largest |L| entry (bits, non-negative doubles order like ints)
+    for (int off = 32; off > 0; off >>= 1) maxabs = fmax(maxabs, __shfl_xor(maxabs, off, 64));
+    if ((threadIdx.x & 63) == 0 && maxabs > 0.0)
+        atomicMax((unsigned long long*)&health[1], (unsigned long long)__double_as_longlong(maxabs));
+    if (threadIdx.x == 0 && minpiv < 0.0) health[0] = 1.0;
+}
+
+// ---- host: symbolic part -----------------------------------------------------------------------------------------------------
+namespace {
+
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+template <class T>
+int upv(T** d, const std::vector<T>& h) {
+    const size_t cnt = std::max<size_t>(h.size(), 1);
+    int rc = nep_pool_alloc((void**)d, cnt * sizeof(T));
+    if (rc) return rc;
+    if (!h.empty()) HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    return NEP_OK;
+}
+
+struct Ent { int32_t row; int32_t g; };
+
+}  // namespace
+
+extern "C" {
+
+int32_t nep_lu_refac_destroy(nep_lu_refac* r) {
+    if (!r) return NEP_OK;
+    (void)hipDeviceSynchronize();
+    nep_pool_free(r->d_amap); nep_pool_free(r->d_ldiag); nep_pool_free(r->d_udiag); nep_pool_free(r->d_Lp); nep_pool_free(r->d_Li);
+    nep_pool_free(r->d_oldof); nep_pool_free(r->d_blk_se); nep_pool_free(r->d_piv_ptr); nep_pool_free(r->d_int);
+    nep_pool_free(r->d_ext_ptr); nep_pool_free(r->d_ext_dst); nep_pool_free(r->d_ext_src); nep_pool_free(r->d_wide);
+    if (r->S) ml_sym_release_ref(r->S);
+    delete r;
+    return NEP_OK;
+}
+
+// ref: a factor of this pattern created from (Lp, Li, Up, Ui, perm_r, perm_c) in CSC (nep_lu_create_csc), block schedule.
+// Ap / Ai: CSC pattern of the matrices that will be factorised (caller's numbering); perm_r[i] / perm_c[j] = position of row
+// i / column j of A in the factored matrix (SuperLU's convention).  NEP_ERR_UNSUPPORTED: the stored pattern is not closed
+// under the elimination (an update has no slot) or the reference factor uses the level schedule.
+int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int32_t* Li, const int32_t* Up, const int32_t* Ui,
+                            const int32_t* perm_r, const int32_t* perm_c, const int32_t* Ap, const int32_t* Ai,
+                            nep_lu_refac** out) {
+    ARGCHK(out != nullptr);
+    *out = nullptr;
+    ARGCHK(ref && Lp && Li && Up && Ui && perm_r && perm_c && Ap && Ai && n > 0);
+    MLFactor* mf = nep_lu_ml(ref);
+    if (!mf) { nep_set_error("device refactorisation needs the block schedule"); return NEP_ERR_UNSUPPORTED; }
+    const double t0 = now_ms();
+    nep_lu_refac* r = new nep_lu_refac();
+    r->S = ml_sym_acquire(mf);
+    int64_t n2; int nlev, nblk; const int32_t *lvl, *blk, *oldof, *blk_se, *lev_blk;
+    ml_sym_partition(r->S, &n2, &nlev, &nblk, &lvl, &blk, &oldof, &blk_se, &lev_blk);
+    if (n2 != n) { nep_lu_refac_destroy(r); nep_set_error("refac: size mismatch"); return NEP_ERR_ARG; }
+    r->n = n; r->nnzL = Lp[n]; r->nnzU = Up[n]; r->nnzA = Ap[n]; r->nlev = nlev; r->nblk = nblk;
+    r->lev_blk.assign(lev_blk, lev_blk + nlev + 1);
+    r->h_blk_se.assign(blk_se, blk_se + 2 * nblk);
+    const int64_t nnzL = r->nnzL, nnzU = r->nnzU;
+    if (nnzL + nnzU >= ((int64_t)1 << 31)) { nep_lu_refac_destroy(r); nep_set_error("refac: factors too large for 32-bit positions"); return NEP_ERR_UNSUPPORTED; }
+    // ---- union columns of F, rows sorted: U part (rows <= j, g = nnzL + e) then L part (rows > j, g = e)
+    std::vector<int64_t> cptr(n + 1, 0);
+    std::vector<Ent> cent((size_t)(nnzL + nnzU));
+    std::vector<int32_t> ldiag(n, -1), udiag(n, -1);
+    {
+        int64_t w = 0;
+        std::vector<Ent> tmp;
+        for (int64_t j = 0; j < n; ++j) {
+            cptr[j] = w;
+            tmp.clear();
+            for (int32_t e = Up[j]; e < Up[j + 1]; ++e) {
+                if (Ui[e] > j) { nep_lu_refac_destroy(r); nep_set_error("refac: U is not upper triangular"); return NEP_ERR_ARG; }
+                if (Ui[e] == j) udiag[j] = (int32_t)(nnzL + e);
+                tmp.push_back({Ui[e], (int32_t)(nnzL + e)});
+            }
+            for (int32_t e = Lp[j]; e < Lp[j + 1]; ++e) {
+                if (Li[e] < j) { nep_lu_refac_destroy(r); nep_set_error("refac: L is not lower triangular"); return NEP_ERR_ARG; }
+                if (Li[e] == j) { ldiag[j] = e; continue; }
+                tmp.push_back({Li[e], e});
+            }
+            std::sort(tmp.begin(), tmp.end(), [](const Ent& a, const Ent& b) { return a.row < b.row; });
+            for (const Ent& t : tmp) cent[w++] = t;
+            if (udiag[j] < 0 || ldiag[j] < 0) { nep_lu_refac_destroy(r); nep_set_error("refac: missing diagonal entry in column %lld", (long long)j); return NEP_ERR_UNSUPPORTED; }
+        }
+        cptr[n] = w;
+    }
+    // rows of U (row k: columns j > k with their positions), sorted by j
+    std::vector<int64_t> urp(n + 1, 0);
+    for (int64_t e = 0; e < nnzU; ++e) urp[Ui[e] + 1]++;
+    for (int64_t i = 0; i < n; ++i) urp[i + 1] += urp[i];
+    std::vector<Ent> urow((size_t)nnzU);
+    {
+        std::vector<int64_t> fill(urp.begin(), urp.end() - 1);
+        for (int64_t j = 0; j < n; ++j)
+            for (int32_t e = Up[j]; e < Up[j + 1]; ++e) urow[fill[Ui[e]]++] = {(int32_t)j, (int32_t)(nnzL + e)};   // j ascending
+    }
+    // ---- A -> F
+    std::vector<int32_t> amap((size_t)r->nnzA);
+    for (int64_t c = 0; c < n; ++c) {
+        const int32_t j = perm_c[c];
+        if (j < 0 || j >= n) { nep_lu_refac_destroy(r); nep_set_error("refac: invalid perm_c"); return NEP_ERR_ARG; }
+        for (int32_t e = Ap[c]; e < Ap[c + 1]; ++e) {
+            const int32_t rr = Ai[e];
+            if (rr < 0 || rr >= n) { nep_lu_refac_destroy(r); nep_set_error("refac: row index out of range"); return NEP_ERR_ARG; }
+            const int32_t i = perm_r[rr];
+            const Ent* b = cent.data() + cptr[j]; const Ent* en = cent.data() + cptr[j + 1];
+            const Ent* it = std::lower_bound(b, en, i, [](const Ent& a, int32_t v) { return a.row < v; });
+            if (it == en || it->row != i) { nep_lu_refac_destroy(r); nep_set_error("refac: an entry of A has no slot in L + U"); return NEP_ERR_UNSUPPORTED; }
+            amap[e] = it->g;
+        }
+    }
+    // ---- levels processed "wide": few blocks (the top of the tree), where a block's pivots form one long sequential chain
+    // with tens of thousands of products per pivot -- one workgroup cannot feed that (measured: 189 pivots 4.8 ms)
+    r->wide.assign(nlev, 0);
+    {
+        const char* e = getenv("NEP_LU_WIDE_MAXBLK");
+        const int maxblk = e ? atoi(e) : 4;
+        for (int l = 1; l < nlev; ++l) r->wide[l] = (lev_blk[l + 1] - lev_blk[l]) <= maxblk ? 1 : 0;
+    }
+    r->wstep0.assign(nlev + 1, 0);
+    for (int l = 0; l < nlev; ++l) {
+        int mx = 0;
+        if (r->wide[l]) for (int b = lev_blk[l]; b < lev_blk[l + 1]; ++b) mx = std::max(mx, blk_se[2 * b + 1] - blk_se[2 * b]);
+        r->wstep0[l + 1] = r->wstep0[l] + mx;
+    }
+    std::vector<std::vector<int32_t>> wprod((size_t)r->wstep0[nlev]);     // per step: gL, gU, gdst, gpiv
+    // ---- enumerate the products
+    std::vector<int32_t> itri;                              // internal: gL, gU, gdst, in ascending k
+    std::vector<int64_t> piv_cnt(n + 1, 0);                 // by schedule position of k
+    std::vector<std::vector<int32_t>> ext(nlev);            // per destination level: gdst, gL, gU (ascending k)
+    std::vector<int32_t> newpos(n);
+    for (int64_t q = 0; q < n; ++q) newpos[oldof[q]] = (int32_t)q;
+    std::vector<std::vector<int32_t>> itri_piv;             // filled per pivot then concatenated in schedule order
+    itri_piv.resize(n);
+    std::vector<Ent> Lk;
+    for (int64_t k = 0; k < n; ++k) {
+        // rows i > k of L(:,k), sorted
+        Lk.clear();
+        {
+            const Ent* b = cent.data() + cptr[k]; const Ent* en = cent.data() + cptr[k + 1];
+            const Ent* it = std::upper_bound(b, en, (int32_t)k, [](int32_t v, const Ent& a) { return v < a.row; });
+            for (; it != en; ++it) Lk.push_back(*it);
+        }
+        if (Lk.empty()) continue;
+        std::vector<int32_t>& mine = itri_piv[k];
+        const bool kwide = r->wide[lvl[k]] != 0;
+        std::vector<int32_t>* wl = kwide ? &wprod[(size_t)(r->wstep0[lvl[k]] + (newpos[k] - blk_se[2 * blk[k]]))] : nullptr;
+        for (int64_t ue = urp[k]; ue < urp[k + 1]; ++ue) {
+            const int32_t j = urow[ue].row, gU = urow[ue].g;
+            if (j <= k) continue;
+            // destinations (i, j), i in Lk: merge with the union column j (rows > k)
+            const Ent* b = cent.data() + cptr[j]; const Ent* en = cent.data() + cptr[j + 1];
+            const Ent* it = std::upper_bound(b, en, (int32_t)k, [](int32_t v, const Ent& a) { return v < a.row; });
+            for (const Ent& le : Lk) {
+                while (it != en && it->row < le.row) ++it;
+                if (it == en || it->row != le.row) {
+                    nep_lu_refac_destroy(r);
+                    nep_set_error("refac: the stored pattern is not closed under the elimination (update (%d,%d) from pivot %lld has no slot)", le.row, j, (long long)k);
+                    return NEP_ERR_UNSUPPORTED;
+                }
+                const int32_t p = std::min(le.row, j);
+                // (pivots of different blocks of a wide level run in the same launch and may share a destination in an
+                // ancestor block: those products stay "external", summed per destination in fixed order)
+                if (kwide && blk[p] == blk[k]) { wl->push_back(le.g); wl->push_back(gU); wl->push_back(it->g); wl->push_back(udiag[k]); }
+                else if (blk[p] == blk[k]) { mine.push_back(le.g); mine.push_back(gU); mine.push_back(it->g); }
+                else {
+                    if (lvl[p] <= lvl[k]) { nep_lu_refac_destroy(r); nep_set_error("refac: update crosses blocks of one level"); return NEP_ERR_UNSUPPORTED; }
+                    std::vector<int32_t>& ex = ext[lvl[p]];
+                    ex.push_back(it->g); ex.push_back(le.g); ex.push_back(gU);
+                }
+                ++r->nprod;
+            }
+        }
+    }
+    // internal products in schedule order
+    std::vector<int64_t> piv_ptr(n + 1, 0);
+    for (int64_t q = 0; q < n; ++q) piv_ptr[q + 1] = piv_ptr[q] + (int64_t)itri_piv[oldof[q]].size() / 3;
+    r->nint = piv_ptr[n];
+    itri.resize((size_t)r->nint * 3);
+    for (int64_t q = 0; q < n; ++q) {
+        const std::vector<int32_t>& v = itri_piv[oldof[q]];
+        if (!v.empty()) memcpy(itri.data() + 3 * piv_ptr[q], v.data(), v.size() * sizeof(int32_t));
+    }
+    { std::vector<std::vector<int32_t>>().swap(itri_piv); }
+    // external products grouped by destination (stable: ascending k inside a segment)
+    std::vector<int64_t> ext_ptr(1, 0);
+    std::vector<int32_t> ext_dst, ext_src;
+    r->ext_seg0.assign(nlev + 1, 0);
+    {
+        std::vector<int64_t> cnt((size_t)(nnzL + nnzU) + 1);
+        for (int l = 0; l < nlev; ++l) {
+            r->ext_seg0[l] = (int64_t)ext_dst.size();
+            const std::vector<int32_t>& ex = ext[l];
+            const int64_t m = (int64_t)ex.size() / 3;
+            if (m == 0) continue;
+            std::fill(cnt.begin(), cnt.end(), 0);
+            for (int64_t t = 0; t < m; ++t) cnt[ex[3 * t] + 1]++;
+            // segments in ascending destination order
+            std::vector<int64_t> start((size_t)(nnzL + nnzU) + 1, -1);
+            const int64_t base = (int64_t)ext_src.size() / 2;
+            int64_t run = base;
+            for (int64_t g = 0; g < nnzL + nnzU; ++g)
+                if (cnt[g + 1] > 0) { start[g] = run; ext_dst.push_back((int32_t)g); run += cnt[g + 1]; ext_ptr.push_back(run); }
+            ext_src.resize((size_t)run * 2);
+            for (int64_t t = 0; t < m; ++t) {
+                const int64_t pos = start[ex[3 * t]]++;
+                ext_src[2 * pos] = ex[3 * t + 1]; ext_src[2 * pos + 1] = ex[3 * t + 2];
+            }
+        }
+        r->ext_seg0[nlev] = (int64_t)ext_dst.size();
+    }
+    r->nseg = (int64_t)ext_dst.size(); r->next_ = (int64_t)ext_src.size() / 2;
+    std::vector<int32_t> wflat;
+    r->wide_ptr.assign(wprod.size() + 1, 0);
+    for (size_t sidx = 0; sidx < wprod.size(); ++sidx) r->wide_ptr[sidx + 1] = r->wide_ptr[sidx] + (int64_t)wprod[sidx].size() / 4;
+    r->nwide = r->wide_ptr[wprod.size()];
+    wflat.resize((size_t)r->nwide * 4);
+    for (size_t sidx = 0; sidx < wprod.size(); ++sidx)
+        if (!wprod[sidx].empty()) memcpy(wflat.data() + 4 * r->wide_ptr[sidx], wprod[sidx].data(), wprod[sidx].size() * sizeof(int32_t));
+    { std::vector<std::vector<int32_t>>().swap(wprod); }
+    // ---- upload
+    int rc;
+    std::vector<int32_t> vLp(Lp, Lp + n + 1), vLi(Li, Li + nnzL), vold(oldof, oldof + n), vse(blk_se, blk_se + 2 * nblk);
+    if ((rc = upv(&r->d_amap, amap)) || (rc = upv(&r->d_ldiag, ldiag)) || (rc = upv(&r->d_udiag, udiag)) || (rc = upv(&r->d_Lp, vLp)) ||
+        (rc = upv(&r->d_Li, vLi)) || (rc = upv(&r->d_oldof, vold)) || (rc = upv(&r->d_blk_se, vse)) || (rc = upv(&r->d_piv_ptr, piv_ptr)) ||
+        (rc = upv(&r->d_int, itri)) || (rc = upv(&r->d_ext_ptr, ext_ptr)) || (rc = upv(&r->d_ext_dst, ext_dst)) ||
+        (rc = upv(&r->d_ext_src, ext_src)) || (rc = upv(&r->d_wide, wflat))) { nep_lu_refac_destroy(r); return rc; }
+    r->t_symbolic_ms = now_ms() - t0;
+    if (getenv("NEP_TIMING"))
+        fprintf(stderr, "[lu_refac] n=%lld products %lld (internal %lld, external %lld in %lld segments, wide %lld in %lld steps), symbolic %.1f ms\n",
+                (long long)n, (long long)r->nprod, (long long)r->nint, (long long)r->next_, (long long)r->nseg, (long long)r->nwide,
+                (long long)r->wstep0[nlev], r->t_symbolic_ms);
+    *out = r;
+    return NEP_OK;
+}
+
+int32_t nep_lu_refac_info(const nep_lu_refac* r, int64_t out[6]) {
+    ARGCHK(r && out);
+    out[0] = r->n; out[1] = r->nprod; out[2] = r->nint; out[3] = r->next_; out[4] = r->nseg; out[5] = (int64_t)r->t_symbolic_ms;
+    return NEP_OK;
+}
+
+// h_Ax: the nnzA values of the new matrix in the CSC order of (Ap, Ai).  h_health[3] (may be NULL): [0] = 1 when a pivot was
+// zero or non-finite, [1] = largest |Re| + |Im| over the entries of L (element growth; 1-ish for a diagonally pivoted factor).
+// d_LUx_out (may be NULL): receives nnzL + nnzU values (L then U, input entry order) -- tests compare them with the host factor.
+// NEP_ERR_SINGULAR when a pivot broke down (nothing is returned then).
+int32_t nep_lu_factor_dev(nep_lu_refac* r, const nep_cdouble* h_Ax, int32_t expected_solves, double growth_limit,
+                          double* h_health, nep_cdouble* h_LUx_out, nep_lu** out, nep_stream stream) {
+    ARGCHK(r && h_Ax && out);
+    *out = nullptr;
+    hipStream_t st = as_stream(stream);
+    const int64_t nF = r->nnzL + r->nnzU;
+    cplx* dF = nullptr; cplx* dA = nullptr; double* dH = nullptr;
+    int rc;
+    if ((rc = nep_pool_alloc((void**)&dF, (size_t)nF * sizeof(cplx) + 64))) return rc;
+    if ((rc = nep_pool_alloc((void**)&dA, (size_t)r->nnzA * sizeof(cplx) + 64))) { nep_pool_free(dF); return rc; }
+    dH = (double*)((char*)dF + (size_t)nF * sizeof(cplx));
+    auto fail = [&](int code) { nep_pool_free_on(dF, st, true); nep_pool_free_on(dA, st, true); return code; };
+    static thread_local PinnedRing ring;
+    if ((rc = ring.upload(dA, h_Ax, (size_t)r->nnzA * sizeof(cplx), st))) return fail(rc);
+    HIPCHK(hipMemsetAsync(dF, 0, (size_t)nF * sizeof(cplx), st));
+    {
+        const int64_t m = std::max<int64_t>(r->nnzA, r->n);
+        hipLaunchKernelGGL(k_lu_init, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, nF, r->n, r->nnzA, (const int32_t*)r->d_amap,
+                           (const cplx*)dA, (const int32_t*)r->d_ldiag, dF, dH);
+        LAUNCHCHK();
+    }
+    for (int l = 0; l < r->nlev; ++l) {
+        const int64_t s0 = r->ext_seg0[l], s1 = r->ext_seg0[l + 1];
+        if (s1 > s0) {
+            hipLaunchKernelGGL(k_lu_ext, dim3((unsigned)((s1 - s0 + 255) / 256)), dim3(256), 0, st, s0, s1, (const int64_t*)r->d_ext_ptr,
+                               (const int32_t*)r->d_ext_dst, (const int32_t*)r->d_ext_src, dF);
+            LAUNCHCHK();
+        }
+        const int b0 = r->lev_blk[l], b1 = r->lev_blk[l + 1];
+        if (b1 <= b0) continue;
+        if (r->wide[l]) {
+            for (int64_t sidx = r->wstep0[l]; sidx < r->wstep0[l + 1]; ++sidx) {
+                const int64_t t0 = r->wide_ptr[sidx], t1 = r->wide_ptr[sidx + 1];
+                if (t1 <= t0) continue;
+                hipLaunchKernelGGL(k_lu_wide, dim3((unsigned)((t1 - t0 + 255) / 256)), dim3(256), 0, st, t0, t1, (const int4*)r->d_wide, dF);
+            }
+            LAUNCHCHK();
+            const int q0 = r->h_blk_se[2 * b0], q1 = r->h_blk_se[2 * (b1 - 1) + 1];
+            hipLaunchKernelGGL(k_lu_scale, dim3((unsigned)((q1 - q0 + 3) / 4)), dim3(256), 0, st, q0, q1, (const int32_t*)r->d_oldof,
+                               (const int32_t*)r->d_Lp, (const int32_t*)r->d_Li, (const int32_t*)r->d_udiag, dF, dH);
+            LAUNCHCHK();
+        } else {
+            hipLaunchKernelGGL(k_lu_int, dim3((unsigned)(b1 - b0)), dim3(512), 0, st, b0, (const int32_t*)r->d_blk_se,
+                               (const int32_t*)r->d_oldof, (const int32_t*)r->d_Lp, (const int32_t*)r->d_Li, (const int32_t*)r->d_udiag,
+                               (const int64_t*)r->d_piv_ptr, (const int32_t*)r->d_int, dF, dH);
+            LAUNCHCHK();
+        }
+    }
+    // health word (and, for tests, the factor values): one read-back behind the factorisation kernels
+    double hh[3] = {0.0, 0.0, 0.0};
+    HIPCHK(hipMemcpyAsync(hh, dH, sizeof(hh), hipMemcpyDeviceToHost, st));
+    if (h_LUx_out) HIPCHK(hipMemcpyAsync(h_LUx_out, dF, (size_t)nF * sizeof(cplx), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (h_health) { h_health[0] = hh[0]; h_health[1] = hh[1]; h_health[2] = hh[2]; }
+    if (hh[0] != 0.0 || !(hh[1] <= growth_limit)) {
+        nep_set_error("device refactorisation: pivot breakdown or element growth %.3g above %.3g with the stored pivot sequence", hh[1], growth_limit);
+        return fail(NEP_ERR_SINGULAR);
+    }
+    MLFactor* F = nullptr;
+    rc = ml_create_from_sym(r->S, (const nep_cdouble*)dF, (const nep_cdouble*)(dF + r->nnzL), st, expected_solves, &F);
+    // dF / dA are read by the gather kernels on the build stream: that stream waited for `st`, and the pool orders the next
+    // user of the blocks behind an event on it -- free behind the factor's `ready` event by waiting on the host side is not
+    // needed because ml_numeric_dev's gathers are enqueued before this returns; order the frees behind the build stream
+    if (rc) return fail(rc);
+    {
+        // the gathers run on a build stream; make `st` wait for the factor's ready event so that frees ordered on st are safe
+        // (ml_solve does the same wait before the first solve anyway)
+        (void)ml_wait_ready(F, st);
+    }
+    nep_pool_free_on(dF, st, true); nep_pool_free_on(dA, st, true);
+    *out = nep_lu_wrap_ml(F, r->n, r->nnzL, r->nnzU);
+    return NEP_OK;
+}
+
+}  // extern "C"

@@ -1000,6 +1000,16 @@ int32_t nep_lu_create_csc(int64_t n, const int32_t* hLp, const int32_t* hLi, con
     return lu_create_any(n, 1, hLp, hLi, hLx, hUp, hUi, hUx, h_perm_r, h_perm_c, out);
 }
 
+}  // extern "C"
+// hooks of csrc/lufac.hip (device-side numeric factorisation)
+MLFactor* nep_lu_ml(nep_lu* lu) { return lu ? lu->ml : nullptr; }
+nep_lu* nep_lu_wrap_ml(MLFactor* F, int64_t n, int64_t nnzL, int64_t nnzU) {
+    nep_lu* lu = new nep_lu();
+    lu->n = n; lu->csc = 1; lu->nnzL_in = nnzL; lu->nnzU_in = nnzU; lu->ml = F;
+    return lu;
+}
+extern "C" {
+
 int32_t nep_lu_refactor(nep_lu* lu, const nep_cdouble* hLx, const nep_cdouble* hUx) {
     ARGCHK(lu && hLx && hUx);
     if (!lu->ml) { nep_set_error("nep_lu_refactor needs the block schedule (this handle uses the level schedule)"); return NEP_ERR_UNSUPPORTED; }

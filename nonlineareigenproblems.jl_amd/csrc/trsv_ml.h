@@ -16,3 +16,16 @@ void ml_destroy(MLFactor* F);
 void ml_info(const MLFactor* F, int64_t info[6], int64_t sched[8]);
 int ml_solve(MLFactor* F, int nrhs, const nep_cdouble* dB, int64_t ldb, const nep_cdouble* dAdd, int64_t ldadd,
              nep_cdouble* dX, int64_t ldx, double scale, hipStream_t st);
+
+// ---- hooks of the device-side numeric factorisation (csrc/lufac.hip): the symbolic part (partition, schedule) of an existing
+// factor is shared; the new factor's values arrive in device arrays laid out like the input L / U of that factor
+struct MLSym;
+MLSym* ml_sym_acquire(MLFactor* F);                 // takes a reference
+void ml_sym_release_ref(MLSym* S);
+// partition in the factor's input numbering: level and block of every pivot, the pivots in schedule order (oldof), the
+// block boundaries in that order (blk_se[2k], blk_se[2k+1]) and the block range of every level (lev_blk[l], lev_blk[l+1])
+void ml_sym_partition(const MLSym* S, int64_t* n, int* nlev, int* nblk, const int32_t** lvl, const int32_t** blk,
+                      const int32_t** oldof, const int32_t** blk_se, const int32_t** lev_blk);
+int ml_create_from_sym(MLSym* S, const nep_cdouble* d_Lx, const nep_cdouble* d_Ux, hipStream_t producer, int expected_solves,
+                       MLFactor** out);
+int ml_wait_ready(MLFactor* F, hipStream_t st);   // st waits for the numeric build of F

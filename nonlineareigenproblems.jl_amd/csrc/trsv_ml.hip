@@ -46,6 +46,7 @@ struct MLFacSym {
     int32_t* d_lvo = nullptr;      // nblk+1
     // host
     std::vector<int32_t> map;      // input entry -> slot*4 + kind   (kind 0 skip, 1 coupling, 2 in-block, 3 diagonal)
+    int32_t* d_map = nullptr;      // the same on the device (uploaded on first use by the device-side numeric path)
     int64_t ncoup = 0, nin = 0, ninv = 0;
     MLChunk* d_chunks = nullptr;   // row chunks of the level kernels (chunk size depends on the level's mode)
     std::vector<int32_t> lev_chunk;    // nlev+1
@@ -69,6 +70,8 @@ struct MLSym {
     int refs = 0;
     int csc = 0;
     int max_block = 0;
+    // partition in the factor's own (input) numbering, for the device-side numeric factorisation (csrc/lufac.hip)
+    std::vector<int32_t> h_lvl, h_blk, h_oldof, h_blk_se;
     double t_build_ms = 0.0;
 };
 
@@ -148,6 +151,18 @@ __global__ __launch_bounds__(256) void k_ml_inverse(const int32_t* __restrict__ 
     }
     if (UPPER) { for (int t = threadIdx.x; t <= j; t += 256) ix[ip[s + t] + (j - t)] = x[t]; }
     else       { for (int t = j + threadIdx.x; t < bsz; t += 256) ix[ip[s + t] + j] = x[t]; }
+}
+
+// device-side numeric path: values of a factor (input entry order) -> the schedule's value array
+__global__ void k_ml_gather(int64_t nnz, const int32_t* __restrict__ map, const cplx* __restrict__ src, cplx* __restrict__ vals,
+                            int64_t o1, int64_t o2, int64_t o3) {
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t v = map[e];
+        const int kind = v & 3;
+        if (kind == 1) vals[o1 + (v >> 2)] = src[e];
+        else if (kind == 2) vals[o2 + (v >> 2)] = src[e];
+        else if (kind == 3) vals[o3 + (v >> 2)] = src[e];
+    }
 }
 
 // ---- solve kernels ------------------------------------------------------------------------------------------------
@@ -458,6 +473,7 @@ int up(T** d, const std::vector<T>& h, size_t min_count = 1) {
 void free_fac(MLFacSym& f) {
     nep_pool_free(f.d_cp); nep_pool_free(f.d_ci); nep_pool_free(f.d_ip); nep_pool_free(f.d_bp); nep_pool_free(f.d_bi);
     nep_pool_free(f.d_slotrow); nep_pool_free(f.d_lvp); nep_pool_free(f.d_lvo); nep_pool_free(f.d_chunks);
+    if (f.d_map) nep_pool_free(f.d_map);
 }
 void free_sym(MLSym* s) {
     if (!s) return;
@@ -705,6 +721,9 @@ int build_symbolic(MLSym* S, int64_t n, const int32_t* Lrp, const int32_t* Lci, 
         newpos[j] = q; oldof[q] = (int32_t)j; rowblk[q] = k; rowlev[q] = lvl[j];
     }
     S->lev_blk = lev_nblk;
+    S->h_lvl.assign(lvl.begin(), lvl.end()); S->h_oldof = oldof; S->h_blk_se = blk_se;
+    S->h_blk.resize(n);
+    for (int64_t j = 0; j < n; ++j) S->h_blk[j] = blkid[bid[j]];
     for (int k = 0; k < nblk; ++k) S->max_block = std::max(S->max_block, blk_se[2 * k + 1] - blk_se[2 * k]);
     // ---- permutations folded into the first and last launch
     std::vector<int32_t> pin(n), pout(n);
@@ -890,6 +909,81 @@ int ml_create(int64_t n, int csc, const int32_t* Lp, const int32_t* Li, const ne
 }
 
 int ml_refactor(MLFactor* F, const nep_cdouble* Lx, const nep_cdouble* Ux) { return ml_numeric(F, Lx, Ux); }
+
+// numeric part with the factor values already on the device (d_Lx / d_Ux in the input entry order, produced on `producer`)
+static int ml_numeric_dev(MLFactor* F, const cplx* d_Lx, const cplx* d_Ux, hipStream_t producer) {
+    MLSym* S = F->sym;
+    const int64_t n = S->n;
+    const int64_t oL = 0, oLb = oL + S->L.ncoup, oU = oLb + S->L.nin, oUb = oU + S->U.ncoup, oD = oUb + S->U.nin;
+    const int64_t ntot = oD + n;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (!S->L.d_map && (rc = up(&S->L.d_map, S->L.map))) return rc;
+        if (!S->U.d_map && (rc = up(&S->U.d_map, S->U.map))) return rc;
+    }
+    hipStream_t bst = g_bstreams.get();
+    if (!F->d_vals) {
+        if ((rc = nep_pool_alloc((void**)&F->d_vals, (size_t)ntot * sizeof(cplx)))) return rc;
+        if ((rc = nep_pool_alloc((void**)&F->d_ixL, (size_t)std::max<int64_t>(S->L.ninv, 1) * sizeof(cplx)))) return rc;
+        if ((rc = nep_pool_alloc((void**)&F->d_ixU, (size_t)std::max<int64_t>(S->U.ninv, 1) * sizeof(cplx)))) return rc;
+        HIPCHK(hipEventCreateWithFlags(&F->ready, hipEventDisableTiming));
+    }
+    {
+        hipEvent_t ev; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev, producer)); HIPCHK(hipStreamWaitEvent(bst, ev, 0)); (void)hipEventDestroy(ev);
+    }
+    const int gl = (int)std::min<int64_t>((S->nnzL + 255) / 256, 4096), gu = (int)std::min<int64_t>((S->nnzU + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_ml_gather, dim3(gl), dim3(256), 0, bst, S->nnzL, (const int32_t*)S->L.d_map, d_Lx, F->d_vals, oL, oLb, oD);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_ml_gather, dim3(gu), dim3(256), 0, bst, S->nnzU, (const int32_t*)S->U.d_map, d_Ux, F->d_vals, oU, oUb, oD);
+    LAUNCHCHK();
+    hipLaunchKernelGGL((k_ml_inverse<false>), dim3((unsigned)n), dim3(256), 0, bst, (const int32_t*)S->d_rowblk,
+                       (const int32_t*)S->d_blk_se, (const int32_t*)S->L.d_lvo, (const int32_t*)S->L.d_lvp,
+                       (const int32_t*)S->L.d_slotrow, (const int32_t*)S->L.d_bp, (const int32_t*)S->L.d_bi,
+                       (const cplx*)(F->d_vals + oLb), (const cplx*)nullptr, (const int64_t*)S->L.d_ip, F->d_ixL);
+    LAUNCHCHK();
+    hipLaunchKernelGGL((k_ml_inverse<true>), dim3((unsigned)n), dim3(256), 0, bst, (const int32_t*)S->d_rowblk,
+                       (const int32_t*)S->d_blk_se, (const int32_t*)S->U.d_lvo, (const int32_t*)S->U.d_lvp,
+                       (const int32_t*)S->U.d_slotrow, (const int32_t*)S->U.d_bp, (const int32_t*)S->U.d_bi,
+                       (const cplx*)(F->d_vals + oUb), (const cplx*)(F->d_vals + oD), (const int64_t*)S->U.d_ip, F->d_ixU);
+    LAUNCHCHK();
+    if (F->apex_la > 0 && (rc = ml_build_apex(F, bst))) return rc;
+    HIPCHK(hipEventRecord(F->ready, bst));
+    F->synced_valid = false;
+    return NEP_OK;
+}
+
+// ---- interface of the device-side numeric factorisation (csrc/lufac.hip) -------------------------------------------------
+MLSym* ml_sym_acquire(MLFactor* F) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    F->sym->refs++;
+    return F->sym;
+}
+void ml_sym_release_ref(MLSym* S) { if (S) sym_release(S); }
+void ml_sym_partition(const MLSym* S, int64_t* n, int* nlev, int* nblk, const int32_t** lvl, const int32_t** blk,
+                      const int32_t** oldof, const int32_t** blk_se, const int32_t** lev_blk) {
+    *n = S->n; *nlev = S->nlev; *nblk = S->nblk; *lvl = S->h_lvl.data(); *blk = S->h_blk.data(); *oldof = S->h_oldof.data();
+    *blk_se = S->h_blk_se.data(); *lev_blk = S->lev_blk.data();
+}
+int ml_wait_ready(MLFactor* F, hipStream_t st) {
+    HIPCHK(hipStreamWaitEvent(st, F->ready, 0));
+    F->synced = st; F->synced_valid = true;
+    return NEP_OK;
+}
+int ml_create_from_sym(MLSym* S, const nep_cdouble* d_Lx, const nep_cdouble* d_Ux, hipStream_t producer, int expected_solves,
+                       MLFactor** out) {
+    *out = nullptr;
+    { std::lock_guard<std::mutex> lk(g_cache_mu); S->refs++; }
+    MLFactor* F = new MLFactor();
+    F->sym = S;
+    F->use_graph = expected_solves >= 3 ? 1 : 0;
+    F->apex_la = choose_apex(S, expected_solves);
+    int rc = ml_numeric_dev(F, (const cplx*)d_Lx, (const cplx*)d_Ux, producer);
+    if (rc) { ml_destroy(F); return rc; }
+    *out = F;
+    return NEP_OK;
+}
 
 // host-only analysis (no device): out[0]=levels, out[1]=blocks, out[2]=largest block, out[3]/[4]=coupling non-zeros and
 // packed inverse entries of L, out[5]/[6] of U, out[7]=levels with a separate coupling launch (L+U)

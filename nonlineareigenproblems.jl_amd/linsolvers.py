@@ -12,6 +12,7 @@ are uploaded once; every lin_solve is the HIP kernel k_lu_solve (csrc/trsv.hip).
 """
 import ctypes as C
 import os
+import threading
 import sys
 import time
 
@@ -116,6 +117,94 @@ import atexit  # noqa: E402
 atexit.register(HostLUPool.shutdown)
 
 
+class _DeviceRefactor:
+    """Per sparsity pattern: the plan of the device-side numeric factorisation (csrc/lufac.hip).  The first matrix of a pattern
+    is factorised on the host; when that factorisation used the symmetric strategy with diagonal pivots only (perm_r ==
+    perm_c) and landed on the block schedule, a background thread enumerates the updates of the right-looking LU for that
+    pivot sequence (0.3 s for the gun pattern, once per pattern and process).  Later matrices with the same pattern -- the next
+    iar call, the next shift of nleigs -- are factorised on the GPU with the stored pivot sequence (static pivoting); pivot
+    breakdown or element growth above `GROWTH` sends that matrix back to the host path."""
+    plans = {}           # key -> dict(state="building"|"ready"|"off", handle, thread, strategy, fails)
+    lock = threading.Lock()
+    GROWTH = float(os.environ.get("NEP_LU_DEV_GROWTH", "1e6"))
+    MAX = 4
+
+    @classmethod
+    def enabled(cls):
+        return os.environ.get("NEP_LU_DEV", "1") != "0"
+
+    @classmethod
+    def key(cls, Ac, opts):
+        import hashlib
+        h = hashlib.blake2b(digest_size=16)
+        h.update(np.ascontiguousarray(Ac.indptr)); h.update(np.ascontiguousarray(Ac.indices))
+        return (h.digest(), Ac.shape, opts)
+
+    @classmethod
+    def lookup(cls, key):
+        with cls.lock:
+            p = cls.plans.get(key)
+            return p if (p is not None and p["state"] == "ready") else None
+
+    @classmethod
+    def maybe_start(cls, key, lu, F, Ac):
+        """called after a host factorisation: start the plan of this pattern if the factor qualifies"""
+        if not cls.enabled() or not lu.block_schedule or F.get("fmt") != "csc":
+            return
+        if not F["strategy"].get("symmetric_mode") or not np.array_equal(F["perm_r"], F["perm_c"]):
+            return
+        with cls.lock:
+            if key in cls.plans:
+                return
+            while len(cls.plans) >= cls.MAX:
+                old = next(iter(cls.plans))
+                po = cls.plans[old]
+                if po["state"] == "building":
+                    return
+                cls.plans.pop(old)
+                if po.get("handle"):
+                    lib.nep_lu_refac_destroy(po["handle"])
+            plan = dict(state="building", handle=None, strategy=dict(F["strategy"]), fails=0, uses=0)
+            cls.plans[key] = plan
+        arrs = [np.array(F[k], dtype=np.int32, copy=True) for k in ("Lp", "Li", "Up", "Ui", "perm_r", "perm_c")]
+        Ap = np.array(Ac.indptr, dtype=np.int32, copy=True); Ai = np.array(Ac.indices, dtype=np.int32, copy=True)
+        n = int(F["n"])
+
+        def build():
+            h = c_vp()
+            rc = lib.nep_lu_refac_create(lu.h, n, *[hptr(a) for a in arrs], hptr(Ap), hptr(Ai), C.byref(h))   # GIL released
+            with cls.lock:
+                if rc == 0:
+                    plan["handle"] = h; plan["state"] = "ready"
+                else:
+                    plan["state"] = "off"
+            plan.pop("keep", None)
+        plan["keep"] = lu                  # the reference factor must outlive the build
+        t = threading.Thread(target=build, name="nep-lu-refac-plan", daemon=True)
+        plan["thread"] = t
+        t.start()
+
+    @classmethod
+    def wait(cls):
+        """block until every plan under construction is finished (tests, benchmarks)"""
+        for p in list(cls.plans.values()):
+            t = p.get("thread")
+            if t is not None:
+                t.join()
+
+    @classmethod
+    def clear(cls):
+        cls.wait()
+        with cls.lock:
+            for p in cls.plans.values():
+                if p.get("handle"):
+                    lib.nep_lu_refac_destroy(p["handle"])
+            cls.plans.clear()
+
+
+atexit.register(_DeviceRefactor.wait)      # a plan thread inside the HIP runtime must not be cut off by interpreter shutdown
+
+
 class DeviceLU:
     """nep_lu handle built from a host sparse LU of A (CSC/CSR/dense).
 
@@ -131,8 +220,15 @@ class DeviceLU:
                  factors=None):
         _lib.require_gpu()
         t0 = time.perf_counter()
+        self.device_factorized = False
+        rkey = None; Ac = None
         if factors is None:
             Ac = sp.csc_matrix(A, dtype=np.complex128)
+            if _DeviceRefactor.enabled():
+                rkey = _DeviceRefactor.key(Ac, (permc_spec, diag_pivot_thresh, symmetric_mode))
+                plan = _DeviceRefactor.lookup(rkey)
+                if plan is not None and self._factor_on_device(plan, Ac, expected_solves, t0):
+                    return
             try:
                 factors = _nep_hostlu.factor(Ac.data, Ac.indices, Ac.indptr, Ac.shape, permc_spec=permc_spec,
                                              diag_pivot_thresh=diag_pivot_thresh, symmetric_mode=symmetric_mode)
@@ -162,6 +258,39 @@ class DeviceLU:
                 _nep_hostlu.release_shm(F)
         self.h = h
         self.t_create = time.perf_counter() - t_b
+        self._describe()
+        self.t_setup = time.perf_counter() - t0
+        if rkey is not None and not shm_backed:
+            _DeviceRefactor.maybe_start(rkey, self, F, Ac)
+
+    def _factor_on_device(self, plan, Ac, expected_solves, t0):
+        """numeric factorisation on the GPU with the pattern's stored pivot sequence; False -> the caller takes the host path"""
+        health = np.zeros(3)
+        h = c_vp()
+        Ax = np.ascontiguousarray(Ac.data, dtype=np.complex128)
+        check(lib.nep_lu_set_expected_solves(int(expected_solves)))
+        rc = lib.nep_lu_factor_dev(plan["handle"], hptr(Ax), int(expected_solves), _DeviceRefactor.GROWTH, hptr(health), None,
+                                   C.byref(h), stream_ptr())
+        if rc != 0:
+            plan["fails"] += 1
+            if rc != _lib.NEP_ERR_SINGULAR or plan["fails"] >= 3:       # repeated breakdowns: the pivot sequence does not suit
+                plan["state"] = "off"
+            return False
+        plan["uses"] += 1
+        self.device_factorized = True
+        self.growth = float(health[1])
+        self.n = int(Ac.shape[0])
+        self.normA = float(np.linalg.norm(Ax))
+        self.strategy = dict(plan["strategy"], numeric="device (stored pivot sequence)")
+        self.t_factor = time.perf_counter() - t0
+        self.t_convert = 0.0; self.t_create = 0.0
+        self.h = h
+        self._describe()
+        self.t_setup = time.perf_counter() - t0
+        return True
+
+    def _describe(self):
+        n = self.n
         info = (c_i64 * 6)()
         check(lib.nep_lu_info(self.h, info))
         self.nnzL, self.nnzU, self.levL, self.levU, self.solve_bytes = (int(info[1]), int(info[2]), int(info[3]),
@@ -178,7 +307,6 @@ class DeviceLU:
             self.levels, self.split_levels, self.blocks = int(sch[2]), int(sch[4]), int(sch[5])
         # (nnz L + nnz U)(16 + 4) + 8(n + 1) + 3*16 n for one right-hand side
         self.algorithmic_bytes = (self.nnzL + self.nnzU) * 20 + 8 * (n + 1) + 48 * n
-        self.t_setup = time.perf_counter() - t0
 
     def refactor(self, Lx, Ux):
         """same-pattern refactorisation (nep_lu_refactor): new values in the entry order of the factors this handle

@@ -125,7 +125,7 @@ def c4_host_errors(n, lam, V):
 
 
 # ---- C5: waveguide (WEP, JARLEBRING), tiar m = 60 ----------------------------------------------------------------------------
-def c5_device(na, nx=1003, nz=999, solver="gmres", N=37, reltol=1e-9, refine=1, maxit=60, timers=None):
+def c5_device(na, nx=1003, nz=999, solver="gmres", N=37, reltol=1e-9, refine=1, maxit=60, timers=None, restart=60):
     """returns (lam, Q, residuals, info).  solver: "lu" = FactorizeLinSolver on the assembled M(sigma) (host SuperLU of an
     n = nx*nz + 2nz matrix), "gmres" = the reference's own solver for this problem (Schur complement + Sylvester-SMW
     preconditioned GMRES, Waveguide.jl:394-567).  reltol / refine: inner GMRES tolerance and refinement sweeps around it
@@ -145,7 +145,7 @@ def c5_device(na, nx=1003, nz=999, solver="gmres", N=37, reltol=1e-9, refine=1, 
             P = na.wep_generate_preconditioner(nep, N, -3 - 3.5j)
             torch.cuda.synchronize()
             info.update(preconditioner_N=N, preconditioner_setup_s=time.perf_counter() - t1)
-            skw = (("Pl", P), ("reltol", reltol), ("restart", 60), ("maxiter", 300), ("orth_meth", "dgks"))
+            skw = (("Pl", P), ("reltol", reltol), ("restart", restart), ("maxiter", 300), ("orth_meth", "dgks"))
         kw["linsolvercreator"] = na.WEPLinSolverCreator(solver_type=solver, kwargs=skw, refinements=refine)
     out = na.tiar(nep, sigma=-3 - 3.5j, gamma=1.0, maxit=maxit, neigs=np.inf, v=v0, tol=1e-8, timers=timers, **kw)
     torch.cuda.synchronize()

@@ -691,3 +691,68 @@ def test_concurrent_lu_create_solve_stress(na):
         t.join()
     assert not errors, errors[:3]
     assert np.linalg.norm(mats[0] @ na.to_host(Xm) - B) <= 1e-9 * np.linalg.norm(B)
+
+
+def test_device_numeric_factorization(na, monkeypatch):
+    """csrc/lufac.hip: the second matrix of a sparsity pattern is factorised on the GPU with the pivot sequence of the first
+    (host) factorisation: L and U equal the host factor's to round-off, the solves agree, a growth limit that is not met
+    sends the matrix back to the host path"""
+    import ctypes as C
+    import scipy.sparse as sp
+    import torch
+    from oracle import gallery as og
+    from nep_amd import linsolvers as ls
+    from nep_amd._lib import lib, check, hptr, c_vp
+    from nep_amd.nep import stream_ptr
+    import nep_amd_hostlu as hl
+    ls._DeviceRefactor.clear()
+    onep = og.gun_spmf_scaled(1310)
+    A0 = sp.csc_matrix(onep.compute_Mder(0.0)).astype(np.complex128)
+    A1 = sp.csc_matrix(onep.compute_Mder(0.15 + 0.05j)).astype(np.complex128)
+    assert np.array_equal(A0.indices, A1.indices)
+    # (i) raw API: values of L and U against the host factor of the same matrix
+    F = hl.factor(A0.data, A0.indices, A0.indptr, A0.shape)
+    ref = na.DeviceLU(factors=F)
+    h = c_vp()
+    check(lib.nep_lu_refac_create(ref.h, A0.shape[0], hptr(F["Lp"]), hptr(F["Li"]), hptr(F["Up"]), hptr(F["Ui"]), hptr(F["perm_r"]),
+                                  hptr(F["perm_c"]), hptr(np.ascontiguousarray(A0.indptr, dtype=np.int32)),
+                                  hptr(np.ascontiguousarray(A0.indices, dtype=np.int32)), C.byref(h)))
+    info = (C.c_int64 * 6)(); check(lib.nep_lu_refac_info(h, info))
+    assert info[1] == info[2] + info[3] + (info[1] - info[2] - info[3]) and info[1] > 0
+    n = A0.shape[0]; nL = len(F["Lx"])
+    for A in (A0, A1):
+        Fh = hl.factor(A.data, A.indices, A.indptr, A.shape)
+        assert np.array_equal(Fh["perm_r"], F["perm_r"])
+        LU = np.empty(nL + len(F["Ux"]), dtype=np.complex128); health = np.zeros(3); out = c_vp()
+        check(lib.nep_lu_factor_dev(h, hptr(np.ascontiguousarray(A.data)), 10, 1e8, hptr(health), hptr(LU), C.byref(out), stream_ptr()))
+        Ld = sp.csc_matrix((LU[:nL], F["Li"], F["Lp"]), shape=(n, n)); Ud = sp.csc_matrix((LU[nL:], F["Ui"], F["Up"]), shape=(n, n))
+        Lh = sp.csc_matrix((Fh["Lx"], Fh["Li"], Fh["Lp"]), shape=(n, n)); Uh = sp.csc_matrix((Fh["Ux"], Fh["Ui"], Fh["Up"]), shape=(n, n))
+        assert abs(Ld - Lh).max() <= 1e-10 * abs(Lh).max() and abs(Ud - Uh).max() <= 1e-10 * abs(Uh).max()
+        assert health[0] == 0 and 0 < health[1] < 1e4
+        b = np.random.default_rng(1).standard_normal(n) + 0j
+        bd = torch.from_numpy(b).to("cuda"); x = torch.empty_like(bd)
+        check(lib.nep_lu_solve(out, 1, c_vp(bd.data_ptr()), n, c_vp(x.data_ptr()), n, 1.0, stream_ptr()))
+        assert np.linalg.norm(A @ x.cpu().numpy() - b) <= 1e-9 * np.linalg.norm(b)
+        lib.nep_lu_destroy(out)
+    # a growth limit below the factor's growth: refused with NEP_ERR_SINGULAR, nothing returned
+    out = c_vp()
+    assert lib.nep_lu_factor_dev(h, hptr(np.ascontiguousarray(A0.data)), 10, 1e-3, None, None, C.byref(out), stream_ptr()) == -3
+    assert not out.value
+    lib.nep_lu_refac_destroy(h)
+    # (ii) through DeviceLU: first matrix on the host (plan built in the background), second on the device
+    lu0 = na.DeviceLU(A0)
+    assert not lu0.device_factorized
+    ls._DeviceRefactor.wait()
+    lu1 = na.DeviceLU(A1)
+    assert lu1.device_factorized and lu1.block_schedule and lu1.growth > 0
+    b = np.random.default_rng(2).standard_normal(n) + 1j
+    x1 = lu1.solve(torch.from_numpy(b).to("cuda")).cpu().numpy()
+    assert np.linalg.norm(A1 @ x1 - b) <= 1e-9 * np.linalg.norm(b)
+    monkeypatch.setattr(ls._DeviceRefactor, "GROWTH", 1e-3)
+    lu2 = na.DeviceLU(A1)                                   # falls back to the host factorisation
+    assert not lu2.device_factorized
+    x2 = lu2.solve(torch.from_numpy(b).to("cuda")).cpu().numpy()
+    assert np.linalg.norm(x2 - x1) <= 1e-9 * np.linalg.norm(x1)
+    monkeypatch.setenv("NEP_LU_DEV", "0")
+    assert not na.DeviceLU(A1).device_factorized
+    ls._DeviceRefactor.clear()
