@@ -345,6 +345,10 @@ def main():
 
     for _ in range(args.warmup):
         bc.c2_device(na, nep, args.maxit, args.permc)
+    # one-time plan of the device-side numeric LU for this sparsity pattern (csrc/lufac.hip): started by the first host
+    # factorisation on a background thread (0.3 s); like graph capture and allocator pools it belongs to the warm-up
+    from nep_amd.linsolvers import _DeviceRefactor
+    _DeviceRefactor.wait()
 
     def barrier():
         if use_dist:
@@ -364,6 +368,19 @@ def main():
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax[0]); pairs = int(round(float(tsum[1])))
+
+    # the same step with the numeric factorisation on the host (SuperLU) every time, for comparison
+    ms_host_lu = None
+    if os.environ.get("NEP_LU_DEV", "1") != "0" and not args.only:
+        os.environ["NEP_LU_DEV"] = "0"
+        try:
+            bc.c2_device(na, nep, args.maxit, args.permc)
+            torch.cuda.synchronize(); th = time.perf_counter()
+            for _ in range(4):
+                bc.c2_device(na, nep, args.maxit, args.permc)
+            torch.cuda.synchronize(); ms_host_lu = (time.perf_counter() - th) / 4 * 1e3
+        finally:
+            os.environ["NEP_LU_DEV"] = "1"
 
     out = None
     if rank == 0:
@@ -399,10 +416,14 @@ def main():
                                    "check_error_every=1 DGKS umfpack_refinements=10; host SuperLU factorisation "
                                    "(UMFPACK-like symmetric strategy) inside the step" % (args.n, args.maxit),
                        "parallelism": "replicas x%d (iar does not shard)" % world,
+                       "factorization": "numeric LU of M(sigma) inside every step: on the device (csrc/lufac.hip, right-looking on the "
+                                        "fill pattern and pivot sequence of the pattern's first host SuperLU factorisation, health "
+                                        "word + host fallback) when the plan of the pattern exists (built during warm-up), else host SuperLU",
                        "eigenpairs_per_step": per_step_pairs,
                        "max_backward_error": maxres},
             "value_excl_setup": world * per_step_pairs / max(ms_step * 1e-3 - t_setup, 1e-9),
             "linsolver_setup_ms": t_setup * 1e3,
+            "ms_per_step_host_lu": ms_host_lu,
             "compute_Mlincomb_GBps": achieved,
             "roofline_compute_Mlincomb": {"bound": "hbm", "kernel": "nep_mlincomb, k=%d columns" % k,
                          "note": "the kernel BASELINE's metric names; at gun size one call moves 17.8 MB (2.2 us at 8 TB/s), "

@@ -262,6 +262,18 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
         for (int64_t j = 0; j < n; ++j)
             for (int32_t e = Up[j]; e < Up[j + 1]; ++e) urow[fill[Ui[e]]++] = {(int32_t)j, (int32_t)(nnzL + e)};   // j ascending
     }
+    // ---- size of the plan: sum_k |L(:,k)| |U(k,:)| products, 12-16 bytes each on the host and on the device
+    {
+        double est = 0.0;
+        for (int64_t k = 0; k < n; ++k) est += (double)(Lp[k + 1] - Lp[k] - 1) * (double)(urp[k + 1] - urp[k] - 1);
+        const char* e = getenv("NEP_LU_DEV_MAXPROD");
+        const double lim = e ? atof(e) : 1.5e8;
+        if (est > lim) {
+            nep_lu_refac_destroy(r);
+            nep_set_error("refac: %.3g products exceed the plan limit %.3g (NEP_LU_DEV_MAXPROD)", est, lim);
+            return NEP_ERR_UNSUPPORTED;
+        }
+    }
     // ---- A -> F
     std::vector<int32_t> amap((size_t)r->nnzA);
     for (int64_t c = 0; c < n; ++c) {

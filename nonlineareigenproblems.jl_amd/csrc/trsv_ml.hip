@@ -82,6 +82,9 @@ struct MLFactor {
     cplx* d_ixU = nullptr;
     cplx* d_Sinv = nullptr;        // apex: dense row-major inverse of the rows of levels >= apex_la (0 = no apex)
     int apex_la = 0;
+    // the apex is built BEHIND the `ready` event: solves that arrive before it is finished walk the apex levels like any
+    // other level (22 us more per gun solve) instead of waiting 3.3 ms for it; apex_live flips when apex_ev has completed
+    hipEvent_t apex_ev = nullptr; bool apex_live = false;
     double* d_rscale = nullptr;    // optional row scaling (UMFPACK's Rs): b is multiplied by it on the way in
     NepScratch work;               // bw | y | x | tmp, each n*nrhs
     hipEvent_t ready = nullptr;    // numeric build complete (recorded on the build stream)
@@ -761,6 +764,29 @@ int build_symbolic(MLSym* S, int64_t n, const int32_t* Lrp, const int32_t* Lci, 
 
 static int ml_build_apex(MLFactor* F, hipStream_t bst);
 static int choose_apex(const MLSym* S, int expected_solves);
+// end of a numeric build on bst: `ready` = block inverses done (solves may start), then the apex behind it
+static int ml_finish_numeric(MLFactor* F, hipStream_t bst) {
+    static const int apex_sync = getenv("NEP_ML_APEX_SYNC") ? atoi(getenv("NEP_ML_APEX_SYNC")) : 0;
+    F->apex_live = false;
+    F->synced_valid = false;
+    if (F->graph) { (void)hipGraphExecDestroy(F->graph); F->graph = nullptr; }
+    if (F->apex_la > 0 && apex_sync) {          // old behaviour: nothing may start before the apex exists
+        int rc = ml_build_apex(F, bst);
+        if (rc) return rc;
+        F->apex_live = true;
+        HIPCHK(hipEventRecord(F->ready, bst));
+        return NEP_OK;
+    }
+    HIPCHK(hipEventRecord(F->ready, bst));
+    if (F->apex_la > 0) {
+        int rc = ml_build_apex(F, bst);
+        if (rc) return rc;
+        if (!F->apex_ev) HIPCHK(hipEventCreateWithFlags(&F->apex_ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(F->apex_ev, bst));
+    }
+    return NEP_OK;
+}
+static inline int eff_apex(const MLFactor* F) { return F->apex_live ? F->apex_la : 0; }
 
 // ---- numeric part: gather the values into the schedule's order, upload, invert the diagonal blocks -----------------------
 static int ml_numeric(MLFactor* F, const nep_cdouble* Lx, const nep_cdouble* Ux) {
@@ -821,9 +847,7 @@ static int ml_numeric(MLFactor* F, const nep_cdouble* Lx, const nep_cdouble* Ux)
                        (const int32_t*)S->U.d_slotrow, (const int32_t*)S->U.d_bp, (const int32_t*)S->U.d_bi,
                        (const cplx*)(F->d_vals + oUb), (const cplx*)(F->d_vals + oD), (const int64_t*)S->U.d_ip, F->d_ixU);
     LAUNCHCHK();
-    if (F->apex_la > 0 && (rc = ml_build_apex(F, bst))) return rc;
-    HIPCHK(hipEventRecord(F->ready, bst));
-    F->synced_valid = false;
+    if ((rc = ml_finish_numeric(F, bst))) return rc;
     return NEP_OK;
 }
 
@@ -948,9 +972,7 @@ static int ml_numeric_dev(MLFactor* F, const cplx* d_Lx, const cplx* d_Ux, hipSt
                        (const int32_t*)S->U.d_slotrow, (const int32_t*)S->U.d_bp, (const int32_t*)S->U.d_bi,
                        (const cplx*)(F->d_vals + oUb), (const cplx*)(F->d_vals + oD), (const int64_t*)S->U.d_ip, F->d_ixU);
     LAUNCHCHK();
-    if (F->apex_la > 0 && (rc = ml_build_apex(F, bst))) return rc;
-    HIPCHK(hipEventRecord(F->ready, bst));
-    F->synced_valid = false;
+    if ((rc = ml_finish_numeric(F, bst))) return rc;
     return NEP_OK;
 }
 
@@ -1026,6 +1048,7 @@ void ml_destroy(MLFactor* F) {
     // the solves enqueued on F->last may still read these blocks: the pool hands them out again only behind that work
     hipStream_t st = F->used ? F->last : nullptr;
     if (F->ready) { (void)hipEventSynchronize(F->ready); (void)hipEventDestroy(F->ready); }   // numeric build done (cheap: long past)
+    if (F->apex_ev) { (void)hipEventSynchronize(F->apex_ev); (void)hipEventDestroy(F->apex_ev); }
     nep_pool_free_on(F->d_vals, st, F->used); nep_pool_free_on(F->d_ixL, st, F->used); nep_pool_free_on(F->d_ixU, st, F->used);
     nep_pool_free_on(F->d_rscale, st, F->used); nep_pool_free_on(F->d_Sinv, st, F->used);
     if (F->work.dptr) { nep_pool_free_on(F->work.dptr, st, F->used); F->work.dptr = nullptr; F->work.cap = 0; }
@@ -1289,10 +1312,10 @@ static int run_apex(const MLSolveCtx& c, hipStream_t st, int* launches) {
 // everything between the first (L level 0) and the last (U level 0) launch: fixed buffers only -> one hipGraph
 static int ml_middle(const MLSolveCtx& c, hipStream_t st, int* launches) {
     const MLSym* S = c.F->sym;
-    const int top = c.F->apex_la > 0 ? c.F->apex_la : S->nlev;      // levels [top, nlev) are handled by the apex
+    const int top = eff_apex(c.F) > 0 ? eff_apex(c.F) : S->nlev;      // levels [top, nlev) are handled by the apex
     int rc;
     for (int l = 1; l < top; ++l) if ((rc = run_L(c, l, false, st, launches))) return rc;
-    if (c.F->apex_la > 0 && (rc = run_apex(c, st, launches))) return rc;
+    if (eff_apex(c.F) > 0 && (rc = run_apex(c, st, launches))) return rc;
     for (int l = top - 1; l >= 1; --l) {
         if ((rc = run_U_coupling(c, l, st, launches))) return rc;
         if ((rc = run_U_level(c, l, false, st, launches))) return rc;
@@ -1301,10 +1324,10 @@ static int ml_middle(const MLSolveCtx& c, hipStream_t st, int* launches) {
 }
 static int ml_middle_count(const MLFactor* F) {
     const MLSym* S = F->sym;
-    const int top = F->apex_la > 0 ? F->apex_la : S->nlev;
+    const int top = eff_apex(F) > 0 ? eff_apex(F) : S->nlev;
     int nmid = 0;
     for (int l = 1; l < top; ++l) nmid += 2 + S->L.split[l] + S->U.split[l];
-    if (F->apex_la > 0) nmid += 2;
+    if (eff_apex(F) > 0) nmid += 2;
     return nmid + S->U.split[0];
 }
 
@@ -1366,6 +1389,11 @@ int ml_solve(MLFactor* F, int nrhs, const nep_cdouble* dB, int64_t ldb, const ne
         HIPCHK(hipEventRecord(ev, F->last)); HIPCHK(hipStreamWaitEvent(st, ev, 0)); (void)hipEventDestroy(ev);
     }
     if (!F->synced_valid || F->synced != st) { HIPCHK(hipStreamWaitEvent(st, F->ready, 0)); F->synced = st; F->synced_valid = true; }
+    if (F->apex_la > 0 && !F->apex_live && F->apex_ev && hipEventQuery(F->apex_ev) == hipSuccess) {
+        HIPCHK(hipStreamWaitEvent(st, F->apex_ev, 0));             // complete already: orders st behind the build stream formally
+        F->apex_live = true;
+        if (F->graph) { (void)hipGraphExecDestroy(F->graph); F->graph = nullptr; }
+    } else if (F->apex_la > 0 && !F->apex_live) (void)hipGetLastError();     // hipErrorNotReady of the query
     int rc;
     const size_t need = (size_t)4 * n * nrhs * sizeof(cplx);
     if (F->work.cap < need) {          // the old block may still be in use by solves in flight on F->last
@@ -1418,7 +1446,7 @@ int ml_solve(MLFactor* F, int nrhs, const nep_cdouble* dB, int64_t ldb, const ne
     if ((rc = run_L(c, 0, true, st, &launches))) return rc;
     const int nmid = ml_middle_count(F);
     bool graphed = false;
-    if (F->use_graph && nmid >= 4 && !getenv("NEP_NO_GRAPH")) {
+    if (F->use_graph && nmid >= 4 && (F->apex_la == 0 || F->apex_live) && !getenv("NEP_NO_GRAPH")) {   // no capture for the few solves before the apex
         if (!F->graph || F->graph_nrhs != nrhs || F->graph_work != F->work.dptr) {
             if (F->graph) { (void)hipGraphExecDestroy(F->graph); F->graph = nullptr; }
             if (!F->cap_stream) HIPCHK(hipStreamCreateWithFlags(&F->cap_stream, hipStreamNonBlocking));

@@ -131,14 +131,15 @@ class _DeviceRefactor:
 
     @classmethod
     def enabled(cls):
-        return os.environ.get("NEP_LU_DEV", "1") != "0"
+        return os.environ.get("NEP_LU_DEV", "1") != "0" and os.environ.get("NEP_LU_SCHED") != "old"
 
     @classmethod
     def key(cls, Ac, opts):
         import hashlib
         h = hashlib.blake2b(digest_size=16)
         h.update(np.ascontiguousarray(Ac.indptr)); h.update(np.ascontiguousarray(Ac.indices))
-        return (h.digest(), Ac.shape, opts)
+        knobs = tuple(os.environ.get(k) for k in ("NEP_ML_BMAX", "NEP_ML_SPLIT", "NEP_ML_CHUNK"))   # they change the partition
+        return (h.digest(), Ac.shape, opts, knobs)
 
     @classmethod
     def lookup(cls, key):
@@ -449,6 +450,12 @@ class FactorizeLinSolver(LinSolver):
         w_prev = np.inf; ret = None
         for step in range(umf + 1):
             if step > plan:
+                # the rule would go on.  At the noise level of omega itself (its own evaluation carries a few eps of
+                # round-off: 4.49e-16 observed on gun against the 4.44e-16 threshold) a further sweep cannot improve the
+                # iterate -- accepted; anything larger is a miss
+                if np.isfinite(w[plan]) and w[plan] <= 4.0 * EPS:
+                    ret = plan
+                    break
                 return False
             omega = w[step]
             if omega <= 2.0 * EPS:
@@ -462,7 +469,10 @@ class FactorizeLinSolver(LinSolver):
                 break
             w_prev = omega
         self.last_omega = w[plan]
-        self._recorded_plan = ret
+        # never plan fewer than one sweep: the accuracy of the raw solve changes within a run when the dense apex of the
+        # block schedule comes on line (trsv_ml.hip: built behind the first solves), and a plan of 0 learnt before would
+        # turn the first solve after it into a miss (a full re-run of the call)
+        self._recorded_plan = max(ret, 1)
         if not np.isfinite(w[plan]):
             return False
         return ret == plan or w[plan] <= max(4.0 * EPS, w[ret])

@@ -420,9 +420,10 @@ def test_recorded_refinement_rule_replay():
     assert s.review_recorded(np.array([1e-13, 1e-16, 5e-17, 0.0]), 2)     # rule stops after 1 sweep, x_2 is as good
     assert s._recorded_plan == 1 and s.blind_plan_recorded() == 1
     assert s.review_recorded(np.array([1e-13, 1e-16, 0.0, 0.0]), 1)       # exactly what the rule does
-    assert s.review_recorded(np.array([1e-17, 0.0, 0.0, 0.0]), 0) and s._recorded_plan == 0
+    assert s.review_recorded(np.array([1e-17, 0.0, 0.0, 0.0]), 0) and s._recorded_plan == 1   # never below one sweep
     assert not s.review_recorded(np.array([1e-13, 0.0, 0.0, 0.0]), 0)     # omega_0 > 2 eps and no sweep taken: miss
     assert not s.review_recorded(np.array([1e-9, 1e-12, 0.0, 0.0]), 1)    # still halving after the sweeps taken: miss
+    assert s.review_recorded(np.array([9.4e-11, 4.4885e-16, 0.0, 0.0]), 1)  # ... unless the kept iterate sits at the noise level of omega
     assert s.review_recorded(np.array([1e-13, 8e-14, 0.0, 0.0]), 1)       # stagnation (> half): the rule stops there too
     assert not s.review_recorded(np.array([1e-13, 5e-13, 0.0, 0.0]), 1)   # the sweep made it worse: rule takes it back
     assert s.review_recorded(np.array([3e-16, 3.5e-16, 0.0, 0.0]), 1) == (3.5e-16 <= 4 * eps)   # ... unless at noise level
