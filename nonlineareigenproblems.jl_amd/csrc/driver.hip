@@ -51,8 +51,11 @@ int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdo
         void* p = nullptr;
         if (nep_pool_alloc(&p, (size_t)mt * 24 + 64)) { delete s; return NEP_ERR_HIP; }
         s->d_cabs = (double*)p; s->d_ccf = (cplx*)((char*)p + (((size_t)mt * 8 + 15) & ~(size_t)15));
-        HIPCHK(hipMemcpy(s->d_cabs, h_cabs, (size_t)mt * 8, hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(s->d_ccf, h_cf, (size_t)mt * 16, hipMemcpyHostToDevice));
+        // asynchronous (pinned staging): a synchronous copy would queue behind the factorisation's build kernels
+        static thread_local PinnedRing ring;
+        int rcu = ring.upload(s->d_cabs, h_cabs, (size_t)mt * 8, nullptr);
+        if (!rcu) rcu = ring.upload(s->d_ccf, h_cf, (size_t)mt * 16, nullptr);
+        if (rcu) { nep_pool_free(p); delete s; return rcu; }
     }
     s->dH = (cplx*)dH; s->hH = h_pinnedH; s->method = orth_method;
     s->ev.assign(m + 1, nullptr);

@@ -15,8 +15,12 @@ void nep_set_error(const char* fmt, ...) {
 
 int NepScratch::ensure(size_t bytes) {
     if (bytes <= cap) return NEP_OK;
-    if (dptr) { nep_pool_free(dptr); dptr = nullptr; cap = 0; }
-    size_t want = bytes + bytes / 4 + 4096;
+    // Growing hands the old block back to the shared pool.  Kernels that were ENQUEUED with it may not have run yet, and the
+    // pool serves other streams and host threads (iar's convergence checks run on their own stream next to a recurrence that
+    // is enqueued tens of milliseconds ahead of the device): wait for the device before the block can change hands.  Rare
+    // by construction: capacities start at 4 MiB and double.
+    if (dptr) { (void)hipDeviceSynchronize(); nep_pool_free(dptr); dptr = nullptr; cap = 0; }
+    size_t want = std::max<size_t>(2 * bytes, (size_t)4 << 20);
     int rc = nep_pool_alloc(&dptr, want);
     if (rc) return rc;
     cap = want;

@@ -74,12 +74,8 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     V = torch.zeros((m + 1, ldv), dtype=CDT, device="cuda")     # the fill overlaps with the host factorisation below
     H = np.zeros((m + 1, m), dtype=np.complex128)
     alpha = gamma ** np.arange(m + 1); alpha[0] = 0
-    t_ls = time.perf_counter()
-    M0inv = create_linsolver(linsolvercreator, nep, sigma)
-    sync(); tm["linsolver_setup"] = tm.get("linsolver_setup", 0.0) + time.perf_counter() - t_ls
-    t_setup_done = time.perf_counter()
-    if timers is not None and hasattr(M0inv, "lu"):
-        tm["host_factorization"] = tm.get("host_factorization", 0.0) + M0inv.lu.t_factor
+    # the synchronous little uploads below come BEFORE the linear solver: once the device is busy with the factorisation and
+    # the apex build behind it, each of them waits for a slot between 300-600 us kernels (5 ms of host time for the lot)
     v0 = np.asarray(v, dtype=np.complex128)
     V[0, :n] = torch.from_numpy(v0 / np.linalg.norm(v0)).to("cuda")
     # derivative table at sigma (DerSPMF, NEPTypes.jl:1108-1128).  The coefficient rows
@@ -107,6 +103,12 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
         Hnp = Hpin.numpy()
         evs = [None] * (m + 1)
         filled = [False] * (m + 1)
+    t_ls = time.perf_counter()
+    M0inv = create_linsolver(linsolvercreator, nep, sigma)
+    sync(); tm["linsolver_setup"] = tm.get("linsolver_setup", 0.0) + time.perf_counter() - t_ls
+    t_setup_done = time.perf_counter()
+    if timers is not None and hasattr(M0inv, "lu"):
+        tm["host_factorization"] = tm.get("host_factorization", 0.0) + M0inv.lu.t_factor
     # native step (csrc/driver.hip nep_iar_step): K1 -> K5 (+ refinement) -> shift -> K6 -> H row to pinned memory as
     # ONE foreign call per Arnoldi step.  Needs a pure SPMF operator and a device LU.  The refinement criterion is never
     # read back inside a step: the step records omega of every iterate behind the H row and fill_H replays UMFPACK's
@@ -142,7 +144,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     from ._affinity import cpu_budget
     # host eig of up to LAG+1 consecutive steps in flight: as many workers as the CPU budget of this rank allows (measured on
     # gun, 16-CPU budget: LAG 3 -> 86 ms per run, 5 -> 75, 9 -> 72, 15 -> 73)
-    LAG = int(os.environ.get("NEP_IAR_LAG", str(max(1, min(9, cpu_budget() - 2)))))
+    LAG = int(os.environ.get("NEP_IAR_LAG", str(max(1, min(12, cpu_budget() - 3)))))
     pool = ThreadPoolExecutor(max_workers=LAG + 1)
     state = {"lam": lam, "QT": QT, "idx": idx, "conv_eig": 0, "k_checked": 0}
 
@@ -263,7 +265,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     # Only with the native step: there this thread touches none of the scratch the checks use (csrc/spmv.hip: coef / part /
     # ring belong to the residual batch, cwpart / cwring to the refinement inside the step).
     check_thread = cstep is not None and not os.environ.get("NEP_IAR_ONE_STREAM") and hasattr(errmeasure, "batch_async")
-    check_stream = torch.cuda.Stream() if check_thread else None
+    check_stream = torch.cuda.Stream() if (check_thread and not os.environ.get("NEP_IAR_CHECK_MAIN_STREAM")) else None
 
     def launch_check(kc, fut):
         """eigen-decomposition of step kc is available: enqueue Ritz block (K7) + residual batch (K2), no waiting"""
@@ -305,7 +307,11 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
             # `slots` bounds how far the recurrence runs ahead of the checks (LAG + 1 decompositions in flight, as before).
             import queue, threading
             todo = queue.Queue(); failure = []
-            slots = threading.Semaphore(LAG + 1)
+            # neigs = Inf: the iteration always runs to maxit, nothing the recurrence does ahead of the checks can be wasted,
+            # so it is not throttled at all (the eigen-decompositions of the last steps -- half of all eig time -- then
+            # queue up behind the device instead of pacing it)
+            unthrottled = np.isinf(neigs) and not os.environ.get("NEP_IAR_THROTTLE")
+            slots = threading.Semaphore(m + 1 if unthrottled else LAG + 1)
 
             def checker():
                 inflight = deque()
@@ -338,6 +344,8 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
             th.start()
             try:
                 BATCH = max(1, min(4, LAG // 2))
+                if unthrottled:
+                    BATCH = int(os.environ.get("NEP_IAR_BATCH", "8"))
                 while k <= m and state["conv_eig"] < neigs and not failure:
                     # as many steps as there are free check slots (at most BATCH) go to the device in ONE foreign call: the
                     # interpreter lock is released for all of it and re-acquired once (with one call per step this thread
