@@ -218,3 +218,26 @@ def test_c5_wep_tiar_m60_fullsize(na):
     assert len(lt) >= 6 and max(rest) < 1e-8
     for l in lam:
         assert np.min(abs(np.asarray(lt) - l)) < 0.25, (l, lt)
+
+
+def test_c2_repeated_runs_are_stable(na):
+    """config C2 ten times in a row (host LU for the first call, device numeric LU once the pattern's plan exists, checks on
+    their own stream next to a recurrence that runs far ahead of the device): every run returns the same eigenpairs.  Guards
+    the cross-stream buffer hazards this pipeline is exposed to (a scratch block changing hands while kernels enqueued with it
+    were pending produced orthogonalisation 'breakdowns' in 2-6 of 8 runs before it was fixed)."""
+    from nep_amd.linsolvers import _DeviceRefactor
+    nep = na.nep_gallery("gun_spmf_scaled")
+    ref = None
+    used_device_lu = 0
+    for rep in range(10):
+        creator = na.FactorizeLinSolverCreator(max_factorizations=0)
+        lam, Q, _ = na.iar(nep, sigma=0.0, gamma=1.0, maxit=100, neigs=np.inf, v=np.ones(nep.n), tol=1e-10, linsolvercreator=creator)
+        if rep == 0:
+            _DeviceRefactor.wait()
+            ref = np.sort_complex(lam)
+            assert len(ref) >= 40
+        else:
+            assert len(lam) == len(ref)
+            assert np.abs(np.sort_complex(lam) - ref).max() <= 1e-9 * np.abs(ref).max()
+    plans = [p for p in _DeviceRefactor.plans.values() if p["state"] == "ready"]
+    assert plans and sum(p["uses"] for p in plans) >= 8        # the later runs were factorised on the device
