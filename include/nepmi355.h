@@ -367,6 +367,10 @@ int32_t nep_lu_refac_destroy(nep_lu_refac* r);
 int32_t nep_lu_refac_info(const nep_lu_refac* r, int64_t out[6]);
 int32_t nep_lu_factor_dev(nep_lu_refac* r, const nep_cdouble* h_Ax, int32_t expected_solves, double growth_limit,
                           double* h_health, nep_cdouble* h_LUx_out, nep_lu** out, nep_stream stream);
+/* B matrices of the plan's pattern in one pass (every launch carries all of them): h_Ax B x nnz(A), h_health B x 3 (required),
+ * out[b] = NULL for a matrix whose factorisation was refused -- factorise that one on the host. */
+int32_t nep_lu_factor_dev_batch(nep_lu_refac* r, int32_t B, const nep_cdouble* h_Ax, int32_t expected_solves, double growth_limit,
+                                double* h_health, nep_cdouble* h_LUx_out, nep_lu** out, nep_stream stream);
 
 /* ---- one infinite-Arnoldi step as one call ------------------------------------------------------
  * replaces: the loop body of iar between two eigenvalue checks, src/method_iar.jl:94-109

@@ -21,7 +21,7 @@ import torch.distributed as dist
 
 from . import dense
 from .errmeasure import DefaultErrmeasure, estimate_errors
-from .linsolvers import BackslashLinSolverCreator, DeviceLU, HostLUPool, create_linsolver, lin_solve
+from .linsolvers import BackslashLinSolverCreator, DeviceLU, HostLUPool, create_linsolver, lin_solve, _DeviceRefactor
 from .nep import CDT, to_dev, to_host
 
 EPS = np.finfo(float).eps
@@ -143,8 +143,33 @@ class _NodeSolve:
         if trace:
             import time as _t
             self._t0 = _t.perf_counter(); self._host_done = []; self._host_meta = []
+        # ---- all nodes on the GPU in one pass when the pattern has a device-factorisation plan (linsolvers._DeviceRefactor):
+        # one B x m_t by m_t x nnz product for the values, one batched numeric LU (every launch carries all nodes); nodes
+        # whose factorisation is refused with the stored pivot sequence take the host path below
+        self.ready = {}
+        ts_host = list(ts)
+        if (_DeviceRefactor.enabled() and hasattr(self.nep, "compute_Mder_batch") and c.permc_spec is None and not c.lu_kw
+                and not os.environ.get("NEP_BEYN_HOST_LU")):
+            mb = self.nep.compute_Mder_batch([self.g(t) + self.sigma for t in ts])
+            if mb is not None:
+                import scipy.sparse as sp_
+                indptr, indices, vals = mb
+                A0 = sp_.csc_matrix((vals[0], indices, indptr), shape=(self.nep.n, self.nep.n))
+                plan = _DeviceRefactor.lookup(_DeviceRefactor.key(A0, (None, None, None)))
+                if plan is not None:
+                    lus = _DeviceRefactor.factor_batch(plan, self.nep.n, vals, expected_solves=1)
+                    ts_host = []
+                    for t, lu in zip(ts, lus):
+                        if lu is None:
+                            ts_host.append(t)
+                        else:
+                            self.ready[t] = lu
+                    if trace:
+                        print("[beyn trace] %d of %d nodes factorised on the device (batched) at %.0f ms" %
+                              (len(self.ready), len(ts), 1e3 * (_t.perf_counter() - self._t0)), flush=True)
+        self.order = list(ts_host)
         strat = None
-        for t in ts:
+        for t in ts_host:
             A = self.nep.compute_Mder(self.g(t) + self.sigma)
             if strat is None:
                 # UMFPACK-like strategy (symmetric pattern + zero-free diagonal?) decided ONCE: all nodes share one pattern
@@ -189,6 +214,12 @@ class _NodeSolve:
             self.built.clear(); self.host.clear()
 
     def __call__(self, t):
+        if t in getattr(self, "ready", {}):
+            lu = self.ready.pop(t)
+            X = lu.solve(self.Vd)
+            if not self.ready and not self.built and self.next >= len(self.order):
+                self.close()
+            return X, self.weight(t)
         if t in self.built:
             try:
                 lu = self.built.pop(t).result()

@@ -65,8 +65,10 @@ struct nep_lu_refac {
 };
 
 // ---- kernels ---------------------------------------------------------------------------------------------------------------
+// (all kernels: blockIdx.y = matrix of a batch; the matrices share the plan and sit nF / nnzA / 3 entries apart)
 __global__ void k_lu_init(int64_t nF, int64_t n, int64_t nnzA, const int32_t* __restrict__ amap, const cplx* __restrict__ Ax,
                           const int32_t* __restrict__ ldiag, cplx* __restrict__ F, double* __restrict__ health) {
+    F += (int64_t)blockIdx.y * nF; Ax += (int64_t)blockIdx.y * nnzA; health += 3 * (int64_t)blockIdx.y;
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     // F was zeroed by a memset; scatter A, unit diagonal of L
     if (i < nnzA) F[amap[i]] = Ax[i];
@@ -77,7 +79,8 @@ __global__ void k_lu_init(int64_t nF, int64_t n, int64_t nnzA, const int32_t* __
 // one thread per destination entry of the level: F[dst] -= sum_products L * U   (sources final: lower levels are done)
 __global__ __launch_bounds__(256) void k_lu_ext(int64_t seg0, int64_t seg1, const int64_t* __restrict__ ptr,
                                                 const int32_t* __restrict__ dst, const int32_t* __restrict__ src,
-                                                cplx* __restrict__ F) {
+                                                cplx* __restrict__ F, int64_t nF) {
+    F += (int64_t)blockIdx.y * nF;
     const int64_t sidx = seg0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (sidx >= seg1) return;
     const int64_t p0 = ptr[sidx], p1 = ptr[sidx + 1];
@@ -91,7 +94,8 @@ __device__ __forceinline__ cplx lu_cdiv(cplx a, cplx b);
 
 // wide level, one pivot step: F[dst] -= (F[gL] / pivot) * F[gU], one product per thread (distinct destinations within a pivot;
 // the column of L stays unscaled until k_lu_scale at the end of the level)
-__global__ __launch_bounds__(256) void k_lu_wide(int64_t t0, int64_t t1, const int4* __restrict__ prod, cplx* __restrict__ F) {
+__global__ __launch_bounds__(256) void k_lu_wide(int64_t t0, int64_t t1, const int4* __restrict__ prod, cplx* __restrict__ F, int64_t nF) {
+    F += (int64_t)blockIdx.y * nF;
     const int64_t t = t0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (t >= t1) return;
     const int4 q = prod[t];
@@ -105,7 +109,8 @@ __global__ __launch_bounds__(256) void k_lu_wide(int64_t t0, int64_t t1, const i
 // end of a wide level: divide the columns of L of the level's pivots (schedule positions [q0, q1)), one wave per pivot
 __global__ __launch_bounds__(256) void k_lu_scale(int q0, int q1, const int32_t* __restrict__ oldof, const int32_t* __restrict__ Lp,
                                                   const int32_t* __restrict__ Li, const int32_t* __restrict__ udiag,
-                                                  cplx* __restrict__ F, double* __restrict__ health) {
+                                                  cplx* __restrict__ F, double* __restrict__ health, int64_t nF) {
+    F += (int64_t)blockIdx.y * nF; health += 3 * (int64_t)blockIdx.y;
     const int q = q0 + blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= q1) return;
@@ -137,7 +142,9 @@ __device__ __forceinline__ cplx lu_cdiv(cplx a, cplx b) {
 __global__ __launch_bounds__(512) void k_lu_int(int blk0, const int32_t* __restrict__ blk_se, const int32_t* __restrict__ oldof,
                                                 const int32_t* __restrict__ Lp, const int32_t* __restrict__ Li,
                                                 const int32_t* __restrict__ udiag, const int64_t* __restrict__ piv_ptr,
-                                                const int32_t* __restrict__ tri, cplx* __restrict__ F, double* __restrict__ health) {
+                                                const int32_t* __restrict__ tri, cplx* __restrict__ F, double* __restrict__ health,
+                                                int64_t nF) {
+    F += (int64_t)blockIdx.y * nF; health += 3 * (int64_t)blockIdx.y;
     const int b = blk0 + blockIdx.x;
     const int q0 = blk_se[2 * b], q1 = blk_se[2 * b + 1];
     double minpiv = 1.0e300, maxabs = 0.0;
@@ -414,6 +421,9 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
     return NEP_OK;
 }
 
+int32_t nep_lu_factor_dev_batch(nep_lu_refac* r, int32_t B, const nep_cdouble* h_Ax, int32_t expected_solves, double growth_limit,
+                                double* h_health, nep_cdouble* h_LUx_out, nep_lu** out, nep_stream stream);
+
 int32_t nep_lu_refac_info(const nep_lu_refac* r, int64_t out[6]) {
     ARGCHK(r && out);
     out[0] = r->n; out[1] = r->nprod; out[2] = r->nint; out[3] = r->next_; out[4] = r->nseg; out[5] = (int64_t)r->t_symbolic_ms;
@@ -422,34 +432,58 @@ int32_t nep_lu_refac_info(const nep_lu_refac* r, int64_t out[6]) {
 
 // h_Ax: the nnzA values of the new matrix in the CSC order of (Ap, Ai).  h_health[3] (may be NULL): [0] = 1 when a pivot was
 // zero or non-finite, [1] = largest |Re| + |Im| over the entries of L (element growth; 1-ish for a diagonally pivoted factor).
-// d_LUx_out (may be NULL): receives nnzL + nnzU values (L then U, input entry order) -- tests compare them with the host factor.
+// h_LUx_out (may be NULL): receives nnzL + nnzU values (L then U, input entry order) -- tests compare them with the host factor.
 // NEP_ERR_SINGULAR when a pivot broke down (nothing is returned then).
 int32_t nep_lu_factor_dev(nep_lu_refac* r, const nep_cdouble* h_Ax, int32_t expected_solves, double growth_limit,
                           double* h_health, nep_cdouble* h_LUx_out, nep_lu** out, nep_stream stream) {
     ARGCHK(r && h_Ax && out);
     *out = nullptr;
+    double hh[3] = {0.0, 0.0, 0.0};
+    int32_t rc = nep_lu_factor_dev_batch(r, 1, h_Ax, expected_solves, growth_limit, hh, h_LUx_out, out, stream);
+    if (h_health) { h_health[0] = hh[0]; h_health[1] = hh[1]; h_health[2] = hh[2]; }
+    if (rc) return rc;
+    if (!*out) {
+        nep_set_error("device refactorisation: pivot breakdown or element growth %.3g above %.3g with the stored pivot sequence", hh[1], growth_limit);
+        return NEP_ERR_SINGULAR;
+    }
+    return NEP_OK;
+}
+
+// B matrices of the plan's pattern in ONE pass (the quadrature nodes of contour_beyn, src/method_beyncontour.jl:89-94): every
+// launch of the factorisation carries all B matrices, so the 64 nodes of config C4 cost about as many launches as one.
+// h_Ax: B x nnzA values; h_health: B x 3 (required); out[b] = NULL for a matrix whose factorisation was refused (pivot
+// breakdown / growth): the caller factorises that one on the host.  h_LUx_out (may be NULL): B x (nnzL + nnzU).
+int32_t nep_lu_factor_dev_batch(nep_lu_refac* r, int32_t B, const nep_cdouble* h_Ax, int32_t expected_solves, double growth_limit,
+                                double* h_health, nep_cdouble* h_LUx_out, nep_lu** out, nep_stream stream) {
+    ARGCHK(r && h_Ax && out && h_health && B >= 1);
+    for (int b = 0; b < B; ++b) out[b] = nullptr;
     hipStream_t st = as_stream(stream);
     const int64_t nF = r->nnzL + r->nnzU;
     cplx* dF = nullptr; cplx* dA = nullptr; double* dH = nullptr;
     int rc;
-    if ((rc = nep_pool_alloc((void**)&dF, (size_t)nF * sizeof(cplx) + 64))) return rc;
-    if ((rc = nep_pool_alloc((void**)&dA, (size_t)r->nnzA * sizeof(cplx) + 64))) { nep_pool_free(dF); return rc; }
-    dH = (double*)((char*)dF + (size_t)nF * sizeof(cplx));
+    if ((rc = nep_pool_alloc((void**)&dF, (size_t)B * nF * sizeof(cplx) + (size_t)B * 24 + 64))) return rc;
+    if ((rc = nep_pool_alloc((void**)&dA, (size_t)B * r->nnzA * sizeof(cplx) + 64))) { nep_pool_free(dF); return rc; }
+    dH = (double*)((char*)dF + (size_t)B * nF * sizeof(cplx));
     auto fail = [&](int code) { nep_pool_free_on(dF, st, true); nep_pool_free_on(dA, st, true); return code; };
     static thread_local PinnedRing ring;
-    if ((rc = ring.upload(dA, h_Ax, (size_t)r->nnzA * sizeof(cplx), st))) return fail(rc);
-    HIPCHK(hipMemsetAsync(dF, 0, (size_t)nF * sizeof(cplx), st));
+    {   // in pieces of at most 8 MiB: the ring's pinned slots stay small (a 90 MB slot for 64 nodes costs ~30 ms to pin)
+        const size_t total = (size_t)B * r->nnzA * sizeof(cplx), piece = (size_t)8 << 20;
+        for (size_t off = 0; off < total; off += piece)
+            if ((rc = ring.upload((char*)dA + off, (const char*)h_Ax + off, std::min(piece, total - off), st))) return fail(rc);
+    }
+    HIPCHK(hipMemsetAsync(dF, 0, (size_t)B * nF * sizeof(cplx), st));
+    const unsigned gy = (unsigned)B;
     {
         const int64_t m = std::max<int64_t>(r->nnzA, r->n);
-        hipLaunchKernelGGL(k_lu_init, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, st, nF, r->n, r->nnzA, (const int32_t*)r->d_amap,
+        hipLaunchKernelGGL(k_lu_init, dim3((unsigned)((m + 255) / 256), gy), dim3(256), 0, st, nF, r->n, r->nnzA, (const int32_t*)r->d_amap,
                            (const cplx*)dA, (const int32_t*)r->d_ldiag, dF, dH);
         LAUNCHCHK();
     }
     for (int l = 0; l < r->nlev; ++l) {
         const int64_t s0 = r->ext_seg0[l], s1 = r->ext_seg0[l + 1];
         if (s1 > s0) {
-            hipLaunchKernelGGL(k_lu_ext, dim3((unsigned)((s1 - s0 + 255) / 256)), dim3(256), 0, st, s0, s1, (const int64_t*)r->d_ext_ptr,
-                               (const int32_t*)r->d_ext_dst, (const int32_t*)r->d_ext_src, dF);
+            hipLaunchKernelGGL(k_lu_ext, dim3((unsigned)((s1 - s0 + 255) / 256), gy), dim3(256), 0, st, s0, s1, (const int64_t*)r->d_ext_ptr,
+                               (const int32_t*)r->d_ext_dst, (const int32_t*)r->d_ext_src, dF, nF);
             LAUNCHCHK();
         }
         const int b0 = r->lev_blk[l], b1 = r->lev_blk[l + 1];
@@ -458,43 +492,40 @@ int32_t nep_lu_factor_dev(nep_lu_refac* r, const nep_cdouble* h_Ax, int32_t expe
             for (int64_t sidx = r->wstep0[l]; sidx < r->wstep0[l + 1]; ++sidx) {
                 const int64_t t0 = r->wide_ptr[sidx], t1 = r->wide_ptr[sidx + 1];
                 if (t1 <= t0) continue;
-                hipLaunchKernelGGL(k_lu_wide, dim3((unsigned)((t1 - t0 + 255) / 256)), dim3(256), 0, st, t0, t1, (const int4*)r->d_wide, dF);
+                hipLaunchKernelGGL(k_lu_wide, dim3((unsigned)((t1 - t0 + 255) / 256), gy), dim3(256), 0, st, t0, t1, (const int4*)r->d_wide, dF, nF);
             }
             LAUNCHCHK();
             const int q0 = r->h_blk_se[2 * b0], q1 = r->h_blk_se[2 * (b1 - 1) + 1];
-            hipLaunchKernelGGL(k_lu_scale, dim3((unsigned)((q1 - q0 + 3) / 4)), dim3(256), 0, st, q0, q1, (const int32_t*)r->d_oldof,
-                               (const int32_t*)r->d_Lp, (const int32_t*)r->d_Li, (const int32_t*)r->d_udiag, dF, dH);
+            hipLaunchKernelGGL(k_lu_scale, dim3((unsigned)((q1 - q0 + 3) / 4), gy), dim3(256), 0, st, q0, q1, (const int32_t*)r->d_oldof,
+                               (const int32_t*)r->d_Lp, (const int32_t*)r->d_Li, (const int32_t*)r->d_udiag, dF, dH, nF);
             LAUNCHCHK();
         } else {
-            hipLaunchKernelGGL(k_lu_int, dim3((unsigned)(b1 - b0)), dim3(512), 0, st, b0, (const int32_t*)r->d_blk_se,
+            hipLaunchKernelGGL(k_lu_int, dim3((unsigned)(b1 - b0), gy), dim3(512), 0, st, b0, (const int32_t*)r->d_blk_se,
                                (const int32_t*)r->d_oldof, (const int32_t*)r->d_Lp, (const int32_t*)r->d_Li, (const int32_t*)r->d_udiag,
-                               (const int64_t*)r->d_piv_ptr, (const int32_t*)r->d_int, dF, dH);
+                               (const int64_t*)r->d_piv_ptr, (const int32_t*)r->d_int, dF, dH, nF);
             LAUNCHCHK();
         }
     }
-    // health word (and, for tests, the factor values): one read-back behind the factorisation kernels
-    double hh[3] = {0.0, 0.0, 0.0};
-    HIPCHK(hipMemcpyAsync(hh, dH, sizeof(hh), hipMemcpyDeviceToHost, st));
-    if (h_LUx_out) HIPCHK(hipMemcpyAsync(h_LUx_out, dF, (size_t)nF * sizeof(cplx), hipMemcpyDeviceToHost, st));
+    // health words (and, for tests, the factor values): one read-back behind the factorisation kernels
+    HIPCHK(hipMemcpyAsync(h_health, dH, (size_t)B * 24, hipMemcpyDeviceToHost, st));
+    if (h_LUx_out) HIPCHK(hipMemcpyAsync(h_LUx_out, dF, (size_t)B * nF * sizeof(cplx), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (h_health) { h_health[0] = hh[0]; h_health[1] = hh[1]; h_health[2] = hh[2]; }
-    if (hh[0] != 0.0 || !(hh[1] <= growth_limit)) {
-        nep_set_error("device refactorisation: pivot breakdown or element growth %.3g above %.3g with the stored pivot sequence", hh[1], growth_limit);
-        return fail(NEP_ERR_SINGULAR);
-    }
-    MLFactor* F = nullptr;
-    rc = ml_create_from_sym(r->S, (const nep_cdouble*)dF, (const nep_cdouble*)(dF + r->nnzL), st, expected_solves, &F);
-    // dF / dA are read by the gather kernels on the build stream: that stream waited for `st`, and the pool orders the next
-    // user of the blocks behind an event on it -- free behind the factor's `ready` event by waiting on the host side is not
-    // needed because ml_numeric_dev's gathers are enqueued before this returns; order the frees behind the build stream
-    if (rc) return fail(rc);
-    {
-        // the gathers run on a build stream; make `st` wait for the factor's ready event so that frees ordered on st are safe
-        // (ml_solve does the same wait before the first solve anyway)
+    for (int b = 0; b < B; ++b) {
+        const double* hh = h_health + 3 * b;
+        if (hh[0] != 0.0 || !(hh[1] <= growth_limit)) continue;        // refused: out[b] stays NULL
+        MLFactor* F = nullptr;
+        const cplx* Fb = dF + (size_t)b * nF;
+        rc = ml_create_from_sym(r->S, (const nep_cdouble*)Fb, (const nep_cdouble*)(Fb + r->nnzL), st, expected_solves, &F);
+        if (rc) {
+            for (int c = 0; c < b; ++c) if (out[c]) { nep_lu_destroy(out[c]); out[c] = nullptr; }
+            return fail(rc);
+        }
+        // the gathers run on a build stream: `st` waits for the factor's ready event so that the frees below, ordered on st,
+        // come after them (ml_solve does the same wait before the first solve anyway)
         (void)ml_wait_ready(F, st);
+        out[b] = nep_lu_wrap_ml(F, r->n, r->nnzL, r->nnzU);
     }
     nep_pool_free_on(dF, st, true); nep_pool_free_on(dA, st, true);
-    *out = nep_lu_wrap_ml(F, r->n, r->nnzL, r->nnzU);
     return NEP_OK;
 }
 

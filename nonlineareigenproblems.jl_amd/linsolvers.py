@@ -186,6 +186,28 @@ class _DeviceRefactor:
         t.start()
 
     @classmethod
+    def factor_batch(cls, plan, n, vals, expected_solves=1):
+        """vals: (B, nnz) values of B matrices of the plan's pattern.  Returns a list of DeviceLU (None where the stored pivot
+        sequence was refused for that matrix -- the caller factorises those on the host)."""
+        B = int(vals.shape[0])
+        vals = np.ascontiguousarray(vals, dtype=np.complex128)
+        health = np.zeros((B, 3))
+        outs = (c_vp * B)()
+        check(lib.nep_lu_set_expected_solves(int(expected_solves)))
+        check(lib.nep_lu_factor_dev_batch(plan["handle"], B, hptr(vals), int(expected_solves), cls.GROWTH, hptr(health), None, outs,
+                                          stream_ptr()))
+        res = []
+        for b in range(B):
+            if not outs[b]:
+                plan["fails"] += 1
+                res.append(None)
+                continue
+            plan["uses"] += 1
+            res.append(DeviceLU._from_handle(c_vp(outs[b]), n, float(np.linalg.norm(vals[b])),
+                                             dict(plan["strategy"], numeric="device (stored pivot sequence, batched)"), float(health[b, 1])))
+        return res
+
+    @classmethod
     def wait(cls):
         """block until every plan under construction is finished (tests, benchmarks)"""
         for p in list(cls.plans.values()):
@@ -263,6 +285,18 @@ class DeviceLU:
         self.t_setup = time.perf_counter() - t0
         if rkey is not None and not shm_backed:
             _DeviceRefactor.maybe_start(rkey, self, F, Ac)
+
+    @classmethod
+    def _from_handle(cls, h, n, normA, strategy, growth):
+        """wrap an nep_lu handle produced by the device-side numeric factorisation"""
+        self = cls.__new__(cls)
+        self.device_factorized = True
+        self.growth = growth
+        self.n = int(n); self.normA = normA; self.strategy = strategy
+        self.t_factor = 0.0; self.t_convert = 0.0; self.t_create = 0.0; self.t_setup = 0.0
+        self.h = h
+        self._describe()
+        return self
 
     def _factor_on_device(self, plan, Ac, expected_solves, t0):
         """numeric factorisation on the GPU with the pattern's stored pivot sequence; False -> the caller takes the host path"""

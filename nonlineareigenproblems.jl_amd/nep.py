@@ -332,6 +332,17 @@ class AbstractSPMF(NEP):
             Z = T if Z is None else Z + T
         return Z
 
+    def compute_Mder_batch(self, lams):
+        """the matrices M(lam_b) of several shifts on the union sparsity pattern: (indptr, indices, values) with values of shape
+        (B, nnz), or None when a term is dense.  One B x m_t by m_t x nnz product instead of B assemblies (contour_beyn)."""
+        al = self._aligned_terms()
+        if al is None:
+            return None
+        indptr, indices, D = al
+        fv = self.get_fv()
+        Cf = np.array([[f.derivs(lam, 1)[0] for f in fv] for lam in lams], dtype=np.complex128)      # B x m_t
+        return indptr, indices, np.ascontiguousarray(np.einsum("ij,bj->bi", D, Cf))
+
     def _aligned_terms(self):
         """(indptr, indices, D) with D[:, t] = values of A_t scattered onto the union CSC pattern of all terms, or None if a
         term is dense"""
