@@ -24,6 +24,7 @@
 #include <vector>
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cstring>
 #include <math.h>
 
@@ -281,6 +282,7 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
             return NEP_ERR_UNSUPPORTED;
         }
     }
+    const double t_cols = now_ms();
     // ---- A -> F
     std::vector<int32_t> amap((size_t)r->nnzA);
     for (int64_t c = 0; c < n; ++c) {
@@ -319,46 +321,101 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
     for (int64_t q = 0; q < n; ++q) newpos[oldof[q]] = (int32_t)q;
     std::vector<std::vector<int32_t>> itri_piv;             // filled per pivot then concatenated in schedule order
     itri_piv.resize(n);
-    std::vector<Ent> Lk;
-    for (int64_t k = 0; k < n; ++k) {
-        // rows i > k of L(:,k), sorted
-        Lk.clear();
-        {
-            const Ent* b = cent.data() + cptr[k]; const Ent* en = cent.data() + cptr[k + 1];
-            const Ent* it = std::upper_bound(b, en, (int32_t)k, [](int32_t v, const Ent& a) { return v < a.row; });
-            for (; it != en; ++it) Lk.push_back(*it);
-        }
-        if (Lk.empty()) continue;
-        std::vector<int32_t>& mine = itri_piv[k];
-        const bool kwide = r->wide[lvl[k]] != 0;
-        std::vector<int32_t>* wl = kwide ? &wprod[(size_t)(r->wstep0[lvl[k]] + (newpos[k] - blk_se[2 * blk[k]]))] : nullptr;
-        for (int64_t ue = urp[k]; ue < urp[k + 1]; ++ue) {
-            const int32_t j = urow[ue].row, gU = urow[ue].g;
-            if (j <= k) continue;
-            // destinations (i, j), i in Lk: merge with the union column j (rows > k)
-            const Ent* b = cent.data() + cptr[j]; const Ent* en = cent.data() + cptr[j + 1];
-            const Ent* it = std::upper_bound(b, en, (int32_t)k, [](int32_t v, const Ent& a) { return v < a.row; });
-            for (const Ent& le : Lk) {
-                while (it != en && it->row < le.row) ++it;
-                if (it == en || it->row != le.row) {
-                    nep_lu_refac_destroy(r);
-                    nep_set_error("refac: the stored pattern is not closed under the elimination (update (%d,%d) from pivot %lld has no slot)", le.row, j, (long long)k);
-                    return NEP_ERR_UNSUPPORTED;
+    const double t_enum0 = now_ms();
+    // the enumeration is independent per pivot: contiguous ranges of k (balanced by their product counts) go to worker
+    // threads with private external / wide lists, which are concatenated in range order afterwards -- the order of the
+    // products of one destination stays ascending in k whatever the thread count (deterministic plan)
+    int nthr = 6;
+    if (const char* e = getenv("NEP_LU_PLAN_THREADS")) nthr = std::max(1, std::min(32, atoi(e)));
+    std::vector<int64_t> kcut(nthr + 1, n);
+    {
+        std::vector<double> w(n + 1, 0.0);
+        for (int64_t k = 0; k < n; ++k)
+            w[k + 1] = w[k] + 1.0 + (double)(Lp[k + 1] - Lp[k] - 1) * (double)(urp[k + 1] - urp[k] - 1);
+        kcut[0] = 0;
+        for (int t = 1; t < nthr; ++t)
+            kcut[t] = std::lower_bound(w.begin(), w.end(), w[n] * t / nthr) - w.begin();
+        for (int t = 1; t <= nthr; ++t) kcut[t] = std::max(kcut[t], kcut[t - 1]);
+        kcut[nthr] = n;
+    }
+    struct Part {
+        std::vector<std::vector<int32_t>> ext;                      // per destination level
+        std::vector<std::pair<int64_t, std::vector<int32_t>>> wide; // (step, products) in the order of first touch
+        int64_t nprod = 0; int err = 0; int32_t ei = 0, ej = 0; int64_t ek = 0;
+    };
+    std::vector<Part> parts(nthr);
+    for (Part& pt : parts) pt.ext.resize(nlev);
+    auto work = [&](int tix) {
+        Part& P = parts[tix];
+        std::vector<Ent> Lk;
+        std::vector<int64_t> widx(wprod.size(), -1);                 // step -> index into P.wide
+        for (int64_t k = kcut[tix]; k < kcut[tix + 1] && !P.err; ++k) {
+            Lk.clear();
+            {
+                const Ent* b = cent.data() + cptr[k]; const Ent* en = cent.data() + cptr[k + 1];
+                const Ent* it = std::upper_bound(b, en, (int32_t)k, [](int32_t v, const Ent& a) { return v < a.row; });
+                for (; it != en; ++it) Lk.push_back(*it);
+            }
+            if (Lk.empty()) continue;
+            std::vector<int32_t>& mine = itri_piv[k];                // one writer per k
+            const bool kwide = r->wide[lvl[k]] != 0;
+            std::vector<int32_t>* wl = nullptr;
+            if (kwide) {
+                const int64_t step = r->wstep0[lvl[k]] + (newpos[k] - blk_se[2 * blk[k]]);
+                if (widx[step] < 0) { widx[step] = (int64_t)P.wide.size(); P.wide.emplace_back(step, std::vector<int32_t>()); }
+                wl = &P.wide[widx[step]].second;
+            }
+            for (int64_t ue = urp[k]; ue < urp[k + 1]; ++ue) {
+                const int32_t j = urow[ue].row, gU = urow[ue].g;
+                if (j <= k) continue;
+                // destinations (i, j), i in Lk: merge with the union column j (rows > k)
+                const Ent* b = cent.data() + cptr[j]; const Ent* en = cent.data() + cptr[j + 1];
+                const Ent* it = std::upper_bound(b, en, (int32_t)k, [](int32_t v, const Ent& a) { return v < a.row; });
+                for (const Ent& le : Lk) {
+                    while (it != en && it->row < le.row) ++it;
+                    if (it == en || it->row != le.row) { P.err = 1; P.ei = le.row; P.ej = j; P.ek = k; break; }
+                    const int32_t p = std::min(le.row, j);
+                    // (pivots of different blocks of a wide level run in the same launch and may share a destination in an
+                    // ancestor block: those products stay "external", summed per destination in fixed order)
+                    if (kwide && blk[p] == blk[k]) { wl->push_back(le.g); wl->push_back(gU); wl->push_back(it->g); wl->push_back(udiag[k]); }
+                    else if (blk[p] == blk[k]) { mine.push_back(le.g); mine.push_back(gU); mine.push_back(it->g); }
+                    else {
+                        if (lvl[p] <= lvl[k]) { P.err = 2; break; }
+                        std::vector<int32_t>& ex = P.ext[lvl[p]];
+                        ex.push_back(it->g); ex.push_back(le.g); ex.push_back(gU);
+                    }
+                    ++P.nprod;
                 }
-                const int32_t p = std::min(le.row, j);
-                // (pivots of different blocks of a wide level run in the same launch and may share a destination in an
-                // ancestor block: those products stay "external", summed per destination in fixed order)
-                if (kwide && blk[p] == blk[k]) { wl->push_back(le.g); wl->push_back(gU); wl->push_back(it->g); wl->push_back(udiag[k]); }
-                else if (blk[p] == blk[k]) { mine.push_back(le.g); mine.push_back(gU); mine.push_back(it->g); }
-                else {
-                    if (lvl[p] <= lvl[k]) { nep_lu_refac_destroy(r); nep_set_error("refac: update crosses blocks of one level"); return NEP_ERR_UNSUPPORTED; }
-                    std::vector<int32_t>& ex = ext[lvl[p]];
-                    ex.push_back(it->g); ex.push_back(le.g); ex.push_back(gU);
-                }
-                ++r->nprod;
+                if (P.err) break;
             }
         }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthr; ++t) th.emplace_back(work, t);
+        work(0);
+        for (std::thread& t : th) t.join();
     }
+    for (int t = 0; t < nthr; ++t) {
+        Part& P = parts[t];
+        if (P.err == 1) {
+            nep_set_error("refac: the stored pattern is not closed under the elimination (update (%d,%d) from pivot %lld has no slot)", P.ei, P.ej, (long long)P.ek);
+            nep_lu_refac_destroy(r);
+            return NEP_ERR_UNSUPPORTED;
+        }
+        if (P.err == 2) { nep_set_error("refac: update crosses blocks of one level"); nep_lu_refac_destroy(r); return NEP_ERR_UNSUPPORTED; }
+        r->nprod += P.nprod;
+        for (int l = 0; l < nlev; ++l) {
+            ext[l].insert(ext[l].end(), P.ext[l].begin(), P.ext[l].end());
+            std::vector<int32_t>().swap(P.ext[l]);
+        }
+        for (auto& ws : P.wide) {
+            std::vector<int32_t>& dstv = wprod[(size_t)ws.first];
+            dstv.insert(dstv.end(), ws.second.begin(), ws.second.end());
+            std::vector<int32_t>().swap(ws.second);
+        }
+    }
+    const double t_enum1 = now_ms();
     // internal products in schedule order
     std::vector<int64_t> piv_ptr(n + 1, 0);
     for (int64_t q = 0; q < n; ++q) piv_ptr[q + 1] = piv_ptr[q] + (int64_t)itri_piv[oldof[q]].size() / 3;
@@ -405,6 +462,7 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
     for (size_t sidx = 0; sidx < wprod.size(); ++sidx)
         if (!wprod[sidx].empty()) memcpy(wflat.data() + 4 * r->wide_ptr[sidx], wprod[sidx].data(), wprod[sidx].size() * sizeof(int32_t));
     { std::vector<std::vector<int32_t>>().swap(wprod); }
+    const double t_group = now_ms();
     // ---- upload
     int rc;
     std::vector<int32_t> vLp(Lp, Lp + n + 1), vLi(Li, Li + nnzL), vold(oldof, oldof + n), vse(blk_se, blk_se + 2 * nblk);
@@ -413,6 +471,9 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
         (rc = upv(&r->d_int, itri)) || (rc = upv(&r->d_ext_ptr, ext_ptr)) || (rc = upv(&r->d_ext_dst, ext_dst)) ||
         (rc = upv(&r->d_ext_src, ext_src)) || (rc = upv(&r->d_wide, wflat))) { nep_lu_refac_destroy(r); return rc; }
     r->t_symbolic_ms = now_ms() - t0;
+    if (getenv("NEP_TIMING"))
+        fprintf(stderr, "[lu_refac] columns %.1f ms, A map + weights %.1f, enumeration %.1f (%d threads), grouping %.1f, upload %.1f\n",
+                t_cols - t0, t_enum0 - t_cols, t_enum1 - t_enum0, nthr, t_group - t_enum1, now_ms() - t_group);
     if (getenv("NEP_TIMING"))
         fprintf(stderr, "[lu_refac] n=%lld products %lld (internal %lld, external %lld in %lld segments, wide %lld in %lld steps), symbolic %.1f ms\n",
                 (long long)n, (long long)r->nprod, (long long)r->nint, (long long)r->next_, (long long)r->nseg, (long long)r->nwide,
