@@ -312,19 +312,18 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
         if (r->wide[l]) for (int b = lev_blk[l]; b < lev_blk[l + 1]; ++b) mx = std::max(mx, blk_se[2 * b + 1] - blk_se[2 * b]);
         r->wstep0[l + 1] = r->wstep0[l] + mx;
     }
-    std::vector<std::vector<int32_t>> wprod((size_t)r->wstep0[nlev]);     // per step: gL, gU, gdst, gpiv
-    // ---- enumerate the products
-    std::vector<int32_t> itri;                              // internal: gL, gU, gdst, in ascending k
-    std::vector<int64_t> piv_cnt(n + 1, 0);                 // by schedule position of k
-    std::vector<std::vector<int32_t>> ext(nlev);            // per destination level: gdst, gL, gU (ascending k)
+    // ---- enumerate the products: TWO passes over the same merges (count, then place).  Both run on worker threads over
+    // contiguous ranges of k balanced by their product counts; every product has ONE final position that does not depend on the
+    // thread count: internal products in pivot order, wide products by (step, block), external products grouped by
+    // destination with ascending k inside a destination (thread ranges ascend, so per-thread base offsets keep that order).
+    const double t_enum0 = now_ms();
+    const int64_t nF = nnzL + nnzU;
     std::vector<int32_t> newpos(n);
     for (int64_t q = 0; q < n; ++q) newpos[oldof[q]] = (int32_t)q;
-    std::vector<std::vector<int32_t>> itri_piv;             // filled per pivot then concatenated in schedule order
-    itri_piv.resize(n);
-    const double t_enum0 = now_ms();
-    // the enumeration is independent per pivot: contiguous ranges of k (balanced by their product counts) go to worker
-    // threads with private external / wide lists, which are concatenated in range order afterwards -- the order of the
-    // products of one destination stays ascending in k whatever the thread count (deterministic plan)
+    std::vector<int32_t> dstpiv((size_t)nF);                  // pivot min(i, j) of every stored entry
+    for (int64_t j = 0; j < n; ++j)
+        for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) dstpiv[cent[e].g] = std::min<int32_t>(cent[e].row, (int32_t)j);
+    for (int64_t k = 0; k < n; ++k) dstpiv[ldiag[k]] = (int32_t)k;
     int nthr = 6;
     if (const char* e = getenv("NEP_LU_PLAN_THREADS")) nthr = std::max(1, std::min(32, atoi(e)));
     std::vector<int64_t> kcut(nthr + 1, n);
@@ -333,23 +332,17 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
         for (int64_t k = 0; k < n; ++k)
             w[k + 1] = w[k] + 1.0 + (double)(Lp[k + 1] - Lp[k] - 1) * (double)(urp[k + 1] - urp[k] - 1);
         kcut[0] = 0;
-        for (int t = 1; t < nthr; ++t)
-            kcut[t] = std::lower_bound(w.begin(), w.end(), w[n] * t / nthr) - w.begin();
+        for (int t = 1; t < nthr; ++t) kcut[t] = std::lower_bound(w.begin(), w.end(), w[n] * t / nthr) - w.begin();
         for (int t = 1; t <= nthr; ++t) kcut[t] = std::max(kcut[t], kcut[t - 1]);
         kcut[nthr] = n;
     }
-    struct Part {
-        std::vector<std::vector<int32_t>> ext;                      // per destination level
-        std::vector<std::pair<int64_t, std::vector<int32_t>>> wide; // (step, products) in the order of first touch
-        int64_t nprod = 0; int err = 0; int32_t ei = 0, ej = 0; int64_t ek = 0;
-    };
-    std::vector<Part> parts(nthr);
-    for (Part& pt : parts) pt.ext.resize(nlev);
-    auto work = [&](int tix) {
-        Part& P = parts[tix];
+    struct Err { int code = 0; int32_t i = 0, j = 0; int64_t k = 0; };
+    std::vector<Err> errs(nthr);
+    // fn(kind, k, gL, gU, gdst): kind 0 internal, 1 external, 2 wide
+    auto visit = [&](int tix, auto&& fn) {
+        Err& E = errs[tix];
         std::vector<Ent> Lk;
-        std::vector<int64_t> widx(wprod.size(), -1);                 // step -> index into P.wide
-        for (int64_t k = kcut[tix]; k < kcut[tix + 1] && !P.err; ++k) {
+        for (int64_t k = kcut[tix]; k < kcut[tix + 1] && !E.code; ++k) {
             Lk.clear();
             {
                 const Ent* b = cent.data() + cptr[k]; const Ent* en = cent.data() + cptr[k + 1];
@@ -357,15 +350,8 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
                 for (; it != en; ++it) Lk.push_back(*it);
             }
             if (Lk.empty()) continue;
-            std::vector<int32_t>& mine = itri_piv[k];                // one writer per k
             const bool kwide = r->wide[lvl[k]] != 0;
-            std::vector<int32_t>* wl = nullptr;
-            if (kwide) {
-                const int64_t step = r->wstep0[lvl[k]] + (newpos[k] - blk_se[2 * blk[k]]);
-                if (widx[step] < 0) { widx[step] = (int64_t)P.wide.size(); P.wide.emplace_back(step, std::vector<int32_t>()); }
-                wl = &P.wide[widx[step]].second;
-            }
-            for (int64_t ue = urp[k]; ue < urp[k + 1]; ++ue) {
+            for (int64_t ue = urp[k]; ue < urp[k + 1] && !E.code; ++ue) {
                 const int32_t j = urow[ue].row, gU = urow[ue].g;
                 if (j <= k) continue;
                 // destinations (i, j), i in Lk: merge with the union column j (rows > k)
@@ -373,95 +359,96 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
                 const Ent* it = std::upper_bound(b, en, (int32_t)k, [](int32_t v, const Ent& a) { return v < a.row; });
                 for (const Ent& le : Lk) {
                     while (it != en && it->row < le.row) ++it;
-                    if (it == en || it->row != le.row) { P.err = 1; P.ei = le.row; P.ej = j; P.ek = k; break; }
+                    if (it == en || it->row != le.row) { E.code = 1; E.i = le.row; E.j = j; E.k = k; break; }
                     const int32_t p = std::min(le.row, j);
                     // (pivots of different blocks of a wide level run in the same launch and may share a destination in an
                     // ancestor block: those products stay "external", summed per destination in fixed order)
-                    if (kwide && blk[p] == blk[k]) { wl->push_back(le.g); wl->push_back(gU); wl->push_back(it->g); wl->push_back(udiag[k]); }
-                    else if (blk[p] == blk[k]) { mine.push_back(le.g); mine.push_back(gU); mine.push_back(it->g); }
-                    else {
-                        if (lvl[p] <= lvl[k]) { P.err = 2; break; }
-                        std::vector<int32_t>& ex = P.ext[lvl[p]];
-                        ex.push_back(it->g); ex.push_back(le.g); ex.push_back(gU);
-                    }
-                    ++P.nprod;
+                    if (blk[p] == blk[k]) fn(kwide ? 2 : 0, k, le.g, gU, it->g);
+                    else if (lvl[p] <= lvl[k]) { E.code = 2; break; }
+                    else fn(1, k, le.g, gU, it->g);
                 }
-                if (P.err) break;
             }
         }
     };
-    {
+    auto run_threads = [&](auto&& body) {
         std::vector<std::thread> th;
-        for (int t = 1; t < nthr; ++t) th.emplace_back(work, t);
-        work(0);
+        for (int t = 1; t < nthr; ++t) th.emplace_back(body, t);
+        body(0);
         for (std::thread& t : th) t.join();
-    }
+    };
+    // pass 1: counts
+    std::vector<int32_t> cnt_int(n, 0), cnt_wide(n, 0);
+    std::vector<std::vector<int32_t>> cnt_ext(nthr);
+    run_threads([&](int tix) {
+        std::vector<int32_t>& ce = cnt_ext[tix];
+        ce.assign((size_t)nF, 0);
+        visit(tix, [&](int kind, int64_t k, int32_t, int32_t, int32_t gd) {
+            if (kind == 0) ++cnt_int[k]; else if (kind == 2) ++cnt_wide[k]; else ++ce[gd];
+        });
+    });
     for (int t = 0; t < nthr; ++t) {
-        Part& P = parts[t];
-        if (P.err == 1) {
-            nep_set_error("refac: the stored pattern is not closed under the elimination (update (%d,%d) from pivot %lld has no slot)", P.ei, P.ej, (long long)P.ek);
+        if (errs[t].code == 1) {
+            nep_set_error("refac: the stored pattern is not closed under the elimination (update (%d,%d) from pivot %lld has no slot)", errs[t].i, errs[t].j, (long long)errs[t].k);
             nep_lu_refac_destroy(r);
             return NEP_ERR_UNSUPPORTED;
         }
-        if (P.err == 2) { nep_set_error("refac: update crosses blocks of one level"); nep_lu_refac_destroy(r); return NEP_ERR_UNSUPPORTED; }
-        r->nprod += P.nprod;
-        for (int l = 0; l < nlev; ++l) {
-            ext[l].insert(ext[l].end(), P.ext[l].begin(), P.ext[l].end());
-            std::vector<int32_t>().swap(P.ext[l]);
-        }
-        for (auto& ws : P.wide) {
-            std::vector<int32_t>& dstv = wprod[(size_t)ws.first];
-            dstv.insert(dstv.end(), ws.second.begin(), ws.second.end());
-            std::vector<int32_t>().swap(ws.second);
-        }
+        if (errs[t].code == 2) { nep_set_error("refac: update crosses blocks of one level"); nep_lu_refac_destroy(r); return NEP_ERR_UNSUPPORTED; }
     }
-    const double t_enum1 = now_ms();
-    // internal products in schedule order
+    // internal: schedule order
     std::vector<int64_t> piv_ptr(n + 1, 0);
-    for (int64_t q = 0; q < n; ++q) piv_ptr[q + 1] = piv_ptr[q] + (int64_t)itri_piv[oldof[q]].size() / 3;
+    for (int64_t q = 0; q < n; ++q) piv_ptr[q + 1] = piv_ptr[q] + cnt_int[oldof[q]];
     r->nint = piv_ptr[n];
-    itri.resize((size_t)r->nint * 3);
-    for (int64_t q = 0; q < n; ++q) {
-        const std::vector<int32_t>& v = itri_piv[oldof[q]];
-        if (!v.empty()) memcpy(itri.data() + 3 * piv_ptr[q], v.data(), v.size() * sizeof(int32_t));
+    // wide: by step, blocks of a step in schedule order
+    const int64_t nsteps = r->wstep0[nlev];
+    r->wide_ptr.assign((size_t)nsteps + 1, 0);
+    std::vector<int64_t> wide_off(n, 0);
+    {
+        auto stepof = [&](int64_t k) { return r->wstep0[lvl[k]] + (newpos[k] - blk_se[2 * blk[k]]); };
+        for (int64_t q = 0; q < n; ++q) { const int64_t k = oldof[q]; if (cnt_wide[k]) r->wide_ptr[stepof(k) + 1] += cnt_wide[k]; }
+        for (int64_t sidx = 0; sidx < nsteps; ++sidx) r->wide_ptr[sidx + 1] += r->wide_ptr[sidx];
+        std::vector<int64_t> cur(r->wide_ptr.begin(), r->wide_ptr.end() - 1);
+        for (int64_t q = 0; q < n; ++q) { const int64_t k = oldof[q]; if (cnt_wide[k]) { wide_off[k] = cur[stepof(k)]; cur[stepof(k)] += cnt_wide[k]; } }
     }
-    { std::vector<std::vector<int32_t>>().swap(itri_piv); }
-    // external products grouped by destination (stable: ascending k inside a segment)
+    r->nwide = r->wide_ptr[nsteps];
+    // external: segments by (destination level, destination), per-thread cursors inside a segment
     std::vector<int64_t> ext_ptr(1, 0);
-    std::vector<int32_t> ext_dst, ext_src;
+    std::vector<int32_t> ext_dst;
     r->ext_seg0.assign(nlev + 1, 0);
     {
-        std::vector<int64_t> cnt((size_t)(nnzL + nnzU) + 1);
+        std::vector<int32_t> tot((size_t)nF, 0);
+        for (int t = 0; t < nthr; ++t) { const int32_t* ce = cnt_ext[t].data(); for (int64_t g = 0; g < nF; ++g) tot[g] += ce[g]; }
+        std::vector<int64_t> start((size_t)nF, 0);
+        int64_t run = 0;
         for (int l = 0; l < nlev; ++l) {
             r->ext_seg0[l] = (int64_t)ext_dst.size();
-            const std::vector<int32_t>& ex = ext[l];
-            const int64_t m = (int64_t)ex.size() / 3;
-            if (m == 0) continue;
-            std::fill(cnt.begin(), cnt.end(), 0);
-            for (int64_t t = 0; t < m; ++t) cnt[ex[3 * t] + 1]++;
-            // segments in ascending destination order
-            std::vector<int64_t> start((size_t)(nnzL + nnzU) + 1, -1);
-            const int64_t base = (int64_t)ext_src.size() / 2;
-            int64_t run = base;
-            for (int64_t g = 0; g < nnzL + nnzU; ++g)
-                if (cnt[g + 1] > 0) { start[g] = run; ext_dst.push_back((int32_t)g); run += cnt[g + 1]; ext_ptr.push_back(run); }
-            ext_src.resize((size_t)run * 2);
-            for (int64_t t = 0; t < m; ++t) {
-                const int64_t pos = start[ex[3 * t]]++;
-                ext_src[2 * pos] = ex[3 * t + 1]; ext_src[2 * pos + 1] = ex[3 * t + 2];
-            }
+            for (int64_t g = 0; g < nF; ++g)
+                if (tot[g] > 0 && lvl[dstpiv[g]] == l) { start[g] = run; ext_dst.push_back((int32_t)g); run += tot[g]; ext_ptr.push_back(run); }
         }
         r->ext_seg0[nlev] = (int64_t)ext_dst.size();
+        if (run >= ((int64_t)1 << 31)) { nep_lu_refac_destroy(r); nep_set_error("refac: too many external products"); return NEP_ERR_UNSUPPORTED; }
+        for (int64_t g = 0; g < nF; ++g) {
+            if (!tot[g]) continue;
+            int64_t c = start[g];
+            for (int t = 0; t < nthr; ++t) { const int32_t m = cnt_ext[t][g]; cnt_ext[t][g] = (int32_t)c; c += m; }
+        }
+        r->next_ = run;
     }
-    r->nseg = (int64_t)ext_dst.size(); r->next_ = (int64_t)ext_src.size() / 2;
-    std::vector<int32_t> wflat;
-    r->wide_ptr.assign(wprod.size() + 1, 0);
-    for (size_t sidx = 0; sidx < wprod.size(); ++sidx) r->wide_ptr[sidx + 1] = r->wide_ptr[sidx] + (int64_t)wprod[sidx].size() / 4;
-    r->nwide = r->wide_ptr[wprod.size()];
-    wflat.resize((size_t)r->nwide * 4);
-    for (size_t sidx = 0; sidx < wprod.size(); ++sidx)
-        if (!wprod[sidx].empty()) memcpy(wflat.data() + 4 * r->wide_ptr[sidx], wprod[sidx].data(), wprod[sidx].size() * sizeof(int32_t));
-    { std::vector<std::vector<int32_t>>().swap(wprod); }
+    r->nseg = (int64_t)ext_dst.size();
+    r->nprod = r->nint + r->nwide + r->next_;
+    // pass 2: placement
+    std::vector<int32_t> itri((size_t)r->nint * 3), ext_src((size_t)r->next_ * 2), wflat((size_t)r->nwide * 4);
+    run_threads([&](int tix) {
+        int32_t* ce = cnt_ext[tix].data();
+        int64_t curk = -1, ci = 0, cw = 0;
+        visit(tix, [&](int kind, int64_t k, int32_t gL, int32_t gU, int32_t gd) {
+            if (k != curk) { curk = k; ci = piv_ptr[newpos[k]]; cw = wide_off[k]; }
+            if (kind == 0) { int32_t* o = itri.data() + 3 * ci++; o[0] = gL; o[1] = gU; o[2] = gd; }
+            else if (kind == 2) { int32_t* o = wflat.data() + 4 * cw++; o[0] = gL; o[1] = gU; o[2] = gd; o[3] = udiag[k]; }
+            else { const int64_t pos = ce[gd]++; ext_src[2 * pos] = gL; ext_src[2 * pos + 1] = gU; }
+        });
+    });
+    { std::vector<std::vector<int32_t>>().swap(cnt_ext); }
+    const double t_enum1 = now_ms();
     const double t_group = now_ms();
     // ---- upload
     int rc;
