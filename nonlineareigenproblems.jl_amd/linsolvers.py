@@ -683,9 +683,27 @@ class LinSolverCache:
         kw = {k: v for k, v in c.lu_kw.items() if k in ("diag_pivot_thresh", "symmetric_mode")}
         return _nep_hostlu.factor(Ac.data, Ac.indices, Ac.indptr, Ac.shape, permc_spec=c.permc_spec, **kw)
 
+    def _device_plan_ready(self):
+        """True when the sparsity pattern of this NEP's M(sigma) has a device-factorisation plan: the shifts are then factorised
+        on the GPU when they are needed (3.5 ms each on gun) and nothing is prefetched on the host"""
+        c = self.linsolvercreator
+        if type(c) is not FactorizeLinSolverCreator or not _DeviceRefactor.enabled():
+            return False
+        if getattr(self, "_plan_key", None) is None:
+            try:
+                A = sp.csc_matrix(self.nep.compute_Mder(0.5 + 0.25j), dtype=np.complex128)   # any shift: the pattern is what counts
+            except Exception:
+                self._plan_key = False
+                return False
+            kw = c.lu_kw
+            self._plan_key = _DeviceRefactor.key(A, (c.permc_spec, kw.get("diag_pivot_thresh"), kw.get("symmetric_mode")))
+        return self._plan_key is not False and _DeviceRefactor.lookup(self._plan_key) is not None
+
     def prefetch(self, shifts):
         c = self.linsolvercreator
         if type(c) is not FactorizeLinSolverCreator or os.environ.get("NEP_LU_PREFETCH", "1") == "0":
+            return
+        if self._device_plan_ready():
             return
         for s in shifts:
             key = complex(s)
@@ -713,12 +731,12 @@ class LinSolverCache:
             solver = FactorizeLinSolver(self.nep, sigma, c.umfpack_refinements, _lu=lu)
             if len(c.recycled_factorizations) < c.max_factorizations:
                 c.recycled_factorizations[key] = lu
-        elif self._pool is not None:
+        elif self._pool is not None and not self._device_plan_ready():
             # keep host factorisations on the one worker thread (they toggle the process-wide BLAS thread count)
             self._pending[key] = self._pool.submit(self._host_factors, key)
             return self._get(sigma, add_to_cache)
         else:
-            solver = create_linsolver(c, self.nep, sigma)
+            solver = create_linsolver(c, self.nep, sigma)         # DeviceLU(A): device factorisation when the plan exists
         if add_to_cache:
             self.solvers[key] = solver
         return solver
