@@ -41,6 +41,7 @@ struct nep_lu_refac {
     std::vector<int32_t> lev_blk;        // nlev+1
     std::vector<int64_t> ext_seg0;       // nlev+1: first external segment of a level
     std::vector<int32_t> h_blk_se;       // 2 nblk (schedule positions)
+    std::vector<int64_t> h_ext_ptr;      // nseg+1 (host copy: launch shapes)
     // device, symbolic
     int32_t* d_amap = nullptr;           // nnzA: entry of A (CSC order of the caller) -> position in F
     int32_t* d_ldiag = nullptr;          // n: position of L(k,k) (unit) in F
@@ -77,18 +78,26 @@ __global__ void k_lu_init(int64_t nF, int64_t n, int64_t nnzA, const int32_t* __
     if (i == 0) { health[0] = 0.0; health[1] = 0.0; health[2] = 0.0; }
 }
 
-// one thread per destination entry of the level: F[dst] -= sum_products L * U   (sources final: lower levels are done)
+// G lanes per destination entry of the level: F[dst] -= sum_products L * U   (sources final: lower levels are done).  Lane g
+// takes products g, g + G, ...; the G partial sums are combined by a fixed shuffle tree, so the result does not depend on
+// anything but G (segments of the top levels hold thousands of products: one thread per segment left most lanes idle)
+template <int G>
 __global__ __launch_bounds__(256) void k_lu_ext(int64_t seg0, int64_t seg1, const int64_t* __restrict__ ptr,
                                                 const int32_t* __restrict__ dst, const int32_t* __restrict__ src,
                                                 cplx* __restrict__ F, int64_t nF) {
     F += (int64_t)blockIdx.y * nF;
-    const int64_t sidx = seg0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    if (sidx >= seg1) return;
-    const int64_t p0 = ptr[sidx], p1 = ptr[sidx + 1];
+    const int sub = threadIdx.x % G;
+    const int64_t sidx = seg0 + (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) / G;
     cplx acc = cmake(0.0, 0.0);
-    for (int64_t p = p0; p < p1; ++p) cfma(acc, F[src[2 * p]], F[src[2 * p + 1]]);
-    const int32_t d = dst[sidx];
-    F[d] = csub(F[d], acc);
+    if (sidx < seg1) {
+        const int64_t p0 = ptr[sidx], p1 = ptr[sidx + 1];
+        for (int64_t p = p0 + sub; p < p1; p += G) cfma(acc, F[src[2 * p]], F[src[2 * p + 1]]);
+    }
+    acc = group_reduce_sum<G>(acc);
+    if (sidx < seg1 && sub == 0) {
+        const int32_t d = dst[sidx];
+        F[d] = csub(F[d], acc);
+    }
 }
 
 __device__ __forceinline__ cplx lu_cdiv(cplx a, cplx b);
@@ -434,6 +443,7 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
         r->next_ = run;
     }
     r->nseg = (int64_t)ext_dst.size();
+    r->h_ext_ptr = ext_ptr;
     r->nprod = r->nint + r->nwide + r->next_;
     // pass 2: placement
     std::vector<int32_t> itri((size_t)r->nint * 3), ext_src((size_t)r->next_ * 2), wflat((size_t)r->nwide * 4);
@@ -530,8 +540,18 @@ int32_t nep_lu_factor_dev_batch(nep_lu_refac* r, int32_t B, const nep_cdouble* h
     for (int l = 0; l < r->nlev; ++l) {
         const int64_t s0 = r->ext_seg0[l], s1 = r->ext_seg0[l + 1];
         if (s1 > s0) {
-            hipLaunchKernelGGL(k_lu_ext, dim3((unsigned)((s1 - s0 + 255) / 256), gy), dim3(256), 0, st, s0, s1, (const int64_t*)r->d_ext_ptr,
-                               (const int32_t*)r->d_ext_dst, (const int32_t*)r->d_ext_src, dF, nF);
+            // lanes per segment from the level's mean segment length (fixed per plan: part of the summation order)
+            const int64_t np_ = r->h_ext_ptr[s1] - r->h_ext_ptr[s0];
+            const double avg = (double)np_ / (double)(s1 - s0);
+            if (avg > 48.0)
+                hipLaunchKernelGGL((k_lu_ext<16>), dim3((unsigned)(((s1 - s0) * 16 + 255) / 256), gy), dim3(256), 0, st, s0, s1,
+                                   (const int64_t*)r->d_ext_ptr, (const int32_t*)r->d_ext_dst, (const int32_t*)r->d_ext_src, dF, nF);
+            else if (avg > 6.0)
+                hipLaunchKernelGGL((k_lu_ext<4>), dim3((unsigned)(((s1 - s0) * 4 + 255) / 256), gy), dim3(256), 0, st, s0, s1,
+                                   (const int64_t*)r->d_ext_ptr, (const int32_t*)r->d_ext_dst, (const int32_t*)r->d_ext_src, dF, nF);
+            else
+                hipLaunchKernelGGL((k_lu_ext<1>), dim3((unsigned)((s1 - s0 + 255) / 256), gy), dim3(256), 0, st, s0, s1,
+                                   (const int64_t*)r->d_ext_ptr, (const int32_t*)r->d_ext_dst, (const int32_t*)r->d_ext_src, dF, nF);
             LAUNCHCHK();
         }
         const int b0 = r->lev_blk[l], b1 = r->lev_blk[l + 1];
