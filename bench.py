@@ -4,14 +4,16 @@
 
 One "step" = one complete `iar(gun_spmf_scaled, sigma=0, gamma=1, maxit=100, neigs=Inf, v=ones,
 tol=1e-10, check_error_every=1)` call on one GPU (config C2 of SURVEY.md section 8d, n = 9956), including
-the one-off host factorisation of M(sigma) and the upload of its factors.  The NEP's matrices are
+the numeric factorisation of M(sigma) -- on the device (csrc/lufac.hip) once the plan of the sparsity pattern exists (it is
+built from the first call's host SuperLU factorisation during warm-up), on the host otherwise; `ms_per_step_host_lu`
+reports the same step with the host factorisation every time.  The NEP's matrices are
 resident in HBM before the timed region.  iar is a sequential Krylov recurrence and does not shard
 ("replicas only"), so with --gpus N every rank runs an independent replica of the same
 workload (weak scaling) and `value` is the whole-job rate: sum over ranks of converged eigenpairs
 divided by the max-over-ranks wall time.
 
 The JSON line also carries
-  value_excl_setup   the same rate with the linear-solver set-up (host SuperLU + factor upload + device-built block inverses)
+  value_excl_setup   the same rate with the linear-solver set-up (numeric LU + device-built block inverses)
                      taken out of every step (set-up time from the instrumented run)
   kernels / phase_share   per-phase time of one instrumented iar run and each phase's share of it
   roofline      the kernel pair with the largest share of device time (K6: k_orth_dots + k_orth_update), ONE Gram-Schmidt
@@ -413,7 +415,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64 (complex128)", "data": "synthetic",
             "config": {"workload": "nep_gallery gun SPMF (n=%d, 4 sparse terms, gun-like stand-in K,M + reference W1,W2), "
                                    "shift_and_scale(250^2, 330^2-220^2), iar sigma=0 maxit=%d neigs=Inf tol=1e-10 "
-                                   "check_error_every=1 DGKS umfpack_refinements=10; host SuperLU factorisation "
+                                   "check_error_every=1 DGKS umfpack_refinements=10; numeric factorisation of M(sigma) "
                                    "(UMFPACK-like symmetric strategy) inside the step" % (args.n, args.maxit),
                        "parallelism": "replicas x%d (iar does not shard)" % world,
                        "factorization": "numeric LU of M(sigma) inside every step: on the device (csrc/lufac.hip, right-looking on the "
