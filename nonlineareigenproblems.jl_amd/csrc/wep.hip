@@ -422,7 +422,8 @@ int32_t nep_wep_sylv_create(int32_t nz, int32_t nx, const nep_cdouble* h_d, doub
     int N1 = nz, N2 = 1;
     for (int a = 2; a * a <= nz; ++a)
         if (nz % a == 0 && std::gcd(a, nz / a) == 1 && a + nz / a < N1 + N2) { N1 = nz / a; N2 = a; }
-    int cols = 4;
+    int cols = getenv("NEP_WEP_DFT_COLS") ? std::max(1, std::min(4, atoi(getenv("NEP_WEP_DFT_COLS")))) : 4;
+    if (cols == 3) cols = 2;
     while (cols > 1 && ((size_t)2 * cols * nz + N1 + N2) * sizeof(cplx) > 150 * 1024) cols >>= 1;
     if (((size_t)2 * cols * nz + N1 + N2) * sizeof(cplx) > 150 * 1024) {
         nep_set_error("nep_wep_sylv_create: nz = %d does not fit the LDS staging of the DFT kernel", nz);
