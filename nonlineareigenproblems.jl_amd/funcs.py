@@ -47,12 +47,20 @@ class ScalarFun:
     def __neg__(self):
         return Scaled(-1.0, self)
 
+    def real_on_reals(self):
+        """True when f maps real arguments (scalars and real matrices) to real values with real derivatives -- what decides the
+        element type of compute_Mder / compute_Mlincomb / compute_MM results for real input (test/compute_types.jl)"""
+        return False
+
 
 class Monomial(ScalarFun):
     """lam^p  (p=0: one(S); p=1: S)   src/types_poly.jl:83-98"""
 
     def __init__(self, p):
         self.p = int(p)
+
+    def real_on_reals(self):
+        return True
 
     def derivs(self, lam, k, scale=1.0):
         lam = complex(lam)
@@ -73,6 +81,9 @@ class Exp(ScalarFun):
 
     def __init__(self, c):
         self.c = c
+
+    def real_on_reals(self):
+        return not np.iscomplexobj(self.c)
 
     def derivs(self, lam, k, scale=1.0):
         return np.exp(self.c * complex(lam)) * np.power(complex(self.c * scale), np.arange(k))
@@ -114,6 +125,9 @@ class Scaled(ScalarFun):
     def __init__(self, c, f):
         self.c, self.f = c, f
 
+    def real_on_reals(self):
+        return not np.iscomplexobj(self.c) and self.f.real_on_reals()
+
     def derivs(self, lam, k, scale=1.0):
         return self.c * self.f.derivs(lam, k, scale)
 
@@ -145,6 +159,9 @@ class Affine(ScalarFun):
 class Sum(ScalarFun):
     def __init__(self, *fs):
         self.fs = fs
+
+    def real_on_reals(self):
+        return all(f.real_on_reals() for f in self.fs)
 
     def derivs(self, lam, k, scale=1.0):
         return sum(f.derivs(lam, k, scale) for f in self.fs)

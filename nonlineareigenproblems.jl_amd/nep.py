@@ -287,6 +287,27 @@ class AbstractSPMF(NEP):
             self._dev = SPMFDevice(self.get_Av())
         return self._dev
 
+    # ---- element type of host results (test/compute_types.jl): the reference returns promote_type(eltype(nep), typeof(lam),
+    # eltype(V)) -- real when the NEP is real (real matrices, functions real on the reals) and every argument is real, complex
+    # otherwise.  The device computes in complex128 throughout; for an all-real call the imaginary parts are exact zeros and the
+    # host result is handed back as float64.  (Julia's other precisions -- Float16/32, BigFloat -- have no counterpart here.)
+    def is_real(self):
+        if getattr(self, "_is_real", None) is None:
+            try:
+                self._is_real = bool(all(not np.iscomplexobj(A.data if sp.issparse(A) else A) for A in self.get_Av())
+                                     and all(f.real_on_reals() for f in self.get_fv()))
+            except Exception:
+                self._is_real = False
+        return self._is_real
+
+    def _promote(self, result, *args):
+        """result (host, complex128) -> float64 when the NEP and all of `args` are real"""
+        if self.is_real() and all(a is None or not np.iscomplexobj(a) for a in args):
+            if sp.issparse(result):
+                return result.real.astype(np.float64) if np.iscomplexobj(result.data) else result
+            return np.ascontiguousarray(np.real(result)) if np.iscomplexobj(result) else result
+        return result
+
     # ---- coefficient block C[j,i] = a_j f_i^(j)(lam) (Appendix A of SURVEY.md; NEPCore.jl:218-228)
     def coeff_block(self, lam, a, startder=0):
         a = np.asarray(a, dtype=np.complex128)
@@ -309,7 +330,7 @@ class AbstractSPMF(NEP):
         if len(a) != k:
             raise ValueError("length of a must equal the number of columns of V")
         z = self.dev.mlincomb(self.coeff_block(lam, a, startder), Vd)
-        return to_host(z.reshape(1, -1))[:, 0] if host else z
+        return self._promote(to_host(z.reshape(1, -1))[:, 0], lam, V, a) if host else z
 
     compute_Mlincomb_ = compute_Mlincomb  # the `!` variant may overwrite V; ours never needs to
 
@@ -325,12 +346,12 @@ class AbstractSPMF(NEP):
             # (contour_beyn assembles 64 of them: 1.6 ms -> 0.7 ms each on gun)
             indptr, indices, D = al
             # (einsum, not `D @ coef`: OpenBLAS' threaded zgemv takes 24 ms for this 88 598 x 4 product, einsum 0.6 ms)
-            return sp.csc_matrix((np.einsum("ij,j->i", D, coef), indices, indptr), shape=Av[0].shape)
+            return self._promote(sp.csc_matrix((np.einsum("ij,j->i", D, coef), indices, indptr), shape=Av[0].shape), lam)
         Z = None
         for A, c in zip(Av, coef):
             T = A * c
             Z = T if Z is None else Z + T
-        return Z
+        return self._promote(Z, lam)
 
     def compute_Mder_batch(self, lams):
         """the matrices M(lam_b) of several shifts on the union sparsity pattern: (indptr, indices, values) with values of shape
@@ -384,6 +405,7 @@ class AbstractSPMF(NEP):
     def compute_MM(self, S, V):
         """sum_i A_i V f_i(S)   (src/NEPTypes.jl:276-319): host f_i(S), device GEMM + SpMM."""
         from .dense import gemm_ts
+        S_in = S
         S = np.atleast_2d(np.asarray(S, dtype=np.complex128))
         p = S.shape[0]
         host = not is_dev(V)
@@ -402,7 +424,7 @@ class AbstractSPMF(NEP):
         ZT = torch.empty((self.n, p), dtype=CDT, device="cuda")
         check(lib.nep_spmm_terms(self.dev.h, p, c_vp(XT.data_ptr()), p * mt, c_vp(ZT.data_ptr()), p, stream_ptr()))
         if host:
-            return ZT.cpu().numpy()
+            return self._promote(ZT.cpu().numpy(), S_in, V)
         return ZT.t().contiguous()
 
     # ---- driver-facing hooks: every Krylov driver goes through these three, so a NEP type with extra

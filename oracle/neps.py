@@ -83,6 +83,15 @@ def _bidiag(lam, k, sub):
 
 
 # ----------------------------------------------------------------------------------
+def result_type(nep_is_real, *args):
+    """Element type the reference returns from compute_Mder / compute_Mlincomb / compute_MM (test/compute_types.jl:62-75,
+    95-106, 146-155): promote_type of the NEP's element type and of every argument, made complex when the NEP is not real.
+    Restricted to the two precisions NumPy and the device share: float64 and complex128 (Julia's Float16/32 and BigFloat rows
+    of that test have no counterpart here; a lower-precision complex argument such as ComplexF16 promotes to complex)."""
+    cplx = (not nep_is_real) or any(a is not None and np.iscomplexobj(a) for a in args)
+    return np.complex128 if cplx else np.float64
+
+
 class NEP:
     def size(self, d=None):
         return (self.n, self.n) if d is None else self.n

@@ -756,3 +756,30 @@ def test_device_numeric_factorization(na, monkeypatch):
     monkeypatch.setenv("NEP_LU_DEV", "0")
     assert not na.DeviceLU(A1).device_factorized
     ls._DeviceRefactor.clear()
+
+
+def test_compute_types(na):
+    """test/compute_types.jl, the precisions NumPy and the device share: host results of a REAL NEP are float64 for real
+    lambda / V / S and complex128 otherwise; a complex NEP (or one with a function that leaves the reals, gun's i*sqrt)
+    always returns complex128.  Values are those of the complex computation."""
+    from oracle import neps as on
+    rng = np.random.default_rng(0)
+    n = 5
+    Ar = [rng.standard_normal((n, n)) for _ in range(3)]
+    cases = [(na.PEP(Ar), True), (na.PEP([A + 1j * np.eye(n) for A in Ar]), False), (na.DEP([Ar[0], Ar[1]], [0.0, 0.7]), True),
+             (na.SPMF_NEP([Ar[0], Ar[1]], [na.funcs.one(), na.funcs.ISqrt(1.0, 0.0)]), False)]
+    for nep, real in cases:
+        assert nep.is_real() == real
+        for lam in (1.0, 1.0 + 1.0j):
+            M = nep.compute_Mder(lam)
+            dt = M.dtype if hasattr(M, "dtype") else np.asarray(M).dtype
+            assert dt == on.result_type(real, lam)
+            for V in (np.ones((n, 3)), np.ones((n, 3)) + 0j):
+                y = nep.compute_Mlincomb(lam, V)
+                assert y.dtype == on.result_type(real, lam, V)
+                yc = nep.compute_Mlincomb(complex(lam), V + 0j)
+                assert np.linalg.norm(y - yc) <= 1e-13 * max(1.0, np.linalg.norm(yc))
+                assert nep.compute_Mlincomb(lam, V[:, 0]).dtype == on.result_type(real, lam, V)
+        for S in (np.eye(2), np.eye(2) + 0j):
+            for V in (np.ones((n, 2)), np.ones((n, 2)) + 0j):
+                assert nep.compute_MM(S, V).dtype == on.result_type(real, S, V)

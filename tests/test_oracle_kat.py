@@ -552,3 +552,17 @@ def test_nleigs_custom_nep_type_kat():
         assert np.linalg.norm(pep.compute_Mlincomb(lam[i], X[:, i])) / np.linalg.norm(X[:, i]) < 1e-5
     lam2, _, _ = onl.nleigs(pep, Sigma, maxit=10, v=np.ones(2) + 0j, blksize=5)
     assert len(lam2) == 4 and max(np.min(abs(lam2 - l)) for l in lam) < 1e-9
+
+
+def test_compute_types_rule_kat():
+    """test/compute_types.jl (reduced type list [Float64, ComplexF16], lines 170-260): a real PEP returns Float64 for real
+    arguments and a complex type as soon as lambda, V or S is complex; a complex PEP always returns a complex type"""
+    from oracle import neps as on
+    f8, c16 = np.float64, np.complex128
+    lam_r, lam_c = 1.0, np.complex64(1 + 1j)           # Float64 / ComplexF16 (any lower-precision complex promotes to complex)
+    V_r, V_c = np.ones((5, 3)), np.ones((5, 3), dtype=np.complex64)
+    assert on.result_type(True, lam_r) is f8 and on.result_type(True, lam_c) is c16                       # compute_Mder
+    assert on.result_type(True, lam_r, V_r) is f8 and on.result_type(True, lam_r, V_c) is c16              # compute_Mlincomb
+    assert on.result_type(True, lam_c, V_r) is c16
+    assert on.result_type(False, lam_r, V_r) is c16                                                        # complex NEP
+    assert on.result_type(True, np.eye(2), V_r) is f8 and on.result_type(True, np.eye(2) + 0j, V_r) is c16  # compute_MM
