@@ -68,8 +68,12 @@ __global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, i
 // h[j] = sum_b partial[b*k + j]; one block per column, fixed summation tree -> deterministic
 __global__ __launch_bounds__(256) void k_orth_reduce_h(int nb, int k, const cplx* __restrict__ partial,
                                                        cplx* __restrict__ h, const int* __restrict__ gate = nullptr,
-                                                       cplx* __restrict__ hacc = nullptr, int first = 1) {
+                                                       cplx* __restrict__ hacc = nullptr, int first = 1,
+                                                       int* __restrict__ state_reset = nullptr) {
     __shared__ cplx sm[4];
+    // first pass of an asynchronous orthogonalisation: clear the pass state here (nothing reads it before k_orth_decide of
+    // this pass) instead of a separate memset command in front of every Arnoldi step
+    if (state_reset && blockIdx.x == 0 && threadIdx.x < 4) state_reset[threadIdx.x] = 0;
     if (gate && *gate == 0) return;
     const int j = blockIdx.x;
     cplx acc = cmake(0.0, 0.0);
@@ -332,7 +336,6 @@ extern "C" int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64
     cplx* w = (cplx*)dw;
     cplx* out = (cplx*)d_out;
     const size_t shm_upd = (size_t)(k + 8 * 64) * sizeof(cplx);
-    HIPCHK(hipMemsetAsync(d_state, 0, 16, st));
     const int npass = method == 1 ? 1 : orth_dev_passes();
     for (int p = 0; p < npass; ++p) {
         const int* gate = p == 0 ? nullptr : d_state;
@@ -340,7 +343,7 @@ extern "C" int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64
                            d_active_rows, (const cplx*)w, d_ph, gate);
         LAUNCHCHK();
         hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_c, gate, out,
-                           p == 0 ? 1 : 0);
+                           p == 0 ? 1 : 0, p == 0 ? d_state : (int*)nullptr);
         LAUNCHCHK();
         hipLaunchKernelGGL(k_orth_update, dim3(nblk), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
                            (const cplx*)d_c, w, d_pn, gate);
