@@ -345,12 +345,17 @@ def main():
                                   "achieved": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS}))
         return
 
+    warm_ms = []
     for _ in range(args.warmup):
+        tw = time.perf_counter()
         bc.c2_device(na, nep, args.maxit, args.permc)
+        torch.cuda.synchronize(); warm_ms.append(round((time.perf_counter() - tw) * 1e3, 2))
     # one-time plan of the device-side numeric LU for this sparsity pattern (csrc/lufac.hip): started by the first host
     # factorisation on a background thread (0.3 s); like graph capture and allocator pools it belongs to the warm-up
     from nep_amd.linsolvers import _DeviceRefactor
+    tw = time.perf_counter()
     _DeviceRefactor.wait()
+    plan_wait_ms = round((time.perf_counter() - tw) * 1e3, 2)
 
     def barrier():
         if use_dist:
@@ -426,6 +431,8 @@ def main():
             "value_excl_setup": world * per_step_pairs / max(ms_step * 1e-3 - t_setup, 1e-9),
             "linsolver_setup_ms": t_setup * 1e3,
             "ms_per_step_host_lu": ms_host_lu,
+            "warmup_calls_ms": warm_ms,           # the first call carries every one-off: symbolic schedule, host LU, allocator pools
+            "plan_wait_ms": plan_wait_ms,         # time the warm-up still had to wait for the device-LU plan (background thread)
             "compute_Mlincomb_GBps": achieved,
             "roofline_compute_Mlincomb": {"bound": "hbm", "kernel": "nep_mlincomb, k=%d columns" % k,
                          "note": "the kernel BASELINE's metric names; at gun size one call moves 17.8 MB (2.2 us at 8 TB/s), "
