@@ -30,7 +30,7 @@ from .nleigs import nleigs, NleigsSolutionDetails
 from . import rk_helper
 from .contour import (contour_beyn, contour_block_SS, integrate_interval, MatrixIntegrator, MatrixTrapezoidal,
                       MatrixTrapezoidalSharded, probe_block)
-from .comm import DeviceComm
+from .comm import DeviceComm, HostStagedComm
 from . import gallery
 from . import wep_linsolvers
 from .wep_linsolvers import (WEPLinSolverCreator, WEPFactorizedLinSolver, WEPBackslashLinSolver, WEPGMRESLinSolver,

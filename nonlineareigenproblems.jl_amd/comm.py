@@ -56,3 +56,29 @@ class DeviceComm:
             self.close()
         except Exception:
             pass
+
+
+class HostStagedComm:
+    """Same interface as DeviceComm, exchange staged through host memory and torch.distributed (any backend, e.g. gloo): for
+    ranks that share ONE GPU -- RCCL refuses two ranks on a device -- i.e. for exercising the multi-rank sharded drivers with
+    device solves on a single-GPU box (tests).  Fixed rank order of the sum, identical result on every rank."""
+
+    def __init__(self):
+        import torch.distributed as dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+
+    def allgather_sum(self, S, out=None):
+        import torch
+        import torch.distributed as dist
+        out = S if out is None else out
+        h = S.detach().cpu()
+        parts = [torch.empty_like(h) for _ in range(self.world)]
+        dist.all_gather(parts, h)
+        acc = torch.zeros_like(h)
+        for p in parts:
+            acc += p
+        out.copy_(acc.to(out.device))
+        return out
+
+    def close(self):
+        pass

@@ -1,0 +1,73 @@
+"""Two processes, ONE GPU: the sharded contour drivers with device solves under world_size = 2.
+
+RCCL refuses two ranks on one device, so the exchange of this test is staged through host memory and gloo
+(`na.HostStagedComm`, same interface as the RCCL communicator of the C ABI).  Everything else is the production path of a
+multi-GPU run: each rank takes the nodes i = r (mod 2), factorises them (host pool or the batched device LU when the pattern's
+plan exists), solves on the GPU, accumulates its moments, exchanges, and extracts the eigenpairs -- both ranks must return the
+eigenpairs of the single-process run."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def na():
+    import nep_amd
+    assert nep_amd.device_count() >= 1, "no GPU visible"
+    return nep_amd
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _rank(rank, world, port, out, n, device_lu):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["NEP_HOSTLU_WORKERS"] = "2"
+    if not device_lu:
+        os.environ["NEP_LU_DEV"] = "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import nep_amd as na
+    from nep_amd.linsolvers import _DeviceRefactor
+    nep = na.nep_gallery("gun_spmf", n); nep.dev
+    if device_lu:                                   # plan of the pattern: one host factorisation, then wait for the builder thread
+        na.DeviceLU(nep.compute_Mder(250.0 ** 2 + 3.0))
+        _DeviceRefactor.wait()
+    na.MatrixTrapezoidalSharded.comm = na.HostStagedComm()
+    info = {}
+    Vh = na.probe_block(n, 16)
+    lam, V = na.contour_beyn(nep, na.MatrixTrapezoidalSharded, sigma=250.0 ** 2, radius=1e4, N=32, k=16, neigs=10 ** 6, tol=1e-6,
+                             Vh=Vh, sanity_check=True, info=info)
+    used = sum(p["uses"] for p in _DeviceRefactor.plans.values())
+    np.savez(os.path.join(out, "r%d.npz" % rank), lam=lam, V=V, nodes=info["nodes"], world=info["world"], used=used)
+    na.HostLUPool.shutdown()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("device_lu", [False, True])
+def test_sharded_beyn_two_ranks_one_gpu(na, tmp_path, device_lu):
+    n = 1310
+    mp.spawn(_rank, args=(2, _free_port(), str(tmp_path), n, device_lu), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "r0.npz"); r1 = np.load(tmp_path / "r1.npz")
+    assert int(r0["world"]) == 2 and int(r0["nodes"]) == 16 and int(r1["nodes"]) == 16
+    assert np.array_equal(r0["lam"], r1["lam"]) and np.array_equal(r0["V"], r1["V"])          # identical on both ranks
+    if device_lu:
+        assert int(r0["used"]) >= 16 and int(r1["used"]) >= 16                               # every node of a rank on the device
+    nep = na.nep_gallery("gun_spmf", n)
+    lam, V = na.contour_beyn(nep, na.MatrixTrapezoidal, sigma=250.0 ** 2, radius=1e4, N=32, k=16, neigs=10 ** 6, tol=1e-6,
+                             Vh=na.probe_block(n, 16), sanity_check=True)
+    assert len(lam) == len(r0["lam"]) >= 1
+    a = np.sort_complex(lam); b = np.sort_complex(r0["lam"])
+    assert np.abs(a - b).max() <= 1e-8 * np.abs(a).max()
