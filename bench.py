@@ -45,6 +45,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+RED_DEV = "cuda"        # device of the tensors that go through torch.distributed reductions
 
 
 def parse():
@@ -148,6 +149,8 @@ def beyn_sharded(na, args, world, rank):
     na.HostLUPool.warm(max(1, min(16, -(-64 // max(world, 1)), cpu_budget() - 2)))
     distd = dist.is_available() and dist.is_initialized()
     integ = na.MatrixTrapezoidalSharded if distd else na.MatrixTrapezoidal
+    if distd and RED_DEV == "cpu":
+        na.MatrixTrapezoidalSharded.comm = na.HostStagedComm()
     bc.c4_device(na, nep, integ, Vh=Vh, N=8 * world)          # warm-up (graph capture, allocator pools)
     if distd:
         dist.barrier()
@@ -160,7 +163,7 @@ def beyn_sharded(na, args, world, rank):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if distd:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=RED_DEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     out = {"workload": "contour_beyn gun SPMF n=%d N=64 k=32 radius=1e4 sigma=250^2 tol=1e-6" % nep.n,
@@ -319,12 +322,22 @@ def main():
     use_dist = world > 1 or bool(os.environ.get("NEP_FORCE_DIST") and "RANK" in os.environ)   # forced: 1-rank RCCL smoke test
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if use_dist:
+    # NEP_BENCH_SHARE_GPU=1: rehearsal of the multi-rank path on a box with ONE GPU -- every rank computes on cuda:0, the
+    # process group is gloo and the contour exchange is staged through host memory (RCCL refuses two ranks on one device).
+    # Not a measurement; it exists so that the N > 1 code path of this file can be executed before an 8-GPU node sees it.
+    share_gpu = bool(os.environ.get("NEP_BENCH_SHARE_GPU"))
+    if use_dist and share_gpu:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
+    global RED_DEV
+    RED_DEV = "cpu" if (use_dist and share_gpu) else "cuda"
     import nep_amd as na
     import baseline_configs as bc
     assert na.device_count() >= 1, "bench.py needs a GPU: the backend has no CPU fallback"
@@ -371,7 +384,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt, float(pairs)], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt, float(pairs)], dtype=torch.float64, device=RED_DEV)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone(); dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         dt = float(tmax[0]); pairs = int(round(float(tsum[1])))
