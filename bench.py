@@ -146,7 +146,10 @@ def beyn_sharded(na, args, world, rank):
     Vh = na.probe_block(nep.n, 32)
     # worker processes for the host factorisations of THIS rank's nodes (64/world of them): no more workers than nodes
     from nep_amd._affinity import cpu_budget
-    na.HostLUPool.warm(max(1, min(16, -(-64 // max(world, 1)), cpu_budget() - 2)))
+    from nep_amd.linsolvers import _DeviceRefactor
+    if not any(p["state"] == "ready" for p in _DeviceRefactor.plans.values()) or os.environ.get("NEP_BEYN_HOST_LU"):
+        # (with a plan for the pattern the nodes are factorised on the device in one batch and no worker process is needed)
+        na.HostLUPool.warm(max(1, min(16, -(-64 // max(world, 1)), cpu_budget() - 2)))
     distd = dist.is_available() and dist.is_initialized()
     integ = na.MatrixTrapezoidalSharded if distd else na.MatrixTrapezoidal
     if distd and RED_DEV == "cpu":
