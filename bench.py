@@ -468,13 +468,13 @@ def main():
         try:
             rf = orth_roofline(na, nep.n, args.maxit)
             try:
-                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc2", "gun_traffic.json")))
+                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc2", "r2_gun_traffic.json")))
                 kb = 0.0
                 for name, d in pj.items():
                     if (name.startswith("k_orth_dots") or name.startswith("k_orth_update")) and d.get("hbm_MB_per_launch", 0) > 100:
                         kb += d["hbm_MB_per_launch"] * 1024.0
                 rf["traffic"] = kb * 1024.0
-                rf["traffic_source"] = ("profiles/pmc2/gun_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
+                rf["traffic_source"] = ("profiles/pmc2/r2_gun_traffic.json (round-2 code; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
                                         "scripts/kernel_bench.py gun, same shape; 2*FETCH + WRITE per the gfx950 note)")
             except Exception:
                 rf["traffic"] = None
