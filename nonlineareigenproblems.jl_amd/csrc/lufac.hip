@@ -243,6 +243,26 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
     r->h_blk_se.assign(blk_se, blk_se + 2 * nblk);
     const int64_t nnzL = r->nnzL, nnzU = r->nnzU;
     if (nnzL + nnzU >= ((int64_t)1 << 31)) { nep_lu_refac_destroy(r); nep_set_error("refac: factors too large for 32-bit positions"); return NEP_ERR_UNSUPPORTED; }
+    // row counts of U first: they give the size of the plan before anything large is built (the waveguide factors -- 126 M
+    // entries, ~1e11 products -- are turned away here)
+    std::vector<int64_t> urp(n + 1, 0);
+    for (int64_t e = 0; e < nnzU; ++e) {
+        if (Ui[e] < 0 || Ui[e] >= n) { nep_lu_refac_destroy(r); nep_set_error("refac: U row index out of range"); return NEP_ERR_ARG; }
+        urp[Ui[e] + 1]++;
+    }
+    for (int64_t i = 0; i < n; ++i) urp[i + 1] += urp[i];
+    // ---- size of the plan: sum_k |L(:,k)| |U(k,:)| products, 12-16 bytes each on the host and on the device
+    {
+        double est = 0.0;
+        for (int64_t k = 0; k < n; ++k) est += (double)(Lp[k + 1] - Lp[k] - 1) * (double)(urp[k + 1] - urp[k] - 1);
+        const char* e = getenv("NEP_LU_DEV_MAXPROD");
+        const double lim = e ? atof(e) : 1.5e8;
+        if (est > lim) {
+            nep_lu_refac_destroy(r);
+            nep_set_error("refac: %.3g products exceed the plan limit %.3g (NEP_LU_DEV_MAXPROD)", est, lim);
+            return NEP_ERR_UNSUPPORTED;
+        }
+    }
     // ---- union columns of F, rows sorted: U part (rows <= j, g = nnzL + e) then L part (rows > j, g = e)
     std::vector<int64_t> cptr(n + 1, 0);
     std::vector<Ent> cent((size_t)(nnzL + nnzU));
@@ -270,26 +290,11 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
         cptr[n] = w;
     }
     // rows of U (row k: columns j > k with their positions), sorted by j
-    std::vector<int64_t> urp(n + 1, 0);
-    for (int64_t e = 0; e < nnzU; ++e) urp[Ui[e] + 1]++;
-    for (int64_t i = 0; i < n; ++i) urp[i + 1] += urp[i];
     std::vector<Ent> urow((size_t)nnzU);
     {
         std::vector<int64_t> fill(urp.begin(), urp.end() - 1);
         for (int64_t j = 0; j < n; ++j)
             for (int32_t e = Up[j]; e < Up[j + 1]; ++e) urow[fill[Ui[e]]++] = {(int32_t)j, (int32_t)(nnzL + e)};   // j ascending
-    }
-    // ---- size of the plan: sum_k |L(:,k)| |U(k,:)| products, 12-16 bytes each on the host and on the device
-    {
-        double est = 0.0;
-        for (int64_t k = 0; k < n; ++k) est += (double)(Lp[k + 1] - Lp[k] - 1) * (double)(urp[k + 1] - urp[k] - 1);
-        const char* e = getenv("NEP_LU_DEV_MAXPROD");
-        const double lim = e ? atof(e) : 1.5e8;
-        if (est > lim) {
-            nep_lu_refac_destroy(r);
-            nep_set_error("refac: %.3g products exceed the plan limit %.3g (NEP_LU_DEV_MAXPROD)", est, lim);
-            return NEP_ERR_UNSUPPORTED;
-        }
     }
     const double t_cols = now_ms();
     // ---- A -> F
