@@ -154,6 +154,8 @@ class _DeviceRefactor:
             return
         if not F["strategy"].get("symmetric_mode") or not np.array_equal(F["perm_r"], F["perm_c"]):
             return
+        if int(F["Lp"][-1]) + int(F["Up"][-1]) > int(os.environ.get("NEP_LU_DEV_MAXNNZ", "4000000")):
+            return        # factors of this size mean far more products than a plan may hold (the library would refuse it anyway)
         with cls.lock:
             if key in cls.plans:
                 return
