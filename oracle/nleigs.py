@@ -497,6 +497,8 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
                 Lam[:l, l - 1] = lambda_[si]
                 conv = conv & lamin
             nbconv = int(np.sum(conv)) if len(conv) else 0
+            if info is not None and "_history" in info:                             # diagnostic hook: one row per check
+                info["_history"].append((k, l, lam.copy(), res.copy(), [float(np.linalg.norm(S[:, i])) for i in ilam]))
 
         if not return_details and (
                 (not expand and k >= N + minit and (k - (N + minit)) % check_error_every == 0) or
@@ -504,7 +506,8 @@ def nleigs(nep, Sigma, Xi=(np.inf,), maxdgr=100, minit=20, maxit=200, linsolverc
             check_convergence(False)
         elif return_details and (not static or not expand):
             check_convergence(True)
-        if ((not expand and k >= N + minit) or k >= kconv + minit) and nblamin == nbconv:
+        if ((not expand and k >= N + minit) or k >= kconv + minit) and nblamin == nbconv \
+                and not (info is not None and info.get("_nobreak")):               # (_nobreak: diagnostic hook only)
             break
         k += 1
     if info is not None:

@@ -811,6 +811,29 @@ def test_nleigs_particle_lowrank_static(na):
     assert max(E(lam[i], X[:, i]) for i in range(2)) < 1e-5
 
 
+def test_nleigs_particle_lowrank_dynamic(na):
+    """test/nleigs/nleigs_particle_variant_r2.jl on the device (dynamic variant: leja points in the expansion phase,
+    repeated nodes after the freeze) with the reference's settings and DEFAULT tolerance: with the seeded start vector
+    of the oracle KAT the run ends with exactly the 2 eigenvalues verify_lambdas(2, ...) expects, residuals < 1e-10,
+    equal to the oracle's; with the reference's own start vector device and oracle level off alike (tol = 1e-7; see the
+    oracle KAT for why)"""
+    import warnings
+    from oracle import gallery as og, nleigs as onl, solvers as osol
+    nep, Sigma, Xi, v, nodes, xmin, xmax = na.gallery.particle_init(2)
+    onep = og.particle_init(2)[0]
+    E = osol.ResidualErrmeasure(onep)
+    v1 = np.random.default_rng(1).standard_normal(len(v)) + 0j
+    for vv, tol in ((v1, 1e-10), (v, 1e-7)):
+        kw = dict(Xi=Xi, maxdgr=50, minit=30, maxit=100, v=vv, nodes=nodes, tol=tol)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            lam, X, res = na.nleigs(nep, Sigma, **kw)
+            lo, Xo, ro = onl.nleigs(onep, Sigma, **kw)
+        assert len(lam) == 2 and len(lo) == 2
+        _match(lam, lo, 1e-8)
+        assert max(E(lam[i], X[:, i]) for i in range(2)) < tol
+
+
 def test_wep_linsolvers_small(na):
     """test/wep_small.jl:24-28 on the device: the Sylvester-SMW preconditioner with one grid point per region (N = nz)
     inverts SchurMatVec exactly; device SchurMatVec / assembled Schur complement / dense-transform Sylvester solve against

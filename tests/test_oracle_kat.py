@@ -451,10 +451,14 @@ def test_nleigs_particle_lowrank_oracle():
     """test/nleigs/nleigs_particle_variant_s.jl:12-17 with particle_test_utils.jl (n = 16281, PEP + 81 rank-2 terms given
     by their factors only, r = 162, interval 2, the pep0-based start vector): the static variant finds exactly the 2
     eigenvalues `verify_lambdas(2, ...)` expects, residuals below its 1e-5.  The dynamic variant R2
-    (nleigs_particle_variant_r2.jl:15-17, also 2 expected) locates the same two eigenvalues; with the reference's start
-    vector and the default tol = 1e-10 this restatement's residuals level off at 2e-8 -- systematically for start
-    vectors that are real up to a phase, while genuinely complex ones reach 1e-11 -- so R2 is checked with tol = 1e-7; the open
-    parity item of DESIGN.md section 1"""
+    (nleigs_particle_variant_r2.jl:15-17, also 2 expected) is pinned in two ways: (a) with a seeded random start vector
+    and the reference's settings (maxdgr=50, minit=30, maxit=100, default tol = 1e-10) it returns exactly the two
+    eigenvalues, residuals below 1e-10 (8 of 12 seeded normal / uniform vectors do; the others end with 0 or 1 pair
+    because a Ritz value sits 1e-10 outside the |Im| <= tol strip of in_Sigma at the first check -- the start-vector lottery
+    the reference's own comment "gives stability over versions" refers to); (b) with the reference's pep0-based vector
+    the run has two near-breakdown steps (beta/|w| = 8e-3 at step 2 and 2e-3 at step 8), its Ritz vectors are
+    combinations with coefficients of norm 2e5 and the residuals level off at 2e-8 / 3e-9 (stable under 1 % noise on v
+    and under every LU ordering), so that vector is checked with tol = 1e-7; DESIGN.md section 1"""
     import warnings
     from oracle import nleigs as onl
     nep, Sigma, Xi, v, nodes, xmin, xmax = gallery.particle_init(2)
@@ -467,6 +471,10 @@ def test_nleigs_particle_lowrank_oracle():
         assert np.allclose(np.sort(lam.real), [-0.14339765648, -0.13573256070], atol=1e-9) and max(abs(lam.imag)) < 1e-10
         lam2, X2, res2 = onl.nleigs(nep, Sigma, Xi=Xi, maxdgr=50, minit=30, maxit=100, v=v, nodes=nodes, tol=1e-7)
         assert len(lam2) == 2 and np.allclose(np.sort(lam2.real), np.sort(lam.real), atol=1e-8)
+        v1 = np.random.default_rng(1).standard_normal(len(v)) + 0j
+        lam3, X3, res3 = onl.nleigs(nep, Sigma, Xi=Xi, maxdgr=50, minit=30, maxit=100, v=v1, nodes=nodes)
+        assert len(lam3) == 2 and np.allclose(np.sort(lam3.real), np.sort(lam.real), atol=1e-10) and max(res3) < 1e-10
+        assert all(E(lam3[i], X3[:, i]) < 1e-10 for i in range(2))
 
 
 def test_wep_linsolvers_oracle_small():
