@@ -469,13 +469,22 @@ class FactorizeLinSolver(LinSolver):
             return self._plan
         return None
 
+    _omega_log = None
+
     def blind_plan_recorded(self):
         """refinement sweeps of the next solve of a step that RECORDS omega of every iterate (nep_iar_step): the settled
         count once a record has been reviewed, the maximum before"""
         if self.umfpack_refinements <= 0:
             return 0
-        # the record holds omega of x_0..x_3; two sweeps to start with (gun needs one), a rule that asks for more is a miss
-        return min(self.umfpack_refinements, 2) if self._recorded_plan is None else self._recorded_plan
+        # the record holds omega of x_0..x_3; two sweeps to start with (gun needs one), a rule that asks for more is a miss.
+        # A solver of a NEP whose previous solver settled on a count starts with that count (nep._refine_hint: iar issues
+        # all its steps before the first record is reviewed, so without the hint every step of every run takes the two
+        # sweeps; gun: omega(x_1) <= 1.7 eps in every step of every run, one sweep, 46 us less per step); a wrong hint is a
+        # miss like any other, and a miss withdraws it.  NEP_REFINE_HINT=0 turns it off.
+        if self._recorded_plan is not None:
+            return self._recorded_plan
+        hint = getattr(self.nep, "_refine_hint", None) if os.environ.get("NEP_REFINE_HINT", "1") != "0" else None
+        return min(self.umfpack_refinements, 2 if hint is None else hint)
 
     def review_recorded(self, w, plan):
         """UMFPACK's stopping rule (the loop of solve_dev) replayed on the recorded omegas w[0..plan] of a solve that took
@@ -483,6 +492,8 @@ class FactorizeLinSolver(LinSolver):
         good; False: the checked loop would have continued, or would have taken a worsening sweep back."""
         umf = self.umfpack_refinements
         w = [float(x) for x in w[:plan + 1]]
+        if FactorizeLinSolver._omega_log is not None:       # diagnostics (scripts/diag/iar_omega_log.py)
+            FactorizeLinSolver._omega_log.append(w)
         w_prev = np.inf; ret = None
         for step in range(umf + 1):
             if step > plan:
@@ -492,6 +503,7 @@ class FactorizeLinSolver(LinSolver):
                 if np.isfinite(w[plan]) and w[plan] <= 4.0 * EPS:
                     ret = plan
                     break
+                self._note_hint(None)
                 return False
             omega = w[step]
             if omega <= 2.0 * EPS:
@@ -509,9 +521,15 @@ class FactorizeLinSolver(LinSolver):
         # block schedule comes on line (trsv_ml.hip: built behind the first solves), and a plan of 0 learnt before would
         # turn the first solve after it into a miss (a full re-run of the call)
         self._recorded_plan = max(ret, 1)
-        if not np.isfinite(w[plan]):
-            return False
-        return ret == plan or w[plan] <= max(4.0 * EPS, w[ret])
+        ok = bool(np.isfinite(w[plan]) and (ret == plan or w[plan] <= max(4.0 * EPS, w[ret])))
+        self._note_hint(self._recorded_plan if ok else None)
+        return ok
+
+    def _note_hint(self, plan):
+        try:
+            self.nep._refine_hint = plan
+        except AttributeError:
+            pass
 
     def note_blind_solve(self, plan):
         self.solves += 1

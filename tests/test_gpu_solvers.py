@@ -148,6 +148,17 @@ def test_iar_recorded_refinement_and_miss_fallback(na, monkeypatch):
         for x, y in zip(a[:3], b[:3]):
             if x > 1e-12 and y > 1e-12:
                 assert 0.2 < x / y < 5
+    # (iii) the settled count travels with the NEP: the next solver starts with it (every step, not only the late ones)
+    assert nep._refine_hint == 1
+    del seen[:]
+    monkeypatch.setattr(FactorizeLinSolver, "review_recorded", spy)
+    l3, Q3, _ = na.iar(nep, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10)
+    assert len(seen) == m and all(ok and plan == 1 for plan, _, ok in seen)
+    _match(l3, l1, 1e-10)
+    monkeypatch.setenv("NEP_REFINE_HINT", "0")
+    del seen[:]
+    na.iar(nep, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10)
+    assert seen[0][0] == 2
 
 
 def test_iar_chebyshev_and_default_inner_solver(na):
