@@ -483,7 +483,7 @@ class FactorizeLinSolver(LinSolver):
         # miss like any other, and a miss withdraws it.  NEP_REFINE_HINT=0 turns it off.
         if self._recorded_plan is not None:
             return self._recorded_plan
-        hint = getattr(self.nep, "_refine_hint", None) if os.environ.get("NEP_REFINE_HINT", "1") != "0" else None
+        hint = getattr(getattr(self, "nep", None), "_refine_hint", None) if os.environ.get("NEP_REFINE_HINT", "1") != "0" else None
         return min(self.umfpack_refinements, 2 if hint is None else hint)
 
     def review_recorded(self, w, plan):
@@ -526,10 +526,12 @@ class FactorizeLinSolver(LinSolver):
         return ok
 
     def _note_hint(self, plan):
-        try:
-            self.nep._refine_hint = plan
-        except AttributeError:
-            pass
+        nep = getattr(self, "nep", None)
+        if nep is not None:
+            try:
+                nep._refine_hint = plan
+            except AttributeError:
+                pass
 
     def note_blind_solve(self, plan):
         self.solves += 1

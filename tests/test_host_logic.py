@@ -430,6 +430,17 @@ def test_recorded_refinement_rule_replay():
     assert not s.review_recorded(np.array([1e-13, np.nan, 0.0, 0.0]), 1)
     s.umfpack_refinements = 0
     assert s.blind_plan_recorded() == 0
+    # the settled count travels with the NEP object: the next solver of the same NEP starts with it, a miss withdraws it
+    class _Nep: pass
+    nep = _Nep()
+    a = FactorizeLinSolver.__new__(FactorizeLinSolver); a.umfpack_refinements = 10; a._recorded_plan = None; a.last_omega = None; a.nep = nep
+    assert a.blind_plan_recorded() == 2
+    assert a.review_recorded(np.array([1e-13, 1e-16, 5e-17, 0.0]), 2) and nep._refine_hint == 1
+    b = FactorizeLinSolver.__new__(FactorizeLinSolver); b.umfpack_refinements = 10; b._recorded_plan = None; b.last_omega = None; b.nep = nep
+    assert b.blind_plan_recorded() == 1
+    assert not b.review_recorded(np.array([1e-9, 1e-12, 0.0, 0.0]), 1) and nep._refine_hint is None
+    c = FactorizeLinSolver.__new__(FactorizeLinSolver); c.umfpack_refinements = 10; c._recorded_plan = None; c.last_omega = None; c.nep = nep
+    assert c.blind_plan_recorded() == 2
 
 
 def test_hosteig_hessenberg_route():
