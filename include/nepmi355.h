@@ -371,6 +371,13 @@ int32_t nep_lu_factor_dev(nep_lu_refac* r, const nep_cdouble* h_Ax, int32_t expe
  * out[b] = NULL for a matrix whose factorisation was refused -- factorise that one on the host. */
 int32_t nep_lu_factor_dev_batch(nep_lu_refac* r, int32_t B, const nep_cdouble* h_Ax, int32_t expected_solves, double growth_limit,
                                 double* h_health, nep_cdouble* h_LUx_out, nep_lu** out, nep_stream stream);
+/* The same for matrices that are combinations of `mt` terms on the plan's pattern, A_b = sum_t h_Cf[b*mt + t] A_t
+ * (M(lam_b) = sum_t f_t(lam_b) A_t at the quadrature nodes of src/method_beyncontour.jl:89-94): d_D is a DEVICE array, nnz(A) x mt
+ * entry-major, with the values of every term scattered onto the union pattern (uploaded once per NEP); the B x nnz(A) value
+ * block is formed inside the scatter kernel instead of on the host. */
+int32_t nep_lu_factor_dev_batch_terms(nep_lu_refac* r, int32_t B, const nep_cdouble* d_D, int32_t mt, const nep_cdouble* h_Cf,
+                                      int32_t expected_solves, double growth_limit, double* h_health, nep_lu** out,
+                                      nep_stream stream);
 
 /* ---- one infinite-Arnoldi step as one call ------------------------------------------------------
  * replaces: the loop body of iar between two eigenvalue checks, src/method_iar.jl:94-109

@@ -111,6 +111,7 @@ class _NodeSolve:
         self.order = []
         self.next = 0
         self.pool = None
+        self._pattern = None  # csc pattern of M (all nodes share it) when the host path may seed a device plan
 
     def _build(self, host_future, dev):
         # host factors -> level analysis, upload, tail inverse (6 ms for gun): off the main thread, which only issues the
@@ -120,7 +121,9 @@ class _NodeSolve:
             F = host_future.result()
         except RuntimeError as e:
             raise np.linalg.LinAlgError("SingularException: " + str(e))
-        return DeviceLU(factors=F, expected_solves=1)
+        # (the first host factorisation of a pattern seeds its device-factorisation plan: the NEXT contour_beyn call on this
+        # pattern factorises all its nodes on the GPU in one batch)
+        return DeviceLU(factors=F, expected_solves=1, plan_pattern=self._pattern)
 
     def _submit_builds(self):
         # never more than AHEAD builds outstanding; submitted in node order by the consuming thread (no blocking
@@ -148,16 +151,24 @@ class _NodeSolve:
         # whose factorisation is refused with the stored pivot sequence take the host path below
         self.ready = {}
         ts_host = list(ts)
-        if (_DeviceRefactor.enabled() and hasattr(self.nep, "compute_Mder_batch") and c.permc_spec is None and not c.lu_kw
+        if (_DeviceRefactor.enabled() and hasattr(self.nep, "aligned_terms_dev") and c.permc_spec is None and not c.lu_kw
                 and not os.environ.get("NEP_BEYN_HOST_LU")):
-            mb = self.nep.compute_Mder_batch([self.g(t) + self.sigma for t in ts])
-            if mb is not None:
-                import scipy.sparse as sp_
-                indptr, indices, vals = mb
-                A0 = sp_.csc_matrix((vals[0], indices, indptr), shape=(self.nep.n, self.nep.n))
+            al = self.nep.aligned_terms_dev()
+            if al is not None:
+                indptr, indices, D_dev, G = al
+
+                class _Pattern:             # what _DeviceRefactor.key / maybe_start read of a csc matrix
+                    pass
+                A0 = _Pattern(); A0.indptr = indptr; A0.indices = indices; A0.shape = (self.nep.n, self.nep.n)
                 plan = _DeviceRefactor.lookup(_DeviceRefactor.key(A0, (None, None, None)))
+                if plan is None:
+                    self._pattern = A0
                 if plan is not None:
-                    lus = _DeviceRefactor.factor_batch(plan, self.nep.n, vals, expected_solves=1)
+                    # M(lam_b) = sum_t f_t(lam_b) A_t: only the B x m_t coefficients travel, the values are formed on the GPU
+                    fv = self.nep.get_fv()
+                    Cf = np.array([[f.derivs(self.g(t) + self.sigma, 1)[0] for f in fv] for t in ts], dtype=np.complex128)
+                    normA = np.sqrt(np.maximum(np.einsum("bs,st,bt->b", Cf.conj(), G, Cf).real, 0.0))
+                    lus = _DeviceRefactor.factor_batch_terms(plan, self.nep.n, D_dev, Cf, normA, expected_solves=1)
                     ts_host = []
                     for t, lu in zip(ts, lus):
                         if lu is None:

@@ -78,6 +78,22 @@ __global__ void k_lu_init(int64_t nF, int64_t n, int64_t nnzA, const int32_t* __
     if (i == 0) { health[0] = 0.0; health[1] = 0.0; health[2] = 0.0; }
 }
 
+// the same with the values of matrix b assembled on the fly, A_b = sum_t Cf[b,t] A_t on the union pattern (D[e*mt + t] = value of
+// term t at entry e): the B x nnz(A) value block of a contour_beyn batch is neither formed on the host nor uploaded
+__global__ void k_lu_init_terms(int64_t nF, int64_t n, int64_t nnzA, const int32_t* __restrict__ amap, const cplx* __restrict__ D,
+                                int mt, const cplx* __restrict__ Cf, const int32_t* __restrict__ ldiag, cplx* __restrict__ F,
+                                double* __restrict__ health) {
+    F += (int64_t)blockIdx.y * nF; Cf += (int64_t)blockIdx.y * mt; health += 3 * (int64_t)blockIdx.y;
+    const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (i < nnzA) {
+        cplx acc = cmake(0.0, 0.0);
+        for (int t = 0; t < mt; ++t) cfma(acc, D[i * mt + t], Cf[t]);
+        F[amap[i]] = acc;
+    }
+    if (i < n) F[ldiag[i]] = cmake(1.0, 0.0);
+    if (i == 0) { health[0] = 0.0; health[1] = 0.0; health[2] = 0.0; }
+}
+
 // G lanes per destination entry of the level: F[dst] -= sum_products L * U   (sources final: lower levels are done).  Lane g
 // takes products g, g + G, ...; the G partial sums are combined by a fixed shuffle tree, so the result does not depend on
 // anything but G (segments of the top levels hold thousands of products: one thread per segment left most lanes idle)
@@ -516,30 +532,54 @@ int32_t nep_lu_factor_dev(nep_lu_refac* r, const nep_cdouble* h_Ax, int32_t expe
 // launch of the factorisation carries all B matrices, so the 64 nodes of config C4 cost about as many launches as one.
 // h_Ax: B x nnzA values; h_health: B x 3 (required); out[b] = NULL for a matrix whose factorisation was refused (pivot
 // breakdown / growth): the caller factorises that one on the host.  h_LUx_out (may be NULL): B x (nnzL + nnzU).
+static int32_t lu_factor_batch_impl(nep_lu_refac* r, int32_t B, const nep_cdouble* h_Ax, const nep_cdouble* d_D, int32_t mt,
+                                    const nep_cdouble* h_Cf, int32_t expected_solves, double growth_limit, double* h_health,
+                                    nep_cdouble* h_LUx_out, nep_lu** out, nep_stream stream);
 int32_t nep_lu_factor_dev_batch(nep_lu_refac* r, int32_t B, const nep_cdouble* h_Ax, int32_t expected_solves, double growth_limit,
                                 double* h_health, nep_cdouble* h_LUx_out, nep_lu** out, nep_stream stream) {
     ARGCHK(r && h_Ax && out && h_health && B >= 1);
+    return lu_factor_batch_impl(r, B, h_Ax, nullptr, 0, nullptr, expected_solves, growth_limit, h_health, h_LUx_out, out, stream);
+}
+// The same for matrices given as combinations of `mt` terms on the plan's pattern, A_b = sum_t h_Cf[b*mt + t] A_t: d_D (DEVICE,
+// nnz(A) x mt, entry-major) holds the term values scattered onto the union pattern -- uploaded once per NEP -- and the values of
+// the B matrices are formed inside the scatter kernel (src/method_beyncontour.jl:89-94: M(lam_b) = sum_t f_t(lam_b) A_t)
+int32_t nep_lu_factor_dev_batch_terms(nep_lu_refac* r, int32_t B, const nep_cdouble* d_D, int32_t mt, const nep_cdouble* h_Cf,
+                                      int32_t expected_solves, double growth_limit, double* h_health, nep_lu** out,
+                                      nep_stream stream) {
+    ARGCHK(r && d_D && h_Cf && out && h_health && B >= 1 && mt >= 1);
+    return lu_factor_batch_impl(r, B, nullptr, d_D, mt, h_Cf, expected_solves, growth_limit, h_health, nullptr, out, stream);
+}
+static int32_t lu_factor_batch_impl(nep_lu_refac* r, int32_t B, const nep_cdouble* h_Ax, const nep_cdouble* d_D, int32_t mt,
+                                    const nep_cdouble* h_Cf, int32_t expected_solves, double growth_limit, double* h_health,
+                                    nep_cdouble* h_LUx_out, nep_lu** out, nep_stream stream) {
     for (int b = 0; b < B; ++b) out[b] = nullptr;
     hipStream_t st = as_stream(stream);
     const int64_t nF = r->nnzL + r->nnzU;
     cplx* dF = nullptr; cplx* dA = nullptr; double* dH = nullptr;
     int rc;
     if ((rc = nep_pool_alloc((void**)&dF, (size_t)B * nF * sizeof(cplx) + (size_t)B * 24 + 64))) return rc;
-    if ((rc = nep_pool_alloc((void**)&dA, (size_t)B * r->nnzA * sizeof(cplx) + 64))) { nep_pool_free(dF); return rc; }
+    // dA: the B x nnz(A) values, or (terms form) the B x mt coefficients
+    const size_t a_bytes = h_Ax ? (size_t)B * r->nnzA * sizeof(cplx) : (size_t)B * mt * sizeof(cplx);
+    if ((rc = nep_pool_alloc((void**)&dA, a_bytes + 64))) { nep_pool_free(dF); return rc; }
     dH = (double*)((char*)dF + (size_t)B * nF * sizeof(cplx));
     auto fail = [&](int code) { nep_pool_free_on(dF, st, true); nep_pool_free_on(dA, st, true); return code; };
     static thread_local PinnedRing ring;
     {   // in pieces of at most 8 MiB: the ring's pinned slots stay small (a 90 MB slot for 64 nodes costs ~30 ms to pin)
-        const size_t total = (size_t)B * r->nnzA * sizeof(cplx), piece = (size_t)8 << 20;
+        const char* srcp = h_Ax ? (const char*)h_Ax : (const char*)h_Cf;
+        const size_t total = a_bytes, piece = (size_t)8 << 20;
         for (size_t off = 0; off < total; off += piece)
-            if ((rc = ring.upload((char*)dA + off, (const char*)h_Ax + off, std::min(piece, total - off), st))) return fail(rc);
+            if ((rc = ring.upload((char*)dA + off, srcp + off, std::min(piece, total - off), st))) return fail(rc);
     }
     HIPCHK(hipMemsetAsync(dF, 0, (size_t)B * nF * sizeof(cplx), st));
     const unsigned gy = (unsigned)B;
     {
         const int64_t m = std::max<int64_t>(r->nnzA, r->n);
-        hipLaunchKernelGGL(k_lu_init, dim3((unsigned)((m + 255) / 256), gy), dim3(256), 0, st, nF, r->n, r->nnzA, (const int32_t*)r->d_amap,
-                           (const cplx*)dA, (const int32_t*)r->d_ldiag, dF, dH);
+        if (h_Ax)
+            hipLaunchKernelGGL(k_lu_init, dim3((unsigned)((m + 255) / 256), gy), dim3(256), 0, st, nF, r->n, r->nnzA, (const int32_t*)r->d_amap,
+                               (const cplx*)dA, (const int32_t*)r->d_ldiag, dF, dH);
+        else
+            hipLaunchKernelGGL(k_lu_init_terms, dim3((unsigned)((m + 255) / 256), gy), dim3(256), 0, st, nF, r->n, r->nnzA,
+                               (const int32_t*)r->d_amap, (const cplx*)d_D, (int)mt, (const cplx*)dA, (const int32_t*)r->d_ldiag, dF, dH);
         LAUNCHCHK();
     }
     for (int l = 0; l < r->nlev; ++l) {

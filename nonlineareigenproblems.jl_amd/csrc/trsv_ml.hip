@@ -44,6 +44,7 @@ struct MLFacSym {
     int32_t* d_slotrow = nullptr;  // n    slot -> local row
     int32_t* d_lvp = nullptr;      //      in-block level pointers (slot positions), block k: [lvo[k], lvo[k+1])
     int32_t* d_lvo = nullptr;      // nblk+1
+    int32_t* d_rowlev = nullptr;   // n    in-block level of every row (k_ml_inverse starts column j at the level of row j)
     // host
     std::vector<int32_t> map;      // input entry -> slot*4 + kind   (kind 0 skip, 1 coupling, 2 in-block, 3 diagonal)
     int32_t* d_map = nullptr;      // the same on the device (uploaded on first use by the device-side numeric path)
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(256) void k_ml_inverse(const int32_t* __restrict__ 
                                                     const int32_t* __restrict__ slotrow, const int32_t* __restrict__ bp,
                                                     const int32_t* __restrict__ bi, const cplx* __restrict__ bx,
                                                     const cplx* __restrict__ diag, const int64_t* __restrict__ ip,
-                                                    cplx* __restrict__ ix) {
+                                                    cplx* __restrict__ ix, const int32_t* __restrict__ rowlev) {
     __shared__ cplx x[ML_BMAX];
     const int q = blockIdx.x;
     const int k = rowblk[q];
@@ -134,7 +135,11 @@ __global__ __launch_bounds__(256) void k_ml_inverse(const int32_t* __restrict__ 
     __syncthreads();
     const int l0 = lvo[k], nlev = lvo[k + 1] - l0 - 1;
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    for (int lev = UPPER ? 0 : 1; lev < nlev; ++lev) {          // level 0 of a unit-lower block needs no work
+    // column j of the inverse is zero in every row that does not depend on row j, i.e. in all rows of lower in-block levels
+    // (and, for the unit-lower factor, of row j's own level): the substitution starts at the level of row j -- half of the
+    // levels of a dense block on average -- and leaves bit-identical values (the skipped rows computed 0 - 0)
+    const int lstart = UPPER ? rowlev[q] : rowlev[q] + 1;
+    for (int lev = lstart; lev < nlev; ++lev) {
         const int s0 = lvp[l0 + lev], s1 = lvp[l0 + lev + 1];
         for (int sl0 = s0; sl0 < s1; sl0 += 16) {
             const int sl = sl0 + grp;
@@ -475,7 +480,7 @@ int up(T** d, const std::vector<T>& h, size_t min_count = 1) {
 
 void free_fac(MLFacSym& f) {
     nep_pool_free(f.d_cp); nep_pool_free(f.d_ci); nep_pool_free(f.d_ip); nep_pool_free(f.d_bp); nep_pool_free(f.d_bi);
-    nep_pool_free(f.d_slotrow); nep_pool_free(f.d_lvp); nep_pool_free(f.d_lvo); nep_pool_free(f.d_chunks);
+    nep_pool_free(f.d_slotrow); nep_pool_free(f.d_lvp); nep_pool_free(f.d_lvo); nep_pool_free(f.d_rowlev); nep_pool_free(f.d_chunks);
     if (f.d_map) nep_pool_free(f.d_map);
 }
 void free_sym(MLSym* s) {
@@ -639,6 +644,10 @@ int build_factor(const MLSym& S, bool upper, const int32_t* rp, const int32_t* c
     if ((rc = up(&F.d_slotrow, slotrow))) return rc;
     if ((rc = up(&F.d_lvp, lvp))) return rc;
     if ((rc = up(&F.d_lvo, lvo))) return rc;
+    {
+        std::vector<int32_t> rl(lvl_in.begin(), lvl_in.end());
+        if ((rc = up(&F.d_rowlev, rl))) return rc;
+    }
     if ((rc = up(&F.d_chunks, chunks))) return rc;
     return NEP_OK;
 }
@@ -840,12 +849,12 @@ static int ml_numeric(MLFactor* F, const nep_cdouble* Lx, const nep_cdouble* Ux)
     hipLaunchKernelGGL((k_ml_inverse<false>), dim3((unsigned)n), dim3(256), 0, bst, (const int32_t*)S->d_rowblk,
                        (const int32_t*)S->d_blk_se, (const int32_t*)S->L.d_lvo, (const int32_t*)S->L.d_lvp,
                        (const int32_t*)S->L.d_slotrow, (const int32_t*)S->L.d_bp, (const int32_t*)S->L.d_bi,
-                       (const cplx*)(F->d_vals + oLb), (const cplx*)nullptr, (const int64_t*)S->L.d_ip, F->d_ixL);
+                       (const cplx*)(F->d_vals + oLb), (const cplx*)nullptr, (const int64_t*)S->L.d_ip, F->d_ixL, (const int32_t*)S->L.d_rowlev);
     LAUNCHCHK();
     hipLaunchKernelGGL((k_ml_inverse<true>), dim3((unsigned)n), dim3(256), 0, bst, (const int32_t*)S->d_rowblk,
                        (const int32_t*)S->d_blk_se, (const int32_t*)S->U.d_lvo, (const int32_t*)S->U.d_lvp,
                        (const int32_t*)S->U.d_slotrow, (const int32_t*)S->U.d_bp, (const int32_t*)S->U.d_bi,
-                       (const cplx*)(F->d_vals + oUb), (const cplx*)(F->d_vals + oD), (const int64_t*)S->U.d_ip, F->d_ixU);
+                       (const cplx*)(F->d_vals + oUb), (const cplx*)(F->d_vals + oD), (const int64_t*)S->U.d_ip, F->d_ixU, (const int32_t*)S->U.d_rowlev);
     LAUNCHCHK();
     if ((rc = ml_finish_numeric(F, bst))) return rc;
     return NEP_OK;
@@ -965,12 +974,12 @@ static int ml_numeric_dev(MLFactor* F, const cplx* d_Lx, const cplx* d_Ux, hipSt
     hipLaunchKernelGGL((k_ml_inverse<false>), dim3((unsigned)n), dim3(256), 0, bst, (const int32_t*)S->d_rowblk,
                        (const int32_t*)S->d_blk_se, (const int32_t*)S->L.d_lvo, (const int32_t*)S->L.d_lvp,
                        (const int32_t*)S->L.d_slotrow, (const int32_t*)S->L.d_bp, (const int32_t*)S->L.d_bi,
-                       (const cplx*)(F->d_vals + oLb), (const cplx*)nullptr, (const int64_t*)S->L.d_ip, F->d_ixL);
+                       (const cplx*)(F->d_vals + oLb), (const cplx*)nullptr, (const int64_t*)S->L.d_ip, F->d_ixL, (const int32_t*)S->L.d_rowlev);
     LAUNCHCHK();
     hipLaunchKernelGGL((k_ml_inverse<true>), dim3((unsigned)n), dim3(256), 0, bst, (const int32_t*)S->d_rowblk,
                        (const int32_t*)S->d_blk_se, (const int32_t*)S->U.d_lvo, (const int32_t*)S->U.d_lvp,
                        (const int32_t*)S->U.d_slotrow, (const int32_t*)S->U.d_bp, (const int32_t*)S->U.d_bi,
-                       (const cplx*)(F->d_vals + oUb), (const cplx*)(F->d_vals + oD), (const int64_t*)S->U.d_ip, F->d_ixU);
+                       (const cplx*)(F->d_vals + oUb), (const cplx*)(F->d_vals + oD), (const int64_t*)S->U.d_ip, F->d_ixU, (const int32_t*)S->U.d_rowlev);
     LAUNCHCHK();
     if ((rc = ml_finish_numeric(F, bst))) return rc;
     return NEP_OK;

@@ -47,9 +47,13 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     try:
         return _iar(nep, **kw)
     except _RefinementMiss:          # never observed; the checked path decides every refinement on the host
+        iar.refinement_misses += 1
         if errhist is not None:
             del errhist[:]
         return _iar(nep, _native_step=False, **kw)
+
+
+iar.refinement_misses = 0            # calls that were re-run with checked solves (diagnostics, tests)
 
 
 def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,

@@ -137,7 +137,8 @@ class _DeviceRefactor:
     def key(cls, Ac, opts):
         import hashlib
         h = hashlib.blake2b(digest_size=16)
-        h.update(np.ascontiguousarray(Ac.indptr)); h.update(np.ascontiguousarray(Ac.indices))
+        # (index dtype normalised: the same pattern arrives as int32 from scipy and as int64 from the NEP's aligned terms)
+        h.update(np.ascontiguousarray(Ac.indptr, dtype=np.int64)); h.update(np.ascontiguousarray(Ac.indices, dtype=np.int64))
         knobs = tuple(os.environ.get(k) for k in ("NEP_ML_BMAX", "NEP_ML_SPLIT", "NEP_ML_CHUNK"))   # they change the partition
         return (h.digest(), Ac.shape, opts, knobs)
 
@@ -210,6 +211,29 @@ class _DeviceRefactor:
         return res
 
     @classmethod
+    def factor_batch_terms(cls, plan, n, D_dev, Cf, normA, expected_solves=1):
+        """the same for B matrices A_b = sum_t Cf[b, t] A_t whose term values sit on the device (D_dev: nnz x m_t, the union
+        pattern of the plan): nothing of size B x nnz is formed on the host or uploaded.  normA: the B Frobenius norms."""
+        Cf = np.ascontiguousarray(Cf, dtype=np.complex128)
+        B, mt = Cf.shape
+        assert D_dev.is_contiguous() and D_dev.shape[1] == mt
+        health = np.zeros((B, 3))
+        outs = (c_vp * B)()
+        check(lib.nep_lu_set_expected_solves(int(expected_solves)))
+        check(lib.nep_lu_factor_dev_batch_terms(plan["handle"], B, c_vp(D_dev.data_ptr()), mt, hptr(Cf), int(expected_solves), cls.GROWTH,
+                                                hptr(health), outs, stream_ptr()))
+        res = []
+        for b in range(B):
+            if not outs[b]:
+                plan["fails"] += 1
+                res.append(None)
+                continue
+            plan["uses"] += 1
+            res.append(DeviceLU._from_handle(c_vp(outs[b]), n, float(normA[b]),
+                                             dict(plan["strategy"], numeric="device (stored pivot sequence, batched)"), float(health[b, 1])))
+        return res
+
+    @classmethod
     def wait(cls):
         """block until every plan under construction is finished (tests, benchmarks)"""
         for p in list(cls.plans.values()):
@@ -242,11 +266,19 @@ class DeviceLU:
     worker) skips the host factorisation."""
 
     def __init__(self, A=None, permc_spec=None, diag_pivot_thresh=None, symmetric_mode=None, expected_solves=50,
-                 factors=None):
+                 factors=None, plan_pattern=None):
+        """plan_pattern (with `factors`): the csc pattern these host factors belong to -- lets a factorisation that was
+        computed elsewhere (contour_beyn's worker processes) seed the pattern's device-factorisation plan"""
         _lib.require_gpu()
         t0 = time.perf_counter()
         self.device_factorized = False
         rkey = None; Ac = None
+        if factors is not None and plan_pattern is not None and _DeviceRefactor.enabled():
+            k0 = _DeviceRefactor.key(plan_pattern, (permc_spec, diag_pivot_thresh, symmetric_mode))
+            with _DeviceRefactor.lock:
+                known = k0 in _DeviceRefactor.plans
+            if not known:
+                rkey = k0; Ac = plan_pattern
         if factors is None:
             Ac = sp.csc_matrix(A, dtype=np.complex128)
             if _DeviceRefactor.enabled():
@@ -278,15 +310,19 @@ class DeviceLU:
             create = lib.nep_lu_create_csc if F.get("fmt", "csr") == "csc" else lib.nep_lu_create
             check(create(n, hptr(Lp), hptr(Li), hptr(Lx), hptr(Up), hptr(Ui), hptr(Ux), hptr(pr), hptr(pc), C.byref(h)))
         finally:
+            Fplan = F
             if shm_backed:
+                if rkey is not None:        # the plan builder reads the index arrays after the shared block is gone
+                    Fplan = {k: (np.array(F[k], copy=True) if k in ("Lp", "Li", "Up", "Ui", "perm_r", "perm_c") else F[k])
+                             for k in ("Lp", "Li", "Up", "Ui", "perm_r", "perm_c", "fmt", "strategy", "n") if k in F}
                 del Lp, Li, Lx, Up, Ui, Ux, pr, pc
                 _nep_hostlu.release_shm(F)
         self.h = h
         self.t_create = time.perf_counter() - t_b
         self._describe()
         self.t_setup = time.perf_counter() - t0
-        if rkey is not None and not shm_backed:
-            _DeviceRefactor.maybe_start(rkey, self, F, Ac)
+        if rkey is not None:
+            _DeviceRefactor.maybe_start(rkey, self, Fplan, Ac)
 
     @classmethod
     def _from_handle(cls, h, n, normA, strategy, growth):

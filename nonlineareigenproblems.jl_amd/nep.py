@@ -364,6 +364,19 @@ class AbstractSPMF(NEP):
         Cf = np.array([[f.derivs(lam, 1)[0] for f in fv] for lam in lams], dtype=np.complex128)      # B x m_t
         return indptr, indices, np.ascontiguousarray(np.einsum("ij,bj->bi", D, Cf))
 
+    def aligned_terms_dev(self):
+        """(indptr, indices, D_dev, G) for the device-side assembly of M(lam_b) batches (nep_lu_factor_dev_batch_terms): D_dev is
+        the nnz x m_t term-value block on the union pattern as a DEVICE tensor (uploaded once), G = D^H D its m_t x m_t Gram
+        matrix (||M(lam)||_F^2 = c^H G c without forming M); None when a term is dense"""
+        al = self._aligned_terms()
+        if al is None:
+            return None
+        if getattr(self, "_aligned_dev", None) is None:
+            indptr, indices, D = al
+            Dc = np.ascontiguousarray(D, dtype=np.complex128)
+            self._aligned_dev = (torch.from_numpy(Dc).to("cuda"), Dc.conj().T @ Dc)
+        return al[0], al[1], self._aligned_dev[0], self._aligned_dev[1]
+
     def _aligned_terms(self):
         """(indptr, indices, D) with D[:, t] = values of A_t scattered onto the union CSC pattern of all terms, or None if a
         term is dense"""

@@ -470,6 +470,28 @@ def test_beyn_gun_twin_vs_oracle(na):
     assert max(oE(lg[i], Vg[:, i]) for i in range(len(lg))) < 1e-6
 
 
+def test_beyn_first_call_seeds_the_device_plan(na):
+    """a process that ONLY runs contour_beyn: the first call factorises its nodes in the host workers and the first of those
+    factorisations seeds the pattern's device-factorisation plan; the second call factorises all nodes on the GPU in one
+    batch and returns the same eigenvalues"""
+    from nep_amd.linsolvers import _DeviceRefactor
+    if not _DeviceRefactor.enabled():
+        pytest.skip("device numeric factorisation switched off")
+    n, k, N = 1310, 16, 16
+    nep = na.nep_gallery("gun_spmf", n)
+    Vh = na.probe_block(n, k)
+    kw = dict(sigma=250.0 ** 2, radius=1.2e4, N=N, k=k, neigs=10 ** 6, tol=1e-6)
+    _DeviceRefactor.clear()
+    l1, V1 = na.contour_beyn(nep, Vh=Vh, **kw)
+    _DeviceRefactor.wait()
+    plans = [p for p in _DeviceRefactor.plans.values() if p["state"] == "ready"]
+    assert len(plans) == 1 and plans[0]["uses"] == 0
+    l2, V2 = na.contour_beyn(nep, Vh=Vh, **kw)
+    assert plans[0]["uses"] + plans[0]["fails"] == N and plans[0]["uses"] >= N - 2
+    assert len(l1) == len(l2) and len(l1) >= 1
+    _match(l2, l1, 1e-8)
+
+
 def test_block_SS_dep0_kat_and_gun_twin(na):
     """test/contour_block_SS.jl:9-24 on the device path (three variants), then a sparse gun twin against the oracle with
     the same probe blocks: same numerical rank, eigenvalues inside the contour agree to 1e-7 relative."""
@@ -1082,3 +1104,38 @@ def test_nleigs_custom_nep_type(na):
     for i in range(len(l2)):
         M = A0 + l2[i] * A1 + l2[i] ** 2 * A2
         assert np.linalg.norm(M @ X2[:, i]) / np.linalg.norm(X2[:, i]) < 1e-8
+
+
+def test_lu_batch_from_terms_equals_batch_from_values(na):
+    """nep_lu_factor_dev_batch_terms (values of M(lam_b) = sum_t f_t(lam_b) A_t formed inside the scatter kernel from the
+    device-resident term block) against nep_lu_factor_dev_batch on host-assembled values: same solves to round-off, and
+    both against the host factorisation"""
+    from nep_amd.linsolvers import _DeviceRefactor, DeviceLU
+    if not _DeviceRefactor.enabled():
+        pytest.skip("device numeric factorisation switched off")
+    import torch
+    n = 1310
+    nep = na.nep_gallery("gun_spmf", n)
+    lams = [250.0 ** 2 + 1.2e4 * np.exp(2j * np.pi * (j + 0.5) / 6) for j in range(6)]
+    _DeviceRefactor.clear()
+    A0 = sp.csc_matrix(nep.compute_Mder(lams[0]), dtype=np.complex128)
+    DeviceLU(A0)                                           # host factorisation, seeds the plan
+    _DeviceRefactor.wait()
+    indptr, indices, D_dev, G = nep.aligned_terms_dev()
+    plan = _DeviceRefactor.lookup(_DeviceRefactor.key(A0, (None, None, None)))
+    assert plan is not None
+    _, _, vals = nep.compute_Mder_batch(lams)
+    Cf = np.array([[f.derivs(l, 1)[0] for f in nep.get_fv()] for l in lams], dtype=np.complex128)
+    normA = np.sqrt(np.einsum("bs,st,bt->b", Cf.conj(), G, Cf).real)
+    assert np.allclose(normA, np.linalg.norm(vals, axis=1), rtol=1e-12)
+    la = _DeviceRefactor.factor_batch(plan, n, vals)
+    lb = _DeviceRefactor.factor_batch_terms(plan, n, D_dev, Cf, normA)
+    rng = np.random.default_rng(3)
+    b = rng.standard_normal((4, n)) + 1j * rng.standard_normal((4, n))
+    bd = torch.from_numpy(b).to("cuda")
+    for j, lam in enumerate(lams):
+        assert la[j] is not None and lb[j] is not None
+        xa = la[j].solve(bd).cpu().numpy(); xb = lb[j].solve(bd).cpu().numpy()
+        M = nep.compute_Mder(lam)
+        assert np.abs(xa - xb).max() <= 1e-10 * np.abs(xa).max()
+        assert np.linalg.norm(M @ xb.T - b.T) <= 1e-8 * np.linalg.norm(b)
