@@ -363,6 +363,12 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
                             const int32_t* perm_r, const int32_t* perm_c, const int32_t* Ap, const int32_t* Ai,
                             nep_lu_refac** out);
 int32_t nep_lu_refac_destroy(nep_lu_refac* r);
+/* Host-only analysis of a plan (no device is touched): symbolic partition + the complete enumeration of nep_lu_refac_create with
+ * the plan arrays hashed instead of uploaded.  out[0] = products, [1] internal, [2] external, [3] external destination segments,
+ * [4] wide, [5] wide pivot steps, [6] levels, [7] hash of the plan arrays (independent of NEP_LU_PLAN_THREADS).  Sanitizer
+ * build (tests/sanitize) and thread-count invariance test. */
+int32_t nep_lu_refac_analyze(int64_t n, const int32_t* Lp, const int32_t* Li, const int32_t* Up, const int32_t* Ui,
+                             const int32_t* perm_r, const int32_t* perm_c, const int32_t* Ap, const int32_t* Ai, int64_t out[8]);
 /* out[0..5] = n, products, internal products, external products, external destination segments, symbolic time in ms */
 int32_t nep_lu_refac_info(const nep_lu_refac* r, int64_t out[6]);
 int32_t nep_lu_factor_dev(nep_lu_refac* r, const nep_cdouble* h_Ax, int32_t expected_solves, double growth_limit,

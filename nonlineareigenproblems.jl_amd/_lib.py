@@ -108,6 +108,7 @@ SIGNATURES = {
     "nep_lu_refac_destroy": [c_vp],
     "nep_lu_refac_info": [c_vp, c_vp],
     "nep_lu_factor_dev": [c_vp, c_vp, c_i32, C.c_double, c_vp, c_vp, c_vp, c_vp],
+    "nep_lu_refac_analyze": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "nep_lu_factor_dev_batch": [c_vp, c_i32, c_vp, c_i32, C.c_double, c_vp, c_vp, c_vp, c_vp],
     "nep_lu_factor_dev_batch_terms": [c_vp, c_i32, c_vp, c_i32, c_vp, c_i32, C.c_double, c_vp, c_vp, c_vp],
     "nep_iar_step": [c_vp, c_i32, c_i32, c_vp],

@@ -35,6 +35,7 @@ MLFactor* nep_lu_ml(nep_lu* lu);
 nep_lu* nep_lu_wrap_ml(MLFactor* F, int64_t n, int64_t nnzL, int64_t nnzU);
 
 struct nep_lu_refac {
+    bool host_only = false;          // nep_lu_refac_analyze: S is a host-only analysis owned by this object
     MLSym* S = nullptr;
     int64_t n = 0, nnzL = 0, nnzU = 0, nnzA = 0, nprod = 0;
     int nlev = 0, nblk = 0;
@@ -210,8 +211,21 @@ namespace {
 
 double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
+// dry run (nep_lu_refac_analyze): nothing goes to the device, the arrays are folded into a hash instead -- the plan must not
+// depend on the number of enumeration threads
+thread_local bool g_refac_dry = false;
+thread_local uint64_t g_refac_hash = 0;
 template <class T>
 int upv(T** d, const std::vector<T>& h) {
+    if (g_refac_dry) {
+        uint64_t x = g_refac_hash ^ (0x9E3779B97F4A7C15ull * (h.size() + 1));
+        const unsigned char* b = (const unsigned char*)h.data();
+        for (size_t i = 0; i < h.size() * sizeof(T); ++i) { x ^= b[i]; x *= 0x100000001B3ull; }
+        g_refac_hash = x;
+        if (getenv("NEP_REFAC_DEBUG")) fprintf(stderr, "[refac dry] array of %zu x %zu bytes -> running hash %016llx\n", h.size(), sizeof(T), (unsigned long long)x);
+        *d = nullptr;
+        return NEP_OK;
+    }
     const size_t cnt = std::max<size_t>(h.size(), 1);
     int rc = nep_pool_alloc((void**)d, cnt * sizeof(T));
     if (rc) return rc;
@@ -227,6 +241,7 @@ extern "C" {
 
 int32_t nep_lu_refac_destroy(nep_lu_refac* r) {
     if (!r) return NEP_OK;
+    if (r->host_only) { if (r->S) ml_sym_free_host(r->S); delete r; return NEP_OK; }
     (void)hipDeviceSynchronize();
     nep_pool_free(r->d_amap); nep_pool_free(r->d_ldiag); nep_pool_free(r->d_udiag); nep_pool_free(r->d_Lp); nep_pool_free(r->d_Li);
     nep_pool_free(r->d_oldof); nep_pool_free(r->d_blk_se); nep_pool_free(r->d_piv_ptr); nep_pool_free(r->d_int);
@@ -240,6 +255,8 @@ int32_t nep_lu_refac_destroy(nep_lu_refac* r) {
 // Ap / Ai: CSC pattern of the matrices that will be factorised (caller's numbering); perm_r[i] / perm_c[j] = position of row
 // i / column j of A in the factored matrix (SuperLU's convention).  NEP_ERR_UNSUPPORTED: the stored pattern is not closed
 // under the elimination (an update has no slot) or the reference factor uses the level schedule.
+static int32_t refac_build(nep_lu_refac* r, int64_t n, const int32_t* Lp, const int32_t* Li, const int32_t* Up, const int32_t* Ui,
+                           const int32_t* perm_r, const int32_t* perm_c, const int32_t* Ap, const int32_t* Ai, nep_lu_refac** out);
 int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int32_t* Li, const int32_t* Up, const int32_t* Ui,
                             const int32_t* perm_r, const int32_t* perm_c, const int32_t* Ap, const int32_t* Ai,
                             nep_lu_refac** out) {
@@ -248,9 +265,39 @@ int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int
     ARGCHK(ref && Lp && Li && Up && Ui && perm_r && perm_c && Ap && Ai && n > 0);
     MLFactor* mf = nep_lu_ml(ref);
     if (!mf) { nep_set_error("device refactorisation needs the block schedule"); return NEP_ERR_UNSUPPORTED; }
-    const double t0 = now_ms();
     nep_lu_refac* r = new nep_lu_refac();
     r->S = ml_sym_acquire(mf);
+    return refac_build(r, n, Lp, Li, Up, Ui, perm_r, perm_c, Ap, Ai, out);
+}
+
+// Host-only analysis of a plan (no device is touched): the symbolic partition of the factors and the complete enumeration /
+// classification / placement of nep_lu_refac_create, with the arrays hashed instead of uploaded.  out[0] = products, [1]
+// internal, [2] external, [3] external destination segments, [4] wide, [5] wide steps, [6] levels, [7] hash of the plan arrays
+// (must not depend on NEP_LU_PLAN_THREADS).  For the sanitizer build and the thread-count invariance test.
+int32_t nep_lu_refac_analyze(int64_t n, const int32_t* Lp, const int32_t* Li, const int32_t* Up, const int32_t* Ui,
+                             const int32_t* perm_r, const int32_t* perm_c, const int32_t* Ap, const int32_t* Ai, int64_t out[8]) {
+    ARGCHK(Lp && Li && Up && Ui && perm_r && perm_c && Ap && Ai && out && n > 0 && n < ((int64_t)1 << 31));
+    ARGCHK(Lp[0] == 0 && Up[0] == 0 && Ap[0] == 0);
+    for (int64_t e = 0; e < Lp[n]; ++e) ARGCHK(Li[e] >= 0 && Li[e] < n);
+    for (int64_t e = 0; e < Up[n]; ++e) ARGCHK(Ui[e] >= 0 && Ui[e] < n);
+    nep_lu_refac* r = new nep_lu_refac();
+    r->host_only = true;
+    int rc = ml_sym_build_host(n, Lp, Li, Up, Ui, perm_r, perm_c, &r->S);
+    if (rc) { delete r; return rc; }
+    nep_lu_refac* res = nullptr;
+    g_refac_dry = true; g_refac_hash = 0xCBF29CE484222325ull;
+    rc = refac_build(r, n, Lp, Li, Up, Ui, perm_r, perm_c, Ap, Ai, &res);
+    g_refac_dry = false;
+    if (rc) return rc;                    // (refac_build released r)
+    out[0] = res->nprod; out[1] = res->nint; out[2] = res->next_; out[3] = res->nseg; out[4] = res->nwide;
+    out[5] = res->wstep0[res->nlev]; out[6] = res->nlev; out[7] = (int64_t)(g_refac_hash >> 1);
+    nep_lu_refac_destroy(res);
+    return NEP_OK;
+}
+
+static int32_t refac_build(nep_lu_refac* r, int64_t n, const int32_t* Lp, const int32_t* Li, const int32_t* Up, const int32_t* Ui,
+                           const int32_t* perm_r, const int32_t* perm_c, const int32_t* Ap, const int32_t* Ai, nep_lu_refac** out) {
+    const double t0 = now_ms();
     int64_t n2; int nlev, nblk; const int32_t *lvl, *blk, *oldof, *blk_se, *lev_blk;
     ml_sym_partition(r->S, &n2, &nlev, &nblk, &lvl, &blk, &oldof, &blk_se, &lev_blk);
     if (n2 != n) { nep_lu_refac_destroy(r); nep_set_error("refac: size mismatch"); return NEP_ERR_ARG; }

@@ -22,6 +22,9 @@ int ml_solve(MLFactor* F, int nrhs, const nep_cdouble* dB, int64_t ldb, const ne
 struct MLSym;
 MLSym* ml_sym_acquire(MLFactor* F);                 // takes a reference
 void ml_sym_release_ref(MLSym* S);
+int ml_sym_build_host(int64_t n, const int32_t* Lp, const int32_t* Li, const int32_t* Up, const int32_t* Ui, const int32_t* perm_r,
+                      const int32_t* perm_c, MLSym** out);      // host-only analysis of CSC factors (no device)
+void ml_sym_free_host(MLSym* S);
 // partition in the factor's input numbering: level and block of every pivot, the pivots in schedule order (oldof), the
 // block boundaries in that order (blk_se[2k], blk_se[2k+1]) and the block range of every level (lev_blk[l], lev_blk[l+1])
 void ml_sym_partition(const MLSym* S, int64_t* n, int* nlev, int* nblk, const int32_t** lvl, const int32_t** blk,

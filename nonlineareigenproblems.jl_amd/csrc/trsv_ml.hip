@@ -1044,6 +1044,24 @@ int ml_analyze(int64_t n, int csc, const int32_t* Lp, const int32_t* Li, const i
     return rc;
 }
 
+// host-only symbolic analysis of CSC factors (no device): the partition a plan of csrc/lufac.hip is built on
+// (nep_lu_refac_analyze).  The caller owns the result and frees it with ml_sym_free_host.
+int ml_sym_build_host(int64_t n, const int32_t* Lp, const int32_t* Li, const int32_t* Up, const int32_t* Ui, const int32_t* perm_r,
+                      const int32_t* perm_c, MLSym** out) {
+    *out = nullptr;
+    MLSym* S = new MLSym();
+    g_ml_dry = true;
+    std::vector<int32_t> Lrp, Lci, Lsrc, Urp, Uci, Usrc;
+    transpose_pattern(n, Lp, Li, Lrp, Lci, &Lsrc);
+    transpose_pattern(n, Up, Ui, Urp, Uci, &Usrc);
+    const int rc = build_symbolic(S, n, Lrp.data(), Lci.data(), Lsrc.data(), Urp.data(), Uci.data(), Usrc.data(), Up, Ui, perm_r, perm_c);
+    g_ml_dry = false;
+    if (rc) { delete S; return rc; }
+    *out = S;
+    return NEP_OK;
+}
+void ml_sym_free_host(MLSym* S) { delete S; }
+
 int ml_set_row_scale(MLFactor* F, const double* h_rs) {
     const int64_t n = F->sym->n;
     if (!h_rs) { if (F->d_rscale) nep_pool_free(F->d_rscale); F->d_rscale = nullptr; return NEP_OK; }

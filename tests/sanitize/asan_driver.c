@@ -1,5 +1,7 @@
 /* AddressSanitizer / UBSan driver for the host-side analysis of the K5 block schedule (nep_lu_analyze: elimination tree,
- * multilevel partition, permutation, per-factor CSR splitting, chunk tables -- csrc/trsv_ml.hip; no device is touched).
+ * multilevel partition, permutation, per-factor CSR splitting, chunk tables -- csrc/trsv_ml.hip; no device is touched)
+ * and for the plan builder of the device-side numeric LU (nep_lu_refac_analyze -- csrc/lufac.hip: the enumeration runs on
+ * worker threads and must give the same plan for every thread count).
  * Random lower/upper patterns of several shapes, CSR and CSC, from 4 threads at once.  Built and run by
  * tests/test_host_logic.py::test_asan_host_analysis (make -C tests/sanitize). */
 #include <pthread.h>
@@ -62,11 +64,73 @@ static void* worker(void* arg) {
     return (void*)checks;
 }
 
+/* ---- plan builder of the device-side numeric LU (nep_lu_refac_analyze: symbolic partition + two-pass product enumeration on
+ * worker threads, host only).  Input: a random structurally symmetric pattern A with full diagonal and its filled pattern
+ * (symbolic elimination without pivoting, done here on a dense boolean matrix), i.e. a pattern closed under the elimination. */
+static long plan_checks(unsigned tid) {
+    const int sizes[] = {3, 40, 300, 700};
+    long checks = 0;
+    for (int s = 0; s < 4; ++s) {
+        const int n = sizes[s];
+        unsigned seed = 77u + 13u * tid + (unsigned)s;
+        unsigned char* M = calloc((size_t)n * n, 1);           /* M[i*n + j] != 0: entry (i, j); bit 1: original entry of A */
+        for (int i = 0; i < n; ++i) {
+            M[(size_t)i * n + i] = 3;
+            for (int b = 1; b <= 3; ++b) if (i + b < n && (lcg(&seed) & 1)) { M[(size_t)i * n + i + b] = 3; M[(size_t)(i + b) * n + i] = 3; }
+            if ((lcg(&seed) & 7) == 0) { int j = (int)(lcg(&seed) % (unsigned)n); M[(size_t)i * n + j] = 3; M[(size_t)j * n + i] = 3; }
+        }
+        for (int k = 0; k < n; ++k)                            /* fill */
+            for (int i = k + 1; i < n; ++i) if (M[(size_t)i * n + k])
+                for (int j = k + 1; j < n; ++j) if (M[(size_t)k * n + j] && !M[(size_t)i * n + j]) M[(size_t)i * n + j] = 1;
+        /* CSC of L (rows >= j), U (rows <= j), A (original entries) */
+        int32_t *Lp = calloc(n + 1, 4), *Up = calloc(n + 1, 4), *Ap = calloc(n + 1, 4);
+        long nl = 0, nu = 0, na = 0;
+        for (int j = 0; j < n; ++j) for (int i = 0; i < n; ++i) if (M[(size_t)i * n + j]) { if (i >= j) ++nl; if (i <= j) ++nu; if (M[(size_t)i * n + j] & 2) ++na; }
+        int32_t *Li = malloc(nl * 4 + 4), *Ui = malloc(nu * 4 + 4), *Ai = malloc(na * 4 + 4), *perm = malloc(n * 4);
+        nl = nu = na = 0;
+        long long expect = 0;
+        for (int j = 0; j < n; ++j) {
+            perm[j] = j;
+            for (int i = 0; i < n; ++i) if (M[(size_t)i * n + j]) {
+                if (i <= j) Ui[nu++] = i;
+                if (i >= j) Li[nl++] = i;
+                if (M[(size_t)i * n + j] & 2) Ai[na++] = i;
+            }
+            Lp[j + 1] = (int32_t)nl; Up[j + 1] = (int32_t)nu; Ap[j + 1] = (int32_t)na;
+        }
+        for (int k = 0; k < n; ++k) {
+            long lc = 0, uc = 0;
+            for (int i = k + 1; i < n; ++i) { if (M[(size_t)i * n + k]) ++lc; if (M[(size_t)k * n + i]) ++uc; }
+            expect += lc * uc;
+        }
+        int64_t o1[8], o4[8];
+        setenv("NEP_LU_PLAN_THREADS", "1", 1);
+        const int rc1 = nep_lu_refac_analyze(n, Lp, Li, Up, Ui, perm, perm, Ap, Ai, o1);
+        setenv("NEP_LU_PLAN_THREADS", "4", 1);
+        const int rc4 = nep_lu_refac_analyze(n, Lp, Li, Up, Ui, perm, perm, Ap, Ai, o4);
+        if (rc1 || rc4) { fprintf(stderr, "refac_analyze failed n=%d rc=%d/%d: %s\n", n, rc1, rc4, nep_last_error()); exit(5); }
+        for (int q = 0; q < 8; ++q) if (o1[q] != o4[q]) { fprintf(stderr, "plan depends on the thread count (n=%d, field %d)\n", n, q); exit(6); }
+        if (o1[0] != expect || o1[0] != o1[1] + o1[2] + o1[4]) { fprintf(stderr, "product count %lld, expected %lld\n", (long long)o1[0], expect); exit(7); }
+        /* an entry of A without a slot in L + U must be refused */
+        if (n >= 40) {
+            int32_t keep = Li[Lp[1] - 1];
+            Li[Lp[1] - 1] = Li[Lp[1] - 1] == n - 1 ? n - 2 : n - 1;      /* move the last row index of column 0: pattern no longer closed / sorted */
+            int64_t ob[8];
+            (void)nep_lu_refac_analyze(n, Lp, Li, Up, Ui, perm, perm, Ap, Ai, ob);   /* any return code; must not crash or leak */
+            Li[Lp[1] - 1] = keep;
+        }
+        ++checks;
+        free(M); free(Lp); free(Up); free(Ap); free(Li); free(Ui); free(Ai); free(perm);
+    }
+    return checks;
+}
+
 int main(void) {
     pthread_t th[4];
     for (uintptr_t t = 0; t < 4; ++t) pthread_create(&th[t], NULL, worker, (void*)t);
     long total = 0;
     for (int t = 0; t < 4; ++t) { void* r; pthread_join(th[t], &r); total += (long)r; }
-    printf("asan_driver ok: %ld analyses\n", total);
+    const long plans = plan_checks(0) + plan_checks(1);       /* (setenv: not from concurrent threads) */
+    printf("asan_driver ok: %ld analyses, %ld device-LU plans\n", total, plans);
     return 0;
 }

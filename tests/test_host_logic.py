@@ -460,3 +460,39 @@ def test_hosteig_hessenberg_route():
         assert sorted(order) == list(range(n)) and np.abs(w[order] - w0).max() <= 1e-10 * np.abs(w0).max()
         for j, i in enumerate(order):                      # same eigenvector up to a phase
             assert 1 - abs(np.vdot(V0[:, j], V[:, i])) <= 1e-8
+
+
+def test_device_lu_plan_is_independent_of_the_enumeration_threads():
+    """nep_lu_refac_analyze (host-only dry run of the plan builder of csrc/lufac.hip: symbolic partition, two-pass product
+    enumeration on worker threads, classification, placement): the product count equals sum_k |L(:,k)| |U(k,:)| computed
+    independently, the classes add up, and the hash of the plan arrays is the same for 1, 2, 5 and 8 enumeration threads"""
+    import ctypes as C
+    import nep_amd_hostlu as hl
+    from nep_amd._lib import lib, hptr
+    nep = na.nep_gallery("gun_spmf_scaled", 1310)
+    A = sp.csc_matrix(nep.compute_Mder(0.0)).astype(np.complex128); A.sort_indices()
+    F = hl.factor(A.data, A.indices, A.indptr, A.shape)
+    assert F["strategy"].get("symmetric_mode") and np.array_equal(F["perm_r"], F["perm_c"])
+    i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+    arrs = [i32(F[k]) for k in ("Lp", "Li", "Up", "Ui", "perm_r", "perm_c")] + [i32(A.indptr), i32(A.indices)]
+    n = A.shape[0]
+    expect = int(np.sum((np.diff(arrs[0]) - 1).astype(np.int64) * (np.bincount(arrs[3], minlength=n) - 1)))
+    res = []
+    old = os.environ.get("NEP_LU_PLAN_THREADS")
+    try:
+        for thr in (1, 2, 5, 8):
+            os.environ["NEP_LU_PLAN_THREADS"] = str(thr)
+            out = (C.c_int64 * 8)()
+            assert lib.nep_lu_refac_analyze(n, *[hptr(a) for a in arrs], out) == 0
+            res.append(list(out))
+    finally:
+        if old is None:
+            os.environ.pop("NEP_LU_PLAN_THREADS", None)
+        else:
+            os.environ["NEP_LU_PLAN_THREADS"] = old
+    assert all(r == res[0] for r in res)
+    prod, internal, external, segs, wide, steps, levels, _ = res[0]
+    assert prod == expect == internal + external + wide and segs >= 1 and levels >= 2 and steps >= 1
+    # malformed input is rejected, not read out of bounds
+    bad = [a.copy() for a in arrs]; bad[1][0] = n + 5
+    assert lib.nep_lu_refac_analyze(n, *[hptr(a) for a in bad], (C.c_int64 * 8)()) != 0
