@@ -109,6 +109,11 @@ struct PinnedRing {
     // copies `bytes` from hsrc to ddst on `st`; hsrc may be freed by the caller right after return
     int upload(void* ddst, const void* hsrc, size_t bytes, hipStream_t st);
     void release();
+    PinnedRing() = default;
+    PinnedRing(const PinnedRing&) = delete;
+    PinnedRing& operator=(const PinnedRing&) = delete;
+    // thread_local rings of short-lived host threads (iar's checker thread, Beyn's builders) are returned when the thread ends
+    ~PinnedRing() { release(); }
 };
 
 // Caching device allocator for objects that are created and destroyed repeatedly (one LU per quadrature node in
@@ -145,4 +150,11 @@ struct NepScratch {
     size_t cap = 0;
     int ensure(size_t bytes);
     void release();
+    NepScratch() = default;
+    NepScratch(const NepScratch&) = delete;
+    NepScratch& operator=(const NepScratch&) = delete;
+    // A thread_local scratch of a short-lived host thread goes back to the pool when the thread ends (iar starts one checker
+    // thread per call: without this every call left its 4 MiB blocks behind -- 9 MB per call, scripts/diag/leak_check.py).
+    // The owner must not exit with kernels on the block still pending (iar's checker drains its stream before it returns).
+    ~NepScratch() { release(); }
 };

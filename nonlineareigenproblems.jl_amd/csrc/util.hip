@@ -152,6 +152,7 @@ int PinnedRing::upload(void* ddst, const void* hsrc, size_t bytes, hipStream_t s
 }
 void PinnedRing::release() {
     for (int i = 0; i < NSLOT; ++i) {
+        if (slot[i] && ev[i] && used[i]) (void)hipEventSynchronize(ev[i]);      // the copy out of the slot may still be queued
         if (slot[i]) (void)hipHostFree(slot[i]);
         if (ev[i]) (void)hipEventDestroy(ev[i]);
         slot[i] = nullptr; ev[i] = nullptr; cap[i] = 0; used[i] = false;

@@ -56,6 +56,17 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
 iar.refinement_misses = 0            # calls that were re-run with checked solves (diagnostics, tests)
 
 
+_CHECK_STREAMS = {}
+
+
+def _check_stream():
+    dev = torch.cuda.current_device()
+    st = _CHECK_STREAMS.get(dev)
+    if st is None:
+        st = _CHECK_STREAMS[dev] = torch.cuda.Stream()
+    return st
+
+
 def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
          errmeasure=None, sigma=0.0, gamma=1.0, v=None, logger=0, check_error_every=1, proj_solve=False,
          errhist=None, timers=None, return_device=False, inner_solver_method=None, _native_step=True):
@@ -269,7 +280,9 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     # Only with the native step: there this thread touches none of the scratch the checks use (csrc/spmv.hip: coef / part /
     # ring belong to the residual batch, cwpart / cwring to the refinement inside the step).
     check_thread = cstep is not None and not os.environ.get("NEP_IAR_ONE_STREAM") and hasattr(errmeasure, "batch_async")
-    check_stream = torch.cuda.Stream() if (check_thread and not os.environ.get("NEP_IAR_CHECK_MAIN_STREAM")) else None
+    # ONE check stream per device for the life of the process: torch's caching allocator keeps freed blocks per stream, and a
+    # fresh stream per call (32 of them in torch's pool) made every stream build its own cache of Ritz blocks
+    check_stream = _check_stream() if (check_thread and not os.environ.get("NEP_IAR_CHECK_MAIN_STREAM")) else None
 
     def launch_check(kc, fut):
         """eigen-decomposition of step kc is available: enqueue Ritz block (K7) + residual batch (K2), no waiting"""
@@ -343,6 +356,13 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                 except BaseException as exc:          # re-raised on the calling thread
                     failure.append(exc)
                     slots.release()
+                finally:
+                    # the library's thread-local scratch of this thread goes back to the shared pool when the thread ends:
+                    # nothing this thread enqueued may still be pending then (dropped speculative checks)
+                    try:
+                        (check_stream.synchronize() if check_stream is not None else torch.cuda.current_stream().synchronize())
+                    except Exception:
+                        pass
 
             th = threading.Thread(target=checker, name="nep-iar-check", daemon=True)
             th.start()

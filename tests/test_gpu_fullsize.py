@@ -241,3 +241,23 @@ def test_c2_repeated_runs_are_stable(na):
             assert np.abs(np.sort_complex(lam) - ref).max() <= 1e-9 * np.abs(ref).max()
     plans = [p for p in _DeviceRefactor.plans.values() if p["state"] == "ready"]
     assert plans and sum(p["uses"] for p in plans) >= 8        # the later runs were factorised on the device
+
+
+def test_c2_device_memory_plateaus(na):
+    """device memory in use does not grow from call to call of the headline configuration (it did by 9 MB per call: the
+    library's thread-local scratch of iar's per-call checker thread had no destructor, and a fresh check stream per call
+    made torch's caching allocator build one cache per stream)"""
+    import torch
+    nep = na.nep_gallery("gun_spmf_scaled"); nep.dev
+
+    def used():
+        torch.cuda.synchronize()
+        free, total = torch.cuda.mem_get_info()
+        return (total - free) / 2 ** 20
+    marks = []
+    for i in range(36):
+        lam = na.iar(nep, maxit=100, neigs=np.inf, v=np.ones(nep.n), tol=1e-10)[0]
+        assert len(lam) == 46
+        if i in (11, 35):
+            marks.append(used())
+    assert marks[1] - marks[0] < 48.0, marks
