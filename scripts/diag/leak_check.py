@@ -13,6 +13,7 @@ for i in range(N):
     lam, Q, V = na.iar(nep, sigma=0.0, gamma=1.0, maxit=100, neigs=np.inf, v=np.ones(nep.n), tol=1e-10, linsolvercreator=creator, return_device=True)
     del Q, V
     if i % (10 if N <= 100 else 50) == 0:
-        torch.cuda.synchronize(); print("call %d: %.0f MiB in use, %d pairs" % (i, used(), len(lam)), flush=True)
+        import psutil
+        torch.cuda.synchronize(); print("call %d: %.0f MiB in use, host RSS %.0f MiB, %d pairs" % (i, used(), psutil.Process().memory_info().rss / 2**20, len(lam)), flush=True)
 import threading
 print("threads alive:", threading.active_count())
