@@ -100,7 +100,7 @@ def mlincomb_roofline(na, nep, k, reps=50):
 
 def orth_roofline(na, n, k, reps=20):
     """K6 at the FIXED shape of iar step k (block-triangular basis, rows = n(k+1)): one classical Gram-Schmidt pass =
-    k_orth_dots + k_orth_update (+ 3 small kernels).  Algorithmic bytes: SURVEY.md section 8d K6 restricted to the non-zero
+    k_orth_dots + k_orth_update (+ 2 small kernels).  Algorithmic bytes: SURVEY.md section 8d K6 restricted to the non-zero
     blocks: 2*16*sum_j active_j + 3*16*rows.  Average over `reps` identical asynchronous nep_orth_dev launches."""
     from nep_amd import dense
     rows = n * (k + 1)
@@ -112,7 +112,7 @@ def orth_roofline(na, n, k, reps=20):
     ms = event_loop(lambda: dense.orthogonalize_and_normalize_dev(V, w, k, out, rows=rows, ldv=rows, active_dev=act_d,
                                                                   method=dense.CGS), reps, warm=2)
     byts = 2 * 16 * int(active.sum()) + 3 * 16 * rows
-    return {"bound": "hbm", "kernel": "K6 nep_orth_dev, one Gram-Schmidt pass (k_orth_dots + k_orth_update + 3 small "
+    return {"bound": "hbm", "kernel": "K6 nep_orth_dev, one Gram-Schmidt pass (k_orth_dots + k_orth_update + 2 small "
             "kernels) at the fixed shape of iar step k=%d: rows=%d, block-triangular basis" % (k, rows),
             "algorithmic_bytes": byts, "ms_per_pass": ms, "launches_timed": reps, "achieved": byts / ms / 1e6,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS}

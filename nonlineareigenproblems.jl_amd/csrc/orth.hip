@@ -16,12 +16,60 @@
 #define DOT_CG 8
 #define DOT_RB (256 * DOT_RPT)
 
+// ---- device-side DGKS decision (asynchronous path) ----------------------------------------------------------------------------
+// After pass p the criterion ||w|| < ||c|| / sqrt(2) says whether pass p + 1 runs.  It used to be a one-workgroup kernel of its
+// own behind every pass (7-8 us + a launch gap, twice per Arnoldi step, 10 000 times per waveguide run); now the kernels that need
+// the answer form it themselves: every workgroup of the next pass' k_orth_dots (and of k_orth_finish) sums the <= ORTH_NPART update
+// partials and the k coefficients in the same fixed order -- identical value everywhere -- and workgroup 0 publishes it.
+// state: [1] = passes done, [2] = breakdown, [4 + p] = "pass p ran and wants another one" (p = 1 ..), written by the k_orth_dots of
+// pass p + 1, read by that pass' other kernels and by the next publisher.
+#define ORTH_NPART 1024          // k_orth_update launches at most this many workgroups on the asynchronous path (one partial each)
+struct OrthDecide {              // what the fused decision reads (partial == nullptr: not in use)
+    const double* partial = nullptr; int np = 0; const cplx* c = nullptr; int k = 0; int method = 0; int* state = nullptr;
+    cplx* out_beta = nullptr;
+};
+__device__ __forceinline__ void orth_pass_norms(const OrthDecide& D, double& nrm, double& p2) {
+    __shared__ double smn[2][16];
+    double acc = 0.0, pj = 0.0;
+    for (int b = threadIdx.x; b < D.np; b += blockDim.x) acc += D.partial[b];
+    for (int j = threadIdx.x; j < D.k; j += blockDim.x) pj += D.c[j].x * D.c[j].x + D.c[j].y * D.c[j].y;
+    acc = wave_reduce_sum(acc); pj = wave_reduce_sum(pj);
+    if ((threadIdx.x & 63) == 0) { smn[0][threadIdx.x >> 6] = acc; smn[1][threadIdx.x >> 6] = pj; }
+    __syncthreads();
+    double t = 0.0, q2 = 0.0;
+    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) { t += smn[0][q]; q2 += smn[1][q]; }
+    __syncthreads();
+    nrm = sqrt(t); p2 = q2;
+}
+// decision after pass `pdone` (1-based), evaluated by the caller's whole workgroup; returns 1 when pass pdone + 1 is to run.
+// publish: this workgroup writes passes / gate / beta / breakdown (exactly one workgroup of the launch does)
+__device__ __forceinline__ int orth_decide_after(const OrthDecide& D, int pdone, bool publish) {
+    if (pdone >= 2 && D.state[4 + pdone - 1] == 0) {          // pass pdone never ran: the chain ended earlier
+        if (publish && threadIdx.x == 0) D.state[4 + pdone] = 0;
+        return 0;
+    }
+    double nrm, p2;
+    orth_pass_norms(D, nrm, p2);
+    const int more = (D.method == 0 && nrm < 0.70710678118654752440 * sqrt(p2)) ? 1 : 0;
+    if (publish && threadIdx.x == 0) {
+        D.out_beta[0] = cmake(nrm, 0.0);
+        D.state[1] = pdone;
+        D.state[4 + pdone] = more;
+        if (!(nrm > 0.0) || !isfinite(nrm)) D.state[2] = 1;
+    }
+    return more;
+}
+
 __global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, int64_t ldv, int64_t rows,
                                                    int k, const int64_t* __restrict__ active,
                                                    const cplx* __restrict__ w, cplx* __restrict__ partial,
-                                                   const int* __restrict__ gate = nullptr) {
+                                                   const int* __restrict__ gate = nullptr,
+                                                   const OrthDecide dec = OrthDecide(), int pdone = 0) {
     __shared__ cplx sm[DOT_CG][4];
     if (gate && *gate == 0) return;          // device-side DGKS decision: this pass is not needed
+    if (dec.partial) {                       // pass pdone + 1 of the asynchronous path: form the decision of pass pdone here
+        if (!orth_decide_after(dec, pdone, blockIdx.x == 0 && blockIdx.y == 0)) return;
+    }
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * DOT_RB;
     cplx wr[DOT_RPT];
@@ -71,9 +119,9 @@ __global__ __launch_bounds__(256) void k_orth_reduce_h(int nb, int k, const cplx
                                                        cplx* __restrict__ hacc = nullptr, int first = 1,
                                                        int* __restrict__ state_reset = nullptr) {
     __shared__ cplx sm[4];
-    // first pass of an asynchronous orthogonalisation: clear the pass state here (nothing reads it before k_orth_decide of
-    // this pass) instead of a separate memset command in front of every Arnoldi step
-    if (state_reset && blockIdx.x == 0 && threadIdx.x < 4) state_reset[threadIdx.x] = 0;
+    // first pass of an asynchronous orthogonalisation: clear the pass state here (nothing reads it before the k_orth_dots of the
+    // NEXT pass) instead of a separate memset command in front of every Arnoldi step
+    if (state_reset && blockIdx.x == 0 && threadIdx.x < 16) state_reset[threadIdx.x] = 0;
     if (gate && *gate == 0) return;
     const int j = blockIdx.x;
     cplx acc = cmake(0.0, 0.0);
@@ -117,72 +165,71 @@ __global__ __launch_bounds__(512) void k_orth_update(const cplx* __restrict__ V,
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int t = threadIdx.x; t < k; t += 512) hs[t] = h[t];
     __syncthreads();
-    const int64_t r0 = blockIdx.x * 64LL;
-    const int64_t row = r0 + lane;
-    const int64_t rowc = row < rows ? row : rows - 1;
-    cplx acc = cmake(0.0, 0.0);
-    const cplx* vp = V + rowc;
+    // a workgroup walks the 64-row tiles blockIdx.x, + gridDim.x, ... and leaves ONE partial norm (grid = number of tiles on
+    // the synchronous path: one tile each, as before; at most ORTH_NPART workgroups on the asynchronous one)
+    const int64_t ntiles = (rows + 63) / 64;
+    double wg_nn = 0.0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * 64LL;
+        const int64_t row = r0 + lane;
+        const int64_t rowc = row < rows ? row : rows - 1;
+        cplx acc = cmake(0.0, 0.0);
+        const cplx* vp = V + rowc;
 #pragma unroll 4
-    for (int j = q; j < k; j += 8) {
-        const int64_t act = active ? active[j] : rows;
-        if (r0 < act) cfma(acc, vp[(int64_t)j * ldv], hs[j]);
-    }
-    sm[q * 64 + lane] = acc;
-    __syncthreads();
-    if (q == 0) {
-        cplx s = sm[lane];
-#pragma unroll
-        for (int t = 1; t < 8; ++t) s = cadd(s, sm[t * 64 + lane]);
-        double nn = 0.0;
-        if (row < rows) {
-            cplx wn = csub(w[row], s);
-            w[row] = wn;
-            nn = fma(wn.x, wn.x, wn.y * wn.y);
+        for (int j = q; j < k; j += 8) {
+            const int64_t act = active ? active[j] : rows;
+            if (r0 < act) cfma(acc, vp[(int64_t)j * ldv], hs[j]);
         }
-        nn = wave_reduce_sum(nn);
-        if (lane == 0) partial[blockIdx.x] = nn;
+        sm[q * 64 + lane] = acc;
+        __syncthreads();
+        if (q == 0) {
+            cplx s = sm[lane];
+#pragma unroll
+            for (int t = 1; t < 8; ++t) s = cadd(s, sm[t * 64 + lane]);
+            double nn = 0.0;
+            if (row < rows) {
+                cplx wn = csub(w[row], s);
+                w[row] = wn;
+                nn = fma(wn.x, wn.x, wn.y * wn.y);
+            }
+            wg_nn += wave_reduce_sum(nn);
+        }
+        __syncthreads();
     }
+    if (q == 0 && lane == 0) partial[blockIdx.x] = wg_nn;
 }
 
-
-// device-side end of a pass: ||w||^2 from the update partials, ||c||^2 of this pass' coefficients, DGKS criterion.
-// state: [0] = gate of the NEXT pass (1 = run), [1] = passes done, [2] = breakdown flag.  out[k] = (beta, 0).
-__global__ __launch_bounds__(1024) void k_orth_decide(int nb, const double* __restrict__ partial, int k,
-                                                      const cplx* __restrict__ c, int method, int* __restrict__ state,
-                                                      const int* __restrict__ gate, cplx* __restrict__ out_beta) {
-    __shared__ double sm[16], sp[16];
-    if (gate && *gate == 0) { if (threadIdx.x == 0) state[0] = 0; return; }
-    double acc = 0.0, pj = 0.0;
-    for (int b = threadIdx.x; b < nb; b += 1024) acc += partial[b];
-    for (int j = threadIdx.x; j < k; j += 1024) pj += c[j].x * c[j].x + c[j].y * c[j].y;
-    acc = wave_reduce_sum(acc); pj = wave_reduce_sum(pj);
-    if ((threadIdx.x & 63) == 0) { sm[threadIdx.x >> 6] = acc; sp[threadIdx.x >> 6] = pj; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double t = 0.0, p2 = 0.0;
-        for (int q = 0; q < 16; ++q) { t += sm[q]; p2 += sp[q]; }
-        const double nrm = sqrt(t);
-        out_beta[0] = cmake(nrm, 0.0);
-        state[1] += 1;
-        state[0] = (method == 0 && nrm < 0.70710678118654752440 * sqrt(p2)) ? 1 : 0;
-        if (!(nrm > 0.0) || !isfinite(nrm)) state[2] = 1;
-    }
-}
 
 // w /= beta (beta on the device); records passes / flags behind beta: out[k+1] = (passes, 2*breakdown + more_needed)
 // mirror (optional): device-mapped pinned host copy of the caller's row [row, row + nmirror) -- h, beta, flags and whatever the
 // caller keeps behind them -- written by block 0, which saves the separate device-to-host copy command of every Arnoldi step
+// dec (asynchronous path): the decision of the LAST enqueued pass (npass) is formed here by every workgroup -- when that pass ran;
+// otherwise the values published by its k_orth_dots stand
 __global__ __launch_bounds__(256) void k_orth_finish(int64_t rows, cplx* __restrict__ w, cplx* __restrict__ out_beta,
-                                                     const int* __restrict__ state, const cplx* __restrict__ row,
-                                                     cplx* __restrict__ mirror, int nmirror) {
-    const double beta = out_beta[0].x;
+                                                     int* __restrict__ state, const cplx* __restrict__ row,
+                                                     cplx* __restrict__ mirror, int nmirror,
+                                                     const OrthDecide dec = OrthDecide(), int npass = 0) {
+    double beta;
+    int passes, more, brk;
+    if (dec.partial) {
+        const OrthDecide& D = dec;
+        const bool ran = npass == 1 || D.state[4 + npass - 1] != 0;
+        if (ran) {
+            double nrm, p2;
+            orth_pass_norms(D, nrm, p2);
+            beta = nrm; passes = npass;
+            more = (D.method == 0 && nrm < 0.70710678118654752440 * sqrt(p2)) ? 1 : 0;
+            brk = (D.state[2] != 0 || !(nrm > 0.0) || !isfinite(nrm)) ? 1 : 0;
+            if (blockIdx.x == 0 && threadIdx.x == 0) out_beta[0] = cmake(nrm, 0.0);
+        } else { beta = out_beta[0].x; passes = D.state[1]; more = 0; brk = D.state[2]; }
+    } else { beta = out_beta[0].x; passes = state[1]; more = state[0]; brk = state[2]; }
     const double inv = (beta > 0.0 && isfinite(beta)) ? 1.0 / beta : 0.0;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
         cplx v = w[i];
         w[i] = cmake(v.x * inv, v.y * inv);
     }
     if (blockIdx.x == 0) {
-        const cplx flags = cmake((double)state[1], (double)(2 * state[2] + state[0]));
+        const cplx flags = cmake((double)passes, (double)(2 * brk + more));
         if (threadIdx.x == 0) out_beta[1] = flags;
         if (mirror) {
             const int iflag = (int)(out_beta + 1 - row);
@@ -293,11 +340,11 @@ extern "C" int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, in
 }
 
 // Fully asynchronous DGKS/CGS: no host synchronisation.  The re-orthogonalisation passes are always enqueued and
-// switch themselves off through a device flag (criterion ||w|| < ||c||/sqrt(2) evaluated by k_orth_decide), at most
+// switch themselves off through a device flag (criterion ||w|| < ||c||/sqrt(2) evaluated inside the next pass' k_orth_dots / k_orth_finish), at most
 // orth_dev_passes() passes.  d_out (k+2 complex, device): h[0..k), (beta,0), (passes, 2*breakdown + more_needed).
 // "Twice is enough" (Kahan/Parlett): after the second pass w is orthogonal to machine precision unless it lies
 // numerically inside span(V), which the breakdown flag reports.  The default therefore enqueues 2 passes (every enqueued
-// pass costs four launches even when its gate is closed: 3 -> 2 passes took 1.4 ms off the 100 steps of the gun run);
+// pass costs three launches even when its gate is closed: 3 -> 2 passes took 1.4 ms off the 100 steps of the gun run);
 // NEP_ORTH_DEV_PASSES=3.. restores the longer chain; the `another_pass_wanted` flag in d_out tells if the criterion still
 // held after the last enqueued pass.
 static int orth_dev_passes() {
@@ -320,11 +367,12 @@ extern "C" int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64
     hipStream_t st = as_stream(stream);
     const int nchunks = (int)((rows + DOT_RB - 1) / DOT_RB);
     const int nblk = (int)((rows + 63) / 64);
-    // scratch: [state 4 int][partial_h nchunks*k cplx][c k cplx][partial_n nblk dbl]
-    size_t off_ph = 16;
+    // scratch: [state 16 int][partial_h nchunks*k cplx][c k cplx][partial_n npart dbl]
+    const int npart = std::min(nblk, ORTH_NPART);
+    size_t off_ph = 64;
     size_t off_c = off_ph + (size_t)nchunks * k * sizeof(cplx);
     size_t off_pn = off_c + (size_t)k * sizeof(cplx);
-    size_t total = off_pn + (size_t)nblk * sizeof(double);
+    size_t total = off_pn + (size_t)npart * sizeof(double);
     int rc = g_orth_scratch.ensure(total);
     if (rc) return rc;
     char* base = (char*)g_orth_scratch.dptr;
@@ -337,24 +385,25 @@ extern "C" int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64
     cplx* out = (cplx*)d_out;
     const size_t shm_upd = (size_t)(k + 8 * 64) * sizeof(cplx);
     const int npass = method == 1 ? 1 : orth_dev_passes();
+    OrthDecide D;
+    D.partial = d_pn; D.np = npart; D.c = d_c; D.k = (int)k; D.method = (int)method; D.state = d_state; D.out_beta = out + k;
+    // per pass three launches (dots, coefficient reduction, update); the decision after pass p is formed inside the dots kernel
+    // of pass p + 1 and, for the last pass, inside k_orth_finish (it was a fourth launch per pass)
     for (int p = 0; p < npass; ++p) {
-        const int* gate = p == 0 ? nullptr : d_state;
+        const int* gate = p == 0 ? nullptr : d_state + 4 + p;       // "pass p ran and wants pass p + 1", published by this pass' dots
         hipLaunchKernelGGL(k_orth_dots, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv, rows, (int)k,
-                           d_active_rows, (const cplx*)w, d_ph, gate);
+                           d_active_rows, (const cplx*)w, d_ph, (const int*)nullptr, p == 0 ? OrthDecide() : D, p);
         LAUNCHCHK();
         hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_c, gate, out,
                            p == 0 ? 1 : 0, p == 0 ? d_state : (int*)nullptr);
         LAUNCHCHK();
-        hipLaunchKernelGGL(k_orth_update, dim3(nblk), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
+        hipLaunchKernelGGL(k_orth_update, dim3(npart), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
                            (const cplx*)d_c, w, d_pn, gate);
-        LAUNCHCHK();
-        hipLaunchKernelGGL(k_orth_decide, dim3(1), dim3(1024), 0, st, nblk, (const double*)d_pn, (int)k, (const cplx*)d_c,
-                           (int)method, d_state, gate, out + k);
         LAUNCHCHK();
     }
     const int g = (int)std::min<int64_t>((rows + 255) / 256, 2048);
-    hipLaunchKernelGGL(k_orth_finish, dim3(g), dim3(256), 0, st, rows, w, out + k, (const int*)d_state, (const cplx*)out,
-                       (cplx*)d_mirror, (int)nmirror);
+    hipLaunchKernelGGL(k_orth_finish, dim3(g), dim3(256), 0, st, rows, w, out + k, d_state, (const cplx*)out,
+                       (cplx*)d_mirror, (int)nmirror, D, npass);
     LAUNCHCHK();
     return NEP_OK;
 }
