@@ -1,5 +1,6 @@
 /* Plain-C smoke program for libnepmi355.so: drives the hot path through the C ABI with no Python in the process --
- *   nep_spmf_create -> nep_mlincomb (K1) -> nep_lu_create_csc + nep_lu_solve (K5) -> nep_orth (K6) -> nep_gemm_ts (K7)
+ *   nep_spmf_create -> nep_mlincomb (K1) -> nep_lu_create_csc + nep_lu_solve (K5) -> nep_lu_refac_create + nep_lu_factor_dev
+ *   (numeric LU on the device) -> nep_orth (K6) -> nep_gemm_ts (K7)
  * and checks every result against a few lines of host arithmetic.  Built by __graft_entry__.build():
  *   gcc -O2 -I include examples/smoke_c.c -o examples/smoke_c -L nonlineareigenproblems.jl_amd -lnepmi355 -lm
  * Exit code 0 = all checks passed (needs a GPU); 77 = no HIP device visible. */
@@ -96,6 +97,60 @@ int main(void) {
     for (int i = 0; i < n; ++i) { err += (r[i].re - b[i].re) * (r[i].re - b[i].re) + (r[i].im - b[i].im) * (r[i].im - b[i].im); nrm += b[i].re * b[i].re + b[i].im * b[i].im; }
     printf("K5 nep_lu_solve          ||LUx - b||/||b|| %.2e\n", sqrt(err / nrm));
     if (sqrt(err / nrm) > 1e-10) return 3;
+
+    /* ---- numeric LU on the device for a known pattern: the plan from the factors above (identity permutations: A = L U is
+     * tridiagonal), then a NEW matrix A2 = L2 U2 of the same pattern is factorised on the GPU from its values alone and solved */
+    {
+        int32_t* perm = malloc(n * sizeof *perm); int32_t* Ap = malloc((n + 1) * sizeof *Ap); int32_t* Ai = malloc(3 * n * sizeof *Ai);
+        nep_cdouble* A2 = malloc(3 * n * sizeof *A2);
+        nep_cdouble* l2 = malloc(n * sizeof *l2); nep_cdouble* u2 = malloc(n * sizeof *u2); nep_cdouble* s2 = malloc(n * sizeof *s2);
+        for (int j = 0; j < n; ++j) {
+            perm[j] = j;
+            l2[j].re = 0.3 * rnd(&seed); l2[j].im = 0.3 * rnd(&seed);        /* L2[j+1][j] */
+            s2[j].re = 0.4 * rnd(&seed); s2[j].im = 0.4 * rnd(&seed);        /* U2[j-1][j] */
+            u2[j].re = 2.0 + rnd(&seed); u2[j].im = rnd(&seed);              /* U2[j][j]   */
+        }
+        int an = 0;
+        for (int j = 0; j < n; ++j) {
+            Ap[j] = an;
+            if (j > 0) { Ai[an] = j - 1; A2[an++] = s2[j]; }
+            Ai[an] = j; A2[an] = u2[j];
+            if (j > 0) { nep_cdouble q = cmul(l2[j - 1], s2[j]); A2[an].re += q.re; A2[an].im += q.im; }
+            ++an;
+            if (j < n - 1) { Ai[an] = j + 1; A2[an++] = cmul(l2[j], u2[j]); }
+        }
+        Ap[n] = an;
+        nep_lu_refac* plan = NULL;
+        CHECK(nep_lu_refac_create(lu, n, Lp, Li, Up, Ui, perm, perm, Ap, Ai, &plan));
+        double health[3] = {0.0, 0.0, 0.0};
+        nep_cdouble* LU2 = malloc((size_t)(ln + un) * sizeof *LU2);
+        nep_lu* lu2 = NULL;
+        CHECK(nep_lu_factor_dev(plan, A2, 10, 1e6, health, LU2, &lu2, NULL));
+        /* the factor values against the L2, U2 the matrix was built from (input entry order: L then U) */
+        double ferr = 0.0;
+        for (int j = 0; j < n; ++j) {
+            for (int e = Lp[j]; e < Lp[j + 1]; ++e) {
+                const nep_cdouble want = (Li[e] == j) ? (nep_cdouble){1.0, 0.0} : l2[j];
+                ferr = fmax(ferr, hypot(LU2[e].re - want.re, LU2[e].im - want.im));
+            }
+            for (int e = Up[j]; e < Up[j + 1]; ++e) {
+                const nep_cdouble want = (Ui[e] == j) ? u2[j] : s2[j];
+                ferr = fmax(ferr, hypot(LU2[ln + e].re - want.re, LU2[ln + e].im - want.im));
+            }
+        }
+        CHECK(nep_lu_solve(lu2, 1, db, n, dx, n, 1.0, NULL));
+        CHECK(nep_download(x, dx, n * sizeof *x, NULL));
+        err = nrm = 0.0;
+        for (int i = 0; i < n; ++i) {                                         /* r = A2 x - b, column sweep over the CSC of A2 */
+            r[i].re = -b[i].re; r[i].im = -b[i].im;
+        }
+        for (int j = 0; j < n; ++j) for (int e = Ap[j]; e < Ap[j + 1]; ++e) { nep_cdouble q = cmul(A2[e], x[j]); r[Ai[e]].re += q.re; r[Ai[e]].im += q.im; }
+        for (int i = 0; i < n; ++i) { err += r[i].re * r[i].re + r[i].im * r[i].im; nrm += b[i].re * b[i].re + b[i].im * b[i].im; }
+        printf("   nep_lu_factor_dev     max |LU - L2 U2 factors| %.2e, ||A2 x - b||/||b|| %.2e, growth %.2f\n", ferr, sqrt(err / nrm), health[1]);
+        if (ferr > 1e-12 || sqrt(err / nrm) > 1e-10 || health[0] != 0.0) return 6;
+        CHECK(nep_lu_destroy(lu2)); CHECK(nep_lu_refac_destroy(plan));
+        free(perm); free(Ap); free(Ai); free(A2); free(l2); free(u2); free(s2); free(LU2);
+    }
 
     /* ---- K6: orthogonalise w against the (orthonormalised) columns of V */
     nep_cdouble h[3]; double beta = 0.0; int32_t npass = 0;
