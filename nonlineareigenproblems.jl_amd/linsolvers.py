@@ -562,10 +562,16 @@ class FactorizeLinSolver(LinSolver):
         return ok
 
     def _note_hint(self, plan):
+        """plan = None: a miss -- the hint is withdrawn for good on this NEP object (a problem whose omega sits at the edge of the
+        rule would otherwise alternate between learning the count and missing with it, every miss a re-run of the call)"""
         nep = getattr(self, "nep", None)
         if nep is not None:
             try:
-                nep._refine_hint = plan
+                if plan is None:
+                    nep._refine_hint = None
+                    nep._refine_hint_off = True
+                elif not getattr(nep, "_refine_hint_off", False):
+                    nep._refine_hint = plan
             except AttributeError:
                 pass
 

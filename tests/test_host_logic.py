@@ -441,6 +441,10 @@ def test_recorded_refinement_rule_replay():
     assert not b.review_recorded(np.array([1e-9, 1e-12, 0.0, 0.0]), 1) and nep._refine_hint is None
     c = FactorizeLinSolver.__new__(FactorizeLinSolver); c.umfpack_refinements = 10; c._recorded_plan = None; c.last_omega = None; c.nep = nep
     assert c.blind_plan_recorded() == 2
+    # ... for good: a later clean record does not bring the hint back on this NEP object
+    assert c.review_recorded(np.array([1e-13, 1e-16, 5e-17, 0.0]), 2) and nep._refine_hint is None
+    d = FactorizeLinSolver.__new__(FactorizeLinSolver); d.umfpack_refinements = 10; d._recorded_plan = None; d.last_omega = None; d.nep = nep
+    assert d.blind_plan_recorded() == 2
 
 
 def test_hosteig_hessenberg_route():
