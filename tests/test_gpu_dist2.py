@@ -73,22 +73,23 @@ def test_sharded_beyn_two_ranks_one_gpu(na, tmp_path, device_lu):
     assert np.abs(a - b).max() <= 1e-8 * np.abs(a).max()
 
 
-def test_bench_two_ranks_rehearsal(na):
-    """bench.py under torch.distributed.run with two ranks sharing the GPU (NEP_BENCH_SHARE_GPU=1: gloo process group, host-staged
+@pytest.mark.parametrize("world", [2, 4])
+def test_bench_two_ranks_rehearsal(na, world):
+    """bench.py under torch.distributed.run with two (four) ranks sharing the GPU (NEP_BENCH_SHARE_GPU=1: gloo process group, host-staged
     contour exchange): the N > 1 code path of the benchmark -- replicas of the headline step, max-over-ranks timing, ONE JSON
-    line from rank 0, the sharded contour_beyn extra with 32 nodes per rank and its parity block"""
+    line from rank 0, the sharded contour_beyn extra with 64 / world nodes per rank and its parity block"""
     import json
     import subprocess
     env = dict(os.environ, NEP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline", "--no-wep-roofline", "--no-c3", "--no-c5", "--no-beyn-parity"]
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["n_gpus"] == world and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["eigenpairs_per_step"] >= 40
     b = d["beyn_sharded"]
-    assert "error" not in b and b["nodes_per_rank"] == 32 and b["eigenpairs"] >= 20
+    assert "error" not in b and b["nodes_per_rank"] == 64 // world and b["eigenpairs"] >= 20
