@@ -17,6 +17,7 @@
 #include "common.h"
 #include <vector>
 #include <stdlib.h>
+#include <time.h>
 
 struct nep_iar {
     nep_spmf* spmf; nep_lu* lu;
@@ -141,6 +142,18 @@ int32_t nep_iar_steps(nep_iar* s, int32_t k0, int32_t count, int32_t refine_step
 // blocks the calling thread until column k of H has reached the pinned buffer
 int32_t nep_iar_wait(nep_iar* s, int32_t k) {
     ARGCHK(s && k >= 1 && k <= s->m && s->ev[k]);
+    static const int poll_last = getenv("NEP_IAR_POLL_LAST") ? atoi(getenv("NEP_IAR_POLL_LAST")) : 1;
+    if (poll_last && k == s->m) {
+        // the decomposition of the LAST step is on the critical path of the call: its waiter polls (20 us naps) instead of
+        // sleeping on the event's interrupt, whose wake-up can take milliseconds on a busy host
+        for (;;) {
+            const hipError_t e = hipEventQuery(s->ev[k]);
+            if (e == hipSuccess) return NEP_OK;
+            if (e != hipErrorNotReady) HIPCHK(e);
+            struct timespec ts = {0, 20000};
+            nanosleep(&ts, nullptr);
+        }
+    }
     HIPCHK(hipEventSynchronize(s->ev[k]));
     return NEP_OK;
 }
