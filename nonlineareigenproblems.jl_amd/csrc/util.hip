@@ -129,20 +129,64 @@ void nep_pool_free_on(void* p, hipStream_t st, bool in_flight) {
     pool_drop(to_free);
 }
 
+// ---- cache of pinned host blocks -----------------------------------------------------------------------------------------------
+// hipHostMalloc / hipHostFree cost 0.3-1 ms each.  The staging rings are thread_local and some host threads live for one
+// driver call only (iar's checker thread: 8 slots allocated and freed per call): released slots are kept here (power-of-two
+// sizes from 1 MiB, at most 256 MiB idle) and handed to the next ring that asks.
+namespace {
+std::mutex g_pin_mu;
+std::multimap<size_t, void*> g_pin_free;
+std::unordered_map<void*, size_t> g_pin_live;
+size_t g_pin_cached = 0;
+const size_t PIN_CAP = (size_t)256 << 20;
+}  // namespace
+static int pinned_alloc(void** p, size_t bytes, size_t* got) {
+    size_t want = (size_t)1 << 20;
+    while (want < bytes) want <<= 1;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        auto it = g_pin_free.find(want);
+        if (it != g_pin_free.end()) {
+            *p = it->second; *got = want;
+            g_pin_live[*p] = want; g_pin_cached -= want;
+            g_pin_free.erase(it);
+            return NEP_OK;
+        }
+    }
+    HIPCHK(hipHostMalloc(p, want, hipHostMallocDefault));
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    g_pin_live[*p] = want; *got = want;
+    return NEP_OK;
+}
+static void pinned_free(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_pin_mu);
+        auto it = g_pin_live.find(p);
+        if (it != g_pin_live.end() && g_pin_cached + it->second <= PIN_CAP) {
+            g_pin_free.emplace(it->second, p); g_pin_cached += it->second;
+            g_pin_live.erase(it);
+            return;
+        }
+        if (it != g_pin_live.end()) g_pin_live.erase(it);
+    }
+    (void)hipHostFree(p);
+}
+
 int PinnedRing::upload(void* ddst, const void* hsrc, size_t bytes, hipStream_t st) {
     const int i = next;
     next = (next + 1) % NSLOT;
     if (!ev[i]) HIPCHK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
     if (used[i]) HIPCHK(hipEventSynchronize(ev[i]));     // slot's previous copy has been consumed
     if (cap[i] < bytes) {
-        if (slot[i]) HIPCHK(hipHostFree(slot[i]));
+        if (slot[i]) pinned_free(slot[i]);
         slot[i] = nullptr; cap[i] = 0;
-        // pinned allocations cost ~1 ms each: start at 1 MiB and double, so a growing parameter block (the B
-        // fragments of iar's Ritz GEMM grow every step) does not reallocate every few calls
-        size_t want = (size_t)1 << 20;
-        while (want < bytes) want <<= 1;
-        HIPCHK(hipHostMalloc(&slot[i], want, hipHostMallocDefault));
-        cap[i] = want;
+        // pinned allocations cost ~1 ms each: sizes start at 1 MiB and double, so a growing parameter block (the B
+        // fragments of iar's Ritz GEMM grow every step) does not reallocate every few calls; blocks come from / go to the cache
+        size_t got = 0;
+        int rcp = pinned_alloc(&slot[i], bytes, &got);
+        if (rcp) return rcp;
+        cap[i] = got;
     }
     memcpy(slot[i], hsrc, bytes);
     HIPCHK(hipMemcpyAsync(ddst, slot[i], bytes, hipMemcpyHostToDevice, st));
@@ -153,7 +197,7 @@ int PinnedRing::upload(void* ddst, const void* hsrc, size_t bytes, hipStream_t s
 void PinnedRing::release() {
     for (int i = 0; i < NSLOT; ++i) {
         if (slot[i] && ev[i] && used[i]) (void)hipEventSynchronize(ev[i]);      // the copy out of the slot may still be queued
-        if (slot[i]) (void)hipHostFree(slot[i]);
+        if (slot[i]) pinned_free(slot[i]);
         if (ev[i]) (void)hipEventDestroy(ev[i]);
         slot[i] = nullptr; ev[i] = nullptr; cap[i] = 0; used[i] = false;
     }
