@@ -232,8 +232,10 @@ __global__ __launch_bounds__(256) void k_orth_finish(int64_t rows, cplx* __restr
         const cplx flags = cmake((double)passes, (double)(2 * brk + more));
         if (threadIdx.x == 0) out_beta[1] = flags;
         if (mirror) {
+            // (beta and the flags from this thread's own registers: thread 0 of this workgroup has only just stored them)
             const int iflag = (int)(out_beta + 1 - row);
-            for (int i = threadIdx.x; i < nmirror; i += blockDim.x) mirror[i] = i == iflag ? flags : row[i];
+            for (int i = threadIdx.x; i < nmirror; i += blockDim.x)
+                mirror[i] = i == iflag ? flags : (i == iflag - 1 ? cmake(beta, 0.0) : row[i]);
         }
     }
 }
