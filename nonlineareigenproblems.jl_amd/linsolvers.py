@@ -761,6 +761,10 @@ class LinSolverCache:
                 return False
             kw = c.lu_kw
             self._plan_key = _DeviceRefactor.key(A, (c.permc_spec, kw.get("diag_pivot_thresh"), kw.get("symmetric_mode")))
+
+            class _Pattern:         # what _DeviceRefactor.key / maybe_start read of a csc matrix (no values kept)
+                pass
+            self._pattern = _Pattern(); self._pattern.indptr = A.indptr; self._pattern.indices = A.indices; self._pattern.shape = A.shape
         return self._plan_key is not False and _DeviceRefactor.lookup(self._plan_key) is not None
 
     def prefetch(self, shifts):
@@ -791,7 +795,11 @@ class LinSolverCache:
             except RuntimeError as e:  # "Factor is exactly singular"
                 raise np.linalg.LinAlgError("SingularException: " + str(e))
             lu_kw = dict(c.lu_kw); lu_kw.setdefault("expected_solves", 200)
-            lu = DeviceLU(factors=factors, **{k: v for k, v in lu_kw.items() if k == "expected_solves"})
+            # (the prefetched host factors seed the pattern's device-factorisation plan like a factorisation made in place would:
+            # a process that only runs nleigs factorises its shifts on the GPU from the second call on)
+            lu = DeviceLU(factors=factors, permc_spec=c.permc_spec, diag_pivot_thresh=lu_kw.get("diag_pivot_thresh"),
+                          symmetric_mode=lu_kw.get("symmetric_mode"), plan_pattern=getattr(self, "_pattern", None),
+                          **{k: v for k, v in lu_kw.items() if k == "expected_solves"})
             solver = FactorizeLinSolver(self.nep, sigma, c.umfpack_refinements, _lu=lu)
             if len(c.recycled_factorizations) < c.max_factorizations:
                 c.recycled_factorizations[key] = lu

@@ -15,4 +15,4 @@ for _ in range(3):
 pr = cProfile.Profile(); pr.enable()
 bc.c3_device(na, nep); torch.cuda.synchronize()
 pr.disable()
-s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("tottime").print_stats(28); print(s.getvalue()[:5500])
+s = io.StringIO(); pstats.Stats(pr, stream=s).sort_stats("cumulative").print_stats(40); print(s.getvalue()[:5500])

@@ -762,6 +762,37 @@ def test_nleigs_lowrank_gun_vs_oracle(na):
     assert max(E(lam[i], X[:, i]) for i in range(len(lam))) < 1e-10
 
 
+def test_nleigs_first_call_seeds_the_device_plan(na):
+    """a process that ONLY runs nleigs: the shifts of the first call are factorised on the host (prefetch thread) and the first of
+    those factorisations seeds the pattern's device-factorisation plan; the second call factorises its shifts on the GPU and
+    returns the same eigenvalues"""
+    from nep_amd.linsolvers import _DeviceRefactor
+    if not _DeviceRefactor.enabled():
+        pytest.skip("device numeric factorisation switched off")
+    n = 1310
+    K, M, W1, W2 = na.gallery.gun_matrices(n)
+    s2 = na.gallery.GUN_SIGMA2
+    fv = [na.funcs.ISqrt(1.0, 0.0), na.funcs.ISqrt(1.0, -s2 ** 2)]
+    lowr = na.SumNEP(na.PEP([K, -M]), na.LowRankFactorizedNEP([na.LowRankMatrixAndFunction(W1, fv[0]), na.LowRankMatrixAndFunction(W2, fv[1])]))
+    gam = 300.0 ** 2 - 200.0 ** 2; mu = 250.0 ** 2
+    th = np.linspace(0, np.pi, int(round(np.pi / 2 * 1000)) + 2)
+    Sig = np.concatenate([(mu - gam) + 2 * gam * (np.exp(1j * th) / 2 + .5), [mu - gam]])
+    nodes = gam * np.array([2 / 3, (1 + 1j) / 3, 0, (-1 + 1j) / 3, -2 / 3]) + mu
+    Xi = -10.0 ** np.linspace(-8, 8, 10000) + s2 ** 2
+    v = np.random.default_rng(1).standard_normal(n) + 0j
+    kw = dict(Xi=Xi, maxit=60, v=v, leja=0, nodes=nodes, reusefact=2)
+    _DeviceRefactor.clear()
+    l1 = na.nleigs(lowr, Sig, errmeasure=na.StandardSPMFErrmeasure(lowr), **kw)[0]
+    _DeviceRefactor.wait()
+    plans = [p for p in _DeviceRefactor.plans.values() if p["state"] == "ready"]
+    assert len(plans) == 1
+    u0 = plans[0]["uses"]
+    l2 = na.nleigs(lowr, Sig, errmeasure=na.StandardSPMFErrmeasure(lowr), **kw)[0]
+    assert plans[0]["uses"] - u0 == 5 and plans[0]["fails"] == 0          # the five shifts of variant R1
+    assert len(l1) == len(l2) and len(l1) >= 5
+    _match(l2, l1, 1e-8)
+
+
 def test_nleigs_lowrank_degree2_vs_oracle(na):
     """polynomial part of degree 2 + two low-rank exponential terms: the n-row recurrences of blocks 1..p-1, the UU^H seams
     at block p and the corrected first-block-row term (oracle/nleigs.py backslash) on the device; dynamic and static
