@@ -971,16 +971,29 @@ static int ml_numeric_dev(MLFactor* F, const cplx* d_Lx, const cplx* d_Ux, hipSt
     LAUNCHCHK();
     hipLaunchKernelGGL(k_ml_gather, dim3(gu), dim3(256), 0, bst, S->nnzU, (const int32_t*)S->U.d_map, d_Ux, F->d_vals, oU, oUb, oD);
     LAUNCHCHK();
+    // the two block-inverse builds are independent (and each a chain of dependent in-block levels that leaves most of the GPU idle):
+    // the U side runs on a second build stream next to the L side (NEP_ML_INV_2STREAM=0: one after the other)
+    static const int two = getenv("NEP_ML_INV_2STREAM") ? atoi(getenv("NEP_ML_INV_2STREAM")) : 1;
+    hipStream_t bst2 = two ? g_bstreams.get() : bst;
+    if (bst2 == bst || !bst2) bst2 = bst;
+    if (bst2 != bst) {
+        hipEvent_t ev; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev, bst)); HIPCHK(hipStreamWaitEvent(bst2, ev, 0)); (void)hipEventDestroy(ev);
+    }
     hipLaunchKernelGGL((k_ml_inverse<false>), dim3((unsigned)n), dim3(256), 0, bst, (const int32_t*)S->d_rowblk,
                        (const int32_t*)S->d_blk_se, (const int32_t*)S->L.d_lvo, (const int32_t*)S->L.d_lvp,
                        (const int32_t*)S->L.d_slotrow, (const int32_t*)S->L.d_bp, (const int32_t*)S->L.d_bi,
                        (const cplx*)(F->d_vals + oLb), (const cplx*)nullptr, (const int64_t*)S->L.d_ip, F->d_ixL, (const int32_t*)S->L.d_rowlev);
     LAUNCHCHK();
-    hipLaunchKernelGGL((k_ml_inverse<true>), dim3((unsigned)n), dim3(256), 0, bst, (const int32_t*)S->d_rowblk,
+    hipLaunchKernelGGL((k_ml_inverse<true>), dim3((unsigned)n), dim3(256), 0, bst2, (const int32_t*)S->d_rowblk,
                        (const int32_t*)S->d_blk_se, (const int32_t*)S->U.d_lvo, (const int32_t*)S->U.d_lvp,
                        (const int32_t*)S->U.d_slotrow, (const int32_t*)S->U.d_bp, (const int32_t*)S->U.d_bi,
                        (const cplx*)(F->d_vals + oUb), (const cplx*)(F->d_vals + oD), (const int64_t*)S->U.d_ip, F->d_ixU, (const int32_t*)S->U.d_rowlev);
     LAUNCHCHK();
+    if (bst2 != bst) {
+        hipEvent_t ev; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(ev, bst2)); HIPCHK(hipStreamWaitEvent(bst, ev, 0)); (void)hipEventDestroy(ev);
+    }
     if ((rc = ml_finish_numeric(F, bst))) return rc;
     return NEP_OK;
 }
