@@ -33,6 +33,10 @@ import json
 import os
 for _v in ("OPENBLAS_NUM_THREADS", "OMP_NUM_THREADS", "MKL_NUM_THREADS"):   # small host BLAS only; big pools stall the launch thread
     os.environ.setdefault(_v, "8")
+# OpenBLAS' idle workers spin for 2^28 cycles (~0.1 s) after every job before they sleep: with a k x k LAPACK call every few
+# hundred microseconds they never do -- seven threads at 100 % for the whole benchmark, and the container's 16-CPU cgroup quota
+# throttled in 26 of 27 scheduler periods (scripts/diag/cfs_throttle.py, cpu_by_thread.py).  2^12 cycles: they sleep at once.
+os.environ.setdefault("OPENBLAS_THREAD_TIMEOUT", "12")
 import sys
 import time
 

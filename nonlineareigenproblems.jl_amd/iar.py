@@ -314,7 +314,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     # spinning worker threads slow the launching thread down: pin BLAS to one thread for the duration of the loop
     import nep_amd_hostlu as _nep_hostlu
     ctl = _nep_hostlu.blas_controller()
-    blas_guard = ctl.limit(limits=1) if ctl is not None else None
+    blas_guard = ctl.limit(limits=1) if (ctl is not None and os.environ.get("NEP_IAR_BLAS_GUARD", "1") != "0") else None
     if blas_guard is not None:
         blas_guard.__enter__()
     try:
