@@ -143,9 +143,11 @@ int32_t nep_iar_steps(nep_iar* s, int32_t k0, int32_t count, int32_t refine_step
 int32_t nep_iar_wait(nep_iar* s, int32_t k) {
     ARGCHK(s && k >= 1 && k <= s->m && s->ev[k]);
     static const int poll_last = getenv("NEP_IAR_POLL_LAST") ? atoi(getenv("NEP_IAR_POLL_LAST")) : 1;
-    if (poll_last && k == s->m) {
-        // the decomposition of the LAST step is on the critical path of the call: its waiter polls (20 us naps) instead of
-        // sleeping on the event's interrupt, whose wake-up can take milliseconds on a busy host
+    if (poll_last && k > s->m - 13) {
+        // the decompositions of the LAST steps are on the critical path of the call (the checks are consumed in order): their
+        // waiters poll (20 us naps) instead of sleeping on the event's interrupt -- an interrupt-driven wait on this stack now and
+        // then wakes 20-35 ms late (seen as "wait eig" tails and as 20-35 ms hipDeviceSynchronize calls on an idle device,
+        // scripts/diag/tail_kernels.py)
         for (;;) {
             const hipError_t e = hipEventQuery(s->ev[k]);
             if (e == hipSuccess) return NEP_OK;
