@@ -142,12 +142,14 @@ int32_t nep_iar_steps(nep_iar* s, int32_t k0, int32_t count, int32_t refine_step
 // blocks the calling thread until column k of H has reached the pinned buffer
 int32_t nep_iar_wait(nep_iar* s, int32_t k) {
     ARGCHK(s && k >= 1 && k <= s->m && s->ev[k]);
-    static const int poll_last = getenv("NEP_IAR_POLL_LAST") ? atoi(getenv("NEP_IAR_POLL_LAST")) : 1;
-    if (poll_last && k > s->m - 13) {
-        // the decompositions of the LAST steps are on the critical path of the call (the checks are consumed in order): their
-        // waiters poll (20 us naps) instead of sleeping on the event's interrupt -- an interrupt-driven wait on this stack now and
-        // then wakes 20-35 ms late (seen as "wait eig" tails and as 20-35 ms hipDeviceSynchronize calls on an idle device,
-        // scripts/diag/tail_kernels.py)
+    // NEP_IAR_POLL_LAST: 2 (default) = every waiter polls, 1 = only those of the last 13 steps, 0 = all sleep on the interrupt
+    static const int poll_last = getenv("NEP_IAR_POLL_LAST") ? atoi(getenv("NEP_IAR_POLL_LAST")) : 2;
+    if (poll_last == 2 || (poll_last && k > s->m - 13)) {
+        // the waiters poll (20 us naps) instead of sleeping on the event's interrupt: an interrupt-driven wait on this stack now
+        // and then wakes 20-35 ms late (seen as "wait eig" tails and as 20-35 ms hipDeviceSynchronize calls on an idle device,
+        // scripts/diag/tail_kernels.py) -- the checks are consumed in order, so a late waiter near the end delays the call --
+        // and the naps cost LESS CPU than the runtime's own wait (0.19 s instead of 0.43 s of CPU per headline call: at most
+        // LAG + 1 waiters exist at any time)
         for (;;) {
             const hipError_t e = hipEventQuery(s->ev[k]);
             if (e == hipSuccess) return NEP_OK;
