@@ -264,7 +264,7 @@ def host_cores():
         return int(os.cpu_count() or 1)
 
 
-def cpu_baseline(args):
+def cpu_baseline(args, dev=None):
     """CPU oracle (NumPy/SciPy restatement of the reference path, SuperLU for UMFPACK) on the SAME configuration as the
     timed GPU step (maxit = args.maxit unless --cpu-maxit bounds it), BLAS threads as set for this process; plus
     compute_Mlincomb at k = 100 through the C port (1 thread, the reference's per-term gemv + CSC scatter structure) and its
@@ -279,8 +279,12 @@ def cpu_baseline(args):
     m = args.cpu_maxit if args.cpu_maxit > 0 else args.maxit
     tm = {}
     t0 = time.perf_counter()
-    lam, Q = bc.c2_oracle(args.n, maxit=m, permc=args.permc or "MMD_AT_PLUS_A", timers=tm)
+    ohist = []
+    lam, Q = bc.c2_oracle(args.n, maxit=m, permc=args.permc or "MMD_AT_PLUS_A", timers=tm, hist=ohist)
     t_iar = time.perf_counter() - t0
+    parity = None
+    if dev is not None and m == args.maxit:       # SURVEY.md section 8d rules (i), (iii), (iv) on the headline configuration itself
+        parity = bc.c2_parity(dev[0], dev[1], lam, ohist)
     onep = og.gun_spmf_scaled(args.n)
     lib = cref.load()
     terms = cref.CscTerms(onep.get_Av())
@@ -314,7 +318,7 @@ def cpu_baseline(args):
                   "residuals %.2f s)" % (nthreads, host_cores(), args.n, m, "" if m == args.maxit else " instead of %d" % args.maxit,
                                          len(lam), t_iar, tm.get("orth", 0), tm.get("mlincomb", 0), tm.get("solve", 0), tm.get("resid", 0)),
         "same_config_as_value": bool(m == args.maxit),
-        "eigenpairs": int(len(lam)), "seconds": t_iar,
+        "eigenpairs": int(len(lam)), "seconds": t_iar, "parity": parity,
         "mlincomb_k100": {"algorithmic_bytes": byts,
                           "c_port_1_thread": {"ms": t_ml * 1e3, "GBps": byts / t_ml / 1e9,
                                               "structure": "per-term gemv + CSC scatter (src/NEPTypes.jl:1006-1007)"},
@@ -427,6 +431,8 @@ def main():
         # instrumented run: time per phase (step-synchronous loop)
         tm = {}
         bc.c2_device(na, nep, args.maxit, args.permc, timers=tm)
+        dev_hist = []
+        dev_lam, _ = bc.c2_device(na, nep, args.maxit, args.permc, hist=dev_hist, return_device=False)
         k = args.maxit
         byts, ms = mlincomb_roofline(na, nep, k)
         byts1, ms1 = mlincomb_roofline(na, nep, 1)
@@ -504,7 +510,7 @@ def main():
             except Exception as e:
                 out["roofline_wep_scale"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args)
+            out["cpu_baseline"] = cpu_baseline(args, dev=(dev_lam, dev_hist))
         if world == 1 and not args.no_c3:
             try:
                 out["c3_nleigs"] = c3_summary(na, args)

@@ -46,6 +46,8 @@ typedef void* nep_stream;
 
 /* ---- library / device ---------------------------------------------------------------- */
 int32_t nep_version(void);
+/* digest (sha256 prefix) of the sources the library was built from; "unknown" for builds outside build.py */
+const char* nep_src_digest(void);
 const char* nep_last_error(void);
 int32_t nep_device_count(int32_t* n);
 int32_t nep_set_device(int32_t dev);

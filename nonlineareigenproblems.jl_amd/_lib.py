@@ -26,11 +26,24 @@ def _load():
     # .so with changed argument lists would corrupt memory through ctypes.  Never falls back to a CPU path.
     from . import build
     if build.needs_build():
-        if os.path.exists("/opt/rocm/bin/hipcc") or os.environ.get("HIPCC"):
-            build.build_lib(verbose=False)
+        if os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+            build.build_lib(verbose=False)        # serialised across processes by a file lock, linked to a temp name + rename
         elif not os.path.exists(LIB_PATH):
             raise ImportError("libnepmi355.so is missing and hipcc is not available to build it")
-    return C.CDLL(LIB_PATH)
+        elif not os.environ.get("NEP_ALLOW_STALE_LIB"):
+            raise ImportError("libnepmi355.so was built from other sources than the ones in %s (digest %s, sources %s) and hipcc "
+                              "is not available to rebuild it; NEP_ALLOW_STALE_LIB=1 loads it anyway"
+                              % (build.CSRC, build.built_digest(), build.source_digest()))
+    l = C.CDLL(LIB_PATH)
+    # the binary itself says which sources it was built from: refuse a library that does not match the binding
+    try:
+        l.nep_src_digest.restype = C.c_char_p
+        have = l.nep_src_digest().decode()
+    except AttributeError:
+        have = None
+    if have != build.source_digest() and not os.environ.get("NEP_ALLOW_STALE_LIB"):
+        raise ImportError("libnepmi355.so reports source digest %r, the binding expects %r" % (have, build.source_digest()))
+    return l
 
 
 lib = _load()
@@ -46,6 +59,7 @@ class cdouble(C.Structure):
 # name -> argtypes (restype is always int32 unless listed)
 SIGNATURES = {
     "nep_version": [],
+    "nep_src_digest": [],
     "nep_last_error": [],
     "nep_device_count": [P(c_i32)],
     "nep_set_device": [c_i32],
@@ -138,7 +152,7 @@ SIGNATURES = {
 for _name, _args in SIGNATURES.items():
     _f = getattr(lib, _name)  # AttributeError here = header/library mismatch
     _f.argtypes = _args
-    _f.restype = C.c_char_p if _name == "nep_last_error" else c_i32
+    _f.restype = C.c_char_p if _name in ("nep_last_error", "nep_src_digest") else c_i32
 
 
 def check(status):

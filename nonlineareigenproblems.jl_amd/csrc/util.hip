@@ -205,7 +205,13 @@ void PinnedRing::release() {
 
 extern "C" {
 
-int32_t nep_version(void) { return 100; }
+int32_t nep_version(void) { return 101; }
+#ifndef NEP_SRC_DIGEST
+#define NEP_SRC_DIGEST "unknown"
+#endif
+// digest of the sources this binary was built from (build.py passes it): the ctypes binding compares it with the sources it
+// sees, so a stale library with changed argument lists is refused instead of corrupting memory
+const char* nep_src_digest(void) { return NEP_SRC_DIGEST; }
 const char* nep_last_error(void) { return g_err; }
 
 int32_t nep_device_count(int32_t* n) {

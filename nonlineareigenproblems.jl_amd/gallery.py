@@ -129,6 +129,7 @@ def gun_matrices(n=9956):
     if n == 9956 and d:
         K = read_sparse_matrix(os.path.join(d, "gun_K.txt"))
         M = read_sparse_matrix(os.path.join(d, "gun_M.txt"))
+        _check_gun_files(K, M)
         return K, M, W1, W2
     if n == 9956:
         K, M = gun_standin_KM()
@@ -136,6 +137,18 @@ def gun_matrices(n=9956):
     nx, ny = _twin_grid(n)
     K, M = gun_standin_KM(nx, ny)
     return K, M, _fold(W1, n, True), _fold(W2, n, False)
+
+
+def _check_gun_files(K, M):
+    """files given through NEPMI_GUN_DIR must be THE gun matrices: shape 9956 x 9956 and the 1-norms the reference pins in
+    test/rk_helper/gun_test_utils.jl:50-51 (a wrong or truncated file would otherwise give a silently different problem)"""
+    for name, A, ref in (("gun_K.txt", K, GUN_NK), ("gun_M.txt", M, GUN_NM)):
+        if A.shape != (9956, 9956):
+            raise ValueError("NEPMI_GUN_DIR/%s: shape %s, expected (9956, 9956)" % (name, A.shape))
+        nrm = _onenorm(A)
+        if not abs(nrm - ref) <= 1e-12 * ref:
+            raise ValueError("NEPMI_GUN_DIR/%s: 1-norm %.16e differs from the reference value %.16e "
+                             "(test/rk_helper/gun_test_utils.jl:50-51)" % (name, nrm, ref))
 
 
 def nlevp_native_gun(n=9956):

@@ -39,14 +39,37 @@ def c2_device(na, nep, maxit=100, permc=None, timers=None, hist=None, return_dev
     return lam, Q
 
 
-def c2_oracle(n=GUN_N, maxit=100, permc="MMD_AT_PLUS_A", timers=None):
+def c2_oracle(n=GUN_N, maxit=100, permc="MMD_AT_PLUS_A", timers=None, hist=None):
     from oracle import gallery as og, solvers as osol, neps as oneps
     onep = og.gun_spmf_scaled(n)
     der = oneps.DerSPMF(onep, 0.0, maxit)
     lam, Q, _ = osol.iar(der, sigma=0.0, gamma=1.0, maxit=maxit, neigs=np.inf, v=np.ones(n), tol=1e-10,
                          errmeasure=osol.StandardSPMFErrmeasure(onep),
-                         linsolvercreator=osol.FactorizeLinSolverCreator(permc_spec=permc), timers=timers)
+                         linsolvercreator=osol.FactorizeLinSolverCreator(permc_spec=permc), timers=timers, errhist=hist)
     return lam, Q
+
+
+def history_agreement(h_dev, h_ora, floor=1e-12, lead=8):
+    """SURVEY.md section 8d parity rule (iv): per iteration the `lead` smallest error estimates of the two runs agree within a
+    factor 10 wherever both are above `floor`.  Returns (ok, worst ratio >= 1, number of compared entries, iterations)."""
+    worst = 1.0; cnt = 0
+    for eg, eo in zip(h_dev, h_ora):
+        a = np.sort(np.asarray(eg, dtype=float)); b = np.sort(np.asarray(eo, dtype=float))
+        kk = min(len(a), len(b), lead)
+        for x, y in zip(a[:kk], b[:kk]):
+            if x > floor and y > floor:
+                worst = max(worst, x / y, y / x); cnt += 1
+    return bool(worst < 10.0 and len(h_dev) == len(h_ora)), float(worst), int(cnt), int(min(len(h_dev), len(h_ora)))
+
+
+def c2_parity(lam_dev, hist_dev, lam_ora, hist_ora):
+    """parity object of the headline configuration (SURVEY.md section 8d rules i, iii, iv): same count, eigenvalue multiset
+    to 1e-8 relative, error histories within a factor 10 above 1e-12"""
+    ok, worst = match(lam_dev, lam_ora, 1e-8)
+    hok, hworst, hcnt, hit = history_agreement(hist_dev, hist_ora)
+    return {"oracle_eigenpairs": int(len(lam_ora)), "same_count": bool(len(lam_dev) == len(lam_ora)),
+            "eigenvalues_match_1e-8": bool(ok), "max_rel_eig_diff": worst, "history_within_x10_above_1e-12": hok,
+            "history_worst_ratio": hworst, "history_entries_compared": hcnt, "history_iterations": hit}
 
 
 # ---- C3: gun nleigs, variant R1 (test/nleigs/nleigs_gun_variant_r1.jl, test/rk_helper/gun_test_utils.jl) ---------------
@@ -154,3 +177,28 @@ def c5_device(na, nx=1003, nz=999, solver="gmres", N=37, reltol=1e-9, refine=1, 
     R = na.ResidualErrmeasure(nep)
     res = [float(na.estimate_error(R, lam[i], Q[:, i])) for i in range(len(lam))]
     return lam, Q, res, info
+
+
+def c5_host_residuals(nx, nz, lam, Q):
+    """||M(lam) v|| / ||v|| of every returned pair re-evaluated in FP64 ON THE HOST by the oracle's matrix-free waveguide
+    operator (oracle/wep.py WEP_FD: sparse stencils + FFT corner term, Waveguide.jl:204-379) -- independent of the device's K1"""
+    from oracle import wep as ow
+    o = ow.WEP_FD(nx, nz, "JARLEBRING")
+    out = []
+    for i in range(len(lam)):
+        v = np.asarray(Q[:, i], dtype=complex)
+        r = o._mlincomb(complex(lam[i]), v.reshape(-1, 1), np.ones(1, dtype=complex))
+        out.append(float(np.linalg.norm(r) / np.linalg.norm(v)))
+    return out
+
+
+def c5_oracle_twin(nx=303, nz=299, maxit=60):
+    """CPU oracle of config C5 on the reduced twin (assembled M(sigma) + SuperLU, oracle tiar, same start vector and
+    tolerances).  Returns (lam, Q, seconds)."""
+    from oracle import wep as ow, solvers as osol
+    o = ow.WEP_FD(nx, nz, "JARLEBRING")
+    n = o.n
+    t0 = time.perf_counter()
+    out = osol.tiar(o, sigma=-3 - 3.5j, gamma=1.0, maxit=maxit, neigs=np.inf, v=np.ones(n) / np.sqrt(n), tol=1e-8,
+                    errmeasure=osol.ResidualErrmeasure(o))
+    return out[0], out[1], time.perf_counter() - t0

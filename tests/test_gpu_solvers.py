@@ -1,6 +1,8 @@
 """GPU parity tests of the drivers: same inputs through the HIP backend and the CPU oracle;
 acceptance = the reference's own criterion verify_lambdas (test/runtests.jl:80-89): eigenpair count
 + residual below tol, plus eigenvalue agreement with the oracle run."""
+import os
+
 import numpy as np
 import scipy.sparse as sp
 import pytest
@@ -1170,3 +1172,31 @@ def test_lu_batch_from_terms_equals_batch_from_values(na):
         M = nep.compute_Mder(lam)
         assert np.abs(xa - xb).max() <= 1e-10 * np.abs(xa).max()
         assert np.linalg.norm(M @ xb.T - b.T) <= 1e-8 * np.linalg.norm(b)
+
+
+@pytest.mark.skipif(not os.environ.get("NEPMI_GUN_DIR"), reason="needs the physical gun_K.txt / gun_M.txt (absent from the "
+                    "reference checkout, .MISSING_LARGE_BLOBS): set NEPMI_GUN_DIR")
+def test_physical_gun_known_answers(na):
+    """the known answers the reference holds for the PHYSICAL gun problem, runnable as soon as the blobs are supplied:
+    ||K||_1, ||M||_1 (test/rk_helper/gun_test_utils.jl:50-51, enforced by the loader), the eigenvalue
+    22345.116783765+0.644998598i found by quasinewton from 150^2+i (test/gun_native.jl:9-19), the derivative check of
+    test/gun_native.jl:22-33, and the 21 eigenvalues of nleigs variant R1 (test/nleigs/nleigs_gun_variant_r1.jl:17)"""
+    from nep_amd import gallery
+    K, M, W1, W2 = gallery.gun_matrices()
+    assert abs(gallery._onenorm(K) - 1.474544889815002e+05) <= 1e-12 * 1.474544889815002e+05
+    assert abs(gallery._onenorm(M) - 2.726114618171165e-02) <= 1e-12 * 2.726114618171165e-02
+    nep = na.nep_gallery("nlevp_native_gun"); n = nep.n
+    tol = 1e-11
+    lam, v = na.quasinewton(nep, lam=150.0 ** 2 + 1j, v=np.ones(n), tol=tol, maxit=500)
+    v = v / np.linalg.norm(v)
+    assert np.linalg.norm(na.to_host(nep.compute_Mlincomb(lam, v))) < np.sqrt(tol)
+    assert abs(lam - (22345.116783765 + 0.644998598j)) < np.sqrt(tol) * 100
+    l0 = 150.0 ** 2 + 2j; ee = 1e-4
+    vv = np.random.default_rng(0).standard_normal(n)
+    z1 = na.to_host(nep.compute_Mlincomb(l0, vv.reshape(-1, 1), a=np.array([1.0]), startder=1))
+    z2 = (na.to_host(nep.compute_Mlincomb(l0 + ee, vv)) - na.to_host(nep.compute_Mlincomb(l0 - ee, vv))) / (2 * ee)
+    assert np.linalg.norm(z2.ravel() - z1.ravel()) < ee ** 2 * 1000
+    Sigma, Xi, nodes, v0 = _gun_r1_setup(n)
+    lam_r1, X, res = na.nleigs(nep, Sigma, Xi=Xi, maxit=100, v=v0, leja=0, nodes=nodes, reusefact=2,
+                               errmeasure=na.StandardSPMFErrmeasure(nep))[:3]
+    assert len(lam_r1) == 21

@@ -23,7 +23,11 @@ def test_library_exports_every_header_symbol():
     for nme in sorted(names):
         assert hasattr(lib, nme), "missing export " + nme
     assert set(na._lib.SIGNATURES) == names          # the ctypes binding covers the whole header
-    assert lib.nep_version() == 100
+    assert lib.nep_version() == 101
+    # the binary names the sources it was built from; the binding refuses a library whose digest differs (_lib._load)
+    from nep_amd import build
+    assert na._lib.lib.nep_src_digest().decode() == build.source_digest() == build.built_digest()
+    assert not build.needs_build()
 
 
 def test_no_cpu_fallback_without_gpu():
@@ -500,3 +504,30 @@ def test_device_lu_plan_is_independent_of_the_enumeration_threads():
     # malformed input is rejected, not read out of bounds
     bad = [a.copy() for a in arrs]; bad[1][0] = n + 5
     assert lib.nep_lu_refac_analyze(n, *[hptr(a) for a in bad], (C.c_int64 * 8)()) != 0
+
+
+def test_gun_loader_from_directory(tmp_path, monkeypatch):
+    """the NEPMI_GUN_DIR path of gallery.gun_matrices (src/gallery_extra/NLEVP_native.jl:4-18 reads gun_K.txt / gun_M.txt in
+    the text format of src/utils/Serialization.jl:8-31): files written in that format are read back bit for bit, pass the
+    1-norm known-answer check of test/rk_helper/gun_test_utils.jl:50-51, and a wrong file is refused instead of silently
+    defining another problem.  (The physical matrices are absent from the reference checkout; the files here hold the
+    stand-in, which carries the reference's norms by construction.)"""
+    import scipy.sparse as sp
+    from nep_amd import gallery
+    K, M = gallery.gun_standin_KM()
+    gallery.write_sparse_matrix(str(tmp_path / "gun_K.txt"), K)
+    gallery.write_sparse_matrix(str(tmp_path / "gun_M.txt"), M)
+    monkeypatch.setenv("NEPMI_GUN_DIR", str(tmp_path))
+    K2, M2, W1, W2 = gallery.gun_matrices()
+    assert (abs(K2 - K)).max() == 0.0 and (abs(M2 - M)).max() == 0.0
+    assert abs(gallery._onenorm(K2) - 1.474544889815002e+05) <= 1e-12 * 1.474544889815002e+05
+    assert abs(gallery._onenorm(M2) - 2.726114618171165e-02) <= 1e-12 * 2.726114618171165e-02
+    assert abs(gallery._onenorm(W1) - 2.328612251920476) < 1e-14 and abs(gallery._onenorm(W2) - 3.793375498194695) < 1e-14
+    nep = gallery.nlevp_native_gun()
+    assert nep.n == 9956
+    gallery.write_sparse_matrix(str(tmp_path / "gun_M.txt"), sp.csc_matrix(M * 1.001))
+    with pytest.raises(ValueError, match="1-norm"):
+        gallery.gun_matrices()
+    gallery.write_sparse_matrix(str(tmp_path / "gun_M.txt"), sp.csc_matrix(M[:100, :100]))
+    with pytest.raises(ValueError, match="shape"):
+        gallery.gun_matrices()
