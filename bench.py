@@ -245,6 +245,17 @@ def wep_scale_roofline(na):
         b = dev.algorithmic_bytes(k)
         out["k=%d" % k] = {"algorithmic_bytes": b, "ms_per_launch": ms, "achieved": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS}
         del V
+    # K2 (nep_resid_batch: the residuals of all k Ritz pairs of a tiar check in one pass over the matrices, src/errmeasure.jl:128-130,
+    # 186-190) at the same size; algorithmic bytes SURVEY.md section 8d K2: matrices + 16 n k (read Q, row-major), norms only
+    for k in (8, 60):
+        QT = torch.randn((n, k), dtype=torch.float64, device="cuda").to(torch.complex128)
+        F = np.random.default_rng(1).standard_normal((dev.mt, k)) + 0j
+        o = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+        ms = event_loop(lambda: dev.resid_batch_dev(F, QT, k, k, o), 10, warm=3)
+        b = dev.matrix_bytes + 16 * n * k
+        out["K2 k=%d" % k] = {"kernel": "nep_resid_batch_dev", "algorithmic_bytes": b, "ms_per_launch": ms, "achieved": b / ms / 1e6,
+                              "frac": b / ms / 1e6 / HBM_PEAK_GBS}
+        del QT
     return out
 
 

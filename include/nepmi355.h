@@ -77,6 +77,19 @@ int32_t nep_spmf_destroy(nep_spmf* s);
 /* info[0]=n info[1]=mt info[2]=total nnz info[3]=value bytes (8|16) info[4]=lanes per row
  * chosen for the SpMV info[5]=algorithmic matrix bytes of one pass over the stacked CSR */
 int32_t nep_spmf_info(const nep_spmf* s, int64_t info[6]);
+/* footprint tiles of the one-launch compute_Mlincomb kernel (csrc/spmv_tile.hip; all zero when the matrix has none):
+ * info[0]=blocks info[1]=largest column footprint info[2]=detected grid stride (0: consecutive rows) info[3],info[4]=patch
+ * shape info[5]=padded entries info[6]=footprint slots info[7]=bytes one launch streams for the matrix side */
+int32_t nep_spmf_tile_info(const nep_spmf* s, int64_t info[8]);
+/* host-only dry run of those tiles for an SPMF given as in nep_spmf_create (nothing goes to the device; tests without a GPU,
+ * sanitizer build): info as above, *maxerr = largest relative difference between z = sum_t A_t (V c_t) evaluated through the
+ * tiles (footprint -> W -> entries -> row map, as the kernel walks them) and directly, deterministic V (n x k), C (k x mt) */
+int32_t nep_spmf_tiles_analyze(int64_t n, int32_t mt, const int32_t* const* h_rowptr, const int32_t* const* h_colind,
+                               const void* const* h_vals, const int32_t* h_val_is_complex, int32_t k, int64_t info[8],
+                               double* maxerr);
+/* tuning / A-B knob for compute_Mlincomb: 0 = automatic choice per (n, k), 1 = the tiled one-launch kernel whenever the
+ * matrix has tiles, 2 = never (k_vc + SpMV / folded SpMV).  Process-wide. */
+int32_t nep_k1_set_mode(int32_t mode);
 int32_t nep_csc_to_csr(int64_t n, const int64_t* colptr, const int64_t* rowval, const void* nzval,
                        int32_t val_is_complex, int32_t one_based, int32_t* rowptr, int32_t* colind,
                        void* vals);
@@ -356,9 +369,10 @@ int32_t nep_wep_region_expand(int32_t nz, int32_t nx, int32_t N, const nep_cdoub
  * ref: a handle created by nep_lu_create_csc from (Lp, Li, Up, Ui, perm_r, perm_c); Ap / Ai: CSC pattern of the matrices to
  * come (caller's numbering), perm_r[i] / perm_c[j]: position of row i / column j of A in the factored matrix.
  * NEP_ERR_UNSUPPORTED: level-schedule handle, or the stored pattern is not closed under the elimination.
- * nep_lu_factor_dev: h_Ax = the nnz(A) values in the order of (Ap, Ai); growth_limit: largest |Re|+|Im| of an entry of L
- * that is accepted (a diagonally pivoted factor stays near 1; the stored pivot sequence may not suit the new values);
- * h_health[3] (may be NULL): [0] pivot breakdown flag, [1] that largest entry; h_LUx_out (may be NULL): the nnz(L) + nnz(U)
+ * nep_lu_factor_dev: h_Ax = the nnz(A) values in the order of (Ap, Ai); growth_limit: largest accepted value of BOTH max |L|
+ * (|Re|+|Im|; a diagonally pivoted factor stays near 1) and the element growth max|U| / max|A| (the stored pivot sequence may
+ * not suit the new values; growth in U is what bounds the backward error of a static-pivot factorisation);
+ * h_health[3] (may be NULL): [0] pivot breakdown flag, [1] max |L|, [2] max|U| / max|A|; h_LUx_out (may be NULL): the nnz(L) + nnz(U)
  * computed values in the input entry order (tests).  NEP_ERR_SINGULAR: breakdown / growth -- factorise on the host instead. */
 typedef struct nep_lu_refac nep_lu_refac;
 int32_t nep_lu_refac_create(nep_lu* ref, int64_t n, const int32_t* Lp, const int32_t* Li, const int32_t* Up, const int32_t* Ui,

@@ -168,7 +168,8 @@ class _NodeSolve:
                     fv = self.nep.get_fv()
                     Cf = np.array([[f.derivs(self.g(t) + self.sigma, 1)[0] for f in fv] for t in ts], dtype=np.complex128)
                     normA = np.sqrt(np.maximum(np.einsum("bs,st,bt->b", Cf.conj(), G, Cf).real, 0.0))
-                    lus = _DeviceRefactor.factor_batch_terms(plan, self.nep.n, D_dev, Cf, normA, expected_solves=1)
+                    lus = _DeviceRefactor.factor_batch_terms(plan, self.nep.n, D_dev, Cf, normA, expected_solves=1,
+                                                             growth=_DeviceRefactor.GROWTH_UNREFINED)
                     ts_host = []
                     for t, lu in zip(ts, lus):
                         if lu is None:

@@ -142,6 +142,27 @@ int nep_mlincomb_dev_shift(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_
 int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, const int64_t* d_active_rows,
                             nep_cdouble* dw, nep_cdouble* d_out, int32_t method, nep_cdouble* d_mirror, int32_t nmirror,
                             nep_stream stream);
+// ... and with an event (hipEvent_t or NULL) the stream waits for before the first kernel that writes w
+int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, const int64_t* d_active_rows,
+                               nep_cdouble* dw, nep_cdouble* d_out, int32_t method, nep_cdouble* d_mirror, int32_t nmirror,
+                               void* before_write, nep_stream stream);
+}
+
+// spmv_tile.hip: K1 in one launch on footprint tiles (built from the host arrays of the stacked CSR; *out stays NULL when the
+// matrix does not qualify)
+struct NepTiles;
+extern "C" {
+int nep_tiles_build(int64_t n, int mt, int valbytes, const int32_t* rowptr, const uint32_t* idx, const void* vals, NepTiles** out);
+void nep_tiles_destroy(NepTiles* t);
+void nep_tiles_info(const NepTiles* t, int64_t info[8]);
+size_t nep_tiles_shmem(const NepTiles* t, int k);
+int nep_tiles_mlincomb(const NepTiles* t, int k, const cplx* dC, int64_t ldc, const cplx* dV, int64_t ldv, cplx* dz, cplx* d_shift,
+                       hipStream_t st);
+// K2 on the tiles: R = residual block of k Ritz pairs (row-major Q), column norms as [nblk][2][k] partials and / or R itself
+int nep_tiles_nblk(const NepTiles* t);
+bool nep_tiles_resid_ok(const NepTiles* t, int k);
+int nep_tiles_resid(const NepTiles* t, int k, const cplx* dF, const cplx* QT, int64_t ldq, cplx* ZT, int64_t ldz, double* partial,
+                    hipStream_t st);
 }
 
 // small per-library scratch (device) helpers, defined in util.hip

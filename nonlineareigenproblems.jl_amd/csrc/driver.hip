@@ -30,6 +30,11 @@ struct nep_iar {
     cplx* hH_dev;                            // device address of the pinned block (NULL: not mapped, rows travel by memcpy)
     int32_t method;
     std::vector<hipEvent_t> ev;              // ev[k]: H column k is in pinned memory
+    // the recorded residual of the kept iterate (a pure check: nothing of the recurrence depends on it) runs on a side stream
+    // next to the projections of the Gram-Schmidt pass; the pass' first write to the vector waits for it
+    hipStream_t side = nullptr; hipEvent_t e_solved = nullptr, e_checked = nullptr;
+    hipEvent_t e_upload = nullptr; bool upload_waited = false;      // |f_t|, f_t were uploaded on the NULL stream
+    hipStream_t last = nullptr;
 };
 
 extern "C" {
@@ -57,6 +62,16 @@ int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdo
         int rcu = ring.upload(s->d_cabs, h_cabs, (size_t)mt * 8, nullptr);
         if (!rcu) rcu = ring.upload(s->d_ccf, h_cf, (size_t)mt * 16, nullptr);
         if (rcu) { nep_pool_free(p); delete s; return rcu; }
+        // the steps run on the caller's stream, which need not be ordered behind the NULL stream (non-blocking streams)
+        if (hipEventCreateWithFlags(&s->e_upload, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(s->e_upload, nullptr);
+        else (void)hipGetLastError();
+        static const int overlap = getenv("NEP_IAR_RESID_OVERLAP") ? atoi(getenv("NEP_IAR_RESID_OVERLAP")) : 1;
+        if (overlap && hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) == hipSuccess) {
+            if (hipEventCreateWithFlags(&s->e_solved, hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&s->e_checked, hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError(); (void)hipStreamDestroy(s->side); s->side = nullptr;
+            }
+        } else (void)hipGetLastError();
     }
     s->dH = (cplx*)dH; s->hH = h_pinnedH; s->method = orth_method;
     s->ev.assign(m + 1, nullptr);
@@ -72,7 +87,13 @@ int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdo
 int32_t nep_iar_destroy(nep_iar* s) {
     if (!s) return NEP_OK;
     for (hipEvent_t e : s->ev) if (e) (void)hipEventDestroy(e);
-    if (s->d_cabs) nep_pool_free(s->d_cabs);
+    if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
+    if (s->e_solved) (void)hipEventDestroy(s->e_solved);
+    if (s->e_checked) (void)hipEventDestroy(s->e_checked);
+    if (s->e_upload) (void)hipEventDestroy(s->e_upload);
+    // steps (speculative ones past convergence included) may still be queued on the last stream: the block goes back to the
+    // pool behind them
+    if (s->d_cabs) nep_pool_free_on(s->d_cabs, s->last, s->last != nullptr);
     delete s;
     return NEP_OK;
 }
@@ -82,6 +103,8 @@ int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream str
     ARGCHK(refine_steps == 0 || !s->cabs.empty());
     hipStream_t st = as_stream(stream);
     const int64_t n = s->n;
+    s->last = st;
+    if (s->e_upload && !s->upload_waited) { HIPCHK(hipStreamWaitEvent(st, s->e_upload, 0)); s->upload_waited = true; }
     cplx* col = s->dV + (int64_t)(k - 1) * s->ldv;      // column k-1: the n x k block of the reference's reshape
     cplx* vv = s->dV + (int64_t)k * s->ldv;
     int32_t shifted = 0;
@@ -108,18 +131,26 @@ int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream str
         }
         if (rc) return rc;
     }
+    void* before_write = nullptr;
     if (record) {       // omega of the iterate that is kept (stored negated in vv)
+        hipStream_t cs = st;
+        if (s->side) {  // reads vv, z; writes dW and the omega word of this row: ordered behind the solve, ahead of the first update
+            HIPCHK(hipEventRecord(s->e_solved, st));
+            HIPCHK(hipStreamWaitEvent(s->side, s->e_solved, 0));
+            cs = s->side;
+        }
         rc = nep_cw_resid_dev(s->spmf, s->d_cabs, (const nep_cdouble*)s->d_ccf, (const nep_cdouble*)vv, (const nep_cdouble*)s->dz,
-                              (nep_cdouble*)s->dW, bits + refine_steps, -1.0, st);
+                              (nep_cdouble*)s->dW, bits + refine_steps, -1.0, cs);
         if (rc) return rc;
+        if (s->side) { HIPCHK(hipEventRecord(s->e_checked, s->side)); before_write = (void*)s->e_checked; }
     }
     if (!shifted) {
         rc = nep_iar_shift_scale(n, k, (const nep_cdouble*)col, (nep_cdouble*)vv, stream);
         if (rc) return rc;
     }
     cplx* mirror = s->hH_dev ? s->hH_dev + (int64_t)(k - 1) * (s->m + 4) : nullptr;
-    rc = nep_orth_dev_mirror((const nep_cdouble*)s->dV, s->ldv, n * (int64_t)(k + 1), k, s->d_active, (nep_cdouble*)vv, (nep_cdouble*)hrow,
-                             s->method, (nep_cdouble*)mirror, k + 4, stream);
+    rc = nep_orth_dev_mirror_ev((const nep_cdouble*)s->dV, s->ldv, n * (int64_t)(k + 1), k, s->d_active, (nep_cdouble*)vv,
+                                (nep_cdouble*)hrow, s->method, (nep_cdouble*)mirror, k + 4, before_write, stream);
     if (rc) return rc;
     if (!mirror)
         HIPCHK(hipMemcpyAsync(s->hH + (int64_t)(k - 1) * (s->m + 4), hrow, (size_t)(k + 4) * sizeof(cplx), hipMemcpyDeviceToHost, st));

@@ -68,15 +68,23 @@ struct nep_lu_refac {
 };
 
 // ---- kernels ---------------------------------------------------------------------------------------------------------------
+// device health block per matrix: [0] = 1 when a pivot was zero / non-finite, [1] = largest |L| entry, [2] = largest |U| entry,
+// [3] = largest |A| entry ([1..3] as bit patterns: non-negative doubles order like integers)
+#define NEP_LU_HW 4
+__device__ __forceinline__ void health_max(double* slot, double v) {
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    if ((threadIdx.x & 63) == 0 && v > 0.0) atomicMax((unsigned long long*)slot, (unsigned long long)__double_as_longlong(v));
+}
 // (all kernels: blockIdx.y = matrix of a batch; the matrices share the plan and sit nF / nnzA / 3 entries apart)
 __global__ void k_lu_init(int64_t nF, int64_t n, int64_t nnzA, const int32_t* __restrict__ amap, const cplx* __restrict__ Ax,
                           const int32_t* __restrict__ ldiag, cplx* __restrict__ F, double* __restrict__ health) {
-    F += (int64_t)blockIdx.y * nF; Ax += (int64_t)blockIdx.y * nnzA; health += 3 * (int64_t)blockIdx.y;
+    F += (int64_t)blockIdx.y * nF; Ax += (int64_t)blockIdx.y * nnzA; health += NEP_LU_HW * (int64_t)blockIdx.y;
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-    // F was zeroed by a memset; scatter A, unit diagonal of L
-    if (i < nnzA) F[amap[i]] = Ax[i];
+    // F and the health words were zeroed by memsets; scatter A, unit diagonal of L, max |A| for the growth factor
+    double amax = 0.0;
+    if (i < nnzA) { const cplx a = Ax[i]; F[amap[i]] = a; amax = fabs(a.x) + fabs(a.y); }
     if (i < n) F[ldiag[i]] = cmake(1.0, 0.0);
-    if (i == 0) { health[0] = 0.0; health[1] = 0.0; health[2] = 0.0; }
+    health_max(&health[3], amax);
 }
 
 // the same with the values of matrix b assembled on the fly, A_b = sum_t Cf[b,t] A_t on the union pattern (D[e*mt + t] = value of
@@ -84,15 +92,32 @@ __global__ void k_lu_init(int64_t nF, int64_t n, int64_t nnzA, const int32_t* __
 __global__ void k_lu_init_terms(int64_t nF, int64_t n, int64_t nnzA, const int32_t* __restrict__ amap, const cplx* __restrict__ D,
                                 int mt, const cplx* __restrict__ Cf, const int32_t* __restrict__ ldiag, cplx* __restrict__ F,
                                 double* __restrict__ health) {
-    F += (int64_t)blockIdx.y * nF; Cf += (int64_t)blockIdx.y * mt; health += 3 * (int64_t)blockIdx.y;
+    F += (int64_t)blockIdx.y * nF; Cf += (int64_t)blockIdx.y * mt; health += NEP_LU_HW * (int64_t)blockIdx.y;
     const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    double amax = 0.0;
     if (i < nnzA) {
         cplx acc = cmake(0.0, 0.0);
         for (int t = 0; t < mt; ++t) cfma(acc, D[i * mt + t], Cf[t]);
         F[amap[i]] = acc;
+        amax = fabs(acc.x) + fabs(acc.y);
     }
     if (i < n) F[ldiag[i]] = cmake(1.0, 0.0);
-    if (i == 0) { health[0] = 0.0; health[1] = 0.0; health[2] = 0.0; }
+    health_max(&health[3], amax);
+}
+
+// largest |U| entry of the finished factor (U occupies F[nnzL, nnzL + nnzU)): with max |A| from k_lu_init this is the element
+// growth max|U| / max|A| of the static-pivot factorisation -- the quantity that bounds its backward error (max |L| alone does
+// not: growth compounds in U)
+__global__ __launch_bounds__(256) void k_lu_umax(int64_t nnzL, int64_t nnzU, const cplx* __restrict__ F, int64_t nF,
+                                                 double* __restrict__ health) {
+    F += (int64_t)blockIdx.y * nF; health += NEP_LU_HW * (int64_t)blockIdx.y;
+    double m = 0.0;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nnzU; i += (int64_t)gridDim.x * blockDim.x) {
+        const cplx u = F[nnzL + i];
+        const double a = fabs(u.x) + fabs(u.y);
+        m = (a == a) ? fmax(m, a) : 1.0e300;           // NaN counts as unbounded growth
+    }
+    health_max(&health[2], m);
 }
 
 // G lanes per destination entry of the level: F[dst] -= sum_products L * U   (sources final: lower levels are done).  Lane g
@@ -137,7 +162,7 @@ __global__ __launch_bounds__(256) void k_lu_wide(int64_t t0, int64_t t1, const i
 __global__ __launch_bounds__(256) void k_lu_scale(int q0, int q1, const int32_t* __restrict__ oldof, const int32_t* __restrict__ Lp,
                                                   const int32_t* __restrict__ Li, const int32_t* __restrict__ udiag,
                                                   cplx* __restrict__ F, double* __restrict__ health, int64_t nF) {
-    F += (int64_t)blockIdx.y * nF; health += 3 * (int64_t)blockIdx.y;
+    F += (int64_t)blockIdx.y * nF; health += NEP_LU_HW * (int64_t)blockIdx.y;
     const int q = q0 + blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (q >= q1) return;
@@ -171,7 +196,7 @@ __global__ __launch_bounds__(512) void k_lu_int(int blk0, const int32_t* __restr
                                                 const int32_t* __restrict__ udiag, const int64_t* __restrict__ piv_ptr,
                                                 const int32_t* __restrict__ tri, cplx* __restrict__ F, double* __restrict__ health,
                                                 int64_t nF) {
-    F += (int64_t)blockIdx.y * nF; health += 3 * (int64_t)blockIdx.y;
+    F += (int64_t)blockIdx.y * nF; health += NEP_LU_HW * (int64_t)blockIdx.y;
     const int b = blk0 + blockIdx.x;
     const int q0 = blk_se[2 * b], q1 = blk_se[2 * b + 1];
     double minpiv = 1.0e300, maxabs = 0.0;
@@ -557,7 +582,8 @@ int32_t nep_lu_refac_info(const nep_lu_refac* r, int64_t out[6]) {
 }
 
 // h_Ax: the nnzA values of the new matrix in the CSC order of (Ap, Ai).  h_health[3] (may be NULL): [0] = 1 when a pivot was
-// zero or non-finite, [1] = largest |Re| + |Im| over the entries of L (element growth; 1-ish for a diagonally pivoted factor).
+// zero or non-finite, [1] = largest |Re| + |Im| over the entries of L (1-ish for a diagonally pivoted factor), [2] = element
+// growth max|U| / max|A|; the factor is refused when [1] or [2] exceeds growth_limit.
 // h_LUx_out (may be NULL): receives nnzL + nnzU values (L then U, input entry order) -- tests compare them with the host factor.
 // NEP_ERR_SINGULAR when a pivot broke down (nothing is returned then).
 int32_t nep_lu_factor_dev(nep_lu_refac* r, const nep_cdouble* h_Ax, int32_t expected_solves, double growth_limit,
@@ -569,7 +595,7 @@ int32_t nep_lu_factor_dev(nep_lu_refac* r, const nep_cdouble* h_Ax, int32_t expe
     if (h_health) { h_health[0] = hh[0]; h_health[1] = hh[1]; h_health[2] = hh[2]; }
     if (rc) return rc;
     if (!*out) {
-        nep_set_error("device refactorisation: pivot breakdown or element growth %.3g above %.3g with the stored pivot sequence", hh[1], growth_limit);
+        nep_set_error("device refactorisation: pivot breakdown or growth (max|L| %.3g, max|U|/max|A| %.3g) above %.3g with the stored pivot sequence", hh[1], hh[2], growth_limit);
         return NEP_ERR_SINGULAR;
     }
     return NEP_OK;
@@ -604,7 +630,7 @@ static int32_t lu_factor_batch_impl(nep_lu_refac* r, int32_t B, const nep_cdoubl
     const int64_t nF = r->nnzL + r->nnzU;
     cplx* dF = nullptr; cplx* dA = nullptr; double* dH = nullptr;
     int rc;
-    if ((rc = nep_pool_alloc((void**)&dF, (size_t)B * nF * sizeof(cplx) + (size_t)B * 24 + 64))) return rc;
+    if ((rc = nep_pool_alloc((void**)&dF, (size_t)B * nF * sizeof(cplx) + (size_t)B * NEP_LU_HW * 8 + 64))) return rc;
     // dA: the B x nnz(A) values, or (terms form) the B x mt coefficients
     const size_t a_bytes = h_Ax ? (size_t)B * r->nnzA * sizeof(cplx) : (size_t)B * mt * sizeof(cplx);
     if ((rc = nep_pool_alloc((void**)&dA, a_bytes + 64))) { nep_pool_free(dF); return rc; }
@@ -617,7 +643,7 @@ static int32_t lu_factor_batch_impl(nep_lu_refac* r, int32_t B, const nep_cdoubl
         for (size_t off = 0; off < total; off += piece)
             if ((rc = ring.upload((char*)dA + off, srcp + off, std::min(piece, total - off), st))) return fail(rc);
     }
-    HIPCHK(hipMemsetAsync(dF, 0, (size_t)B * nF * sizeof(cplx), st));
+    HIPCHK(hipMemsetAsync(dF, 0, (size_t)B * nF * sizeof(cplx) + (size_t)B * NEP_LU_HW * 8, st));      // factor values + health words
     const unsigned gy = (unsigned)B;
     {
         const int64_t m = std::max<int64_t>(r->nnzA, r->n);
@@ -666,13 +692,23 @@ static int32_t lu_factor_batch_impl(nep_lu_refac* r, int32_t B, const nep_cdoubl
             LAUNCHCHK();
         }
     }
+    hipLaunchKernelGGL(k_lu_umax, dim3((unsigned)std::min<int64_t>(256, (r->nnzU + 255) / 256), gy), dim3(256), 0, st, r->nnzL, r->nnzU,
+                       (const cplx*)dF, nF, dH);
+    LAUNCHCHK();
     // health words (and, for tests, the factor values): one read-back behind the factorisation kernels
-    HIPCHK(hipMemcpyAsync(h_health, dH, (size_t)B * 24, hipMemcpyDeviceToHost, st));
+    std::vector<double> hw((size_t)B * NEP_LU_HW);
+    HIPCHK(hipMemcpyAsync(hw.data(), dH, (size_t)B * NEP_LU_HW * 8, hipMemcpyDeviceToHost, st));
     if (h_LUx_out) HIPCHK(hipMemcpyAsync(h_LUx_out, dF, (size_t)B * nF * sizeof(cplx), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     for (int b = 0; b < B; ++b) {
-        const double* hh = h_health + 3 * b;
-        if (hh[0] != 0.0 || !(hh[1] <= growth_limit)) continue;        // refused: out[b] stays NULL
+        // reported: [0] bad pivot, [1] max |L|, [2] element growth max|U| / max|A| of this static-pivot factorisation
+        double* hh = h_health + 3 * b;
+        const double amax = hw[(size_t)b * NEP_LU_HW + 3], umax = hw[(size_t)b * NEP_LU_HW + 2];
+        hh[0] = hw[(size_t)b * NEP_LU_HW]; hh[1] = hw[(size_t)b * NEP_LU_HW + 1];
+        hh[2] = amax > 0.0 ? umax / amax : (umax > 0.0 ? 1.0e300 : 0.0);
+        // refused (out[b] stays NULL, the caller factorises this one on the host with fresh pivoting): a broken pivot, or
+        // growth in L or in U above the limit -- growth in U is the factor that bounds the backward error
+        if (hh[0] != 0.0 || !(hh[1] <= growth_limit) || !(hh[2] <= growth_limit)) continue;
         MLFactor* F = nullptr;
         const cplx* Fb = dF + (size_t)b * nF;
         rc = ml_create_from_sym(r->S, (const nep_cdouble*)Fb, (const nep_cdouble*)(Fb + r->nnzL), st, expected_solves, &F);

@@ -363,6 +363,13 @@ extern "C" int32_t nep_orth_dev(const nep_cdouble* dV, int64_t ldv, int64_t rows
 extern "C" int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
                                        const int64_t* d_active_rows, nep_cdouble* dw, nep_cdouble* d_out, int32_t method,
                                        nep_cdouble* d_mirror, int32_t nmirror, nep_stream stream) {
+    return nep_orth_dev_mirror_ev(dV, ldv, rows, k, d_active_rows, dw, d_out, method, d_mirror, nmirror, nullptr, stream);
+}
+// before_write (may be NULL): an event the stream waits for before the first kernel that WRITES w (the first update): work on
+// another stream that still reads w -- iar's recorded residual of the kept iterate -- runs next to the projections
+extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
+                                          const int64_t* d_active_rows, nep_cdouble* dw, nep_cdouble* d_out, int32_t method,
+                                          nep_cdouble* d_mirror, int32_t nmirror, void* before_write, nep_stream stream) {
     ARGCHK(dV && dw && d_out);
     ARGCHK(rows > 0 && k >= 1 && ldv >= rows);
     ARGCHK(method == 0 || method == 1);
@@ -399,6 +406,7 @@ extern "C" int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64
         hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_c, gate, out,
                            p == 0 ? 1 : 0, p == 0 ? d_state : (int*)nullptr);
         LAUNCHCHK();
+        if (p == 0 && before_write) HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)before_write, 0));
         hipLaunchKernelGGL(k_orth_update, dim3(npart), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
                            (const cplx*)d_c, w, d_pn, gate);
         LAUNCHCHK();

@@ -26,6 +26,7 @@ struct nep_spmf {
     uint32_t* d_sell_idx = nullptr;
     void* d_sell_val = nullptr;
     int64_t sell_cols = 0;           // padded entries / 64
+    NepTiles* tiles = nullptr;       // footprint tiles (spmv_tile.hip): K1 in one launch, no W round trip
     NepScratch coef;          // staged coefficient matrices
     NepScratch part;          // per-block partials
     NepScratch cwpart;        // nep_cw_backward_error's own scratch: it runs on the solve stream while a residual batch
@@ -439,6 +440,10 @@ static int launch_spmv_fold(const nep_spmf* s, const cplx* v, const cplx* dC, in
     return NEP_OK;
 }
 
+static int fuse_max_small() {
+    static const int env = getenv("NEP_K1_FUSE_MAX") ? atoi(getenv("NEP_K1_FUSE_MAX")) : -1;
+    return env >= 0 ? (env < 16 ? env : 16) : 16;
+}
 // 2 <= k <= fuse_max(): one launch, no W (see k_spmv_sell_kfused)
 static int fuse_max(const nep_spmf* s) {
     static const int env = getenv("NEP_K1_FUSE_MAX") ? atoi(getenv("NEP_K1_FUSE_MAX")) : -1;
@@ -615,10 +620,11 @@ static int launch_spmm(const nep_spmf* s, int k, const cplx* dF, const cplx* XT,
 
 extern "C" {
 
-int32_t nep_spmf_create(int64_t n, int32_t mt, const int32_t* const* h_rowptr, const int32_t* const* h_colind,
-                        const void* const* h_vals, const int32_t* h_val_is_complex, nep_spmf** out) {
-    ARGCHK(out != nullptr);
-    *out = nullptr;
+// stacked CSR on the host: per row, the entries of all terms sorted by (col, term)
+static int stack_terms(int64_t n, int32_t mt, const int32_t* const* h_rowptr, const int32_t* const* h_colind,
+                       const void* const* h_vals, const int32_t* h_val_is_complex, std::vector<int32_t>& rowptr,
+                       std::vector<uint32_t>& idx, std::vector<double>& vr, std::vector<nep_cdouble>& vc, bool* any_complex_out,
+                       int64_t* nnz_out) {
     ARGCHK(n > 0 && n <= (int64_t)NEP_COL_MASK);
     ARGCHK(mt > 0 && mt <= NEP_MAX_TERMS);
     ARGCHK(h_rowptr && h_colind && h_vals && h_val_is_complex);
@@ -630,11 +636,10 @@ int32_t nep_spmf_create(int64_t n, int32_t mt, const int32_t* const* h_rowptr, c
         any_complex |= (h_val_is_complex[i] != 0);
     }
     ARGCHK(nnz < ((int64_t)1 << 31) - 64);
-    // ---- build the stacked CSR on the host: per row, entries of all terms sorted by (col, term)
-    std::vector<int32_t> rowptr(n + 1);
-    std::vector<uint32_t> idx(nnz);
-    std::vector<double> vr(any_complex ? 0 : nnz);
-    std::vector<nep_cdouble> vc(any_complex ? nnz : 0);
+    rowptr.assign(n + 1, 0);
+    idx.assign(nnz, 0u);
+    vr.assign(any_complex ? 0 : nnz, 0.0);
+    vc.assign(any_complex ? nnz : 0, nep_cdouble());
     struct Ent { uint32_t col; uint32_t term; double re, im; };
     std::vector<Ent> tmp;
     int64_t pos = 0;
@@ -660,6 +665,38 @@ int32_t nep_spmf_create(int64_t n, int32_t mt, const int32_t* const* h_rowptr, c
             ++pos;
         }
         rowptr[r + 1] = (int32_t)pos;
+    }
+    *any_complex_out = any_complex; *nnz_out = nnz;
+    return NEP_OK;
+}
+
+extern "C" int nep_tiles_dryrun(int64_t n, int mt, int valbytes, const int32_t* rowptr, const uint32_t* idx, const void* vals, int k,
+                                int64_t info[8], double* maxerr);
+
+// host-only dry run of the footprint tiles of the one-launch K1 kernel (csrc/spmv_tile.hip) for the SPMF given as in
+// nep_spmf_create: nothing goes to the device.  info as nep_spmf_tile_info; *maxerr = largest relative difference between
+// z = sum_t A_t (V c_t) evaluated through the tiles and directly (deterministic V, C with k columns / rows).
+int32_t nep_spmf_tiles_analyze(int64_t n, int32_t mt, const int32_t* const* h_rowptr, const int32_t* const* h_colind,
+                               const void* const* h_vals, const int32_t* h_val_is_complex, int32_t k, int64_t info[8],
+                               double* maxerr) {
+    ARGCHK(info && maxerr && k >= 1);
+    std::vector<int32_t> rowptr; std::vector<uint32_t> idx; std::vector<double> vr; std::vector<nep_cdouble> vc;
+    bool any_complex = false; int64_t nnz = 0;
+    const int rc = stack_terms(n, mt, h_rowptr, h_colind, h_vals, h_val_is_complex, rowptr, idx, vr, vc, &any_complex, &nnz);
+    if (rc) return rc;
+    return nep_tiles_dryrun(n, mt, any_complex ? 16 : 8, rowptr.data(), idx.data(),
+                            any_complex ? (const void*)vc.data() : (const void*)vr.data(), k, info, maxerr);
+}
+
+int32_t nep_spmf_create(int64_t n, int32_t mt, const int32_t* const* h_rowptr, const int32_t* const* h_colind,
+                        const void* const* h_vals, const int32_t* h_val_is_complex, nep_spmf** out) {
+    ARGCHK(out != nullptr);
+    *out = nullptr;
+    std::vector<int32_t> rowptr; std::vector<uint32_t> idx; std::vector<double> vr; std::vector<nep_cdouble> vc;
+    bool any_complex = false; int64_t nnz = 0;
+    {
+        const int rc = stack_terms(n, mt, h_rowptr, h_colind, h_vals, h_val_is_complex, rowptr, idx, vr, vc, &any_complex, &nnz);
+        if (rc) return rc;
     }
     nep_spmf* s = new nep_spmf();
     s->n = n; s->mt = mt; s->nnz = nnz; s->valbytes = any_complex ? 16 : 8;
@@ -719,12 +756,55 @@ int32_t nep_spmf_create(int64_t n, int32_t mt, const int32_t* const* h_rowptr, c
         }
     }
 #undef CRCHK
+    {
+        const int rc = nep_tiles_build(n, mt, s->valbytes, rowptr.data(), idx.data(),
+                                       any_complex ? (const void*)vc.data() : (const void*)vr.data(), &s->tiles);
+        if (rc) { nep_spmf_destroy(s); return rc; }
+    }
     *out = s;
+    return NEP_OK;
+}
+
+// K1 kernel choice (tuning / A-B knob): 0 = automatic, 1 = footprint tiles whenever they exist, 2 = never tiles
+static int g_k1_mode = -1;
+int32_t nep_k1_set_mode(int32_t mode) { g_k1_mode = mode; return NEP_OK; }
+static bool use_tiles(const nep_spmf* s, int k) {
+    if (!s->tiles) return false;
+    if (g_k1_mode < 0) g_k1_mode = getenv("NEP_K1_MODE") ? atoi(getenv("NEP_K1_MODE")) : 0;
+    if (g_k1_mode == 2) return false;
+    if (nep_tiles_shmem(s->tiles, k) > 160 * 1024) return false;
+    if (g_k1_mode == 1) return true;
+    // measured ranges: at n = 1e6 the tiles win for 2 <= k <= 12 (no W round trip; k = 1 stays with the folded
+    // SELL SpMV, large k with k_vc + SELL whose W round trip is small against V); at gun size see NEP_K1_TILE_SMALL_KMIN
+    static const int kmin_l = getenv("NEP_K1_TILE_KMIN") ? atoi(getenv("NEP_K1_TILE_KMIN")) : 2;
+    static const int kmax_l = getenv("NEP_K1_TILE_KMAX") ? atoi(getenv("NEP_K1_TILE_KMAX")) : 12;
+    static const int kmin_s = getenv("NEP_K1_TILE_SMALL_KMIN") ? atoi(getenv("NEP_K1_TILE_SMALL_KMIN")) : (1 << 30);
+    if (s->d_sell_ptr) return k >= kmin_l && k <= kmax_l;
+    return k >= kmin_s;
+}
+
+// K2 on the tiles: large matrices only (at gun size the wave-per-row kernel's gathers are L2 hits and it is launch-bound)
+static bool use_tiles_k2(const nep_spmf* s, int k) {
+    if (!s->tiles) return false;
+    if (g_k1_mode < 0) g_k1_mode = getenv("NEP_K1_MODE") ? atoi(getenv("NEP_K1_MODE")) : 0;
+    if (g_k1_mode == 2 || !nep_tiles_resid_ok(s->tiles, k)) return false;
+    if (g_k1_mode == 1) return true;
+    // measured at n = 1e6: 4.5x faster than the wave-per-row kernel at k = 8, 1.35x at k = 30, slower at k = 60
+    // (row-major Q: a column panel of a footprint row is a 64-byte piece of a 16 k-byte row)
+    static const int kmax = getenv("NEP_K2_TILE_KMAX") ? atoi(getenv("NEP_K2_TILE_KMAX")) : 40;
+    return s->d_sell_ptr != nullptr && k <= kmax;
+}
+
+int32_t nep_spmf_tile_info(const nep_spmf* s, int64_t info[8]) {
+    ARGCHK(s && info);
+    for (int i = 0; i < 8; ++i) info[i] = 0;
+    if (s->tiles) nep_tiles_info(s->tiles, info);
     return NEP_OK;
 }
 
 int32_t nep_spmf_destroy(nep_spmf* s) {
     if (!s) return NEP_OK;
+    if (s->tiles) nep_tiles_destroy(s->tiles);
     if (s->d_rowptr) (void)hipFree(s->d_rowptr);
     if (s->d_idx) (void)hipFree(s->d_idx);
     if (s->d_vals) (void)hipFree(s->d_vals);
@@ -760,6 +840,8 @@ int32_t nep_mlincomb(nep_spmf* s, int32_t k, const nep_cdouble* hC, const nep_cd
     // the pinned ring protects the host side
     rc = s->ring.upload(s->coef.dptr, hC, cbytes, st);
     if (rc) return rc;
+    if (use_tiles(s, k))
+        return nep_tiles_mlincomb(s->tiles, k, (const cplx*)s->coef.dptr, k, (const cplx*)dV, ldv, (cplx*)dz, nullptr, st);
     if (k == 1) {
         if (s->valbytes == 8) return launch_spmv_fold<double>(s, (const cplx*)dV, (const cplx*)s->coef.dptr, 1, (cplx*)dz, st);
         return launch_spmv_fold<cplx>(s, (const cplx*)dV, (const cplx*)s->coef.dptr, 1, (cplx*)dz, st);
@@ -779,6 +861,8 @@ int32_t nep_mlincomb_dev(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t 
     ARGCHK(s && dC && dV && dz);
     ARGCHK(k >= 1 && ldv >= s->n && ldc >= k);
     hipStream_t st = as_stream(stream);
+    if (use_tiles(s, k))
+        return nep_tiles_mlincomb(s->tiles, k, (const cplx*)dC, ldc, (const cplx*)dV, ldv, (cplx*)dz, nullptr, st);
     if (k == 1) {
         if (s->valbytes == 8) return launch_spmv_fold<double>(s, (const cplx*)dV, (const cplx*)dC, ldc, (cplx*)dz, st);
         return launch_spmv_fold<cplx>(s, (const cplx*)dV, (const cplx*)dC, ldc, (cplx*)dz, st);
@@ -798,6 +882,10 @@ int32_t nep_mlincomb_dev(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t 
 int nep_mlincomb_dev_shift(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_t ldc, const nep_cdouble* dV, int64_t ldv,
                            nep_cdouble* dz, nep_cdouble* d_shift, int32_t* folded, hipStream_t st) {
     *folded = 0;
+    if (use_tiles(s, k) && !getenv("NEP_NO_SHIFT_FOLD")) {      // one launch: coefficient product, SpMV and the block shift
+        *folded = 1;
+        return nep_tiles_mlincomb(s->tiles, k, (const cplx*)dC, ldc, (const cplx*)dV, ldv, (cplx*)dz, (cplx*)d_shift, st);
+    }
     if (k == 1 || (k <= fuse_max(s) && (size_t)s->mt * k * sizeof(cplx) <= 48 * 1024) || getenv("NEP_NO_SHIFT_FOLD"))
         return nep_mlincomb_dev(s, k, dC, ldc, dV, ldv, dz, (nep_stream)st);
     int rc = launch_vc(s, k, (const cplx*)dC, ldc, (const cplx*)dV, ldv, st, (cplx*)d_shift);
@@ -867,13 +955,16 @@ static int resid_panels(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
         if (rc) return rc;
         rc = s->ring.upload(s->coef.dptr, hF + (size_t)j0 * s->mt, cbytes, st);
         if (rc) return rc;
-        int grid = (int)std::min<int64_t>((s->n + 3) / 4, 2048);
+        const bool tiled = use_tiles_k2(s, kk);
+        int grid = tiled ? nep_tiles_nblk(s->tiles) : (int)std::min<int64_t>((s->n + 3) / 4, 2048);
         rc = s->part.ensure(((size_t)grid * 2 * kk + 2 * kk) * sizeof(double));
         if (rc) return rc;
         double* partial = (double*)s->part.dptr;
         double* outd = d_out ? d_out + 2 * (size_t)j0 : partial + (size_t)grid * 2 * kk;
         const cplx* Q = (const cplx*)dQT + j0;
-        if (s->valbytes == 8)
+        if (tiled)
+            rc = nep_tiles_resid(s->tiles, kk, (const cplx*)s->coef.dptr, Q, ldq, nullptr, 0, partial, st);
+        else if (s->valbytes == 8)
             rc = launch_spmm<double>(s, kk, (const cplx*)s->coef.dptr, Q, ldq, 0, nullptr, 0, partial, grid, st);
         else
             rc = launch_spmm<cplx>(s, kk, (const cplx*)s->coef.dptr, Q, ldq, 0, nullptr, 0, partial, grid, st);
@@ -921,7 +1012,8 @@ int32_t nep_resid_block(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
         const cplx* F = (const cplx*)s->coef.dptr + (size_t)j0 * s->mt;
         const cplx* Q = (const cplx*)dQT + j0;
         cplx* R = (cplx*)dRT + j0;
-        if (s->valbytes == 8) rc = launch_spmm<double>(s, kk, F, Q, ldq, 0, R, ldr, nullptr, grid, st);
+        if (use_tiles_k2(s, kk)) rc = nep_tiles_resid(s->tiles, kk, F, Q, ldq, R, ldr, nullptr, st);
+        else if (s->valbytes == 8) rc = launch_spmm<double>(s, kk, F, Q, ldq, 0, R, ldr, nullptr, grid, st);
         else rc = launch_spmm<cplx>(s, kk, F, Q, ldq, 0, R, ldr, nullptr, grid, st);
         if (rc) return rc;
     }

@@ -1,0 +1,664 @@
+// libnepmi355: K1 (compute_Mlincomb, src/NEPTypes.jl:972-1011 / 1130-1160) as ONE launch on footprint tiles (gfx950).
+//
+//   z = sum_t A_t (V c_t)                     V n x k (column-major), c_t = C[:, t]
+//
+// The two-launch form (k_vc: W = V C, n x m_t through HBM; then the SpMV over the stacked matrix gathers W) pays a round trip
+// of W and a kernel boundary; folding the coefficient product into the SpMV per ENTRY instead (k_spmv_sell_kfused) turns every
+// matrix entry into k gathers that go to L2.  Here the matrix is cut into blocks of rows whose COLUMN FOOTPRINT (the distinct
+// columns its entries touch) fits in LDS:
+//
+//   phase 1  for every footprint column c of the block:  W[t][c] = sum_j V[c, j] C[j, t]   -> LDS     (V read coalesced along c)
+//   phase 2  for every row r of the block:               z[r] = sum_e val[e] W[term(e)][local(e)]      (entries from HBM, W from LDS)
+//
+// For matrices of a 2-D grid (the waveguide's 5-point stencils with row = x nz + z, the gun stand-in's 9-point stencil) the
+// blocks are xp x zp PATCHES of the grid -- the dominant off-diagonal stride s is detected from the pattern -- so the
+// footprint is the patch plus a one-point halo ((xp+2)(zp+2) columns for xp zp rows: 1.3x at 8 x 64) instead of the 2 s + R
+// columns a block of R consecutive rows touches.  The halo columns are read by the neighbouring blocks as well; blocks are
+// dealt to the XCDs in contiguous ranges, so those re-reads are L2 hits and the HBM traffic of the launch is the algorithmic
+// minimum: matrix + V + z.  Entries carry a 16-bit (term, local column) index instead of the 32-bit (term, column) of the
+// stacked CSR: 10 bytes per non-zero of a real matrix instead of 12.
+//
+// Nothing here depends on the grid guess being right: the footprint of every block is computed from its entries, blocks whose
+// footprint does not fit are split, and a matrix with a row that does not fit at all simply gets no tiles (the caller keeps
+// the two-launch path).
+#include "common.h"
+#include <vector>
+#include <algorithm>
+#include <cmath>
+
+struct TileDesc {
+    int32_t r0, stride, zp, nrows;     // local row l -> global row r0 + (l / zp) * stride + l % zp,  l < nrows
+    int32_t fp_off, fp_cnt;            // footprint slots [fp_off, fp_off + fp_cnt)
+    int32_t ent_off64;                 // first entry / 64
+    int32_t wrb;                       // width (entries per row, padded) | rb << 16 (rows padded to a multiple of 16)
+};
+
+struct NepTiles {
+    int64_t n = 0; int mt = 0; int valbytes = 8;
+    int nblk = 0, fcap = 0, lbits = 13, stride = 0, xp = 0, zp = 0;
+    int64_t nent = 0, nfp = 0;
+    TileDesc* d_desc = nullptr;
+    uint32_t* d_fp = nullptr;
+    uint16_t* d_eidx = nullptr;
+    void* d_eval = nullptr;
+};
+
+#define TILE_OWN 0x80000000u
+
+__device__ __forceinline__ int tile_block(int swz) {
+    const int b = blockIdx.x, nb = gridDim.x;
+    if (!swz) return b;
+    const int x = b & 7, i = b >> 3, per = nb >> 3, rem = nb & 7;
+    return x * per + (x < rem ? x : rem) + i;
+}
+
+typedef double d2t __attribute__((ext_vector_type(2)));
+template <bool NT> __device__ __forceinline__ double tload(const double* p) { return NT ? __builtin_nontemporal_load(p) : *p; }
+template <bool NT> __device__ __forceinline__ cplx tload(const cplx* p) {
+    if (NT) { const d2t v = __builtin_nontemporal_load((const d2t*)p); return cmake(v.x, v.y); }
+    return *p;
+}
+
+// MTC = min(mt, 4) accumulators per footprint column; mt in 5..8 takes two passes over V (L1/L2 hits).
+// blockDim.x = 256 (large matrices: several workgroups per CU overlap their phases) or 512 / 1024 (small matrices with many
+// columns: the k loads of a footprint column are split over NG thread groups so that every load of a block is in flight at
+// once -- at gun size the kernel is bound by dependent-load round trips, not by bytes).
+// PF: the entries of the thread's rows (phase 2) are fetched into registers BEFORE the coefficient phase and its barrier
+// (blocks of at most 2 blockDim rows x 8 entries: the waveguide stencils), so phase 2 only reads LDS.
+template <typename VT, int MTC, bool NT, bool PF>
+__global__ __launch_bounds__(PF ? 256 : 1024) void k_tile_mlincomb(const TileDesc* __restrict__ desc, const uint32_t* __restrict__ fp,
+                                                        const uint16_t* __restrict__ eidx, const VT* __restrict__ eval,
+                                                        const cplx* __restrict__ V, int64_t ldv, int k,
+                                                        const cplx* __restrict__ C, int64_t ldc, int mt, int fcap, int lbits,
+                                                        cplx* __restrict__ z, cplx* __restrict__ shift_dst, int swz, int split) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* W = (cplx*)smem;                       // [mt][fcap]
+    cplx* cs = W + (size_t)mt * fcap;            // [mt][k]
+    cplx* part = cs + (size_t)mt * k;            // [NG][MTC][Fpad], NG * Fpad <= blockDim (split launches only)
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const TileDesc d = desc[tile_block(swz)];
+    const int width = d.wrb & 0xffff, rb = d.wrb >> 16;
+    const uint16_t* __restrict__ ib = eidx + (int64_t)d.ent_off64 * 64;
+    const VT* __restrict__ vb = eval + (int64_t)d.ent_off64 * 64;
+    // ---- phase-2 operands fetched ahead (independent of everything below)
+    uint16_t pidx[2][8]; VT pval[2][8];
+    const bool pf = PF && width <= 8 && rb <= 2 * nthr;
+    if (PF && pf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int l = tid + q * nthr;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool on = l < rb && j < width;
+                const int64_t e = on ? (int64_t)j * rb + l : 0;
+                pidx[q][j] = NT ? __builtin_nontemporal_load(ib + e) : ib[e];
+                pval[q][j] = tload<NT>(vb + e);
+                if (!on) { pidx[q][j] = 0; if constexpr (sizeof(VT) == 8) pval[q][j] = 0.0; else pval[q][j] = cmake(0.0, 0.0); }
+            }
+        }
+    }
+    for (int i = tid; i < mt * k; i += nthr) cs[i] = C[(i % k) + (int64_t)(i / k) * ldc];
+    __syncthreads();
+    const int F = d.fp_cnt;
+    const uint32_t* __restrict__ fpb = fp + d.fp_off;
+    const int Fpad = (F + 15) & ~15;
+    int NG = 1;
+    if (split) { NG = nthr / Fpad; if (NG > k / 2) NG = k / 2; if (NG < 1) NG = 1; }
+    if (NG == 1) {
+        for (int f = tid; f < F; f += nthr) {
+            const uint32_t raw = fpb[f];
+            const int64_t c = raw & NEP_COL_MASK;
+            const bool own = (raw & TILE_OWN) != 0 && shift_dst != nullptr;
+            const cplx* vp = V + c;
+            for (int i0 = 0; i0 < mt; i0 += MTC) {
+                cplx acc[MTC];
+#pragma unroll
+                for (int i = 0; i < MTC; ++i) acc[i] = cmake(0.0, 0.0);
+                const cplx* cp = cs + (size_t)i0 * k;
+#pragma unroll 8
+                for (int j = 0; j < k; ++j) {
+                    const cplx v = vp[(int64_t)j * ldv];
+                    if (own && i0 == 0) {               // iar: block j+1 of the next basis column = block j / (j+1) (method_iar.jl:97-98)
+                        const double sc = 1.0 / (double)(j + 1);
+                        shift_dst[c + (int64_t)j * ldv] = cmake(v.x * sc, v.y * sc);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MTC; ++i)
+                        if (i0 + i < mt) cfma(acc[i], v, cp[i * k + j]);
+                }
+#pragma unroll
+                for (int i = 0; i < MTC; ++i)
+                    if (i0 + i < mt) W[(size_t)(i0 + i) * fcap + f] = acc[i];
+            }
+        }
+    } else {
+        const int g = tid / Fpad, f = tid - g * Fpad;
+        const bool live = g < NG && f < F;
+        const uint32_t raw = live ? fpb[f] : 0u;
+        const int64_t c = raw & NEP_COL_MASK;
+        const bool own = live && (raw & TILE_OWN) != 0 && shift_dst != nullptr;
+        const cplx* vp = V + c;
+        for (int i0 = 0; i0 < mt; i0 += MTC) {
+            cplx acc[MTC];
+#pragma unroll
+            for (int i = 0; i < MTC; ++i) acc[i] = cmake(0.0, 0.0);
+            const cplx* cp = cs + (size_t)i0 * k;
+            if (live) {
+#pragma unroll 8
+                for (int j = g; j < k; j += NG) {
+                    const cplx v = vp[(int64_t)j * ldv];
+                    if (own && i0 == 0) {
+                        const double sc = 1.0 / (double)(j + 1);
+                        shift_dst[c + (int64_t)j * ldv] = cmake(v.x * sc, v.y * sc);
+                    }
+#pragma unroll
+                    for (int i = 0; i < MTC; ++i)
+                        if (i0 + i < mt) cfma(acc[i], v, cp[i * k + j]);
+                }
+            }
+            if (i0 > 0) __syncthreads();
+            if (g < NG) {
+#pragma unroll
+                for (int i = 0; i < MTC; ++i) part[(size_t)(g * MTC + i) * Fpad + f] = acc[i];
+            }
+            __syncthreads();
+            for (int t = tid; t < MTC * Fpad; t += nthr) {
+                const int i = t / Fpad, ff = t - i * Fpad;
+                if (ff < F && i0 + i < mt) {
+                    cplx s = part[(size_t)i * Fpad + ff];
+                    for (int q = 1; q < NG; ++q) s = cadd(s, part[(size_t)(q * MTC + i) * Fpad + ff]);
+                    W[(size_t)(i0 + i) * fcap + ff] = s;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: rows of the block, G lanes per row when the block has few rows
+    const uint32_t lmask = (1u << lbits) - 1u;
+    if (PF && pf) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int l = tid + q * nthr;
+            cplx acc = cmake(0.0, 0.0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t id = pidx[q][j];
+                cfma(acc, pval[q][j], W[(size_t)(id >> lbits) * fcap + (id & lmask)]);
+            }
+            if (l < d.nrows) {
+                const int i = l / d.zp, jz = l - i * d.zp;
+                z[(int64_t)d.r0 + (int64_t)i * d.stride + jz] = acc;
+            }
+        }
+        return;
+    }
+    int G = 1;
+    while (G < 16 && rb * G * 2 <= nthr) G <<= 1;
+    const int rpp = nthr / G;
+    const int g = tid % G;
+    for (int l0 = 0; l0 < rb; l0 += rpp) {
+        const int l = l0 + tid / G;
+        cplx acc = cmake(0.0, 0.0);
+        if (l < rb) {
+#pragma unroll 4
+            for (int j = g; j < width; j += G) {
+                const int64_t e = (int64_t)j * rb + l;
+                const uint32_t id = NT ? __builtin_nontemporal_load(ib + e) : ib[e];
+                const VT a = tload<NT>(vb + e);
+                cfma(acc, a, W[(size_t)(id >> lbits) * fcap + (id & lmask)]);
+            }
+        }
+        for (int off = G >> 1; off > 0; off >>= 1) { acc.x += shfl_xor_d(acc.x, off); acc.y += shfl_xor_d(acc.y, off); }
+        if (g == 0 && l < d.nrows) {
+            const int i = l / d.zp, jz = l - i * d.zp;
+            z[(int64_t)d.r0 + (int64_t)i * d.stride + jz] = acc;
+        }
+    }
+}
+
+// ---- K2 on the same tiles: residuals of all k Ritz pairs of a convergence check (src/errmeasure.jl:128-130, 186-190) ----------
+//   R[r, s] = sum_e val[e] F[term(e), s] Q[col(e), s]      Q row-major (n x k, row r holds the k Ritz vectors' r-th entries)
+// The wave-per-row kernel (k_spmm_rm) gathers one Q row per matrix entry through L2: 8 entries per row at waveguide scale =
+// 8x the bytes of Q through L2 and 0.18 of the HBM roofline at k = 60.  Here the Q rows of a block's column footprint are
+// staged in LDS once per column panel (PS columns: F x PS x 16 B), one thread per row walks the row's entries with the
+// panel's PS columns in registers, one accumulator per term, and the coefficients are applied once per row at the end.
+// HBM traffic of a launch: matrix + Q (the halo rows of a patch are L2 hits, see the header of this file).
+// Column norms: per-wave shuffle sums -> LDS -> one partial per block and column, summed in block order by k_sum_partials_d:
+// deterministic, no atomics.
+template <typename VT, int MT, int PS, bool NT>
+__global__ __launch_bounds__(256) void k_tile_resid(const TileDesc* __restrict__ desc, const uint32_t* __restrict__ fp,
+                                                    const uint16_t* __restrict__ eidx, const VT* __restrict__ eval,
+                                                    const cplx* __restrict__ QT, int64_t ldq, int k, const cplx* __restrict__ F,
+                                                    int mt, int fcap, int lbits, cplx* __restrict__ ZT, int64_t ldz,
+                                                    double* __restrict__ partial, int swz) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* Qt = (cplx*)smem;                                 // [fcap][PS]
+    cplx* Fs = Qt + (size_t)fcap * PS;                      // [k][mt]  (F[t + s * mt])
+    double* wsum = (double*)(Fs + (size_t)mt * k);          // [2][4 waves][kpad]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int kpad = (k + PS - 1) / PS * PS;
+    const int blk = tile_block(swz);
+    const TileDesc d = desc[blk];
+    for (int i = tid; i < mt * k; i += 256) Fs[i] = F[i];
+    const int Fn = d.fp_cnt;
+    const uint32_t* __restrict__ fpb = fp + d.fp_off;
+    const int width = d.wrb & 0xffff, rb = d.wrb >> 16;
+    const uint32_t lmask = (1u << lbits) - 1u;
+    const uint16_t* __restrict__ ib = eidx + (int64_t)d.ent_off64 * 64;
+    const VT* __restrict__ vb = eval + (int64_t)d.ent_off64 * 64;
+    const int s1 = tid % PS;                                // phase 1: this thread's column within the panel
+    for (int p0 = 0; p0 < k; p0 += PS) {
+        const int pw = min(PS, k - p0);
+        if (p0 > 0) __syncthreads();                        // the previous panel's readers are done with Qt
+        double qn = 0.0;
+        for (int i = tid; i < Fn * PS; i += 256) {
+            const int f = i / PS;
+            const uint32_t raw = fpb[f];
+            cplx q = cmake(0.0, 0.0);
+            if (s1 < pw) q = QT[(int64_t)(raw & NEP_COL_MASK) * ldq + p0 + s1];
+            Qt[i] = q;
+            if (raw & TILE_OWN) qn = fma(q.x, q.x, fma(q.y, q.y, qn));
+        }
+        __syncthreads();
+        double rn[PS];
+#pragma unroll
+        for (int s = 0; s < PS; ++s) rn[s] = 0.0;
+        for (int l = tid; l < rb; l += 256) {
+            cplx acc[MT][PS];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int s = 0; s < PS; ++s) acc[t][s] = cmake(0.0, 0.0);
+#pragma unroll 2
+            for (int j = 0; j < width; ++j) {
+                const int64_t e = (int64_t)j * rb + l;
+                const uint32_t id = NT ? __builtin_nontemporal_load(ib + e) : ib[e];
+                const VT a = tload<NT>(vb + e);
+                const int t = id >> lbits;
+                const cplx* qp = Qt + (size_t)(id & lmask) * PS;
+#pragma unroll
+                for (int tt = 0; tt < MT; ++tt) {
+                    VT am;
+                    if constexpr (sizeof(VT) == 8) am = (t == tt) ? a : 0.0; else am = (t == tt) ? a : cmake(0.0, 0.0);
+#pragma unroll
+                    for (int s = 0; s < PS; ++s) cfma(acc[tt][s], am, qp[s]);
+                }
+            }
+            if (l < d.nrows) {
+                const int i = l / d.zp, jz = l - i * d.zp;
+                const int64_t row = (int64_t)d.r0 + (int64_t)i * d.stride + jz;
+#pragma unroll
+                for (int s = 0; s < PS; ++s) {
+                    if (s < pw) {
+                        cplx r = cmake(0.0, 0.0);
+#pragma unroll
+                        for (int tt = 0; tt < MT; ++tt)
+                            if (tt < mt) cfma(r, Fs[(size_t)(p0 + s) * mt + tt], acc[tt][s]);
+                        if (ZT) ZT[row * ldz + p0 + s] = r;
+                        rn[s] = fma(r.x, r.x, fma(r.y, r.y, rn[s]));
+                    }
+                }
+            }
+        }
+        if (partial) {
+            // |r|^2: all 64 lanes hold their rows' sums for the panel's PS columns; |q|^2: lanes with the same tid % PS
+#pragma unroll
+            for (int s = 0; s < PS; ++s) {
+                const double v = wave_reduce_sum(rn[s]);
+                if (lane == 0) wsum[(size_t)(0 * 4 + wv) * kpad + p0 + s] = v;
+            }
+            for (int off = 32; off >= PS; off >>= 1) qn += shfl_xor_d(qn, off);
+            if (lane < PS) wsum[(size_t)(1 * 4 + wv) * kpad + p0 + lane] = qn;
+        }
+    }
+    if (partial) {
+        __syncthreads();
+        for (int t = tid; t < 2 * k; t += 256) {
+            const int which = t / k, s = t - which * k;
+            const double* w = wsum + (size_t)which * 4 * kpad + s;
+            partial[((int64_t)blk * 2 + which) * k + s] = (w[0] + w[kpad]) + (w[2 * kpad] + w[3 * kpad]);
+        }
+    }
+}
+
+// ---- host: tiles from the stacked CSR -----------------------------------------------------------------------------------------
+namespace {
+
+struct TileBuilder {
+    int64_t n; int mt; int valbytes; int lbits; int fcap_max;
+    const int32_t* rowptr; const uint32_t* idx; const void* vals;
+    std::vector<TileDesc> desc;
+    std::vector<uint32_t> fp;
+    std::vector<uint16_t> eidx;
+    std::vector<double> evr; std::vector<cplx> evc;
+    std::vector<int32_t> mark, loc;
+    std::vector<int64_t> rows;      // scratch: global rows of the block in local order
+    std::vector<uint32_t> cols;
+    int fcap_seen = 0;
+    bool failed = false;
+
+    // rows of the rectangle [x0,x1) x [z0,z1) of the grid with line length s (s = 0: the 1-D range [z0, z1))
+    int footprint(int64_t r0, int stride, int nx, int nz) {
+        const int32_t stamp = split_salt;
+        cols.clear();
+        for (int i = 0; i < nx; ++i)
+            for (int j = 0; j < nz; ++j) {
+                const int64_t r = r0 + (int64_t)i * stride + j;
+                for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+                    const uint32_t c = idx[e] & NEP_COL_MASK;
+                    if (mark[c] != stamp) { mark[c] = stamp; cols.push_back(c); }
+                }
+                if (mark[r] != stamp) { mark[r] = stamp; cols.push_back((uint32_t)r); }     // owned rows are always in the footprint
+            }
+        return (int)cols.size();
+    }
+    int32_t split_salt = 0;
+
+    void block(int64_t r0, int stride, int nx, int nz) {
+        if (failed) return;
+        if (++split_salt == 0x7fffffff) { std::fill(mark.begin(), mark.end(), 0); split_salt = 1; }   // a fresh stamp per attempt
+        const int F = footprint(r0, stride, nx, nz);
+        if (F > fcap_max || nx * nz > 4096) {
+            if (nx > 1) { const int h = nx / 2; block(r0, stride, h, nz); block(r0 + (int64_t)h * stride, stride, nx - h, nz); }
+            else if (nz > 1) { const int h = nz / 2; block(r0, stride, 1, h); block(r0 + h, stride, 1, nz - h); }
+            else failed = true;
+            return;
+        }
+        std::sort(cols.begin(), cols.end());
+        for (int f = 0; f < F; ++f) loc[cols[f]] = f;
+        TileDesc d;
+        d.r0 = (int32_t)r0; d.stride = stride; d.zp = nz; d.nrows = nx * nz;
+        d.fp_off = (int32_t)fp.size(); d.fp_cnt = F;
+        const int nrows = nx * nz;
+        const int rb = (nrows + 15) / 16 * 16;
+        int width = 0;
+        for (int i = 0; i < nx; ++i)
+            for (int j = 0; j < nz; ++j) {
+                const int64_t r = r0 + (int64_t)i * stride + j;
+                width = std::max(width, rowptr[r + 1] - rowptr[r]);
+            }
+        // footprint slots; the owned rows carry TILE_OWN
+        const size_t fp0 = fp.size();
+        for (int f = 0; f < F; ++f) fp.push_back(cols[f]);
+        for (int i = 0; i < nx; ++i)
+            for (int j = 0; j < nz; ++j) fp[fp0 + loc[r0 + (int64_t)i * stride + j]] |= TILE_OWN;
+        // entries: (j, l) at ent0 + j * rb + l, zero padded
+        const size_t ent0 = (eidx.size() + 63) / 64 * 64;
+        const size_t cnt = (size_t)width * rb;
+        eidx.resize(ent0 + cnt, 0);
+        if (valbytes == 8) evr.resize(ent0 + cnt, 0.0); else evc.resize(ent0 + cnt, cmake_h(0.0, 0.0));
+        for (int i = 0; i < nx; ++i)
+            for (int j = 0; j < nz; ++j) {
+                const int l = i * nz + j;
+                const int64_t r = r0 + (int64_t)i * stride + j;
+                for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+                    const size_t q = ent0 + (size_t)(e - rowptr[r]) * rb + l;
+                    const uint32_t c = idx[e] & NEP_COL_MASK, t = idx[e] >> NEP_TERM_SHIFT;
+                    eidx[q] = (uint16_t)((t << lbits) | (uint32_t)loc[c]);
+                    if (valbytes == 8) evr[q] = ((const double*)vals)[e]; else evc[q] = ((const cplx*)vals)[e];
+                }
+            }
+        d.ent_off64 = (int32_t)(ent0 / 64);
+        d.wrb = width | (rb << 16);
+        desc.push_back(d);
+        fcap_seen = std::max(fcap_seen, F);
+    }
+    static cplx cmake_h(double a, double b) { cplx r; r.x = a; r.y = b; return r; }
+};
+
+int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+}  // namespace
+
+extern "C" {
+
+void nep_tiles_destroy(NepTiles* t) {
+    if (!t) return;
+    if (t->d_desc) (void)hipFree(t->d_desc);
+    if (t->d_fp) (void)hipFree(t->d_fp);
+    if (t->d_eidx) (void)hipFree(t->d_eidx);
+    if (t->d_eval) (void)hipFree(t->d_eval);
+    delete t;
+}
+
+// host part of nep_tiles_build: false when the matrix does not qualify
+static bool tiles_build_host(TileBuilder& B, int64_t n, int mt, int valbytes, const int32_t* rowptr, const uint32_t* idx,
+                             const void* vals, int* stride_out, int* xp_out, int* zp_out) {
+    if (env_int("NEP_K1_TILE", 1) == 0 || mt > 8 || n < 64) return false;
+    int tb = 0; while ((1 << tb) < mt) ++tb;
+    B.n = n; B.mt = mt; B.valbytes = valbytes; B.rowptr = rowptr; B.idx = idx; B.vals = vals;
+    B.lbits = 16 - tb;
+    const int lds_kb = env_int("NEP_K1_TILE_LDS_KB", 64);
+    B.fcap_max = std::min(1 << B.lbits, lds_kb * 1024 / (16 * mt));
+    B.mark.assign(n, 0); B.loc.assign(n, 0);
+    // dominant off-diagonal stride: the most frequent column offset > 1 (the line length of a 2-D grid numbering)
+    int stride = 0;
+    {
+        const int64_t dmax = std::min<int64_t>(n, (int64_t)1 << 22);
+        std::vector<int64_t> cnt(dmax, 0);
+        for (int64_t r = 0; r < n; ++r)
+            for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+                const int64_t dd = (int64_t)(idx[e] & NEP_COL_MASK) - r;
+                if (dd > 1 && dd < dmax) ++cnt[dd];
+            }
+        int64_t best = 0;
+        for (int64_t dd = 2; dd < dmax; ++dd) if (cnt[dd] > best) { best = cnt[dd]; stride = (int)dd; }
+        if (best < n / 4) stride = 0;
+        if (const char* e = getenv("NEP_K1_TILE_STRIDE")) stride = atoi(e);
+    }
+    const bool small = n < 32768;
+    int zp = env_int("NEP_K1_TILE_ZP", small ? 16 : 64), xp = env_int("NEP_K1_TILE_XP", small ? 4 : 8);
+    if (zp < 1) zp = 1;
+    if (xp < 1) xp = 1;
+    if (stride > 0) {
+        zp = std::min(zp, stride);
+        const int64_t X = n / stride;
+        for (int64_t x0 = 0; x0 < X; x0 += xp)
+            for (int z0 = 0; z0 < stride; z0 += zp)
+                B.block(x0 * stride + z0, stride, (int)std::min<int64_t>(xp, X - x0), std::min(zp, stride - z0));
+        const int R = xp * zp;
+        for (int64_t a = X * stride; a < n; a += R) B.block(a, 0, 1, (int)std::min<int64_t>(R, n - a));
+    } else {
+        const int R = xp * zp;
+        for (int64_t a = 0; a < n; a += R) B.block(a, 0, 1, (int)std::min<int64_t>(R, n - a));
+    }
+    *stride_out = stride; *xp_out = xp; *zp_out = zp;
+    return !(B.failed || B.desc.empty());
+}
+
+// host-only dry run (tests without a GPU, sanitizer build): builds the tiles, then evaluates z = sum_t A_t (V c_t) for a
+// deterministic V (n x k) and C (k x mt) twice -- through the tiles exactly as k_tile_mlincomb walks them (footprint ->
+// W -> entries -> row map) and directly from the stacked CSR -- and returns the largest difference relative to max |z|.
+// info as nep_tiles_info; info[0] = 0 when the matrix gets no tiles (then *maxerr = 0).
+int nep_tiles_dryrun(int64_t n, int mt, int valbytes, const int32_t* rowptr, const uint32_t* idx, const void* vals, int k,
+                     int64_t info[8], double* maxerr) {
+    for (int i = 0; i < 8; ++i) info[i] = 0;
+    *maxerr = 0.0;
+    TileBuilder B;
+    int stride = 0, xp = 0, zp = 0;
+    if (!tiles_build_host(B, n, mt, valbytes, rowptr, idx, vals, &stride, &xp, &zp)) return NEP_OK;
+    info[0] = (int64_t)B.desc.size(); info[1] = B.fcap_seen; info[2] = stride; info[3] = xp; info[4] = zp;
+    info[5] = (int64_t)B.eidx.size(); info[6] = (int64_t)B.fp.size();
+    info[7] = info[5] * (2 + valbytes) + info[6] * 4 + info[0] * (int64_t)sizeof(TileDesc);
+    auto hv = [&](int64_t r, int j) { cplx v; v.x = sin(0.37 * (double)(r % 1009) + 1.3 * j) + 0.1; v.y = cos(0.11 * (double)(r % 2003) - 0.7 * j); return v; };
+    auto hc = [&](int j, int t) { cplx v; v.x = 1.0 / (1.0 + j + 2 * t); v.y = 0.25 * (t - j % 3); return v; };
+    auto mul = [](cplx a, cplx b) { cplx r; r.x = a.x * b.x - a.y * b.y; r.y = a.x * b.y + a.y * b.x; return r; };
+    std::vector<cplx> Wd((size_t)n * mt), zd(n), zt(n), Wl;
+    std::vector<int> hits(n, 0);
+    for (int64_t r = 0; r < n; ++r)
+        for (int t = 0; t < mt; ++t) {
+            cplx a; a.x = 0; a.y = 0;
+            for (int j = 0; j < k; ++j) { const cplx p = mul(hv(r, j), hc(j, t)); a.x += p.x; a.y += p.y; }
+            Wd[(size_t)r * mt + t] = a;
+        }
+    double zmax = 0.0;
+    for (int64_t r = 0; r < n; ++r) {
+        cplx a; a.x = 0; a.y = 0;
+        for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
+            cplx v; if (valbytes == 8) { v.x = ((const double*)vals)[e]; v.y = 0; } else v = ((const cplx*)vals)[e];
+            const cplx p = mul(v, Wd[(size_t)(idx[e] & NEP_COL_MASK) * mt + (idx[e] >> NEP_TERM_SHIFT)]);
+            a.x += p.x; a.y += p.y;
+        }
+        zd[r] = a; zmax = std::max(zmax, std::max(fabs(a.x), fabs(a.y)));
+    }
+    const uint32_t lmask = (1u << B.lbits) - 1u;
+    for (const TileDesc& d : B.desc) {
+        Wl.assign((size_t)mt * d.fp_cnt, cplx());
+        int owned = 0;
+        for (int f = 0; f < d.fp_cnt; ++f) {
+            const uint32_t raw = B.fp[d.fp_off + f];
+            if (raw & TILE_OWN) ++owned;
+            for (int t = 0; t < mt; ++t) Wl[(size_t)t * d.fp_cnt + f] = Wd[(size_t)(raw & NEP_COL_MASK) * mt + t];
+        }
+        if (owned != d.nrows) { *maxerr = 1e300; return NEP_OK; }
+        const int width = d.wrb & 0xffff, rb = d.wrb >> 16;
+        for (int l = 0; l < d.nrows; ++l) {
+            cplx a; a.x = 0; a.y = 0;
+            for (int j = 0; j < width; ++j) {
+                const size_t e = (size_t)d.ent_off64 * 64 + (size_t)j * rb + l;
+                cplx v; if (valbytes == 8) { v.x = B.evr[e]; v.y = 0; } else v = B.evc[e];
+                const uint32_t id = B.eidx[e];
+                const cplx p = mul(v, Wl[(size_t)(id >> B.lbits) * d.fp_cnt + (id & lmask)]);
+                a.x += p.x; a.y += p.y;
+            }
+            const int i = l / d.zp, jz = l - i * d.zp;
+            const int64_t r = (int64_t)d.r0 + (int64_t)i * d.stride + jz;
+            zt[r] = a; ++hits[r];
+        }
+    }
+    double err = 0.0;
+    for (int64_t r = 0; r < n; ++r) {
+        if (hits[r] != 1) { *maxerr = 1e300; return NEP_OK; }        // every row belongs to exactly one block
+        err = std::max(err, std::max(fabs(zt[r].x - zd[r].x), fabs(zt[r].y - zd[r].y)));
+    }
+    *maxerr = zmax > 0 ? err / zmax : err;
+    return NEP_OK;
+}
+
+// host arrays of the stacked CSR (idx = term << 25 | column).  *out stays NULL when the matrix does not qualify (more than 8
+// terms, a row whose footprint exceeds the LDS budget, NEP_K1_TILE=0): not an error, the caller keeps its other kernels.
+int nep_tiles_build(int64_t n, int mt, int valbytes, const int32_t* rowptr, const uint32_t* idx, const void* vals, NepTiles** out) {
+    *out = nullptr;
+    TileBuilder B;
+    int stride = 0, xp = 0, zp = 0;
+    if (!tiles_build_host(B, n, mt, valbytes, rowptr, idx, vals, &stride, &xp, &zp)) return NEP_OK;
+    NepTiles* t = new NepTiles();
+    t->n = n; t->mt = mt; t->valbytes = valbytes; t->nblk = (int)B.desc.size(); t->fcap = (B.fcap_seen + 15) / 16 * 16;
+    t->lbits = B.lbits; t->stride = stride; t->xp = xp; t->zp = zp;
+    t->nent = (int64_t)B.eidx.size(); t->nfp = (int64_t)B.fp.size();
+#define TCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { nep_set_error("%s:%d: %s: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); nep_tiles_destroy(t); return NEP_ERR_HIP; } } while (0)
+    TCHK(hipMalloc((void**)&t->d_desc, B.desc.size() * sizeof(TileDesc)));
+    TCHK(hipMalloc((void**)&t->d_fp, B.fp.size() * 4 + 256));
+    TCHK(hipMalloc((void**)&t->d_eidx, B.eidx.size() * 2 + 256));
+    TCHK(hipMalloc(&t->d_eval, B.eidx.size() * (size_t)valbytes + 256));
+    TCHK(hipMemcpy(t->d_desc, B.desc.data(), B.desc.size() * sizeof(TileDesc), hipMemcpyHostToDevice));
+    TCHK(hipMemcpy(t->d_fp, B.fp.data(), B.fp.size() * 4, hipMemcpyHostToDevice));
+    TCHK(hipMemcpy(t->d_eidx, B.eidx.data(), B.eidx.size() * 2, hipMemcpyHostToDevice));
+    if (valbytes == 8) TCHK(hipMemcpy(t->d_eval, B.evr.data(), B.eidx.size() * 8, hipMemcpyHostToDevice));
+    else TCHK(hipMemcpy(t->d_eval, B.evc.data(), B.eidx.size() * 16, hipMemcpyHostToDevice));
+#undef TCHK
+    *out = t;
+    return NEP_OK;
+}
+
+// info: blocks, largest footprint, stride, xp, zp, entries (padded), footprint slots, bytes one launch streams (entries +
+// footprints + descriptors)
+void nep_tiles_info(const NepTiles* t, int64_t info[8]) {
+    info[0] = t->nblk; info[1] = t->fcap; info[2] = t->stride; info[3] = t->xp; info[4] = t->zp; info[5] = t->nent; info[6] = t->nfp;
+    info[7] = t->nent * (2 + t->valbytes) + t->nfp * 4 + (int64_t)t->nblk * (int64_t)sizeof(TileDesc);
+}
+
+// threads per workgroup / split of the k columns over thread groups, by matrix size and k (see the kernel's header)
+static void tiles_launch_shape(const NepTiles* t, int k, int* nthr, int* split) {
+    *nthr = 256; *split = 0;
+    if (t->n < 32768) {
+        static const int force = env_int("NEP_K1_TILE_THREADS", 0);
+        *nthr = force ? force : (k >= 48 ? 1024 : (k >= 16 ? 512 : 256));
+        *split = (k >= 4 && ((t->fcap + 15) & ~15) * 2 <= *nthr) ? 1 : 0;
+    }
+}
+size_t nep_tiles_shmem(const NepTiles* t, int k) {
+    int nthr, split; tiles_launch_shape(t, k, &nthr, &split);
+    return ((size_t)t->mt * t->fcap + (size_t)t->mt * k + (split ? (size_t)nthr * std::min(t->mt, 4) : 0)) * sizeof(cplx);
+}
+
+int nep_tiles_mlincomb(const NepTiles* t, int k, const cplx* dC, int64_t ldc, const cplx* dV, int64_t ldv, cplx* dz,
+                       cplx* d_shift, hipStream_t st) {
+    const size_t shm = nep_tiles_shmem(t, k);
+    if (shm > 160 * 1024) { nep_set_error("tiled K1: k = %d needs %zu bytes of LDS", k, shm); return NEP_ERR_ARG; }
+    static const int swz = env_int("NEP_XCD_SWIZZLE", 1);
+    static const int pf_on = env_int("NEP_K1_TILE_PF", 1);
+    int nthr, split; tiles_launch_shape(t, k, &nthr, &split);
+    const bool nt = t->n >= 32768;          // entries streamed once (HBM) vs re-read from L2 by every call (small matrices)
+    const bool pf = nt && pf_on;
+    const int mtc = std::min(t->mt, 4);
+#define TL(VT, M, NTF, PFF)                                                                                                    \
+    do {                                                                                                                       \
+        if (shm > 64 * 1024) {                                                                                                 \
+            static bool raised = false;                                                                                        \
+            if (!raised) {                                                                                                     \
+                HIPCHK(hipFuncSetAttribute((const void*)k_tile_mlincomb<VT, M, NTF, PFF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                raised = true;                                                                                                 \
+            }                                                                                                                  \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((k_tile_mlincomb<VT, M, NTF, PFF>), dim3((unsigned)t->nblk), dim3(nthr), shm, st, (const TileDesc*)t->d_desc, \
+                           (const uint32_t*)t->d_fp, (const uint16_t*)t->d_eidx, (const VT*)t->d_eval, dV, ldv, k, dC, ldc, t->mt,  \
+                           t->fcap, t->lbits, dz, d_shift, swz, split);                                                        \
+    } while (0)
+#define TL_M(VT, NTF, PFF) do { switch (mtc) { case 1: TL(VT, 1, NTF, PFF); break; case 2: TL(VT, 2, NTF, PFF); break; case 3: TL(VT, 3, NTF, PFF); break; default: TL(VT, 4, NTF, PFF); break; } } while (0)
+    if (t->valbytes == 8) { if (nt) { if (pf) TL_M(double, true, true); else TL_M(double, true, false); } else TL_M(double, false, false); }
+    else { if (nt) { if (pf) TL_M(cplx, true, true); else TL_M(cplx, true, false); } else TL_M(cplx, false, false); }
+#undef TL_M
+#undef TL
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+size_t nep_tiles_resid_shmem(const NepTiles* t, int k, int ps) {
+    const int kpad = (k + ps - 1) / ps * ps;
+    return ((size_t)t->fcap * ps + (size_t)t->mt * k) * sizeof(cplx) + (size_t)2 * 4 * kpad * sizeof(double);
+}
+// panel width: 8 columns when the footprint tile then still leaves room for two workgroups per CU, else 4
+int nep_tiles_resid_ps(const NepTiles* t, int k) {
+    static const int force = env_int("NEP_K2_TILE_PS", 0);
+    if (force == 4 || force == 8) return force;
+    return nep_tiles_resid_shmem(t, k, 8) <= 72 * 1024 ? 8 : 4;
+}
+int nep_tiles_nblk(const NepTiles* t) { return t->nblk; }
+bool nep_tiles_resid_ok(const NepTiles* t, int k) {
+    return t->mt <= 4 && nep_tiles_resid_shmem(t, k, nep_tiles_resid_ps(t, k)) <= 160 * 1024;
+}
+
+// partial: [nblk][2][k] doubles (|r|^2 then |q|^2 per column), or NULL; ZT (n x k row-major, ld ldz) or NULL
+int nep_tiles_resid(const NepTiles* t, int k, const cplx* dF, const cplx* QT, int64_t ldq, cplx* ZT, int64_t ldz, double* partial,
+                    hipStream_t st) {
+    const int ps = nep_tiles_resid_ps(t, k);
+    const size_t shm = nep_tiles_resid_shmem(t, k, ps);
+    if (t->mt > 4 || shm > 160 * 1024) { nep_set_error("tiled K2: mt = %d, k = %d not supported", t->mt, k); return NEP_ERR_ARG; }
+    static const int swz = env_int("NEP_XCD_SWIZZLE", 1);
+    const bool nt = t->n >= 32768;
+#define RL(VT, M, P, NTF)                                                                                                      \
+    do {                                                                                                                       \
+        if (shm > 64 * 1024) {                                                                                                 \
+            static bool raised = false;                                                                                        \
+            if (!raised) {                                                                                                     \
+                HIPCHK(hipFuncSetAttribute((const void*)k_tile_resid<VT, M, P, NTF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                raised = true;                                                                                                 \
+            }                                                                                                                  \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((k_tile_resid<VT, M, P, NTF>), dim3((unsigned)t->nblk), dim3(256), shm, st, (const TileDesc*)t->d_desc,  \
+                           (const uint32_t*)t->d_fp, (const uint16_t*)t->d_eidx, (const VT*)t->d_eval, QT, ldq, k, dF, t->mt,       \
+                           t->fcap, t->lbits, ZT, ldz, partial, swz);                                                          \
+    } while (0)
+#define RL_M(VT, P, NTF) do { switch (t->mt) { case 1: RL(VT, 1, P, NTF); break; case 2: RL(VT, 2, P, NTF); break; case 3: RL(VT, 3, P, NTF); break; default: RL(VT, 4, P, NTF); break; } } while (0)
+#define RL_P(VT, NTF) do { if (ps == 8) RL_M(VT, 8, NTF); else RL_M(VT, 4, NTF); } while (0)
+    if (t->valbytes == 8) { if (nt) RL_P(double, true); else RL_P(double, false); }
+    else { if (nt) RL_P(cplx, true); else RL_P(cplx, false); }
+#undef RL_P
+#undef RL_M
+#undef RL
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+}  // extern "C"

@@ -127,6 +127,10 @@ class _DeviceRefactor:
     plans = {}           # key -> dict(state="building"|"ready"|"off", handle, thread, strategy, fails)
     lock = threading.Lock()
     GROWTH = float(os.environ.get("NEP_LU_DEV_GROWTH", "1e6"))
+    # factors whose solves are NOT followed by iterative refinement (contour_beyn's node solves; the reference pivots afresh at
+    # every node): accepted only with element growth max|U| / max|A| and max|L| up to 1e3 -- the growth a threshold-pivoted
+    # factorisation with diag_pivot_thresh = 1e-3 tolerates per step -- otherwise that node goes to the host
+    GROWTH_UNREFINED = float(os.environ.get("NEP_LU_DEV_GROWTH_UNREFINED", "1e3"))
     MAX = 4
 
     @classmethod
@@ -189,7 +193,7 @@ class _DeviceRefactor:
         t.start()
 
     @classmethod
-    def factor_batch(cls, plan, n, vals, expected_solves=1):
+    def factor_batch(cls, plan, n, vals, expected_solves=1, growth=None):
         """vals: (B, nnz) values of B matrices of the plan's pattern.  Returns a list of DeviceLU (None where the stored pivot
         sequence was refused for that matrix -- the caller factorises those on the host)."""
         B = int(vals.shape[0])
@@ -197,7 +201,8 @@ class _DeviceRefactor:
         health = np.zeros((B, 3))
         outs = (c_vp * B)()
         check(lib.nep_lu_set_expected_solves(int(expected_solves)))
-        check(lib.nep_lu_factor_dev_batch(plan["handle"], B, hptr(vals), int(expected_solves), cls.GROWTH, hptr(health), None, outs,
+        check(lib.nep_lu_factor_dev_batch(plan["handle"], B, hptr(vals), int(expected_solves),
+                                          cls.GROWTH if growth is None else float(growth), hptr(health), None, outs,
                                           stream_ptr()))
         res = []
         for b in range(B):
@@ -207,11 +212,12 @@ class _DeviceRefactor:
                 continue
             plan["uses"] += 1
             res.append(DeviceLU._from_handle(c_vp(outs[b]), n, float(np.linalg.norm(vals[b])),
-                                             dict(plan["strategy"], numeric="device (stored pivot sequence, batched)"), float(health[b, 1])))
+                                             dict(plan["strategy"], numeric="device (stored pivot sequence, batched)"),
+                                             float(max(health[b, 1], health[b, 2]))))
         return res
 
     @classmethod
-    def factor_batch_terms(cls, plan, n, D_dev, Cf, normA, expected_solves=1):
+    def factor_batch_terms(cls, plan, n, D_dev, Cf, normA, expected_solves=1, growth=None):
         """the same for B matrices A_b = sum_t Cf[b, t] A_t whose term values sit on the device (D_dev: nnz x m_t, the union
         pattern of the plan): nothing of size B x nnz is formed on the host or uploaded.  normA: the B Frobenius norms."""
         Cf = np.ascontiguousarray(Cf, dtype=np.complex128)
@@ -220,8 +226,8 @@ class _DeviceRefactor:
         health = np.zeros((B, 3))
         outs = (c_vp * B)()
         check(lib.nep_lu_set_expected_solves(int(expected_solves)))
-        check(lib.nep_lu_factor_dev_batch_terms(plan["handle"], B, c_vp(D_dev.data_ptr()), mt, hptr(Cf), int(expected_solves), cls.GROWTH,
-                                                hptr(health), outs, stream_ptr()))
+        check(lib.nep_lu_factor_dev_batch_terms(plan["handle"], B, c_vp(D_dev.data_ptr()), mt, hptr(Cf), int(expected_solves),
+                                                cls.GROWTH if growth is None else float(growth), hptr(health), outs, stream_ptr()))
         res = []
         for b in range(B):
             if not outs[b]:
@@ -230,7 +236,8 @@ class _DeviceRefactor:
                 continue
             plan["uses"] += 1
             res.append(DeviceLU._from_handle(c_vp(outs[b]), n, float(normA[b]),
-                                             dict(plan["strategy"], numeric="device (stored pivot sequence, batched)"), float(health[b, 1])))
+                                             dict(plan["strategy"], numeric="device (stored pivot sequence, batched)"),
+                                             float(max(health[b, 1], health[b, 2]))))
         return res
 
     @classmethod
@@ -351,7 +358,7 @@ class DeviceLU:
             return False
         plan["uses"] += 1
         self.device_factorized = True
-        self.growth = float(health[1])
+        self.growth = float(max(health[1], health[2]))       # max |L| and the element growth max|U| / max|A|
         self.n = int(Ac.shape[0])
         self.normA = float(np.linalg.norm(Ax))
         self.strategy = dict(plan["strategy"], numeric="device (stored pivot sequence)")

@@ -79,6 +79,38 @@ def _to_csr(A):
     return M
 
 
+def _term_arrays(Av):
+    """per-term CSR arrays in the argument layout of nep_spmf_create (the caller keeps `keep` alive)"""
+    mt = len(Av)
+    csr = [_to_csr(A) for A in Av]
+    keep = []
+    rp = (c_vp * mt)(); ci = (c_vp * mt)(); vv = (c_vp * mt)()
+    isc = (c_i32 * mt)()
+    for i, M in enumerate(csr):
+        cplx = np.iscomplexobj(M.data)
+        ip = np.ascontiguousarray(M.indptr, dtype=np.int32)
+        ix = np.ascontiguousarray(M.indices, dtype=np.int32)
+        dv = np.ascontiguousarray(M.data, dtype=np.complex128 if cplx else np.float64)
+        keep += [ip, ix, dv]
+        rp[i] = ip.ctypes.data; ci[i] = ix.ctypes.data; vv[i] = dv.ctypes.data
+        isc[i] = 1 if cplx else 0
+    return rp, ci, vv, isc, keep
+
+
+_TILE_KEYS = ("blocks", "max_footprint", "stride", "xp", "zp", "entries", "footprint_slots", "stream_bytes")
+
+
+def tiles_analyze(Av, k=3):
+    """host-only dry run of the footprint tiles of the one-launch K1 kernel (nep_spmf_tiles_analyze): tile statistics and
+    the relative difference between z = sum_t A_t (V c_t) evaluated through the tiles and directly.  Needs no GPU."""
+    rp, ci, vv, isc, keep = _term_arrays(Av)
+    info = (c_i64 * 8)(); err = C.c_double(0.0)
+    check(lib.nep_spmf_tiles_analyze(Av[0].shape[0], len(Av), rp, ci, vv, isc, int(k), info, C.byref(err)))
+    d = dict(zip(_TILE_KEYS, [int(x) for x in info]))
+    d["max_rel_err"] = float(err.value)
+    return d
+
+
 class SPMFDevice:
     """Owns the device-side stacked CSR (nep_spmf handle)."""
 
@@ -86,18 +118,7 @@ class SPMFDevice:
         _lib.require_gpu()
         self.n = Av[0].shape[0]
         self.mt = len(Av)
-        csr = [_to_csr(A) for A in Av]
-        keep = []
-        rp = (c_vp * self.mt)(); ci = (c_vp * self.mt)(); vv = (c_vp * self.mt)()
-        isc = (c_i32 * self.mt)()
-        for i, M in enumerate(csr):
-            cplx = np.iscomplexobj(M.data)
-            ip = np.ascontiguousarray(M.indptr, dtype=np.int32)
-            ix = np.ascontiguousarray(M.indices, dtype=np.int32)
-            dv = np.ascontiguousarray(M.data, dtype=np.complex128 if cplx else np.float64)
-            keep += [ip, ix, dv]
-            rp[i] = ip.ctypes.data; ci[i] = ix.ctypes.data; vv[i] = dv.ctypes.data
-            isc[i] = 1 if cplx else 0
+        rp, ci, vv, isc, keep = _term_arrays(Av)
         h = c_vp()
         check(lib.nep_spmf_create(self.n, self.mt, rp, ci, vv, isc, C.byref(h)))
         self.h = h
@@ -105,6 +126,12 @@ class SPMFDevice:
         check(lib.nep_spmf_info(self.h, info))
         self.nnz = int(info[2]); self.valbytes = int(info[3]); self.lanes = int(info[4])
         self.matrix_bytes = int(info[5])
+
+    def tile_info(self):
+        """footprint tiles of the one-launch compute_Mlincomb kernel (all zero: none)"""
+        info = (c_i64 * 8)()
+        check(lib.nep_spmf_tile_info(self.h, info))
+        return dict(zip(_TILE_KEYS, [int(x) for x in info]))
 
     def __del__(self):
         try:

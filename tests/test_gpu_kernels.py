@@ -729,6 +729,9 @@ def test_device_numeric_factorization(na, monkeypatch):
         Lh = sp.csc_matrix((Fh["Lx"], Fh["Li"], Fh["Lp"]), shape=(n, n)); Uh = sp.csc_matrix((Fh["Ux"], Fh["Ui"], Fh["Up"]), shape=(n, n))
         assert abs(Ld - Lh).max() <= 1e-10 * abs(Lh).max() and abs(Ud - Uh).max() <= 1e-10 * abs(Uh).max()
         assert health[0] == 0 and 0 < health[1] < 1e4
+        # health[2] = the element growth max|U| / max|A| (|Re| + |Im| norm) of THIS factorisation, against the host factor's
+        a1 = lambda z: (abs(z.real) + abs(z.imag)).max()
+        assert health[2] == pytest.approx(a1(Fh["Ux"]) / a1(A.data), rel=1e-8)
         b = np.random.default_rng(1).standard_normal(n) + 0j
         bd = torch.from_numpy(b).to("cuda"); x = torch.empty_like(bd)
         check(lib.nep_lu_solve(out, 1, c_vp(bd.data_ptr()), n, c_vp(x.data_ptr()), n, 1.0, stream_ptr()))
@@ -738,6 +741,14 @@ def test_device_numeric_factorization(na, monkeypatch):
     out = c_vp()
     assert lib.nep_lu_factor_dev(h, hptr(np.ascontiguousarray(A0.data)), 10, 1e-3, None, None, C.byref(out), stream_ptr()) == -3
     assert not out.value
+    # ... also when only the growth in U exceeds it (limit between max |L| and max|U| / max|A|, whichever order they come in)
+    hh = np.zeros(3); out = c_vp()
+    check(lib.nep_lu_factor_dev(h, hptr(np.ascontiguousarray(A0.data)), 10, 1e8, hptr(hh), None, C.byref(out), stream_ptr()))
+    lib.nep_lu_destroy(out)
+    if abs(np.log(hh[1] / hh[2])) > 0.1:
+        mid = float(np.sqrt(hh[1] * hh[2])); out = c_vp()
+        assert lib.nep_lu_factor_dev(h, hptr(np.ascontiguousarray(A0.data)), 10, mid, None, None, C.byref(out), stream_ptr()) == -3
+        assert not out.value
     lib.nep_lu_refac_destroy(h)
     # (ii) through DeviceLU: first matrix on the host (plan built in the background), second on the device
     lu0 = na.DeviceLU(A0)
@@ -783,3 +794,117 @@ def test_compute_types(na):
         for S in (np.eye(2), np.eye(2) + 0j):
             for V in (np.ones((n, 2)), np.ones((n, 2)) + 0j):
                 assert nep.compute_MM(S, V).dtype == on.result_type(real, S, V)
+
+
+@pytest.mark.parametrize("case", ["gun", "wep", "qdep0", "random_complex"])
+def test_mlincomb_tiled_one_launch_kernel(na, case):
+    """csrc/spmv_tile.hip: compute_Mlincomb as ONE launch on footprint tiles (grid patches for the gun / waveguide stencils,
+    consecutive-row blocks otherwise) against the two-launch / folded kernels (nep_k1_set_mode 2) and host NumPy; every k
+    regime of the kernel: k = 1, small k (one thread group per footprint column), large k (column groups + LDS reduction);
+    V not modified"""
+    import torch
+    from nep_amd._lib import lib, check
+    from nep_amd import gallery, wep
+    rng = np.random.default_rng(11)
+    if case == "gun":
+        K, M, W1, W2 = gallery.gun_matrices(); Av = [K, -M, W1, W2]
+    elif case == "wep":
+        Av = wep.WaveguideData(303, 299, "JARLEBRING").big_matrices()          # n = 91 195: SELL path, non-temporal entry loads
+    elif case == "qdep0":
+        Av = na.nep_gallery("qdep0").get_Av()
+    else:
+        n0 = 3001
+        Av = [sp.random(n0, n0, density=0.003, random_state=1, format="csr") + sp.identity(n0, format="csr"),
+              sp.random(n0, n0, density=0.002, random_state=2, format="csr") * (1 + 2j),
+              sp.random(n0, n0, density=0.001, random_state=3, format="csr")]
+    dev = na.SPMFDevice(Av)
+    ti = dev.tile_info()
+    assert ti["blocks"] > 0 and ti["max_footprint"] > 0
+    if case in ("gun", "wep"):
+        assert ti["stride"] == (131 if case == "gun" else 299)               # the grid line length, found from the pattern
+    n, mt = dev.n, dev.mt
+    try:
+        for k in (1, 2, 7, 8, 33, 100):
+            V = rng.standard_normal((k, n)) + 1j * rng.standard_normal((k, n))
+            Cm = rng.standard_normal((k, mt)) + 1j * rng.standard_normal((k, mt))
+            Vd = torch.from_numpy(V).to("cuda"); V0 = Vd.clone()
+            ref = sum(Av[t] @ (V.T @ Cm[:, t]) for t in range(mt))
+            zs = {}
+            for mode in (1, 2):
+                check(lib.nep_k1_set_mode(mode))
+                zs[mode] = dev.mlincomb(Cm, Vd).cpu().numpy()
+                zd = torch.empty(n, dtype=torch.complex128, device="cuda")
+                dev.mlincomb_dev(na.to_dev(Cm), k, k, Vd, n, zd)
+                assert np.array_equal(zd.cpu().numpy(), zs[mode])                # host- and device-coefficient entry points agree
+            assert torch.equal(Vd, V0)
+            scale = np.linalg.norm(ref)
+            assert np.linalg.norm(zs[1] - ref) <= 1e-12 * scale and np.linalg.norm(zs[2] - ref) <= 1e-12 * scale
+    finally:
+        check(lib.nep_k1_set_mode(0))
+
+
+def test_iar_same_result_with_tiled_k1(na):
+    """iar's native step folds the block shift of the basis column into the K1 kernel: with the tiled kernel forced on for
+    every k (mode 1) and forced off (mode 2) the gun twin returns the same eigenpairs and error history"""
+    from nep_amd._lib import lib, check
+    nep = na.nep_gallery("gun_spmf_scaled", 1310); n = nep.n
+    out = {}
+    try:
+        for mode in (1, 2):
+            check(lib.nep_k1_set_mode(mode))
+            h = []
+            lam, Q, _ = na.iar(nep, sigma=0.0, gamma=1.0, maxit=40, neigs=np.inf, v=np.ones(n), tol=1e-10, errhist=h)
+            out[mode] = (lam, h)
+    finally:
+        check(lib.nep_k1_set_mode(0))
+    (l1, h1), (l2, h2) = out[1], out[2]
+    assert len(l1) == len(l2) >= 1 and len(h1) == len(h2)
+    assert max(np.min(abs(l2 - x)) / max(1.0, abs(x)) for x in l1) < 1e-11
+
+
+@pytest.mark.parametrize("case", ["wep", "gun", "random_complex"])
+def test_resid_batch_tiled_kernel(na, case):
+    """K2 on the footprint tiles (k_tile_resid: Q rows of a block's footprint staged in LDS per column panel, thread per row)
+    against the wave-per-row kernel (mode 2) and NumPy: column norms of the residual block and of Q (nep_resid_batch_dev), and
+    the residual block itself (nep_resid_block); k below, at and above the panel widths, ldq > k"""
+    import ctypes as C
+    import torch
+    from nep_amd._lib import lib, check, hptr, c_vp
+    from nep_amd import gallery, wep
+    rng = np.random.default_rng(12)
+    if case == "gun":
+        K, M, W1, W2 = gallery.gun_matrices(); Av = [K, -M, W1, W2]
+    elif case == "wep":
+        Av = wep.WaveguideData(303, 299, "JARLEBRING").big_matrices()
+    else:
+        n0 = 3001
+        Av = [sp.random(n0, n0, density=0.003, random_state=1, format="csr") + sp.identity(n0, format="csr"),
+              sp.random(n0, n0, density=0.002, random_state=2, format="csr") * (1 + 2j)]
+    dev = na.SPMFDevice(Av)
+    n, mt = dev.n, dev.mt
+    try:
+        for k, ldq in ((1, 1), (3, 5), (8, 8), (13, 16), (60, 60), (130, 130)):
+            Q = rng.standard_normal((n, ldq)) + 1j * rng.standard_normal((n, ldq))
+            F = np.asfortranarray(rng.standard_normal((mt, k)) + 1j * rng.standard_normal((mt, k)))
+            R = np.column_stack([sum(F[t, s] * (Av[t] @ Q[:, s]) for t in range(mt)) for s in range(k)])
+            Qd = torch.from_numpy(Q).to("cuda")
+            res = {}
+            for mode in (1, 2):
+                check(lib.nep_k1_set_mode(mode))
+                o = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+                check(lib.nep_resid_batch_dev(dev.h, k, hptr(F), c_vp(Qd.data_ptr()), ldq, c_vp(o.data_ptr()), None))
+                RT = torch.zeros((n, k), dtype=torch.complex128, device="cuda")
+                check(lib.nep_resid_block(dev.h, k, hptr(F), c_vp(Qd.data_ptr()), ldq, c_vp(RT.data_ptr()), k, None))
+                res[mode] = (o.cpu().numpy(), RT.cpu().numpy())
+            for mode in (1, 2):
+                o, RT = res[mode]
+                assert np.allclose(o[:k], np.sum(abs(R) ** 2, axis=0), rtol=1e-12)
+                assert np.allclose(o[k:], np.sum(abs(Q[:, :k]) ** 2, axis=0), rtol=1e-12)
+                assert np.linalg.norm(RT - R) <= 1e-13 * np.linalg.norm(R)
+            # deterministic: a second launch returns the same bits
+            check(lib.nep_k1_set_mode(1))
+            o2 = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+            check(lib.nep_resid_batch_dev(dev.h, k, hptr(F), c_vp(Qd.data_ptr()), ldq, c_vp(o2.data_ptr()), None))
+            assert np.array_equal(o2.cpu().numpy(), res[1][0])
+    finally:
+        check(lib.nep_k1_set_mode(0))

@@ -531,3 +531,43 @@ def test_gun_loader_from_directory(tmp_path, monkeypatch):
     gallery.write_sparse_matrix(str(tmp_path / "gun_M.txt"), sp.csc_matrix(M[:100, :100]))
     with pytest.raises(ValueError, match="shape"):
         gallery.gun_matrices()
+
+
+@pytest.mark.parametrize("case", ["gun", "wep", "qdep0", "random", "dense_row"])
+def test_k1_footprint_tiles_host_dryrun(case, monkeypatch):
+    """csrc/spmv_tile.hip, host side (nep_spmf_tiles_analyze, no GPU): every row belongs to exactly one block, owned rows are
+    flagged in their block's footprint, and z = sum_t A_t (V c_t) walked through the tiles (footprint -> W -> 16-bit entries
+    -> row map) equals the direct evaluation; grid stride detection on the gun / waveguide stencils; blocks whose footprint
+    exceeds the LDS budget are split; a matrix with a row that can never fit gets no tiles"""
+    import scipy.sparse as sp
+    from nep_amd.nep import tiles_analyze
+    from nep_amd import gallery, wep
+    if case == "gun":
+        K, M, W1, W2 = gallery.gun_matrices()
+        d = tiles_analyze([K, -M, W1, W2], k=5)
+        assert d["stride"] == 131 and d["blocks"] >= 256 and d["max_footprint"] <= 128
+        assert d["stream_bytes"] < 12 * (K.nnz + M.nnz + W1.nnz + W2.nnz) + 4 * 4 * 9957      # below the stacked CSR's bytes
+    elif case == "wep":
+        Av = wep.WaveguideData(109, 105, "JARLEBRING").big_matrices()
+        d = tiles_analyze(Av, k=3)
+        assert d["stride"] == 105 and d["blocks"] > 0
+        monkeypatch.setenv("NEP_K1_TILE_XP", "8"); monkeypatch.setenv("NEP_K1_TILE_ZP", "64")
+        d2 = tiles_analyze(Av, k=3)
+        assert d2["max_rel_err"] <= 1e-14 and d2["blocks"] < d["blocks"]
+        monkeypatch.setenv("NEP_K1_TILE_LDS_KB", "8")               # 8 KiB / (16 B * 3 terms) = 170 columns: patches must split
+        d3 = tiles_analyze(Av, k=3)
+        assert d3["max_footprint"] <= 170 and d3["blocks"] > d2["blocks"] and d3["max_rel_err"] <= 1e-14
+    elif case == "qdep0":
+        d = tiles_analyze(na.nep_gallery("qdep0").get_Av(), k=2)
+        assert d["stride"] == 0 and d["blocks"] > 0
+    elif case == "random":
+        A = sp.random(4000, 4000, density=0.002, random_state=1, format="csr") + sp.identity(4000, format="csr")
+        B = sp.random(4000, 4000, density=0.001, random_state=2, format="csr") * (1 + 2j)
+        d = tiles_analyze([A, B], k=4)
+        assert d["blocks"] > 0
+    else:
+        A = sp.lil_matrix((6000, 6000)); A.setdiag(1.0); A[17, :] = 1.0      # one dense row: 6000 columns > any LDS budget
+        d = tiles_analyze([sp.csr_matrix(A)], k=2)
+        assert d["blocks"] == 0
+        return
+    assert d["max_rel_err"] <= 1e-14
