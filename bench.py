@@ -145,6 +145,8 @@ def beyn_sharded(na, args, world, rank):
     all-gather of the 2 n k partial moment block.  Strong scaling (total work fixed).  Timed with barriers.  Parity on rank
     0: count and eigenvalues against the CPU oracle on the same probe block, backward errors re-evaluated on the host."""
     import baseline_configs as bc
+    if os.environ.get("NEP_BENCH_BEYN_FAIL"):          # test hook: the extra fails on every rank, the headline line must survive
+        raise RuntimeError("injected failure of the sharded contour_beyn extra (NEP_BENCH_BEYN_FAIL)")
     nep = na.nep_gallery("gun_spmf", args.n)
     nep.dev
     Vh = na.probe_block(nep.n, 32)
@@ -169,11 +171,17 @@ def beyn_sharded(na, args, world, rank):
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_rank = None
     if distd:
+        mine = {"rank": rank, "nodes": int(info.get("nodes", -1)), "wall_s": round(dt, 5),
+                "exchange_s": None if info.get("exchange_s") is None else round(float(info["exchange_s"]), 6)}
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
         t = torch.tensor([dt], dtype=torch.float64, device=RED_DEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
     out = {"workload": "contour_beyn gun SPMF n=%d N=64 k=32 radius=1e4 sigma=250^2 tol=1e-6" % nep.n,
+           "per_rank": per_rank, "wall": "max over ranks",
            "eigenpairs": int(len(lam)), "seconds": dt, "eigenpairs_per_s": len(lam) / dt, "rank_p": int(info.get("p", -1)),
            "nodes_per_rank": int(info.get("nodes", 64)), "scaling": "strong",
            "exchange": "one all_gather of 2*n*k complex128 per rank (%.1f MB)" % (2 * nep.n * 32 * 16 / 1e6) if distd else "none"}

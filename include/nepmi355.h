@@ -443,6 +443,10 @@ int32_t nep_comm_info(const nep_comm* c, int32_t out[2]);     /* out[0] = rank, 
  * library-owned world x len block + one summation kernel, all on `stream` (asynchronous).  d_total may alias
  * d_partial. */
 int32_t nep_allgather_sum(nep_comm* c, const nep_cdouble* d_partial, int64_t len, nep_cdouble* d_total, nep_stream stream);
+/* the reduction half of nep_allgather_sum on a caller-provided gather buffer (world x len complex128, rank r's block at
+ * r * len): d_total[i] = sum_r d_parts[r * len + i] in rank order r = 0 .. world-1 (bit-identical wherever it runs);
+ * d_total may alias block 0.  For tests and for hosts that move the blocks themselves. */
+int32_t nep_sum_ranks(const nep_cdouble* d_parts, int64_t len, int32_t world, nep_cdouble* d_total, nep_stream stream);
 
 #ifdef __cplusplus
 }

@@ -1,19 +1,16 @@
-# INTEGRATION — binding libnepmi355.so from NonlinearEigenproblems.jl
+# NEPMI355X.jl -- Julia binding of libnepmi355.so (include/nepmi355.h) for NonlinearEigenproblems.jl.
+#
+# This is the file INTEGRATION.md describes, shipped as source: `include` it from src/NonlinearEigenproblems.jl after
+# NEPSolver (it refers to the parent package's modules with `..`).  It subtypes the reference's four plug-in seams
+# (AbstractSPMF / LinSolver + LinSolverCreator / IterativeSolvers.OrthogonalizationMethod / MatrixIntegrator, SURVEY.md
+# section 8b) and forwards to the C ABI with `ccall`; the solver drivers (iar, tiar, resinv, nleigs, contour_beyn) then run
+# unchanged.  Julia is not installed in the build image of this repository, so the file has NOT been executed there; every C
+# symbol it calls is exercised by the ctypes host (nonlineareigenproblems.jl_amd/_lib.py) in the `-m gpu` test suite, and
+# tests/test_host_logic.py::test_julia_binding_symbols_exist checks that each `ccall` target below is exported by the
+# library and declared in include/nepmi355.h.
+#
+# Library search: put the directory of libnepmi355.so on LD_LIBRARY_PATH (or set `const LIB` to its absolute path).
 
-The reference is pure Julia and selects behaviour by multiple dispatch on four small abstract types
-(SURVEY.md §8b).  A maintainer makes the MI355X backend a drop-in by adding ONE file (below) that subtypes those
-seams and forwards to the C ABI of `include/nepmi355.h` with `ccall`.  Julia is not available in the build image,
-so this file is shipped as source and has not been executed; the same C symbols are exercised by the Python/ctypes
-host (`nonlineareigenproblems.jl_amd/_lib.py`) in every `-m gpu` test.
-
-**The binding below is shipped as a file: `julia/NEPMI355X.jl`** (the first code block of this document verbatim;
-`julia/usage_examples.jl` holds the usage snippets further down; `tests/test_host_logic.py::test_julia_binding_symbols_exist`
-keeps the two in step and checks every `ccall` target against the header and the built library).
-
-Build the library: `python __graft_entry__.py` (or `python nonlineareigenproblems.jl_amd/build.py`) →
-`nonlineareigenproblems.jl_amd/libnepmi355.so` (hipcc, `--offload-arch=gfx950`).
-
-```julia
 # src/backends/MI355X.jl  -- to be `include`d from src/NonlinearEigenproblems.jl after NEPSolver
 module MI355X
 using ..NEPCore, ..NEPTypes, ..LinSolvers, ..NEPSolver
@@ -230,61 +227,3 @@ function integrate_interval(::Type{MatrixTrapezoidalSharded}, ::Type{T}, f, gv, 
     reshape(download(S), n, k, m)                               # Array{T,3}, as src/method_contour_common.jl:93 returns it
 end
 end # module
-```
-
-Usage from the reference's own drivers, unchanged:
-
-```julia
-nep  = DeviceSPMF(shift_and_scale(SPMF_NEP(get_Av(gun), get_fv(gun)), shift=250^2, scale=330^2-220^2))
-λ, Q = iar(nep; maxit=100, neigs=Inf, v=ones(size(nep,1)), linsolvercreator=MI355X.DeviceLinSolverCreator())
-```
-
-`contour_beyn(nep, MI355X.MatrixTrapezoidalSharded; N=64, k=32, ...)` then runs config C4 over the ranks: the integrand of
-`method_beyncontour.jl:89-98` creates a `DeviceLinSolver` per node and calls `lin_solve!` on a device copy of the probe
-block.  With host arrays at the other seams a call pays an upload/download of what it touches (one basis column and `w` per
-orthogonalisation; `V` per `compute_Mlincomb` unless the `DevBuf` overload is used); the device-resident drivers (basis, Ritz block and
-work vectors never leave HBM) are what `nonlineareigenproblems.jl_amd/{iar,tiar,newton,contour}.py` implement on top of the
-same symbols, and are the model for `method_*.jl` variants that keep `V` in a `DevBuf`.
-
-### The whole Arnoldi step as one `ccall` (`nep_iar_step` / `nep_iar_steps`)
-
-A Julia `iar` variant that keeps the basis in a `DevBuf` issues ONE foreign call per step (or per batch of steps) instead of
-one per statement of `method_iar.jl:94-109`:
-
-```julia
-# V: DevBuf, (m+1) columns of n(m+1); Ctab: DevBuf m x mt, row j = alpha_j/j * f^(j)(sigma); H: DevBuf m x (m+4), zero-filled;
-# Hpin: pinned host Matrix{ComplexF64}(undef, m+4, m) (hipHostMalloc'ed, read by the eig task)
-h = Ref{Ptr{Cvoid}}()
-chk(ccall((:nep_iar_create, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid},
-          Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}, Int32, Ptr{Cvoid}, Ptr{ComplexF64}, Int32, Ref{Ptr{Cvoid}}),
-          spmf.h, lu.h, n, m, V.p, n*(m+1), Ctab.p, m, active.p, work3n.p, abs.(fσ), fσ, length(fσ), H.p, Hpin, 0, h))
-for k in 1:m
-    chk(ccall((:nep_iar_step, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}), h[], k, sweeps, C_NULL))
-    @async begin                                   # eig(H_k) overlaps the following steps, as in iar.py
-        ccall((:nep_iar_wait, LIB), Int32, (Ptr{Cvoid}, Int32), h[], k)
-        row = @view Hpin[:, k]                     # h[1:k], beta, (passes, flags), then 4 Float64: omega of x_0..x_sweeps
-        ω = reinterpret(Float64, row[k+3:k+4])
-        review_umfpack_rule(ω, sweeps) || error("refinement miss: rerun with checked solves")   # linsolvers.py review_recorded
-        ...
-    end
-end
-```
-
-`sweeps` is UMFPACK's refinement count taken blindly (2 until the first record has been reviewed, then what the rule asked
-for); the step records UMFPACK's componentwise backward error of every iterate so that the host replays `umfpack_refinements`'
-stopping rule without a read-back inside the step.
-
-## Symbol → reference map
-
-See the per-function comments in `include/nepmi355.h`; in short: `nep_spmf_create` ↔ `SPMF_NEP` struct
-(`NEPTypes.jl:162-170`), `nep_mlincomb[_dev]` ↔ `compute_Mlincomb(!)` (`NEPTypes.jl:972-1011,1130-1160`), `nep_resid_batch`
-↔ `estimate_error` (`errmeasure.jl:128-190`), `nep_spmm_terms` + `nep_gemm_ts` ↔ `compute_MM` (`NEPTypes.jl:276-319`),
-`nep_resid_block` (coefficients e_i 1ᵀ) + `nep_gemm_h_rm` ↔ `WT*nep.orgnep_Av[i]*V` of `set_projectmatrices!` (`NEPTypes.jl:733`), `nep_gemv_h` ↔ the
-row / column updates of `expand_projectmatrices!` (`:782-783`), `nep_coldotsu` ↔ `mat_sum` of `ilan` (`method_ilan.jl:299-308`), `nep_resid_batch_dev` / `nep_orth_dev` ↔ the same two reference calls without any host synchronisation (squared norms, H column, β and
-the DGKS decision stay on the device; used by the pipelined `iar`), `nep_lu_create[_csc]/solve` ↔ `FactorizeLinSolver`/`lin_solve` (`LinSolvers.jl:109-137`), `nep_lu_refactor` ↔ the N same-pattern factorisations of `method_beyncontour.jl:89-94`, `nep_lu_refac_create` / `nep_lu_factor_dev[_batch]` ↔ the numeric phase of those factorisations (`lu` / `factorize`, `LinSolvers.jl:116`) on the GPU, `nep_lu_set_row_scale` ↔ UMFPACK's `F.Rs`, `nep_comm_create` / `nep_allgather_sum` ↔ the reduction of `integrate_interval` (`method_contour_common.jl:61-94`) over ranks, `nep_cw_backward_error` +
-`nep_lu_solve_add` ↔ UMFPACK's iterative refinement behind `Afact\\x` (`LinSolvers.jl:118-120`, `umfpack_refinements`), `nep_orth` ↔
-`orthogonalize_and_normalize!` (IterativeSolvers), `nep_gemm_ts` ↔ `Q=VV*Z` (`method_iar.jl:115`), `nep_axpy` ↔
-`S[:,:,j] += temp*G[i,j]` (`method_contour_common.jl:88-90`), `nep_iar_shift_scale` ↔ `method_iar.jl:100-105`,
-`nep_rk_bw` / `nep_block_recur` ↔ the block loops of `backslash` (`method_nleigs.jl:417-436,445-487,496-515`), `nep_csr_create/mv` ↔ the
-low-rank factors of `RKNEP` (`rk_nep.jl:128-152`): `P.UU'*x` (`method_nleigs.jl:430,480,510`) and the `LL`/`iLr` scatter loop (`:464-471`), and `nep.C1*…`, `nep.C2T*…` of the
-waveguide Schur complement (`Waveguide.jl:405,561,565`); `nep_zgemm` ↔ the FFTW transforms `V!/Vh!/W/Wh` of `waveguide_preconditioner.jl:163-219` as dense DFT / sine-transform products.

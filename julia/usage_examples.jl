@@ -1,0 +1,21 @@
+# Usage of julia/NEPMI355X.jl from NonlinearEigenproblems.jl (the snippets of INTEGRATION.md; not executed in this image)
+
+nep  = DeviceSPMF(shift_and_scale(SPMF_NEP(get_Av(gun), get_fv(gun)), shift=250^2, scale=330^2-220^2))
+λ, Q = iar(nep; maxit=100, neigs=Inf, v=ones(size(nep,1)), linsolvercreator=MI355X.DeviceLinSolverCreator())
+
+# V: DevBuf, (m+1) columns of n(m+1); Ctab: DevBuf m x mt, row j = alpha_j/j * f^(j)(sigma); H: DevBuf m x (m+4), zero-filled;
+# Hpin: pinned host Matrix{ComplexF64}(undef, m+4, m) (hipHostMalloc'ed, read by the eig task)
+h = Ref{Ptr{Cvoid}}()
+chk(ccall((:nep_iar_create, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid},
+          Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}, Int32, Ptr{Cvoid}, Ptr{ComplexF64}, Int32, Ref{Ptr{Cvoid}}),
+          spmf.h, lu.h, n, m, V.p, n*(m+1), Ctab.p, m, active.p, work3n.p, abs.(fσ), fσ, length(fσ), H.p, Hpin, 0, h))
+for k in 1:m
+    chk(ccall((:nep_iar_step, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}), h[], k, sweeps, C_NULL))
+    @async begin                                   # eig(H_k) overlaps the following steps, as in iar.py
+        ccall((:nep_iar_wait, LIB), Int32, (Ptr{Cvoid}, Int32), h[], k)
+        row = @view Hpin[:, k]                     # h[1:k], beta, (passes, flags), then 4 Float64: omega of x_0..x_sweeps
+        ω = reinterpret(Float64, row[k+3:k+4])
+        review_umfpack_rule(ω, sweeps) || error("refinement miss: rerun with checked solves")   # linsolvers.py review_recorded
+        ...
+    end
+end

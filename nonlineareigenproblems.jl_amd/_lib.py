@@ -136,6 +136,7 @@ SIGNATURES = {
     "nep_comm_destroy": [c_vp],
     "nep_comm_info": [c_vp, P(c_i32)],
     "nep_allgather_sum": [c_vp, c_vp, c_i64, c_vp, c_vp],
+    "nep_sum_ranks": [c_vp, c_i64, c_i32, c_vp, c_vp],
     "nep_iar_shift_scale": [c_i64, c_i32, c_vp, c_vp, c_vp],
     "nep_rk_bw": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
     "nep_block_recur": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],

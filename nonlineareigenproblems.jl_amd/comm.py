@@ -3,6 +3,7 @@ one RCCL communicator per process (= per GPU), an all-gather of the partial mome
 order.  The 128-byte unique id reaches the ranks out of band -- here through torch.distributed's process group (any backend),
 in a Julia host through MPI.jl."""
 import ctypes as C
+import time
 
 import numpy as np
 
@@ -41,8 +42,22 @@ class DeviceComm:
     def allgather_sum(self, S, out=None):
         """out = sum over ranks of S (device complex128 tensor, same shape on every rank), identical on every rank"""
         out = S if out is None else out
+        import torch
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
         check(lib.nep_allgather_sum(self.h, c_vp(S.data_ptr()), S.numel(), c_vp(out.data_ptr()), stream_ptr()))
+        e1.record()
+        self._last_events = (e0, e1)                  # read by last_exchange_s (no synchronisation here)
         return out
+
+    @property
+    def last_exchange_s(self):
+        """device time of the last all-gather + sum (waits for it)"""
+        ev = getattr(self, "_last_events", None)
+        if ev is None:
+            return None
+        ev[1].synchronize()
+        return ev[0].elapsed_time(ev[1]) * 1e-3
 
     def close(self):
         if getattr(self, "h", None):
@@ -71,13 +86,15 @@ class HostStagedComm:
         import torch
         import torch.distributed as dist
         out = S if out is None else out
+        t0 = time.perf_counter()
         h = S.detach().cpu()
         parts = [torch.empty_like(h) for _ in range(self.world)]
         dist.all_gather(parts, h)
-        acc = torch.zeros_like(h)
-        for p in parts:
-            acc += p
-        out.copy_(acc.to(out.device))
+        # the same fixed-order sum kernel the RCCL path runs behind its all-gather (nep_sum_ranks): identical bits on every rank
+        G = torch.stack(parts).to(S.device).contiguous()
+        check(lib.nep_sum_ranks(c_vp(G.data_ptr()), S.numel(), self.world, c_vp(out.data_ptr()), stream_ptr()))
+        torch.cuda.synchronize()
+        self.last_exchange_s = time.perf_counter() - t0
         return out
 
     def close(self):

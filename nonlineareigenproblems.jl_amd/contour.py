@@ -92,6 +92,8 @@ def integrate_interval(ST, f, gv, a, b, N, info=None, ops=_DeviceOps):
     ops.scal(S, h)
     if info is not None:
         info.update(world=world, rank=rank, nodes=len(mine))
+        if comm is not None and getattr(comm, "last_exchange_s", None) is not None:
+            info["exchange_s"] = float(comm.last_exchange_s)
     return S
 
 

@@ -62,7 +62,7 @@ struct nep_comm {
 };
 
 // total[i] = sum_r parts[r*len + i], r = 0..world-1 in this order on every rank
-__global__ void k_sum_ranks(int64_t len, int world, const cplx* __restrict__ parts, cplx* __restrict__ total) {
+__global__ void k_sum_ranks(int64_t len, int world, const cplx* parts, cplx* total) {
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < len; i += (int64_t)gridDim.x * blockDim.x) {
         cplx s = parts[i];
         for (int r = 1; r < world; ++r) { const cplx v = parts[(int64_t)r * len + i]; s.x += v.x; s.y += v.y; }
@@ -113,6 +113,19 @@ int32_t nep_comm_info(const nep_comm* c, int32_t out[2]) {
     return NEP_OK;
 }
 
+// the second half of nep_allgather_sum on a gather buffer the caller provides (world x len, rank r's block at r * len):
+// total[i] = parts[0][i] + parts[1][i] + ... in THIS order -- what every rank executes after the all-gather, so that all of
+// them hold the same bits.  d_total may alias block 0 of d_parts.  Exposed so that the reduction can be tested (and used by
+// hosts that move the blocks themselves, e.g. ranks sharing one GPU) without a multi-rank RCCL communicator.
+int32_t nep_sum_ranks(const nep_cdouble* d_parts, int64_t len, int32_t world, nep_cdouble* d_total, nep_stream stream) {
+    ARGCHK(d_parts && d_total && len > 0 && world >= 1);
+    hipStream_t st = as_stream(stream);
+    const int g = (int)std::min<int64_t>((len + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_sum_ranks, dim3(g), dim3(256), 0, st, len, (int)world, (const cplx*)d_parts, (cplx*)d_total);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
 int32_t nep_allgather_sum(nep_comm* c, const nep_cdouble* d_partial, int64_t len, nep_cdouble* d_total, nep_stream stream) {
     ARGCHK(c && d_partial && d_total && len > 0);
     hipStream_t st = as_stream(stream);
@@ -120,10 +133,7 @@ int32_t nep_allgather_sum(nep_comm* c, const nep_cdouble* d_partial, int64_t len
     if (rc) return rc;
     const int s = g_rccl.allgather(d_partial, c->gather.dptr, (size_t)2 * len, NCCL_DOUBLE, c->comm, st);
     if (s != 0) return rccl_fail("ncclAllGather", s);
-    const int g = (int)std::min<int64_t>((len + 255) / 256, 4096);
-    hipLaunchKernelGGL(k_sum_ranks, dim3(g), dim3(256), 0, st, len, c->world, (const cplx*)c->gather.dptr, (cplx*)d_total);
-    LAUNCHCHK();
-    return NEP_OK;
+    return nep_sum_ranks((const nep_cdouble*)c->gather.dptr, len, c->world, d_total, stream);
 }
 
 }  // extern "C"

@@ -65,7 +65,9 @@ int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdo
         // the steps run on the caller's stream, which need not be ordered behind the NULL stream (non-blocking streams)
         if (hipEventCreateWithFlags(&s->e_upload, hipEventDisableTiming) == hipSuccess) (void)hipEventRecord(s->e_upload, nullptr);
         else (void)hipGetLastError();
-        static const int overlap = getenv("NEP_IAR_RESID_OVERLAP") ? atoi(getenv("NEP_IAR_RESID_OVERLAP")) : 1;
+        // MEASURED: slower (gun iar 45.1 ms per call against 42.8 ms): the two cross-stream dependencies per step cost more on
+        // the device than the 11 us kernel they take off the critical path.  Opt-in (NEP_IAR_RESID_OVERLAP=1).
+        static const int overlap = getenv("NEP_IAR_RESID_OVERLAP") ? atoi(getenv("NEP_IAR_RESID_OVERLAP")) : 0;
         if (overlap && hipStreamCreateWithFlags(&s->side, hipStreamNonBlocking) == hipSuccess) {
             if (hipEventCreateWithFlags(&s->e_solved, hipEventDisableTiming) != hipSuccess ||
                 hipEventCreateWithFlags(&s->e_checked, hipEventDisableTiming) != hipSuccess) {

@@ -353,6 +353,82 @@ __device__ __forceinline__ void ml_coupling_body(const MLCplArgs& C, const int b
 template <int G, int RB>
 __global__ __launch_bounds__(256) void k_ml_coupling(const MLCplArgs C) { ml_coupling_body<G, RB>(C, (int)blockIdx.x, (int)blockIdx.y); }
 
+// ---- last launch of a single-vector solve: U level 0 with its coupling product inside ------------------------------------------
+//   x_B = inv(U_BB) (y_B - U[B, T] x_T)   for every level-0 block B, then the caller's X through the output permutation.
+// The two-launch form (k_ml_coupling over the level's rows, then k_ml_level<MODE 1> in 4-row chunks) pays a kernel boundary
+// and a round trip of the coupled right-hand side; forming the product inside the chunked level kernel would repeat it for
+// every chunk of a block.  Here TWO workgroups of 1024 threads own a block: each forms r_B = y_B - U[B, T] x_T once in LDS
+// (4 lanes per row; twice per block in total), then applies its half of the packed inverse rows.  The rows of a triangular
+// inverse have lengths 1 .. b: rows l and b-1-l are PAIRED (b + 1 entries together) and every pair is walked by 16 lanes,
+// so all lanes carry the same number of loads; the workgroup with index parity h takes the pairs p = h, h + 2, ...
+struct MLU0Args {
+    const int32_t* blk_se; int blk0, nblk;
+    const int32_t* cp; const int32_t* ci; const cplx* cx;        // U coupling CSR (rows of the level, columns in the apex / later levels)
+    const cplx* ix; const int64_t* ip;                           // packed inverse rows of U_BB: row q holds columns [q, e)
+    const cplx* y; const cplx* x;                                // y (all rows), x of the later levels (new order)
+    cplx* outX; const int32_t* pout; double scale; const cplx* add;
+    int64_t side_lo, side_hi;                                    // rows of the later levels: scattered to outX by extra workgroups
+};
+__global__ __launch_bounds__(1024) void k_ml_u0_fused(const MLU0Args A) {
+    __shared__ cplx r[ML_BMAX];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x >= 2 * A.nblk) {                          // ---- side job: x of the later levels -> caller's X
+        const int64_t q = A.side_lo + ((int64_t)blockIdx.x - 2 * A.nblk) * 1024 + tid;
+        if (q < A.side_hi) {
+            const int64_t g = A.pout ? A.pout[q] : q;
+            cplx v = A.x[q];
+            if (A.add) { const cplx ad = A.add[g]; v.x += ad.x; v.y += ad.y; }
+            A.outX[g] = cmake(A.scale * v.x, A.scale * v.y);
+        }
+        return;
+    }
+    const int k = A.blk0 + ((int)blockIdx.x >> 1), half = (int)blockIdx.x & 1;
+    const int s = A.blk_se[2 * k], e = A.blk_se[2 * k + 1], b = e - s;
+    {   // r_l = y[s + l] - sum_p U[s + l, col_p] x[col_p]: 4 lanes per row
+        const int l = tid >> 2, sub = tid & 3;
+        cplx acc = cmake(0.0, 0.0);
+        if (l < b) {
+            const int q = s + l;
+            const int e1 = A.cp[q + 1];
+#pragma unroll 4
+            for (int p = A.cp[q] + sub; p < e1; p += 4) cfma(acc, A.cx[p], A.x[A.ci[p]]);
+        }
+        acc = group_reduce_sum<4>(acc);
+        if (l < b && sub == 0) r[l] = csub(A.y[s + l], acc);
+    }
+    __syncthreads();
+    // pairs of rows (l, b-1-l), l < ceil(b/2): 16 lanes per pair, 64 pairs per pass
+    const int npair = (b + 1) >> 1;
+    const int sub = tid & 15;
+    for (int p = half + 2 * (tid >> 4); p < npair; p += 128) {
+        const int la = p, lb = b - 1 - p;                         // la <= lb
+        const int lenA = b - la, lenB = (lb > la) ? b - lb : 0;   // row l holds columns [l, b)
+        const cplx* rowA = A.ix + A.ip[s + la];
+        const cplx* rowB = A.ix + A.ip[s + lb];
+        cplx accA = cmake(0.0, 0.0), accB = cmake(0.0, 0.0);
+        const int tot = lenA + lenB;
+#pragma unroll 4
+        for (int pos = sub; pos < tot; pos += 16) {
+            if (pos < lenA) cfma(accA, rowA[pos], r[la + pos]);
+            else { const int t = pos - lenA; cfma(accB, rowB[t], r[lb + t]); }
+        }
+        accA = group_reduce_sum<16>(accA);
+        accB = group_reduce_sum<16>(accB);
+        if (sub == 0) {
+            const int64_t ga = A.pout ? A.pout[s + la] : s + la;
+            cplx v = accA;
+            if (A.add) { const cplx ad = A.add[ga]; v.x += ad.x; v.y += ad.y; }
+            A.outX[ga] = cmake(A.scale * v.x, A.scale * v.y);
+            if (lb > la) {
+                const int64_t gb = A.pout ? A.pout[s + lb] : s + lb;
+                cplx w = accB;
+                if (A.add) { const cplx ad = A.add[gb]; w.x += ad.x; w.y += ad.y; }
+                A.outX[gb] = cmake(A.scale * w.x, A.scale * w.y);
+            }
+        }
+    }
+}
+
 // ---- apex: the last levels as ONE dense inverse S^{-1} = inv(U_TT) inv(L_TT) (T x T, row-major) ---------------------------
 // out (row-major T x T) = transpose of the column-major block `in` (ld = T)
 __global__ __launch_bounds__(256) void k_apex_transpose(int T, const cplx* __restrict__ in, cplx* __restrict__ out) {
@@ -396,6 +472,34 @@ __device__ __forceinline__ void apex_gemv_body(const MLApexArgs& P, const int bx
 
 template <int RB>
 __global__ __launch_bounds__(256) void k_apex_gemv(const MLApexArgs P) { apex_gemv_body<RB>(P, (int)blockIdx.x, (int)blockIdx.y); }
+
+// single right-hand side: the whole vector t (T <= 2048 entries) is staged in LDS once per workgroup, every wave owns two rows
+// and keeps eight 16-byte loads of S^{-1} in flight per lane (the wave-per-row form above had four: 28 MB in 9.4 us)
+#define ML_APEX_TMAX 2048
+__global__ __launch_bounds__(256) void k_apex_gemv1(const MLApexArgs P) {
+    __shared__ cplx ts[ML_APEX_TMAX];
+    const int T = P.T, R0 = P.R0;
+    for (int c = threadIdx.x; c < T; c += 256) ts[c] = P.t[R0 + c];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int r0 = ((int)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2;
+    if (r0 >= T) return;
+    const bool two = r0 + 1 < T;
+    const cplx* __restrict__ rowA = P.Sinv + (int64_t)r0 * T;
+    const cplx* __restrict__ rowB = P.Sinv + (int64_t)(two ? r0 + 1 : r0) * T;
+    cplx a0 = cmake(0.0, 0.0), a1 = cmake(0.0, 0.0), b0 = cmake(0.0, 0.0), b1 = cmake(0.0, 0.0);
+    int c = lane;
+    for (; c + 192 < T; c += 256) {
+        const cplx m0 = rowA[c], m1 = rowA[c + 64], m2 = rowA[c + 128], m3 = rowA[c + 192];
+        const cplx n0 = rowB[c], n1 = rowB[c + 64], n2 = rowB[c + 128], n3 = rowB[c + 192];
+        const cplx t0 = ts[c], t1 = ts[c + 64], t2 = ts[c + 128], t3 = ts[c + 192];
+        cfma(a0, m0, t0); cfma(a1, m1, t1); cfma(a0, m2, t2); cfma(a1, m3, t3);
+        cfma(b0, n0, t0); cfma(b1, n1, t1); cfma(b0, n2, t2); cfma(b1, n3, t3);
+    }
+    for (; c < T; c += 64) { const cplx tt = ts[c]; cfma(a0, rowA[c], tt); cfma(b0, rowB[c], tt); }
+    const cplx sa = group_reduce_sum<64>(cadd(a0, a1)), sb = group_reduce_sum<64>(cadd(b0, b1));
+    if (lane == 0) { P.x[R0 + r0] = sa; if (two) P.x[R0 + r0 + 1] = sb; }
+}
 
 // =====================================================================================================================
 // host side
@@ -1342,7 +1446,10 @@ static int run_apex(const MLSolveCtx& c, hipStream_t st, int* launches) {
         return NEP_OK;
     }
 #define APEX_GEMV(RB_) hipLaunchKernelGGL((k_apex_gemv<RB_>), dim3((unsigned)((T + 3) / 4), (c.nrhs + RB_ - 1) / RB_), dim3(256), 0, st, P)
-    if (c.nrhs >= 8) APEX_GEMV(8); else if (c.nrhs >= 2) APEX_GEMV(4); else APEX_GEMV(1);
+    const int gemv1 = getenv("NEP_ML_GEMV1") ? atoi(getenv("NEP_ML_GEMV1")) : 1;
+    if (c.nrhs >= 8) APEX_GEMV(8); else if (c.nrhs >= 2) APEX_GEMV(4);
+    else if (gemv1 && T <= ML_APEX_TMAX) hipLaunchKernelGGL(k_apex_gemv1, dim3((unsigned)((T + 7) / 8)), dim3(256), 0, st, P);
+    else APEX_GEMV(1);
 #undef APEX_GEMV
     LAUNCHCHK();
     if (launches) *launches += 2;
@@ -1350,6 +1457,37 @@ static int run_apex(const MLSolveCtx& c, hipStream_t st, int* launches) {
 }
 
 // everything between the first (L level 0) and the last (U level 0) launch: fixed buffers only -> one hipGraph
+// the last launch of a single-vector solve takes U level 0's coupling product inside (k_ml_u0_fused) when that level runs the
+// product as its own launch today
+static bool u0_fused(const MLFactor* F, int nrhs) {
+    // MEASURED: no gain on gun (4 launches 38.4 us against 36.7 us for 5 launches with the same apex kernel): the fused kernel
+    // strings the dependent-load chains of the two kernels it replaces together (block range -> row pointers -> entries ->
+    // gathers -> LDS -> inverse row offsets -> rows -> permutation -> store), and a solve at this size is bound by those
+    // chains, not by its launches.  Kept opt-in (NEP_ML_U0FUSE=1) and tested.
+    const char* e = getenv("NEP_ML_U0FUSE");            // (read per solve: tests switch it)
+    const int on = e ? atoi(e) : 0;
+    const MLSym* S = F->sym;
+    if (!on || nrhs != 1 || g_rec || S->nlev < 2 || !S->U.split[0] || S->max_block > ML_BMAX) return false;
+    // two 1024-thread workgroups per block pay off for blocks of ~100 rows and more (gun: 51 blocks of 169 rows on average);
+    // the 64-row blocks of a million-row factor stay with the chunked kernels
+    const int nb0 = S->lev_blk[1] - S->lev_blk[0];
+    return nb0 > 0 && S->lev_row[1] / nb0 >= 96;
+}
+static int run_U0_fused(const MLSolveCtx& c, hipStream_t st, int* launches) {
+    const MLSym* S = c.F->sym;
+    const MLFacSym& f = S->U;
+    MLU0Args a;
+    a.blk_se = S->d_blk_se; a.blk0 = S->lev_blk[0]; a.nblk = S->lev_blk[1] - S->lev_blk[0];
+    a.cp = f.d_cp; a.ci = f.d_ci; a.cx = c.F->d_vals + (S->L.ncoup + S->L.nin);
+    a.ix = c.F->d_ixU; a.ip = f.d_ip; a.y = c.y; a.x = c.x;
+    a.outX = c.dX; a.pout = S->d_pout; a.scale = c.scale; a.add = c.dAdd;
+    a.side_lo = S->lev_row[1]; a.side_hi = S->n;
+    const unsigned gx = (unsigned)(2 * a.nblk + (a.side_hi - a.side_lo + 1023) / 1024);
+    hipLaunchKernelGGL(k_ml_u0_fused, dim3(gx), dim3(1024), 0, st, a);
+    LAUNCHCHK(); if (launches) ++*launches;
+    return NEP_OK;
+}
+
 static int ml_middle(const MLSolveCtx& c, hipStream_t st, int* launches) {
     const MLSym* S = c.F->sym;
     const int top = eff_apex(c.F) > 0 ? eff_apex(c.F) : S->nlev;      // levels [top, nlev) are handled by the apex
@@ -1360,15 +1498,16 @@ static int ml_middle(const MLSolveCtx& c, hipStream_t st, int* launches) {
         if ((rc = run_U_coupling(c, l, st, launches))) return rc;
         if ((rc = run_U_level(c, l, false, st, launches))) return rc;
     }
+    if (u0_fused(c.F, c.nrhs)) return NEP_OK;
     return run_U_coupling(c, 0, st, launches);
 }
-static int ml_middle_count(const MLFactor* F) {
+static int ml_middle_count(const MLFactor* F, int nrhs) {
     const MLSym* S = F->sym;
     const int top = eff_apex(F) > 0 ? eff_apex(F) : S->nlev;
     int nmid = 0;
     for (int l = 1; l < top; ++l) nmid += 2 + S->L.split[l] + S->U.split[l];
     if (eff_apex(F) > 0) nmid += 2;
-    return nmid + S->U.split[0];
+    return nmid + (u0_fused(F, nrhs) ? 0 : S->U.split[0]);
 }
 
 // numeric build of the apex: S^{-1} e_j for all T unit vectors = the block solve of levels >= la restricted to the apex
@@ -1484,7 +1623,7 @@ int ml_solve(MLFactor* F, int nrhs, const nep_cdouble* dB, int64_t ldb, const ne
         F->fuse_off = 1;          // too many phases for one kernel-argument block: multi-launch path from now on
     }
     if ((rc = run_L(c, 0, true, st, &launches))) return rc;
-    const int nmid = ml_middle_count(F);
+    const int nmid = ml_middle_count(F, nrhs);
     bool graphed = false;
     if (F->use_graph && nmid >= 4 && (F->apex_la == 0 || F->apex_live) && !getenv("NEP_NO_GRAPH")) {   // no capture for the few solves before the apex
         if (!F->graph || F->graph_nrhs != nrhs || F->graph_work != F->work.dptr) {
@@ -1505,7 +1644,8 @@ int ml_solve(MLFactor* F, int nrhs, const nep_cdouble* dB, int64_t ldb, const ne
         if (F->graph) { HIPCHK(hipGraphLaunch(F->graph, st)); launches += nmid; graphed = true; }
     }
     if (!graphed && (rc = ml_middle(c, st, &launches))) return rc;
-    if ((rc = run_U_level(c, 0, true, st, &launches))) return rc;
+    if (u0_fused(F, nrhs)) { if ((rc = run_U0_fused(c, st, &launches))) return rc; }
+    else if ((rc = run_U_level(c, 0, true, st, &launches))) return rc;
     F->launches = launches;
     F->last = st; F->used = true;
     return NEP_OK;

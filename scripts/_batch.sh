@@ -1,15 +1,13 @@
 set -x
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/b3
+mkdir -p gpurun_out/b4
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "tiled or mlincomb or resid" > gpurun_out/b3/t_tile.log 2>&1; echo "rc=$?" >> gpurun_out/b3/t_tile.log
-timeout 600 python scripts/k1_tile_bench.py all > gpurun_out/b3/k1_default.jsonl 2> gpurun_out/b3/k1.err
-NEP_K1_TILE_PF=0 timeout 600 python scripts/k1_tile_bench.py wep > gpurun_out/b3/k1_wep_nopf.jsonl 2>> gpurun_out/b3/k1.err
-NEP_K1_TILE_XP=8 timeout 600 python scripts/k1_tile_bench.py wep > gpurun_out/b3/k1_wep_8x64.jsonl 2>> gpurun_out/b3/k1.err
-NEP_K1_TILE_XP=2 timeout 600 python scripts/k1_tile_bench.py wep > gpurun_out/b3/k1_wep_2x64.jsonl 2>> gpurun_out/b3/k1.err
-NEP_K2_TILE_PS=4 timeout 600 python scripts/k1_tile_bench.py wep > gpurun_out/b3/k1_wep_ps4.jsonl 2>> gpurun_out/b3/k1.err
-for shape in "4 16" "2 16" "8 8"; do set -- $shape
-  NEP_K1_TILE_XP=$1 NEP_K1_TILE_ZP=$2 timeout 600 python scripts/k1_tile_bench.py gun > gpurun_out/b3/k1_gun_$1x$2.jsonl 2>> gpurun_out/b3/k1.err
-done
-NEP_K1_TILE_THREADS=512 timeout 600 python scripts/k1_tile_bench.py gun > gpurun_out/b3/k1_gun_t512.jsonl 2>> gpurun_out/b3/k1.err
+timeout 1500 python -m pytest tests/test_gpu_kernels.py tests/test_goldens.py -x -q -m gpu > gpurun_out/b4/t_kernels.log 2>&1; echo "rc=$?" >> gpurun_out/b4/t_kernels.log
+timeout 300 python bench.py --only k5 --reps 200 > gpurun_out/b4/k5_new.json 2> gpurun_out/b4/k5.err
+NEP_ML_U0FUSE=0 NEP_ML_GEMV1=0 timeout 300 python bench.py --only k5 --reps 200 > gpurun_out/b4/k5_old.json 2>> gpurun_out/b4/k5.err
+NEP_ML_U0FUSE=0 timeout 300 python bench.py --only k5 --reps 200 > gpurun_out/b4/k5_gemv_only.json 2>> gpurun_out/b4/k5.err
+timeout 300 python scripts/iar_runs.py 10 > gpurun_out/b4/iar_new.log 2>&1
+NEP_ML_U0FUSE=0 NEP_ML_GEMV1=0 NEP_IAR_RESID_OVERLAP=0 timeout 300 python scripts/iar_runs.py 10 > gpurun_out/b4/iar_old.log 2>&1
+NEP_IAR_RESID_OVERLAP=0 timeout 300 python scripts/iar_runs.py 10 > gpurun_out/b4/iar_nooverlap.log 2>&1
+timeout 1500 python -m pytest tests/test_gpu_solvers.py -x -q -m gpu > gpurun_out/b4/t_solvers.log 2>&1; echo "rc=$?" >> gpurun_out/b4/t_solvers.log
 echo done

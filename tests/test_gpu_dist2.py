@@ -93,3 +93,53 @@ def test_bench_two_ranks_rehearsal(na, world):
     assert d["config"]["eigenpairs_per_step"] >= 40
     b = d["beyn_sharded"]
     assert "error" not in b and b["nodes_per_rank"] == 64 // world and b["eigenpairs"] >= 20
+    # per-rank record of the sharded extra: every rank reports its nodes, wall time and exchange time
+    pr = b["per_rank"]
+    assert [p["rank"] for p in pr] == list(range(world)) and all(p["nodes"] == 64 // world for p in pr)
+    assert all(p["exchange_s"] is not None and p["exchange_s"] > 0 for p in pr)
+    assert abs(max(p["wall_s"] for p in pr) - b["seconds"]) < 0.05
+
+
+def test_bench_headline_survives_a_failing_extra(na):
+    """the sharded contour_beyn extra raises on EVERY rank (NEP_BENCH_BEYN_FAIL): rank 0 still prints one valid headline line,
+    the failure is recorded under beyn_sharded.error and the process group shuts down cleanly"""
+    import json
+    import subprocess
+    env = dict(os.environ, NEP_BENCH_SHARE_GPU="1", NEP_BENCH_BEYN_FAIL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-wep-roofline", "--no-c3", "--no-c5", "--no-beyn-parity"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["ms_per_step"] > 0 and d["roofline"]["frac"] > 0
+    assert "injected failure" in d["beyn_sharded"]["error"]
+
+
+def test_sum_ranks_fixed_order_kernel(na):
+    """the reduction half of nep_allgather_sum (nep_sum_ranks, csrc/comm.hip k_sum_ranks) on a FABRICATED world x len gather
+    buffer: the result is the rank-ordered sum ((p0 + p1) + p2) + ... bit for bit -- what makes A0, A1 identical on every rank
+    whatever the arrival order -- for world 1 .. 8, a length that is no multiple of the block size, aliasing output = block 0,
+    and values whose sum depends on the order (so a tree or a reversed loop would be caught)"""
+    from nep_amd._lib import lib, check, c_vp
+    rng = np.random.default_rng(7)
+    ln = 100003
+    for world in (1, 2, 3, 8):
+        P = (rng.standard_normal((world, ln)) * 10.0 ** rng.integers(-8, 8, (world, ln))
+             + 1j * rng.standard_normal((world, ln)) * 10.0 ** rng.integers(-8, 8, (world, ln)))
+        ref = P[0].copy()
+        for r in range(1, world):
+            ref = ref + P[r]
+        G = torch.from_numpy(P).to("cuda").contiguous()
+        out = torch.zeros(ln, dtype=torch.complex128, device="cuda")
+        check(lib.nep_sum_ranks(c_vp(G.data_ptr()), ln, world, c_vp(out.data_ptr()), None))
+        assert np.array_equal(out.cpu().numpy(), ref)
+        if world >= 3:                                   # the order matters for these values: a reversed sum differs somewhere
+            rev = P[world - 1].copy()
+            for r in range(world - 2, -1, -1):
+                rev = rev + P[r]
+            assert not np.array_equal(rev, ref)
+        check(lib.nep_sum_ranks(c_vp(G.data_ptr()), ln, world, c_vp(G.data_ptr()), None))          # output aliases block 0
+        assert np.array_equal(G[0].cpu().numpy(), ref)

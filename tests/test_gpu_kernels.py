@@ -908,3 +908,39 @@ def test_resid_batch_tiled_kernel(na, case):
             assert np.array_equal(o2.cpu().numpy(), res[1][0])
     finally:
         check(lib.nep_k1_set_mode(0))
+
+
+def test_lu_fused_last_launch_and_apex_gemv(na, monkeypatch):
+    """K5 single-vector solve: the last launch with U level 0's coupling product inside (k_ml_u0_fused: paired rows of the packed
+    inverse, two workgroups per block) and the two-rows-per-wave apex product (k_apex_gemv1) against the separate launches
+    (NEP_ML_U0FUSE=0, NEP_ML_GEMV1=0) and SciPy; with and without the fused refinement update x + A^{-1} r and UMFPACK's row
+    scaling; one launch fewer per solve"""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    import torch
+    from oracle import gallery as og
+    A = sp.csc_matrix(og.gun_spmf_scaled(9956).compute_Mder(0.0)).astype(np.complex128)
+    n = A.shape[0]
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    xs = spla.splu(A).solve(b)
+    lu = na.DeviceLU(A, expected_solves=100)
+    bd = torch.from_numpy(b).to("cuda")
+    torch.cuda.synchronize()
+    import time
+    time.sleep(0.05)                                   # the dense apex is built behind the first solves
+    res = {}
+    for fuse, gemv in (("0", "0"), ("1", "1")):
+        monkeypatch.setenv("NEP_ML_U0FUSE", fuse); monkeypatch.setenv("NEP_ML_GEMV1", gemv)
+        for _ in range(3):
+            x = lu.solve(bd).cpu().numpy()
+        res[fuse] = (x, lu.launches_last_solve())
+        assert np.linalg.norm(x - xs) <= 1e-9 * np.linalg.norm(xs)
+    assert np.linalg.norm(res["1"][0] - res["0"][0]) <= 1e-12 * np.linalg.norm(xs)
+    assert res["1"][1] == res["0"][1] - 1                # (the fused form is opt-in: measured no faster, DESIGN.md K5)
+    # through FactorizeLinSolver: refinement update fused into the last launch (nep_lu_solve_add), omega at round-off
+    nep = na.nep_gallery("gun_spmf_scaled")
+    ls = na.create_linsolver(na.FactorizeLinSolverCreator(), nep, 0.0)
+    xr = na.lin_solve(ls, b)
+    assert ls.last_omega < 10 * np.finfo(float).eps
+    assert np.linalg.norm(A @ xr - b) <= 1e-13 * np.linalg.norm(b) * np.sqrt(n)

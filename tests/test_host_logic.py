@@ -571,3 +571,21 @@ def test_k1_footprint_tiles_host_dryrun(case, monkeypatch):
         assert d["blocks"] == 0
         return
     assert d["max_rel_err"] <= 1e-14
+
+
+def test_julia_binding_symbols_exist():
+    """julia/NEPMI355X.jl (the reference-side binding of INTEGRATION.md, shipped as a file; Julia is not installed here, so it
+    cannot be executed): every `ccall` target is declared in include/nepmi355.h and exported by the library, and the file is
+    the code block of INTEGRATION.md verbatim (one source of truth)"""
+    jl = open(os.path.join(ROOT, "julia", "NEPMI355X.jl")).read()
+    ex = open(os.path.join(ROOT, "julia", "usage_examples.jl")).read()
+    names = set(re.findall(r"\(:(nep_[a-z0-9_]+)\s*,\s*LIB\)", jl + ex))
+    assert len(names) >= 25
+    hdr = open(os.path.join(ROOT, "include", "nepmi355.h")).read()
+    lib = ctypes.CDLL(na.LIB_PATH)
+    for nme in sorted(names):
+        assert re.search(r"\b%s\s*\(" % nme, hdr), "not in the header: " + nme
+        assert hasattr(lib, nme), "not exported: " + nme
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    first = md.split("```julia\n", 1)[1].split("\n```", 1)[0]
+    assert first.strip() in jl
