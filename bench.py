@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--no-wep-roofline", action="store_true", help="skip the waveguide-scale K1 roofline extra")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 (nleigs) summary")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 (waveguide tiar, n = 1e6) summary")
+    ap.add_argument("--no-cold", action="store_true", help="skip the fresh-process first-call measurement (about 3 s)")
+    ap.add_argument("--no-c5-oracle", action="store_true", help="skip the CPU oracle of the C5 twin (about 40 s)")
     ap.add_argument("--c5-nx", type=int, default=1003)
     ap.add_argument("--c5-nz", type=int, default=999)
     ap.add_argument("--only", default=None, choices=["orth", "k5", "mlincomb"],
@@ -120,6 +122,45 @@ def orth_roofline(na, n, k, reps=20):
             "kernels) at the fixed shape of iar step k=%d: rows=%d, block-triangular basis" % (k, rows),
             "algorithmic_bytes": byts, "ms_per_pass": ms, "launches_timed": reps, "achieved": byts / ms / 1e6,
             "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": byts / ms / 1e6 / HBM_PEAK_GBS}
+
+
+def orth_run_weighted(na, n, m, reps=3):
+    """K6 over the shapes of a WHOLE iar run (step k = 1 .. m: rows = n (k + 1), block-triangular basis), one nep_orth_dev call
+    per shape as the pipeline enqueues it (first pass + the gated second pass, which costs its launches also when the device
+    decision switches it off): sum of the algorithmic bytes of the first passes / sum of the HIP-event times.  The fixed-shape
+    `roofline` above is this sum's largest term; the steps below k ~ 35 are launch-bound."""
+    from nep_amd import dense
+    rows_max = n * (m + 1)
+    # columns of norm ~ 1 and almost orthogonal, w generic: the DGKS criterion of the first pass is not met, so the second
+    # pass is the gated-off one (as in 77 of the 100 steps of the headline run; the other 23 run it for real)
+    V = (torch.randn((m, rows_max), dtype=torch.float64, device="cuda") / np.sqrt(rows_max)).to(torch.complex128)
+    w = torch.randn(rows_max, dtype=torch.float64, device="cuda").to(torch.complex128)
+    out = torch.zeros(m + 2, dtype=torch.complex128, device="cuda")
+    tot_b = 0; tot_ms = 0.0; small_ms = 0.0
+    for k in range(1, m + 1):
+        rows = n * (k + 1)
+        active = torch.from_numpy((np.arange(1, k + 1) * n).astype(np.int64)).to("cuda")
+
+        def call():
+            dense.orthogonalize_and_normalize_dev(V, w, k, out, rows=rows, ldv=rows_max, active_dev=active, method=dense.DGKS)
+        ms = event_loop(call, reps, warm=1)
+        b = 2 * 16 * n * (k * (k + 1) // 2) + 3 * 16 * rows
+        tot_b += b; tot_ms += ms
+        if k <= 35:
+            small_ms += ms
+    del V
+    return {"algorithmic_bytes_first_passes": tot_b, "ms_all_steps": tot_ms, "ms_steps_1_to_35": small_ms,
+            "achieved": tot_b / tot_ms / 1e6, "frac": tot_b / tot_ms / 1e6 / HBM_PEAK_GBS,
+            "note": "sum over the %d step shapes of one iar run; DGKS as enqueued by the pipeline (gated second pass included)" % m}
+
+
+def _file_digest(path):
+    import hashlib
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:16]
+    except OSError:
+        return None
 
 
 def k5_roofline(na, nep, args, reps=100):
@@ -226,7 +267,29 @@ def c5_summary(na, args):
     t0 = time.perf_counter()
     lam, Q, res, info = bc.c5_device(na, nx=args.c5_nx, nz=args.c5_nz, solver="gmres", timers=tm)
     dt = time.perf_counter() - t0
-    return {"workload": "WEP JARLEBRING nx=%d nz=%d (n=%d) tiar sigma=-3-3.5i maxit=60 tol=1e-8, Schur complement + "
+    extra = {}
+    try:        # SURVEY.md section 8d rule (ii): every pair re-evaluated in FP64 on the HOST by the oracle's matrix-free operator
+        Qh = na.to_host(Q) if not isinstance(Q, np.ndarray) else Q
+        hres = bc.c5_host_residuals(args.c5_nx, args.c5_nz, lam, Qh)
+        extra["max_residual_host_fp64"] = max(hres + [0.0])
+    except Exception as e:
+        extra["max_residual_host_fp64"] = repr(e)[:200]
+    if not args.no_c5_oracle:
+        try:    # CPU baseline + parity of this configuration on its 303 x 299 twin (the oracle's assembled-matrix LU route does
+                # not finish in minutes at n = 1e6): device twin and oracle twin by eigenvalue
+            t1 = time.perf_counter()
+            lt, Qt, rest, it = bc.c5_device(na, 303, 299, solver="lu")
+            t_dev_twin = time.perf_counter() - t1
+            lo, Qo, t_or = bc.c5_oracle_twin(303, 299)
+            ok, worst = bc.match(lt, lo, 1e-8)
+            extra["cpu_baseline_twin"] = {"kind": "port", "workload": "the same tiar call on the 303 x 299 twin (n = 91 195), oracle: assembled M(sigma) + SuperLU",
+                                          "value": len(lo) / t_or, "unit": "eigenpairs/s", "eigenpairs": int(len(lo)), "seconds": t_or,
+                                          "device_twin_eigenpairs": int(len(lt)), "device_twin_seconds_incl_generation": t_dev_twin,
+                                          "device_twin_solve_s": it["solve_s"], "same_count": len(lo) == len(lt),
+                                          "eigenvalues_match_1e-8": bool(ok), "max_rel_eig_diff": worst}
+        except Exception as e:
+            extra["cpu_baseline_twin"] = {"error": repr(e)[:300]}
+    return {**extra, "workload": "WEP JARLEBRING nx=%d nz=%d (n=%d) tiar sigma=-3-3.5i maxit=60 tol=1e-8, Schur complement + "
                         "Sylvester-SMW preconditioned GMRES (the reference's solver for this problem; 37 x 41 regions, inner reltol 1e-9, one "
                         "refinement sweep)" % (args.c5_nx, args.c5_nz, info["n"]),
             "eigenpairs": int(len(lam)), "max_residual": max(res + [0.0]), "seconds_incl_generation": dt,
@@ -265,6 +328,22 @@ def wep_scale_roofline(na):
                               "frac": b / ms / 1e6 / HBM_PEAK_GBS}
         del QT
     return out
+
+
+def cold_call_summary():
+    """config C2 in a FRESH process (scripts/cold_call.py): what a first call costs -- context, upload, symbolic schedule,
+    host factorisation, allocator pools, the device-LU plan being built behind it -- and how many calls it takes to reach the
+    steady state the headline `value` is quoted at"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cold_call.py"), "6"], capture_output=True, text=True, timeout=300)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or not line:
+        return {"error": (r.stderr or r.stdout)[-300:]}
+    d = json.loads(line[-1])
+    calls = d["calls_ms"]; steady = min(calls[-2:])
+    d["cold_call_ms"] = calls[0]
+    d["calls_to_steady_state"] = next((i + 1 for i, c in enumerate(calls) if c <= 1.1 * steady), len(calls))
+    return d
 
 
 def _cpu_budget():
@@ -497,16 +576,30 @@ def main():
         try:
             rf = orth_roofline(na, nep.n, args.maxit)
             try:
-                pj = json.load(open(os.path.join(ROOT, "profiles", "pmc2", "r2_gun_traffic.json")))
+                # HBM bytes of the two kernels from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
+                # scripts/pmc_collect.sh, 2*FETCH + WRITE per the gfx950 note).  The file names the digest of csrc/orth.hip it
+                # was collected on: a kernel change makes `traffic_stale` true instead of going unnoticed.
+                tfile = os.path.join(ROOT, "profiles", "pmc2", "r3_gun_traffic.json")
+                if not os.path.exists(tfile):
+                    tfile = os.path.join(ROOT, "profiles", "pmc2", "r2_gun_traffic.json")
+                pj = json.load(open(tfile))
                 kb = 0.0
                 for name, d in pj.items():
-                    if (name.startswith("k_orth_dots") or name.startswith("k_orth_update")) and d.get("hbm_MB_per_launch", 0) > 100:
+                    if (name.startswith("k_orth_dots") or name.startswith("k_orth_update")) and isinstance(d, dict) and d.get("hbm_MB_per_launch", 0) > 100:
                         kb += d["hbm_MB_per_launch"] * 1024.0
                 rf["traffic"] = kb * 1024.0
-                rf["traffic_source"] = ("profiles/pmc2/r2_gun_traffic.json (round-2 code; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of "
-                                        "scripts/kernel_bench.py gun, same shape; 2*FETCH + WRITE per the gfx950 note)")
+                meta = pj.get("_meta", {})
+                cur = _file_digest(os.path.join(ROOT, "nonlineareigenproblems.jl_amd", "csrc", "orth.hip"))
+                rf["traffic_source"] = {"file": os.path.relpath(tfile, ROOT), "collected_at_commit": meta.get("commit"),
+                                        "orth_hip_digest_then": meta.get("orth_hip_digest"), "orth_hip_digest_now": cur,
+                                        "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE passes (scripts/pmc_collect.sh gun), 2*FETCH + WRITE"}
+                rf["traffic_stale"] = bool(meta.get("orth_hip_digest") != cur)
             except Exception:
                 rf["traffic"] = None
+            try:
+                rf["run_weighted"] = orth_run_weighted(na, nep.n, args.maxit)
+            except Exception as e:
+                rf["run_weighted"] = {"error": repr(e)[:200]}
             rf["share_of_step"] = out["phase_share"].get("orth")
             out["roofline"] = rf
         except Exception as e:
@@ -528,6 +621,14 @@ def main():
                 out["roofline_wep_scale"] = wep_scale_roofline(na)
             except Exception as e:
                 out["roofline_wep_scale"] = {"error": repr(e)[:200]}
+        if world == 1 and not args.no_cold:
+            try:
+                cc = cold_call_summary()
+                out["cold_call"] = cc
+                out["cold_call_ms"] = cc.get("cold_call_ms")
+                out["eigenpairs_per_s_cold"] = cc.get("eigenpairs_per_s_cold")
+            except Exception as e:
+                out["cold_call"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, dev=(dev_lam, dev_hist))
         if world == 1 and not args.no_c3:

@@ -134,6 +134,13 @@ int32_t nep_resid_batch(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
 int32_t nep_resid_batch_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
                             double* d_out, nep_stream stream);
 
+/* K2 for operators with an extra term on their last rows (WEP: dense corner block on the 2 nz boundary rows,
+ * src/gallery_extra/waveguide/Waveguide.jl:351-374): one pass gives d_out (device, 2k doubles) = squared column norms of the
+ * SPMF residual over rows [0, row0) and of Q over all rows, and dRT_tail ((n - row0) x k row-major, ld ldt) = the residual
+ * rows [row0, n); the caller adds its term to the tail and the tail's norms to d_out. */
+int32_t nep_resid_split_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq, int64_t row0,
+                            double* d_out, nep_cdouble* dRT_tail, int64_t ldt, nep_stream stream);
+
 /* same residuals, but the block R^T (row-major, row stride ldr >= k) is written instead of its norms --
  * for NEPs with an extra non-SPMF term (the WEP corner, src/gallery_extra/waveguide/Waveguide.jl:351-374)
  * whose contribution is added before the norms are taken.  Asynchronous. */
@@ -189,7 +196,8 @@ int32_t nep_gemm_ts_dev(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_
                         nep_cdouble* dY, int64_t ldy, int32_t y_rowmajor, nep_stream stream);
 
 /* plain dense complex GEMM, column-major:  C = alpha op(A) op(B) + beta C,  op = 0 none | 1 transpose | 2 conjugate
- * transpose; A: m x k after op, B: k x n after op.  Runs rocBLAS zgemm (loaded on first use).
+ * transpose; A: m x k after op, B: k x n after op.  The library's own LDS-tiled kernel (csrc/gemm.hip k_gemm_general; no
+ * vendor BLAS behind the ABI); C is not read when beta == 0.
  * replaces: the FFTW transforms of the waveguide Sylvester solver, src/gallery_extra/waveguide/waveguide_preconditioner.jl:
  *           120-219 (V!, Vh!, W, Wh as dense DFT / sine-transform matrices), and the small dense products of the
  *           Sylvester-SMW preconditioner (:221-421). */
@@ -197,7 +205,7 @@ int32_t nep_zgemm(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t 
                   const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb, nep_cdouble beta,
                   nep_cdouble* dC, int64_t ldc, nep_stream stream);
 
-/* real GEMM (rocBLAS dgemm), op = 0 none | 1 transpose.  A complex column-major m x n block is a real 2m x n block, so
+/* real GEMM (same kernel, float64), op = 0 none | 1 transpose.  A complex column-major m x n block is a real 2m x n block, so
  * products X * W with a real W (the sine transform W of waveguide_preconditioner.jl:176-199) run at half the flops. */
 int32_t nep_dgemm(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t k, double alpha,
                   const double* dA, int64_t lda, const double* dB, int64_t ldb, double beta,

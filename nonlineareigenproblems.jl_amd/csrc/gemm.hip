@@ -520,43 +520,89 @@ extern "C" int32_t nep_gemm_h_rm(const nep_cdouble* dWT, int64_t ldw, const nep_
 
 
 // ------------------------------------------------------------------------------------------------
-// Plain dense complex GEMM  C = alpha op(A) op(B) + beta C  (column-major) through rocBLAS: the DFT / sine-transform
-// products of the waveguide Sylvester solver (waveguide_preconditioner.jl:120-219 does them with FFTW; nz = 999 = 27*37 and
-// 2(nx+1) = 2008 = 8*251 are poor FFT lengths, while a 1000^3 complex GEMM is 8 GFLOP on the FP64 matrix cores).  These are
-// ordinary square library GEMMs, not a fused hot op, so the vendor library is the right tool; it is loaded on first use
-// (dlopen) so that the rest of the library does not depend on it.
-#include <dlfcn.h>
+// Plain dense GEMM  C = alpha op(A) op(B) + beta C  (column-major; op = none / transpose / conjugate transpose), complex128
+// (nep_zgemm) and float64 (nep_dgemm).  Utility entry points: the dense-transform form of the waveguide Sylvester solver for
+// shapes the prime-factor DFT + tridiagonal-scan kernels of csrc/wep.hip do not take (nx > 2048), region means / expansions
+// of its A/B reference path, and hosts that want a dense product next to their device blocks.  Until round 3 these two called
+// rocBLAS; they are this library's own kernel now, so that no vendor GEMM sits behind the C ABI.
+// Kernel: 64 x 64 tile of C per workgroup (256 threads, 4 x 4 outputs per thread), 16-deep panels of op(A) and op(B) staged in
+// LDS with the transposition / conjugation applied on the way in, FP64 FMAs on the vector pipe (FP64 MFMA and FP64 vector FMA
+// have the same peak on gfx950; the tall-skinny MFMA kernels above serve the hot shapes).
 namespace {
-typedef void* rb_handle;
-typedef int (*rb_create_t)(rb_handle*);
-typedef int (*rb_set_stream_t)(rb_handle, hipStream_t);
-typedef int (*rb_zgemm_t)(rb_handle, int, int, int, int, int, const void*, const void*, int, const void*, int, const void*,
-                          void*, int);
-typedef rb_zgemm_t rb_dgemm_t;
-struct RocblasApi {
-    void* lib = nullptr;
-    rb_create_t create = nullptr;
-    rb_set_stream_t set_stream = nullptr;
-    rb_zgemm_t zgemm = nullptr;
-    rb_dgemm_t dgemm = nullptr;
-    rb_handle handle = nullptr;
-    bool tried = false;
-};
-static RocblasApi g_rb;
-static int rocblas_ready() {
-    if (g_rb.handle) return NEP_OK;
-    if (g_rb.tried) { nep_set_error("rocBLAS is not available (librocblas.so could not be loaded)"); return NEP_ERR_HIP; }
-    g_rb.tried = true;
-    const char* names[] = {"librocblas.so", "librocblas.so.5", "librocblas.so.4", "/opt/rocm/lib/librocblas.so"};
-    for (const char* nm : names) { g_rb.lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (g_rb.lib) break; }
-    if (!g_rb.lib) { nep_set_error("dlopen(librocblas.so): %s", dlerror()); return NEP_ERR_HIP; }
-    g_rb.create = (rb_create_t)dlsym(g_rb.lib, "rocblas_create_handle");
-    g_rb.set_stream = (rb_set_stream_t)dlsym(g_rb.lib, "rocblas_set_stream");
-    g_rb.zgemm = (rb_zgemm_t)dlsym(g_rb.lib, "rocblas_zgemm");
-    g_rb.dgemm = (rb_dgemm_t)dlsym(g_rb.lib, "rocblas_dgemm");
-    if (!g_rb.create || !g_rb.set_stream || !g_rb.zgemm || !g_rb.dgemm) { nep_set_error("rocBLAS symbols missing"); return NEP_ERR_HIP; }
-    if (g_rb.create(&g_rb.handle) != 0 || !g_rb.handle) { g_rb.handle = nullptr; nep_set_error("rocblas_create_handle failed"); return NEP_ERR_HIP; }
-    return NEP_OK;
+__device__ __forceinline__ double gconj(double v, bool) { return v; }
+__device__ __forceinline__ cplx gconj(cplx v, bool c) { return c ? cmake(v.x, -v.y) : v; }
+__device__ __forceinline__ double gzero(double*) { return 0.0; }
+__device__ __forceinline__ cplx gzero(cplx*) { return cmake(0.0, 0.0); }
+__device__ __forceinline__ void gfma(double& acc, double a, double b) { acc = fma(a, b, acc); }
+__device__ __forceinline__ void gfma(cplx& acc, cplx a, cplx b) { cfma(acc, a, b); }
+__device__ __forceinline__ double gmul(double a, double b) { return a * b; }
+__device__ __forceinline__ cplx gmul(cplx a, cplx b) { return cmul(a, b); }
+__device__ __forceinline__ double gadd(double a, double b) { return a + b; }
+__device__ __forceinline__ cplx gadd(cplx a, cplx b) { return cadd(a, b); }
+__device__ __forceinline__ bool gnonzero(double v) { return v != 0.0; }
+__device__ __forceinline__ bool gnonzero(cplx v) { return v.x != 0.0 || v.y != 0.0; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gemm_general(int ta, int tb, int m, int n, int k, T alpha, const T* __restrict__ A,
+                                                      int64_t lda, const T* __restrict__ B, int64_t ldb, T beta, T* __restrict__ C,
+                                                      int64_t ldc) {
+    constexpr int TM = 64, TN = 64, TK = 16;
+    __shared__ T As[TK][TM + 1];          // As[kk][i] = op(A)[i0 + i, k0 + kk]
+    __shared__ T Bs[TK][TN + 1];          // Bs[kk][j] = op(B)[k0 + kk, j0 + j]
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int i0 = blockIdx.x * TM, j0 = blockIdx.y * TN;
+    T acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = gzero((T*)nullptr);
+    for (int k0 = 0; k0 < k; k0 += TK) {
+        // stage: 64 x 16 elements each, 4 per thread; the fast index follows the operand's storage order
+        for (int t = threadIdx.x; t < TM * TK; t += 256) {
+            int i, kk;
+            if (ta == 0) { i = t % TM; kk = t / TM; } else { kk = t % TK; i = t / TK; }
+            const int gi = i0 + i, gk = k0 + kk;
+            T v = gzero((T*)nullptr);
+            if (gi < m && gk < k) v = ta == 0 ? A[gi + (int64_t)gk * lda] : gconj(A[gk + (int64_t)gi * lda], ta == 2);
+            As[kk][i] = v;
+        }
+        for (int t = threadIdx.x; t < TN * TK; t += 256) {
+            int j, kk;
+            if (tb == 0) { kk = t % TK; j = t / TK; } else { j = t % TN; kk = t / TN; }
+            const int gj = j0 + j, gk = k0 + kk;
+            T v = gzero((T*)nullptr);
+            if (gj < n && gk < k) v = tb == 0 ? B[gk + (int64_t)gj * ldb] : gconj(B[gj + (int64_t)gk * ldb], tb == 2);
+            Bs[kk][j] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TK; ++kk) {
+            T av[4], bv[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) av[a] = As[kk][tx + 16 * a];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) bv[b] = Bs[kk][ty + 16 * b];
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) gfma(acc[a][b], av[a], bv[b]);
+        }
+        __syncthreads();
+    }
+    const bool use_c = gnonzero(beta);
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int gj = j0 + ty + 16 * b;
+        if (gj >= n) continue;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int gi = i0 + tx + 16 * a;
+            if (gi >= m) continue;
+            T v = gmul(alpha, acc[a][b]);
+            if (use_c) v = gadd(v, gmul(beta, C[gi + (int64_t)gj * ldc]));       // C is not read when beta == 0 (may hold NaN)
+            C[gi + (int64_t)gj * ldc] = v;
+        }
+    }
 }
 }  // namespace
 
@@ -566,28 +612,23 @@ extern "C" int32_t nep_zgemm(int32_t transa, int32_t transb, int32_t m, int32_t 
     ARGCHK(dA && dB && dC && m >= 1 && n >= 1 && k >= 1);
     ARGCHK(transa >= 0 && transa <= 2 && transb >= 0 && transb <= 2);
     ARGCHK(lda >= (transa ? k : m) && ldb >= (transb ? n : k) && ldc >= m);
-    int rc = rocblas_ready();
-    if (rc) return rc;
-    if (g_rb.set_stream(g_rb.handle, as_stream(stream)) != 0) { nep_set_error("rocblas_set_stream failed"); return NEP_ERR_HIP; }
-    static const int op[3] = {111, 112, 113};      // rocblas_operation_none / transpose / conjugate_transpose
-    const int st = g_rb.zgemm(g_rb.handle, op[transa], op[transb], m, n, k, &alpha, dA, (int)lda, dB, (int)ldb, &beta, dC, (int)ldc);
-    if (st != 0) { nep_set_error("rocblas_zgemm failed with status %d", st); return NEP_ERR_HIP; }
+    cplx al, be; al.x = alpha.re; al.y = alpha.im; be.x = beta.re; be.y = beta.im;
+    hipLaunchKernelGGL(k_gemm_general<cplx>, dim3((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64)), dim3(256), 0, as_stream(stream),
+                       (int)transa, (int)transb, (int)m, (int)n, (int)k, al, (const cplx*)dA, lda, (const cplx*)dB, ldb, be, (cplx*)dC, ldc);
+    LAUNCHCHK();
     return NEP_OK;
 }
 
-// real counterpart (rocBLAS dgemm): a complex column-major m x n block IS a real 2m x n block (re / im interleaved along the
-// rows), so X * W with a REAL W -- the sine transform of the waveguide Sylvester solver -- costs half the flops of a zgemm.
+// real counterpart: a complex column-major m x n block IS a real 2m x n block (re / im interleaved along the rows), so X * W
+// with a REAL W -- the sine transform of the waveguide Sylvester solver -- costs half the flops of a complex product.
 extern "C" int32_t nep_dgemm(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t k, double alpha,
                              const double* dA, int64_t lda, const double* dB, int64_t ldb, double beta,
                              double* dC, int64_t ldc, nep_stream stream) {
     ARGCHK(dA && dB && dC && m >= 1 && n >= 1 && k >= 1);
     ARGCHK(transa >= 0 && transa <= 1 && transb >= 0 && transb <= 1);
     ARGCHK(lda >= (transa ? k : m) && ldb >= (transb ? n : k) && ldc >= m);
-    int rc = rocblas_ready();
-    if (rc) return rc;
-    if (g_rb.set_stream(g_rb.handle, as_stream(stream)) != 0) { nep_set_error("rocblas_set_stream failed"); return NEP_ERR_HIP; }
-    static const int op[2] = {111, 112};
-    const int st = g_rb.dgemm(g_rb.handle, op[transa], op[transb], m, n, k, &alpha, dA, (int)lda, dB, (int)ldb, &beta, dC, (int)ldc);
-    if (st != 0) { nep_set_error("rocblas_dgemm failed with status %d", st); return NEP_ERR_HIP; }
+    hipLaunchKernelGGL(k_gemm_general<double>, dim3((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64)), dim3(256), 0, as_stream(stream),
+                       (int)transa, (int)transb, (int)m, (int)n, (int)k, alpha, dA, lda, dB, ldb, beta, dC, ldc);
+    LAUNCHCHK();
     return NEP_OK;
 }

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(256) void k_spmm_rm(const int32_t* __restrict__ row
                                                  const VT* __restrict__ vals, int64_t n, int mt, int k,
                                                  const cplx* __restrict__ F, const cplx* __restrict__ XT,
                                                  int64_t ldx, int xoff, cplx* __restrict__ ZT, int64_t ldz,
-                                                 double* __restrict__ partial /* [grid][2][k] or null */) {
+                                                 double* __restrict__ partial /* [grid][2][k] or null */, int64_t split_row) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* Fs = (cplx*)smem_raw;                       // mt*k coefficients (if F)
     double* red = (double*)(Fs + (F ? mt * k : 0));   // [4][2][NCH*64]
@@ -340,9 +340,12 @@ __global__ __launch_bounds__(256) void k_spmm_rm(const int32_t* __restrict__ row
         for (int ch = 0; ch < NCH; ++ch) {
             const int s = lane + 64 * ch;
             if (s < k) {
-                if (ZT) ZT[row * ldz + s] = acc[ch];
+                // split_row >= 0: rows below it only enter the norms, rows from it on are only written (row - split_row)
+                const bool wr = split_row < 0 ? ZT != nullptr : row >= split_row;
+                const bool nr = split_row < 0 || row < split_row;
+                if (wr) ZT[(split_row < 0 ? row : row - split_row) * ldz + s] = acc[ch];
                 if (partial) {
-                    rn[ch] = fma(acc[ch].x, acc[ch].x, fma(acc[ch].y, acc[ch].y, rn[ch]));
+                    if (nr) rn[ch] = fma(acc[ch].x, acc[ch].x, fma(acc[ch].y, acc[ch].y, rn[ch]));
                     if (xoff == 0) {
                         const cplx q = XT[row * ldx + s];
                         qn[ch] = fma(q.x, q.x, fma(q.y, q.y, qn[ch]));
@@ -600,14 +603,14 @@ static int launch_vc(const nep_spmf* s, int k, const cplx* dC, int64_t ldc, cons
 
 template <typename VT>
 static int launch_spmm(const nep_spmf* s, int k, const cplx* dF, const cplx* XT, int64_t ldx, int xoff,
-                       cplx* ZT, int64_t ldz, double* partial, int grid, hipStream_t st) {
+                       cplx* ZT, int64_t ldz, double* partial, int grid, hipStream_t st, int64_t split_row = -1) {
     const int nch = (k + 63) / 64;
     const size_t shm = (dF ? (size_t)s->mt * k * sizeof(cplx) : 0) + (size_t)4 * 2 * nch * 64 * sizeof(double);
     const VT* vals = (const VT*)s->d_vals;
 #define SPMM_CASE(N)                                                                                   \
     case N:                                                                                            \
         hipLaunchKernelGGL((k_spmm_rm<N, VT>), dim3(grid), dim3(256), shm, st, s->d_rowptr, s->d_idx,  \
-                           vals, s->n, s->mt, k, dF, XT, ldx, xoff, ZT, ldz, partial);                 \
+                           vals, s->n, s->mt, k, dF, XT, ldx, xoff, ZT, ldz, partial, split_row);      \
         break;
     switch (nch) {
         SPMM_CASE(1) SPMM_CASE(2) SPMM_CASE(3) SPMM_CASE(4)
@@ -944,7 +947,8 @@ static inline int32_t resid_panel_width(int32_t mt) { return std::min(256, std::
 
 // shared body: d_out != NULL -> squared norms stay on the device (no synchronisation); else host results
 static int resid_panels(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
-                        double* d_out, double* h_rnorm, double* h_qnorm, hipStream_t st) {
+                        double* d_out, double* h_rnorm, double* h_qnorm, hipStream_t st, int64_t split_row = -1,
+                        cplx* tail = nullptr, int64_t ldt = 0) {
     // panels of at most 256 Ritz vectors per pass over the matrix (fewer when the mt x kk coefficient block would not
     // fit the 48 KiB LDS budget of k_spmm_rm)
     const int32_t P = resid_panel_width(s->mt);
@@ -962,12 +966,13 @@ static int resid_panels(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
         double* partial = (double*)s->part.dptr;
         double* outd = d_out ? d_out + 2 * (size_t)j0 : partial + (size_t)grid * 2 * kk;
         const cplx* Q = (const cplx*)dQT + j0;
+        cplx* T = tail ? tail + j0 : nullptr;
         if (tiled)
-            rc = nep_tiles_resid(s->tiles, kk, (const cplx*)s->coef.dptr, Q, ldq, nullptr, 0, partial, st);
+            rc = nep_tiles_resid(s->tiles, kk, (const cplx*)s->coef.dptr, Q, ldq, T, ldt, partial, split_row, st);
         else if (s->valbytes == 8)
-            rc = launch_spmm<double>(s, kk, (const cplx*)s->coef.dptr, Q, ldq, 0, nullptr, 0, partial, grid, st);
+            rc = launch_spmm<double>(s, kk, (const cplx*)s->coef.dptr, Q, ldq, 0, T, ldt, partial, grid, st, split_row);
         else
-            rc = launch_spmm<cplx>(s, kk, (const cplx*)s->coef.dptr, Q, ldq, 0, nullptr, 0, partial, grid, st);
+            rc = launch_spmm<cplx>(s, kk, (const cplx*)s->coef.dptr, Q, ldq, 0, T, ldt, partial, grid, st, split_row);
         if (rc) return rc;
         hipLaunchKernelGGL(k_sum_partials_d, dim3(2 * kk), dim3(256), 0, st, grid, 2 * kk, partial, outd);
         LAUNCHCHK();
@@ -995,6 +1000,18 @@ int32_t nep_resid_batch_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, const
     return resid_panels(s, k, hF, dQT, ldq, d_out, nullptr, nullptr, as_stream(stream));
 }
 
+// K2 for operators with extra terms on their LAST rows (the waveguide's dense corner block on its 2 nz boundary rows): one pass
+// over the matrices gives the squared column norms of the residual over the rows [0, row0) and of Q over all rows (d_out,
+// 2k doubles, device), and the residual ROWS [row0, n) themselves (dRT_tail, (n - row0) x k row-major) -- the caller adds its
+// extra term to that small block and its norms to d_out.  Neither the n x k residual block nor a second pass over Q touches
+// HBM (nep_resid_block + two column-norm kernels moved four times the bytes of Q).
+int32_t nep_resid_split_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq, int64_t row0,
+                            double* d_out, nep_cdouble* dRT_tail, int64_t ldt, nep_stream stream) {
+    ARGCHK(s && hF && dQT && d_out && dRT_tail);
+    ARGCHK(k >= 1 && ldq >= k && ldt >= k && row0 >= 0 && row0 <= s->n);
+    return resid_panels(s, k, hF, dQT, ldq, d_out, nullptr, nullptr, as_stream(stream), row0, (cplx*)dRT_tail, ldt);
+}
+
 int32_t nep_resid_block(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
                         nep_cdouble* dRT, int64_t ldr, nep_stream stream) {
     ARGCHK(s && hF && dQT && dRT);
@@ -1012,7 +1029,7 @@ int32_t nep_resid_block(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
         const cplx* F = (const cplx*)s->coef.dptr + (size_t)j0 * s->mt;
         const cplx* Q = (const cplx*)dQT + j0;
         cplx* R = (cplx*)dRT + j0;
-        if (use_tiles_k2(s, kk)) rc = nep_tiles_resid(s->tiles, kk, F, Q, ldq, R, ldr, nullptr, st);
+        if (use_tiles_k2(s, kk)) rc = nep_tiles_resid(s->tiles, kk, F, Q, ldq, R, ldr, nullptr, -1, st);
         else if (s->valbytes == 8) rc = launch_spmm<double>(s, kk, F, Q, ldq, 0, R, ldr, nullptr, grid, st);
         else rc = launch_spmm<cplx>(s, kk, F, Q, ldq, 0, R, ldr, nullptr, grid, st);
         if (rc) return rc;

@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void k_tile_resid(const TileDesc* __restrict__
                                                     const uint16_t* __restrict__ eidx, const VT* __restrict__ eval,
                                                     const cplx* __restrict__ QT, int64_t ldq, int k, const cplx* __restrict__ F,
                                                     int mt, int fcap, int lbits, cplx* __restrict__ ZT, int64_t ldz,
-                                                    double* __restrict__ partial, int swz) {
+                                                    double* __restrict__ partial, int swz, int64_t split_row) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx* Qt = (cplx*)smem;                                 // [fcap][PS]
     cplx* Fs = Qt + (size_t)fcap * PS;                      // [k][mt]  (F[t + s * mt])
@@ -294,8 +294,10 @@ __global__ __launch_bounds__(256) void k_tile_resid(const TileDesc* __restrict__
 #pragma unroll
                         for (int tt = 0; tt < MT; ++tt)
                             if (tt < mt) cfma(r, Fs[(size_t)(p0 + s) * mt + tt], acc[tt][s]);
-                        if (ZT) ZT[row * ldz + p0 + s] = r;
-                        rn[s] = fma(r.x, r.x, fma(r.y, r.y, rn[s]));
+                        // split_row >= 0: rows below it only enter the norms, rows from it on are only written (row - split_row)
+                        if (split_row < 0) { if (ZT) ZT[row * ldz + p0 + s] = r; rn[s] = fma(r.x, r.x, fma(r.y, r.y, rn[s])); }
+                        else if (row < split_row) rn[s] = fma(r.x, r.x, fma(r.y, r.y, rn[s]));
+                        else ZT[(row - split_row) * ldz + p0 + s] = r;
                     }
                 }
             }
@@ -631,7 +633,7 @@ bool nep_tiles_resid_ok(const NepTiles* t, int k) {
 
 // partial: [nblk][2][k] doubles (|r|^2 then |q|^2 per column), or NULL; ZT (n x k row-major, ld ldz) or NULL
 int nep_tiles_resid(const NepTiles* t, int k, const cplx* dF, const cplx* QT, int64_t ldq, cplx* ZT, int64_t ldz, double* partial,
-                    hipStream_t st) {
+                    int64_t split_row, hipStream_t st) {
     const int ps = nep_tiles_resid_ps(t, k);
     const size_t shm = nep_tiles_resid_shmem(t, k, ps);
     if (t->mt > 4 || shm > 160 * 1024) { nep_set_error("tiled K2: mt = %d, k = %d not supported", t->mt, k); return NEP_ERR_ARG; }
@@ -648,7 +650,7 @@ int nep_tiles_resid(const NepTiles* t, int k, const cplx* dF, const cplx* QT, in
         }                                                                                                                      \
         hipLaunchKernelGGL((k_tile_resid<VT, M, P, NTF>), dim3((unsigned)t->nblk), dim3(256), shm, st, (const TileDesc*)t->d_desc,  \
                            (const uint32_t*)t->d_fp, (const uint16_t*)t->d_eidx, (const VT*)t->d_eval, QT, ldq, k, dF, t->mt,       \
-                           t->fcap, t->lbits, ZT, ldz, partial, swz);                                                          \
+                           t->fcap, t->lbits, ZT, ldz, partial, swz, split_row);                                               \
     } while (0)
 #define RL_M(VT, P, NTF) do { switch (t->mt) { case 1: RL(VT, 1, P, NTF); break; case 2: RL(VT, 2, P, NTF); break; case 3: RL(VT, 3, P, NTF); break; default: RL(VT, 4, P, NTF); break; } } while (0)
 #define RL_P(VT, NTF) do { if (ps == 8) RL_M(VT, 8, NTF); else RL_M(VT, 4, NTF); } while (0)

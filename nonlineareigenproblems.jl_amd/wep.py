@@ -10,6 +10,8 @@ rank-one nz x nz blocks (2 nz^3 = 2e9 non-zeros at nz = 999).  Here the NEP is
 i.e. three big REAL sparse matrices in one stacked CSR (the HBM-bound part) plus a factored corner term applied as
 two small dense products with Rm (nz x nz, the scaled DFT matrix of Waveguide.jl:53-65).
 """
+import os
+
 import numpy as np
 import scipy.sparse as sp
 
@@ -289,6 +291,11 @@ class WEP(AbstractSPMF):
         return sp.csc_matrix(M + Cn)
 
     def resid_norms(self, lams, QT):
+        """(||M(lam_s) q_s||, ||q_s||, F) for the k columns of the row-major block QT.  ONE pass over the three sparse terms
+        (nep_resid_split_dev) gives the squared norms of the SPMF residual over the N interior rows, the squared norms of Q
+        and the residual rows of the 2 nz boundary unknowns; the dense corner term (Waveguide.jl:351-374) is added to that
+        2 nz x k block only.  (Until round 3 the whole n x k residual block was written, the corner added, and two column-norm
+        kernels read both blocks again: four times the bytes of Q per check.  NEP_WEP_RESID_SPLIT=0 keeps that form.)"""
         la = np.asarray(lams, dtype=np.complex128)
         k = len(la)
         F = np.empty((3, k), dtype=np.complex128, order="F")
@@ -297,8 +304,17 @@ class WEP(AbstractSPMF):
         n, nz, N = self.n, self.nz, self.N
         ldq = QT.shape[1]
         st = stream_ptr()
-        RT = torch.empty((n, k), dtype=CDT, device="cuda")
-        check(lib.nep_resid_block(self.dev.h, k, hptr(F), c_vp(QT.data_ptr()), ldq, c_vp(RT.data_ptr()), k, st))
+        split = os.environ.get("NEP_WEP_RESID_SPLIT", "1") != "0"
+        if split:
+            out = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+            RT = torch.empty((2 * nz, k), dtype=CDT, device="cuda")                 # residual rows N .. n-1 only
+            check(lib.nep_resid_split_dev(self.dev.h, k, hptr(F), c_vp(QT.data_ptr()), ldq, N, c_vp(out.data_ptr()),
+                                          c_vp(RT.data_ptr()), k, st))
+            tail0 = 0
+        else:
+            RT = torch.empty((n, k), dtype=CDT, device="cuda")
+            check(lib.nep_resid_block(self.dev.h, k, hptr(F), c_vp(QT.data_ptr()), ldq, c_vp(RT.data_ptr()), k, st))
+            tail0 = N
         # corner: R[N:, s] += Rfull diag(s(lam_s)) Rfull^H Q[N:, s] / nz
         Rm, RmH = self._corner_dev()
         S = np.column_stack([_corner_derivs(self.wd, l, 1)[:, 0] for l in la]) / nz      # 2nz x k
@@ -312,10 +328,15 @@ class WEP(AbstractSPMF):
             check(lib.nep_hadamard(nz, k, c_vp(P.data_ptr()), nz, c_vp(Sd.data_ptr() + 16 * half * nz), 2 * nz, st))
             check(lib.nep_gemm_ts_dev(c_vp(Rm.data_ptr()), nz, nz, nz, c_vp(P.data_ptr()), nz, 0, k,
                                       c_vp(Y.data_ptr()), k, 1, st))
-            check(lib.nep_axpy(nz * k, _lib.cd(1.0), c_vp(Y.data_ptr()), c_vp(RT.data_ptr() + 16 * row0 * k), st))
+            check(lib.nep_axpy(nz * k, _lib.cd(1.0), c_vp(Y.data_ptr()), c_vp(RT.data_ptr() + 16 * (tail0 + half * nz) * k), st))
         rn = np.empty(k); qn = np.empty(k)
-        check(lib.nep_rowmajor_colnorms(n, k, c_vp(RT.data_ptr()), k, hptr(rn), st))
-        check(lib.nep_rowmajor_colnorms(n, k, c_vp(QT.data_ptr()), ldq, hptr(qn), st))
+        if split:
+            check(lib.nep_rowmajor_colnorms(2 * nz, k, c_vp(RT.data_ptr()), k, hptr(rn), st))      # (synchronises)
+            o = out.cpu().numpy()
+            rn = np.sqrt(o[:k] + rn ** 2); qn = np.sqrt(o[k:])
+        else:
+            check(lib.nep_rowmajor_colnorms(n, k, c_vp(RT.data_ptr()), k, hptr(rn), st))
+            check(lib.nep_rowmajor_colnorms(n, k, c_vp(QT.data_ptr()), ldq, hptr(qn), st))
         return rn, qn, F
 
     def fro_norms(self):

@@ -250,7 +250,7 @@ class WEPGMRESLinSolver(LinSolver):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                vin.zero_(); step()                      # warm-up outside the capture (rocBLAS handle, lazy kernel loads)
+                vin.zero_(); step()                      # warm-up outside the capture (lazy kernel loads)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
@@ -321,7 +321,8 @@ class WEPPreconditioner:
         w = np.zeros(nz, dtype=complex); w[1] = 1; w[nz - 1] = -1; w *= self.sigma / wd.hz
         D = np.fft.fft(v + w) + (self.sigma ** 2 + k_bar)
         # Sylvester solve: prime-factor DFT along z + one tridiagonal solve per z-mode along x (csrc/wep.hip); the dense
-        # transform matrices of round 1 (rocBLAS GEMMs) remain as the A/B reference behind NEP_WEP_GEMM=1
+        # transform matrices of round 1 (dense GEMMs, since round 3 the library's own k_gemm_general) serve the shapes those
+        # kernels do not take (nx > 2048) and remain the A/B reference behind NEP_WEP_GEMM=1
         self.sylv = None
         self.dd1 = (2 / wd.hx) / wd.hx ** 2; self.dd2 = (-1 / (2 * wd.hx)) / wd.hx ** 2
         if not os.environ.get("NEP_WEP_GEMM"):

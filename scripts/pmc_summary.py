@@ -28,8 +28,22 @@ def main():
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             e["hbm_MB_per_launch"] = (2 * e["FETCH_SIZE"]["avg_KB"] + e["WRITE_SIZE"]["avg_KB"]) / 1024.0
         out[key] = e
+    # provenance: digests of the kernel sources the counters were collected on (bench.py compares them with the tree it runs
+    # in and flags a stale file); the commit hash is added when the file is copied into profiles/ (the GPU box has no .git)
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    meta = {}
+    for src in ("orth.hip", "spmv.hip", "spmv_tile.hip", "trsv_ml.hip", "gemm.hip"):
+        try:
+            meta[src.replace(".", "_") + "_digest"] = hashlib.sha256(open(os.path.join(root, "nonlineareigenproblems.jl_amd", "csrc", src), "rb").read()).hexdigest()[:16]
+        except OSError:
+            pass
+    meta["commit"] = os.environ.get("NEP_PROFILE_COMMIT")
+    out["_meta"] = meta
     json.dump(out, open(os.path.join(d, "%s_traffic.json" % tag), "w"), indent=1)
     for key, e in out.items():
+        if key == "_meta":
+            continue
         print("%-60s %s" % (key[:60], {k: (round(v["avg_KB"] / 1024, 2) if isinstance(v, dict) else round(v, 2)) for k, v in e.items()}))
 
 

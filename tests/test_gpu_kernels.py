@@ -588,7 +588,7 @@ def test_many_terms(na, mt):
 
 @pytest.mark.parametrize("ta,tb", [(0, 0), (2, 0), (0, 1), (1, 2)])
 def test_zgemm_vs_numpy(na, ta, tb):
-    """nep_zgemm (rocBLAS zgemm behind the C ABI): C = alpha op(A) op(B) + beta C with none / transpose / conjugate
+    """nep_zgemm (the library's own LDS-tiled GEMM behind the C ABI, csrc/gemm.hip k_gemm_general; no vendor BLAS): C = alpha op(A) op(B) + beta C with none / transpose / conjugate
     transpose, leading dimensions larger than the matrices; 1e-13 relative (k = 77 products per entry)"""
     import torch
     from nep_amd.wep_linsolvers import zgemm
@@ -944,3 +944,27 @@ def test_lu_fused_last_launch_and_apex_gemv(na, monkeypatch):
     xr = na.lin_solve(ls, b)
     assert ls.last_omega < 10 * np.finfo(float).eps
     assert np.linalg.norm(A @ xr - b) <= 1e-13 * np.linalg.norm(b) * np.sqrt(n)
+
+
+@pytest.mark.parametrize("m,n,k", [(130, 70, 33), (64, 64, 16), (1, 1, 1), (200, 3, 129)])
+def test_own_gemm_tile_edges_and_real(na, m, n, k):
+    """k_gemm_general at tile edges (sizes that are, straddle, or fall short of the 64 x 64 x 16 tiles), beta = 0 with NaN in
+    C (C must not be read), and the float64 instantiation behind nep_dgemm"""
+    import torch
+    from nep_amd._lib import lib, check, c_vp, cd
+    from nep_amd.nep import stream_ptr
+    rng = np.random.default_rng(m + 7 * n + 13 * k)
+    A = rng.standard_normal((k, m)) + 1j * rng.standard_normal((k, m))           # used as A^H
+    B = rng.standard_normal((k, n)) + 1j * rng.standard_normal((k, n))
+    Ad, Bd = na.to_dev(A), na.to_dev(B)                                          # column-major k x m, k x n
+    Cd = torch.full((n, m), float("nan"), dtype=torch.complex128, device="cuda")
+    check(lib.nep_zgemm(2, 0, m, n, k, cd(1.0), c_vp(Ad.data_ptr()), k, c_vp(Bd.data_ptr()), k, cd(0.0), c_vp(Cd.data_ptr()), m, stream_ptr()))
+    ref = A.conj().T @ B
+    assert np.linalg.norm(Cd.cpu().numpy().T - ref) <= 1e-13 * np.linalg.norm(ref)
+    Ar = rng.standard_normal((m, k)); Br = rng.standard_normal((n, k)); C0 = rng.standard_normal((m, n))
+    Ard = torch.from_numpy(np.asfortranarray(Ar).T.copy()).to("cuda")            # column-major m x k
+    Brd = torch.from_numpy(np.asfortranarray(Br).T.copy()).to("cuda")            # column-major n x k, used transposed
+    Crd = torch.from_numpy(np.asfortranarray(C0).T.copy()).to("cuda")
+    check(lib.nep_dgemm(0, 1, m, n, k, 0.5, c_vp(Ard.data_ptr()), m, c_vp(Brd.data_ptr()), n, -2.0, c_vp(Crd.data_ptr()), m, stream_ptr()))
+    refr = 0.5 * Ar @ Br.T - 2.0 * C0
+    assert np.linalg.norm(Crd.cpu().numpy().T - refr) <= 1e-13 * np.linalg.norm(refr)

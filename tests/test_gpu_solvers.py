@@ -1200,3 +1200,29 @@ def test_physical_gun_known_answers(na):
     lam_r1, X, res = na.nleigs(nep, Sigma, Xi=Xi, maxit=100, v=v0, leja=0, nodes=nodes, reusefact=2,
                                errmeasure=na.StandardSPMFErrmeasure(nep))[:3]
     assert len(lam_r1) == 21
+
+
+@pytest.mark.parametrize("nx,nz", [(109, 105), (303, 299)])
+def test_wep_residual_batch_split_vs_oracle(na, nx, nz, monkeypatch):
+    """ResidualErrmeasure on the waveguide problem for a batch of GENERIC pairs (residuals of order one, k below and above
+    the panel widths of the tiled K2 kernel): the one-pass form (nep_resid_split_dev: norms over the interior rows + the
+    2 nz boundary rows of the residual, corner term added there) equals the full-block form (NEP_WEP_RESID_SPLIT=0) and the
+    oracle's matrix-free operator to 1e-12"""
+    import torch
+    from oracle import wep as ow
+    nep = na.nep_gallery("WEP", nx=nx, nz=nz, benchmark_problem="JARLEBRING"); n = nep.n
+    o = ow.WEP_FD(nx, nz, "JARLEBRING")
+    rng = np.random.default_rng(nx)
+    for k in (1, 5, 13):
+        Q = rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k))
+        lams = (-2.7 - 3.1j) + 0.3 * (rng.standard_normal(k) + 1j * rng.standard_normal(k))
+        ref = np.array([np.linalg.norm(o._mlincomb(complex(lams[s]), Q[:, s:s + 1], np.ones(1, dtype=complex))) / np.linalg.norm(Q[:, s])
+                        for s in range(k)])
+        QT = torch.from_numpy(np.ascontiguousarray(Q)).to("cuda")
+        E = na.ResidualErrmeasure(nep)
+        got = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("NEP_WEP_RESID_SPLIT", flag)
+            got[flag] = np.asarray(E.batch(list(lams), QT))
+            assert np.allclose(got[flag], ref, rtol=1e-12), (flag, k)
+        assert np.allclose(got["1"], got["0"], rtol=1e-13)

@@ -589,3 +589,13 @@ def test_julia_binding_symbols_exist():
     md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     first = md.split("```julia\n", 1)[1].split("\n```", 1)[0]
     assert first.strip() in jl
+
+
+def test_no_vendor_blas_or_fft_behind_the_abi():
+    """the product's library carries no reference to rocBLAS / hipBLAS / rocFFT (until round 3 nep_zgemm / nep_dgemm dlopen'ed
+    rocBLAS for the dense-transform fallback of the waveguide preconditioner): every GEMM / DFT behind the C ABI is this
+    library's own kernel.  (RCCL is the one vendor library it loads: the collective of the sharded contour integrators.)"""
+    blob = open(na.LIB_PATH, "rb").read().lower()
+    for name in (b"rocblas", b"hipblas", b"rocfft", b"hipfft", b"rocsparse", b"rocsolver"):
+        assert name not in blob, name
+    assert b"rccl" in blob
