@@ -140,6 +140,13 @@ int32_t nep_resid_batch_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, const
  * rows [row0, n); the caller adds its term to the tail and the tail's norms to d_out. */
 int32_t nep_resid_split_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq, int64_t row0,
                             double* d_out, nep_cdouble* dRT_tail, int64_t ldt, nep_stream stream);
+/* K2 with a COLUMN-major Ritz block (n x k, column s at dQ + s ldq, what nep_gemm_ts writes with y_rowmajor = 0): at
+ * waveguide scale the panel loads of the tiled kernel are then contiguous per column and every byte of Q crosses HBM once
+ * (csrc/spmv_tile.hip k_tile_resid_cm).  d_out: 2k squared norms (device).  row0 < 0: whole residual in the norms; row0 >= 0:
+ * rows [0, row0) in the norms, rows [row0, n) written to dR_tail ((n - row0) x k column-major, ld ldt) as in
+ * nep_resid_split_dev.  NEP_ERR_UNSUPPORTED when the matrix has no footprint tiles or more than 4 terms. */
+int32_t nep_resid_batch_cm_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQ, int64_t ldq, int64_t row0,
+                               double* d_out, nep_cdouble* dR_tail, int64_t ldt, nep_stream stream);
 
 /* same residuals, but the block R^T (row-major, row stride ldr >= k) is written instead of its norms --
  * for NEPs with an extra non-SPMF term (the WEP corner, src/gallery_extra/waveguide/Waveguide.jl:351-374)

@@ -161,6 +161,9 @@ int nep_tiles_mlincomb(const NepTiles* t, int k, const cplx* dC, int64_t ldc, co
 // K2 on the tiles: R = residual block of k Ritz pairs (row-major Q), column norms as [nblk][2][k] partials and / or R itself
 int nep_tiles_nblk(const NepTiles* t);
 bool nep_tiles_resid_ok(const NepTiles* t, int k);
+bool nep_tiles_resid_cm_ok(const NepTiles* t, int k);
+int nep_tiles_resid_cm(const NepTiles* t, int k, const cplx* dF, const cplx* Q, int64_t ldq, cplx* R, int64_t ldr, double* partial,
+                       int64_t split_row, hipStream_t st);
 // split_row >= 0: rows below it enter the norms only, rows from it on are written to ZT (row - split_row) only
 int nep_tiles_resid(const NepTiles* t, int k, const cplx* dF, const cplx* QT, int64_t ldq, cplx* ZT, int64_t ldz, double* partial,
                     int64_t split_row, hipStream_t st);

@@ -1012,6 +1012,32 @@ int32_t nep_resid_split_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, const
     return resid_panels(s, k, hF, dQT, ldq, d_out, nullptr, nullptr, as_stream(stream), row0, (cplx*)dRT_tail, ldt);
 }
 
+// K2 with a COLUMN-major Ritz block (n x k, column s at dQ + s ldq; what K7 writes with y_rowmajor = 0): squared column norms
+// of the residual block and of Q into d_out (2k doubles, device), no synchronisation.  Only for matrices with footprint
+// tiles (nep_spmf_tile_info) and at most 4 terms -- NEP_ERR_UNSUPPORTED otherwise: the caller then uses the row-major form.
+// row0 >= 0 / dR_tail: as nep_resid_split_dev, the tail block column-major ((n - row0) x k, ld ldt).
+int32_t nep_resid_batch_cm_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQ, int64_t ldq, int64_t row0,
+                               double* d_out, nep_cdouble* dR_tail, int64_t ldt, nep_stream stream) {
+    ARGCHK(s && hF && dQ && d_out);
+    ARGCHK(k >= 1 && ldq >= s->n && (row0 < 0 || (dR_tail && row0 <= s->n && ldt >= s->n - row0)));
+    if (!s->tiles || !nep_tiles_resid_cm_ok(s->tiles, k)) { nep_set_error("column-major K2: no footprint tiles for this matrix / k"); return NEP_ERR_UNSUPPORTED; }
+    hipStream_t st = as_stream(stream);
+    const size_t cbytes = (size_t)k * s->mt * sizeof(cplx);
+    int rc = s->coef.ensure(cbytes);
+    if (rc) return rc;
+    rc = s->ring.upload(s->coef.dptr, hF, cbytes, st);
+    if (rc) return rc;
+    const int grid = nep_tiles_nblk(s->tiles);
+    rc = s->part.ensure((size_t)grid * 2 * k * sizeof(double));
+    if (rc) return rc;
+    double* partial = (double*)s->part.dptr;
+    rc = nep_tiles_resid_cm(s->tiles, k, (const cplx*)s->coef.dptr, (const cplx*)dQ, ldq, (cplx*)dR_tail, ldt, partial, row0 < 0 ? -1 : row0, st);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_sum_partials_d, dim3(2 * k), dim3(256), 0, st, grid, 2 * k, partial, d_out);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
 int32_t nep_resid_block(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep_cdouble* dQT, int64_t ldq,
                         nep_cdouble* dRT, int64_t ldr, nep_stream stream) {
     ARGCHK(s && hF && dQT && dRT);

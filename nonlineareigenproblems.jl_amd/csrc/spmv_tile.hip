@@ -36,6 +36,7 @@ struct TileDesc {
 struct NepTiles {
     int64_t n = 0; int mt = 0; int valbytes = 8;
     int nblk = 0, fcap = 0, lbits = 13, stride = 0, xp = 0, zp = 0;
+    int wmax = 0, rbmax = 0;        // widest row / largest padded row count over the blocks
     int64_t nent = 0, nfp = 0;
     TileDesc* d_desc = nullptr;
     uint32_t* d_fp = nullptr;
@@ -323,6 +324,117 @@ __global__ __launch_bounds__(256) void k_tile_resid(const TileDesc* __restrict__
     }
 }
 
+// ---- K2 on the tiles, COLUMN-major Q (n x k, column s at Q + s ldq) ------------------------------------------------------------
+// With a row-major Q a column panel of a footprint row is a 64-byte piece of a 16 k-byte row: k_tile_resid moves 2.9x the
+// algorithmic bytes (PMC, profiles/pmc2/r3_tiles_traffic.json) and walks its panels one after the other inside a block, two
+// barriers each.  Column-major, the panel loads are what K1's coefficient phase does -- consecutive lanes read consecutive
+// rows of ONE column, 1 KiB per wave load -- and the panels become the SECOND GRID DIMENSION: workgroup (b, p) handles block b
+// and the PS columns of panel p, start to end without a loop (footprint x PS tile into LDS, one barrier, thread per row).  The
+// block's entries are re-read by the k / PS workgroups that share it (L2 hits: 41 KB per block); every byte of Q crosses HBM
+// once.  Measured at n = 1 003 995: k = 8 0.081 ms (0.35 of the HBM roofline; wave-per-row kernel 0.57 ms, row-major tiles
+// 0.124 ms), k = 60 0.51 ms (0.26; 0.73 / 0.95 ms).  Two other forms were built, measured and removed: the panel loop inside
+// the workgroup with the entries in registers (512 threads, one workgroup per CU: 0.88 ms at k = 60), and a software-pipelined
+// one (next panel's loads in flight during the reduction, two LDS tiles: 0.62-0.74 ms) -- a workgroup's chain descriptor ->
+// footprint -> Q -> barrier -> entries is what bounds all three, and the short-lived workgroups of this form overlap best.
+template <typename VT, int MT, int PS, bool NT>
+__global__ __launch_bounds__(256) void k_tile_resid_cm(const TileDesc* __restrict__ desc, const uint32_t* __restrict__ fp,
+                                                       const uint16_t* __restrict__ eidx, const VT* __restrict__ eval,
+                                                       const cplx* __restrict__ Q, int64_t ldq, int k, const cplx* __restrict__ F,
+                                                       int mt, int fcap, int lbits, cplx* __restrict__ R, int64_t ldr,
+                                                       double* __restrict__ partial, int swz, int64_t split_row) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* Qt = (cplx*)smem;                                 // [fcap][PS]
+    double* wsum = (double*)(Qt + (size_t)fcap * PS);       // [2][4 waves][PS]
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int blk = tile_block(swz);
+    const int p0 = (int)blockIdx.y * PS;
+    const int pw = min(PS, k - p0);
+    const TileDesc d = desc[blk];
+    const int Fn = d.fp_cnt;
+    const uint32_t* __restrict__ fpb = fp + d.fp_off;
+    const int width = d.wrb & 0xffff, rb = d.wrb >> 16;
+    const uint32_t lmask = (1u << lbits) - 1u;
+    const uint16_t* __restrict__ ib = eidx + (int64_t)d.ent_off64 * 64;
+    const VT* __restrict__ vb = eval + (int64_t)d.ent_off64 * 64;
+    // coefficients of this panel: F[t + s mt], s in the panel (uniform loads)
+    cplx fc[MT][PS];
+#pragma unroll
+    for (int s = 0; s < PS; ++s)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) fc[t][s] = (s < pw && t < mt) ? F[(size_t)(p0 + s) * mt + t] : cmake(0.0, 0.0);
+    double qn[PS];
+#pragma unroll
+    for (int s = 0; s < PS; ++s) qn[s] = 0.0;
+    for (int f = tid; f < Fn; f += 256) {
+        const uint32_t raw = fpb[f];
+        const cplx* qp = Q + (int64_t)(raw & NEP_COL_MASK) + (int64_t)p0 * ldq;
+        const bool own = (raw & TILE_OWN) != 0;
+        cplx qv[PS];
+#pragma unroll
+        for (int s = 0; s < PS; ++s) qv[s] = s < pw ? qp[(int64_t)s * ldq] : cmake(0.0, 0.0);
+#pragma unroll
+        for (int s = 0; s < PS; ++s) {
+            Qt[(size_t)f * PS + s] = qv[s];
+            if (own) qn[s] = fma(qv[s].x, qv[s].x, fma(qv[s].y, qv[s].y, qn[s]));
+        }
+    }
+    __syncthreads();
+    double rn[PS];
+#pragma unroll
+    for (int s = 0; s < PS; ++s) rn[s] = 0.0;
+    for (int l = tid; l < rb; l += 256) {
+        cplx acc[MT][PS];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+            for (int s = 0; s < PS; ++s) acc[t][s] = cmake(0.0, 0.0);
+#pragma unroll 4
+        for (int j = 0; j < width; ++j) {
+            const int64_t e = (int64_t)j * rb + l;
+            const uint32_t id = ib[e];                      // (re-read by the other panels of the block: regular loads, L2)
+            const VT a = vb[e];
+            const int t = id >> lbits;
+            const cplx* tp = Qt + (size_t)(id & lmask) * PS;
+#pragma unroll
+            for (int tt = 0; tt < MT; ++tt) {
+                VT am;
+                if constexpr (sizeof(VT) == 8) am = (t == tt) ? a : 0.0; else am = (t == tt) ? a : cmake(0.0, 0.0);
+#pragma unroll
+                for (int s = 0; s < PS; ++s) cfma(acc[tt][s], am, tp[s]);
+            }
+        }
+        if (l < d.nrows) {
+            const int i = l / d.zp, jz = l - i * d.zp;
+            const int64_t row = (int64_t)d.r0 + (int64_t)i * d.stride + jz;
+#pragma unroll
+            for (int s = 0; s < PS; ++s) {
+                if (s < pw) {
+                    cplx r = cmake(0.0, 0.0);
+#pragma unroll
+                    for (int tt = 0; tt < MT; ++tt) cfma(r, fc[tt][s], acc[tt][s]);
+                    if (split_row < 0) { if (R) R[row + (int64_t)(p0 + s) * ldr] = r; rn[s] = fma(r.x, r.x, fma(r.y, r.y, rn[s])); }
+                    else if (row < split_row) rn[s] = fma(r.x, r.x, fma(r.y, r.y, rn[s]));
+                    else R[(row - split_row) + (int64_t)(p0 + s) * ldr] = r;
+                }
+            }
+        }
+    }
+    if (partial) {
+#pragma unroll
+        for (int s = 0; s < PS; ++s) {
+            const double v = wave_reduce_sum(rn[s]);
+            const double u = wave_reduce_sum(qn[s]);
+            if (lane == 0) { wsum[(0 * 4 + wv) * PS + s] = v; wsum[(1 * 4 + wv) * PS + s] = u; }
+        }
+        __syncthreads();
+        if (tid < 2 * pw) {
+            const int which = tid / pw, s = tid - which * pw;
+            const double* w = wsum + (size_t)which * 4 * PS + s;
+            partial[((int64_t)blk * 2 + which) * k + p0 + s] = (w[0] + w[PS]) + (w[2 * PS] + w[3 * PS]);
+        }
+    }
+}
+
 // ---- host: tiles from the stacked CSR -----------------------------------------------------------------------------------------
 namespace {
 
@@ -336,7 +448,7 @@ struct TileBuilder {
     std::vector<int32_t> mark, loc;
     std::vector<int64_t> rows;      // scratch: global rows of the block in local order
     std::vector<uint32_t> cols;
-    int fcap_seen = 0;
+    int fcap_seen = 0, wmax = 0, rbmax = 0;
     bool failed = false;
 
     // rows of the rectangle [x0,x1) x [z0,z1) of the grid with line length s (s = 0: the 1-D range [z0, z1))
@@ -404,6 +516,7 @@ struct TileBuilder {
         d.wrb = width | (rb << 16);
         desc.push_back(d);
         fcap_seen = std::max(fcap_seen, F);
+        wmax = std::max(wmax, width); rbmax = std::max(rbmax, rb);
     }
     static cplx cmake_h(double a, double b) { cplx r; r.x = a; r.y = b; return r; }
 };
@@ -546,7 +659,7 @@ int nep_tiles_build(int64_t n, int mt, int valbytes, const int32_t* rowptr, cons
     if (!tiles_build_host(B, n, mt, valbytes, rowptr, idx, vals, &stride, &xp, &zp)) return NEP_OK;
     NepTiles* t = new NepTiles();
     t->n = n; t->mt = mt; t->valbytes = valbytes; t->nblk = (int)B.desc.size(); t->fcap = (B.fcap_seen + 15) / 16 * 16;
-    t->lbits = B.lbits; t->stride = stride; t->xp = xp; t->zp = zp;
+    t->lbits = B.lbits; t->stride = stride; t->xp = xp; t->zp = zp; t->wmax = B.wmax; t->rbmax = B.rbmax;
     t->nent = (int64_t)B.eidx.size(); t->nfp = (int64_t)B.fp.size();
 #define TCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { nep_set_error("%s:%d: %s: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); nep_tiles_destroy(t); return NEP_ERR_HIP; } } while (0)
     TCHK(hipMalloc((void**)&t->d_desc, B.desc.size() * sizeof(TileDesc)));
@@ -632,6 +745,44 @@ bool nep_tiles_resid_ok(const NepTiles* t, int k) {
 }
 
 // partial: [nblk][2][k] doubles (|r|^2 then |q|^2 per column), or NULL; ZT (n x k row-major, ld ldz) or NULL
+// column-major Q (n x k, ld ldq >= n) and, when given, column-major R: see k_tile_resid_cm
+int nep_tiles_resid_cm(const NepTiles* t, int k, const cplx* dF, const cplx* Q, int64_t ldq, cplx* R, int64_t ldr, double* partial,
+                       int64_t split_row, hipStream_t st) {
+    if (t->mt > 4) { nep_set_error("tiled K2 (column-major): mt = %d not supported", t->mt); return NEP_ERR_ARG; }
+    // columns per panel: 2 (measured at n = 1e6, k = 60: 0.51 ms with 2, 0.64 with 4, 1.24 with 8 -- the smaller tile leaves
+    // room for more workgroups per CU, and the kernel is bound by the dependent loads of each workgroup, not by bytes)
+    static const int ps_env = env_int("NEP_K2_CM_PS", 2);
+    const int ps = ps_env == 8 ? 8 : (ps_env == 4 ? 4 : 2);
+    const size_t shm = (size_t)t->fcap * ps * sizeof(cplx) + (size_t)2 * 4 * ps * sizeof(double);
+    if (shm > 160 * 1024) { nep_set_error("tiled K2 (column-major): footprint too large"); return NEP_ERR_ARG; }
+    static const int swz = env_int("NEP_XCD_SWIZZLE", 1);
+    const bool nt = t->n >= 32768;
+    const dim3 grid((unsigned)t->nblk, (unsigned)((k + ps - 1) / ps));
+#define RC(VT, M, P, NTF)                                                                                                      \
+    do {                                                                                                                       \
+        if (shm > 64 * 1024) {                                                                                                 \
+            static bool raised = false;                                                                                        \
+            if (!raised) {                                                                                                     \
+                HIPCHK(hipFuncSetAttribute((const void*)k_tile_resid_cm<VT, M, P, NTF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                raised = true;                                                                                                 \
+            }                                                                                                                  \
+        }                                                                                                                      \
+        hipLaunchKernelGGL((k_tile_resid_cm<VT, M, P, NTF>), grid, dim3(256), shm, st, (const TileDesc*)t->d_desc,             \
+                           (const uint32_t*)t->d_fp, (const uint16_t*)t->d_eidx, (const VT*)t->d_eval, Q, ldq, k, dF, t->mt,   \
+                           t->fcap, t->lbits, R, ldr, partial, swz, split_row);                                                \
+    } while (0)
+#define RC_M(VT, P, NTF) do { switch (t->mt) { case 1: RC(VT, 1, P, NTF); break; case 2: RC(VT, 2, P, NTF); break; case 3: RC(VT, 3, P, NTF); break; default: RC(VT, 4, P, NTF); break; } } while (0)
+#define RC_P(VT, NTF) do { if (ps == 8) RC_M(VT, 8, NTF); else if (ps == 2) RC_M(VT, 2, NTF); else RC_M(VT, 4, NTF); } while (0)
+    if (t->valbytes == 8) { if (nt) RC_P(double, true); else RC_P(double, false); }
+    else { if (nt) RC_P(cplx, true); else RC_P(cplx, false); }
+#undef RC_P
+#undef RC_M
+#undef RC
+    LAUNCHCHK();
+    return NEP_OK;
+}
+bool nep_tiles_resid_cm_ok(const NepTiles* t, int k) { return t->mt <= 4 && (size_t)t->fcap * 8 * sizeof(cplx) <= 150 * 1024; }
+
 int nep_tiles_resid(const NepTiles* t, int k, const cplx* dF, const cplx* QT, int64_t ldq, cplx* ZT, int64_t ldz, double* partial,
                     int64_t split_row, hipStream_t st) {
     const int ps = nep_tiles_resid_ps(t, k);

@@ -129,8 +129,28 @@ def copy(src, dst, length=None):
     check(lib.nep_dev_copy(c_vp(dst.data_ptr()), c_vp(src.data_ptr()), 16 * (length if length is not None else src.numel()), stream_ptr()))
 
 
+class ColMajorBlock:
+    """a Ritz block kept COLUMN-major: `t` is a device (k, rows) tensor = rows x k column-major (what nep_gemm_ts writes with
+    y_rowmajor = 0).  Large sparse problems use it for their convergence checks: the tiled residual kernel then reads every
+    column contiguously (nep_resid_batch_cm_dev); everything that accepts a row-major (rows, k) block accepts this wrapper."""
+
+    def __init__(self, t):
+        self.t = t
+
+    @property
+    def shape(self):
+        return (self.t.shape[1], self.t.shape[0])
+
+    def cpu_matrix(self):
+        return self.t.cpu().numpy().T
+
+
 def rowmajor_to_cols(QT, cols=None):
     """(rows, k) row-major device block -> (ncols, rows) column-major tensor of the chosen columns"""
+    if isinstance(QT, ColMajorBlock):
+        if cols is None:
+            return QT.t
+        return QT.t[torch.as_tensor(np.ascontiguousarray(cols, dtype=np.int64), device=QT.t.device)].contiguous()
     rows, k = QT.shape
     if cols is None:
         cols = np.arange(k)

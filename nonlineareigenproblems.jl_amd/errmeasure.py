@@ -105,7 +105,7 @@ def estimate_error(errm, lam, v):
 
 def estimate_errors(errm, lams, QT):
     if callable(errm) and not isinstance(errm, Errmeasure):
-        Q = QT.cpu().numpy()
+        Q = QT.cpu_matrix() if hasattr(QT, "cpu_matrix") else QT.cpu().numpy()
         return np.array([errm(l, Q[:, s]) for s, l in enumerate(lams)])
     return errm.batch(list(lams), QT)
 

@@ -66,6 +66,8 @@ def tiar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     z = torch.empty(n, dtype=CDT, device="cuda")
     conv_eig_hist = np.zeros(m + 1, dtype=int)
     lam = np.zeros(0, dtype=np.complex128); QT = None; idx = np.zeros(0, dtype=int)
+    # large sparse problems keep the Ritz block of a check column-major (tiled K2 with contiguous column loads)
+    ritz_cm = bool(getattr(nep, "prefers_colmajor_ritz", lambda: False)())
     pnep = None
     if proj_solve:                                           # method_tiar.jl:104-106
         from .projection import create_proj_NEP, inner_solve, DefaultInnerSolver
@@ -121,9 +123,11 @@ def tiar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                                        tol=tol / 10)
                 II = np.argsort(abs(lamp - sigma), kind="stable")
                 lam = np.asarray(lamp)[II]; Qp = np.asarray(Qp)[:, II]
-                QT = dense.gemm_ts(Z, Qp, rowmajor=True, k=k, rows=n, ldz=n)
+                QT = dense.gemm_ts(Z, Qp, rowmajor=not ritz_cm, k=k, rows=n, ldz=n)
             else:
-                QT = dense.gemm_ts(Z, a[0, :k, :k].T @ W, rowmajor=True, k=k, rows=n, ldz=n)
+                QT = dense.gemm_ts(Z, a[0, :k, :k].T @ W, rowmajor=not ritz_cm, k=k, rows=n, ldz=n)
+            if ritz_cm:
+                QT = dense.ColMajorBlock(QT)
             sync(); t6 = time.perf_counter()
             e = estimate_errors(errmeasure, lam, QT) if len(lam) else np.zeros(0)
             t7 = time.perf_counter()

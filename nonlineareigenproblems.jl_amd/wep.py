@@ -302,8 +302,30 @@ class WEP(AbstractSPMF):
         for i, f in enumerate(self.fi):
             F[i, :] = f.values(la)
         n, nz, N = self.n, self.nz, self.N
-        ldq = QT.shape[1]
         st = stream_ptr()
+        if hasattr(QT, "cpu_matrix"):
+            # column-major Ritz block (dense.ColMajorBlock, device (k, n)): tiled K2 with contiguous column loads; the
+            # residual rows of the 2 nz boundary unknowns come back column-major and take the corner term
+            Qc = QT.t
+            tail = torch.empty((k, 2 * nz), dtype=CDT, device="cuda")
+            out = self.dev.resid_batch_cm(F, Qc, k, row0=N, tail=tail)
+            Rm, RmH = self._corner_dev()
+            S = np.column_stack([_corner_derivs(self.wd, l, 1)[:, 0] for l in la]) / nz
+            Sd = to_dev(S)
+            P = torch.empty((k, nz), dtype=CDT, device="cuda")
+            Y = torch.empty((k, nz), dtype=CDT, device="cuda")
+            for half in (0, 1):
+                row0 = N + half * nz
+                check(lib.nep_gemm_ts_dev(c_vp(RmH.data_ptr()), nz, nz, nz, c_vp(Qc.data_ptr() + 16 * row0), n, 0, k,
+                                          c_vp(P.data_ptr()), nz, 0, st))
+                check(lib.nep_hadamard(nz, k, c_vp(P.data_ptr()), nz, c_vp(Sd.data_ptr() + 16 * half * nz), 2 * nz, st))
+                check(lib.nep_gemm_ts_dev(c_vp(Rm.data_ptr()), nz, nz, nz, c_vp(P.data_ptr()), nz, 0, k,
+                                          c_vp(Y.data_ptr()), nz, 0, st))
+                tail[:, half * nz:(half + 1) * nz] += Y
+            tn2 = (tail.real ** 2 + tail.imag ** 2).sum(dim=1)
+            o = out.cpu().numpy()
+            return np.sqrt(o[:k] + tn2.cpu().numpy()), np.sqrt(o[k:]), F
+        ldq = QT.shape[1]
         split = os.environ.get("NEP_WEP_RESID_SPLIT", "1") != "0"
         if split:
             out = torch.zeros(2 * k, dtype=torch.float64, device="cuda")

@@ -968,3 +968,41 @@ def test_own_gemm_tile_edges_and_real(na, m, n, k):
     check(lib.nep_dgemm(0, 1, m, n, k, 0.5, c_vp(Ard.data_ptr()), m, c_vp(Brd.data_ptr()), n, -2.0, c_vp(Crd.data_ptr()), m, stream_ptr()))
     refr = 0.5 * Ar @ Br.T - 2.0 * C0
     assert np.linalg.norm(Crd.cpu().numpy().T - refr) <= 1e-13 * np.linalg.norm(refr)
+
+
+@pytest.mark.parametrize("case", ["wep", "gun"])
+def test_resid_batch_column_major_tiled(na, case):
+    """nep_resid_batch_cm_dev (k_tile_resid_cm: K2 on the footprint tiles with a COLUMN-major Ritz block, entries of a thread's
+    row held in registers across the column panels): squared norms against NumPy for k below / at / above the panel width, and
+    the split form (rows below row0 in the norms, the tail rows written column-major)"""
+    import torch
+    from nep_amd._lib import lib, check, hptr, c_vp
+    from nep_amd import gallery, wep
+    rng = np.random.default_rng(21)
+    if case == "gun":
+        K, M, W1, W2 = gallery.gun_matrices(); Av = [K, -M, W1, W2]
+    else:
+        Av = wep.WaveguideData(303, 299, "JARLEBRING").big_matrices()
+    dev = na.SPMFDevice(Av)
+    n, mt = dev.n, dev.mt
+    for k in (1, 3, 4, 9, 60):
+        Q = rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k))
+        F = np.asfortranarray(rng.standard_normal((mt, k)) + 1j * rng.standard_normal((mt, k)))
+        R = np.column_stack([sum(F[t, s] * (Av[t] @ Q[:, s]) for t in range(mt)) for s in range(k)])
+        Qc = torch.from_numpy(np.ascontiguousarray(Q.T)).to("cuda")              # (k, n) = column-major n x k
+        o = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+        check(lib.nep_resid_batch_cm_dev(dev.h, k, hptr(F), c_vp(Qc.data_ptr()), n, -1, c_vp(o.data_ptr()), None, 0, None))
+        oh = o.cpu().numpy()
+        assert np.allclose(oh[:k], np.sum(abs(R) ** 2, axis=0), rtol=1e-12)
+        assert np.allclose(oh[k:], np.sum(abs(Q) ** 2, axis=0), rtol=1e-12)
+        row0 = n - 37
+        o2 = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+        tail = torch.full((k, n - row0), float("nan"), dtype=torch.complex128, device="cuda")
+        check(lib.nep_resid_batch_cm_dev(dev.h, k, hptr(F), c_vp(Qc.data_ptr()), n, row0, c_vp(o2.data_ptr()), c_vp(tail.data_ptr()),
+                                         n - row0, None))
+        o2h = o2.cpu().numpy()
+        assert np.allclose(o2h[:k], np.sum(abs(R[:row0]) ** 2, axis=0), rtol=1e-12)
+        assert np.allclose(o2h[k:], np.sum(abs(Q) ** 2, axis=0), rtol=1e-12)
+        assert np.linalg.norm(tail.cpu().numpy().T - R[row0:]) <= 1e-13 * np.linalg.norm(R[row0:])
+        check(lib.nep_resid_batch_cm_dev(dev.h, k, hptr(F), c_vp(Qc.data_ptr()), n, -1, c_vp(o2.data_ptr()), None, 0, None))
+        assert np.array_equal(o2.cpu().numpy(), oh)                              # deterministic

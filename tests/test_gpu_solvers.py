@@ -1226,3 +1226,40 @@ def test_wep_residual_batch_split_vs_oracle(na, nx, nz, monkeypatch):
             got[flag] = np.asarray(E.batch(list(lams), QT))
             assert np.allclose(got[flag], ref, rtol=1e-12), (flag, k)
         assert np.allclose(got["1"], got["0"], rtol=1e-13)
+
+
+def test_tiar_column_major_ritz_blocks(na, monkeypatch):
+    """tiar on a waveguide problem large enough for the column-major Ritz path (n >= 32768: dense.ColMajorBlock -> tiled K2 with
+    contiguous column loads, WEP corner term on the column-major tail) returns the eigenpairs of the row-major path
+    (NEP_K2_CM=0) and of the oracle's matrix-free residual; also through a user-supplied (callable) error measure"""
+    from oracle import wep as ow
+    nx, nz = 183, 179
+    nep = na.nep_gallery("WEP", nx=nx, nz=nz, benchmark_problem="JARLEBRING"); n = nep.n
+    assert n >= 32768
+    v0 = np.ones(n) / np.sqrt(n)
+    res = {}
+    monkeypatch.setenv("NEP_K2_CM", "1")
+    assert nep.prefers_colmajor_ritz()
+    for flag in ("1", "0"):
+        monkeypatch.setenv("NEP_K2_CM", flag)
+        assert nep.prefers_colmajor_ritz() == (flag == "1")
+        h = []
+        lam, Q, _, _ = na.tiar(nep, sigma=-3 - 3.5j, gamma=1.0, maxit=40, neigs=np.inf, v=v0, tol=1e-8, errhist=h)
+        res[flag] = (lam, Q, h)
+    (l1, Q1, h1), (l0, Q0, h0) = res["1"], res["0"]
+    assert len(l1) == len(l0) >= 2 and len(h1) == len(h0)
+    assert max(np.min(abs(l0 - x)) for x in l1) < 1e-9
+    for a, b in zip(h1, h0):
+        kk = min(len(a), len(b), 4)
+        for x, y in zip(np.sort(a)[:kk], np.sort(b)[:kk]):
+            if x > 1e-10 and y > 1e-10:
+                assert 0.5 < x / y < 2.0
+    o = ow.WEP_FD(nx, nz, "JARLEBRING")
+    for i in range(len(l1)):
+        r = o._mlincomb(complex(l1[i]), Q1[:, i:i + 1], np.ones(1, dtype=complex))
+        assert np.linalg.norm(r) / np.linalg.norm(Q1[:, i]) < 1e-8
+    monkeypatch.setenv("NEP_K2_CM", "1")
+    R = na.ResidualErrmeasure(nep)
+    lam_c, Qc, _, _ = na.tiar(nep, sigma=-3 - 3.5j, gamma=1.0, maxit=25, neigs=np.inf, v=v0, tol=1e-8,
+                              errmeasure=lambda l, v: float(na.estimate_error(R, l, v)))
+    assert len(lam_c) >= 1 and max(np.min(abs(l1 - x)) for x in lam_c) < 1e-8
