@@ -19,3 +19,11 @@ for k in 1:m
         ...
     end
 end
+
+
+# residuals of all k Ritz pairs of a convergence check, Q = VV*Z column-major on the device (DevBuf n x k), F[t, s] = f_t(λ_s)
+# (nep_resid_batch_cm_dev: the tiled K2 kernel for column-major blocks; row0 = -1: the whole residual enters the norms)
+out = DevBuf(k, 1)                                       # 2k Float64 = k ComplexF64 slots: squared norms |r_s|², then |q_s|²
+chk(ccall((:nep_resid_batch_cm_dev, LIB), Int32,
+          (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Ptr{Cvoid}, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}),
+          nep.h, k, F, Q.ptr, n, -1, out.ptr, C_NULL, 0, C_NULL))
