@@ -35,6 +35,12 @@ class _RefinementMiss(Exception):
     """a step's recorded backward errors show that UMFPACK's rule wanted more refinement than the step took"""
 
 
+class _OrthPassMiss(Exception):
+    """the device-side DGKS of a step still met the re-orthogonalisation criterion after its last ENQUEUED pass (the
+    reference's IterativeSolvers DGKS repeats while ||w|| < ||c|| / sqrt(2), without a bound): the call is re-run with the
+    step-synchronous loop, whose nep_orth repeats until the criterion is no longer met"""
+
+
 def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
         errmeasure=None, sigma=0.0, gamma=1.0, v=None, logger=0, check_error_every=1, proj_solve=False,
         errhist=None, timers=None, return_device=False, inner_solver_method=None):
@@ -51,9 +57,15 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
         if errhist is not None:
             del errhist[:]
         return _iar(nep, _native_step=False, **kw)
+    except _OrthPassMiss:            # "twice is enough" failed for a step: exact DGKS semantics through the synchronous loop
+        iar.orth_pass_misses += 1
+        if errhist is not None:
+            del errhist[:]
+        return _iar(nep, _force_sync=True, **kw)
 
 
 iar.refinement_misses = 0            # calls that were re-run with checked solves (diagnostics, tests)
+iar.orth_pass_misses = 0             # calls that were re-run because a step wanted more DGKS passes than were enqueued
 
 
 _CHECK_STREAMS = {}
@@ -63,13 +75,16 @@ def _check_stream():
     dev = torch.cuda.current_device()
     st = _CHECK_STREAMS.get(dev)
     if st is None:
-        st = _CHECK_STREAMS[dev] = torch.cuda.Stream()
+        # the convergence checks are off the critical path: their stream gets the LOWEST priority the device offers, so that
+        # the dispatcher serves the recurrence's kernels first when both streams have work (NEP_IAR_CHECK_PRIO overrides;
+        # torch clamps to the device's range, a lower number is a higher priority)
+        st = _CHECK_STREAMS[dev] = torch.cuda.Stream(priority=int(os.environ.get("NEP_IAR_CHECK_PRIO", "1")))
     return st
 
 
 def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
          errmeasure=None, sigma=0.0, gamma=1.0, v=None, logger=0, check_error_every=1, proj_solve=False,
-         errhist=None, timers=None, return_device=False, inner_solver_method=None, _native_step=True):
+         errhist=None, timers=None, return_device=False, inner_solver_method=None, _native_step=True, _force_sync=False):
     t_entry = time.perf_counter()
     n = nep.size(1); m = int(maxit)
     sigma = complex(sigma); gamma = complex(gamma)
@@ -104,7 +119,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     # enqueues step k+1.. while the device is still executing step k.  `timers` (instrumented run), MGS and
     # NEP_IAR_SYNC=1 use the step-synchronous loop; both produce the same iterates.
     use_async = (timers is None and dense._orth_code(orthmethod) in (0, 1) and not os.environ.get("NEP_IAR_SYNC")
-                 and not proj_solve)
+                 and not proj_solve and not _force_sync)
     pnep = None
     if proj_solve:                                       # method_iar.jl:89-92
         from .projection import create_proj_NEP, inner_solve, DefaultInnerSolver
@@ -213,6 +228,8 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                 row = Hnp[j - 1]
                 if int(row[j + 1].imag) & 2:
                     raise NepError(NEP_ERR_BREAKDOWN, "orthogonalisation breakdown in step %d: ||w|| = %g" % (j, row[j].real))
+                if int(row[j + 1].imag) & 1 and dense._orth_code(orthmethod) == 0:
+                    raise _OrthPassMiss(j)        # another DGKS pass was wanted after the last enqueued one
                 if cstep is not None and M0inv.umfpack_refinements > 0:
                     if not M0inv.review_recorded(row[j + 2:j + 4].view(np.float64), plans[j]):
                         raise _RefinementMiss(j)

@@ -1263,3 +1263,27 @@ def test_tiar_column_major_ritz_blocks(na, monkeypatch):
     lam_c, Qc, _, _ = na.tiar(nep, sigma=-3 - 3.5j, gamma=1.0, maxit=25, neigs=np.inf, v=v0, tol=1e-8,
                               errmeasure=lambda l, v: float(na.estimate_error(R, l, v)))
     assert len(lam_c) >= 1 and max(np.min(abs(l1 - x)) for x in lam_c) < 1e-8
+
+
+def test_iar_reruns_when_a_dgks_pass_is_missing(na):
+    """the asynchronous DGKS enqueues two passes ("twice is enough"); the reference's DGKS repeats without a bound.  When the
+    device reports that the criterion still held after the last enqueued pass, iar re-runs the call with the synchronous loop
+    (exact DGKS).  Forced here by enqueuing ONE pass only (NEP_ORTH_DEV_PASSES=1, read once per process -> subprocess): the
+    call must notice (orth_pass_misses = 1) and return the eigenvalues of the normal run"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); import nep_amd as na; "
+            "nep = na.nep_gallery('gun_spmf_scaled', 1310); "
+            "lam, Q, _ = na.iar(nep, sigma=0.0, gamma=1.0, maxit=40, neigs=np.inf, v=np.ones(nep.n), tol=1e-10); "
+            "print(json.dumps({'misses': na.iar.orth_pass_misses, 're': list(np.sort_complex(lam).real), 'im': list(np.sort_complex(lam).imag)}))") % root
+    out = {}
+    for passes in ("1", "2"):
+        env = dict(os.environ, NEP_ORTH_DEV_PASSES=passes)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-1500:]
+        out[passes] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["2"]["misses"] == 0 and out["1"]["misses"] == 1
+    a = np.array(out["1"]["re"]) + 1j * np.array(out["1"]["im"]); b = np.array(out["2"]["re"]) + 1j * np.array(out["2"]["im"])
+    assert len(a) == len(b) >= 1 and np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max())
