@@ -12,6 +12,14 @@
 #include <math.h>
 #include <stdlib.h>
 
+// V is streamed once per kernel; for blocks far larger than the 256 MB last-level cache the loads are non-temporal so that the
+// stream does not evict what the kernels around a Gram-Schmidt pass re-read (the factors of the fixed-shift solve: 65 MB on gun)
+typedef double orth_d2 __attribute__((ext_vector_type(2)));
+template <bool NT> __device__ __forceinline__ cplx vload(const cplx* p) {
+    if (NT) { const orth_d2 v = __builtin_nontemporal_load((const orth_d2*)p); return cmake(v.x, v.y); }
+    return *p;
+}
+
 #define DOT_RPT 4
 #define DOT_CG 8
 #define DOT_RB (256 * DOT_RPT)
@@ -60,6 +68,7 @@ __device__ __forceinline__ int orth_decide_after(const OrthDecide& D, int pdone,
     return more;
 }
 
+template <bool NT>
 __global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, int64_t ldv, int64_t rows,
                                                    int k, const int64_t* __restrict__ active,
                                                    const cplx* __restrict__ w, cplx* __restrict__ partial,
@@ -94,7 +103,7 @@ __global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, i
                     const cplx* vp = V + (int64_t)j * ldv;
 #pragma unroll
                     for (int i = 0; i < DOT_RPT; ++i)
-                        if (rr[i] < act) cfma_conj(acc, vp[rr[i]], wr[i]);
+                        if (rr[i] < act) cfma_conj(acc, vload<NT>(vp + rr[i]), wr[i]);
                     acc = group_reduce_sum<64>(acc);
                 }
             }
@@ -152,6 +161,7 @@ __global__ __launch_bounds__(1024) void k_orth_reduce_n(int nb, const double* __
 }
 
 // w[r] -= sum_j V[r,j] h[j];  block = 8 waves x 64 rows, wave q takes columns q, q+8, ...
+template <bool NT>
 __global__ __launch_bounds__(512) void k_orth_update(const cplx* __restrict__ V, int64_t ldv, int64_t rows,
                                                      int k, const int64_t* __restrict__ active,
                                                      const cplx* __restrict__ h, cplx* __restrict__ w,
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(512) void k_orth_update(const cplx* __restrict__ V,
 #pragma unroll 4
         for (int j = q; j < k; j += 8) {
             const int64_t act = active ? active[j] : rows;
-            if (r0 < act) cfma(acc, vp[(int64_t)j * ldv], hs[j]);
+            if (r0 < act) cfma(acc, vload<NT>(vp + (int64_t)j * ldv), hs[j]);
         }
         sm[q * 64 + lane] = acc;
         __syncthreads();
@@ -288,12 +298,12 @@ extern "C" int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, in
         // modified Gram-Schmidt: column by column (test/reference-comparison path; not tuned)
         for (int j = 0; j < k; ++j) {
             const int64_t* actj = d_act ? d_act + j : nullptr;
-            hipLaunchKernelGGL(k_orth_dots, dim3(nchunks, 1), dim3(256), 0, st, V + (int64_t)j * ldv, ldv, rows, 1,
+            hipLaunchKernelGGL(k_orth_dots<false>, dim3(nchunks, 1), dim3(256), 0, st, V + (int64_t)j * ldv, ldv, rows, 1,
                                actj, (const cplx*)w, d_ph);
             LAUNCHCHK();
             hipLaunchKernelGGL(k_orth_reduce_h, dim3(1), dim3(256), 0, st, nchunks, 1, (const cplx*)d_ph, d_h + j);
             LAUNCHCHK();
-            hipLaunchKernelGGL(k_orth_update, dim3(nblk), dim3(512), (1 + 8 * 64) * sizeof(cplx), st,
+            hipLaunchKernelGGL(k_orth_update<false>, dim3(nblk), dim3(512), (1 + 8 * 64) * sizeof(cplx), st,
                                V + (int64_t)j * ldv, ldv, rows, 1, actj, (const cplx*)(d_h + j), w, d_pn);
             LAUNCHCHK();
         }
@@ -307,12 +317,12 @@ extern "C" int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, in
     } else {
         const double eta = 1.0 / sqrt(2.0);
         while (true) {
-            hipLaunchKernelGGL(k_orth_dots, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv,
+            hipLaunchKernelGGL(k_orth_dots<false>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv,
                                rows, (int)k, (const int64_t*)d_act, (const cplx*)w, d_ph);
             LAUNCHCHK();
             hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_h);
             LAUNCHCHK();
-            hipLaunchKernelGGL(k_orth_update, dim3(nblk), dim3(512), shm_upd, st, V, ldv, rows, (int)k,
+            hipLaunchKernelGGL(k_orth_update<false>, dim3(nblk), dim3(512), shm_upd, st, V, ldv, rows, (int)k,
                                (const int64_t*)d_act, (const cplx*)d_h, w, d_pn);
             LAUNCHCHK();
             hipLaunchKernelGGL(k_orth_reduce_n, dim3(1), dim3(1024), 0, st, nblk, (const double*)d_pn, d_n);
@@ -394,21 +404,35 @@ extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, in
     cplx* out = (cplx*)d_out;
     const size_t shm_upd = (size_t)(k + 8 * 64) * sizeof(cplx);
     const int npass = method == 1 ? 1 : orth_dev_passes();
+    // non-temporal V loads when the block that is streamed (iar: the non-zero staircase, about half of rows x k) is far larger
+    // than the last-level cache: NEP_ORTH_NT = 0 never, 1 always, unset: above NEP_ORTH_NT_MB (default 192) megabytes
+    static const int nt_env = getenv("NEP_ORTH_NT") ? atoi(getenv("NEP_ORTH_NT")) : -1;
+    static const double nt_mb = getenv("NEP_ORTH_NT_MB") ? atof(getenv("NEP_ORTH_NT_MB")) : 192.0;
+    const double streamed_mb = 16.0e-6 * (double)rows * (double)k * (d_active_rows ? 0.5 : 1.0);
+    const bool nt = nt_env >= 0 ? nt_env != 0 : streamed_mb > nt_mb;
     OrthDecide D;
     D.partial = d_pn; D.np = npart; D.c = d_c; D.k = (int)k; D.method = (int)method; D.state = d_state; D.out_beta = out + k;
     // per pass three launches (dots, coefficient reduction, update); the decision after pass p is formed inside the dots kernel
     // of pass p + 1 and, for the last pass, inside k_orth_finish (it was a fourth launch per pass)
     for (int p = 0; p < npass; ++p) {
         const int* gate = p == 0 ? nullptr : d_state + 4 + p;       // "pass p ran and wants pass p + 1", published by this pass' dots
-        hipLaunchKernelGGL(k_orth_dots, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv, rows, (int)k,
-                           d_active_rows, (const cplx*)w, d_ph, (const int*)nullptr, p == 0 ? OrthDecide() : D, p);
+        if (nt)
+            hipLaunchKernelGGL(k_orth_dots<true>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv, rows, (int)k,
+                               d_active_rows, (const cplx*)w, d_ph, (const int*)nullptr, p == 0 ? OrthDecide() : D, p);
+        else
+            hipLaunchKernelGGL(k_orth_dots<false>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv, rows, (int)k,
+                               d_active_rows, (const cplx*)w, d_ph, (const int*)nullptr, p == 0 ? OrthDecide() : D, p);
         LAUNCHCHK();
         hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_c, gate, out,
                            p == 0 ? 1 : 0, p == 0 ? d_state : (int*)nullptr);
         LAUNCHCHK();
         if (p == 0 && before_write) HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)before_write, 0));
-        hipLaunchKernelGGL(k_orth_update, dim3(npart), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
-                           (const cplx*)d_c, w, d_pn, gate);
+        if (nt)
+            hipLaunchKernelGGL(k_orth_update<true>, dim3(npart), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
+                               (const cplx*)d_c, w, d_pn, gate);
+        else
+            hipLaunchKernelGGL(k_orth_update<false>, dim3(npart), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
+                               (const cplx*)d_c, w, d_pn, gate);
         LAUNCHCHK();
     }
     const int g = (int)std::min<int64_t>((rows + 255) / 256, 2048);
@@ -431,7 +455,7 @@ extern "C" int32_t nep_gemv_h(const nep_cdouble* dV, int64_t ldv, int64_t rows, 
     if (rc) return rc;
     cplx* d_ph = (cplx*)g_orth_scratch.dptr;
     cplx* d_h = (cplx*)((char*)g_orth_scratch.dptr + off_h);
-    hipLaunchKernelGGL(k_orth_dots, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, (const cplx*)dV, ldv, rows,
+    hipLaunchKernelGGL(k_orth_dots<false>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, (const cplx*)dV, ldv, rows,
                        (int)k, (const int64_t*)nullptr, (const cplx*)dw, d_ph);
     LAUNCHCHK();
     hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_h);
