@@ -126,12 +126,18 @@ __global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, i
 __global__ __launch_bounds__(256) void k_orth_reduce_h(int nb, int k, const cplx* __restrict__ partial,
                                                        cplx* __restrict__ h, const int* __restrict__ gate = nullptr,
                                                        cplx* __restrict__ hacc = nullptr, int first = 1,
-                                                       int* __restrict__ state_reset = nullptr) {
+                                                       int* __restrict__ state_reset = nullptr,
+                                                       const OrthDecide dec = OrthDecide(), int pdone = 0) {
     __shared__ cplx sm[4];
     // first pass of an asynchronous orthogonalisation: clear the pass state here (nothing reads it before the k_orth_dots of the
     // NEXT pass) instead of a separate memset command in front of every Arnoldi step
     if (state_reset && blockIdx.x == 0 && threadIdx.x < 16) state_reset[threadIdx.x] = 0;
     if (gate && *gate == 0) return;
+    // fused-dots path: this launch opens pass pdone + 1, so the decision of pass pdone is formed here (every workgroup, same
+    // fixed order; workgroup 0 publishes it).  dec.c must not be the array this kernel writes (h).
+    if (dec.partial) {
+        if (!orth_decide_after(dec, pdone, blockIdx.x == 0)) return;
+    }
     const int j = blockIdx.x;
     cplx acc = cmake(0.0, 0.0);
     for (int b = threadIdx.x; b < nb; b += 256) acc = cadd(acc, partial[(int64_t)b * k + j]);
@@ -209,6 +215,84 @@ __global__ __launch_bounds__(512) void k_orth_update(const cplx* __restrict__ V,
     if (q == 0 && lane == 0) partial[blockIdx.x] = wg_nn;
 }
 
+
+// First update of a DGKS orthogonalisation with the projections of the SECOND pass formed in the same sweep over V:
+//   w' = w - V h              (as k_orth_update)
+//   cpart[b][j] = sum over this workgroup's rows of conj(V[r, j]) w'[r]      (what the second pass' k_orth_dots would compute)
+// A wave keeps the V values of its columns (q, q + 8, ...: KPW of them) in registers between the two uses -- a tile is read from
+// HBM once -- and accumulates its conj(v) w' products per lane across the tiles it walks; one wave reduction per column at the
+// end.  The second pass then needs no k_orth_dots at all: its coefficients are a reduction of cpart (k_orth_reduce_h), it runs in
+// the 24 % of the gun steps that meet the criterion with ONE pass over V instead of two, and a gated-off second pass is two
+// launches instead of three.  KPW = ceil(k / 8) columns per wave as a compile-time constant (registers).
+template <int KPW, bool NT>
+__global__ __launch_bounds__(512) void k_orth_update_fd(const cplx* __restrict__ V, int64_t ldv, int64_t rows, int k,
+                                                        const int64_t* __restrict__ active, const cplx* __restrict__ h,
+                                                        cplx* __restrict__ w, double* __restrict__ partial,
+                                                        cplx* __restrict__ cpart) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* hs = (cplx*)smem_raw;         // k
+    cplx* sm = hs + k;                  // [8][64]
+    cplx* wt = sm + 8 * 64;             // [64] updated w of the tile
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int t = threadIdx.x; t < k; t += 512) hs[t] = h[t];
+    __syncthreads();
+    const int64_t ntiles = (rows + 63) / 64;
+    double wg_nn = 0.0;
+    cplx cacc[KPW];
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) cacc[i] = cmake(0.0, 0.0);
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * 64LL;
+        const int64_t row = r0 + lane;
+        const int64_t rowc = row < rows ? row : rows - 1;
+        const cplx* vp = V + rowc;
+        cplx vreg[KPW];
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            const int j = q + 8 * i;
+            vreg[i] = cmake(0.0, 0.0);
+            if (j < k) {
+                const int64_t act = active ? active[j] : rows;
+                if (r0 < act) vreg[i] = vload<NT>(vp + (int64_t)j * ldv);
+            }
+        }
+        cplx acc = cmake(0.0, 0.0);
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) {
+            const int j = q + 8 * i;
+            if (j < k) cfma(acc, vreg[i], hs[j]);
+        }
+        sm[q * 64 + lane] = acc;
+        __syncthreads();
+        if (q == 0) {
+            cplx s = sm[lane];
+#pragma unroll
+            for (int t = 1; t < 8; ++t) s = cadd(s, sm[t * 64 + lane]);
+            double nn = 0.0;
+            cplx wn = cmake(0.0, 0.0);
+            if (row < rows) {
+                wn = csub(w[row], s);
+                w[row] = wn;
+                nn = fma(wn.x, wn.x, wn.y * wn.y);
+            }
+            wt[lane] = wn;                                   // rows beyond the end contribute zero
+            wg_nn += wave_reduce_sum(nn);
+        }
+        __syncthreads();
+        const cplx wl = wt[lane];
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) cfma_conj(cacc[i], vreg[i], wl);     // (columns inactive on this tile hold zero)
+        // (no barrier needed here: the next tile's first barrier separates this read of wt from its next write)
+    }
+    if (q == 0 && lane == 0) partial[blockIdx.x] = wg_nn;
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+        const int j = q + 8 * i;
+        const cplx c = group_reduce_sum<64>(cacc[i]);
+        if (lane == 0 && j < k) cpart[(int64_t)blockIdx.x * k + j] = c;
+    }
+}
 
 // w /= beta (beta on the device); records passes / flags behind beta: out[k+1] = (passes, 2*breakdown + more_needed)
 // mirror (optional): device-mapped pinned host copy of the caller's row [row, row + nmirror) -- h, beta, flags and whatever the
@@ -386,24 +470,35 @@ extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, in
     hipStream_t st = as_stream(stream);
     const int nchunks = (int)((rows + DOT_RB - 1) / DOT_RB);
     const int nblk = (int)((rows + 63) / 64);
-    // scratch: [state 16 int][partial_h nchunks*k cplx][c k cplx][partial_n npart dbl]
     const int npart = std::min(nblk, ORTH_NPART);
+    const int npass = method == 1 ? 1 : orth_dev_passes();
+    // NEP_ORTH_FUSED_DOTS=1 (opt-in, read per call): DGKS with two enqueued passes forms the second pass' projections inside
+    // the first update (k_orth_update_fd).  MEASURED SLOWER on the headline run (45.0 ms per call against 42.2 ms; K6 over the 100
+    // step shapes 16.3 ms against 12.7 ms): the fused kernel holds a tile's V values in registers (157 VGPRs at k = 100, one
+    // workgroup per CU) and every step's first update pays for that, while only the 24 % of the steps that run their second pass
+    // save a k_orth_dots.
+    const char* fused_e = getenv("NEP_ORTH_FUSED_DOTS");
+    const bool fused = fused_e && atoi(fused_e) != 0 && method == 0 && npass == 2 && k <= 128;
+    // scratch: [state 16 int][partial_h nchunks*k cplx][c k cplx][c2 k cplx][partial_n npart dbl][partial_c2 npart*k cplx]
     size_t off_ph = 64;
     size_t off_c = off_ph + (size_t)nchunks * k * sizeof(cplx);
-    size_t off_pn = off_c + (size_t)k * sizeof(cplx);
-    size_t total = off_pn + (size_t)npart * sizeof(double);
+    size_t off_c2 = off_c + (size_t)k * sizeof(cplx);
+    size_t off_pn = off_c2 + (size_t)k * sizeof(cplx);
+    size_t off_pc2 = (off_pn + (size_t)npart * sizeof(double) + 15) & ~(size_t)15;
+    size_t total = off_pc2 + (fused ? (size_t)npart * k * sizeof(cplx) : 0);
     int rc = g_orth_scratch.ensure(total);
     if (rc) return rc;
     char* base = (char*)g_orth_scratch.dptr;
     int* d_state = (int*)base;
     cplx* d_ph = (cplx*)(base + off_ph);
     cplx* d_c = (cplx*)(base + off_c);
+    cplx* d_c2 = (cplx*)(base + off_c2);
     double* d_pn = (double*)(base + off_pn);
+    cplx* d_pc2 = (cplx*)(base + off_pc2);
     const cplx* V = (const cplx*)dV;
     cplx* w = (cplx*)dw;
     cplx* out = (cplx*)d_out;
     const size_t shm_upd = (size_t)(k + 8 * 64) * sizeof(cplx);
-    const int npass = method == 1 ? 1 : orth_dev_passes();
     // non-temporal V loads when the block that is streamed (iar: the non-zero staircase, about half of rows x k) is far larger
     // than the last-level cache: NEP_ORTH_NT = 0 never, 1 always, unset: above NEP_ORTH_NT_MB (default 192) megabytes
     static const int nt_env = getenv("NEP_ORTH_NT") ? atoi(getenv("NEP_ORTH_NT")) : -1;
@@ -412,6 +507,44 @@ extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, in
     const bool nt = nt_env >= 0 ? nt_env != 0 : streamed_mb > nt_mb;
     OrthDecide D;
     D.partial = d_pn; D.np = npart; D.c = d_c; D.k = (int)k; D.method = (int)method; D.state = d_state; D.out_beta = out + k;
+    if (fused) {
+        // pass 1: dots, coefficient reduction, update + the projections of pass 2
+        if (nt)
+            hipLaunchKernelGGL(k_orth_dots<true>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv, rows, (int)k,
+                               d_active_rows, (const cplx*)w, d_ph, (const int*)nullptr, OrthDecide(), 0);
+        else
+            hipLaunchKernelGGL(k_orth_dots<false>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv, rows, (int)k,
+                               d_active_rows, (const cplx*)w, d_ph, (const int*)nullptr, OrthDecide(), 0);
+        LAUNCHCHK();
+        hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_c, (const int*)nullptr, out,
+                           1, d_state, OrthDecide(), 0);
+        LAUNCHCHK();
+        if (before_write) HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)before_write, 0));
+        const size_t shm_fd = (size_t)(k + 8 * 64 + 64) * sizeof(cplx);
+#define UPD_FD(KPW_)                                                                                                           \
+        do {                                                                                                                   \
+            if (nt) hipLaunchKernelGGL((k_orth_update_fd<KPW_, true>), dim3(npart), dim3(512), shm_fd, st, V, ldv, rows, (int)k, \
+                                       d_active_rows, (const cplx*)d_c, w, d_pn, d_pc2);                                       \
+            else hipLaunchKernelGGL((k_orth_update_fd<KPW_, false>), dim3(npart), dim3(512), shm_fd, st, V, ldv, rows, (int)k,  \
+                                    d_active_rows, (const cplx*)d_c, w, d_pn, d_pc2);                                          \
+        } while (0)
+        if (k <= 16) UPD_FD(2); else if (k <= 32) UPD_FD(4); else if (k <= 64) UPD_FD(8); else if (k <= 104) UPD_FD(13); else UPD_FD(16);
+#undef UPD_FD
+        LAUNCHCHK();
+        // pass 2 (gated by the decision formed in its first kernel): coefficients = reduction of the fused partials, one update
+        hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, npart, (int)k, (const cplx*)d_pc2, d_c2, (const int*)nullptr, out,
+                           0, (int*)nullptr, D, 1);
+        LAUNCHCHK();
+        const int* gate2 = d_state + 4 + 1;
+        if (nt)
+            hipLaunchKernelGGL(k_orth_update<true>, dim3(npart), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
+                               (const cplx*)d_c2, w, d_pn, gate2);
+        else
+            hipLaunchKernelGGL(k_orth_update<false>, dim3(npart), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
+                               (const cplx*)d_c2, w, d_pn, gate2);
+        LAUNCHCHK();
+        D.c = d_c2;                  // the finish kernel forms the decision after pass 2 from that pass' coefficients
+    } else {
     // per pass three launches (dots, coefficient reduction, update); the decision after pass p is formed inside the dots kernel
     // of pass p + 1 and, for the last pass, inside k_orth_finish (it was a fourth launch per pass)
     for (int p = 0; p < npass; ++p) {
@@ -424,7 +557,7 @@ extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, in
                                d_active_rows, (const cplx*)w, d_ph, (const int*)nullptr, p == 0 ? OrthDecide() : D, p);
         LAUNCHCHK();
         hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_c, gate, out,
-                           p == 0 ? 1 : 0, p == 0 ? d_state : (int*)nullptr);
+                           p == 0 ? 1 : 0, p == 0 ? d_state : (int*)nullptr, OrthDecide(), 0);
         LAUNCHCHK();
         if (p == 0 && before_write) HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)before_write, 0));
         if (nt)
@@ -434,6 +567,7 @@ extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, in
             hipLaunchKernelGGL(k_orth_update<false>, dim3(npart), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
                                (const cplx*)d_c, w, d_pn, gate);
         LAUNCHCHK();
+    }
     }
     const int g = (int)std::min<int64_t>((rows + 255) / 256, 2048);
     hipLaunchKernelGGL(k_orth_finish, dim3(g), dim3(256), 0, st, rows, w, out + k, d_state, (const cplx*)out,

@@ -1006,3 +1006,49 @@ def test_resid_batch_column_major_tiled(na, case):
         assert np.linalg.norm(tail.cpu().numpy().T - R[row0:]) <= 1e-13 * np.linalg.norm(R[row0:])
         check(lib.nep_resid_batch_cm_dev(dev.h, k, hptr(F), c_vp(Qc.data_ptr()), n, -1, c_vp(o2.data_ptr()), None, 0, None))
         assert np.array_equal(o2.cpu().numpy(), oh)                              # deterministic
+
+
+@pytest.mark.parametrize("fused", ["1", "0"])
+@pytest.mark.parametrize("k", [3, 16, 17, 40, 70, 104, 128, 130])
+@pytest.mark.parametrize("reorth", [False, True])
+def test_orth_dev_fused_second_pass_dots(na, k, reorth, fused, monkeypatch):
+    """the asynchronous DGKS (nep_orth_dev) with the second pass' projections formed inside the first update
+    (k_orth_update_fd: the V values of a tile stay in registers between the update and the conj(v) w' products) against the
+    oracle's DGKS and against the unfused chain (NEP_ORTH_FUSED_DOTS=0): h, beta, w, pass count and flags; every register
+    variant (2 / 4 / 8 / 13 / 16 columns per wave), k > 128 (unfused fallback), with and without a forced second pass, iar's
+    block-triangular basis (`active`), rows that are no multiple of the 64-row tile"""
+    import torch
+    from oracle import solvers as osol
+    rng = np.random.default_rng(100 + k)
+    n = 37
+    rows = n * (k + 1) + 5
+    V = np.zeros((rows, k), dtype=complex)
+    for j in range(k):
+        V[:(j + 1) * n, j] = rng.standard_normal((j + 1) * n) + 1j * rng.standard_normal((j + 1) * n)
+    V, _ = np.linalg.qr(V)
+    active = (np.arange(1, k + 1) * n).astype(np.int64)
+    if reorth:
+        w = V @ (rng.standard_normal(k) + 1j * rng.standard_normal(k)) + 1e-9 * (rng.standard_normal(rows) + 1j * rng.standard_normal(rows))
+    else:
+        w = rng.standard_normal(rows) + 1j * rng.standard_normal(rows)
+    wo = w.copy(); ho = np.zeros(k, dtype=complex)
+    bo = osol.dgks(V, wo, ho)
+    Vd = na.to_dev(V); act_d = torch.from_numpy(active).to("cuda")
+    monkeypatch.setenv("NEP_ORTH_FUSED_DOTS", fused)        # opt-in kernel (measured slower on the headline run): kept correct here
+    out = torch.zeros(k + 2, dtype=torch.complex128, device="cuda")
+    wd = na.to_dev(w)[0]
+    na.dense.orthogonalize_and_normalize_dev(Vd, wd, k, out, rows=rows, ldv=rows, active_dev=act_d)
+    o = out.cpu().numpy()
+    h, beta, passes, flags = o[:k], o[k].real, int(o[k + 1].real), int(o[k + 1].imag)
+    assert passes == (2 if reorth else 1) and flags == 0
+    assert beta == pytest.approx(bo, rel=1e-6 if reorth else 1e-12)
+    assert np.linalg.norm(h - ho) <= 1e-12 * np.linalg.norm(ho)
+    wh = wd.cpu().numpy()
+    assert np.linalg.norm(V.conj().T @ wh) < 1e-12 and abs(np.linalg.norm(wh) - 1.0) < 1e-12
+    if not reorth:
+        assert np.linalg.norm(wh - wo) <= 1e-11
+    # deterministic
+    out2 = torch.zeros(k + 2, dtype=torch.complex128, device="cuda")
+    wd2 = na.to_dev(w)[0]
+    na.dense.orthogonalize_and_normalize_dev(Vd, wd2, k, out2, rows=rows, ldv=rows, active_dev=act_d)
+    assert torch.equal(out, out2) and torch.equal(wd, wd2)
