@@ -498,7 +498,7 @@ static int launch_spmv_kfused(const nep_spmf* s, int k, const cplx* V, int64_t l
 // Arioli/Demmel/Duff):  r = b - Mx,  omega = max_i |r_i| / ( sum_t |c_t| sum_j |A_t[i,j]| |x_j| + |b_i| ).
 // One pass over the stacked CSR; the maximum lands in *omega_bits (non-negative doubles order like their bit patterns).
 __device__ __forceinline__ double absval(double v) { return fabs(v); }
-__device__ __forceinline__ double absval(cplx v) { return hypot(v.x, v.y); }
+__device__ __forceinline__ double absval(cplx v) { return sqrt(fma(v.x, v.x, v.y * v.y)); }   // (entries of x and A: no overflow concern)
 
 // FUSED: Mx is not given but accumulated in the same pass with the complex coefficients ccf (pure SPMF operators).
 template <int G, typename VT, bool FUSED>
@@ -543,7 +543,14 @@ __global__ __launch_bounds__(256) void k_cw_resid(const int32_t* __restrict__ ro
     __syncthreads();
     if (threadIdx.x == 0 && omega_bits) {
         const double m = fmax(fmax(wmax[0], wmax[1]), fmax(wmax[2], wmax[3]));
-        if (m > 0.0) atomicMax(omega_bits, (unsigned long long)__double_as_longlong(m));
+        // one atomic per workgroup on ONE word serialises at the end of a kernel this short (623 workgroups on gun: ~12 ns each);
+        // a maximum only ever grows, so a workgroup whose value does not exceed what it can already see skips the atomic
+        // (device-scope relaxed load: served by L2, never a stale L1 line)
+        if (m > 0.0) {
+            const unsigned long long mine = (unsigned long long)__double_as_longlong(m);
+            const unsigned long long seen = __hip_atomic_load(omega_bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mine > seen) atomicMax(omega_bits, mine);
+        }
     }
 }
 

@@ -1,15 +1,11 @@
 set -x
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-mkdir -p gpurun_out/b17
-timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_solvers.py -x -q -m gpu -k "orth or dgks or iar or gmres" > gpurun_out/b17/t.log 2>&1; echo "rc=$?" >> gpurun_out/b17/t.log
-NEP_ORTH_FUSED_DOTS=0 timeout 900 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "orth_dev_fused" > gpurun_out/b17/t_unfused.log 2>&1; echo "rc=$?" >> gpurun_out/b17/t_unfused.log
-for i in 1 2; do
-NEP_ORTH_FUSED_DOTS=0 timeout 300 python scripts/iar_runs.py 12 > gpurun_out/b17/iar_unfused_$i.log 2>&1
-timeout 300 python scripts/iar_runs.py 12 > gpurun_out/b17/iar_fused_$i.log 2>&1
+mkdir -p gpurun_out/b18
+timeout 900 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_solvers.py -x -q -m gpu -k "refine or lin_solve or iar or backward or linsolver or lu" > gpurun_out/b18/t.log 2>&1; echo "rc=$?" >> gpurun_out/b18/t.log
+for i in 1 2 3; do
+timeout 300 python scripts/iar_runs.py 12 > gpurun_out/b18/iar_$i.log 2>&1
 done
-NEP_ORTH_FUSED_DOTS=0 timeout 300 python bench.py --no-c5 --no-c3 --no-beyn --no-cpu-baseline --no-wep-roofline --no-cold > gpurun_out/b17/bench_unfused.json 2> gpurun_out/b17/bench_unfused.err
-timeout 300 python bench.py --no-c5 --no-c3 --no-beyn --no-cpu-baseline --no-wep-roofline --no-cold > gpurun_out/b17/bench_fused.json 2> gpurun_out/b17/bench_fused.err
-timeout 300 python scripts/run_configs.py c5 --wep-nx 1003 --wep-nz 999 --wep-solver gmres > gpurun_out/b17/c5_fused.log 2>&1
-NEP_ORTH_FUSED_DOTS=0 timeout 300 python scripts/run_configs.py c5 --wep-nx 1003 --wep-nz 999 --wep-solver gmres > gpurun_out/b17/c5_unfused.log 2>&1
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tr5 -o tr -- python $GRAFT_REPO_ROOT/scripts/iar_runs.py 6 > $GRAFT_REPO_ROOT/gpurun_out/b18/trace_run.log 2>&1)
+cp $(find /tmp/tr5 -name "*kernel_stats.csv" | head -1) gpurun_out/b18/iar_kernel_stats.csv
 echo done
