@@ -344,6 +344,14 @@ static int dots_grid_y(int nchunks, int k) {
 
 static thread_local NepScratch g_orth_scratch;
 
+// non-temporal V loads when the streamed block is far larger than the last-level cache (see nep_orth_dev)
+static bool orth_use_nt(int64_t rows, int64_t k, bool staircase) {
+    static const int nt_env = getenv("NEP_ORTH_NT") ? atoi(getenv("NEP_ORTH_NT")) : -1;
+    static const double nt_mb = getenv("NEP_ORTH_NT_MB") ? atof(getenv("NEP_ORTH_NT_MB")) : 192.0;
+    const double streamed_mb = 16.0e-6 * (double)rows * (double)k * (staircase ? 0.5 : 1.0);
+    return nt_env >= 0 ? nt_env != 0 : streamed_mb > nt_mb;
+}
+
 extern "C" int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
                             const int64_t* h_active_rows, nep_cdouble* dw, nep_cdouble* h_h, double* h_beta,
                             int32_t method, int32_t* h_npasses, nep_stream stream) {
@@ -400,14 +408,23 @@ extern "C" int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, in
         passes = 1;
     } else {
         const double eta = 1.0 / sqrt(2.0);
+        const bool nt = orth_use_nt(rows, k, d_act != nullptr);
         while (true) {
-            hipLaunchKernelGGL(k_orth_dots<false>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv,
-                               rows, (int)k, (const int64_t*)d_act, (const cplx*)w, d_ph);
+            if (nt)
+                hipLaunchKernelGGL(k_orth_dots<true>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv,
+                                   rows, (int)k, (const int64_t*)d_act, (const cplx*)w, d_ph);
+            else
+                hipLaunchKernelGGL(k_orth_dots<false>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv,
+                                   rows, (int)k, (const int64_t*)d_act, (const cplx*)w, d_ph);
             LAUNCHCHK();
             hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_h);
             LAUNCHCHK();
-            hipLaunchKernelGGL(k_orth_update<false>, dim3(nblk), dim3(512), shm_upd, st, V, ldv, rows, (int)k,
-                               (const int64_t*)d_act, (const cplx*)d_h, w, d_pn);
+            if (nt)
+                hipLaunchKernelGGL(k_orth_update<true>, dim3(nblk), dim3(512), shm_upd, st, V, ldv, rows, (int)k,
+                                   (const int64_t*)d_act, (const cplx*)d_h, w, d_pn);
+            else
+                hipLaunchKernelGGL(k_orth_update<false>, dim3(nblk), dim3(512), shm_upd, st, V, ldv, rows, (int)k,
+                                   (const int64_t*)d_act, (const cplx*)d_h, w, d_pn);
             LAUNCHCHK();
             hipLaunchKernelGGL(k_orth_reduce_n, dim3(1), dim3(1024), 0, st, nblk, (const double*)d_pn, d_n);
             LAUNCHCHK();
@@ -501,10 +518,7 @@ extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, in
     const size_t shm_upd = (size_t)(k + 8 * 64) * sizeof(cplx);
     // non-temporal V loads when the block that is streamed (iar: the non-zero staircase, about half of rows x k) is far larger
     // than the last-level cache: NEP_ORTH_NT = 0 never, 1 always, unset: above NEP_ORTH_NT_MB (default 192) megabytes
-    static const int nt_env = getenv("NEP_ORTH_NT") ? atoi(getenv("NEP_ORTH_NT")) : -1;
-    static const double nt_mb = getenv("NEP_ORTH_NT_MB") ? atof(getenv("NEP_ORTH_NT_MB")) : 192.0;
-    const double streamed_mb = 16.0e-6 * (double)rows * (double)k * (d_active_rows ? 0.5 : 1.0);
-    const bool nt = nt_env >= 0 ? nt_env != 0 : streamed_mb > nt_mb;
+    const bool nt = orth_use_nt(rows, k, d_active_rows != nullptr);
     OrthDecide D;
     D.partial = d_pn; D.np = npart; D.c = d_c; D.k = (int)k; D.method = (int)method; D.state = d_state; D.out_beta = out + k;
     if (fused) {

@@ -14,10 +14,11 @@ rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 names = defaultdict(lambda: [0, 0.0])
 for r in rows:
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    nm = r["Kernel_Name"].split("(")[0]
+    nm = r["Kernel_Name"].split("(")[0].replace("void ", "")
     names[nm][0] += 1; names[nm][1] += d
-dots = [r for r in rows if r["Kernel_Name"].startswith("k_orth_dots")]
-upd = [r for r in rows if r["Kernel_Name"].startswith("k_orth_update")]
+kname = lambda r: r["Kernel_Name"].replace("void ", "")
+dots = [r for r in rows if kname(r).startswith("k_orth_dots")]
+upd = [r for r in rows if kname(r).startswith("k_orth_update")]
 dur = lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
 # group the dots launches into runs of 2*m (two passes per step)
 per_run = 2 * m
