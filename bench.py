@@ -48,6 +48,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
+MFMA64_PEAK_TFLOPS = 78.6        # dense FP64 matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 RED_DEV = "cuda"        # device of the tensors that go through torch.distributed reductions
 
@@ -71,7 +72,7 @@ def parse():
     ap.add_argument("--no-c5-oracle", action="store_true", help="skip the CPU oracle of the C5 twin (about 40 s)")
     ap.add_argument("--c5-nx", type=int, default=1003)
     ap.add_argument("--c5-nz", type=int, default=999)
-    ap.add_argument("--only", default=None, choices=["orth", "k5", "mlincomb"],
+    ap.add_argument("--only", default=None, choices=["orth", "k5", "mlincomb", "wepscale"],
                     help="run only one fixed-shape kernel loop (the command the committed rocprofv3 summaries come from)")
     ap.add_argument("--reps", type=int, default=50)
     return ap.parse_args()
@@ -327,6 +328,27 @@ def wep_scale_roofline(na):
         out["K2 k=%d" % k] = {"kernel": "nep_resid_batch_dev", "algorithmic_bytes": b, "ms_per_launch": ms, "achieved": b / ms / 1e6,
                               "frac": b / ms / 1e6 / HBM_PEAK_GBS}
         del QT
+    # K7 (tall-skinny FP64-MFMA GEMM, the Ritz block Q = V Z of tiar / iar: src/method_tiar.jl:188-189, src/method_iar.jl:115) at the
+    # tiar m = 60 shape, B resident on the device (nep_gemm_ts_dev: fragment expansion kernel + the GEMM kernel per call), HIP
+    # events around 50 back-to-back calls after 30 warm-up calls (the first ~15 ms of FP64-MFMA work after memory-bound kernels run
+    # 13 % slower -- clocks ramping -- scripts/diag/k7_timing.py); peak = the dense FP64 matrix rate of MI355X_MICROARCH.md
+    try:
+        from nep_amd._lib import lib, check, c_vp
+        from nep_amd.nep import stream_ptr
+        for k in (60, 64):
+            Zb = torch.complex(torch.randn((k, n), dtype=torch.float64, device="cuda"), torch.randn((k, n), dtype=torch.float64, device="cuda"))
+            Bd = torch.complex(torch.randn((k, k), dtype=torch.float64, device="cuda"), torch.randn((k, k), dtype=torch.float64, device="cuda"))
+            Yb = torch.empty((n, k), dtype=torch.complex128, device="cuda")
+            ms = event_loop(lambda: check(lib.nep_gemm_ts_dev(c_vp(Zb.data_ptr()), n, n, k, c_vp(Bd.data_ptr()), k, 0, k,
+                                                              c_vp(Yb.data_ptr()), k, 1, stream_ptr())), 50, warm=30)
+            fl = 8.0 * n * k * k
+            out["K7 k=p=%d" % k] = {"kernel": "nep_gemm_ts_dev (k_expand_B + k_gemm_ts_res), row-major Y", "bound": "mfma", "flops": fl,
+                                    "algorithmic_bytes": 16.0 * n * 2 * k, "ms_per_launch": ms, "achieved": fl / ms / 1e9,
+                                    "peak": MFMA64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": fl / ms / 1e9 / MFMA64_PEAK_TFLOPS,
+                                    "hbm_GBps": 16.0 * n * 2 * k / ms / 1e6}
+            del Zb, Yb
+    except Exception as e:
+        out["K7"] = {"error": repr(e)[:200]}
     return out
 
 
@@ -460,6 +482,8 @@ def main():
             print(json.dumps(orth_roofline(na, nep.n, args.maxit, reps=args.reps)))
         elif args.only == "k5":
             print(json.dumps(k5_roofline(na, nep, args, reps=args.reps)))
+        elif args.only == "wepscale":
+            print(json.dumps(wep_scale_roofline(na)))
         else:
             for k in (args.maxit, 1):
                 b, ms = mlincomb_roofline(na, nep, k, reps=args.reps)

@@ -140,26 +140,47 @@ __global__ __launch_bounds__(512) void k_gemm_ts(const cplx* __restrict__ Z, int
 }
 
 // ------------------------------------------------------------------------------------------------
-// B-resident persistent variant: when ALL B fragments of a column panel fit in LDS (nks * NT KiB <= 144 KiB, e.g. k = p = 60:
-// 120 KiB) they are loaded once per workgroup and every wave walks 16-row strips on its own -- no __syncthreads in the main
-// loop, the Z values are prefetched four k-steps (64 MFMAs) ahead through a small register ring, across strip boundaries.  One workgroup
-// per CU (LDS-bound), 2 waves per SIMD.
+// B-resident persistent variant for tall blocks: when ALL B fragments of a column panel fit in LDS (nks * NT KiB <= 144 KiB, e.g.
+// k = p = 60: 120 KiB) they are loaded once per workgroup and every wave walks 16-row strips on its own -- no __syncthreads in
+// the main loop.  The Z values of a WHOLE strip live in a register buffer of MAXKS slots; slot ks is refilled for the wave's next
+// strip right behind the MFMAs of k-step ks, so every load has a full strip of MFMAs (about 16 us) to land.  The number of k-steps
+// is a run-time argument: all MAXKS loads of a strip are issued (columns clamped to k - 1: the surplus ones hit L1) and only the
+// MFMA blocks of k-steps >= nks are skipped, by wave-uniform branches.  That keeps the number of memory operations per strip a
+// compile-time constant -- the condition under which the compiler's s_waitcnt vmcnt(N) for "Z of k-step ks has landed" does not
+// also drain the younger loads and the stores of the previous strip (gfx950 has ONE counter for loads and stores).  For the same
+// reason the prologue loads are pinned in k-step order and the first strip is peeled off the loop (both predecessors of the loop
+// header then carry the same queue).  Round 3; the ring-of-four kernel of round 2 padded the k-steps to a multiple of 8 (k = 60:
+// 16 instead of 15, k = 52: 16 instead of 13) and waited for its ring once per 4 k-steps: 48 -> 52 TFLOP/s at k = p = 60, 43 -> 50
+// at k = 52 (scripts/ub_k7.hip, full-entropy operands).  One workgroup per CU (LDS-bound), 2 waves per SIMD.
 #define GEMM_RES_MAXKS 24
 #define GEMM_TALL_ROWS (16LL * 16 * 8 * 256)   // >= 16 strips per wave of a full grid: the resident kernel is worth its set-up
-// k-steps for a block of `rows` rows: padded to a multiple of 8 for tall blocks so that the resident kernel can take them
-// (the extra k-steps multiply zero B rows)
-static inline int gemm_nks(int k, int64_t rows) {
-    int nks = (k + 3) / 4;
-    if (rows >= GEMM_TALL_ROWS) { const int np = (nks + 7) & ~7; if (np <= GEMM_RES_MAXKS) nks = np; }
-    return nks;
-}
-template <int NT, bool ROWMAJOR>
+static inline int gemm_nks(int k, int64_t rows) { (void)rows; return (k + 3) / 4; }
+template <int NT, int MAXKS, bool ROWMAJOR>
 __global__ __launch_bounds__(512) void k_gemm_ts_res(const cplx* __restrict__ Z, int64_t ldz, int64_t rows, int k,
                                                      const double* __restrict__ Bfrag, int nks, int p, int j0,
                                                      cplx* __restrict__ Y, int64_t ldy) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int PER_KS = NT * 2 * 64;
     double* bs = (double*)smem_raw;                       // [nks][NT][2][64]
+    const int lane = threadIdx.x & 63;
+    const int wv = threadIdx.x >> 6;
+    const int m = lane & 15, q = lane >> 4;
+    const int64_t nstrips = (rows + 15) / 16;
+    const int64_t stride = (int64_t)gridDim.x * 8;
+    int64_t strip = blockIdx.x * 8LL + wv;
+    const bool have = strip < nstrips;
+    cplx z[MAXKS];
+    auto colptr = [&](int ks) -> const cplx* {
+        int col = 4 * ks + q;
+        col = col < k ? col : k - 1;                      // the matching B rows are zero / the k-step is skipped
+        return Z + (int64_t)col * ldz;
+    };
+    if (have) {                                           // the first strip's loads are in flight during the fragment copy
+        int64_t arow = strip * 16 + m;
+        if (arow >= rows) arow = rows - 1;
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks) { z[ks] = colptr(ks)[arow]; __builtin_amdgcn_sched_barrier(0); }
+    }
     {
         const double2* src = (const double2*)Bfrag;
         double2* dst = (double2*)bs;
@@ -167,66 +188,29 @@ __global__ __launch_bounds__(512) void k_gemm_ts_res(const cplx* __restrict__ Z,
         for (int t = threadIdx.x; t < n2; t += 512) dst[t] = src[t];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wv = threadIdx.x >> 6;
-    const int m = lane & 15, q = lane >> 4;
-    const int64_t nstrips = (rows + 15) / 16;
-    const int64_t stride = (int64_t)gridDim.x * 8;
-    // Z values travel through two rings of RES_D registers used alternately (ping-pong, so no register copies and the
-    // only waits are at the first use of a ring): while the MFMAs of k-steps kb .. kb+RES_D-1 consume ring A, the loads for
-    // kb+RES_D .. kb+2*RES_D-1 go into ring B -- of this strip, or of the wave's next strip once the index runs past nks.
-    // The loads are unconditional (clamped addresses) and pinned in front of the MFMAs with scheduling barriers.
-    constexpr int RES_D = 4;
-    cplx ra[RES_D], rb[RES_D];
-    int64_t strip = blockIdx.x * 8LL + wv;
-    auto zload = [&](int ks, int64_t arow, int64_t nrow) -> cplx {      // k-step ks of this strip, or ks - nks of the next one
-        const bool same = ks < nks;
-        int col = 4 * (same ? ks : ks - nks) + q;
-        if (col >= k) col = k - 1;                  // the matching B rows are zero
-        return Z[(int64_t)col * ldz + (same ? arow : nrow)];
-    };
-    {
-        int64_t arow = (strip < nstrips ? strip : nstrips - 1) * 16 + m;
-        if (arow >= rows) arow = rows - 1;
-#pragma unroll
-        for (int j = 0; j < RES_D; ++j) ra[j] = zload(j, arow, arow);
-    }
-    for (; strip < nstrips; strip += stride) {
+    if (!have) return;
+    const double* bl = bs + lane;
+    auto body = [&](int64_t strip) __attribute__((always_inline)) {
         const int64_t next = strip + stride < nstrips ? strip + stride : strip;
-        int64_t arow = strip * 16 + m, nrow = next * 16 + m;
-        if (arow >= rows) arow = rows - 1;
+        int64_t nrow = next * 16 + m;
         if (nrow >= rows) nrow = rows - 1;
         d4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-        for (int kb = 0; kb < nks; kb += 2 * RES_D) {      // nks is a multiple of 2 * RES_D (padded by the host side)
 #pragma unroll
-            for (int j = 0; j < RES_D; ++j) rb[j] = zload(kb + RES_D + j, arow, nrow);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int ks = 0; ks < MAXKS; ++ks) {
+            if (ks < nks) {
+                const cplx a = z[ks];
+                double f[2 * NT];
 #pragma unroll
-            for (int j = 0; j < RES_D; ++j) {
-                const double* bk = bs + (size_t)(kb + j) * PER_KS + lane;
+                for (int i = 0; i < 2 * NT; ++i) f[i] = bl[ks * PER_KS + i * 64];
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[j].x, bk[(t * 2 + 0) * 64], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.x, f[t * 2 + 0], acc[t], 0, 0, 0);
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(ra[j].y, bk[(t * 2 + 1) * 64], acc[t], 0, 0, 0);
+                for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a.y, f[t * 2 + 1], acc[t], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < RES_D; ++j) ra[j] = zload(kb + 2 * RES_D + j, arow, nrow);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int j = 0; j < RES_D; ++j) {
-                const double* bk = bs + (size_t)(kb + RES_D + j) * PER_KS + lane;
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rb[j].x, bk[(t * 2 + 0) * 64], acc[t], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(rb[j].y, bk[(t * 2 + 1) * 64], acc[t], 0, 0, 0);
-            }
+            z[ks] = colptr(ks)[nrow];                     // the same k-step of the wave's next strip: a whole strip ahead
             __builtin_amdgcn_sched_barrier(0);
         }
         const int64_t row0 = strip * 16;
@@ -245,27 +229,29 @@ __global__ __launch_bounds__(512) void k_gemm_ts_res(const cplx* __restrict__ Z,
                 }
             }
         } else {
+            const bool odd = n & 1;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int jc = 8 * t + (n >> 1);
-                const bool odd = n & 1;
+                // even lanes keep regs {0,2}, odd lanes regs {1,3}; the partner supplies the other part
                 const double s0 = odd ? acc[t][0] : acc[t][1];
                 const double s1 = odd ? acc[t][2] : acc[t][3];
                 const double r0 = shfl_xor_d(s0, 1);
                 const double r1 = shfl_xor_d(s1, 1);
                 cplx v0, v1;
-                int i0, i1;
-                if (!odd) { v0 = cmake(acc[t][0], r0); v1 = cmake(acc[t][2], r1); i0 = 0; i1 = 2; }
-                else      { v0 = cmake(r0, acc[t][1]); v1 = cmake(r1, acc[t][3]); i0 = 1; i1 = 3; }
+                if (!odd) { v0 = cmake(acc[t][0], r0); v1 = cmake(acc[t][2], r1); }
+                else      { v0 = cmake(r0, acc[t][1]); v1 = cmake(r1, acc[t][3]); }
+                const int64_t ra = row0 + g + (odd ? 4 : 0), rb = ra + 8;
                 if (jc < p) {
-                    const int64_t ra = row0 + g + 4 * i0, rb = row0 + g + 4 * i1;
                     cplx* col = Y + (int64_t)(j0 + jc) * ldy;
                     if (ra < rows) col[ra] = v0;
                     if (rb < rows) col[rb] = v1;
                 }
             }
         }
-    }
+    };
+    body(strip);
+    for (strip += stride; strip < nstrips; strip += stride) body(strip);
 }
 
 static inline int gemm_nt(int pp) {   // N-tiles of 8 complex output columns
@@ -281,20 +267,20 @@ static int gemm_launch(bool rowmajor, const cplx* Z, int64_t ldz, int64_t rows, 
     // B-resident persistent kernel: all fragments in LDS (<= 144 KiB), tall blocks only (>= 16 strips per wave)
     static const int res_mode = getenv("NEP_GEMM_RES") ? atoi(getenv("NEP_GEMM_RES")) : 1;
     const size_t res_bytes = (size_t)nks * NT * 2 * 64 * sizeof(double);
-    // (the ping-pong rings of the resident kernel need nks to be a multiple of 8: the entry points pad it for tall blocks)
-    if (NT <= 8 && res_mode && nks <= GEMM_RES_MAXKS && nks % 8 == 0 && res_bytes <= 147456 && rows >= GEMM_TALL_ROWS) {   // NT > 8 would spill
+    // (NT = 8 with more than 16 k-steps would spill: 96 buffer + 64 accumulator registers)
+    if constexpr (NT <= 8) if (res_mode && nks <= (NT == 8 ? 16 : GEMM_RES_MAXKS) && res_bytes <= 147456 && rows >= GEMM_TALL_ROWS) {
         static thread_local int ncu = 0;
         if (!ncu) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); ncu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256; }
         const dim3 grid((unsigned)ncu), block(512);
-        if (rowmajor) {
-            static thread_local bool set_t = false;
-            if (!set_t) { HIPCHK(hipFuncSetAttribute((const void*)k_gemm_ts_res<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456)); set_t = true; }
-            hipLaunchKernelGGL((k_gemm_ts_res<NT, true>), grid, block, res_bytes, st, Z, ldz, rows, k, dB, nks, p, j0, Y, ldy);
-        } else {
-            static thread_local bool set_f = false;
-            if (!set_f) { HIPCHK(hipFuncSetAttribute((const void*)k_gemm_ts_res<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456)); set_f = true; }
-            hipLaunchKernelGGL((k_gemm_ts_res<NT, false>), grid, block, res_bytes, st, Z, ldz, rows, k, dB, nks, p, j0, Y, ldy);
-        }
+#define RES_LAUNCH(MAXKS_, RM_)                                                                                               \
+        do {                                                                                                                  \
+            static thread_local bool set_ = false;                                                                            \
+            if (!set_) { HIPCHK(hipFuncSetAttribute((const void*)k_gemm_ts_res<NT, MAXKS_, RM_>, hipFuncAttributeMaxDynamicSharedMemorySize, 147456)); set_ = true; } \
+            hipLaunchKernelGGL((k_gemm_ts_res<NT, MAXKS_, RM_>), grid, block, res_bytes, st, Z, ldz, rows, k, dB, nks, p, j0, Y, ldy); \
+        } while (0)
+        if (nks <= 16) { if (rowmajor) RES_LAUNCH(16, true); else RES_LAUNCH(16, false); }
+        else if constexpr (NT < 8) { if (rowmajor) RES_LAUNCH(24, true); else RES_LAUNCH(24, false); }
+#undef RES_LAUNCH
         LAUNCHCHK();
         return NEP_OK;
     }

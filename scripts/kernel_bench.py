@@ -95,7 +95,7 @@ def bench_gemm(na, rows, k, p, label, reps, rowmajor=True):
     Z = crandn(k, rows)
     B = np.random.default_rng(1).standard_normal((k, p)) + 1j * np.random.default_rng(2).standard_normal((k, p))
     out = torch.empty((rows, p) if rowmajor else (p, rows), dtype=torch.complex128, device="cuda")
-    ms = ev_time(lambda: na.gemm_ts(Z, B, rowmajor=rowmajor, out=out), reps)
+    ms = ev_time(lambda: na.gemm_ts(Z, B, rowmajor=rowmajor, out=out), max(reps, 30), warm=30)    # clocks settle after ~15 ms of MFMA work
     fl = 8.0 * rows * k * p
     b = 16.0 * rows * (k + p)
     emit(kernel="K7 nep_gemm_ts (incl. host B expansion + H2D)", case=label, rows=rows, k=k, p=p, flops=fl, bytes=b, ms=ms,

@@ -150,10 +150,12 @@ def test_c5_wep_fullsize_schur_gmres_round_trip(na):
     assert float(torch.linalg.norm(x12 - x1 - 2.0 * x2) / torch.linalg.norm(x12)) <= 1e-9
 
 
-@pytest.mark.parametrize("k,p,rowmajor", [(60, 60, True), (60, 60, False), (37, 64, True), (80, 13, False)])
+@pytest.mark.parametrize("k,p,rowmajor", [(60, 60, True), (60, 60, False), (37, 64, True), (80, 13, False), (52, 60, True), (3, 5, False),
+                                          (70, 40, True), (93, 20, False), (64, 64, False), (61, 9, True)])
 def test_k7_resident_variant_tall_blocks(na, k, p, rowmajor):
     """K7 on blocks tall enough for the B-resident persistent kernel (rows >= 524 288, all B fragments in LDS): against NumPy,
-    1e-13 relative per entry scale; both output layouts, k not a multiple of 4, p not a multiple of 8"""
+    1e-13 relative per entry scale; both output layouts, k not a multiple of 4, p not a multiple of 8, every N-tile count of the
+    resident kernel with both register-buffer sizes (k-steps <= 16 and 17 ... 24; round 3: no k-step padding)"""
     rows = 600_003
     rng = np.random.default_rng(k * 100 + p)
     Z = rng.standard_normal((rows, k)) + 1j * rng.standard_normal((rows, k))
