@@ -402,6 +402,10 @@ int32_t nep_lu_refac_analyze(int64_t n, const int32_t* Lp, const int32_t* Li, co
                              const int32_t* perm_r, const int32_t* perm_c, const int32_t* Ap, const int32_t* Ai, int64_t out[8]);
 /* out[0..5] = n, products, internal products, external products, external destination segments, symbolic time in ms */
 int32_t nep_lu_refac_info(const nep_lu_refac* r, int64_t out[6]);
+/* out[0] = hash of the plan arrays as they sit on the device (the quantity nep_lu_refac_analyze returns in out[7] for the host
+ * enumeration of the same inputs), out[1] = 1 when the products were enumerated on the device (default; NEP_LU_PLAN_GPU=0: on
+ * host threads).  Round 3: the enumeration of nep_lu_refac_create runs on the GPU (0.10-0.18 s -> a few ms for the gun pattern). */
+int32_t nep_lu_refac_hash(const nep_lu_refac* r, int64_t out[2]);
 int32_t nep_lu_factor_dev(nep_lu_refac* r, const nep_cdouble* h_Ax, int32_t expected_solves, double growth_limit,
                           double* h_health, nep_cdouble* h_LUx_out, nep_lu** out, nep_stream stream);
 /* B matrices of the plan's pattern in one pass (every launch carries all of them): h_Ax B x nnz(A), h_health B x 3 (required),

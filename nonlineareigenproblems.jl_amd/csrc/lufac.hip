@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
+#include <hipcub/hipcub.hpp>
 #include <cstring>
 #include <math.h>
 
@@ -65,6 +66,7 @@ struct nep_lu_refac {
     int32_t* d_wide = nullptr;           // 4 per product: gL, gU, gdst, position of the pivot U(k,k)
     int64_t nwide = 0;
     double t_symbolic_ms = 0.0;
+    bool gpu_enumerated = false;         // the product arrays were built by k_lu_enum_* (round 3), not by the host threads
 };
 
 // ---- kernels ---------------------------------------------------------------------------------------------------------------
@@ -231,6 +233,96 @@ __global__ __launch_bounds__(512) void k_lu_int(int blk0, const int32_t* __restr
     if (threadIdx.x == 0 && minpiv < 0.0) health[0] = 1.0;
 }
 
+// ---- plan enumeration on the device (round 3) ---------------------------------------------------------------------------------
+// The 22 M products of the gun plan took 0.10 s (six host threads) to 0.18 s (one) to enumerate and 24 ms to upload -- during
+// which the second and third iar call of a process still factorised on the host.  On the device: one thread per product
+// (pivot k by bisection of the product offsets, then (a, b) -> U entry a of row k and L entry b of column k, destination slot by
+// bisection of the union column), the positions of internal and wide products from ONE exclusive scan over the product
+// flags, the external products sorted by (destination segment, pivot) with a radix sort.  The arrays are bit-identical to the
+// host enumeration's (nep_lu_refac_hash against nep_lu_refac_analyze; NEP_LU_PLAN_GPU=0 keeps the host path).
+struct LuEnt { int32_t row; int32_t g; };
+struct LuEnumArgs {
+    int64_t nprod; int32_t n;
+    const int64_t* pbase;        // n+1: first product of pivot k
+    const int64_t* lstart;       // n: first entry of union column k below the diagonal
+    const int32_t* nL;           // n: entries of L(:,k) below the diagonal
+    const int64_t* urp;          // n+1: rows of U (diagonal first)
+    const LuEnt* urow; const int64_t* cptr; const LuEnt* cent;
+    const int32_t* blk; const int32_t* lvl; const uint8_t* wide;
+};
+#define LU_KIND_SHIFT 30
+__device__ __forceinline__ int32_t lu_find_pivot(const int64_t* __restrict__ pbase, int32_t n, int64_t t) {
+    int32_t lo = 0, hi = n;                     // largest k with pbase[k] <= t
+    while (hi - lo > 1) { const int32_t mid = (lo + hi) >> 1; if (pbase[mid] <= t) lo = mid; else hi = mid; }
+    return lo;
+}
+// code[t] = destination slot | kind << 30 (0 internal, 1 external, 2 wide); tot[g] += 1 for external products; err: 1 = no slot,
+// 2 = update crosses blocks of one level (the host enumeration is re-run for the message)
+__global__ void k_lu_enum_classify(LuEnumArgs A, uint32_t* __restrict__ code, int32_t* __restrict__ tot, int32_t* __restrict__ err) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= A.nprod) return;
+    const int32_t k = lu_find_pivot(A.pbase, A.n, t);
+    const int64_t local = t - A.pbase[k];
+    const int32_t nl = A.nL[k];
+    const int64_t a = local / nl; const int32_t b = (int32_t)(local - a * nl);
+    const LuEnt ue = A.urow[A.urp[k] + 1 + a];
+    const LuEnt le = A.cent[A.lstart[k] + b];
+    const int32_t j = ue.row, i = le.row;
+    int64_t lo = A.cptr[j], hi = A.cptr[j + 1];
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (A.cent[mid].row < i) lo = mid + 1; else hi = mid; }
+    if (lo >= A.cptr[j + 1] || A.cent[lo].row != i) { atomicMax(err, 1); code[t] = 3u << LU_KIND_SHIFT; return; }
+    const uint32_t gd = (uint32_t)A.cent[lo].g;
+    const int32_t p = i < j ? i : j;
+    uint32_t kind;
+    if (A.blk[p] == A.blk[k]) kind = A.wide[A.lvl[k]] ? 2u : 0u;
+    else if (A.lvl[p] <= A.lvl[k]) { atomicMax(err, 2); code[t] = 3u << LU_KIND_SHIFT; return; }
+    else { kind = 1u; atomicAdd(&tot[gd], 1); }
+    code[t] = gd | (kind << LU_KIND_SHIFT);
+}
+struct LuFlagOp {
+    __host__ __device__ __forceinline__ unsigned long long operator()(uint32_t c) const {
+        const uint32_t kind = c >> LU_KIND_SHIFT;
+        return kind == 0u ? 1ull : (kind == 2u ? (1ull << 32) : 0ull);
+    }
+};
+__global__ void k_lu_enum_counts(int32_t n, const int64_t* __restrict__ pbase, const unsigned long long* __restrict__ scan,
+                                 int32_t* __restrict__ cnt_int, int32_t* __restrict__ cnt_wide) {
+    const int32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const unsigned long long s0 = scan[pbase[k]], s1 = scan[pbase[k + 1]];
+    cnt_int[k] = (int32_t)((uint32_t)s1 - (uint32_t)s0);
+    cnt_wide[k] = (int32_t)((uint32_t)(s1 >> 32) - (uint32_t)(s0 >> 32));
+}
+__global__ void k_lu_enum_place(LuEnumArgs A, const uint32_t* __restrict__ code, const unsigned long long* __restrict__ scan,
+                                const int64_t* __restrict__ piv_ptr, const int32_t* __restrict__ newpos,
+                                const int64_t* __restrict__ wide_off, const int32_t* __restrict__ udiag,
+                                const int32_t* __restrict__ segid, int32_t* __restrict__ itri, int32_t* __restrict__ wflat,
+                                unsigned long long* __restrict__ keys, unsigned long long* __restrict__ vals) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= A.nprod) return;
+    const int32_t k = lu_find_pivot(A.pbase, A.n, t);
+    const int64_t t0 = A.pbase[k];
+    const int64_t local = t - t0;
+    const int32_t nl = A.nL[k];
+    const int64_t a = local / nl; const int32_t b = (int32_t)(local - a * nl);
+    const int32_t gU = A.urow[A.urp[k] + 1 + a].g;
+    const int32_t gL = A.cent[A.lstart[k] + b].g;
+    const uint32_t c = code[t];
+    const uint32_t kind = c >> LU_KIND_SHIFT; const int32_t gd = (int32_t)(c & ((1u << LU_KIND_SHIFT) - 1u));
+    const unsigned long long s = scan[t], s0 = scan[t0];
+    if (kind == 0u) {
+        int32_t* o = itri + 3 * (piv_ptr[newpos[k]] + (int64_t)((uint32_t)s - (uint32_t)s0));
+        o[0] = gL; o[1] = gU; o[2] = gd;
+    } else if (kind == 2u) {
+        int32_t* o = wflat + 4 * (wide_off[k] + (int64_t)((uint32_t)(s >> 32) - (uint32_t)(s0 >> 32)));
+        o[0] = gL; o[1] = gU; o[2] = gd; o[3] = udiag[k];
+    } else if (kind == 1u) {
+        const int64_t e = t - (int64_t)(uint32_t)s - (int64_t)(uint32_t)(s >> 32);      // rank among the external products
+        keys[e] = ((unsigned long long)(uint32_t)segid[gd] << 32) | (uint32_t)k;
+        vals[e] = ((unsigned long long)(uint32_t)gU << 32) | (uint32_t)gL;              // int32 view: [gL, gU]
+    }
+}
+
 // ---- host: symbolic part -----------------------------------------------------------------------------------------------------
 namespace {
 
@@ -240,6 +332,7 @@ double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::
 // depend on the number of enumeration threads
 thread_local bool g_refac_dry = false;
 thread_local uint64_t g_refac_hash = 0;
+thread_local hipStream_t g_refac_stream = nullptr;
 template <class T>
 int upv(T** d, const std::vector<T>& h) {
     if (g_refac_dry) {
@@ -254,11 +347,113 @@ int upv(T** d, const std::vector<T>& h) {
     const size_t cnt = std::max<size_t>(h.size(), 1);
     int rc = nep_pool_alloc((void**)d, cnt * sizeof(T));
     if (rc) return rc;
-    if (!h.empty()) HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    // (on the plan's own non-blocking stream when there is one: a copy on the null stream would queue behind everything the
+    // caller's stream has enqueued -- an iar call runs up to 100 steps ahead of the device)
+    if (!h.empty()) {
+        if (g_refac_stream) { HIPCHK(hipMemcpyAsync(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, g_refac_stream)); HIPCHK(hipStreamSynchronize(g_refac_stream)); }
+        else HIPCHK(hipMemcpy(*d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
     return NEP_OK;
 }
 
 struct Ent { int32_t row; int32_t g; };
+
+// device side of the plan enumeration (kernels k_lu_enum_*): temporaries from the pool, its own non-blocking stream -- the plan is
+// built on a background thread while the caller's stream runs an iar call, and neither may wait for the other
+struct LuGpuEnum {
+    std::vector<int64_t> pbase, lstart; std::vector<int32_t> nL;
+    double t_classify = 0.0;
+    hipStream_t st = nullptr;
+    std::vector<void*> tmp;
+    LuEnumArgs A{};
+    uint32_t* d_code = nullptr; unsigned long long* d_scan = nullptr; int32_t* d_tot = nullptr;
+    template <class T> int dev(T** d, size_t cnt) {
+        int rc = nep_pool_alloc((void**)d, std::max<size_t>(cnt, 1) * sizeof(T));
+        if (!rc) tmp.push_back((void*)*d);
+        return rc;
+    }
+    template <class T> int up(const T** d, const T* h, size_t cnt) {
+        T* p = nullptr; int rc = dev(&p, cnt); if (rc) return rc;
+        if (cnt) HIPCHK(hipMemcpyAsync(p, h, cnt * sizeof(T), hipMemcpyHostToDevice, st));
+        *d = p; return NEP_OK;
+    }
+    void release() {
+        if (st) { (void)hipStreamSynchronize(st); }
+        for (void* p : tmp) nep_pool_free(p);
+        tmp.clear();
+        if (st) { (void)hipStreamDestroy(st); st = nullptr; }
+    }
+    int classify(int64_t n, int64_t nF, const std::vector<int64_t>& urp, const std::vector<Ent>& urow, const std::vector<int64_t>& cptr,
+                 const std::vector<Ent>& cent, const int32_t* blk, const int32_t* lvl, const std::vector<uint8_t>& wide,
+                 std::vector<int32_t>& cnt_int, std::vector<int32_t>& cnt_wide, std::vector<int32_t>& tot) {
+        const int64_t nprod = pbase[n];
+        if (nprod <= 0 || nprod >= ((int64_t)1 << 31) - 2) return NEP_ERR_UNSUPPORTED;
+        HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        int rc;
+        A.nprod = nprod; A.n = (int32_t)n;
+        const LuEnt *d_urow = nullptr, *d_cent = nullptr;
+        if ((rc = up(&A.pbase, pbase.data(), n + 1)) || (rc = up(&A.lstart, lstart.data(), n)) || (rc = up(&A.nL, nL.data(), n)) ||
+            (rc = up(&A.urp, urp.data(), n + 1)) || (rc = up(&d_urow, (const LuEnt*)urow.data(), urow.size())) ||
+            (rc = up(&A.cptr, cptr.data(), n + 1)) || (rc = up(&d_cent, (const LuEnt*)cent.data(), (size_t)cptr[n])) ||
+            (rc = up(&A.blk, blk, n)) || (rc = up(&A.lvl, lvl, n)) || (rc = up(&A.wide, wide.data(), wide.size()))) return rc;
+        A.urow = d_urow; A.cent = d_cent;
+        int32_t *d_err = nullptr, *d_ci = nullptr, *d_cw = nullptr;
+        if ((rc = dev(&d_code, (size_t)nprod + 1)) || (rc = dev(&d_scan, (size_t)nprod + 1)) || (rc = dev(&d_tot, (size_t)nF)) ||
+            (rc = dev(&d_err, 1)) || (rc = dev(&d_ci, (size_t)n)) || (rc = dev(&d_cw, (size_t)n))) return rc;
+        HIPCHK(hipMemsetAsync(d_tot, 0, (size_t)nF * sizeof(int32_t), st));
+        HIPCHK(hipMemsetAsync(d_err, 0, sizeof(int32_t), st));
+        const uint32_t endcode = 3u << LU_KIND_SHIFT;
+        HIPCHK(hipMemcpyAsync(d_code + nprod, &endcode, sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_lu_enum_classify, dim3((unsigned)((nprod + 255) / 256)), dim3(256), 0, st, A, d_code, d_tot, d_err);
+        LAUNCHCHK();
+        hipcub::TransformInputIterator<unsigned long long, LuFlagOp, const uint32_t*> flags((const uint32_t*)d_code, LuFlagOp());
+        size_t tb = 0;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, d_scan, (int)(nprod + 1), st));
+        char* d_tmp = nullptr;
+        if ((rc = dev(&d_tmp, tb))) return rc;
+        HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, flags, d_scan, (int)(nprod + 1), st));
+        hipLaunchKernelGGL(k_lu_enum_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (int32_t)n, A.pbase, d_scan, d_ci, d_cw);
+        LAUNCHCHK();
+        int32_t herr = 0;
+        tot.resize((size_t)nF);
+        HIPCHK(hipMemcpyAsync(&herr, d_err, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(cnt_int.data(), d_ci, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(cnt_wide.data(), d_cw, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(tot.data(), d_tot, (size_t)nF * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (herr) { std::fill(cnt_int.begin(), cnt_int.end(), 0); std::fill(cnt_wide.begin(), cnt_wide.end(), 0); tot.clear(); return NEP_ERR_UNSUPPORTED; }
+        return NEP_OK;
+    }
+    int place(nep_lu_refac* r, int64_t n, int64_t nF, const std::vector<int64_t>& piv_ptr, const std::vector<int32_t>& newpos,
+              const std::vector<int64_t>& wide_off, const std::vector<int32_t>& udiag, const std::vector<int32_t>& segid) {
+        int rc;
+        const int64_t* d_piv = nullptr; const int32_t* d_newpos = nullptr; const int64_t* d_woff = nullptr;
+        const int32_t* d_ud = nullptr; const int32_t* d_seg = nullptr;
+        if ((rc = up(&d_piv, piv_ptr.data(), n + 1)) || (rc = up(&d_newpos, newpos.data(), n)) || (rc = up(&d_woff, wide_off.data(), n)) ||
+            (rc = up(&d_ud, udiag.data(), n)) || (rc = up(&d_seg, segid.data(), (size_t)nF))) return rc;
+        // the plan's own arrays (kept): internal triples, wide quadruples, external pairs
+        if ((rc = nep_pool_alloc((void**)&r->d_int, std::max<size_t>((size_t)r->nint * 3, 1) * sizeof(int32_t))) ||
+            (rc = nep_pool_alloc((void**)&r->d_wide, std::max<size_t>((size_t)r->nwide * 4, 1) * sizeof(int32_t))) ||
+            (rc = nep_pool_alloc((void**)&r->d_ext_src, std::max<size_t>((size_t)r->next_ * 2, 1) * sizeof(int32_t)))) return rc;
+        unsigned long long *d_kin = nullptr, *d_vin = nullptr, *d_kout = nullptr;
+        if ((rc = dev(&d_kin, (size_t)r->next_)) || (rc = dev(&d_vin, (size_t)r->next_)) || (rc = dev(&d_kout, (size_t)r->next_))) return rc;
+        hipLaunchKernelGGL(k_lu_enum_place, dim3((unsigned)((A.nprod + 255) / 256)), dim3(256), 0, st, A, (const uint32_t*)d_code,
+                           (const unsigned long long*)d_scan, d_piv, d_newpos, d_woff, d_ud, d_seg, r->d_int, r->d_wide, d_kin, d_vin);
+        LAUNCHCHK();
+        if (r->next_ > 0) {
+            int segbits = 1; while (((int64_t)1 << segbits) < (int64_t)r->nseg + 1 && segbits < 31) ++segbits;
+            size_t tb = 0;
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_kin, d_kout, d_vin, (unsigned long long*)r->d_ext_src,
+                                                      (int)r->next_, 0, 32 + segbits, st));
+            char* d_tmp = nullptr;
+            if ((rc = dev(&d_tmp, tb))) return rc;
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_kin, d_kout, d_vin, (unsigned long long*)r->d_ext_src,
+                                                      (int)r->next_, 0, 32 + segbits, st));
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        return NEP_OK;
+    }
+};
 
 }  // namespace
 
@@ -481,7 +676,26 @@ static int32_t refac_build(nep_lu_refac* r, int64_t n, const int32_t* Lp, const 
     // pass 1: counts
     std::vector<int32_t> cnt_int(n, 0), cnt_wide(n, 0);
     std::vector<std::vector<int32_t>> cnt_ext(nthr);
-    run_threads([&](int tix) {
+    std::vector<int32_t> tot;                                  // external products per destination slot
+    // ---- the same on the device (see k_lu_enum_classify): host path when switched off, in the dry run, or when it fails
+    static const bool gpu_on = !(getenv("NEP_LU_PLAN_GPU") && atoi(getenv("NEP_LU_PLAN_GPU")) == 0);
+    bool gpu = gpu_on && !g_refac_dry && nF < ((int64_t)1 << LU_KIND_SHIFT);
+    LuGpuEnum G;
+    if (gpu) {
+        G.pbase.assign(n + 1, 0); G.lstart.assign(n, 0); G.nL.assign(n, 0);
+        for (int64_t k = 0; k < n; ++k) {
+            const Ent* b = cent.data() + cptr[k]; const Ent* en = cent.data() + cptr[k + 1];
+            const Ent* it = std::upper_bound(b, en, (int32_t)k, [](int32_t v, const Ent& a) { return v < a.row; });
+            G.lstart[k] = it - cent.data(); G.nL[k] = (int32_t)(en - it);
+            // (row k of U: the diagonal entry first, the urp[k+1] - urp[k] - 1 entries right of it are the U operands)
+            G.pbase[k + 1] = G.pbase[k] + (int64_t)G.nL[k] * (urp[k + 1] - urp[k] - 1);
+        }
+        const double tg0 = now_ms();
+        const int rcg = G.classify(n, nF, urp, urow, cptr, cent, blk, lvl, r->wide, cnt_int, cnt_wide, tot);
+        G.t_classify = now_ms() - tg0;
+        if (rcg) { G.release(); gpu = false; }                 // (pattern errors are diagnosed by the host enumeration below)
+    }
+    if (!gpu) run_threads([&](int tix) {
         std::vector<int32_t>& ce = cnt_ext[tix];
         ce.assign((size_t)nF, 0);
         visit(tix, [&](int kind, int64_t k, int32_t, int32_t, int32_t gd) {
@@ -517,8 +731,10 @@ static int32_t refac_build(nep_lu_refac* r, int64_t n, const int32_t* Lp, const 
     std::vector<int32_t> ext_dst;
     r->ext_seg0.assign(nlev + 1, 0);
     {
-        std::vector<int32_t> tot((size_t)nF, 0);
-        for (int t = 0; t < nthr; ++t) { const int32_t* ce = cnt_ext[t].data(); for (int64_t g = 0; g < nF; ++g) tot[g] += ce[g]; }
+        if (!gpu) {
+            tot.assign((size_t)nF, 0);
+            for (int t = 0; t < nthr; ++t) { const int32_t* ce = cnt_ext[t].data(); for (int64_t g = 0; g < nF; ++g) tot[g] += ce[g]; }
+        }
         std::vector<int64_t> start((size_t)nF, 0);
         int64_t run = 0;
         for (int l = 0; l < nlev; ++l) {
@@ -528,7 +744,7 @@ static int32_t refac_build(nep_lu_refac* r, int64_t n, const int32_t* Lp, const 
         }
         r->ext_seg0[nlev] = (int64_t)ext_dst.size();
         if (run >= ((int64_t)1 << 31)) { nep_lu_refac_destroy(r); nep_set_error("refac: too many external products"); return NEP_ERR_UNSUPPORTED; }
-        for (int64_t g = 0; g < nF; ++g) {
+        if (!gpu) for (int64_t g = 0; g < nF; ++g) {
             if (!tot[g]) continue;
             int64_t c = start[g];
             for (int t = 0; t < nthr; ++t) { const int32_t m = cnt_ext[t][g]; cnt_ext[t][g] = (int32_t)c; c += m; }
@@ -539,7 +755,18 @@ static int32_t refac_build(nep_lu_refac* r, int64_t n, const int32_t* Lp, const 
     r->h_ext_ptr = ext_ptr;
     r->nprod = r->nint + r->nwide + r->next_;
     // pass 2: placement
-    std::vector<int32_t> itri((size_t)r->nint * 3), ext_src((size_t)r->next_ * 2), wflat((size_t)r->nwide * 4);
+    std::vector<int32_t> itri, ext_src, wflat;
+    if (gpu) {
+        // destination slot -> segment index, then placement + sort on the device: the three big arrays never exist on the host
+        std::vector<int32_t> segid((size_t)nF, -1);
+        for (int64_t sg = 0; sg < (int64_t)ext_dst.size(); ++sg) segid[ext_dst[sg]] = (int32_t)sg;
+        const double tg1 = now_ms();
+        const int rcg = G.place(r, n, nF, piv_ptr, newpos, wide_off, udiag, segid);
+        G.release();
+        if (getenv("NEP_TIMING")) fprintf(stderr, "[lu_refac] device enumeration: offsets + upload + classify + scan + counts back %.1f ms, placement + sort %.1f ms\n", G.t_classify, now_ms() - tg1);
+        if (rcg) { nep_lu_refac_destroy(r); return rcg; }
+    } else {
+    itri.resize((size_t)r->nint * 3); ext_src.resize((size_t)r->next_ * 2); wflat.resize((size_t)r->nwide * 4);
     run_threads([&](int tix) {
         int32_t* ce = cnt_ext[tix].data();
         int64_t curk = -1, ci = 0, cw = 0;
@@ -550,20 +777,26 @@ static int32_t refac_build(nep_lu_refac* r, int64_t n, const int32_t* Lp, const 
             else { const int64_t pos = ce[gd]++; ext_src[2 * pos] = gL; ext_src[2 * pos + 1] = gU; }
         });
     });
+    }
     { std::vector<std::vector<int32_t>>().swap(cnt_ext); }
     const double t_enum1 = now_ms();
     const double t_group = now_ms();
     // ---- upload
     int rc;
+    struct UpStream {
+        UpStream(bool on) { if (on && hipStreamCreateWithFlags(&g_refac_stream, hipStreamNonBlocking) != hipSuccess) g_refac_stream = nullptr; }
+        ~UpStream() { if (g_refac_stream) { (void)hipStreamDestroy(g_refac_stream); g_refac_stream = nullptr; } }
+    } up_stream(!g_refac_dry);
     std::vector<int32_t> vLp(Lp, Lp + n + 1), vLi(Li, Li + nnzL), vold(oldof, oldof + n), vse(blk_se, blk_se + 2 * nblk);
     if ((rc = upv(&r->d_amap, amap)) || (rc = upv(&r->d_ldiag, ldiag)) || (rc = upv(&r->d_udiag, udiag)) || (rc = upv(&r->d_Lp, vLp)) ||
         (rc = upv(&r->d_Li, vLi)) || (rc = upv(&r->d_oldof, vold)) || (rc = upv(&r->d_blk_se, vse)) || (rc = upv(&r->d_piv_ptr, piv_ptr)) ||
-        (rc = upv(&r->d_int, itri)) || (rc = upv(&r->d_ext_ptr, ext_ptr)) || (rc = upv(&r->d_ext_dst, ext_dst)) ||
-        (rc = upv(&r->d_ext_src, ext_src)) || (rc = upv(&r->d_wide, wflat))) { nep_lu_refac_destroy(r); return rc; }
+        (!gpu && (rc = upv(&r->d_int, itri))) || (rc = upv(&r->d_ext_ptr, ext_ptr)) || (rc = upv(&r->d_ext_dst, ext_dst)) ||
+        (!gpu && (rc = upv(&r->d_ext_src, ext_src))) || (!gpu && (rc = upv(&r->d_wide, wflat)))) { nep_lu_refac_destroy(r); return rc; }
+    r->gpu_enumerated = gpu;
     r->t_symbolic_ms = now_ms() - t0;
     if (getenv("NEP_TIMING"))
-        fprintf(stderr, "[lu_refac] columns %.1f ms, A map + weights %.1f, enumeration %.1f (%d threads), grouping %.1f, upload %.1f\n",
-                t_cols - t0, t_enum0 - t_cols, t_enum1 - t_enum0, nthr, t_group - t_enum1, now_ms() - t_group);
+        fprintf(stderr, "[lu_refac] columns %.1f ms, A map + weights %.1f, enumeration %.1f (%s, %d host threads), grouping %.1f, upload %.1f\n",
+                t_cols - t0, t_enum0 - t_cols, t_enum1 - t_enum0, gpu ? "device" : "host", nthr, t_group - t_enum1, now_ms() - t_group);
     if (getenv("NEP_TIMING"))
         fprintf(stderr, "[lu_refac] n=%lld products %lld (internal %lld, external %lld in %lld segments, wide %lld in %lld steps), symbolic %.1f ms\n",
                 (long long)n, (long long)r->nprod, (long long)r->nint, (long long)r->next_, (long long)r->nseg, (long long)r->nwide,
@@ -574,6 +807,32 @@ static int32_t refac_build(nep_lu_refac* r, int64_t n, const int32_t* Lp, const 
 
 int32_t nep_lu_factor_dev_batch(nep_lu_refac* r, int32_t B, const nep_cdouble* h_Ax, int32_t expected_solves, double growth_limit,
                                 double* h_health, nep_cdouble* h_LUx_out, nep_lu** out, nep_stream stream);
+
+// out[0] = the hash nep_lu_refac_analyze puts in its out[7], computed from the plan arrays AS THEY SIT ON THE DEVICE (downloaded);
+// out[1] = 1 when the product arrays were enumerated on the device.  Test: a device-built plan equals the host enumeration bit for bit.
+int32_t nep_lu_refac_hash(const nep_lu_refac* r, int64_t out[2]) {
+    ARGCHK(r && out && !r->host_only);
+    HIPCHK(hipDeviceSynchronize());
+    uint64_t x = 0xCBF29CE484222325ull;
+    std::vector<unsigned char> buf;
+    auto fold = [&](const void* d, size_t cnt, size_t esz) -> int {
+        buf.resize(cnt * esz);
+        if (cnt) HIPCHK(hipMemcpy(buf.data(), d, cnt * esz, hipMemcpyDeviceToHost));
+        x ^= 0x9E3779B97F4A7C15ull * (cnt + 1);
+        for (size_t i = 0; i < cnt * esz; ++i) { x ^= buf[i]; x *= 0x100000001B3ull; }
+        return NEP_OK;
+    };
+    int rc;
+    if ((rc = fold(r->d_amap, (size_t)r->nnzA, 4)) || (rc = fold(r->d_ldiag, (size_t)r->n, 4)) || (rc = fold(r->d_udiag, (size_t)r->n, 4)) ||
+        (rc = fold(r->d_Lp, (size_t)r->n + 1, 4)) || (rc = fold(r->d_Li, (size_t)r->nnzL, 4)) || (rc = fold(r->d_oldof, (size_t)r->n, 4)) ||
+        (rc = fold(r->d_blk_se, (size_t)2 * r->nblk, 4)) || (rc = fold(r->d_piv_ptr, (size_t)r->n + 1, 8)) ||
+        (rc = fold(r->d_int, (size_t)r->nint * 3, 4)) || (rc = fold(r->d_ext_ptr, (size_t)r->nseg + 1, 8)) ||
+        (rc = fold(r->d_ext_dst, (size_t)r->nseg, 4)) || (rc = fold(r->d_ext_src, (size_t)r->next_ * 2, 4)) ||
+        (rc = fold(r->d_wide, (size_t)r->nwide * 4, 4))) return rc;
+    out[0] = (int64_t)(x >> 1);
+    out[1] = r->gpu_enumerated ? 1 : 0;
+    return NEP_OK;
+}
 
 int32_t nep_lu_refac_info(const nep_lu_refac* r, int64_t out[6]) {
     ARGCHK(r && out);

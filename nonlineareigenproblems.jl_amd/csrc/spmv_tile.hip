@@ -334,20 +334,38 @@ __global__ __launch_bounds__(256) void k_tile_resid(const TileDesc* __restrict__
 // once.  Measured at n = 1 003 995: k = 8 0.081 ms (0.35 of the HBM roofline; wave-per-row kernel 0.57 ms, row-major tiles
 // 0.124 ms), k = 60 0.51 ms (0.26; 0.73 / 0.95 ms).  Two other forms were built, measured and removed: the panel loop inside
 // the workgroup with the entries in registers (512 threads, one workgroup per CU: 0.88 ms at k = 60), and a software-pipelined
-// one (next panel's loads in flight during the reduction, two LDS tiles: 0.62-0.74 ms) -- a workgroup's chain descriptor ->
-// footprint -> Q -> barrier -> entries is what bounds all three, and the short-lived workgroups of this form overlap best.
+// one (next panel's loads in flight during the reduction, two LDS tiles: 0.62-0.74 ms); fetching the thread's entries into registers
+// ahead of the gather and its barrier (what helps K1) changed nothing either (0.52-0.54 ms).  What all forms share is phase 2's LDS
+// traffic: rows x 8 entries x k columns x 16 B = 7.7 GB of 16-byte reads at k = 60, two- to three-way bank conflicts at the 32-byte
+// stride of a 2-column tile -- about 0.3 ms of LDS pipe per CU however the panels are arranged; the short-lived workgroups of this
+// form overlap it best with the gathers.  Launch order (round 3, late): one-dimensional, the panels of a block back to back on ONE
+// XCD, so that the block's entries and footprint list are L2 hits for all but the first panel: 0.531 -> 0.500 ms at k = 60,
+// 0.082 -> 0.076 at k = 8 (NEP_K2_CM_ORDER=0: panels as grid.y, a block's workgroups rotate over the XCDs).
 template <typename VT, int MT, int PS, bool NT>
 __global__ __launch_bounds__(256) void k_tile_resid_cm(const TileDesc* __restrict__ desc, const uint32_t* __restrict__ fp,
                                                        const uint16_t* __restrict__ eidx, const VT* __restrict__ eval,
                                                        const cplx* __restrict__ Q, int64_t ldq, int k, const cplx* __restrict__ F,
                                                        int mt, int fcap, int lbits, cplx* __restrict__ R, int64_t ldr,
-                                                       double* __restrict__ partial, int swz, int64_t split_row) {
+                                                       double* __restrict__ partial, int swz, int64_t split_row, int nblk, int npan) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cplx* Qt = (cplx*)smem;                                 // [fcap][PS]
     double* wsum = (double*)(Qt + (size_t)fcap * PS);       // [2][4 waves][PS]
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int blk = tile_block(swz);
-    const int p0 = (int)blockIdx.y * PS;
+    int blk, p0;
+    if (gridDim.y == 1 && npan > 0) {
+        // one-dimensional launch, panel fastest INSIDE an XCD (workgroup id % 8 = XCD): the npan workgroups that share a block's
+        // entries and footprint list run back to back on the same L2.  (With the panels as grid.y a block's workgroups sit nblk ids
+        // apart and rotate over the XCDs unless nblk % 8 == 0: every panel fetched the entries again.)
+        const int x = blockIdx.x & 7, i = blockIdx.x >> 3;
+        const int per = nblk >> 3, rem = nblk & 7;
+        const int tl = i / npan;
+        if (tl >= per + (x < rem ? 1 : 0)) return;
+        blk = x * per + (x < rem ? x : rem) + tl;
+        p0 = (i - tl * npan) * PS;
+    } else {
+        blk = tile_block(swz);
+        p0 = (int)blockIdx.y * PS;
+    }
     const int pw = min(PS, k - p0);
     const TileDesc d = desc[blk];
     const int Fn = d.fp_cnt;
@@ -391,7 +409,7 @@ __global__ __launch_bounds__(256) void k_tile_resid_cm(const TileDesc* __restric
 #pragma unroll 4
         for (int j = 0; j < width; ++j) {
             const int64_t e = (int64_t)j * rb + l;
-            const uint32_t id = ib[e];                      // (re-read by the other panels of the block: regular loads, L2)
+            const uint32_t id = ib[e];                      // (re-read by the other panels of the block: L2 hits, see the launch order)
             const VT a = vb[e];
             const int t = id >> lbits;
             const cplx* tp = Qt + (size_t)(id & lmask) * PS;
@@ -757,7 +775,10 @@ int nep_tiles_resid_cm(const NepTiles* t, int k, const cplx* dF, const cplx* Q, 
     if (shm > 160 * 1024) { nep_set_error("tiled K2 (column-major): footprint too large"); return NEP_ERR_ARG; }
     static const int swz = env_int("NEP_XCD_SWIZZLE", 1);
     const bool nt = t->n >= 32768;
-    const dim3 grid((unsigned)t->nblk, (unsigned)((k + ps - 1) / ps));
+    const int npan = (k + ps - 1) / ps;
+    static const int order = env_int("NEP_K2_CM_ORDER", 1);      // 1: panels of a block back to back on one XCD (1-D launch); 0: panels as grid.y
+    const dim3 grid = order ? dim3((unsigned)(8 * ((t->nblk + 7) / 8) * npan)) : dim3((unsigned)t->nblk, (unsigned)npan);
+    const int npan_arg = order ? npan : 0;
 #define RC(VT, M, P, NTF)                                                                                                      \
     do {                                                                                                                       \
         if (shm > 64 * 1024) {                                                                                                 \
@@ -769,7 +790,7 @@ int nep_tiles_resid_cm(const NepTiles* t, int k, const cplx* dF, const cplx* Q, 
         }                                                                                                                      \
         hipLaunchKernelGGL((k_tile_resid_cm<VT, M, P, NTF>), grid, dim3(256), shm, st, (const TileDesc*)t->d_desc,             \
                            (const uint32_t*)t->d_fp, (const uint16_t*)t->d_eidx, (const VT*)t->d_eval, Q, ldq, k, dF, t->mt,   \
-                           t->fcap, t->lbits, R, ldr, partial, swz, split_row);                                                \
+                           t->fcap, t->lbits, R, ldr, partial, swz, split_row, t->nblk, npan_arg);                             \
     } while (0)
 #define RC_M(VT, P, NTF) do { switch (t->mt) { case 1: RC(VT, 1, P, NTF); break; case 2: RC(VT, 2, P, NTF); break; case 3: RC(VT, 3, P, NTF); break; default: RC(VT, 4, P, NTF); break; } } while (0)
 #define RC_P(VT, NTF) do { if (ps == 8) RC_M(VT, 8, NTF); else if (ps == 2) RC_M(VT, 2, NTF); else RC_M(VT, 4, NTF); } while (0)

@@ -325,6 +325,14 @@ class AbstractSPMF(NEP):
     def dev(self):
         if self._dev is None:
             self._dev = SPMFDevice(self.get_Av())
+            # the other one-off derived data of the matrices (Frobenius norms for the error measures, the term values on the union
+            # pattern for compute_Mder / the device LU) are built with the upload, not inside the first solver call
+            try:
+                self.fro_norms()
+                if self.issparse():
+                    self._aligned_terms()
+            except Exception:
+                pass
         return self._dev
 
     # ---- element type of host results (test/compute_types.jl): the reference returns promote_type(eltype(nep), typeof(lam),
@@ -445,9 +453,7 @@ class AbstractSPMF(NEP):
                 assert np.array_equal(keyU[pos], key)
                 D[pos, t] = M.data
             indices = (keyU % n).astype(np.int32)
-            indptr = np.zeros(n + 1, dtype=np.int32)
-            np.add.at(indptr, (keyU // n) + 1, 1)
-            indptr = np.cumsum(indptr).astype(np.int32)
+            indptr = np.concatenate(([0], np.cumsum(np.bincount(keyU // n, minlength=n)))).astype(np.int32)
 
             class _U:                                                      # the three attributes the caller reads
                 pass
@@ -544,8 +550,11 @@ class AbstractSPMF(NEP):
 
     def fro_norms(self):
         if self._fro is None:
-            self._fro = [float(np.linalg.norm(A.data)) if sp.issparse(A) else float(np.linalg.norm(A))
-                         for A in self.get_Av()]
+            # (sum of squares without BLAS: no thread-pool start-up for a handful of norms)
+            def fro(x):
+                x = np.asarray(x).ravel()
+                return float(np.sqrt(np.sum(x.real * x.real) + (np.sum(x.imag * x.imag) if np.iscomplexobj(x) else 0.0)))
+            self._fro = [fro(A.data) if sp.issparse(A) else fro(A) for A in self.get_Av()]
         return self._fro
 
 

@@ -1,3 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/b22
-python scripts/diag/k7_timing.py > gpurun_out/b22/k7_timing.jsonl 2>&1
+export TMPDIR=/tmp
+mkdir -p gpurun_out/b26
+timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/b26/pytest.log 2>&1
+python bench.py --steps 20 --warmup 5 > gpurun_out/b26/bench.json 2> gpurun_out/b26/bench.err
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/b26/smoke.log 2>&1

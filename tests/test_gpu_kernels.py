@@ -693,6 +693,34 @@ def test_concurrent_lu_create_solve_stress(na):
     assert np.linalg.norm(mats[0] @ na.to_host(Xm) - B) <= 1e-9 * np.linalg.norm(B)
 
 
+@pytest.mark.parametrize("n", [1310, 9956])
+def test_device_plan_enumeration_equals_host_enumeration(na, n):
+    """csrc/lufac.hip, round 3: the products of the refactorisation plan are enumerated, classified and placed ON THE DEVICE
+    (k_lu_enum_*, one scan + one radix sort).  The plan arrays downloaded from the device hash to the value of the host-only
+    enumeration of the same inputs (nep_lu_refac_analyze), i.e. they are bit-identical; gun pattern at test size and at full size."""
+    import ctypes as C
+    import scipy.sparse as sp
+    from oracle import gallery as og
+    from nep_amd._lib import lib, check, hptr, c_vp
+    import nep_amd_hostlu as hl
+    onep = og.gun_spmf_scaled(n)
+    A0 = sp.csc_matrix(onep.compute_Mder(0.0)).astype(np.complex128)
+    F = hl.factor(A0.data, A0.indices, A0.indptr, A0.shape)
+    ref = na.DeviceLU(factors=F)
+    arrs = [np.ascontiguousarray(F[k], dtype=np.int32) for k in ("Lp", "Li", "Up", "Ui", "perm_r", "perm_c")]
+    Ap = np.ascontiguousarray(A0.indptr, dtype=np.int32); Ai = np.ascontiguousarray(A0.indices, dtype=np.int32)
+    ana = (C.c_int64 * 8)()
+    check(lib.nep_lu_refac_analyze(n, *[hptr(a) for a in arrs], hptr(Ap), hptr(Ai), ana))
+    h = c_vp()
+    check(lib.nep_lu_refac_create(ref.h, n, *[hptr(a) for a in arrs], hptr(Ap), hptr(Ai), C.byref(h)))
+    info = (C.c_int64 * 6)(); check(lib.nep_lu_refac_info(h, info))
+    hh = (C.c_int64 * 2)(); check(lib.nep_lu_refac_hash(h, hh))
+    lib.nep_lu_refac_destroy(h)
+    assert hh[1] == 1, "the plan was not enumerated on the device"
+    assert (info[1], info[2], info[3], info[4]) == (ana[0], ana[1], ana[2], ana[3])
+    assert hh[0] == ana[7]
+
+
 def test_device_numeric_factorization(na, monkeypatch):
     """csrc/lufac.hip: the second matrix of a sparsity pattern is factorised on the GPU with the pivot sequence of the first
     (host) factorisation: L and U equal the host factor's to round-off, the solves agree, a growth limit that is not met
