@@ -72,7 +72,7 @@ def parse():
     ap.add_argument("--no-c5-oracle", action="store_true", help="skip the CPU oracle of the C5 twin (about 40 s)")
     ap.add_argument("--c5-nx", type=int, default=1003)
     ap.add_argument("--c5-nz", type=int, default=999)
-    ap.add_argument("--only", default=None, choices=["orth", "k5", "mlincomb", "wepscale"],
+    ap.add_argument("--only", default=None, choices=["orth", "k5", "mlincomb", "wepscale", "c5step"],
                     help="run only one fixed-shape kernel loop (the command the committed rocprofv3 summaries come from)")
     ap.add_argument("--reps", type=int, default=50)
     return ap.parse_args()
@@ -262,6 +262,40 @@ def c3_summary(na, args):
     return out
 
 
+def c5_step_roofline(na, nx=1003, nz=999, N=37, reps=50):
+    """config C5's inner loop: ONE preconditioned operator step w = Pl^{-1} S v of the Schur-complement GMRES (Waveguide.jl:398-446,
+    the reference's linear solver for this problem) at n = 1e6, timed with HIP events as the solver issues it (one hipGraph replay) and
+    in its two halves.  Algorithmic bytes: S v = K1 at k = 1 on the three waveguide matrices plus the interior
+    vector once more for the boundary update (16 N); Pl^{-1} = the interior vector read and written once (32 N) -- the transforms and
+    tridiagonal sweeps of the Sylvester solve are traffic of the implementation, not of the operation."""
+    from nep_amd import wep_linsolvers as wl
+    nep = na.nep_gallery("WEP", nx=nx, nz=nz, benchmark_problem="JARLEBRING"); nep.dev
+    sigma = -3 - 3.5j
+    P = na.wep_generate_preconditioner(nep, N, sigma)
+    cr = na.WEPLinSolverCreator(solver_type="gmres", kwargs=(("Pl", P), ("reltol", 1e-9), ("restart", 60), ("maxiter", 300)), refinements=0)
+    solver = na.create_linsolver(cr, nep, sigma)
+    ops = solver.ops
+    Nn = ops.N
+    v = torch.randn(Nn, dtype=torch.float64, device="cuda").to(torch.complex128); w = torch.empty_like(v)
+    b_op = nep.dev.algorithmic_bytes(1) + 16.0 * Nn
+    b_pre = 32.0 * Nn
+    ms_op = event_loop(lambda: ops.matvec(v, w), reps, warm=5)
+    prec = solver.gmres._Pl_call
+    ms_pre = event_loop(lambda: prec(w), reps, warm=5)
+    out = {"workload": "WEP JARLEBRING nx=%d nz=%d (N = %d interior unknowns), sigma = -3-3.5i, preconditioner %d x %d regions" % (nx, nz, Nn, N, N + 4),
+           "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "schur_matvec": {"algorithmic_bytes": b_op, "ms": ms_op, "achieved": b_op / ms_op / 1e6, "frac": b_op / ms_op / 1e6 / HBM_PEAK_GBS},
+           "preconditioner": {"algorithmic_bytes": b_pre, "ms": ms_pre, "achieved": b_pre / ms_pre / 1e6, "frac": b_pre / ms_pre / 1e6 / HBM_PEAK_GBS}}
+    fused = getattr(solver.gmres, "fused_step", None)
+    if fused is not None:
+        ms_st = event_loop(lambda: fused(v, w), reps, warm=5)
+        out["step_as_issued"] = {"what": "copy in + hipGraph replay of S v and Pl^{-1} + copy out (what one GMRES iteration launches besides its "
+                                         "Gram-Schmidt pass)", "algorithmic_bytes": b_op + b_pre, "ms": ms_st,
+                                 "achieved": (b_op + b_pre) / ms_st / 1e6, "frac": (b_op + b_pre) / ms_st / 1e6 / HBM_PEAK_GBS}
+    return out
+
+
+
 def c5_summary(na, args):
     import baseline_configs as bc
     tm = {}
@@ -328,6 +362,24 @@ def wep_scale_roofline(na):
         out["K2 k=%d" % k] = {"kernel": "nep_resid_batch_dev", "algorithmic_bytes": b, "ms_per_launch": ms, "achieved": b / ms / 1e6,
                               "frac": b / ms / 1e6 / HBM_PEAK_GBS}
         del QT
+    # the same residual batch on a COLUMN-major Ritz block (nep_resid_batch_cm_dev: what K7 writes with y_rowmajor = 0 and what a Julia
+    # host holds; the row-major rows above are what this package's own drivers call)
+    try:
+        import ctypes as C_
+        from nep_amd._lib import lib, hptr, c_vp
+        for k in (8, 60):
+            Qc = torch.randn((k, n), dtype=torch.float64, device="cuda").to(torch.complex128)
+            Fm = np.asfortranarray(np.random.default_rng(1).standard_normal((dev.mt, k)) + 0j)
+            oc = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+            call = lambda: lib.nep_resid_batch_cm_dev(dev.h, k, hptr(Fm), c_vp(Qc.data_ptr()), n, -1, c_vp(oc.data_ptr()), None, 0, None)
+            if call() == 0:
+                ms = event_loop(call, 10, warm=3)
+                b = dev.matrix_bytes + 16 * n * k
+                out["K2 column-major k=%d" % k] = {"kernel": "nep_resid_batch_cm_dev", "algorithmic_bytes": b, "ms_per_launch": ms,
+                                                   "achieved": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS}
+            del Qc
+    except Exception as e:
+        out["K2 column-major"] = {"error": repr(e)[:200]}
     # K7 (tall-skinny FP64-MFMA GEMM, the Ritz block Q = V Z of tiar / iar: src/method_tiar.jl:188-189, src/method_iar.jl:115) at the
     # tiar m = 60 shape, B resident on the device (nep_gemm_ts_dev: fragment expansion kernel + the GEMM kernel per call), HIP
     # events around 50 back-to-back calls after 30 warm-up calls (the first ~15 ms of FP64-MFMA work after memory-bound kernels run
@@ -484,6 +536,8 @@ def main():
             print(json.dumps(k5_roofline(na, nep, args, reps=args.reps)))
         elif args.only == "wepscale":
             print(json.dumps(wep_scale_roofline(na)))
+        elif args.only == "c5step":
+            print(json.dumps(c5_step_roofline(na)))
         else:
             for k in (args.maxit, 1):
                 b, ms = mlincomb_roofline(na, nep, k, reps=args.reps)
@@ -696,6 +750,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_c5:
         try:
             out["c5_wep"] = c5_summary(na, args)
+            try:
+                if args.c5_nx == 1003 and args.c5_nz == 999:
+                    out["c5_wep"]["roofline_operator_step"] = c5_step_roofline(na)
+            except Exception as e:
+                out["c5_wep"]["roofline_operator_step"] = {"error": repr(e)[:300]}
         except Exception as e:
             out["c5_wep"] = {"error": repr(e)[:300]}
     if use_dist:

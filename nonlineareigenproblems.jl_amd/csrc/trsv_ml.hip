@@ -86,6 +86,7 @@ struct MLFactor {
     // the apex is built BEHIND the `ready` event: solves that arrive before it is finished walk the apex levels like any
     // other level (22 us more per gun solve) instead of waiting 3.3 ms for it; apex_live flips when apex_ev has completed
     hipEvent_t apex_ev = nullptr; bool apex_live = false;
+    int solves_since_numeric = 0;      // the switch to the apex happens at a FIXED solve of a factor (NEP_ML_APEX_AT), not when a query says so
     double* d_rscale = nullptr;    // optional row scaling (UMFPACK's Rs): b is multiplied by it on the way in
     NepScratch work;               // bw | y | x | tmp, each n*nrhs
     hipEvent_t ready = nullptr;    // numeric build complete (recorded on the build stream)
@@ -881,6 +882,7 @@ static int choose_apex(const MLSym* S, int expected_solves);
 static int ml_finish_numeric(MLFactor* F, hipStream_t bst) {
     static const int apex_sync = getenv("NEP_ML_APEX_SYNC") ? atoi(getenv("NEP_ML_APEX_SYNC")) : 0;
     F->apex_live = false;
+    F->solves_since_numeric = 0;
     F->synced_valid = false;
     if (F->graph) { (void)hipGraphExecDestroy(F->graph); F->graph = nullptr; }
     if (F->apex_la > 0 && apex_sync) {          // old behaviour: nothing may start before the apex exists
@@ -1568,11 +1570,23 @@ int ml_solve(MLFactor* F, int nrhs, const nep_cdouble* dB, int64_t ldb, const ne
         HIPCHK(hipEventRecord(ev, F->last)); HIPCHK(hipStreamWaitEvent(st, ev, 0)); (void)hipEventDestroy(ev);
     }
     if (!F->synced_valid || F->synced != st) { HIPCHK(hipStreamWaitEvent(st, F->ready, 0)); F->synced = st; F->synced_valid = true; }
-    if (F->apex_la > 0 && !F->apex_live && F->apex_ev && hipEventQuery(F->apex_ev) == hipSuccess) {
-        HIPCHK(hipStreamWaitEvent(st, F->apex_ev, 0));             // complete already: orders st behind the build stream formally
-        F->apex_live = true;
-        if (F->graph) { (void)hipGraphExecDestroy(F->graph); F->graph = nullptr; }
-    } else if (F->apex_la > 0 && !F->apex_live) (void)hipGetLastError();     // hipErrorNotReady of the query
+    // Which solve of a factor first uses the dense apex is FIXED (the two paths round differently: a switch point that depended on
+    // host / device timing made iar iterates differ from run to run in the last bits): solve number NEP_ML_APEX_AT
+    // (default 12: the 3.3 ms build has finished by then in every run measured) waits for the build on the stream -- the host
+    // never blocks -- and every later solve takes the apex.  NEP_ML_APEX_AT=0: as soon as a query finds the build finished (round 2).
+    static const int apex_at = getenv("NEP_ML_APEX_AT") ? atoi(getenv("NEP_ML_APEX_AT")) : 12;
+    if (F->apex_la > 0 && !F->apex_live && F->apex_ev) {
+        bool take = false;
+        if (apex_at > 0) take = F->solves_since_numeric >= apex_at;
+        else if (hipEventQuery(F->apex_ev) == hipSuccess) take = true;
+        else (void)hipGetLastError();                               // hipErrorNotReady of the query
+        if (take) {
+            HIPCHK(hipStreamWaitEvent(st, F->apex_ev, 0));
+            F->apex_live = true;
+            if (F->graph) { (void)hipGraphExecDestroy(F->graph); F->graph = nullptr; }
+        }
+    }
+    ++F->solves_since_numeric;
     int rc;
     const size_t need = (size_t)4 * n * nrhs * sizeof(cplx);
     if (F->work.cap < need) {          // the old block may still be in use by solves in flight on F->last

@@ -34,6 +34,16 @@ struct nep_wep_sylv {
     double b = 0.0;
 };
 
+// workgroup -> column group, XCD-contiguous (workgroup id % 8 = XCD): the groups an XCD works on at one time are neighbours in x, so
+// the 64-byte pieces they write to (read from) one mode row of the transposed block are neighbours too -- its L2 sees 2 KB runs per
+// row instead of every other 64-byte piece of a line belonging to another XCD (NEP_WEP_DFT_XCD=0: group = workgroup id as before)
+__device__ __forceinline__ int dft_group(int xcd_order) {
+    const int b = blockIdx.x, nb = gridDim.x;
+    if (!xcd_order) return b;
+    const int x = b & 7, i = b >> 3, per = nb >> 3, rem = nb & 7;
+    return x * per + (x < rem ? x : rem) + i;
+}
+
 // ---- prime-factor DFT of COLS columns per workgroup ---------------------------------------------------------------------
 // FWD = true : in  X (z fastest, column x at X + x*nz), out T (x fastest, mode i at T + i*nx), exponent sign `sgn`
 // FWD = false: in  T (x fastest), out X (z fastest)
@@ -41,13 +51,13 @@ template <bool FWD, int COLS>
 __global__ __launch_bounds__(1024) void k_dft_cols(int nz, int nx, int N1, int N2, const int32_t* __restrict__ in_idx,
                                                    const int32_t* __restrict__ out_idx, const cplx* __restrict__ w1,
                                                    const cplx* __restrict__ w2, double sgn, double scale,
-                                                   const cplx* __restrict__ src, cplx* __restrict__ dst) {
+                                                   const cplx* __restrict__ src, cplx* __restrict__ dst, int xcd_order) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* xs = (cplx*)smem_raw;                 // [q][COLS], natural (n1, n2) order q = n1 N2 + n2
     cplx* ts = xs + (size_t)COLS * nz;          // [q][COLS], q = k1 N2 + n2
     cplx* r1 = ts + (size_t)COLS * nz;          // N1 roots
     cplx* r2 = r1 + N1;                         // N2 roots
-    const int x0 = blockIdx.x * COLS;
+    const int x0 = dft_group(xcd_order) * COLS;
     const int nc = min(COLS, nx - x0);
     const int nt = blockDim.x;
     for (int t = threadIdx.x; t < N1; t += nt) r1[t] = cmake(w1[t].x, sgn * w1[t].y);
@@ -119,14 +129,14 @@ __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int
                                                       const int32_t* __restrict__ in_inv,
                                                       const int32_t* __restrict__ out_idx, const cplx* __restrict__ w1,
                                                       const cplx* __restrict__ w2, double sgn, double scale,
-                                                      const cplx* __restrict__ src, cplx* __restrict__ dst) {
+                                                      const cplx* __restrict__ src, cplx* __restrict__ dst, int xcd_order) {
     constexpr int COLS = 4, KB = 3;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* xs = (cplx*)smem_raw;                 // [q][COLS], q = n1 N2 + n2
     cplx* ts = xs + (size_t)COLS * nz;          // [q][COLS], q = k1 N2 + n2
     cplx* r1 = ts + (size_t)COLS * nz;
     cplx* r2 = r1 + N1;
-    const int x0 = blockIdx.x * COLS;
+    const int x0 = dft_group(xcd_order) * COLS;
     const int nc = min(COLS, nx - x0);
     const int nt = blockDim.x;
     for (int t = threadIdx.x; t < N1; t += nt) r1[t] = cmake(w1[t].x, sgn * w1[t].y);
@@ -559,12 +569,13 @@ int32_t nep_wep_sylv_solve(nep_wep_sylv* s, nep_cdouble* dX, nep_stream stream) 
     const int threads = nz >= 768 ? 1024 : (nz >= 384 ? 512 : 256);
 #define DFT_LAUNCH(F_, C_, SGN_, SRC_, DST_)                                                                               \
     hipLaunchKernelGGL((k_dft_cols<F_, C_>), grid, dim3(threads), shm, st, nz, nx, s->N1, s->N2, (const int32_t*)s->d_in,    \
-                       (const int32_t*)s->d_out, (const cplx*)s->d_w1, (const cplx*)s->d_w2, SGN_, scale, SRC_, DST_)
+                       (const int32_t*)s->d_out, (const cplx*)s->d_w1, (const cplx*)s->d_w2, SGN_, scale, SRC_, DST_, xcd_order)
+    static const int xcd_order = getenv("NEP_WEP_DFT_XCD") ? atoi(getenv("NEP_WEP_DFT_XCD")) : 1;
     static const int rb = getenv("NEP_WEP_DFT_RB") ? atoi(getenv("NEP_WEP_DFT_RB")) : 1;
 #define DFT_BY_COLS(F_, SGN_, SRC_, DST_)                                                                                  \
     do { if (s->cols == 4 && rb)                                                                                            \
              hipLaunchKernelGGL((k_dft_cols_rb<F_>), grid, dim3(384), shm, st, nz, nx, s->N1, s->N2, (const int32_t*)s->d_in, \
-                                (const int32_t*)s->d_in_inv, (const int32_t*)s->d_out, (const cplx*)s->d_w1, (const cplx*)s->d_w2, SGN_, scale, SRC_, DST_); \
+                                (const int32_t*)s->d_in_inv, (const int32_t*)s->d_out, (const cplx*)s->d_w1, (const cplx*)s->d_w2, SGN_, scale, SRC_, DST_, xcd_order); \
          else if (s->cols == 4) DFT_LAUNCH(F_, 4, SGN_, SRC_, DST_); else if (s->cols == 2) DFT_LAUNCH(F_, 2, SGN_, SRC_, DST_);  \
          else DFT_LAUNCH(F_, 1, SGN_, SRC_, DST_); } while (0)
     // F^H X : exponent +, result transposed into T

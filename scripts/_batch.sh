@@ -1,6 +1,7 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-mkdir -p gpurun_out/b26
-timeout 2400 python -m pytest tests -m gpu -x -q > gpurun_out/b26/pytest.log 2>&1
-python bench.py --steps 20 --warmup 5 > gpurun_out/b26/bench.json 2> gpurun_out/b26/bench.err
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/b26/smoke.log 2>&1
+mkdir -p gpurun_out/b28
+for at in 0 24 40 56 12 0 40; do
+NEP_ML_APEX_AT=$at python bench.py --steps 30 --warmup 5 --no-c5 --no-cold 2>/dev/null | python -c "
+import sys,json
+j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$at', j['value'], j['ms_per_step'])" >> gpurun_out/b28/apex_at.txt
+done

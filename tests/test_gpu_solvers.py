@@ -82,6 +82,23 @@ def test_iar_gun_twin_vs_oracle(na):
                 assert 0.1 < a / b < 10
 
 
+def test_iar_runs_are_bit_reproducible(na):
+    """two iar calls on the same problem return bit-identical eigenvalues and vectors once the pattern's device-LU plan exists
+    (K5's switch from the level sweep to the dense apex used to happen when a query found the background build
+    finished, i.e. at a timing-dependent solve; now at a fixed solve of each factor, NEP_ML_APEX_AT)"""
+    from nep_amd.linsolvers import _DeviceRefactor
+    n, m = 9956, 60
+    nep = na.nep_gallery("gun_spmf_scaled", n)
+    kw = dict(sigma=0.0, gamma=1.0, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10)
+    na.iar(nep, **kw); _DeviceRefactor.wait()
+    runs = [na.iar(nep, **kw) for _ in range(3)]
+    l0, Q0 = np.asarray(runs[0][0]), np.asarray(runs[0][1])
+    assert len(l0) >= 1
+    for lam, Q, _ in runs[1:]:
+        assert np.array_equal(np.asarray(lam).view(np.float64), l0.view(np.float64))
+        assert np.array_equal(np.asarray(Q).view(np.float64), Q0.view(np.float64))
+
+
 def test_transf_shift_and_scale_iar_qdep0(na):
     """test/transf.jl:44-52 on the device path: the recipe of config C2 (shift_and_scale + iar) on the in-tree sparse SPMF
     qdep0; residuals evaluated by the ORACLE on the original problem < sqrt(eps); eigenvalues equal the oracle's"""
