@@ -1,7 +1,6 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/b28
-for at in 0 24 40 56 12 0 40; do
-NEP_ML_APEX_AT=$at python bench.py --steps 30 --warmup 5 --no-c5 --no-cold 2>/dev/null | python -c "
-import sys,json
-j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$at', j['value'], j['ms_per_step'])" >> gpurun_out/b28/apex_at.txt
-done
+export TMPDIR=/tmp
+rm -rf gpurun_out/r3p
+bash scripts/make_profiles_r3.sh > gpurun_out/make_profiles.log 2>&1
+mkdir -p gpurun_out/b29
+python bench.py --steps 20 --warmup 5 > gpurun_out/b29/bench.json 2> gpurun_out/b29/bench.err
