@@ -279,7 +279,8 @@ __global__ __launch_bounds__(256) void k_spmm_rm(const int32_t* __restrict__ row
                                                  const VT* __restrict__ vals, int64_t n, int mt, int k,
                                                  const cplx* __restrict__ F, const cplx* __restrict__ XT,
                                                  int64_t ldx, int xoff, cplx* __restrict__ ZT, int64_t ldz,
-                                                 double* __restrict__ partial /* [grid][2][k] or null */, int64_t split_row) {
+                                                 double* __restrict__ partial /* [grid][2][k] or null */, int64_t split_row,
+                                                 int xcd_rows) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* Fs = (cplx*)smem_raw;                       // mt*k coefficients (if F)
     double* red = (double*)(Fs + (F ? mt * k : 0));   // [4][2][NCH*64]
@@ -293,7 +294,19 @@ __global__ __launch_bounds__(256) void k_spmm_rm(const int32_t* __restrict__ row
 #pragma unroll
     for (int c = 0; c < NCH; ++c) { rn[c] = 0.0; qn[c] = 0.0; }
 
-    for (int64_t row = blockIdx.x * 4LL + w; row < n; row += gridDim.x * 4LL) {
+    // rows -> workgroups, XCD-contiguous (workgroup id % 8 = XCD) for large matrices: XCD x sweeps the rows [x per, (x + 1) per) with
+    // its own workgroups, so the rows of XT a stencil row gathers (i, i +- 1, i +- n_z: a megabyte apart at k = 60) can come from ITS
+    // L2 (with the plain grid-stride mapping consecutive 4-row chunks go to different XCDs).  xcd_rows = 0: grid-stride mapping.
+    // Measured at n = 1e6: no difference in time (0.728 / 0.734 ms at k = 60) -- this kernel is bound by instruction issue (one
+    // wave per row, ~60 instructions per entry, 12 % of the lanes busy at k = 8), not by bytes: 0.55 / 0.69 / 0.73 ms at k = 8 / 30 /
+    // 60.  A version with the row pointers and entries fetched one and two rows ahead and the gathers issued in groups of eight
+    // was SLOWER (0.79 / 0.98 / 1.04 ms: more instructions); removed.
+    const int64_t xcd = blockIdx.x & 7;
+    const int64_t nslots = xcd_rows ? ((int64_t)gridDim.x + 7 - xcd) >> 3 : gridDim.x;
+    const int64_t per = xcd_rows ? (((n + 7) / 8 + 3) & ~3LL) : n;
+    const int64_t r_lo = xcd_rows ? xcd * per : 0, r_hi = xcd_rows ? (r_lo + per < n ? r_lo + per : n) : n;
+    const int64_t slot = xcd_rows ? (blockIdx.x >> 3) : blockIdx.x;
+    for (int64_t row = r_lo + slot * 4LL + w; row < r_hi; row += nslots * 4LL) {
         cplx acc[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; ++c) acc[c] = cmake(0.0, 0.0);
@@ -608,17 +621,157 @@ static int launch_vc(const nep_spmf* s, int k, const cplx* dC, int64_t ldc, cons
     return launch_vc_rows<32>(s, k, dC, ldc, V, ldv, st, shift_dst);
 }
 
+// The same for k <= 64 with the dependent round trips of a row taken apart (round 3, late): k_spmm_rm waits for the gathered row
+// of XT of every ENTRY before it issues the next one (8 round trips per stencil row) behind the row-pointer and entry loads -- a
+// wave spends 4.5 us per row whatever k.  Here the entries of the NEXT row are fetched during the current row (its pointers one row
+// earlier still), and the gathers of eight entries are issued back to back, unconditionally (lanes >= k read column k - 1, entries
+// past the row's end repeat its last entry with coefficient 0), before the first is consumed.
+// (One accumulator per term picked by a wave-uniform branch, with the coefficients applied once per row, was tried: the branches cost
+// more than the four FP64 operations they save -- 0.48 / 0.50 / 0.52 ms against 0.44 / 0.47 / 0.50.)
+template <typename VT, int NCH>
+__global__ __launch_bounds__(256) void k_spmm_rm_g(const int32_t* __restrict__ rowptr, const uint32_t* __restrict__ idx,
+                                                   const VT* __restrict__ vals, int64_t n, int mt, int k,
+                                                   const cplx* __restrict__ F, const cplx* __restrict__ XT,
+                                                   int64_t ldx, int xoff, cplx* __restrict__ ZT, int64_t ldz,
+                                                   double* __restrict__ partial, int64_t split_row, int xcd_rows) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* Fs = (cplx*)smem_raw;                       // mt*k coefficients (if F)
+    double* red = (double*)(Fs + (F ? mt * k : 0));   // [4][2][NCH*64]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (F) {
+        for (int t = threadIdx.x; t < mt * k; t += 256) Fs[t] = F[t];
+        __syncthreads();
+    }
+    constexpr int GU = NCH == 1 ? 8 : 4;              // entries whose gathers are in flight together (8 loads either way)
+    int sl[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) sl[c] = lane + 64 * c < k ? lane + 64 * c : k - 1;
+    double rn[NCH], qn[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) { rn[c] = 0.0; qn[c] = 0.0; }
+    const int64_t xcd = blockIdx.x & 7;
+    const int64_t nslots = xcd_rows ? ((int64_t)gridDim.x + 7 - xcd) >> 3 : gridDim.x;
+    const int64_t per = xcd_rows ? (((n + 7) / 8 + 3) & ~3LL) : n;
+    const int64_t r_lo = xcd_rows ? xcd * per : 0, r_hi = xcd_rows ? (r_lo + per < n ? r_lo + per : n) : n;
+    const int64_t slot = xcd_rows ? (blockIdx.x >> 3) : blockIdx.x;
+    const int64_t step = nslots * 4LL;
+    int64_t row = r_lo + slot * 4LL + w;
+    if (row >= r_hi) row = -1;
+    const int64_t last = r_hi - 1;
+    // pipeline registers: entries of the current row (id_c, a_c, extent ce0..ce1), pointers of the next row (e0n, e1n)
+    int ce0 = 0, ce1 = 0, e0n = 0, e1n = 0;
+    uint32_t id_c = 0; VT a_c;
+    if constexpr (sizeof(VT) == 8) a_c = 0.0; else a_c = cmake(0.0, 0.0);
+    if (row >= 0) {
+        ce0 = __builtin_amdgcn_readfirstlane(rowptr[row]); ce1 = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
+        const int me = min(ce0 + lane, ce1 > ce0 ? ce1 - 1 : ce0);
+        id_c = idx[me]; a_c = vals[me];
+        const int64_t r1 = min(row + step, last);
+        e0n = __builtin_amdgcn_readfirstlane(rowptr[r1]); e1n = __builtin_amdgcn_readfirstlane(rowptr[r1 + 1]);
+    }
+    for (; row >= 0 && row < r_hi; row += step) {
+        // ---- ahead (unconditional, clamped to the last row of the range): entries of the next row, pointers of the one after
+        const int ne0 = e0n, ne1 = e1n;
+        const int men = min(ne0 + lane, ne1 > ne0 ? ne1 - 1 : ne0);
+        const uint32_t id_n = idx[men];
+        const VT a_n = vals[men];
+        {
+            const int64_t r2 = min(row + 2 * step, last);
+            e0n = __builtin_amdgcn_readfirstlane(rowptr[r2]); e1n = __builtin_amdgcn_readfirstlane(rowptr[r2 + 1]);
+        }
+        // (the row of XT for |q|^2 is fetched with the gathers, not after them: one round trip less per row)
+        const bool want_q = partial && xoff == 0;
+        cplx qv[NCH], acc[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) { qv[c] = cmake(0.0, 0.0); if (want_q) qv[c] = XT[row * ldx + sl[c]]; acc[c] = cmake(0.0, 0.0); }
+        auto chunk = [&](uint32_t id_l, VT a_l, int m) __attribute__((always_inline)) {
+            // element offsets of all (up to 64) entries at once on the lanes, 32-bit (the host checks n ldx + mt xoff < 2^32): the
+            // per-entry scalar work is a readlane and one 64-bit add instead of three scalar multiplies -- this kernel is bound by
+            // instruction issue (the scalar unit is shared by the four SIMDs of a CU), not by bytes
+            const uint32_t off_l = (id_l & NEP_COL_MASK) * (uint32_t)ldx + (id_l >> NEP_TERM_SHIFT) * (uint32_t)xoff;
+            const uint32_t t_l = id_l >> NEP_TERM_SHIFT;
+            for (int j0 = 0; j0 < m; j0 += GU) {
+                cplx xv[GU][NCH]; int tt[GU]; VT av[GU];
+#pragma unroll
+                for (int u = 0; u < GU; ++u) {
+                    const int j = min(j0 + u, m - 1);
+                    const uint32_t o = (uint32_t)readlane_i((int)off_l, j);
+                    tt[u] = F ? readlane_i((int)t_l, j) : 0;
+                    const cplx* xrow = XT + o;
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) xv[u][c] = xrow[sl[c]];
+                    if constexpr (sizeof(VT) == 8) { const double a = readlane_d(a_l, j); av[u] = j0 + u < m ? a : 0.0; }
+                    else { cplx a; a.x = readlane_d(a_l.x, j); a.y = readlane_d(a_l.y, j); av[u] = j0 + u < m ? a : cmake(0.0, 0.0); }
+                }
+#pragma unroll
+                for (int u = 0; u < GU; ++u)
+#pragma unroll
+                    for (int c = 0; c < NCH; ++c) {
+                        cplx x = xv[u][c];
+                        if (F) x = cmul(Fs[tt[u] + sl[c] * mt], x);
+                        cfma(acc[c], av[u], x);
+                    }
+            }
+        };
+        chunk(id_c, a_c, min(64, ce1 - ce0));          // (straight-line: the only loads in flight are the two prefetches above)
+        for (int base = ce0 + 64; base < ce1; base += 64) {      // rows with more than 64 entries: further chunks loaded in place
+            const int me = min(base + lane, ce1 - 1);
+            chunk(idx[me], vals[me], min(64, ce1 - base));
+        }
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int sc = lane + 64 * c;
+            if (sc < k) {
+                const bool wr = split_row < 0 ? ZT != nullptr : row >= split_row;
+                const bool nr = split_row < 0 || row < split_row;
+                if (wr) ZT[(split_row < 0 ? row : row - split_row) * ldz + sc] = acc[c];
+                if (partial) {
+                    if (nr) rn[c] = fma(acc[c].x, acc[c].x, fma(acc[c].y, acc[c].y, rn[c]));
+                    if (xoff == 0) qn[c] = fma(qv[c].x, qv[c].x, fma(qv[c].y, qv[c].y, qn[c]));
+                }
+            }
+        }
+        ce0 = ne0; ce1 = ne1; id_c = id_n; a_c = a_n;
+    }
+    if (partial) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            red[(w * 2 + 0) * (NCH * 64) + c * 64 + lane] = rn[c];
+            red[(w * 2 + 1) * (NCH * 64) + c * 64 + lane] = qn[c];
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < 2 * k; t += 256) {
+            const int which = t / k, sidx = t % k;
+            double v = 0.0;
+            for (int q = 0; q < 4; ++q) v += red[(q * 2 + which) * (NCH * 64) + sidx];
+            partial[((int64_t)blockIdx.x * 2 + which) * k + sidx] = v;
+        }
+    }
+}
+
 template <typename VT>
 static int launch_spmm(const nep_spmf* s, int k, const cplx* dF, const cplx* XT, int64_t ldx, int xoff,
                        cplx* ZT, int64_t ldz, double* partial, int grid, hipStream_t st, int64_t split_row = -1) {
     const int nch = (k + 63) / 64;
     const size_t shm = (dF ? (size_t)s->mt * k * sizeof(cplx) : 0) + (size_t)4 * 2 * nch * 64 * sizeof(double);
     const VT* vals = (const VT*)s->d_vals;
+    static const int xcd_env = getenv("NEP_SPMM_XCD") ? atoi(getenv("NEP_SPMM_XCD")) : 1;
+    const int xcd_rows = (xcd_env && s->n >= 65536 && grid >= 64) ? 1 : 0;      // small matrices sit in every L2 anyway
 #define SPMM_CASE(N)                                                                                   \
     case N:                                                                                            \
         hipLaunchKernelGGL((k_spmm_rm<N, VT>), dim3(grid), dim3(256), shm, st, s->d_rowptr, s->d_idx,  \
-                           vals, s->n, s->mt, k, dF, XT, ldx, xoff, ZT, ldz, partial, split_row);      \
+                           vals, s->n, s->mt, k, dF, XT, ldx, xoff, ZT, ldz, partial, split_row, xcd_rows); \
         break;
+    static const int grouped = getenv("NEP_SPMM_GROUPED") ? atoi(getenv("NEP_SPMM_GROUPED")) : 1;
+    if (nch <= 2 && grouped && (uint64_t)s->n * (uint64_t)ldx + (uint64_t)s->mt * (uint64_t)(xoff < 0 ? -xoff : xoff) < (1ull << 32)) {
+if (nch == 1) hipLaunchKernelGGL((k_spmm_rm_g<VT, 1>), dim3(grid), dim3(256), shm, st, s->d_rowptr, s->d_idx, vals, s->n, s->mt, k, dF, XT, ldx,
+                                         xoff, ZT, ldz, partial, split_row, xcd_rows);
+        else hipLaunchKernelGGL((k_spmm_rm_g<VT, 2>), dim3(grid), dim3(256), shm, st, s->d_rowptr, s->d_idx, vals, s->n, s->mt, k, dF, XT, ldx,
+                                xoff, ZT, ldz, partial, split_row, xcd_rows);
+        LAUNCHCHK();
+        return NEP_OK;
+    }
     switch (nch) {
         SPMM_CASE(1) SPMM_CASE(2) SPMM_CASE(3) SPMM_CASE(4)
         default: nep_set_error("k=%d too large for one spmm pass", k); return NEP_ERR_ARG;
@@ -801,7 +954,7 @@ static bool use_tiles_k2(const nep_spmf* s, int k) {
     if (g_k1_mode == 1) return true;
     // measured at n = 1e6: 4.5x faster than the wave-per-row kernel at k = 8, 1.35x at k = 30, slower at k = 60
     // (row-major Q: a column panel of a footprint row is a 64-byte piece of a 16 k-byte row)
-    static const int kmax = getenv("NEP_K2_TILE_KMAX") ? atoi(getenv("NEP_K2_TILE_KMAX")) : 40;
+    static const int kmax = getenv("NEP_K2_TILE_KMAX") ? atoi(getenv("NEP_K2_TILE_KMAX")) : 26;     // above: k_spmm_rm_g (0.47 ms at k = 30, tiles 0.50)
     return s->d_sell_ptr != nullptr && k <= kmax;
 }
 
