@@ -101,12 +101,20 @@ __global__ __launch_bounds__(256) void k_spmv(const int32_t* __restrict__ rowptr
     const int64_t row = blockIdx.x * (int64_t)RPB + threadIdx.x / G;
     cplx acc = cmake(0.0, 0.0);
     if (row < n) {
-        const int e1 = rowptr[row + 1];
-        for (int e = rowptr[row] + sub; e < e1; e += G) {
-            const uint32_t id = idx[e];
-            const int64_t c = id & NEP_COL_MASK;
-            const int t = id >> NEP_TERM_SHIFT;
-            cfma(acc, vals[e], WT[c * mt + t]);
+        // four entries per lane and trip: index / value loads together, then the four gathers, then the arithmetic (the compiler
+        // waits for an entry's gather before it issues the next entry's loads: two dependent round trips per ENTRY otherwise)
+        const int e0 = rowptr[row], e1 = rowptr[row + 1];
+        for (int e = e0 + sub; e < e1; e += 4 * G) {
+            uint32_t id[4]; VT v[4]; cplx wv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ee = e + u * G < e1 ? e + u * G : e;
+                id[u] = idx[ee]; v[u] = vals[ee];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) wv[u] = WT[(int64_t)(id[u] & NEP_COL_MASK) * mt + (id[u] >> NEP_TERM_SHIFT)];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (e + u * G < e1) cfma(acc, v[u], wv[u]);
         }
     }
     acc = group_reduce_sum<G>(acc);
@@ -529,14 +537,26 @@ __global__ __launch_bounds__(256) void k_cw_resid(const int32_t* __restrict__ ro
     double d = 0.0;
     cplx acc = cmake(0.0, 0.0);
     if (row < n) {
-        const int e1 = rowptr[row + 1];
-        for (int e = rowptr[row] + sub; e < e1; e += G) {
-            const uint32_t id = idx[e];
-            const int t = id >> NEP_TERM_SHIFT;
-            const cplx xv = x[id & NEP_COL_MASK];
-            const VT v = vals[e];
-            d += absval(v) * cabs[t] * absval(xv);
-            if (FUSED) cfma(acc, cscale(v, ccf[t]), xv);
+        // four entries per lane and trip: their index / value loads are issued together, then the four gathers of x, then the
+        // arithmetic -- three dependent round trips per trip instead of two per ENTRY (a gun row has ~60 entries: 4 per lane at G = 16)
+        const int e0 = rowptr[row], e1 = rowptr[row + 1];
+        for (int e = e0 + sub; e < e1; e += 4 * G) {
+            uint32_t id[4]; VT v[4]; cplx xv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ee = e + u * G < e1 ? e + u * G : e;             // (past the end: a valid entry, not accumulated)
+                id[u] = idx[ee]; v[u] = vals[ee];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xv[u] = x[id[u] & NEP_COL_MASK];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (e + u * G < e1) {
+                    const int t = id[u] >> NEP_TERM_SHIFT;
+                    d += absval(v[u]) * cabs[t] * absval(xv[u]);
+                    if (FUSED) cfma(acc, cscale(v[u], ccf[t]), xv[u]);
+                }
+            }
         }
     }
     d = group_reduce_sum<G>(d);

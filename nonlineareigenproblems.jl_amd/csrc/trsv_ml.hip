@@ -234,13 +234,29 @@ __device__ __forceinline__ void ml_level_body(const MLArgs& A, const int bx, con
             for (int r = 0; r < RB; ++r) acc[r] = cmake(0.0, 0.0);
             if (A.has_coupling) {
                 const int e1 = A.cp[c + 1];
-                for (int p = A.cp[c]; p < e1; ++p) {
-                    const cplx v = A.cx[p];
-                    const int64_t col = A.ci[p];
-                    if (col < A.col_lo) continue;
+                if (RB == 1) {
+                    for (int p = A.cp[c]; p < e1; p += 4) {            // four entries per trip: loads first, then the gathers
+                        cplx v[4], xv[4]; int64_t col[4]; bool on[4];
 #pragma unroll
-                    for (int r = 0; r < RB; ++r)
-                        if (r < nb) cfma(acc[r], v, A.xin[(int64_t)(rhs0 + r) * A.ldxin + col]);
+                        for (int u = 0; u < 4; ++u) {
+                            const int pp = p + u < e1 ? p + u : p;
+                            v[u] = A.cx[pp]; col[u] = A.ci[pp];
+                            on[u] = p + u < e1 && col[u] >= A.col_lo;
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) xv[u] = A.xin[(int64_t)rhs0 * A.ldxin + col[u]];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) if (on[u]) cfma(acc[0], v[u], xv[u]);
+                    }
+                } else {
+                    for (int p = A.cp[c]; p < e1; ++p) {
+                        const cplx v = A.cx[p];
+                        const int64_t col = A.ci[p];
+                        if (col < A.col_lo) continue;
+#pragma unroll
+                        for (int r = 0; r < RB; ++r)
+                            if (r < nb) cfma(acc[r], v, A.xin[(int64_t)(rhs0 + r) * A.ldxin + col]);
+                    }
                 }
             }
             const int64_t g = A.gat ? A.gat[c] : c;
@@ -268,15 +284,32 @@ __device__ __forceinline__ void ml_level_body(const MLArgs& A, const int bx, con
     cplx acc[RB];
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = cmake(0.0, 0.0);
-    for (int t = sub; t < len; t += G2) {
-        const cplx m = row[t];
+    if (RB == 1) {
+        // (fetching the first trip ahead of the right-hand-side gather and its barrier was measured: 8.1 -> 10.2 us, removed)
+        // single right-hand side: the loads of four trips are issued together (a row of a packed inverse has up to 256 entries,
+        // 4 per lane at G2 = 64 -- one round trip instead of four)
+        for (int t = sub; t < len; t += 4 * G2) {
+            cplx m[4], rv[4];
 #pragma unroll
-        for (int r = 0; r < RB; ++r)
-            if (r < nb) {
-                const cplx rv = MODE == 0 ? rbuf[r * ML_BMAX + (c0 - base) + t]
-                                          : A.tmp[(int64_t)(rhs0 + r) * A.ldtmp + c0 + t];
-                cfma(acc[r], m, rv);
+            for (int u = 0; u < 4; ++u) {
+                const int tt = t + u * G2 < len ? t + u * G2 : t;
+                m[u] = row[tt];
+                rv[u] = MODE == 0 ? rbuf[(c0 - base) + tt] : A.tmp[(int64_t)rhs0 * A.ldtmp + c0 + tt];
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (t + u * G2 < len) cfma(acc[0], m[u], rv[u]);
+        }
+    } else {
+        for (int t = sub; t < len; t += G2) {
+            const cplx m = row[t];
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (r < nb) {
+                    const cplx rv = MODE == 0 ? rbuf[r * ML_BMAX + (c0 - base) + t]
+                                              : A.tmp[(int64_t)(rhs0 + r) * A.ldtmp + c0 + t];
+                    cfma(acc[r], m, rv);
+                }
+        }
     }
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = group_reduce_sum<G2>(acc[r]);
@@ -318,14 +351,33 @@ __device__ __forceinline__ void ml_coupling_body(const MLCplArgs& C, const int b
 #pragma unroll
     for (int r = 0; r < RB; ++r) acc[r] = cmake(0.0, 0.0);
     if (q < r1) {
-        const int e1 = cp[q + 1];
-        for (int p = cp[q] + sub; p < e1; p += G) {
-            const int col = ci[p];
-            if (col < col_lo || col >= col_hi) continue;
-            const cplx v = cx[p];
+        const int e0 = cp[q], e1 = cp[q + 1];
+        if (RB == 1) {
+            // single right-hand side: four entries per lane and trip -- index and value loads together, then the four gathers of
+            // xin, then the arithmetic: three dependent round trips per trip instead of two per entry (the compiler waits for the
+            // gather of an entry before it issues the loads of the next)
+            for (int p = e0 + sub; p < e1; p += 4 * G) {
+                int col[4]; cplx v[4], xv[4]; bool on[4];
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
-                if (r < nb) cfma(acc[r], v, xin[(int64_t)(rhs0 + r) * ldxin + col]);
+                for (int u = 0; u < 4; ++u) {
+                    const int pp = p + u * G < e1 ? p + u * G : p;
+                    col[u] = ci[pp]; v[u] = cx[pp];
+                    on[u] = p + u * G < e1 && col[u] >= col_lo && col[u] < col_hi;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) xv[u] = xin[(int64_t)rhs0 * ldxin + col[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (on[u]) cfma(acc[0], v[u], xv[u]);
+            }
+        } else {
+            for (int p = e0 + sub; p < e1; p += G) {
+                const int col = ci[p];
+                if (col < col_lo || col >= col_hi) continue;
+                const cplx v = cx[p];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+                    if (r < nb) cfma(acc[r], v, xin[(int64_t)(rhs0 + r) * ldxin + col]);
+            }
         }
     }
 #pragma unroll
