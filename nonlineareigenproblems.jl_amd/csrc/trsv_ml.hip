@@ -120,46 +120,96 @@ __device__ __forceinline__ cplx ml_cdiv(cplx a, cplx b) {
 
 // ---- numeric set-up: column j of inv(L_BB) / inv(U_BB) for every diagonal block --------------------------------------
 // grid.x = n (one workgroup per column of the block-diagonal inverse), 16 lanes per row, x in LDS
+// threads per column of k_ml_inverse: ONE wave (4 slots of 16 lanes per batch).  A dense block has one row per in-block level, so
+// 256 threads mostly waited at the barrier of every level (9956 columns x ~100 levels); with one wave per column the barrier is free
+// and four times as many columns are resident (measured: 0.55 + 0.61 ms -> see DESIGN.md section 3 K5 set-up)
+#define ML_INV_NT 64
 template <bool UPPER>
-__global__ __launch_bounds__(256) void k_ml_inverse(const int32_t* __restrict__ rowblk, const int32_t* __restrict__ blk_se,
+__global__ __launch_bounds__(ML_INV_NT) void k_ml_inverse(const int32_t* __restrict__ rowblk, const int32_t* __restrict__ blk_se,
                                                     const int32_t* __restrict__ lvo, const int32_t* __restrict__ lvp,
                                                     const int32_t* __restrict__ slotrow, const int32_t* __restrict__ bp,
                                                     const int32_t* __restrict__ bi, const cplx* __restrict__ bx,
                                                     const cplx* __restrict__ diag, const int64_t* __restrict__ ip,
                                                     cplx* __restrict__ ix, const int32_t* __restrict__ rowlev) {
     __shared__ cplx x[ML_BMAX];
+    // round 3: the block's level pointers, slot rows and row pointers sit in LDS (one coalesced load each at the start), and the
+    // first entry of every lane for the NEXT batch of 16 slots is fetched while the current batch is reduced -- a dense 256-row block
+    // has 256 in-block levels, and each used to cost two dependent global round trips (row pointers -> entries) before its barrier
+    __shared__ int32_t s_lvp[ML_BMAX + 2], s_row[ML_BMAX + 1], s_bp[ML_BMAX + 2];
     const int q = blockIdx.x;
     const int k = rowblk[q];
     const int s = blk_se[2 * k], e = blk_se[2 * k + 1];
     const int j = q - s, bsz = e - s;
-    for (int t = threadIdx.x; t < bsz; t += 256) x[t] = cmake(t == j ? 1.0 : 0.0, 0.0);
-    __syncthreads();
     const int l0 = lvo[k], nlev = lvo[k + 1] - l0 - 1;
+    for (int t = threadIdx.x; t < bsz; t += ML_INV_NT) x[t] = cmake(t == j ? 1.0 : 0.0, 0.0);
+    for (int t = threadIdx.x; t <= nlev; t += ML_INV_NT) s_lvp[t] = lvp[l0 + t];
+    const int slot0 = lvp[l0], nslot = lvp[l0 + nlev] - slot0;          // the block's slots are contiguous, level after level
+    for (int t = threadIdx.x; t < nslot; t += ML_INV_NT) s_row[t] = slotrow[slot0 + t];
+    for (int t = threadIdx.x; t <= nslot; t += ML_INV_NT) s_bp[t] = bp[slot0 + t];
+    __syncthreads();
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
     // column j of the inverse is zero in every row that does not depend on row j, i.e. in all rows of lower in-block levels
     // (and, for the unit-lower factor, of row j's own level): the substitution starts at the level of row j -- half of the
     // levels of a dense block on average -- and leaves bit-identical values (the skipped rows computed 0 - 0)
     const int lstart = UPPER ? rowlev[q] : rowlev[q] + 1;
-    for (int lev = lstart; lev < nlev; ++lev) {
-        const int s0 = lvp[l0 + lev], s1 = lvp[l0 + lev + 1];
-        for (int sl0 = s0; sl0 < s1; sl0 += 16) {
-            const int sl = sl0 + grp;
-            int i = -1;
-            cplx acc = cmake(0.0, 0.0);
-            if (sl < s1) {
-                i = slotrow[sl];
-                if (UPPER ? (i <= j) : (i > j)) {               // the other rows of the column stay zero
-                    const int e1 = bp[sl + 1];
-                    for (int p = bp[sl] + sub; p < e1; p += 16) cfma(acc, bx[p], x[bi[p]]);
-                } else i = -1;
+    // batch = ML_INV_NT / 16 consecutive slots of one level.  The lane's first entry of a batch is fetched FOUR batches ahead (four
+    // rotating register sets, the loop body replicated four times): a level of a dense block is one short batch, shorter than a
+    // global round trip, so a look-ahead of one batch still left one round trip per level (0.36 + 0.41 ms with it, this form: see
+    // DESIGN.md section 3 K5 set-up)
+    // A level with a single row (every level of a dense block) is taken by all 64 lanes of the wave instead of 16: such rows have up
+    // to 255 entries, and 16 trips of 16 lanes were 4 grouped round trips per level.
+    struct St { int i, p, e1, col, last, valid, wide; cplx v; };
+    int plev = lstart, psl0 = plev < nlev ? s_lvp[plev] - slot0 : 0;       // prefetch cursor
+    auto issue = [&](St& S) __attribute__((always_inline)) {
+        S.i = -1; S.p = 0; S.e1 = 0; S.col = 0; S.last = 0; S.wide = 0; S.valid = plev < nlev; S.v = cmake(0.0, 0.0);
+        if (!S.valid) return;
+        const int lend = s_lvp[plev + 1] - slot0;
+        S.wide = (ML_INV_NT == 64 && lend - psl0 == 1) ? 1 : 0;          // (psl0 is the level's first slot whenever one slot remains and ...)
+        const int sl = S.wide ? psl0 : psl0 + grp;
+        if (sl < lend) {
+            const int i = s_row[sl];
+            if (UPPER ? (i <= j) : (i > j)) {                   // the other rows of the column stay zero
+                S.i = i; S.p = s_bp[sl] + (S.wide ? (int)threadIdx.x : sub); S.e1 = s_bp[sl + 1];
+                if (S.p < S.e1) { S.v = bx[S.p]; S.col = bi[S.p]; }
             }
-            acc = group_reduce_sum<16>(acc);
-            if (i >= 0 && sub == 0) x[i] = UPPER ? ml_cdiv(csub(x[i], acc), diag[s + i]) : csub(x[i], acc);
         }
-        __syncthreads();
+        psl0 += ML_INV_NT / 16;
+        if (psl0 >= lend) { S.last = 1; ++plev; psl0 = plev < nlev ? s_lvp[plev] - slot0 : 0; }
+    };
+    auto consume = [&](const St& S) __attribute__((always_inline)) -> bool {
+        if (!S.valid) return false;
+        cplx acc = cmake(0.0, 0.0);
+        if (S.i >= 0) {
+            const int st = S.wide ? 64 : 16;
+            if (S.p < S.e1) cfma(acc, S.v, x[S.col]);
+            for (int p = S.p + st; p < S.e1; p += 4 * st) {      // long rows: four trips' loads together
+                cplx v[4]; int col[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const int pp = p + st * u < S.e1 ? p + st * u : p; v[u] = bx[pp]; col[u] = bi[pp]; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (p + st * u < S.e1) cfma(acc, v[u], x[col[u]]);
+            }
+        }
+        acc = group_reduce_sum<16>(acc);
+        if (S.wide) {                                           // the four 16-lane groups worked on ONE row: add their sums
+            acc.x += __shfl_xor(acc.x, 16, 64); acc.y += __shfl_xor(acc.y, 16, 64);
+            acc.x += __shfl_xor(acc.x, 32, 64); acc.y += __shfl_xor(acc.y, 32, 64);
+        }
+        if (S.i >= 0 && (S.wide ? threadIdx.x == 0 : sub == 0)) x[S.i] = UPPER ? ml_cdiv(csub(x[S.i], acc), diag[s + S.i]) : csub(x[S.i], acc);
+        if (S.last) __syncthreads();
+        return true;
+    };
+    St A, B, C, D;
+    issue(A); issue(B); issue(C); issue(D);
+    while (true) {
+        if (!consume(A)) break; issue(A);
+        if (!consume(B)) break; issue(B);
+        if (!consume(C)) break; issue(C);
+        if (!consume(D)) break; issue(D);
     }
-    if (UPPER) { for (int t = threadIdx.x; t <= j; t += 256) ix[ip[s + t] + (j - t)] = x[t]; }
-    else       { for (int t = j + threadIdx.x; t < bsz; t += 256) ix[ip[s + t] + j] = x[t]; }
+    __syncthreads();
+    if (UPPER) { for (int t = threadIdx.x; t <= j; t += ML_INV_NT) ix[ip[s + t] + (j - t)] = x[t]; }
+    else       { for (int t = j + threadIdx.x; t < bsz; t += ML_INV_NT) ix[ip[s + t] + j] = x[t]; }
 }
 
 // device-side numeric path: values of a factor (input entry order) -> the schedule's value array
@@ -1004,12 +1054,12 @@ static int ml_numeric(MLFactor* F, const nep_cdouble* Lx, const nep_cdouble* Ux)
     }
     HIPCHK(hipMemcpyAsync(F->d_vals, h, (size_t)ntot * sizeof(cplx), hipMemcpyHostToDevice, bst));
     g_pinned.release(pidx, bst);
-    hipLaunchKernelGGL((k_ml_inverse<false>), dim3((unsigned)n), dim3(256), 0, bst, (const int32_t*)S->d_rowblk,
+    hipLaunchKernelGGL((k_ml_inverse<false>), dim3((unsigned)n), dim3(ML_INV_NT), 0, bst, (const int32_t*)S->d_rowblk,
                        (const int32_t*)S->d_blk_se, (const int32_t*)S->L.d_lvo, (const int32_t*)S->L.d_lvp,
                        (const int32_t*)S->L.d_slotrow, (const int32_t*)S->L.d_bp, (const int32_t*)S->L.d_bi,
                        (const cplx*)(F->d_vals + oLb), (const cplx*)nullptr, (const int64_t*)S->L.d_ip, F->d_ixL, (const int32_t*)S->L.d_rowlev);
     LAUNCHCHK();
-    hipLaunchKernelGGL((k_ml_inverse<true>), dim3((unsigned)n), dim3(256), 0, bst, (const int32_t*)S->d_rowblk,
+    hipLaunchKernelGGL((k_ml_inverse<true>), dim3((unsigned)n), dim3(ML_INV_NT), 0, bst, (const int32_t*)S->d_rowblk,
                        (const int32_t*)S->d_blk_se, (const int32_t*)S->U.d_lvo, (const int32_t*)S->U.d_lvp,
                        (const int32_t*)S->U.d_slotrow, (const int32_t*)S->U.d_bp, (const int32_t*)S->U.d_bi,
                        (const cplx*)(F->d_vals + oUb), (const cplx*)(F->d_vals + oD), (const int64_t*)S->U.d_ip, F->d_ixU, (const int32_t*)S->U.d_rowlev);
@@ -1138,12 +1188,12 @@ static int ml_numeric_dev(MLFactor* F, const cplx* d_Lx, const cplx* d_Ux, hipSt
         hipEvent_t ev; HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
         HIPCHK(hipEventRecord(ev, bst)); HIPCHK(hipStreamWaitEvent(bst2, ev, 0)); (void)hipEventDestroy(ev);
     }
-    hipLaunchKernelGGL((k_ml_inverse<false>), dim3((unsigned)n), dim3(256), 0, bst, (const int32_t*)S->d_rowblk,
+    hipLaunchKernelGGL((k_ml_inverse<false>), dim3((unsigned)n), dim3(ML_INV_NT), 0, bst, (const int32_t*)S->d_rowblk,
                        (const int32_t*)S->d_blk_se, (const int32_t*)S->L.d_lvo, (const int32_t*)S->L.d_lvp,
                        (const int32_t*)S->L.d_slotrow, (const int32_t*)S->L.d_bp, (const int32_t*)S->L.d_bi,
                        (const cplx*)(F->d_vals + oLb), (const cplx*)nullptr, (const int64_t*)S->L.d_ip, F->d_ixL, (const int32_t*)S->L.d_rowlev);
     LAUNCHCHK();
-    hipLaunchKernelGGL((k_ml_inverse<true>), dim3((unsigned)n), dim3(256), 0, bst2, (const int32_t*)S->d_rowblk,
+    hipLaunchKernelGGL((k_ml_inverse<true>), dim3((unsigned)n), dim3(ML_INV_NT), 0, bst2, (const int32_t*)S->d_rowblk,
                        (const int32_t*)S->d_blk_se, (const int32_t*)S->U.d_lvo, (const int32_t*)S->U.d_lvp,
                        (const int32_t*)S->U.d_slotrow, (const int32_t*)S->U.d_bp, (const int32_t*)S->U.d_bi,
                        (const cplx*)(F->d_vals + oUb), (const cplx*)(F->d_vals + oD), (const int64_t*)S->U.d_ip, F->d_ixU, (const int32_t*)S->U.d_rowlev);
