@@ -144,14 +144,37 @@ __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int
     if (FWD) {
         // consecutive threads read consecutive z (coalesced) and scatter into the (n1, n2) slot in LDS -- reading THROUGH the
         // index map instead touched a different 64-byte line with every 16-byte load
-        for (int t = threadIdx.x; t < COLS * nz; t += nt) {
-            const int c = t / nz, z = t - c * nz;
-            xs[in_inv[z] * COLS + c] = c < nc ? src[(int64_t)(x0 + c) * nz + z] : cmake(0.0, 0.0);
+        // (four trips' loads are issued together, unconditionally with a clamped column: a trip's index + value round trip was
+        // waited for before the next trip's loads went out -- eleven serial round trips per workgroup)
+        for (int t = threadIdx.x; t < COLS * nz; t += 4 * nt) {
+            int slot[4]; cplx v[4]; bool on[4], live[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = t + u * nt;
+                live[u] = tt < COLS * nz;
+                const int tc = live[u] ? tt : t;
+                const int c = tc / nz, z = tc - c * nz;
+                on[u] = c < nc;
+                slot[u] = in_inv[z] * COLS + c;
+                v[u] = src[(int64_t)(x0 + (on[u] ? c : 0)) * nz + z];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (live[u]) xs[slot[u]] = on[u] ? v[u] : cmake(0.0, 0.0);
         }
     } else {
-        for (int t = threadIdx.x; t < COLS * nz; t += nt) {
-            const int q = t / COLS, c = t - q * COLS;
-            xs[t] = c < nc ? src[(int64_t)in_idx[q] * nx + (x0 + c)] : cmake(0.0, 0.0);
+        for (int t = threadIdx.x; t < COLS * nz; t += 4 * nt) {
+            cplx v[4]; bool on[4], live[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = t + u * nt;
+                live[u] = tt < COLS * nz;
+                const int tc = live[u] ? tt : t;
+                const int q = tc / COLS, c = tc - q * COLS;
+                on[u] = c < nc;
+                v[u] = src[(int64_t)in_idx[q] * nx + (x0 + (on[u] ? c : 0))];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (live[u]) xs[t + u * nt] = on[u] ? v[u] : cmake(0.0, 0.0);
         }
     }
     __syncthreads();
