@@ -106,8 +106,14 @@ __global__ __launch_bounds__(PF ? 256 : 1024) void k_tile_mlincomb(const TileDes
     int NG = 1;
     if (split) { NG = nthr / Fpad; if (NG > k / 2) NG = k / 2; if (NG < 1) NG = 1; }
     if (NG == 1) {
-        for (int f = tid; f < F; f += nthr) {
-            const uint32_t raw = fpb[f];
+        // (the thread's footprint list entries are fetched up front: list entry -> V round trips of one trip were waited for before the
+        // next trip's list entry was loaded)
+        uint32_t raws[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) raws[u] = tid + u * nthr < F ? fpb[tid + u * nthr] : 0u;
+        int trip = 0;
+        for (int f = tid; f < F; f += nthr, ++trip) {
+            const uint32_t raw = trip < 4 ? (trip == 0 ? raws[0] : trip == 1 ? raws[1] : trip == 2 ? raws[2] : raws[3]) : fpb[f];
             const int64_t c = raw & NEP_COL_MASK;
             const bool own = (raw & TILE_OWN) != 0 && shift_dst != nullptr;
             const cplx* vp = V + c;
@@ -383,17 +389,30 @@ __global__ __launch_bounds__(256) void k_tile_resid_cm(const TileDesc* __restric
     double qn[PS];
 #pragma unroll
     for (int s = 0; s < PS; ++s) qn[s] = 0.0;
-    for (int f = tid; f < Fn; f += 256) {
-        const uint32_t raw = fpb[f];
-        const cplx* qp = Q + (int64_t)(raw & NEP_COL_MASK) + (int64_t)p0 * ldq;
-        const bool own = (raw & TILE_OWN) != 0;
-        cplx qv[PS];
+    // (the footprint list entries of four trips are loaded together, then their Q values: a trip's list entry -> Q round trips were
+    // waited for before the next trip started -- three serial pairs of round trips for a 660-row footprint)
+    for (int f0 = tid; f0 < Fn; f0 += 4 * 256) {
+        uint32_t raw[4]; cplx qv[4][PS];
 #pragma unroll
-        for (int s = 0; s < PS; ++s) qv[s] = s < pw ? qp[(int64_t)s * ldq] : cmake(0.0, 0.0);
+        for (int u = 0; u < 4; ++u) raw[u] = fpb[f0 + 256 * u < Fn ? f0 + 256 * u : f0];
 #pragma unroll
-        for (int s = 0; s < PS; ++s) {
-            Qt[(size_t)f * PS + s] = qv[s];
-            if (own) qn[s] = fma(qv[s].x, qv[s].x, fma(qv[s].y, qv[s].y, qn[s]));
+        for (int u = 0; u < 4; ++u) {
+            const cplx* qp = Q + (int64_t)(raw[u] & NEP_COL_MASK) + (int64_t)p0 * ldq;
+#pragma unroll
+            for (int s = 0; s < PS; ++s) qv[u][s] = qp[(int64_t)(s < pw ? s : 0) * ldq];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int f = f0 + 256 * u;
+            if (f < Fn) {
+                const bool own = (raw[u] & TILE_OWN) != 0;
+#pragma unroll
+                for (int s = 0; s < PS; ++s) {
+                    const cplx q = s < pw ? qv[u][s] : cmake(0.0, 0.0);
+                    Qt[(size_t)f * PS + s] = q;
+                    if (own) qn[s] = fma(q.x, q.x, fma(q.y, q.y, qn[s]));
+                }
+            }
         }
     }
     __syncthreads();

@@ -1,7 +1,4 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-mkdir -p gpurun_out/b39
-timeout 900 python -m pytest tests -x -q -m gpu -k "wep or sylv or waveguide" > gpurun_out/b39/pytest.log 2>&1
-python bench.py --only c5step > gpurun_out/b39/c5step.json 2> gpurun_out/b39/c5step.err
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pc5 -o c5 -- python $GRAFT_REPO_ROOT/bench.py --only c5step > $GRAFT_REPO_ROOT/gpurun_out/b39/prof.log 2>&1)
-cp $(find /tmp/pc5 -name "*kernel_stats.csv" | head -1) gpurun_out/b39/c5step_kernel_stats.csv
+mkdir -p gpurun_out/b41
+python scripts/k1_tile_bench.py wep > gpurun_out/b41/tiles2.jsonl 2>&1
+timeout 600 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "tile or mlincomb" > gpurun_out/b41/pytest.log 2>&1
