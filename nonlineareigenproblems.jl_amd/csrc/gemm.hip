@@ -298,11 +298,11 @@ static int gemm_launch(bool rowmajor, const cplx* Z, int64_t ldz, int64_t rows, 
 // B[c, j] = b_rowmajor ? dB[c*ldb + j] : dB[j*ldb + c]
 __global__ void k_expand_B(const cplx* __restrict__ B, int64_t ldb, int b_rowmajor, int k, int pp, int j0, int nks,
                            int nt, double* __restrict__ frag) {
-    const int64_t total = (int64_t)nks * nt * 64;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int l = (int)(i & 63);
-        const int64_t kt = i >> 6;            // ks*nt + t
-        const int t = (int)(kt % nt), ks = (int)(kt / nt);
+    const int total = nks * nt * 64;          // (32-bit index arithmetic: the 64-bit divisions cost more than the rest of this kernel)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int l = i & 63;
+        const int kt = i >> 6;                // ks*nt + t
+        const int ks = kt / nt, t = kt - ks * nt;
         const int q = l >> 4, n = l & 15;
         const int c = 4 * ks + q, jc = 8 * t + (n >> 1);
         double b0 = 0.0, b1 = 0.0;
@@ -310,7 +310,7 @@ __global__ void k_expand_B(const cplx* __restrict__ B, int64_t ldb, int b_rowmaj
             const cplx b = b_rowmajor ? B[(int64_t)c * ldb + (j0 + jc)] : B[(int64_t)(j0 + jc) * ldb + c];
             if ((n & 1) == 0) { b0 = b.x; b1 = -b.y; } else { b0 = b.y; b1 = b.x; }
         }
-        double* f = frag + kt * 128;
+        double* f = frag + (int64_t)kt * 128;
         f[l] = b0;
         f[64 + l] = b1;
     }

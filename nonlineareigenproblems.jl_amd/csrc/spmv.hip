@@ -536,6 +536,9 @@ __global__ __launch_bounds__(256) void k_cw_resid(const int32_t* __restrict__ ro
     const int64_t row = blockIdx.x * (int64_t)RPB + threadIdx.x / G;
     double d = 0.0;
     cplx acc = cmake(0.0, 0.0);
+    // (the right-hand side entry and the extra denominator term of the row are requested up front, not behind the reduction)
+    cplx brow = cmake(0.0, 0.0); double dex = 0.0;
+    if (row < n && sub == 0) { brow = b[row]; if (den_extra) dex = den_extra[row].x; }
     if (row < n) {
         // four entries per lane and trip: their index / value loads are issued together, then the four gathers of x, then the
         // arithmetic -- three dependent round trips per trip instead of two per ENTRY (a gun row has ~60 entries: 4 per lane at G = 16)
@@ -564,9 +567,9 @@ __global__ __launch_bounds__(256) void k_cw_resid(const int32_t* __restrict__ ro
     double ratio = 0.0;
     if (row < n && sub == 0) {
         const cplx mx = FUSED ? cmake(xsign * acc.x, xsign * acc.y) : Mx[row];      // xsign = -1: the iterate is stored as -x
-        const cplx rr = csub(b[row], mx);
+        const cplx rr = csub(brow, mx);
         r[row] = rr;
-        const double num = absval(rr), den = d + absval(b[row]) + (den_extra ? den_extra[row].x : 0.0);
+        const double num = absval(rr), den = d + absval(brow) + dex;
         ratio = den > 0.0 ? num / den : (num > 0.0 ? 1.0e300 : 0.0);
         if (!(ratio == ratio)) ratio = 1.0e300;     // NaN -> "not converged"
     }
