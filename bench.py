@@ -172,7 +172,7 @@ def k5_roofline(na, nep, args, reps=100):
     n = lu.n
     B = torch.randn(n, dtype=torch.float64, device="cuda").to(torch.complex128)
     X = torch.empty_like(B)
-    ms = event_loop(lambda: lu.solve(B, out=X), reps, warm=24)      # (the first 12 solves of a factor walk the apex levels, NEP_ML_APEX_AT)
+    ms = event_loop(lambda: lu.solve(B, out=X), reps, warm=24)      # (the first solves of a factor walk the apex levels, NEP_ML_APEX_AT)
     ba = lu.algorithmic_bytes
     return {"bound": "hbm (dependent-launch latency in practice)", "kernel": "K5 nep_lu_solve, one right-hand side, gun M(sigma): "
             "%s" % ("elimination-tree block schedule, %d levels, %d blocks" % (lu.levels, lu.blocks) if lu.block_schedule

@@ -1674,9 +1674,11 @@ int ml_solve(MLFactor* F, int nrhs, const nep_cdouble* dB, int64_t ldb, const ne
     if (!F->synced_valid || F->synced != st) { HIPCHK(hipStreamWaitEvent(st, F->ready, 0)); F->synced = st; F->synced_valid = true; }
     // Which solve of a factor first uses the dense apex is FIXED (the two paths round differently: a switch point that depended on
     // host / device timing made iar iterates differ from run to run in the last bits): solve number NEP_ML_APEX_AT
-    // (default 12: the 3.3 ms build has finished by then in every run measured) waits for the build on the stream -- the host
-    // never blocks -- and every later solve takes the apex.  NEP_ML_APEX_AT=0: as soon as a query finds the build finished (round 2).
-    static const int apex_at = getenv("NEP_ML_APEX_AT") ? atoi(getenv("NEP_ML_APEX_AT")) : 12;
+    // (default 6) waits for the build on the stream -- the host never blocks -- and every later solve takes the apex.  Measured per
+    // iar call: 38.5 ms at 4 ... 8, 38.9-39.8 at 1, 39.5-40.2 at 12, 41.4 at 40: a short wait while the build has the device to
+    // itself beats both more solves through the apex levels and an immediate wait.  NEP_ML_APEX_AT=0: as soon as a query finds the
+    // build finished (round 2).
+    static const int apex_at = getenv("NEP_ML_APEX_AT") ? atoi(getenv("NEP_ML_APEX_AT")) : 6;
     if (F->apex_la > 0 && !F->apex_live && F->apex_ev) {
         bool take = false;
         if (apex_at > 0) take = F->solves_since_numeric >= apex_at;
