@@ -294,7 +294,7 @@ __device__ __forceinline__ void ml_level_body(const MLArgs& A, const int bx, con
                             on[u] = p + u < e1 && col[u] >= A.col_lo;
                         }
 #pragma unroll
-                        for (int u = 0; u < 4; ++u) xv[u] = A.xin[(int64_t)rhs0 * A.ldxin + col[u]];
+                        for (int u = 0; u < 4; ++u) xv[u] = A.xin[(int64_t)rhs0 * A.ldxin + (on[u] ? col[u] : (int64_t)A.col_lo)];
 #pragma unroll
                         for (int u = 0; u < 4; ++u) if (on[u]) cfma(acc[0], v[u], xv[u]);
                     }
@@ -415,11 +415,13 @@ __device__ __forceinline__ void ml_coupling_body(const MLCplArgs& C, const int b
                     on[u] = p + u * G < e1 && col[u] >= col_lo && col[u] < col_hi;
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) xv[u] = xin[(int64_t)rhs0 * ldxin + col[u]];
+                for (int u = 0; u < 4; ++u) xv[u] = xin[(int64_t)rhs0 * ldxin + (on[u] ? col[u] : col_lo)];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) if (on[u]) cfma(acc[0], v[u], xv[u]);
             }
         } else {
+            // (several right-hand sides, i.e. the apex build: grouping two entries' 2 + 16 loads per trip was measured -- coupling
+            // 225 -> 256 us, level kernels 368 -> 402 / 504 -> 469 us: no net gain, not in)
             for (int p = e0 + sub; p < e1; p += G) {
                 const int col = ci[p];
                 if (col < col_lo || col >= col_hi) continue;

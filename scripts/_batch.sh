@@ -1,7 +1,5 @@
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/b46
-for at in 12 1 4 8 12 1 6; do
-NEP_ML_APEX_AT=$at python bench.py --steps 30 --warmup 5 --no-c5 --no-cold 2>/dev/null | python -c "
-import sys,json
-j=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$at', j['value'], j['ms_per_step'])" >> gpurun_out/b46/apex_at.txt
-done
+export TMPDIR=/tmp
+mkdir -p gpurun_out/b48
+timeout 1800 python -m pytest tests/test_gpu_kernels.py tests/test_gpu_solvers.py -x -q -m gpu -k "lu or solve or iar or refine or trsv or factor" > gpurun_out/b48/pytest.log 2>&1
+python bench.py --steps 30 --warmup 5 --no-c5 --no-cold > gpurun_out/b48/bench.json 2> gpurun_out/b48/bench.err
