@@ -115,6 +115,38 @@ def test_resid_batch(na, k):
         assert e[s] == pytest.approx(ref, rel=1e-11)
 
 
+@pytest.mark.parametrize("k", [1, 7, 64, 65, 128])
+def test_resid_batch_long_and_empty_rows(na, k):
+    """K2 on the row-major wave-per-row kernel (k_spmm_rm_g, round 3: gathers issued in groups, entries fetched a row ahead) with rows of
+    more than 64 stacked entries (further chunks loaded inside the row), rows without entries and a complex term; k at the 64 / 128
+    column boundaries of its two instantiations -- against NumPy"""
+    import torch
+    n, mt = 403, 4
+    AA, ofv, rng = _rand_spmf(n, mt, 0.11, 11, cplx_vals=True)          # ~ 4 x 44 (+ complex part) = 180-270 entries per row
+    AA = [sp.lil_matrix(A) for A in AA]
+    for A in AA:
+        for r in (0, 17, 200, n - 1):
+            A[r, :] = 0                                              # rows without entries in every term
+    AA = [sp.csc_matrix(A) for A in AA]
+    for A in AA:
+        A.eliminate_zeros()
+    pnep = na.SPMF_NEP(AA, _pfv(na, mt))
+    Q = rng.standard_normal((n, k)) + 1j * rng.standard_normal((n, k))
+    lams = 120.0 ** 2 + rng.standard_normal(k) * 100 + 1j * rng.standard_normal(k)
+    QT = torch.from_numpy(np.ascontiguousarray(Q)).to("cuda")
+    e = na.ResidualErrmeasure(pnep).batch(list(lams), QT)
+    fv = _pfv(na, mt)
+    for s in range(k):
+        r = sum(fv[i](lams[s]) * (AA[i] @ Q[:, s]) for i in range(mt))
+        assert e[s] == pytest.approx(np.linalg.norm(r) / np.linalg.norm(Q[:, s]), rel=1e-11)
+    # compute_MM runs its SpMM through the same kernel (coefficient 1, one column block per term)
+    if k <= 7:
+        S = rng.standard_normal((k, k)) + 120.0 ** 2 * np.eye(k)
+        from oracle import neps as oneps
+        Zo = oneps.SPMF_NEP(AA, ofv).compute_MM(S, Q)
+        assert np.linalg.norm(pnep.compute_MM(S, Q) - Zo) <= 1e-10 * np.linalg.norm(Zo)
+
+
 @pytest.mark.parametrize("rows,k,p", [(16, 4, 8), (100, 3, 5), (1000, 37, 41), (333, 100, 100), (257, 61, 120),
                                       (5, 2, 1), (4096, 16, 60)])
 @pytest.mark.parametrize("rowmajor", [False, True])
