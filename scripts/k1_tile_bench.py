@@ -92,5 +92,5 @@ if what in ("wep", "all"):
     from nep_amd import wep
     wd = wep.WaveguideData(1003, 999, "JARLEBRING")
     dev = na.SPMFDevice(wd.big_matrices())
-    run("wep", dev, (1, 2, 4, 8, 16, 32, 60), 20)
+    run("wep", dev, tuple(int(x) for x in os.environ.get("NEP_TILE_BENCH_KS", "1,2,4,8,16,32,60").split(",")), 20)
     run_k2("wep", dev, (8, 30, 60), 10)
