@@ -290,10 +290,17 @@ __global__ __launch_bounds__(256) void k_tridiag_modes(int nz, int nx, const cpl
     const int64_t base = (int64_t)i * nx;
     const int j0 = lane * SEG;
     cplx c[SEG], al[SEG];           // c: right-hand side, then y, then h;  al: forward multipliers, then g
+    // (unconditional loads with a clamped index, masked afterwards: behind a per-entry `if (j < nx)` the 2 x SEG loads of a lane sat in
+    // SEG exec-masked branches and were waited for one pair at a time)
+    cplx dv[SEG];                   // dinv of the segment, fetched with the other two arrays (used by the backward sweep)
 #pragma unroll
     for (int t = 0; t < SEG; ++t) {
-        const int j = j0 + t;
-        if (j < nx) { c[t] = T[base + j]; const cplx m = mfac[base + j]; al[t] = cmake(-m.x, -m.y); }
+        const int j = j0 + t < nx ? j0 + t : nx - 1;
+        c[t] = T[base + j]; al[t] = mfac[base + j]; dv[t] = dinv[base + j];
+    }
+#pragma unroll
+    for (int t = 0; t < SEG; ++t) {
+        if (j0 + t < nx) al[t] = cmake(-al[t].x, -al[t].y);
         else { c[t] = cmake(0.0, 0.0); al[t] = cmake(0.0, 0.0); }     // padding maps everything to 0 (never used downstream)
     }
     // ---- forward: segment composite, inclusive scan over lanes, apply
@@ -315,7 +322,7 @@ __global__ __launch_bounds__(256) void k_tridiag_modes(int nz, int nx, const cpl
 #pragma unroll
     for (int t = 0; t < SEG; ++t) {
         const int j = j0 + t;
-        if (j < nx) { const cplx di = dinv[base + j]; al[t] = cmake(-b * di.x, -b * di.y); c[t] = cmul(c[t], di); }
+        if (j < nx) { const cplx di = dv[t]; al[t] = cmake(-b * di.x, -b * di.y); c[t] = cmul(c[t], di); }
         else { al[t] = cmake(0.0, 0.0); c[t] = cmake(0.0, 0.0); }      // beyond the end: x = 0
     }
     Aff segb; segb.A = cmake(1.0, 0.0); segb.B = cmake(0.0, 0.0);      // maps x_{j0+SEG} to x_{j0}: entry SEG-1 acts first
