@@ -222,6 +222,9 @@ __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int
             for (int c = 0; c < COLS; ++c) acc[b][c] = cmake(0.0, 0.0);
         }
         const cplx* tc = ts + (size_t)k1 * N2 * COLS;
+        int oidx[KB];                                   // output positions: requested before the n2 loop, not behind it
+#pragma unroll
+        for (int b = 0; b < KB; ++b) oidx[b] = out_idx[k1 * N2 + (kk[b] < N2 ? kk[b] : 0)];
         for (int n2 = 0; n2 < N2; ++n2) {
             const cplx* tp = tc + (size_t)n2 * COLS;
             const cplx t0v = tp[0], t1v = tp[1], t2v = tp[2], t3v = tp[3];
@@ -236,7 +239,7 @@ __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int
 #pragma unroll
         for (int b = 0; b < KB; ++b)
             if (kk[b] < N2) {
-                const int o = out_idx[k1 * N2 + kk[b]];
+                const int o = oidx[b];
                 if (FWD) {
 #pragma unroll
                     for (int c = 0; c < COLS; ++c)
