@@ -977,7 +977,7 @@ static bool use_tiles_k2(const nep_spmf* s, int k) {
     if (g_k1_mode == 1) return true;
     // measured at n = 1e6: 4.5x faster than the wave-per-row kernel at k = 8, 1.35x at k = 30, slower at k = 60
     // (row-major Q: a column panel of a footprint row is a 64-byte piece of a 16 k-byte row)
-    static const int kmax = getenv("NEP_K2_TILE_KMAX") ? atoi(getenv("NEP_K2_TILE_KMAX")) : 26;     // above: k_spmm_rm_g (0.47 ms at k = 30, tiles 0.50)
+    static const int kmax = getenv("NEP_K2_TILE_KMAX") ? atoi(getenv("NEP_K2_TILE_KMAX")) : 20;     // above: k_spmm_rm_g (0.47 ms at k = 30, tiles 0.50-0.63)
     return s->d_sell_ptr != nullptr && k <= kmax;
 }
 

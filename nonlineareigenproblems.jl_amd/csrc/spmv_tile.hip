@@ -602,6 +602,29 @@ static bool tiles_build_host(TileBuilder& B, int64_t n, int mt, int valbytes, co
     int zp = env_int("NEP_K1_TILE_ZP", small ? 16 : 64), xp = env_int("NEP_K1_TILE_XP", small ? 4 : 8);
     if (zp < 1) zp = 1;
     if (xp < 1) xp = 1;
+    // Patch height for large grids (round 3, late): the launch runs in ROUNDS of (CUs x resident workgroups per CU) blocks, and a
+    // last round that is barely filled costs as much as a full one -- 8 x 64 patches on the 1003 x 999 waveguide grid: 2016 blocks
+    // = 1.6 rounds of 5 per CU (0.58 of the HBM roofline at k = 8), 10 x 64: 2.1 rounds of 3 (0.47), 11 x 64 / 12 x 64: 1.9 / 1.75
+    // rounds of 3 (0.60-0.62).  Pick the height that minimises ceil(rounds) x resident blocks x footprint (a 5-point halo assumed).
+    if (!small && stride > 0 && !getenv("NEP_K1_TILE_XP")) {
+        const int ncu = env_int("NEP_K1_TILE_NCU", 256);
+        const int zq = std::min(zp, stride);
+        const int64_t X = n / stride;
+        const int mtc = std::min(mt, 4);
+        double best = 1.0e300; int best_xp = xp;
+        for (int cand = 8; cand <= 14; ++cand) {
+            const int64_t nb = ((X + cand - 1) / cand) * ((stride + zq - 1) / zq);
+            const int64_t fpn = (int64_t)(cand + 2) * (zq + 2);
+            const double lds = (double)fpn * mtc * 16.0;
+            if (lds > lds_kb * 1024.0 || fpn > B.fcap_max) continue;
+            const int bpc = std::min(8, (int)(152.0 * 1024.0 / lds));
+            if (bpc < 3) continue;                            // two workgroups per CU do not hide their own dependent loads
+            const int64_t rounds = (nb + (int64_t)ncu * bpc - 1) / ((int64_t)ncu * bpc);
+            const double score = (double)rounds * bpc * (double)fpn;
+            if (score < best - 1e-9) { best = score; best_xp = cand; }
+        }
+        xp = best_xp;
+    }
     if (stride > 0) {
         zp = std::min(zp, stride);
         const int64_t X = n / stride;
