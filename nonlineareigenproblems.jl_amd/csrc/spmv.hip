@@ -682,13 +682,14 @@ __global__ __launch_bounds__(256) void k_spmm_rm_g(const int32_t* __restrict__ r
     int64_t row = r_lo + slot * 4LL + w;
     if (row >= r_hi) row = -1;
     const int64_t last = r_hi - 1;
+    const int nnzm1 = max(__builtin_amdgcn_readfirstlane(rowptr[n]) - 1, 0);
     // pipeline registers: entries of the current row (id_c, a_c, extent ce0..ce1), pointers of the next row (e0n, e1n)
     int ce0 = 0, ce1 = 0, e0n = 0, e1n = 0;
     uint32_t id_c = 0; VT a_c;
     if constexpr (sizeof(VT) == 8) a_c = 0.0; else a_c = cmake(0.0, 0.0);
     if (row >= 0) {
         ce0 = __builtin_amdgcn_readfirstlane(rowptr[row]); ce1 = __builtin_amdgcn_readfirstlane(rowptr[row + 1]);
-        const int me = min(ce0 + lane, ce1 > ce0 ? ce1 - 1 : ce0);
+        const int me = min(min(ce0 + lane, ce1 > ce0 ? ce1 - 1 : ce0), nnzm1);        // (an empty LAST row has ce0 = nnz: stay inside the arrays)
         id_c = idx[me]; a_c = vals[me];
         const int64_t r1 = min(row + step, last);
         e0n = __builtin_amdgcn_readfirstlane(rowptr[r1]); e1n = __builtin_amdgcn_readfirstlane(rowptr[r1 + 1]);
@@ -696,7 +697,7 @@ __global__ __launch_bounds__(256) void k_spmm_rm_g(const int32_t* __restrict__ r
     for (; row >= 0 && row < r_hi; row += step) {
         // ---- ahead (unconditional, clamped to the last row of the range): entries of the next row, pointers of the one after
         const int ne0 = e0n, ne1 = e1n;
-        const int men = min(ne0 + lane, ne1 > ne0 ? ne1 - 1 : ne0);
+        const int men = min(min(ne0 + lane, ne1 > ne0 ? ne1 - 1 : ne0), nnzm1);
         const uint32_t id_n = idx[men];
         const VT a_n = vals[men];
         {
