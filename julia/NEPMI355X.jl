@@ -7,7 +7,8 @@
 # unchanged.  Julia is not installed in the build image of this repository, so the file has NOT been executed there; every C
 # symbol it calls is exercised by the ctypes host (nonlineareigenproblems.jl_amd/_lib.py) in the `-m gpu` test suite, and
 # tests/test_host_logic.py::test_julia_binding_symbols_exist checks that each `ccall` target below is exported by the
-# library and declared in include/nepmi355.h.
+# library and declared in include/nepmi355.h; test_julia_ccall_signatures_match_the_header parses every `ccall` type tuple and
+# compares arity, scalar widths and pointer-ness with the C prototype (Julia is absent from the GPU box as well: probed, round 4).
 #
 # Library search: put the directory of libnepmi355.so on LD_LIBRARY_PATH (or set `const LIB` to its absolute path).
 
@@ -85,9 +86,23 @@ function compute_Mlincomb(d::DeviceSPMF, λ::Number, V::DevBuf, a::Vector = ones
 end
 
 # ---- LinSolver seam (src/LinSolvers.jl:64-91 is the reference's own extension recipe) ---------------------
-mutable struct DeviceLinSolver <: LinSolver; handle::Ptr{Cvoid}; n::Int; end
-struct DeviceLinSolverCreator <: LinSolverCreator end
-function create_linsolver(::DeviceLinSolverCreator, nep, λ)
+# A DeviceLinSolver is what FactorizeLinSolver is in the reference (src/LinSolvers.jl:109-122): factors of M(λ) made once
+# and, like `Afact \ x` with control[8] = umfpack_refinements, every solve followed by iterative refinement with UMFPACK's
+# stopping rule.  `spmf` / `cf` / `cabs` (handle, f_t(λ), |f_t(λ)|) are what the refinement needs to form r = b - M(λ)x on the
+# device; a solver made for a NEP that is not a DeviceSPMF has spmf == C_NULL and solves without refinement.
+mutable struct DeviceLinSolver <: LinSolver
+    handle::Ptr{Cvoid}; n::Int
+    spmf::Ptr{Cvoid}; cf::Vector{ComplexF64}; cabs::Vector{Float64}; umfpack_refinements::Int
+    resident::Bool                 # lin_solve returns a DevBuf (left in HBM) instead of a host array
+    keep::Any                      # keeps the DeviceSPMF (owner of `spmf`) alive as long as the solver
+end
+DeviceLinSolver(h::Ptr{Cvoid}, n::Integer) = DeviceLinSolver(h, n, C_NULL, ComplexF64[], Float64[], 0, false, nothing)
+struct DeviceLinSolverCreator <: LinSolverCreator
+    umfpack_refinements::Int       # same meaning and default as FactorizeLinSolverCreator (src/LinSolverCreators.jl:62-75)
+    resident::Bool
+end
+DeviceLinSolverCreator(; umfpack_refinements = 10, resident = false) = DeviceLinSolverCreator(umfpack_refinements, resident)
+function create_linsolver(creator::DeviceLinSolverCreator, nep, λ)
     F = lu(SparseMatrixCSC{ComplexF64,Int}(compute_Mder(nep, λ)))     # UMFPACK on the host, one-off per shift
     # UMFPACK: F.L * F.U == (F.Rs .* A)[F.p, F.q].  nep_lu_create_csc takes SparseMatrixCSC as it is (0-based Int32 indices);
     # (Pr b)[perm_r[i]] = b[i] -> perm_r = invperm(p) - 1 ;  x[i] = y[perm_c[i]] -> perm_c = invperm(q) - 1 ;
@@ -99,6 +114,11 @@ function create_linsolver(::DeviceLinSolverCreator, nep, λ)
         L.nzval, Int32.(U.colptr .- 1), Int32.(U.rowval .- 1), U.nzval, pr, pc, h))
     chk(ccall((:nep_lu_set_row_scale, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}), h[], Float64.(F.Rs)))
     s = DeviceLinSolver(h[], n)
+    if nep isa DeviceSPMF                                              # refinement needs M(λ)x on the device
+        s.spmf = nep.handle; s.keep = nep; s.umfpack_refinements = creator.umfpack_refinements
+        s.cf = ComplexF64[f(ComplexF64(λ)) for f in get_fv(nep)]; s.cabs = abs.(s.cf)
+    end
+    s.resident = creator.resident
     finalizer(x -> ccall((:nep_lu_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), s); s     # stream-ordered: safe with solves in flight
 end
 # Beyn factors N matrices of ONE sparsity pattern (method_beyncontour.jl:89-94): when UMFPACK returns the same L/U patterns and
@@ -133,13 +153,77 @@ function factor_nodes_on_device(plan, D::DevBuf, fv, λs::Vector{ComplexF64}, n;
         Ptr{Float64}, Ptr{Ptr{Cvoid}}, Ptr{Cvoid}), plan, length(λs), D.ptr, length(fv), Cf, 1, growth, health, hs, C_NULL))
     [h == C_NULL ? nothing : DeviceLinSolver(h, n) for h in hs]    # nothing: that node is factorised on the host (lu(M(λ_b)))
 end
-function lin_solve(s::DeviceLinSolver, b::AbstractVecOrMat; tol = 0)
-    B = Matrix{ComplexF64}(reshape(b, s.n, :)); dB = DevBuf(s.n, size(B, 2)); upload!(dB, B)
-    lin_solve!(s, dB); X = download(dB); b isa AbstractVector ? vec(X) : X   # same shape as b, matrix RHS allowed (method_beyncontour.jl:91-93)
+# lin_solve: a new array shaped like b, matrix right-hand sides allowed (method_beyncontour.jl:21-23,91-93); `tol` is a
+# hint that direct solvers ignore (src/LinSolvers.jl:135-137).  A resident solver (DeviceLinSolverCreator(resident = true))
+# returns the DevBuf instead; `*(::DevBuf, ::Number)` below keeps the unchanged integrand `Tv(g(t))*gp(t)` of
+# method_beyncontour.jl:96-97 on the device, and integrate_interval accepts either kind of value.
+const PROBE = Ref{Any}(nothing)                   # (objectid, size, DevBuf) of the last uploaded right-hand-side block
+function upload_rhs(b::AbstractVecOrMat, n)
+    B = Matrix{ComplexF64}(reshape(b, n, :)); dB = DevBuf(n, size(B, 2)); upload!(dB, B); dB
 end
-lin_solve!(s::DeviceLinSolver, dB::DevBuf; scale = 1.0) =        # device-resident right-hand sides, solved in place
-    chk(ccall((:nep_lu_solve, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}),
-              s.handle, dB.cols, dB.ptr, s.n, dB.ptr, s.n, scale, C_NULL))
+function lin_solve(s::DeviceLinSolver, b::AbstractVecOrMat; tol = 0)
+    p = PROBE[]
+    if s.resident && b isa AbstractMatrix && p !== nothing && p[1] == objectid(b) && p[2] == size(b)
+        dB = DevBuf(s.n, size(b, 2))               # contour solvers pass the SAME probe block Vh at every node: uploaded once
+        chk(ccall((:nep_dev_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), dB.ptr, p[3].ptr, 16s.n*dB.cols, C_NULL))
+    else
+        dB = upload_rhs(b, s.n)
+        if s.resident && b isa AbstractMatrix
+            keep = DevBuf(s.n, dB.cols)
+            chk(ccall((:nep_dev_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), keep.ptr, dB.ptr, 16s.n*dB.cols, C_NULL))
+            PROBE[] = (objectid(b), size(b), keep)
+        end
+    end
+    lin_solve!(s, dB)
+    s.resident && return dB
+    X = download(dB); b isa AbstractVector ? vec(X) : X
+end
+# device-resident right-hand sides, solved in place: x = A^{-1} b, then per column UMFPACK's refinement loop
+# (src/LinSolvers.jl:114-122: control[8] = umfpack_refinements).  r = b - M(λ)x and the componentwise backward error
+# omega = max_i |r_i| / (Σ_t |f_t(λ)| (|A_t||x|)_i + |b_i|) come from nep_cw_backward_error in one pass over the matrices;
+# the update x <- x + A^{-1} r is nep_lu_solve_add.  Stop when omega <= 2 eps, when omega stops halving (a step that made it
+# worse is taken back) or after umfpack_refinements steps -- the rule nonlineareigenproblems.jl_amd/linsolvers.py:630-646 runs.
+function lin_solve!(s::DeviceLinSolver, dB::DevBuf; scale = 1.0)
+    n = s.n; nrhs = dB.cols
+    if s.spmf == C_NULL || s.umfpack_refinements <= 0
+        chk(ccall((:nep_lu_solve, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}),
+                  s.handle, nrhs, dB.ptr, n, dB.ptr, n, scale, C_NULL))
+        return dB
+    end
+    x = DevBuf(n, 1); xprev = DevBuf(n, 1); r = DevBuf(n, 1); ω = Ref{Float64}(0.0)
+    for j in 1:nrhs
+        b = dB.ptr + 16n*(j-1)                                        # column j of the right-hand sides, kept until the end
+        chk(ccall((:nep_lu_solve, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Float64, Ptr{Cvoid}),
+                  s.handle, 1, b, n, x.ptr, n, 1.0, C_NULL))
+        ωprev = Inf
+        for step in 0:s.umfpack_refinements
+            chk(ccall((:nep_cw_backward_error, LIB), Cint, (Ptr{Cvoid}, Ptr{Float64}, Ptr{ComplexF64}, Ptr{Cvoid}, Ptr{Cvoid},
+                      Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ref{Float64}, Ptr{Cvoid}),
+                      s.spmf, s.cabs, s.cf, x.ptr, b, C_NULL, C_NULL, r.ptr, ω, C_NULL))
+            ω[] <= 2eps(Float64) && break
+            if ω[] > ωprev / 2
+                ω[] > ωprev && chk(ccall((:nep_dev_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}),
+                                         x.ptr, xprev.ptr, 16n, C_NULL))       # the last step made it worse: take it back
+                break
+            end
+            step == s.umfpack_refinements && break
+            ωprev = ω[]
+            chk(ccall((:nep_dev_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), xprev.ptr, x.ptr, 16n, C_NULL))
+            chk(ccall((:nep_lu_solve_add, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Int64,
+                      Float64, Ptr{Cvoid}), s.handle, 1, r.ptr, n, x.ptr, n, x.ptr, n, 1.0, C_NULL))     # x <- x + A^{-1} r
+        end
+        chk(ccall((:nep_dev_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), b, x.ptr, 16n, C_NULL))
+    end
+    scale == 1.0 || chk(ccall((:nep_scal, LIB), Cint, (Int64, ComplexF64, Ptr{Cvoid}, Ptr{Cvoid}), n*nrhs, ComplexF64(scale), dB.ptr, C_NULL))
+    dB
+end
+# X * α on the device (a new DevBuf): what `Tv(g(t))*gp(t)` of method_beyncontour.jl:97 becomes for a resident solver
+function Base.:*(X::DevBuf, α::Number)
+    Y = DevBuf(X.rows, X.cols)
+    chk(ccall((:nep_dev_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), Y.ptr, X.ptr, 16X.rows*X.cols, C_NULL))
+    chk(ccall((:nep_scal, LIB), Cint, (Int64, ComplexF64, Ptr{Cvoid}, Ptr{Cvoid}), X.rows*X.cols, ComplexF64(α), Y.ptr, C_NULL)); Y
+end
+Base.size(X::DevBuf) = (X.rows, X.cols)
 
 # ---- orthogonalisation seam: a new IterativeSolvers.OrthogonalizationMethod (cf. test/iar.jl:7-17) ----------
 # The reference drivers pass HOST views (`view(V,1:nk,1:k)`, src/method_iar.jl:107; `Z[:,1:k]`, method_tiar.jl:128) and a
@@ -205,25 +289,43 @@ function init_comm!(rank::Integer, world::Integer, bcast!)      # bcast!(buf::Ve
     chk(ccall((:nep_comm_create, LIB), Cint, (Int32, Int32, Ptr{UInt8}, Ref{Ptr{Cvoid}}), rank, world, uid, h))
     COMM[] = Comm(h[], rank, world)
 end
-# same contract as the reference method: returns I[:,:,j] ~ int f g_j.  f(t) is the expensive part (one factorisation + one
-# block solve per node, method_beyncontour.jl:89-98); here it returns a DevBuf (n x k, left on the device by lin_solve!).
+# Same contract as the reference method (src/method_contour_common.jl:61-94): returns I[:,:,j] ~ int f g_j as an Array{T,3},
+# for ANY integrand the unchanged drivers build -- `f(t) = Tv(g(t))*gp(t)` of method_beyncontour.jl:89-98 returns a host
+# Matrix with the default (host-array) lin_solve and a DevBuf with a resident DeviceLinSolver; both are accepted, nothing else
+# is asked of f.  Rank r owns the nodes i = r+1, r+1+P, ...; the shape of an integrand value comes from the first value a
+# rank computes, and a rank without a node (N < P) learns it from the others through the same collective.
 function integrate_interval(::Type{MatrixTrapezoidalSharded}, ::Type{T}, f, gv, a, b, N, logger) where {T<:Number}
-    c = COMM[]; h = (b - a) / N; t = range(a, stop = b - h, length = N); m = length(gv)
-    S = nothing
-    for i in (c.rank+1):c.world:N                               # rank r owns the nodes i = r (mod P)
-        X = f(t[i])::DevBuf
-        S === nothing && (S = DevBuf(X.rows * X.cols, m);
-            chk(ccall((:nep_dev_memset, LIB), Cint, (Ptr{Cvoid}, Int32, Csize_t, Ptr{Cvoid}), S.ptr, 0, 16S.rows*m, C_NULL)))
+    c = COMM[]; c === nothing && error("MI355X.init_comm! has not been called on this rank")
+    h = (b - a) / N; t = range(a, stop = b - h, length = N); m = size(gv, 1)
+    G = ComplexF64[gv[j](t[i]) for i in 1:N, j in 1:m]          # the cheap part (method_contour_common.jl:71-78)
+    S = nothing                                                 # DevBuf (rows*cols) x m, partial sums of this rank
+    shape = (0, 0)
+    for i in (c.rank+1):c.world:N
+        X = f(t[i])                                             # the expensive part: one factorisation + one block solve
+        dX = X isa DevBuf ? X : upload_rhs(X, size(X, 1))       # host value: one upload per node (gun, k = 32: 5 MB)
+        if S === nothing
+            shape = (dX.rows, dX.cols); S = DevBuf(dX.rows * dX.cols, m)
+            chk(ccall((:nep_dev_memset, LIB), Cint, (Ptr{Cvoid}, Int32, Csize_t, Ptr{Cvoid}), S.ptr, 0, 16S.rows*m, C_NULL))
+        end
         for j in 1:m                                            # S[:,:,j] += X * g_j(t_i)   (method_contour_common.jl:88-90)
             chk(ccall((:nep_axpy, LIB), Cint, (Int64, ComplexF64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-                      S.rows, ComplexF64(gv[j](t[i])), X.ptr, S.ptr + 16S.rows*(j-1), C_NULL))
+                      S.rows, G[i, j], dX.ptr, S.ptr + 16S.rows*(j-1), C_NULL))
         end
     end
-    # the only exchange: all-gather of the partial block over xGMI + sum in rank order -> bit-identical on every rank
+    # every rank must enter the collective with a block of the same length: agree on the shape first.  Each rank that owns a
+    # node contributes (rows, cols, 1), the others zeros; the rank-ordered sum divided by its last entry is the shape.
+    meta = DevBuf(3, 1); upload!(meta, reshape(ComplexF64[shape[1], shape[2], S === nothing ? 0 : 1], 3, 1))
+    chk(ccall((:nep_allgather_sum, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}), c.handle, meta.ptr, 3, meta.ptr, C_NULL))
+    mt = real.(vec(download(meta))); mt[3] > 0 || error("integrate_interval: no rank owns a quadrature node (N = $N)")
+    n = round(Int, mt[1] / mt[3]); k = round(Int, mt[2] / mt[3])
+    if S === nothing                                            # a rank without a node contributes zeros
+        S = DevBuf(n * k, m)
+        chk(ccall((:nep_dev_memset, LIB), Cint, (Ptr{Cvoid}, Int32, Csize_t, Ptr{Cvoid}), S.ptr, 0, 16S.rows*m, C_NULL))
+    end
+    # the only exchange of data: all-gather of the partial block over xGMI + sum in rank order -> bit-identical on every rank
     chk(ccall((:nep_allgather_sum, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
               c.handle, S.ptr, S.rows * m, S.ptr, C_NULL))
     chk(ccall((:nep_scal, LIB), Cint, (Int64, ComplexF64, Ptr{Cvoid}, Ptr{Cvoid}), S.rows * m, ComplexF64(h), S.ptr, C_NULL))
-    n, k = size(f(t[1]; shape_only = true))                     # (rows, cols) of one integrand value
-    reshape(download(S), n, k, m)                               # Array{T,3}, as src/method_contour_common.jl:93 returns it
+    Array{T,3}(reshape(download(S), n, k, m))                   # S * h as src/method_contour_common.jl:93 returns it
 end
 end # module

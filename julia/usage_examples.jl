@@ -3,6 +3,14 @@
 nep  = DeviceSPMF(shift_and_scale(SPMF_NEP(get_Av(gun), get_fv(gun)), shift=250^2, scale=330^2-220^2))
 λ, Q = iar(nep; maxit=100, neigs=Inf, v=ones(size(nep,1)), linsolvercreator=MI355X.DeviceLinSolverCreator())
 
+# config C4, one Julia process per GPU (MPI.jl only launches the ranks and carries RCCL's 128-byte id); contour_beyn itself is
+# the reference's, unchanged -- MatrixTrapezoidalSharded is selected by its third positional argument (method_beyncontour.jl:48-51)
+MPI.Init(); comm = MPI.COMM_WORLD
+MI355X.init_comm!(MPI.Comm_rank(comm), MPI.Comm_size(comm), buf -> MPI.Bcast!(buf, 0, comm))
+gunspmf = DeviceSPMF(SPMF_NEP(get_Av(gun), get_fv(gun)))
+λ, V = contour_beyn(gunspmf, MI355X.MatrixTrapezoidalSharded; σ=250.0^2, radius=1e4, N=64, k=32, neigs=typemax(Int), tol=1e-6,
+                    linsolvercreator=MI355X.DeviceLinSolverCreator(umfpack_refinements=0, resident=true))
+
 # V: DevBuf, (m+1) columns of n(m+1); Ctab: DevBuf m x mt, row j = alpha_j/j * f^(j)(sigma); H: DevBuf m x (m+4), zero-filled;
 # Hpin: pinned host Matrix{ComplexF64}(undef, m+4, m) (hipHostMalloc'ed, read by the eig task)
 h = Ref{Ptr{Cvoid}}()

@@ -591,6 +591,111 @@ def test_julia_binding_symbols_exist():
     assert first.strip() in jl
 
 
+def _split_top(txt):
+    """split at top-level commas (parentheses, brackets and braces nest; string literals are skipped)"""
+    out, depth, cur, i = [], 0, "", 0
+    while i < len(txt):
+        ch = txt[i]
+        if ch == '"':
+            j = txt.index('"', i + 1); cur += txt[i:j + 1]; i = j + 1; continue
+        if ch in "([{":
+            depth += 1
+        elif ch in ")]}":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+        i += 1
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _balanced(txt, start):
+    """text between the parenthesis at `start` and its partner"""
+    depth, i = 0, start
+    while True:
+        if txt[i] == '"':
+            i = txt.index('"', i + 1)
+        elif txt[i] == "(":
+            depth += 1
+        elif txt[i] == ")":
+            depth -= 1
+            if depth == 0:
+                return txt[start + 1:i]
+        i += 1
+
+
+def _julia_class(t):
+    t = t.strip()
+    if t.startswith(("Ptr{", "Ref{")) or t in ("Cstring",):
+        return "ptr"
+    return {"Cint": "i32", "Int32": "i32", "Int64": "i64", "Csize_t": "i64", "Float64": "f64", "ComplexF64": "c128"}[t]
+
+
+def _c_class(t):
+    t = t.strip()
+    if "*" in t or re.match(r"(const\s+)?nep_stream\b", t):
+        return "ptr"
+    t = re.sub(r"\bconst\b", "", t).split()[0]
+    return {"int32_t": "i32", "int": "i32", "int64_t": "i64", "size_t": "i64", "double": "f64", "nep_cdouble": "c128"}[t]
+
+
+def _c_prototypes(hdr):
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ ]*?[\s\*]+)(nep_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", hdr):
+        ret, name, args = m.group(1), m.group(2), m.group(3)
+        args = [] if args.strip() in ("", "void") else [a for a in _split_top(args)]
+        protos[name] = (_c_class(ret + " x"), [_c_class(a) for a in args])
+    return protos
+
+
+def _julia_ccalls(src):
+    src = "\n".join(ln.split("#")[0] if '"' not in ln else ln for ln in src.splitlines())      # comments off (no '#' in strings here)
+    calls = []
+    for m in re.finditer(r"\bccall\(", src):
+        parts = _split_top(_balanced(src, m.end() - 1))
+        name = re.match(r"\(:(nep_[a-z0-9_]+)\s*,\s*LIB\)", parts[0]).group(1)
+        tup = parts[2]
+        assert tup.startswith("(") and tup.endswith(")"), (name, tup)
+        types = [x for x in _split_top(tup[1:-1]) if x]
+        calls.append((name, _julia_class(parts[1]), [_julia_class(x) for x in types], len(parts) - 3))
+    return calls
+
+
+def test_julia_ccall_signatures_match_the_header():
+    """every `ccall` of julia/NEPMI355X.jl and julia/usage_examples.jl against its prototype in include/nepmi355.h: same
+    number of arguments in the type tuple AND in the call, same scalar width / pointer-ness per position, same return kind
+    (Julia cannot be run here, and a wrong tuple is silent memory corruption there).  The checker itself is checked on a
+    deliberately broken tuple."""
+    protos = _c_prototypes(open(os.path.join(ROOT, "include", "nepmi355.h")).read())
+    assert len(protos) >= 90 and protos["nep_axpy"] == ("i32", ["i64", "c128", "ptr", "ptr", "ptr"])
+    n = 0
+    for fn in ("NEPMI355X.jl", "usage_examples.jl"):
+        for name, ret, types, nargs in _julia_ccalls(open(os.path.join(ROOT, "julia", fn)).read()):
+            cret, cargs = protos[name]
+            assert ret == cret, (fn, name, "return", ret, cret)
+            assert types == cargs, (fn, name, types, cargs)
+            assert nargs == len(types), (fn, name, "call passes %d values for %d types" % (nargs, len(types)))
+            n += 1
+    assert n >= 40
+    # also the ccalls quoted in INTEGRATION.md outside the file's own block
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for block in md.split("```julia\n")[2:]:
+        for name, ret, types, nargs in _julia_ccalls(block.split("\n```", 1)[0]):
+            assert (ret, types) == protos[name], ("INTEGRATION.md", name, types, protos[name][1])
+            assert nargs == len(types), ("INTEGRATION.md", name)
+    # the checker fails on a broken tuple: Int32 where the header has int64_t, and a missing argument
+    bad = 'chk(ccall((:nep_axpy, LIB), Cint, (Int32, ComplexF64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), n, a, x, y, C_NULL))'
+    (name, ret, types, nargs), = _julia_ccalls(bad)
+    assert types != protos[name][1]
+    bad2 = 'chk(ccall((:nep_axpy, LIB), Cint, (Int64, ComplexF64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), n, a, x, y))'
+    (name, ret, types, nargs), = _julia_ccalls(bad2)
+    assert types == protos[name][1] and nargs != len(types)
+
+
 def test_no_vendor_blas_or_fft_behind_the_abi():
     """the product's library carries no reference to rocBLAS / hipBLAS / rocFFT (until round 3 nep_zgemm / nep_dgemm dlopen'ed
     rocBLAS for the dense-transform fallback of the waveguide preconditioner): every GEMM / DFT behind the C ABI is this
