@@ -420,6 +420,26 @@ def cold_call_summary():
     return d
 
 
+def cpu2_summary(ms_step):
+    """the headline step in a fresh process restricted to TWO CPUs (scripts/cpu2_call.py): the budget a replica has when 8
+    ranks share the benchmark box's 16-CPU quota.  Also the same with eig(H_k) on host LAPACK threads (the round-3 route)."""
+    import subprocess
+    out = {}
+    for mode in ("dev", "host"):
+        env = dict(os.environ, NEP_IAR_EIG=mode)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cpu2_call.py"), "10", "2"], capture_output=True, text=True,
+                           timeout=300, env=env)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode != 0 or not line:
+            out[mode] = {"error": (r.stderr or r.stdout)[-300:]}
+        else:
+            out[mode] = json.loads(line[-1])
+    if "ms_per_call_mean" in out.get("dev", {}):
+        out["ms_per_step_cpu2"] = out["dev"]["ms_per_call_mean"]
+        out["ratio_to_ms_per_step"] = out["dev"]["ms_per_call_mean"] / ms_step
+    return out
+
+
 def _cpu_budget():
     try:
         from nep_amd._affinity import cpu_budget
@@ -570,14 +590,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    import resource
+
+    def cpu_seconds():
+        r = resource.getrusage(resource.RUSAGE_SELF)
+        return r.ru_utime + r.ru_stime
+
     barrier()
-    t0 = time.perf_counter()
+    t0 = time.perf_counter(); c0 = cpu_seconds()
     pairs = 0
     for _ in range(args.steps):
         lam, Q = bc.c2_device(na, nep, args.maxit, args.permc)
         pairs += len(lam)
     barrier()
     dt = time.perf_counter() - t0
+    cpu_s_per_call = (cpu_seconds() - c0) / args.steps        # host CPU of this rank, all threads, per timed step
     if use_dist:
         t = torch.tensor([dt, float(pairs)], dtype=torch.float64, device=RED_DEV)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -641,6 +668,8 @@ def main():
             "value_excl_setup": world * per_step_pairs / max(ms_step * 1e-3 - t_setup, 1e-9),
             "linsolver_setup_ms": t_setup * 1e3,
             "ms_per_step_host_lu": ms_host_lu,
+            "cpu_s_per_call": cpu_s_per_call,     # host CPU seconds per timed step (getrusage, all threads of this rank)
+            "eig_route": os.environ.get("NEP_IAR_EIG", "dev") + " (eig(H_k) of every step: csrc/hesseig.hip on the device | LAPACK on host threads)",
             "warmup_calls_ms": warm_ms,           # the first call carries every one-off: symbolic schedule, host LU, allocator pools
             "settle_calls_ms": settle_ms,         # extra untimed calls after the device-LU plan became ready (when W < 4)
             "plan_wait_ms": plan_wait_ms,         # time the warm-up still had to wait for the device-LU plan (background thread)
@@ -710,6 +739,9 @@ def main():
                 out["roofline_wep_scale"] = {"error": repr(e)[:200]}
         if world == 1 and not args.no_cold:
             try:
+                c2 = cpu2_summary(ms_step)
+                out["cpu2"] = c2
+                out["ms_per_step_cpu2"] = c2.get("ms_per_step_cpu2")
                 cc = cold_call_summary()
                 out["cold_call"] = cc
                 out["cold_call_ms"] = cc.get("cold_call_ms")

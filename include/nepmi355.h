@@ -61,6 +61,11 @@ int32_t nep_upload(void* ddst, const void* hsrc, size_t bytes, nep_stream stream
 int32_t nep_download(void* hdst, const void* dsrc, size_t bytes, nep_stream stream); /* sync */
 int32_t nep_dev_copy(void* ddst, const void* dsrc, size_t bytes, nep_stream stream);
 int32_t nep_stream_sync(nep_stream stream);
+/* *out = 1 when kernels of the two streams execute one after the other (the streams share a hardware queue of the runtime's
+ * pool), 0 when they overlap.  Measured (three ~0.4 ms probes; both streams are synchronised): a host that puts long
+ * one-wavefront kernels (nep_hess_eig*_dev) on a side stream picks one that serialises with neither its main stream nor the
+ * stream of its convergence checks. */
+int32_t nep_stream_pair_serializes(nep_stream a, nep_stream b, int32_t* out);
 
 /* ---- SPMF object: M(lambda) = sum_i f_i(lambda) A_i ------------------------------------
  * replaces: struct SPMF_NEP  src/NEPTypes.jl:162-170 (+ get_Av :103, DEP :427-443,
@@ -186,6 +191,37 @@ int32_t nep_gemv_h(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, 
  * index, per-workgroup partial tiles summed in a fixed order.  Synchronous. */
 int32_t nep_gemm_h_rm(const nep_cdouble* dWT, int64_t ldw, const nep_cdouble* dYT, int64_t ldy, int64_t rows,
                       int32_t k, int32_t p, nep_cdouble* h_C, nep_stream stream);
+
+/* ---- eigen-decomposition of the small Hessenberg matrix of a Krylov driver, on the device ---------------------------------
+ * replaces: `D,Z = eigen(H[1:k,1:k])`  src/method_iar.jl:112, src/method_tiar.jl:182 (LAPACK zgeev on the host there).
+ * dH: k x k upper Hessenberg, column-major with leading dimension ldh (entries below the first subdiagonal are not read --
+ * the rows of nep_iar_step's device H block, leading dimension m + 4, are exactly this layout).
+ * nep_hess_eigvals_dev: eigenvalues by the shifted QR iteration (one wavefront, matrix in LDS; k <= 100, else
+ *   NEP_ERR_UNSUPPORTED) -> d_w[0..k); d_w[k] = (0 | 1-based index of the eigenvalue the iteration gave up on, sweeps).
+ * nep_hess_eigvecs_dev: right eigenvectors by inverse iteration (LAPACK zhsein's scheme, one wavefront per eigenvalue) ->
+ *   dZ (k x k column-major, ldz), unit 2-norm, largest component real positive; d_w[k+1] = (vectors that failed, 0).
+ *   Must follow nep_hess_eigvals_dev on the same stream with the same d_w / d_work.
+ * d_w: k + 2 complex (device).  d_work: nep_hess_eig_worksize bytes (device).  h_mirror: NULL, or mapped pinned host memory
+ * of k + 2 complex that receives a copy of d_w (eigenvalues + status as soon as the first kernel ends, the second status
+ * word when the last eigenvector is done) -- a host that records an event behind each call reads them without a copy command.
+ * A caller that finds a non-zero status falls back to LAPACK.  Asynchronous. */
+int32_t nep_hess_eig_worksize(int32_t k, int64_t* bytes);
+int32_t nep_hess_eigvals_dev(int32_t k, const nep_cdouble* dH, int64_t ldh, nep_cdouble* d_w, void* d_work,
+                             nep_cdouble* h_mirror, nep_stream stream);
+int32_t nep_hess_eigvecs_dev(int32_t k, nep_cdouble* d_w, nep_cdouble* dZ, int64_t ldz, void* d_work, nep_cdouble* h_mirror,
+                             nep_stream stream);
+/* the same for a batch of nb leading blocks of ONE Hessenberg matrix, sizes k0, k0 + kstep, ... (the Arnoldi matrices of
+ * consecutive steps), one workgroup per block in a single launch -- the decompositions of a driver's steps then overlap each
+ * other on one stream instead of queueing behind each other (a decomposition is a serial chain of ~50 k^2 rotations: 3 ms at
+ * k = 100, while an Arnoldi step takes 0.3 ms).  Block b: results at d_w + b w_stride (w_stride >= kmax + 2), eigenvectors at
+ * dZ + b z_stride with leading dimension ldz >= kmax, workspace d_work + b work_stride bytes (work_stride >=
+ * nep_hess_eig_worksize(kmax), multiple of 16), mirror at h_mirror + b mirror_stride. */
+int32_t nep_hess_eigvals_batch_dev(int32_t nb, int32_t k0, int32_t kstep, const nep_cdouble* dH, int64_t ldh, nep_cdouble* d_w,
+                                   int64_t w_stride, void* d_work, int64_t work_stride, nep_cdouble* h_mirror,
+                                   int64_t mirror_stride, nep_stream stream);
+int32_t nep_hess_eigvecs_batch_dev(int32_t nb, int32_t k0, int32_t kstep, nep_cdouble* d_w, int64_t w_stride, nep_cdouble* dZ,
+                                   int64_t ldz, int64_t z_stride, void* d_work, int64_t work_stride, nep_cdouble* h_mirror,
+                                   int64_t mirror_stride, nep_stream stream);
 
 /* ---- K7 tall-skinny GEMM on the FP64 matrix cores --------------------------------------
  * Y = Z * B,  Z: rows x k (ldz, device), B: k x p (host, column-major, ldb), Y: rows x p.
@@ -444,6 +480,9 @@ int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream str
 /* steps k0 .. k0+count-1 (same refine_steps) in one foreign call */
 int32_t nep_iar_steps(nep_iar* s, int32_t k0, int32_t count, int32_t refine_steps, nep_stream stream);
 int32_t nep_iar_wait(nep_iar* s, int32_t k);
+/* device-side counterpart of nep_iar_wait: work enqueued on `stream` after this call starts only when column k of H is
+ * complete (the eigen-decomposition of step k on a second stream: nep_hess_eigvals_dev on row block dH of nep_iar_create) */
+int32_t nep_iar_stream_wait(nep_iar* s, int32_t k, nep_stream stream);
 
 /* ---- multi-GPU exchange of the contour integrators ----------------------------------------
  * replaces: the reduction inside `integrate_interval(::Type{<:MatrixIntegrator}, ...)` src/method_contour_common.jl:46,61-94

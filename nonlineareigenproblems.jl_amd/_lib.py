@@ -26,7 +26,8 @@ def _load():
     # .so with changed argument lists would corrupt memory through ctypes.  Never falls back to a CPU path.
     from . import build
     if build.needs_build():
-        if os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+        import shutil
+        if shutil.which(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
             build.build_lib(verbose=False)        # serialised across processes by a file lock, linked to a temp name + rename
         elif not os.path.exists(LIB_PATH):
             raise ImportError("libnepmi355.so is missing and hipcc is not available to build it")
@@ -71,6 +72,7 @@ SIGNATURES = {
     "nep_download": [c_vp, c_vp, c_sz, c_vp],
     "nep_dev_copy": [c_vp, c_vp, c_sz, c_vp],
     "nep_stream_sync": [c_vp],
+    "nep_stream_pair_serializes": [c_vp, c_vp, P(c_i32)],
     "nep_spmf_create": [c_i64, c_i32, P(c_vp), P(c_vp), P(c_vp), P(c_i32), P(c_vp)],
     "nep_spmf_destroy": [c_vp],
     "nep_spmf_info": [c_vp, P(c_i64)],
@@ -134,6 +136,12 @@ SIGNATURES = {
     "nep_iar_step": [c_vp, c_i32, c_i32, c_vp],
     "nep_iar_steps": [c_vp, c_i32, c_i32, c_i32, c_vp],
     "nep_iar_wait": [c_vp, c_i32],
+    "nep_iar_stream_wait": [c_vp, c_i32, c_vp],
+    "nep_hess_eig_worksize": [c_i32, P(c_i64)],
+    "nep_hess_eigvals_dev": [c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
+    "nep_hess_eigvecs_dev": [c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp],
+    "nep_hess_eigvals_batch_dev": [c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
+    "nep_hess_eigvecs_batch_dev": [c_i32, c_i32, c_i32, c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp],
     "nep_comm_unique_id": [c_vp],
     "nep_comm_create": [c_i32, c_i32, c_vp, P(c_vp)],
     "nep_comm_destroy": [c_vp],

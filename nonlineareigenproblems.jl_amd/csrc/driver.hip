@@ -195,4 +195,11 @@ int32_t nep_iar_wait(nep_iar* s, int32_t k) {
     return NEP_OK;
 }
 
+// orders `stream` behind step k without involving the host
+int32_t nep_iar_stream_wait(nep_iar* s, int32_t k, nep_stream stream) {
+    ARGCHK(s && k >= 1 && k <= s->m && s->ev[k]);
+    HIPCHK(hipStreamWaitEvent(as_stream(stream), s->ev[k], 0));
+    return NEP_OK;
+}
+
 }  // extern "C"

@@ -3,6 +3,7 @@
 #include <vector>
 #include <algorithm>
 #include <math.h>
+#include <time.h>
 
 static thread_local char g_err[1024] = "";
 
@@ -259,6 +260,43 @@ int32_t nep_download(void* hdst, const void* dsrc, size_t bytes, nep_stream stre
 int32_t nep_dev_copy(void* ddst, const void* dsrc, size_t bytes, nep_stream stream);
 int32_t nep_stream_sync(nep_stream stream) {
     HIPCHK(hipStreamSynchronize(as_stream(stream)));
+    return NEP_OK;
+}
+
+// Do two streams execute their kernels one after the other?  The runtime maps streams onto a small pool of hardware queues (4
+// by default) and two streams that land on the same queue serialise -- a 3 ms one-wavefront kernel (csrc/hesseig.hip) then
+// holds up whatever shares its queue (measured: iar's convergence checks behind the eigen-decompositions, 4 ms per batch; a
+// stream created with a compute-unit mask does get a queue of its own, but the recurrence's queue then stalls while such a
+// kernel runs).  There is no query for the mapping, so it is measured: a one-wavefront kernel that idles for ~0.4 ms on
+// stream a, an empty kernel on stream b right behind it, and the host's clock around b's synchronisation.
+__global__ void k_idle_cycles(long long cycles) {
+    const long long t0 = clock64();
+    while (clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(8);
+}
+__global__ void k_empty() {}
+
+int32_t nep_stream_pair_serializes(nep_stream a, nep_stream b, int32_t* out) {
+    ARGCHK(out != nullptr);
+    *out = 0;
+    hipStream_t sa = as_stream(a), sb = as_stream(b);
+    if (sa == sb) { *out = 1; return NEP_OK; }
+    int votes = 0;
+    for (int rep = 0; rep < 3; ++rep) {
+        HIPCHK(hipStreamSynchronize(sa)); HIPCHK(hipStreamSynchronize(sb));
+        hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, sb);          // first-use costs out of the way
+        HIPCHK(hipStreamSynchronize(sb));
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
+        hipLaunchKernelGGL(k_idle_cycles, dim3(1), dim3(64), 0, sa, (long long)1000000);       // ~0.4 ms at 2.4 GHz
+        hipLaunchKernelGGL(k_empty, dim3(1), dim3(64), 0, sb);
+        HIPCHK(hipStreamSynchronize(sb));
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        HIPCHK(hipStreamSynchronize(sa));
+        const double us = (t1.tv_sec - t0.tv_sec) * 1e6 + (t1.tv_nsec - t0.tv_nsec) * 1e-3;
+        if (us > 250.0) ++votes;
+    }
+    LAUNCHCHK();
+    *out = votes >= 2 ? 1 : 0;
     return NEP_OK;
 }
 

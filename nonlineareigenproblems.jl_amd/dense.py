@@ -5,7 +5,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import lib, check, hptr, c_vp, c_i32, c_dbl
+from ._lib import lib, check, hptr, c_vp, c_i32, c_i64, c_dbl
 from .nep import CDT, stream_ptr
 
 DGKS, CGS, MGS = 0, 1, 2
@@ -47,6 +47,20 @@ def gemm_ts(Z, B, rowmajor=False, out=None, k=None, rows=None, ldz=None):
     ldy = out.shape[1]
     check(lib.nep_gemm_ts(c_vp(Z.data_ptr()), ldz, rows, k, hptr(Bm), Bm.shape[0], p, c_vp(out.data_ptr()), ldy,
                           1 if rowmajor else 0, stream_ptr()))
+    return out
+
+
+def gemm_ts_dev(Z, Bd, p, ldb, rowmajor=False, out=None, k=None, rows=None, ldz=None, b_rowmajor=False):
+    """Y = Z[:, :k] * B with B resident on the device (nep_gemm_ts_dev): B[c, j] = Bd[j * ldb + c] (or Bd[c * ldb + j] when
+    b_rowmajor) -- the eigenvector block nep_hess_eigvecs_dev leaves in HBM goes straight into the Ritz GEMM"""
+    if rows is None:
+        rows = Z.shape[-1]
+    if ldz is None:
+        ldz = Z.shape[-1]
+    if out is None:
+        out = torch.empty((rows, p) if rowmajor else (p, rows), dtype=CDT, device="cuda")
+    check(lib.nep_gemm_ts_dev(c_vp(Z.data_ptr()), ldz, rows, k, c_vp(Bd.data_ptr()), ldb, 1 if b_rowmajor else 0, p,
+                              c_vp(out.data_ptr()), out.shape[1], 1 if rowmajor else 0, stream_ptr()))
     return out
 
 
@@ -160,3 +174,31 @@ def rowmajor_to_cols(QT, cols=None):
         check(lib.nep_rowmajor_to_colmajor(rows, k, c_vp(QT.data_ptr()), k, hptr(cols), len(cols),
                                            c_vp(out.data_ptr()), rows, stream_ptr()))
     return out
+
+
+HESS_EIG_KMAX = 100
+
+
+def hess_eig_worksize(k):
+    nb = c_i64(0)
+    check(lib.nep_hess_eig_worksize(int(k), C.byref(nb)))
+    return int(nb.value)
+
+
+def hess_eig_dev(Hd, k, ldh=None, work=None, w=None, Z=None, mirror=None):
+    """`eigen(H[1:k,1:k])` (src/method_iar.jl:112) on the device: Hd is a device tensor holding the k x k upper Hessenberg
+    matrix column-major with leading dimension ldh.  Returns (w, Z): w device (k+2,) = eigenvalues, then the two status
+    words (nep_hess_eigvals_dev / nep_hess_eigvecs_dev); Z device (k, k) whose row j is eigenvector j (= column-major k x k).
+    Asynchronous: nothing is read back."""
+    if ldh is None:
+        ldh = Hd.shape[-1]
+    if work is None:
+        work = torch.empty(hess_eig_worksize(k), dtype=torch.uint8, device="cuda")
+    if w is None:
+        w = torch.empty(k + 2, dtype=CDT, device="cuda")
+    if Z is None:
+        Z = torch.empty((k, k), dtype=CDT, device="cuda")
+    mp = c_vp(mirror.data_ptr()) if mirror is not None else None
+    check(lib.nep_hess_eigvals_dev(int(k), c_vp(Hd.data_ptr()), int(ldh), c_vp(w.data_ptr()), c_vp(work.data_ptr()), mp, stream_ptr()))
+    check(lib.nep_hess_eigvecs_dev(int(k), c_vp(w.data_ptr()), c_vp(Z.data_ptr()), int(Z.shape[-1]), c_vp(work.data_ptr()), mp, stream_ptr()))
+    return w, Z

@@ -22,7 +22,7 @@ import numpy as np
 import torch
 
 from . import dense, _hosteig
-from ._lib import lib, check, c_vp, NepError, NEP_ERR_BREAKDOWN
+from ._lib import lib, check, c_vp, c_i32, NepError, NEP_ERR_BREAKDOWN
 from .errmeasure import DefaultErrmeasure, estimate_errors, estimate_errors_async
 from .exceptions import NoConvergenceException
 from .linsolvers import DefaultLinSolverCreator, create_linsolver
@@ -50,22 +50,27 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
     kw = dict(orthmethod=orthmethod, maxit=maxit, linsolvercreator=linsolvercreator, tol=tol, neigs=neigs, errmeasure=errmeasure,
               sigma=sigma, gamma=gamma, v=v, logger=logger, check_error_every=check_error_every, proj_solve=proj_solve,
               errhist=errhist, timers=timers, return_device=return_device, inner_solver_method=inner_solver_method)
-    try:
-        return _iar(nep, **kw)
-    except _RefinementMiss:          # never observed; the checked path decides every refinement on the host
-        iar.refinement_misses += 1
+    flags = {}
+    while True:                      # both downgrades may be needed in one call (each at most once)
+        try:
+            return _iar(nep, **kw, **flags)
+        except _RefinementMiss:      # never observed; the checked path decides every refinement on the host
+            if flags.get("_native_step") is False:
+                raise
+            iar.refinement_misses += 1
+            flags["_native_step"] = False
+        except _OrthPassMiss:        # "twice is enough" failed for a step: exact DGKS semantics through the synchronous loop
+            if flags.get("_force_sync"):
+                raise
+            iar.orth_pass_misses += 1
+            flags["_force_sync"] = True
         if errhist is not None:
             del errhist[:]
-        return _iar(nep, _native_step=False, **kw)
-    except _OrthPassMiss:            # "twice is enough" failed for a step: exact DGKS semantics through the synchronous loop
-        iar.orth_pass_misses += 1
-        if errhist is not None:
-            del errhist[:]
-        return _iar(nep, _force_sync=True, **kw)
 
 
 iar.refinement_misses = 0            # calls that were re-run with checked solves (diagnostics, tests)
 iar.orth_pass_misses = 0             # calls that were re-run because a step wanted more DGKS passes than were enqueued
+iar.dev_eig_fallbacks = 0            # checks whose device eigen-decomposition reported a failure and was redone by LAPACK
 
 
 _CHECK_STREAMS = {}
@@ -80,6 +85,54 @@ def _check_stream():
         # torch clamps to the device's range, a lower number is a higher priority)
         st = _CHECK_STREAMS[dev] = torch.cuda.Stream(priority=int(os.environ.get("NEP_IAR_CHECK_PRIO", "1")))
     return st
+
+
+_EIG_STREAMS = {}
+_EIG_WORK = {}
+
+
+def _eig_streams(count, others=()):
+    """streams for the device eigen-decompositions (3 ms one-wavefront kernels) that overlap with the streams in `others`
+    (the recurrence's and the checks').  The runtime maps streams onto a small pool of hardware queues and gives no way to ask
+    which; two streams on one queue serialise (measured: the convergence checks queued 4 ms per batch behind the
+    decompositions).  So candidates are probed (nep_stream_pair_serializes, ~1.5 ms each, once per process and device) and the
+    first ones that serialise with none of `others` nor with each other are kept."""
+    dev = torch.cuda.current_device()
+    sts = _EIG_STREAMS.setdefault(dev, [])
+    if len(sts) >= count:
+        return sts[:count]
+    import ctypes as _C
+    cands = [torch.cuda.Stream(priority=int(os.environ.get("NEP_IAR_EIG_PRIO", "0"))) for _ in range(int(os.environ.get("NEP_IAR_EIG_CANDIDATES", "8")))]
+    probe = os.environ.get("NEP_IAR_EIG_PROBE", "1") != "0"
+    for c in cands:
+        if len(sts) >= count:
+            break
+        ok = True
+        if probe:
+            for o in list(others) + sts:
+                r = c_i32(0)
+                check(lib.nep_stream_pair_serializes(c_vp(o.cuda_stream), c_vp(c.cuda_stream), _C.byref(r)))
+                if r.value:
+                    ok = False
+                    break
+        if ok:
+            sts.append(c)
+    while len(sts) < count:              # no free hardware queue: better a shared one than none
+        sts.append(cands[len(sts) % len(cands)])
+        _eig_streams.shared = True
+    return sts[:count]
+
+
+_eig_streams.shared = False
+
+
+def _eig_work(idx, need):
+    dev = torch.cuda.current_device()
+    key = (dev, idx)
+    w = _EIG_WORK.get(key)
+    if w is None or w.numel() < need:
+        w = _EIG_WORK[key] = torch.empty(need, dtype=torch.uint8, device="cuda")
+    return w
 
 
 def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
@@ -301,6 +354,15 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     # fresh stream per call (32 of them in torch's pool) made every stream build its own cache of Ritz blocks
     check_stream = _check_stream() if (check_thread and not os.environ.get("NEP_IAR_CHECK_MAIN_STREAM")) else None
 
+    # eigen-decompositions on the device (csrc/hesseig.hip) instead of LAPACK on host worker threads: no eig thread, no waiter
+    # per step -- 133 ms of host CPU per headline call gone; NEP_IAR_EIG=host keeps the round-3 route (and is the fallback for
+    # maxit beyond the LDS-resident limit, or when a decomposition reports a failure)
+    dev_eig = (check_thread and check_stream is not None and m <= dense.HESS_EIG_KMAX
+               and os.environ.get("NEP_IAR_EIG", "dev") != "host")
+    # its stream: one whose hardware queue is shared neither with this thread's stream nor with the check stream (probed once
+    # per process and device, on this thread, before the first step is enqueued)
+    eig_stream = _eig_streams(1, others=(torch.cuda.current_stream(), check_stream))[0] if dev_eig else None
+
     def launch_check(kc, fut):
         """eigen-decomposition of step kc is available: enqueue Ritz block (K7) + residual batch (K2), no waiting"""
         (D, Z), t_eig = fut.result()
@@ -345,7 +407,8 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
             # so it is not throttled at all (the eigen-decompositions of the last steps -- half of all eig time -- then
             # queue up behind the device instead of pacing it)
             unthrottled = np.isinf(neigs) and not os.environ.get("NEP_IAR_THROTTLE")
-            slots = threading.Semaphore(m + 1 if unthrottled else LAG + 1)
+            # (device decompositions go out in batches of up to NEP_IAR_EIG_BATCH steps: the look-ahead is that batch, whatever the CPU budget)
+            slots = threading.Semaphore(m + 1 if unthrottled else (max(LAG + 1, int(os.environ.get("NEP_IAR_EIG_BATCH", "16"))) if dev_eig else LAG + 1))
 
             def checker():
                 inflight = deque()
@@ -381,7 +444,159 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                     except Exception:
                         pass
 
-            th = threading.Thread(target=checker, name="nep-iar-check", daemon=True)
+            def checker_dev():
+                """the same checks with eig(H_kc) on the device.  (A) The decompositions of consecutive steps go out as BATCHES:
+                one launch, one workgroup per step (a decomposition is a serial chain, 3 ms at k = 100, ten Arnoldi steps: the
+                steps' decompositions have to overlap each other, and more than two or three extra streams stall the
+                recurrence's own queue), on one of NS eig streams behind the event of the batch's last step -- nothing of it
+                needs the host.  (B) When a batch's eigenvalues have reached the pinned mirror (an event behind the first
+                kernel; only the inverse iterations are still running) the host forms lambda = sigma + gamma / D and f_t(lambda)
+                per step and enqueues Ritz GEMM (B operand = the device eigenvector block) + residual batch on the check stream.
+                (C) The 2 kc norms come back behind another event.  One thread polls the event queues; no LAPACK, no waiters."""
+                BMAX = max(1, int(os.environ.get("NEP_IAR_EIG_BATCH", "16")))
+                LASTB = max(1, int(os.environ.get("NEP_IAR_EIG_LAST", "8")))
+                T100 = float(os.environ.get("NEP_IAR_EIG_MS100", "3.3"))     # ms of one decomposition at k = 100 (scales as k^2)
+                TSTEP = float(os.environ.get("NEP_IAR_EIG_MSSTEP", "0.35"))  # ms per Arnoldi step (gun, k ~ 100)
+                est = eig_stream
+                wsz = (dense.hess_eig_worksize(m) + 15) // 16 * 16
+                work = _eig_work(0, BMAX * wsz)
+                wdev = torch.empty((m, m + 2), dtype=CDT, device="cuda")
+                wpin = torch.zeros((m, m + 2), dtype=CDT).pin_memory()
+                wnp = wpin.numpy()
+                pendA = deque(); stA = deque(); stC = deque()
+                done = False
+                t_poll = float(os.environ.get("NEP_IAR_POLL_US", "30")) * 1e-6
+                force_fail = int(os.environ.get("NEP_IAR_EIG_FAIL_AT", "0"))   # tests: treat this step's decomposition as failed
+                # Batch plan.  A batch occupies the eig stream for the time of its LARGEST decomposition whatever its size, and
+                # cannot start before its last step has run: batches of about twice (decomposition time / step time) steps keep
+                # the stream half idle, so the last batch starts the moment step m is done; that last batch is kept smaller,
+                # because its checks (Ritz GEMM + residual batch, 0.17 ms each at k = 100) all come after its 3 ms.
+                # neigs = Inf: every check step is known in advance -> boundaries planned backwards from m.  Otherwise (the
+                # recurrence is throttled to LAG + 1 steps ahead of the checks) a batch is whatever is pending.
+                plan_end = None
+                if unthrottled:
+                    allk = [kk for kk in range(1, m + 1) if kk % check_error_every == 0 or kk == m]
+                    ends = []; e_ = len(allk)
+                    size = min(LASTB, e_)
+                    while e_ > 0:
+                        ends.append(allk[e_ - 1]); e_ -= size
+                        if e_ > 0:
+                            size = int(min(BMAX, e_, max(1, np.ceil(2.0 * T100 * (allk[e_ - 1] / 100.0) ** 2 / (TSTEP * check_error_every)))))
+                    plan_end = set(ends)
+
+                def host_redo(kc):
+                    """the device decomposition of step kc reported a failure: LAPACK on the host, Ritz block from its Z"""
+                    iar.dev_eig_fallbacks += 1
+                    (D, Z), _ = timed_eig(H[:kc, :kc].copy())
+                    with torch.cuda.stream(check_stream):
+                        QTl = dense.gemm_ts(V, Z, rowmajor=True, k=kc, rows=n, ldz=ldv)
+                    return D, QTl
+
+                def launch_batch(count):
+                    kcs = [pendA.popleft() for _ in range(count)]
+                    k0 = kcs[0]; nb = len(kcs); kmax = kcs[-1]
+                    kstep = (kcs[1] - k0) if nb > 1 else 0
+                    with torch.cuda.stream(est):
+                        sp_ = stream_ptr()
+                        check(lib.nep_iar_stream_wait(cstep, kmax, sp_))
+                        wrow = c_vp(wdev.data_ptr() + 16 * (k0 - 1) * (m + 2))
+                        mrow = c_vp(wpin.data_ptr() + 16 * (k0 - 1) * (m + 2))
+                        check(lib.nep_hess_eigvals_batch_dev(nb, k0, kstep, c_vp(Hdev.data_ptr()), m + 4, wrow, kstep * (m + 2),
+                                                             c_vp(work.data_ptr()), wsz, mrow, kstep * (m + 2), sp_))
+                        evW = torch.cuda.Event(); evW.record()
+                        Zb = torch.empty((nb, kmax, kmax), dtype=CDT, device="cuda")
+                        check(lib.nep_hess_eigvecs_batch_dev(nb, k0, kstep, wrow, kstep * (m + 2), c_vp(Zb.data_ptr()), kmax, kmax * kmax,
+                                                             c_vp(work.data_ptr()), wsz, mrow, kstep * (m + 2), sp_))
+                        evZ = torch.cuda.Event(); evZ.record()
+                    stA.append((kcs, Zb, kmax, evW, evZ))
+
+                def batch_ready():
+                    """number of pending steps that form the next batch (0: wait for more)"""
+                    if not pendA:
+                        return 0
+                    cnt = 1
+                    while cnt < len(pendA) and cnt < BMAX and pendA[cnt] - pendA[cnt - 1] == pendA[1] - pendA[0] and (plan_end is None or pendA[cnt - 1] not in plan_end):
+                        cnt += 1
+                    if plan_end is None or pendA[cnt - 1] in plan_end or cnt >= BMAX or done:
+                        return cnt
+                    return 0
+
+                try:
+                    while True:
+                        progressed = False
+                        # ---- new steps
+                        while not done:
+                            try:
+                                item = todo.get_nowait() if (pendA or stA or stC) else todo.get()
+                            except queue.Empty:
+                                break
+                            progressed = True
+                            if item is None:
+                                done = True
+                            elif state["conv_eig"] >= neigs:
+                                slots.release()
+                            else:
+                                pendA.append(item[0])
+                        # ---- (A) batches onto the eig stream (its order is the order of the steps: nothing to wait for here)
+                        while state["conv_eig"] < neigs:
+                            cnt = batch_ready()
+                            if not cnt:
+                                break
+                            launch_batch(cnt); progressed = True
+                        # ---- (B) eigenvalues on the host: Ritz values, coefficients, Ritz block + residual batch
+                        while stA and state["conv_eig"] < neigs and stA[0][3].query():
+                            progressed = True
+                            kcs, Zb, kmax, evW, evZ = stA.popleft()
+                            waited = False
+                            for b_, kc in enumerate(kcs):
+                                if trace is not None:
+                                    trace["dev_done_%d" % kc] = time.perf_counter()
+                                fill_H(kc)
+                                if wnp[kc - 1, kc].real != 0 or kc == force_fail:   # QR iteration gave up (never observed)
+                                    D, QTl = host_redo(kc)
+                                else:
+                                    D = wnp[kc - 1, :kc].copy()
+                                    with torch.cuda.stream(check_stream):
+                                        if not waited:
+                                            check_stream.wait_event(evZ); waited = True
+                                        QTl = dense.gemm_ts_dev(V, Zb[b_], kc, kmax, rowmajor=True, k=kc, rows=n, ldz=ldv)
+                                laml = sigma + gamma / D
+                                with torch.cuda.stream(check_stream):
+                                    perr = estimate_errors_async(errmeasure, laml, QTl)
+                                stC.append((kc, laml, QTl, perr, Zb))
+                                slots.release()
+                        # ---- (C) norms on the host
+                        while stC and state["conv_eig"] < neigs and stC[0][3].ready():
+                            progressed = True
+                            kc, laml, QTl, perr, Zb = stC.popleft()
+                            if wnp[kc - 1, kc + 1].real != 0 or kc == -force_fail:   # an inverse iteration did not grow: redo on the host
+                                D, QTl = host_redo(kc)
+                                laml = sigma + gamma / D
+                                with torch.cuda.stream(check_stream):
+                                    perr = estimate_errors_async(errmeasure, laml, QTl)
+                            consume_check(kc, laml, QTl, perr)
+                        if state["conv_eig"] >= neigs:
+                            while pendA:
+                                pendA.popleft(); slots.release()
+                            while stA:
+                                for _ in stA.popleft()[0]:
+                                    slots.release()
+                            stC.clear()
+                        if done and not pendA and not stA and not stC:
+                            break
+                        if not progressed:
+                            time.sleep(t_poll)
+                except BaseException as exc:          # re-raised on the calling thread
+                    failure.append(exc)
+                    slots.release()
+                finally:
+                    try:
+                        est.synchronize()             # dropped speculative decompositions still read Hdev / write wdev
+                        check_stream.synchronize()
+                    except Exception:
+                        pass
+
+            th = threading.Thread(target=checker_dev if dev_eig else checker, name="nep-iar-check", daemon=True)
             th.start()
             try:
                 BATCH = max(1, min(4, LAG // 2))
@@ -417,7 +632,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                         if trace is not None:
                             trace["enq_%d" % kk] = time.perf_counter()
                         if (kk % check_error_every == 0) or (kk == m):
-                            todo.put((kk, pool.submit(timed_eig_async, kk)))
+                            todo.put((kk, None if dev_eig else pool.submit(timed_eig_async, kk)))
                     k += nb
             finally:
                 todo.put(None)

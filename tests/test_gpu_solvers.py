@@ -109,6 +109,55 @@ def test_iar_runs_are_bit_reproducible(na):
             c = np.vdot(Q0[:, j], Q1[:, j]) / (np.linalg.norm(Q0[:, j]) * np.linalg.norm(Q1[:, j]))
             assert abs(abs(c) - 1.0) < 1e-10
 
+@pytest.mark.parametrize("neigs", [np.inf, 5])
+def test_iar_device_eig_equals_host_lapack_route(na, monkeypatch, neigs):
+    """eig(H_k) of every step on the device (csrc/hesseig.hip, batches on their own stream) against LAPACK on host worker
+    threads (the round-3 route, NEP_IAR_EIG=host): same eigenpair count, eigenvalues to 1e-10 relative, error histories within
+    1 % on the 8 best pairs of every iteration above 1e-12 (src/method_iar.jl:112-116).  neigs = 5: the throttled pipeline
+    (batches = whatever is pending) stops at the same step.  No decomposition fell back to the host."""
+    from nep_amd.linsolvers import _DeviceRefactor
+    n, m = 9956, 70
+    nep = na.nep_gallery("gun_spmf_scaled", n)
+    kw = dict(sigma=0.0, gamma=1.0, maxit=m, neigs=neigs, v=np.ones(n), tol=1e-10)
+    na.iar(nep, **kw); _DeviceRefactor.wait()
+    res = {}
+    for mode in ("host", "dev"):
+        monkeypatch.setenv("NEP_IAR_EIG", mode)
+        hist = []
+        fb0 = na.iar.dev_eig_fallbacks
+        lam, Q, V = na.iar(nep, errhist=hist, **kw)
+        res[mode] = (np.asarray(lam), hist, na.iar.dev_eig_fallbacks - fb0)
+    lh, hh, _ = res["host"]; ld, hd, fb = res["dev"]
+    assert fb == 0
+    assert len(lh) == len(ld) >= (5 if neigs == 5 else 20)
+    assert len(hh) == len(hd)
+    for x in ld:
+        assert np.min(np.abs(lh - x)) <= 1e-10 * max(1.0, abs(x))
+    cnt = 0
+    for a, b in zip(hd, hh):
+        a = np.sort(a)[:8]; b = np.sort(b)[:8]
+        for x, y in zip(a, b):
+            if x > 1e-12 and y > 1e-12:
+                assert 0.99 < x / y < 1.01; cnt += 1
+    assert cnt > 50
+
+
+def test_iar_device_eig_failure_falls_back_to_lapack(na, monkeypatch):
+    """a decomposition that reports a failure (forced here for one step: the QR status word of step 23, the inverse-iteration
+    status word of step 31) is redone by LAPACK on the host and the run returns what the all-device run returns"""
+    n, m = 2000, 40
+    nep = na.nep_gallery("gun_spmf_scaled", n)
+    kw = dict(sigma=0.0, gamma=1.0, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10)
+    monkeypatch.setenv("NEP_IAR_EIG", "dev")
+    lam0, _, _ = na.iar(nep, **kw)
+    for fail in ("23", "-31"):
+        monkeypatch.setenv("NEP_IAR_EIG_FAIL_AT", fail)
+        fb0 = na.iar.dev_eig_fallbacks
+        lam1, _, _ = na.iar(nep, **kw)
+        assert na.iar.dev_eig_fallbacks == fb0 + 1
+        assert len(lam1) == len(lam0) and np.allclose(np.sort_complex(lam1), np.sort_complex(lam0), rtol=1e-10, atol=0)
+
+
 def test_transf_shift_and_scale_iar_qdep0(na):
     """test/transf.jl:44-52 on the device path: the recipe of config C2 (shift_and_scale + iar) on the in-tree sparse SPMF
     qdep0; residuals evaluated by the ORACLE on the original problem < sqrt(eps); eigenvalues equal the oracle's"""
