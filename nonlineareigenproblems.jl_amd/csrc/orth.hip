@@ -25,14 +25,14 @@ template <bool NT> __device__ __forceinline__ cplx vload(const cplx* p) {
 #define DOT_RB (256 * DOT_RPT)
 
 // ---- device-side DGKS decision (asynchronous path) ----------------------------------------------------------------------------
-// After pass p the criterion ||w|| < ||c|| / sqrt(2) says whether pass p + 1 runs.  It used to be a one-workgroup kernel of its
-// own behind every pass (7-8 us + a launch gap, twice per Arnoldi step, 10 000 times per waveguide run); now the kernels that need
-// the answer form it themselves: every workgroup of the next pass' k_orth_dots (and of k_orth_finish) sums the <= ORTH_NPART update
-// partials and the k coefficients in the same fixed order -- identical value everywhere -- and workgroup 0 publishes it.
-// state: [1] = passes done, [2] = breakdown, [4 + p] = "pass p ran and wants another one" (p = 1 ..), written by the k_orth_dots of
-// pass p + 1, read by that pass' other kernels and by the next publisher.
+// After pass p the criterion ||w|| < ||c|| / sqrt(2) says whether pass p + 1 runs.  History: a one-workgroup kernel of its own
+// behind every pass (round 1: 7-8 us + a launch gap, twice per Arnoldi step); then formed by every workgroup of the next pass'
+// k_orth_dots from the <= ORTH_NPART update partials (round 2: no extra launch, but 15 us for every gated-off launch); now
+// published by workgroup 0 of the pass' own k_orth_update BEFORE the update runs, from ||w||^2 (one more output of k_orth_dots)
+// and ||c||^2 by Pythagoras -- the kernels of a gated-off pass read one word and leave.
+// state: [1] = passes done, [4 + p] = "pass p ran and wants another one" (p = 1 ..).
 #define ORTH_NPART 1024          // k_orth_update launches at most this many workgroups on the asynchronous path (one partial each)
-struct OrthDecide {              // what the fused decision reads (partial == nullptr: not in use)
+struct OrthDecide {              // what k_orth_finish reads on the asynchronous path (partial == nullptr: not in use)
     const double* partial = nullptr; int np = 0; const cplx* c = nullptr; int k = 0; int method = 0; int* state = nullptr;
     cplx* out_beta = nullptr;
 };
@@ -49,36 +49,14 @@ __device__ __forceinline__ void orth_pass_norms(const OrthDecide& D, double& nrm
     __syncthreads();
     nrm = sqrt(t); p2 = q2;
 }
-// decision after pass `pdone` (1-based), evaluated by the caller's whole workgroup; returns 1 when pass pdone + 1 is to run.
-// publish: this workgroup writes passes / gate / beta / breakdown (exactly one workgroup of the launch does)
-__device__ __forceinline__ int orth_decide_after(const OrthDecide& D, int pdone, bool publish) {
-    if (pdone >= 2 && D.state[4 + pdone - 1] == 0) {          // pass pdone never ran: the chain ended earlier
-        if (publish && threadIdx.x == 0) D.state[4 + pdone] = 0;
-        return 0;
-    }
-    double nrm, p2;
-    orth_pass_norms(D, nrm, p2);
-    const int more = (D.method == 0 && nrm < 0.70710678118654752440 * sqrt(p2)) ? 1 : 0;
-    if (publish && threadIdx.x == 0) {
-        D.out_beta[0] = cmake(nrm, 0.0);
-        D.state[1] = pdone;
-        D.state[4 + pdone] = more;
-        if (!(nrm > 0.0) || !isfinite(nrm)) D.state[2] = 1;
-    }
-    return more;
-}
-
 template <bool NT>
 __global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, int64_t ldv, int64_t rows,
                                                    int k, const int64_t* __restrict__ active,
                                                    const cplx* __restrict__ w, cplx* __restrict__ partial,
                                                    const int* __restrict__ gate = nullptr,
-                                                   const OrthDecide dec = OrthDecide(), int pdone = 0) {
+                                                   double* __restrict__ partial_ww = nullptr) {
     __shared__ cplx sm[DOT_CG][4];
-    if (gate && *gate == 0) return;          // device-side DGKS decision: this pass is not needed
-    if (dec.partial) {                       // pass pdone + 1 of the asynchronous path: form the decision of pass pdone here
-        if (!orth_decide_after(dec, pdone, blockIdx.x == 0 && blockIdx.y == 0)) return;
-    }
+    if (gate && *gate == 0) return;          // device-side DGKS decision (published by the previous pass' update): not needed
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int64_t r0 = (int64_t)blockIdx.x * DOT_RB;
     cplx wr[DOT_RPT];
@@ -87,6 +65,18 @@ __global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, i
     for (int i = 0; i < DOT_RPT; ++i) {
         rr[i] = r0 + threadIdx.x + 256 * i;
         wr[i] = rr[i] < rows ? w[rr[i]] : cmake(0.0, 0.0);
+    }
+    // ||w||^2 of the slice (asynchronous path): with the projection coefficients it gives the norm AFTER the update by
+    // Pythagoras, i.e. the DGKS decision of this pass before its update has run (see k_orth_update)
+    if (partial_ww && blockIdx.y == 0) {
+        double a = 0.0;
+#pragma unroll
+        for (int i = 0; i < DOT_RPT; ++i) a += fma(wr[i].x, wr[i].x, wr[i].y * wr[i].y);
+        a = wave_reduce_sum(a);
+        if (lane == 0) sm[0][wv].x = a;
+        __syncthreads();
+        if (threadIdx.x == 0) partial_ww[blockIdx.x] = (sm[0][0].x + sm[0][1].x) + (sm[0][2].x + sm[0][3].x);
+        __syncthreads();
     }
     // a block keeps its 1024-row slice of w in registers and walks over column groups blockIdx.y, +gridDim.y, ...:
     // with gridDim.y == 1 (large row counts) w is read once per slice instead of once per column group
@@ -127,17 +117,14 @@ __global__ __launch_bounds__(256) void k_orth_reduce_h(int nb, int k, const cplx
                                                        cplx* __restrict__ h, const int* __restrict__ gate = nullptr,
                                                        cplx* __restrict__ hacc = nullptr, int first = 1,
                                                        int* __restrict__ state_reset = nullptr,
-                                                       const OrthDecide dec = OrthDecide(), int pdone = 0) {
+                                                       const OrthDecide dec = OrthDecide(), int pdone = 0,
+                                                       const double* __restrict__ partial_ww = nullptr, double* __restrict__ ww = nullptr) {
     __shared__ cplx sm[4];
     // first pass of an asynchronous orthogonalisation: clear the pass state here (nothing reads it before the k_orth_dots of the
     // NEXT pass) instead of a separate memset command in front of every Arnoldi step
     if (state_reset && blockIdx.x == 0 && threadIdx.x < 16) state_reset[threadIdx.x] = 0;
     if (gate && *gate == 0) return;
-    // fused-dots path: this launch opens pass pdone + 1, so the decision of pass pdone is formed here (every workgroup, same
-    // fixed order; workgroup 0 publishes it).  dec.c must not be the array this kernel writes (h).
-    if (dec.partial) {
-        if (!orth_decide_after(dec, pdone, blockIdx.x == 0)) return;
-    }
+    (void)dec; (void)pdone;
     const int j = blockIdx.x;
     cplx acc = cmake(0.0, 0.0);
     for (int b = threadIdx.x; b < nb; b += 256) acc = cadd(acc, partial[(int64_t)b * k + j]);
@@ -148,6 +135,15 @@ __global__ __launch_bounds__(256) void k_orth_reduce_h(int nb, int k, const cplx
         const cplx c = cadd(cadd(sm[0], sm[1]), cadd(sm[2], sm[3]));
         h[j] = c;
         if (hacc) hacc[j] = first ? c : cadd(hacc[j], c);     // accumulated projection coefficients (device path)
+    }
+    if (partial_ww && blockIdx.x == 0) {                     // ||w||^2 before this pass' update (fixed order)
+        __syncthreads();
+        double a = 0.0;
+        for (int b = threadIdx.x; b < nb; b += 256) a += partial_ww[b];
+        a = wave_reduce_sum(a);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6].x = a;
+        __syncthreads();
+        if (threadIdx.x == 0) ww[0] = (sm[0].x + sm[1].x) + (sm[2].x + sm[3].x);
     }
 }
 
@@ -172,7 +168,9 @@ __global__ __launch_bounds__(512) void k_orth_update(const cplx* __restrict__ V,
                                                      int k, const int64_t* __restrict__ active,
                                                      const cplx* __restrict__ h, cplx* __restrict__ w,
                                                      double* __restrict__ partial,
-                                                     const int* __restrict__ gate = nullptr) {
+                                                     const int* __restrict__ gate = nullptr,
+                                                     const double* __restrict__ ww = nullptr, int* __restrict__ state = nullptr,
+                                                     int pdone = 0, int method = 0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     if (gate && *gate == 0) return;
     cplx* hs = (cplx*)smem_raw;         // k
@@ -181,6 +179,23 @@ __global__ __launch_bounds__(512) void k_orth_update(const cplx* __restrict__ V,
     const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int t = threadIdx.x; t < k; t += 512) hs[t] = h[t];
     __syncthreads();
+    // Asynchronous path: the DGKS decision of THIS pass (pass `pdone`, 1-based), published by workgroup 0 before the update has
+    // run: ||w - V c||^2 = ||w||^2 - ||c||^2 for an orthonormal V, so "||w_new|| < ||c|| / sqrt(2)" reads ||w||^2 < 1.5 ||c||^2
+    // (no cancellation near the threshold: the two sides differ by a factor 3 there; where the basis has lost orthogonality
+    // the true norm is smaller than the estimate's and the flag in the caller's row reports what the last pass left).  The
+    // kernels of the next pass read one word and leave -- the decision used to be re-formed by EVERY workgroup of the next
+    // pass' k_orth_dots from the 1024 update partials (15 us per gated-off launch, 1.1 ms per gun run).
+    if (state && blockIdx.x == 0 && q == 0) {
+        double p2 = 0.0;
+        for (int j = lane; j < k; j += 64) p2 += fma(hs[j].x, hs[j].x, hs[j].y * hs[j].y);
+        p2 = wave_reduce_sum(p2);
+        if (lane == 0) {
+            const double w2 = ww[0];
+            const int more = (method == 0 && !(w2 >= 1.5 * p2)) ? 1 : 0;
+            state[1] = pdone;
+            state[4 + pdone] = more;
+        }
+    }
     // a workgroup walks the 64-row tiles blockIdx.x, + gridDim.x, ... and leaves ONE partial norm (grid = number of tiles on
     // the synchronous path: one tile each, as before; at most ORTH_NPART workgroups on the asynchronous one)
     const int64_t ntiles = (rows + 63) / 64;
@@ -216,84 +231,6 @@ __global__ __launch_bounds__(512) void k_orth_update(const cplx* __restrict__ V,
 }
 
 
-// First update of a DGKS orthogonalisation with the projections of the SECOND pass formed in the same sweep over V:
-//   w' = w - V h              (as k_orth_update)
-//   cpart[b][j] = sum over this workgroup's rows of conj(V[r, j]) w'[r]      (what the second pass' k_orth_dots would compute)
-// A wave keeps the V values of its columns (q, q + 8, ...: KPW of them) in registers between the two uses -- a tile is read from
-// HBM once -- and accumulates its conj(v) w' products per lane across the tiles it walks; one wave reduction per column at the
-// end.  The second pass then needs no k_orth_dots at all: its coefficients are a reduction of cpart (k_orth_reduce_h), it runs in
-// the 24 % of the gun steps that meet the criterion with ONE pass over V instead of two, and a gated-off second pass is two
-// launches instead of three.  KPW = ceil(k / 8) columns per wave as a compile-time constant (registers).
-template <int KPW, bool NT>
-__global__ __launch_bounds__(512) void k_orth_update_fd(const cplx* __restrict__ V, int64_t ldv, int64_t rows, int k,
-                                                        const int64_t* __restrict__ active, const cplx* __restrict__ h,
-                                                        cplx* __restrict__ w, double* __restrict__ partial,
-                                                        cplx* __restrict__ cpart) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    cplx* hs = (cplx*)smem_raw;         // k
-    cplx* sm = hs + k;                  // [8][64]
-    cplx* wt = sm + 8 * 64;             // [64] updated w of the tile
-    const int lane = threadIdx.x & 63;
-    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    for (int t = threadIdx.x; t < k; t += 512) hs[t] = h[t];
-    __syncthreads();
-    const int64_t ntiles = (rows + 63) / 64;
-    double wg_nn = 0.0;
-    cplx cacc[KPW];
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) cacc[i] = cmake(0.0, 0.0);
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int64_t r0 = tile * 64LL;
-        const int64_t row = r0 + lane;
-        const int64_t rowc = row < rows ? row : rows - 1;
-        const cplx* vp = V + rowc;
-        cplx vreg[KPW];
-#pragma unroll
-        for (int i = 0; i < KPW; ++i) {
-            const int j = q + 8 * i;
-            vreg[i] = cmake(0.0, 0.0);
-            if (j < k) {
-                const int64_t act = active ? active[j] : rows;
-                if (r0 < act) vreg[i] = vload<NT>(vp + (int64_t)j * ldv);
-            }
-        }
-        cplx acc = cmake(0.0, 0.0);
-#pragma unroll
-        for (int i = 0; i < KPW; ++i) {
-            const int j = q + 8 * i;
-            if (j < k) cfma(acc, vreg[i], hs[j]);
-        }
-        sm[q * 64 + lane] = acc;
-        __syncthreads();
-        if (q == 0) {
-            cplx s = sm[lane];
-#pragma unroll
-            for (int t = 1; t < 8; ++t) s = cadd(s, sm[t * 64 + lane]);
-            double nn = 0.0;
-            cplx wn = cmake(0.0, 0.0);
-            if (row < rows) {
-                wn = csub(w[row], s);
-                w[row] = wn;
-                nn = fma(wn.x, wn.x, wn.y * wn.y);
-            }
-            wt[lane] = wn;                                   // rows beyond the end contribute zero
-            wg_nn += wave_reduce_sum(nn);
-        }
-        __syncthreads();
-        const cplx wl = wt[lane];
-#pragma unroll
-        for (int i = 0; i < KPW; ++i) cfma_conj(cacc[i], vreg[i], wl);     // (columns inactive on this tile hold zero)
-        // (no barrier needed here: the next tile's first barrier separates this read of wt from its next write)
-    }
-    if (q == 0 && lane == 0) partial[blockIdx.x] = wg_nn;
-#pragma unroll
-    for (int i = 0; i < KPW; ++i) {
-        const int j = q + 8 * i;
-        const cplx c = group_reduce_sum<64>(cacc[i]);
-        if (lane == 0 && j < k) cpart[(int64_t)blockIdx.x * k + j] = c;
-    }
-}
-
 // w /= beta (beta on the device); records passes / flags behind beta: out[k+1] = (passes, 2*breakdown + more_needed)
 // mirror (optional): device-mapped pinned host copy of the caller's row [row, row + nmirror) -- h, beta, flags and whatever the
 // caller keeps behind them -- written by block 0, which saves the separate device-to-host copy command of every Arnoldi step
@@ -306,16 +243,14 @@ __global__ __launch_bounds__(256) void k_orth_finish(int64_t rows, cplx* __restr
     double beta;
     int passes, more, brk;
     if (dec.partial) {
+        // asynchronous path: the update partials in dec.partial are those of the last pass that ran (a gated-off update leaves
+        // them alone); passes / "another pass wanted" were published by that pass' update
         const OrthDecide& D = dec;
-        const bool ran = npass == 1 || D.state[4 + npass - 1] != 0;
-        if (ran) {
-            double nrm, p2;
-            orth_pass_norms(D, nrm, p2);
-            beta = nrm; passes = npass;
-            more = (D.method == 0 && nrm < 0.70710678118654752440 * sqrt(p2)) ? 1 : 0;
-            brk = (D.state[2] != 0 || !(nrm > 0.0) || !isfinite(nrm)) ? 1 : 0;
-            if (blockIdx.x == 0 && threadIdx.x == 0) out_beta[0] = cmake(nrm, 0.0);
-        } else { beta = out_beta[0].x; passes = D.state[1]; more = 0; brk = D.state[2]; }
+        double nrm, p2;
+        orth_pass_norms(D, nrm, p2);
+        beta = nrm; passes = D.state[1]; more = D.state[4 + passes];
+        brk = (!(nrm > 0.0) || !isfinite(nrm)) ? 1 : 0;
+        if (blockIdx.x == 0 && threadIdx.x == 0) out_beta[0] = cmake(nrm, 0.0);
     } else { beta = out_beta[0].x; passes = state[1]; more = state[0]; brk = state[2]; }
     const double inv = (beta > 0.0 && isfinite(beta)) ? 1.0 / beta : 0.0;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows; i += (int64_t)gridDim.x * blockDim.x) {
@@ -489,29 +424,28 @@ extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, in
     const int nblk = (int)((rows + 63) / 64);
     const int npart = std::min(nblk, ORTH_NPART);
     const int npass = method == 1 ? 1 : orth_dev_passes();
-    // NEP_ORTH_FUSED_DOTS=1 (opt-in, read per call): DGKS with two enqueued passes forms the second pass' projections inside
-    // the first update (k_orth_update_fd).  MEASURED SLOWER on the headline run (45.0 ms per call against 42.2 ms; K6 over the 100
-    // step shapes 16.3 ms against 12.7 ms): the fused kernel holds a tile's V values in registers (157 VGPRs at k = 100, one
-    // workgroup per CU) and every step's first update pays for that, while only the 24 % of the steps that run their second pass
-    // save a k_orth_dots.
-    const char* fused_e = getenv("NEP_ORTH_FUSED_DOTS");
-    const bool fused = fused_e && atoi(fused_e) != 0 && method == 0 && npass == 2 && k <= 128;
+    // (a variant that formed the second pass' projections inside the first update -- one sweep over V instead of two in the 24 %
+    // of the gun steps that re-orthogonalise -- was built in round 3 and measured SLOWER on the headline run, 45.0 against 42.2 ms
+    // per call: the tile's V values held in registers cost every first update more than the saved k_orth_dots; removed in round 4)
     // scratch: [state 16 int][partial_h nchunks*k cplx][c k cplx][c2 k cplx][partial_n npart dbl][partial_c2 npart*k cplx]
     size_t off_ph = 64;
     size_t off_c = off_ph + (size_t)nchunks * k * sizeof(cplx);
     size_t off_c2 = off_c + (size_t)k * sizeof(cplx);
     size_t off_pn = off_c2 + (size_t)k * sizeof(cplx);
     size_t off_pc2 = (off_pn + (size_t)npart * sizeof(double) + 15) & ~(size_t)15;
-    size_t total = off_pc2 + (fused ? (size_t)npart * k * sizeof(cplx) : 0);
+    size_t off_pww = off_pc2;
+    size_t total = off_pww + ((size_t)nchunks + 2) * sizeof(double);
     int rc = g_orth_scratch.ensure(total);
     if (rc) return rc;
     char* base = (char*)g_orth_scratch.dptr;
     int* d_state = (int*)base;
     cplx* d_ph = (cplx*)(base + off_ph);
     cplx* d_c = (cplx*)(base + off_c);
-    cplx* d_c2 = (cplx*)(base + off_c2);
+    (void)off_c2;
     double* d_pn = (double*)(base + off_pn);
-    cplx* d_pc2 = (cplx*)(base + off_pc2);
+
+    double* d_pww = (double*)(base + off_pww);
+    double* d_ww = d_pww + nchunks;
     const cplx* V = (const cplx*)dV;
     cplx* w = (cplx*)dw;
     cplx* out = (cplx*)d_out;
@@ -521,65 +455,28 @@ extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, in
     const bool nt = orth_use_nt(rows, k, d_active_rows != nullptr);
     OrthDecide D;
     D.partial = d_pn; D.np = npart; D.c = d_c; D.k = (int)k; D.method = (int)method; D.state = d_state; D.out_beta = out + k;
-    if (fused) {
-        // pass 1: dots, coefficient reduction, update + the projections of pass 2
-        if (nt)
-            hipLaunchKernelGGL(k_orth_dots<true>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv, rows, (int)k,
-                               d_active_rows, (const cplx*)w, d_ph, (const int*)nullptr, OrthDecide(), 0);
-        else
-            hipLaunchKernelGGL(k_orth_dots<false>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv, rows, (int)k,
-                               d_active_rows, (const cplx*)w, d_ph, (const int*)nullptr, OrthDecide(), 0);
-        LAUNCHCHK();
-        hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_c, (const int*)nullptr, out,
-                           1, d_state, OrthDecide(), 0);
-        LAUNCHCHK();
-        if (before_write) HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)before_write, 0));
-        const size_t shm_fd = (size_t)(k + 8 * 64 + 64) * sizeof(cplx);
-#define UPD_FD(KPW_)                                                                                                           \
-        do {                                                                                                                   \
-            if (nt) hipLaunchKernelGGL((k_orth_update_fd<KPW_, true>), dim3(npart), dim3(512), shm_fd, st, V, ldv, rows, (int)k, \
-                                       d_active_rows, (const cplx*)d_c, w, d_pn, d_pc2);                                       \
-            else hipLaunchKernelGGL((k_orth_update_fd<KPW_, false>), dim3(npart), dim3(512), shm_fd, st, V, ldv, rows, (int)k,  \
-                                    d_active_rows, (const cplx*)d_c, w, d_pn, d_pc2);                                          \
-        } while (0)
-        if (k <= 16) UPD_FD(2); else if (k <= 32) UPD_FD(4); else if (k <= 64) UPD_FD(8); else if (k <= 104) UPD_FD(13); else UPD_FD(16);
-#undef UPD_FD
-        LAUNCHCHK();
-        // pass 2 (gated by the decision formed in its first kernel): coefficients = reduction of the fused partials, one update
-        hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, npart, (int)k, (const cplx*)d_pc2, d_c2, (const int*)nullptr, out,
-                           0, (int*)nullptr, D, 1);
-        LAUNCHCHK();
-        const int* gate2 = d_state + 4 + 1;
-        if (nt)
-            hipLaunchKernelGGL(k_orth_update<true>, dim3(npart), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
-                               (const cplx*)d_c2, w, d_pn, gate2);
-        else
-            hipLaunchKernelGGL(k_orth_update<false>, dim3(npart), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
-                               (const cplx*)d_c2, w, d_pn, gate2);
-        LAUNCHCHK();
-        D.c = d_c2;                  // the finish kernel forms the decision after pass 2 from that pass' coefficients
-    } else {
-    // per pass three launches (dots, coefficient reduction, update); the decision after pass p is formed inside the dots kernel
-    // of pass p + 1 and, for the last pass, inside k_orth_finish (it was a fourth launch per pass)
+    {
+    // per pass three launches (dots, coefficient reduction, update); the decision of pass p is published by its update kernel
+    // BEFORE that update runs (Pythagoras, see k_orth_update), so a gated-off pass costs three launches that read one word
     for (int p = 0; p < npass; ++p) {
-        const int* gate = p == 0 ? nullptr : d_state + 4 + p;       // "pass p ran and wants pass p + 1", published by this pass' dots
+        const int* gate = p == 0 ? nullptr : d_state + 4 + p;       // "pass p ran and wants pass p + 1"
         if (nt)
             hipLaunchKernelGGL(k_orth_dots<true>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv, rows, (int)k,
-                               d_active_rows, (const cplx*)w, d_ph, (const int*)nullptr, p == 0 ? OrthDecide() : D, p);
+                               d_active_rows, (const cplx*)w, d_ph, gate, d_pww);
         else
             hipLaunchKernelGGL(k_orth_dots<false>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv, rows, (int)k,
-                               d_active_rows, (const cplx*)w, d_ph, (const int*)nullptr, p == 0 ? OrthDecide() : D, p);
+                               d_active_rows, (const cplx*)w, d_ph, gate, d_pww);
         LAUNCHCHK();
         hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_c, gate, out,
-                           p == 0 ? 1 : 0, p == 0 ? d_state : (int*)nullptr, OrthDecide(), 0);
+                           p == 0 ? 1 : 0, p == 0 ? d_state : (int*)nullptr, OrthDecide(), 0, (const double*)d_pww, d_ww);
         LAUNCHCHK();
         if (p == 0 && before_write) HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)before_write, 0));
         if (nt)
             hipLaunchKernelGGL(k_orth_update<true>, dim3(npart), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
-                               (const cplx*)d_c, w, d_pn, gate);
+                               (const cplx*)d_c, w, d_pn, gate, (const double*)d_ww, d_state, p + 1, (int)method);
         else
             hipLaunchKernelGGL(k_orth_update<false>, dim3(npart), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
-                               (const cplx*)d_c, w, d_pn, gate);
+                               (const cplx*)d_c, w, d_pn, gate, (const double*)d_ww, d_state, p + 1, (int)method);
         LAUNCHCHK();
     }
     }

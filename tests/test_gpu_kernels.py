@@ -1068,15 +1068,14 @@ def test_resid_batch_column_major_tiled(na, case):
         assert np.array_equal(o2.cpu().numpy(), oh)                              # deterministic
 
 
-@pytest.mark.parametrize("fused", ["1", "0"])
 @pytest.mark.parametrize("k", [3, 16, 17, 40, 70, 104, 128, 130])
-@pytest.mark.parametrize("reorth", [False, True])
-def test_orth_dev_fused_second_pass_dots(na, k, reorth, fused, monkeypatch):
-    """the asynchronous DGKS (nep_orth_dev) with the second pass' projections formed inside the first update
-    (k_orth_update_fd: the V values of a tile stay in registers between the update and the conj(v) w' products) against the
-    oracle's DGKS and against the unfused chain (NEP_ORTH_FUSED_DOTS=0): h, beta, w, pass count and flags; every register
-    variant (2 / 4 / 8 / 13 / 16 columns per wave), k > 128 (unfused fallback), with and without a forced second pass, iar's
-    block-triangular basis (`active`), rows that are no multiple of the 64-row tile"""
+@pytest.mark.parametrize("reorth", [False, True, "borderline"])
+def test_orth_dev_decision_published_by_the_update(na, k, reorth):
+    """the asynchronous DGKS (nep_orth_dev): the decision of a pass is published by that pass' own update kernel before the
+    update runs, from ||w||^2 and ||c||^2 (Pythagoras; csrc/orth.hip k_orth_update) -- against the oracle's DGKS, which takes the
+    norm of the updated vector (IterativeSolvers 0.9.2): h, beta, w, pass count and flags, with and without a forced second
+    pass, a vector placed 2 % on either side of the criterion's threshold, iar's block-triangular basis (`active`), rows that are
+    no multiple of the 64-row tile"""
     import torch
     from oracle import solvers as osol
     rng = np.random.default_rng(100 + k)
@@ -1087,6 +1086,22 @@ def test_orth_dev_fused_second_pass_dots(na, k, reorth, fused, monkeypatch):
         V[:(j + 1) * n, j] = rng.standard_normal((j + 1) * n) + 1j * rng.standard_normal((j + 1) * n)
     V, _ = np.linalg.qr(V)
     active = (np.arange(1, k + 1) * n).astype(np.int64)
+    if reorth == "borderline":
+        # ||w_perp|| / ||c|| = 0.98 / sqrt(2) (re-orthogonalise) resp. 1.02 / sqrt(2) (do not): both sides of the threshold
+        for fac, want in ((0.98, 2), (1.02, 1)):
+            c = rng.standard_normal(k) + 1j * rng.standard_normal(k)
+            z = rng.standard_normal(rows) + 1j * rng.standard_normal(rows)
+            z -= V @ (V.conj().T @ z)
+            wb = V @ c + z * (fac * np.linalg.norm(c) / np.sqrt(2) / np.linalg.norm(z))
+            wo = wb.copy(); ho = np.zeros(k, dtype=complex)
+            osol.dgks(V, wo, ho)
+            outb = torch.zeros(k + 2, dtype=torch.complex128, device="cuda")
+            wdb = na.to_dev(wb)[0]
+            na.dense.orthogonalize_and_normalize_dev(na.to_dev(V), wdb, k, outb, rows=rows, ldv=rows, active_dev=torch.from_numpy(active).to("cuda"))
+            ob = outb.cpu().numpy()
+            assert int(ob[k + 1].real) == want and int(ob[k + 1].imag) == 0
+            assert np.linalg.norm(ob[:k] - ho) <= 1e-12 * np.linalg.norm(ho)
+        return
     if reorth:
         w = V @ (rng.standard_normal(k) + 1j * rng.standard_normal(k)) + 1e-9 * (rng.standard_normal(rows) + 1j * rng.standard_normal(rows))
     else:
@@ -1094,7 +1109,6 @@ def test_orth_dev_fused_second_pass_dots(na, k, reorth, fused, monkeypatch):
     wo = w.copy(); ho = np.zeros(k, dtype=complex)
     bo = osol.dgks(V, wo, ho)
     Vd = na.to_dev(V); act_d = torch.from_numpy(active).to("cuda")
-    monkeypatch.setenv("NEP_ORTH_FUSED_DOTS", fused)        # opt-in kernel (measured slower on the headline run): kept correct here
     out = torch.zeros(k + 2, dtype=torch.complex128, device="cuda")
     wd = na.to_dev(w)[0]
     na.dense.orthogonalize_and_normalize_dev(Vd, wd, k, out, rows=rows, ldv=rows, active_dev=act_d)
