@@ -135,7 +135,10 @@ __device__ __forceinline__ bool negligible_sub(const cplx* A, int ld, int kk, in
 // Wave 1 (RQ half): H <- R G_{l+1}^H ... G_i^H + t I, lane = row, trails wave 0 by two steps: step j needs rotation j and
 // the rows <= j of R, i.e. what wave 0 stores at the start of its step j + 2.  Wave 0 publishes its step counter behind
 // those stores; the LDS unit executes a wavefront's instructions in order, so a reader that sees the counter sees the data.
-// The serial chain (rotation j needs column j after rotation j - 1) is all that is left on wave 0.
+// The serial chain (rotation j needs column j after rotation j - 1) is all that is left on wave 0.  Measured split of its
+// ~475 cycles per rotation (one column per lane, -DHQ_PROF builds with pieces taken out): rotation generation 130, LDS
+// traffic (look-ahead load, three stores, progress word) 140, lane reads + application + loop 205 -- a lone wavefront issues
+// one instruction every ~7 cycles, so the count of instructions is what there is to save, not their latency.
 struct HqCtl {            // control block in LDS (ints)
     int seq;              // sweep number published by wave 0 (-1: exit)
     int l, i;             // window of that sweep

@@ -1,6 +1,9 @@
+"""cycle split of k_hess_qr (csrc/hesseig.hip) from an instrumented build: compile util.hip + hesseig.hip with -DHQ_PROF into
+scripts/diag/_hq_prof.so (hipcc -shared), then `python scripts/diag/hq_prof_run.py`: cycles in wait / deflation scan / shift /
+publish / QR half per sweep and per rotation."""
 import ctypes as C, numpy as np, torch, sys, os
 sys.path.insert(0,'/root/repo')
-lib=C.CDLL('/root/repo/scripts/diag/_hq_prof.so')
+lib=C.CDLL('/root/repo/scripts/diag/_hq_prof%s.so' % (sys.argv[1] if len(sys.argv) > 1 else ''))
 H=np.load('/root/repo/tests/golden/gun_iar_H100.npy')
 for k in (10,50,100):
     Hk=np.ascontiguousarray(H[:k,:k].T)
