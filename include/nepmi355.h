@@ -476,6 +476,8 @@ int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdo
                        const double* h_cabs, const nep_cdouble* h_cf, int32_t mt, nep_cdouble* dH, nep_cdouble* h_pinnedH,
                        int32_t orth_method, nep_iar** out);
 int32_t nep_iar_destroy(nep_iar* s);
+/* refine_steps | 0x100: the backward error of the KEPT iterate is recorded only in steps whose index is a multiple of 8 (its slot
+ * stays 0 otherwise) -- for callers whose refinement count has settled (the check costs one pass over the matrices per step) */
 int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream stream);
 /* steps k0 .. k0+count-1 (same refine_steps) in one foreign call */
 int32_t nep_iar_steps(nep_iar* s, int32_t k0, int32_t count, int32_t refine_steps, nep_stream stream);

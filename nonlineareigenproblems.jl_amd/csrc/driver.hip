@@ -101,6 +101,11 @@ int32_t nep_iar_destroy(nep_iar* s) {
 }
 
 int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream stream) {
+    // refine_steps + NEP_IAR_SKIP_FINAL_RECORD (0x100): the backward error of the iterate that is KEPT is not recorded in steps
+    // whose index is no multiple of 8 (a pure check, one pass over the matrices per step: the caller asks for this once its
+    // refinement count has settled -- the policy FactorizeLinSolver.solve_dev applies to its checked solves, 7 of 8 taken on trust)
+    const bool skip_final = (refine_steps & 0x100) != 0 && (k % 8) != 0;
+    refine_steps &= 0xff;
     ARGCHK(s && k >= 1 && k <= s->m && refine_steps >= 0 && refine_steps <= 3);
     ARGCHK(refine_steps == 0 || !s->cabs.empty());
     hipStream_t st = as_stream(stream);
@@ -134,7 +139,7 @@ int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream str
         if (rc) return rc;
     }
     void* before_write = nullptr;
-    if (record) {       // omega of the iterate that is kept (stored negated in vv)
+    if (record && !skip_final) {       // omega of the iterate that is kept (stored negated in vv)
         hipStream_t cs = st;
         if (s->side) {  // reads vv, z; writes dW and the omega word of this row: ordered behind the solve, ahead of the first update
             HIPCHK(hipEventRecord(s->e_solved, st));

@@ -422,7 +422,8 @@ extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, in
     hipStream_t st = as_stream(stream);
     const int nchunks = (int)((rows + DOT_RB - 1) / DOT_RB);
     const int nblk = (int)((rows + 63) / 64);
-    const int npart = std::min(nblk, ORTH_NPART);
+    static const int npart_max = getenv("NEP_ORTH_NPART") ? std::max(64, atoi(getenv("NEP_ORTH_NPART"))) : ORTH_NPART;
+    const int npart = std::min(nblk, npart_max);
     const int npass = method == 1 ? 1 : orth_dev_passes();
     // (a variant that formed the second pass' projections inside the first update -- one sweep over V instead of two in the 24 %
     // of the gun steps that re-orthogonalise -- was built in round 3 and measured SLOWER on the headline run, 45.0 against 42.2 ms

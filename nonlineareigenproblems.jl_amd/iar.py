@@ -237,13 +237,15 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     def arnoldi_step(k):
         if cstep is not None:
             plan = M0inv.blind_plan_recorded()
+            if plan > 0 and M0inv.settled_plan():
+                plan |= 0x100                 # the kept iterate's backward error: recorded in every 8th step only
             plans[k] = plan
             t0 = time.perf_counter()
             check(lib.nep_iar_step(cstep, k, plan, stream_ptr()))
             if trace is not None:
                 trace["native_s"] = trace.get("native_s", 0.0) + time.perf_counter() - t0
                 trace["native_n"] = trace.get("native_n", 0) + 1
-            M0inv.note_blind_solve(plan)
+            M0inv.note_blind_solve(plan & 0xff)
             evs[k] = "native"
             return
         t0 = time.perf_counter()
@@ -284,7 +286,8 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                 if int(row[j + 1].imag) & 1 and dense._orth_code(orthmethod) == 0:
                     raise _OrthPassMiss(j)        # another DGKS pass was wanted after the last enqueued one
                 if cstep is not None and M0inv.umfpack_refinements > 0:
-                    if not M0inv.review_recorded(row[j + 2:j + 4].view(np.float64), plans[j]):
+                    if not M0inv.review_recorded(row[j + 2:j + 4].view(np.float64), plans[j] & 0xff,
+                                                 final_recorded=not (plans[j] & 0x100 and j % 8 != 0)):
                         raise _RefinementMiss(j)
                 H[:j, j - 1] = row[:j]
                 H[j, j - 1] = row[j].real
@@ -620,6 +623,8 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                     if failure:
                         break
                     plan = M0inv.blind_plan_recorded()
+                    if plan > 0 and M0inv.settled_plan():
+                        plan |= 0x100             # the kept iterate's backward error: recorded in every 8th step only
                     t0 = time.perf_counter()
                     check(lib.nep_iar_steps(cstep, k, nb, plan, stream_ptr()))
                     if trace is not None:
@@ -627,7 +632,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                         trace["native_n"] = trace.get("native_n", 0) + nb
                     for kk in range(k, k + nb):
                         plans[kk] = plan
-                        M0inv.note_blind_solve(plan)
+                        M0inv.note_blind_solve(plan & 0xff)
                         evs[kk] = "native"
                         if trace is not None:
                             trace["enq_%d" % kk] = time.perf_counter()

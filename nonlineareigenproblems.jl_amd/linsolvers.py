@@ -533,11 +533,31 @@ class FactorizeLinSolver(LinSolver):
         hint = getattr(getattr(self, "nep", None), "_refine_hint", None) if os.environ.get("NEP_REFINE_HINT", "1") != "0" else None
         return min(self.umfpack_refinements, 2 if hint is None else hint)
 
-    def review_recorded(self, w, plan):
+    def settled_plan(self):
+        """True when the refinement count of this solver's NEP has settled (a reviewed record of this solver, or the count a
+        previous solver of the NEP settled on): steps may then skip the record of the kept iterate 7 times out of 8"""
+        if os.environ.get("NEP_IAR_RECORD_ALL"):
+            return False
+        if self._recorded_plan is not None:
+            return True
+        return os.environ.get("NEP_REFINE_HINT", "1") != "0" and getattr(getattr(self, "nep", None), "_refine_hint", None) is not None
+
+    def review_recorded(self, w, plan, final_recorded=True):
         """UMFPACK's stopping rule (the loop of solve_dev) replayed on the recorded omegas w[0..plan] of a solve that took
         `plan` sweeps without looking.  True: what was returned is what the checked loop returns, or an iterate at least as
-        good; False: the checked loop would have continued, or would have taken a worsening sweep back."""
+        good; False: the checked loop would have continued, or would have taken a worsening sweep back.
+        final_recorded=False: omega of the kept iterate x_plan was not evaluated (a step that took it on trust, 7 of 8 once
+        the count has settled); the rule is replayed on x_0..x_{plan-1} and must not have stopped there."""
         umf = self.umfpack_refinements
+        if not final_recorded:
+            w_prev = np.inf
+            for step in range(plan):
+                omega = float(w[step])
+                if not np.isfinite(omega) or omega <= 2.0 * EPS or omega > 0.5 * w_prev:
+                    self._note_hint(None)          # the checked loop would have stopped before the sweeps that were taken
+                    return False
+                w_prev = omega
+            return True
         w = [float(x) for x in w[:plan + 1]]
         if FactorizeLinSolver._omega_log is not None:       # diagnostics (scripts/diag/iar_omega_log.py)
             FactorizeLinSolver._omega_log.append(w)

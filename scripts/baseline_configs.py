@@ -2,6 +2,7 @@
 rule of section 8d (same count, eigenvalues as multisets to 1e-8 relative, every pair below the driver's tolerance when
 re-evaluated on the host).  Measurement / test infrastructure: used by bench.py, scripts/run_configs.py and
 tests/test_gpu_fullsize.py -- never by the product."""
+import os
 import time
 
 import numpy as np
@@ -168,7 +169,8 @@ def c5_device(na, nx=1003, nz=999, solver="gmres", N=37, reltol=1e-9, refine=1, 
             P = na.wep_generate_preconditioner(nep, N, -3 - 3.5j)
             torch.cuda.synchronize()
             info.update(preconditioner_N=N, preconditioner_setup_s=time.perf_counter() - t1)
-            skw = (("Pl", P), ("reltol", reltol), ("restart", restart), ("maxiter", 300), ("orth_meth", "dgks"))
+            skw = (("Pl", P), ("reltol", reltol), ("restart", restart), ("maxiter", 300),
+                   ("orth_meth", os.environ.get("NEP_GMRES_ORTH_FORCE", "cgs")))
         kw["linsolvercreator"] = na.WEPLinSolverCreator(solver_type=solver, kwargs=skw, refinements=refine)
     out = na.tiar(nep, sigma=-3 - 3.5j, gamma=1.0, maxit=maxit, neigs=np.inf, v=v0, tol=1e-8, timers=timers, **kw)
     torch.cuda.synchronize()

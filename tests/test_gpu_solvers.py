@@ -200,22 +200,22 @@ def test_iar_recorded_refinement_and_miss_fallback(na, monkeypatch):
     seen = []
     orig = FactorizeLinSolver.review_recorded
 
-    def spy(self, w, plan):
-        ok = orig(self, w, plan)
-        seen.append((plan, [float(x) for x in w[:plan + 1]], ok))
+    def spy(self, w, plan, final_recorded=True):
+        ok = orig(self, w, plan, final_recorded=final_recorded)
+        seen.append((plan, [float(x) for x in w[:plan + 1]], ok, final_recorded))
         return ok
     monkeypatch.setattr(FactorizeLinSolver, "review_recorded", spy)
     h1 = []
     l1, Q1, _ = na.iar(nep, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10, errhist=h1)
-    assert len(seen) == m and all(ok for _, _, ok in seen)
-    assert all(w[-1] <= 4 * np.finfo(float).eps for _, w, _ in seen)          # every kept iterate is converged
+    assert len(seen) == m and all(ok for _, _, ok, _ in seen)
+    assert all(w[-1] <= 4 * np.finfo(float).eps for _, w, _, _ in seen)       # every kept iterate is converged
     assert seen[0][0] == 2 and seen[-1][0] <= 1                                 # two sweeps to start, then the settled count
     # (ii) force a miss on the 7th review
     count = [0]
 
-    def miss(self, w, plan):
+    def miss(self, w, plan, final_recorded=True):
         count[0] += 1
-        return orig(self, w, plan) and count[0] != 7
+        return orig(self, w, plan, final_recorded=final_recorded) and count[0] != 7
     monkeypatch.setattr(FactorizeLinSolver, "review_recorded", miss)
     h2 = []
     l2, Q2, _ = na.iar(nep, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10, errhist=h2)
@@ -231,7 +231,11 @@ def test_iar_recorded_refinement_and_miss_fallback(na, monkeypatch):
     del seen[:]
     monkeypatch.setattr(FactorizeLinSolver, "review_recorded", spy)
     l3, Q3, _ = na.iar(nep, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10)
-    assert len(seen) == m and all(ok and plan == 1 for plan, _, ok in seen)
+    assert len(seen) == m and all(ok and plan == 1 for plan, _, ok, _ in seen)
+    # ... and with a settled count the backward error of the KEPT iterate is evaluated in every 8th step only (the policy of
+    # FactorizeLinSolver.solve_dev: 7 of 8 solves on trust); omega of x_0 is still recorded in every step
+    assert [fr for _, _, _, fr in seen] == [(j % 8 == 0) for j in range(1, m + 1)]
+    assert all(w[0] > 4 * np.finfo(float).eps for _, w, _, _ in seen)
     _match(l3, l1, 1e-10)
     monkeypatch.setenv("NEP_REFINE_HINT", "0")
     del seen[:]
