@@ -222,8 +222,27 @@ def beyn_sharded(na, args, world, rank):
         t = torch.tensor([dt], dtype=torch.float64, device=RED_DEV)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t[0])
+    # a further, untimed call with a device synchronisation behind every phase: which parts shard (factorise, solve) and which
+    # every rank repeats (probe upload, moment download, SVD / eig on the host, eigenvectors, residual filter) -- recorded for
+    # one rank as well, so that the serial fraction of the strong-scaling curve is known before an 8-GPU node measures it
+    phases = None
+    try:
+        pinfo = {"phases_s": {}}
+        bc.c4_device(na, nep, integ, Vh=Vh, info=pinfo)
+        torch.cuda.synchronize()
+        ph = {k_: round(float(v), 6) for k_, v in pinfo["phases_s"].items()}
+        shard = ph.get("factorise_nodes", 0.0) + ph.get("solve_nodes_and_accumulate", 0.0)
+        tot = sum(ph.values())
+        phases = {"seconds": ph, "sharded_s": round(shard, 6), "replicated_s": round(tot - shard, 6),
+                  "replicated_fraction_of_this_run": round((tot - shard) / tot, 4) if tot > 0 else None,
+                  "note": "each phase closed by a device synchronisation (the timed call above has none); with P ranks the sharded "
+                          "part divides by P, the replicated part and the exchange do not"}
+    except Exception as e:
+        phases = {"error": repr(e)[:200]}
+    if distd:
+        dist.barrier()
     out = {"workload": "contour_beyn gun SPMF n=%d N=64 k=32 radius=1e4 sigma=250^2 tol=1e-6" % nep.n,
-           "per_rank": per_rank, "wall": "max over ranks",
+           "per_rank": per_rank, "wall": "max over ranks", "phases": phases,
            "eigenpairs": int(len(lam)), "seconds": dt, "eigenpairs_per_s": len(lam) / dt, "rank_p": int(info.get("p", -1)),
            "nodes_per_rank": int(info.get("nodes", 64)), "scaling": "strong",
            "exchange": "one all_gather of 2*n*k complex128 per rank (%.1f MB)" % (2 * nep.n * 32 * 16 / 1e6) if distd else "none"}
@@ -565,6 +584,10 @@ def main():
                                   "achieved": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS}))
         return
 
+    if use_dist and world > 1 and os.environ.get("NEP_BENCH_SEED_BCAST", "1") != "0":
+        # the pattern's one host factorisation (ordering, pivots, fill) on rank 0 only, factors broadcast, plans built per GPU:
+        # no rank runs SuperLU in its first call (8 ranks on a shared CPU quota would start 8 of them at once)
+        na.seed_plan_from_rank0(nep, 0.0, permc_spec=args.permc)
     warm_ms = []
     for _ in range(args.warmup):
         tw = time.perf_counter()

@@ -13,7 +13,7 @@ from .nep import (NEP, AbstractSPMF, SPMF_NEP, DEP, PEP, SumNEP, DerSPMF, shift_
                   to_dev, to_host)
 from .linsolvers import (LinSolver, FactorizeLinSolver, BackslashLinSolver, FactorizeLinSolverCreator,
                          BackslashLinSolverCreator, DefaultLinSolverCreator, create_linsolver, lin_solve,
-                         LinSolverCache, DeviceLU, HostLUPool, GMRESLinSolver, GMRESLinSolverCreator)
+                         LinSolverCache, DeviceLU, HostLUPool, GMRESLinSolver, GMRESLinSolverCreator, seed_plan_from_rank0)
 from .errmeasure import (Errmeasure, ResidualErrmeasure, StandardSPMFErrmeasure, DefaultErrmeasure,
                          estimate_error, estimate_errors)
 from .dense import gemm_ts, orthogonalize_and_normalize, DGKS, CGS, MGS

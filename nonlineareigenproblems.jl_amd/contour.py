@@ -68,14 +68,28 @@ def integrate_interval(ST, f, gv, a, b, N, info=None, ops=_DeviceOps):
         world, rank = dist.get_world_size(), dist.get_rank()
     S = None
     mine = range(rank, N, world)
+    # info["phases_s"] (a dict the caller put there): wall time of the pieces, each closed by a device synchronisation -- for the
+    # record of what is sharded (factorise, solve) and what every rank repeats (the rest), also with one rank
+    ph = info.get("phases_s") if (info is not None and isinstance(info.get("phases_s"), dict)) else None
+    import time as _time
+
+    def _tick(name, t0):
+        if ph is not None:
+            if torch.cuda.is_available() and (S is None or S.is_cuda):
+                torch.cuda.synchronize()
+            ph[name] = ph.get(name, 0.0) + _time.perf_counter() - t0
+        return _time.perf_counter()
+    tp = _time.perf_counter()
     if hasattr(f, "prefetch"):
         f.prefetch([t[i] for i in mine])
+    tp = _tick("factorise_nodes", tp)
     for i in mine:
         X, c = f(t[i])
         if S is None:
             S = torch.zeros((m,) + tuple(X.shape), dtype=CDT, device=X.device)
         for j in range(m):
             ops.axpy(c * G[i, j], X, S[j])
+    tp = _tick("solve_nodes_and_accumulate", tp)
     if S is None:
         raise ValueError("rank %d owns no quadrature node (N=%d < world size %d)" % (rank, N, world))
     if getattr(ST, "sharded", False) and S.is_cuda and (comm is not None or (dist.is_available() and dist.is_initialized())):
@@ -90,6 +104,7 @@ def integrate_interval(ST, f, gv, a, b, N, info=None, ops=_DeviceOps):
         for p in parts:                            # fixed rank order -> identical on every rank
             ops.axpy(1.0, p, S)
     ops.scal(S, h)
+    tp = _tick("exchange_and_sum", tp)
     if info is not None:
         info.update(world=world, rank=rank, nodes=len(mine))
         if comm is not None and getattr(comm, "last_exchange_s", None) is not None:
@@ -290,15 +305,27 @@ def contour_beyn(nep, MIntegrator=MatrixTrapezoidal, tol=np.sqrt(EPS), sigma=0.0
         raise ValueError("Cannot compute more eigenvalues than the size of the NEP with contour_beyn() k=%d n=%d" % (k, n))
     if k <= 0:
         raise ValueError("k must be positive, k=%d." % k)
+    import time as _time
+    ph = info.get("phases_s") if (info is not None and isinstance(info.get("phases_s"), dict)) else None
+
+    def _tick(name, t0):
+        if ph is not None:
+            torch.cuda.synchronize()
+            ph[name] = ph.get(name, 0.0) + _time.perf_counter() - t0
+        return _time.perf_counter()
+    tp = _time.perf_counter()
     if Vh is None:
         Vh = probe_block(n, k)
     Vd = to_dev(Vh)
+    tp = _tick("probe_generate_and_upload", tp)
 
     f = _NodeSolve(nep, linsolvercreator, sigma, g, Vd, gp)
 
     S = integrate_interval(MIntegrator, f, [lambda s: 1.0 + 0j, g], 0.0, 2 * np.pi, N, info=info)
+    tp = _time.perf_counter()
     A0 = to_host(S[0]) / (2j * np.pi)
     A1 = to_host(S[1]) / (2j * np.pi)
+    tp = _tick("moments_download", tp)
     V, Sv, Wh = sla.svd(A0, full_matrices=False)
     W = Wh.conj().T
     p = int(np.sum(Sv / Sv[0] > rank_drop_tol))
@@ -306,9 +333,11 @@ def contour_beyn(nep, MIntegrator=MatrixTrapezoidal, tol=np.sqrt(EPS), sigma=0.0
     B = (V0.conj().T @ A1 @ W0) @ np.diag(1.0 / Sv[:p])
     lam, VB = sla.eig(B)
     lam = lam + sigma
+    tp = _tick("svd_and_eig_host", tp)
     # eigenvectors V0*VB on the device (K7), normalised
     V0d = to_dev(V0)
     QT = dense.gemm_ts(V0d, VB, rowmajor=True)                 # (n, p) row-major
+    tp = _tick("eigenvectors", tp)
     if info is not None:
         info.update(p=p, S=Sv, A0=A0, A1=A1)
 
@@ -324,6 +353,7 @@ def contour_beyn(nep, MIntegrator=MatrixTrapezoidal, tol=np.sqrt(EPS), sigma=0.0
         perm = np.argsort(~inside(lam[si]), kind="stable")
         return lam[si[perm]], cols(si[perm])
     errs = estimate_errors(errmeasure, lam, QT)
+    tp = _tick("residual_filter", tp)
     good = np.nonzero(errs < tol)[0]
     sgi = good[np.argsort(abs(sigma - lam[good]), kind="stable")]
     perm = np.argsort(~inside(lam[sgi]), kind="stable")

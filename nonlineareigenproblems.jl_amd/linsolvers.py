@@ -438,6 +438,35 @@ class DeviceLU:
 EPS = np.finfo(float).eps
 
 
+def seed_plan_from_rank0(nep, lam, group=None, permc_spec=None, wait=True):
+    """Collective over the ranks of a node (torch.distributed): the FIRST factorisation of a sparsity pattern -- the host SuperLU
+    run that fixes ordering, pivot sequence and fill, and from which the pattern's device-factorisation plan is built -- is done
+    by rank 0 alone and its factor arrays are broadcast; every rank uploads them, starts its plan (enumerated on its own GPU,
+    21 ms for gun) and, with wait=True, returns when the plan is ready, so that no rank ever runs SuperLU for this pattern (8
+    ranks on a shared CPU quota would otherwise start 8 concurrent host factorisations in their first call).  Returns the
+    DeviceLU of M(lam) built from the broadcast factors.  Without an initialised process group: the plain local path."""
+    import torch.distributed as dist
+    A = sp.csc_matrix(nep.compute_Mder(lam), dtype=np.complex128)
+    A.sort_indices()
+    distd = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    rank = dist.get_rank(group) if distd else 0
+    F = None
+    if rank == 0:
+        F = _nep_hostlu.factor(A.data, A.indices, A.indptr, A.shape, permc_spec=permc_spec, diag_pivot_thresh=None, symmetric_mode=None)
+    if distd:
+        box = [F]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        F = box[0]
+    seed_plan_from_rank0.host_factorisations += 1 if rank == 0 else 0
+    lu = DeviceLU(factors=F, plan_pattern=A, permc_spec=permc_spec)
+    if wait:
+        _DeviceRefactor.wait()
+    return lu
+
+
+seed_plan_from_rank0.host_factorisations = 0
+
+
 class FactorizeLinSolver(LinSolver):
     """src/LinSolvers.jl:109-137: factor M(lam) once, solve many right-hand sides.  Like UMFPACK's solve
     (control[8] = umfpack_refinements, LinSolvers.jl:118-120) each single-vector solve is followed by iterative

@@ -143,3 +143,44 @@ def test_sum_ranks_fixed_order_kernel(na):
             assert not np.array_equal(rev, ref)
         check(lib.nep_sum_ranks(c_vp(G.data_ptr()), ln, world, c_vp(G.data_ptr()), None))          # output aliases block 0
         assert np.array_equal(G[0].cpu().numpy(), ref)
+
+
+def _seed_rank(rank, world, port, out, n):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    import nep_amd as na
+    import nep_amd_hostlu as hl
+    from nep_amd.linsolvers import _DeviceRefactor
+    calls = [0]
+    orig = hl.factor
+
+    def counting(*a, **kw):
+        calls[0] += 1
+        return orig(*a, **kw)
+    hl.factor = counting
+    nep = na.nep_gallery("gun_spmf_scaled", n); nep.dev
+    lu0 = na.seed_plan_from_rank0(nep, 0.0)                   # collective: rank 0 factorises, everybody gets the factors + a plan
+    ready = [p["state"] for p in _DeviceRefactor.plans.values()]
+    b = np.ones(n, dtype=complex)
+    x0 = na.to_host(lu0.solve(na.to_dev(b)))
+    lam, Q, _ = na.iar(nep, maxit=30, neigs=np.inf, v=np.ones(n), tol=1e-10)      # factorises M(0) on the device: no SuperLU here
+    used = sum(p["uses"] for p in _DeviceRefactor.plans.values())
+    np.savez(os.path.join(out, "s%d.npz" % rank), host_calls=calls[0], ready=np.array([r == "ready" for r in ready]), used=used, lam=lam, x0=x0)
+    dist.destroy_process_group()
+
+
+def test_seed_factorisation_broadcast_from_rank0(na, tmp_path):
+    """the first (host) factorisation of a pattern is done by rank 0 only and broadcast (seed_plan_from_rank0): rank 1 never
+    calls SuperLU, both ranks end up with a ready device-LU plan, use it in their next iar call and return the same eigenvalues;
+    the solve with the broadcast factors is the same on both ranks"""
+    n = 1310
+    mp.spawn(_seed_rank, args=(2, _free_port(), str(tmp_path), n), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "s0.npz"); r1 = np.load(tmp_path / "s1.npz")
+    assert int(r0["host_calls"]) == 1 and int(r1["host_calls"]) == 0
+    assert r0["ready"].all() and r1["ready"].all() and len(r0["ready"]) == 1
+    assert int(r0["used"]) >= 1 and int(r1["used"]) >= 1
+    assert np.array_equal(r0["x0"], r1["x0"])
+    assert len(r0["lam"]) == len(r1["lam"]) >= 1
+    assert np.abs(np.sort_complex(r0["lam"]) - np.sort_complex(r1["lam"])).max() <= 1e-10 * np.abs(r0["lam"]).max()
