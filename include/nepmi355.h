@@ -301,6 +301,9 @@ int32_t nep_lu_destroy(nep_lu* lu);
  * dependency chain per solve): FactorizeLinSolver (iar/tiar: maxit solves) passes a large number,
  * BackslashLinSolver (one block solve per factorisation, src/LinSolvers.jl:157-159) passes 1. */
 int32_t nep_lu_set_expected_solves(int32_t nsolves);
+/* host threads of the plan enumeration of nep_lu_refac_create when it runs on the host (0 = default 6; the variable
+ * NEP_LU_PLAN_THREADS overrides): a setter instead of an environment write from a running multi-threaded host */
+int32_t nep_lu_set_plan_threads(int32_t n);
 /* info[0]=n info[1]=nnz(L) info[2]=nnz(U) info[3]=dependent steps(L) info[4]=dependent steps(U)
  * info[5]=bytes one solve with one right-hand side moves under the schedule in use (the ALGORITHMIC bytes of SURVEY.md
  * section 8d are (nnz(L)+nnz(U))*20 + 8(n+1) + 48n, computable from info[0..2]) */

@@ -107,6 +107,7 @@ SIGNATURES = {
     "nep_lu_analyze": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, P(c_i64)],
     "nep_lu_destroy": [c_vp],
     "nep_lu_set_expected_solves": [c_i32],
+    "nep_lu_set_plan_threads": [c_i32],
     "nep_cw_backward_error": [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "nep_absvec": [c_i64, c_vp, c_vp, c_vp],
     "nep_lu_info": [c_vp, P(c_i64)],

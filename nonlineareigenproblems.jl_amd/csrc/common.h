@@ -169,6 +169,11 @@ int nep_tiles_resid(const NepTiles* t, int k, const cplx* dF, const cplx* QT, in
                     int64_t split_row, hipStream_t st);
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (host thread, device, kernel): the attribute belongs to the function
+// object of the CURRENT device, so a process that drives several GPUs (nep_set_device) must raise it on each of them -- a plain
+// `static bool raised` would launch with more than 64 KB of LDS on a device where the limit was never raised
+extern "C" int nep_raise_lds(const void* kernel, int bytes);
+
 // small per-library scratch (device) helpers, defined in util.hip
 struct NepScratch {
     void* dptr = nullptr;

@@ -647,17 +647,6 @@ __global__ __launch_bounds__(64) void k_hess_invit(int k0, int kstep, cplx* __re
     }
 }
 
-int raise_lds(size_t bytes) {
-    // per thread and device (a process may drive several GPUs): the attribute is set on the current device's function object
-    static thread_local int done_dev = -1; static thread_local size_t done_bytes = 0;
-    int dev = 0; HIPCHK(hipGetDevice(&dev));
-    if (dev != done_dev || bytes > done_bytes) {
-        HIPCHK(hipFuncSetAttribute((const void*)k_hess_qr, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
-        done_dev = dev; done_bytes = 163840;
-    }
-    return NEP_OK;
-}
-
 cplx* mapped(nep_cdouble* h_mirror) {
     if (!h_mirror) return nullptr;
     void* dp = nullptr;
@@ -688,7 +677,7 @@ int32_t nep_hess_eigvals_batch_dev(int32_t nb, int32_t k0, int32_t kstep, const 
         ARGCHK(w_stride >= kmax + 2 && work_stride >= need && (work_stride % 16) == 0 && (!h_mirror || mirror_stride >= kmax + 2));
     }
     const size_t lds = (size_t)16 * kmax * kmax + (size_t)32 * (kmax + 1) + 48;       // matrix, rotations, control block
-    if (lds > 65536) { int rc = raise_lds(lds); if (rc) return rc; }
+    if (lds > 65536) { int rc = nep_raise_lds((const void*)k_hess_qr, 163840); if (rc) return rc; }
     cplx* mir = mapped(h_mirror);
     if (h_mirror && !mir) { nep_set_error("nep_hess_eigvals_dev: h_mirror is not mapped pinned host memory"); return NEP_ERR_ARG; }
     hipLaunchKernelGGL(k_hess_qr, dim3((unsigned)nb), dim3(128), lds, as_stream(stream), (int)k0, (int)kstep, (const cplx*)dH, ldh,

@@ -26,6 +26,12 @@
 #include <chrono>
 #include <thread>
 #include <hipcub/hipcub.hpp>
+#include <atomic>
+// (hipCUB -- header-only device primitives, compiled into this library; no run-time dependency -- serves the ONE-OFF enumeration
+// of a pattern's plan: an exclusive scan and a radix sort over its products.  Nothing on a solve / factorisation path uses it;
+// it is the one vendor component besides RCCL, named in tests/test_host_logic.py::test_no_vendor_blas_or_fft_behind_the_abi.)
+static std::atomic<int> g_plan_threads{0};     // host enumeration threads (0: default 6); set by the host language, not via putenv
+extern "C" int32_t nep_lu_set_plan_threads(int32_t n) { g_plan_threads.store(n < 0 ? 0 : (n > 32 ? 32 : n)); return NEP_OK; }
 #include <cstring>
 #include <math.h>
 
@@ -383,6 +389,10 @@ struct LuGpuEnum {
         tmp.clear();
         if (st) { (void)hipStreamDestroy(st); st = nullptr; }
     }
+    ~LuGpuEnum() { release(); }       // every exit of nep_lu_refac_create returns the stream and the pool temporaries
+    LuGpuEnum() = default;
+    LuGpuEnum(const LuGpuEnum&) = delete;
+    LuGpuEnum& operator=(const LuGpuEnum&) = delete;
     int classify(int64_t n, int64_t nF, const std::vector<int64_t>& urp, const std::vector<Ent>& urow, const std::vector<int64_t>& cptr,
                  const std::vector<Ent>& cent, const int32_t* blk, const int32_t* lvl, const std::vector<uint8_t>& wide,
                  std::vector<int32_t>& cnt_int, std::vector<int32_t>& cnt_wide, std::vector<int32_t>& tot) {
@@ -621,7 +631,7 @@ static int32_t refac_build(nep_lu_refac* r, int64_t n, const int32_t* Lp, const 
     for (int64_t j = 0; j < n; ++j)
         for (int64_t e = cptr[j]; e < cptr[j + 1]; ++e) dstpiv[cent[e].g] = std::min<int32_t>(cent[e].row, (int32_t)j);
     for (int64_t k = 0; k < n; ++k) dstpiv[ldiag[k]] = (int32_t)k;
-    int nthr = 6;
+    int nthr = g_plan_threads.load() > 0 ? g_plan_threads.load() : 6;       // nep_lu_set_plan_threads; the variable overrides
     if (const char* e = getenv("NEP_LU_PLAN_THREADS")) nthr = std::max(1, std::min(32, atoi(e)));
     std::vector<int64_t> kcut(nthr + 1, n);
     {
@@ -693,7 +703,11 @@ static int32_t refac_build(nep_lu_refac* r, int64_t n, const int32_t* Lp, const 
         const double tg0 = now_ms();
         const int rcg = G.classify(n, nF, urp, urow, cptr, cent, blk, lvl, r->wide, cnt_int, cnt_wide, tot);
         G.t_classify = now_ms() - tg0;
-        if (rcg) { G.release(); gpu = false; }                 // (pattern errors are diagnosed by the host enumeration below)
+        if (rcg) {                                             // (pattern errors are diagnosed by the host enumeration below)
+            G.release(); gpu = false;
+            // a failure behind the asynchronous copies may have left the count arrays partly written: the host path starts clean
+            std::fill(cnt_int.begin(), cnt_int.end(), 0); std::fill(cnt_wide.begin(), cnt_wide.end(), 0); std::fill(tot.begin(), tot.end(), 0);
+        }
     }
     if (!gpu) run_threads([&](int tix) {
         std::vector<int32_t>& ce = cnt_ext[tix];

@@ -765,16 +765,12 @@ int nep_tiles_mlincomb(const NepTiles* t, int k, const cplx* dC, int64_t ldc, co
     static const int pf_on = env_int("NEP_K1_TILE_PF", 1);
     int nthr, split; tiles_launch_shape(t, k, &nthr, &split);
     const bool nt = t->n >= 32768;          // entries streamed once (HBM) vs re-read from L2 by every call (small matrices)
-    const bool pf = nt && pf_on;
+    const bool pf = nt && pf_on && t->rbmax <= 512;      // the register prefetch covers 2 x 256 rows per block (k_tile_mlincomb: rb <= 2 nthr)
     const int mtc = std::min(t->mt, 4);
 #define TL(VT, M, NTF, PFF)                                                                                                    \
     do {                                                                                                                       \
         if (shm > 64 * 1024) {                                                                                                 \
-            static bool raised = false;                                                                                        \
-            if (!raised) {                                                                                                     \
-                HIPCHK(hipFuncSetAttribute((const void*)k_tile_mlincomb<VT, M, NTF, PFF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-                raised = true;                                                                                                 \
-            }                                                                                                                  \
+            { const int rc_ = nep_raise_lds((const void*)k_tile_mlincomb<VT, M, NTF, PFF>, 160 * 1024); if (rc_) return rc_; }                                  \
         }                                                                                                                      \
         hipLaunchKernelGGL((k_tile_mlincomb<VT, M, NTF, PFF>), dim3((unsigned)t->nblk), dim3(nthr), shm, st, (const TileDesc*)t->d_desc, \
                            (const uint32_t*)t->d_fp, (const uint16_t*)t->d_eidx, (const VT*)t->d_eval, dV, ldv, k, dC, ldc, t->mt,  \
@@ -824,11 +820,7 @@ int nep_tiles_resid_cm(const NepTiles* t, int k, const cplx* dF, const cplx* Q, 
 #define RC(VT, M, P, NTF)                                                                                                      \
     do {                                                                                                                       \
         if (shm > 64 * 1024) {                                                                                                 \
-            static bool raised = false;                                                                                        \
-            if (!raised) {                                                                                                     \
-                HIPCHK(hipFuncSetAttribute((const void*)k_tile_resid_cm<VT, M, P, NTF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-                raised = true;                                                                                                 \
-            }                                                                                                                  \
+            { const int rc_ = nep_raise_lds((const void*)k_tile_resid_cm<VT, M, P, NTF>, 160 * 1024); if (rc_) return rc_; }                                  \
         }                                                                                                                      \
         hipLaunchKernelGGL((k_tile_resid_cm<VT, M, P, NTF>), grid, dim3(256), shm, st, (const TileDesc*)t->d_desc,             \
                            (const uint32_t*)t->d_fp, (const uint16_t*)t->d_eidx, (const VT*)t->d_eval, Q, ldq, k, dF, t->mt,   \
@@ -856,11 +848,7 @@ int nep_tiles_resid(const NepTiles* t, int k, const cplx* dF, const cplx* QT, in
 #define RL(VT, M, P, NTF)                                                                                                      \
     do {                                                                                                                       \
         if (shm > 64 * 1024) {                                                                                                 \
-            static bool raised = false;                                                                                        \
-            if (!raised) {                                                                                                     \
-                HIPCHK(hipFuncSetAttribute((const void*)k_tile_resid<VT, M, P, NTF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
-                raised = true;                                                                                                 \
-            }                                                                                                                  \
+            { const int rc_ = nep_raise_lds((const void*)k_tile_resid<VT, M, P, NTF>, 160 * 1024); if (rc_) return rc_; }                                  \
         }                                                                                                                      \
         hipLaunchKernelGGL((k_tile_resid<VT, M, P, NTF>), dim3((unsigned)t->nblk), dim3(256), shm, st, (const TileDesc*)t->d_desc,  \
                            (const uint32_t*)t->d_fp, (const uint16_t*)t->d_eidx, (const VT*)t->d_eval, QT, ldq, k, dF, t->mt,       \

@@ -263,6 +263,16 @@ int32_t nep_stream_sync(nep_stream stream) {
     return NEP_OK;
 }
 
+int nep_raise_lds(const void* kernel, int bytes) {
+    static thread_local std::vector<std::pair<int, const void*>> done;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    for (const auto& d : done) if (d.first == dev && d.second == kernel) return NEP_OK;
+    HIPCHK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    done.emplace_back(dev, kernel);
+    return NEP_OK;
+}
+
 // Do two streams execute their kernels one after the other?  The runtime maps streams onto a small pool of hardware queues (4
 // by default) and two streams that land on the same queue serialise -- a 3 ms one-wavefront kernel (csrc/hesseig.hip) then
 // holds up whatever shares its queue (measured: iar's convergence checks behind the eigen-decompositions, 4 ms per batch; a

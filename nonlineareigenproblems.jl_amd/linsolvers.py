@@ -188,9 +188,10 @@ class _DeviceRefactor:
                     plan["state"] = "off"
             plan.pop("keep", None)
         if "NEP_LU_PLAN_THREADS" not in os.environ:
-            # enumeration threads from the CPU budget of this rank (8 ranks on a 16-CPU quota must not start 48 threads)
+            # enumeration threads from the CPU budget of this rank (8 ranks on a 16-CPU quota must not start 48 threads); through a
+            # setter: writing the environment from here would race with getenv calls of plan threads already running
             from ._affinity import cpu_budget
-            os.environ["NEP_LU_PLAN_THREADS"] = str(max(1, min(6, cpu_budget() - 1)))
+            check(lib.nep_lu_set_plan_threads(max(1, min(6, cpu_budget() - 1))))
         plan["keep"] = lu                  # the reference factor must outlive the build
         t = threading.Thread(target=build, name="nep-lu-refac-plan", daemon=True)
         plan["thread"] = t

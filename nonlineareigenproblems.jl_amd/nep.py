@@ -325,14 +325,14 @@ class AbstractSPMF(NEP):
     def dev(self):
         if self._dev is None:
             self._dev = SPMFDevice(self.get_Av())
-            # the other one-off derived data of the matrices (Frobenius norms for the error measures, the term values on the union
-            # pattern for compute_Mder / the device LU) are built with the upload, not inside the first solver call
-            try:
-                self.fro_norms()
-                if self.issparse():
-                    self._aligned_terms()
-            except Exception:
-                pass
+            # the other one-off derived data of the matrices are built with the upload instead of inside the first solver call:
+            # the Frobenius norms (error measures) always; the term values on the union pattern (compute_Mder, the device LU)
+            # only for small problems (gun: 88 598 union entries x 4 terms, 2 ms) -- on a waveguide-sized pattern the aligned block
+            # costs seconds of host time and 240 MB, and the solvers used there (GMRES on the Schur complement, tiar) never ask
+            # for it; it stays lazy (first compute_Mder / aligned_terms_dev call).  Failures are not swallowed.
+            self.fro_norms()
+            if self.issparse() and sum(int(A.nnz) for A in self.get_Av()) <= int(os.environ.get("NEP_ALIGNED_PREFETCH_NNZ", "2000000")):
+                self._aligned_terms()
         return self._dev
 
     # ---- element type of host results (test/compute_types.jl): the reference returns promote_type(eltype(nep), typeof(lam),
