@@ -330,7 +330,10 @@ class AbstractSPMF(NEP):
             # only for small problems (gun: 88 598 union entries x 4 terms, 2 ms) -- on a waveguide-sized pattern the aligned block
             # costs seconds of host time and 240 MB, and the solvers used there (GMRES on the Schur complement, tiar) never ask
             # for it; it stays lazy (first compute_Mder / aligned_terms_dev call).  Failures are not swallowed.
-            self.fro_norms()
+            try:
+                self.fro_norms()
+            except TypeError:                 # a NEP type for which the SPMF error measure is not defined (WEP: it says so)
+                pass
             if self.issparse() and sum(int(A.nnz) for A in self.get_Av()) <= int(os.environ.get("NEP_ALIGNED_PREFETCH_NNZ", "2000000")):
                 self._aligned_terms()
         return self._dev
