@@ -124,6 +124,17 @@ __global__ __launch_bounds__(1024) void k_dft_cols(int nz, int nx, int N1, int N
 // multiply-adds instead of 4 (the one-output-per-thread form moves 80 bytes of LDS per 32 flops and is LDS-bound at 35 us;
 // this one moves 112 bytes per 96 flops).  Measured at 999 x 1003: 31.5 / 33.5 us (forward / inverse) against 35.8 / 34.0 us -- the kernel
 // is bound by exposed latency (one 128 KB workgroup per CU, six waves), not by LDS bytes; `NEP_WEP_DFT_RB=0` selects the old form.
+#ifdef WEP_PROF
+__device__ unsigned long long g_dft_prof[16];
+extern "C" int32_t nep_wep_prof_read(unsigned long long* out, int32_t reset) {
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dft_prof), sizeof(unsigned long long) * 16));
+    if (reset) { unsigned long long z[16] = {0}; HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(g_dft_prof), z, sizeof(z))); }
+    return NEP_OK;
+}
+#define WP(x) const long long x = clock64()
+#else
+#define WP(x)
+#endif
 template <bool FWD>
 __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int N2, const int32_t* __restrict__ in_idx,
                                                       const int32_t* __restrict__ in_inv,
@@ -136,6 +147,7 @@ __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int
     cplx* ts = xs + (size_t)COLS * nz;          // [q][COLS], q = k1 N2 + n2
     cplx* r1 = ts + (size_t)COLS * nz;
     cplx* r2 = r1 + N1;
+    WP(tp0);
     const int x0 = dft_group(xcd_order) * COLS;
     const int nc = min(COLS, nx - x0);
     const int nt = blockDim.x;
@@ -178,6 +190,7 @@ __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int
         }
     }
     __syncthreads();
+    WP(tp1);
     // stage 1: ts[k1, n2] = sum_n1 xs[n1, n2] r1^(n1 k1), three k1 per thread
     const int G1 = (N1 + KB - 1) / KB;
     for (int t = threadIdx.x; t < G1 * N2; t += nt) {
@@ -209,6 +222,7 @@ __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int
             }
     }
     __syncthreads();
+    WP(tp2);
     // stage 2: out[k1, k2] = sum_n2 ts[k1, n2] r2^(n2 k2), three k2 per thread
     const int G2 = (N2 + KB - 1) / KB;
     for (int t = threadIdx.x; t < N1 * G2; t += nt) {
@@ -252,7 +266,28 @@ __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int
                 }
             }
     }
+#ifdef WEP_PROF
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long tp3 = clock64();
+        const int o = FWD ? 0 : 8;
+        atomicAdd(&g_dft_prof[o + 0], (unsigned long long)(tp1 - tp0)); atomicAdd(&g_dft_prof[o + 1], (unsigned long long)(tp2 - tp1));
+        atomicAdd(&g_dft_prof[o + 2], (unsigned long long)(tp3 - tp2)); atomicAdd(&g_dft_prof[o + 3], 1ull);
+        atomicMax(&g_dft_prof[o + 4], (unsigned long long)(tp3 - tp0));
+    }
+#endif
 }
+
+// (Round 4: the same two stages were also written for the FP64 matrix cores -- complex products as four v_mfma_f64_16x16x4_f64 on
+// the halves of one 16-byte LDS read, results of stage 1 kept in registers across a barrier so that ONE 64 KB buffer serves
+// four columns -- correct against the NumPy reference, and exactly as fast: 28 / 30 us per transform against 28 / 30.  A
+// -DWEP_PROF build (scripts/diag/wep_prof_run.py) shows why: a workgroup spends 8-10 k cycles loading, 28-29 k in stage 1 and
+// 21 k in stage 2 + store with either kernel.  The two dense DFTs are 2.0 MFLOP per workgroup = 16 k cycles at the CU's
+// 128 flop/clk, vector or matrix pipe alike on gfx950 (the FP64 MFMA issues one 16x16x4 per 64 cycles and SIMD); the matrix form
+// pays 1.4x padding (27 -> 32, 37 -> 48) and its dependent accumulator chains, the vector form its issue rate at 1.5 wavefronts
+// per SIMD.  The kernel is bound by the arithmetic of the prime-factor scheme at ~35 % of the FP64 peak, not by its transposing
+// stores; what would lower it is fewer flops (27 = 3^3 by radix-3 steps: stage 1 from 27 to ~9 multiply-adds per entry), not
+// another pipe.  The matrix-core version was removed again.)
 
 // ---- Thomas pivots of (d_i I + B), one thread per mode (one-off per shift) -------------------------------------------------------
 __global__ void k_tridiag_factor(int nz, int nx, const cplx* __restrict__ d, double b, cplx* __restrict__ mfac,
