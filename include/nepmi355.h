@@ -196,7 +196,7 @@ int32_t nep_gemm_h_rm(const nep_cdouble* dWT, int64_t ldw, const nep_cdouble* dY
  * replaces: `D,Z = eigen(H[1:k,1:k])`  src/method_iar.jl:112, src/method_tiar.jl:182 (LAPACK zgeev on the host there).
  * dH: k x k upper Hessenberg, column-major with leading dimension ldh (entries below the first subdiagonal are not read --
  * the rows of nep_iar_step's device H block, leading dimension m + 4, are exactly this layout).
- * nep_hess_eigvals_dev: eigenvalues by the shifted QR iteration (one wavefront, matrix in LDS; k <= 100, else
+ * nep_hess_eigvals_dev: eigenvalues by the shifted QR iteration (two wavefronts, matrix packed in LDS; k <= 128, else
  *   NEP_ERR_UNSUPPORTED) -> d_w[0..k); d_w[k] = (0 | 1-based index of the eigenvalue the iteration gave up on, sweeps).
  * nep_hess_eigvecs_dev: right eigenvectors by inverse iteration (LAPACK zhsein's scheme, one wavefront per eigenvalue) ->
  *   dZ (k x k column-major, ldz), unit 2-norm, largest component real positive; d_w[k+1] = (vectors that failed, 0).

@@ -7,7 +7,9 @@
 //
 // Two kernels (both latency-bound by a serial chain; neither has an HBM or MFMA roofline -- the matrix is <= 160 KB):
 //
-//   k_hess_qr     ONE wavefront per matrix, the matrix in LDS (k <= 100: 16 k^2 + 32 k bytes of the CU's 160 KiB).
+//   k_hess_qr     TWO wavefronts per matrix (QR half / RQ half, below), the matrix in LDS as a packed upper Hessenberg array
+//                 (k <= 128: 16 (k^2/2 + 1.5 k) + 32 k bytes = 86 KB at k = 100 -- half a CU's LDS, so that the streaming kernels
+//                 of the recurrence keep a place on the CUs a decomposition runs on).
 //                 Explicit single-shift QR iteration on the active window [l, i] (the structure of EISPACK's comqr) with
 //                 LAPACK zlahqr's choices: Wilkinson shift from the trailing 2 x 2 block, exceptional shifts at iterations 10
 //                 and 20, the Ahues-Tisseur deflation test, 30 max(10, k) iterations per eigenvalue, eigenvalues only (only
@@ -32,8 +34,11 @@ namespace {
 
 constexpr double HQ_ULP = 2.220446049250313e-16;        // dlamch('P')
 constexpr double HQ_SAFMIN = 2.2250738585072014e-308;   // dlamch('S')
-constexpr int HQ_KMAX = 100;
+constexpr int HQ_KMAX = 128;                             // two columns per lane; 16 (k^2/2 + 1.5 k) + 32 k bytes of LDS (k = 128: 141 KB)
 
+// packed upper Hessenberg storage: column c holds its rows 0 .. c + 1 (the last column: 0 .. k - 1) at offset c (c + 3) / 2
+__host__ __device__ __forceinline__ int hq_off(int c) { return (c * (c + 3)) >> 1; }
+__host__ __device__ __forceinline__ int hq_entries(int k) { return hq_off(k - 1) + k; }
 __device__ __forceinline__ double cabs1(cplx z) { return fabs(z.x) + fabs(z.y); }
 __device__ __forceinline__ cplx readlane_c(cplx v, int lane) { return cmake(readlane_d(v.x, lane), readlane_d(v.y, lane)); }
 __device__ __forceinline__ cplx cconj(cplx a) { return cmake(a.x, -a.y); }
@@ -103,16 +108,16 @@ __device__ __forceinline__ cplx csqrt_fast(cplx z) {
 // zlahqr's test for a negligible subdiagonal entry H(kk, kk-1) (with |re| + |im| where zlahqr, whose subdiagonal is kept
 // real, has |re|)
 __device__ __forceinline__ bool negligible_sub(const cplx* A, int ld, int kk, int n, double smlnum) {
-    const double sub = cabs1(A[(kk - 1) * ld + kk]);
+    const double sub = cabs1(A[hq_off((kk - 1)) + kk]);
     if (sub <= smlnum) return true;
-    const cplx d1 = A[(kk - 1) * ld + kk - 1], d2 = A[kk * ld + kk];
+    const cplx d1 = A[hq_off((kk - 1)) + kk - 1], d2 = A[hq_off(kk) + kk];
     double tst = cabs1(d1) + cabs1(d2);
     if (tst == 0.0) {
-        if (kk - 2 >= 0) tst += cabs1(A[(kk - 2) * ld + kk - 1]);
-        if (kk + 1 <= n - 1) tst += cabs1(A[kk * ld + kk + 1]);
+        if (kk - 2 >= 0) tst += cabs1(A[hq_off((kk - 2)) + kk - 1]);
+        if (kk + 1 <= n - 1) tst += cabs1(A[hq_off(kk) + kk + 1]);
     }
     if (sub <= HQ_ULP * tst) {
-        const double sup = cabs1(A[kk * ld + kk - 1]);
+        const double sup = cabs1(A[hq_off(kk) + kk - 1]);
         const double ab = fmax(sub, sup), ba = fmin(sub, sup);
         const double a2 = cabs1(d2), dd = cabs1(csub(d1, d2));
         const double aa = fmax(a2, dd), bb = fmin(a2, dd);
@@ -167,7 +172,7 @@ __device__ __forceinline__ void qr_half(cplx* A, cplx* rot, int* prog, const int
     const int c0 = l + lane;
     if (!TWO) {
         const bool in0 = c0 <= i;
-        cplx* col = A + (in0 ? c0 : i) * ld;
+        cplx* col = A + hq_off(in0 ? c0 : i);
         cplx up = col[l], lo = col[l + 1];
         cplx lon = col[l + 2];                                          // (row i + 1 at most: inside the allocation, unused)
         double c; cplx s;
@@ -176,7 +181,7 @@ __device__ __forceinline__ void qr_half(cplx* A, cplx* rot, int* prog, const int
         { HQ_APPLY(c, s, up, lo, nu, nl); pnu = nu; pc = c; ps = s; up = nl; lo = lon; }
         for (int j = l + 2; j <= i; ++j) {
             lon = col[j + 1];
-            if (in0) col[j - 2] = pnu;
+            if (in0 && c0 + 2 >= j) col[j - 2] = pnu;            // rows <= c + 1 exist in the packed column c
             rot[2 * (j - 1)] = cmake(pc, 0.0); rot[2 * (j - 1) + 1] = ps;      // every lane writes the same pair
             HQ_CBAR(); ctl_store(prog, j); HQ_CBAR();
             const int gl = j - 1 - l;
@@ -184,15 +189,15 @@ __device__ __forceinline__ void qr_half(cplx* A, cplx* rot, int* prog, const int
             HQ_APPLY(c, s, up, lo, nu, nl);
             pnu = nu; pc = c; ps = s; up = nl; lo = lon;
         }
-        if (in0) col[i - 1] = pnu;
+        if (in0 && c0 + 2 >= i + 1) col[i - 1] = pnu;
         rot[2 * i] = cmake(pc, 0.0); rot[2 * i + 1] = ps;
         if (c0 == i) col[i] = up;
     } else {
         // window wider than a wavefront: every lane of set 0 is inside it
         const int c1 = c0 + 64;
         const bool in1 = c1 <= i;
-        cplx* col0 = A + c0 * ld;
-        cplx* col1 = A + (in1 ? c1 : i) * ld;
+        cplx* col0 = A + hq_off(c0);
+        cplx* col1 = A + hq_off(in1 ? c1 : i);
         cplx up0 = col0[l], up1 = col1[l];
         cplx lo0 = col0[l + 1], lo1 = col1[l + 1];
         cplx lo0n = col0[l + 2], lo1n = col1[l + 2];
@@ -206,8 +211,8 @@ __device__ __forceinline__ void qr_half(cplx* A, cplx* rot, int* prog, const int
         const int jm = l + 64;                                          // last rotation generated inside set 0 (jm <= i)
         for (int j = l + 2; j <= jm; ++j) {
             lo0n = col0[j + 1]; lo1n = col1[j + 1];
-            col0[j - 2] = pnu0;
-            if (in1) col1[j - 2] = pnu1;
+            if (c0 + 2 >= j) col0[j - 2] = pnu0;
+            if (in1) col1[j - 2] = pnu1;                              // (c1 >= l + 64 >= j - 1 in this loop)
             rot[2 * (j - 1)] = cmake(pc, 0.0); rot[2 * (j - 1) + 1] = ps;
             HQ_CBAR(); ctl_store(prog, j); HQ_CBAR();
             const int gl = j - 1 - l;
@@ -217,10 +222,10 @@ __device__ __forceinline__ void qr_half(cplx* A, cplx* rot, int* prog, const int
             pnu0 = nu0; pnu1 = nu1; pc = c; ps = s;
             up0 = nl0; up1 = nl1; lo0 = lo0n; lo1 = lo1n;
         }
-        col0[jm - 1] = pnu0;                                             // set 0 is left of every further rotation
+        if (c0 + 2 >= jm + 1) col0[jm - 1] = pnu0;                       // set 0 is left of every further rotation
         for (int j = jm + 1; j <= i; ++j) {
             lo1n = col1[j + 1];
-            if (in1) col1[j - 2] = pnu1;
+            if (in1 && c1 + 2 >= j) col1[j - 2] = pnu1;
             rot[2 * (j - 1)] = cmake(pc, 0.0); rot[2 * (j - 1) + 1] = ps;
             HQ_CBAR(); ctl_store(prog, j); HQ_CBAR();
             const int gl = j - 1 - l - 64;
@@ -229,7 +234,7 @@ __device__ __forceinline__ void qr_half(cplx* A, cplx* rot, int* prog, const int
             pnu1 = nu1; pc = c; ps = s;
             up1 = nl1; lo1 = lo1n;
         }
-        if (in1) col1[i - 1] = pnu1;
+        if (in1 && c1 + 2 >= i + 1) col1[i - 1] = pnu1;
         rot[2 * i] = cmake(pc, 0.0); rot[2 * i + 1] = ps;
         if (c1 == i) col1[i] = up1;
     }
@@ -254,50 +259,50 @@ __device__ __forceinline__ void rq_half(cplx* A, const cplx* rot, const int* pro
     if (!TWO) {
         const bool in0 = r0 <= i;
         const int r0c = in0 ? r0 : i;
-        cplx y = (lane == 0) ? A[l * ld + l] : czero();
+        cplx y = (lane == 0) ? A[hq_off(l) + l] : czero();
         for (int j = l + 1; j <= i; ++j) {
             HQ_WAIT(j + 2);
-            cplx z = A[j * ld + r0c];
+            cplx z = A[hq_off(j) + r0c];
             const double c = rot[2 * j].x; const cplx s = rot[2 * j + 1];
             if (r0 > j) z = czero();
             HQ_RQ(c, s, y, z, o, ny);
             if (r0 == j - 1) o = cadd(o, t);
-            if (in0) A[(j - 1) * ld + r0] = o;
+            if (in0 && r0 <= j) A[hq_off((j - 1)) + r0] = o;      // rows <= j exist in the packed column j - 1
             y = ny;
         }
-        if (in0) { if (r0 == i) y = cadd(y, t); A[i * ld + r0] = y; }
+        if (in0) { if (r0 == i) y = cadd(y, t); A[hq_off(i) + r0] = y; }
     } else {
         const int r1 = r0 + 64;
         const bool in1 = r1 <= i;
         const int r1c = in1 ? r1 : i;
-        cplx y0 = (lane == 0) ? A[l * ld + l] : czero(), y1 = czero();
+        cplx y0 = (lane == 0) ? A[hq_off(l) + l] : czero(), y1 = czero();
         const int jm = l + 63;                                          // rows of set 1 join from j = l + 64 on (jm < i)
         for (int j = l + 1; j <= jm; ++j) {
             HQ_WAIT(j + 2);
-            cplx z0 = A[j * ld + r0];
+            cplx z0 = A[hq_off(j) + r0];
             const double c = rot[2 * j].x; const cplx s = rot[2 * j + 1];
             if (r0 > j) z0 = czero();
             HQ_RQ(c, s, y0, z0, o, ny);
             if (r0 == j - 1) o = cadd(o, t);
-            A[(j - 1) * ld + r0] = o;
+            if (r0 <= j) A[hq_off((j - 1)) + r0] = o;
             y0 = ny;
         }
         for (int j = jm + 1; j <= i; ++j) {
             HQ_WAIT(j + 2);
-            const cplx z0 = A[j * ld + r0];
-            cplx z1 = A[j * ld + r1c];
+            const cplx z0 = A[hq_off(j) + r0];
+            cplx z1 = A[hq_off(j) + r1c];
             const double c = rot[2 * j].x; const cplx s = rot[2 * j + 1];
             if (r1 > j) z1 = czero();
             HQ_RQ(c, s, y0, z0, o0, n0);
             HQ_RQ(c, s, y1, z1, o1, n1);
             if (r0 == j - 1) o0 = cadd(o0, t);
             if (r1 == j - 1) o1 = cadd(o1, t);
-            A[(j - 1) * ld + r0] = o0;
-            if (in1) A[(j - 1) * ld + r1] = o1;
+            A[hq_off((j - 1)) + r0] = o0;
+            if (in1 && r1 <= j) A[hq_off((j - 1)) + r1] = o1;
             y0 = n0; y1 = n1;
         }
-        A[i * ld + r0] = y0;                                             // (r0 < i: the window is wider than 64)
-        if (in1) { if (r1 == i) y1 = cadd(y1, t); A[i * ld + r1] = y1; }
+        A[hq_off(i) + r0] = y0;                                             // (r0 < i: the window is wider than 64)
+        if (in1) { if (r1 == i) y1 = cadd(y1, t); A[hq_off(i) + r1] = y1; }
     }
 }
 
@@ -322,8 +327,8 @@ __global__ __launch_bounds__(128) void k_hess_qr(int k0, int kstep, const cplx* 
     cplx* __restrict__ Ht = Wk.Ht; cplx* __restrict__ wk_out = Wk.wk; cplx* __restrict__ misc = Wk.misc;
     cplx* __restrict__ mirror = mirror_base ? mirror_base + (size_t)blockIdx.x * mirror_stride : nullptr;
     extern __shared__ cplx sm[];
-    cplx* A = sm;                                // column-major k x k, A(r, c) = A[c * k + r]
-    cplx* rot = sm + k * k;                      // rot[2 j] = (c_j, 0), rot[2 j + 1] = s_j; reused for the eigenvalues at the end
+    cplx* A = sm;                                // packed upper Hessenberg: A(r, c) = A[hq_off(c) + r], r <= c + 1
+    cplx* rot = sm + hq_entries(k);                      // rot[2 j] = (c_j, 0), rot[2 j + 1] = s_j; reused for the eigenvalues at the end
     HqCtl* ctl = (HqCtl*)(rot + 2 * (k + 1));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -353,19 +358,21 @@ __global__ __launch_bounds__(128) void k_hess_qr(int k0, int kstep, const cplx* 
     }
     // ---- wave 0: load, scale, iterate (deflation test, shift, QR halves), results
     double amax = 0.0;
-    for (int c = 0; c < k; ++c)
-        for (int r = lane; r < k; r += 64) {
-            const cplx v = (r <= c + 1) ? H[(size_t)c * ldh + r] : czero();
-            A[c * ld + r] = v;
+    for (int c = 0; c < k; ++c) {
+        const int rl = c + 1 < k - 1 ? c + 1 : k - 1;                 // last row stored for column c
+        for (int r = lane; r <= rl; r += 64) {
+            const cplx v = H[(size_t)c * ldh + r];
+            A[hq_off(c) + r] = v;
             amax = fmax(amax, fmax(fabs(v.x), fabs(v.y)));
         }
+    }
     // row-major copy for the eigenvector kernel (coalesced reads with lane = column there) and the infinity norm (zlanhs 'I')
     double hn = 0.0;
     for (int r = 0; r < k; ++r)
-        for (int c = lane; c < k; c += 64) Ht[(size_t)r * k + c] = A[c * ld + r];
+        for (int c = lane; c < k; c += 64) Ht[(size_t)r * k + c] = (r <= c + 1) ? A[hq_off(c) + r] : czero();
     for (int r = lane; r < k; r += 64) {
         double sum = 0.0;
-        for (int c = (r > 0 ? r - 1 : 0); c < k; ++c) { const cplx v = A[c * ld + r]; sum += hypot(v.x, v.y); }
+        for (int c = (r > 0 ? r - 1 : 0); c < k; ++c) { const cplx v = A[hq_off(c) + r]; sum += hypot(v.x, v.y); }
         hn = fmax(hn, sum);
     }
 #pragma unroll
@@ -375,8 +382,7 @@ __global__ __launch_bounds__(128) void k_hess_qr(int k0, int kstep, const cplx* 
     // power-of-two scaling to max |entry| in [1/2, 1): exact, undone on the eigenvalues
     const int sexp = (amax > 0.0 && amax < INFINITY) ? __builtin_amdgcn_frexp_exp(amax) : 0;
     if (sexp != 0)
-        for (int c = 0; c < k; ++c)
-            for (int r = lane; r < k; r += 64) { cplx v = A[c * ld + r]; A[c * ld + r] = cmake(ldexp(v.x, -sexp), ldexp(v.y, -sexp)); }
+        for (int e = lane; e < hq_entries(k); e += 64) { const cplx v = A[e]; A[e] = cmake(ldexp(v.x, -sexp), ldexp(v.y, -sexp)); }
 
     int info = (amax < INFINITY) ? 0 : k, sweeps = 0;                 // Inf / NaN in the input: nothing to iterate on
     int i = k - 1;
@@ -406,22 +412,22 @@ __global__ __launch_bounds__(128) void k_hess_qr(int k0, int kstep, const cplx* 
                 if (m) { found = base - (__ffsll((long long)m) - 1); break; }
             }
             l = __builtin_amdgcn_readfirstlane(found);      // wave-uniform by construction; says so to the compiler (scalar loop control)
-            if (l > 0 && lane == 0) A[(l - 1) * ld + l] = czero();
+            if (l > 0 && lane == 0) A[hq_off((l - 1)) + l] = czero();
             if (l >= i) { conv = true; break; }
             ++kdefl; ++sweeps;
             TP(tq2);
             // ---- shift (zlahqr)
             cplx t;
             if (kdefl % 20 == 0) {
-                t = A[i * ld + i]; t.x += 0.75 * cabs1(A[(i - 1) * ld + i]);
+                t = A[hq_off(i) + i]; t.x += 0.75 * cabs1(A[hq_off((i - 1)) + i]);
             } else if (kdefl % 10 == 0) {
-                t = A[l * ld + l]; t.x += 0.75 * cabs1(A[l * ld + l + 1]);
+                t = A[hq_off(l) + l]; t.x += 0.75 * cabs1(A[hq_off(l) + l + 1]);
             } else {
-                t = A[i * ld + i];
-                const cplx u = cmul(csqrt_fast(A[i * ld + i - 1]), csqrt_fast(A[(i - 1) * ld + i]));
+                t = A[hq_off(i) + i];
+                const cplx u = cmul(csqrt_fast(A[hq_off(i) + i - 1]), csqrt_fast(A[hq_off((i - 1)) + i]));
                 double s = cabs1(u);
                 if (s != 0.0) {
-                    const cplx x = cscale(0.5, csub(A[(i - 1) * ld + i - 1], t));
+                    const cplx x = cscale(0.5, csub(A[hq_off((i - 1)) + i - 1], t));
                     const double sx = cabs1(x);
                     s = fmax(s, sx);
                     const double is = rcp_nr(s);
@@ -438,8 +444,8 @@ __global__ __launch_bounds__(128) void k_hess_qr(int k0, int kstep, const cplx* 
             TP(tq3);
             {
                 const int d0 = lw + lane, d1 = d0 + 64;
-                if (d0 <= iw) A[d0 * ld + d0] = csub(A[d0 * ld + d0], t);
-                if (d1 <= iw) A[d1 * ld + d1] = csub(A[d1 * ld + d1], t);
+                if (d0 <= iw) A[hq_off(d0) + d0] = csub(A[hq_off(d0) + d0], t);
+                if (d1 <= iw) A[hq_off(d1) + d1] = csub(A[hq_off(d1) + d1], t);
             }
             ++seq;
             HQ_CBAR();
@@ -469,7 +475,7 @@ __global__ __launch_bounds__(128) void k_hess_qr(int k0, int kstep, const cplx* 
     cplx* wk = rot;
     for (int e = lane; e < k; e += 64) {
         cplx we = czero();
-        if (info == 0) { we = A[e * ld + e]; we = cmake(ldexp(we.x, sexp), ldexp(we.y, sexp)); }
+        if (info == 0) { we = A[hq_off(e) + e]; we = cmake(ldexp(we.x, sexp), ldexp(we.y, sexp)); }
         wk[e] = we; w_out[e] = we;
         if (mirror) mirror[e] = we;
     }
@@ -676,7 +682,7 @@ int32_t nep_hess_eigvals_batch_dev(int32_t nb, int32_t k0, int32_t kstep, const 
         int64_t need = 0; int rcw = nep_hess_eig_worksize(kmax, &need); if (rcw) return rcw;
         ARGCHK(w_stride >= kmax + 2 && work_stride >= need && (work_stride % 16) == 0 && (!h_mirror || mirror_stride >= kmax + 2));
     }
-    const size_t lds = (size_t)16 * kmax * kmax + (size_t)32 * (kmax + 1) + 48;       // matrix, rotations, control block
+    const size_t lds = (size_t)16 * hq_entries(kmax) + (size_t)32 * (kmax + 1) + 48;  // packed matrix, rotations, control block
     if (lds > 65536) { int rc = nep_raise_lds((const void*)k_hess_qr, 163840); if (rc) return rc; }
     cplx* mir = mapped(h_mirror);
     if (h_mirror && !mir) { nep_set_error("nep_hess_eigvals_dev: h_mirror is not mapped pinned host memory"); return NEP_ERR_ARG; }

@@ -176,7 +176,7 @@ def rowmajor_to_cols(QT, cols=None):
     return out
 
 
-HESS_EIG_KMAX = 100
+HESS_EIG_KMAX = 128
 
 
 def hess_eig_worksize(k):

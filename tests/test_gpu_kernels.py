@@ -1162,7 +1162,7 @@ def test_hess_eig_dev_gun_arnoldi_matrix(na, k):
     _hess_eig_check(na, H, 1e-12, 1e-12)
 
 
-@pytest.mark.parametrize("case", ["random", "real", "triangular", "blocks", "defective", "graded", "zero"])
+@pytest.mark.parametrize("case", ["random", "real", "triangular", "blocks", "defective", "graded", "zero", "k128"])
 def test_hess_eig_dev_edge_matrices(na, case):
     """shapes the QR iteration and the inverse iteration have to survive: random complex, real entries (conjugate pairs), an
     already triangular matrix (no sweep at all), zero subdiagonal entries (decoupled blocks), a Jordan-like block (coincident
@@ -1186,6 +1186,9 @@ def test_hess_eig_dev_edge_matrices(na, case):
         A = np.triu(A, -1); eig_tol = 1e-9; res_tol = 1e-12
     elif case == "zero":
         A = np.zeros((k, k), dtype=complex)
+    elif case == "k128":                                                      # the largest size the packed LDS layout takes
+        k = 128
+        A = np.triu(rng.standard_normal((k, k)) + 1j * rng.standard_normal((k, k)), -1)
     if case == "defective":
         import torch
         from nep_amd import dense
@@ -1216,4 +1219,4 @@ def test_hess_eig_dev_reads_the_iar_row_layout(na):
     ref = np.linalg.eigvals(H)
     assert np.abs(np.sort_complex(wh[:k]) - np.sort_complex(ref)).max() <= 1e-11 * np.abs(ref).max()
     with pytest.raises(na.NepError):
-        dense.hess_eig_worksize(101)                                         # LDS-resident limit: the caller keeps LAPACK there
+        dense.hess_eig_worksize(129)                                         # LDS-resident limit: the caller keeps LAPACK there
