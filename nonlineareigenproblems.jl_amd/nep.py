@@ -252,6 +252,61 @@ class NEP:
     def size(self, d=None):
         return (self.n, self.n) if d is None else self.n
 
+    # ---- the reference's generic fallbacks (src/NEPCore.jl:218-270) for NEP types that implement only ONE of the three compute
+    # functions: a user type assigns e.g. `compute_Mlincomb = NEP.compute_Mlincomb_from_MM`, exactly as the reference's
+    # `compute_Mlincomb(nep::MyNEP, lam, V, a) = compute_Mlincomb_from_MM(nep, lam, V, a)`.  The work is done by the type's own
+    # compute_MM / compute_Mder -- on the device when those are (SPMF types; Mder_NEP's rectangular-CSR operator below).
+    def compute_Mlincomb_from_MM(self, lam, V, a=None, startder=0):
+        """NEPCore.jl:218-228: Mlincomb through compute_MM of the bidiagonal S = diag(lam) + subdiag(a_{j+1} / a_j * j); V and a
+        are not modified (the reference's non-`!` form copies them)"""
+        host = not is_dev(V)
+        Vh = np.array(to_host(V) if not host else V, dtype=np.complex128, copy=True)
+        if Vh.ndim == 1:
+            Vh = Vh.reshape(-1, 1)
+        k = Vh.shape[1]
+        a = np.ones(k, dtype=np.complex128) if a is None else np.array(a, dtype=np.complex128, copy=True)
+        if startder > 0:                                   # NEPCore.jl:156-160
+            a = np.concatenate([np.zeros(startder, dtype=np.complex128), a])
+            Vh = np.hstack([np.zeros((Vh.shape[0], startder), dtype=np.complex128), Vh]); k += startder
+        z0 = a == 0
+        Vh[:, z0] = 0
+        a[z0] = 1
+        S = np.diag(np.full(k, complex(lam)))
+        if k > 1:
+            S = S + np.diag((a[1:k] / a[0:k - 1]) * np.arange(1, k), -1)
+        Z = self.compute_MM(S, Vh)
+        z = a[0] * np.asarray(to_host(Z) if is_dev(Z) else Z)[:, 0]
+        return z if host else to_dev(z.reshape(-1, 1))[0]
+
+    def compute_Mlincomb_from_Mder(self, lam, V, a=None):
+        """NEPCore.jl:164-172 ("poor man's" route): sum_i a_i M^(i-1)(lam) v_i with the matrices from compute_Mder"""
+        host = not is_dev(V)
+        Vh = np.asarray(to_host(V) if not host else V, dtype=np.complex128)
+        if Vh.ndim == 1:
+            Vh = Vh.reshape(-1, 1)
+        k = Vh.shape[1]
+        a = np.ones(k, dtype=np.complex128) if a is None else np.asarray(a, dtype=np.complex128)
+        z = torch.zeros(self.n, dtype=CDT, device="cuda")
+        Vd = to_dev(Vh)
+        for i in range(k):
+            if a[i] != 0:
+                DeviceCSR(sp.csr_matrix(self.compute_Mder(lam, i), dtype=np.complex128)).mv(complex(a[i]), Vd[i], 1.0, z, z)
+        return to_host(z.reshape(1, -1))[:, 0] if host else z
+
+    def compute_Mder_from_MM(self, lam, i=0):
+        """NEPCore.jl:258-265: MM of a (transposed) Jordan block yields the derivatives -- S = J^T (x) I_n of size n (i + 1), as in
+        the reference only meant for small problems"""
+        import math
+        n = self.n
+        J = np.diag(np.full(i + 1, complex(lam))) + np.diag(np.ones(i), -1)       # transpose(jordan_matrix(i + 1, lam))
+        S = np.kron(J, np.eye(n))
+        e = np.zeros((1, i + 1)); e[0, 0] = 1.0                                   # sparse(1.0I, 1, i + 1)[:, end:-1:1] has its one at the LAST place
+        e = e[:, ::-1]
+        Vb = math.factorial(i) * np.kron(e, np.eye(n))
+        W = self.compute_MM(S, Vb.astype(np.complex128))
+        W = np.asarray(to_host(W) if is_dev(W) else W)
+        return W[:n, :n]
+
 
 class Mder_NEP(NEP):
     """A NEP known only through a function lam -> M(lam) (and optionally its derivatives i <= maxder): the reference's

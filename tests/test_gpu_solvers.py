@@ -1367,3 +1367,54 @@ def test_iar_reruns_when_a_dgks_pass_is_missing(na):
     assert out["2"]["misses"] == 0 and out["1"]["misses"] == 1
     a = np.array(out["1"]["re"]) + 1j * np.array(out["1"]["im"]); b = np.array(out["2"]["re"]) + 1j * np.array(out["2"]["im"])
     assert len(a) == len(b) >= 1 and np.abs(a - b).max() <= 1e-9 * max(1.0, np.abs(b).max())
+
+
+def test_generic_fallbacks_from_MM_and_from_Mder(na):
+    """src/NEPCore.jl:218-270: a user NEP type that implements only compute_MM (resp. only compute_Mder) gets compute_Mlincomb
+    through compute_Mlincomb_from_MM (resp. _from_Mder) and compute_Mder through compute_Mder_from_MM; checked as test/core.jl:
+    16-32 checks them -- against the type's own compute_Mlincomb / compute_Mder -- on dep0 (dense, n = 5) and a sparse SPMF with
+    the gun functions, with zeros in `a` and with `startder`, for host and device V"""
+    rng = np.random.default_rng(5)
+
+    class OnlyMM(na.NEP):                      # knows nothing but compute_MM (delegated to a full type of this backend)
+        def __init__(self, full):
+            self.full, self.n = full, full.n
+
+        def compute_MM(self, S, V):
+            return self.full.compute_MM(S, V)
+        compute_Mlincomb = na.NEP.compute_Mlincomb_from_MM
+        compute_Mder = na.NEP.compute_Mder_from_MM
+
+    class OnlyMder(na.NEP):
+        def __init__(self, full):
+            self.full, self.n = full, full.n
+
+        def compute_Mder(self, lam, i=0):
+            return self.full.compute_Mder(lam, i)
+        compute_Mlincomb = na.NEP.compute_Mlincomb_from_Mder
+
+    dep = na.nep_gallery("dep0")
+    gun = na.nep_gallery("nlevp_native_gun", 300)
+    for full, lam in ((dep, -0.3 + 0.2j), (gun, 250.0 ** 2 + 40.0j)):
+        n = full.n
+        um, ud = OnlyMM(full), OnlyMder(full)
+        V = rng.standard_normal((n, 4)) + 1j * rng.standard_normal((n, 4))
+        for a in (None, np.array([1.0, -2.0, 0.5, 3.0]), np.array([0.0, 0.0, 1.0, 2.0])):
+            ref = full.compute_Mlincomb(lam, V, a) if a is not None else full.compute_Mlincomb(lam, V)
+            z1 = um.compute_Mlincomb(lam, V, a)
+            z2 = ud.compute_Mlincomb(lam, V, a)
+            sc = np.linalg.norm(ref)
+            assert np.linalg.norm(z1 - ref) <= 1e-9 * sc and np.linalg.norm(z2 - ref) <= 1e-10 * sc
+        # startder: [0, 0, 1] == startder = 2 (test/core.jl:60-70)
+        z3 = um.compute_Mlincomb(lam, V[:, :1], np.ones(1), 2)
+        ref3 = full.compute_Mlincomb(lam, V[:, :1], np.ones(1), 2)
+        assert np.linalg.norm(z3 - ref3) <= 1e-9 * max(np.linalg.norm(ref3), 1e-300)
+        # device V in, device vector out
+        zd = um.compute_Mlincomb(lam, na.to_dev(V))
+        refd = full.compute_Mlincomb(lam, V)
+        assert np.linalg.norm(na.to_host(zd.reshape(1, -1))[:, 0] - refd) <= 1e-9 * np.linalg.norm(refd)
+    # compute_Mder_from_MM (dense, small: S has size n (i + 1))
+    um = OnlyMM(dep)
+    for i in (0, 1, 2):
+        D = um.compute_Mder(-0.3 + 0.2j, i); R = np.asarray(dep.compute_Mder(-0.3 + 0.2j, i))
+        assert np.linalg.norm(D - R) <= 1e-10 * max(np.linalg.norm(R), 1e-300)
