@@ -718,9 +718,8 @@ def main():
                 # HBM bytes of the two kernels from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
                 # scripts/pmc_collect.sh, 2*FETCH + WRITE per the gfx950 note).  The file names the digest of csrc/orth.hip it
                 # was collected on: a kernel change makes `traffic_stale` true instead of going unnoticed.
-                tfile = os.path.join(ROOT, "profiles", "pmc2", "r3_gun_traffic.json")
-                if not os.path.exists(tfile):
-                    tfile = os.path.join(ROOT, "profiles", "pmc2", "r2_gun_traffic.json")
+                tfile = next((f for f in (os.path.join(ROOT, "profiles", "pmc2", "r%d_gun_traffic.json" % r_) for r_ in (4, 3, 2))
+                              if os.path.exists(f)), None)
                 pj = json.load(open(tfile))
                 kb = 0.0
                 for name, d in pj.items():
