@@ -70,6 +70,10 @@ def parse():
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 (waveguide tiar, n = 1e6) summary")
     ap.add_argument("--no-cold", action="store_true", help="skip the fresh-process first-call measurement (about 3 s)")
     ap.add_argument("--no-c5-oracle", action="store_true", help="skip the CPU oracle of the C5 twin (about 40 s)")
+    ap.add_argument("--c5-oracle-full", action="store_true",
+                    help="also run the CPU oracle of C5 at the FULL size by the reference's own route (matrix-free Schur complement + "
+                         "Sylvester-SMW preconditioned GMRES): tens of minutes of host time, one run; the record of the last such run is "
+                         "profiles/r4_c5_oracle_full.json")
     ap.add_argument("--c5-nx", type=int, default=1003)
     ap.add_argument("--c5-nz", type=int, default=999)
     ap.add_argument("--only", default=None, choices=["orth", "k5", "mlincomb", "wepscale", "c5step"],
@@ -343,6 +347,23 @@ def c5_summary(na, args):
                                           "eigenvalues_match_1e-8": bool(ok), "max_rel_eig_diff": worst}
         except Exception as e:
             extra["cpu_baseline_twin"] = {"error": repr(e)[:300]}
+    if args.c5_oracle_full:
+        try:
+            extra["cpu_baseline_full"] = c5_oracle_full_record(bc, args.c5_nx, args.c5_nz, lam)
+        except Exception as e:
+            extra["cpu_baseline_full"] = {"error": repr(e)[:300]}
+    else:       # the committed record of the last full-size oracle run (scripts/c5_oracle_full.py through gpurun), marked as such
+        try:
+            with open(os.path.join(ROOT, "profiles", "r4_c5_oracle_full.json")) as f:
+                rec = json.load(f)
+            if (rec.get("nx"), rec.get("nz")) == (args.c5_nx, args.c5_nz):
+                ok, worst = bc.match(lam, [complex(a, b) for a, b in rec["eigenvalues"]], 1e-8)
+                extra["cpu_baseline_full"] = {**{k_: rec[k_] for k_ in ("kind", "workload", "value", "unit", "eigenpairs", "seconds_solver", "threads", "host")
+                                                 if k_ in rec},
+                                              "measured": "recorded run (profiles/r4_c5_oracle_full.json), not this process; --c5-oracle-full re-measures",
+                                              "this_run_eigenvalues_match_1e-8": bool(ok), "this_run_max_rel_eig_diff": worst}
+        except (OSError, KeyError, ValueError):
+            pass
     return {**extra, "workload": "WEP JARLEBRING nx=%d nz=%d (n=%d) tiar sigma=-3-3.5i maxit=60 tol=1e-8, Schur complement + "
                         "Sylvester-SMW preconditioned GMRES (the reference's solver for this problem; 37 x 41 regions, inner reltol 1e-9, one "
                         "refinement sweep)" % (args.c5_nx, args.c5_nz, info["n"]),
@@ -351,6 +372,32 @@ def c5_summary(na, args):
             "generate_s": info["generate_s"], "preconditioner_setup_s": info.get("preconditioner_setup_s"),
             "phases_s": {k_: round(v_, 4) for k_, v_ in tm.items()},
             "eigenvalues": [[float(l.real), float(l.imag)] for l in lam[:8]]}
+
+
+def c5_oracle_full_record(bc, nx, nz, lam_dev=None, N=37, progress=None):
+    """the CPU oracle of C5 at full size by the reference's route, as a cpu_baseline object (and, given the device run's
+    eigenvalues, SURVEY.md section 8d rules (i)/(iii) at full size)"""
+    import platform
+    try:
+        from threadpoolctl import threadpool_info
+        nthreads = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] + [1])
+    except Exception:
+        nthreads = None
+    lo, Qo, info = bc.c5_oracle_full(nx, nz, N=N, progress=progress)
+    rec = {"kind": "port", "nx": nx, "nz": nz, "n": info["n"],
+           "workload": "the same tiar call (maxit 60, tol 1e-8, same start vector) at nx=%d nz=%d by the reference's own route: matrix-free Schur "
+                       "complement + Sylvester-SMW preconditioner (%d x %d regions) + GMRES(60) reltol 1e-9 + one refinement sweep, oracle/wep_linsolvers.py"
+                       % (nx, nz, N, N + 4),
+           "value": len(lo) / info["seconds_solver"], "unit": "eigenpairs/s", "eigenpairs": int(len(lo)),
+           "seconds_solver": info["seconds_solver"], "preconditioner_setup_s": info["preconditioner_setup_s"], "tiar_s": info["tiar_s"],
+           "generate_s": info["generate_s"], "gmres_iterations_total": int(sum(info["gmres_iterations"])),
+           "gmres_solves": len(info["gmres_iterations"]), "threads": nthreads, "cpus_allowed": len(os.sched_getaffinity(0)),
+           "host": platform.processor() or platform.machine(),
+           "eigenvalues": [[float(l.real), float(l.imag)] for l in lo]}
+    if lam_dev is not None:
+        ok, worst = bc.match(lam_dev, lo, 1e-8)
+        rec.update(same_count=len(lo) == len(lam_dev), **{"eigenvalues_match_1e-8": bool(ok)}, max_rel_eig_diff=worst)
+    return rec
 
 
 def wep_scale_roofline(na):

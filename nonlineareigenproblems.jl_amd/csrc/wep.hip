@@ -23,16 +23,29 @@
 
 struct nep_wep_sylv {
     int nz = 0, nx = 0, N1 = 0, N2 = 0, cols = 4;
+    int ldt = 0, lseg = 0;        // row length / log2(SEG) of the x-fastest blocks below (TLay)
     int32_t* d_in = nullptr;      // nz: input position of (n1, n2)
     int32_t* d_out = nullptr;     // nz: output position of (k1, k2)
     int32_t* d_in_inv = nullptr;  // nz: (n1, n2) slot of input position z (coalesced loads, scattered LDS writes)
     cplx* d_w1 = nullptr;         // N1 roots exp(-2 pi i j / N1)
     cplx* d_w2 = nullptr;         // N2 roots
-    cplx* d_m = nullptr;          // nz x nx (x fastest): forward multipliers m_j = b / dtilde_{j-1}
+    cplx* d_m = nullptr;          // nz x ldt (x fastest, TLay order): forward multipliers m_j = b / dtilde_{j-1}
     cplx* d_dinv = nullptr;       // nz x nx: 1 / dtilde_j
     cplx* d_T = nullptr;          // nz x nx work (x fastest)
     double b = 0.0;
 };
+
+// Layout of the transposed block T (and of the Thomas factors read with it): mode i at T + i * ldt.  The tridiagonal kernel gives every
+// lane SEG = 2^lseg consecutive x; with x stored in order a wave-wide 16-byte load touched 64 different lines (lane stride 16 SEG bytes)
+// and the 16 loads of a lane came back to each line after 3 x 16 KB per wave had passed through the 32 KB L1.  For SEG >= 4 the row is
+// stored in pieces of four x as [piece within the segment][lane][4]: the four x a DFT workgroup writes stay one 64-byte piece, and the
+// tridiagonal kernel's loads are contiguous over the wave (ldt = 64 SEG).  SEG < 4 (nx <= 128): plain order, ldt = nx.
+struct TLay { int ldt, lseg; };
+__device__ __forceinline__ int tpos(int x, const TLay tl) {
+    if (tl.lseg < 2) return x;
+    const int seg_mask = (1 << tl.lseg) - 1;
+    return (((x & seg_mask) >> 2) << 8) + ((x >> tl.lseg) << 2) + (x & 3);
+}
 
 // workgroup -> column group, XCD-contiguous (workgroup id % 8 = XCD): the groups an XCD works on at one time are neighbours in x, so
 // the 64-byte pieces they write to (read from) one mode row of the transposed block are neighbours too -- its L2 sees 2 KB runs per
@@ -51,7 +64,7 @@ template <bool FWD, int COLS>
 __global__ __launch_bounds__(1024) void k_dft_cols(int nz, int nx, int N1, int N2, const int32_t* __restrict__ in_idx,
                                                    const int32_t* __restrict__ out_idx, const cplx* __restrict__ w1,
                                                    const cplx* __restrict__ w2, double sgn, double scale,
-                                                   const cplx* __restrict__ src, cplx* __restrict__ dst, int xcd_order) {
+                                                   const cplx* __restrict__ src, cplx* __restrict__ dst, int xcd_order, TLay tl) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* xs = (cplx*)smem_raw;                 // [q][COLS], natural (n1, n2) order q = n1 N2 + n2
     cplx* ts = xs + (size_t)COLS * nz;          // [q][COLS], q = k1 N2 + n2
@@ -71,7 +84,7 @@ __global__ __launch_bounds__(1024) void k_dft_cols(int nz, int nx, int N1, int N
     } else {
         for (int t = threadIdx.x; t < COLS * nz; t += nt) {      // consecutive threads -> consecutive x of one mode
             const int q = t / COLS, c = t - q * COLS;
-            xs[t] = c < nc ? src[(int64_t)in_idx[q] * nx + (x0 + c)] : cmake(0.0, 0.0);
+            xs[t] = c < nc ? src[(int64_t)in_idx[q] * tl.ldt + tpos(x0 + c, tl)] : cmake(0.0, 0.0);
         }
     }
     __syncthreads();
@@ -113,7 +126,7 @@ __global__ __launch_bounds__(1024) void k_dft_cols(int nz, int nx, int N1, int N
         for (int c = 0; c < COLS; ++c)
             if (c < nc) {
                 const cplx v = cmake(scale * acc[c].x, scale * acc[c].y);
-                if (FWD) dst[(int64_t)o * nx + (x0 + c)] = v;          // COLS consecutive x of one mode: COLS * 16 bytes
+                if (FWD) dst[(int64_t)o * tl.ldt + tpos(x0 + c, tl)] = v;          // COLS consecutive x of one mode: COLS * 16 bytes
                 else dst[(int64_t)(x0 + c) * nz + o] = v;
             }
     }
@@ -140,7 +153,7 @@ __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int
                                                       const int32_t* __restrict__ in_inv,
                                                       const int32_t* __restrict__ out_idx, const cplx* __restrict__ w1,
                                                       const cplx* __restrict__ w2, double sgn, double scale,
-                                                      const cplx* __restrict__ src, cplx* __restrict__ dst, int xcd_order) {
+                                                      const cplx* __restrict__ src, cplx* __restrict__ dst, int xcd_order, TLay tl) {
     constexpr int COLS = 4, KB = 3;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* xs = (cplx*)smem_raw;                 // [q][COLS], q = n1 N2 + n2
@@ -183,7 +196,7 @@ __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int
                 const int tc = live[u] ? tt : t;
                 const int q = tc / COLS, c = tc - q * COLS;
                 on[u] = c < nc;
-                v[u] = src[(int64_t)in_idx[q] * nx + (x0 + (on[u] ? c : 0))];
+                v[u] = src[(int64_t)in_idx[q] * tl.ldt + tpos(x0 + (on[u] ? c : 0), tl)];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) if (live[u]) xs[t + u * nt] = on[u] ? v[u] : cmake(0.0, 0.0);
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int
                 if (FWD) {
 #pragma unroll
                     for (int c = 0; c < COLS; ++c)
-                        if (c < nc) dst[(int64_t)o * nx + (x0 + c)] = cmake(scale * acc[b][c].x, scale * acc[b][c].y);
+                        if (c < nc) dst[(int64_t)o * tl.ldt + tpos(x0 + c, tl)] = cmake(scale * acc[b][c].x, scale * acc[b][c].y);
                 } else {
                     // (staging the result in LDS for a coalesced store was measured: 35.3 us against 33.5 us for this direct store)
 #pragma unroll
@@ -278,6 +291,209 @@ __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int
 #endif
 }
 
+// ---- the two dense stages by the symmetry of the roots (N1, N2 odd) --------------------------------------------------------------
+// For odd N the roots pair up: w^(n k) and w^((N-n) k) are conjugates, and so are w^(n k) and w^(n (N-k)).  With
+//   s_n = x_n + x_(N-n),  d_n = x_n - x_(N-n)   (n = 1 .. H, H = (N-1)/2),
+//   A_k = x_0 + sum_n cos(2 pi n k / N) s_n,     B_k = sum_n sin(2 pi n k / N) d_n       (REAL coefficients, complex data)
+// the outputs are X_k = A_k - i sgn B_k and X_(N-k) = A_k + i sgn B_k (exponent -i sgn theta) and X_0 = x_0 + sum_n s_n:
+// H^2 real-by-complex pairs (4 FMA) make 2 H outputs where the plain dense stage spends N^2 complex multiply-adds (4 FMA each) on
+// N -- 3.9x fewer flops at N = 37 and 27, the same two stages, index maps and stores otherwise.  One LDS buffer: stage 1 keeps its
+// results in registers across a barrier and overwrites its input (every work item is in flight at once: the launch sizes the
+// workgroup to the number of items), which also leaves room for a second workgroup per CU.  Layout [column][q]: consecutive lanes
+// (consecutive n2 / k1) read consecutive 16-byte words.  A thread owns KB values of k (both members of each pair) of one n2 / k1.
+// dft_sym_stages: both stages on xs ([c][q], q = n1 N2 + n2, overwritten), roots c1 / c2 as (cos, sin)(2 pi e / N); the result
+// X[k1, k2] of column c is handed to put(out_idx[k1 N2 + k2], c, re, im).  blockDim.x >= max(G1 N2, G2 N1) items.
+template <int COLS, int KB, class Put>
+__device__ __forceinline__ void dft_sym_stages(cplx* __restrict__ xs, const cplx* __restrict__ c1, const cplx* __restrict__ c2, int nz,
+                                               int N1, int N2, double sgn, const int32_t* __restrict__ out_idx, Put put) {
+    cplx A[KB][COLS], B[KB][COLS], S0[COLS];
+    int kk[KB], e[KB];
+    // ---- stage 1 (over n1, for one n2): item = (g, n2), k1 = 1 + g + b G1
+    const int H1 = (N1 - 1) / 2, G1 = (H1 + KB - 1) / KB;
+    const int t1 = threadIdx.x;
+    const bool act1 = t1 < G1 * N2;
+    const int g1 = act1 ? t1 / N2 : 0, n2 = act1 ? t1 - g1 * N2 : 0;
+    if (act1) {
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) S0[c] = xs[(size_t)c * nz + n2];
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            kk[b] = 1 + g1 + b * G1; if (kk[b] > H1) kk[b] = 0;
+            e[b] = kk[b];
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) { A[b][c] = S0[c]; B[b][c] = cmake(0.0, 0.0); }
+        }
+        for (int n = 1; n <= H1; ++n) {
+            const cplx* pa = xs + n * N2 + n2;
+            const cplx* pb = xs + (N1 - n) * N2 + n2;
+            cplx sv[COLS], dv[COLS];
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) {
+                const cplx xa = pa[(size_t)c * nz], xb = pb[(size_t)c * nz];
+                sv[c] = cadd(xa, xb); dv[c] = csub(xa, xb);
+                S0[c] = cadd(S0[c], sv[c]);
+            }
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                const cplx w = c1[e[b]];
+#pragma unroll
+                for (int c = 0; c < COLS; ++c) {
+                    A[b][c].x = fma(w.x, sv[c].x, A[b][c].x); A[b][c].y = fma(w.x, sv[c].y, A[b][c].y);
+                    B[b][c].x = fma(w.y, dv[c].x, B[b][c].x); B[b][c].y = fma(w.y, dv[c].y, B[b][c].y);
+                }
+                e[b] += kk[b]; if (e[b] >= N1) e[b] -= N1;
+            }
+        }
+    }
+    __syncthreads();                                   // every input has been read: the results go where the inputs were
+    if (act1) {
+        if (g1 == 0) {
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) xs[(size_t)c * nz + n2] = S0[c];
+        }
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+            if (kk[b]) {
+#pragma unroll
+                for (int c = 0; c < COLS; ++c) {
+                    const double bx = sgn * B[b][c].y, by = -sgn * B[b][c].x;          // -i sgn B
+                    xs[(size_t)c * nz + kk[b] * N2 + n2] = cmake(A[b][c].x + bx, A[b][c].y + by);
+                    xs[(size_t)c * nz + (N1 - kk[b]) * N2 + n2] = cmake(A[b][c].x - bx, A[b][c].y - by);
+                }
+            }
+    }
+    __syncthreads();
+    // ---- stage 2 (over n2, for one k1): item = (g, k1), k2 = 1 + g + b G2
+    const int H2 = (N2 - 1) / 2, G2 = (H2 + KB - 1) / KB;
+    const int t2 = threadIdx.x;
+    if (t2 < G2 * N1) {
+        const int g2 = t2 / N1, k1 = t2 - g2 * N1;
+        const cplx* row = xs + k1 * N2;
+        int oa[KB], ob[KB];
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+            kk[b] = 1 + g2 + b * G2; if (kk[b] > H2) kk[b] = 0;
+            e[b] = kk[b];
+            oa[b] = out_idx[k1 * N2 + kk[b]]; ob[b] = out_idx[k1 * N2 + (kk[b] ? N2 - kk[b] : 0)];
+        }
+        const int o0 = out_idx[k1 * N2];
+#pragma unroll
+        for (int c = 0; c < COLS; ++c) S0[c] = row[(size_t)c * nz];
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) { A[b][c] = S0[c]; B[b][c] = cmake(0.0, 0.0); }
+        for (int n = 1; n <= H2; ++n) {
+            const cplx* pa = row + n;
+            const cplx* pb = row + (N2 - n);
+            cplx sv[COLS], dv[COLS];
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) {
+                const cplx xa = pa[(size_t)c * nz], xb = pb[(size_t)c * nz];
+                sv[c] = cadd(xa, xb); dv[c] = csub(xa, xb);
+                S0[c] = cadd(S0[c], sv[c]);
+            }
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                const cplx w = c2[e[b]];
+#pragma unroll
+                for (int c = 0; c < COLS; ++c) {
+                    A[b][c].x = fma(w.x, sv[c].x, A[b][c].x); A[b][c].y = fma(w.x, sv[c].y, A[b][c].y);
+                    B[b][c].x = fma(w.y, dv[c].x, B[b][c].x); B[b][c].y = fma(w.y, dv[c].y, B[b][c].y);
+                }
+                e[b] += kk[b]; if (e[b] >= N2) e[b] -= N2;
+            }
+        }
+        if (g2 == 0) {
+#pragma unroll
+            for (int c = 0; c < COLS; ++c) put(o0, c, S0[c].x, S0[c].y);
+        }
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+            if (kk[b]) {
+#pragma unroll
+                for (int c = 0; c < COLS; ++c) {
+                    const double bx = sgn * B[b][c].y, by = -sgn * B[b][c].x;
+                    put(oa[b], c, A[b][c].x + bx, A[b][c].y + by);
+                }
+#pragma unroll
+                for (int c = 0; c < COLS; ++c) {
+                    const double bx = sgn * B[b][c].y, by = -sgn * B[b][c].x;
+                    put(ob[b], c, A[b][c].x - bx, A[b][c].y - by);
+                }
+            }
+    }
+}
+
+template <bool FWD, int COLS, int KB>
+__global__ __launch_bounds__(512) void k_dft_cols_sym(int nz, int nx, int N1, int N2, const int32_t* __restrict__ in_idx,
+                                                       const int32_t* __restrict__ in_inv, const int32_t* __restrict__ out_idx,
+                                                       const cplx* __restrict__ w1, const cplx* __restrict__ w2, double sgn,
+                                                       double scale, const cplx* __restrict__ src, cplx* __restrict__ dst,
+                                                       int xcd_order, TLay tl) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* xs = (cplx*)smem_raw;                 // [c][q], q = n1 N2 + n2, then q = k1 N2 + n2
+    cplx* c1 = xs + (size_t)COLS * nz;          // (cos, sin)(2 pi e / N1)
+    cplx* c2 = c1 + N1;
+    WP(tp0);
+    const int x0 = dft_group(xcd_order) * COLS;
+    const int nc = min(COLS, nx - x0);
+    const int nt = blockDim.x;
+    for (int t = threadIdx.x; t < N1; t += nt) c1[t] = cmake(w1[t].x, -w1[t].y);
+    for (int t = threadIdx.x; t < N2; t += nt) c2[t] = cmake(w2[t].x, -w2[t].y);
+    if (FWD) {
+        for (int t = threadIdx.x; t < COLS * nz; t += 4 * nt) {
+            int slot[4]; cplx v[4]; bool on[4], live[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = t + u * nt;
+                live[u] = tt < COLS * nz;
+                const int tc = live[u] ? tt : t;
+                const int c = tc / nz, z = tc - c * nz;
+                on[u] = c < nc;
+                slot[u] = c * nz + in_inv[z];
+                v[u] = src[(int64_t)(x0 + (on[u] ? c : 0)) * nz + z];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (live[u]) xs[slot[u]] = on[u] ? v[u] : cmake(0.0, 0.0);
+        }
+    } else {
+        for (int t = threadIdx.x; t < COLS * nz; t += 4 * nt) {
+            int slot[4]; cplx v[4]; bool on[4], live[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int tt = t + u * nt;
+                live[u] = tt < COLS * nz;
+                const int tc = live[u] ? tt : t;
+                const int q = tc / COLS, c = tc - q * COLS;
+                on[u] = c < nc;
+                slot[u] = c * nz + q;
+                v[u] = src[(int64_t)in_idx[q] * tl.ldt + tpos(x0 + (on[u] ? c : 0), tl)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (live[u]) xs[slot[u]] = on[u] ? v[u] : cmake(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+    WP(tp1);
+    dft_sym_stages<COLS, KB>(xs, c1, c2, nz, N1, N2, sgn, out_idx, [&](int o, int c, double re, double im) {
+        if (c < nc) {
+            if (FWD) dst[(int64_t)o * tl.ldt + tpos(x0 + c, tl)] = cmake(scale * re, scale * im);
+            else dst[(int64_t)(x0 + c) * nz + o] = cmake(scale * re, scale * im);
+        }
+    });
+#ifdef WEP_PROF
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long tp3 = clock64();
+        const int o = FWD ? 0 : 8;
+        atomicAdd(&g_dft_prof[o + 0], (unsigned long long)(tp1 - tp0)); atomicAdd(&g_dft_prof[o + 1], (unsigned long long)(tp3 - tp1));
+        atomicAdd(&g_dft_prof[o + 3], 1ull);
+        atomicMax(&g_dft_prof[o + 4], (unsigned long long)(tp3 - tp0));
+    }
+#endif
+}
+
 // (Round 4: the same two stages were also written for the FP64 matrix cores -- complex products as four v_mfma_f64_16x16x4_f64 on
 // the halves of one 16-byte LDS read, results of stage 1 kept in registers across a barrier so that ONE 64 KB buffer serves
 // four columns -- correct against the NumPy reference, and exactly as fast: 28 / 30 us per transform against 28 / 30.  A
@@ -291,21 +507,21 @@ __global__ __launch_bounds__(384) void k_dft_cols_rb(int nz, int nx, int N1, int
 
 // ---- Thomas pivots of (d_i I + B), one thread per mode (one-off per shift) -------------------------------------------------------
 __global__ void k_tridiag_factor(int nz, int nx, const cplx* __restrict__ d, double b, cplx* __restrict__ mfac,
-                                 cplx* __restrict__ dinv) {
+                                 cplx* __restrict__ dinv, TLay tl) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nz) return;
     const cplx a = cmake(d[i].x - 2.0 * b, d[i].y);
     cplx piv = a;
     auto inv = [](cplx z) { const double s = 1.0 / (z.x * z.x + z.y * z.y); return cmake(z.x * s, -z.y * s); };
     cplx pinv = inv(piv);
-    mfac[(int64_t)i * nx] = cmake(0.0, 0.0);
-    dinv[(int64_t)i * nx] = pinv;
+    mfac[(int64_t)i * tl.ldt] = cmake(0.0, 0.0);
+    dinv[(int64_t)i * tl.ldt] = pinv;
     for (int j = 1; j < nx; ++j) {
         const cplx m = cmake(b * pinv.x, b * pinv.y);            // m_j = b / dtilde_{j-1}
         piv = cmake(a.x - b * m.x, a.y - b * m.y);               // dtilde_j = a - b m_j
         pinv = inv(piv);
-        mfac[(int64_t)i * nx + j] = m;
-        dinv[(int64_t)i * nx + j] = pinv;
+        mfac[(int64_t)i * tl.ldt + tpos(j, tl)] = m;
+        dinv[(int64_t)i * tl.ldt + tpos(j, tl)] = pinv;
     }
 }
 
@@ -325,7 +541,7 @@ __global__ __launch_bounds__(256) void k_tridiag_modes(int nz, int nx, const cpl
     const int lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= nz) return;
-    const int64_t base = (int64_t)i * nx;
+    const int64_t base = (int64_t)i * (SEG >= 4 ? 64 * SEG : nx);
     const int j0 = lane * SEG;
     cplx c[SEG], al[SEG];           // c: right-hand side, then y, then h;  al: forward multipliers, then g
     // (unconditional loads with a clamped index, masked afterwards: behind a per-entry `if (j < nx)` the 2 x SEG loads of a lane sat in
@@ -333,7 +549,9 @@ __global__ __launch_bounds__(256) void k_tridiag_modes(int nz, int nx, const cpl
     cplx dv[SEG];                   // dinv of the segment, fetched with the other two arrays (used by the backward sweep)
 #pragma unroll
     for (int t = 0; t < SEG; ++t) {
-        const int j = j0 + t < nx ? j0 + t : nx - 1;
+        // SEG >= 4: entry lane * SEG + t sits at (t / 4) * 256 + lane * 4 + t % 4 of a row of 64 SEG entries (TLay); entries beyond nx are
+        // allocated padding, read and then masked
+        const int j = SEG >= 4 ? ((t >> 2) << 8) + (lane << 2) + (t & 3) : (j0 + t < nx ? j0 + t : nx - 1);
         c[t] = T[base + j]; al[t] = mfac[base + j]; dv[t] = dinv[base + j];
     }
 #pragma unroll
@@ -379,7 +597,7 @@ __global__ __launch_bounds__(256) void k_tridiag_modes(int nz, int nx, const cpl
     for (int t = SEG - 1; t >= 0; --t) {
         cplx v = c[t]; cfma(v, al[t], carryb); carryb = v;
         const int j = j0 + t;
-        if (j < nx) T[base + j] = v;
+        if (j < nx) T[base + (SEG >= 4 ? ((t >> 2) << 8) + (lane << 2) + (t & 3) : j)] = v;
     }
 }
 
@@ -476,6 +694,36 @@ __global__ __launch_bounds__(1024) void k_wep_pinv(int nz, int N1, int N2, const
     }
 }
 
+// k_wep_pinv with the symmetric-half stages (N1, N2 odd): the plain form above is bound by the LDS bandwidth of its one CU per half
+// (two 16-byte reads per complex multiply-add, 13.6 us of reads at 999 points); this one reads 12 bytes per product of the plain form
+__global__ __launch_bounds__(512) void k_wep_pinv_sym(int nz, int N1, int N2, const int32_t* __restrict__ in_idx,
+                                                      const int32_t* __restrict__ out_idx, const cplx* __restrict__ w1,
+                                                      const cplx* __restrict__ w2, const cplx* __restrict__ bb,
+                                                      const cplx* __restrict__ sinv, const cplx* __restrict__ x, cplx* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    cplx* a = (cplx*)smem_raw;        // nz: stage buffer
+    cplx* v = a + nz;                 // nz: result of pass 0, natural order
+    cplx* c1 = v + nz; cplx* c2 = c1 + N1;
+    const int half = blockIdx.x;
+    const cplx* xh = x + (int64_t)half * nz;
+    const cplx* sh = sinv + (int64_t)half * nz;
+    cplx* oh = out + (int64_t)half * nz;
+    const int nt = blockDim.x;
+    for (int q = threadIdx.x; q < N1; q += nt) c1[q] = cmake(w1[q].x, -w1[q].y);
+    for (int q = threadIdx.x; q < N2; q += nt) c2[q] = cmake(w2[q].x, -w2[q].y);
+    for (int q = threadIdx.x; q < nz; q += nt) {
+        const int m = in_idx[q];
+        const cplx b = bb[m];
+        a[q] = cmul(cmake(b.x, -b.y), xh[nz - 1 - m]);
+    }
+    __syncthreads();
+    dft_sym_stages<1, 1>(a, c1, c2, nz, N1, N2, -1.0, out_idx, [&](int k, int, double re, double im) { v[k] = cmul(cmake(re, im), sh[k]); });
+    __syncthreads();
+    for (int q = threadIdx.x; q < nz; q += nt) a[q] = v[in_idx[q]];
+    __syncthreads();
+    dft_sym_stages<1, 1>(a, c1, c2, nz, N1, N2, 1.0, out_idx, [&](int k, int, double re, double im) { oh[nz - 1 - k] = cmul(bb[k], cmake(re, im)); });
+}
+
 static int egcd_inv(int a, int m) {            // a^{-1} mod m (gcd = 1)
     int t = 0, nt = 1, r = m, nr = a % m;
     while (nr) { const int q = r / nr; int tmp = t - q * nt; t = nt; nt = tmp; tmp = r - q * nr; r = nr; nr = tmp; }
@@ -520,14 +768,20 @@ int32_t nep_wep_sylv_create(int32_t nz, int32_t nx, const nep_cdouble* h_d, doub
     std::vector<nep_cdouble> w1(N1), w2(N2);
     for (int j = 0; j < N1; ++j) { const double th = -2.0 * M_PI * j / N1; w1[j].re = cos(th); w1[j].im = sin(th); }
     for (int j = 0; j < N2; ++j) { const double th = -2.0 * M_PI * j / N2; w2[j].re = cos(th); w2[j].im = sin(th); }
+    {   // SEG of k_tridiag_modes (nep_wep_sylv_solve): the smallest power of two with 64 SEG >= nx
+        int seg = 1, lseg = 0;
+        while (64 * seg < nx) { seg <<= 1; ++lseg; }
+        s->lseg = lseg; s->ldt = seg >= 4 ? 64 * seg : nx;
+    }
+    const size_t ldt = (size_t)s->ldt;
     int rc = nep_pool_alloc((void**)&s->d_in, (size_t)nz * 4);
     if (!rc) rc = nep_pool_alloc((void**)&s->d_out, (size_t)nz * 4);
     if (!rc) rc = nep_pool_alloc((void**)&s->d_in_inv, (size_t)nz * 4);
     if (!rc) rc = nep_pool_alloc((void**)&s->d_w1, (size_t)N1 * 16);
     if (!rc) rc = nep_pool_alloc((void**)&s->d_w2, (size_t)N2 * 16);
-    if (!rc) rc = nep_pool_alloc((void**)&s->d_m, (size_t)nz * nx * 16);
-    if (!rc) rc = nep_pool_alloc((void**)&s->d_dinv, (size_t)nz * nx * 16);
-    if (!rc) rc = nep_pool_alloc((void**)&s->d_T, (size_t)nz * nx * 16);
+    if (!rc) rc = nep_pool_alloc((void**)&s->d_m, (size_t)nz * ldt * 16);
+    if (!rc) rc = nep_pool_alloc((void**)&s->d_dinv, (size_t)nz * ldt * 16);
+    if (!rc) rc = nep_pool_alloc((void**)&s->d_T, (size_t)nz * ldt * 16);
     cplx* d_d = nullptr;
     if (!rc) rc = nep_pool_alloc((void**)&d_d, (size_t)nz * 16);
     if (rc) { nep_wep_sylv_destroy(s); return rc; }
@@ -540,7 +794,7 @@ int32_t nep_wep_sylv_create(int32_t nz, int32_t nx, const nep_cdouble* h_d, doub
     if (e == hipSuccess) e = hipMemcpy(s->d_w2, w2.data(), (size_t)N2 * 16, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(d_d, h_d, (size_t)nz * 16, hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        hipLaunchKernelGGL(k_tridiag_factor, dim3((nz + 63) / 64), dim3(64), 0, nullptr, (int)nz, (int)nx, (const cplx*)d_d, b, s->d_m, s->d_dinv);
+        hipLaunchKernelGGL(k_tridiag_factor, dim3((nz + 63) / 64), dim3(64), 0, nullptr, (int)nz, (int)nx, (const cplx*)d_d, b, s->d_m, s->d_dinv, TLay{s->ldt, s->lseg});
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();
     }
@@ -602,6 +856,17 @@ int32_t nep_wep_pinv_apply(nep_wep_pinv* p, const nep_cdouble* d_sinv, const nep
     ARGCHK(p && d_sinv && dX && dOut);
     static thread_local bool attr_set = false;
     if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_wep_pinv, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
+    static const bool sym_on = !(getenv("NEP_WEP_PINV_SYM") && atoi(getenv("NEP_WEP_PINV_SYM")) == 0);
+    if (sym_on && (p->N1 & 1) && (p->N2 & 1) && p->N1 >= 3 && p->N2 >= 3) {
+        const int items = std::max((p->N1 - 1) / 2 * p->N2, (p->N2 - 1) / 2 * p->N1);
+        if (items <= 512) {
+            hipLaunchKernelGGL(k_wep_pinv_sym, dim3(2), dim3((items + 63) / 64 * 64), ((size_t)2 * p->nz + p->N1 + p->N2) * sizeof(cplx),
+                               as_stream(stream), p->nz, p->N1, p->N2, (const int32_t*)p->d_in, (const int32_t*)p->d_out, (const cplx*)p->d_w1,
+                               (const cplx*)p->d_w2, (const cplx*)p->d_bb, (const cplx*)d_sinv, (const cplx*)dX, (cplx*)dOut);
+            LAUNCHCHK();
+            return NEP_OK;
+        }
+    }
     const size_t shm = ((size_t)3 * p->nz + p->N1 + p->N2) * sizeof(cplx);
     const int threads = p->nz >= 768 ? 1024 : (p->nz >= 256 ? 512 : 256);
     hipLaunchKernelGGL(k_wep_pinv, dim3(2), dim3(threads), shm, as_stream(stream), p->nz, p->N1, p->N2, (const int32_t*)p->d_in,
@@ -633,21 +898,53 @@ int32_t nep_wep_sylv_solve(nep_wep_sylv* s, nep_cdouble* dX, nep_stream stream) 
         attr_set = true;
     }
     const double scale = 1.0 / sqrt((double)nz);
+    const TLay tl{s->ldt, s->lseg};
     const dim3 grid((unsigned)((nx + s->cols - 1) / s->cols));
     const int threads = nz >= 768 ? 1024 : (nz >= 384 ? 512 : 256);
 #define DFT_LAUNCH(F_, C_, SGN_, SRC_, DST_)                                                                               \
     hipLaunchKernelGGL((k_dft_cols<F_, C_>), grid, dim3(threads), shm, st, nz, nx, s->N1, s->N2, (const int32_t*)s->d_in,    \
-                       (const int32_t*)s->d_out, (const cplx*)s->d_w1, (const cplx*)s->d_w2, SGN_, scale, SRC_, DST_, xcd_order)
+                       (const int32_t*)s->d_out, (const cplx*)s->d_w1, (const cplx*)s->d_w2, SGN_, scale, SRC_, DST_, xcd_order, tl)
     static const int xcd_order = getenv("NEP_WEP_DFT_XCD") ? atoi(getenv("NEP_WEP_DFT_XCD")) : 1;
     static const int rb = getenv("NEP_WEP_DFT_RB") ? atoi(getenv("NEP_WEP_DFT_RB")) : 1;
 #define DFT_BY_COLS(F_, SGN_, SRC_, DST_)                                                                                  \
     do { if (s->cols == 4 && rb)                                                                                            \
              hipLaunchKernelGGL((k_dft_cols_rb<F_>), grid, dim3(384), shm, st, nz, nx, s->N1, s->N2, (const int32_t*)s->d_in, \
-                                (const int32_t*)s->d_in_inv, (const int32_t*)s->d_out, (const cplx*)s->d_w1, (const cplx*)s->d_w2, SGN_, scale, SRC_, DST_, xcd_order); \
+                                (const int32_t*)s->d_in_inv, (const int32_t*)s->d_out, (const cplx*)s->d_w1, (const cplx*)s->d_w2, SGN_, scale, SRC_, DST_, xcd_order, tl); \
          else if (s->cols == 4) DFT_LAUNCH(F_, 4, SGN_, SRC_, DST_); else if (s->cols == 2) DFT_LAUNCH(F_, 2, SGN_, SRC_, DST_);  \
          else DFT_LAUNCH(F_, 1, SGN_, SRC_, DST_); } while (0)
+    // symmetric-half form of the two dense stages (odd N1, N2): NEP_WEP_DFT_SYM = "cols*10 + kb" (42, 43, 22, 23) or 0 = off
+    static const int symcfg = getenv("NEP_WEP_DFT_SYM") ? atoi(getenv("NEP_WEP_DFT_SYM")) : 42;
+    int sym_cols = symcfg / 10, sym_kb = symcfg % 10, sym_threads = 0;
+    if (symcfg && (s->N1 & 1) && (s->N2 & 1) && s->N1 >= 3 && s->N2 >= 3 && (sym_cols == 2 || sym_cols == 4) && (sym_kb == 2 || sym_kb == 3)) {
+        const int H1 = (s->N1 - 1) / 2, H2 = (s->N2 - 1) / 2;
+        const int items = std::max(((H1 + sym_kb - 1) / sym_kb) * s->N2, ((H2 + sym_kb - 1) / sym_kb) * s->N1);
+        sym_threads = (items + 63) / 64 * 64;
+        if (sym_threads > 512 || ((size_t)sym_cols * nz + s->N1 + s->N2) * sizeof(cplx) > 150 * 1024) sym_threads = 0;
+    }
+    if (sym_threads) {
+        static thread_local bool sym_attr = false;
+        if (!sym_attr) {
+#define SYM_ATTR(F_, C_, K_) HIPCHK(hipFuncSetAttribute((const void*)k_dft_cols_sym<F_, C_, K_>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024))
+            SYM_ATTR(true, 4, 2); SYM_ATTR(false, 4, 2); SYM_ATTR(true, 4, 3); SYM_ATTR(false, 4, 3);
+            SYM_ATTR(true, 2, 2); SYM_ATTR(false, 2, 2); SYM_ATTR(true, 2, 3); SYM_ATTR(false, 2, 3);
+#undef SYM_ATTR
+            sym_attr = true;
+        }
+    }
+    const size_t sym_shm = ((size_t)sym_cols * nz + s->N1 + s->N2) * sizeof(cplx);
+    const dim3 sym_grid((unsigned)((nx + std::max(sym_cols, 1) - 1) / std::max(sym_cols, 1)));
+#define SYM_LAUNCH(F_, C_, K_, SGN_, SRC_, DST_)                                                                             \
+    hipLaunchKernelGGL((k_dft_cols_sym<F_, C_, K_>), sym_grid, dim3(sym_threads), sym_shm, st, nz, nx, s->N1, s->N2,          \
+                       (const int32_t*)s->d_in, (const int32_t*)s->d_in_inv, (const int32_t*)s->d_out, (const cplx*)s->d_w1,  \
+                       (const cplx*)s->d_w2, SGN_, scale, SRC_, DST_, xcd_order, tl)
+#define DFT_SYM(F_, SGN_, SRC_, DST_)                                                                                        \
+    do { if (sym_cols == 4 && sym_kb == 2) SYM_LAUNCH(F_, 4, 2, SGN_, SRC_, DST_);                                            \
+         else if (sym_cols == 4) SYM_LAUNCH(F_, 4, 3, SGN_, SRC_, DST_);                                                      \
+         else if (sym_kb == 2) SYM_LAUNCH(F_, 2, 2, SGN_, SRC_, DST_);                                                        \
+         else SYM_LAUNCH(F_, 2, 3, SGN_, SRC_, DST_); } while (0)
     // F^H X : exponent +, result transposed into T
-    DFT_BY_COLS(true, -1.0, (const cplx*)dX, s->d_T);
+    if (sym_threads) DFT_SYM(true, -1.0, (const cplx*)dX, s->d_T);
+    else DFT_BY_COLS(true, -1.0, (const cplx*)dX, s->d_T);
     LAUNCHCHK();
     const int seg = (nx + 63) / 64;
     const dim3 g2((unsigned)((nz + 3) / 4));
@@ -656,8 +953,11 @@ int32_t nep_wep_sylv_solve(nep_wep_sylv* s, nep_cdouble* dX, nep_stream stream) 
 #undef TRI
     LAUNCHCHK();
     // F T : exponent -, back to z fastest
-    DFT_BY_COLS(false, 1.0, (const cplx*)s->d_T, (cplx*)dX);
+    if (sym_threads) DFT_SYM(false, 1.0, (const cplx*)s->d_T, (cplx*)dX);
+    else DFT_BY_COLS(false, 1.0, (const cplx*)s->d_T, (cplx*)dX);
     LAUNCHCHK();
+#undef DFT_SYM
+#undef SYM_LAUNCH
 #undef DFT_BY_COLS
 #undef DFT_LAUNCH
     return NEP_OK;

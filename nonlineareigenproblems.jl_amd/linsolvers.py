@@ -895,6 +895,9 @@ class LinSolverCache:
         return self._get(sigma, add_to_cache).solve_dev(y, out=out, scale=scale)
 
 
+_GMRES_TRUE_RESIDUAL = bool(os.environ.get("NEP_GMRES_TRUE_RESIDUAL"))     # A/B: re-evaluate the residual after a converged cycle
+
+
 class GMRESLinSolver(LinSolver):
     """src/LinSolvers.jl:171-188: matrix-free restarted GMRES on v -> compute_Mlincomb(nep, lam, v), i.e. every
     iteration is one K1 call (folded single-vector SpMV) + one K6 orthogonalisation (IterativeSolvers' default
@@ -1023,6 +1026,11 @@ class GMRESLinSolver(LinSolver):
             y = np.linalg.solve(np.triu(H[:j_done, :j_done]), g[:j_done])
             dx = dense.gemm_ts(V, y.reshape(-1, 1), k=j_done, rows=n, ldz=n)          # (1, n)
             dense.axpy(1.0, dx, x, n)
+            if abs(g[j_done]) <= tolabs and not _GMRES_TRUE_RESIDUAL:
+                # converged by the recurrence's residual norm: IterativeSolvers.gmres leaves here too (it evaluates the true
+                # residual only when it restarts), which saves one operator + preconditioner application per solve
+                beta = abs(g[j_done])
+                break
             # true (preconditioned) residual for the restart
             dense.copy(self.nep.compute_Mlincomb(self.lam, x.reshape(1, n)), r, n)
             dense.scal(r, -1.0, n); dense.axpy(1.0, bvec, r, n); self._prec(r)

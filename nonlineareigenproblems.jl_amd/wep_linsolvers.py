@@ -144,9 +144,9 @@ class _SchurSolve:
         self.q = torch.empty(ops.N, dtype=CDT, device="cuda")
         self.tmp = torch.empty(ops.n, dtype=CDT, device="cuda")
 
-    def _one(self, b, out, tol=None):
+    def _one(self, b, out, tol=None, sweep=False):
         self.ops.eliminate(b, self.rhs)
-        self.inner(self.rhs, self.q, tol)
+        self.inner(self.rhs, self.q, tol, sweep)
         self.ops.recover(self.q, b, out)
 
     def solve(self, B, out=None, scale=1.0, tol=None):
@@ -161,7 +161,7 @@ class _SchurSolve:
 
     def solve_add(self, B, add, out, scale=1.0):
         Bd = B if B.dim() == 2 else B.reshape(1, -1)
-        self._one(Bd[0], self.tmp)
+        self._one(Bd[0], self.tmp, sweep=True)         # a refinement sweep: the right-hand side is a residual
         dense.axpy(1.0, add, self.tmp, self.n)
         dense.copy(self.tmp, out, self.n)
         if scale != 1.0:
@@ -215,7 +215,9 @@ class WEPGMRESLinSolver(LinSolver):
     `refinements` (not in the reference; 0 = its behaviour): iterative refinement of the full system around the GMRES solve
     with the stopping rule of FactorizeLinSolver (componentwise backward error).  Left-preconditioned GMRES controls the
     preconditioned residual; at n = 10^6 the true residual levels off near 5e-12 however small reltol is chosen, while
-    a few cheap sweeps (reltol ~ 1e-6, each on the residual of the last) reach the accuracy of a direct solve."""
+    a few cheap sweeps (reltol ~ 1e-6, each on the residual of the last) reach the accuracy of a direct solve.
+    kwargs key `sweep_reltol`: the inner tolerance of those sweeps (a correction of relative size 1e-9 needs no nine
+    digits of its own); default = reltol."""
     accepts_tol = True
 
     def __init__(self, nep, lam, kwargs=(), refinements=0):
@@ -223,6 +225,7 @@ class WEPGMRESLinSolver(LinSolver):
         self.ops = SchurOps(nep, lam)
         kw = dict(kwargs)
         kw.pop("log", None)
+        self.sweep_reltol = kw.pop("sweep_reltol", None)
         self.gmres = GMRESLinSolver(_SchurOperator(self.ops), self.lam, kw)
         self.iterations = []
 
@@ -230,8 +233,12 @@ class WEPGMRESLinSolver(LinSolver):
         if self.gmres._Pl_call is not None and os.environ.get("NEP_WEP_GRAPH", "1") != "0":
             self._capture_step()
 
-        def inner(rhs, q, tol):
-            self.gmres.solve_dev(rhs, out=q, tol=tol if self.gmres.reltol is None else None)
+        def inner(rhs, q, tol, sweep=False):
+            if sweep and self.sweep_reltol is not None:
+                tol = float(self.sweep_reltol)
+            elif self.gmres.reltol is not None:
+                tol = None
+            self.gmres.solve_dev(rhs, out=q, tol=tol)
             self.iterations.append(self.gmres.iterations)
         self.schur = _SchurSolve(self.ops, inner)
         self.refined = FactorizeLinSolver(nep, lam, refinements, _lu=self.schur) if refinements > 0 else None

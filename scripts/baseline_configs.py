@@ -149,7 +149,7 @@ def c4_host_errors(n, lam, V):
 
 
 # ---- C5: waveguide (WEP, JARLEBRING), tiar m = 60 ----------------------------------------------------------------------------
-def c5_device(na, nx=1003, nz=999, solver="gmres", N=37, reltol=1e-9, refine=1, maxit=60, timers=None, restart=60):
+def c5_device(na, nx=1003, nz=999, solver="gmres", N=37, reltol=1e-9, refine=1, maxit=60, timers=None, restart=60, sweep_reltol=None):
     """returns (lam, Q, residuals, info).  solver: "lu" = FactorizeLinSolver on the assembled M(sigma) (host SuperLU of an
     n = nx*nz + 2nz matrix), "gmres" = the reference's own solver for this problem (Schur complement + Sylvester-SMW
     preconditioned GMRES, Waveguide.jl:394-567).  reltol / refine: inner GMRES tolerance and refinement sweeps around it
@@ -169,8 +169,13 @@ def c5_device(na, nx=1003, nz=999, solver="gmres", N=37, reltol=1e-9, refine=1, 
             P = na.wep_generate_preconditioner(nep, N, -3 - 3.5j)
             torch.cuda.synchronize()
             info.update(preconditioner_N=N, preconditioner_setup_s=time.perf_counter() - t1)
-            skw = (("Pl", P), ("reltol", reltol), ("restart", restart), ("maxiter", 300),
+            if os.environ.get("NEP_C5_SWEEP_RELTOL"):
+                sweep_reltol = float(os.environ["NEP_C5_SWEEP_RELTOL"])
+            if os.environ.get("NEP_C5_RELTOL"):
+                reltol = float(os.environ["NEP_C5_RELTOL"])
+            skw = (("Pl", P), ("reltol", reltol), ("restart", restart), ("maxiter", 300), ("sweep_reltol", sweep_reltol),
                    ("orth_meth", os.environ.get("NEP_GMRES_ORTH_FORCE", "cgs")))
+            info.update(reltol=reltol, sweep_reltol=sweep_reltol)
         kw["linsolvercreator"] = na.WEPLinSolverCreator(solver_type=solver, kwargs=skw, refinements=refine)
     out = na.tiar(nep, sigma=-3 - 3.5j, gamma=1.0, maxit=maxit, neigs=np.inf, v=v0, tol=1e-8, timers=timers, **kw)
     torch.cuda.synchronize()
@@ -204,3 +209,57 @@ def c5_oracle_twin(nx=303, nz=299, maxit=60):
     out = osol.tiar(o, sigma=-3 - 3.5j, gamma=1.0, maxit=maxit, neigs=np.inf, v=np.ones(n) / np.sqrt(n), tol=1e-8,
                     errmeasure=osol.ResidualErrmeasure(o))
     return out[0], out[1], time.perf_counter() - t0
+
+
+class _SweptOracleCreator:
+    """the oracle's matrix-free waveguide solver with `refine` residual-correction sweeps around it -- what the device
+    configuration runs (c5_device: refinements=refine); the sweeps use the oracle's own M(sigma) product"""
+
+    def __init__(self, inner, refine, progress=None):
+        self.inner, self.refine, self.progress = inner, refine, progress
+
+    def create_linsolver(self, nep, lam):
+        s = self.inner.create_linsolver(nep, lam)
+        self.last = s.iterations
+        one = np.ones(1, dtype=complex)
+        outer = self
+
+        class _S:
+            iterations = s.iterations
+
+            def lin_solve(self, b, tol=0):
+                b = np.asarray(b, dtype=complex).ravel()
+                x = s.lin_solve(b)
+                for _ in range(outer.refine):
+                    r = b - nep._mlincomb(complex(lam), x.reshape(-1, 1), one).ravel()
+                    x = x + s.lin_solve(r)
+                if outer.progress is not None:
+                    outer.progress(len(s.iterations), list(s.iterations[-(outer.refine + 1):]))
+                return x
+        return _S()
+
+
+def c5_oracle_full(nx=1003, nz=999, N=37, reltol=1e-9, refine=1, maxit=60, restart=60, progress=None):
+    """CPU oracle of config C5 by the reference's own route for this problem at ANY size (Waveguide.jl:427-567 +
+    waveguide_preconditioner.jl:36-421 as restated in oracle/wep_linsolvers.py): Schur complement, Sylvester-SMW
+    preconditioner with N x (N+4) regions, restarted GMRES, oracle tiar with the device configuration's start vector,
+    tolerances, inner tolerance and refinement sweeps.  Returns (lam, Q, info) with the wall seconds of each part."""
+    from oracle import wep as ow, solvers as osol, wep_linsolvers as owl
+    info = {}
+    t0 = time.perf_counter()
+    o = ow.WEP_FD(nx, nz, "JARLEBRING")
+    n = o.n
+    info["generate_s"] = time.perf_counter() - t0
+    t1 = time.perf_counter()
+    P = owl.wep_generate_preconditioner(o, N, -3 - 3.5j)
+    info["preconditioner_setup_s"] = time.perf_counter() - t1
+    inner = owl.WEPLinSolverCreator("gmres", (("Pl", P), ("reltol", reltol), ("restart", restart), ("maxiter", 300)))
+    cr = _SweptOracleCreator(inner, refine, progress)
+    t2 = time.perf_counter()
+    out = osol.tiar(o, sigma=-3 - 3.5j, gamma=1.0, maxit=maxit, neigs=np.inf, v=np.ones(n) / np.sqrt(n), tol=1e-8,
+                    errmeasure=osol.ResidualErrmeasure(o), linsolvercreator=cr)
+    info["tiar_s"] = time.perf_counter() - t2
+    info["seconds_solver"] = time.perf_counter() - t1           # what c5_device's solve_s covers: preconditioner + tiar
+    info["n"] = n
+    info["gmres_iterations"] = [int(i) for i in getattr(cr, "last", []) ]
+    return out[0], out[1], info

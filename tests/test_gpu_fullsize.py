@@ -220,7 +220,8 @@ def test_c5_wep_tiar_m60_fullsize(na):
     complement + Sylvester-SMW preconditioned GMRES, no factorisation): >= 6 eigenpairs whose residual ||M(lam) v|| / ||v|| is
     below the driver tolerance both by the device's own K1 AND re-evaluated in FP64 on the host by the oracle's matrix-free
     operator (SURVEY.md section 8d rule ii); the 303 x 299 twin is compared with the CPU oracle's tiar on the same twin BY
-    EIGENVALUE (rules i, iii), and the full-size eigenvalues follow the twin's (discretisation trend: 0.05-0.17)"""
+    EIGENVALUE (rules i, iii), the full-size eigenvalues follow the twin's (discretisation trend: 0.05-0.17) AND equal, to 1e-8
+    relative, the eigenvalues the CPU oracle found at full size (tests/golden/c5_full_oracle_eigs.json)"""
     bc = _bc()
     lam, Q, res, info = bc.c5_device(na, 1003, 999, solver="gmres")
     assert info["n"] == 1003995 and len(lam) >= 6
@@ -237,6 +238,16 @@ def test_c5_wep_tiar_m60_fullsize(na):
     assert ok, worst
     for l in lam:
         assert np.min(abs(np.asarray(lt) - l)) < 0.25, (l, lt)
+    # rules (i) and (iii) at FULL size: the CPU oracle's run of the same call by the reference's own route (matrix-free Schur
+    # complement + Sylvester-SMW preconditioned GMRES, oracle/wep_linsolvers.py; one 757 s run on the GPU box's host,
+    # scripts/c5_oracle_full.py, record in profiles/r4_c5_oracle_full.json) found these eigenvalues
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "c5_full_oracle_eigs.json")) as f:
+        gold = [complex(a, b) for a, b in json.load(f)["eigenvalues"]]
+    assert len(lam) == len(gold), (lam, gold)
+    ok, worst = bc.match(lam, gold, 1e-8)
+    assert ok, worst
 
 
 def test_c2_repeated_runs_are_stable(na):

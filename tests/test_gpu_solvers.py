@@ -1100,11 +1100,12 @@ def test_sharded_beyn_through_the_c_abi_one_rank_rccl(na):
         comm.close()
 
 
-@pytest.mark.parametrize("nz,nx", [(7, 11), (105, 109), (299, 303), (60, 64)])
+@pytest.mark.parametrize("nz,nx", [(7, 11), (105, 109), (299, 303), (60, 64), (111, 115), (999, 1003)])
 def test_wep_sylvester_solve_pfa_vs_numpy(na, nz, nx):
     """nep_wep_sylv_solve (prime-factor DFT along z + per-mode tridiagonal scans along x, csrc/wep.hip) against the dense
     diagonalisation it replaces, X = F (G .* (F^H C W)) W with the DFT matrix F and the sine matrix W
-    (waveguide_preconditioner.jl:120-219): sizes with N2 = 1 (7 prime), 105 = 15 * 7, 299 = 13 * 23, 60 = 15 * 4; also the
+    (waveguide_preconditioner.jl:120-219): sizes with N2 = 1 (7 prime), 105 = 15 * 7, 299 = 13 * 23, 60 = 15 * 4 (an even factor: the
+    plain dense stages), 111 = 37 * 3 and the full-size 999 = 37 * 27 (odd factors: the symmetric-half stages); also the
     region means / expansion kernels against their indicator-matrix products"""
     import ctypes as C
     import torch
