@@ -288,8 +288,9 @@ def c3_summary(na, args):
 def c5_step_roofline(na, nx=1003, nz=999, N=37, reps=50):
     """config C5's inner loop: ONE preconditioned operator step w = Pl^{-1} S v of the Schur-complement GMRES (Waveguide.jl:398-446,
     the reference's linear solver for this problem) at n = 1e6, timed with HIP events as the solver issues it (one hipGraph replay) and
-    in its two halves.  Algorithmic bytes: S v = K1 at k = 1 on the three waveguide matrices plus the interior
-    vector once more for the boundary update (16 N); Pl^{-1} = the interior vector read and written once (32 N) -- the transforms and
+    in its two halves.  Algorithmic bytes: S v in its matrix-free form = vector and diagonal read, result written (48 N) (assembled
+    form, NEP_WEP_STENCIL=0: K1 at k = 1 on the three waveguide matrices, SURVEY.md section 8d, plus the interior vector once more for
+    the boundary update); Pl^{-1} = the interior vector read and written once (32 N) -- the transforms and
     tridiagonal sweeps of the Sylvester solve are traffic of the implementation, not of the operation."""
     from nep_amd import wep_linsolvers as wl
     nep = na.nep_gallery("WEP", nx=nx, nz=nz, benchmark_problem="JARLEBRING"); nep.dev
@@ -300,14 +301,20 @@ def c5_step_roofline(na, nx=1003, nz=999, N=37, reps=50):
     ops = solver.ops
     Nn = ops.N
     v = torch.randn(Nn, dtype=torch.float64, device="cuda").to(torch.complex128); w = torch.empty_like(v)
-    b_op = nep.dev.algorithmic_bytes(1) + 16.0 * Nn
+    if getattr(ops, "stencil", None) is not None:
+        # matrix-free Schur complement (round 4): v and the diagonal read once, the result written once (48 N) + the boundary vectors
+        b_op = 48.0 * Nn + 6 * 16.0 * nz
+        op_form = "matrix-free five-point stencil + P^{-1} (nep_wep_schur_matvec): 48 bytes per interior unknown"
+    else:
+        b_op = nep.dev.algorithmic_bytes(1) + 16.0 * Nn
+        op_form = "assembled: K1 at k = 1 on the three stacked sparse terms + P^{-1} + C1"
     b_pre = 32.0 * Nn
     ms_op = event_loop(lambda: ops.matvec(v, w), reps, warm=5)
     prec = solver.gmres._Pl_call
     ms_pre = event_loop(lambda: prec(w), reps, warm=5)
     out = {"workload": "WEP JARLEBRING nx=%d nz=%d (N = %d interior unknowns), sigma = -3-3.5i, preconditioner %d x %d regions" % (nx, nz, Nn, N, N + 4),
            "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-           "schur_matvec": {"algorithmic_bytes": b_op, "ms": ms_op, "achieved": b_op / ms_op / 1e6, "frac": b_op / ms_op / 1e6 / HBM_PEAK_GBS},
+           "schur_matvec": {"form": op_form, "algorithmic_bytes": b_op, "ms": ms_op, "achieved": b_op / ms_op / 1e6, "frac": b_op / ms_op / 1e6 / HBM_PEAK_GBS},
            "preconditioner": {"algorithmic_bytes": b_pre, "ms": ms_pre, "achieved": b_pre / ms_pre / 1e6, "frac": b_pre / ms_pre / 1e6 / HBM_PEAK_GBS}}
     fused = getattr(solver.gmres, "fused_step", None)
     if fused is not None:

@@ -401,6 +401,14 @@ typedef struct nep_wep_pinv nep_wep_pinv;
 int32_t nep_wep_pinv_create(int32_t nz, const nep_cdouble* h_bb, nep_wep_pinv** out);
 int32_t nep_wep_pinv_destroy(nep_wep_pinv* p);
 int32_t nep_wep_pinv_apply(nep_wep_pinv* p, const nep_cdouble* d_sinv, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream);
+/* Schur complement of the waveguide applied matrix-free (SchurMatVec, /root/reference/src/gallery_extra/waveguide/Waveguide.jl:394-425):
+ * dOut (nz nx) = vec(A(lam) X + X B + K .* X) - C1 P(lam)^{-1} C2T v for X = reshape(dV, nz, nx).  The interior operator is a
+ * five-point stencil: weights cp / cm on the z + 1 / z - 1 neighbours (periodic), cx on the x - 1 / x + 1 neighbours (Dirichlet), the
+ * diagonal dD0 (nz nx entries: K + lam^2 - 2/hz^2 - 2/hx^2); C2T v = d1 X[:, 0] + d2 X[:, 1] (and the mirror image at the other
+ * end), C1 = c1s times the first / last column (generate_fd_boundary_mat).  dP: 2 nz entries of work.  dV and dOut must differ. */
+int32_t nep_wep_schur_matvec(nep_wep_pinv* p, const nep_cdouble* d_sinv, int32_t nx, const nep_cdouble* dV, const nep_cdouble* dD0,
+                             nep_cdouble cp, nep_cdouble cm, double cx, double d1, double d2, double c1s, nep_cdouble* dP,
+                             nep_cdouble* dOut, nep_stream stream);
 /* Sylvester-SMW matrix (generate_smw_matrix, waveguide_preconditioner.jl:221-313): column kappa of dM (mm x mm column-major,
  * mm = N (N+4)) = region means of Linv(E_kappa); the caller adds the identity and inverts.  All mm columns in one call (1517
  * Sylvester solves at N = 37).  dWork: nz*nx + 4 nz + mm complex. */

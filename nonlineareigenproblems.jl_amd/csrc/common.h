@@ -79,6 +79,29 @@ __device__ __forceinline__ double wave_reduce_sum(double v) {
     for (int off = 32; off > 0; off >>= 1) v += shfl_xor_d(v, off);
     return v;
 }
+// Sum over the 64 lanes by data-parallel-primitive moves (no LDS crossbar: __shfl_xor is a ds_bpermute round trip of ~100 cycles per
+// 32-bit half and step): quad permutes (xor 1, xor 2), row rotations by 4 and 8 (every lane of a 16-lane row then holds the row's
+// sum), and the four row sums through v_readlane.  The result is uniform.  Fixed order -> deterministic.
+template <int CTRL>
+__device__ __forceinline__ double dpp_move_d(double v) {
+    union { double d; int i[2]; } u, r; u.d = v;
+    r.i[0] = __builtin_amdgcn_update_dpp(0, u.i[0], CTRL, 0xf, 0xf, false);
+    r.i[1] = __builtin_amdgcn_update_dpp(0, u.i[1], CTRL, 0xf, 0xf, false);
+    return r.d;
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_move_d<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_move_d<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_move_d<0x124>(v);         // row_ror:4
+    v += dpp_move_d<0x128>(v);         // row_ror:8
+    union { double d; int i[2]; } u, a, b, c, d; u.d = v;
+    a.i[0] = __builtin_amdgcn_readlane(u.i[0], 0);  a.i[1] = __builtin_amdgcn_readlane(u.i[1], 0);
+    b.i[0] = __builtin_amdgcn_readlane(u.i[0], 16); b.i[1] = __builtin_amdgcn_readlane(u.i[1], 16);
+    c.i[0] = __builtin_amdgcn_readlane(u.i[0], 32); c.i[1] = __builtin_amdgcn_readlane(u.i[1], 32);
+    d.i[0] = __builtin_amdgcn_readlane(u.i[0], 48); d.i[1] = __builtin_amdgcn_readlane(u.i[1], 48);
+    return (a.d + b.d) + (c.d + d.d);
+}
+__device__ __forceinline__ cplx wave_sum_dpp(cplx v) { return cmake(wave_sum_dpp(v.x), wave_sum_dpp(v.y)); }
 __device__ __forceinline__ int readlane_i(int v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
 __device__ __forceinline__ double readlane_d(double v, int lane) {
     union { double d; int i[2]; } u; u.d = v;

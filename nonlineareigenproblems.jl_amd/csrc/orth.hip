@@ -81,24 +81,49 @@ __global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, i
     // a block keeps its 1024-row slice of w in registers and walks over column groups blockIdx.y, +gridDim.y, ...:
     // with gridDim.y == 1 (large row counts) w is read once per slice instead of once per column group
     // (PMC: 971 MB fetched for 820 MB of algorithmic traffic at iar step 100 with one group per block)
+    // (the loads of a column group go out together, unconditionally and with clamped rows, and are masked afterwards: behind the
+    // per-column `if (r0 < act)` / per-row `if (row < act)` tests a workgroup waited for one column's four loads, reduced, and only
+    // then asked for the next column -- 16 KB in flight per workgroup; at k <= 30 columns (GMRES on the waveguide, the first third
+    // of an iar run) the kernel ran at 3.3 TB/s for that reason)
+    int64_t rc[DOT_RPT];
+#pragma unroll
+    for (int i = 0; i < DOT_RPT; ++i) rc[i] = rr[i] < rows ? rr[i] : rows - 1;
     for (int j0 = blockIdx.y * DOT_CG; j0 < k; j0 += gridDim.y * DOT_CG) {
+        int64_t actv[DOT_CG];
+        bool grp_on = false;
 #pragma unroll
         for (int jj = 0; jj < DOT_CG; ++jj) {
             const int j = j0 + jj;
-            cplx acc = cmake(0.0, 0.0);
-            if (j < k) {
-                int64_t act = active ? active[j] : rows;
-                if (act > rows) act = rows;
-                if (r0 < act) {
-                    const cplx* vp = V + (int64_t)j * ldv;
-#pragma unroll
-                    for (int i = 0; i < DOT_RPT; ++i)
-                        if (rr[i] < act) cfma_conj(acc, vload<NT>(vp + rr[i]), wr[i]);
-                    acc = group_reduce_sum<64>(acc);
-                }
-            }
-            if (lane == 0) sm[jj][wv] = acc;
+            int64_t a = 0;
+            if (j < k) { a = active ? active[j] : rows; if (a > rows) a = rows; }
+            actv[jj] = a;
+            grp_on = grp_on || r0 < a;
         }
+        cplx accs[DOT_CG];
+#pragma unroll
+        for (int jj = 0; jj < DOT_CG; ++jj) accs[jj] = cmake(0.0, 0.0);
+        if (grp_on) {
+            cplx v[DOT_CG][DOT_RPT];
+#pragma unroll
+            for (int jj = 0; jj < DOT_CG; ++jj) {
+                const cplx* vp = V + (int64_t)(j0 + jj < k ? j0 + jj : k - 1) * ldv;
+#pragma unroll
+                for (int i = 0; i < DOT_RPT; ++i) v[jj][i] = vload<NT>(vp + rc[i]);
+            }
+#pragma unroll
+            for (int jj = 0; jj < DOT_CG; ++jj) {
+                cplx acc = cmake(0.0, 0.0);
+#pragma unroll
+                for (int i = 0; i < DOT_RPT; ++i) {
+                    const bool on = rr[i] < actv[jj];
+                    cfma_conj(acc, cmake(on ? v[jj][i].x : 0.0, on ? v[jj][i].y : 0.0), wr[i]);
+                }
+                accs[jj] = wave_sum_dpp(acc);
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < DOT_CG; ++jj)
+            if (lane == 0) sm[jj][wv] = accs[jj];
         __syncthreads();
         if (threadIdx.x < DOT_CG) {
             const int j = j0 + threadIdx.x;
@@ -231,6 +256,88 @@ __global__ __launch_bounds__(512) void k_orth_update(const cplx* __restrict__ V,
 }
 
 
+// Row-per-thread form of k_orth_update for FEW columns: a thread owns one row of a 256-row tile and walks over all k columns with
+// eight loads in flight; no shared-memory reduction and no barrier per tile.  The wave-per-column-slice kernel above gives each of
+// its 8 waves k / 8 columns of a 64-row tile and meets at two barriers per tile: at k <= 30 that is one or two 1 KB loads per wave
+// between barriers (GMRES on the waveguide: 2.9 TB/s; iar steps 1-35: launch- and latency-bound).  Same arguments and outputs
+// (one partial norm per workgroup); columns that are structurally zero on the whole tile are skipped as a leading run.
+template <bool NT>
+__global__ __launch_bounds__(256) void k_orth_update_rows(const cplx* __restrict__ V, int64_t ldv, int64_t rows,
+                                                          int k, const int64_t* __restrict__ active,
+                                                          const cplx* __restrict__ h, cplx* __restrict__ w,
+                                                          double* __restrict__ partial,
+                                                          const int* __restrict__ gate = nullptr,
+                                                          const double* __restrict__ ww = nullptr, int* __restrict__ state = nullptr,
+                                                          int pdone = 0, int method = 0) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    __shared__ double smn[4];
+    if (gate && *gate == 0) return;
+    cplx* hs = (cplx*)smem_raw;         // k
+    const int lane = threadIdx.x & 63;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int t = threadIdx.x; t < k; t += 256) hs[t] = h[t];
+    __syncthreads();
+    if (state && blockIdx.x == 0 && q == 0) {            // the DGKS decision of this pass: see k_orth_update
+        double p2 = 0.0;
+        for (int j = lane; j < k; j += 64) p2 += fma(hs[j].x, hs[j].x, hs[j].y * hs[j].y);
+        p2 = wave_reduce_sum(p2);
+        if (lane == 0) {
+            const double w2 = ww[0];
+            const int more = (method == 0 && !(w2 >= 1.5 * p2)) ? 1 : 0;
+            state[1] = pdone;
+            state[4 + pdone] = more;
+        }
+    }
+    const int64_t ntiles = (rows + 255) / 256;
+    double nn = 0.0;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t r0 = tile * 256LL;
+        const int64_t row = r0 + threadIdx.x;
+        const int64_t rowc = row < rows ? row : rows - 1;
+        const cplx w0 = w[rowc];
+        int jmin = 0;
+        if (active) {                                    // leading run of columns with no active row on this tile
+            for (int base = 0; base < k; base += 64) {
+                const int j = base + lane;
+                const bool off = j < k && active[j] <= r0;
+                const unsigned long long m = __ballot(off);
+                const int run = m == ~0ull ? 64 : __ffsll((long long)~m) - 1;
+                jmin = base + run;
+                if (run < 64) break;
+            }
+            if (jmin > k) jmin = k;
+            jmin = __builtin_amdgcn_readfirstlane(jmin);
+        }
+        cplx acc = cmake(0.0, 0.0);
+        const cplx* vp = V + rowc;
+        int j = jmin;
+        for (; j + 8 <= k; j += 8) {
+            cplx v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = vload<NT>(vp + (int64_t)(j + u) * ldv);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) cfma(acc, v[u], hs[j + u]);
+        }
+        if (j < k) {
+            cplx v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = vload<NT>(vp + (int64_t)(j + u < k ? j + u : k - 1) * ldv);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) if (j + u < k) cfma(acc, v[u], hs[j + u]);
+        }
+        if (row < rows) {
+            const cplx wn = csub(w0, acc);
+            w[row] = wn;
+            nn += fma(wn.x, wn.x, wn.y * wn.y);
+        }
+    }
+    nn = wave_sum_dpp(nn);
+    if (lane == 0) smn[q] = nn;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (smn[0] + smn[1]) + (smn[2] + smn[3]);
+}
+
+
 // w /= beta (beta on the device); records passes / flags behind beta: out[k+1] = (passes, 2*breakdown + more_needed)
 // mirror (optional): device-mapped pinned host copy of the caller's row [row, row + nmirror) -- h, beta, flags and whatever the
 // caller keeps behind them -- written by block 0, which saves the separate device-to-host copy command of every Arnoldi step
@@ -279,12 +386,25 @@ static int dots_grid_y(int nchunks, int k) {
 
 static thread_local NepScratch g_orth_scratch;
 
+// k at or below which the update runs row-per-thread (k_orth_update_rows); NEP_ORTH_ROWS_K=0 switches that form off.  Measured alone
+// the two forms meet at k = 100 (310 against 313 us per pass at iar's last step) and the row form wins below (k = 48: 81 / 88 us,
+// k = 8 at 10^6 rows: 62 / 67); inside the gun run, next to the eigenvalue kernels of the other queue, the row form is faster at
+// every k (whole call 37.7 ms against 39.3 with the switch at 64 and 39.7 without it), so it is the default for all k
+static int orth_rows_k() {
+    static const int v = getenv("NEP_ORTH_ROWS_K") ? atoi(getenv("NEP_ORTH_ROWS_K")) : 1 << 30;
+    return v;
+}
+
 // non-temporal V loads when the streamed block is far larger than the last-level cache (see nep_orth_dev)
 static bool orth_use_nt(int64_t rows, int64_t k, bool staircase) {
     static const int nt_env = getenv("NEP_ORTH_NT") ? atoi(getenv("NEP_ORTH_NT")) : -1;
     static const double nt_mb = getenv("NEP_ORTH_NT_MB") ? atof(getenv("NEP_ORTH_NT_MB")) : 192.0;
+    // full columns (GMRES / tiar bases; no factorisation to protect next to them): the update's sweep over V follows the
+    // projection's at once and finds a block of up to ~1.5x the last-level cache largely still there -- measured at 10^6 rows,
+    // one pass: k = 12 103 -> 81 us, k = 16 114 -> 100, k = 20 146 -> 127, k = 24 158 -> 152 with ordinary loads
+    static const double nt_full_mb = getenv("NEP_ORTH_NT_FULL_MB") ? atof(getenv("NEP_ORTH_NT_FULL_MB")) : 512.0;
     const double streamed_mb = 16.0e-6 * (double)rows * (double)k * (staircase ? 0.5 : 1.0);
-    return nt_env >= 0 ? nt_env != 0 : streamed_mb > nt_mb;
+    return nt_env >= 0 ? nt_env != 0 : streamed_mb > (staircase ? nt_mb : nt_full_mb);
 }
 
 extern "C" int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
@@ -455,7 +575,9 @@ extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, in
     // than the last-level cache: NEP_ORTH_NT = 0 never, 1 always, unset: above NEP_ORTH_NT_MB (default 192) megabytes
     const bool nt = orth_use_nt(rows, k, d_active_rows != nullptr);
     OrthDecide D;
-    D.partial = d_pn; D.np = npart; D.c = d_c; D.k = (int)k; D.method = (int)method; D.state = d_state; D.out_beta = out + k;
+    const bool rows_form = k <= orth_rows_k();
+    const int nb_rows = (int)std::min<int64_t>((rows + 255) / 256, npart);
+    D.partial = d_pn; D.np = rows_form ? nb_rows : npart; D.c = d_c; D.k = (int)k; D.method = (int)method; D.state = d_state; D.out_beta = out + k;
     {
     // per pass three launches (dots, coefficient reduction, update); the decision of pass p is published by its update kernel
     // BEFORE that update runs (Pythagoras, see k_orth_update), so a gated-off pass costs three launches that read one word
@@ -472,7 +594,15 @@ extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, in
                            p == 0 ? 1 : 0, p == 0 ? d_state : (int*)nullptr, OrthDecide(), 0, (const double*)d_pww, d_ww);
         LAUNCHCHK();
         if (p == 0 && before_write) HIPCHK(hipStreamWaitEvent(st, (hipEvent_t)before_write, 0));
-        if (nt)
+        if (rows_form) {
+            const int nb = nb_rows;
+            if (nt)
+                hipLaunchKernelGGL(k_orth_update_rows<true>, dim3(nb), dim3(256), (size_t)k * sizeof(cplx), st, V, ldv, rows, (int)k,
+                                   d_active_rows, (const cplx*)d_c, w, d_pn, gate, (const double*)d_ww, d_state, p + 1, (int)method);
+            else
+                hipLaunchKernelGGL(k_orth_update_rows<false>, dim3(nb), dim3(256), (size_t)k * sizeof(cplx), st, V, ldv, rows, (int)k,
+                                   d_active_rows, (const cplx*)d_c, w, d_pn, gate, (const double*)d_ww, d_state, p + 1, (int)method);
+        } else if (nt)
             hipLaunchKernelGGL(k_orth_update<true>, dim3(npart), dim3(512), shm_upd, st, V, ldv, rows, (int)k, d_active_rows,
                                (const cplx*)d_c, w, d_pn, gate, (const double*)d_ww, d_state, p + 1, (int)method);
         else

@@ -649,10 +649,19 @@ __global__ void k_region_expand(int nz, int nx, int N, int L, const cplx* __rest
 // ---- boundary operator P(lam)^{-1} = R diag(1 / s(lam)) R^H / nz,  R x = reverse(bb .* fft(x))  (Waveguide.jl:53-65,159-162) ------
 // one workgroup per half (minus / plus block): x -> reverse -> conj(bb) .* -> inverse-direction DFT -> scale by sinv = 1/(nz s) ->
 // DFT -> bb .* -> reverse, both DFTs by the same prime-factor scheme out of LDS.  Replaces four nz x nz dense GEMVs per application.
+// entry i of the half's input: x[i], or -- gathered from the interior block X (nz x gnx, z fastest) -- the boundary functional C2T of
+// generate_fd_boundary_mat: gd1 X[i, 0] + gd2 X[i, 1] (minus half), gd1 X[i, nx-1] + gd2 X[i, nx-2] (plus half)
+__device__ __forceinline__ cplx pinv_in(const cplx* __restrict__ xh, const cplx* __restrict__ gX, int gnx, double gd1, double gd2,
+                                        int half, int nz, int i) {
+    if (!gX) return xh[i];
+    const cplx u = gX[(int64_t)(half ? gnx - 1 : 0) * nz + i], v = gX[(int64_t)(half ? gnx - 2 : 1) * nz + i];
+    return cmake(fma(gd1, u.x, gd2 * v.x), fma(gd1, u.y, gd2 * v.y));
+}
 __global__ __launch_bounds__(1024) void k_wep_pinv(int nz, int N1, int N2, const int32_t* __restrict__ in_idx,
                                                    const int32_t* __restrict__ out_idx, const cplx* __restrict__ w1,
                                                    const cplx* __restrict__ w2, const cplx* __restrict__ bb,
-                                                   const cplx* __restrict__ sinv, const cplx* __restrict__ x, cplx* __restrict__ out) {
+                                                   const cplx* __restrict__ sinv, const cplx* __restrict__ x, cplx* __restrict__ out,
+                                                      const cplx* __restrict__ gX = nullptr, int gnx = 0, double gd1 = 0.0, double gd2 = 0.0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* a = (cplx*)smem_raw;        // nz
     cplx* t = a + nz;                 // nz
@@ -670,7 +679,7 @@ __global__ __launch_bounds__(1024) void k_wep_pinv(int nz, int N1, int N2, const
         for (int q = threadIdx.x; q < N2; q += nt) r2[q] = cmake(w2[q].x, sgn * w2[q].y);
         for (int q = threadIdx.x; q < nz; q += nt) {
             const int m = in_idx[q];
-            if (pass == 0) { const cplx b = bb[m]; a[q] = cmul(cmake(b.x, -b.y), xh[nz - 1 - m]); }
+            if (pass == 0) { const cplx b = bb[m]; a[q] = cmul(cmake(b.x, -b.y), pinv_in(xh, gX, gnx, gd1, gd2, half, nz, nz - 1 - m)); }
             else a[q] = v[m];
         }
         __syncthreads();
@@ -699,7 +708,8 @@ __global__ __launch_bounds__(1024) void k_wep_pinv(int nz, int N1, int N2, const
 __global__ __launch_bounds__(512) void k_wep_pinv_sym(int nz, int N1, int N2, const int32_t* __restrict__ in_idx,
                                                       const int32_t* __restrict__ out_idx, const cplx* __restrict__ w1,
                                                       const cplx* __restrict__ w2, const cplx* __restrict__ bb,
-                                                      const cplx* __restrict__ sinv, const cplx* __restrict__ x, cplx* __restrict__ out) {
+                                                      const cplx* __restrict__ sinv, const cplx* __restrict__ x, cplx* __restrict__ out,
+                                                      const cplx* __restrict__ gX = nullptr, int gnx = 0, double gd1 = 0.0, double gd2 = 0.0) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* a = (cplx*)smem_raw;        // nz: stage buffer
     cplx* v = a + nz;                 // nz: result of pass 0, natural order
@@ -714,7 +724,7 @@ __global__ __launch_bounds__(512) void k_wep_pinv_sym(int nz, int N1, int N2, co
     for (int q = threadIdx.x; q < nz; q += nt) {
         const int m = in_idx[q];
         const cplx b = bb[m];
-        a[q] = cmul(cmake(b.x, -b.y), xh[nz - 1 - m]);
+        a[q] = cmul(cmake(b.x, -b.y), pinv_in(xh, gX, gnx, gd1, gd2, half, nz, nz - 1 - m));
     }
     __syncthreads();
     dft_sym_stages<1, 1>(a, c1, c2, nz, N1, N2, -1.0, out_idx, [&](int k, int, double re, double im) { v[k] = cmul(cmake(re, im), sh[k]); });
@@ -852,8 +862,14 @@ int32_t nep_wep_pinv_create(int32_t nz, const nep_cdouble* h_bb, nep_wep_pinv** 
 }
 
 // dOut (2 nz) = blkdiag(R, R) diag(d_sinv) blkdiag(R, R)^H dX, d_sinv = 1 / (nz s_j(lam)) (2 nz device entries); dOut may alias dX
+static int32_t pinv_apply_impl(nep_wep_pinv* p, const nep_cdouble* d_sinv, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream,
+                               const cplx* gX, int gnx, double gd1, double gd2);
 int32_t nep_wep_pinv_apply(nep_wep_pinv* p, const nep_cdouble* d_sinv, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream) {
     ARGCHK(p && d_sinv && dX && dOut);
+    return pinv_apply_impl(p, d_sinv, dX, dOut, stream, nullptr, 0, 0.0, 0.0);
+}
+static int32_t pinv_apply_impl(nep_wep_pinv* p, const nep_cdouble* d_sinv, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream,
+                               const cplx* gX, int gnx, double gd1, double gd2) {
     static thread_local bool attr_set = false;
     if (!attr_set) { HIPCHK(hipFuncSetAttribute((const void*)k_wep_pinv, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr_set = true; }
     static const bool sym_on = !(getenv("NEP_WEP_PINV_SYM") && atoi(getenv("NEP_WEP_PINV_SYM")) == 0);
@@ -862,7 +878,7 @@ int32_t nep_wep_pinv_apply(nep_wep_pinv* p, const nep_cdouble* d_sinv, const nep
         if (items <= 512) {
             hipLaunchKernelGGL(k_wep_pinv_sym, dim3(2), dim3((items + 63) / 64 * 64), ((size_t)2 * p->nz + p->N1 + p->N2) * sizeof(cplx),
                                as_stream(stream), p->nz, p->N1, p->N2, (const int32_t*)p->d_in, (const int32_t*)p->d_out, (const cplx*)p->d_w1,
-                               (const cplx*)p->d_w2, (const cplx*)p->d_bb, (const cplx*)d_sinv, (const cplx*)dX, (cplx*)dOut);
+                               (const cplx*)p->d_w2, (const cplx*)p->d_bb, (const cplx*)d_sinv, (const cplx*)dX, (cplx*)dOut, gX, gnx, gd1, gd2);
             LAUNCHCHK();
             return NEP_OK;
         }
@@ -871,7 +887,46 @@ int32_t nep_wep_pinv_apply(nep_wep_pinv* p, const nep_cdouble* d_sinv, const nep
     const int threads = p->nz >= 768 ? 1024 : (p->nz >= 256 ? 512 : 256);
     hipLaunchKernelGGL(k_wep_pinv, dim3(2), dim3(threads), shm, as_stream(stream), p->nz, p->N1, p->N2, (const int32_t*)p->d_in,
                        (const int32_t*)p->d_out, (const cplx*)p->d_w1, (const cplx*)p->d_w2, (const cplx*)p->d_bb, (const cplx*)d_sinv,
-                       (const cplx*)dX, (cplx*)dOut);
+                       (const cplx*)dX, (cplx*)dOut, gX, gnx, gd1, gd2);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
+// ---- Schur complement of the waveguide, matrix-free (SchurMatVec, Waveguide.jl:394-425) ------------------------------------------
+//   out = vec(A(lam) X + X B + K .* X) - C1 P(lam)^{-1} C2T v,   X = reshape(v, nz, nx)
+// with A(lam) = Dzz + 2 lam Dz + lam^2 I (periodic second / central first difference along z), B = Dxx (Dirichlet along x):
+// a five-point stencil with constant off-diagonal weights cp (z+1), cm (z-1), cx (x-1, x+1) and the diagonal D0 = K + lam^2 -
+// 2/hz^2 - 2/hx^2 as an array; C2T v is gathered inside the boundary kernel (pinv_in), C1 adds c1s * P^{-1}(..) to the first and
+// the last column.  One read of X and D0, one write: 48 bytes per unknown where the assembled operator (three stacked sparse terms
+// through K1, a copy in front and a CSR pass behind it) moved 148.
+__global__ __launch_bounds__(256) void k_wep_schur_stencil(int nz, int nx, const cplx* __restrict__ X, const cplx* __restrict__ D0,
+                                                           cplx cp, cplx cm, double cx, double c1s, const cplx* __restrict__ pb,
+                                                           cplx* __restrict__ out) {
+    const int x = blockIdx.y;
+    const int z = blockIdx.x * 256 + threadIdx.x;
+    if (z >= nz) return;
+    const int64_t i = (int64_t)x * nz + z;
+    const cplx c = X[i];
+    const cplx up = X[(int64_t)x * nz + (z + 1 < nz ? z + 1 : 0)];
+    const cplx dn = X[(int64_t)x * nz + (z > 0 ? z - 1 : nz - 1)];
+    cplx r = cmul(D0[i], c);
+    cfma(r, cp, up); cfma(r, cm, dn);
+    if (x > 0) { const cplx l = X[i - nz]; r.x = fma(cx, l.x, r.x); r.y = fma(cx, l.y, r.y); }
+    if (x + 1 < nx) { const cplx rr = X[i + nz]; r.x = fma(cx, rr.x, r.x); r.y = fma(cx, rr.y, r.y); }
+    if (x == 0) { const cplx q = pb[z]; r.x = fma(-c1s, q.x, r.x); r.y = fma(-c1s, q.y, r.y); }
+    if (x == nx - 1) { const cplx q = pb[nz + z]; r.x = fma(-c1s, q.x, r.x); r.y = fma(-c1s, q.y, r.y); }
+    out[i] = r;
+}
+
+int32_t nep_wep_schur_matvec(nep_wep_pinv* p, const nep_cdouble* d_sinv, int32_t nx, const nep_cdouble* dV, const nep_cdouble* dD0,
+                             nep_cdouble cp, nep_cdouble cm, double cx, double d1, double d2, double c1s, nep_cdouble* dP,
+                             nep_cdouble* dOut, nep_stream stream) {
+    ARGCHK(p && d_sinv && dV && dD0 && dP && dOut && nx >= 2 && dV != dOut);
+    int rc = pinv_apply_impl(p, d_sinv, dV, dP, stream, (const cplx*)dV, nx, d1, d2);
+    if (rc) return rc;
+    cplx cpv, cmv; cpv.x = cp.re; cpv.y = cp.im; cmv.x = cm.re; cmv.y = cm.im;
+    hipLaunchKernelGGL(k_wep_schur_stencil, dim3((p->nz + 255) / 256, nx), dim3(256), 0, as_stream(stream), p->nz, (int)nx,
+                       (const cplx*)dV, (const cplx*)dD0, cpv, cmv, cx, c1s, (const cplx*)dP, (cplx*)dOut);
     LAUNCHCHK();
     return NEP_OK;
 }
@@ -913,7 +968,7 @@ int32_t nep_wep_sylv_solve(nep_wep_sylv* s, nep_cdouble* dX, nep_stream stream) 
          else if (s->cols == 4) DFT_LAUNCH(F_, 4, SGN_, SRC_, DST_); else if (s->cols == 2) DFT_LAUNCH(F_, 2, SGN_, SRC_, DST_);  \
          else DFT_LAUNCH(F_, 1, SGN_, SRC_, DST_); } while (0)
     // symmetric-half form of the two dense stages (odd N1, N2): NEP_WEP_DFT_SYM = "cols*10 + kb" (42, 43, 22, 23) or 0 = off
-    static const int symcfg = getenv("NEP_WEP_DFT_SYM") ? atoi(getenv("NEP_WEP_DFT_SYM")) : 42;
+    static const int symcfg = getenv("NEP_WEP_DFT_SYM") ? atoi(getenv("NEP_WEP_DFT_SYM")) : 22;
     int sym_cols = symcfg / 10, sym_kb = symcfg % 10, sym_threads = 0;
     if (symcfg && (s->N1 & 1) && (s->N2 & 1) && s->N1 >= 3 && s->N2 >= 3 && (sym_cols == 2 || sym_cols == 4) && (sym_kb == 2 || sym_kb == 3)) {
         const int H1 = (s->N1 - 1) / 2, H2 = (s->N2 - 1) / 2;

@@ -65,6 +65,15 @@ class SchurOps:
         s = _corner_derivs(nep.wd, self.lam, 1)[:, 0]
         self.sinv = to_dev(1.0 / (s * self.nz))[0]                     # 1 / (nz s_j(lam)), 2 nz entries
         self.coef = to_dev(np.array([[1.0, self.lam, self.lam ** 2]], dtype=np.complex128))    # 1 x 3, device resident
+        # matrix-free form of the interior operator (five-point stencil, csrc/wep.hip nep_wep_schur_matvec): weights of
+        # generate_fd_interior_mat / generate_fd_boundary_mat (Waveguide.jl:17-19), diagonal K + lam^2 - 2/hz^2 - 2/hx^2
+        wd = nep.wd
+        self.stencil = None
+        if nep._pinv_plan() is not None and os.environ.get("NEP_WEP_STENCIL", "1") != "0":
+            lam_ = self.lam
+            D0 = np.asarray(wd.K, dtype=np.complex128) + (lam_ ** 2 - 2.0 / wd.hz ** 2 - 2.0 / wd.hx ** 2)
+            self.stencil = dict(D0=to_dev(D0), cp=_lib.cd(1.0 / wd.hz ** 2 + lam_ / wd.hz), cm=_lib.cd(1.0 / wd.hz ** 2 - lam_ / wd.hz),
+                                cx=1.0 / wd.hx ** 2, d1=2.0 / wd.hx, d2=-1.0 / (2.0 * wd.hx), c1s=1.0 / wd.hx ** 2)
         self.pad = torch.zeros(self.n, dtype=CDT, device="cuda")
         self.z = torch.empty(self.n, dtype=CDT, device="cuda")
         self.t = torch.empty(2 * self.nz, dtype=CDT, device="cuda")
@@ -92,6 +101,11 @@ class SchurOps:
     def matvec(self, v, out):
         """out = vec(A(lam) X + X B + K .* X) - C1 P(lam)^{-1} C2T v   (SchurMatVec, Waveguide.jl:398-406)"""
         N, n = self.N, self.n
+        if self.stencil is not None and v.data_ptr() != out.data_ptr():
+            st = self.stencil
+            check(lib.nep_wep_schur_matvec(self.nep._pinv_plan(), c_vp(self.sinv.data_ptr()), self.nx, _p(v), _p(st["D0"]), st["cp"], st["cm"],
+                                           st["cx"], st["d1"], st["d2"], st["c1s"], c_vp(self.t.data_ptr()), _p(out), stream_ptr()))
+            return out
         check(lib.nep_dev_copy(c_vp(self.pad.data_ptr()), _p(v), 16 * N, stream_ptr()))
         self.nep.dev.mlincomb_dev(self.coef, 1, 1, self.pad.data_ptr(), n, self.z)      # no host->device copy: graph-safe
         self.pinv(self.z.data_ptr() + 16 * N, self.t)
@@ -140,13 +154,18 @@ class _SchurSolve:
 
     def __init__(self, ops, inner):
         self.ops, self.inner, self.n = ops, inner, ops.n
+        import inspect
+        self._sweep_kw = "sweep" in inspect.signature(inner).parameters      # the iterative inner solver is told which solves are sweeps
         self.rhs = torch.empty(ops.N, dtype=CDT, device="cuda")
         self.q = torch.empty(ops.N, dtype=CDT, device="cuda")
         self.tmp = torch.empty(ops.n, dtype=CDT, device="cuda")
 
     def _one(self, b, out, tol=None, sweep=False):
         self.ops.eliminate(b, self.rhs)
-        self.inner(self.rhs, self.q, tol, sweep)
+        if sweep and self._sweep_kw:
+            self.inner(self.rhs, self.q, tol, sweep=True)
+        else:
+            self.inner(self.rhs, self.q, tol)
         self.ops.recover(self.q, b, out)
 
     def solve(self, B, out=None, scale=1.0, tol=None):

@@ -149,12 +149,13 @@ def c4_host_errors(n, lam, V):
 
 
 # ---- C5: waveguide (WEP, JARLEBRING), tiar m = 60 ----------------------------------------------------------------------------
-def c5_device(na, nx=1003, nz=999, solver="gmres", N=37, reltol=1e-9, refine=1, maxit=60, timers=None, restart=60, sweep_reltol=None):
+def c5_device(na, nx=1003, nz=999, solver="gmres", N=37, reltol=1e-9, refine=1, maxit=60, timers=None, restart=60, sweep_reltol=1e-6):
     """returns (lam, Q, residuals, info).  solver: "lu" = FactorizeLinSolver on the assembled M(sigma) (host SuperLU of an
     n = nx*nz + 2nz matrix), "gmres" = the reference's own solver for this problem (Schur complement + Sylvester-SMW
     preconditioned GMRES, Waveguide.jl:394-567).  reltol / refine: inner GMRES tolerance and refinement sweeps around it
     (measured at n = 1e6: (1e-6, 10) 2.9 s, (1e-9, 1) 2.2 s, same 7 eigenpairs and residuals; without a sweep the left-
-    preconditioned residual GMRES controls is not the true one and no pair converges)"""
+    preconditioned residual GMRES controls is not the true one and no pair converges).  sweep_reltol: inner tolerance of the
+    sweep (round 4: 1e-6 finds the same 7 pairs to 5e-12 in 22 -> 14 iterations per sweep; 1e-4 loses one pair)"""
     import torch
     t0 = time.perf_counter()
     nep = na.nep_gallery("WEP", nx=nx, nz=nz, benchmark_problem="JARLEBRING"); n = nep.n; nep.dev

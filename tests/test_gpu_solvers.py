@@ -1100,6 +1100,33 @@ def test_sharded_beyn_through_the_c_abi_one_rank_rccl(na):
         comm.close()
 
 
+@pytest.mark.parametrize("nx,nz", [(19, 15), (115, 111), (15, 11), (29, 25)])
+def test_wep_schur_matvec_stencil_equals_assembled(na, nx, nz):
+    """SchurMatVec (Waveguide.jl:394-425) in its matrix-free form (nep_wep_schur_matvec: five-point stencil + the boundary functional
+    gathered inside the P^{-1} kernel) against the assembled route (K1 on the three stacked sparse terms, P^{-1}, C1) and against the
+    host Schur complement of construct_WEP_schur_complement (Waveguide.jl:523-550); nz = 15, 111 take the symmetric-half P^{-1}
+    kernel, nz = 11 (prime) and 25 (no coprime factors) the plain one"""
+    import torch
+    from nep_amd import wep_linsolvers as wl
+    nep = na.nep_gallery("WEP", nx=nx, nz=nz, benchmark_problem="JARLEBRING")
+    lam = -1.3 - 0.7j
+    ops = wl.SchurOps(nep, lam)
+    assert ops.stencil is not None
+    rng = np.random.default_rng(nx)
+    v = rng.standard_normal(nx * nz) + 1j * rng.standard_normal(nx * nz)
+    vd = na.to_dev(v)[0]
+    o1 = torch.empty_like(vd); o2 = torch.empty_like(vd)
+    ops.matvec(vd, o1)
+    st, ops.stencil = ops.stencil, None
+    ops.matvec(vd, o2)
+    ops.stencil = st
+    torch.cuda.synchronize()
+    a = na.to_host(o1).ravel(); b = na.to_host(o2).ravel()
+    ref = wl.construct_WEP_schur_complement(nep, lam) @ v
+    assert np.linalg.norm(a - b) <= 1e-13 * np.linalg.norm(b)
+    assert np.linalg.norm(a - ref) <= 1e-12 * np.linalg.norm(ref)
+
+
 @pytest.mark.parametrize("nz,nx", [(7, 11), (105, 109), (299, 303), (60, 64), (111, 115), (999, 1003)])
 def test_wep_sylvester_solve_pfa_vs_numpy(na, nz, nx):
     """nep_wep_sylv_solve (prime-factor DFT along z + per-mode tridiagonal scans along x, csrc/wep.hip) against the dense
