@@ -49,7 +49,12 @@ __device__ __forceinline__ void orth_pass_norms(const OrthDecide& D, double& nrm
     __syncthreads();
     nrm = sqrt(t); p2 = q2;
 }
-template <bool NT>
+// DPP: the eight wave sums of a column group by data-parallel-primitive moves (wave_sum_dpp) instead of the shuffle butterfly.  Both are
+// fixed-order sums; they round differently.  Blocks below ORTH_DPP_ROWS rows keep the butterfly: the kernel is launch-bound there, and the
+// small projected problems of nlar / the inner solvers (n <= 150) are sensitive to the last bit of their Hessenberg entries -- the gun
+// twin of test/nlar.jl finds its second eigenvalue with one order and not with the other (scripts/diag/nlar_dbg.py).
+#define ORTH_DPP_ROWS 32768
+template <bool NT, bool DPP>
 __global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, int64_t ldv, int64_t rows,
                                                    int k, const int64_t* __restrict__ active,
                                                    const cplx* __restrict__ w, cplx* __restrict__ partial,
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, i
                     const bool on = rr[i] < actv[jj];
                     cfma_conj(acc, cmake(on ? v[jj][i].x : 0.0, on ? v[jj][i].y : 0.0), wr[i]);
                 }
-                accs[jj] = wave_sum_dpp(acc);
+                accs[jj] = DPP ? wave_sum_dpp(acc) : group_reduce_sum<64>(acc);
             }
         }
 #pragma unroll
@@ -384,6 +389,14 @@ static int dots_grid_y(int nchunks, int k) {
     return gy < 1 ? 1 : (gy > ngroups ? ngroups : gy);
 }
 
+#define ORTH_DOTS_LAUNCH(NT_, DPP_, GRID_, ST_, ...)                                                                   \
+    do {                                                                                                               \
+        if (NT_) { if (DPP_) hipLaunchKernelGGL((k_orth_dots<true, true>), GRID_, dim3(256), 0, ST_, __VA_ARGS__);       \
+                   else hipLaunchKernelGGL((k_orth_dots<true, false>), GRID_, dim3(256), 0, ST_, __VA_ARGS__); }          \
+        else { if (DPP_) hipLaunchKernelGGL((k_orth_dots<false, true>), GRID_, dim3(256), 0, ST_, __VA_ARGS__);          \
+               else hipLaunchKernelGGL((k_orth_dots<false, false>), GRID_, dim3(256), 0, ST_, __VA_ARGS__); }             \
+    } while (0)
+
 static thread_local NepScratch g_orth_scratch;
 
 // k at or below which the update runs row-per-thread (k_orth_update_rows); NEP_ORTH_ROWS_K=0 switches that form off.  Measured alone
@@ -445,7 +458,7 @@ extern "C" int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, in
         // modified Gram-Schmidt: column by column (test/reference-comparison path; not tuned)
         for (int j = 0; j < k; ++j) {
             const int64_t* actj = d_act ? d_act + j : nullptr;
-            hipLaunchKernelGGL(k_orth_dots<false>, dim3(nchunks, 1), dim3(256), 0, st, V + (int64_t)j * ldv, ldv, rows, 1,
+            hipLaunchKernelGGL((k_orth_dots<false, false>), dim3(nchunks, 1), dim3(256), 0, st, V + (int64_t)j * ldv, ldv, rows, 1,
                                actj, (const cplx*)w, d_ph);
             LAUNCHCHK();
             hipLaunchKernelGGL(k_orth_reduce_h, dim3(1), dim3(256), 0, st, nchunks, 1, (const cplx*)d_ph, d_h + j);
@@ -465,12 +478,8 @@ extern "C" int32_t nep_orth(const nep_cdouble* dV, int64_t ldv, int64_t rows, in
         const double eta = 1.0 / sqrt(2.0);
         const bool nt = orth_use_nt(rows, k, d_act != nullptr);
         while (true) {
-            if (nt)
-                hipLaunchKernelGGL(k_orth_dots<true>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv,
-                                   rows, (int)k, (const int64_t*)d_act, (const cplx*)w, d_ph);
-            else
-                hipLaunchKernelGGL(k_orth_dots<false>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv,
-                                   rows, (int)k, (const int64_t*)d_act, (const cplx*)w, d_ph);
+            ORTH_DOTS_LAUNCH(nt, rows >= ORTH_DPP_ROWS, dim3(nchunks, dots_grid_y(nchunks, k)), st, V, ldv,
+                             rows, (int)k, (const int64_t*)d_act, (const cplx*)w, d_ph);
             LAUNCHCHK();
             hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_h);
             LAUNCHCHK();
@@ -583,12 +592,8 @@ extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, in
     // BEFORE that update runs (Pythagoras, see k_orth_update), so a gated-off pass costs three launches that read one word
     for (int p = 0; p < npass; ++p) {
         const int* gate = p == 0 ? nullptr : d_state + 4 + p;       // "pass p ran and wants pass p + 1"
-        if (nt)
-            hipLaunchKernelGGL(k_orth_dots<true>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv, rows, (int)k,
-                               d_active_rows, (const cplx*)w, d_ph, gate, d_pww);
-        else
-            hipLaunchKernelGGL(k_orth_dots<false>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, V, ldv, rows, (int)k,
-                               d_active_rows, (const cplx*)w, d_ph, gate, d_pww);
+        ORTH_DOTS_LAUNCH(nt, rows >= ORTH_DPP_ROWS, dim3(nchunks, dots_grid_y(nchunks, k)), st, V, ldv, rows, (int)k,
+                         d_active_rows, (const cplx*)w, d_ph, gate, d_pww);
         LAUNCHCHK();
         hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_c, gate, out,
                            p == 0 ? 1 : 0, p == 0 ? d_state : (int*)nullptr, OrthDecide(), 0, (const double*)d_pww, d_ww);
@@ -631,8 +636,8 @@ extern "C" int32_t nep_gemv_h(const nep_cdouble* dV, int64_t ldv, int64_t rows, 
     if (rc) return rc;
     cplx* d_ph = (cplx*)g_orth_scratch.dptr;
     cplx* d_h = (cplx*)((char*)g_orth_scratch.dptr + off_h);
-    hipLaunchKernelGGL(k_orth_dots<false>, dim3(nchunks, dots_grid_y(nchunks, k)), dim3(256), 0, st, (const cplx*)dV, ldv, rows,
-                       (int)k, (const int64_t*)nullptr, (const cplx*)dw, d_ph);
+    ORTH_DOTS_LAUNCH(false, rows >= ORTH_DPP_ROWS, dim3(nchunks, dots_grid_y(nchunks, k)), st, (const cplx*)dV, ldv, rows,
+                     (int)k, (const int64_t*)nullptr, (const cplx*)dw, d_ph);
     LAUNCHCHK();
     hipLaunchKernelGGL(k_orth_reduce_h, dim3(k), dim3(256), 0, st, nchunks, (int)k, (const cplx*)d_ph, d_h);
     LAUNCHCHK();

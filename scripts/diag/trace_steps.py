@@ -1,0 +1,30 @@
+"""kernel sequence of single Arnoldi steps from a rocprofv3 kernel trace of repeated headline calls:
+python scripts/diag/trace_steps.py kernel_trace.csv [step ...]   (steps of the LAST run; default 10 50 90)
+A step is what the recurrence's queue runs between two consecutive k_orth_finish kernels; kernels of other queues that overlap are listed
+with a leading '|'."""
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+steps = [int(a) for a in sys.argv[2:]] or [10, 50, 90]
+fin = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_orth_finish")]
+# runs: groups of 100 finishes
+nrun = len(fin) // 100
+base = (nrun - 1) * 100
+qkey = "Queue_Id" if "Queue_Id" in rows[0] else None
+mainq = rows[fin[base]][qkey] if qkey else None
+def short(n):
+    n = n.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0][:44]
+for s in steps:
+    i0, i1 = fin[base + s - 2], fin[base + s - 1]
+    t0 = int(rows[i0]["End_Timestamp"])
+    print("== step %d: %.1f us from the end of the previous k_orth_finish to the end of this one" % (s, (int(rows[i1]["End_Timestamp"]) - t0) / 1e3))
+    prev_end = t0; busy = 0; n = 0
+    for r in rows[i0 + 1:i1 + 1]:
+        st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if qkey and r[qkey] != mainq:
+            print("   | %-44s start %7.1f dur %6.1f  (queue %s)" % (short(r["Kernel_Name"]), (st - t0) / 1e3, (en - st) / 1e3, r[qkey]))
+            continue
+        print("  %-46s start %7.1f gap %5.1f dur %6.1f" % (short(r["Kernel_Name"]), (st - t0) / 1e3, (st - prev_end) / 1e3, (en - st) / 1e3))
+        busy += en - st; prev_end = en; n += 1
+    print("   launches %d, kernel time %.1f us, gaps %.1f us" % (n, busy / 1e3, (prev_end - t0 - busy) / 1e3))
