@@ -414,6 +414,19 @@ int32_t nep_wep_schur_matvec(nep_wep_pinv* p, const nep_cdouble* d_sinv, int32_t
  * Sylvester solves at N = 37).  dWork: nz*nx + 4 nz + mm complex. */
 int32_t nep_wep_smw_matrix(nep_wep_sylv* s, nep_wep_pinv* p, int32_t N, const nep_cdouble* dKsc, double dd1, double dd2,
                            const nep_cdouble* d_sinv, nep_cdouble* dWork, nep_cdouble* dM, nep_stream stream);
+/* The same matrix in mode space (column kappa = G S(Tsolve(F^H E_kappa)), dG as in nep_wep_smw_apply): no back transform, the
+ * interior-region columns batched and restricted to the L grid columns of their region.  NEP_ERR_UNSUPPORTED like nep_wep_smw_apply. */
+int32_t nep_wep_smw_matrix_modes(nep_wep_sylv* s, nep_wep_pinv* p, int32_t N, const nep_cdouble* dKsc, double dd1, double dd2,
+                                 const nep_cdouble* d_sinv, const nep_cdouble* dG, nep_cdouble* dM, nep_stream stream);
+/* One application of the Sylvester-SMW preconditioner, in place on dR (nz nx) (solve_smw, waveguide_preconditioner.jl:323-421):
+ * dR <- Linv dR - Linv(sum_k alpha_k E_k), alpha = M^{-1} f(Linv dR).  Three transforms instead of four: the region means f are
+ * taken in mode space (f = G S, S = x-region sums of the tridiagonal solutions) and the second solve is subtracted in mode space;
+ * the expansion sum_k alpha_k E_k is formed inside the transform's loader from dKsc.  dMinvH: (M^{-1})^H, mm x mm column-major;
+ * dG (N x nz, row rz at dG + rz nz): G[rz, i] = mean over the z of region rz of exp(-2 pi i z i / nz) / sqrt(nz).
+ * NEP_ERR_UNSUPPORTED when nz has no odd coprime factorisation that fits the symmetric-half DFT kernel (use the pieces above). */
+int32_t nep_wep_smw_apply(nep_wep_sylv* s, nep_wep_pinv* p, int32_t N, const nep_cdouble* dKsc, double dd1, double dd2,
+                          const nep_cdouble* d_sinv, const nep_cdouble* dMinvH, const nep_cdouble* dG, nep_cdouble* dR,
+                          nep_stream stream);
 /* dOut (N x (N+4), column-major) = means of X over the N x (N+4) regions (interior regions L x L with L = nz/N, the four
  * boundary columns of X are regions of their own); needs nx = nz + 4 */
 int32_t nep_wep_region_means(int32_t nz, int32_t nx, int32_t N, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream);

@@ -123,6 +123,8 @@ SIGNATURES = {
     "nep_wep_pinv_apply": [c_vp, c_vp, c_vp, c_vp, c_vp],
     "nep_wep_schur_matvec": [c_vp, c_vp, c_i32, c_vp, c_vp, cdouble, cdouble, c_dbl, c_dbl, c_dbl, c_dbl, c_vp, c_vp, c_vp],
     "nep_wep_smw_matrix": [c_vp, c_vp, c_i32, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp],
+    "nep_wep_smw_matrix_modes": [c_vp, c_vp, c_i32, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp],
+    "nep_wep_smw_apply": [c_vp, c_vp, c_i32, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp, c_vp, c_vp],
     "nep_wep_region_means": [c_i32, c_i32, c_i32, c_vp, c_vp, c_vp],
     "nep_wep_region_expand": [c_i32, c_i32, c_i32, c_vp, c_vp, c_dbl, c_dbl, c_vp, c_vp, c_vp],
     "nep_iar_create": [c_vp, c_vp, c_i64, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, P(c_vp)],

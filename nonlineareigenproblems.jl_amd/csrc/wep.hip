@@ -32,6 +32,8 @@ struct nep_wep_sylv {
     cplx* d_m = nullptr;          // nz x ldt (x fastest, TLay order): forward multipliers m_j = b / dtilde_{j-1}
     cplx* d_dinv = nullptr;       // nz x nx: 1 / dtilde_j
     cplx* d_T = nullptr;          // nz x nx work (x fastest)
+    cplx* d_T2 = nullptr;         // second block of that shape + the small vectors of nep_wep_smw_apply (allocated on first use)
+    int smw_N = 0;                // region count the small vectors were sized for
     double b = 0.0;
 };
 
@@ -425,19 +427,37 @@ __device__ __forceinline__ void dft_sym_stages(cplx* __restrict__ xs, const cplx
     }
 }
 
-template <bool FWD, int COLS, int KB>
+// EXPAND (forward only): the input block is not read but formed on the fly -- the expansion sum_k alpha_k E_k of the Sylvester-SMW
+// correction (k_region_expand + the boundary pieces): Y[z, x] = alpha[region(z), region(x)] Ksc[z, x], minus pb[z] in the first and
+// pb[nz + z] in the last grid column; `src` is Ksc
+// EXPAND = 2 (set-up of the SMW matrix): a BATCH of unit expansions E_kappa, kappa = kap0 + blockIdx.y = rz + N rx of an interior
+// region (2 <= rx < N + 2): K_scaled on the L x L block of region (rz, rx), zero elsewhere, no boundary pieces.  Only the L columns
+// of region rx are transformed (grid.x = ceil(L / COLS)); batch item b writes to dst + b tstride (cleared by the caller).
+struct DftExpand { const cplx* alpha; const cplx* pb; int N, L; int kap0; int64_t tstride; };
+template <bool FWD, int COLS, int KB, int EXPAND = 0>
 __global__ __launch_bounds__(512) void k_dft_cols_sym(int nz, int nx, int N1, int N2, const int32_t* __restrict__ in_idx,
                                                        const int32_t* __restrict__ in_inv, const int32_t* __restrict__ out_idx,
                                                        const cplx* __restrict__ w1, const cplx* __restrict__ w2, double sgn,
                                                        double scale, const cplx* __restrict__ src, cplx* __restrict__ dst,
-                                                       int xcd_order, TLay tl) {
+                                                       int xcd_order, TLay tl, DftExpand ex = DftExpand{nullptr, nullptr, 0, 0, 0, 0}) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     cplx* xs = (cplx*)smem_raw;                 // [c][q], q = n1 N2 + n2, then q = k1 N2 + n2
     cplx* c1 = xs + (size_t)COLS * nz;          // (cos, sin)(2 pi e / N1)
     cplx* c2 = c1 + N1;
     WP(tp0);
-    const int x0 = dft_group(xcd_order) * COLS;
-    const int nc = min(COLS, nx - x0);
+    int x0, nc, rzb = 0;
+    if (EXPAND == 2) {
+        const int kap = ex.kap0 + (int)blockIdx.y;
+        const int rxb = kap / ex.N;
+        rzb = kap - rxb * ex.N;
+        const int xs0 = 2 + (rxb - 2) * ex.L;
+        x0 = xs0 + (int)blockIdx.x * COLS;
+        nc = min(COLS, xs0 + ex.L - x0);
+        dst += (int64_t)blockIdx.y * ex.tstride;
+    } else {
+        x0 = dft_group(xcd_order) * COLS;
+        nc = min(COLS, nx - x0);
+    }
     const int nt = blockDim.x;
     for (int t = threadIdx.x; t < N1; t += nt) c1[t] = cmake(w1[t].x, -w1[t].y);
     for (int t = threadIdx.x; t < N2; t += nt) c2[t] = cmake(w2[t].x, -w2[t].y);
@@ -452,7 +472,18 @@ __global__ __launch_bounds__(512) void k_dft_cols_sym(int nz, int nx, int N1, in
                 const int c = tc / nz, z = tc - c * nz;
                 on[u] = c < nc;
                 slot[u] = c * nz + in_inv[z];
-                v[u] = src[(int64_t)(x0 + (on[u] ? c : 0)) * nz + z];
+                const int x = x0 + (on[u] ? c : 0);
+                v[u] = src[(int64_t)x * nz + z];
+                if (EXPAND == 2) {
+                    if (z / ex.L != rzb) v[u] = cmake(0.0, 0.0);
+                }
+                if (EXPAND == 1) {
+                    const int rz = z / ex.L;
+                    const int rx = x < 2 ? x : (x >= nx - 2 ? ex.N + 2 + (x - (nx - 2)) : 2 + (x - 2) / ex.L);
+                    v[u] = cmul(ex.alpha[(int64_t)rx * ex.N + rz], v[u]);
+                    if (x == 0) v[u] = csub(v[u], ex.pb[z]);
+                    if (x == nx - 1) v[u] = csub(v[u], ex.pb[nz + z]);
+                }
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) if (live[u]) xs[slot[u]] = on[u] ? v[u] : cmake(0.0, 0.0);
@@ -535,13 +566,27 @@ __device__ __forceinline__ cplx shfl_c(cplx v, int src) { return cmake(__shfl(v.
 // ---- (d_i I + B) x = c for every mode i: one wave per mode, SEG consecutive x per lane -----------------------------------------
 // forward  y_j = c_j - m_j y_{j-1}            (y_{-1} = 0)
 // backward x_j = (y_j - b x_{j+1}) dinv_j     (x_{nx} = 0)
-template <int SEG>
+// MODE 0: in place on T.
+// MODE 1: in place on T, and the x-region sums of the solution of every mode, S[rx nz + i] = wx(rx) sum_{x in region rx} x_i[x]
+//         (regions as in k_region_means: columns 0, 1, nx-2, nx-1 alone with weight 1, N blocks of L columns with weight 1/L) -- the
+//         region means of the Sylvester-SMW correction are taken in MODE space from these (nep_wep_smw_apply).
+// MODE 2: right-hand sides from T2, result T <- T - solution (the second solve of nep_wep_smw_apply, subtracted in mode space).
+template <int SEG, int MODE>
 __global__ __launch_bounds__(256) void k_tridiag_modes(int nz, int nx, const cplx* __restrict__ mfac, const cplx* __restrict__ dinv,
-                                                       double b, cplx* __restrict__ T) {
+                                                       double b, cplx* __restrict__ T, const cplx* __restrict__ T2 = nullptr,
+                                                       cplx* __restrict__ S = nullptr, int N = 0, int L = 0, int64_t tstride = 0,
+                                                       int64_t sstride = 0) {
+    extern __shared__ __attribute__((aligned(16))) char tri_smem[];
+    T += (int64_t)blockIdx.y * tstride;              // batch of right-hand side blocks (MODE 1, set-up of the SMW matrix)
+    if (MODE == 1) S += (int64_t)blockIdx.y * sstride;
     const int lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (i >= nz) return;
+    const int wv = threadIdx.x >> 6;
+    const int iraw = blockIdx.x * 4 + wv;
+    if (MODE != 1 && iraw >= nz) return;
+    const bool valid = iraw < nz;                    // MODE 1 meets at a barrier: a wave past the last mode works on a copy of it
+    const int i = valid ? iraw : nz - 1;
     const int64_t base = (int64_t)i * (SEG >= 4 ? 64 * SEG : nx);
+    const cplx* __restrict__ Tin = MODE == 2 ? T2 : T;
     const int j0 = lane * SEG;
     cplx c[SEG], al[SEG];           // c: right-hand side, then y, then h;  al: forward multipliers, then g
     // (unconditional loads with a clamped index, masked afterwards: behind a per-entry `if (j < nx)` the 2 x SEG loads of a lane sat in
@@ -552,7 +597,7 @@ __global__ __launch_bounds__(256) void k_tridiag_modes(int nz, int nx, const cpl
         // SEG >= 4: entry lane * SEG + t sits at (t / 4) * 256 + lane * 4 + t % 4 of a row of 64 SEG entries (TLay); entries beyond nx are
         // allocated padding, read and then masked
         const int j = SEG >= 4 ? ((t >> 2) << 8) + (lane << 2) + (t & 3) : (j0 + t < nx ? j0 + t : nx - 1);
-        c[t] = T[base + j]; al[t] = mfac[base + j]; dv[t] = dinv[base + j];
+        c[t] = Tin[base + j]; al[t] = mfac[base + j]; dv[t] = dinv[base + j];
     }
 #pragma unroll
     for (int t = 0; t < SEG; ++t) {
@@ -593,12 +638,61 @@ __global__ __launch_bounds__(256) void k_tridiag_modes(int nz, int nx, const cpl
     }
     cplx carryb = shfl_c(incb.B, lane < 63 ? lane + 1 : 63);          // x at the start of the next lane's segment
     if (lane == 63) carryb = cmake(0.0, 0.0);
+    cplx* rowbuf = (cplx*)tri_smem + (size_t)wv * nx;          // MODE 1: the solution of this wave's mode in plain x order
+    cplx prev[SEG];
+    if (MODE == 2) {
+#pragma unroll
+        for (int t = 0; t < SEG; ++t)
+            prev[t] = T[base + (SEG >= 4 ? ((t >> 2) << 8) + (lane << 2) + (t & 3) : (j0 + t < nx ? j0 + t : nx - 1))];
+    }
 #pragma unroll
     for (int t = SEG - 1; t >= 0; --t) {
         cplx v = c[t]; cfma(v, al[t], carryb); carryb = v;
         const int j = j0 + t;
-        if (j < nx) T[base + (SEG >= 4 ? ((t >> 2) << 8) + (lane << 2) + (t & 3) : j)] = v;
+        if (MODE == 1) { if (j < nx) rowbuf[j] = v; }
+        if (MODE == 2) v = csub(prev[t], v);
+        if (j < nx && (MODE != 1 || valid)) T[base + (SEG >= 4 ? ((t >> 2) << 8) + (lane << 2) + (t & 3) : j)] = v;
     }
+    if (MODE == 1) {
+        __syncthreads();
+        for (int r = lane; r < N + 4; r += 64) {
+            int x0, len; double w;
+            if (r < 2) { x0 = r; len = 1; w = 1.0; }
+            else if (r >= N + 2) { x0 = nx - 2 + (r - (N + 2)); len = 1; w = 1.0; }
+            else { x0 = 2 + (r - 2) * L; len = L; w = 1.0 / L; }
+            cplx acc = cmake(0.0, 0.0);
+            for (int x = x0; x < x0 + len; ++x) { acc.x += rowbuf[x].x; acc.y += rowbuf[x].y; }
+            if (valid) S[(int64_t)r * nz + i] = cmake(w * acc.x, w * acc.y);
+        }
+    }
+}
+
+// f[rx N + rz] = sum_i G[rz nz + i] S[rx nz + i]: the region means of F U (U: mode-space solution, F: the inverse transform) from the
+// x-region sums S of the modes; G[rz, i] = mean over the z of region rz of F[z, i] (host, once per grid).  One wave per entry.
+__global__ __launch_bounds__(256) void k_wep_mode_means(int nz, int N, const cplx* __restrict__ G, const cplx* __restrict__ S,
+                                                        cplx* __restrict__ f, int64_t sstride = 0, int64_t fstride = 0) {
+    S += (int64_t)blockIdx.y * sstride; f += (int64_t)blockIdx.y * fstride;      // batch (set-up of the SMW matrix)
+    const int lane = threadIdx.x & 63;
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= N * (N + 4)) return;
+    const int rx = o / N, rz = o - rx * N;
+    const cplx* g = G + (int64_t)rz * nz;
+    const cplx* sc = S + (int64_t)rx * nz;
+    cplx acc = cmake(0.0, 0.0);
+    for (int i = lane; i < nz; i += 64) cfma(acc, g[i], sc[i]);
+    acc = group_reduce_sum<64>(acc);
+    if (lane == 0) f[o] = acc;
+}
+
+// the boundary pieces of the expansion (k_region_expand's eb) alone: eb[:, 0] = dd1 a[rz, 0] + dd2 a[rz, 1],
+// eb[:, 1] = dd2 a[rz, N+2] + dd1 a[rz, N+3]
+__global__ void k_region_eb(int nz, int N, int L, const cplx* __restrict__ alpha, double dd1, double dd2, cplx* __restrict__ eb) {
+    const int z = blockIdx.x * blockDim.x + threadIdx.x;
+    if (z >= nz) return;
+    const int rz = z / L;
+    const cplx a0 = alpha[rz], a1 = alpha[(int64_t)N + rz], a2 = alpha[(int64_t)(N + 2) * N + rz], a3 = alpha[(int64_t)(N + 3) * N + rz];
+    eb[z] = cmake(dd1 * a0.x + dd2 * a1.x, dd1 * a0.y + dd2 * a1.y);
+    eb[nz + z] = cmake(dd2 * a2.x + dd1 * a3.x, dd2 * a2.y + dd1 * a3.y);
 }
 
 // ---- region means / expansion of the SMW correction (waveguide_preconditioner.jl:263-304) -------------------------------------
@@ -745,7 +839,7 @@ extern "C" {
 int32_t nep_wep_sylv_destroy(nep_wep_sylv* s) {
     if (!s) return NEP_OK;
     nep_pool_free(s->d_in); nep_pool_free(s->d_out); nep_pool_free(s->d_in_inv); nep_pool_free(s->d_w1); nep_pool_free(s->d_w2);
-    nep_pool_free(s->d_m); nep_pool_free(s->d_dinv); nep_pool_free(s->d_T);
+    nep_pool_free(s->d_m); nep_pool_free(s->d_dinv); nep_pool_free(s->d_T); nep_pool_free(s->d_T2);
     delete s;
     return NEP_OK;
 }
@@ -1003,7 +1097,7 @@ int32_t nep_wep_sylv_solve(nep_wep_sylv* s, nep_cdouble* dX, nep_stream stream) 
     LAUNCHCHK();
     const int seg = (nx + 63) / 64;
     const dim3 g2((unsigned)((nz + 3) / 4));
-#define TRI(S_) hipLaunchKernelGGL((k_tridiag_modes<S_>), g2, dim3(256), 0, st, nz, nx, (const cplx*)s->d_m, (const cplx*)s->d_dinv, s->b, s->d_T)
+#define TRI(S_) hipLaunchKernelGGL((k_tridiag_modes<S_, 0>), g2, dim3(256), 0, st, nz, nx, (const cplx*)s->d_m, (const cplx*)s->d_dinv, s->b, s->d_T)
     if (seg <= 1) TRI(1); else if (seg <= 2) TRI(2); else if (seg <= 4) TRI(4); else if (seg <= 8) TRI(8); else if (seg <= 16) TRI(16); else TRI(32);
 #undef TRI
     LAUNCHCHK();
@@ -1016,6 +1110,114 @@ int32_t nep_wep_sylv_solve(nep_wep_sylv* s, nep_cdouble* dX, nep_stream stream) 
 #undef DFT_BY_COLS
 #undef DFT_LAUNCH
     return NEP_OK;
+}
+
+// ---- the whole Sylvester-SMW preconditioner application in THREE transforms (solve_smw, waveguide_preconditioner.jl:323-421) --------
+//   r <- Linv r - Linv(sum_k alpha_k E_k),   alpha = M^{-1} f(Linv r),   Linv = F Tsolve F^H
+// As issued through the pieces above this is four transforms, two tridiagonal sweeps and seven smaller kernels (region means of the
+// back-transformed block, expansion into a full block, boundary pieces, three axpy).  Linv is linear and the region means are a
+// linear functional of the MODE-space solution U1 = Tsolve(F^H r):  f = G S  with S the x-region sums of the modes (taken by the
+// tridiagonal kernel from the rows it has just solved) and G the z-region means of the columns of F.  So
+//   r <- F ( U1 - Tsolve(F^H E alpha) ):
+//   1. T  = F^H r                       k_dft_cols_sym<forward>
+//   2. U1 = Tsolve(T), S                k_tridiag_modes<.., 1>
+//   3. f = G S, alpha = M^{-1} f        k_wep_mode_means, nep_gemv_hd
+//   4. eb(alpha), pb = P^{-1}(sigma) eb k_region_eb, k_wep_pinv(_sym)
+//   5. T2 = F^H (E alpha)               k_dft_cols_sym<forward, EXPAND>: the expansion is formed in the loader from K_scaled, never stored
+//   6. T  = U1 - Tsolve(T2)             k_tridiag_modes<.., 2>
+//   7. r  = F T                         k_dft_cols_sym<inverse>
+// 9 launches and ~11 passes over the 16 nx nz byte block instead of 17 launches and ~24 passes.  Needs the symmetric-half DFT form (odd
+// coprime factors); NEP_ERR_UNSUPPORTED otherwise (the caller keeps the piecewise route).
+// dMinvH: (M^{-1})^H, mm x mm column-major (nep_gemv_hd applies its conjugate transpose); dG: N x nz, row rz at dG + rz nz.
+}  // extern "C"
+struct SymCfg { int cols = 0, kb = 0, threads = 0; size_t shm = 0; unsigned grid = 0; };
+static bool sylv_sym_cfg(const nep_wep_sylv* s, SymCfg& c) {
+    static const int symcfg = getenv("NEP_WEP_DFT_SYM") ? atoi(getenv("NEP_WEP_DFT_SYM")) : 22;
+    c.cols = symcfg / 10; c.kb = symcfg % 10;
+    if (!(symcfg && (s->N1 & 1) && (s->N2 & 1) && s->N1 >= 3 && s->N2 >= 3 && (c.cols == 2 || c.cols == 4) && (c.kb == 2 || c.kb == 3)))
+        return false;
+    const int H1 = (s->N1 - 1) / 2, H2 = (s->N2 - 1) / 2;
+    const int items = std::max(((H1 + c.kb - 1) / c.kb) * s->N2, ((H2 + c.kb - 1) / c.kb) * s->N1);
+    c.threads = (items + 63) / 64 * 64;
+    c.shm = ((size_t)c.cols * s->nz + s->N1 + s->N2) * sizeof(cplx);
+    if (c.threads > 512 || c.shm > 150 * 1024) return false;
+    c.grid = (unsigned)((s->nx + c.cols - 1) / c.cols);
+    return true;
+}
+template <bool FWD, int EXPAND>
+static int32_t sylv_dft_sym_launch(nep_wep_sylv* s, const SymCfg& c, double sgn, const cplx* src, cplx* dst, hipStream_t st, DftExpand ex,
+                                   int batch = 1) {
+    static const int xcd_order = getenv("NEP_WEP_DFT_XCD") ? atoi(getenv("NEP_WEP_DFT_XCD")) : 1;
+    const double scale = 1.0 / sqrt((double)s->nz);
+    const TLay tl{s->ldt, s->lseg};
+#define SYMX(C_, K_)                                                                                                          \
+    do {                                                                                                                      \
+        static thread_local bool attr = false;                                                                                \
+        if (!attr) { HIPCHK(hipFuncSetAttribute((const void*)k_dft_cols_sym<FWD, C_, K_, EXPAND>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; } \
+        const dim3 grid_ = EXPAND == 2 ? dim3((unsigned)((ex.L + C_ - 1) / C_), (unsigned)batch) : dim3(c.grid);                \
+        hipLaunchKernelGGL((k_dft_cols_sym<FWD, C_, K_, EXPAND>), grid_, dim3(c.threads), c.shm, st, s->nz, s->nx, s->N1, s->N2, \
+                           (const int32_t*)s->d_in, (const int32_t*)s->d_in_inv, (const int32_t*)s->d_out, (const cplx*)s->d_w1,  \
+                           (const cplx*)s->d_w2, sgn, scale, src, dst, xcd_order, tl, ex);                                     \
+    } while (0)
+    if (c.cols == 4 && c.kb == 2) SYMX(4, 2); else if (c.cols == 4) SYMX(4, 3); else if (c.kb == 2) SYMX(2, 2); else SYMX(2, 3);
+#undef SYMX
+    LAUNCHCHK();
+    return NEP_OK;
+}
+template <int MODE>
+static int32_t sylv_tri_launch(nep_wep_sylv* s, hipStream_t st, cplx* T, const cplx* T2, cplx* S, int N, int L, int batch = 1,
+                               int64_t tstride = 0, int64_t sstride = 0) {
+    const int nz = s->nz, nx = s->nx;
+    const int seg = (nx + 63) / 64;
+    const dim3 g2((unsigned)((nz + 3) / 4), (unsigned)batch);
+    const size_t shm = MODE == 1 ? (size_t)4 * nx * sizeof(cplx) : 0;
+#define TRIX(S_)                                                                                                              \
+    do {                                                                                                                      \
+        static thread_local bool attr = false;                                                                                \
+        if (MODE == 1 && !attr) { HIPCHK(hipFuncSetAttribute((const void*)k_tridiag_modes<S_, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; } \
+        hipLaunchKernelGGL((k_tridiag_modes<S_, MODE>), g2, dim3(256), shm, st, nz, nx, (const cplx*)s->d_m, (const cplx*)s->d_dinv, s->b, T, T2, S, N, L, tstride, sstride); \
+    } while (0)
+    if (seg <= 1) TRIX(1); else if (seg <= 2) TRIX(2); else if (seg <= 4) TRIX(4); else if (seg <= 8) TRIX(8); else if (seg <= 16) TRIX(16); else TRIX(32);
+#undef TRIX
+    LAUNCHCHK();
+    return NEP_OK;
+}
+extern "C" {
+int32_t nep_gemv_hd(const nep_cdouble* dA, int64_t lda, int64_t rows, int32_t k, const nep_cdouble* dx,
+                    const nep_cdouble* dd, nep_cdouble* dy, nep_stream stream);
+
+int32_t nep_wep_smw_apply(nep_wep_sylv* s, nep_wep_pinv* p, int32_t N, const nep_cdouble* dKsc, double dd1, double dd2,
+                          const nep_cdouble* d_sinv, const nep_cdouble* dMinvH, const nep_cdouble* dG, nep_cdouble* dR,
+                          nep_stream stream) {
+    ARGCHK(s && p && dKsc && d_sinv && dMinvH && dG && dR && N >= 1 && s->nz % N == 0 && s->nx == s->nz + 4 && p->nz == s->nz);
+    SymCfg c;
+    if (!sylv_sym_cfg(s, c) || (size_t)4 * s->nx * sizeof(cplx) > 150 * 1024) return NEP_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const int nz = s->nz, nx = s->nx, mm = N * (N + 4), L = nz / N;
+    const size_t tsz = (size_t)nz * s->ldt;
+    // second transposed block + S (nz (N+4)) + f, alpha (mm each) + eb, pb (2 nz each): one pool block, kept with the plan
+    const size_t small = (size_t)nz * (N + 4) + 2 * (size_t)mm + 4 * (size_t)nz;
+    if (!s->d_T2 || s->smw_N != N) {
+        if (s->d_T2) { nep_pool_free(s->d_T2); s->d_T2 = nullptr; }
+        int rc = nep_pool_alloc((void**)&s->d_T2, (tsz + small) * sizeof(cplx));
+        if (rc) return rc;
+        s->smw_N = N;
+    }
+    cplx* T2 = s->d_T2; cplx* S = T2 + tsz; cplx* f = S + (size_t)nz * (N + 4); cplx* al = f + mm; cplx* eb = al + mm; cplx* pb = eb + 2 * (size_t)nz;
+    const DftExpand none{nullptr, nullptr, 0, 0, 0, 0};
+    int32_t rc;
+    if ((rc = sylv_dft_sym_launch<true, 0>(s, c, -1.0, (const cplx*)dR, s->d_T, st, none))) return rc;              // 1
+    if ((rc = sylv_tri_launch<1>(s, st, s->d_T, nullptr, S, N, L))) return rc;                                      // 2
+    hipLaunchKernelGGL(k_wep_mode_means, dim3((unsigned)((mm + 3) / 4)), dim3(256), 0, st, nz, (int)N, (const cplx*)dG, (const cplx*)S, f);
+    LAUNCHCHK();                                                                                                    // 3
+    if ((rc = nep_gemv_hd(dMinvH, mm, mm, mm, (const nep_cdouble*)f, nullptr, (nep_cdouble*)al, stream))) return rc;
+    hipLaunchKernelGGL(k_region_eb, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, nz, (int)N, L, (const cplx*)al, dd1, dd2, eb);
+    LAUNCHCHK();                                                                                                    // 4
+    if ((rc = pinv_apply_impl(p, d_sinv, (const nep_cdouble*)eb, (nep_cdouble*)pb, stream, nullptr, 0, 0.0, 0.0))) return rc;
+    const DftExpand ex{al, pb, (int)N, L, 0, 0};
+    if ((rc = sylv_dft_sym_launch<true, 1>(s, c, -1.0, (const cplx*)dKsc, T2, st, ex))) return rc;                  // 5
+    if ((rc = sylv_tri_launch<2>(s, st, s->d_T, T2, nullptr, N, L))) return rc;                                     // 6
+    return sylv_dft_sym_launch<false, 0>(s, c, 1.0, (const cplx*)s->d_T, (cplx*)dR, st, none);                      // 7
 }
 
 // alpha <- e_kappa (N x (N+4) block as a vector of mm entries)
@@ -1057,6 +1259,55 @@ int32_t nep_wep_smw_matrix(nep_wep_sylv* s, nep_wep_pinv* p, int32_t N, const ne
         if (rc) return rc;
     }
     return NEP_OK;
+}
+
+// The same matrix through the pieces of nep_wep_smw_apply: column kappa = G S(Tsolve(F^H E_kappa)) -- no back transform, no
+// expanded block, and for the N^2 interior regions (E_kappa = K_scaled on one L x L block, no boundary pieces) only the L columns of
+// the region are transformed, `batch` columns of the matrix per launch (the tridiagonal kernel alone has 250 workgroups per
+// right-hand side block: one column at a time left the chip three quarters empty).  The 4 N boundary-region columns take the
+// general loader (EXPAND = 1) one at a time.  NEP_ERR_UNSUPPORTED: see nep_wep_smw_apply.
+int32_t nep_wep_smw_matrix_modes(nep_wep_sylv* s, nep_wep_pinv* p, int32_t N, const nep_cdouble* dKsc, double dd1, double dd2,
+                                 const nep_cdouble* d_sinv, const nep_cdouble* dG, nep_cdouble* dM, nep_stream stream) {
+    ARGCHK(s && p && dKsc && d_sinv && dG && dM && N >= 1 && s->nz % N == 0 && s->nx == s->nz + 4 && p->nz == s->nz);
+    SymCfg c;
+    if (!sylv_sym_cfg(s, c) || (size_t)4 * s->nx * sizeof(cplx) > 150 * 1024) return NEP_ERR_UNSUPPORTED;
+    hipStream_t st = as_stream(stream);
+    const int nz = s->nz, mm = N * (N + 4), L = nz / N;
+    const int64_t tsz = (int64_t)nz * s->ldt, ssz = (int64_t)nz * (N + 4);
+    int B = getenv("NEP_WEP_SMW_BATCH") ? atoi(getenv("NEP_WEP_SMW_BATCH")) : 16;
+    B = std::max(1, std::min(B, (int)std::max<int64_t>(1, ((int64_t)1 << 30) / (tsz * (int64_t)sizeof(cplx)))));
+    cplx* work = nullptr;
+    int32_t rc = nep_pool_alloc((void**)&work, ((size_t)B * (tsz + ssz) + mm + 4 * (size_t)nz) * sizeof(cplx));
+    if (rc) return rc;
+    cplx* Tb = work; cplx* Sb = Tb + (size_t)B * tsz; cplx* alpha = Sb + (size_t)B * ssz; cplx* eb = alpha + mm; cplx* pb = eb + 2 * (size_t)nz;
+    auto done = [&](int32_t code) { nep_pool_free_on(work, st, true); return code; };
+    const dim3 gm((unsigned)((mm + 3) / 4));
+    // interior regions, kappa = rz + N rx with 2 <= rx < N + 2: consecutive kappa, B per round
+    for (int kap0 = 2 * N; kap0 < (N + 2) * N; kap0 += B) {
+        const int nb = std::min(B, (N + 2) * N - kap0);
+        hipError_t e = hipMemsetAsync(Tb, 0, (size_t)nb * tsz * sizeof(cplx), st);
+        if (e != hipSuccess) { nep_set_error("nep_wep_smw_matrix_modes: %s", hipGetErrorString(e)); return done(NEP_ERR_HIP); }
+        const DftExpand ex{nullptr, nullptr, (int)N, L, kap0, tsz};
+        if ((rc = sylv_dft_sym_launch<true, 2>(s, c, -1.0, (const cplx*)dKsc, Tb, st, ex, nb))) return done(rc);
+        if ((rc = sylv_tri_launch<1>(s, st, Tb, nullptr, Sb, N, L, nb, tsz, ssz))) return done(rc);
+        hipLaunchKernelGGL(k_wep_mode_means, dim3(gm.x, (unsigned)nb), dim3(256), 0, st, nz, (int)N, (const cplx*)dG, (const cplx*)Sb,
+                           (cplx*)dM + (size_t)kap0 * mm, ssz, (int64_t)mm);
+        if (hipGetLastError() != hipSuccess) { nep_set_error("nep_wep_smw_matrix_modes: launch failed"); return done(NEP_ERR_HIP); }
+    }
+    // the four boundary-region columns of x: unit alpha through the general loader (boundary pieces included)
+    for (int kappa = 0; kappa < mm; ++kappa) {
+        if (kappa >= 2 * N && kappa < (N + 2) * N) continue;
+        hipLaunchKernelGGL(k_unit_vector, dim3((mm + 255) / 256), dim3(256), 0, st, mm, kappa, alpha);
+        hipLaunchKernelGGL(k_region_eb, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, nz, (int)N, L, (const cplx*)alpha, dd1, dd2, eb);
+        if ((rc = pinv_apply_impl(p, d_sinv, (const nep_cdouble*)eb, (nep_cdouble*)pb, stream, nullptr, 0, 0.0, 0.0))) return done(rc);
+        const DftExpand ex{alpha, pb, (int)N, L, 0, 0};
+        if ((rc = sylv_dft_sym_launch<true, 1>(s, c, -1.0, (const cplx*)dKsc, Tb, st, ex))) return done(rc);
+        if ((rc = sylv_tri_launch<1>(s, st, Tb, nullptr, Sb, N, L))) return done(rc);
+        hipLaunchKernelGGL(k_wep_mode_means, gm, dim3(256), 0, st, nz, (int)N, (const cplx*)dG, (const cplx*)Sb, (cplx*)dM + (size_t)kappa * mm,
+                           (int64_t)0, (int64_t)0);
+        if (hipGetLastError() != hipSuccess) { nep_set_error("nep_wep_smw_matrix_modes: launch failed"); return done(NEP_ERR_HIP); }
+    }
+    return done(NEP_OK);
 }
 
 int32_t nep_wep_region_means(int32_t nz, int32_t nx, int32_t N, const nep_cdouble* dX, nep_cdouble* dOut, nep_stream stream) {

@@ -149,6 +149,17 @@ def _corner_derivs(wd, lam, k, scale=1.0):
     return D
 
 
+def _corner_values(wd, lams):
+    """S[r, s] = s_r(lam_s) for all 2 nz corner functions and all shifts at once: column s equals _corner_derivs(wd, lam_s, 1)[:, 0]
+    (the residual batches of a convergence check evaluate up to 100 shifts: 44 us per call of the scalar form)"""
+    la = np.asarray(lams, dtype=np.complex128).reshape(1, -1)
+    b = np.concatenate([wd.b, wd.b]).reshape(-1, 1); c = np.concatenate([wd.cM, wd.cP]).astype(np.complex128).reshape(-1, 1)
+    q0 = la * la + b * la + c
+    s0 = np.sqrt(q0)
+    sg = np.sign(q0.imag); sg[sg == 0] = 1.0
+    return 1j * (sg * s0) + wd.d0
+
+
 class WEP(AbstractSPMF):
     """Waveguide eigenvalue problem on the device: 3 real sparse terms (stacked CSR / SELL) + factored corner.
     Mirrors `nep_gallery(WEP, nx=, nz=, benchmark_problem=, neptype=, delta=)` (GalleryWaveguide.jl:60-94); both
@@ -290,7 +301,27 @@ class WEP(AbstractSPMF):
             M = M - sp.bmat([[sp.csc_matrix((N, N)), None], [None, corner_spmf]], format="csc")
         return sp.csc_matrix(M + Cn)
 
-    def resid_norms(self, lams, QT):
+    def resid_norms_async(self, lams, QT):
+        """enqueues the residual batch and the corner term; the returned object's get() runs the two synchronising read-backs
+        (tiar's deferred convergence checks: the host prepares check k + 1 while the device works on check k)"""
+        from .nep import PendingNorms
+        if hasattr(QT, "cpu_matrix") or os.environ.get("NEP_WEP_RESID_SPLIT", "1") == "0":
+            return PendingNorms(result=self.resid_norms(lams, QT))
+        fin = self.resid_norms(lams, QT, _defer=True)
+        ev = torch.cuda.Event(); ev.record()
+
+        class _P:
+            def __init__(s_):
+                s_.result = None
+            def ready(s_):
+                return s_.result is not None or ev.query()
+            def get(s_):
+                if s_.result is None:
+                    s_.result = fin()
+                return s_.result
+        return _P()
+
+    def resid_norms(self, lams, QT, _defer=False):
         """(||M(lam_s) q_s||, ||q_s||, F) for the k columns of the row-major block QT.  ONE pass over the three sparse terms
         (nep_resid_split_dev) gives the squared norms of the SPMF residual over the N interior rows, the squared norms of Q
         and the residual rows of the 2 nz boundary unknowns; the dense corner term (Waveguide.jl:351-374) is added to that
@@ -310,7 +341,7 @@ class WEP(AbstractSPMF):
             tail = torch.empty((k, 2 * nz), dtype=CDT, device="cuda")
             out = self.dev.resid_batch_cm(F, Qc, k, row0=N, tail=tail)
             Rm, RmH = self._corner_dev()
-            S = np.column_stack([_corner_derivs(self.wd, l, 1)[:, 0] for l in la]) / nz
+            S = _corner_values(self.wd, la) / nz
             Sd = to_dev(S)
             P = torch.empty((k, nz), dtype=CDT, device="cuda")
             Y = torch.empty((k, nz), dtype=CDT, device="cuda")
@@ -339,7 +370,7 @@ class WEP(AbstractSPMF):
             tail0 = N
         # corner: R[N:, s] += Rfull diag(s(lam_s)) Rfull^H Q[N:, s] / nz
         Rm, RmH = self._corner_dev()
-        S = np.column_stack([_corner_derivs(self.wd, l, 1)[:, 0] for l in la]) / nz      # 2nz x k
+        S = _corner_values(self.wd, la) / nz      # 2nz x k
         Sd = to_dev(S)
         P = torch.empty((k, nz), dtype=CDT, device="cuda")
         Y = torch.empty((nz, k), dtype=CDT, device="cuda")
@@ -353,9 +384,13 @@ class WEP(AbstractSPMF):
             check(lib.nep_axpy(nz * k, _lib.cd(1.0), c_vp(Y.data_ptr()), c_vp(RT.data_ptr() + 16 * (tail0 + half * nz) * k), st))
         rn = np.empty(k); qn = np.empty(k)
         if split:
-            check(lib.nep_rowmajor_colnorms(2 * nz, k, c_vp(RT.data_ptr()), k, hptr(rn), st))      # (synchronises)
-            o = out.cpu().numpy()
-            rn = np.sqrt(o[:k] + rn ** 2); qn = np.sqrt(o[k:])
+            def finish():
+                check(lib.nep_rowmajor_colnorms(2 * nz, k, c_vp(RT.data_ptr()), k, hptr(rn), st))      # (synchronises)
+                o = out.cpu().numpy()
+                return np.sqrt(o[:k] + rn ** 2), np.sqrt(o[k:]), F
+            if _defer:
+                return finish
+            return finish()
         else:
             check(lib.nep_rowmajor_colnorms(n, k, c_vp(RT.data_ptr()), k, hptr(rn), st))
             check(lib.nep_rowmajor_colnorms(n, k, c_vp(QT.data_ptr()), ldq, hptr(qn), st))

@@ -249,7 +249,12 @@ class WEPGMRESLinSolver(LinSolver):
         self.iterations = []
 
         self._graph = None
-        if self.gmres._Pl_call is not None and os.environ.get("NEP_WEP_GRAPH", "1") != "0":
+        # one operator step = 2 foreign calls (nep_wep_schur_matvec, nep_wep_smw_apply: 11 launches) when both fused forms apply:
+        # issued directly, without the copy in / copy out of a graph on fixed buffers (measured on C5: 1.29 s against 1.35 s);
+        # the graph remains for the piecewise routes (~30 launches from Python per step)
+        Pl = self.gmres._Pl_call
+        direct = self.ops.stencil is not None and isinstance(Pl, WEPPreconditioner) and Pl.fused_available()
+        if Pl is not None and os.environ.get("NEP_WEP_GRAPH", "0" if direct else "1") != "0":
             self._capture_step()
 
         def inner(rhs, q, tol, sweep=False):
@@ -389,6 +394,8 @@ class WEPPreconditioner:
         self.eb = e(2, nz)                     # nz x 2 = [e_minus, e_plus]
         self.pb = e(2 * nz)
         self.MinvH = None
+        self._G = None
+        self._fused = False if os.environ.get("NEP_WEP_SMW_FUSED", "1") == "0" else None     # None: not tried yet
         self._generate()
 
     def __del__(self):
@@ -455,9 +462,19 @@ class WEPPreconditioner:
         if self.sylv is not None and plan is not None:
             # all mm columns inside the library (one foreign call instead of ~8 per column)
             nz, nx = self.nep.nz, self.nep.nx
-            work = torch.empty(nz * nx + 4 * nz + mm, dtype=CDT, device="cuda")
-            check(lib.nep_wep_smw_matrix(self.sylv, plan, N, _p(self.Ksc), self.dd1, self.dd2, _p(self.ops.sinv), _p(work), _p(Mdev),
-                                         stream_ptr()))
+            st = _lib.NEP_ERR_UNSUPPORTED
+            if self._fused is not False:
+                # mode-space form (no back transforms, interior columns batched); falls through when the grid does not take it
+                if self._G is None:
+                    self._G = self._mode_means_matrix()
+                st = lib.nep_wep_smw_matrix_modes(self.sylv, plan, N, _p(self.Ksc), self.dd1, self.dd2, _p(self.ops.sinv), _p(self._G),
+                                                  _p(Mdev), stream_ptr())
+                if st not in (0, _lib.NEP_ERR_UNSUPPORTED):
+                    check(st)
+            if st != 0:
+                work = torch.empty(nz * nx + 4 * nz + mm, dtype=CDT, device="cuda")
+                check(lib.nep_wep_smw_matrix(self.sylv, plan, N, _p(self.Ksc), self.dd1, self.dd2, _p(self.ops.sinv), _p(work), _p(Mdev),
+                                             stream_ptr()))
             self._M = to_host(Mdev) + np.eye(mm)
             self.MinvH = to_dev(np.linalg.inv(self._M).conj().T)
             return
@@ -480,9 +497,39 @@ class WEPPreconditioner:
             self._cond = float(np.linalg.cond(self._M))
         return self._cond
 
+    def _mode_means_matrix(self):
+        """G (N x nz): mean over the z of region rz of column i of the inverse transform F[z, i] = exp(-2 pi i z i / nz) / sqrt(nz)
+        (what nep_wep_sylv_solve's last kernel applies) -- the region means of F U are G (U summed over the x-regions)"""
+        nz, N, L = self.nep.nz, self.N, self.L
+        i = np.arange(nz)
+        # mean over z = rz L + l of w^(z i), w = exp(-2 pi i / nz):  w^(rz L i) * (sum_l w^(l i)) / L  (exponents reduced mod nz)
+        inner = np.exp(-2j * np.pi * (np.outer(np.arange(L), i) % nz) / nz).sum(axis=0) / L                 # nz
+        outer = np.exp(-2j * np.pi * (np.outer(np.arange(N) * L, i) % nz) / nz)                              # N x nz
+        G = outer * inner[None, :] / np.sqrt(nz)
+        return to_dev(np.ascontiguousarray(G).T)                                       # to_dev stores (rows, cols) column-major
+
+    def fused_available(self):
+        """True when nep_wep_smw_apply takes this grid (tried once on a zero vector)"""
+        if self._fused is None:
+            self(torch.zeros(self.nep.nz * self.nep.nx, dtype=CDT, device="cuda"))
+        return self._fused is True
+
     def __call__(self, r):
         """solve_smw (waveguide_preconditioner.jl:323-421), in place on the device vector r"""
         nz, nx, N, mm = self.nep.nz, self.nep.nx, self.N, self.mm
+        if self.sylv is not None and self._fused is not False:
+            plan = self.nep._pinv_plan()
+            if plan is not None:
+                if self._G is None:
+                    self._G = self._mode_means_matrix()
+                st = lib.nep_wep_smw_apply(self.sylv, plan, N, _p(self.Ksc), self.dd1, self.dd2, _p(self.ops.sinv), _p(self.MinvH),
+                                           _p(self._G), _p(r), stream_ptr())
+                if st == 0:
+                    self._fused = True
+                    return r
+                if st != _lib.NEP_ERR_UNSUPPORTED:
+                    check(st)
+            self._fused = False                                                # piecewise route from now on
         self.linv(r)                                                           # C = Linv r
         self.functionals(r, self.fb)
         check(lib.nep_gemv_hd(c_vp(self.MinvH.data_ptr()), mm, mm, mm, c_vp(self.fb.data_ptr()), None, c_vp(self.al.data_ptr()),

@@ -1127,6 +1127,48 @@ def test_wep_schur_matvec_stencil_equals_assembled(na, nx, nz):
     assert np.linalg.norm(a - ref) <= 1e-12 * np.linalg.norm(ref)
 
 
+@pytest.mark.parametrize("nz,N", [(15, 15), (15, 5), (105, 21), (111, 37), (999, 37)])
+def test_wep_preconditioner_three_transform_form(na, nz, N):
+    """solve_smw (waveguide_preconditioner.jl:323-421) through nep_wep_smw_apply -- three transforms, region means taken in mode
+    space, the expansion formed inside the transform's loader, the second solve subtracted in mode space -- against the piecewise
+    route (four transforms; NEP_WEP_SMW_FUSED=0) on the same vector, and, with one region per grid row (N = nz), against the
+    property that the preconditioner then inverts SchurMatVec exactly"""
+    import torch
+    from nep_amd import wep_linsolvers as wl
+    nx = nz + 4
+    nep = na.nep_gallery("WEP", nx=nx, nz=nz, benchmark_problem="JARLEBRING")
+    lam = -1.3 - 0.7j
+    P = na.wep_generate_preconditioner(nep, N, lam)
+    # the SMW matrix itself: mode-space columns (nep_wep_smw_matrix_modes, interior regions batched) against the piecewise columns
+    os.environ["NEP_WEP_SMW_FUSED"] = "0"
+    try:
+        P0 = na.wep_generate_preconditioner(nep, N, lam)
+    finally:
+        del os.environ["NEP_WEP_SMW_FUSED"]
+    assert P0._fused is False and P._G is not None
+    assert np.linalg.norm(P._M - P0._M) <= 1e-12 * np.linalg.norm(P0._M), np.linalg.norm(P._M - P0._M) / np.linalg.norm(P0._M)
+    rng = np.random.default_rng(nz + N)
+    v = rng.standard_normal(nx * nz) + 1j * rng.standard_normal(nx * nz)
+    r1 = na.to_dev(v)[0].clone(); r2 = na.to_dev(v)[0].clone()
+    P(r1)
+    assert P._fused is True, "the three-transform form was not taken"
+    P._fused = False
+    P(r2)
+    P._fused = None
+    torch.cuda.synchronize()
+    a = na.to_host(r1.reshape(1, -1))[:, 0]; b = na.to_host(r2.reshape(1, -1))[:, 0]
+    assert np.linalg.norm(a - b) <= 1e-12 * np.linalg.norm(b), np.linalg.norm(a - b) / np.linalg.norm(b)
+    r3 = na.to_dev(v)[0].clone()
+    P(r3); torch.cuda.synchronize()
+    assert np.array_equal(na.to_host(r3.reshape(1, -1))[:, 0], a)            # same bits on a repeat
+    if N == nz:
+        ops = wl.SchurOps(nep, lam)
+        out = torch.empty_like(r1)
+        ops.matvec(na.to_dev(v)[0], out)
+        w = P(out); torch.cuda.synchronize()
+        assert np.linalg.norm(na.to_host(w.reshape(1, -1))[:, 0] - v) <= 1e-11 * np.linalg.norm(v)
+
+
 @pytest.mark.parametrize("nz,nx", [(7, 11), (105, 109), (299, 303), (60, 64), (111, 115), (999, 1003)])
 def test_wep_sylvester_solve_pfa_vs_numpy(na, nz, nx):
     """nep_wep_sylv_solve (prime-factor DFT along z + per-mode tridiagonal scans along x, csrc/wep.hip) against the dense
