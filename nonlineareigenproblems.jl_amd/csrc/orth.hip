@@ -108,12 +108,20 @@ __global__ __launch_bounds__(256) void k_orth_dots(const cplx* __restrict__ V, i
 #pragma unroll
         for (int jj = 0; jj < DOT_CG; ++jj) accs[jj] = cmake(0.0, 0.0);
         if (grp_on) {
+            // (a column that has no active row on this chunk is skipped by a wave-uniform branch: nothing waits inside it, the
+            // loads of the other columns stay in flight together; without the skip the staircase of iar read 998 MB for 830 MB
+            // algorithmic at step 100 -- the half-empty column groups along the stairs, profiles/pmc2)
             cplx v[DOT_CG][DOT_RPT];
 #pragma unroll
             for (int jj = 0; jj < DOT_CG; ++jj) {
-                const cplx* vp = V + (int64_t)(j0 + jj < k ? j0 + jj : k - 1) * ldv;
+                if (r0 < actv[jj]) {
+                    const cplx* vp = V + (int64_t)(j0 + jj) * ldv;
 #pragma unroll
-                for (int i = 0; i < DOT_RPT; ++i) v[jj][i] = vload<NT>(vp + rc[i]);
+                    for (int i = 0; i < DOT_RPT; ++i) v[jj][i] = vload<NT>(vp + rc[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < DOT_RPT; ++i) v[jj][i] = cmake(0.0, 0.0);
+                }
             }
 #pragma unroll
             for (int jj = 0; jj < DOT_CG; ++jj) {

@@ -74,9 +74,14 @@ def bench_orth(na, rows, k, label, reps, active=None):
     w0 = crandn(rows)
     w = w0.clone()
 
+    # the asynchronous path (nep_orth_dev: what iar / GMRES issue and what bench.py's `roofline` times) so that the PMC passes of
+    # scripts/pmc_collect.sh count the kernels of the bench line: k_orth_dots + k_orth_update_rows
+    out = torch.empty(k + 2, dtype=torch.complex128, device="cuda")
+    act_dev = torch.from_numpy(np.asarray(active, dtype=np.int64)).to("cuda") if active is not None else None
+
     def run():
         na.dense.copy(w0, w)
-        na.orthogonalize_and_normalize(V, w, k, active_rows=active, method=1)    # one CGS pass = dots + update
+        na.dense.orthogonalize_and_normalize_dev(V, w, k, out, rows=rows, ldv=rows, active_dev=act_dev, method=1)    # one CGS pass
     t0 = time.perf_counter(); run(); torch.cuda.synchronize()
     t = time.perf_counter()
     for _ in range(reps):
