@@ -678,8 +678,17 @@ __global__ __launch_bounds__(256) void k_wep_mode_means(int nz, int N, const cpl
     const int rx = o / N, rz = o - rx * N;
     const cplx* g = G + (int64_t)rz * nz;
     const cplx* sc = S + (int64_t)rx * nz;
-    cplx acc = cmake(0.0, 0.0);
-    for (int i = lane; i < nz; i += 64) cfma(acc, g[i], sc[i]);
+    cplx acc = cmake(0.0, 0.0), acc2 = cmake(0.0, 0.0);        // eight trips in flight, two accumulators, fixed order
+    int i = lane;
+    for (; i + 7 * 64 < nz; i += 8 * 64) {
+        cplx gv[8], sv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { gv[u] = g[i + u * 64]; sv[u] = sc[i + u * 64]; }
+#pragma unroll
+        for (int u = 0; u < 8; u += 2) { cfma(acc, gv[u], sv[u]); cfma(acc2, gv[u + 1], sv[u + 1]); }
+    }
+    for (; i < nz; i += 64) cfma(acc, g[i], sc[i]);
+    acc = cadd(acc, acc2);
     acc = group_reduce_sum<64>(acc);
     if (lane == 0) f[o] = acc;
 }
@@ -745,9 +754,16 @@ __global__ void k_region_expand(int nz, int nx, int N, int L, const cplx* __rest
 // DFT -> bb .* -> reverse, both DFTs by the same prime-factor scheme out of LDS.  Replaces four nz x nz dense GEMVs per application.
 // entry i of the half's input: x[i], or -- gathered from the interior block X (nz x gnx, z fastest) -- the boundary functional C2T of
 // generate_fd_boundary_mat: gd1 X[i, 0] + gd2 X[i, 1] (minus half), gd1 X[i, nx-1] + gd2 X[i, nx-2] (plus half)
+// ... or, gnx < 0 (nep_wep_smw_apply): the boundary pieces of the expansion formed on the fly from the region coefficients alpha = gX
+// (N x (N+4), N = -gnx):  minus half gd1 a[rz, 0] + gd2 a[rz, 1],  plus half gd2 a[rz, N+2] + gd1 a[rz, N+3]  (k_region_eb)
 __device__ __forceinline__ cplx pinv_in(const cplx* __restrict__ xh, const cplx* __restrict__ gX, int gnx, double gd1, double gd2,
                                         int half, int nz, int i) {
     if (!gX) return xh[i];
+    if (gnx < 0) {
+        const int N = -gnx, rz = i / (nz / N);
+        const cplx a = gX[(int64_t)(half ? N + 2 : 0) * N + rz], b = gX[(int64_t)(half ? N + 3 : 1) * N + rz];
+        return half ? cmake(fma(gd2, a.x, gd1 * b.x), fma(gd2, a.y, gd1 * b.y)) : cmake(fma(gd1, a.x, gd2 * b.x), fma(gd1, a.y, gd2 * b.y));
+    }
     const cplx u = gX[(int64_t)(half ? gnx - 1 : 0) * nz + i], v = gX[(int64_t)(half ? gnx - 2 : 1) * nz + i];
     return cmake(fma(gd1, u.x, gd2 * v.x), fma(gd1, u.y, gd2 * v.y));
 }
@@ -1122,11 +1138,11 @@ int32_t nep_wep_sylv_solve(nep_wep_sylv* s, nep_cdouble* dX, nep_stream stream) 
 //   1. T  = F^H r                       k_dft_cols_sym<forward>
 //   2. U1 = Tsolve(T), S                k_tridiag_modes<.., 1>
 //   3. f = G S, alpha = M^{-1} f        k_wep_mode_means, nep_gemv_hd
-//   4. eb(alpha), pb = P^{-1}(sigma) eb k_region_eb, k_wep_pinv(_sym)
+//   4. pb = P^{-1}(sigma) eb(alpha)     k_wep_pinv(_sym), the boundary pieces eb formed in its loader
 //   5. T2 = F^H (E alpha)               k_dft_cols_sym<forward, EXPAND>: the expansion is formed in the loader from K_scaled, never stored
 //   6. T  = U1 - Tsolve(T2)             k_tridiag_modes<.., 2>
 //   7. r  = F T                         k_dft_cols_sym<inverse>
-// 9 launches and ~11 passes over the 16 nx nz byte block instead of 17 launches and ~24 passes.  Needs the symmetric-half DFT form (odd
+// 8 launches and ~11 passes over the 16 nx nz byte block instead of 17 launches and ~24 passes.  Needs the symmetric-half DFT form (odd
 // coprime factors); NEP_ERR_UNSUPPORTED otherwise (the caller keeps the piecewise route).
 // dMinvH: (M^{-1})^H, mm x mm column-major (nep_gemv_hd applies its conjugate transpose); dG: N x nz, row rz at dG + rz nz.
 }  // extern "C"
@@ -1211,9 +1227,8 @@ int32_t nep_wep_smw_apply(nep_wep_sylv* s, nep_wep_pinv* p, int32_t N, const nep
     hipLaunchKernelGGL(k_wep_mode_means, dim3((unsigned)((mm + 3) / 4)), dim3(256), 0, st, nz, (int)N, (const cplx*)dG, (const cplx*)S, f);
     LAUNCHCHK();                                                                                                    // 3
     if ((rc = nep_gemv_hd(dMinvH, mm, mm, mm, (const nep_cdouble*)f, nullptr, (nep_cdouble*)al, stream))) return rc;
-    hipLaunchKernelGGL(k_region_eb, dim3((unsigned)((nz + 255) / 256)), dim3(256), 0, st, nz, (int)N, L, (const cplx*)al, dd1, dd2, eb);
-    LAUNCHCHK();                                                                                                    // 4
-    if ((rc = pinv_apply_impl(p, d_sinv, (const nep_cdouble*)eb, (nep_cdouble*)pb, stream, nullptr, 0, 0.0, 0.0))) return rc;
+    // 4: the boundary pieces eb(alpha) are formed inside the P^{-1} kernel's loader (gnx = -N)
+    if ((rc = pinv_apply_impl(p, d_sinv, (const nep_cdouble*)eb, (nep_cdouble*)pb, stream, (const cplx*)al, -(int)N, dd1, dd2))) return rc;
     const DftExpand ex{al, pb, (int)N, L, 0, 0};
     if ((rc = sylv_dft_sym_launch<true, 1>(s, c, -1.0, (const cplx*)dKsc, T2, st, ex))) return rc;                  // 5
     if ((rc = sylv_tri_launch<2>(s, st, s->d_T, T2, nullptr, N, L))) return rc;                                     // 6
