@@ -531,8 +531,15 @@ __device__ __forceinline__ bool gnonzero(cplx v) { return v.x != 0.0 || v.y != 0
 template <typename T>
 __global__ __launch_bounds__(256) void k_gemm_general(int ta, int tb, int m, int n, int k, T alpha, const T* __restrict__ A,
                                                       int64_t lda, const T* __restrict__ B, int64_t ldb, T beta, T* __restrict__ C,
-                                                      int64_t ldc) {
+                                                      int64_t ldc, const int32_t* __restrict__ krange = nullptr, int kchunk = 0,
+                                                      T* __restrict__ P = nullptr) {
+    // krange (per 64-row tile of C: [k_lo, k_hi)): op(A) is zero outside that range on the tile's rows (block-diagonal A: the
+    // diagonal-block inverses of the dense apex build, trsv_ml.hip).  kchunk > 0: split-K -- workgroup z sums k in [z kchunk,
+    // (z+1) kchunk) and stores the raw partial tile into P + z m n (ld = m); k_gemm_splitk_reduce adds the slices in order.
     constexpr int TM = 64, TN = 64, TK = 16;
+    int k_lo = 0, k_hi = k;
+    if (krange) { k_lo = krange[2 * blockIdx.x]; k_hi = krange[2 * blockIdx.x + 1]; }
+    if (kchunk > 0) { k_lo = (int)blockIdx.z * kchunk; k_hi = min(k, k_lo + kchunk); }
     __shared__ T As[TK][TM + 1];          // As[kk][i] = op(A)[i0 + i, k0 + kk]
     __shared__ T Bs[TK][TN + 1];          // Bs[kk][j] = op(B)[k0 + kk, j0 + j]
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
@@ -542,14 +549,14 @@ __global__ __launch_bounds__(256) void k_gemm_general(int ta, int tb, int m, int
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = gzero((T*)nullptr);
-    for (int k0 = 0; k0 < k; k0 += TK) {
+    for (int k0 = k_lo; k0 < k_hi; k0 += TK) {
         // stage: 64 x 16 elements each, 4 per thread; the fast index follows the operand's storage order
         for (int t = threadIdx.x; t < TM * TK; t += 256) {
             int i, kk;
             if (ta == 0) { i = t % TM; kk = t / TM; } else { kk = t % TK; i = t / TK; }
             const int gi = i0 + i, gk = k0 + kk;
             T v = gzero((T*)nullptr);
-            if (gi < m && gk < k) v = ta == 0 ? A[gi + (int64_t)gk * lda] : gconj(A[gk + (int64_t)gi * lda], ta == 2);
+            if (gi < m && gk < k_hi) v = ta == 0 ? A[gi + (int64_t)gk * lda] : gconj(A[gk + (int64_t)gi * lda], ta == 2);
             As[kk][i] = v;
         }
         for (int t = threadIdx.x; t < TN * TK; t += 256) {
@@ -557,7 +564,7 @@ __global__ __launch_bounds__(256) void k_gemm_general(int ta, int tb, int m, int
             if (tb == 0) { kk = t % TK; j = t / TK; } else { j = t % TN; kk = t / TN; }
             const int gj = j0 + j, gk = k0 + kk;
             T v = gzero((T*)nullptr);
-            if (gj < n && gk < k) v = tb == 0 ? B[gk + (int64_t)gj * ldb] : gconj(B[gj + (int64_t)gk * ldb], tb == 2);
+            if (gj < n && gk < k_hi) v = tb == 0 ? B[gk + (int64_t)gj * ldb] : gconj(B[gj + (int64_t)gk * ldb], tb == 2);
             Bs[kk][j] = v;
         }
         __syncthreads();
@@ -575,6 +582,20 @@ __global__ __launch_bounds__(256) void k_gemm_general(int ta, int tb, int m, int
         }
         __syncthreads();
     }
+    if (kchunk > 0) {                                   // split-K: raw partial tile
+        T* Pz = P + (int64_t)blockIdx.z * m * n;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int gj = j0 + ty + 16 * b;
+            if (gj >= n) continue;
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int gi = i0 + tx + 16 * a;
+                if (gi < m) Pz[gi + (int64_t)gj * m] = acc[a][b];
+            }
+        }
+        return;
+    }
     const bool use_c = gnonzero(beta);
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -590,7 +611,45 @@ __global__ __launch_bounds__(256) void k_gemm_general(int ta, int tb, int m, int
         }
     }
 }
+// C = alpha (P_0 + P_1 + ... in this order) + beta C
+__global__ __launch_bounds__(256) void k_gemm_splitk_reduce(int m, int n, int nz_, cplx alpha, const cplx* __restrict__ P, cplx beta,
+                                                            cplx* __restrict__ C, int64_t ldc) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= (int64_t)m * n) return;
+    const int i = (int)(t % m), j = (int)(t / m);
+    cplx sacc = P[t];
+    for (int z = 1; z < nz_; ++z) sacc = cadd(sacc, P[(int64_t)z * m * n + t]);
+    cplx v = cmul(alpha, sacc);
+    if (beta.x != 0.0 || beta.y != 0.0) v = cadd(v, cmul(beta, C[i + (int64_t)j * ldc]));
+    C[i + (int64_t)j * ldc] = v;
+}
 }  // namespace
+
+// internal (trsv_ml.hip, dense apex build): complex GEMM without transposition with (a) a K range per 64-row tile for a block-diagonal
+// A (h_krange on the HOST, 2 ints per tile, uploaded through dWork) or (b) deterministic split-K for products with few tiles and a
+// long K (dWork: ksplit * m * n complex).  ksplit <= 1 and h_krange == NULL: plain nep_zgemm.
+extern "C" int32_t nep_zgemm_ex(int32_t m, int32_t n, int32_t k, nep_cdouble alpha, const nep_cdouble* dA, int64_t lda,
+                                const nep_cdouble* dB, int64_t ldb, nep_cdouble beta, nep_cdouble* dC, int64_t ldc,
+                                const int32_t* d_krange, int32_t ksplit, nep_cdouble* dWork, nep_stream stream) {
+    ARGCHK(dA && dB && dC && m >= 1 && n >= 1 && k >= 1 && lda >= m && ldb >= k && ldc >= m);
+    cplx al, be; al.x = alpha.re; al.y = alpha.im; be.x = beta.re; be.y = beta.im;
+    const dim3 g((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64), 1);
+    if (ksplit > 1 && dWork) {
+        const int kchunk = ((k + ksplit - 1) / ksplit + 15) / 16 * 16;
+        const int nzs = (k + kchunk - 1) / kchunk;
+        hipLaunchKernelGGL(k_gemm_general<cplx>, dim3(g.x, g.y, (unsigned)nzs), dim3(256), 0, as_stream(stream), 0, 0, (int)m, (int)n, (int)k, al,
+                           (const cplx*)dA, lda, (const cplx*)dB, ldb, be, (cplx*)dC, ldc, (const int32_t*)nullptr, kchunk, (cplx*)dWork);
+        LAUNCHCHK();
+        hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3((unsigned)(((int64_t)m * n + 255) / 256)), dim3(256), 0, as_stream(stream), (int)m, (int)n, nzs,
+                           al, (const cplx*)dWork, be, (cplx*)dC, ldc);
+        LAUNCHCHK();
+        return NEP_OK;
+    }
+    hipLaunchKernelGGL(k_gemm_general<cplx>, g, dim3(256), 0, as_stream(stream), 0, 0, (int)m, (int)n, (int)k, al, (const cplx*)dA, lda,
+                       (const cplx*)dB, ldb, be, (cplx*)dC, ldc, d_krange, 0, (cplx*)nullptr);
+    LAUNCHCHK();
+    return NEP_OK;
+}
 
 extern "C" int32_t nep_zgemm(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t k, nep_cdouble alpha,
                              const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb, nep_cdouble beta,

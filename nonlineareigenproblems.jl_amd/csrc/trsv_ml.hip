@@ -74,6 +74,8 @@ struct MLSym {
     // partition in the factor's own (input) numbering, for the device-side numeric factorisation (csrc/lufac.hip)
     std::vector<int32_t> h_lvl, h_blk, h_oldof, h_blk_se;
     double t_build_ms = 0.0;
+    // dense apex build: K range of every 64-row tile of a level's block-diagonal factor (2 ints per tile), levels >= apex_kr_la
+    int32_t* d_apex_kr = nullptr; int apex_kr_la = -1; std::vector<int32_t> apex_kr_off;
 };
 
 struct MLFactor {
@@ -697,6 +699,7 @@ void free_sym(MLSym* s) {
     free_fac(s->L); free_fac(s->U);
     nep_pool_free(s->d_blk_se); nep_pool_free(s->d_rowblk);
     nep_pool_free(s->d_pin); nep_pool_free(s->d_pout);
+    if (s->d_apex_kr) nep_pool_free(s->d_apex_kr);
     delete s;
 }
 
@@ -981,6 +984,7 @@ int build_symbolic(MLSym* S, int64_t n, const int32_t* Lrp, const int32_t* Lci, 
 }  // namespace
 
 static int ml_build_apex(MLFactor* F, hipStream_t bst);
+static int ml_build_apex_dense(MLFactor* F, hipStream_t bst);
 static int choose_apex(const MLSym* S, int expected_solves);
 // end of a numeric build on bst: `ready` = block inverses done (solves may start), then the apex behind it
 static int ml_finish_numeric(MLFactor* F, hipStream_t bst) {
@@ -989,6 +993,14 @@ static int ml_finish_numeric(MLFactor* F, hipStream_t bst) {
     F->solves_since_numeric = 0;
     F->synced_valid = false;
     if (F->graph) { (void)hipGraphExecDestroy(F->graph); F->graph = nullptr; }
+    static const int apex_dense = getenv("NEP_ML_APEX_DENSE") ? atoi(getenv("NEP_ML_APEX_DENSE")) : 1;
+    if (F->apex_la > 0 && apex_dense) {         // dense build: short enough to finish before the first solve (no switch point)
+        int rc = ml_build_apex_dense(F, bst);
+        if (rc) return rc;
+        F->apex_live = true;
+        HIPCHK(hipEventRecord(F->ready, bst));
+        return NEP_OK;
+    }
     if (F->apex_la > 0 && apex_sync) {          // old behaviour: nothing may start before the apex exists
         int rc = ml_build_apex(F, bst);
         if (rc) return rc;
@@ -1641,6 +1653,117 @@ static int ml_build_apex(MLFactor* F, hipStream_t bst) {
     hipError_t e = hipGetLastError();
     nep_pool_free_on(wk, bst, true);
     if (e != hipSuccess) { nep_set_error("apex build failed: %s", hipGetErrorString(e)); return NEP_ERR_HIP; }
+    return NEP_OK;
+}
+
+// ---- the apex inverse as DENSE block algebra (round 4) ---------------------------------------------------------------------------
+// ml_build_apex above runs the sparse level kernels on T unit vectors, eight at a time: 3.4 ms of device-filling launches on gun
+// (T = 1326) next to the first solves of the factor, whose few-microsecond kernels then take 25-80 us each -- measured on the headline
+// call: 37.0 ms, 37.4 with the build finished before the first solve, 41.5 without an apex; the build costs ~3 ms either way.
+// Here the apex rows of the factors are scattered into dense T x T blocks (coupling entries between apex levels; the explicit
+// inverses of the diagonal blocks), and S^{-1} = inv(U_TT) inv(L_TT) is formed level by level with the library's own GEMM:
+//   X[I_l, :] = DLinv_l (E_l - Lc[I_l, <a_l] X[<a_l, :]),     then  W[I_l, :] = DUinv_l (X[I_l, :] - Uc[I_l, >=b_l] W[>=b_l, :])
+// one coupling product per level and one product per diagonal block.  The arithmetic differs from the substitution by rounding only.
+__global__ __launch_bounds__(256) void k_apex_densify(int R0, int T, const int32_t* __restrict__ rowblk, const int32_t* __restrict__ blk_se,
+                                                      const int32_t* __restrict__ cpL, const int32_t* __restrict__ ciL, const cplx* __restrict__ cxL,
+                                                      const int32_t* __restrict__ cpU, const int32_t* __restrict__ ciU, const cplx* __restrict__ cxU,
+                                                      const int64_t* __restrict__ ipL, const cplx* __restrict__ ixL,
+                                                      const int64_t* __restrict__ ipU, const cplx* __restrict__ ixU,
+                                                      cplx* __restrict__ Lc, cplx* __restrict__ Uc, cplx* __restrict__ DL, cplx* __restrict__ DU) {
+    const int r = R0 + (int)blockIdx.x;                     // one workgroup per apex row (new numbering)
+    const int64_t lr = r - R0;
+    for (int p = cpL[r] + threadIdx.x; p < cpL[r + 1]; p += 256) { const int c = ciL[p]; if (c >= R0) Lc[lr + (int64_t)(c - R0) * T] = cxL[p]; }
+    for (int p = cpU[r] + threadIdx.x; p < cpU[r + 1]; p += 256) { const int c = ciU[p]; if (c >= R0) Uc[lr + (int64_t)(c - R0) * T] = cxU[p]; }
+    const int b = rowblk[r], s = blk_se[2 * b], e = blk_se[2 * b + 1];
+    for (int t = threadIdx.x; t <= r - s; t += 256) DL[lr + (int64_t)(s + t - R0) * T] = ixL[ipL[r] + t];      // columns [s, r]
+    for (int t = threadIdx.x; t < e - r; t += 256) DU[lr + (int64_t)(r + t - R0) * T] = ixU[ipU[r] + t];       // columns [r, e)
+}
+// Y[a + i, a + i] = 1 for the rows [a, b) of a level (the block is cleared by the caller)
+__global__ void k_apex_ident(int a, int b, int T, cplx* __restrict__ Y) {
+    const int i = a + blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < b) Y[i + (int64_t)i * T] = cmake(1.0, 0.0);
+}
+extern "C" int32_t nep_zgemm_ex(int32_t m, int32_t n, int32_t k, nep_cdouble alpha, const nep_cdouble* dA, int64_t lda,
+                                const nep_cdouble* dB, int64_t ldb, nep_cdouble beta, nep_cdouble* dC, int64_t ldc,
+                                const int32_t* d_krange, int32_t ksplit, nep_cdouble* dWork, nep_stream stream);
+
+static int ml_build_apex_dense(MLFactor* F, hipStream_t bst) {
+    MLSym* S = F->sym;
+    const int la = F->apex_la;
+    const int R0 = S->lev_row[la];
+    const int T = (int)(S->n - R0);
+    const int64_t TT = (int64_t)T * T;
+    int rc;
+    if (!F->d_Sinv && (rc = nep_pool_alloc((void**)&F->d_Sinv, (size_t)TT * sizeof(cplx)))) return rc;
+    // K range per 64-row tile of every level's block-diagonal factor (once per pattern and apex level)
+    static std::mutex kr_mu;                                  // (factors of one pattern may be built from several host threads)
+    std::unique_lock<std::mutex> kr_lock(kr_mu);
+    if (!S->d_apex_kr || S->apex_kr_la != la) {
+        if (S->d_apex_kr) { nep_pool_free(S->d_apex_kr); S->d_apex_kr = nullptr; }
+        std::vector<int32_t> kr; S->apex_kr_off.assign(S->nlev + 1, 0);
+        for (int l = la; l < S->nlev; ++l) {
+            S->apex_kr_off[l] = (int32_t)kr.size();
+            const int a = S->lev_row[l], b = S->lev_row[l + 1];
+            int k = S->lev_blk[l];
+            for (int r0 = a; r0 < b; r0 += 64) {
+                const int r1 = std::min(b, r0 + 64) - 1;
+                while (S->h_blk_se[2 * k + 1] <= r0) ++k;
+                int k1 = k;
+                while (S->h_blk_se[2 * k1 + 1] <= r1) ++k1;
+                kr.push_back(S->h_blk_se[2 * k] - a); kr.push_back(S->h_blk_se[2 * k1 + 1] - a);
+            }
+        }
+        if ((rc = nep_pool_alloc((void**)&S->d_apex_kr, std::max<size_t>(kr.size(), 2) * sizeof(int32_t)))) return rc;
+        HIPCHK(hipMemcpy(S->d_apex_kr, kr.data(), kr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        S->apex_kr_la = la;
+    }
+    kr_lock.unlock();
+    cplx* wk = nullptr;
+    if ((rc = nep_pool_alloc((void**)&wk, (size_t)9 * TT * sizeof(cplx)))) return rc;
+    cplx *Lc = wk, *Uc = wk + TT, *DL = wk + 2 * TT, *DU = wk + 3 * TT, *X = wk + 4 * TT, *Y = wk + 5 * TT, *W = wk + 6 * TT, *P = wk + 7 * TT;
+    // split-K factor of a coupling product: enough workgroups for the chip, partial slices within the 2 T^2 workspace
+    auto ksplit_of = [&](int m, int n, int k) {
+        const int64_t tiles = (int64_t)((m + 63) / 64) * ((n + 63) / 64);
+        int ks = (int)std::min<int64_t>(8, (640 + tiles - 1) / tiles);
+        while (ks > 1 && (int64_t)ks * m * n > 2 * TT) --ks;
+        if (k < 128 * ks) ks = std::max(1, k / 128);
+        return ks;
+    };
+    auto fail = [&](int code) { nep_pool_free_on(wk, bst, true); return code; };
+    if (hipMemsetAsync(wk, 0, (size_t)6 * TT * sizeof(cplx), bst) != hipSuccess) return fail(NEP_ERR_HIP);
+    const cplx* cxL = F->d_vals;
+    const cplx* cxU = F->d_vals + (S->L.ncoup + S->L.nin);
+    hipLaunchKernelGGL(k_apex_densify, dim3((unsigned)T), dim3(256), 0, bst, R0, T, (const int32_t*)S->d_rowblk, (const int32_t*)S->d_blk_se,
+                       (const int32_t*)S->L.d_cp, (const int32_t*)S->L.d_ci, cxL, (const int32_t*)S->U.d_cp, (const int32_t*)S->U.d_ci, cxU,
+                       (const int64_t*)S->L.d_ip, (const cplx*)F->d_ixL, (const int64_t*)S->U.d_ip, (const cplx*)F->d_ixU, Lc, Uc, DL, DU);
+    if (hipGetLastError() != hipSuccess) return fail(NEP_ERR_HIP);
+    const nep_cdouble one{1.0, 0.0}, mone{-1.0, 0.0}, zero{0.0, 0.0};
+    nep_stream ns = (nep_stream)bst;
+#define ZGS(m_, n_, k_, al_, A_, B_, be_, C_) do { if ((rc = nep_zgemm_ex(m_, n_, k_, al_, (const nep_cdouble*)(A_), (int64_t)T, (const nep_cdouble*)(B_), (int64_t)T, be_, \
+        (nep_cdouble*)(C_), (int64_t)T, nullptr, ksplit_of(m_, n_, k_), (nep_cdouble*)P, ns))) return fail(rc); } while (0)
+#define ZGD(l_, m_, n_, A_, B_, C_) do { if ((rc = nep_zgemm_ex(m_, n_, m_, one, (const nep_cdouble*)(A_), (int64_t)T, (const nep_cdouble*)(B_), (int64_t)T, zero, \
+        (nep_cdouble*)(C_), (int64_t)T, (const int32_t*)S->d_apex_kr + S->apex_kr_off[l_], 1, nullptr, ns))) return fail(rc); } while (0)
+    // ---- X = inv(L_TT): rows of level l only have columns < b_l
+    for (int l = la; l < S->nlev; ++l) {
+        const int a = S->lev_row[l] - R0, b = S->lev_row[l + 1] - R0, ml = b - a;
+        if (ml <= 0) continue;
+        hipLaunchKernelGGL(k_apex_ident, dim3((unsigned)((ml + 255) / 256)), dim3(256), 0, bst, a, b, T, Y);
+        if (a > 0) ZGS(ml, a, a, mone, Lc + a, X, one, Y + a);
+        ZGD(l, ml, b, DL + a + (int64_t)a * T, Y + a, X + a);            // all diagonal blocks of the level in one product
+    }
+    // ---- W = inv(U_TT) X, from the last level up
+    for (int l = S->nlev - 1; l >= la; --l) {
+        const int a = S->lev_row[l] - R0, b = S->lev_row[l + 1] - R0, ml = b - a;
+        if (ml <= 0) continue;
+        if (b < T) ZGS(ml, T, T - b, mone, Uc + a + (int64_t)b * T, W + b, one, X + a);
+        ZGD(l, ml, T, DU + a + (int64_t)a * T, X + a, W + a);
+    }
+#undef ZGS
+#undef ZGD
+    hipLaunchKernelGGL(k_apex_transpose, dim3((unsigned)((T + 15) / 16), (unsigned)((T + 15) / 16)), dim3(256), 0, bst, T, (const cplx*)W, F->d_Sinv);
+    hipError_t e = hipGetLastError();
+    nep_pool_free_on(wk, bst, true);
+    if (e != hipSuccess) { nep_set_error("dense apex build failed: %s", hipGetErrorString(e)); return NEP_ERR_HIP; }
     return NEP_OK;
 }
 
