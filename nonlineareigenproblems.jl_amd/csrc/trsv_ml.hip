@@ -993,7 +993,19 @@ static int ml_finish_numeric(MLFactor* F, hipStream_t bst) {
     F->solves_since_numeric = 0;
     F->synced_valid = false;
     if (F->graph) { (void)hipGraphExecDestroy(F->graph); F->graph = nullptr; }
-    static const int apex_dense = getenv("NEP_ML_APEX_DENSE") ? atoi(getenv("NEP_ML_APEX_DENSE")) : 1;
+    // NEP_ML_APEX_DENSE: 0 = the sparse build (T unit vectors through the level kernels, 3.4 ms on gun) behind `ready`; 1 = the dense build
+    // finished BEFORE the first solve (apex from solve 1); 2 (default) = the dense build behind `ready`, the switch at solve NEP_ML_APEX_AT:
+    // measured on the headline call 37.0 / 35.0-35.8 / 34.5 ms (the 1.07 ms build next to the first five solves disturbs them far less than
+    // the sparse one did, and nothing waits for it)
+    static const int apex_dense = getenv("NEP_ML_APEX_DENSE") ? atoi(getenv("NEP_ML_APEX_DENSE")) : 2;
+    if (F->apex_la > 0 && apex_dense == 2) {    // dense build behind `ready`, switch at solve NEP_ML_APEX_AT like the sparse build
+        HIPCHK(hipEventRecord(F->ready, bst));
+        int rc = ml_build_apex_dense(F, bst);
+        if (rc) return rc;
+        if (!F->apex_ev) HIPCHK(hipEventCreateWithFlags(&F->apex_ev, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(F->apex_ev, bst));
+        return NEP_OK;
+    }
     if (F->apex_la > 0 && apex_dense) {         // dense build: short enough to finish before the first solve (no switch point)
         int rc = ml_build_apex_dense(F, bst);
         if (rc) return rc;
