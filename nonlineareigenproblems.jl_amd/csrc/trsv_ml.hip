@@ -76,6 +76,9 @@ struct MLSym {
     double t_build_ms = 0.0;
     // dense apex build: K range of every 64-row tile of a level's block-diagonal factor (2 ints per tile), levels >= apex_kr_la
     int32_t* d_apex_kr = nullptr; int apex_kr_la = -1; std::vector<int32_t> apex_kr_off;
+    // ... and its 9 T^2 workspace (253 MB on gun), kept with the pattern: one build at a time uses it, ordered by an event (a block
+    // taken from the pool per factorisation and freed behind its stream made the pool's footprint depend on the timing of the calls)
+    cplx* d_apex_work = nullptr; int64_t apex_work_T = 0; hipEvent_t apex_work_ev = nullptr; bool apex_work_used = false;
 };
 
 struct MLFactor {
@@ -700,6 +703,8 @@ void free_sym(MLSym* s) {
     nep_pool_free(s->d_blk_se); nep_pool_free(s->d_rowblk);
     nep_pool_free(s->d_pin); nep_pool_free(s->d_pout);
     if (s->d_apex_kr) nep_pool_free(s->d_apex_kr);
+    if (s->apex_work_ev) { (void)hipEventSynchronize(s->apex_work_ev); (void)hipEventDestroy(s->apex_work_ev); }
+    if (s->d_apex_work) nep_pool_free(s->d_apex_work);
     delete s;
 }
 
@@ -1729,9 +1734,15 @@ static int ml_build_apex_dense(MLFactor* F, hipStream_t bst) {
         HIPCHK(hipMemcpy(S->d_apex_kr, kr.data(), kr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         S->apex_kr_la = la;
     }
-    kr_lock.unlock();
-    cplx* wk = nullptr;
-    if ((rc = nep_pool_alloc((void**)&wk, (size_t)9 * TT * sizeof(cplx)))) return rc;
+    // the workspace belongs to the pattern; the lock is held until this build is enqueued, the event orders builds on different streams
+    if (!S->d_apex_work || S->apex_work_T != T) {
+        if (S->d_apex_work) { if (S->apex_work_ev) (void)hipEventSynchronize(S->apex_work_ev); nep_pool_free(S->d_apex_work); S->d_apex_work = nullptr; }
+        if ((rc = nep_pool_alloc((void**)&S->d_apex_work, (size_t)9 * TT * sizeof(cplx)))) return rc;
+        S->apex_work_T = T; S->apex_work_used = false;
+    }
+    if (!S->apex_work_ev) HIPCHK(hipEventCreateWithFlags(&S->apex_work_ev, hipEventDisableTiming));
+    if (S->apex_work_used) HIPCHK(hipStreamWaitEvent(bst, S->apex_work_ev, 0));
+    cplx* wk = S->d_apex_work;
     cplx *Lc = wk, *Uc = wk + TT, *DL = wk + 2 * TT, *DU = wk + 3 * TT, *X = wk + 4 * TT, *Y = wk + 5 * TT, *W = wk + 6 * TT, *P = wk + 7 * TT;
     // split-K factor of a coupling product: enough workgroups for the chip, partial slices within the 2 T^2 workspace
     auto ksplit_of = [&](int m, int n, int k) {
@@ -1741,7 +1752,7 @@ static int ml_build_apex_dense(MLFactor* F, hipStream_t bst) {
         if (k < 128 * ks) ks = std::max(1, k / 128);
         return ks;
     };
-    auto fail = [&](int code) { nep_pool_free_on(wk, bst, true); return code; };
+    auto fail = [&](int code) { (void)hipEventRecord(S->apex_work_ev, bst); S->apex_work_used = true; return code; };
     if (hipMemsetAsync(wk, 0, (size_t)6 * TT * sizeof(cplx), bst) != hipSuccess) return fail(NEP_ERR_HIP);
     const cplx* cxL = F->d_vals;
     const cplx* cxU = F->d_vals + (S->L.ncoup + S->L.nin);
@@ -1774,7 +1785,7 @@ static int ml_build_apex_dense(MLFactor* F, hipStream_t bst) {
 #undef ZGD
     hipLaunchKernelGGL(k_apex_transpose, dim3((unsigned)((T + 15) / 16), (unsigned)((T + 15) / 16)), dim3(256), 0, bst, T, (const cplx*)W, F->d_Sinv);
     hipError_t e = hipGetLastError();
-    nep_pool_free_on(wk, bst, true);
+    (void)hipEventRecord(S->apex_work_ev, bst); S->apex_work_used = true;
     if (e != hipSuccess) { nep_set_error("dense apex build failed: %s", hipGetErrorString(e)); return NEP_ERR_HIP; }
     return NEP_OK;
 }
