@@ -973,6 +973,7 @@ static int32_t lu_factor_batch_impl(nep_lu_refac* r, int32_t B, const nep_cdoubl
     HIPCHK(hipMemcpyAsync(hw.data(), dH, (size_t)B * NEP_LU_HW * 8, hipMemcpyDeviceToHost, st));
     if (h_LUx_out) HIPCHK(hipMemcpyAsync(h_LUx_out, dF, (size_t)B * nF * sizeof(cplx), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    std::vector<int> accepted;
     for (int b = 0; b < B; ++b) {
         // reported: [0] bad pivot, [1] max |L|, [2] element growth max|U| / max|A| of this static-pivot factorisation
         double* hh = h_health + 3 * b;
@@ -982,17 +983,38 @@ static int32_t lu_factor_batch_impl(nep_lu_refac* r, int32_t B, const nep_cdoubl
         // refused (out[b] stays NULL, the caller factorises this one on the host with fresh pivoting): a broken pivot, or
         // growth in L or in U above the limit -- growth in U is the factor that bounds the backward error
         if (hh[0] != 0.0 || !(hh[1] <= growth_limit) || !(hh[2] <= growth_limit)) continue;
-        MLFactor* F = nullptr;
-        const cplx* Fb = dF + (size_t)b * nF;
-        rc = ml_create_from_sym(r->S, (const nep_cdouble*)Fb, (const nep_cdouble*)(Fb + r->nnzL), st, expected_solves, &F);
-        if (rc) {
-            for (int c = 0; c < b; ++c) if (out[c]) { nep_lu_destroy(out[c]); out[c] = nullptr; }
-            return fail(rc);
+        accepted.push_back(b);
+    }
+    // the solve schedules of all accepted factors in one batched build (value gathers + block inverses with grid.y = factor);
+    // NEP_LU_BATCH_BUILD=0: one factor at a time as before
+    static const int batch_build = getenv("NEP_LU_BATCH_BUILD") ? atoi(getenv("NEP_LU_BATCH_BUILD")) : 1;
+    if (batch_build && accepted.size() > 1) {
+        std::vector<const nep_cdouble*> pL(accepted.size()), pU(accepted.size());
+        std::vector<MLFactor*> Fs(accepted.size(), nullptr);
+        for (size_t a = 0; a < accepted.size(); ++a) {
+            const cplx* Fb = dF + (size_t)accepted[a] * nF;
+            pL[a] = (const nep_cdouble*)Fb; pU[a] = (const nep_cdouble*)(Fb + r->nnzL);
         }
-        // the gathers run on a build stream: `st` waits for the factor's ready event so that the frees below, ordered on st,
-        // come after them (ml_solve does the same wait before the first solve anyway)
-        (void)ml_wait_ready(F, st);
-        out[b] = nep_lu_wrap_ml(F, r->n, r->nnzL, r->nnzU);
+        rc = ml_create_from_sym_batch(r->S, (int)accepted.size(), pL.data(), pU.data(), st, expected_solves, Fs.data());
+        if (rc) return fail(rc);
+        for (size_t a = 0; a < accepted.size(); ++a) {
+            (void)ml_wait_ready(Fs[a], st);
+            out[accepted[a]] = nep_lu_wrap_ml(Fs[a], r->n, r->nnzL, r->nnzU);
+        }
+    } else {
+        for (int b : accepted) {
+            MLFactor* F = nullptr;
+            const cplx* Fb = dF + (size_t)b * nF;
+            rc = ml_create_from_sym(r->S, (const nep_cdouble*)Fb, (const nep_cdouble*)(Fb + r->nnzL), st, expected_solves, &F);
+            if (rc) {
+                for (int c = 0; c < B; ++c) if (out[c]) { nep_lu_destroy(out[c]); out[c] = nullptr; }
+                return fail(rc);
+            }
+            // the gathers run on a build stream: `st` waits for the factor's ready event so that the frees below, ordered on st,
+            // come after them (ml_solve does the same wait before the first solve anyway)
+            (void)ml_wait_ready(F, st);
+            out[b] = nep_lu_wrap_ml(F, r->n, r->nnzL, r->nnzU);
+        }
     }
     nep_pool_free_on(dF, st, true); nep_pool_free_on(dA, st, true);
     return NEP_OK;

@@ -31,4 +31,6 @@ void ml_sym_partition(const MLSym* S, int64_t* n, int* nlev, int* nblk, const in
                       const int32_t** oldof, const int32_t** blk_se, const int32_t** lev_blk);
 int ml_create_from_sym(MLSym* S, const nep_cdouble* d_Lx, const nep_cdouble* d_Ux, hipStream_t producer, int expected_solves,
                        MLFactor** out);
+int ml_create_from_sym_batch(MLSym* S, int B, const nep_cdouble* const* d_Lx, const nep_cdouble* const* d_Ux, hipStream_t producer,
+                             int expected_solves, MLFactor** out);
 int ml_wait_ready(MLFactor* F, hipStream_t st);   // st waits for the numeric build of F

@@ -129,13 +129,22 @@ __device__ __forceinline__ cplx ml_cdiv(cplx a, cplx b) {
 // 256 threads mostly waited at the barrier of every level (9956 columns x ~100 levels); with one wave per column the barrier is free
 // and four times as many columns are resident (measured: 0.55 + 0.61 ms -> see DESIGN.md section 3 K5 set-up)
 #define ML_INV_NT 64
+struct MLBatchTab { cplx* const* vals = nullptr; cplx* const* ix = nullptr; int64_t off_bx = 0, off_diag = 0; };
 template <bool UPPER>
 __global__ __launch_bounds__(ML_INV_NT) void k_ml_inverse(const int32_t* __restrict__ rowblk, const int32_t* __restrict__ blk_se,
                                                     const int32_t* __restrict__ lvo, const int32_t* __restrict__ lvp,
                                                     const int32_t* __restrict__ slotrow, const int32_t* __restrict__ bp,
-                                                    const int32_t* __restrict__ bi, const cplx* __restrict__ bx,
-                                                    const cplx* __restrict__ diag, const int64_t* __restrict__ ip,
-                                                    cplx* __restrict__ ix, const int32_t* __restrict__ rowlev) {
+                                                    const int32_t* __restrict__ bi, const cplx* bx,
+                                                    const cplx* diag, const int64_t* __restrict__ ip,
+                                                    cplx* ix, const int32_t* __restrict__ rowlev,
+                                                    const MLBatchTab tab = MLBatchTab()) {
+    // batch of factors of one pattern (ml_create_from_sym_batch: the nodes of contour_beyn): grid.y = factor; its value block and its
+    // packed-inverse block come from the pointer table, bx / diag are then OFFSETS into the value block
+    if (tab.vals) {
+        cplx* vb = tab.vals[blockIdx.y];
+        bx = vb + tab.off_bx; diag = UPPER ? vb + tab.off_diag : nullptr;
+        ix = tab.ix[blockIdx.y];
+    }
     __shared__ cplx x[ML_BMAX];
     // round 3: the block's level pointers, slot rows and row pointers sit in LDS (one coalesced load each at the start), and the
     // first entry of every lane for the NEXT batch of 16 slots is fetched while the current batch is reduced -- a dense 256-row block
@@ -218,8 +227,9 @@ __global__ __launch_bounds__(ML_INV_NT) void k_ml_inverse(const int32_t* __restr
 }
 
 // device-side numeric path: values of a factor (input entry order) -> the schedule's value array
-__global__ void k_ml_gather(int64_t nnz, const int32_t* __restrict__ map, const cplx* __restrict__ src, cplx* __restrict__ vals,
-                            int64_t o1, int64_t o2, int64_t o3) {
+__global__ void k_ml_gather(int64_t nnz, const int32_t* __restrict__ map, const cplx* src, cplx* vals,
+                            int64_t o1, int64_t o2, int64_t o3, cplx* const* batch_vals = nullptr, const cplx* const* batch_src = nullptr) {
+    if (batch_vals) { vals = batch_vals[blockIdx.y]; src = batch_src[blockIdx.y]; }
     for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < nnz; e += (int64_t)gridDim.x * blockDim.x) {
         const int32_t v = map[e];
         const int kind = v & 3;
@@ -1254,6 +1264,69 @@ int ml_wait_ready(MLFactor* F, hipStream_t st) {
     F->synced = st; F->synced_valid = true;
     return NEP_OK;
 }
+// B factors of ONE pattern in one go (the quadrature nodes of contour_beyn, lufac.hip): the value gathers and the block-inverse builds of
+// all of them in four launches with grid.y = factor.  One factor at a time, k_ml_inverse is a chain of dependent in-block levels that
+// leaves most of the chip idle for 0.3 ms -- 64 nodes were 128 such launches over four build streams, 39 ms of the 100 ms of config C4.
+// d_Lx[b] / d_Ux[b]: device value arrays (input entry order) of factor b.  out[b] receives the factors (all or none).
+int ml_create_from_sym_batch(MLSym* S, int B, const nep_cdouble* const* d_Lx, const nep_cdouble* const* d_Ux, hipStream_t producer,
+                             int expected_solves, MLFactor** out) {
+    for (int b = 0; b < B; ++b) out[b] = nullptr;
+    if (B <= 0) return NEP_OK;
+    const int64_t n = S->n;
+    const int64_t oL = 0, oLb = oL + S->L.ncoup, oU = oLb + S->L.nin, oUb = oU + S->U.ncoup, oD = oUb + S->U.nin;
+    const int64_t ntot = oD + n;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        if (!S->L.d_map && (rc = up(&S->L.d_map, S->L.map))) return rc;
+        if (!S->U.d_map && (rc = up(&S->U.d_map, S->U.map))) return rc;
+    }
+    auto undo = [&](int code) { for (int b = 0; b < B; ++b) if (out[b]) { ml_destroy(out[b]); out[b] = nullptr; } return code; };
+    std::vector<void*> tab((size_t)5 * B);          // [vals | ixL | ixU | srcL | srcU] x B
+    for (int b = 0; b < B; ++b) {
+        { std::lock_guard<std::mutex> lk(g_cache_mu); S->refs++; }
+        MLFactor* F = new MLFactor();
+        F->sym = S; F->use_graph = expected_solves >= 3 ? 1 : 0; F->apex_la = choose_apex(S, expected_solves);
+        out[b] = F;
+        if ((rc = nep_pool_alloc((void**)&F->d_vals, (size_t)ntot * sizeof(cplx)))) return undo(rc);
+        if ((rc = nep_pool_alloc((void**)&F->d_ixL, (size_t)std::max<int64_t>(S->L.ninv, 1) * sizeof(cplx)))) return undo(rc);
+        if ((rc = nep_pool_alloc((void**)&F->d_ixU, (size_t)std::max<int64_t>(S->U.ninv, 1) * sizeof(cplx)))) return undo(rc);
+        if (hipEventCreateWithFlags(&F->ready, hipEventDisableTiming) != hipSuccess) return undo(NEP_ERR_HIP);
+        tab[b] = F->d_vals; tab[(size_t)B + b] = F->d_ixL; tab[(size_t)2 * B + b] = F->d_ixU;
+        tab[(size_t)3 * B + b] = (void*)d_Lx[b]; tab[(size_t)4 * B + b] = (void*)d_Ux[b];
+    }
+    void** d_tab = nullptr;
+    if ((rc = nep_pool_alloc((void**)&d_tab, tab.size() * sizeof(void*)))) return undo(rc);
+    hipStream_t bst = g_bstreams.get();
+    {
+        hipEvent_t ev;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { nep_pool_free(d_tab); return undo(NEP_ERR_HIP); }
+        (void)hipEventRecord(ev, producer); (void)hipStreamWaitEvent(bst, ev, 0); (void)hipEventDestroy(ev);
+    }
+    // (pageable source: the copy is complete when the call returns, the table may go out of scope)
+    if (hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice, bst) != hipSuccess) { nep_pool_free(d_tab); return undo(NEP_ERR_HIP); }
+    cplx* const* t_vals = (cplx* const*)d_tab; cplx* const* t_ixL = (cplx* const*)(d_tab + B); cplx* const* t_ixU = (cplx* const*)(d_tab + 2 * (size_t)B);
+    const cplx* const* t_sL = (const cplx* const*)(d_tab + 3 * (size_t)B); const cplx* const* t_sU = (const cplx* const*)(d_tab + 4 * (size_t)B);
+    const int gl = (int)std::min<int64_t>((S->nnzL + 255) / 256, 4096), gu = (int)std::min<int64_t>((S->nnzU + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_ml_gather, dim3(gl, B), dim3(256), 0, bst, S->nnzL, (const int32_t*)S->L.d_map, (const cplx*)nullptr, (cplx*)nullptr, oL, oLb, oD, t_vals, t_sL);
+    hipLaunchKernelGGL(k_ml_gather, dim3(gu, B), dim3(256), 0, bst, S->nnzU, (const int32_t*)S->U.d_map, (const cplx*)nullptr, (cplx*)nullptr, oU, oUb, oD, t_vals, t_sU);
+    MLBatchTab tl; tl.vals = t_vals; tl.ix = t_ixL; tl.off_bx = oLb; tl.off_diag = 0;
+    MLBatchTab tu; tu.vals = t_vals; tu.ix = t_ixU; tu.off_bx = oUb; tu.off_diag = oD;
+    hipLaunchKernelGGL((k_ml_inverse<false>), dim3((unsigned)n, (unsigned)B), dim3(ML_INV_NT), 0, bst, (const int32_t*)S->d_rowblk,
+                       (const int32_t*)S->d_blk_se, (const int32_t*)S->L.d_lvo, (const int32_t*)S->L.d_lvp,
+                       (const int32_t*)S->L.d_slotrow, (const int32_t*)S->L.d_bp, (const int32_t*)S->L.d_bi,
+                       (const cplx*)nullptr, (const cplx*)nullptr, (const int64_t*)S->L.d_ip, (cplx*)nullptr, (const int32_t*)S->L.d_rowlev, tl);
+    hipLaunchKernelGGL((k_ml_inverse<true>), dim3((unsigned)n, (unsigned)B), dim3(ML_INV_NT), 0, bst, (const int32_t*)S->d_rowblk,
+                       (const int32_t*)S->d_blk_se, (const int32_t*)S->U.d_lvo, (const int32_t*)S->U.d_lvp,
+                       (const int32_t*)S->U.d_slotrow, (const int32_t*)S->U.d_bp, (const int32_t*)S->U.d_bi,
+                       (const cplx*)nullptr, (const cplx*)nullptr, (const int64_t*)S->U.d_ip, (cplx*)nullptr, (const int32_t*)S->U.d_rowlev, tu);
+    if (hipGetLastError() != hipSuccess) { nep_pool_free_on(d_tab, bst, true); nep_set_error("batched numeric build failed"); return undo(NEP_ERR_HIP); }
+    nep_pool_free_on(d_tab, bst, true);
+    for (int b = 0; b < B; ++b)
+        if ((rc = ml_finish_numeric(out[b], bst))) return undo(rc);
+    return NEP_OK;
+}
+
 int ml_create_from_sym(MLSym* S, const nep_cdouble* d_Lx, const nep_cdouble* d_Ux, hipStream_t producer, int expected_solves,
                        MLFactor** out) {
     *out = nullptr;
