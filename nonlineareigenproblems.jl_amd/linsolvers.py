@@ -828,11 +828,29 @@ class LinSolverCache:
             self._pattern = _Pattern(); self._pattern.indptr = A.indptr; self._pattern.indices = A.indices; self._pattern.shape = A.shape
         return self._plan_key is not False and _DeviceRefactor.lookup(self._plan_key) is not None
 
-    def prefetch(self, shifts):
+    def prefetch(self, shifts, keep_all=None):
+        """`keep_all` (optional): every distinct shift the driver WILL use and keep (nleigs with reusefact = 2).  When the pattern has a
+        device-factorisation plan they are factorised in ONE batched pass (nep_lu_factor_dev_batch: each of the ~600 launches of the
+        numeric factorisation carries all of them, and their solve schedules are built together) -- config C3: five shifts, 96 -> 88 ms."""
         c = self.linsolvercreator
         if type(c) is not FactorizeLinSolverCreator or os.environ.get("NEP_LU_PREFETCH", "1") == "0":
             return
         if self._device_plan_ready():
+            if keep_all is not None and not getattr(self, "_batched", False) and os.environ.get("NEP_LU_CACHE_BATCH", "1") != "0":
+                self._batched = True
+                todo = [complex(s) for s in keep_all if np.isfinite(complex(s)) and complex(s) not in self.solvers
+                        and complex(s) not in c.recycled_factorizations]
+                plan = _DeviceRefactor.lookup(self._plan_key)
+                if len(todo) >= 2 and plan is not None:
+                    mats = [sp.csc_matrix(self.nep.compute_Mder(k), dtype=np.complex128) for k in todo]
+                    P = self._pattern
+                    if all(M.shape == P.shape and np.array_equal(M.indptr, P.indptr) and np.array_equal(M.indices, P.indices) for M in mats):
+                        lu_kw = dict(c.lu_kw); lu_kw.setdefault("expected_solves", 200)
+                        lus = _DeviceRefactor.factor_batch(plan, mats[0].shape[0], np.stack([M.data for M in mats]),
+                                                           expected_solves=lu_kw["expected_solves"])
+                        for key, lu in zip(todo, lus):
+                            if lu is not None:          # (a refused one is factorised on its own when it is needed)
+                                self.solvers[key] = FactorizeLinSolver(self.nep, key, c.umfpack_refinements, _lu=lu)
             return
         for s in shifts:
             key = complex(s)

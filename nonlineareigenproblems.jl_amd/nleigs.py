@@ -149,7 +149,9 @@ def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger
     st = stream_ptr
 
     v0 = _c128(v) / np.linalg.norm(v)
-    cache.prefetch(sigma[:3])                   # host factorisations of the next shifts run ahead on a worker thread
+    # host factorisations of the next shifts run ahead on a worker thread; with reusefact = 2 (every factorisation is kept) and a
+    # device-factorisation plan for the pattern, ALL distinct shifts are factorised on the GPU in one batched pass instead
+    cache.prefetch(sigma[:3], keep_all=list(dict.fromkeys(complex(s_) for s_ in sigma)) if reusefact == 2 else None)
     x0 = cache.solve(sigma[0], to_dev(v0)[0], reusefact == 2)
     nx0 = dense.nrm2(x0)
     dense.copy(x0, V[0], n); dense.scal(V[0], 1.0 / nx0, n)
