@@ -1303,8 +1303,10 @@ int ml_create_from_sym_batch(MLSym* S, int B, const nep_cdouble* const* d_Lx, co
         if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { nep_pool_free(d_tab); return undo(NEP_ERR_HIP); }
         (void)hipEventRecord(ev, producer); (void)hipStreamWaitEvent(bst, ev, 0); (void)hipEventDestroy(ev);
     }
-    // (pageable source: the copy is complete when the call returns, the table may go out of scope)
-    if (hipMemcpyAsync(d_tab, tab.data(), tab.size() * sizeof(void*), hipMemcpyHostToDevice, bst) != hipSuccess) { nep_pool_free(d_tab); return undo(NEP_ERR_HIP); }
+    {   // through a pinned staging slot: the table may go out of scope right after the call
+        static thread_local PinnedRing ring;
+        if ((rc = ring.upload(d_tab, tab.data(), tab.size() * sizeof(void*), bst))) { nep_pool_free(d_tab); return undo(rc); }
+    }
     cplx* const* t_vals = (cplx* const*)d_tab; cplx* const* t_ixL = (cplx* const*)(d_tab + B); cplx* const* t_ixU = (cplx* const*)(d_tab + 2 * (size_t)B);
     const cplx* const* t_sL = (const cplx* const*)(d_tab + 3 * (size_t)B); const cplx* const* t_sU = (const cplx* const*)(d_tab + 4 * (size_t)B);
     const int gl = (int)std::min<int64_t>((S->nnzL + 255) / 256, 4096), gu = (int)std::min<int64_t>((S->nnzU + 255) / 256, 4096);
