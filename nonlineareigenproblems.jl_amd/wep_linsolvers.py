@@ -256,6 +256,14 @@ class WEPGMRESLinSolver(LinSolver):
         direct = self.ops.stencil is not None and isinstance(Pl, WEPPreconditioner) and Pl.fused_available()
         if Pl is not None and os.environ.get("NEP_WEP_GRAPH", "0" if direct else "1") != "0":
             self._capture_step()
+        elif direct:
+            # straight from basis vector j into basis vector j + 1: no operator-owned output block and no copy behind it
+            ops_ = self.ops
+
+            def direct_step(v, w):
+                ops_.matvec(v, w)
+                Pl(w)
+            self.gmres.fused_step = direct_step
 
         def inner(rhs, q, tol, sweep=False):
             if sweep and self.sweep_reltol is not None:
