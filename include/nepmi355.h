@@ -462,6 +462,11 @@ int32_t nep_lu_refac_analyze(int64_t n, const int32_t* Lp, const int32_t* Li, co
                              const int32_t* perm_r, const int32_t* perm_c, const int32_t* Ap, const int32_t* Ai, int64_t out[8]);
 /* out[0..5] = n, products, internal products, external products, external destination segments, symbolic time in ms */
 int32_t nep_lu_refac_info(const nep_lu_refac* r, int64_t out[6]);
+/* The "wide" levels (top of the elimination tree: few blocks, one long chain of pivots each) are factorised in panels of P
+ * consecutive pivots per launch (round 4; NEP_LU_WIDE_P = 1..4, default 4; 1 = one launch per pivot step as before):
+ * out[0] = P, [1] = pivot steps of the wide levels, [2] = launches they take per factorisation, [3] = destination records,
+ * [4] = deferred products (updates into a panel's own later rows / columns, applied at the end of the level). */
+int32_t nep_lu_refac_wide_info(const nep_lu_refac* r, int64_t out[5]);
 /* out[0] = hash of the plan arrays as they sit on the device (the quantity nep_lu_refac_analyze returns in out[7] for the host
  * enumeration of the same inputs), out[1] = 1 when the products were enumerated on the device (default; NEP_LU_PLAN_GPU=0: on
  * host threads).  Round 3: the enumeration of nep_lu_refac_create runs on the GPU (0.10-0.18 s -> a few ms for the gun pattern). */

@@ -132,6 +132,7 @@ SIGNATURES = {
     "nep_lu_refac_create": [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "nep_lu_refac_destroy": [c_vp],
     "nep_lu_refac_info": [c_vp, c_vp],
+    "nep_lu_refac_wide_info": [c_vp, c_vp],
     "nep_lu_refac_hash": [c_vp, c_vp],
     "nep_lu_factor_dev": [c_vp, c_vp, c_i32, C.c_double, c_vp, c_vp, c_vp, c_vp],
     "nep_lu_refac_analyze": [c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],

@@ -71,6 +71,17 @@ struct nep_lu_refac {
     std::vector<int64_t> wide_ptr;       // nsteps+1 (host: launch bounds)
     int32_t* d_wide = nullptr;           // 4 per product: gL, gU, gdst, position of the pivot U(k,k)
     int64_t nwide = 0;
+    // wide levels, panels of P consecutive pivots per launch (refac_build_fused): records of P operand pairs per destination,
+    // the updates INTO the panel's own later rows / columns deferred to P - 1 launches at the end of the level
+    int fuseP = 0;
+    std::vector<int64_t> f_step0;        // nlev+1: first panel step of a level
+    std::vector<int64_t> f_base;         // per panel step: first record
+    std::vector<int32_t> f_cnt;          // per panel step: records
+    std::vector<int64_t> fix_base;       // nlev * (P-1): first deferred product of (level, round)
+    std::vector<int32_t> fix_cnt;
+    int32_t* d_frec = nullptr;           // 2P + 2 per record: gL[P], gU[P], gdst, panel
+    int32_t* d_fhdr = nullptr;           // LU_FUSE_HS per panel: positions of the panel's P x P diagonal block, number of pivots
+    int32_t* d_ffix = nullptr;           // 4 per deferred product (the k_lu_wide form)
     double t_symbolic_ms = 0.0;
     bool gpu_enumerated = false;         // the product arrays were built by k_lu_enum_* (round 3), not by the host threads
 };
@@ -196,6 +207,128 @@ __device__ __forceinline__ cplx lu_cdiv(cplx a, cplx b) {
     }
     const double r = b.x / b.y, d = b.x * r + b.y;
     return cmake((a.x * r + a.y) / d, (a.y * r - a.x) / d);
+}
+
+// ---- wide levels, P pivots per launch -------------------------------------------------------------------------------------------
+// A wide level is a chain of dependent launches (one per pivot step, ~7 us each, 583 on the gun pattern: 4.1 ms of a 5 ms
+// factorisation); the products of a step fill the device for a fraction of that.  P consecutive pivots k_0 .. k_{P-1} of a block
+// are applied by ONE launch instead: a destination (i, j) outside the panel's rows and columns receives
+//     F(i,j) -= [F(i,k_0) .. F(i,k_{P-1})]  D^{-1}  [F(k_0,j) .. F(k_{P-1},j)]^T ,      D = F(k_q, k_r)  (P x P),
+// every thread eliminating the bordered (P+1) x (P+1) matrix of ITS destination from the values as they stand before the launch
+// (the P x P block is eliminated redundantly by every thread: 2 P^3 / 3 flops against a launch latency).  For that the panel's
+// later rows and columns (of k_1 .. k_{P-1}) must not change during the launch: the products that update them are deferred and
+// applied at the end of the level in P - 1 launches of k_lu_wide (round r: the products of every panel's pivot r -- its row and
+// column are final after rounds < r; no later panel reads a row or column of an earlier one).  Same operations as the
+// step-by-step form, one destination's products summed before the subtraction instead of subtracted one by one.
+#define LU_FUSE_MAXP 4
+#define LU_FUSE_HS 20                       // header stride: P*P positions (<= 16) + [16] = number of pivots
+template <int P>
+__global__ __launch_bounds__(256) void k_lu_widep(int64_t t0, int64_t t1, const int32_t* __restrict__ recs,
+                                                  const int32_t* __restrict__ hdrs, cplx* __restrict__ F, int64_t nF) {
+    F += (int64_t)blockIdx.y * nF;
+    const int64_t t = t0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= t1) return;
+    constexpr int RS = 2 * P + 2;
+    int32_t rc[RS];
+    {
+        const int2* rp = (const int2*)(recs + RS * t);
+#pragma unroll
+        for (int w = 0; w < RS / 2; ++w) { const int2 v = rp[w]; rc[2 * w] = v.x; rc[2 * w + 1] = v.y; }
+    }
+    const int32_t* __restrict__ h = hdrs + LU_FUSE_HS * (int64_t)rc[2 * P + 1];
+    const int np = h[16];
+    cplx D[P][P], lr[P], ur[P];
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+#pragma unroll
+        for (int c = 0; c < P; ++c) { const int32_t g = h[q * P + c]; D[q][c] = g >= 0 ? F[g] : cmake(0.0, 0.0); }
+        lr[q] = rc[q] >= 0 ? F[rc[q]] : cmake(0.0, 0.0);
+        ur[q] = rc[P + q] >= 0 ? F[rc[P + q]] : cmake(0.0, 0.0);
+    }
+    cplx acc = cmake(0.0, 0.0);
+#pragma unroll
+    for (int q = 0; q < P; ++q) {
+        if (q < np) {
+            const cplx pv = D[q][q];
+#pragma unroll
+            for (int r2 = q + 1; r2 < P; ++r2) {
+                const cplx m = lu_cdiv(D[r2][q], pv);
+#pragma unroll
+                for (int c = q + 1; c < P; ++c) { D[r2][c].x -= m.x * D[q][c].x - m.y * D[q][c].y; D[r2][c].y -= m.x * D[q][c].y + m.y * D[q][c].x; }
+                ur[r2].x -= m.x * ur[q].x - m.y * ur[q].y; ur[r2].y -= m.x * ur[q].y + m.y * ur[q].x;
+            }
+            const cplx ml = lu_cdiv(lr[q], pv);
+#pragma unroll
+            for (int c = q + 1; c < P; ++c) { lr[c].x -= ml.x * D[q][c].x - ml.y * D[q][c].y; lr[c].y -= ml.x * D[q][c].y + ml.y * D[q][c].x; }
+            acc.x += ml.x * ur[q].x - ml.y * ur[q].y; acc.y += ml.x * ur[q].y + ml.y * ur[q].x;
+        }
+    }
+    cplx f = F[rc[2 * P]];
+    f.x -= acc.x; f.y -= acc.y;
+    F[rc[2 * P]] = f;
+}
+
+// plan time: position of a panel pivot's U(k,k) -> 4 * panel + index in the panel
+__global__ void k_fuse_pivmap(int64_t npanel, const int32_t* __restrict__ hdrs, int P, int32_t* __restrict__ pivmap) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= npanel * P) return;
+    const int64_t hidx = t / P; const int q = (int)(t - hidx * P);
+    const int32_t* h = hdrs + LU_FUSE_HS * hidx;
+    if (q < h[16]) pivmap[h[q * P + q]] = (int32_t)(hidx * 4 + q);
+}
+// plan time: the products [t0, t1) of one step (pivot r of its panel, every block of the level) go into the records of their
+// destinations (slot[dst]: record of this panel step, handed out on first touch) or, when the destination lies in a row or column
+// of a later pivot of the same panel, onto the deferred list of (level, r)
+template <int P>
+__global__ __launch_bounds__(256) void k_fuse_scatter(int r, int64_t t0, int64_t t1, const int4* __restrict__ prod,
+                                                      const int32_t* __restrict__ pivmap, const int32_t* __restrict__ hdrs,
+                                                      int32_t* __restrict__ slot, int32_t* __restrict__ cnt, int64_t recbase,
+                                                      int32_t* __restrict__ recs, int32_t* __restrict__ fixcnt, int64_t fixbase,
+                                                      int4* __restrict__ fix, int32_t* __restrict__ link, int64_t nF) {
+    const int64_t t = t0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= t1) return;
+    const int4 q = prod[t];
+    const int32_t hidx = pivmap[q.w] >> 2;
+    const int32_t* __restrict__ h = hdrs + LU_FUSE_HS * (int64_t)hidx;
+    bool rowt = false, colt = false;
+    for (int q2 = r + 1; q2 < P; ++q2) {
+        const int32_t gl = h[q2 * P + r], gu = h[r * P + q2];        // F(k_q2, k_r): the L operand of row k_q2;  F(k_r, k_q2): the U operand
+        if (gl >= 0 && q.x == gl) rowt = true;
+        if (gu >= 0 && q.y == gu) colt = true;
+    }
+    if (rowt || colt) {
+        fix[fixbase + atomicAdd(fixcnt, 1)] = q;
+        // the operand chain of the panel: F(i, k_q2) is updated from F(i, k_r), F(k_q2, j) from F(k_r, j) -- k_fuse_fill follows it
+        if (colt && !rowt) link[(int64_t)r * nF + q.z] = q.x;
+        if (rowt && !colt) link[(int64_t)r * nF + q.z] = q.y;
+        return;
+    }
+    int32_t sl = slot[q.z];                                          // destinations are distinct within one pivot's products
+    if (sl < 0) { sl = atomicAdd(cnt, 1); slot[q.z] = sl; }
+    int32_t* o = recs + (2 * P + 2) * (recbase + sl);
+    o[r] = q.x; o[P + r] = q.y; o[2 * P] = q.z; o[2 * P + 1] = hidx;
+}
+// plan time: complete the operands of a panel step's records.  A destination (i, j) that pivot k_q updates needs F(i, k_r), r < q,
+// whenever that entry feeds F(i, k_q) inside the panel -- also when k_r itself has no product for (i, j) (U(k_r, j) not stored);
+// the same for the U operands.  link[r][position of F(i, k_q)] = position of F(i, k_r) comes from the deferred products.
+template <int P>
+__global__ __launch_bounds__(256) void k_fuse_fill(const int32_t* __restrict__ cnt, int64_t recbase, int32_t* __restrict__ recs,
+                                                   const int32_t* __restrict__ link, int64_t nF) {
+    const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t >= *cnt) return;
+    int32_t* o = recs + (2 * P + 2) * (recbase + t);
+    for (int side = 0; side < 2; ++side) {
+        int32_t* g = o + side * P;
+        for (int q = P - 1; q >= 1; --q) {
+            if (g[q] < 0) continue;
+            for (int r = q - 1; r >= 0; --r)
+                if (g[r] < 0) { const int32_t c = link[(int64_t)r * nF + g[q]]; if (c >= 0) g[r] = c; }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_fuse_reset(int64_t t0, int64_t t1, const int4* __restrict__ prod, int32_t* __restrict__ slot) {
+    const int64_t t = t0 + blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (t < t1) slot[prod[t].z] = -1;
 }
 
 // one workgroup per block of the level, pivots in schedule order
@@ -476,6 +609,7 @@ int32_t nep_lu_refac_destroy(nep_lu_refac* r) {
     nep_pool_free(r->d_amap); nep_pool_free(r->d_ldiag); nep_pool_free(r->d_udiag); nep_pool_free(r->d_Lp); nep_pool_free(r->d_Li);
     nep_pool_free(r->d_oldof); nep_pool_free(r->d_blk_se); nep_pool_free(r->d_piv_ptr); nep_pool_free(r->d_int);
     nep_pool_free(r->d_ext_ptr); nep_pool_free(r->d_ext_dst); nep_pool_free(r->d_ext_src); nep_pool_free(r->d_wide);
+    nep_pool_free(r->d_frec); nep_pool_free(r->d_fhdr); nep_pool_free(r->d_ffix);
     if (r->S) ml_sym_release_ref(r->S);
     delete r;
     return NEP_OK;
@@ -522,6 +656,134 @@ int32_t nep_lu_refac_analyze(int64_t n, const int32_t* Lp, const int32_t* Li, co
     out[0] = res->nprod; out[1] = res->nint; out[2] = res->next_; out[3] = res->nseg; out[4] = res->nwide;
     out[5] = res->wstep0[res->nlev]; out[6] = res->nlev; out[7] = (int64_t)(g_refac_hash >> 1);
     nep_lu_refac_destroy(res);
+    return NEP_OK;
+}
+
+// the panel form of the wide levels (k_lu_widep), built ON THE DEVICE from the wide products as they sit there (either enumeration
+// leaves them in d_wide): per panel step the products of its P steps are merged by destination.  NEP_LU_WIDE_P = 1 keeps the
+// step-by-step form.  Record order within a panel step comes from an atomic counter; every record has its own destination, so
+// the factor values do not depend on it.
+static int32_t refac_build_fused(nep_lu_refac* r, int64_t n, int64_t nF, int nlev, const int32_t* oldof, const int32_t* blk_se,
+                                 const int32_t* lev_blk, const std::vector<int64_t>& cptr, const std::vector<Ent>& cent) {
+    const int P_env = getenv("NEP_LU_WIDE_P") ? atoi(getenv("NEP_LU_WIDE_P")) : 4;       // read per plan (tests build one per size)
+    const int P = std::max(1, std::min(LU_FUSE_MAXP, P_env));
+    if (P < 2) return NEP_OK;
+    (void)n;
+    const double t0 = now_ms();
+    auto posof = [&](int32_t i, int32_t j) -> int32_t {              // position of F(i, j) in the union column j, -1: not stored
+        const Ent* b = cent.data() + cptr[j]; const Ent* en = cent.data() + cptr[j + 1];
+        const Ent* it = std::lower_bound(b, en, i, [](const Ent& a, int32_t v) { return a.row < v; });
+        return (it != en && it->row == i) ? it->g : -1;
+    };
+    // panels (headers) and panel steps
+    std::vector<int32_t> hdr;
+    r->f_step0.assign(nlev + 1, 0);
+    for (int l = 0; l < nlev; ++l) {
+        const int64_t steps = r->wstep0[l + 1] - r->wstep0[l];
+        r->f_step0[l + 1] = r->f_step0[l] + (r->wide[l] ? (steps + P - 1) / P : 0);
+        if (!r->wide[l]) continue;
+        for (int b = lev_blk[l]; b < lev_blk[l + 1]; ++b)
+            for (int q0 = blk_se[2 * b]; q0 < blk_se[2 * b + 1]; q0 += P) {
+                const int np = std::min(P, blk_se[2 * b + 1] - q0);
+                const size_t o = hdr.size();
+                hdr.resize(o + LU_FUSE_HS, -1);
+                for (int a = 0; a < np; ++a)
+                    for (int c = 0; c < np; ++c) hdr[o + a * P + c] = posof(oldof[q0 + a], oldof[q0 + c]);
+                hdr[o + 16] = np;
+            }
+    }
+    const int64_t npanel = (int64_t)(hdr.size() / LU_FUSE_HS), nps = r->f_step0[nlev];
+    r->f_base.assign((size_t)nps, 0); r->f_cnt.assign((size_t)nps, 0);
+    r->fix_base.assign((size_t)nlev * (P - 1), 0); r->fix_cnt.assign((size_t)nlev * (P - 1), 0);
+    {
+        int64_t fb = 0;
+        for (int l = 0; l < nlev; ++l) {
+            if (!r->wide[l]) continue;
+            for (int64_t ps = r->f_step0[l]; ps < r->f_step0[l + 1]; ++ps)
+                r->f_base[ps] = r->wide_ptr[r->wstep0[l] + (ps - r->f_step0[l]) * P];      // capacity: the products of its steps
+            for (int rr = 0; rr + 1 < P; ++rr) {
+                r->fix_base[(size_t)l * (P - 1) + rr] = fb;
+                for (int64_t s = r->wstep0[l] + rr; s < r->wstep0[l + 1]; s += P) fb += r->wide_ptr[s + 1] - r->wide_ptr[s];
+            }
+        }
+    }
+    const int RS = 2 * P + 2;
+    hipStream_t st = g_refac_stream;
+    int32_t *d_slot = nullptr, *d_pivmap = nullptr, *d_cnt = nullptr, *d_link = nullptr;
+    const size_t ncnt = (size_t)nps + (size_t)nlev * (P - 1);
+    int rc;
+    if ((rc = upv(&r->d_fhdr, hdr)) || (rc = nep_pool_alloc((void**)&r->d_frec, (size_t)r->nwide * RS * sizeof(int32_t))) ||
+        (rc = nep_pool_alloc((void**)&r->d_ffix, (size_t)r->nwide * 4 * sizeof(int32_t))) ||
+        (rc = nep_pool_alloc((void**)&d_slot, (size_t)nF * sizeof(int32_t))) || (rc = nep_pool_alloc((void**)&d_pivmap, (size_t)nF * sizeof(int32_t))) ||
+        (rc = nep_pool_alloc((void**)&d_cnt, ncnt * sizeof(int32_t))) ||
+        (rc = nep_pool_alloc((void**)&d_link, (size_t)(P - 1) * nF * sizeof(int32_t)))) {
+        nep_pool_free(d_slot); nep_pool_free(d_pivmap); nep_pool_free(d_cnt); nep_pool_free(d_link);
+        return rc;
+    }
+    HIPCHK(hipMemsetAsync(d_link, 0xFF, (size_t)(P - 1) * nF * sizeof(int32_t), st));
+    HIPCHK(hipMemsetAsync(r->d_frec, 0xFF, (size_t)r->nwide * RS * sizeof(int32_t), st));
+    HIPCHK(hipMemsetAsync(d_slot, 0xFF, (size_t)nF * sizeof(int32_t), st));
+    HIPCHK(hipMemsetAsync(d_cnt, 0, ncnt * sizeof(int32_t), st));
+    hipLaunchKernelGGL(k_fuse_pivmap, dim3((unsigned)((npanel * P + 255) / 256)), dim3(256), 0, st, npanel, (const int32_t*)r->d_fhdr, P, d_pivmap);
+    for (int l = 0; l < nlev; ++l) {
+        if (!r->wide[l]) continue;
+        for (int64_t ps = r->f_step0[l]; ps < r->f_step0[l + 1]; ++ps) {
+            const int64_t s0 = r->wstep0[l] + (ps - r->f_step0[l]) * P;
+            for (int pass = 0; pass < 2; ++pass)
+                for (int rr = 0; rr < P && s0 + rr < r->wstep0[l + 1]; ++rr) {
+                    const int64_t t0p = r->wide_ptr[s0 + rr], t1p = r->wide_ptr[s0 + rr + 1];
+                    if (t1p <= t0p) continue;
+                    const dim3 g((unsigned)((t1p - t0p + 255) / 256));
+                    if (pass) { hipLaunchKernelGGL(k_fuse_reset, g, dim3(256), 0, st, t0p, t1p, (const int4*)r->d_wide, d_slot); continue; }
+                    int32_t* fc = d_cnt + nps + (size_t)l * (P - 1) + std::min(rr, P - 2);
+                    const int64_t fbase = r->fix_base[(size_t)l * (P - 1) + std::min(rr, P - 2)];
+#define FUSE_SCATTER(P_) hipLaunchKernelGGL((k_fuse_scatter<P_>), g, dim3(256), 0, st, rr, t0p, t1p, (const int4*)r->d_wide, (const int32_t*)d_pivmap, \
+                                            (const int32_t*)r->d_fhdr, d_slot, d_cnt + ps, r->f_base[ps], r->d_frec, fc, fbase, (int4*)r->d_ffix, d_link, nF)
+                    if (P == 2) FUSE_SCATTER(2); else if (P == 3) FUSE_SCATTER(3); else FUSE_SCATTER(4);
+#undef FUSE_SCATTER
+                }
+            {
+                const int64_t cap = r->wide_ptr[std::min<int64_t>(s0 + P, r->wstep0[l + 1])] - r->wide_ptr[s0];
+                if (cap > 0) {
+                    const dim3 g((unsigned)((cap + 255) / 256));
+                    if (P == 2) hipLaunchKernelGGL((k_fuse_fill<2>), g, dim3(256), 0, st, (const int32_t*)(d_cnt + ps), r->f_base[ps], r->d_frec, (const int32_t*)d_link, nF);
+                    else if (P == 3) hipLaunchKernelGGL((k_fuse_fill<3>), g, dim3(256), 0, st, (const int32_t*)(d_cnt + ps), r->f_base[ps], r->d_frec, (const int32_t*)d_link, nF);
+                    else hipLaunchKernelGGL((k_fuse_fill<4>), g, dim3(256), 0, st, (const int32_t*)(d_cnt + ps), r->f_base[ps], r->d_frec, (const int32_t*)d_link, nF);
+                }
+            }
+        }
+    }
+    LAUNCHCHK();
+    std::vector<int32_t> hc(ncnt);
+    HIPCHK(hipMemcpyAsync(hc.data(), d_cnt, ncnt * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    nep_pool_free(d_slot); nep_pool_free(d_pivmap); nep_pool_free(d_cnt); nep_pool_free(d_link);
+    int64_t nrec = 0, nfix = 0;
+    for (int64_t ps = 0; ps < nps; ++ps) { r->f_cnt[ps] = hc[ps]; nrec += hc[ps]; }
+    for (size_t i = 0; i < (size_t)nlev * (P - 1); ++i) { r->fix_cnt[i] = hc[nps + i]; nfix += hc[nps + i]; }
+    // right-sized copies (the build arrays hold one slot per product: 4 x the records at P = 4)
+    {
+        int32_t *d_rec2 = nullptr, *d_fix2 = nullptr;
+        if ((rc = nep_pool_alloc((void**)&d_rec2, std::max<size_t>((size_t)nrec * RS, 1) * sizeof(int32_t))) ||
+            (rc = nep_pool_alloc((void**)&d_fix2, std::max<size_t>((size_t)nfix * 4, 1) * sizeof(int32_t)))) { nep_pool_free(d_rec2); return rc; }
+        int64_t w = 0;
+        for (int64_t ps = 0; ps < nps; ++ps) {
+            if (r->f_cnt[ps]) HIPCHK(hipMemcpyAsync(d_rec2 + w * RS, r->d_frec + r->f_base[ps] * RS, (size_t)r->f_cnt[ps] * RS * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            r->f_base[ps] = w; w += r->f_cnt[ps];
+        }
+        w = 0;
+        for (size_t i = 0; i < (size_t)nlev * (P - 1); ++i) {
+            if (r->fix_cnt[i]) HIPCHK(hipMemcpyAsync(d_fix2 + w * 4, r->d_ffix + r->fix_base[i] * 4, (size_t)r->fix_cnt[i] * 4 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+            r->fix_base[i] = w; w += r->fix_cnt[i];
+        }
+        HIPCHK(hipStreamSynchronize(st));
+        nep_pool_free(r->d_frec); nep_pool_free(r->d_ffix);
+        r->d_frec = d_rec2; r->d_ffix = d_fix2;
+    }
+    r->fuseP = P;
+    if (getenv("NEP_TIMING"))
+        fprintf(stderr, "[lu_refac] wide levels in panels of %d: %lld steps -> %lld launches, %lld products -> %lld records + %lld deferred, %.1f ms\n",
+                P, (long long)r->wstep0[nlev], (long long)nps, (long long)r->nwide, (long long)nrec, (long long)nfix, now_ms() - t0);
     return NEP_OK;
 }
 
@@ -807,6 +1069,10 @@ static int32_t refac_build(nep_lu_refac* r, int64_t n, const int32_t* Lp, const 
         (!gpu && (rc = upv(&r->d_int, itri))) || (rc = upv(&r->d_ext_ptr, ext_ptr)) || (rc = upv(&r->d_ext_dst, ext_dst)) ||
         (!gpu && (rc = upv(&r->d_ext_src, ext_src))) || (!gpu && (rc = upv(&r->d_wide, wflat)))) { nep_lu_refac_destroy(r); return rc; }
     r->gpu_enumerated = gpu;
+    if (!g_refac_dry && r->nwide > 0) {
+        const int rcf = refac_build_fused(r, n, nF, nlev, oldof, blk_se, lev_blk, cptr, cent);
+        if (rcf) { nep_lu_refac_destroy(r); return rcf; }
+    }
     r->t_symbolic_ms = now_ms() - t0;
     if (getenv("NEP_TIMING"))
         fprintf(stderr, "[lu_refac] columns %.1f ms, A map + weights %.1f, enumeration %.1f (%s, %d host threads), grouping %.1f, upload %.1f\n",
@@ -851,6 +1117,21 @@ int32_t nep_lu_refac_hash(const nep_lu_refac* r, int64_t out[2]) {
 int32_t nep_lu_refac_info(const nep_lu_refac* r, int64_t out[6]) {
     ARGCHK(r && out);
     out[0] = r->n; out[1] = r->nprod; out[2] = r->nint; out[3] = r->next_; out[4] = r->nseg; out[5] = (int64_t)r->t_symbolic_ms;
+    return NEP_OK;
+}
+
+// the wide levels of the plan: out[0] = pivots per launch (1: step by step), [1] = pivot steps, [2] = launches per factorisation
+// (panel steps + deferred rounds), [3] = destination records, [4] = deferred products
+int32_t nep_lu_refac_wide_info(const nep_lu_refac* r, int64_t out[5]) {
+    ARGCHK(r && out);
+    const int64_t steps = r->wstep0.empty() ? 0 : r->wstep0.back();
+    out[0] = r->fuseP >= 2 ? r->fuseP : 1; out[1] = steps; out[2] = steps; out[3] = 0; out[4] = 0;
+    if (r->fuseP >= 2) {
+        int64_t launches = 0, rec = 0, fix = 0;
+        for (int32_t c : r->f_cnt) { launches += c > 0; rec += c; }
+        for (int32_t c : r->fix_cnt) { launches += c > 0; fix += c; }
+        out[2] = launches; out[3] = rec; out[4] = fix;
+    }
     return NEP_OK;
 }
 
@@ -947,7 +1228,27 @@ static int32_t lu_factor_batch_impl(nep_lu_refac* r, int32_t B, const nep_cdoubl
         }
         const int b0 = r->lev_blk[l], b1 = r->lev_blk[l + 1];
         if (b1 <= b0) continue;
-        if (r->wide[l]) {
+        if (r->wide[l] && r->fuseP >= 2) {
+            const int P = r->fuseP;
+            for (int64_t ps = r->f_step0[l]; ps < r->f_step0[l + 1]; ++ps) {
+                const int64_t t0 = r->f_base[ps], t1 = t0 + r->f_cnt[ps];
+                if (t1 <= t0) continue;
+                const dim3 g((unsigned)((t1 - t0 + 255) / 256), gy);
+                if (P == 2) hipLaunchKernelGGL((k_lu_widep<2>), g, dim3(256), 0, st, t0, t1, (const int32_t*)r->d_frec, (const int32_t*)r->d_fhdr, dF, nF);
+                else if (P == 3) hipLaunchKernelGGL((k_lu_widep<3>), g, dim3(256), 0, st, t0, t1, (const int32_t*)r->d_frec, (const int32_t*)r->d_fhdr, dF, nF);
+                else hipLaunchKernelGGL((k_lu_widep<4>), g, dim3(256), 0, st, t0, t1, (const int32_t*)r->d_frec, (const int32_t*)r->d_fhdr, dF, nF);
+            }
+            for (int rr = 0; rr + 1 < P; ++rr) {
+                const int64_t t0 = r->fix_base[(size_t)l * (P - 1) + rr], t1 = t0 + r->fix_cnt[(size_t)l * (P - 1) + rr];
+                if (t1 <= t0) continue;
+                hipLaunchKernelGGL(k_lu_wide, dim3((unsigned)((t1 - t0 + 255) / 256), gy), dim3(256), 0, st, t0, t1, (const int4*)r->d_ffix, dF, nF);
+            }
+            LAUNCHCHK();
+            const int q0 = r->h_blk_se[2 * b0], q1 = r->h_blk_se[2 * (b1 - 1) + 1];
+            hipLaunchKernelGGL(k_lu_scale, dim3((unsigned)((q1 - q0 + 3) / 4), gy), dim3(256), 0, st, q0, q1, (const int32_t*)r->d_oldof,
+                               (const int32_t*)r->d_Lp, (const int32_t*)r->d_Li, (const int32_t*)r->d_udiag, dF, dH, nF);
+            LAUNCHCHK();
+        } else if (r->wide[l]) {
             for (int64_t sidx = r->wstep0[l]; sidx < r->wstep0[l + 1]; ++sidx) {
                 const int64_t t0 = r->wide_ptr[sidx], t1 = r->wide_ptr[sidx + 1];
                 if (t1 <= t0) continue;

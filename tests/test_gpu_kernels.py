@@ -829,6 +829,85 @@ def test_device_numeric_factorization(na, monkeypatch):
     ls._DeviceRefactor.clear()
 
 
+@pytest.mark.parametrize("case", ["gun1310", "gun2600", "grid_random"])
+def test_device_factorization_wide_levels_in_panels(na, monkeypatch, case):
+    """csrc/lufac.hip, k_lu_widep: the chain of pivot steps at the top of the elimination tree taken P pivots per launch (every
+    thread eliminates the bordered (P+1) x (P+1) matrix of its destination, the updates into the panel's own later rows and
+    columns are deferred to the end of the level).  Same factor as the step-by-step form (P = 1) and as the host factorisation
+    for P = 2, 3, 4 -- also on a pattern whose top is NOT dense (operands that reach a destination only through the panel's
+    chain) and for a batch of matrices in one pass -- with a quarter of the launches at P = 4."""
+    import ctypes as C
+    import torch
+    from oracle import gallery as og
+    from nep_amd._lib import lib, check, hptr, c_vp
+    from nep_amd.nep import stream_ptr
+    import nep_amd_hostlu as hl
+    rng = np.random.default_rng(5)
+    if case.startswith("gun"):
+        onep = og.gun_spmf_scaled(int(case[3:]))
+        mats = [sp.csc_matrix(onep.compute_Mder(z)).astype(np.complex128) for z in (0.1, 0.15 + 0.05j)]
+    else:
+        nx = 24; n_ = nx * nx
+        T = sp.diags([-1, 2.2, -1], [-1, 0, 1], shape=(nx, nx))
+        K = sp.kron(sp.identity(nx), T) + sp.kron(T, sp.identity(nx))
+        R = sp.random(n_, n_, density=1.0 / n_, random_state=7, format="csc")
+        patt = (abs(K) + abs(R) + abs(R.T)).tocsc(); patt.sort_indices()
+        mats = []
+        for _ in range(2):
+            A = patt.astype(np.complex128).copy()
+            A.data = 0.05 * (rng.standard_normal(A.nnz) + 1j * rng.standard_normal(A.nnz))
+            mats.append((A + sp.identity(n_) * (4.0 + 0.5j)).tocsc())
+    for A in mats:
+        A.sort_indices()
+    A0, A1 = mats
+    assert np.array_equal(A0.indices, A1.indices) and np.array_equal(A0.indptr, A1.indptr)
+    n = A0.shape[0]
+    F = hl.factor(A0.data, A0.indices, A0.indptr, A0.shape)
+    F1 = hl.factor(A1.data, A1.indices, A1.indptr, A1.shape)
+    ref = na.DeviceLU(factors=F)
+    nL = len(F["Lx"]); nU = len(F["Ux"])
+    LUs = {}; launches = {}
+    for P in (1, 2, 3, 4):
+        monkeypatch.setenv("NEP_LU_WIDE_P", str(P))
+        h = c_vp()
+        check(lib.nep_lu_refac_create(ref.h, n, hptr(F["Lp"]), hptr(F["Li"]), hptr(F["Up"]), hptr(F["Ui"]), hptr(F["perm_r"]),
+                                      hptr(F["perm_c"]), hptr(np.ascontiguousarray(A0.indptr, dtype=np.int32)),
+                                      hptr(np.ascontiguousarray(A0.indices, dtype=np.int32)), C.byref(h)))
+        wi = (C.c_int64 * 5)(); check(lib.nep_lu_refac_wide_info(h, wi))
+        assert wi[0] == P and wi[1] > 0
+        launches[P] = wi[2]
+        if P > 1:
+            assert wi[3] > 0 and wi[2] <= (wi[1] + P - 1) // P + 16 * (P - 1)
+        # both matrices in one pass (grid.y = matrix), values read back
+        Ax = np.ascontiguousarray(np.stack([A0.data, A1.data]))
+        LU = np.empty((2, nL + nU), dtype=np.complex128); health = np.zeros((2, 3)); outs = (c_vp * 2)()
+        check(lib.nep_lu_factor_dev_batch(h, 2, hptr(Ax), 10, 1e8, hptr(health), hptr(LU), outs, stream_ptr()))
+        assert outs[0] and outs[1] and health[0, 0] == 0 and health[1, 0] == 0
+        LUs[P] = LU.copy()
+        for b_, (A, Fh) in enumerate(((A0, F), (A1, F1))):
+            if np.array_equal(Fh["perm_r"], F["perm_r"]) and np.array_equal(Fh["perm_c"], F["perm_c"]) and np.array_equal(Fh["Lp"], F["Lp"]):
+                # (copies: scipy sorts the index arrays it was given IN PLACE on the first subtraction, and the plan of the next
+                # P is created from F's arrays)
+                mk = lambda x, i_, p_: sp.csc_matrix((np.array(x), np.array(i_), np.array(p_)), shape=(n, n))
+                Ld = mk(LU[b_, :nL], F["Li"], F["Lp"]); Ud = mk(LU[b_, nL:], F["Ui"], F["Up"])
+                Lh = mk(Fh["Lx"], Fh["Li"], Fh["Lp"]); Uh = mk(Fh["Ux"], Fh["Ui"], Fh["Up"])
+                assert abs(Ld - Lh).max() <= 1e-10 * abs(Lh).max() and abs(Ud - Uh).max() <= 1e-10 * abs(Uh).max()
+            rhs = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+            bd = torch.from_numpy(rhs).to("cuda"); x = torch.empty_like(bd)
+            check(lib.nep_lu_solve(outs[b_], 1, c_vp(bd.data_ptr()), n, c_vp(x.data_ptr()), n, 1.0, stream_ptr()))
+            assert np.linalg.norm(A @ x.cpu().numpy() - rhs) <= 1e-9 * np.linalg.norm(rhs)
+            lib.nep_lu_destroy(outs[b_])
+        # the same plan, the same matrix: the same bits (record order comes from an atomic counter; the values must not)
+        LU2 = np.empty(nL + nU, dtype=np.complex128); out = c_vp()
+        check(lib.nep_lu_factor_dev(h, hptr(np.ascontiguousarray(A0.data)), 10, 1e8, None, hptr(LU2), C.byref(out), stream_ptr()))
+        assert np.array_equal(LU2.view(np.float64), LUs[P][0].view(np.float64))
+        lib.nep_lu_destroy(out)
+        lib.nep_lu_refac_destroy(h)
+    for P in (2, 3, 4):
+        assert np.abs(LUs[P] - LUs[1]).max() <= 1e-10 * np.abs(LUs[1]).max()
+    assert launches[4] < launches[2] < launches[1] and launches[4] <= launches[1] // 3 + 8
+
+
 def test_compute_types(na):
     """test/compute_types.jl, the precisions NumPy and the device share: host results of a REAL NEP are float64 for real
     lambda / V / S and complex128 otherwise; a complex NEP (or one with a function that leaves the reals, gun's i*sqrt)
