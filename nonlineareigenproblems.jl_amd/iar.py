@@ -154,18 +154,25 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
 
     # initialization (method_iar.jl:76-86)
     ldv = n * (m + 1)
-    V = torch.zeros((m + 1, ldv), dtype=CDT, device="cuda")     # the fill overlaps with the host factorisation below
     H = np.zeros((m + 1, m), dtype=np.complex128)
     alpha = gamma ** np.arange(m + 1); alpha[0] = 0
     # the synchronous little uploads below come BEFORE the linear solver: once the device is busy with the factorisation and
-    # the apex build behind it, each of them waits for a slot between 300-600 us kernels (5 ms of host time for the lot)
+    # the apex build behind it, each of them waits for a slot between 300-600 us kernels (5 ms of host time for the lot) --
+    # and the start vector BEFORE the 1.6 GB zero fill of the basis is enqueued (a pageable upload behind the fill held the host
+    # for 0.46 ms; now the fill runs while the host assembles the call, the start vector goes in by a device copy behind it)
     v0 = np.asarray(v, dtype=np.complex128)
-    V[0, :n] = torch.from_numpy(v0 / np.linalg.norm(v0)).to("cuda")
+    v0d = torch.from_numpy(v0 / np.linalg.norm(v0)).to("cuda")
+    t_marks = [("v0", time.perf_counter())]
     # derivative table at sigma (DerSPMF, NEPTypes.jl:1108-1128).  The coefficient rows
     # C[j-1,:] = alpha_j/j * f^(j)(sigma) do not depend on k: uploaded once, each step uses the first k rows
     tab = nep.derivative_table(sigma, m, rowscale=alpha[1:m + 1] / np.arange(1, m + 1))
+    t_marks.append(("tab", time.perf_counter()))
     z = torch.empty(n, dtype=CDT, device="cuda")
     active = (np.arange(1, m + 2) * n).astype(np.int64)   # column j has (j+1) non-zero blocks
+    active_d0 = torch.from_numpy(active).to("cuda")
+    V = torch.zeros((m + 1, ldv), dtype=CDT, device="cuda")     # the fill overlaps with the host side of the factorisation below
+    V[0, :n].copy_(v0d)                                         # (the fill on a side stream next to the factorisation: no gain)
+    t_marks.append(("V", time.perf_counter()))
     # Asynchronous pipeline (default): nothing on the Arnoldi critical path waits for the device.  The DGKS decision
     # is taken on the device (nep_orth_dev), H's new column travels to pinned host memory behind an event that the eigen
     # worker waits for, the residual norms of the Ritz pairs come back the same way (nep_resid_batch_dev) -- the host
@@ -180,13 +187,14 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
         if inner_solver_method is None:
             inner_solver_method = DefaultInnerSolver()
     if use_async:
-        active_d = torch.from_numpy(active).to("cuda")
+        active_d = active_d0
         Hdev = torch.zeros((m, m + 4), dtype=CDT, device="cuda")     # row k-1: h[0..k), beta, flags, 4 recorded omegas
         Hpin = torch.zeros((m, m + 4), dtype=CDT).pin_memory()
         Hnp = Hpin.numpy()
         evs = [None] * (m + 1)
         filled = [False] * (m + 1)
     t_ls = time.perf_counter()
+    t_marks.append(("pre", t_ls))
     M0inv = create_linsolver(linsolvercreator, nep, sigma)
     sync(); tm["linsolver_setup"] = tm.get("linsolver_setup", 0.0) + time.perf_counter() - t_ls
     t_setup_done = time.perf_counter()
@@ -214,6 +222,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                                          hptr(rc_[0]) if rc_ else None, hptr(rc_[1]) if rc_ else None, len(nep.get_fv()),
                                          c_vp(Hdev.data_ptr()), c_vp(Hpin.data_ptr()), dense._orth_code(orthmethod), _C.byref(hh)))
                 cstep = hh
+    t_marks += [("ls", t_setup_done), ("cstep", time.perf_counter())]
     err = np.full((m, m), np.nan)
     lam = np.zeros(0, dtype=np.complex128); QT = None; idx = np.zeros(0, dtype=int)
     # ---- main loop.  The small dense eigenproblem of step k (host LAPACK, method_iar.jl:112; 7.5 ms at
@@ -233,6 +242,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
 
     trace = {} if os.environ.get("NEP_IAR_TRACE") else None
     plans = [0] * (m + 1)
+    t_marks.append(("pool", time.perf_counter()))
 
     def arnoldi_step(k):
         if cstep is not None:
@@ -399,6 +409,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     blas_guard = ctl.limit(limits=1) if (ctl is not None and os.environ.get("NEP_IAR_BLAS_GUARD", "1") != "0") else None
     if blas_guard is not None:
         blas_guard.__enter__()
+    t_marks.append(("blas", time.perf_counter()))
     try:
         if use_async and check_thread:
             # native step: this thread only issues nep_iar_step (one foreign call per step, GIL released); the checker thread
@@ -601,6 +612,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
 
             th = threading.Thread(target=checker_dev if dev_eig else checker, name="nep-iar-check", daemon=True)
             th.start()
+            t_marks.append(("thread", time.perf_counter()))
             try:
                 BATCH = max(1, min(4, LAG // 2))
                 if unthrottled:
@@ -684,7 +696,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
         if trace is not None:
             t_end = time.perf_counter()
             ks = [kk for kk in (1, 10, 25, 50, 75, 100) if "enq_%d" % kk in trace and "dev_done_%d" % kk in trace]
-            print("iar trace (ms after entry): setup %.1f | " % ((t_setup_done - t_entry) * 1e3)
+            print("iar trace (ms after entry): setup %.1f (%s) | " % ((t_setup_done - t_entry) * 1e3, " ".join("%s %.2f" % (a_, (b_ - t_entry) * 1e3) for a_, b_ in t_marks))
                   + " ".join("k=%d enq %.1f dev %.1f" % (kk, (trace["enq_%d" % kk] - t_entry) * 1e3, (trace["dev_done_%d" % kk] - t_entry) * 1e3) for kk in ks)
                   + " | end %.1f | native steps %d, %.1f ms inside nep_iar_step; checker: wait eig %.1f launch %.1f consume %.1f ms" % ((t_end - t_entry) * 1e3, trace.get("native_n", 0), trace.get("native_s", 0.0) * 1e3, trace.get("chk_wait", 0) * 1e3, trace.get("chk_launch", 0) * 1e3, trace.get("chk_consume", 0) * 1e3))
         if use_async and os.environ.get("NEP_IAR_PASSES"):

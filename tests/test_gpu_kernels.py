@@ -908,6 +908,54 @@ def test_device_factorization_wide_levels_in_panels(na, monkeypatch, case):
     assert launches[4] < launches[2] < launches[1] and launches[4] <= launches[1] // 3 + 8
 
 
+def test_linear_solver_from_terms_and_pattern_digest_memo(na, monkeypatch):
+    """linsolvers.FactorizeLinSolver._lu_from_terms: with a ready plan the matrix of a pure SPMF NEP is assembled and factorised on
+    the device from the m_t coefficients (no compute_Mder, no value upload) -- same solves as the general route, which
+    NEP_LU_TERMS=0 restores; _DeviceRefactor.key does not hash index arrays it has hashed before (same memory, kept alive)
+    and still tells patterns apart."""
+    import torch
+    from nep_amd import linsolvers as ls
+    ls._DeviceRefactor.clear()
+    nep = na.nep_gallery("gun_spmf_scaled", 1310)
+    lam0, lam1 = 0.0, 0.12 + 0.03j
+    s0 = ls.FactorizeLinSolver(nep, lam0)                       # host factorisation; starts the plan
+    assert not s0.lu.device_factorized
+    ls._DeviceRefactor.wait()
+    calls = {"n": 0}
+    orig = type(nep).compute_Mder
+
+    def counting(self, lam, i=0):
+        calls["n"] += 1
+        return orig(self, lam, i)
+    monkeypatch.setattr(type(nep), "compute_Mder", counting)
+    # (patched: the terms route must refuse a NEP whose compute_Mder is not the SPMF one)
+    s_gen = ls.FactorizeLinSolver(nep, lam1)
+    assert calls["n"] == 1 and s_gen.lu.device_factorized
+    monkeypatch.undo()
+    s_t = ls.FactorizeLinSolver(nep, lam1)
+    assert s_t.lu.device_factorized and s_t.lu.normA == pytest.approx(s_gen.lu.normA, rel=1e-12)
+    b = np.random.default_rng(3).standard_normal(nep.n) + 1j * np.random.default_rng(4).standard_normal(nep.n)
+    bd = torch.from_numpy(b).to("cuda")
+    x_t = ls.lin_solve(s_t, bd).cpu().numpy().ravel(); x_g = ls.lin_solve(s_gen, bd).cpu().numpy().ravel()
+    A1 = nep.compute_Mder(lam1)
+    assert np.linalg.norm(A1 @ x_t - b) <= 1e-10 * np.linalg.norm(b)
+    assert np.linalg.norm(x_t - x_g) <= 1e-9 * np.linalg.norm(x_g)
+    monkeypatch.setenv("NEP_LU_TERMS", "0")
+    assert ls.FactorizeLinSolver._lu_from_terms(nep, lam1, None, {"expected_solves": 200}) is None
+    monkeypatch.delenv("NEP_LU_TERMS")
+    assert ls.FactorizeLinSolver._lu_from_terms(nep, lam1, "COLAMD", {"expected_solves": 200}) is None
+    # digest memo: two matrices of the NEP share the index arrays -> one hash; equal to a fresh hash; a different pattern differs
+    Aa = sp.csc_matrix(nep.compute_Mder(lam0), dtype=np.complex128); Ab = sp.csc_matrix(nep.compute_Mder(lam1), dtype=np.complex128)
+    ka = ls._DeviceRefactor.key(Aa, (None, None, None)); kb = ls._DeviceRefactor.key(Ab, (None, None, None))
+    del ls._DeviceRefactor._digests[:]
+    Ac = Aa.copy()
+    assert ka == kb == ls._DeviceRefactor.key(Ac, (None, None, None))
+    Ad = Ac.copy(); Ad.indices = Ad.indices.copy(); Ad.indices[0], Ad.indices[1] = Ad.indices[1], Ad.indices[0]
+    assert ls._DeviceRefactor.key(Ad, (None, None, None)) != ka
+    assert ls._DeviceRefactor.key(Ac, (None, None, None)) == ka and len(ls._DeviceRefactor._digests) <= 8
+    ls._DeviceRefactor.clear()
+
+
 def test_compute_types(na):
     """test/compute_types.jl, the precisions NumPy and the device share: host results of a REAL NEP are float64 for real
     lambda / V / S and complex128 otherwise; a complex NEP (or one with a function that leaves the reals, gun's i*sqrt)
