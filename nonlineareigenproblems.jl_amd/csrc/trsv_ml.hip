@@ -394,6 +394,99 @@ __device__ __forceinline__ void ml_level_body(const MLArgs& A, const int bx, con
 template <bool UPPER, int RB, int MODE, int G2>
 __global__ __launch_bounds__(256) void k_ml_level(const MLArgs A) { ml_level_body<UPPER, RB, MODE, G2>(A, (int)blockIdx.x, (int)blockIdx.y); }
 
+// Blocks of right-hand sides (contour_beyn: 32 per node): ONE workgroup per diagonal block and group of RB right-hand sides.
+// In the chunk form above every 4-row chunk stages the right-hand-side rows its dot products read -- up to the whole block, RB
+// columns, gathered through the input permutation: 64 chunks of a 256-row block load the same 32 KB (k_ml_level<false, 8, 0> on
+// the gun factor: 301 us for level 0, 10 000 workgroups, 25 x the bytes and the flops of the product).  Here the block's r sits
+// in LDS once and the workgroup walks its packed inverse rows 16 at a time, 16 lanes per row.  Same grid as the chunk form (the
+// workgroup of a block's FIRST chunk does the block, the others leave; side-job workgroups unchanged), same sums per row up to
+// the order of the lane partials.
+template <bool UPPER, int RB, int MODE>
+__global__ __launch_bounds__(256) void k_ml_level_blk(const MLArgs A) {
+    const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
+    if (bx >= A.nchunks) { ml_level_body<UPPER, RB, MODE, 64>(A, bx, by); return; }      // side job
+    const MLChunk ch = A.chunks[bx];
+    if (ch.a != ch.s) return;
+    const int rhs0 = by * RB;
+    const int nb = min(RB, A.nrhs - rhs0);
+    const int s = ch.s, e = ch.e, nrow = e - s;
+    __shared__ cplx rbuf[RB * ML_BMAX];
+    for (int t = threadIdx.x; t < nrow; t += 256) {
+        const int c = s + t;
+        if (MODE == 0) {
+            cplx acc[RB];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) acc[r] = cmake(0.0, 0.0);
+            if (A.has_coupling) {
+                const int e1 = A.cp[c + 1];
+                for (int p = A.cp[c]; p < e1; ++p) {
+                    const cplx v = A.cx[p];
+                    const int64_t col = A.ci[p];
+                    if (col < A.col_lo) continue;
+#pragma unroll
+                    for (int r = 0; r < RB; ++r)
+                        if (r < nb) cfma(acc[r], v, A.xin[(int64_t)(rhs0 + r) * A.ldxin + col]);
+                }
+            }
+            const int64_t g = A.gat ? A.gat[c] : c;
+            const double sc = A.rs ? A.rs[g] : 1.0;
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (r < nb) {
+                    const cplx v = A.src[(int64_t)(rhs0 + r) * A.ldsrc + g];
+                    rbuf[r * ML_BMAX + t] = cmake(sc * v.x - acc[r].x, sc * v.y - acc[r].y);
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+                if (r < nb) rbuf[r * ML_BMAX + t] = A.tmp[(int64_t)(rhs0 + r) * A.ldtmp + c];
+        }
+    }
+    __syncthreads();
+    const int sub = threadIdx.x & 15, rloc = threadIdx.x >> 4;
+    for (int row0 = 0; row0 < nrow; row0 += 16) {
+        const int d = row0 + rloc;
+        const bool live = d < nrow;
+        const int rho = s + d;
+        // packed rows: LOWER row d holds columns [s, s + d], UPPER row d holds [s + d, e)
+        const int len = !live ? 0 : (UPPER ? nrow - d : d + 1);
+        const int c0 = UPPER ? d : 0;
+        const int64_t off = ch.ipa + (UPPER ? (int64_t)d * nrow - (int64_t)d * (d - 1) / 2 : (int64_t)d * (d + 1) / 2);
+        const cplx* __restrict__ row = A.ix + off;
+        cplx acc[RB];
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = cmake(0.0, 0.0);
+        // a row has at most 256 entries, 16 per lane: all of a lane's loads go out before the first product (one round trip
+        // per 16 rows; a load per trip left the single workgroup of a block waiting 16 times as often)
+        for (int t0 = 0; t0 < len; t0 += 128) {
+            cplx m[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int t = t0 + sub + 16 * u; m[u] = t < len ? row[t] : cmake(0.0, 0.0); }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int t = t0 + sub + 16 * u;
+                if (t < len) {
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) cfma(acc[r], m[u], rbuf[r * ML_BMAX + c0 + t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RB; ++r) acc[r] = group_reduce_sum<16>(acc[r]);
+        if (live && sub == 0) {
+            for (int r = 0; r < nb; ++r) {
+                A.xout[(int64_t)(rhs0 + r) * A.ldxout + rho] = acc[r];
+                if (UPPER && A.outX) {
+                    const int64_t g = A.pout ? A.pout[rho] : rho;
+                    cplx v = acc[r];
+                    if (A.add) { const cplx ad = A.add[(int64_t)(rhs0 + r) * A.ldadd + g]; v.x += ad.x; v.y += ad.y; }
+                    A.outX[(int64_t)(rhs0 + r) * A.ldX + g] = cmake(A.scale * v.x, A.scale * v.y);
+                }
+            }
+        }
+    }
+}
+
 // tmp[q] = src[q] - sum_{col_lo <= col < col_hi} C[q,col] xin[col]   for the rows [r0, r1) of one level; G lanes per row
 // (G = 256: one workgroup per row); ident_row0 >= 0: src is the identity block (rhs j = e_(ident_row0 + j))
 struct MLCplArgs {
@@ -1532,7 +1625,20 @@ static void launch_level_g(const MLArgs& a, int nside_wg, int nrhs, hipStream_t 
         if (rec_push(&p, PH_LEVEL, (UPPER ? 6 : 0) + MODE * 3 + (G2 == 64 ? 0 : (G2 == 16 ? 1 : 2)), (int)gx)) p->u.lv = a;
         return;
     }
-    if (nrhs >= 8) hipLaunchKernelGGL((k_ml_level<UPPER, 8, MODE, G2>), dim3(gx, (nrhs + 7) / 8), b, 0, st, a);
+    // blocks of right-hand sides on a level of many diagonal blocks (gun level 0: 51 blocks, 9 000 rows): one workgroup per
+    // block and 4 right-hand sides (k_ml_level_blk; C4 77 -> 66 ms).  Levels of few blocks keep the chunk form -- a block's lone
+    // workgroup takes 30-90 us whatever the level holds (measured: all levels in block form 70 ms, 8 RHS per workgroup 85 ms).
+    // (read per multi-right-hand-side launch, not cached: tests switch forms inside one process; single-vector solves never get here)
+    int blk_rhs = 0, blk_min = 0;
+    if (nrhs >= 8) {
+        const char* e1 = getenv("NEP_ML_BLK_RHS"); const char* e2 = getenv("NEP_ML_BLK_RHS_MIN");
+        blk_rhs = e1 ? atoi(e1) : 4;                // 0: chunk form everywhere
+        blk_min = e2 ? atoi(e2) : 4000;             // rows of the level
+    }
+    const bool blk_ok = nrhs >= 8 && a.ident_row0 < 0 && (int64_t)a.nchunks * (256 / G2) >= blk_min;
+    if (blk_ok && blk_rhs == 4) hipLaunchKernelGGL((k_ml_level_blk<UPPER, 4, MODE>), dim3(gx, (nrhs + 3) / 4), b, 0, st, a);
+    else if (blk_ok && blk_rhs) hipLaunchKernelGGL((k_ml_level_blk<UPPER, 8, MODE>), dim3(gx, (nrhs + 7) / 8), b, 0, st, a);
+    else if (nrhs >= 8) hipLaunchKernelGGL((k_ml_level<UPPER, 8, MODE, G2>), dim3(gx, (nrhs + 7) / 8), b, 0, st, a);
     else if (nrhs >= 2) hipLaunchKernelGGL((k_ml_level<UPPER, 4, MODE, G2>), dim3(gx, (nrhs + 3) / 4), b, 0, st, a);
     else hipLaunchKernelGGL((k_ml_level<UPPER, 1, MODE, G2>), dim3(gx, 1), b, 0, st, a);
 }

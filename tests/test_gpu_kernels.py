@@ -237,6 +237,39 @@ def test_lu_solve_vs_host(na, nrhs):
     assert np.linalg.norm(na.to_host(Bd) + Xo) <= 1e-10 * np.linalg.norm(Xo)
 
 
+@pytest.mark.parametrize("nrhs", [8, 13, 32])
+@pytest.mark.parametrize("bmax", [None, "96"])
+def test_lu_solve_blocks_of_rhs_one_workgroup_per_block(na, monkeypatch, nrhs, bmax):
+    """csrc/trsv_ml.hip k_ml_level_blk: blocks of right-hand sides (contour_beyn) on a level of many diagonal blocks -- one
+    workgroup per block and 4 (or 8) right-hand sides, the block's r staged in LDS once -- against the chunk form
+    (NEP_ML_BLK_RHS=0) and the host solve; forced onto every level (NEP_ML_BLK_RHS_MIN=0), with ragged groups of right-hand
+    sides, in-place output with scale, and smaller diagonal blocks."""
+    from oracle import gallery as og
+    if bmax:
+        monkeypatch.setenv("NEP_ML_BMAX", bmax)
+    nep = og.nlevp_native_gun(2200)
+    A = sp.csc_matrix(nep.compute_Mder(250.0 ** 2 + 1j), dtype=complex)
+    rng = np.random.default_rng(12)
+    n = A.shape[0]
+    B = rng.standard_normal((n, nrhs)) + 1j * rng.standard_normal((n, nrhs))
+    lu = na.DeviceLU(A)
+    Xo = spla.splu(A).solve(B)
+    res = {}
+    for form, rows_min in (("0", "0"), ("4", "0"), ("8", "0"), ("4", "4000")):
+        monkeypatch.setenv("NEP_ML_BLK_RHS", form); monkeypatch.setenv("NEP_ML_BLK_RHS_MIN", rows_min)
+        X = na.to_host(lu.solve(na.to_dev(B)))
+        assert np.linalg.norm(X - Xo) <= 1e-10 * np.linalg.norm(Xo)
+        Bd = na.to_dev(B)
+        lu.solve(Bd, out=Bd, scale=-0.5)
+        assert np.linalg.norm(na.to_host(Bd) + 0.5 * X) <= 1e-13 * np.linalg.norm(X)
+        res[(form, rows_min)] = X
+    for key in (("4", "0"), ("8", "0")):
+        assert np.linalg.norm(res[key] - res[("0", "0")]) <= 1e-12 * np.linalg.norm(Xo)
+    # (n = 2200: no level reaches 4000 rows, the default threshold leaves every level in chunk form; not compared bit for bit --
+    # the factor's solves switch to the dense apex inverse at the sixth solve)
+    assert np.linalg.norm(res[("4", "4000")] - res[("0", "0")]) <= 1e-12 * np.linalg.norm(Xo)
+
+
 @pytest.mark.parametrize("spec", [dict(), dict(NEP_LU_BLOCK="64", NEP_LU_MID="512", NEP_LU_TAIL="0"),
                                   dict(NEP_LU_BLOCK="128", NEP_LU_MID="384", NEP_LU_TAIL="100"), dict(NEP_LU_MID="0")])
 def test_lu_blocked_mid_region(na, spec, monkeypatch):
