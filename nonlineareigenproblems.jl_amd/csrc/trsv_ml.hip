@@ -400,18 +400,25 @@ __global__ __launch_bounds__(256) void k_ml_level(const MLArgs A) { ml_level_bod
 // the gun factor: 301 us for level 0, 10 000 workgroups, 25 x the bytes and the flops of the product).  Here the block's r sits
 // in LDS once and the workgroup walks its packed inverse rows 16 at a time, 16 lanes per row.  Same grid as the chunk form (the
 // workgroup of a block's FIRST chunk does the block, the others leave; side-job workgroups unchanged), same sums per row up to
-// the order of the lane partials.
+// the order of the lane partials.  A block's rows go in SEGMENTS of 64 to separate workgroups (a lone workgroup per 256-row block
+// was one long chain: 131 us on gun's level 0, 30-90 us on a level of six blocks); a segment stages the columns its rows read.
+#define ML_BLK_SEG 64
 template <bool UPPER, int RB, int MODE>
 __global__ __launch_bounds__(256) void k_ml_level_blk(const MLArgs A) {
     const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
     if (bx >= A.nchunks) { ml_level_body<UPPER, RB, MODE, 64>(A, bx, by); return; }      // side job
     const MLChunk ch = A.chunks[bx];
-    if (ch.a != ch.s) return;
+    // (a block's rows in segments of ML_BLK_SEG: the workgroup of the chunk a segment starts with does the segment, the
+    // others leave; a segment stages the columns its rows read -- [s, end of segment) for LOWER, [start of segment, e) for UPPER)
+    const int d0 = ch.a - ch.s;
+    if (d0 % ML_BLK_SEG != 0) return;
     const int rhs0 = by * RB;
     const int nb = min(RB, A.nrhs - rhs0);
     const int s = ch.s, e = ch.e, nrow = e - s;
+    const int d1 = min(d0 + ML_BLK_SEG, nrow);
+    const int64_t ipa_s = ch.ipa - (UPPER ? (int64_t)d0 * nrow - (int64_t)d0 * (d0 - 1) / 2 : (int64_t)d0 * (d0 + 1) / 2);
     __shared__ cplx rbuf[RB * ML_BMAX];
-    for (int t = threadIdx.x; t < nrow; t += 256) {
+    for (int t = (UPPER ? d0 : 0) + threadIdx.x; t < (UPPER ? nrow : d1); t += 256) {
         const int c = s + t;
         if (MODE == 0) {
             cplx acc[RB];
@@ -444,14 +451,14 @@ __global__ __launch_bounds__(256) void k_ml_level_blk(const MLArgs A) {
     }
     __syncthreads();
     const int sub = threadIdx.x & 15, rloc = threadIdx.x >> 4;
-    for (int row0 = 0; row0 < nrow; row0 += 16) {
+    for (int row0 = d0; row0 < d1; row0 += 16) {
         const int d = row0 + rloc;
-        const bool live = d < nrow;
+        const bool live = d < d1;
         const int rho = s + d;
         // packed rows: LOWER row d holds columns [s, s + d], UPPER row d holds [s + d, e)
         const int len = !live ? 0 : (UPPER ? nrow - d : d + 1);
         const int c0 = UPPER ? d : 0;
-        const int64_t off = ch.ipa + (UPPER ? (int64_t)d * nrow - (int64_t)d * (d - 1) / 2 : (int64_t)d * (d + 1) / 2);
+        const int64_t off = ipa_s + (UPPER ? (int64_t)d * nrow - (int64_t)d * (d - 1) / 2 : (int64_t)d * (d + 1) / 2);
         const cplx* __restrict__ row = A.ix + off;
         cplx acc[RB];
 #pragma unroll
@@ -1625,15 +1632,16 @@ static void launch_level_g(const MLArgs& a, int nside_wg, int nrhs, hipStream_t 
         if (rec_push(&p, PH_LEVEL, (UPPER ? 6 : 0) + MODE * 3 + (G2 == 64 ? 0 : (G2 == 16 ? 1 : 2)), (int)gx)) p->u.lv = a;
         return;
     }
-    // blocks of right-hand sides on a level of many diagonal blocks (gun level 0: 51 blocks, 9 000 rows): one workgroup per
-    // block and 4 right-hand sides (k_ml_level_blk; C4 77 -> 66 ms).  Levels of few blocks keep the chunk form -- a block's lone
-    // workgroup takes 30-90 us whatever the level holds (measured: all levels in block form 70 ms, 8 RHS per workgroup 85 ms).
+    // blocks of right-hand sides: one workgroup per 64-row segment of a diagonal block and 4 right-hand sides (k_ml_level_blk;
+    // C4 77 -> 62 ms; 8 right-hand sides per workgroup: 83 ms -- registers).  With whole blocks per workgroup the levels of few
+    // blocks were better off in the chunk form (a lone workgroup per block took 30-90 us: 70 ms with every level in block form,
+    // 65.5 ms with levels of >= 4000 rows only); in segments every level gains.
     // (read per multi-right-hand-side launch, not cached: tests switch forms inside one process; single-vector solves never get here)
     int blk_rhs = 0, blk_min = 0;
     if (nrhs >= 8) {
         const char* e1 = getenv("NEP_ML_BLK_RHS"); const char* e2 = getenv("NEP_ML_BLK_RHS_MIN");
         blk_rhs = e1 ? atoi(e1) : 4;                // 0: chunk form everywhere
-        blk_min = e2 ? atoi(e2) : 4000;             // rows of the level
+        blk_min = e2 ? atoi(e2) : 0;                // rows of the level below which the chunk form is kept
     }
     const bool blk_ok = nrhs >= 8 && a.ident_row0 < 0 && (int64_t)a.nchunks * (256 / G2) >= blk_min;
     if (blk_ok && blk_rhs == 4) hipLaunchKernelGGL((k_ml_level_blk<UPPER, 4, MODE>), dim3(gx, (nrhs + 3) / 4), b, 0, st, a);

@@ -265,8 +265,8 @@ def test_lu_solve_blocks_of_rhs_one_workgroup_per_block(na, monkeypatch, nrhs, b
         res[(form, rows_min)] = X
     for key in (("4", "0"), ("8", "0")):
         assert np.linalg.norm(res[key] - res[("0", "0")]) <= 1e-12 * np.linalg.norm(Xo)
-    # (n = 2200: no level reaches 4000 rows, the default threshold leaves every level in chunk form; not compared bit for bit --
-    # the factor's solves switch to the dense apex inverse at the sixth solve)
+    # (a row threshold no level of this factor reaches: chunk form again; not compared bit for bit -- the factor's solves switch
+    # to the dense apex inverse at the sixth solve)
     assert np.linalg.norm(res[("4", "4000")] - res[("0", "0")]) <= 1e-12 * np.linalg.norm(Xo)
 
 
