@@ -30,6 +30,7 @@
 #include <chrono>
 #include <cstring>
 
+#define ML_BLK_SEG 64          // rows of a diagonal block per workgroup of k_ml_level_blk (a multiple of every chunk size)
 #define ML_BMAX 256            // largest diagonal block (rows): LDS staging of the fused level kernel is sized for it
 
 struct MLChunk { int32_t a, b, s, e; int64_t ipa; };   // rows [a,b) of the block with rows [s,e); ipa = offset of row a's packed inverse row
@@ -50,6 +51,8 @@ struct MLFacSym {
     int32_t* d_map = nullptr;      // the same on the device (uploaded on first use by the device-side numeric path)
     int64_t ncoup = 0, nin = 0, ninv = 0;
     MLChunk* d_chunks = nullptr;   // row chunks of the level kernels (chunk size depends on the level's mode)
+    int32_t* d_segs = nullptr;     // k_ml_level_blk: the chunks (index inside their level) that start a 64-row segment of a block
+    std::vector<int32_t> lev_seg;  // nlev+1
     std::vector<int32_t> lev_chunk;    // nlev+1
     std::vector<int> lev_ch;       // per level: rows per chunk (4, 16 or 32)
     std::vector<uint8_t> split;    // per level: coupling product as its own launch
@@ -242,6 +245,7 @@ __global__ void k_ml_gather(int64_t nnz, const int32_t* __restrict__ map, const 
 // ---- solve kernels ------------------------------------------------------------------------------------------------
 struct MLArgs {
     const MLChunk* chunks; int nchunks;
+    const int32_t* segs; int nsegs; int nside;                     // k_ml_level_blk: segment-starting chunks, side-job workgroups
     const int32_t* cp; const int32_t* ci; const cplx* cx;          // coupling CSR
     const cplx* ix;                                                // packed inverse rows (offsets in the chunk records)
     int has_coupling;
@@ -402,16 +406,22 @@ __global__ __launch_bounds__(256) void k_ml_level(const MLArgs A) { ml_level_bod
 // workgroup of a block's FIRST chunk does the block, the others leave; side-job workgroups unchanged), same sums per row up to
 // the order of the lane partials.  A block's rows go in SEGMENTS of 64 to separate workgroups (a lone workgroup per 256-row block
 // was one long chain: 131 us on gun's level 0, 30-90 us on a level of six blocks); a segment stages the columns its rows read.
-#define ML_BLK_SEG 64
 template <bool UPPER, int RB, int MODE>
 __global__ __launch_bounds__(256) void k_ml_level_blk(const MLArgs A) {
-    const int bx = (int)blockIdx.x, by = (int)blockIdx.y;
-    if (bx >= A.nchunks) { ml_level_body<UPPER, RB, MODE, 64>(A, bx, by); return; }      // side job
+    // 1-D grid over (segment or side-job workgroup) x (group of RB right-hand sides), XCD-aware: workgroups are dealt to the 8
+    // XCDs round robin by their linear id, so the groups of right-hand sides of ONE segment take ids 8 apart: they land on one
+    // XCD, one after the other -- the segment's packed inverse rows come from HBM once and from that XCD's L2 for the other groups
+    // (a 2-D grid put every group on another XCD -- 8 x the reads -- or, with gridDim.x a multiple of 8, all of them on one)
+    const int ngy = (A.nrhs + RB - 1) / RB;
+    const int xcd = (int)(blockIdx.x & 7), slot = (int)(blockIdx.x >> 3);
+    const int by = slot % ngy, item = (slot / ngy) * 8 + xcd;
+    if (item >= A.nsegs + A.nside) return;
+    if (item >= A.nsegs) { ml_level_body<UPPER, RB, MODE, 64>(A, A.nchunks + item - A.nsegs, by); return; }      // side job
+    const int bx = A.segs[item];
     const MLChunk ch = A.chunks[bx];
-    // (a block's rows in segments of ML_BLK_SEG: the workgroup of the chunk a segment starts with does the segment, the
-    // others leave; a segment stages the columns its rows read -- [s, end of segment) for LOWER, [start of segment, e) for UPPER)
+    // (a block's rows in segments of ML_BLK_SEG; a segment stages the columns its rows read -- [s, end of segment) for LOWER,
+    // [start of segment, e) for UPPER)
     const int d0 = ch.a - ch.s;
-    if (d0 % ML_BLK_SEG != 0) return;
     const int rhs0 = by * RB;
     const int nb = min(RB, A.nrhs - rhs0);
     const int s = ch.s, e = ch.e, nrow = e - s;
@@ -804,7 +814,7 @@ int up(T** d, const std::vector<T>& h, size_t min_count = 1) {
 
 void free_fac(MLFacSym& f) {
     nep_pool_free(f.d_cp); nep_pool_free(f.d_ci); nep_pool_free(f.d_ip); nep_pool_free(f.d_bp); nep_pool_free(f.d_bi);
-    nep_pool_free(f.d_slotrow); nep_pool_free(f.d_lvp); nep_pool_free(f.d_lvo); nep_pool_free(f.d_rowlev); nep_pool_free(f.d_chunks);
+    nep_pool_free(f.d_slotrow); nep_pool_free(f.d_lvp); nep_pool_free(f.d_lvo); nep_pool_free(f.d_rowlev); nep_pool_free(f.d_chunks); nep_pool_free(f.d_segs);
     if (f.d_map) nep_pool_free(f.d_map);
 }
 void free_sym(MLSym* s) {
@@ -928,7 +938,9 @@ int build_factor(const MLSym& S, bool upper, const int32_t* rp, const int32_t* c
     // redundantly by every chunk of a block) or as its own launch; rows per chunk
     F.split.assign(S.nlev, 0); F.cpl_lanes.assign(S.nlev, 8); F.lev_coup.assign(S.nlev, 0); F.lev_ch.assign(S.nlev, 4);
     F.lev_chunk.assign(S.nlev + 1, 0);
+    F.lev_seg.assign(S.nlev + 1, 0);
     std::vector<MLChunk> chunks;
+    std::vector<int32_t> segs;
     const char* fs = getenv("NEP_ML_SPLIT");       // experiment knobs: 0 = always fused, 1 = always split; rows per chunk
     int ch_env = 0;
     if (const char* e = getenv("NEP_ML_CHUNK")) { const int v = atoi(e); if (v == 4 || v == 16 || v == 32) ch_env = v; }
@@ -956,12 +968,17 @@ int build_factor(const MLSym& S, bool upper, const int32_t* rp, const int32_t* c
         if (ch_env) CH = ch_env;
         F.lev_ch[l] = CH;
         F.lev_chunk[l] = (int32_t)chunks.size();
+        F.lev_seg[l] = (int32_t)segs.size();
         for (int k = S.lev_blk[l]; k < S.lev_blk[l + 1]; ++k) {
             const int32_t s = blk_se[2 * k], e = blk_se[2 * k + 1];
-            for (int32_t a = s; a < e; a += CH) chunks.push_back(MLChunk{a, std::min(a + CH, e), s, e, ip[a]});
+            for (int32_t a = s; a < e; a += CH) {
+                if ((a - s) % ML_BLK_SEG == 0) segs.push_back((int32_t)chunks.size() - F.lev_chunk[l]);
+                chunks.push_back(MLChunk{a, std::min(a + CH, e), s, e, ip[a]});
+            }
         }
     }
     F.lev_chunk[S.nlev] = (int32_t)chunks.size();
+    F.lev_seg[S.nlev] = (int32_t)segs.size();
     int rc;
     if ((rc = up(&F.d_cp, cp))) return rc;
     if ((rc = up(&F.d_ci, cci))) return rc;
@@ -976,6 +993,7 @@ int build_factor(const MLSym& S, bool upper, const int32_t* rp, const int32_t* c
         if ((rc = up(&F.d_rowlev, rl))) return rc;
     }
     if ((rc = up(&F.d_chunks, chunks))) return rc;
+    if ((rc = up(&F.d_segs, segs))) return rc;
     return NEP_OK;
 }
 
@@ -1644,8 +1662,12 @@ static void launch_level_g(const MLArgs& a, int nside_wg, int nrhs, hipStream_t 
         blk_min = e2 ? atoi(e2) : 0;                // rows of the level below which the chunk form is kept
     }
     const bool blk_ok = nrhs >= 8 && a.ident_row0 < 0 && (int64_t)a.nchunks * (256 / G2) >= blk_min;
-    if (blk_ok && blk_rhs == 4) hipLaunchKernelGGL((k_ml_level_blk<UPPER, 4, MODE>), dim3(gx, (nrhs + 3) / 4), b, 0, st, a);
-    else if (blk_ok && blk_rhs) hipLaunchKernelGGL((k_ml_level_blk<UPPER, 8, MODE>), dim3(gx, (nrhs + 7) / 8), b, 0, st, a);
+    if (blk_ok && blk_rhs) {
+        MLArgs a2 = a; a2.nside = nside_wg;
+        const unsigned items8 = (unsigned)((a.nsegs + nside_wg + 7) / 8);
+        if (blk_rhs == 4) hipLaunchKernelGGL((k_ml_level_blk<UPPER, 4, MODE>), dim3(items8 * 8 * (unsigned)((nrhs + 3) / 4)), b, 0, st, a2);
+        else hipLaunchKernelGGL((k_ml_level_blk<UPPER, 8, MODE>), dim3(items8 * 8 * (unsigned)((nrhs + 7) / 8)), b, 0, st, a2);
+    }
     else if (nrhs >= 8) hipLaunchKernelGGL((k_ml_level<UPPER, 8, MODE, G2>), dim3(gx, (nrhs + 7) / 8), b, 0, st, a);
     else if (nrhs >= 2) hipLaunchKernelGGL((k_ml_level<UPPER, 4, MODE, G2>), dim3(gx, (nrhs + 3) / 4), b, 0, st, a);
     else hipLaunchKernelGGL((k_ml_level<UPPER, 1, MODE, G2>), dim3(gx, 1), b, 0, st, a);
@@ -1701,6 +1723,7 @@ static int run_L(const MLSolveCtx& c, int l, bool first, hipStream_t st, int* la
     }
     MLArgs a; memset(&a, 0, sizeof(a));
     a.chunks = f.d_chunks + f.lev_chunk[l]; a.nchunks = f.lev_chunk[l + 1] - f.lev_chunk[l];
+    a.segs = f.d_segs + f.lev_seg[l]; a.nsegs = f.lev_seg[l + 1] - f.lev_seg[l];
     a.cp = f.d_cp; a.ci = f.d_ci; a.cx = cx; a.ix = c.F->d_ixL; a.has_coupling = f.lev_coup[l] > 0 ? 1 : 0;
     a.src = src; a.ldsrc = ldsrc; a.gat = first ? S->d_pin : nullptr; a.rs = first ? c.F->d_rscale : nullptr;
     a.ident_row0 = c.ident_row0; a.col_lo = c.col_lo;
@@ -1733,6 +1756,7 @@ static int run_U_level(const MLSolveCtx& c, int l, bool final, hipStream_t st, i
     const cplx* cx = c.F->d_vals + (S->L.ncoup + S->L.nin);
     MLArgs a; memset(&a, 0, sizeof(a));
     a.chunks = f.d_chunks + f.lev_chunk[l]; a.nchunks = f.lev_chunk[l + 1] - f.lev_chunk[l];
+    a.segs = f.d_segs + f.lev_seg[l]; a.nsegs = f.lev_seg[l + 1] - f.lev_seg[l];
     a.cp = f.d_cp; a.ci = f.d_ci; a.cx = cx; a.ix = c.F->d_ixU; a.has_coupling = f.lev_coup[l] > 0 ? 1 : 0;
     a.src = c.y; a.ldsrc = c.ld; a.xin = c.x; a.ldxin = c.ld; a.xout = c.x; a.ldxout = c.ld; a.tmp = c.tmp; a.ldtmp = c.ld;
     a.ident_row0 = -1; a.col_lo = 0;
