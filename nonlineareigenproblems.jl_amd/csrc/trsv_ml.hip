@@ -491,7 +491,9 @@ __global__ __launch_bounds__(256) void k_ml_level_blk(const MLArgs A) {
 #pragma unroll
         for (int r = 0; r < RB; ++r) acc[r] = group_reduce_sum<16>(acc[r]);
         if (live && sub == 0) {
-            for (int r = 0; r < nb; ++r) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {        // (static indices: a run-time bound put acc[] into scratch memory)
+                if (r >= nb) break;
                 A.xout[(int64_t)(rhs0 + r) * A.ldxout + rho] = acc[r];
                 if (UPPER && A.outX) {
                     const int64_t g = A.pout ? A.pout[rho] : rho;
