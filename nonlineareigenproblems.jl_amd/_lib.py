@@ -155,6 +155,7 @@ SIGNATURES = {
     "nep_sum_ranks": [c_vp, c_i64, c_i32, c_vp, c_vp],
     "nep_iar_shift_scale": [c_i64, c_i32, c_vp, c_vp, c_vp],
     "nep_rk_bw": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp],
+    "nep_discretize_polygon": [c_i32, c_vp, c_i32, c_vp],
     "nep_block_recur": [c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp],
     "nep_axpy": [c_i64, cdouble, c_vp, c_vp, c_vp],
     "nep_scal": [c_i64, cdouble, c_vp, c_vp],

@@ -642,6 +642,45 @@ int32_t nep_nrm2(int64_t len, const nep_cdouble* dx, double* h_out, nep_stream s
     return nep_colnorms(len, 1, dx, len, h_out, stream);
 }
 
+// host only: src/rk_helper/discretizepolygon.jl, the boundary walk (see include/nepmi355.h).  Every operation separately rounded, in
+// the order of the interpreted walk (NumPy scalars): |z1 - z0| through hypot, a real times a complex as the full complex product
+// with a zero imaginary part.
+int32_t nep_discretize_polygon(int32_t nz, const nep_cdouble* h_z, int32_t npts, nep_cdouble* h_out) {
+#pragma clang fp contract(off)
+    ARGCHK(nz >= 3 && h_z && npts >= 1 && h_out);
+    std::vector<double> zx((size_t)nz + 1), zy((size_t)nz + 1);
+    for (int i = 0; i < nz; ++i) { zx[i] = h_z[i].re; zy[i] = h_z[i].im; }
+    zx[nz] = zx[0]; zy[nz] = zy[0];
+    // L = np.sum(abs(np.diff(z))): NumPy's pairwise summation for n >= 8 differs from a running sum -- the caller passes L's
+    // terms through the same np.sum, so L comes in h_out[0].re
+    const double L = h_out[0].re;
+    int ind = 0; double alph = 0.0;
+    const double step = L / (double)npts;
+    double remL = step;
+    int have = 1;
+    h_out[0].re = zx[0]; h_out[0].im = zy[0];
+    while (have < npts) {
+        if (ind >= nz) { nep_set_error("discretize_polygon: walked past the last edge"); return NEP_ERR_ARG; }
+        const double dx = zx[ind + 1] - zx[ind], dy = zy[ind + 1] - zy[ind];
+        const double d = hypot(dx, dy);
+        const double t = (1.0 - alph) * d;
+        if (t < remL) {
+            ind += 1;
+            remL = remL - t;
+            alph = 0.0;
+        } else {
+            const double q = remL / d;
+            alph = alph + q;
+            remL = step;
+            // z[ind] + alph * (z[ind+1] - z[ind]) with alph promoted to (alph + 0i)
+            const double pr = alph * dx - 0.0 * dy, pi = alph * dy + 0.0 * dx;
+            h_out[have].re = zx[ind] + pr; h_out[have].im = zy[ind] + pi;
+            ++have;
+        }
+    }
+    return NEP_OK;
+}
+
 static thread_local NepScratch g_rk_scratch;
 static thread_local PinnedRing g_rk_ring;
 

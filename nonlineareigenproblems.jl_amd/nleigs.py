@@ -21,6 +21,7 @@ the weighted block sum in between is one nep_rowdot.
 followed by K6 DGKS on the (N+1) n-row basis with per-column active row counts, and -- every check_error_every
 steps -- host `eig(K,H)`, one K7 GEMM for the Ritz block and K2 for all residuals.
 """
+import os
 import numpy as np
 import scipy.linalg as sla
 import torch
@@ -46,9 +47,22 @@ class NleigsSolutionDetails:
         self.Lam, self.Res, self.sigma, self.xi, self.beta, self.nrmD, self.kconv = Lam, Res, sigma, xi, beta, nrmD, kconv
 
 
-def nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger=0, maxdgr=100, minit=20, maxit=200,
-           linsolvercreator=None, tol=1e-10, tollin=None, v=None, errmeasure=None, isfunm=True, static=False, leja=1,
-           nodes=(), reusefact=1, blksize=20, return_details=False, check_error_every=5, info=None):
+def nleigs(nep, *args, **kw):
+    """src/method_nleigs.jl (see _nleigs).  The host side of a call is a few hundred small dense operations (divided differences
+    of matrix functions: 102 x 102 solves, the pencil's generalised eigenproblem, Leja-Bagby points): with a threaded BLAS each of
+    them pays the wake-up of the pool -- 6 ms per 102 x 102 `solve` instead of 0.3 (gun R1: 23 of 86 ms) -- so BLAS runs on one
+    thread for the duration of the call (NEP_NLEIGS_BLAS_GUARD=0: left alone), as in iar's loop."""
+    import nep_amd_hostlu as _nep_hostlu
+    ctl = _nep_hostlu.blas_controller() if os.environ.get("NEP_NLEIGS_BLAS_GUARD", "1") != "0" else None
+    if ctl is None:
+        return _nleigs(nep, *args, **kw)
+    with ctl.limit(limits=1, user_api="blas"):
+        return _nleigs(nep, *args, **kw)
+
+
+def _nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger=0, maxdgr=100, minit=20, maxit=200,
+            linsolvercreator=None, tol=1e-10, tollin=None, v=None, errmeasure=None, isfunm=True, static=False, leja=1,
+            nodes=(), reusefact=1, blksize=20, return_details=False, check_error_every=5, info=None):
     import warnings
     if tollin is None:
         tollin = max(tol / 10, 100 * EPS)

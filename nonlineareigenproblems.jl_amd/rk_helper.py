@@ -46,6 +46,20 @@ def in_Sigma(z, Sigma, tol):
     return np.array([inpolygon(p.real, p.imag, rx, iy) for p in np.atleast_1d(z)], dtype=bool)
 
 
+def _discretize_native(zv, L, npts):
+    """the boundary walk through the library (host code); None when switched off or not applicable"""
+    import os
+    if os.environ.get("NEP_RK_NATIVE", "1") == "0" or npts < 1 or len(zv) < 3 or not np.isfinite(L) or not L > 0:
+        return None
+    from ._lib import lib, hptr
+    zc = np.ascontiguousarray(zv, dtype=np.complex128)
+    out = np.empty(npts, dtype=np.complex128)
+    out[0] = L                                   # (L = np.sum(...) travels in: NumPy's pairwise sum is not a running sum)
+    if lib.nep_discretize_polygon(len(zc), hptr(zc), int(npts), hptr(out)) != 0:
+        return None
+    return out
+
+
 def discretizepolygon(z, include_interior_points=False, npts=10000, nptsint=5):
     z = np.asarray(z, dtype=complex)
     if len(z) == 0:
@@ -57,20 +71,25 @@ def discretizepolygon(z, include_interior_points=False, npts=10000, nptsint=5):
     else:
         z = np.concatenate([z, z[:1]])
         L = np.sum(abs(np.diff(z)))
-        ind = 0; alph = 0.0
-        pts = [z[0]]
-        remL = L / npts
-        while len(pts) < npts:
-            d = abs(z[ind + 1] - z[ind])
-            if (1 - alph) * d < remL:
-                ind += 1
-                remL -= (1 - alph) * d
-                alph = 0.0
-            else:
-                alph += remL / d
-                remL = L / npts
-                pts.append(z[ind] + alph * (z[ind + 1] - z[ind]))
-        zz = np.asarray(pts, dtype=complex)
+        # the point-by-point walk of discretizepolygon.jl (10 000 interpreted iterations: 8 ms of a nleigs call) in the library's
+        # host code, operation by operation (nep_discretize_polygon; NEP_RK_NATIVE=0 keeps the interpreted walk -- same bits,
+        # tests/test_host_logic.py::test_discretizepolygon_native_walk_equals_the_interpreted_one)
+        zz = _discretize_native(z[:-1], L, npts)
+        if zz is None:
+            ind = 0; alph = 0.0
+            pts = [z[0]]
+            remL = L / npts
+            while len(pts) < npts:
+                d = abs(z[ind + 1] - z[ind])
+                if (1 - alph) * d < remL:
+                    ind += 1
+                    remL -= (1 - alph) * d
+                    alph = 0.0
+                else:
+                    alph += remL / d
+                    remL = L / npts
+                    pts.append(z[ind] + alph * (z[ind + 1] - z[ind]))
+            zz = np.asarray(pts, dtype=complex)
     zz = np.concatenate([zz, z])
     Z = np.zeros(0, dtype=complex)
     if include_interior_points:

@@ -711,3 +711,43 @@ def test_no_vendor_blas_or_fft_behind_the_abi():
     users = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h"))
                    and re.search(r"#include\s*<(hipcub|rocprim|rocblas|hipblas|rocfft|hipfft|rocsparse|rocsolver|rocwmma|ck)[/_.]", open(os.path.join(csrc, f)).read()))
     assert users == ["lufac.hip"], users
+
+
+def test_discretizepolygon_native_walk_equals_the_interpreted_one(monkeypatch):
+    """nep_amd.rk_helper.discretizepolygon hands the boundary walk of src/rk_helper/discretizepolygon.jl to the library's host
+    code (nep_discretize_polygon: every operation separately rounded, no fused multiply-adds) where oracle/nleigs.py walks it in
+    the interpreter: the SAME bits for every point (the Leja-Bagby selection behind it takes an argmax over these candidates) --
+    polygons of 3-11 vertices over nine decades of size, a 1500-vertex arc like gun's target set, near-degenerate edges, point
+    counts that end mid-edge; NEP_RK_NATIVE=0 is the interpreted walk"""
+    from nep_amd import rk_helper as rk
+    from oracle import nleigs as on
+    rng = np.random.default_rng(0)
+    cases = [np.array([-1 - 1j, -1 + 1j, 1 + 1j, 1 - 1j]),
+             146.71 ** 2 + (300.0 ** 2 - 146.71 ** 2) / 2 * (1 + np.exp(1j * np.linspace(0, np.pi, 9))),
+             62500.0 + 28000.0 * np.exp(1j * np.linspace(0, np.pi, 1500))]
+    for _ in range(60):
+        k = int(rng.integers(3, 12))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, k)); r = rng.uniform(0.1, 5, k) * 10.0 ** int(rng.integers(-3, 6))
+        cases.append(r * np.exp(1j * ang) + 3 * rng.standard_normal())
+    for _ in range(10):
+        z = rng.standard_normal(5) + 1j * rng.standard_normal(5); z[2] = z[1] + 1e-13
+        cases.append(z)
+    calls = {"n": 0}
+    orig = rk._discretize_native
+
+    def counting(*a):
+        r = orig(*a)
+        calls["n"] += r is not None
+        return r
+    monkeypatch.setattr(rk, "_discretize_native", counting)
+    for z in cases:
+        for npts in (10000, 1000, 37, 3):
+            a, _ = rk.discretizepolygon(z, False, npts); b, _ = on.discretizepolygon(z, False, npts)
+            assert a.shape == b.shape and np.array_equal(a.view(np.float64), b.view(np.float64))
+    assert calls["n"] == 4 * len(cases)                      # the library did the walks
+    a, Za = rk.discretizepolygon(cases[0], True); b, Zb = on.discretizepolygon(cases[0], True)
+    assert np.array_equal(a, b) and np.array_equal(Za, Zb)
+    monkeypatch.setenv("NEP_RK_NATIVE", "0")
+    n0 = calls["n"]
+    a, _ = rk.discretizepolygon(cases[2]); b, _ = on.discretizepolygon(cases[2])
+    assert calls["n"] == n0 and np.array_equal(a.view(np.float64), b.view(np.float64))
