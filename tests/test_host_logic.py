@@ -751,3 +751,24 @@ def test_discretizepolygon_native_walk_equals_the_interpreted_one(monkeypatch):
     n0 = calls["n"]
     a, _ = rk.discretizepolygon(cases[2]); b, _ = on.discretizepolygon(cases[2])
     assert calls["n"] == n0 and np.array_equal(a.view(np.float64), b.view(np.float64))
+
+
+def test_lejabagby_in_place_form_equals_the_oracle_bit_for_bit():
+    """nep_amd.rk_helper.lejabagby issues the reference's update  s * betainv * (X - a_j) / (1 - X * binv)  (src/rk_helper/lejabagby.jl)
+    as the same ufunc calls into work arrays: nodes, poles and scaling factors equal oracle/nleigs.py's to the last bit -- finite and
+    infinite poles, forced infinities, kept nodes, A and C the same array or not"""
+    from nep_amd import rk_helper as rk
+    from oracle import nleigs as on
+    rng = np.random.default_rng(1)
+    for t in range(12):
+        nA = int(rng.integers(5, 1500)); nC = int(rng.integers(5, 1500)); m = int(rng.integers(2, 30))
+        A = (rng.standard_normal(nA) + 1j * rng.standard_normal(nA)) * 10.0 ** int(rng.integers(-2, 5))
+        C = A if t % 3 == 0 else rng.standard_normal(nC) + 1j * rng.standard_normal(nC)
+        for B in ([np.inf], list(rng.standard_normal(7) * 50), [np.inf, 3.0, -2.5]):
+            for keepA in (False, True):
+                for force in (0, 3):
+                    if keepA and len(A) < m:
+                        continue
+                    r1 = rk.lejabagby(A, B, C, m, keepA, force); r2 = on.lejabagby(A, B, C, m, keepA, force)
+                    for x, y in zip(r1, r2):
+                        assert np.array_equal(np.asarray(x).view(np.float64), np.asarray(y).view(np.float64), equal_nan=True)
