@@ -398,14 +398,14 @@ __device__ __forceinline__ void ml_level_body(const MLArgs& A, const int bx, con
 template <bool UPPER, int RB, int MODE, int G2>
 __global__ __launch_bounds__(256) void k_ml_level(const MLArgs A) { ml_level_body<UPPER, RB, MODE, G2>(A, (int)blockIdx.x, (int)blockIdx.y); }
 
-// Blocks of right-hand sides (contour_beyn: 32 per node): ONE workgroup per diagonal block and group of RB right-hand sides.
-// In the chunk form above every 4-row chunk stages the right-hand-side rows its dot products read -- up to the whole block, RB
-// columns, gathered through the input permutation: 64 chunks of a 256-row block load the same 32 KB (k_ml_level<false, 8, 0> on
-// the gun factor: 301 us for level 0, 10 000 workgroups, 25 x the bytes and the flops of the product).  Here the block's r sits
-// in LDS once and the workgroup walks its packed inverse rows 16 at a time, 16 lanes per row.  Same grid as the chunk form (the
-// workgroup of a block's FIRST chunk does the block, the others leave; side-job workgroups unchanged), same sums per row up to
-// the order of the lane partials.  A block's rows go in SEGMENTS of 64 to separate workgroups (a lone workgroup per 256-row block
-// was one long chain: 131 us on gun's level 0, 30-90 us on a level of six blocks); a segment stages the columns its rows read.
+// Blocks of right-hand sides (contour_beyn: 32 per node): one workgroup per 64-row SEGMENT of a diagonal block and group of RB
+// right-hand sides.  In the chunk form above every 4-row chunk stages the right-hand-side rows its dot products read -- up to the
+// whole block, RB columns, gathered through the input permutation: 64 chunks of a 256-row block load the same 32 KB
+// (k_ml_level<false, 8, 0> on the gun factor: 301 us for level 0, 10 000 workgroups, 25 x the bytes and the flops of the product).
+// Here a segment stages the columns its rows read once ([s, end of segment) for LOWER, [start of segment, e) for UPPER) and walks
+// its packed inverse rows 16 at a time, 16 lanes per row; same sums per row up to the order of the lane partials.  (A whole block
+// per workgroup was one long chain: 131 us on gun's level 0, 30-90 us on a level of six blocks.)  The segments of a level come
+// from a list built with the chunks (MLFacSym::d_segs); side-job workgroups follow them in the grid.
 template <bool UPPER, int RB, int MODE>
 __global__ __launch_bounds__(256) void k_ml_level_blk(const MLArgs A) {
     // 1-D grid over (segment or side-job workgroup) x (group of RB right-hand sides), XCD-aware: workgroups are dealt to the 8
