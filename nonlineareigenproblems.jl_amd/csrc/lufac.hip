@@ -709,17 +709,19 @@ static int32_t refac_build_fused(nep_lu_refac* r, int64_t n, int64_t nF, int nle
     }
     const int RS = 2 * P + 2;
     hipStream_t st = g_refac_stream;
-    int32_t *d_slot = nullptr, *d_pivmap = nullptr, *d_cnt = nullptr, *d_link = nullptr;
+    // (scratch of the build: released on every way out, the early returns of HIPCHK / LAUNCHCHK included)
+    struct Scratch {
+        int32_t *slot = nullptr, *pivmap = nullptr, *cnt = nullptr, *link = nullptr;
+        ~Scratch() { nep_pool_free(slot); nep_pool_free(pivmap); nep_pool_free(cnt); nep_pool_free(link); }
+    } scr;
+    int32_t *&d_slot = scr.slot, *&d_pivmap = scr.pivmap, *&d_cnt = scr.cnt, *&d_link = scr.link;
     const size_t ncnt = (size_t)nps + (size_t)nlev * (P - 1);
     int rc;
     if ((rc = upv(&r->d_fhdr, hdr)) || (rc = nep_pool_alloc((void**)&r->d_frec, (size_t)r->nwide * RS * sizeof(int32_t))) ||
         (rc = nep_pool_alloc((void**)&r->d_ffix, (size_t)r->nwide * 4 * sizeof(int32_t))) ||
         (rc = nep_pool_alloc((void**)&d_slot, (size_t)nF * sizeof(int32_t))) || (rc = nep_pool_alloc((void**)&d_pivmap, (size_t)nF * sizeof(int32_t))) ||
         (rc = nep_pool_alloc((void**)&d_cnt, ncnt * sizeof(int32_t))) ||
-        (rc = nep_pool_alloc((void**)&d_link, (size_t)(P - 1) * nF * sizeof(int32_t)))) {
-        nep_pool_free(d_slot); nep_pool_free(d_pivmap); nep_pool_free(d_cnt); nep_pool_free(d_link);
-        return rc;
-    }
+        (rc = nep_pool_alloc((void**)&d_link, (size_t)(P - 1) * nF * sizeof(int32_t)))) return rc;
     HIPCHK(hipMemsetAsync(d_link, 0xFF, (size_t)(P - 1) * nF * sizeof(int32_t), st));
     HIPCHK(hipMemsetAsync(r->d_frec, 0xFF, (size_t)r->nwide * RS * sizeof(int32_t), st));
     HIPCHK(hipMemsetAsync(d_slot, 0xFF, (size_t)nF * sizeof(int32_t), st));
@@ -757,7 +759,6 @@ static int32_t refac_build_fused(nep_lu_refac* r, int64_t n, int64_t nF, int nle
     std::vector<int32_t> hc(ncnt);
     HIPCHK(hipMemcpyAsync(hc.data(), d_cnt, ncnt * sizeof(int32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    nep_pool_free(d_slot); nep_pool_free(d_pivmap); nep_pool_free(d_cnt); nep_pool_free(d_link);
     int64_t nrec = 0, nfix = 0;
     for (int64_t ps = 0; ps < nps; ++ps) { r->f_cnt[ps] = hc[ps]; nrec += hc[ps]; }
     for (size_t i = 0; i < (size_t)nlev * (P - 1); ++i) { r->fix_cnt[i] = hc[nps + i]; nfix += hc[nps + i]; }
