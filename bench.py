@@ -623,9 +623,34 @@ def cpu_baseline(args, dev=None):
     }
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start the N ranks HERE (one process per GPU, torch.distributed.run on
+    127.0.0.1 with a free port) and hand its exit code back.  The ranks run this same file with WORLD_SIZE / RANK / LOCAL_RANK set, so
+    the code path is the one `python -m torch.distributed.run ... bench.py --gpus N` takes; rank 0 prints the one JSON line."""
+    import socket
+    import subprocess
+    if not os.environ.get("NEP_BENCH_SHARE_GPU") and torch.cuda.device_count() < args.gpus:
+        sys.exit("bench.py --gpus %d: this node shows %d GPU(s) (NEP_BENCH_SHARE_GPU=1 rehearses the multi-rank path on one GPU; "
+                 "not a measurement)" % (args.gpus, torch.cuda.device_count()))
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    env = dict(os.environ, NEP_BENCH_LAUNCHED="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not (world == 1 and os.environ.get("NEP_FORCE_DIST")):
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d -- the flag and the launcher disagree" % (args.gpus, world))
     use_dist = world > 1 or bool(os.environ.get("NEP_FORCE_DIST") and "RANK" in os.environ)   # forced: 1-rank RCCL smoke test
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -100,6 +100,24 @@ def test_bench_two_ranks_rehearsal(na, world):
     assert abs(max(p["wall_s"] for p in pr) - b["seconds"]) < 0.05
 
 
+def test_bench_gpus_flag_launches_its_own_ranks(na):
+    """`python bench.py --gpus 2` as the driver invokes it -- NO torch.distributed.run around it: the file starts its two ranks itself
+    (bench.launch_ranks) and rank 0 prints ONE line with n_gpus = 2"""
+    import json
+    import subprocess
+    env = {k_: v_ for k_, v_ in os.environ.items() if k_ not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(NEP_BENCH_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-wep-roofline", "--no-c3", "--no-c5", "--no-beyn-parity"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["beyn_sharded"]["nodes_per_rank"] == 32
+
+
 def test_bench_headline_survives_a_failing_extra(na):
     """the sharded contour_beyn extra raises on EVERY rank (NEP_BENCH_BEYN_FAIL): rank 0 still prints one valid headline line,
     the failure is recorded under beyn_sharded.error and the process group shuts down cleanly"""

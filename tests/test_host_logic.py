@@ -772,3 +772,22 @@ def test_lejabagby_in_place_form_equals_the_oracle_bit_for_bit():
                     r1 = rk.lejabagby(A, B, C, m, keepA, force); r2 = on.lejabagby(A, B, C, m, keepA, force)
                     for x, y in zip(r1, r2):
                         assert np.array_equal(np.asarray(x).view(np.float64), np.asarray(y).view(np.float64), equal_nan=True)
+
+
+def test_bench_gpus_flag_and_launcher_must_agree():
+    """bench.py: `--gpus N` is what decides the rank count.  Under a launcher (WORLD_SIZE set) a different N is an error, not a
+    silently ignored flag; without a launcher and N > 1 the file starts its own ranks (the GPU suite runs that for real,
+    tests/test_gpu_dist2.py::test_bench_gpus_flag_launches_its_own_ranks) -- here: on a box without GPUs that is a loud exit too."""
+    import subprocess
+    import sys
+    bench = os.path.join(ROOT, "bench.py")
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "disagree" in r.stderr
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "NEP_BENCH_SHARE_GPU")}
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, bench, "--gpus", "2"], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and "GPU(s)" in r.stderr
+    src = open(bench).read()
+    assert "args.gpus" in src and "torch.distributed.run" in src
