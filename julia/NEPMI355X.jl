@@ -157,21 +157,24 @@ end
 # hint that direct solvers ignore (src/LinSolvers.jl:135-137).  A resident solver (DeviceLinSolverCreator(resident = true))
 # returns the DevBuf instead; `*(::DevBuf, ::Number)` below keeps the unchanged integrand `Tv(g(t))*gp(t)` of
 # method_beyncontour.jl:96-97 on the device, and integrate_interval accepts either kind of value.
-const PROBE = Ref{Any}(nothing)                   # (objectid, size, DevBuf) of the last uploaded right-hand-side block
+const PROBE = Ref{Any}(nothing)                   # (objectid, size, content hash, DevBuf) of the last uploaded right-hand-side block
+clear_probe!() = (PROBE[] = nothing)              # drop the cached block (frees its HBM at the next GC)
 function upload_rhs(b::AbstractVecOrMat, n)
     B = Matrix{ComplexF64}(reshape(b, n, :)); dB = DevBuf(n, size(B, 2)); upload!(dB, B); dB
 end
 function lin_solve(s::DeviceLinSolver, b::AbstractVecOrMat; tol = 0)
     p = PROBE[]
-    if s.resident && b isa AbstractMatrix && p !== nothing && p[1] == objectid(b) && p[2] == size(b)
+    # the cached block is reused only for the same array WITH THE SAME CONTENTS (hash: one pass over 5 MB of host memory, against
+    # an upload of the same 5 MB) -- a caller that refills its matrix in place gets the new values solved, not the old ones
+    if s.resident && b isa AbstractMatrix && p !== nothing && p[1] == objectid(b) && p[2] == size(b) && p[3] == hash(b)
         dB = DevBuf(s.n, size(b, 2))               # contour solvers pass the SAME probe block Vh at every node: uploaded once
-        chk(ccall((:nep_dev_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), dB.ptr, p[3].ptr, 16s.n*dB.cols, C_NULL))
+        chk(ccall((:nep_dev_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), dB.ptr, p[4].ptr, 16s.n*dB.cols, C_NULL))
     else
         dB = upload_rhs(b, s.n)
         if s.resident && b isa AbstractMatrix
             keep = DevBuf(s.n, dB.cols)
             chk(ccall((:nep_dev_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), keep.ptr, dB.ptr, 16s.n*dB.cols, C_NULL))
-            PROBE[] = (objectid(b), size(b), keep)
+            PROBE[] = (objectid(b), size(b), hash(b), keep)
         end
     end
     lin_solve!(s, dB)
@@ -236,14 +239,19 @@ reset_basis!() = (MIRROR[] = nothing)                    # call before a new iar
 function IterativeSolvers.orthogonalize_and_normalize!(V::StridedMatrix{ComplexF64}, w::StridedVector{ComplexF64},
                                                         h::StridedVector{ComplexF64}, ::Type{DeviceDGKS})
     rows, k = size(V); ldmax = size(parent(V), 1); kmax = size(parent(V), 2)
+    (stride(V, 1) == 1 && stride(w, 1) == 1 && stride(h, 1) == 1) || error("DeviceDGKS: unit row stride expected")
     m = MIRROR[]
     if m === nothing || m.ld != ldmax || k < m.ncols
         m = BasisMirror(DevBuf(ldmax, kmax), ldmax, 0, DevBuf(ldmax, 1)); MIRROR[] = m
         chk(ccall((:nep_dev_memset, LIB), Cint, (Ptr{Cvoid}, Int32, Csize_t, Ptr{Cvoid}), m.buf.ptr, 0, 16ldmax*kmax, C_NULL))
     end
+    # Column j of the view starts stride(V, 2) ELEMENTS of the parent after column j-1.  iar passes view(V, 1:1:n*(k+1), 1:k)
+    # (method_iar.jl:96) with rows < ldmax: such a view is not contiguous, and `pointer(V, i::Int)` takes i as a linear index in
+    # the VIEW's index space (rows per column), so a parent-space offset there addresses the wrong column.  Byte arithmetic on
+    # the address of the view's first element has one meaning only.
     for j in m.ncols+1:k                                    # columns not yet mirrored (one per call after the first)
         chk(ccall((:nep_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Csize_t, Ptr{Cvoid}),
-                  m.buf.ptr + 16ldmax*(j-1), pointer(V, (j-1)*stride(V, 2) + 1), 16rows, C_NULL))
+                  m.buf.ptr + 16ldmax*(j-1), pointer(V) + 16stride(V, 2)*(j-1), 16rows, C_NULL))
     end
     m.ncols = k
     chk(ccall((:nep_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Csize_t, Ptr{Cvoid}), m.w.ptr, w, 16rows, C_NULL))

@@ -791,3 +791,157 @@ def test_bench_gpus_flag_and_launcher_must_agree():
         assert r.returncode != 0 and "GPU(s)" in r.stderr
     src = open(bench).read()
     assert "args.gpus" in src and "torch.distributed.run" in src
+
+
+# ---- a small model of Julia's Array / SubArray addressing, to evaluate the pointer expressions of julia/NEPMI355X.jl -------------
+class _JArray:
+    """column-major Array{ComplexF64,N} at byte address `base`"""
+    elsize = 16
+
+    def __init__(self, dims, base):
+        self.dims = tuple(dims); self.base = base
+        self.strides = tuple(int(np.prod(self.dims[:d])) for d in range(len(self.dims)))
+        self.first = 1                        # linear index (1-based) of the first element in the parent = itself
+
+    def parent(self):
+        return self
+
+    def addr_linear(self, i):                 # pointer(A, i)
+        return self.base + self.elsize * (i - 1)
+
+
+class _JSub:
+    """SubArray of a _JArray, indices = ints or (start, step, length) ranges (1-based): what `view(A, ...)` builds.  `first` is
+    Base.first_index(V) (parent-space linear index of V[1,1,...]), `strides` are in parent ELEMENTS."""
+    elsize = 16
+
+    def __init__(self, par, idx):
+        assert len(idx) == len(par.dims)
+        self.par = par; dims = []; strides = []; first = 1
+        for d, ix in enumerate(idx):
+            if isinstance(ix, int):
+                first += (ix - 1) * par.strides[d]
+            else:
+                st, step, ln = ix
+                assert 1 <= st and st + (ln - 1) * step <= par.dims[d]
+                first += (st - 1) * par.strides[d]
+                dims.append(ln); strides.append(step * par.strides[d])
+        self.dims = tuple(dims); self.strides = tuple(strides); self.first = first
+
+    def parent(self):
+        return self.par
+
+    def addr_first(self):                     # unsafe_convert(Ptr{T}, V) = pointer(parent) + _byte_offset(V)
+        return self.par.base + self.elsize * (self.first - 1)
+
+    def addr_linear(self, i):                 # pointer(V, i::Int): i is a linear index IN THE VIEW (Base._memory_offset via _to_subscript_indices)
+        sub = []; r = i - 1
+        for ln in self.dims[:-1]:
+            sub.append(r % ln); r //= ln
+        sub.append(r)
+        return self.addr_first() + self.elsize * sum(s * st for s, st in zip(sub, self.strides))
+
+    def addr_cart(self, *I):
+        return self.addr_first() + self.elsize * sum((i - 1) * st for i, st in zip(I, self.strides))
+
+
+def _jl_env():
+    def pointer(A, i=None):
+        if i is None:
+            return A.addr_first() if isinstance(A, _JSub) else A.base
+        return A.addr_linear(i)
+
+    def size(A, d=None):
+        return A.dims if d is None else A.dims[d - 1]
+    return {"pointer": pointer, "size": size, "stride": lambda A, d: A.strides[d - 1], "parent": lambda A: A.parent(), "__builtins__": {}}
+
+
+def _jl_to_py(expr):
+    """Julia arithmetic -> Python: juxtaposed numeric literal coefficients (`16ldmax`, `16S.rows`, `16stride(V, 2)`) get their `*`"""
+    return re.sub(r"(?<![A-Za-z_0-9.])(\d+)\s*(?=[A-Za-z_(])", r"\1*", expr)
+
+
+def _jl_eval(expr, **names):
+    env = _jl_env(); env.update(names)
+    return eval(_jl_to_py(expr), env)
+
+
+def _julia_call_args(src, symbol, within=None):
+    """argument VALUES (texts) of every ccall of `symbol`, optionally only inside the function whose text contains `within`"""
+    src = "\n".join(ln.split("#")[0] if '"' not in ln else ln for ln in src.splitlines())
+    if within is not None:
+        a = src.index(within); src = src[a:src.index("\nend", a)]
+    out = []
+    for m in re.finditer(r"\bccall\(", src):
+        parts = _split_top(_balanced(src, m.end() - 1))
+        if re.match(r"\(:%s\s*,\s*LIB\)" % symbol, parts[0]):
+            out.append(parts[3:])
+    return out
+
+
+def test_julia_glue_pointer_arithmetic_on_subarray_model():
+    """every address julia/NEPMI355X.jl forms by arithmetic, evaluated on the model above for the shapes the reference's drivers pass
+    (iar: method_iar.jl:96-107, a NON-contiguous view with rows < leading dimension; tiar: method_tiar.jl:128, contiguous columns;
+    Beyn: column blocks of DevBufs) and compared with the byte address the C side expects.  Julia cannot run here; the by-reading
+    defect of round 4 (`pointer(V, (j-1)*stride(V, 2) + 1)`: parent-space offset used as a view-space linear index) is the
+    known-bad expression this test must reject."""
+    from types import SimpleNamespace as NS
+    jl = open(os.path.join(ROOT, "julia", "NEPMI355X.jl")).read()
+    ups = _julia_call_args(jl, "nep_upload", within="function IterativeSolvers.orthogonalize_and_normalize!")
+    assert len(ups) == 2                                       # the column loop and w
+    (dst_col, src_col, nbytes_col, _), (dst_w, src_w, nbytes_w, _) = ups
+    assert "pointer(V, " not in src_col                        # no linear-index form
+    orth = _julia_call_args(jl, "nep_orth", within="function IterativeSolvers.orthogonalize_and_normalize!")[0]
+    assert orth[0] == "m.buf.ptr" and orth[1] == "ldmax" and orth[2] == "rows" and orth[3] == "k" and orth[5] == "m.w.ptr"
+    bad = "pointer(V, (j-1)*stride(V, 2) + 1)"
+    BUF = 0x7000_0000_0000; WB = 0x7100_0000_0000
+    seen_bad = False
+
+    def check_orth_call(V, w, par_base, ld_parent, col0, k):
+        """V: the view passed as basis (k columns starting at parent column col0), w: the view passed as new vector"""
+        nonlocal seen_bad
+        rows = V.dims[0]
+        names = dict(V=V, w=w, rows=rows, k=k, ldmax=_jl_eval("size(parent(V), 1)", V=V), m=NS(buf=NS(ptr=BUF), w=NS(ptr=WB)))
+        assert names["ldmax"] == ld_parent
+        assert _jl_eval("stride(V, 1)", V=V) == 1 and _jl_eval("stride(w, 1)", w=w) == 1
+        for j in range(1, k + 1):
+            want_src = par_base + 16 * ((col0 - 1 + j - 1) * ld_parent)                 # parent element (1, col0 + j - 1)
+            assert _jl_eval(src_col, j=j, **names) == want_src == V.addr_cart(1, j)
+            assert _jl_eval(dst_col, j=j, **names) == BUF + 16 * ld_parent * (j - 1)    # column j of the mirror, ldv = ldmax as nep_orth is told
+            if _jl_eval(bad, j=j, **names) != want_src:
+                seen_bad = True
+        assert _jl_eval(nbytes_col, **names) == 16 * rows == _jl_eval(nbytes_w, **names)
+        assert rows <= ld_parent
+
+    # iar (method_iar.jl:96-97): V = zeros(n(m+1), m+1); VV = view(V, 1:1:n(k+1), 1:k); vv = view(V, 1:1:n(k+1), k+1)
+    n, m = 7, 5
+    base = 0x1000_0000
+    Vp = _JArray((n * (m + 1), m + 1), base)
+    for k in range(1, m + 1):
+        VV = _JSub(Vp, ((1, 1, n * (k + 1)), (1, 1, k)))
+        vv = _JSub(Vp, ((1, 1, n * (k + 1)), k + 1))
+        assert VV.dims == (n * (k + 1), k) and vv.dims == (n * (k + 1),)
+        check_orth_call(VV, vv, base, n * (m + 1), 1, k)
+        assert _jl_eval("pointer(w)", w=vv) == base + 16 * k * n * (m + 1)               # what `w` passed as Ptr{ComplexF64} converts to
+    assert seen_bad, "the round-4 expression must be wrong on the iar view for some k < m, j > 1"
+    # tiar (method_tiar.jl:128): Z n x (m+1); view(Z, :, 1:k), view(Z, :, k+1): contiguous, leading dimension n
+    Zp = _JArray((n, m + 1), base)
+    for k in range(1, m + 1):
+        check_orth_call(_JSub(Zp, ((1, 1, n), (1, 1, k))), _JSub(Zp, ((1, 1, n), k + 1)), base, n, 1, k)
+    # a view that does not start at the parent's first column or row stays right as well (pointer(V) carries the offset)
+    Vo = _JSub(Vp, ((3, 1, n), (2, 1, 3)))
+    for j in (1, 2, 3):
+        assert _jl_eval(src_col, V=Vo, j=j) == base + 16 * ((j) * n * (m + 1) + 2)
+    # a plain Matrix (no view): parent(V) === V
+    M = _JArray((n, 4), base)
+    assert _jl_eval("size(parent(V), 1)", V=M) == n and _jl_eval(src_col, V=M, j=3) == base + 16 * 2 * n
+    # Beyn / lin_solve!: column j of the right-hand-side block and of the partial-sum block
+    assert "b = dB.ptr + 16n*(j-1)" in jl and "S.ptr + 16S.rows*(j-1)" in jl
+    DB = 0x7200_0000_0000
+    for j in (1, 2, 32):
+        assert _jl_eval("dB.ptr + 16n*(j-1)", dB=NS(ptr=DB), n=9956, j=j) == DB + 16 * 9956 * (j - 1)
+        assert _jl_eval("S.ptr + 16S.rows*(j-1)", S=NS(ptr=DB, rows=9956 * 32), j=j) == DB + 16 * 9956 * 32 * (j - 1)
+    # the model itself: linear indexing of a non-contiguous view walks the VIEW (Base semantics), cartesian agrees with strides
+    Vs = _JSub(Vp, ((1, 1, 2 * n), (1, 1, 3)))
+    assert Vs.addr_linear(2 * n + 1) == Vs.addr_cart(1, 2) == base + 16 * n * (m + 1)
+    assert Vs.addr_linear(n * (m + 1) + 1) != Vs.addr_cart(1, 2)
