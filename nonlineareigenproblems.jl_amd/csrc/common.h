@@ -169,6 +169,13 @@ int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64_t rows, in
 int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, const int64_t* d_active_rows,
                                nep_cdouble* dw, nep_cdouble* d_out, int32_t method, nep_cdouble* d_mirror, int32_t nmirror,
                                void* before_write, nep_stream stream);
+// orth.hip: iar's form (rows = n (k + 1)): the last kernel also forms step k + 1's coefficient product d_WT (n x mt) from the
+// normalised vector and writes its block shift to d_shift (k_orth_finish_vc); spmv.hip: the SpMV on such a product
+int32_t nep_orth_dev_iar_next(const nep_cdouble* dV, int64_t ldv, int64_t n, int32_t k, const int64_t* d_active_rows,
+                              nep_cdouble* dw, nep_cdouble* d_out, int32_t method, nep_cdouble* d_mirror, int32_t nmirror,
+                              void* before_write, const nep_cdouble* dC, int64_t ldc, int32_t mt, nep_cdouble* d_WT,
+                              nep_cdouble* d_shift, nep_stream stream);
+int nep_spmv_wt(nep_spmf* s, const nep_cdouble* d_WT, nep_cdouble* dz, hipStream_t st);
 }
 
 // spmv_tile.hip: K1 in one launch on footprint tiles (built from the host arrays of the stacked CSR; *out stays NULL when the

@@ -35,6 +35,9 @@ struct nep_iar {
     hipStream_t side = nullptr; hipEvent_t e_solved = nullptr, e_checked = nullptr;
     hipEvent_t e_upload = nullptr; bool upload_waited = false;      // |f_t|, f_t were uploaded on the NULL stream
     hipStream_t last = nullptr;
+    // step k's last kernel (k_orth_finish_vc) forms step k + 1's coefficient product and block shift: dWT (n x mt) holds the
+    // product for step `wt_for` (0: none)
+    cplx* dWT = nullptr; int32_t wt_for = 0;
 };
 
 extern "C" {
@@ -76,6 +79,11 @@ int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdo
         } else (void)hipGetLastError();
     }
     s->dH = (cplx*)dH; s->hH = h_pinnedH; s->method = orth_method;
+    const int fuse_vc = getenv("NEP_IAR_FUSE_VC") ? atoi(getenv("NEP_IAR_FUSE_VC")) : 1;      // (read per object: tests compare both forms)
+    if (fuse_vc && mt <= 4) {
+        void* p = nullptr;
+        if (nep_pool_alloc(&p, (size_t)n * mt * sizeof(cplx)) == 0) s->dWT = (cplx*)p;
+    }
     s->ev.assign(m + 1, nullptr);
     s->hH_dev = nullptr;
     if (!getenv("NEP_IAR_NO_MIRROR")) {
@@ -96,6 +104,7 @@ int32_t nep_iar_destroy(nep_iar* s) {
     // steps (speculative ones past convergence included) may still be queued on the last stream: the block goes back to the
     // pool behind them
     if (s->d_cabs) nep_pool_free_on(s->d_cabs, s->last, s->last != nullptr);
+    if (s->dWT) nep_pool_free_on(s->dWT, s->last, s->last != nullptr);
     delete s;
     return NEP_OK;
 }
@@ -115,8 +124,14 @@ int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream str
     cplx* col = s->dV + (int64_t)(k - 1) * s->ldv;      // column k-1: the n x k block of the reference's reshape
     cplx* vv = s->dV + (int64_t)k * s->ldv;
     int32_t shifted = 0;
-    int rc = nep_mlincomb_dev_shift(s->spmf, k, (const nep_cdouble*)s->dCtab, s->ldc, (const nep_cdouble*)col, n, (nep_cdouble*)s->dz,
+    int rc;
+    if (s->dWT && s->wt_for == k) {       // the previous step's last kernel left the coefficient product and the shifted block
+        rc = nep_spmv_wt(s->spmf, (const nep_cdouble*)s->dWT, (nep_cdouble*)s->dz, st);
+        shifted = 1;
+    } else
+        rc = nep_mlincomb_dev_shift(s->spmf, k, (const nep_cdouble*)s->dCtab, s->ldc, (const nep_cdouble*)col, n, (nep_cdouble*)s->dz,
                                     (nep_cdouble*)(vv + n), &shifted, st);
+    s->wt_for = 0;
     if (rc) return rc;
     cplx* hrow = s->dH + (int64_t)(k - 1) * (s->m + 4);
     unsigned long long* bits = (unsigned long long*)(hrow + k + 2);      // zero: dH is zero-filled by the caller, a row is used once
@@ -156,8 +171,14 @@ int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream str
         if (rc) return rc;
     }
     cplx* mirror = s->hH_dev ? s->hH_dev + (int64_t)(k - 1) * (s->m + 4) : nullptr;
-    rc = nep_orth_dev_mirror_ev((const nep_cdouble*)s->dV, s->ldv, n * (int64_t)(k + 1), k, s->d_active, (nep_cdouble*)vv,
-                                (nep_cdouble*)hrow, s->method, (nep_cdouble*)mirror, k + 4, before_write, stream);
+    if (s->dWT && k < s->m) {           // + step k + 1's coefficient product and block shift (column k + 1, blocks 1 ..)
+        rc = nep_orth_dev_iar_next((const nep_cdouble*)s->dV, s->ldv, n, k, s->d_active, (nep_cdouble*)vv, (nep_cdouble*)hrow, s->method,
+                                   (nep_cdouble*)mirror, k + 4, before_write, (const nep_cdouble*)s->dCtab, s->ldc, s->mt,
+                                   (nep_cdouble*)s->dWT, (nep_cdouble*)(vv + s->ldv + n), stream);
+        if (!rc) s->wt_for = k + 1;
+    } else
+        rc = nep_orth_dev_mirror_ev((const nep_cdouble*)s->dV, s->ldv, n * (int64_t)(k + 1), k, s->d_active, (nep_cdouble*)vv,
+                                    (nep_cdouble*)hrow, s->method, (nep_cdouble*)mirror, k + 4, before_write, stream);
     if (rc) return rc;
     if (!mirror)
         HIPCHK(hipMemcpyAsync(s->hH + (int64_t)(k - 1) * (s->m + 4), hrow, (size_t)(k + 4) * sizeof(cplx), hipMemcpyDeviceToHost, st));

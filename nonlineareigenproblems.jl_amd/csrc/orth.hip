@@ -37,15 +37,19 @@ struct OrthDecide {              // what k_orth_finish reads on the asynchronous
     cplx* out_beta = nullptr;
 };
 __device__ __forceinline__ void orth_pass_norms(const OrthDecide& D, double& nrm, double& p2) {
-    __shared__ double smn[2][16];
-    double acc = 0.0, pj = 0.0;
-    for (int b = threadIdx.x; b < D.np; b += blockDim.x) acc += D.partial[b];
-    for (int j = threadIdx.x; j < D.k; j += blockDim.x) pj += D.c[j].x * D.c[j].x + D.c[j].y * D.c[j].y;
-    acc = wave_reduce_sum(acc); pj = wave_reduce_sum(pj);
-    if ((threadIdx.x & 63) == 0) { smn[0][threadIdx.x >> 6] = acc; smn[1][threadIdx.x >> 6] = pj; }
+    // (the first 256 threads of the workgroup, whatever its size: the order of the sum -- and with it the last bit of beta -- is the
+    // same in the 256-thread k_orth_finish and the 512-thread k_orth_finish_vc)
+    __shared__ double smn[2][4];
+    if (threadIdx.x < 256) {
+        double acc = 0.0, pj = 0.0;
+        for (int b = threadIdx.x; b < D.np; b += 256) acc += D.partial[b];
+        for (int j = threadIdx.x; j < D.k; j += 256) pj += D.c[j].x * D.c[j].x + D.c[j].y * D.c[j].y;
+        acc = wave_reduce_sum(acc); pj = wave_reduce_sum(pj);
+        if ((threadIdx.x & 63) == 0) { smn[0][threadIdx.x >> 6] = acc; smn[1][threadIdx.x >> 6] = pj; }
+    }
     __syncthreads();
     double t = 0.0, q2 = 0.0;
-    for (int q = 0; q < (int)(blockDim.x >> 6); ++q) { t += smn[0][q]; q2 += smn[1][q]; }
+    for (int q = 0; q < 4; ++q) { t += smn[0][q]; q2 += smn[1][q]; }
     __syncthreads();
     nrm = sqrt(t); p2 = q2;
 }
@@ -369,6 +373,10 @@ __global__ __launch_bounds__(256) void k_orth_finish(int64_t rows, cplx* __restr
         double nrm, p2;
         orth_pass_norms(D, nrm, p2);
         beta = nrm; passes = D.state[1]; more = D.state[4 + passes];
+        // the flag the update published is the Pythagoras ESTIMATE of the criterion; here the true norm of the last pass that ran
+        // and its ||c|| exist: the reported "another pass wanted" is the estimate OR the exact test of IterativeSolvers' DGKS loop
+        // (a basis that has lost orthogonality makes the true norm smaller than the estimate)
+        if (D.method == 0 && nrm < 0.70710678118654752 * sqrt(p2)) more = 1;
         brk = (!(nrm > 0.0) || !isfinite(nrm)) ? 1 : 0;
         if (blockIdx.x == 0 && threadIdx.x == 0) out_beta[0] = cmake(nrm, 0.0);
     } else { beta = out_beta[0].x; passes = state[1]; more = state[0]; brk = state[2]; }
@@ -386,6 +394,95 @@ __global__ __launch_bounds__(256) void k_orth_finish(int64_t rows, cplx* __restr
             for (int i = threadIdx.x; i < nmirror; i += blockDim.x)
                 mirror[i] = i == iflag ? flags : (i == iflag - 1 ? cmake(beta, 0.0) : row[i]);
         }
+    }
+}
+
+// iar: the LAST kernel of step k's orthogonalisation also does the FIRST kernel of step k + 1's compute_Mlincomb.  The vector it
+// normalises, v = w / beta (rows = n (k + 1)), is the basis column step k + 1 reshapes into its n x (k + 1) block y
+// (method_iar.jl:96-100): the coefficient product WT[r, t] = sum_j y[r, j] C[j, t] (k_vc of csrc/spmv.hip) and the block shift
+// of the column (next column, block j + 1 = block j / (j + 1)) read exactly these values.  One workgroup owns ROWS rows r of y and
+// ALL k + 1 blocks of them: it forms beta like k_orth_finish (every workgroup sums the <= ORTH_NPART partial norms), scales, writes
+// v back, writes the shifted block and accumulates the product -- the same operations in the same order as k_orth_finish followed by
+// k_vc<MT, ROWS, true> (NG column groups, the groups summed in order), so WT, the basis and H are bit-identical to the two-kernel form.
+// Step k + 1 then starts with the SpMV on WT: one dependent launch and one sweep over the column less per step.
+struct OrthNextVc { const cplx* C = nullptr; int64_t ldc = 0; int mt = 0; cplx* WT = nullptr; cplx* shift_dst = nullptr; int64_t n = 0; };
+template <int MT, int ROWS>
+__global__ __launch_bounds__(512) void k_orth_finish_vc(int64_t n, int kb, cplx* __restrict__ w, cplx* __restrict__ out_beta,
+                                                        const cplx* __restrict__ row_, cplx* __restrict__ mirror, int nmirror,
+                                                        const OrthDecide dec, const cplx* __restrict__ C, int64_t ldc, int mt_total,
+                                                        cplx* __restrict__ WT, cplx* __restrict__ shift_dst) {
+    constexpr int NG = 512 / ROWS;
+    constexpr int KC = 128;
+    __shared__ cplx sm[NG][MT][ROWS];
+    __shared__ cplx cs[MT][KC];
+    double nrm, p2;
+    orth_pass_norms(dec, nrm, p2);
+    const double beta = nrm;
+    const int passes = dec.state[1];
+    int more = dec.state[4 + passes];
+    if (dec.method == 0 && nrm < 0.70710678118654752 * sqrt(p2)) more = 1;
+    const int brk = (!(nrm > 0.0) || !isfinite(nrm)) ? 1 : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) out_beta[0] = cmake(nrm, 0.0);
+    const double inv = (beta > 0.0 && isfinite(beta)) ? 1.0 / beta : 0.0;
+    const int rr0 = threadIdx.x % ROWS;
+    const int g = threadIdx.x / ROWS;
+    const int64_t row = blockIdx.x * (int64_t)ROWS + rr0;
+    const int64_t rowc = row < n ? row : n - 1;
+    cplx acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i] = cmake(0.0, 0.0);
+    cplx* vp = w + rowc;
+    for (int j0 = 0; j0 < kb; j0 += KC) {
+        const int kc = min(KC, kb - j0);
+        if (j0 > 0) __syncthreads();
+        for (int t = threadIdx.x; t < kc * MT; t += 512) {
+            const int i = t / kc, j = t % kc;
+            cs[i][j] = C[j0 + j + (int64_t)i * ldc];
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int j = g; j < kc; j += NG) {
+            const cplx u = vp[(int64_t)(j0 + j) * n];
+            const cplx v = cmake(u.x * inv, u.y * inv);
+            if (row < n) {
+                vp[(int64_t)(j0 + j) * n] = v;
+                const double sc = 1.0 / (double)(j0 + j + 1);
+                shift_dst[row + (int64_t)(j0 + j) * n] = cmake(v.x * sc, v.y * sc);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) cfma(acc[i], v, cs[i][j]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) sm[g][i][rr0] = acc[i];
+    __syncthreads();
+    for (int t = threadIdx.x; t < ROWS * MT; t += 512) {
+        const int rr = t / MT, i = t % MT;
+        cplx s = sm[0][i][rr];
+#pragma unroll
+        for (int q = 1; q < NG; ++q) s = cadd(s, sm[q][i][rr]);
+        const int64_t r = blockIdx.x * (int64_t)ROWS + rr;
+        if (r < n) WT[r * mt_total + i] = s;
+    }
+    if (blockIdx.x == 0) {
+        const cplx flags = cmake((double)passes, (double)(2 * brk + more));
+        if (threadIdx.x == 0) out_beta[1] = flags;
+        if (mirror) {
+            const int iflag = (int)(out_beta + 1 - row_);
+            for (int i = threadIdx.x; i < nmirror; i += blockDim.x)
+                mirror[i] = i == iflag ? flags : (i == iflag - 1 ? cmake(beta, 0.0) : row_[i]);
+        }
+    }
+}
+template <int ROWS>
+static void launch_finish_vc(const OrthNextVc& nx, int kb, cplx* w, cplx* out_beta, const cplx* row, cplx* mirror, int nmirror,
+                             const OrthDecide& D, hipStream_t st) {
+    const dim3 grid((unsigned)((nx.n + ROWS - 1) / ROWS)), block(512);
+    switch (nx.mt) {
+        case 4: hipLaunchKernelGGL((k_orth_finish_vc<4, ROWS>), grid, block, 0, st, nx.n, kb, w, out_beta, row, mirror, nmirror, D, nx.C, nx.ldc, nx.mt, nx.WT, nx.shift_dst); break;
+        case 3: hipLaunchKernelGGL((k_orth_finish_vc<3, ROWS>), grid, block, 0, st, nx.n, kb, w, out_beta, row, mirror, nmirror, D, nx.C, nx.ldc, nx.mt, nx.WT, nx.shift_dst); break;
+        case 2: hipLaunchKernelGGL((k_orth_finish_vc<2, ROWS>), grid, block, 0, st, nx.n, kb, w, out_beta, row, mirror, nmirror, D, nx.C, nx.ldc, nx.mt, nx.WT, nx.shift_dst); break;
+        default: hipLaunchKernelGGL((k_orth_finish_vc<1, ROWS>), grid, block, 0, st, nx.n, kb, w, out_beta, row, mirror, nmirror, D, nx.C, nx.ldc, nx.mt, nx.WT, nx.shift_dst); break;
     }
 }
 
@@ -550,9 +647,27 @@ extern "C" int32_t nep_orth_dev_mirror(const nep_cdouble* dV, int64_t ldv, int64
 }
 // before_write (may be NULL): an event the stream waits for before the first kernel that WRITES w (the first update): work on
 // another stream that still reads w -- iar's recorded residual of the kept iterate -- runs next to the projections
+static int orth_dev_impl(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
+                         const int64_t* d_active_rows, nep_cdouble* dw, nep_cdouble* d_out, int32_t method,
+                         nep_cdouble* d_mirror, int32_t nmirror, void* before_write, const OrthNextVc* next, nep_stream stream);
 extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
                                           const int64_t* d_active_rows, nep_cdouble* dw, nep_cdouble* d_out, int32_t method,
                                           nep_cdouble* d_mirror, int32_t nmirror, void* before_write, nep_stream stream) {
+    return orth_dev_impl(dV, ldv, rows, k, d_active_rows, dw, d_out, method, d_mirror, nmirror, before_write, nullptr, stream);
+}
+// iar's form: rows = n (k + 1); the last kernel also forms step k + 1's coefficient product d_WT (n x mt, row-major) from the
+// normalised vector and the coefficient table dC (ldc), and writes the block shift of the vector to d_shift (see k_orth_finish_vc)
+extern "C" int32_t nep_orth_dev_iar_next(const nep_cdouble* dV, int64_t ldv, int64_t n, int32_t k, const int64_t* d_active_rows,
+                                         nep_cdouble* dw, nep_cdouble* d_out, int32_t method, nep_cdouble* d_mirror, int32_t nmirror,
+                                         void* before_write, const nep_cdouble* dC, int64_t ldc, int32_t mt, nep_cdouble* d_WT,
+                                         nep_cdouble* d_shift, nep_stream stream) {
+    ARGCHK(dC && d_WT && d_shift && mt >= 1 && mt <= 4 && ldc >= k + 1 && n > 0);
+    OrthNextVc nx; nx.C = (const cplx*)dC; nx.ldc = ldc; nx.mt = mt; nx.WT = (cplx*)d_WT; nx.shift_dst = (cplx*)d_shift; nx.n = n;
+    return orth_dev_impl(dV, ldv, n * (int64_t)(k + 1), k, d_active_rows, dw, d_out, method, d_mirror, nmirror, before_write, &nx, stream);
+}
+static int orth_dev_impl(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k,
+                         const int64_t* d_active_rows, nep_cdouble* dw, nep_cdouble* d_out, int32_t method,
+                         nep_cdouble* d_mirror, int32_t nmirror, void* before_write, const OrthNextVc* next, nep_stream stream) {
     ARGCHK(dV && dw && d_out);
     ARGCHK(rows > 0 && k >= 1 && ldv >= rows);
     ARGCHK(method == 0 || method == 1);
@@ -623,6 +738,12 @@ extern "C" int32_t nep_orth_dev_mirror_ev(const nep_cdouble* dV, int64_t ldv, in
                                (const cplx*)d_c, w, d_pn, gate, (const double*)d_ww, d_state, p + 1, (int)method);
         LAUNCHCHK();
     }
+    }
+    if (next) {
+        if (next->n >= 65536) launch_finish_vc<64>(*next, (int)k + 1, w, out + k, (const cplx*)out, (cplx*)d_mirror, (int)nmirror, D, st);
+        else launch_finish_vc<32>(*next, (int)k + 1, w, out + k, (const cplx*)out, (cplx*)d_mirror, (int)nmirror, D, st);
+        LAUNCHCHK();
+        return NEP_OK;
     }
     const int g = (int)std::min<int64_t>((rows + 255) / 256, 2048);
     hipLaunchKernelGGL(k_orth_finish, dim3(g), dim3(256), 0, st, rows, w, out + k, d_state, (const cplx*)out,

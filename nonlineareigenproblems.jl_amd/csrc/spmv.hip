@@ -1082,6 +1082,12 @@ int nep_mlincomb_dev_shift(nep_spmf* s, int32_t k, const nep_cdouble* dC, int64_
     return launch_spmv<cplx>(s, s->d_WT, (cplx*)dz, st);
 }
 
+// the second half of K1 on a coefficient product that exists already (iar: formed by the previous step's k_orth_finish_vc)
+int nep_spmv_wt(nep_spmf* s, const nep_cdouble* d_WT, nep_cdouble* dz, hipStream_t st) {
+    if (s->valbytes == 8) return launch_spmv<double>(s, (const cplx*)d_WT, (cplx*)dz, st);
+    return launch_spmv<cplx>(s, (const cplx*)d_WT, (cplx*)dz, st);
+}
+
 int32_t nep_cw_backward_error(nep_spmf* s, const double* h_cabs, const nep_cdouble* h_c, const nep_cdouble* dx,
                               const nep_cdouble* db, const nep_cdouble* dMx, const nep_cdouble* d_den_extra,
                               nep_cdouble* dr, double* h_omega, nep_stream stream) {

@@ -142,6 +142,41 @@ def test_iar_device_eig_equals_host_lapack_route(na, monkeypatch, neigs):
     assert cnt > 50
 
 
+@pytest.mark.parametrize("n,m", [(9956, 40), (1310, 20)])
+def test_iar_fused_finish_and_coefficient_product_is_bit_identical(na, monkeypatch, n, m):
+    """step k's last kernel also forms step k + 1's coefficient product and block shift (k_orth_finish_vc, csrc/orth.hip; K1 of the
+    next step is then the SpMV alone) against the separate kernels (NEP_IAR_FUSE_VC=0: k_orth_finish, then k_vc / the fused small-k
+    SpMV + nep_iar_shift_scale): the product is summed in k_vc's order, but for k <= 8 the separate form runs the fused small-k SpMV, which
+    sums differently -- so the two runs agree to rounding, not bitwise: eigenvalues to 1e-12, the six best backward errors of every
+    iteration within 10 %; the fused form itself is bitwise repeatable"""
+    from nep_amd.linsolvers import _DeviceRefactor
+    nep = na.nep_gallery("gun_spmf_scaled", n)
+    kw = dict(sigma=0.0, gamma=1.0, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10)
+    try:
+        na.iar(nep, **kw)
+    except na.NoConvergenceException:
+        pass
+    _DeviceRefactor.wait()
+    res = {}
+    for mode in ("0", "1", "1"):
+        monkeypatch.setenv("NEP_IAR_FUSE_VC", mode)
+        hist = []
+        try:
+            lam, Q, V = na.iar(nep, errhist=hist, **kw)
+        except na.NoConvergenceException as e:
+            lam, Q = e.lam, e.v
+        res.setdefault(mode, []).append((np.asarray(lam), np.asarray(na.to_host(Q)) if not isinstance(Q, np.ndarray) else Q, hist))
+    (l0, q0, h0), = res["0"]; (l1, q1, h1), (l2, q2, h2) = res["1"]
+    assert np.array_equal(l1, l2) and np.array_equal(q1, q2)                       # run to run: bitwise
+    assert len(h0) == len(h1) == m and len(l0) == len(l1)
+    assert np.abs(np.sort_complex(l0) - np.sort_complex(l1)).max() <= 1e-12 * max(1.0, np.abs(l0).max()) if len(l0) else True
+    for a, b in zip(h0, h1):
+        a = np.sort(a)[:6]; b = np.sort(b)[:6]
+        for x, y in zip(a, b):
+            if x > 1e-11 and y > 1e-11:
+                assert 0.9 < x / y < 1.1
+
+
 def test_iar_device_eig_failure_falls_back_to_lapack(na, monkeypatch):
     """a decomposition that reports a failure (forced here for one step: the QR status word of step 23, the inverse-iteration
     status word of step 31) is redone by LAPACK on the host and the run returns what the all-device run returns"""
