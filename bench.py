@@ -733,11 +733,19 @@ def main():
     t0 = time.perf_counter(); c0 = cpu_seconds()
     pairs = 0
     for _ in range(args.steps):
-        lam, Q = bc.c2_device(na, nep, args.maxit, args.permc)
+        # the timed step returns what the reference's iar returns: eigenvalues AND the n x 46 eigenvector block on the HOST
+        # (return_device=False: 7.3 MB device-to-host inside the timed region); the device-resident form is timed separately below
+        lam, Qh_last = bc.c2_device(na, nep, args.maxit, args.permc, return_device=False)
         pairs += len(lam)
     barrier()
     dt = time.perf_counter() - t0
     cpu_s_per_call = (cpu_seconds() - c0) / args.steps        # host CPU of this rank, all threads, per timed step
+    nres = max(2, min(5, args.steps))
+    torch.cuda.synchronize(); tr0 = time.perf_counter()
+    for _ in range(nres):
+        lam, Q = bc.c2_device(na, nep, args.maxit, args.permc)
+    torch.cuda.synchronize()
+    ms_resident = (time.perf_counter() - tr0) / nres * 1e3
     if use_dist:
         t = torch.tensor([dt, float(pairs)], dtype=torch.float64, device=RED_DEV)
         tmax = t.clone(); dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -760,7 +768,7 @@ def main():
     out = None
     if rank == 0:
         # independent parity check of the returned pairs (host FP64, reference residual criterion)
-        Qh = na.to_host(Q)
+        Qh = Qh_last                     # the host block the last TIMED step returned
         errs = bc.host_backward_errors(nep.get_Av(), nep.get_fv(), lam, Qh)
         maxres = max(errs + [0.0])
         # set-up share: median of 5 separately timed create_linsolver calls (host factorisation + device schedule; the
@@ -798,6 +806,8 @@ def main():
                                         "word + host fallback) when the plan of the pattern exists (built during warm-up), else host SuperLU",
                        "eigenpairs_per_step": per_step_pairs,
                        "max_backward_error": maxres},
+            "returns": "eigenvalues + eigenvectors on the host (download inside the timed step)",
+            "ms_per_step_device_resident": ms_resident,     # the same call leaving the eigenvector block in HBM (mean of a few calls after the timed region)
             "value_excl_setup": world * per_step_pairs / max(ms_step * 1e-3 - t_setup, 1e-9),
             "linsolver_setup_ms": t_setup * 1e3,
             "ms_per_step_host_lu": ms_host_lu,

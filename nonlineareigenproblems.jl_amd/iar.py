@@ -16,6 +16,7 @@ Reference step (method_iar.jl:94-164)            device realisation
   err[k,s]=estimate_error(...) for s=1:k          K2 nep_resid_batch (one pass for all k pairs)
 """
 import os
+import threading
 import time
 
 import numpy as np
@@ -26,7 +27,7 @@ from ._lib import lib, check, c_vp, c_i32, NepError, NEP_ERR_BREAKDOWN
 from .errmeasure import DefaultErrmeasure, estimate_errors, estimate_errors_async
 from .exceptions import NoConvergenceException
 from .linsolvers import DefaultLinSolverCreator, create_linsolver
-from .nep import CDT, to_host, stream_ptr
+from .nep import CDT, to_host, to_host_cm, stream_ptr
 
 EPS = np.finfo(float).eps
 
@@ -126,13 +127,32 @@ def _eig_streams(count, others=()):
 _eig_streams.shared = False
 
 
-def _eig_work(idx, need):
+_EIG_WORK_LOCK = threading.Lock()
+_EIG_WORK_KEEP = 2          # idle blocks kept per device (260 MB each at m = 100); more concurrent calls allocate and free their own
+
+
+def _eig_work_acquire(need):
+    """scratch of the device eigen-decompositions, CHECKED OUT for one iar call (its checker thread): the eigenvalue and the
+    eigenvector kernels of a batch are two launches that share this block, so two calls that run on one GPU at the same time
+    must not share it (call A's inverse iteration would read call B's matrices, status words clean).  Sequential calls get
+    the same block back."""
     dev = torch.cuda.current_device()
-    key = (dev, idx)
-    w = _EIG_WORK.get(key)
-    if w is None or w.numel() < need:
-        w = _EIG_WORK[key] = torch.empty(need, dtype=torch.uint8, device="cuda")
-    return w
+    with _EIG_WORK_LOCK:
+        free = _EIG_WORK.setdefault(dev, [])
+        for i, w in enumerate(free):
+            if w.numel() >= need:
+                return free.pop(i)
+        if free:
+            free.pop()                      # too small for this call: let it go instead of keeping both
+    return torch.empty(need, dtype=torch.uint8, device="cuda")
+
+
+def _eig_work_release(w):
+    """back to the pool; the caller has drained the streams that used it"""
+    with _EIG_WORK_LOCK:
+        free = _EIG_WORK.setdefault(w.device.index, [])
+        if len(free) < _EIG_WORK_KEEP:
+            free.append(w)
 
 
 def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
@@ -473,7 +493,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                 TSTEP = float(os.environ.get("NEP_IAR_EIG_MSSTEP", "0.35"))  # ms per Arnoldi step (gun, k ~ 100)
                 est = eig_stream
                 wsz = (dense.hess_eig_worksize(m) + 15) // 16 * 16
-                work = _eig_work(0, BMAX * wsz)
+                work = _eig_work_acquire(BMAX * wsz)
                 wdev = torch.empty((m, m + 2), dtype=CDT, device="cuda")
                 wpin = torch.zeros((m, m + 2), dtype=CDT).pin_memory()
                 wnp = wpin.numpy()
@@ -515,8 +535,15 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                         check(lib.nep_iar_stream_wait(cstep, kmax, sp_))
                         wrow = c_vp(wdev.data_ptr() + 16 * (k0 - 1) * (m + 2))
                         mrow = c_vp(wpin.data_ptr() + 16 * (k0 - 1) * (m + 2))
-                        check(lib.nep_hess_eigvals_batch_dev(nb, k0, kstep, c_vp(Hdev.data_ptr()), m + 4, wrow, kstep * (m + 2),
-                                                             c_vp(work.data_ptr()), wsz, mrow, kstep * (m + 2), sp_))
+                        rc_ = lib.nep_hess_eigvals_batch_dev(nb, k0, kstep, c_vp(Hdev.data_ptr()), m + 4, wrow, kstep * (m + 2),
+                                                            c_vp(work.data_ptr()), wsz, mrow, kstep * (m + 2), sp_)
+                        if rc_ != 0 or os.environ.get("NEP_IAR_EIG_LAUNCH_FAIL"):
+                            # the launch itself was refused (e.g. a device that does not grant the kernel's 160 KB of LDS): not a
+                            # reason to abort the run -- the batch's decompositions go to LAPACK on the host (host_redo), behind an
+                            # event that says its last step has run
+                            evW = torch.cuda.Event(); evW.record()
+                            stA.append((kcs, None, kmax, evW, None))
+                            return
                         evW = torch.cuda.Event(); evW.record()
                         Zb = torch.empty((nb, kmax, kmax), dtype=CDT, device="cuda")
                         check(lib.nep_hess_eigvecs_batch_dev(nb, k0, kstep, wrow, kstep * (m + 2), c_vp(Zb.data_ptr()), kmax, kmax * kmax,
@@ -566,7 +593,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                                 if trace is not None:
                                     trace["dev_done_%d" % kc] = time.perf_counter()
                                 fill_H(kc)
-                                if wnp[kc - 1, kc].real != 0 or kc == force_fail:   # QR iteration gave up (never observed)
+                                if Zb is None or wnp[kc - 1, kc].real != 0 or kc == force_fail:   # launch refused / QR iteration gave up (never observed)
                                     D, QTl = host_redo(kc)
                                 else:
                                     D = wnp[kc - 1, :kc].copy()
@@ -583,7 +610,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                         while stC and state["conv_eig"] < neigs and stC[0][3].ready():
                             progressed = True
                             kc, laml, QTl, perr, Zb = stC.popleft()
-                            if wnp[kc - 1, kc + 1].real != 0 or kc == -force_fail:   # an inverse iteration did not grow: redo on the host
+                            if Zb is not None and (wnp[kc - 1, kc + 1].real != 0 or kc == -force_fail):   # an inverse iteration did not grow: redo on the host
                                 D, QTl = host_redo(kc)
                                 laml = sigma + gamma / D
                                 with torch.cuda.stream(check_stream):
@@ -607,6 +634,7 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
                     try:
                         est.synchronize()             # dropped speculative decompositions still read Hdev / write wdev
                         check_stream.synchronize()
+                        _eig_work_release(work)       # (only behind a clean drain: a block with work pending is dropped, not shared)
                     except Exception:
                         pass
 
@@ -718,4 +746,4 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     Qd = dense.rowmajor_to_cols(QT, idx[:nc])          # (nc, n) = column-major n x nc
     if return_device:
         return lam, Qd, V[:k]
-    return lam, to_host(Qd), V[:k]
+    return lam, to_host_cm(Qd), V[:k]

@@ -139,6 +139,11 @@ class _DeviceRefactor:
 
     _digests = []          # (indptr array, indices array, digest) of the last patterns hashed: see key()
 
+    @staticmethod
+    def _fingerprint(ip, ix):
+        return (ip[::max(1, ip.shape[0] // 256)].tobytes(), ix[::max(1, ix.shape[0] // 768)].tobytes(),
+                int(ip[-1]) if ip.shape[0] else 0)
+
     @classmethod
     def key(cls, Ac, opts):
         import hashlib
@@ -148,12 +153,17 @@ class _DeviceRefactor:
         # per linear solver on the gun pattern)
         ip, ix = Ac.indptr, Ac.indices
         dig = None
+        fp = None
         if isinstance(ip, np.ndarray) and isinstance(ix, np.ndarray):
             a_ip = ip.__array_interface__["data"][0]; a_ix = ix.__array_interface__["data"][0]
-            for rp, rx, d in cls._digests:
+            # ... and whose CONTENTS still look the same: keeping the arrays alive rules out a recycled address, not an in-place
+            # edit (A.sort_indices(), a rewritten A.indices of equal length).  A strided sample of both arrays (about 1 k entries,
+            # a few microseconds) travels with the digest; an edit that leaves every sampled entry alone would have to be aimed
+            fp = cls._fingerprint(ip, ix)
+            for rp, rx, d, f in cls._digests:
                 if (rp.__array_interface__["data"][0] == a_ip and rx.__array_interface__["data"][0] == a_ix and rp.shape == ip.shape
                         and rx.shape == ix.shape and rp.dtype == ip.dtype and rx.dtype == ix.dtype
-                        and rp.strides == ip.strides and rx.strides == ix.strides):
+                        and rp.strides == ip.strides and rx.strides == ix.strides and f == fp):
                     dig = d
                     break
         if dig is None:
@@ -163,7 +173,7 @@ class _DeviceRefactor:
             dig = h.digest()
             if isinstance(ip, np.ndarray) and isinstance(ix, np.ndarray):
                 with cls.lock:
-                    cls._digests.append((ip, ix, dig))
+                    cls._digests.append((ip, ix, dig, fp))
                     del cls._digests[:-8]
         knobs = tuple(os.environ.get(k) for k in ("NEP_ML_BMAX", "NEP_ML_SPLIT", "NEP_ML_CHUNK"))   # they change the partition
         return (dig, Ac.shape, opts, knobs)
@@ -617,8 +627,23 @@ class FactorizeLinSolver(LinSolver):
         # miss like any other, and a miss withdraws it.  NEP_REFINE_HINT=0 turns it off.
         if self._recorded_plan is not None:
             return self._recorded_plan
-        hint = getattr(getattr(self, "nep", None), "_refine_hint", None) if os.environ.get("NEP_REFINE_HINT", "1") != "0" else None
+        hint = self._hint()
         return min(self.umfpack_refinements, 2 if hint is None else hint)
+
+    def _hint(self):
+        """the sweep count a previous solver of this NEP settled on AT THIS SHIFT (None otherwise): conditioning and pivot growth
+        of M(sigma) change with sigma, so a count learnt at another shift says nothing about this factorisation"""
+        if os.environ.get("NEP_REFINE_HINT", "1") == "0":
+            return None
+        nep = getattr(self, "nep", None)
+        h = getattr(nep, "_refine_hint", None)
+        if h is None or getattr(nep, "_refine_hint_lam", None) != self._lam_key():
+            return None
+        return h
+
+    def _lam_key(self):
+        lam = getattr(self, "lam", None)
+        return None if lam is None else complex(lam)
 
     def settled_plan(self):
         """True when the refinement count of this solver's NEP has settled (a reviewed record of this solver, or the count a
@@ -627,7 +652,7 @@ class FactorizeLinSolver(LinSolver):
             return False
         if self._recorded_plan is not None:
             return True
-        return os.environ.get("NEP_REFINE_HINT", "1") != "0" and getattr(getattr(self, "nep", None), "_refine_hint", None) is not None
+        return self._hint() is not None
 
     def review_recorded(self, w, plan, final_recorded=True):
         """UMFPACK's stopping rule (the loop of solve_dev) replayed on the recorded omegas w[0..plan] of a solve that took
@@ -640,7 +665,13 @@ class FactorizeLinSolver(LinSolver):
             w_prev = np.inf
             for step in range(plan):
                 omega = float(w[step])
-                if not np.isfinite(omega) or omega <= 2.0 * EPS or omega > 0.5 * w_prev:
+                if np.isfinite(omega) and omega <= 2.0 * EPS:
+                    # the checked loop would have stopped at x_step, which satisfies UMFPACK's criterion already; the sweeps taken
+                    # beyond it start from a converged iterate (a sweep from there moves x by O(eps) |x|): accepted, and the
+                    # following steps plan that many sweeps -- not a miss (a miss re-runs the whole call unfused)
+                    self._recorded_plan = max(step, 1)
+                    return True
+                if not np.isfinite(omega) or omega > 0.5 * w_prev:
                     self._note_hint(None)          # the checked loop would have stopped before the sweeps that were taken
                     return False
                 w_prev = omega
@@ -690,6 +721,7 @@ class FactorizeLinSolver(LinSolver):
                     nep._refine_hint_off = True
                 elif not getattr(nep, "_refine_hint_off", False):
                     nep._refine_hint = plan
+                    nep._refine_hint_lam = self._lam_key()
             except AttributeError:
                 pass
 

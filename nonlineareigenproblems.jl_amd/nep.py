@@ -61,6 +61,12 @@ def to_host(T):
     return T.cpu().numpy().T.copy()
 
 
+def to_host_cm(T):
+    """device (k, n) tensor -> host n x k ndarray in COLUMN-major order (as the reference's Julia arrays are): the transposed view of
+    the downloaded block, no second, transposing pass over it on the host (the eigenvector block a Krylov driver returns)"""
+    return T.cpu().numpy().T
+
+
 def is_dev(x):
     return isinstance(x, torch.Tensor)
 

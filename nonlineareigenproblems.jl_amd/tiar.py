@@ -24,7 +24,7 @@ from . import dense
 from .errmeasure import DefaultErrmeasure, estimate_errors
 from .exceptions import NoConvergenceException, LostOrthogonalityException
 from .linsolvers import DefaultLinSolverCreator, create_linsolver
-from .nep import CDT, to_host
+from .nep import CDT, to_host, to_host_cm
 
 EPS = np.finfo(float).eps
 
@@ -203,4 +203,4 @@ def tiar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
     Qd = dense.rowmajor_to_cols(QT, idx[:nc])
     if return_device:
         return lam, Qd, Z[:k], conv_eig_hist
-    return lam, to_host(Qd), Z[:k], conv_eig_hist
+    return lam, to_host_cm(Qd), Z[:k], conv_eig_hist

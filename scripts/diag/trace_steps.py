@@ -6,7 +6,7 @@ import csv, sys, os
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 steps = [int(a) for a in sys.argv[2:] if not a.startswith("-")] or [10, 50, 90]
-fin = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_orth_finish")]
+fin = [i for i, r in enumerate(rows) if r["Kernel_Name"].replace("void ", "").startswith("k_orth_finish")]
 # runs: groups of 100 finishes
 nrun = len(fin) // 100
 base = (nrun - 1) * 100

@@ -185,6 +185,13 @@ def test_iar_device_eig_failure_falls_back_to_lapack(na, monkeypatch):
     kw = dict(sigma=0.0, gamma=1.0, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10)
     monkeypatch.setenv("NEP_IAR_EIG", "dev")
     lam0, _, _ = na.iar(nep, **kw)
+    # a refused LAUNCH of the eigenvalue kernel (a device that does not grant its LDS): every batch goes to the host, same result
+    monkeypatch.setenv("NEP_IAR_EIG_LAUNCH_FAIL", "1")
+    fb0 = na.iar.dev_eig_fallbacks
+    lam1, _, _ = na.iar(nep, **kw)
+    monkeypatch.delenv("NEP_IAR_EIG_LAUNCH_FAIL")
+    assert na.iar.dev_eig_fallbacks - fb0 == m and len(lam1) == len(lam0)
+    assert np.abs(np.sort_complex(np.asarray(lam1)) - np.sort_complex(np.asarray(lam0))).max() <= 1e-10 * np.abs(lam0).max()
     for fail in ("23", "-31"):
         monkeypatch.setenv("NEP_IAR_EIG_FAIL_AT", fail)
         fb0 = na.iar.dev_eig_fallbacks

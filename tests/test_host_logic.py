@@ -449,6 +449,25 @@ def test_recorded_refinement_rule_replay():
     assert c.review_recorded(np.array([1e-13, 1e-16, 5e-17, 0.0]), 2) and nep._refine_hint is None
     d = FactorizeLinSolver.__new__(FactorizeLinSolver); d.umfpack_refinements = 10; d._recorded_plan = None; d.last_omega = None; d.nep = nep
     assert d.blind_plan_recorded() == 2
+    # the hint belongs to ONE shift: a solver of the same NEP at another sigma neither starts with the count nor counts as settled
+    nep2 = _Nep()
+    def mk(lam):
+        x = FactorizeLinSolver.__new__(FactorizeLinSolver); x.umfpack_refinements = 10; x._recorded_plan = None; x.last_omega = None
+        x.nep = nep2; x.lam = lam
+        return x
+    e = mk(0.0)
+    assert not e.settled_plan()
+    assert e.review_recorded(np.array([1e-13, 1e-16, 5e-17, 0.0]), 2) and nep2._refine_hint == 1 and nep2._refine_hint_lam == 0j
+    assert mk(0.0).blind_plan_recorded() == 1 and mk(0.0).settled_plan()
+    assert mk(0.3 + 0.1j).blind_plan_recorded() == 2 and not mk(0.3 + 0.1j).settled_plan()
+    # a step whose kept iterate was NOT recorded (7 of 8 once settled): the rule is replayed on x_0 .. x_{plan-1}
+    f = mk(0.0)
+    assert f.review_recorded(np.array([1e-13, 0.0, 0.0, 0.0]), 1, final_recorded=False)            # still improving when the sweep was taken
+    assert f.review_recorded(np.array([1e-17, 0.0, 0.0, 0.0]), 1, final_recorded=False)            # x_0 converged already: accepted, not a miss
+    assert f._recorded_plan == 1 and nep2._refine_hint == 1
+    assert f.review_recorded(np.array([1e-13, 1e-17, 0.0, 0.0]), 2, final_recorded=False) and f._recorded_plan == 1
+    assert not f.review_recorded(np.array([1e-13, 9e-14, 0.0, 0.0]), 2, final_recorded=False)      # stagnation before the last sweep: miss
+    assert nep2._refine_hint is None
 
 
 def test_hosteig_hessenberg_route():
@@ -945,3 +964,23 @@ def test_julia_glue_pointer_arithmetic_on_subarray_model():
     Vs = _JSub(Vp, ((1, 1, 2 * n), (1, 1, 3)))
     assert Vs.addr_linear(2 * n + 1) == Vs.addr_cart(1, 2) == base + 16 * n * (m + 1)
     assert Vs.addr_linear(n * (m + 1) + 1) != Vs.addr_cart(1, 2)
+
+
+def test_pattern_digest_cache_notices_an_in_place_edit():
+    """_DeviceRefactor.key remembers the digest of index arrays it has hashed (same memory, same shape) -- and a strided content sample
+    with it: a pattern edited IN PLACE (here: two column indices of every row swapped, nnz unchanged) gets a new digest, not the plan
+    of the old pattern"""
+    from nep_amd.linsolvers import _DeviceRefactor
+    rng = np.random.default_rng(5)
+    A = (sp.random(400, 400, density=0.02, random_state=3, format="csr") + sp.identity(400)).tocsr()
+    A.sort_indices()
+    k1 = _DeviceRefactor.key(A, ("x",))
+    assert _DeviceRefactor.key(A, ("x",)) == k1                       # cached: same arrays, same contents
+    ip, ix = A.indptr, A.indices
+    for r in range(400):
+        if ip[r + 1] - ip[r] >= 2:
+            ix[ip[r]], ix[ip[r] + 1] = ix[ip[r] + 1], ix[ip[r]]      # in place: same address, same length
+    k2 = _DeviceRefactor.key(A, ("x",))
+    assert k2 != k1
+    B = A.copy()
+    assert _DeviceRefactor.key(B, ("x",)) == k2                       # content decides, not the address
