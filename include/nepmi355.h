@@ -95,6 +95,10 @@ int32_t nep_spmf_tiles_analyze(int64_t n, int32_t mt, const int32_t* const* h_ro
 /* tuning / A-B knob for compute_Mlincomb: 0 = automatic choice per (n, k), 1 = the tiled one-launch kernel whenever the
  * matrix has tiles, 2 = never (k_vc + SpMV / folded SpMV).  Process-wide. */
 int32_t nep_k1_set_mode(int32_t mode);
+/* K2 kernel choice (A/B knob): the super-panel residual kernel (csrc/spmv_tile.hip k_tile_resid_sp) 0 = never, 1 = on large matrices
+ * (default), 2 = whenever the footprint tiles allow it, -1 = the environment variable NEP_K2_SP decides.  Reference: the residual of
+ * all Ritz pairs, src/errmeasure.jl:128-130,186-190. */
+int32_t nep_k2_set_sp_mode(int32_t mode);
 int32_t nep_csc_to_csr(int64_t n, const int64_t* colptr, const int64_t* rowval, const void* nzval,
                        int32_t val_is_complex, int32_t one_based, int32_t* rowptr, int32_t* colind,
                        void* vals);

@@ -79,6 +79,7 @@ SIGNATURES = {
     "nep_spmf_tile_info": [c_vp, P(c_i64)],
     "nep_spmf_tiles_analyze": [c_i64, c_i32, P(c_vp), P(c_vp), P(c_vp), P(c_i32), c_i32, P(c_i64), P(c_dbl)],
     "nep_k1_set_mode": [c_i32],
+    "nep_k2_set_sp_mode": [c_i32],
     "nep_csc_to_csr": [c_i64, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp],
     "nep_mlincomb": [c_vp, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp],
     "nep_mlincomb_dev": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp],

@@ -955,6 +955,9 @@ int32_t nep_spmf_create(int64_t n, int32_t mt, const int32_t* const* h_rowptr, c
 // K1 kernel choice (tuning / A-B knob): 0 = automatic, 1 = footprint tiles whenever they exist, 2 = never tiles
 static int g_k1_mode = -1;
 int32_t nep_k1_set_mode(int32_t mode) { g_k1_mode = mode; return NEP_OK; }
+// K2 super-panel kernel (A-B knob, same values as NEP_K2_SP; -1 = the environment decides)
+static int g_k2_sp_mode = -1;
+int32_t nep_k2_set_sp_mode(int32_t mode) { g_k2_sp_mode = mode; return NEP_OK; }
 static bool use_tiles(const nep_spmf* s, int k) {
     if (!s->tiles) return false;
     if (g_k1_mode < 0) g_k1_mode = getenv("NEP_K1_MODE") ? atoi(getenv("NEP_K1_MODE")) : 0;
@@ -980,6 +983,15 @@ static bool use_tiles_k2(const nep_spmf* s, int k) {
     // (row-major Q: a column panel of a footprint row is a 64-byte piece of a 16 k-byte row)
     static const int kmax = getenv("NEP_K2_TILE_KMAX") ? atoi(getenv("NEP_K2_TILE_KMAX")) : 20;     // above: k_spmm_rm_g (0.47 ms at k = 30, tiles 0.50-0.63)
     return s->d_sell_ptr != nullptr && k <= kmax;
+}
+
+// K2 in super-panels (k_tile_resid_sp, spmv_tile.hip): NEP_K2_SP = 0 never, 1 (default) on large matrices (those with a SELL copy: the
+// sizes at which K2 is bound by HBM; at gun size the wave-per-row kernel's gathers are L2 hits), 2 whenever the tiles allow it (tests)
+static bool use_sp_k2(const nep_spmf* s, int k) {
+    static const int mode = getenv("NEP_K2_SP") ? atoi(getenv("NEP_K2_SP")) : 1;
+    const int m = g_k2_sp_mode >= 0 ? g_k2_sp_mode : mode;
+    if (m == 0 || !s->tiles || !nep_tiles_resid_sp_ok(s->tiles, k)) return false;
+    return m == 2 || s->d_sell_ptr != nullptr;
 }
 
 int32_t nep_spmf_tile_info(const nep_spmf* s, int64_t info[8]) {
@@ -1149,7 +1161,8 @@ static int resid_panels(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
         if (rc) return rc;
         rc = s->ring.upload(s->coef.dptr, hF + (size_t)j0 * s->mt, cbytes, st);
         if (rc) return rc;
-        const bool tiled = use_tiles_k2(s, kk);
+        const bool sp = use_sp_k2(s, kk);
+        const bool tiled = sp || use_tiles_k2(s, kk);
         int grid = tiled ? nep_tiles_nblk(s->tiles) : (int)std::min<int64_t>((s->n + 3) / 4, 2048);
         rc = s->part.ensure(((size_t)grid * 2 * kk + 2 * kk) * sizeof(double));
         if (rc) return rc;
@@ -1157,7 +1170,9 @@ static int resid_panels(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
         double* outd = d_out ? d_out + 2 * (size_t)j0 : partial + (size_t)grid * 2 * kk;
         const cplx* Q = (const cplx*)dQT + j0;
         cplx* T = tail ? tail + j0 : nullptr;
-        if (tiled)
+        if (sp)
+            rc = nep_tiles_resid_sp(s->tiles, kk, (const cplx*)s->coef.dptr, Q, ldq, 0, T, ldt, partial, split_row, st);
+        else if (tiled)
             rc = nep_tiles_resid(s->tiles, kk, (const cplx*)s->coef.dptr, Q, ldq, T, ldt, partial, split_row, st);
         else if (s->valbytes == 8)
             rc = launch_spmm<double>(s, kk, (const cplx*)s->coef.dptr, Q, ldq, 0, T, ldt, partial, grid, st, split_row);
@@ -1221,7 +1236,10 @@ int32_t nep_resid_batch_cm_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, co
     rc = s->part.ensure((size_t)grid * 2 * k * sizeof(double));
     if (rc) return rc;
     double* partial = (double*)s->part.dptr;
-    rc = nep_tiles_resid_cm(s->tiles, k, (const cplx*)s->coef.dptr, (const cplx*)dQ, ldq, (cplx*)dR_tail, ldt, partial, row0 < 0 ? -1 : row0, st);
+    if (use_sp_k2(s, k))
+        rc = nep_tiles_resid_sp(s->tiles, k, (const cplx*)s->coef.dptr, (const cplx*)dQ, ldq, 1, (cplx*)dR_tail, ldt, partial, row0 < 0 ? -1 : row0, st);
+    else
+        rc = nep_tiles_resid_cm(s->tiles, k, (const cplx*)s->coef.dptr, (const cplx*)dQ, ldq, (cplx*)dR_tail, ldt, partial, row0 < 0 ? -1 : row0, st);
     if (rc) return rc;
     hipLaunchKernelGGL(k_sum_partials_d, dim3(2 * k), dim3(256), 0, st, grid, 2 * k, partial, d_out);
     LAUNCHCHK();
@@ -1245,7 +1263,8 @@ int32_t nep_resid_block(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
         const cplx* F = (const cplx*)s->coef.dptr + (size_t)j0 * s->mt;
         const cplx* Q = (const cplx*)dQT + j0;
         cplx* R = (cplx*)dRT + j0;
-        if (use_tiles_k2(s, kk)) rc = nep_tiles_resid(s->tiles, kk, F, Q, ldq, R, ldr, nullptr, -1, st);
+        if (use_sp_k2(s, kk)) rc = nep_tiles_resid_sp(s->tiles, kk, F, Q, ldq, 0, R, ldr, nullptr, -1, st);
+        else if (use_tiles_k2(s, kk)) rc = nep_tiles_resid(s->tiles, kk, F, Q, ldq, R, ldr, nullptr, -1, st);
         else if (s->valbytes == 8) rc = launch_spmm<double>(s, kk, F, Q, ldq, 0, R, ldr, nullptr, grid, st);
         else rc = launch_spmm<cplx>(s, kk, F, Q, ldq, 0, R, ldr, nullptr, grid, st);
         if (rc) return rc;

@@ -37,6 +37,9 @@ struct NepTiles {
     int64_t n = 0; int mt = 0; int valbytes = 8;
     int nblk = 0, fcap = 0, lbits = 13, stride = 0, xp = 0, zp = 0;
     int wmax = 0, rbmax = 0;        // widest row / largest padded row count over the blocks
+    // term-slotted entries (matrices whose per-term row lengths add up to at most 8: the waveguide's 5 + 2 + 1): entry slot j of EVERY
+    // row holds an entry of term (slot_terms >> 4 j) & 15 or a zero -- the term of an entry is then uniform over a wavefront
+    int slotted = 0; uint32_t slot_terms = 0;
     int64_t nent = 0, nfp = 0;
     TileDesc* d_desc = nullptr;
     uint32_t* d_fp = nullptr;
@@ -472,6 +475,201 @@ __global__ __launch_bounds__(256) void k_tile_resid_cm(const TileDesc* __restric
     }
 }
 
+
+// ---- K2 in SUPER-PANELS (round 5) ------------------------------------------------------------------------------------------------
+// One workgroup per block, one thread per row, ALL k columns in one residency: the row's entries are read ONCE into registers
+// (8 entries x 10 bytes; k_tile_resid_cm re-reads them for each of its k / 2 panels) and the Ritz block is walked in panels of 4
+// columns through TWO footprint tiles in LDS.  The tiles are filled by the CU's LDS-DMA path (gfx950 global_load_lds_dwordx4: 16
+// bytes per lane straight from HBM into LDS, lane l of a wave to slot base + 16 l; no registers, no ds_write): while the workgroup
+// reduces panel p against its entries, the loads of panel p + 1 are in flight into the other tile -- the ~55 KB a CU keeps outstanding
+// is what streaming at the chip's rate needs (Little: 31 GB/s per CU x ~2 us).  A tile is stored COLUMN by column (Qt[c][f]: the 64 rows
+// of a wave read 64 consecutive slots of one column -- a conflict-free 16-byte read; the [f][c] tiles of the older kernels had a 2-3 way
+// conflict at their 32-byte stride, 0.3 ms of LDS pipe at k = 60).  Either layout of the Ritz block feeds the same tile: column-major (CM)
+// or row-major (the package's own drivers).  HBM traffic of a launch: entries once + halo x 16 n k.  Norm partials and the optional tail
+// block as in k_tile_resid_cm; deterministic (fixed-order sums, no atomics).
+#define SP_PSW 4
+#define SP_IMAX 6            // LDS-DMA instructions per wave and panel: 4 columns x (fpad / 64) chunks over the waves of the workgroup
+#define SP_FPAD(NTHR_) ((NTHR_) == 512 ? 640 : ((NTHR_) == 768 ? 896 : 1152))     // footprint slots per tile column, by workgroup size
+// (inline assembly, not __builtin_amdgcn_global_load_lds: the compiler orders every LDS read behind ALL outstanding LDS-DMA of the
+// wave -- an `s_waitcnt vmcnt(0)` in front of the first ds_read of the panel being reduced, i.e. no overlap at all; here it does not
+// know, and the kernel waits itself: vmcnt(0) + barrier before a tile is read)
+__device__ __forceinline__ void sp_dma16(const cplx* src, cplx* lds_dst) {
+    const uint32_t a = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(a) : "memory", "m0");
+}
+// eight per-lane doubles -> their eight wave sums in 3 halving exchanges + 3 plain ones (10 exchanges instead of 48): after the
+// exchange with lane ^ 32 a lane keeps v[0..4) or v[4..8) by its bit 5, after ^ 16 two of them by bit 4, after ^ 8 one by bit 3; the
+// 8 lanes that share bits 5..3 then add up.  Returns the sum of v[i] on every lane whose bits 5..3 spell i.  Fixed order.
+__device__ __forceinline__ double sp_wave_reduce8(const double v[8], int lane) {
+    double a[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const double keep = (lane & 32) ? v[4 + i] : v[i], give = (lane & 32) ? v[i] : v[4 + i];
+        a[i] = keep + shfl_xor_d(give, 32);
+    }
+    double b[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double keep = (lane & 16) ? a[2 + i] : a[i], give = (lane & 16) ? a[i] : a[2 + i];
+        b[i] = keep + shfl_xor_d(give, 16);
+    }
+    const double keep = (lane & 8) ? b[1] : b[0], give = (lane & 8) ? b[0] : b[1];
+    double c = keep + shfl_xor_d(give, 8);
+    c += shfl_xor_d(c, 4); c += shfl_xor_d(c, 2); c += shfl_xor_d(c, 1);
+    return c;
+}
+// The tiles' entries are TERM-SLOTTED (NepTiles::slotted): slot j of every row belongs to term (slot_terms >> 4 j) & 15, so the
+// term of an entry is a scalar.  One accumulator per column runs over the slots, and where the term changes (a uniform branch) it is
+// flushed into the residual with the term's coefficient -- 2 FMA per (entry, column) instead of the 2 x m_t + selects of per-term
+// accumulators picked by a per-lane mask (measured: the masked form ran VALU-bound at 0.55 ms for k = 60, slower than the kernel
+// it was to replace).
+// FM: the slots after which the accumulators are flushed (bit j: slot j is the last of its term), known at compile time for the
+// common slot layouts (0xD0: the waveguide's 5 + 2 + 1; 0x80: one term; 0xFF: after every slot -- right for ANY slotting) so that
+// the panel loop has no branch in it.
+template <typename VT, bool CM, int NTHR, int FM>
+__global__ __launch_bounds__(NTHR) void k_tile_resid_sp(const TileDesc* __restrict__ desc, const uint32_t* __restrict__ fp,
+                                                        const uint16_t* __restrict__ eidx, const VT* __restrict__ eval,
+                                                        const cplx* __restrict__ Q, int64_t ldq, int k, const cplx* __restrict__ F,
+                                                        int mt, int lbits, uint32_t slot_terms, cplx* __restrict__ R,
+                                                        int64_t ldr, double* __restrict__ partial, int swz, int64_t split_row) {
+    constexpr int NW = NTHR / 64;
+    constexpr int PSW = SP_PSW;
+    constexpr int fpad = SP_FPAD(NTHR);       // compile-time tile pitch: the 4 columns of an entry are ONE address + immediate offsets
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* Qt = (cplx*)smem;                                   // [2][PSW][fpad], fpad a multiple of 64
+    double* wsum = (double*)(Qt + (size_t)2 * PSW * fpad);    // [2 parities][NW][2 PSW]
+    uint32_t* fpl = (uint32_t*)(wsum + 2 * NW * 2 * PSW);     // [fpad]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = tile_block(swz);
+    const TileDesc d = desc[blk];
+    const int Fn = d.fp_cnt;
+    const uint32_t* __restrict__ fpb = fp + d.fp_off;
+    const int width = d.wrb & 0xffff, rb = d.wrb >> 16;
+    const uint32_t lmask = (1u << lbits) - 1u;
+    const uint16_t* __restrict__ ib = eidx + (int64_t)d.ent_off64 * 64;
+    const VT* __restrict__ vb = eval + (int64_t)d.ent_off64 * 64;
+    // ---- DMA instruction i = wv + t NW of a panel is (chunk i / 4 of 64 footprint slots, panel column i % 4); the lane's footprint
+    // column comes from the list in LDS every time (NOT from registers kept across the panels: the compiler spilled those, and a
+    // scratch reload is a VMEM load -- its `s_waitcnt vmcnt(0)` waits for every DMA in flight, one after the other, 5 us per panel);
+    // slots past the footprint repeat its last one (their tile slots are padding)
+    constexpr int NI = PSW * (fpad >> 6);
+    for (int f = tid; f < fpad; f += NTHR) fpl[f] = fpb[f < Fn ? f : Fn - 1];
+    __syncthreads();
+    const int np = (k + PSW - 1) / PSW;
+    auto issue = [&](int p, int buf) {
+#pragma unroll
+        for (int t = 0; t < SP_IMAX; ++t) {
+            const int i = wv + t * NW;
+            if (i < NI) {                                      // wave-uniform
+                const int c = i & 3;
+                const int cc = p * PSW + c < k ? p * PSW + c : k - 1;
+                const int64_t col = (int64_t)(fpl[(i >> 2) * 64 + lane] & NEP_COL_MASK);
+                sp_dma16(Q + (CM ? col + (int64_t)cc * ldq : col * ldq + cc), Qt + ((size_t)(buf * PSW + c) * fpad + (size_t)(i >> 2) * 64));
+            }
+        }
+    };
+    issue(0, 0);
+    // ---- the row's entries, once (local footprint index; the term is the slot's)
+    uint32_t pid2[4] = {0u, 0u, 0u, 0u}; VT pv[8];            // pid2: two 16-bit BYTE offsets of footprint slots per register (fpad 16 < 2^16)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool on = tid < rb && j < width;
+        const int64_t e = on ? (int64_t)j * rb + tid : 0;
+        uint32_t o = ((uint32_t)__builtin_nontemporal_load(ib + e) & lmask) * 16u;
+        pv[j] = tload<true>(vb + e);
+        if (!on) { o = 0; if constexpr (sizeof(VT) == 8) pv[j] = 0.0; else pv[j] = cmake(0.0, 0.0); }
+        pid2[j >> 1] |= o << (16 * (j & 1));
+    }
+    const int li = tid / d.zp, ljz = tid - li * d.zp;
+    const int64_t row = (int64_t)d.r0 + (int64_t)li * d.stride + ljz;
+    const bool rowon = tid < d.nrows;
+    const int outlane = (lane & 7) == 0;                       // the lanes 0, 8, .., 56 publish the 8 sums of sp_wave_reduce8
+    for (int p = 0; p < np; ++p) {
+        const int p0 = p * PSW;
+        __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's share of panel p has landed in LDS
+        __syncthreads();                           // ... everybody's; and every wave is done with the other tile and with wsum of panel p - 1
+        if (partial && p > 0 && tid < 2 * PSW) {
+            const int which = tid / PSW, s = tid - which * PSW;
+            const double* w = wsum + (size_t)((p - 1) & 1) * NW * 2 * PSW + which * PSW + s;
+            double a = 0.0;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) a += w[q * 2 * PSW];
+            partial[((int64_t)blk * 2 + which) * k + p0 - PSW + s] = a;        // (p0 - PSW + s < k: only the LAST panel can be short)
+        }
+        if (p + 1 < np) issue(p + 1, (p + 1) & 1);
+        const cplx* tile = Qt + (size_t)((p & 1) * PSW) * fpad;
+        // two columns at a time, each finished (residual entry, its square, the optional store) before the next pair starts: the
+        // accumulators of four columns with their tile data in flight pushed loop invariants into scratch
+        double red[2 * PSW];
+#pragma unroll
+        for (int h = 0; h < PSW / 2; ++h) {
+            cplx acc[2], r[2];
+            const cplx* Fc[2];                                 // coefficient column of each panel column (uniform: scalar loads)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                acc[s] = cmake(0.0, 0.0); r[s] = cmake(0.0, 0.0);
+                Fc[s] = F + (p0 + 2 * h + s < k ? p0 + 2 * h + s : k - 1) * mt;
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t o16 = (j & 1) ? (pid2[j >> 1] >> 16) : (pid2[j >> 1] & 0xffffu);      // byte offset of the entry's footprint slot
+                const cplx* tp = (const cplx*)((const char*)(tile + (size_t)(2 * h) * fpad) + o16);
+                const bool first = j == 0 || ((FM >> (j - 1)) & 1);          // first slot of its term: the accumulators start over
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const cplx q = tp[(size_t)s * fpad];
+                    if (first) acc[s] = cscale(pv[j], q); else cfma(acc[s], pv[j], q);
+                }
+                if ((FM >> j) & 1) {                                          // last slot of its term (compile time)
+                    const int tj = (int)((slot_terms >> (4 * j)) & 15u);
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) cfma(r[s], Fc[s][tj], acc[s]);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int col = p0 + 2 * h + s;
+                double r2 = 0.0;
+                if (rowon && col < k) {
+                    r2 = fma(r[s].x, r[s].x, r[s].y * r[s].y);
+                    if (split_row < 0) { if (R) R[CM ? row + (int64_t)col * ldr : row * ldr + col] = r[s]; }
+                    else if (row >= split_row) { R[CM ? (row - split_row) + (int64_t)col * ldr : (row - split_row) * ldr + col] = r[s]; r2 = 0.0; }
+                }
+                red[2 * h + s] = r2; red[PSW + 2 * h + s] = 0.0;
+            }
+            // (a scheduling fence: the compiler would otherwise issue the tile reads of the whole panel up front and SPILL loop
+            // invariants to make room -- and a spill reload is a scratch load whose vmcnt(0) drains the DMA queue, see above)
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (partial) {
+            // |q|^2 over the columns this block owns
+            for (int f = tid; f < Fn; f += NTHR) {
+                if (fpl[f] & TILE_OWN) {
+#pragma unroll
+                    for (int s = 0; s < PSW; ++s) { const cplx q = tile[(size_t)s * fpad + f]; red[PSW + s] = fma(q.x, q.x, fma(q.y, q.y, red[PSW + s])); }
+                }
+            }
+            const double sum = sp_wave_reduce8(red, lane);
+            if (outlane) wsum[(size_t)(p & 1) * NW * 2 * PSW + wv * 2 * PSW + (lane >> 3)] = sum;
+        }
+    }
+    __syncthreads();
+    if (partial) {
+        const int p0 = (np - 1) * PSW, pw = k - p0;
+        if (tid < 2 * PSW) {
+            const int which = tid / PSW, s = tid - which * PSW;
+            if (s < pw) {
+                const double* w = wsum + (size_t)((np - 1) & 1) * NW * 2 * PSW + which * PSW + s;
+                double a = 0.0;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) a += w[q * 2 * PSW];
+                partial[((int64_t)blk * 2 + which) * k + p0 + s] = a;
+            }
+        }
+    }
+}
+
 // ---- host: tiles from the stacked CSR -----------------------------------------------------------------------------------------
 namespace {
 
@@ -487,6 +685,7 @@ struct TileBuilder {
     std::vector<uint32_t> cols;
     int fcap_seen = 0, wmax = 0, rbmax = 0;
     bool failed = false;
+    int slot_w = 0; int slot_off[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // slot_w > 0: term t owns the entry slots [slot_off[t], slot_off[t + 1])
 
     // rows of the rectangle [x0,x1) x [z0,z1) of the grid with line length s (s = 0: the 1-D range [z0, z1))
     int footprint(int64_t r0, int stride, int nx, int nz) {
@@ -522,12 +721,13 @@ struct TileBuilder {
         d.fp_off = (int32_t)fp.size(); d.fp_cnt = F;
         const int nrows = nx * nz;
         const int rb = (nrows + 15) / 16 * 16;
-        int width = 0;
-        for (int i = 0; i < nx; ++i)
-            for (int j = 0; j < nz; ++j) {
-                const int64_t r = r0 + (int64_t)i * stride + j;
-                width = std::max(width, rowptr[r + 1] - rowptr[r]);
-            }
+        int width = slot_w;
+        if (!slot_w)
+            for (int i = 0; i < nx; ++i)
+                for (int j = 0; j < nz; ++j) {
+                    const int64_t r = r0 + (int64_t)i * stride + j;
+                    width = std::max(width, rowptr[r + 1] - rowptr[r]);
+                }
         // footprint slots; the owned rows carry TILE_OWN
         const size_t fp0 = fp.size();
         for (int f = 0; f < F; ++f) fp.push_back(cols[f]);
@@ -542,9 +742,11 @@ struct TileBuilder {
             for (int j = 0; j < nz; ++j) {
                 const int l = i * nz + j;
                 const int64_t r = r0 + (int64_t)i * stride + j;
+                int used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) {
-                    const size_t q = ent0 + (size_t)(e - rowptr[r]) * rb + l;
                     const uint32_t c = idx[e] & NEP_COL_MASK, t = idx[e] >> NEP_TERM_SHIFT;
+                    const int slot = slot_w ? slot_off[t] + used[t]++ : (int)(e - rowptr[r]);
+                    const size_t q = ent0 + (size_t)slot * rb + l;
                     eidx[q] = (uint16_t)((t << lbits) | (uint32_t)loc[c]);
                     if (valbytes == 8) evr[q] = ((const double*)vals)[e]; else evc[q] = ((const cplx*)vals)[e];
                 }
@@ -597,6 +799,22 @@ static bool tiles_build_host(TileBuilder& B, int64_t n, int mt, int valbytes, co
         for (int64_t dd = 2; dd < dmax; ++dd) if (cnt[dd] > best) { best = cnt[dd]; stride = (int)dd; }
         if (best < n / 4) stride = 0;
         if (const char* e = getenv("NEP_K1_TILE_STRIDE")) stride = atoi(e);
+    }
+    // term-slotted entries when the longest row of every term adds up to at most 8 slots (see NepTiles::slotted)
+    {
+        int cmax[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int64_t r = 0; r < n; ++r) {
+            int c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int32_t e = rowptr[r]; e < rowptr[r + 1]; ++e) ++c[idx[e] >> NEP_TERM_SHIFT];
+            for (int t = 0; t < mt; ++t) cmax[t] = std::max(cmax[t], c[t]);
+        }
+        int tot = 0;
+        for (int t = 0; t < mt; ++t) tot += cmax[t];
+        if (tot >= 1 && tot <= 8 && env_int("NEP_TILE_SLOTTED", 1)) {
+            B.slot_w = tot;
+            for (int t = 0; t < mt; ++t) B.slot_off[t + 1] = B.slot_off[t] + cmax[t];
+            for (int t = mt; t < 8; ++t) B.slot_off[t + 1] = B.slot_off[t];
+        }
     }
     const bool small = n < 32768;
     int zp = env_int("NEP_K1_TILE_ZP", small ? 16 : 64), xp = env_int("NEP_K1_TILE_XP", small ? 4 : 8);
@@ -721,6 +939,15 @@ int nep_tiles_build(int64_t n, int mt, int valbytes, const int32_t* rowptr, cons
     t->n = n; t->mt = mt; t->valbytes = valbytes; t->nblk = (int)B.desc.size(); t->fcap = (B.fcap_seen + 15) / 16 * 16;
     t->lbits = B.lbits; t->stride = stride; t->xp = xp; t->zp = zp; t->wmax = B.wmax; t->rbmax = B.rbmax;
     t->nent = (int64_t)B.eidx.size(); t->nfp = (int64_t)B.fp.size();
+    if (B.slot_w) {
+        t->slotted = 1; t->slot_terms = 0;
+        int last = 0;
+        for (int j = 0; j < 8; ++j) {
+            int term = last;
+            for (int q = 0; q < mt; ++q) if (j >= B.slot_off[q] && j < B.slot_off[q + 1]) term = q;
+            t->slot_terms |= (uint32_t)term << (4 * j); last = term;          // slots past the width repeat the last term (their values are 0)
+        }
+    }
 #define TCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { nep_set_error("%s:%d: %s: %s", __FILE__, __LINE__, #call, hipGetErrorString(e_)); nep_tiles_destroy(t); return NEP_ERR_HIP; } } while (0)
     TCHK(hipMalloc((void**)&t->d_desc, B.desc.size() * sizeof(TileDesc)));
     TCHK(hipMalloc((void**)&t->d_fp, B.fp.size() * 4 + 256));
@@ -836,6 +1063,49 @@ int nep_tiles_resid_cm(const NepTiles* t, int k, const cplx* dF, const cplx* Q, 
     LAUNCHCHK();
     return NEP_OK;
 }
+// K2 in super-panels (k_tile_resid_sp): every row of a block on its own thread, term-slotted entries (at most 8 per row), two
+// footprint tiles of 4 columns in LDS.  cm: column-major Q (ld ldq >= n) and R, else row-major (ld >= k).
+static int sp_threads(const NepTiles* t) { return t->rbmax <= 512 ? 512 : (t->rbmax <= 768 ? 768 : 1024); }
+static size_t sp_shmem(const NepTiles* t, int nthr) {
+    const int fpad = SP_FPAD(nthr);
+    return (size_t)2 * SP_PSW * fpad * sizeof(cplx) + (size_t)2 * (nthr / 64) * 2 * SP_PSW * sizeof(double) + (size_t)fpad * 4;
+}
+bool nep_tiles_resid_sp_ok(const NepTiles* t, int k) {
+    (void)k;
+    if (!t || !t->slotted || t->mt > 8 || t->wmax > 8 || t->rbmax > 1024) return false;
+    const int nthr = sp_threads(t);
+    const int fpad = SP_FPAD(nthr);
+    if (t->fcap > fpad || SP_PSW * (fpad / 64) > SP_IMAX * (nthr / 64)) return false;          // tile pitch; DMA instructions per wave
+    return sp_shmem(t, nthr) <= 160 * 1024;
+}
+int nep_tiles_resid_sp(const NepTiles* t, int k, const cplx* dF, const cplx* Q, int64_t ldq, int cm, cplx* R, int64_t ldr,
+                       double* partial, int64_t split_row, hipStream_t st) {
+    if (!nep_tiles_resid_sp_ok(t, k)) { nep_set_error("super-panel K2: not available for this matrix / k = %d", k); return NEP_ERR_ARG; }
+    const int nthr = sp_threads(t);
+    const size_t shm = sp_shmem(t, nthr);
+    static const int swz = env_int("NEP_XCD_SWIZZLE", 1);
+    // flush mask of the slot layout: bit j = slot j is the last of its term
+    int fm = 0x80;
+    for (int j = 0; j < 7; ++j) if (((t->slot_terms >> (4 * j)) & 15u) != ((t->slot_terms >> (4 * (j + 1))) & 15u)) fm |= 1 << j;
+#define SPL(VT, C, NT_, FM_)                                                                                                   \
+    do {                                                                                                                       \
+        if (shm > 64 * 1024) { const int rc_ = nep_raise_lds((const void*)k_tile_resid_sp<VT, C, NT_, FM_>, 160 * 1024); if (rc_) return rc_; } \
+        hipLaunchKernelGGL((k_tile_resid_sp<VT, C, NT_, FM_>), dim3((unsigned)t->nblk), dim3(NT_), shm, st, (const TileDesc*)t->d_desc, \
+                           (const uint32_t*)t->d_fp, (const uint16_t*)t->d_eidx, (const VT*)t->d_eval, Q, ldq, k, dF, t->mt,        \
+                           t->lbits, t->slot_terms, R, ldr, partial, swz, split_row);                                           \
+    } while (0)
+#define SPL_F(VT, C, NT_) do { if (fm == 0xD0) SPL(VT, C, NT_, 0xD0); else if (fm == 0x80) SPL(VT, C, NT_, 0x80); else SPL(VT, C, NT_, 0xFF); } while (0)
+#define SPL_C(VT, NT_) do { if (cm) SPL_F(VT, true, NT_); else SPL_F(VT, false, NT_); } while (0)
+#define SPL_T(VT) do { if (nthr == 512) SPL_C(VT, 512); else if (nthr == 768) SPL_C(VT, 768); else SPL_C(VT, 1024); } while (0)
+    if (t->valbytes == 8) SPL_T(double); else SPL_T(cplx);
+#undef SPL_T
+#undef SPL_C
+#undef SPL_F
+#undef SPL
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
 bool nep_tiles_resid_cm_ok(const NepTiles* t, int k) { return t->mt <= 4 && (size_t)t->fcap * 8 * sizeof(cplx) <= 150 * 1024; }
 
 int nep_tiles_resid(const NepTiles* t, int k, const cplx* dF, const cplx* QT, int64_t ldq, cplx* ZT, int64_t ldz, double* partial,

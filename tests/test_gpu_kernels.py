@@ -1228,6 +1228,71 @@ def test_resid_batch_column_major_tiled(na, case):
         assert np.array_equal(o2.cpu().numpy(), oh)                              # deterministic
 
 
+@pytest.mark.parametrize("case", ["wep", "gun", "wep_small_patch"])
+def test_resid_batch_super_panel_kernel(na, case, monkeypatch):
+    """K2 in super-panels (k_tile_resid_sp: one workgroup per block, the row's entries in registers, 4-column footprint tiles filled by
+    LDS-DMA, double-buffered) against NumPy and against the older kernels, for BOTH layouts of the Ritz block: row-major
+    (nep_resid_batch_dev, nep_resid_block, nep_resid_split_dev) and column-major (nep_resid_batch_cm_dev, with and without a tail
+    block); k below / at / above the panel width and odd; ldq > k; bitwise repeatable"""
+    import torch
+    from nep_amd._lib import lib, check, hptr, c_vp
+    from nep_amd import gallery, wep
+    rng = np.random.default_rng(33)
+    if case == "gun":
+        K, M, W1, W2 = gallery.gun_matrices(); Av = [K, -M, W1, W2]
+    elif case == "wep":
+        Av = wep.WaveguideData(303, 299, "JARLEBRING").big_matrices()
+    else:
+        Av = wep.WaveguideData(61, 37, "JARLEBRING").big_matrices()          # blocks cut by the grid's edge, short footprints
+    dev = na.SPMFDevice(Av)
+    n, mt = dev.n, dev.mt
+    try:
+        for k, ldq in ((1, 1), (3, 5), (4, 4), (7, 8), (8, 8), (13, 16), (60, 60), (61, 64)):
+            Q = rng.standard_normal((n, ldq)) + 1j * rng.standard_normal((n, ldq))
+            F = np.asfortranarray(rng.standard_normal((mt, k)) + 1j * rng.standard_normal((mt, k)))
+            R = np.column_stack([sum(F[t, s] * (Av[t] @ Q[:, s]) for t in range(mt)) for s in range(k)])
+            r2 = np.sum(abs(R) ** 2, axis=0); q2 = np.sum(abs(Q[:, :k]) ** 2, axis=0)
+            Qd = torch.from_numpy(Q).to("cuda")
+            Qc = torch.from_numpy(np.ascontiguousarray(Q[:, :k].T)).to("cuda")          # (k, n) = column-major n x k
+            row0 = n - 37
+            got = {}
+            for mode in (0, 2):
+                check(lib.nep_k2_set_sp_mode(mode))
+                o = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+                check(lib.nep_resid_batch_dev(dev.h, k, hptr(F), c_vp(Qd.data_ptr()), ldq, c_vp(o.data_ptr()), None))
+                RT = torch.zeros((n, k), dtype=torch.complex128, device="cuda")
+                check(lib.nep_resid_block(dev.h, k, hptr(F), c_vp(Qd.data_ptr()), ldq, c_vp(RT.data_ptr()), k, None))
+                os_ = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+                tl = torch.full((n - row0, k), float("nan"), dtype=torch.complex128, device="cuda")
+                check(lib.nep_resid_split_dev(dev.h, k, hptr(F), c_vp(Qd.data_ptr()), ldq, row0, c_vp(os_.data_ptr()), c_vp(tl.data_ptr()), k, None))
+                oc = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+                rc = lib.nep_resid_batch_cm_dev(dev.h, k, hptr(F), c_vp(Qc.data_ptr()), n, -1, c_vp(oc.data_ptr()), None, 0, None)
+                oc2 = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+                tc = torch.full((k, n - row0), float("nan"), dtype=torch.complex128, device="cuda")
+                rc2 = lib.nep_resid_batch_cm_dev(dev.h, k, hptr(F), c_vp(Qc.data_ptr()), n, row0, c_vp(oc2.data_ptr()), c_vp(tc.data_ptr()), n - row0, None)
+                assert rc == 0 and rc2 == 0
+                got[mode] = [x.cpu().numpy() for x in (o, RT, os_, tl, oc, oc2, tc)]
+            for mode in (0, 2):
+                o, RT, os_, tl, oc, oc2, tc = got[mode]
+                assert np.allclose(o[:k], r2, rtol=1e-12) and np.allclose(o[k:], q2, rtol=1e-12), (mode, k)
+                assert np.linalg.norm(RT - R) <= 1e-13 * np.linalg.norm(R)
+                assert np.allclose(os_[:k], np.sum(abs(R[:row0]) ** 2, axis=0), rtol=1e-12) and np.allclose(os_[k:], q2, rtol=1e-12)
+                assert np.linalg.norm(tl - R[row0:]) <= 1e-13 * np.linalg.norm(R[row0:])
+                assert np.allclose(oc[:k], r2, rtol=1e-12) and np.allclose(oc[k:], q2, rtol=1e-12)
+                assert np.allclose(oc2[:k], np.sum(abs(R[:row0]) ** 2, axis=0), rtol=1e-12) and np.allclose(oc2[k:], q2, rtol=1e-12)
+                assert np.linalg.norm(tc.T - R[row0:]) <= 1e-13 * np.linalg.norm(R[row0:])
+            # the super-panel form again: the same bits
+            check(lib.nep_k2_set_sp_mode(2))
+            o = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+            check(lib.nep_resid_batch_dev(dev.h, k, hptr(F), c_vp(Qd.data_ptr()), ldq, c_vp(o.data_ptr()), None))
+            assert np.array_equal(o.cpu().numpy(), got[2][0])
+            oc = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+            check(lib.nep_resid_batch_cm_dev(dev.h, k, hptr(F), c_vp(Qc.data_ptr()), n, -1, c_vp(oc.data_ptr()), None, 0, None))
+            assert np.array_equal(oc.cpu().numpy(), got[2][4])
+    finally:
+        check(lib.nep_k2_set_sp_mode(-1))
+
+
 @pytest.mark.parametrize("k", [3, 16, 17, 40, 70, 104, 128, 130])
 @pytest.mark.parametrize("reorth", [False, True, "borderline"])
 def test_orth_dev_decision_published_by_the_update(na, k, reorth):
