@@ -497,6 +497,10 @@ __device__ __forceinline__ void sp_dma16(const cplx* src, cplx* lds_dst) {
     const uint32_t a = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds_dst);
     asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(src), "s"(a) : "memory", "m0");
 }
+__device__ __forceinline__ void sp_dma4(const uint32_t* src, uint32_t* lds_dst) {            // 4 bytes per lane, lane l to lds_dst + l
+    const uint32_t a = (uint32_t)(size_t)((__attribute__((address_space(3))) char*)lds_dst);
+    asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dword %0, off" : : "v"(src), "s"(a) : "memory", "m0");
+}
 // eight per-lane doubles -> their eight wave sums in 3 halving exchanges + 3 plain ones (10 exchanges instead of 48): after the
 // exchange with lane ^ 32 a lane keeps v[0..4) or v[4..8) by its bit 5, after ^ 16 two of them by bit 4, after ^ 8 one by bit 3; the
 // 8 lanes that share bits 5..3 then add up.  Returns the sum of v[i] on every lane whose bits 5..3 spell i.  Fixed order.
@@ -523,6 +527,113 @@ __device__ __forceinline__ double sp_wave_reduce8(const double v[8], int lane) {
 // flushed into the residual with the term's coefficient -- 2 FMA per (entry, column) instead of the 2 x m_t + selects of per-term
 // accumulators picked by a per-lane mask (measured: the masked form ran VALU-bound at 0.55 ms for k = 60, slower than the kernel
 // it was to replace).
+// one panel (4 columns in `tile`) against the thread's row: residual entries, their squares, the optional store, |q|^2 of the block's
+// own columns, and the 8 wave sums into ws[wv][0..8)
+template <typename VT, bool CM, int NTHR, int FM>
+__device__ __forceinline__ void sp_panel(const cplx* __restrict__ tile, const uint32_t (&pid2)[4], const VT (&pv)[8], int p0, int k,
+                                         const cplx* __restrict__ F, int mt, uint32_t slot_terms, bool rowon, int64_t row,
+                                         int64_t split_row, cplx* __restrict__ R, int64_t ldr, bool want_norms,
+                                         const uint32_t* __restrict__ fpl, int Fn, int tid, int lane, int wv, double* __restrict__ ws) {
+    constexpr int PSW = SP_PSW;
+    constexpr int fpad = SP_FPAD(NTHR);
+    // two columns at a time, each finished (residual entry, its square, the optional store) before the next pair starts: the
+    // accumulators of four columns with their tile data in flight pushed loop invariants into scratch
+    double red[2 * PSW];
+#pragma unroll
+    for (int h = 0; h < PSW / 2; ++h) {
+        cplx acc[2], r[2];
+        const cplx* Fc[2];                                 // coefficient column of each panel column (uniform: scalar loads)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            acc[s] = cmake(0.0, 0.0); r[s] = cmake(0.0, 0.0);
+            Fc[s] = F + (p0 + 2 * h + s < k ? p0 + 2 * h + s : k - 1) * mt;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t o16 = (j & 1) ? (pid2[j >> 1] >> 16) : (pid2[j >> 1] & 0xffffu);      // byte offset of the entry's footprint slot
+            const cplx* tp = (const cplx*)((const char*)(tile + (size_t)(2 * h) * fpad) + o16);
+            const bool first = j == 0 || ((FM >> (j - 1)) & 1);          // first slot of its term: the accumulators start over
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const cplx q = tp[(size_t)s * fpad];
+                if (first) acc[s] = cscale(pv[j], q); else cfma(acc[s], pv[j], q);
+            }
+            if ((FM >> j) & 1) {                                          // last slot of its term (compile time)
+                const int tj = (int)((slot_terms >> (4 * j)) & 15u);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) cfma(r[s], Fc[s][tj], acc[s]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int col = p0 + 2 * h + s;
+            double r2 = 0.0;
+            if (rowon && col < k) {
+                r2 = fma(r[s].x, r[s].x, r[s].y * r[s].y);
+                if (split_row < 0) { if (R) R[CM ? row + (int64_t)col * ldr : row * ldr + col] = r[s]; }
+                else if (row >= split_row) { R[CM ? (row - split_row) + (int64_t)col * ldr : (row - split_row) * ldr + col] = r[s]; r2 = 0.0; }
+            }
+            red[2 * h + s] = r2; red[PSW + 2 * h + s] = 0.0;
+        }
+        // (a scheduling fence: the compiler would otherwise issue the tile reads of the whole panel up front and SPILL loop
+        // invariants to make room -- and a spill reload is a scratch load whose vmcnt(0) drains the DMA queue, see k_tile_resid_sp)
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    if (want_norms) {
+        // |q|^2 over the columns this block owns
+        for (int f = tid; f < Fn; f += NTHR) {
+            if (fpl[f] & TILE_OWN) {
+#pragma unroll
+                for (int s = 0; s < PSW; ++s) { const cplx q = tile[(size_t)s * fpad + f]; red[PSW + s] = fma(q.x, q.x, fma(q.y, q.y, red[PSW + s])); }
+            }
+        }
+        const double sum = sp_wave_reduce8(red, lane);
+        if ((lane & 7) == 0) ws[wv * 2 * PSW + (lane >> 3)] = sum;          // the lanes 0, 8, .., 56 hold the 8 sums
+    }
+}
+// the same in two steps for the persistent kernel: the loads (results untouched, so that nothing waits for them before the DMA that is
+// issued behind them) and, at the block switch, the packing
+template <typename VT>
+__device__ __forceinline__ void sp_entries_load(const uint16_t* __restrict__ ib, const VT* __restrict__ vb, int rb, int width, int tid,
+                                                uint32_t (&nid)[8], VT (&pv)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool on = tid < rb && j < width;
+        const int64_t e = on ? (int64_t)j * rb + tid : 0;
+        nid[j] = __builtin_nontemporal_load(ib + e);
+        pv[j] = tload<true>(vb + e);
+    }
+}
+template <typename VT>
+__device__ __forceinline__ void sp_entries_pack(const uint32_t (&nid)[8], const VT (&npv)[8], int rb, int width, int tid, uint32_t lmask,
+                                                uint32_t (&pid2)[4], VT (&pv)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pid2[j] = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool on = tid < rb && j < width;
+        uint32_t o = ((uint32_t)nid[j] & lmask) * 16u;
+        pv[j] = npv[j];
+        if (!on) { o = 0; if constexpr (sizeof(VT) == 8) pv[j] = 0.0; else pv[j] = cmake(0.0, 0.0); }
+        pid2[j >> 1] |= o << (16 * (j & 1));
+    }
+}
+// the row's entries of a block (local footprint BYTE offsets, two per register; the term is the slot's) -- once per block
+template <typename VT>
+__device__ __forceinline__ void sp_entries(const uint16_t* __restrict__ ib, const VT* __restrict__ vb, int rb, int width, int tid,
+                                           uint32_t lmask, uint32_t (&pid2)[4], VT (&pv)[8]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) pid2[j] = 0u;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const bool on = tid < rb && j < width;
+        const int64_t e = on ? (int64_t)j * rb + tid : 0;
+        uint32_t o = ((uint32_t)__builtin_nontemporal_load(ib + e) & lmask) * 16u;
+        pv[j] = tload<true>(vb + e);
+        if (!on) { o = 0; if constexpr (sizeof(VT) == 8) pv[j] = 0.0; else pv[j] = cmake(0.0, 0.0); }
+        pid2[j >> 1] |= o << (16 * (j & 1));
+    }
+}
 // FM: the slots after which the accumulators are flushed (bit j: slot j is the last of its term), known at compile time for the
 // common slot layouts (0xD0: the waveguide's 5 + 2 + 1; 0x80: one term; 0xFF: after every slot -- right for ANY slotting) so that
 // the panel loop has no branch in it.
@@ -554,8 +665,6 @@ __global__ __launch_bounds__(NTHR) void k_tile_resid_sp(const TileDesc* __restri
     // scratch reload is a VMEM load -- its `s_waitcnt vmcnt(0)` waits for every DMA in flight, one after the other, 5 us per panel);
     // slots past the footprint repeat its last one (their tile slots are padding)
     constexpr int NI = PSW * (fpad >> 6);
-    for (int f = tid; f < fpad; f += NTHR) fpl[f] = fpb[f < Fn ? f : Fn - 1];
-    __syncthreads();
     const int np = (k + PSW - 1) / PSW;
     auto issue = [&](int p, int buf) {
 #pragma unroll
@@ -569,22 +678,38 @@ __global__ __launch_bounds__(NTHR) void k_tile_resid_sp(const TileDesc* __restri
             }
         }
     };
-    issue(0, 0);
-    // ---- the row's entries, once (local footprint index; the term is the slot's)
-    uint32_t pid2[4] = {0u, 0u, 0u, 0u}; VT pv[8];            // pid2: two 16-bit BYTE offsets of footprint slots per register (fpad 16 < 2^16)
+    // the first TWO panels go out at once, straight from the footprint list in global memory (both tiles are free, and the list in
+    // LDS needs a barrier before anybody reads it): a block starts with one memory latency for both instead of one after the other
+    {
+        uint32_t raw[SP_IMAX];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const bool on = tid < rb && j < width;
-        const int64_t e = on ? (int64_t)j * rb + tid : 0;
-        uint32_t o = ((uint32_t)__builtin_nontemporal_load(ib + e) & lmask) * 16u;
-        pv[j] = tload<true>(vb + e);
-        if (!on) { o = 0; if constexpr (sizeof(VT) == 8) pv[j] = 0.0; else pv[j] = cmake(0.0, 0.0); }
-        pid2[j >> 1] |= o << (16 * (j & 1));
+        for (int t = 0; t < SP_IMAX; ++t) {
+            const int i = wv + t * NW;
+            const int f = (i >> 2) * 64 + lane;
+            raw[t] = fpb[(i < NI && f < Fn) ? f : Fn - 1];
+        }
+#pragma unroll
+        for (int t = 0; t < SP_IMAX; ++t) {
+            const int i = wv + t * NW;
+            if (i < NI) {
+                const int c = i & 3;
+                if (c == 0) fpl[(i >> 2) * 64 + lane] = raw[t];          // every footprint slot exactly once (the c = 0 instruction of its chunk)
+                const int64_t col = (int64_t)(raw[t] & NEP_COL_MASK);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    if (p < np) {
+                        const int cc = p * PSW + c < k ? p * PSW + c : k - 1;
+                        sp_dma16(Q + (CM ? col + (int64_t)cc * ldq : col * ldq + cc), Qt + ((size_t)(p * PSW + c) * fpad + (size_t)(i >> 2) * 64));
+                    }
+                }
+            }
+        }
     }
+    uint32_t pid2[4]; VT pv[8];
+    sp_entries<VT>(ib, vb, rb, width, tid, lmask, pid2, pv);
     const int li = tid / d.zp, ljz = tid - li * d.zp;
     const int64_t row = (int64_t)d.r0 + (int64_t)li * d.stride + ljz;
     const bool rowon = tid < d.nrows;
-    const int outlane = (lane & 7) == 0;                       // the lanes 0, 8, .., 56 publish the 8 sums of sp_wave_reduce8
     for (int p = 0; p < np; ++p) {
         const int p0 = p * PSW;
         __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's share of panel p has landed in LDS
@@ -597,62 +722,9 @@ __global__ __launch_bounds__(NTHR) void k_tile_resid_sp(const TileDesc* __restri
             for (int q = 0; q < NW; ++q) a += w[q * 2 * PSW];
             partial[((int64_t)blk * 2 + which) * k + p0 - PSW + s] = a;        // (p0 - PSW + s < k: only the LAST panel can be short)
         }
-        if (p + 1 < np) issue(p + 1, (p + 1) & 1);
-        const cplx* tile = Qt + (size_t)((p & 1) * PSW) * fpad;
-        // two columns at a time, each finished (residual entry, its square, the optional store) before the next pair starts: the
-        // accumulators of four columns with their tile data in flight pushed loop invariants into scratch
-        double red[2 * PSW];
-#pragma unroll
-        for (int h = 0; h < PSW / 2; ++h) {
-            cplx acc[2], r[2];
-            const cplx* Fc[2];                                 // coefficient column of each panel column (uniform: scalar loads)
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                acc[s] = cmake(0.0, 0.0); r[s] = cmake(0.0, 0.0);
-                Fc[s] = F + (p0 + 2 * h + s < k ? p0 + 2 * h + s : k - 1) * mt;
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const uint32_t o16 = (j & 1) ? (pid2[j >> 1] >> 16) : (pid2[j >> 1] & 0xffffu);      // byte offset of the entry's footprint slot
-                const cplx* tp = (const cplx*)((const char*)(tile + (size_t)(2 * h) * fpad) + o16);
-                const bool first = j == 0 || ((FM >> (j - 1)) & 1);          // first slot of its term: the accumulators start over
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-                    const cplx q = tp[(size_t)s * fpad];
-                    if (first) acc[s] = cscale(pv[j], q); else cfma(acc[s], pv[j], q);
-                }
-                if ((FM >> j) & 1) {                                          // last slot of its term (compile time)
-                    const int tj = (int)((slot_terms >> (4 * j)) & 15u);
-#pragma unroll
-                    for (int s = 0; s < 2; ++s) cfma(r[s], Fc[s][tj], acc[s]);
-                }
-            }
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const int col = p0 + 2 * h + s;
-                double r2 = 0.0;
-                if (rowon && col < k) {
-                    r2 = fma(r[s].x, r[s].x, r[s].y * r[s].y);
-                    if (split_row < 0) { if (R) R[CM ? row + (int64_t)col * ldr : row * ldr + col] = r[s]; }
-                    else if (row >= split_row) { R[CM ? (row - split_row) + (int64_t)col * ldr : (row - split_row) * ldr + col] = r[s]; r2 = 0.0; }
-                }
-                red[2 * h + s] = r2; red[PSW + 2 * h + s] = 0.0;
-            }
-            // (a scheduling fence: the compiler would otherwise issue the tile reads of the whole panel up front and SPILL loop
-            // invariants to make room -- and a spill reload is a scratch load whose vmcnt(0) drains the DMA queue, see above)
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (partial) {
-            // |q|^2 over the columns this block owns
-            for (int f = tid; f < Fn; f += NTHR) {
-                if (fpl[f] & TILE_OWN) {
-#pragma unroll
-                    for (int s = 0; s < PSW; ++s) { const cplx q = tile[(size_t)s * fpad + f]; red[PSW + s] = fma(q.x, q.x, fma(q.y, q.y, red[PSW + s])); }
-                }
-            }
-            const double sum = sp_wave_reduce8(red, lane);
-            if (outlane) wsum[(size_t)(p & 1) * NW * 2 * PSW + wv * 2 * PSW + (lane >> 3)] = sum;
-        }
+        if (p >= 1 && p + 1 < np) issue(p + 1, (p + 1) & 1);       // (panel 1 went out with panel 0)
+        sp_panel<VT, CM, NTHR, FM>(Qt + (size_t)((p & 1) * PSW) * fpad, pid2, pv, p0, k, F, mt, slot_terms, rowon, row, split_row, R, ldr,
+                                   partial != nullptr, fpl, Fn, tid, lane, wv, wsum + (size_t)(p & 1) * NW * 2 * PSW);
     }
     __syncthreads();
     if (partial) {
@@ -666,6 +738,146 @@ __global__ __launch_bounds__(NTHR) void k_tile_resid_sp(const TileDesc* __restri
                 for (int q = 0; q < NW; ++q) a += w[q * 2 * PSW];
                 partial[((int64_t)blk * 2 + which) * k + p0 + s] = a;
             }
+        }
+    }
+}
+
+// PERSISTENT form: one workgroup per CU walks the blocks of its XCD's range, and the (block, panel) items form ONE pipeline -- while
+// the last panel of a block is reduced, the first panel of the next block is already on its way into the other tile.  A block's own
+// start-up chain (descriptor -> footprint list -> first tile: three dependent memory latencies, ~4 us of the ~12 us a block takes at
+// k = 8) then overlaps with the previous block's arithmetic: the LDS tiles leave room for one workgroup per CU only, so nothing else
+// on the CU would hide it.  What travels ahead of the pipeline: the next block's footprint list (by LDS-DMA into the OTHER list
+// buffer during the second-to-last panel) and the next block's entries (loaded during the last panel into a second register set,
+// taken over at its end: ordinary loads issued BEFORE the item's DMA and consumed at the item's end -- the compiler's vmcnt wait for
+// them covers the younger DMA as well, which is exactly the wait the next item starts with).  np >= 2.
+template <typename VT, bool CM, int NTHR, int FM>
+__global__ __launch_bounds__(NTHR) void k_tile_resid_spp(const TileDesc* __restrict__ desc, const uint32_t* __restrict__ fp,
+                                                         const uint16_t* __restrict__ eidx, const VT* __restrict__ eval,
+                                                         const cplx* __restrict__ Q, int64_t ldq, int k, const cplx* __restrict__ F,
+                                                         int mt, int lbits, uint32_t slot_terms, cplx* __restrict__ R,
+                                                         int64_t ldr, double* __restrict__ partial, int64_t split_row, int nblk) {
+    constexpr int NW = NTHR / 64;
+    constexpr int PSW = SP_PSW;
+    constexpr int fpad = SP_FPAD(NTHR);
+    constexpr int NI = PSW * (fpad >> 6);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* Qt = (cplx*)smem;                                   // [2][PSW][fpad]
+    double* wsum = (double*)(Qt + (size_t)2 * PSW * fpad);    // [2 parities][NW][2 PSW]
+    uint32_t* fplb = (uint32_t*)(wsum + 2 * NW * 2 * PSW);    // [2][fpad]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t lmask = (1u << lbits) - 1u;
+    // the blocks of this workgroup: XCD x = id % 8 owns a contiguous range of blocks, its gridDim / 8 workgroups take every
+    // (gridDim / 8)-th of them (neighbouring blocks -- shared halo columns -- run at the same time on the same L2)
+    const int x = blockIdx.x & 7, wi = blockIdx.x >> 3, g8 = gridDim.x >> 3;
+    const int per = nblk >> 3, rem = nblk & 7;
+    const int lo = x * per + (x < rem ? x : rem), cnt = per + (x < rem ? 1 : 0);
+    if (wi >= cnt) return;
+    const int M = (cnt - wi + g8 - 1) / g8;
+    const int np = (k + PSW - 1) / PSW;
+    auto dma_panel = [&](const uint32_t* fl, int p, int buf) {
+#pragma unroll
+        for (int t = 0; t < SP_IMAX; ++t) {
+            const int i = wv + t * NW;
+            if (i < NI) {                                      // wave-uniform
+                const int c = i & 3;
+                const int cc = p * PSW + c < k ? p * PSW + c : k - 1;
+                const int64_t col = (int64_t)(fl[(i >> 2) * 64 + lane] & NEP_COL_MASK);
+                sp_dma16(Q + (CM ? col + (int64_t)cc * ldq : col * ldq + cc), Qt + ((size_t)(buf * PSW + c) * fpad + (size_t)(i >> 2) * 64));
+            }
+        }
+    };
+    // ---- block 0: footprint list straight from global memory, both first panels at once (as k_tile_resid_sp)
+    int cblk = lo + wi;
+    TileDesc d = desc[cblk];
+    {
+        const uint32_t* __restrict__ fpb = fp + d.fp_off;
+        uint32_t raw[SP_IMAX];
+#pragma unroll
+        for (int t = 0; t < SP_IMAX; ++t) {
+            const int i = wv + t * NW;
+            const int f = (i >> 2) * 64 + lane;
+            raw[t] = fpb[(i < NI && f < d.fp_cnt) ? f : d.fp_cnt - 1];
+        }
+#pragma unroll
+        for (int t = 0; t < SP_IMAX; ++t) {
+            const int i = wv + t * NW;
+            if (i < NI) {
+                const int c = i & 3;
+                if (c == 0) fplb[(i >> 2) * 64 + lane] = raw[t];
+                const int64_t col = (int64_t)(raw[t] & NEP_COL_MASK);
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const int cc = p * PSW + c < k ? p * PSW + c : k - 1;
+                    sp_dma16(Q + (CM ? col + (int64_t)cc * ldq : col * ldq + cc), Qt + ((size_t)(p * PSW + c) * fpad + (size_t)(i >> 2) * 64));
+                }
+            }
+        }
+    }
+    uint32_t pid2[4]; VT pv[8];
+    sp_entries<VT>(eidx + (int64_t)d.ent_off64 * 64, eval + (int64_t)d.ent_off64 * 64, d.wrb >> 16, d.wrb & 0xffff, tid, lmask, pid2, pv);
+    int li = tid / d.zp;
+    int64_t row = (int64_t)d.r0 + (int64_t)li * d.stride + (tid - li * d.zp);
+    bool rowon = tid < d.nrows;
+    int Fn = d.fp_cnt;
+    int q = 0, pblk = 0, pp0 = 0;                 // item counter; block and first column of the previous item (its norm partials)
+    for (int m = 0; m < M; ++m) {
+        const bool have_next = m + 1 < M;
+        const int nblk_id = cblk + g8;
+        uint32_t nid[8]; VT npv[8];
+        TileDesc dn = d;
+        if (have_next) dn = desc[nblk_id];
+        for (int p = 0; p < np; ++p, ++q) {
+            const int p0 = p * PSW;
+            __builtin_amdgcn_s_waitcnt(0x0f70);        // vmcnt(0): this wave's share of the item's tile has landed in LDS
+            __syncthreads();                           // ... everybody's; every wave is done with the other tile, the other list, wsum of item q - 1
+            if (partial && q > 0 && tid < 2 * PSW) {
+                const int which = tid / PSW, s_ = tid - which * PSW;
+                if (pp0 + s_ < k) {
+                    const double* w = wsum + (size_t)((q - 1) & 1) * NW * 2 * PSW + which * PSW + s_;
+                    double a = 0.0;
+#pragma unroll
+                    for (int u = 0; u < NW; ++u) a += w[u * 2 * PSW];
+                    partial[((int64_t)pblk * 2 + which) * k + pp0 + s_] = a;
+                }
+            }
+            // what the NEXT block needs ahead of its first item, issued before this item's DMA (see the kernel comment)
+            if (have_next && p == np - 2) {            // the list itself by LDS-DMA (4 bytes per lane) into the other list buffer: no registers
+                const uint32_t* __restrict__ fpn = fp + dn.fp_off;
+                for (int ch = wv; ch < (fpad >> 6); ch += NW) {
+                    const int f = ch * 64 + lane;
+                    sp_dma4(fpn + (f < dn.fp_cnt ? f : dn.fp_cnt - 1), fplb + (size_t)((m + 1) & 1) * fpad + ch * 64);
+                }
+            }
+            if (have_next && p == np - 1)
+                sp_entries_load<VT>(eidx + (int64_t)dn.ent_off64 * 64, eval + (int64_t)dn.ent_off64 * 64, dn.wrb >> 16, dn.wrb & 0xffff, tid, nid, npv);
+            // the tile of item q + 1 (items 0 and 1 went out together above)
+            if (q >= 1) {
+                if (p + 1 < np) dma_panel(fplb + (size_t)(m & 1) * fpad, p + 1, (q + 1) & 1);
+                else if (have_next) dma_panel(fplb + (size_t)((m + 1) & 1) * fpad, 0, (q + 1) & 1);
+            }
+            sp_panel<VT, CM, NTHR, FM>(Qt + (size_t)((q & 1) * PSW) * fpad, pid2, pv, p0, k, F, mt, slot_terms, rowon, row, split_row, R, ldr,
+                                       partial != nullptr, fplb + (size_t)(m & 1) * fpad, Fn, tid, lane, wv, wsum + (size_t)(q & 1) * NW * 2 * PSW);
+            pblk = cblk; pp0 = p0;
+        }
+        if (have_next) {                               // the next block becomes the current one
+            sp_entries_pack<VT>(nid, npv, dn.wrb >> 16, dn.wrb & 0xffff, tid, lmask, pid2, pv);
+            d = dn; cblk = nblk_id;
+            li = tid / d.zp;
+            row = (int64_t)d.r0 + (int64_t)li * d.stride + (tid - li * d.zp);
+            rowon = tid < d.nrows;
+            Fn = d.fp_cnt;
+        }
+    }
+    __syncthreads();
+    if (partial && tid < 2 * PSW) {
+        const int which = tid / PSW, s_ = tid - which * PSW;
+        if (pp0 + s_ < k) {
+            const double* w = wsum + (size_t)((q - 1) & 1) * NW * 2 * PSW + which * PSW + s_;
+            double a = 0.0;
+#pragma unroll
+            for (int u = 0; u < NW; ++u) a += w[u * 2 * PSW];
+            partial[((int64_t)pblk * 2 + which) * k + pp0 + s_] = a;
         }
     }
 }
@@ -1076,23 +1288,44 @@ bool nep_tiles_resid_sp_ok(const NepTiles* t, int k) {
     const int nthr = sp_threads(t);
     const int fpad = SP_FPAD(nthr);
     if (t->fcap > fpad || SP_PSW * (fpad / 64) > SP_IMAX * (nthr / 64)) return false;          // tile pitch; DMA instructions per wave
-    return sp_shmem(t, nthr) <= 160 * 1024;
+    return sp_shmem(t, nthr) + (size_t)fpad * 4 <= 160 * 1024;
 }
 int nep_tiles_resid_sp(const NepTiles* t, int k, const cplx* dF, const cplx* Q, int64_t ldq, int cm, cplx* R, int64_t ldr,
                        double* partial, int64_t split_row, hipStream_t st) {
     if (!nep_tiles_resid_sp_ok(t, k)) { nep_set_error("super-panel K2: not available for this matrix / k = %d", k); return NEP_ERR_ARG; }
     const int nthr = sp_threads(t);
-    const size_t shm = sp_shmem(t, nthr);
+    const size_t shm = sp_shmem(t, nthr) + (size_t)SP_FPAD(nthr) * 4;          // (+ the second footprint list of the persistent form)
     static const int swz = env_int("NEP_XCD_SWIZZLE", 1);
+    // persistent form (k_tile_resid_spp) from two panels on: one workgroup per CU (the tiles leave room for one), a multiple of 8
+    static const int persist = env_int("NEP_K2_SP_PERSIST", 1);
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount >= 8) ? pr.multiProcessorCount : 256;
+        ncu = env_int("NEP_K2_SP_GRID", ncu) / 8 * 8;
+        if (ncu < 8) ncu = 8;
+    }
+    // measured at n = 1e6 (kernel time, rocprofv3): k = 8 persistent 58.6 us / one block per workgroup 64.6 us (the old kernel: 59.4);
+    // k = 60 320 / 297 us (450): with many panels per block the start-up is a small part, and the hardware's own dispatch of one
+    // workgroup per free CU balances the tail better than the static walk.  NEP_K2_SP_PERSIST = 0 never, 2 always (k > 4)
+    const bool pers = k > SP_PSW && (persist == 2 || (persist == 1 && k <= 3 * SP_PSW));
+    const int pgrid = std::min(ncu, (t->nblk + 7) / 8 * 8);
     // flush mask of the slot layout: bit j = slot j is the last of its term
     int fm = 0x80;
     for (int j = 0; j < 7; ++j) if (((t->slot_terms >> (4 * j)) & 15u) != ((t->slot_terms >> (4 * (j + 1))) & 15u)) fm |= 1 << j;
 #define SPL(VT, C, NT_, FM_)                                                                                                   \
     do {                                                                                                                       \
-        if (shm > 64 * 1024) { const int rc_ = nep_raise_lds((const void*)k_tile_resid_sp<VT, C, NT_, FM_>, 160 * 1024); if (rc_) return rc_; } \
-        hipLaunchKernelGGL((k_tile_resid_sp<VT, C, NT_, FM_>), dim3((unsigned)t->nblk), dim3(NT_), shm, st, (const TileDesc*)t->d_desc, \
-                           (const uint32_t*)t->d_fp, (const uint16_t*)t->d_eidx, (const VT*)t->d_eval, Q, ldq, k, dF, t->mt,        \
-                           t->lbits, t->slot_terms, R, ldr, partial, swz, split_row);                                           \
+        if (pers) {                                                                                                            \
+            if (shm > 64 * 1024) { const int rc_ = nep_raise_lds((const void*)k_tile_resid_spp<VT, C, NT_, FM_>, 160 * 1024); if (rc_) return rc_; } \
+            hipLaunchKernelGGL((k_tile_resid_spp<VT, C, NT_, FM_>), dim3((unsigned)pgrid), dim3(NT_), shm, st, (const TileDesc*)t->d_desc, \
+                               (const uint32_t*)t->d_fp, (const uint16_t*)t->d_eidx, (const VT*)t->d_eval, Q, ldq, k, dF, t->mt,    \
+                               t->lbits, t->slot_terms, R, ldr, partial, split_row, t->nblk);                                   \
+        } else {                                                                                                               \
+            if (shm > 64 * 1024) { const int rc_ = nep_raise_lds((const void*)k_tile_resid_sp<VT, C, NT_, FM_>, 160 * 1024); if (rc_) return rc_; } \
+            hipLaunchKernelGGL((k_tile_resid_sp<VT, C, NT_, FM_>), dim3((unsigned)t->nblk), dim3(NT_), shm, st, (const TileDesc*)t->d_desc, \
+                               (const uint32_t*)t->d_fp, (const uint16_t*)t->d_eidx, (const VT*)t->d_eval, Q, ldq, k, dF, t->mt,    \
+                               t->lbits, t->slot_terms, R, ldr, partial, swz, split_row);                                       \
+        }                                                                                                                      \
     } while (0)
 #define SPL_F(VT, C, NT_) do { if (fm == 0xD0) SPL(VT, C, NT_, 0xD0); else if (fm == 0x80) SPL(VT, C, NT_, 0x80); else SPL(VT, C, NT_, 0xFF); } while (0)
 #define SPL_C(VT, NT_) do { if (cm) SPL_F(VT, true, NT_); else SPL_F(VT, false, NT_); } while (0)
