@@ -248,6 +248,17 @@ int32_t nep_gemm_ts_dev(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_
  * replaces: the FFTW transforms of the waveguide Sylvester solver, src/gallery_extra/waveguide/waveguide_preconditioner.jl:
  *           120-219 (V!, Vh!, W, Wh as dense DFT / sine-transform matrices), and the small dense products of the
  *           Sylvester-SMW preconditioner (:221-421). */
+/* Thin QR of a tall device block by column-wise DGKS (K6), no host synchronisation: dQ (rows x k, column-major, ld ldq) is
+ * orthonormalised in place; row j of d_out (k rows of k + 2 complex, device) = R[0..j, j], (R[j, j], 0), (passes, 2 * breakdown +
+ * another_pass_wanted).  A column inside the span of its predecessors leaves a tiny R[j, j] (the rank shows in R).
+ * replaces: `V, S, W = svd(A0)` of the n x k moment block in Beyn's method, src/method_beyncontour.jl:114-121, which becomes
+ *           svd(R) of the k x k factor (V = Q U_R). */
+int32_t nep_orth_qr_dev(nep_cdouble* dQ, int64_t ldq, int64_t rows, int32_t k, nep_cdouble* d_out, nep_stream stream);
+/* nep_zgemm with the reduction split over `ksplit` workgroups per tile, slices summed in order (deterministic); dWork: ksplit * m * n
+ * complex (device).  For products of a few tiles with a long K: the k x k block V0^H A1 of src/method_beyncontour.jl:123. */
+int32_t nep_zgemm_sk(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t k, nep_cdouble alpha,
+                     const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb, nep_cdouble beta,
+                     nep_cdouble* dC, int64_t ldc, int32_t ksplit, nep_cdouble* dWork, nep_stream stream);
 int32_t nep_zgemm(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t k, nep_cdouble alpha,
                   const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb, nep_cdouble beta,
                   nep_cdouble* dC, int64_t ldc, nep_stream stream);

@@ -651,6 +651,28 @@ extern "C" int32_t nep_zgemm_ex(int32_t m, int32_t n, int32_t k, nep_cdouble alp
     return NEP_OK;
 }
 
+// C = alpha op(A) op(B) + beta C with the K range split over `ksplit` workgroups per tile (deterministic: the slices are summed in
+// order): products of a few tiles with a long reduction -- the k x k Gram block Q^H A1 of Beyn's method (one 32 x 32 tile, K = n).
+// dWork: ksplit * m * n complex.
+extern "C" int32_t nep_zgemm_sk(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t k, nep_cdouble alpha,
+                                const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb, nep_cdouble beta,
+                                nep_cdouble* dC, int64_t ldc, int32_t ksplit, nep_cdouble* dWork, nep_stream stream) {
+    ARGCHK(dA && dB && dC && dWork && m >= 1 && n >= 1 && k >= 1 && ksplit >= 1);
+    ARGCHK(transa >= 0 && transa <= 2 && transb >= 0 && transb <= 2);
+    ARGCHK(lda >= (transa ? k : m) && ldb >= (transb ? n : k) && ldc >= m);
+    cplx al, be; al.x = alpha.re; al.y = alpha.im; be.x = beta.re; be.y = beta.im;
+    const int kchunk = ((k + ksplit - 1) / ksplit + 15) / 16 * 16;
+    const int nzs = (k + kchunk - 1) / kchunk;
+    hipLaunchKernelGGL(k_gemm_general<cplx>, dim3((unsigned)((m + 63) / 64), (unsigned)((n + 63) / 64), (unsigned)nzs), dim3(256), 0,
+                       as_stream(stream), (int)transa, (int)transb, (int)m, (int)n, (int)k, al, (const cplx*)dA, lda, (const cplx*)dB, ldb, be,
+                       (cplx*)dC, ldc, (const int32_t*)nullptr, kchunk, (cplx*)dWork);
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_gemm_splitk_reduce, dim3((unsigned)(((int64_t)m * n + 255) / 256)), dim3(256), 0, as_stream(stream), (int)m, (int)n, nzs,
+                       al, (const cplx*)dWork, be, (cplx*)dC, ldc);
+    LAUNCHCHK();
+    return NEP_OK;
+}
+
 extern "C" int32_t nep_zgemm(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t k, nep_cdouble alpha,
                              const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb, nep_cdouble beta,
                              nep_cdouble* dC, int64_t ldc, nep_stream stream) {

@@ -752,6 +752,38 @@ static int orth_dev_impl(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32
     return NEP_OK;
 }
 
+// first column of a thin QR: beta = ||w||, w /= beta; out[0] = (beta, 0), out[1] = (1 pass, 2 * breakdown).  One workgroup.
+__global__ __launch_bounds__(1024) void k_qr_first(int64_t rows, cplx* __restrict__ w, cplx* __restrict__ out) {
+    __shared__ double sm[16];
+    double a = 0.0;
+    for (int64_t i = threadIdx.x; i < rows; i += 1024) a += fma(w[i].x, w[i].x, w[i].y * w[i].y);
+    a = wave_reduce_sum(a);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+    __syncthreads();
+    double t = 0.0;
+    for (int q = 0; q < 16; ++q) t += sm[q];
+    const double nrm = sqrt(t);
+    const int brk = (!(nrm > 0.0) || !isfinite(nrm)) ? 1 : 0;
+    const double inv = brk ? 0.0 : 1.0 / nrm;
+    for (int64_t i = threadIdx.x; i < rows; i += 1024) w[i] = cmake(w[i].x * inv, w[i].y * inv);
+    if (threadIdx.x == 0) { out[0] = cmake(nrm, 0.0); out[1] = cmake(1.0, (double)(2 * brk)); }
+}
+// Thin QR of a tall block by column-wise DGKS, all on the device and without a host synchronisation: column j of dQ (rows x k,
+// column-major, ld ldq) is orthogonalised against the columns before it and normalised in place (nep_orth_dev); row j of d_out
+// (k rows of k + 2 complex) receives h[0..j) = R[0..j, j], (beta, 0) = R[j, j], and the (passes, flags) word of nep_orth_dev.
+// A column inside the span of its predecessors leaves a tiny R[j, j] and a normalised noise vector -- the caller reads the rank off
+// R.  (Beyn's method: the SVD of the n x k moment block becomes svd(R), method_beyncontour.jl:114-128.)
+extern "C" int32_t nep_orth_qr_dev(nep_cdouble* dQ, int64_t ldq, int64_t rows, int32_t k, nep_cdouble* d_out, nep_stream stream) {
+    ARGCHK(dQ && d_out && rows > 0 && k >= 1 && ldq >= rows);
+    hipLaunchKernelGGL(k_qr_first, dim3(1), dim3(1024), 0, as_stream(stream), rows, (cplx*)dQ, (cplx*)d_out);
+    LAUNCHCHK();
+    for (int32_t j = 1; j < k; ++j) {
+        const int rc = nep_orth_dev(dQ, ldq, rows, j, nullptr, dQ + (int64_t)j * ldq, d_out + (int64_t)j * (k + 2), 0, stream);
+        if (rc) return rc;
+    }
+    return NEP_OK;
+}
+
 // h = V^H w  (rows x k block, no update of w): the projection products W^H (A_i v) of Proj_SPMF_NEP
 // (src/NEPTypes.jl:724-790) and Gram matrices.  Synchronous (k host results).
 extern "C" int32_t nep_gemv_h(const nep_cdouble* dV, int64_t ldv, int64_t rows, int32_t k, const nep_cdouble* dw,

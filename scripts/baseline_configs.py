@@ -131,6 +131,8 @@ def c4_device(na, nep, integrator=None, Vh=None, info=None, **over):
     if Vh is None:
         Vh = na.probe_block(nep.n, kw["k"])
     args = (nep,) if integrator is None else (nep, integrator)
+    if info is not None:
+        info.setdefault("moments", False)      # the n x k moment blocks stay on the device (contour_beyn downloads them for callers that ask)
     return na.contour_beyn(*args, Vh=Vh, info=info, **kw)
 
 

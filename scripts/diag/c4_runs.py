@@ -17,3 +17,13 @@ for i in range(N):
     if i == 0:
         from nep_amd.linsolvers import _DeviceRefactor
         _DeviceRefactor.wait()
+# phase split of one more call (each phase closed by a device synchronisation), both tails
+for mode in ("1", "0"):
+    os.environ["NEP_BEYN_DEVICE_TAIL"] = mode
+    bc.c4_device(na, nep, Vh=Vh, info={})
+    pinfo = {"phases_s": {}}
+    bc.c4_device(na, nep, Vh=Vh, info=pinfo)
+    ph = pinfo["phases_s"]
+    shard = ph.get("factorise_nodes", 0.0) + ph.get("solve_nodes_and_accumulate", 0.0)
+    tot = sum(ph.values())
+    print("device tail" if mode == "1" else "host tail", {k_: round(v * 1e3, 3) for k_, v in ph.items()}, "replicated %.1f %%" % (100 * (tot - shard) / tot), "p =", pinfo.get("p"))

@@ -594,6 +594,34 @@ def test_beyn_gun_twin_vs_oracle(na):
     assert max(oE(lg[i], Vg[:, i]) for i in range(len(lg))) < 1e-6
 
 
+def test_beyn_device_tail_equals_host_tail(na, monkeypatch):
+    """the dense tail of contour_beyn with the moments left on the device (A0 = Q R by DGKS on the device, svd of the k x k R, the
+    k x k Gram block Q^H A1 from the device, eigenvectors by K7; contour._beyn_tail_device) against the reference's own order of
+    operations on the host (svd of the n x k block, method_beyncontour.jl:114-128): same rank, singular values to 1e-10 relative
+    (above the rank threshold), same eigenvalues to 1e-9, eigenvectors with residuals below tol; A0 has rank < k here (the block
+    the QR orthonormalises has columns of pure noise)"""
+    n, k, N = 1310, 16, 32
+    nep = na.nep_gallery("gun_spmf", n)
+    Vh = na.probe_block(n, k)
+    kw = dict(sigma=250.0 ** 2, radius=1.2e4, N=N, k=k, neigs=10 ** 6, tol=1e-6, sanity_check=True)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("NEP_BEYN_DEVICE_TAIL", mode)
+        info = {"moments": mode == "0"}
+        lam, V = na.contour_beyn(nep, Vh=Vh, info=info, **kw)
+        res[mode] = (np.asarray(lam), V, info)
+    (l0, V0, i0), (l1, V1, i1) = res["0"], res["1"]
+    assert i1["A0"] is None and i0["A0"] is not None              # the device tail downloaded no n x k block
+    assert i0["p"] == i1["p"] < k
+    p = i0["p"]
+    assert np.abs(i0["S"][:p] - i1["S"][:p]).max() <= 1e-10 * i0["S"][0]
+    assert len(l0) == len(l1) >= 1
+    _match(l1, l0, 1e-9)
+    from oracle import gallery as og, solvers as osol
+    oE = osol.StandardSPMFErrmeasure(og.gun_spmf(n))
+    assert max(oE(l1[i], V1[:, i]) for i in range(len(l1))) < 1e-6
+
+
 def test_beyn_first_call_seeds_the_device_plan(na):
     """a process that ONLY runs contour_beyn: the first call factorises its nodes in the host workers and the first of those
     factorisations seeds the pattern's device-factorisation plan; the second call factorises all nodes on the GPU in one
