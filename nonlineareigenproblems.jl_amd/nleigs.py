@@ -54,15 +54,29 @@ def nleigs(nep, *args, **kw):
     thread for the duration of the call (NEP_NLEIGS_BLAS_GUARD=0: left alone), as in iar's loop."""
     import nep_amd_hostlu as _nep_hostlu
     ctl = _nep_hostlu.blas_controller() if os.environ.get("NEP_NLEIGS_BLAS_GUARD", "1") != "0" else None
+
+    def run():
+        try:
+            return _nleigs(nep, *args, **kw)
+        except _OrthPassMiss:          # "twice is enough" failed for a step of the asynchronous Gram-Schmidt: exact DGKS through the synchronous calls
+            nleigs.orth_misses += 1
+            return _nleigs(nep, *args, _sync_orth=True, **kw)
     if ctl is None:
-        return _nleigs(nep, *args, **kw)
+        return run()
     with ctl.limit(limits=1, user_api="blas"):
-        return _nleigs(nep, *args, **kw)
+        return run()
+
+
+class _OrthPassMiss(Exception):
+    pass
+
+
+nleigs.orth_misses = 0
 
 
 def _nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger=0, maxdgr=100, minit=20, maxit=200,
             linsolvercreator=None, tol=1e-10, tollin=None, v=None, errmeasure=None, isfunm=True, static=False, leja=1,
-            nodes=(), reusefact=1, blksize=20, return_details=False, check_error_every=5, info=None):
+            nodes=(), reusefact=1, blksize=20, return_details=False, check_error_every=5, info=None, _sync_orth=False):
     import warnings
     if tollin is None:
         tollin = max(tol / 10, 100 * EPS)
@@ -158,6 +172,35 @@ def _nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logge
         ylr = torch.empty(r, dtype=CDT, device="cuda")
         Wlr = to_dev(sgdd[p + 1 + LR.iL, :])          # (maxdgr+2, r): column ii holds dd[iL] of method_nleigs.jl:464
     H = np.zeros((ncol, ncol - 1), dtype=complex); K = np.zeros((ncol, ncol - 1), dtype=complex)
+    # Asynchronous Gram-Schmidt (default): the rational Krylov recurrence itself never reads H -- the continuation vector is the last
+    # basis vector (method_nleigs.jl:287-288) and shifts, poles and block sizes are host data -- so the orthogonalisation of a step
+    # is enqueued with the DGKS decision on the device (nep_orth_dev: h, beta and the flags stay in row l - 1 of Hdev) and the rows
+    # are fetched in ONE copy when the pencil (K, H) is needed: at a convergence check and at the end.  The step-synchronous
+    # nep_orth (h and beta read back in every step: the host waited for the device and the device for the host, 100 times per call)
+    # remains for NEP_NLEIGS_SYNC=1 and as the fallback when a step still wanted a third pass.
+    async_orth = not _sync_orth and os.environ.get("NEP_NLEIGS_SYNC", "0") == "0"
+    if async_orth:
+        Hdev = torch.zeros((ncol, ncol + 2), dtype=CDT, device="cuda")
+        active_d = torch.zeros(ncol, dtype=torch.int64, device="cuda")
+    pending = []                                       # (l, k) of the steps whose row of Hdev has not been read yet
+
+    def flush_H():
+        if not pending:
+            return
+        l0 = pending[0][0]; l1 = pending[-1][0]
+        rows_ = Hdev[l0 - 1:l1].cpu().numpy()          # one device-to-host copy (synchronises)
+        for (l_, k_) in pending:
+            row = rows_[l_ - l0]
+            flags = int(row[l_ + 1].imag)
+            if flags & 2:
+                raise ArithmeticError("orthogonalisation breakdown in nleigs step %d" % k_)
+            if flags & 1:
+                raise _OrthPassMiss(k_)
+            H[:l_, l_ - 1] = row[:l_]; H[l_, l_ - 1] = row[l_].real
+            K[:l_, l_ - 1] = H[:l_, l_ - 1] * sigma[k_]
+            K[l_ - 1, l_ - 1] += 1.0
+            K[l_, l_ - 1] = H[l_, l_ - 1] * sigma[k_]
+        pending.clear()
     Lam = np.zeros((ncol - 1, ncol - 1), dtype=complex); Res = np.zeros((ncol - 1, ncol - 1))
     active = np.zeros(ncol, dtype=np.int64)
     st = stream_ptr
@@ -269,6 +312,7 @@ def _nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logge
         backslash = backslash_lowrank
 
     def check_convergence(k, l, all_=False):
+        flush_H()
         lambda_, S = sla.eig(K[:l, :l], H[:l, :l])
         if not all_:
             lamin = rk.in_Sigma(lambda_, Sigma, tol)
@@ -330,11 +374,19 @@ def _nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logge
             cache.prefetch(sigma[k:k + 3])
             w = backslash(k, l)
             active[l] = kn
-            h, hb, _ = dense.orthogonalize_and_normalize(V, w, l, rows=kn, ldv=ldv, active_rows=active, method=dense.DGKS)
-            H[:l, l - 1] = h; H[l, l - 1] = hb
-            K[:l, l - 1] = H[:l, l - 1] * sigma[k]
-            K[l - 1, l - 1] += 1.0
-            K[l, l - 1] = hb * sigma[k]
+            if async_orth:
+                if not pending or pending[-1][0] != l - 1 or l == 1:
+                    active_d[:l + 1].copy_(torch.from_numpy(active[:l + 1]))        # (first step, or after a gap: the whole prefix)
+                else:
+                    active_d[l:l + 1].fill_(int(kn))
+                dense.orthogonalize_and_normalize_dev(V, w, l, Hdev[l - 1], rows=kn, ldv=ldv, active_dev=active_d, method=dense.DGKS)
+                pending.append((l, k))
+            else:
+                h, hb, _ = dense.orthogonalize_and_normalize(V, w, l, rows=kn, ldv=ldv, active_rows=active, method=dense.DGKS)
+                H[:l, l - 1] = h; H[l, l - 1] = hb
+                K[:l, l - 1] = H[:l, l - 1] * sigma[k]
+                K[l - 1, l - 1] += 1.0
+                K[l, l - 1] = hb * sigma[k]
         if not return_details and (
                 (not expand and k >= N + minit and (k - (N + minit)) % check_error_every == 0) or
                 (k >= kconv + minit and (k - (kconv + minit)) % check_error_every == 0) or k == kmax):
@@ -344,6 +396,7 @@ def _nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logge
         if ((not expand and k >= N + minit) or k >= kconv + minit) and nblamin == nbconv:
             break
         k += 1
+    flush_H()
     lam = res_state["lam"]; conv = res_state["conv"]; res = res_state["res"]
     cache.close()
     if info is not None:
