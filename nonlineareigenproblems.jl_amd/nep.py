@@ -58,7 +58,14 @@ def to_dev(A):
 
 def to_host(T):
     """device (k, n) tensor -> host n x k ndarray"""
-    return T.cpu().numpy().T.copy()
+    if not T.is_cuda:
+        return T.numpy().T
+    # through a pinned block (torch's caching host allocator hands the same pages out again once the caller has dropped the array):
+    # a pageable `T.cpu()` of the 7 MB gun block runs at ~10 GB/s, the pinned copy at the link's rate
+    h = torch.empty(T.shape, dtype=T.dtype, pin_memory=True)
+    h.copy_(T, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return h.numpy().T.copy()
 
 
 def to_host_cm(T):
