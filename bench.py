@@ -463,7 +463,7 @@ def wep_scale_roofline(na):
         o = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
         ms = event_loop(lambda: dev.resid_batch_dev(F, QT, k, k, o), 10, warm=3)
         b = dev.matrix_bytes + 16 * n * k
-        out["K2 k=%d" % k] = {"kernel": "nep_resid_batch_dev", "algorithmic_bytes": b, "ms_per_launch": ms, "achieved": b / ms / 1e6,
+        out["K2 k=%d" % k] = {"kernel": "nep_resid_batch_dev (row-major Ritz block; k_tile_resid_sp / _spp: super-panels, LDS-DMA tiles)", "algorithmic_bytes": b, "ms_per_launch": ms, "achieved": b / ms / 1e6,
                               "frac": b / ms / 1e6 / HBM_PEAK_GBS}
         del QT
     # the same residual batch on a COLUMN-major Ritz block (nep_resid_batch_cm_dev: what K7 writes with y_rowmajor = 0 and what a Julia
@@ -479,7 +479,7 @@ def wep_scale_roofline(na):
             if call() == 0:
                 ms = event_loop(call, 10, warm=3)
                 b = dev.matrix_bytes + 16 * n * k
-                out["K2 column-major k=%d" % k] = {"kernel": "nep_resid_batch_cm_dev", "algorithmic_bytes": b, "ms_per_launch": ms,
+                out["K2 column-major k=%d" % k] = {"kernel": "nep_resid_batch_cm_dev (column-major Ritz block, the layout of a Julia host; same kernels)", "algorithmic_bytes": b, "ms_per_launch": ms,
                                                    "achieved": b / ms / 1e6, "frac": b / ms / 1e6 / HBM_PEAK_GBS}
             del Qc
     except Exception as e:
@@ -505,6 +505,32 @@ def wep_scale_roofline(na):
             del Zb, Yb
     except Exception as e:
         out["K7"] = {"error": repr(e)[:200]}
+    # HBM bytes of the K2 / K7 launches from the stored PMC passes (scripts/make_profiles_r5.sh: separate --pmc FETCH_SIZE / WRITE_SIZE
+    # runs of `bench.py --only wepscale`; 2*FETCH + WRITE per the gfx950 note), with the digest of the kernel source they were taken on
+    try:
+        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc2", "r5_wepscale_traffic.json")))
+        cur = _file_digest(os.path.join(ROOT, "nonlineareigenproblems.jl_amd", "csrc", "spmv_tile.hip"))
+        stale = bool(pj.get("_meta", {}).get("spmv_tile_hip_digest") != cur)
+
+        def traffic_of(prefix):
+            v = [d["hbm_MB_per_launch"] * 1024.0 * 1024.0 for name, d in pj.items() if name.startswith(prefix) and isinstance(d, dict) and "hbm_MB_per_launch" in d]
+            return max(v) if v else None
+        for key, prefix in (("K2 k=8", "k_tile_resid_spp<double, false"), ("K2 k=60", "k_tile_resid_sp<double, false"),
+                            ("K2 column-major k=8", "k_tile_resid_spp<double, true"), ("K2 column-major k=60", "k_tile_resid_sp<double, true")):
+            if key in out and isinstance(out[key], dict):
+                t = traffic_of(prefix)
+                out[key]["traffic"] = t
+                out[key]["traffic_over_algorithmic"] = None if t is None else t / out[key]["algorithmic_bytes"]
+                out[key]["traffic_stale"] = stale
+        mf = json.load(open(os.path.join(ROOT, "profiles", "pmc2", "r5_mfma_counters.json")))
+        for key in ("K7 k=p=60", "K7 k=p=64"):
+            if key in out:
+                out[key]["mfma_utilisation_pmc"] = {"value": mf.get("k_gemm_ts_res<8, 16, true> grid=131072", {}).get("mfma_utilisation"),
+                                                    "file": "profiles/pmc2/r5_mfma_counters.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), k = p = 60)",
+                                                    "gemm_hip_digest_then": pj.get("_meta", {}).get("gemm_hip_digest"),
+                                                    "gemm_hip_digest_now": _file_digest(os.path.join(ROOT, "nonlineareigenproblems.jl_amd", "csrc", "gemm.hip"))}
+    except Exception as e:
+        out["pmc_note"] = repr(e)[:200]
     return out
 
 
@@ -838,7 +864,7 @@ def main():
                 # HBM bytes of the two kernels from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
                 # scripts/pmc_collect.sh, 2*FETCH + WRITE per the gfx950 note).  The file names the digest of csrc/orth.hip it
                 # was collected on: a kernel change makes `traffic_stale` true instead of going unnoticed.
-                tfile = next((f for f in (os.path.join(ROOT, "profiles", "pmc2", "r%d_gun_traffic.json" % r_) for r_ in (4, 3, 2))
+                tfile = next((f for f in (os.path.join(ROOT, "profiles", "pmc2", "r%d_gun_traffic.json" % r_) for r_ in (5, 4, 3, 2))
                               if os.path.exists(f)), None)
                 pj = json.load(open(tfile))
                 kb = 0.0

@@ -24,6 +24,8 @@ for k, e in out.items():
         e["mfma_busy_over_sq_busy"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / e["SQ_BUSY_CYCLES"]
     if "SQ_VALU_MFMA_BUSY_CYCLES" in e and e.get("GRBM_GUI_ACTIVE"):
         e["mfma_busy_cycles_per_gpu_cycle"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / e["GRBM_GUI_ACTIVE"]
+        # busy cycles of all 1024 SIMDs against the cycles the launch took (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+        e["mfma_utilisation"] = e["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * e["GRBM_GUI_ACTIVE"] / 8.0)
 json.dump(out, open(os.path.join(d, "mfma_counters.json"), "w"), indent=1)
 for k, e in out.items():
     print(k[:50], {c: (round(v, 3) if v < 100 else int(v)) for c, v in e.items()})
