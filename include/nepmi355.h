@@ -254,6 +254,14 @@ int32_t nep_gemm_ts_dev(const nep_cdouble* dZ, int64_t ldz, int64_t rows, int32_
  * replaces: `V, S, W = svd(A0)` of the n x k moment block in Beyn's method, src/method_beyncontour.jl:114-121, which becomes
  *           svd(R) of the k x k factor (V = Q U_R). */
 int32_t nep_orth_qr_dev(nep_cdouble* dQ, int64_t ldq, int64_t rows, int32_t k, nep_cdouble* d_out, nep_stream stream);
+/* Dense complex inverse on the device (in-place Gauss-Jordan with partial pivoting, deterministic):
+ *   dOut (n x n, column-major, ld ldo) = inv(M + add_identity * I)^H,   M n x n column-major (ld ldm), both on the device.
+ * dWork: 2 n + 2 complex of device scratch.  *h_info = 0, or 1 + the step whose pivot was zero / not finite (the call synchronises
+ * the stream once at its end to read it).
+ * replaces: `inv(M)` of the mm x mm Sylvester-SMW matrix, src/gallery_extra/waveguide/waveguide_preconditioner.jl:221-313 (the
+ *           adjoint of the inverse is what nep_gemv_hd applies). */
+int32_t nep_zinv_h_dev(int32_t n, const nep_cdouble* dM, int64_t ldm, double add_identity, nep_cdouble* dOut, int64_t ldo,
+                       nep_cdouble* dWork, int32_t* h_info, nep_stream stream);
 /* nep_zgemm with the reduction split over `ksplit` workgroups per tile, slices summed in order (deterministic); dWork: ksplit * m * n
  * complex (device).  For products of a few tiles with a long K: the k x k block V0^H A1 of src/method_beyncontour.jl:123. */
 int32_t nep_zgemm_sk(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t k, nep_cdouble alpha,

@@ -89,6 +89,7 @@ SIGNATURES = {
     "nep_resid_split_dev": [c_vp, c_i32, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp],
     "nep_resid_batch_cm_dev": [c_vp, c_i32, c_vp, c_vp, c_i64, c_i64, c_vp, c_vp, c_i64, c_vp],
     "nep_spmm_terms": [c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp],
+    "nep_zinv_h_dev": [c_i32, c_vp, c_i64, c_dbl, c_vp, c_i64, c_vp, P(c_i32), c_vp],
     "nep_orth_qr_dev": [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp],
     "nep_zgemm_sk": [c_i32, c_i32, c_i32, c_i32, c_i32, cdouble, c_vp, c_i64, c_vp, c_i64, cdouble, c_vp, c_i64, c_i32, c_vp, c_vp],
     "nep_zgemm": [c_i32, c_i32, c_i32, c_i32, c_i32, cdouble, c_vp, c_i64, c_vp, c_i64, cdouble, c_vp, c_i64, c_vp],

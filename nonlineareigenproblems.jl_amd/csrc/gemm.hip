@@ -654,6 +654,125 @@ extern "C" int32_t nep_zgemm_ex(int32_t m, int32_t n, int32_t k, nep_cdouble alp
 // C = alpha op(A) op(B) + beta C with the K range split over `ksplit` workgroups per tile (deterministic: the slices are summed in
 // order): products of a few tiles with a long reduction -- the k x k Gram block Q^H A1 of Beyn's method (one 32 x 32 tile, K = n).
 // dWork: ksplit * m * n complex.
+// ---- dense complex inverse on the device: in-place Gauss-Jordan with partial pivoting ------------------------------------------
+// (the mm x mm Sylvester-SMW matrix of the waveguide preconditioner, waveguide_preconditioner.jl:221-313: mm = 1517, 0.14 s of
+// numpy.linalg.inv per tiar run until round 4.)  Column-major A, n steps of two launches:
+//   k_gj_pivot  (one workgroup): p = argmax_{i >= j} |A[i, j]| (ties: smallest i), rows j <-> p, f = column j, column j <- e_j,
+//               row j <- row j / pivot
+//   k_gj_update (grid):          A[i, c] -= f[i] A[j, c]  for i != j
+// and at the end the column exchanges in reverse order.  Deterministic; a zero / non-finite pivot is reported through *info.
+namespace {
+__global__ __launch_bounds__(256) void k_conjt_addi(int n, const cplx* __restrict__ M, int64_t ldm, double add, cplx* __restrict__ out, int64_t ldo) {
+    // out[r, c] = conj(M[c, r]) + add (r == c): 32 x 32 tiles through LDS
+    __shared__ cplx t[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    for (int q = ty; q < 32; q += 8) {            // read M[c0 + tx, r0 + q]  (row index fast)
+        const int rr = c0 + tx, cc = r0 + q;
+        t[q][tx] = (rr < n && cc < n) ? M[rr + (int64_t)cc * ldm] : cmake(0.0, 0.0);
+    }
+    __syncthreads();
+    for (int q = ty; q < 32; q += 8) {            // write out[r0 + tx, c0 + q] = conj(M[c0 + q, r0 + tx]) = conj(t[tx][q])
+        const int r = r0 + tx, c = c0 + q;
+        if (r < n && c < n) { cplx v = t[tx][q]; out[r + (int64_t)c * ldo] = cmake(v.x + (r == c ? add : 0.0), -v.y); }
+    }
+}
+__global__ __launch_bounds__(1024) void k_gj_pivot(int n, int j, cplx* __restrict__ A, int64_t lda, cplx* __restrict__ f, int* __restrict__ piv,
+                                                   int* __restrict__ info) {
+    __shared__ double sv[16]; __shared__ int si[16]; __shared__ int sp;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double best = -1.0; int bi = n;
+    for (int i = j + tid; i < n; i += 1024) {
+        const cplx a = A[i + (int64_t)j * lda];
+        const double m = a.x * a.x + a.y * a.y;
+        if (m > best || (m == best && i < bi)) { best = m; bi = i; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        const double ob = __shfl_xor(best, off, 64); const int oi = __shfl_xor(bi, off, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { sv[wv] = best; si[wv] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        double b = sv[0]; int ix = si[0];
+        for (int q = 1; q < 16; ++q) if (sv[q] > b || (sv[q] == b && si[q] < ix)) { b = sv[q]; ix = si[q]; }
+        if (!(b > 0.0) || !isfinite(b)) { if (*info == 0) *info = j + 1; ix = j; }
+        sp = ix; piv[j] = ix;
+    }
+    __syncthreads();
+    const int p = sp;
+    if (p != j)
+        for (int c = tid; c < n; c += 1024) {
+            const cplx a = A[j + (int64_t)c * lda], b = A[p + (int64_t)c * lda];
+            A[j + (int64_t)c * lda] = b; A[p + (int64_t)c * lda] = a;
+        }
+    __syncthreads();
+    const cplx pv = A[j + (int64_t)j * lda];
+    const double den = pv.x * pv.x + pv.y * pv.y;
+    const cplx inv = den > 0.0 ? cmake(pv.x / den, -pv.y / den) : cmake(0.0, 0.0);
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {                    // f = column j (0 at the pivot row), column j <- e_j
+        const cplx a = A[i + (int64_t)j * lda];
+        f[i] = i == j ? cmake(0.0, 0.0) : a;
+        A[i + (int64_t)j * lda] = i == j ? cmake(1.0, 0.0) : cmake(0.0, 0.0);
+    }
+    __syncthreads();
+    for (int c = tid; c < n; c += 1024) A[j + (int64_t)c * lda] = cmul(A[j + (int64_t)c * lda], inv);
+}
+__global__ __launch_bounds__(256) void k_gj_update(int n, int j, cplx* __restrict__ A, int64_t lda, const cplx* __restrict__ f) {
+    // thread = row i of a 256-row strip, workgroup y = a group of 8 columns
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int c0 = blockIdx.y * 8;
+    if (i >= n || i == j) return;
+    const cplx fi = f[i];
+    if (fi.x == 0.0 && fi.y == 0.0) return;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int c = c0 + q;
+        if (c < n) {
+            const cplx r = A[j + (int64_t)c * lda];
+            cplx a = A[i + (int64_t)c * lda];
+            a.x -= fi.x * r.x - fi.y * r.y; a.y -= fi.x * r.y + fi.y * r.x;
+            A[i + (int64_t)c * lda] = a;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_gj_unpermute(int n, cplx* __restrict__ A, int64_t lda, const int* __restrict__ piv) {
+    const int i = blockIdx.x * 256 + threadIdx.x;           // row i: the column exchanges of the pivoting, last first
+    if (i >= n) return;
+    for (int j = n - 1; j >= 0; --j) {
+        const int p = piv[j];
+        if (p != j) { const cplx a = A[i + (int64_t)j * lda], b = A[i + (int64_t)p * lda]; A[i + (int64_t)j * lda] = b; A[i + (int64_t)p * lda] = a; }
+    }
+}
+}  // namespace
+// dOut (n x n, column-major, ld ldo) = inv(M + add_identity I)^H  = inv((M + add_identity I)^H), M n x n column-major (ld ldm) on the
+// device; dWork: n complex + (n + 1) int32 of device scratch ((n + 1) complex + ... : 2 n + 2 complex is enough).  *h_info = 0, or
+// 1 + the step whose pivot was zero / not finite (host value: the call synchronises the stream once at its end).
+extern "C" int32_t nep_zinv_h_dev(int32_t n, const nep_cdouble* dM, int64_t ldm, double add_identity, nep_cdouble* dOut, int64_t ldo,
+                                  nep_cdouble* dWork, int32_t* h_info, nep_stream stream) {
+    ARGCHK(dM && dOut && dWork && h_info && n >= 1 && ldm >= n && ldo >= n);
+    hipStream_t st = as_stream(stream);
+    cplx* f = (cplx*)dWork; int* piv = (int*)(f + n); int* info = piv + n;
+    HIPCHK(hipMemsetAsync(info, 0, sizeof(int), st));
+    hipLaunchKernelGGL(k_conjt_addi, dim3((unsigned)((n + 31) / 32), (unsigned)((n + 31) / 32)), dim3(256), 0, st, (int)n, (const cplx*)dM, ldm,
+                       add_identity, (cplx*)dOut, ldo);
+    LAUNCHCHK();
+    const dim3 gu((unsigned)((n + 255) / 256), (unsigned)((n + 7) / 8));
+    for (int j = 0; j < n; ++j) {
+        hipLaunchKernelGGL(k_gj_pivot, dim3(1), dim3(1024), 0, st, (int)n, j, (cplx*)dOut, ldo, f, piv, info);
+        hipLaunchKernelGGL(k_gj_update, gu, dim3(256), 0, st, (int)n, j, (cplx*)dOut, ldo, (const cplx*)f);
+    }
+    LAUNCHCHK();
+    hipLaunchKernelGGL(k_gj_unpermute, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (int)n, (cplx*)dOut, ldo, (const int*)piv);
+    LAUNCHCHK();
+    int hi = 0;
+    HIPCHK(hipMemcpyAsync(&hi, info, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    *h_info = hi;
+    return NEP_OK;
+}
+
 extern "C" int32_t nep_zgemm_sk(int32_t transa, int32_t transb, int32_t m, int32_t n, int32_t k, nep_cdouble alpha,
                                 const nep_cdouble* dA, int64_t lda, const nep_cdouble* dB, int64_t ldb, nep_cdouble beta,
                                 nep_cdouble* dC, int64_t ldc, int32_t ksplit, nep_cdouble* dWork, nep_stream stream) {

@@ -18,6 +18,7 @@ costs less than a mixed-radix FFT would save.  The
 region sums / expansions of the SMW correction are products with 0/1 indicator matrices (small GEMMs), the mm x mm SMW
 matrix is inverted once on the host and applied as a GEMV, so one preconditioner application never synchronises.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -483,8 +484,7 @@ class WEPPreconditioner:
                 work = torch.empty(nz * nx + 4 * nz + mm, dtype=CDT, device="cuda")
                 check(lib.nep_wep_smw_matrix(self.sylv, plan, N, _p(self.Ksc), self.dd1, self.dd2, _p(self.ops.sinv), _p(work), _p(Mdev),
                                              stream_ptr()))
-            self._M = to_host(Mdev) + np.eye(mm)
-            self.MinvH = to_dev(np.linalg.inv(self._M).conj().T)
+            self._set_inverse(Mdev, mm)
             return
         unit = torch.zeros((N + 4, N), dtype=CDT, device="cuda").reshape(-1)
         one = torch.ones(1, dtype=CDT, device="cuda")
@@ -494,8 +494,30 @@ class WEPPreconditioner:
             self.expand(unit, self.Y)
             self.linv(self.Y)
             self.functionals(self.Y, Mdev[kappa])
-        self._M = to_host(Mdev) + np.eye(mm)
-        self.MinvH = to_dev(np.linalg.inv(self._M).conj().T)     # alpha = (Minv^H)^H f through nep_gemv_hd
+        self._set_inverse(Mdev, mm)
+
+    def _set_inverse(self, Mdev, mm):
+        """MinvH = inv(I + M)^H (alpha = (MinvH)^H f through nep_gemv_hd).  On the device by the library's Gauss-Jordan inverse
+        (nep_zinv_h_dev: 2 launches per column; 1517 x 1517 in ~35 ms against 0.14 s of numpy.linalg.inv on 8 BLAS threads + two
+        36 MB transfers); NEP_WEP_SMW_INV=host keeps the host route, which is also the fallback for a zero pivot."""
+        self._Mdev = Mdev
+        self._M_host = None
+        if os.environ.get("NEP_WEP_SMW_INV", "dev") != "host":
+            out = torch.empty((mm, mm), dtype=CDT, device="cuda")
+            work = torch.empty(2 * mm + 2, dtype=CDT, device="cuda")
+            info = C.c_int32(0)
+            check(lib.nep_zinv_h_dev(mm, _p(Mdev), mm, 1.0, _p(out), mm, _p(work), C.byref(info), stream_ptr()))
+            if info.value == 0:
+                self.MinvH = out
+                return
+        self._M_host = to_host(Mdev) + np.eye(mm)
+        self.MinvH = to_dev(np.linalg.inv(self._M_host).conj().T)
+
+    @property
+    def _M(self):
+        if self._M_host is None:
+            self._M_host = to_host(self._Mdev) + np.eye(self._Mdev.shape[0])
+        return self._M_host
 
     @property
     def cond(self):

@@ -1228,6 +1228,51 @@ def test_resid_batch_column_major_tiled(na, case):
         assert np.array_equal(o2.cpu().numpy(), oh)                              # deterministic
 
 
+@pytest.mark.parametrize("n", [1, 5, 64, 257, 1000])
+def test_dense_inverse_gauss_jordan_on_the_device(na, n):
+    """nep_zinv_h_dev: inv(M + I)^H by in-place Gauss-Jordan with partial pivoting (the Sylvester-SMW matrix of the waveguide
+    preconditioner) against numpy.linalg.inv: a matrix that NEEDS the pivoting (tiny diagonal), leading dimensions larger than n, the
+    singular case reported through info, bitwise repeatable"""
+    import ctypes as C
+    import torch
+    from nep_amd._lib import lib, check, c_vp
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+    M[np.arange(n), np.arange(n)] = 1e-9 - 1.0              # M + I has a tiny diagonal: unpivoted elimination would lose everything
+    ld = n + 3
+    Md = torch.zeros((n, ld), dtype=torch.complex128, device="cuda")          # column-major, ld > n
+    Md[:, :n] = torch.from_numpy(np.ascontiguousarray(M.T)).to("cuda")
+    outs = []
+    for _ in range(2):
+        out = torch.zeros((n, ld), dtype=torch.complex128, device="cuda")
+        work = torch.empty(2 * n + 2, dtype=torch.complex128, device="cuda")
+        info = C.c_int32(-1)
+        check(lib.nep_zinv_h_dev(n, c_vp(Md.data_ptr()), ld, 1.0, c_vp(out.data_ptr()), ld, c_vp(work.data_ptr()), C.byref(info), None))
+        assert info.value == 0
+        outs.append(out.cpu().numpy()[:, :n].T)             # out[c, r] = X[r, c]
+    ref = np.linalg.inv(M + np.eye(n)).conj().T
+    assert np.linalg.norm(outs[0] - ref) <= 1e-10 * np.linalg.norm(ref) * max(1.0, np.linalg.cond(M + np.eye(n)) * 1e-3)
+    assert np.array_equal(outs[0], outs[1])
+    if n >= 5:                                               # singular: M + I with two equal rows, and with a zero column
+        for kind in ("rows", "column"):
+            A = rng.standard_normal((n, n)) + 1j * rng.standard_normal((n, n))
+            if kind == "rows":
+                A[3] = A[1]
+            else:
+                A[:, 2] = 0.0
+            S = A - np.eye(n)
+            Sd = torch.from_numpy(np.ascontiguousarray(S.T)).to("cuda").contiguous()
+            out = torch.zeros((n, n), dtype=torch.complex128, device="cuda")
+            work = torch.empty(2 * n + 2, dtype=torch.complex128, device="cuda")
+            info = C.c_int32(0)
+            check(lib.nep_zinv_h_dev(n, c_vp(Sd.data_ptr()), n, 1.0, c_vp(out.data_ptr()), n, c_vp(work.data_ptr()), C.byref(info), None))
+            oh = out.cpu().numpy()
+            if kind == "column":                                 # (a zero column of M + I = a zero ROW of the adjoint that is inverted:
+                assert info.value == n                           #  the search avoids it until the last step)
+            else:                                                # rounding leaves a pivot of ~1e-16 instead of 0: reported or visible
+                assert info.value != 0 or not np.isfinite(oh).all() or np.abs(oh).max() > 1e8
+
+
 @pytest.mark.parametrize("case", ["wep", "gun", "wep_small_patch"])
 def test_resid_batch_super_panel_kernel(na, case, monkeypatch):
     """K2 in super-panels (k_tile_resid_sp: one workgroup per block, the row's entries in registers, 4-column footprint tiles filled by
