@@ -177,6 +177,39 @@ def test_iar_fused_finish_and_coefficient_product_is_bit_identical(na, monkeypat
                 assert 0.9 < x / y < 1.1
 
 
+def test_two_concurrent_iar_calls_on_one_gpu(na):
+    """two host threads run iar at the same time on their own NEP objects (one GPU, one eig stream, one check stream): the scratch
+    of the device eigen-decompositions is checked out per call (two launches of a batch share it -- with a process-wide block call
+    A's inverse iteration could run on call B's matrices, status words clean), so every result equals the single-threaded one"""
+    import threading
+    import torch
+    n, m = 2000, 40
+    neps = [na.nep_gallery("gun_spmf_scaled", n) for _ in range(2)]
+    kw = dict(sigma=0.0, gamma=1.0, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10)
+    ref = np.sort_complex(np.asarray(na.iar(neps[0], **kw)[0]))
+    na.iar(neps[1], **kw)
+    bad = []
+
+    def work(nep):
+        torch.cuda.set_device(0)
+        for _ in range(6):
+            try:
+                lam = np.sort_complex(np.asarray(na.iar(nep, **kw)[0]))
+                if len(lam) != len(ref) or np.abs(lam - ref).max() > 1e-9 * np.abs(ref).max():
+                    bad.append("differs")
+            except Exception as e:      # noqa: BLE001
+                bad.append(repr(e)[:200])
+    th = [threading.Thread(target=work, args=(neps[i],)) for i in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not bad, bad
+    import sys as _sys
+    pool = _sys.modules["nep_amd.iar"]._EIG_WORK.get(torch.cuda.current_device(), [])
+    assert len(pool) <= 2                                   # idle blocks kept per device: bounded
+
+
 def test_iar_device_eig_failure_falls_back_to_lapack(na, monkeypatch):
     """a decomposition that reports a failure (forced here for one step: the QR status word of step 23, the inverse-iteration
     status word of step 31) is redone by LAPACK on the host and the run returns what the all-device run returns"""
