@@ -527,7 +527,7 @@ def wep_scale_roofline(na):
             if key in out:
                 out[key]["mfma_utilisation_pmc"] = {"value": mf.get("k_gemm_ts_res<8, 16, true> grid=131072", {}).get("mfma_utilisation"),
                                                     "file": "profiles/pmc2/r5_mfma_counters.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), k = p = 60)",
-                                                    "gemm_hip_digest_then": pj.get("_meta", {}).get("gemm_hip_digest"),
+                                                    "gemm_hip_digest_then": mf.get("_meta", {}).get("gemm_hip_digest"),
                                                     "gemm_hip_digest_now": _file_digest(os.path.join(ROOT, "nonlineareigenproblems.jl_amd", "csrc", "gemm.hip"))}
     except Exception as e:
         out["pmc_note"] = repr(e)[:200]
