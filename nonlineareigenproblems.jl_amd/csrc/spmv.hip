@@ -1236,7 +1236,9 @@ int32_t nep_resid_batch_cm_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, co
     rc = s->part.ensure((size_t)grid * 2 * k * sizeof(double));
     if (rc) return rc;
     double* partial = (double*)s->part.dptr;
-    if (use_sp_k2(s, k))
+    // (up to two panels the older kernel -- many short-lived workgroups per CU -- hides a block's start-up better: 69 against 77 us at k = 8)
+    static const int sp_cm_kmin = getenv("NEP_K2_SP_CM_KMIN") ? atoi(getenv("NEP_K2_SP_CM_KMIN")) : 9;
+    if (use_sp_k2(s, k) && (k >= sp_cm_kmin || g_k2_sp_mode == 2))
         rc = nep_tiles_resid_sp(s->tiles, k, (const cplx*)s->coef.dptr, (const cplx*)dQ, ldq, 1, (cplx*)dR_tail, ldt, partial, row0 < 0 ? -1 : row0, st);
     else
         rc = nep_tiles_resid_cm(s->tiles, k, (const cplx*)s->coef.dptr, (const cplx*)dQ, ldq, (cplx*)dR_tail, ldt, partial, row0 < 0 ? -1 : row0, st);

@@ -527,6 +527,24 @@ __device__ __forceinline__ double sp_wave_reduce8(const double v[8], int lane) {
 // flushed into the residual with the term's coefficient -- 2 FMA per (entry, column) instead of the 2 x m_t + selects of per-term
 // accumulators picked by a per-lane mask (measured: the masked form ran VALU-bound at 0.55 ms for k = 60, slower than the kernel
 // it was to replace).
+// Where a footprint value lives in a tile, by layout of the Ritz block:
+//   column-major Q  tile[c][f]              -- a DMA instruction = 64 consecutive slots of ONE panel column (64 consecutive rows of the
+//                                              block's column: 1 KB contiguous); a wave's tile read = 64 consecutive 16-byte slots
+//   row-major Q     tile[f][c ^ g(f)], g(f) = (f >> 1) & 3
+//                                           -- a DMA instruction = 16 consecutive slots x the panel's 4 columns (16 rows of the block,
+//                                              64 contiguous bytes each: a quarter of the requests of a one-column gather); the
+//                                              exchange of columns inside a slot's 64 bytes makes 8 consecutive slots of one column
+//                                              fall into 8 different 16-byte bank groups: a wave's tile read is conflict-free too
+template <bool CM, int NTHR> struct SpMap {
+    static constexpr int fpad = SP_FPAD(NTHR);
+    static constexpr int NI = SP_PSW * (fpad >> 6);                                    // DMA instructions per panel (either layout)
+    __device__ __forceinline__ static int slot(int i, int lane) { return CM ? (i >> 2) * 64 + lane : i * 16 + (lane >> 2); }
+    __device__ __forceinline__ static int col(int i, int lane, int f) { return CM ? (i & 3) : ((lane & 3) ^ ((f >> 1) & 3)); }
+    __device__ __forceinline__ static size_t dst(int i) { return CM ? (size_t)(i & 3) * fpad + (size_t)(i >> 2) * 64 : (size_t)i * 64; }
+    __device__ __forceinline__ static bool lists(int i, int lane) { return CM ? (i & 3) == 0 : (lane & 3) == 0; }
+    __device__ __forceinline__ static uint32_t entry_off(uint32_t loc) { return CM ? loc * 16u : loc * 64u + ((loc >> 1) & 3u) * 16u; }   // bytes, < 2^16
+    __device__ __forceinline__ static size_t elem(int f, int c) { return CM ? (size_t)c * fpad + f : (size_t)f * 4 + (c ^ ((f >> 1) & 3)); }
+};
 // one panel (4 columns in `tile`) against the thread's row: residual entries, their squares, the optional store, |q|^2 of the block's
 // own columns, and the 8 wave sums into ws[wv][0..8)
 template <typename VT, bool CM, int NTHR, int FM>
@@ -550,12 +568,12 @@ __device__ __forceinline__ void sp_panel(const cplx* __restrict__ tile, const ui
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint32_t o16 = (j & 1) ? (pid2[j >> 1] >> 16) : (pid2[j >> 1] & 0xffffu);      // byte offset of the entry's footprint slot
-            const cplx* tp = (const cplx*)((const char*)(tile + (size_t)(2 * h) * fpad) + o16);
+            const uint32_t o16 = (j & 1) ? (pid2[j >> 1] >> 16) : (pid2[j >> 1] & 0xffffu);      // SpMap::entry_off of the entry's footprint slot
             const bool first = j == 0 || ((FM >> (j - 1)) & 1);          // first slot of its term: the accumulators start over
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const cplx q = tp[(size_t)s * fpad];
+                const cplx q = CM ? *(const cplx*)((const char*)(tile + (size_t)(2 * h + s) * fpad) + o16)
+                                  : *(const cplx*)((const char*)tile + (o16 ^ (uint32_t)((2 * h + s) * 16)));
                 if (first) acc[s] = cscale(pv[j], q); else cfma(acc[s], pv[j], q);
             }
             if ((FM >> j) & 1) {                                          // last slot of its term (compile time)
@@ -584,7 +602,7 @@ __device__ __forceinline__ void sp_panel(const cplx* __restrict__ tile, const ui
         for (int f = tid; f < Fn; f += NTHR) {
             if (fpl[f] & TILE_OWN) {
 #pragma unroll
-                for (int s = 0; s < PSW; ++s) { const cplx q = tile[(size_t)s * fpad + f]; red[PSW + s] = fma(q.x, q.x, fma(q.y, q.y, red[PSW + s])); }
+                for (int s = 0; s < PSW; ++s) { const cplx q = tile[SpMap<CM, NTHR>::elem(f, s)]; red[PSW + s] = fma(q.x, q.x, fma(q.y, q.y, red[PSW + s])); }
             }
         }
         const double sum = sp_wave_reduce8(red, lane);
@@ -604,7 +622,7 @@ __device__ __forceinline__ void sp_entries_load(const uint16_t* __restrict__ ib,
         pv[j] = tload<true>(vb + e);
     }
 }
-template <typename VT>
+template <typename VT, bool CM, int NTHR>
 __device__ __forceinline__ void sp_entries_pack(const uint32_t (&nid)[8], const VT (&npv)[8], int rb, int width, int tid, uint32_t lmask,
                                                 uint32_t (&pid2)[4], VT (&pv)[8]) {
 #pragma unroll
@@ -612,14 +630,14 @@ __device__ __forceinline__ void sp_entries_pack(const uint32_t (&nid)[8], const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const bool on = tid < rb && j < width;
-        uint32_t o = ((uint32_t)nid[j] & lmask) * 16u;
+        uint32_t o = SpMap<CM, NTHR>::entry_off((uint32_t)nid[j] & lmask);
         pv[j] = npv[j];
         if (!on) { o = 0; if constexpr (sizeof(VT) == 8) pv[j] = 0.0; else pv[j] = cmake(0.0, 0.0); }
         pid2[j >> 1] |= o << (16 * (j & 1));
     }
 }
 // the row's entries of a block (local footprint BYTE offsets, two per register; the term is the slot's) -- once per block
-template <typename VT>
+template <typename VT, bool CM, int NTHR>
 __device__ __forceinline__ void sp_entries(const uint16_t* __restrict__ ib, const VT* __restrict__ vb, int rb, int width, int tid,
                                            uint32_t lmask, uint32_t (&pid2)[4], VT (&pv)[8]) {
 #pragma unroll
@@ -628,7 +646,7 @@ __device__ __forceinline__ void sp_entries(const uint16_t* __restrict__ ib, cons
     for (int j = 0; j < 8; ++j) {
         const bool on = tid < rb && j < width;
         const int64_t e = on ? (int64_t)j * rb + tid : 0;
-        uint32_t o = ((uint32_t)__builtin_nontemporal_load(ib + e) & lmask) * 16u;
+        uint32_t o = SpMap<CM, NTHR>::entry_off((uint32_t)__builtin_nontemporal_load(ib + e) & lmask);
         pv[j] = tload<true>(vb + e);
         if (!on) { o = 0; if constexpr (sizeof(VT) == 8) pv[j] = 0.0; else pv[j] = cmake(0.0, 0.0); }
         pid2[j >> 1] |= o << (16 * (j & 1));
@@ -671,10 +689,11 @@ __global__ __launch_bounds__(NTHR) void k_tile_resid_sp(const TileDesc* __restri
         for (int t = 0; t < SP_IMAX; ++t) {
             const int i = wv + t * NW;
             if (i < NI) {                                      // wave-uniform
-                const int c = i & 3;
+                const int f = SpMap<CM, NTHR>::slot(i, lane);
+                const int c = SpMap<CM, NTHR>::col(i, lane, f);
                 const int cc = p * PSW + c < k ? p * PSW + c : k - 1;
-                const int64_t col = (int64_t)(fpl[(i >> 2) * 64 + lane] & NEP_COL_MASK);
-                sp_dma16(Q + (CM ? col + (int64_t)cc * ldq : col * ldq + cc), Qt + ((size_t)(buf * PSW + c) * fpad + (size_t)(i >> 2) * 64));
+                const int64_t col = (int64_t)(fpl[f] & NEP_COL_MASK);
+                sp_dma16(Q + (CM ? col + (int64_t)cc * ldq : col * ldq + cc), Qt + ((size_t)(buf * PSW) * fpad + SpMap<CM, NTHR>::dst(i)));
             }
         }
     };
@@ -685,28 +704,29 @@ __global__ __launch_bounds__(NTHR) void k_tile_resid_sp(const TileDesc* __restri
 #pragma unroll
         for (int t = 0; t < SP_IMAX; ++t) {
             const int i = wv + t * NW;
-            const int f = (i >> 2) * 64 + lane;
-            raw[t] = fpb[(i < NI && f < Fn) ? f : Fn - 1];
+            const int f = SpMap<CM, NTHR>::slot(i < NI ? i : 0, lane);
+            raw[t] = fpb[f < Fn ? f : Fn - 1];
         }
 #pragma unroll
         for (int t = 0; t < SP_IMAX; ++t) {
             const int i = wv + t * NW;
             if (i < NI) {
-                const int c = i & 3;
-                if (c == 0) fpl[(i >> 2) * 64 + lane] = raw[t];          // every footprint slot exactly once (the c = 0 instruction of its chunk)
+                const int f = SpMap<CM, NTHR>::slot(i, lane);
+                const int c = SpMap<CM, NTHR>::col(i, lane, f);
+                if (SpMap<CM, NTHR>::lists(i, lane)) fpl[f] = raw[t];          // every footprint slot exactly once
                 const int64_t col = (int64_t)(raw[t] & NEP_COL_MASK);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     if (p < np) {
                         const int cc = p * PSW + c < k ? p * PSW + c : k - 1;
-                        sp_dma16(Q + (CM ? col + (int64_t)cc * ldq : col * ldq + cc), Qt + ((size_t)(p * PSW + c) * fpad + (size_t)(i >> 2) * 64));
+                        sp_dma16(Q + (CM ? col + (int64_t)cc * ldq : col * ldq + cc), Qt + ((size_t)(p * PSW) * fpad + SpMap<CM, NTHR>::dst(i)));
                     }
                 }
             }
         }
     }
     uint32_t pid2[4]; VT pv[8];
-    sp_entries<VT>(ib, vb, rb, width, tid, lmask, pid2, pv);
+    sp_entries<VT, CM, NTHR>(ib, vb, rb, width, tid, lmask, pid2, pv);
     const int li = tid / d.zp, ljz = tid - li * d.zp;
     const int64_t row = (int64_t)d.r0 + (int64_t)li * d.stride + ljz;
     const bool rowon = tid < d.nrows;
@@ -780,10 +800,11 @@ __global__ __launch_bounds__(NTHR) void k_tile_resid_spp(const TileDesc* __restr
         for (int t = 0; t < SP_IMAX; ++t) {
             const int i = wv + t * NW;
             if (i < NI) {                                      // wave-uniform
-                const int c = i & 3;
+                const int f = SpMap<CM, NTHR>::slot(i, lane);
+                const int c = SpMap<CM, NTHR>::col(i, lane, f);
                 const int cc = p * PSW + c < k ? p * PSW + c : k - 1;
-                const int64_t col = (int64_t)(fl[(i >> 2) * 64 + lane] & NEP_COL_MASK);
-                sp_dma16(Q + (CM ? col + (int64_t)cc * ldq : col * ldq + cc), Qt + ((size_t)(buf * PSW + c) * fpad + (size_t)(i >> 2) * 64));
+                const int64_t col = (int64_t)(fl[f] & NEP_COL_MASK);
+                sp_dma16(Q + (CM ? col + (int64_t)cc * ldq : col * ldq + cc), Qt + ((size_t)(buf * PSW) * fpad + SpMap<CM, NTHR>::dst(i)));
             }
         }
     };
@@ -796,26 +817,27 @@ __global__ __launch_bounds__(NTHR) void k_tile_resid_spp(const TileDesc* __restr
 #pragma unroll
         for (int t = 0; t < SP_IMAX; ++t) {
             const int i = wv + t * NW;
-            const int f = (i >> 2) * 64 + lane;
-            raw[t] = fpb[(i < NI && f < d.fp_cnt) ? f : d.fp_cnt - 1];
+            const int f = SpMap<CM, NTHR>::slot(i < NI ? i : 0, lane);
+            raw[t] = fpb[f < d.fp_cnt ? f : d.fp_cnt - 1];
         }
 #pragma unroll
         for (int t = 0; t < SP_IMAX; ++t) {
             const int i = wv + t * NW;
             if (i < NI) {
-                const int c = i & 3;
-                if (c == 0) fplb[(i >> 2) * 64 + lane] = raw[t];
+                const int f = SpMap<CM, NTHR>::slot(i, lane);
+                const int c = SpMap<CM, NTHR>::col(i, lane, f);
+                if (SpMap<CM, NTHR>::lists(i, lane)) fplb[f] = raw[t];
                 const int64_t col = (int64_t)(raw[t] & NEP_COL_MASK);
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const int cc = p * PSW + c < k ? p * PSW + c : k - 1;
-                    sp_dma16(Q + (CM ? col + (int64_t)cc * ldq : col * ldq + cc), Qt + ((size_t)(p * PSW + c) * fpad + (size_t)(i >> 2) * 64));
+                    sp_dma16(Q + (CM ? col + (int64_t)cc * ldq : col * ldq + cc), Qt + ((size_t)(p * PSW) * fpad + SpMap<CM, NTHR>::dst(i)));
                 }
             }
         }
     }
     uint32_t pid2[4]; VT pv[8];
-    sp_entries<VT>(eidx + (int64_t)d.ent_off64 * 64, eval + (int64_t)d.ent_off64 * 64, d.wrb >> 16, d.wrb & 0xffff, tid, lmask, pid2, pv);
+    sp_entries<VT, CM, NTHR>(eidx + (int64_t)d.ent_off64 * 64, eval + (int64_t)d.ent_off64 * 64, d.wrb >> 16, d.wrb & 0xffff, tid, lmask, pid2, pv);
     int li = tid / d.zp;
     int64_t row = (int64_t)d.r0 + (int64_t)li * d.stride + (tid - li * d.zp);
     bool rowon = tid < d.nrows;
@@ -861,7 +883,7 @@ __global__ __launch_bounds__(NTHR) void k_tile_resid_spp(const TileDesc* __restr
             pblk = cblk; pp0 = p0;
         }
         if (have_next) {                               // the next block becomes the current one
-            sp_entries_pack<VT>(nid, npv, dn.wrb >> 16, dn.wrb & 0xffff, tid, lmask, pid2, pv);
+            sp_entries_pack<VT, CM, NTHR>(nid, npv, dn.wrb >> 16, dn.wrb & 0xffff, tid, lmask, pid2, pv);
             d = dn; cblk = nblk_id;
             li = tid / d.zp;
             row = (int64_t)d.r0 + (int64_t)li * d.stride + (tid - li * d.zp);
@@ -1297,7 +1319,7 @@ int nep_tiles_resid_sp(const NepTiles* t, int k, const cplx* dF, const cplx* Q, 
     const size_t shm = sp_shmem(t, nthr) + (size_t)SP_FPAD(nthr) * 4;          // (+ the second footprint list of the persistent form)
     static const int swz = env_int("NEP_XCD_SWIZZLE", 1);
     // persistent form (k_tile_resid_spp) from two panels on: one workgroup per CU (the tiles leave room for one), a multiple of 8
-    static const int persist = env_int("NEP_K2_SP_PERSIST", 1);
+    static const int persist = env_int("NEP_K2_SP_PERSIST", 0);
     static int ncu = 0;
     if (!ncu) {
         int dev = 0; hipDeviceProp_t pr;
@@ -1307,7 +1329,10 @@ int nep_tiles_resid_sp(const NepTiles* t, int k, const cplx* dF, const cplx* Q, 
     }
     // measured at n = 1e6 (kernel time, rocprofv3): k = 8 persistent 58.6 us / one block per workgroup 64.6 us (the old kernel: 59.4);
     // k = 60 320 / 297 us (450): with many panels per block the start-up is a small part, and the hardware's own dispatch of one
-    // workgroup per free CU balances the tail better than the static walk.  NEP_K2_SP_PERSIST = 0 never, 2 always (k > 4)
+    // workgroup per free CU balances the tail better than the static walk.  With the second register set of the next block's
+    // entries the persistent form sits at the 168-VGPR budget of a 768-thread workgroup and spills since the row-major tile layout
+    // added its address arithmetic (84.7 against 70 us per launch at k = 8): OPT-IN.  NEP_K2_SP_PERSIST = 0 (default) never,
+    // 1 for 4 < k <= 12, 2 always (k > 4)
     const bool pers = k > SP_PSW && (persist == 2 || (persist == 1 && k <= 3 * SP_PSW));
     const int pgrid = std::min(ncu, (t->nblk + 7) / 8 * 8);
     // flush mask of the slot layout: bit j = slot j is the last of its term
