@@ -530,7 +530,7 @@ __device__ __forceinline__ double sp_wave_reduce8(const double v[8], int lane) {
 // Where a footprint value lives in a tile, by layout of the Ritz block:
 //   column-major Q  tile[c][f]              -- a DMA instruction = 64 consecutive slots of ONE panel column (64 consecutive rows of the
 //                                              block's column: 1 KB contiguous); a wave's tile read = 64 consecutive 16-byte slots
-//   row-major Q     tile[f][c ^ g(f)], g(f) = (f >> 1) & 3
+//   row-major Q     tile[f][c ^ g(f)], g(f) from bits 1..3 of f (see SpMap::g)
 //                                           -- a DMA instruction = 16 consecutive slots x the panel's 4 columns (16 rows of the block,
 //                                              64 contiguous bytes each: a quarter of the requests of a one-column gather); the
 //                                              exchange of columns inside a slot's 64 bytes makes 8 consecutive slots of one column
@@ -539,11 +539,12 @@ template <bool CM, int NTHR> struct SpMap {
     static constexpr int fpad = SP_FPAD(NTHR);
     static constexpr int NI = SP_PSW * (fpad >> 6);                                    // DMA instructions per panel (either layout)
     __device__ __forceinline__ static int slot(int i, int lane) { return CM ? (i >> 2) * 64 + lane : i * 16 + (lane >> 2); }
-    __device__ __forceinline__ static int col(int i, int lane, int f) { return CM ? (i & 3) : ((lane & 3) ^ ((f >> 1) & 3)); }
+    __device__ __forceinline__ static int g(int f) { return (((f >> 1) ^ (f >> 3)) & 1) | (((f >> 2) & 1) << 1); }
+    __device__ __forceinline__ static int col(int i, int lane, int f) { return CM ? (i & 3) : ((lane & 3) ^ g(f)); }
     __device__ __forceinline__ static size_t dst(int i) { return CM ? (size_t)(i & 3) * fpad + (size_t)(i >> 2) * 64 : (size_t)i * 64; }
     __device__ __forceinline__ static bool lists(int i, int lane) { return CM ? (i & 3) == 0 : (lane & 3) == 0; }
-    __device__ __forceinline__ static uint32_t entry_off(uint32_t loc) { return CM ? loc * 16u : loc * 64u + ((loc >> 1) & 3u) * 16u; }   // bytes, < 2^16
-    __device__ __forceinline__ static size_t elem(int f, int c) { return CM ? (size_t)c * fpad + f : (size_t)f * 4 + (c ^ ((f >> 1) & 3)); }
+    __device__ __forceinline__ static uint32_t entry_off(uint32_t loc) { return CM ? loc * 16u : loc * 64u + (uint32_t)g((int)loc) * 16u; }   // bytes, < 2^16
+    __device__ __forceinline__ static size_t elem(int f, int c) { return CM ? (size_t)c * fpad + f : (size_t)f * 4 + (c ^ g(f)); }
 };
 // one panel (4 columns in `tile`) against the thread's row: residual entries, their squares, the optional store, |q|^2 of the block's
 // own columns, and the 8 wave sums into ws[wv][0..8)
