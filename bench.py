@@ -512,13 +512,19 @@ def wep_scale_roofline(na):
         cur = _file_digest(os.path.join(ROOT, "nonlineareigenproblems.jl_amd", "csrc", "spmv_tile.hip"))
         stale = bool(pj.get("_meta", {}).get("spmv_tile_hip_digest") != cur)
 
-        def traffic_of(prefix):
-            v = [d["hbm_MB_per_launch"] * 1024.0 * 1024.0 for name, d in pj.items() if name.startswith(prefix) and isinstance(d, dict) and "hbm_MB_per_launch" in d]
-            return max(v) if v else None
-        for key, prefix in (("K2 k=8", "k_tile_resid_spp<double, false"), ("K2 k=60", "k_tile_resid_sp<double, false"),
-                            ("K2 column-major k=8", "k_tile_resid_spp<double, true"), ("K2 column-major k=60", "k_tile_resid_sp<double, true")):
+        def traffic_of(prefix, alg):
+            # the launches of that kernel whose traffic lies within a factor 2 of this row's algorithmic bytes (one kernel name serves
+            # k = 8 and k = 60): their median
+            v = []
+            for name, d in pj.items():
+                if name.startswith(prefix) and isinstance(d, dict):
+                    v += [x * 1024.0 * 1024.0 for x in d.get("hbm_MB_launches", [d.get("hbm_MB_per_launch", 0.0)])]
+            v = sorted(x for x in v if 0.5 * alg <= x <= 2.0 * alg)
+            return v[len(v) // 2] if v else None
+        for key, prefix in (("K2 k=8", "k_tile_resid_sp<double, false"), ("K2 k=60", "k_tile_resid_sp<double, false"),
+                            ("K2 column-major k=8", "k_tile_resid_cm<double"), ("K2 column-major k=60", "k_tile_resid_sp<double, true")):
             if key in out and isinstance(out[key], dict):
-                t = traffic_of(prefix)
+                t = traffic_of(prefix, out[key]["algorithmic_bytes"])
                 out[key]["traffic"] = t
                 out[key]["traffic_over_algorithmic"] = None if t is None else t / out[key]["algorithmic_bytes"]
                 out[key]["traffic_stale"] = stale

@@ -27,6 +27,10 @@ def main():
         e = {c: {"n": len(v), "avg_KB": sum(v) / len(v)} for c, v in cs.items()}
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             e["hbm_MB_per_launch"] = (2 * e["FETCH_SIZE"]["avg_KB"] + e["WRITE_SIZE"]["avg_KB"]) / 1024.0
+            # per launch, in dispatch order (the two passes run the same command: launch i of one is launch i of the other) -- a kernel
+            # that is launched with different arguments under one name and grid (K2 at k = 8 and k = 60) is told apart by the caller
+            if len(cs["FETCH_SIZE"]) == len(cs["WRITE_SIZE"]):
+                e["hbm_MB_launches"] = [round((2 * f_ + w_) / 1024.0, 2) for f_, w_ in zip(cs["FETCH_SIZE"], cs["WRITE_SIZE"])]
         out[key] = e
     # provenance: digests of the kernel sources the counters were collected on (bench.py compares them with the tree it runs
     # in and flags a stale file); the commit hash is added when the file is copied into profiles/ (the GPU box has no .git)
@@ -44,7 +48,8 @@ def main():
     for key, e in out.items():
         if key == "_meta":
             continue
-        print("%-60s %s" % (key[:60], {k: (round(v["avg_KB"] / 1024, 2) if isinstance(v, dict) else round(v, 2)) for k, v in e.items()}))
+        print("%-60s %s" % (key[:60], {k: (round(v["avg_KB"] / 1024, 2) if isinstance(v, dict) else (round(v, 2) if not isinstance(v, list) else "%d launches" % len(v)))
+                                     for k, v in e.items()}))
 
 
 if __name__ == "__main__":
