@@ -221,6 +221,13 @@ def beyn_sharded(na, args, world, rank):
     if distd:
         mine = {"rank": rank, "nodes": int(info.get("nodes", -1)), "wall_s": round(dt, 5),
                 "exchange_s": None if info.get("exchange_s") is None else round(float(info["exchange_s"]), 6)}
+        try:          # which part of this rank's share does not shrink with the number of ranks: its (batched) factorisation, instrumented
+            pi_ = {"phases_s": {}}
+            bc.c4_device(na, nep, integ, Vh=Vh, info=pi_)
+            mine["factorise_nodes_s"] = round(float(pi_["phases_s"].get("factorise_nodes", 0.0)), 6)
+            mine["solve_nodes_s"] = round(float(pi_["phases_s"].get("solve_nodes_and_accumulate", 0.0)), 6)
+        except Exception:
+            mine["factorise_nodes_s"] = None
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
         t = torch.tensor([dt], dtype=torch.float64, device=RED_DEV)
@@ -241,6 +248,26 @@ def beyn_sharded(na, args, world, rank):
                   "replicated_fraction_of_this_run": round((tot - shard) / tot, 4) if tot > 0 else None,
                   "note": "each phase closed by a device synchronisation (the timed call above has none); with P ranks the sharded "
                           "part divides by P, the replicated part and the exchange do not"}
+        if not distd:
+            # expected strong-scaling curve from MEASURED pieces of this device (no "sharded / P"): with P ranks a rank factorises and
+            # solves 64 / P nodes -- the batched device LU is a chain of ~150 launches whose time depends little on the batch size, so
+            # that stage does NOT divide by P; it is run here at the batch sizes an 8-GPU node will see.  Exchange: one all-gather of
+            # 2 n k complex128 per rank over xGMI, (P - 1) / P of the gathered block crosses a link at ~50 GB/s effective per
+            # direction (ring); the replicated tail is what this run measured.
+            pred = {}
+            rep_s = tot - shard
+            for P in (2, 4, 8):
+                pi = {"phases_s": {}}
+                bc.c4_device(na, nep, integ, Vh=Vh, info={"phases_s": {}}, N=64 // P)        # (first call at this N: warm-up)
+                bc.c4_device(na, nep, integ, Vh=Vh, info=pi, N=64 // P)
+                torch.cuda.synchronize()
+                f_ = float(pi["phases_s"].get("factorise_nodes", 0.0)); s_ = float(pi["phases_s"].get("solve_nodes_and_accumulate", 0.0))
+                exch = (2 * nep.n * 32 * 16) * (P - 1) / 50e9
+                tP = f_ + s_ + rep_s + exch
+                pred["P%d" % P] = {"factorise_nodes_s": round(f_, 6), "solve_nodes_s": round(s_, 6), "exchange_model_s": round(exch, 6),
+                                   "seconds": round(tP, 6), "speedup_vs_1": round(tot / tP, 3) if tP > 0 else None}
+            phases["predicted"] = dict(pred, note="factorise / solve measured on THIS GPU at 64 / P nodes (instrumented: a device "
+                                       "synchronisation behind each phase), replicated part as measured at P = 1, exchange modelled")
     except Exception as e:
         phases = {"error": repr(e)[:200]}
     if distd:

@@ -43,6 +43,10 @@ typedef void* nep_stream;
 #define NEP_ERR_SINGULAR -3 /* zero pivot met in the triangular solve (SingularException analogue) */
 #define NEP_ERR_BREAKDOWN -4 /* orthogonalisation breakdown: ||w|| == 0 */
 #define NEP_ERR_UNSUPPORTED -5 /* the request does not fit this code path (internal: callers fall back) */
+#define NEP_ERR_RETRY -6       /* nep_iar_run: the recorded refinement / DGKS / eig status of a step asks for more than the
+                                * enqueued work did -- re-run through the step-synchronous route (nep_iar_result.retry_reason) */
+#define NEP_ERR_NOCONV -7      /* nep_iar_run: fewer than `neigs` pairs converged within maxit steps; the best pairs ARE returned
+                                * (the reference throws NoConvergenceException(lambda, Q, err, msg), src/method_iar.jl:163-175) */
 
 /* ---- library / device ---------------------------------------------------------------- */
 int32_t nep_version(void);
@@ -543,6 +547,55 @@ int32_t nep_iar_wait(nep_iar* s, int32_t k);
 /* device-side counterpart of nep_iar_wait: work enqueued on `stream` after this call starts only when column k of H is
  * complete (the eigen-decomposition of step k on a second stream: nep_hess_eigvals_dev on row block dH of nep_iar_create) */
 int32_t nep_iar_stream_wait(nep_iar* s, int32_t k, nep_stream stream);
+
+/* ---- the whole infinite-Arnoldi run as one call ---------------------------------------------
+ * replaces: the body of `iar(::Type{T}, nep::NEP; orthmethod, maxit, linsolvercreator, tol, neigs, errmeasure, sigma, gamma, v, logger,
+ *           check_error_every, ...)`, src/method_iar.jl:46-182, after `create_linsolver` (:84): recurrence (:94-109, nep_iar_step),
+ *           `eigen(H[1:k,1:k])` (:112, nep_hess_eig*_batch_dev), `Q = VV*Z` (:115, nep_gemm_ts_dev), `estimate_error` for every Ritz
+ *           pair (:133-135, nep_resid_batch_dev; StandardSPMFErrmeasure src/errmeasure.jl:174-190 / ResidualErrmeasure :114,128-130),
+ *           convergence count, sort and extraction (:137-160), the NoConvergenceException (:163-175).  A Julia method
+ *           `iar(::Type{T}, nep::DeviceSPMF; ...)` is one ccall of this (julia/NEPMI355X.jl); the Python host calls it too.
+ * lu: the factors of M(sigma) (nep_lu_create_csc / nep_lu_factor_dev); h_v0: the start vector (n, not normalised);
+ * h_Ctab: m x mt column-major, row j-1 = gamma^j / j * f_t^(j)(sigma) (the DerSPMF table src/NEPTypes.jl:1108-1128 with iar's
+ * alpha_j / j scaling :83,101); h_cabs / h_cf: |f_t(sigma)|, f_t(sigma) (required when umfpack_refinements > 0);
+ * h_fro: ||A_t||_F (errmeasure 1); fv(ctx, nlam, lam, F): the host evaluates F[t + s mt] = f_t(lam[s]) (the scalar functions of
+ * the SPMF are closures of the host language), returns 0 -- called on the calling thread only.
+ * Results: h_lam (capacity maxit), dQ (device, n x maxit column-major, ld n; may be NULL), h_Q (host, same shape; may be NULL:
+ * pinned memory gets the link's rate), h_err (maxit x maxit column-major, err[k-1 + (s-1) maxit] = sorted error s of step k, NaN
+ * where unset; may be NULL), dV_basis (device, maxit+1 columns of leading dimension n (maxit+1): the Krylov basis the reference
+ * returns as V[:,1:k]; NULL: library-owned and released at return).  NEP_OK: res->nret converged pairs (all pairs below tol when neigs = INFINITY); NEP_ERR_NOCONV: the
+ * res->nret best pairs; NEP_ERR_RETRY / NEP_ERR_UNSUPPORTED (maxit > 128): nothing returned, use the per-step entry points. */
+typedef struct nep_iar_opts {
+    int32_t maxit;               /* m */
+    int32_t check_error_every;
+    int32_t orth_method;         /* 0 DGKS, 1 classical Gram-Schmidt */
+    int32_t umfpack_refinements; /* <= 0: plain solves; else UMFPACK's refinement rule with this bound (control[8]) */
+    int32_t errmeasure;          /* 0: ||M(lam) v|| / ||v||;  1: that / sum_t ||A_t||_F |f_t(lam)| */
+    int32_t refine_hint;         /* sweeps a previous run at THIS shift settled on (nep_iar_result.refine_plan), -1: none */
+    double tol;
+    double neigs;                /* INFINITY: run to maxit, return every pair below tol */
+    nep_cdouble sigma, gamma;
+} nep_iar_opts;
+typedef struct nep_iar_result {
+    int32_t k;                   /* step whose check produced the returned pairs */
+    int32_t nconv;               /* pairs below tol at that step */
+    int32_t nret;                /* pairs written to h_lam / dQ / h_Q */
+    int32_t refine_plan;         /* refinement sweeps the run settled on (-1: none) -- the next run's refine_hint */
+    int32_t refine_hint_off;     /* 1: a miss withdrew the hint for this NEP */
+    int32_t retry_reason;        /* NEP_ERR_RETRY: 1 refinement record, 2 DGKS pass, 3 device eigen-decomposition */
+} nep_iar_result;
+typedef int32_t (*nep_fv_eval)(void* ctx, int32_t nlam, const nep_cdouble* lam, nep_cdouble* F);
+/* UMFPACK's refinement stopping rule (umfpack_solve behind `Afact \ x` with control[8] = umfpack_refinements, src/LinSolvers.jl:
+ * 114-122) replayed on the omegas w4[0..plan] that nep_iar_step recorded for a solve that took `plan` sweeps without reading them
+ * back (final_recorded = 0: omega of the kept iterate x_plan was not evaluated).  out[0] = 1: what the step kept is what the checked
+ * loop keeps (or at least as good); 0: a miss -- re-run with checked solves.  out[1] = sweeps to plan from now on (-1: unchanged),
+ * out[2] = hint for later solvers at this shift (-1: none), out[3] = 1: the hint is withdrawn for good. */
+int32_t nep_refine_review(int32_t umfpack_refinements, int32_t plan, int32_t final_recorded, const double* w4, int32_t hint_in,
+                          int32_t out[4]);
+int32_t nep_iar_run(nep_spmf* spmf, nep_lu* lu, int64_t n, const nep_iar_opts* opts, const nep_cdouble* h_v0,
+                    const nep_cdouble* h_Ctab, int32_t mt, const double* h_cabs, const nep_cdouble* h_cf, const double* h_fro,
+                    nep_fv_eval fv, void* ctx, nep_cdouble* h_lam, nep_cdouble* dQ, nep_cdouble* h_Q, double* h_err,
+                    nep_cdouble* dV_basis, nep_iar_result* res, nep_stream stream);
 
 /* ---- multi-GPU exchange of the contour integrators ----------------------------------------
  * replaces: the reduction inside `integrate_interval(::Type{<:MatrixIntegrator}, ...)` src/method_contour_common.jl:46,61-94

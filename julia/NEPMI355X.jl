@@ -20,7 +20,7 @@ import IterativeSolvers
 import ..NEPCore: compute_Mlincomb, compute_Mlincomb!, compute_Mder, compute_MM, size, issparse
 import ..NEPTypes: get_Av, get_fv
 import ..LinSolvers: lin_solve, create_linsolver
-import ..NEPSolver: integrate_interval
+import ..NEPSolver: integrate_interval, iar, tiar
 
 const LIB = "libnepmi355"
 chk(st) = st == 0 || error(unsafe_string(ccall((:nep_last_error, LIB), Cstring, ())))
@@ -37,11 +37,17 @@ download(b::DevBuf) = (A = Matrix{ComplexF64}(undef, b.rows, b.cols);
     chk(ccall((:nep_download, LIB), Cint, (Ptr{ComplexF64}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), A, b.ptr, sizeof(A), C_NULL)); A)
 
 # ---- NEP seam: an AbstractSPMF whose compute_* run on the device ------------------------------------------
-# replaces SPMF_NEP (src/NEPTypes.jl:162-170); wraps any AbstractSPMF (PEP, DEP, SPMFSumNEP ...) via get_Av/get_fv
-mutable struct DeviceSPMF{T} <: AbstractSPMF{T}
-    org::AbstractSPMF{T}          # kept for compute_Mder (host, one-off per shift) and get_fv
+# replaces SPMF_NEP (src/NEPTypes.jl:162-170); wraps any AbstractSPMF (SPMF_NEP, PEP, DEP, SPMFSumNEP ...) via get_Av/get_fv.
+# Julia's type parameters are invariant: PEP <: AbstractSPMF{AbstractMatrix} (src/types_poly.jl:31) and SPMFSumNEP <:
+# AbstractSPMF{AbstractMatrix} (src/NEPTypes.jl:838) while eltype(get_Av(.)) is a concrete SparseMatrixCSC -- a field
+# `org::AbstractSPMF{T}` with T = eltype(Av) cannot hold them (nlevp_native_gun IS an SPMFSumNEP(PEP, SPMF_NEP),
+# src/gallery_extra/NLEVP_native.jl:4-18).  So the wrapper is declared the way those two are: no parameter, supertype
+# AbstractSPMF{AbstractMatrix}, and the wrapped problem in an unparametrised field.
+mutable struct DeviceSPMF <: AbstractSPMF{AbstractMatrix}
+    org::AbstractSPMF             # kept for compute_Mder (host, one-off per shift) and get_fv
     handle::Ptr{Cvoid}
     n::Int
+    refine_hint::Dict{ComplexF64,Int}   # refinement sweeps nep_iar_run settled on, per shift (nep_iar_result.refine_plan)
 end
 function DeviceSPMF(org::AbstractSPMF)
     Av = get_Av(org); n = size(org, 1); mt = length(Av)
@@ -54,7 +60,7 @@ function DeviceSPMF(org::AbstractSPMF)
     GC.@preserve rp ci vals chk(ccall((:nep_spmf_create, LIB), Cint,
         (Int64, Int32, Ptr{Ptr{Int32}}, Ptr{Ptr{Int32}}, Ptr{Ptr{Cvoid}}, Ptr{Int32}, Ref{Ptr{Cvoid}}),
         n, mt, pointer.(rp), pointer.(ci), [Ptr{Cvoid}(pointer(v)) for v in vals], isc, h))
-    d = DeviceSPMF{eltype(Av)}(org, h[], n)
+    d = DeviceSPMF(org, h[], n, Dict{ComplexF64,Int}())
     finalizer(x -> ccall((:nep_spmf_destroy, LIB), Cint, (Ptr{Cvoid},), x.handle), d); d
 end
 size(d::DeviceSPMF) = (d.n, d.n); size(d::DeviceSPMF, i) = d.n
@@ -74,8 +80,15 @@ function compute_Mlincomb(d::DeviceSPMF, λ::Number, V::AbstractVecOrMat, a::Vec
     dV = DevBuf(d.n, k); upload!(dV, Vm); dz = DevBuf(d.n, 1); C = coeff_block(d, λ, a)
     chk(ccall((:nep_mlincomb, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
               d.handle, k, C, dV.ptr, d.n, dz.ptr, C_NULL))
-    vec(download(dz))                           # a new Vector of length n, V untouched (test/spmf.jl:26-30)
+    z = vec(download(dz))                       # a new Vector of length n, V untouched (test/spmf.jl:26-30)
+    # the reference's element type (test/compute_types.jl; src/NEPTypes.jl:985-999: promote_type of λ, a, the SPMF's Ftype and V;
+    # Ftype is ComplexF64 unless the problem was built with another one): the device computes in ComplexF64 throughout, a real
+    # result type is returned as its real part
+    TT = promote_type(eltype(V), typeof(λ), eltype(a), ftype(d.org))
+    TT <: Real ? Vector{TT}(real.(z)) : (TT == ComplexF64 ? z : Vector{TT}(z))
 end
+ftype(::SPMF_NEP{T,Ftype}) where {T,Ftype} = Ftype
+ftype(::AbstractSPMF) = ComplexF64
 compute_Mlincomb!(d::DeviceSPMF, λ::Number, V::AbstractVecOrMat, a::Vector = ones(size(V, 2))) = compute_Mlincomb(d, λ, V, a)
 # device-resident overload: V already lives in HBM (a DevBuf, e.g. the basis kept by DeviceDGKS below) -- nothing is uploaded,
 # the result stays on the device; `cols` selects the leading columns (iar: column k of the basis *is* the n x k block)
@@ -157,16 +170,18 @@ end
 # hint that direct solvers ignore (src/LinSolvers.jl:135-137).  A resident solver (DeviceLinSolverCreator(resident = true))
 # returns the DevBuf instead; `*(::DevBuf, ::Number)` below keeps the unchanged integrand `Tv(g(t))*gp(t)` of
 # method_beyncontour.jl:96-97 on the device, and integrate_interval accepts either kind of value.
-const PROBE = Ref{Any}(nothing)                   # (objectid, size, content hash, DevBuf) of the last uploaded right-hand-side block
+const PROBE = Ref{Any}(nothing)                   # (objectid, size, host copy, DevBuf) of the last uploaded right-hand-side block
 clear_probe!() = (PROBE[] = nothing)              # drop the cached block (frees its HBM at the next GC)
 function upload_rhs(b::AbstractVecOrMat, n)
     B = Matrix{ComplexF64}(reshape(b, n, :)); dB = DevBuf(n, size(B, 2)); upload!(dB, B); dB
 end
 function lin_solve(s::DeviceLinSolver, b::AbstractVecOrMat; tol = 0)
     p = PROBE[]
-    # the cached block is reused only for the same array WITH THE SAME CONTENTS (hash: one pass over 5 MB of host memory, against
-    # an upload of the same 5 MB) -- a caller that refills its matrix in place gets the new values solved, not the old ones
-    if s.resident && b isa AbstractMatrix && p !== nothing && p[1] == objectid(b) && p[2] == size(b) && p[3] == hash(b)
+    # the cached block is reused only for the same array WITH THE SAME CONTENTS.  Base.hash(::AbstractArray) is NOT a content check
+    # (it samples O(log N) entries of arrays of 8192 or more elements): the kept host copy is compared entry by entry (`==` on two
+    # 5 MB blocks: one pass over host memory, against an upload of the same 5 MB over PCIe) -- a caller that refills its matrix in
+    # place, wholly or in part, gets the new values solved, not the old ones
+    if s.resident && b isa AbstractMatrix && p !== nothing && p[1] == objectid(b) && p[2] == size(b) && p[3] == b
         dB = DevBuf(s.n, size(b, 2))               # contour solvers pass the SAME probe block Vh at every node: uploaded once
         chk(ccall((:nep_dev_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), dB.ptr, p[4].ptr, 16s.n*dB.cols, C_NULL))
     else
@@ -174,7 +189,7 @@ function lin_solve(s::DeviceLinSolver, b::AbstractVecOrMat; tol = 0)
         if s.resident && b isa AbstractMatrix
             keep = DevBuf(s.n, dB.cols)
             chk(ccall((:nep_dev_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), keep.ptr, dB.ptr, 16s.n*dB.cols, C_NULL))
-            PROBE[] = (objectid(b), size(b), hash(b), keep)
+            PROBE[] = (objectid(b), size(b), copy(b), keep)
         end
     end
     lin_solve!(s, dB)
@@ -230,14 +245,15 @@ Base.size(X::DevBuf) = (X.rows, X.cols)
 
 # ---- orthogonalisation seam: a new IterativeSolvers.OrthogonalizationMethod (cf. test/iar.jl:7-17) ----------
 # The reference drivers pass HOST views (`view(V,1:nk,1:k)`, src/method_iar.jl:107; `Z[:,1:k]`, method_tiar.jl:128) and a
-# method TYPE.  DeviceDGKS therefore owns a device mirror of the basis: the drivers only ever append one column per step (the
+# method INSTANCE (`orthmethod=DGKS()`, src/method_iar.jl:50; the user recipe test/iar.jl:13-17 dispatches on `::DoubleGS`):
+# `iar(nep, orthmethod=DeviceDGKS())`.  DeviceDGKS therefore owns a device mirror of the basis: the drivers only ever append one column per step (the
 # normalised w of the previous call), so call k uploads that ONE column, never the basis (iar m=100: 16 MB instead of 1.6 GB).
-abstract type DeviceDGKS <: IterativeSolvers.OrthogonalizationMethod end
+struct DeviceDGKS <: IterativeSolvers.OrthogonalizationMethod end
 mutable struct BasisMirror; buf::DevBuf; ld::Int; ncols::Int; w::DevBuf; end
 const MIRROR = Ref{Union{Nothing,BasisMirror}}(nothing)
 reset_basis!() = (MIRROR[] = nothing)                    # call before a new iar/tiar run
 function IterativeSolvers.orthogonalize_and_normalize!(V::StridedMatrix{ComplexF64}, w::StridedVector{ComplexF64},
-                                                        h::StridedVector{ComplexF64}, ::Type{DeviceDGKS})
+                                                        h::StridedVector{ComplexF64}, ::DeviceDGKS)
     rows, k = size(V); ldmax = size(parent(V), 1); kmax = size(parent(V), 2)
     (stride(V, 1) == 1 && stride(w, 1) == 1 && stride(h, 1) == 1) || error("DeviceDGKS: unit row stride expected")
     m = MIRROR[]
@@ -260,6 +276,209 @@ function IterativeSolvers.orthogonalize_and_normalize!(V::StridedMatrix{ComplexF
         Int32, Ref{Int32}, Ptr{Cvoid}), m.buf.ptr, ldmax, rows, k, C_NULL, m.w.ptr, h, β, 0, np, C_NULL))
     chk(ccall((:nep_download, LIB), Cint, (Ptr{ComplexF64}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), w, m.w.ptr, 16rows, C_NULL))
     β[]                                                   # w and h updated in place, returns ||w|| before normalisation
+end
+
+# ---- iar / tiar on the device pipeline: `iar(nep; ...)` / `tiar(nep; ...)` with nep::DeviceSPMF, caller unchanged ----------
+# Julia dispatches on the NEP type: these two methods are more specific than the reference's `iar(::Type{T}, nep::NEP; ...)`
+# (src/method_iar.jl:46-64) / `tiar(::Type{T}, nep::NEP; ...)` (src/method_tiar.jl:52-70), take the same keywords with the same
+# defaults and return what those return.  iar is ONE ccall of nep_iar_run (csrc/iar_run.hip): recurrence, Hessenberg
+# eigen-decompositions, Ritz blocks, residual batches, convergence test, sort and extraction all stay in the library on three
+# streams -- the pipeline bench.py measures (the Python host calls the same entry point).  What the library cannot do is taken
+# from the reference's own method: a request outside the fast path (T other than ComplexF64, proj_solve, an error measure that is
+# a user function, MGS or a user orthogonalisation, another linear-solver creator, maxit > 128) or a run that reports
+# NEP_ERR_RETRY goes to `invoke(iar, Tuple{Type{T},NEP}, ...)`, i.e. the reference's loop over the four seams above.
+const NEP_ERR_RETRY = -6; const NEP_ERR_NOCONV = -7
+struct IarOpts                       # nep_iar_opts, include/nepmi355.h (same field order and widths)
+    maxit::Int32; check_error_every::Int32; orth_method::Int32; umfpack_refinements::Int32; errmeasure::Int32; refine_hint::Int32
+    tol::Float64; neigs::Float64; sigma::ComplexF64; gamma::ComplexF64
+end
+struct IarResult                     # nep_iar_result
+    k::Int32; nconv::Int32; nret::Int32; refine_plan::Int32; refine_hint_off::Int32; retry_reason::Int32
+end
+orth_code(::IterativeSolvers.DGKS) = Int32(0)
+orth_code(::DeviceDGKS) = Int32(0)
+orth_code(::IterativeSolvers.ClassicalGramSchmidt) = Int32(1)
+orth_code(::IterativeSolvers.ModifiedGramSchmidt) = Int32(2)
+orth_code(x) = nothing
+# (kind, ||A_t||_F) of an error measure the library evaluates itself: src/errmeasure.jl:91-101 (Default), :114,128-130 (Residual),
+# :174-190 (StandardSPMF); a user function or an error measure of another problem: nothing
+native_errmeasure(e::DefaultErrmeasure, nep) = native_errmeasure(e.errm, nep)
+native_errmeasure(e::StandardSPMFErrmeasure, nep) = e.nep === nep ? (Int32(1), Vector{Float64}(e.coeffs)) : nothing
+native_errmeasure(e::ResidualErrmeasure, nep) = e.nep === nep ? (Int32(0), Float64[]) : nothing
+native_errmeasure(e, nep) = nothing
+# the reference's default creator (DefaultLinSolverCreator = FactorizeLinSolverCreator, src/LinSolverCreators.jl:62-122,196) asked
+# of a DeviceSPMF means "factorise once, solve many, UMFPACK refinement": the device solver with the same umfpack_refinements
+device_creator(c::DeviceLinSolverCreator) = c
+device_creator(c::FactorizeLinSolverCreator) = (isempty(c.recycled_factorizations) && c.max_factorizations == 0) ?
+    DeviceLinSolverCreator(umfpack_refinements = c.umfpack_refinements, resident = true) : nothing
+device_creator(c) = nothing
+# row j+1 = f_t^(j)(σ), j = 0..m: first column of f_t at the bidiagonal matrix σ I + subdiag(1..m) (the device the reference's
+# DerSPMF uses, src/NEPTypes.jl:1108-1128)
+function derivative_table(d::DeviceSPMF, σ::ComplexF64, m::Int)
+    S = diagm(0 => fill(σ, m + 1), -1 => ComplexF64.(1:m))
+    hcat([Vector{ComplexF64}(f(S)[:, 1]) for f in get_fv(d)]...)
+end
+# nep_fv_eval: F[t + (s-1) mt] = f_t(λ_s); runs on the calling thread, inside the ccall of nep_iar_run
+function fv_eval(ctx::Ptr{Cvoid}, nlam::Int32, lam::Ptr{ComplexF64}, F::Ptr{ComplexF64})::Int32
+    try
+        fs = unsafe_pointer_to_objref(ctx)::Vector{Any}; mt = length(fs)
+        for s in 1:nlam, t in 1:mt
+            unsafe_store!(F, ComplexF64(fs[t](unsafe_load(lam, s))), t + (s - 1) * mt)
+        end
+        return Int32(0)
+    catch
+        return Int32(1)                # an exception must not unwind through the C frames: the run ends with NEP_ERR_ARG
+    end
+end
+Base.Matrix(b::DevBuf) = download(b); Base.Array(b::DevBuf) = download(b)
+
+iar(nep::DeviceSPMF; params...) = iar(ComplexF64, nep; params...)
+function iar(::Type{T}, nep::DeviceSPMF;
+             orthmethod = IterativeSolvers.DGKS(), maxit = 30, linsolvercreator = DefaultLinSolverCreator(),
+             tol = eps(real(T)) * 10000, neigs = 6, errmeasure::ErrmeasureType = DefaultErrmeasure(nep), σ = zero(T), γ = one(T),
+             v = randn(real(T), size(nep, 1)), logger = 0, check_error_every = 1, proj_solve = false,
+             inner_solver_method = DefaultInnerSolver(), inner_logger = 0) where {T<:Number}
+    reference() = invoke(iar, Tuple{Type{T},NEP}, T, nep; orthmethod = orthmethod, maxit = maxit,
+                         linsolvercreator = linsolvercreator, tol = tol, neigs = neigs, errmeasure = errmeasure, σ = σ, γ = γ, v = v,
+                         logger = logger, check_error_every = check_error_every, proj_solve = proj_solve,
+                         inner_solver_method = inner_solver_method, inner_logger = inner_logger)
+    ek = native_errmeasure(errmeasure, nep); oc = orth_code(orthmethod); dc = device_creator(linsolvercreator)
+    if T != ComplexF64 || proj_solve || ek === nothing || oc === nothing || oc > 1 || dc === nothing || maxit > 128
+        return reference()
+    end
+    n = nep.n; m = Int(maxit); σc = ComplexF64(σ); γc = ComplexF64(γ)
+    M0inv = create_linsolver(dc, nep, σc)::DeviceLinSolver            # src/method_iar.jl:84
+    fD = derivative_table(nep, σc, m); mt = size(fD, 2)
+    Ctab = ComplexF64[γc^j / j * fD[j + 1, t] for j in 1:m, t in 1:mt]   # m x mt: α_j / j f_t^(j)(σ), α = γ.^(0:m) (:83,:101)
+    v0 = Vector{ComplexF64}(v)
+    refine = M0inv.umfpack_refinements > 0 && !isempty(M0inv.cf)
+    opts = IarOpts(m, check_error_every, oc, refine ? M0inv.umfpack_refinements : 0, ek[1], get(nep.refine_hint, σc, -1),
+                   Float64(tol), Float64(neigs), σc, γc)
+    res = Ref(IarResult(0, 0, 0, -1, 0, 0))
+    λ = zeros(ComplexF64, m); Q = Matrix{ComplexF64}(undef, n, m); err = fill(NaN, m, m)
+    V = DevBuf(n * (m + 1), m + 1)                                     # the Krylov basis stays on the device (1.6 GB for gun, m = 100)
+    fs = Any[f for f in get_fv(nep)]
+    cb = @cfunction(fv_eval, Int32, (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Ptr{ComplexF64}))
+    st = GC.@preserve fs ccall((:nep_iar_run, LIB), Cint,
+        (Ptr{Cvoid}, Ptr{Cvoid}, Int64, Ref{IarOpts}, Ptr{ComplexF64}, Ptr{ComplexF64}, Int32, Ptr{Float64}, Ptr{ComplexF64},
+         Ptr{Float64}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{Cvoid}, Ptr{ComplexF64}, Ptr{Float64}, Ptr{Cvoid},
+         Ref{IarResult}, Ptr{Cvoid}),
+        nep.handle, M0inv.handle, n, Ref(opts), v0, Ctab, mt, refine ? M0inv.cabs : C_NULL, refine ? M0inv.cf : C_NULL,
+        ek[1] == 1 ? ek[2] : C_NULL, cb, pointer_from_objref(fs), λ, C_NULL, Q, err, V.ptr, res, C_NULL)
+    r = res[]
+    if r.refine_hint_off != 0
+        delete!(nep.refine_hint, σc)
+    elseif r.refine_plan >= 0
+        nep.refine_hint[σc] = r.refine_plan
+    end
+    st == NEP_ERR_RETRY && return reference()      # a step wanted more refinement sweeps / DGKS passes than were enqueued (rare)
+    (st == 0 || st == NEP_ERR_NOCONV) || chk(st)
+    k = Int(r.k); nret = Int(r.nret)
+    if st == NEP_ERR_NOCONV                         # src/method_iar.jl:163-175
+        msg = "Number of iterations exceeded. maxit=$(maxit)."
+        r.nconv < 3 && (msg = string(msg, "Try to change the inner_solver_method for better performance."))
+        throw(NoConvergenceException(λ[1:nret], Q[:, 1:nret], err[k, 1:nret], msg))
+    end
+    V.cols = k                                      # V[:,1:k] of src/method_iar.jl:181, left in HBM: Matrix(V) downloads it
+    return λ[1:nret], Q[:, 1:nret], V
+end
+
+# tiar: the reference's loop (src/method_tiar.jl:116-239) with the basis Z resident in HBM.  Per step: K1 on Z with the k x k
+# tensor slice folded into the coefficient block (z = Σ_t A_t Z (B diag(α) fD_t): no n x k product is formed), K5 with UMFPACK's
+# refinement in place, K6 (DGKS / CGS / MGS) with h and β returned, the O(k³) tensor algebra on the host; per check: eig(H_k) on
+# the host, ONE K7 GEMM Q = Z (a[1,1:k,1:k]ᵀ W) and ONE K2 residual batch for all k pairs.
+tiar(nep::DeviceSPMF; params...) = tiar(ComplexF64, nep; params...)
+function tiar(::Type{T}, nep::DeviceSPMF;
+              orthmethod = IterativeSolvers.DGKS(), maxit = 30, linsolvercreator = DefaultLinSolverCreator(),
+              tol = eps(real(T)) * 10000, neigs = 6, errmeasure::ErrmeasureType = DefaultErrmeasure(nep), σ = zero(T), γ = one(T),
+              v = randn(real(T), size(nep, 1)), logger = 0, check_error_every = 1, proj_solve = false,
+              inner_solver_method = DefaultInnerSolver(), inner_logger = 0) where {T}
+    ek = native_errmeasure(errmeasure, nep); oc = orth_code(orthmethod); dc = device_creator(linsolvercreator)
+    if T != ComplexF64 || proj_solve || ek === nothing || oc === nothing || dc === nothing
+        return invoke(tiar, Tuple{Type{T},NEP}, T, nep; orthmethod = orthmethod, maxit = maxit,
+                      linsolvercreator = linsolvercreator, tol = tol, neigs = neigs, errmeasure = errmeasure, σ = σ, γ = γ, v = v,
+                      logger = logger, check_error_every = check_error_every, proj_solve = proj_solve,
+                      inner_solver_method = inner_solver_method, inner_logger = inner_logger)
+    end
+    n = nep.n; m = Int(maxit); σc = ComplexF64(σ); γc = ComplexF64(γ)
+    n < m && throw(LostOrthogonalityException("Loss of orthogonality in the matrix Z. The problem size is too small, use iar instead."))
+    a = zeros(ComplexF64, m + 1, m + 1, m + 1); t = zeros(ComplexF64, m + 1); H = zeros(ComplexF64, m + 1, m)
+    α = γc .^ (0:m); α[1] = 0
+    M0inv = create_linsolver(dc, nep, σc)::DeviceLinSolver
+    fD = derivative_table(nep, σc, m); fv = get_fv(nep); mt = length(fv)
+    Z = DevBuf(n, m + 1)
+    chk(ccall((:nep_dev_memset, LIB), Cint, (Ptr{Cvoid}, Int32, Csize_t, Ptr{Cvoid}), Z.ptr, 0, 16n * (m + 1), C_NULL))
+    v0 = Vector{ComplexF64}(v); v0 ./= norm(v0)
+    chk(ccall((:nep_upload, LIB), Cint, (Ptr{Cvoid}, Ptr{ComplexF64}, Csize_t, Ptr{Cvoid}), Z.ptr, v0, 16n, C_NULL))
+    a[1, 1, 1] = 1
+    z = DevBuf(n, 1); err = fill(NaN, m + 1, m + 1); conv_eig_hist = zeros(Int, m + 1)
+    λ = ComplexF64[]; QT = DevBuf(1, 1); idx = Int[]; kq = 0
+    k = 1; conv_eig = 0
+    while k <= m && conv_eig < neigs
+        # y[:,2:k+1] = Z[:,1:k] * transpose(a[1:k,k,1:k]) ./ (1:k)' and compute_Mlincomb!(nep, σ, y, α) in one K1 call (:120-125)
+        B = transpose(a[1:k, k, 1:k]) ./ transpose(1:k)
+        C = Matrix{ComplexF64}((B .* transpose(α[2:k+1])) * fD[2:k+1, :])              # k x mt
+        chk(ccall((:nep_mlincomb, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Ptr{Cvoid}, Int64, Ptr{Cvoid}, Ptr{Cvoid}),
+                  nep.handle, k, C, Z.ptr, n, z.ptr, C_NULL))
+        lin_solve!(M0inv, z; scale = -1.0)                                               # :126
+        zk = Z.ptr + 16n * k                                                             # column k+1 of Z
+        chk(ccall((:nep_dev_copy, LIB), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Csize_t, Ptr{Cvoid}), zk, z.ptr, 16n, C_NULL))
+        hk = zeros(ComplexF64, k); β = Ref{Float64}(0); np = Ref{Int32}(0)               # :129-130
+        chk(ccall((:nep_orth, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Int32, Ptr{Int64}, Ptr{Cvoid}, Ptr{ComplexF64}, Ref{Float64},
+                  Int32, Ref{Int32}, Ptr{Cvoid}), Z.ptr, n, n, k, C_NULL, zk, hk, β, oc, np, C_NULL))
+        t[1:k] = hk; t[k+1] = β[]
+        # tensor orthogonalisation, twice (:131-183)
+        g = zeros(ComplexF64, k + 1, k + 1)
+        g[1, :] = t[1:k+1]
+        for l in 1:k+1, i in 2:k+1
+            g[i, l] = a[i-1, k, l] / (i - 1)
+        end
+        h = zeros(ComplexF64, k)
+        for l in 1:k; h .+= a[1:k, 1:k, l]' * g[1:k, l]; end
+        for l in 1:k; g[1:k+1, l] .-= a[1:k+1, 1:k, l] * h; end
+        hh = zeros(ComplexF64, k)
+        for l in 1:k; hh .+= a[1:k, 1:k, l]' * g[1:k, l]; end
+        for l in 1:k; g[1:k+1, l] .-= a[1:k+1, 1:k, l] * hh; end
+        h .+= hh; βt = norm(g)
+        H[1:k, k] = h; H[k+1, k] = βt
+        a[1:k+1, k+1, 1:k+1] = g ./ βt
+        if rem(k, check_error_every) == 0 || k == m
+            D, W = eigen(H[1:k, 1:k])                                                   # :185
+            λ = σc .+ γc ./ D
+            Bq = Matrix{ComplexF64}(transpose(a[1, 1:k, 1:k]) * W)                       # Q = Z[:,1:k] * Bq  (:186-187)
+            QT = DevBuf(k, n); kq = k                                                    # k x n column-major = n x k ROW-major
+            chk(ccall((:nep_gemm_ts, LIB), Cint, (Ptr{Cvoid}, Int64, Int64, Int32, Ptr{ComplexF64}, Int64, Int32, Ptr{Cvoid}, Int64,
+                      Int32, Ptr{Cvoid}), Z.ptr, n, n, k, Bq, k, k, QT.ptr, k, 1, C_NULL))
+            F = ComplexF64[f(λ[s]) for f in fv, s in 1:k]                                # mt x k
+            rn = zeros(k); qn = zeros(k)
+            chk(ccall((:nep_resid_batch, LIB), Cint, (Ptr{Cvoid}, Int32, Ptr{ComplexF64}, Ptr{Cvoid}, Int64, Ptr{Float64},
+                      Ptr{Float64}, Ptr{Cvoid}), nep.handle, k, F, QT.ptr, k, rn, qn, C_NULL))
+            e = ek[1] == 1 ? rn ./ (qn .* vec(transpose(ek[2]) * abs.(F))) : rn ./ qn  # src/errmeasure.jl:128-130,186-190
+            conv_eig = count(<(tol), e)
+            idx = sortperm(e); err[k, 1:k] = e[idx]                                      # :222-223
+            if k == m || conv_eig >= neigs                                               # :225-229
+                nrof = Int(min(length(λ), neigs)); λ = λ[idx[1:nrof]]; idx = idx[1:nrof]
+            end
+            conv_eig_hist[k] = conv_eig
+        end
+        k += 1
+    end
+    k -= 1
+    function columns(cols)                        # the chosen columns of the row-major Ritz block as a host n x length(cols) matrix
+        isempty(cols) && return Matrix{ComplexF64}(undef, n, 0)
+        Qd = DevBuf(n, length(cols))
+        chk(ccall((:nep_rowmajor_to_colmajor, LIB), Cint, (Int64, Int32, Ptr{Cvoid}, Int64, Ptr{Int32}, Int32, Ptr{Cvoid}, Int64,
+                  Ptr{Cvoid}), n, kq, QT.ptr, kq, Int32.(cols .- 1), length(cols), Qd.ptr, n, C_NULL))
+        download(Qd)
+    end
+    if conv_eig < neigs && neigs != Inf                                                  # :241-251
+        msg = "Number of iterations exceeded. maxit=$(maxit)."
+        conv_eig < 3 && (msg = string(msg, " Check that σ is not an eigenvalue."))
+        throw(NoConvergenceException(λ, columns(idx[1:length(λ)]), err[k, 1:length(λ)], msg))
+    end
+    nc = min(length(λ), conv_eig)
+    Z.cols = k
+    return λ[1:nc], columns(idx[1:nc]), Z, conv_eig_hist
 end
 
 # ---- rectangular operators and plain dense products (low-rank NLEIGS factors, waveguide Schur complement) ---

@@ -19,6 +19,7 @@ class NepError(RuntimeError):
 
 
 NEP_OK, NEP_ERR_HIP, NEP_ERR_ARG, NEP_ERR_SINGULAR, NEP_ERR_BREAKDOWN, NEP_ERR_UNSUPPORTED = 0, -1, -2, -3, -4, -5
+NEP_ERR_RETRY, NEP_ERR_NOCONV = -6, -7
 
 
 def _load():
@@ -55,6 +56,19 @@ P = C.POINTER
 
 class cdouble(C.Structure):
     _fields_ = [("re", c_dbl), ("im", c_dbl)]
+
+
+class IarOpts(C.Structure):                    # nep_iar_opts (include/nepmi355.h)
+    _fields_ = [("maxit", c_i32), ("check_error_every", c_i32), ("orth_method", c_i32), ("umfpack_refinements", c_i32),
+                ("errmeasure", c_i32), ("refine_hint", c_i32), ("tol", c_dbl), ("neigs", c_dbl), ("sigma", cdouble), ("gamma", cdouble)]
+
+
+class IarResult(C.Structure):                  # nep_iar_result
+    _fields_ = [("k", c_i32), ("nconv", c_i32), ("nret", c_i32), ("refine_plan", c_i32), ("refine_hint_off", c_i32),
+                ("retry_reason", c_i32)]
+
+
+FV_EVAL = C.CFUNCTYPE(c_i32, c_vp, c_i32, c_vp, c_vp)     # nep_fv_eval
 
 
 # name -> argtypes (restype is always int32 unless listed)
@@ -146,6 +160,8 @@ SIGNATURES = {
     "nep_iar_steps": [c_vp, c_i32, c_i32, c_i32, c_vp],
     "nep_iar_wait": [c_vp, c_i32],
     "nep_iar_stream_wait": [c_vp, c_i32, c_vp],
+    "nep_refine_review": [c_i32, c_i32, c_i32, c_vp, c_i32, c_vp],
+    "nep_iar_run": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "nep_hess_eig_worksize": [c_i32, P(c_i64)],
     "nep_hess_eigvals_dev": [c_i32, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp],
     "nep_hess_eigvecs_dev": [c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp],

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libnepmi355.so")
-SOURCES = ["util.hip", "spmv.hip", "spmv_tile.hip", "orth.hip", "gemm.hip", "trsv.hip", "trsv_ml.hip", "comm.hip", "driver.hip", "wep.hip", "lufac.hip", "hesseig.hip"]
+SOURCES = ["util.hip", "spmv.hip", "spmv_tile.hip", "orth.hip", "gemm.hip", "trsv.hip", "trsv_ml.hip", "comm.hip", "driver.hip", "wep.hip", "lufac.hip", "hesseig.hip", "iar_run.hip"]
 
 
 def _torch_lib_dir():

@@ -198,7 +198,7 @@ int nep_tiles_resid_cm(const NepTiles* t, int k, const cplx* dF, const cplx* Q, 
 int nep_tiles_resid(const NepTiles* t, int k, const cplx* dF, const cplx* QT, int64_t ldq, cplx* ZT, int64_t ldz, double* partial,
                     int64_t split_row, hipStream_t st);
 // K2 in super-panels of 8 columns, entries in registers (k_tile_resid_sp): either layout of Q / R (cm != 0: column-major)
-bool nep_tiles_resid_sp_ok(const NepTiles* t, int k);
+bool nep_tiles_resid_sp_ok(const NepTiles* t, int k, int cm);
 int nep_tiles_resid_sp(const NepTiles* t, int k, const cplx* dF, const cplx* Q, int64_t ldq, int cm, cplx* R, int64_t ldr,
                        double* partial, int64_t split_row, hipStream_t st);
 }

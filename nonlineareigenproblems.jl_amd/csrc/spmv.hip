@@ -987,10 +987,10 @@ static bool use_tiles_k2(const nep_spmf* s, int k) {
 
 // K2 in super-panels (k_tile_resid_sp, spmv_tile.hip): NEP_K2_SP = 0 never, 1 (default) on large matrices (those with a SELL copy: the
 // sizes at which K2 is bound by HBM; at gun size the wave-per-row kernel's gathers are L2 hits), 2 whenever the tiles allow it (tests)
-static bool use_sp_k2(const nep_spmf* s, int k) {
+static bool use_sp_k2(const nep_spmf* s, int k, int cm) {
     static const int mode = getenv("NEP_K2_SP") ? atoi(getenv("NEP_K2_SP")) : 1;
     const int m = g_k2_sp_mode >= 0 ? g_k2_sp_mode : mode;
-    if (m == 0 || !s->tiles || !nep_tiles_resid_sp_ok(s->tiles, k)) return false;
+    if (m == 0 || !s->tiles || !nep_tiles_resid_sp_ok(s->tiles, k, cm)) return false;
     return m == 2 || s->d_sell_ptr != nullptr;
 }
 
@@ -1161,7 +1161,7 @@ static int resid_panels(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
         if (rc) return rc;
         rc = s->ring.upload(s->coef.dptr, hF + (size_t)j0 * s->mt, cbytes, st);
         if (rc) return rc;
-        const bool sp = use_sp_k2(s, kk);
+        const bool sp = use_sp_k2(s, kk, 0);
         const bool tiled = sp || use_tiles_k2(s, kk);
         int grid = tiled ? nep_tiles_nblk(s->tiles) : (int)std::min<int64_t>((s->n + 3) / 4, 2048);
         rc = s->part.ensure(((size_t)grid * 2 * kk + 2 * kk) * sizeof(double));
@@ -1238,7 +1238,7 @@ int32_t nep_resid_batch_cm_dev(nep_spmf* s, int32_t k, const nep_cdouble* hF, co
     double* partial = (double*)s->part.dptr;
     // (up to two panels the older kernel -- many short-lived workgroups per CU -- hides a block's start-up better: 69 against 77 us at k = 8)
     static const int sp_cm_kmin = getenv("NEP_K2_SP_CM_KMIN") ? atoi(getenv("NEP_K2_SP_CM_KMIN")) : 9;
-    if (use_sp_k2(s, k) && (k >= sp_cm_kmin || g_k2_sp_mode == 2))
+    if (use_sp_k2(s, k, 1) && (k >= sp_cm_kmin || g_k2_sp_mode == 2))
         rc = nep_tiles_resid_sp(s->tiles, k, (const cplx*)s->coef.dptr, (const cplx*)dQ, ldq, 1, (cplx*)dR_tail, ldt, partial, row0 < 0 ? -1 : row0, st);
     else
         rc = nep_tiles_resid_cm(s->tiles, k, (const cplx*)s->coef.dptr, (const cplx*)dQ, ldq, (cplx*)dR_tail, ldt, partial, row0 < 0 ? -1 : row0, st);
@@ -1265,7 +1265,7 @@ int32_t nep_resid_block(nep_spmf* s, int32_t k, const nep_cdouble* hF, const nep
         const cplx* F = (const cplx*)s->coef.dptr + (size_t)j0 * s->mt;
         const cplx* Q = (const cplx*)dQT + j0;
         cplx* R = (cplx*)dRT + j0;
-        if (use_sp_k2(s, kk)) rc = nep_tiles_resid_sp(s->tiles, kk, F, Q, ldq, 0, R, ldr, nullptr, -1, st);
+        if (use_sp_k2(s, kk, 0)) rc = nep_tiles_resid_sp(s->tiles, kk, F, Q, ldq, 0, R, ldr, nullptr, -1, st);
         else if (use_tiles_k2(s, kk)) rc = nep_tiles_resid(s->tiles, kk, F, Q, ldq, R, ldr, nullptr, -1, st);
         else if (s->valbytes == 8) rc = launch_spmm<double>(s, kk, F, Q, ldq, 0, R, ldr, nullptr, grid, st);
         else rc = launch_spmm<cplx>(s, kk, F, Q, ldq, 0, R, ldr, nullptr, grid, st);

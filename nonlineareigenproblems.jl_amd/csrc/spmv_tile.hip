@@ -1305,9 +1305,13 @@ static size_t sp_shmem(const NepTiles* t, int nthr) {
     const int fpad = SP_FPAD(nthr);
     return (size_t)2 * SP_PSW * fpad * sizeof(cplx) + (size_t)2 * (nthr / 64) * 2 * SP_PSW * sizeof(double) + (size_t)fpad * 4;
 }
-bool nep_tiles_resid_sp_ok(const NepTiles* t, int k) {
+bool nep_tiles_resid_sp_ok(const NepTiles* t, int k, int cm) {
     (void)k;
     if (!t || !t->slotted || t->mt > 8 || t->wmax > 8 || t->rbmax > 1024) return false;
+    // the row's entries carry their tile BYTE offset in 16 bits (sp_entries, SpMap::entry_off): 16 f column-major, 64 f + 16 g(f)
+    // row-major -- a footprint slot f >= 1024 of the row-major tile does not fit (fpad is 1152 with 1024-thread workgroups, a
+    // 14 x 64 patch has a 16 x 66 = 1056-slot footprint); such matrices take the older row-major kernels
+    if (!cm && t->fcap > 1024) return false;
     const int nthr = sp_threads(t);
     const int fpad = SP_FPAD(nthr);
     if (t->fcap > fpad || SP_PSW * (fpad / 64) > SP_IMAX * (nthr / 64)) return false;          // tile pitch; DMA instructions per wave
@@ -1315,7 +1319,7 @@ bool nep_tiles_resid_sp_ok(const NepTiles* t, int k) {
 }
 int nep_tiles_resid_sp(const NepTiles* t, int k, const cplx* dF, const cplx* Q, int64_t ldq, int cm, cplx* R, int64_t ldr,
                        double* partial, int64_t split_row, hipStream_t st) {
-    if (!nep_tiles_resid_sp_ok(t, k)) { nep_set_error("super-panel K2: not available for this matrix / k = %d", k); return NEP_ERR_ARG; }
+    if (!nep_tiles_resid_sp_ok(t, k, cm)) { nep_set_error("super-panel K2: not available for this matrix / k = %d / layout %d", k, cm); return NEP_ERR_ARG; }
     const int nthr = sp_threads(t);
     const size_t shm = sp_shmem(t, nthr) + (size_t)SP_FPAD(nthr) * 4;          // (+ the second footprint list of the persistent form)
     static const int swz = env_int("NEP_XCD_SWIZZLE", 1);

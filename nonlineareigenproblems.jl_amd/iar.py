@@ -36,6 +36,11 @@ class _RefinementMiss(Exception):
     """a step's recorded backward errors show that UMFPACK's rule wanted more refinement than the step took"""
 
 
+class _NativeRunMiss(Exception):
+    """nep_iar_run returned NEP_ERR_RETRY for a reason the step-at-a-time pipeline handles itself (a device eigen-decomposition
+    that reported a failure: that pipeline redoes the one decomposition with LAPACK)"""
+
+
 class _OrthPassMiss(Exception):
     """the device-side DGKS of a step still met the re-orthogonalisation criterion after its last ENQUEUED pass (the
     reference's IterativeSolvers DGKS repeats while ||w|| < ||c|| / sqrt(2), without a bound): the call is re-run with the
@@ -65,12 +70,19 @@ def iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 1
                 raise
             iar.orth_pass_misses += 1
             flags["_force_sync"] = True
+        except _NativeRunMiss:
+            if flags.get("_native_run") is False:
+                raise
+            iar.native_run_misses += 1
+            flags["_native_run"] = False
         if errhist is not None:
             del errhist[:]
 
 
 iar.refinement_misses = 0            # calls that were re-run with checked solves (diagnostics, tests)
 iar.orth_pass_misses = 0             # calls that were re-run because a step wanted more DGKS passes than were enqueued
+iar.native_run_misses = 0           # calls whose one-call native run (nep_iar_run) was re-run through the step-at-a-time pipeline
+iar.native_runs = 0                 # calls served by nep_iar_run
 iar.dev_eig_fallbacks = 0            # checks whose device eigen-decomposition reported a failure and was redone by LAPACK
 
 
@@ -155,9 +167,94 @@ def _eig_work_release(w):
             free.append(w)
 
 
+def _native_errmeasure(errmeasure, nep):
+    """(kind, fro) of an error measure nep_iar_run evaluates itself (0: ||M(lam)v|| / ||v||, 1: the SPMF backward error), or None"""
+    from .errmeasure import ResidualErrmeasure, StandardSPMFErrmeasure
+    e = getattr(errmeasure, "errm", errmeasure) if isinstance(errmeasure, DefaultErrmeasure) else errmeasure
+    if type(e) is StandardSPMFErrmeasure and e.nep is nep:
+        return 1, np.ascontiguousarray(e.coeffs, dtype=np.float64)
+    if type(e) is ResidualErrmeasure and e.nep is nep:
+        return 0, None
+    return None
+
+
+def _iar_native_run(nep, M0inv, orthmethod, m, tol, neigs, errkind, sigma, gamma, v, check_error_every, errhist, return_device):
+    """the whole run as ONE foreign call (csrc/iar_run.hip nep_iar_run) -- what the Julia binding's `iar(nep::DeviceSPMF; ...)`
+    method calls too (julia/NEPMI355X.jl); this host only marshals the inputs (derivative table, start vector, the f_t(lambda)
+    callback) and shapes the outputs.  method_iar.jl:46-182."""
+    import ctypes as _C
+    from ._lib import IarOpts, IarResult, FV_EVAL, hptr, cdouble, NEP_ERR_RETRY, NEP_ERR_NOCONV
+    n = nep.size(1)
+    fv = nep.get_fv(); mt = len(fv)
+    alpha = gamma ** np.arange(m + 1); alpha[0] = 0
+    tab = nep.derivative_table(sigma, m)
+    Ctab = np.asfortranarray((alpha[1:m + 1] / np.arange(1, m + 1))[:, None] * tab["fD"][1:m + 1, :], dtype=np.complex128)   # m x mt
+    v0 = np.ascontiguousarray(v, dtype=np.complex128)
+    rc_ = M0inv.refine_coefficients() if M0inv.umfpack_refinements > 0 else None
+    if M0inv.umfpack_refinements > 0 and rc_ is None:
+        return None
+    hint = M0inv._recorded_plan if M0inv._recorded_plan is not None else M0inv._hint()
+    o = IarOpts(m, int(check_error_every), dense._orth_code(orthmethod), int(max(0, M0inv.umfpack_refinements)), errkind[0],
+                -1 if hint is None else int(hint), float(tol), float(neigs), cdouble(sigma.real, sigma.imag), cdouble(gamma.real, gamma.imag))
+    res = IarResult()
+
+    def fv_eval(ctx, nlam, lam_p, F_p):
+        try:
+            la = np.frombuffer((_C.c_double * (2 * nlam)).from_address(lam_p), dtype=np.complex128)
+            F = np.frombuffer((_C.c_double * (2 * nlam * mt)).from_address(F_p), dtype=np.complex128).reshape(nlam, mt)
+            for t, f in enumerate(fv):
+                F[:, t] = f.values(la)
+            return 0
+        except Exception:              # an exception must not cross the foreign frame: reported as a failed callback
+            import traceback
+            traceback.print_exc()
+            return 1
+    cb = FV_EVAL(fv_eval)
+    ldv = n * (m + 1)
+    V = torch.empty((m + 1, ldv), dtype=CDT, device="cuda")
+    Qd = torch.empty((m, n), dtype=CDT, device="cuda") if return_device else None
+    Qh = None if return_device else torch.empty((m, n), dtype=CDT, pin_memory=True)
+    lam = np.zeros(m, dtype=np.complex128)
+    err = np.full((m, m), np.nan, order="F")
+    st = lib.nep_iar_run(nep.dev.h, M0inv.lu.h, n, _C.addressof(o), hptr(v0), hptr(Ctab), mt,
+                         hptr(rc_[0]) if rc_ else None, hptr(rc_[1]) if rc_ else None, hptr(errkind[1]) if errkind[1] is not None else None,
+                         _C.cast(cb, c_vp), None, hptr(lam), c_vp(Qd.data_ptr()) if Qd is not None else None,
+                         c_vp(Qh.data_ptr()) if Qh is not None else None, hptr(err), c_vp(V.data_ptr()), _C.addressof(res), stream_ptr())
+    # what the run learnt about the refinement count belongs to this NEP and shift (FactorizeLinSolver._hint)
+    if res.refine_hint_off:
+        M0inv._note_hint(None)
+    elif res.refine_plan >= 0 and M0inv.umfpack_refinements > 0:
+        M0inv._recorded_plan = int(res.refine_plan)
+        M0inv._note_hint(int(res.refine_plan))
+    if st == NEP_ERR_RETRY:
+        if res.retry_reason == 1:
+            raise _RefinementMiss(0)
+        if res.retry_reason == 2:
+            raise _OrthPassMiss(0)
+        raise _NativeRunMiss(res.retry_reason)
+    if st not in (0, NEP_ERR_NOCONV):
+        check(st)
+    iar.native_runs += 1
+    k = int(res.k); nret = int(res.nret)
+    M0inv.solves += k
+    if errhist is not None:
+        for kc in range(1, k + 1):
+            if kc % check_error_every == 0 or kc == m:
+                errhist.append(err[kc - 1, :kc].copy())
+    lam = lam[:nret].copy()
+    Q = Qd[:nret] if return_device else Qh.numpy()[:nret].T
+    if st == NEP_ERR_NOCONV:
+        msg = "Number of iterations exceeded. maxit=%d." % m
+        if res.nconv < 3:
+            msg += "Try to change the inner_solver_method for better performance."
+        raise NoConvergenceException(lam, to_host(Qd[:nret]) if return_device else Q, err[k - 1, :nret].copy(), msg)
+    return lam, Q, V[:k]
+
+
 def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 10000, neigs=6,
          errmeasure=None, sigma=0.0, gamma=1.0, v=None, logger=0, check_error_every=1, proj_solve=False,
-         errhist=None, timers=None, return_device=False, inner_solver_method=None, _native_step=True, _force_sync=False):
+         errhist=None, timers=None, return_device=False, inner_solver_method=None, _native_step=True, _force_sync=False,
+         _native_run=True):
     t_entry = time.perf_counter()
     n = nep.size(1); m = int(maxit)
     sigma = complex(sigma); gamma = complex(gamma)
@@ -167,6 +264,25 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
         errmeasure = DefaultErrmeasure(nep)
     if v is None:
         v = np.random.randn(n)
+    # ---- the one-call route: pure SPMF operator, device LU, DGKS / CGS, an error measure the library evaluates itself
+    M0inv = None
+    if (_native_run and _native_step and not _force_sync and timers is None and not proj_solve and m <= dense.HESS_EIG_KMAX
+            and dense._orth_code(orthmethod) in (0, 1) and os.environ.get("NEP_IAR_NATIVE_RUN", "1") != "0"
+            and not any(os.environ.get(e) for e in ("NEP_IAR_SYNC", "NEP_IAR_PYSTEP", "NEP_IAR_TRACE", "NEP_IAR_ONE_STREAM", "NEP_IAR_PASSES"))
+            and os.environ.get("NEP_IAR_EIG", "dev") != "host"):
+        from .linsolvers import FactorizeLinSolver
+        from .nep import AbstractSPMF
+        errkind = _native_errmeasure(errmeasure, nep)
+        pure = (isinstance(nep, AbstractSPMF) and type(nep).lincomb_rowscale is AbstractSPMF.lincomb_rowscale
+                and type(nep).compute_Mlincomb is AbstractSPMF.compute_Mlincomb and type(nep).resid_norms is AbstractSPMF.resid_norms
+                and hasattr(nep, "dev"))
+        if errkind is not None and pure:
+            M0inv = create_linsolver(linsolvercreator, nep, sigma)
+            if type(M0inv) is FactorizeLinSolver and getattr(M0inv.lu, "h", None):
+                out = _iar_native_run(nep, M0inv, orthmethod, m, tol, neigs, errkind, sigma, gamma, v, check_error_every, errhist,
+                                      return_device)
+                if out is not None:
+                    return out
     tm = timers if timers is not None else {}
     for key in ("mlincomb", "solve", "orth", "ritz", "resid", "host_eig"):
         tm.setdefault(key, 0.0)
@@ -215,7 +331,8 @@ def _iar(nep, orthmethod=dense.DGKS, maxit=30, linsolvercreator=None, tol=EPS * 
         filled = [False] * (m + 1)
     t_ls = time.perf_counter()
     t_marks.append(("pre", t_ls))
-    M0inv = create_linsolver(linsolvercreator, nep, sigma)
+    if M0inv is None:
+        M0inv = create_linsolver(linsolvercreator, nep, sigma)
     sync(); tm["linsolver_setup"] = tm.get("linsolver_setup", 0.0) + time.perf_counter() - t_ls
     t_setup_done = time.perf_counter()
     if timers is not None and hasattr(M0inv, "lu"):

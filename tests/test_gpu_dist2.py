@@ -73,9 +73,9 @@ def test_sharded_beyn_two_ranks_one_gpu(na, tmp_path, device_lu):
     assert np.abs(a - b).max() <= 1e-8 * np.abs(a).max()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_bench_two_ranks_rehearsal(na, world):
-    """bench.py under torch.distributed.run with two (four) ranks sharing the GPU (NEP_BENCH_SHARE_GPU=1: gloo process group, host-staged
+    """bench.py under torch.distributed.run with two (four; eight = the shape an 8-GPU node runs: 8 nodes per rank) ranks sharing the GPU (NEP_BENCH_SHARE_GPU=1: gloo process group, host-staged
     contour exchange): the N > 1 code path of the benchmark -- replicas of the headline step, max-over-ranks timing, ONE JSON
     line from rank 0, the sharded contour_beyn extra with 64 / world nodes per rank and its parity block"""
     import json
@@ -84,7 +84,7 @@ def test_bench_two_ranks_rehearsal(na, world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
            "--no-cpu-baseline", "--no-wep-roofline", "--no-c3", "--no-c5", "--no-beyn-parity"]
-    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -97,6 +97,7 @@ def test_bench_two_ranks_rehearsal(na, world):
     pr = b["per_rank"]
     assert [p["rank"] for p in pr] == list(range(world)) and all(p["nodes"] == 64 // world for p in pr)
     assert all(p["exchange_s"] is not None and p["exchange_s"] > 0 for p in pr)
+    assert all(p.get("factorise_nodes_s") is not None and p["factorise_nodes_s"] > 0 for p in pr)
     assert abs(max(p["wall_s"] for p in pr) - b["seconds"]) < 0.05
 
 

@@ -38,11 +38,108 @@ def test_c2_gun_iar_m100_fullsize(na):
     # SURVEY.md section 8d parity rules (i), (iii), (iv) against the CPU oracle ON THE SAME full-size configuration (about 10 s):
     # same count, eigenvalue multiset to 1e-8 relative, per-iteration error history within a factor 10 above 1e-12
     bc = _bc()
-    oh = []
-    lo, Qo = bc.c2_oracle(n, maxit=100, hist=oh)
+    lo, oh = _c2_oracle(n)
     par = bc.c2_parity(lam, hist, lo, oh)
     assert par["same_count"] and par["eigenvalues_match_1e-8"], par
     assert par["history_within_x10_above_1e-12"] and par["history_entries_compared"] > 100, par
+
+
+_C2_ORACLE = {}
+
+
+def _c2_oracle(n):
+    """the CPU oracle on config C2 (about 10 s), once per test process"""
+    if n not in _C2_ORACLE:
+        oh = []
+        lo, _ = _bc().c2_oracle(n, maxit=100, hist=oh)
+        _C2_ORACLE[n] = (lo, oh)
+    return _C2_ORACLE[n]
+
+
+def test_c2_through_the_c_abi_only_in_the_julia_call_order(na):
+    """config C2 driven through ctypes ONLY, in the call order of `iar(::Type{T}, nep::DeviceSPMF; ...)` of julia/NEPMI355X.jl
+    (no iar.py, no linsolvers.py, no nep.py device wrappers): DeviceSPMF(org) = nep_spmf_create on the CSR of each term;
+    create_linsolver(DeviceLinSolverCreator) = a host LU (SuperLU here, UMFPACK there) -> nep_lu_create_csc; derivative table,
+    |f_t(sigma)|, ||A_t||_F on the host; ONE nep_iar_run with the f_t(lambda) callback.  46 pairs, parity with the CPU oracle by
+    SURVEY section 8d rules (i), (iii), (iv); residuals re-evaluated on the host."""
+    import ctypes as C
+    import scipy.sparse.linalg as spla
+    from nep_amd import _lib
+    lib = _lib.lib
+    nep = na.nep_gallery("gun_spmf_scaled"); n = nep.n
+    Av = [sp.csr_matrix(A) for A in nep.get_Av()]; fv = nep.get_fv(); mt = len(Av)
+    # ---- DeviceSPMF(org)
+    keep = []
+    rp = (C.c_void_p * mt)(); ci = (C.c_void_p * mt)(); vv = (C.c_void_p * mt)(); isc = (C.c_int32 * mt)()
+    for t, A in enumerate(Av):
+        A.sort_indices()
+        r = np.ascontiguousarray(A.indptr, dtype=np.int32); c = np.ascontiguousarray(A.indices, dtype=np.int32)
+        cplx = np.iscomplexobj(A.data) and np.any(A.data.imag != 0)
+        v = np.ascontiguousarray(A.data, dtype=np.complex128 if cplx else np.float64)
+        keep += [r, c, v]
+        rp[t] = r.ctypes.data; ci[t] = c.ctypes.data; vv[t] = v.ctypes.data; isc[t] = 1 if cplx else 0
+    spmf = C.c_void_p()
+    _lib.check(lib.nep_spmf_create(n, mt, rp, ci, vv, isc, C.byref(spmf)))
+    # ---- create_linsolver(DeviceLinSolverCreator(), nep, sigma): host factorisation of M(sigma), factors to the device as they are
+    sigma = 0.0 + 0.0j; gamma = 1.0 + 0.0j; m = 100
+    cf = np.ascontiguousarray([f(sigma) for f in fv], dtype=np.complex128); cabs = np.ascontiguousarray(np.abs(cf))
+    M0 = sp.csc_matrix(sum(c * A for c, A in zip(cf, Av)), dtype=np.complex128)
+    F = spla.splu(M0, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    L = sp.csc_matrix(F.L); U = sp.csc_matrix(F.U)
+    arr = [np.ascontiguousarray(x, dtype=np.int32) for x in (L.indptr, L.indices, U.indptr, U.indices, F.perm_r, F.perm_c)]
+    Lx = np.ascontiguousarray(L.data, dtype=np.complex128); Ux = np.ascontiguousarray(U.data, dtype=np.complex128)
+    lu = C.c_void_p()
+    _lib.check(lib.nep_lu_set_expected_solves(200))
+    _lib.check(lib.nep_lu_create_csc(n, _lib.hptr(arr[0]), _lib.hptr(arr[1]), _lib.hptr(Lx), _lib.hptr(arr[2]), _lib.hptr(arr[3]),
+                                     _lib.hptr(Ux), _lib.hptr(arr[4]), _lib.hptr(arr[5]), C.byref(lu)))
+    # ---- host inputs of the run: Ctab[j-1, t] = gamma^j / j f_t^(j)(sigma), ||A_t||_F, the callback
+    fD = np.column_stack([f.derivs(sigma, m + 1) for f in fv])
+    Ctab = np.asfortranarray((gamma ** np.arange(1, m + 1) / np.arange(1, m + 1))[:, None] * fD[1:m + 1, :], dtype=np.complex128)
+    fro = np.ascontiguousarray([np.sqrt((abs(A.data) ** 2).sum()) for A in Av])
+    ncalls = [0]
+
+    def fv_eval(ctx, nlam, lam_p, F_p):
+        la = np.frombuffer((C.c_double * (2 * nlam)).from_address(lam_p), dtype=np.complex128)
+        Fm = np.frombuffer((C.c_double * (2 * nlam * mt)).from_address(F_p), dtype=np.complex128).reshape(nlam, mt)
+        for t, f in enumerate(fv):
+            Fm[:, t] = [f(x) for x in la]
+        ncalls[0] += 1
+        return 0
+    cb = _lib.FV_EVAL(fv_eval)
+    o = _lib.IarOpts(m, 1, 0, 10, 1, -1, 1e-10, float("inf"), _lib.cdouble(0.0, 0.0), _lib.cdouble(1.0, 0.0))
+    res = _lib.IarResult()
+    lam = np.zeros(m, dtype=np.complex128); Q = np.zeros((m, n), dtype=np.complex128); err = np.full((m, m), np.nan, order="F")
+    v0 = np.ones(n, dtype=np.complex128)
+    st = lib.nep_iar_run(spmf, lu, n, C.addressof(o), _lib.hptr(v0), _lib.hptr(Ctab), mt, _lib.hptr(cabs), _lib.hptr(cf), _lib.hptr(fro),
+                         C.cast(cb, C.c_void_p), None, _lib.hptr(lam), None, _lib.hptr(Q), _lib.hptr(err), None, C.addressof(res), None)
+    _lib.check(st)
+    assert res.k == m and res.nret == 46 and res.nconv == 46 and ncalls[0] == m and res.retry_reason == 0
+    assert 1 <= res.refine_plan <= 2
+    lam = lam[:res.nret]; Q = Q[:res.nret].T
+    for s in range(len(lam)):                                     # host FP64 re-evaluation, the reference's criterion
+        r = sum(f(lam[s]) * (A @ Q[:, s]) for A, f in zip(Av, fv))
+        den = sum(c * abs(f(lam[s])) for c, f in zip(fro, fv)) * np.linalg.norm(Q[:, s])
+        assert np.linalg.norm(r) / den < 1e-10
+    hist = [err[kc - 1, :kc].copy() for kc in range(1, m + 1)]
+    assert all(np.all(np.diff(h) >= 0) for h in hist)             # every row sorted (method_iar.jl:150-151)
+    lo, oh = _c2_oracle(n)
+    par = _bc().c2_parity(lam, hist, lo, oh)
+    assert par["same_count"] and par["eigenvalues_match_1e-8"], par
+    assert par["history_within_x10_above_1e-12"] and par["history_entries_compared"] > 100, par
+    # a second run with the learnt refinement count as the hint, and a finite neigs: ends early with exactly neigs pairs
+    o2 = _lib.IarOpts(m, 1, 0, 10, 1, res.refine_plan, 1e-10, 12.0, _lib.cdouble(0.0, 0.0), _lib.cdouble(1.0, 0.0))
+    res2 = _lib.IarResult(); lam2 = np.zeros(m, dtype=np.complex128)
+    _lib.check(lib.nep_iar_run(spmf, lu, n, C.addressof(o2), _lib.hptr(v0), _lib.hptr(Ctab), mt, _lib.hptr(cabs), _lib.hptr(cf), _lib.hptr(fro),
+                               C.cast(cb, C.c_void_p), None, _lib.hptr(lam2), None, None, None, None, C.addressof(res2), None))
+    assert res2.nret == 12 and res2.nconv >= 12 and res2.k < m
+    assert max(np.min(abs(lam - x)) for x in lam2[:12]) < 1e-9
+    # too few steps for the request: NEP_ERR_NOCONV, the best pairs are returned all the same
+    o3 = _lib.IarOpts(20, 1, 0, 10, 1, res.refine_plan, 1e-10, 30.0, _lib.cdouble(0.0, 0.0), _lib.cdouble(1.0, 0.0))
+    res3 = _lib.IarResult(); lam3 = np.zeros(20, dtype=np.complex128)
+    st3 = lib.nep_iar_run(spmf, lu, n, C.addressof(o3), _lib.hptr(v0), _lib.hptr(Ctab[:20].copy(order="F")), mt, _lib.hptr(cabs), _lib.hptr(cf),
+                          _lib.hptr(fro), C.cast(cb, C.c_void_p), None, _lib.hptr(lam3), None, None, None, None, C.addressof(res3), None)
+    assert st3 == _lib.NEP_ERR_NOCONV and res3.k == 20 and res3.nret == 20 and res3.nconv < 30
+    _lib.check(lib.nep_lu_destroy(lu)); _lib.check(lib.nep_spmf_destroy(spmf))
 
 
 def test_c2_pipelined_iar_equals_step_synchronous(na, monkeypatch):

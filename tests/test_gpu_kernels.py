@@ -1273,7 +1273,7 @@ def test_dense_inverse_gauss_jordan_on_the_device(na, n):
                 assert info.value != 0 or not np.isfinite(oh).all() or np.abs(oh).max() > 1e8
 
 
-@pytest.mark.parametrize("case", ["wep", "gun", "wep_small_patch"])
+@pytest.mark.parametrize("case", ["wep", "gun", "wep_small_patch", "wep_tall_patch"])
 def test_resid_batch_super_panel_kernel(na, case, monkeypatch):
     """K2 in super-panels (k_tile_resid_sp: one workgroup per block, the row's entries in registers, 4-column footprint tiles filled by
     LDS-DMA, double-buffered) against NumPy and against the older kernels, for BOTH layouts of the Ritz block: row-major
@@ -1287,10 +1287,19 @@ def test_resid_batch_super_panel_kernel(na, case, monkeypatch):
         K, M, W1, W2 = gallery.gun_matrices(); Av = [K, -M, W1, W2]
     elif case == "wep":
         Av = wep.WaveguideData(303, 299, "JARLEBRING").big_matrices()
+    elif case == "wep_tall_patch":
+        # a 14 x 64 patch: footprint 16 x 66 = 1056 slots, inside the tile pitch of a 1024-thread workgroup (1152) but beyond what
+        # the 16-bit byte offset of the ROW-major tile can address (slot >= 1024): row-major blocks must take the older kernels,
+        # column-major ones stay on the super-panel kernel (silent wrong residuals before)
+        monkeypatch.setenv("NEP_K1_TILE_XP", "14"); monkeypatch.setenv("NEP_K1_TILE_ZP", "64")
+        Av = wep.WaveguideData(303, 299, "JARLEBRING").big_matrices()
     else:
         Av = wep.WaveguideData(61, 37, "JARLEBRING").big_matrices()          # blocks cut by the grid's edge, short footprints
     dev = na.SPMFDevice(Av)
     n, mt = dev.n, dev.mt
+    if case == "wep_tall_patch":
+        ti = dev.tile_info()
+        assert ti["blocks"] > 0 and 1024 < ti["max_footprint"] <= 1152, ti
     try:
         for k, ldq in ((1, 1), (3, 5), (4, 4), (7, 8), (8, 8), (13, 16), (60, 60), (61, 64)):
             Q = rng.standard_normal((n, ldq)) + 1j * rng.standard_normal((n, ldq))

@@ -217,6 +217,7 @@ def test_iar_device_eig_failure_falls_back_to_lapack(na, monkeypatch):
     nep = na.nep_gallery("gun_spmf_scaled", n)
     kw = dict(sigma=0.0, gamma=1.0, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10)
     monkeypatch.setenv("NEP_IAR_EIG", "dev")
+    monkeypatch.setenv("NEP_IAR_NATIVE_RUN", "0")        # the step-at-a-time pipeline (the one-call route reports NEP_ERR_RETRY instead: next test)
     lam0, _, _ = na.iar(nep, **kw)
     # a refused LAUNCH of the eigenvalue kernel (a device that does not grant its LDS): every batch goes to the host, same result
     monkeypatch.setenv("NEP_IAR_EIG_LAUNCH_FAIL", "1")
@@ -231,6 +232,43 @@ def test_iar_device_eig_failure_falls_back_to_lapack(na, monkeypatch):
         lam1, _, _ = na.iar(nep, **kw)
         assert na.iar.dev_eig_fallbacks == fb0 + 1
         assert len(lam1) == len(lam0) and np.allclose(np.sort_complex(lam1), np.sort_complex(lam0), rtol=1e-10, atol=0)
+
+
+def test_iar_native_run_retry_routes(na, monkeypatch):
+    """nep_iar_run (the one-call route) reports NEP_ERR_RETRY when a step's record asks for what the enqueued work did not do; the
+    host then takes the route that can: checked solves (reason 1), the step-synchronous DGKS loop (2), the step-at-a-time pipeline
+    with its LAPACK fallback (3).  Injected at one step each; the call returns what the clean run returns."""
+    n, m = 2000, 40
+    nep = na.nep_gallery("gun_spmf_scaled", n)
+    kw = dict(sigma=0.0, gamma=1.0, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10)
+    r0 = na.iar.native_runs
+    h0 = []
+    lam0, Q0, _ = na.iar(nep, errhist=h0, **kw)
+    assert na.iar.native_runs == r0 + 1 and len(h0) == m
+    for kind, counter in ((1, "refinement_misses"), (2, "orth_pass_misses"), (3, "native_run_misses")):
+        monkeypatch.setenv("NEP_IAR_RUN_FAIL_AT", "%d:17" % kind)
+        c0 = getattr(na.iar, counter); r0 = na.iar.native_runs
+        h1 = []
+        lam1, Q1, _ = na.iar(nep, errhist=h1, **kw)
+        assert getattr(na.iar, counter) == c0 + 1 and na.iar.native_runs == r0
+        assert len(h1) == m and len(lam1) == len(lam0)
+        _match(lam1, lam0, 1e-10)
+    monkeypatch.delenv("NEP_IAR_RUN_FAIL_AT")
+    # a device basis, a device eigenvector block, a finite neigs and a check every 3rd step through the same entry point
+    lam2, Qd, V = na.iar(nep, return_device=True, **kw)
+    assert Qd.shape == (len(lam0), n) and V.shape[0] == m
+    Qh = na.to_host(Qd)                      # (the order of pairs with equal errors is not fixed from run to run: matched by eigenvalue)
+    for i, x in enumerate(lam2):
+        j = int(np.argmin(abs(lam0 - x)))
+        assert abs(lam0[j] - x) <= 1e-10 * max(1.0, abs(x))
+        a = Q0[:, j] / np.linalg.norm(Q0[:, j]); b = Qh[:, i] / np.linalg.norm(Qh[:, i])
+        assert abs(abs(np.vdot(a, b)) - 1.0) < 1e-8
+    h3 = []
+    lam3, _, _ = na.iar(nep, sigma=0.0, gamma=1.0, maxit=m, neigs=4, v=np.ones(n), tol=1e-10, check_error_every=3, errhist=h3)
+    assert len(lam3) == 4 and len(h3) < m // 3 + 1 and all(len(h) % 3 == 0 or len(h) == m for h in h3)
+    with pytest.raises(na.NoConvergenceException) as ei:
+        na.iar(nep, sigma=0.0, gamma=1.0, maxit=12, neigs=30, v=np.ones(n), tol=1e-10)
+    assert len(ei.value.lam) == 12 and ei.value.v.shape == (n, 12)
 
 
 def test_transf_shift_and_scale_iar_qdep0(na):
@@ -272,6 +310,7 @@ def test_iar_recorded_refinement_and_miss_fallback(na, monkeypatch):
     from nep_amd.linsolvers import FactorizeLinSolver
     n, m = 1310, 30
     nep = na.nep_gallery("gun_spmf_scaled", n)
+    monkeypatch.setenv("NEP_IAR_NATIVE_RUN", "0")        # the step-at-a-time pipeline: its host replays the rule in Python
     seen = []
     orig = FactorizeLinSolver.review_recorded
 

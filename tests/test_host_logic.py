@@ -655,7 +655,7 @@ def _julia_class(t):
 
 def _c_class(t):
     t = t.strip()
-    if "*" in t or re.match(r"(const\s+)?nep_stream\b", t):
+    if "*" in t or "[" in t or re.match(r"(const\s+)?(nep_stream|nep_fv_eval)\b", t):   # (arrays decay; nep_fv_eval: a function-pointer typedef)
         return "ptr"
     t = re.sub(r"\bconst\b", "", t).split()[0]
     return {"int32_t": "i32", "int": "i32", "int64_t": "i64", "size_t": "i64", "double": "f64", "nep_cdouble": "c128"}[t]
@@ -984,3 +984,126 @@ def test_pattern_digest_cache_notices_an_in_place_edit():
     assert k2 != k1
     B = A.copy()
     assert _DeviceRefactor.key(B, ("x",)) == k2                       # content decides, not the address
+
+
+def _struct_fields_c(hdr, name):
+    body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    out = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        typ, names = decl.split(None, 1)
+        for nm in names.split(","):
+            out.append((nm.strip(), {"int32_t": "i32", "double": "f64", "nep_cdouble": "c128"}[typ]))
+    return out
+
+
+def test_julia_and_ctypes_structs_match_the_header():
+    """nep_iar_opts / nep_iar_result are passed by reference from three places: the header's definition, the Julia `struct`s and
+    the ctypes Structures must list the same fields in the same order with the same widths"""
+    from nep_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "nepmi355.h")).read()
+    jl = open(os.path.join(ROOT, "julia", "NEPMI355X.jl")).read()
+    jmap = {"Int32": "i32", "Float64": "f64", "ComplexF64": "c128"}
+    cmap = {_lib.c_i32: "i32", _lib.c_dbl: "f64", _lib.cdouble: "c128"}
+    for cname, jname, ct in (("nep_iar_opts", "IarOpts", _lib.IarOpts), ("nep_iar_result", "IarResult", _lib.IarResult)):
+        want = _struct_fields_c(hdr, cname)
+        body = re.search(r"struct %s\b[^\n]*\n(.*?)\nend" % jname, jl, flags=re.S).group(1)
+        body = "\n".join(ln.split("#")[0] for ln in body.splitlines())
+        jf = [(a.strip(), jmap[b.strip()]) for a, b in re.findall(r"([A-Za-z_]+)::([A-Za-z0-9]+)", body)]
+        assert [t for _, t in jf] == [t for _, t in want], (cname, jf, want)
+        assert [n for n, _ in jf] == [n for n, _ in want], (cname, jf, want)
+        assert [(n, cmap[t]) for n, t in ct._fields_] == want, cname
+
+
+def test_julia_wrapper_types_accept_every_reference_spmf_type():
+    """Julia's type parameters are invariant: a field `org::AbstractSPMF{T}` with a concrete T cannot hold the reference's
+    `PEP <: AbstractSPMF{AbstractMatrix}` or `SPMFSumNEP <: AbstractSPMF{AbstractMatrix}` (round-5 defect: DeviceSPMF{T}).  Checked
+    against the reference's own struct declarations when the checkout is present: every AbstractSPMF subtype declared there must
+    be a legal value of every field of the glue that is typed AbstractSPMF..., and the glue's own subtypes of a parametric abstract
+    type must not carry a parametric field of that abstract type."""
+    jl = open(os.path.join(ROOT, "julia", "NEPMI355X.jl")).read()
+    jl_nc = "\n".join(ln.split("#")[0] for ln in jl.splitlines())
+    fields = re.findall(r"(\w+)::(AbstractSPMF[^\s;,)]*)", jl_nc)
+    assert fields, "the glue wraps an AbstractSPMF somewhere"
+    for name, typ in fields:
+        assert typ == "AbstractSPMF", "field / argument %s::%s is parametric: invariance excludes PEP and SPMFSumNEP" % (name, typ)
+    assert re.search(r"mutable struct DeviceSPMF <: AbstractSPMF\{AbstractMatrix\}", jl_nc)
+    assert "DeviceSPMF{" not in jl_nc
+    ref = "/root/reference/src"
+    if not os.path.isdir(ref):
+        pytest.skip("reference checkout not present (GPU box)")
+    decl = {}
+    for fn in os.listdir(ref):
+        if fn.endswith(".jl"):
+            for m in re.finditer(r"^\s*(?:mutable\s+)?struct\s+(\w+)(\{[^}]*\})?\s*<:\s*AbstractSPMF(\{[^}]*\})?", open(os.path.join(ref, fn)).read(), flags=re.M):
+                decl[m.group(1)] = m.group(3)
+    # the types the gallery hands out for the BASELINE problems are among them, with BOTH kinds of supertype parameter
+    assert decl.get("PEP") == "{AbstractMatrix}" and decl.get("SPMFSumNEP") == "{AbstractMatrix}" and decl.get("SPMF_NEP") == "{T}"
+    # the orthogonalisation method is dispatched on an INSTANCE (src/method_iar.jl:50 `orthmethod=DGKS()`, test/iar.jl:13-17)
+    assert re.search(r"^struct DeviceDGKS <: IterativeSolvers.OrthogonalizationMethod end", jl, flags=re.M)
+    assert "::Type{DeviceDGKS}" not in jl_nc and re.search(r"h::StridedVector\{ComplexF64\}, ::DeviceDGKS\)", jl_nc)
+    assert "orthmethod=DGKS()" in open(os.path.join(ref, "method_iar.jl")).read()
+    # the probe cache compares contents (Base.hash samples arrays of >= 8192 entries)
+    assert "hash(b)" not in jl_nc and "p[3] == b" in jl_nc
+
+
+def test_julia_iar_tiar_methods_mirror_the_reference_keywords():
+    """`iar(::Type{T}, nep::DeviceSPMF; ...)` / `tiar(...)` take exactly the keyword list of the reference's methods (an unchanged
+    caller's keywords must all be accepted), and their fallback `invoke`s the reference method with every one of them"""
+    ref = "/root/reference/src"
+    if not os.path.isdir(ref):
+        pytest.skip("reference checkout not present (GPU box)")
+    jl = open(os.path.join(ROOT, "julia", "NEPMI355X.jl")).read()
+
+    def kwnames(src, head):
+        i = src.index(head)
+        j = src.index("(", i)
+        sig = _balanced(src, j)
+        kws = sig.split(";", 1)[1]
+        return [re.match(r"\s*([\wσγ]+)", part).group(1) for part in _split_top(kws)]
+    for meth, fn in (("iar", "method_iar.jl"), ("tiar", "method_tiar.jl")):
+        rsrc = open(os.path.join(ref, fn)).read()
+        want = kwnames(rsrc, "function %s(" % meth)
+        have = kwnames(jl, "function %s(::Type{T}, nep::DeviceSPMF;" % meth)
+        assert have == want, (meth, have, want)
+        inv = jl[jl.index("invoke(%s, Tuple{Type{T},NEP}, T, nep;" % meth):]
+        inv = _balanced(inv, inv.index("("))
+        passed = re.findall(r"([\wσγ]+)\s*=\s*\1\b", inv)
+        assert sorted(passed) == sorted(want), (meth, passed, want)
+
+
+def test_refinement_rule_in_c_equals_the_python_host():
+    """UMFPACK's stopping rule replayed on recorded omegas exists twice: linsolvers.py review_recorded (the step-at-a-time host) and
+    csrc/iar_run.hip (nep_iar_run; exported as nep_refine_review).  Same verdict, same planned sweeps, same hint on a grid of omega
+    sequences around every threshold of the rule (no GPU needed)."""
+    import itertools
+    from nep_amd import _lib
+    from nep_amd.linsolvers import FactorizeLinSolver
+    eps = np.finfo(float).eps
+    vals = [0.0, 0.5 * eps, 1.9 * eps, 2.1 * eps, 3.9 * eps, 4.1 * eps, 1e-14, 0.49e-14, 0.51e-14, 1e-12, 1e-9, float("nan"), float("inf")]
+
+    class _Nep:
+        pass
+    n = 0
+    for umf in (1, 2, 10):
+        for plan in (0, 1, 2, 3):
+            for final in (True, False):
+                for w in itertools.product(vals, repeat=plan + 1):
+                    if final is False and plan == 0:
+                        continue
+                    s = FactorizeLinSolver.__new__(FactorizeLinSolver)
+                    s.umfpack_refinements = umf; s._recorded_plan = None; s.last_omega = None; s.lam = 0.0
+                    s.nep = _Nep()
+                    w4 = np.zeros(4); w4[:plan + 1] = w
+                    ok = s.review_recorded(w4, plan, final_recorded=final)
+                    out = (_lib.c_i32 * 4)()
+                    _lib.check(_lib.lib.nep_refine_review(umf, plan, 1 if final else 0, _lib.hptr(w4), -1, out))
+                    hint = getattr(s.nep, "_refine_hint", None); off = getattr(s.nep, "_refine_hint_off", False)
+                    assert bool(out[0]) == bool(ok), (umf, plan, final, w)
+                    assert out[1] == (-1 if s._recorded_plan is None else s._recorded_plan), (umf, plan, final, w, out[1], s._recorded_plan)
+                    assert out[2] == (-1 if hint is None else hint) and bool(out[3]) == bool(off), (umf, plan, final, w)
+                    n += 1
+    assert n > 10000
