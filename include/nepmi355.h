@@ -518,6 +518,13 @@ int32_t nep_lu_factor_dev_batch_terms(nep_lu_refac* r, int32_t B, const nep_cdou
                                       int32_t expected_solves, double growth_limit, double* h_health, nep_lu** out,
                                       nep_stream stream);
 
+/* the library's own device-wide primitives (csrc/devprims.h: reduce-then-scan exclusive prefix sum; stable LSD radix sort, 8-bit
+ * digits, wave-ballot ranking) that the one-off plan enumeration of nep_lu_refac_create runs on -- no hipCUB / rocPRIM behind the
+ * ABI.  d_out[i] = sum_{j<i} d_in[j]; (d_keys, d_vals) sorted in place by the key bits [0, nbits), equal keys keep their order.
+ * Asynchronous.  Entry points for tests and diagnostics. */
+int32_t nep_devprim_exclusive_sum(const uint64_t* d_in, uint64_t* d_out, int64_t n, nep_stream stream);
+int32_t nep_devprim_sort_pairs(uint64_t* d_keys, uint64_t* d_vals, int64_t n, int32_t nbits, nep_stream stream);
+
 /* ---- one infinite-Arnoldi step as one call ------------------------------------------------------
  * replaces: the loop body of iar between two eigenvalue checks, src/method_iar.jl:94-109
  *           (compute_Mlincomb! at sigma through the DerSPMF table :1130-1160, lin_solve, the 1/j shift of the block

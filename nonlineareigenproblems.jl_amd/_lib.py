@@ -160,6 +160,8 @@ SIGNATURES = {
     "nep_iar_steps": [c_vp, c_i32, c_i32, c_i32, c_vp],
     "nep_iar_wait": [c_vp, c_i32],
     "nep_iar_stream_wait": [c_vp, c_i32, c_vp],
+    "nep_devprim_exclusive_sum": [c_vp, c_vp, c_i64, c_vp],
+    "nep_devprim_sort_pairs": [c_vp, c_vp, c_i64, c_i32, c_vp],
     "nep_refine_review": [c_i32, c_i32, c_i32, c_vp, c_i32, c_vp],
     "nep_iar_run": [c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp],
     "nep_hess_eig_worksize": [c_i32, P(c_i64)],

@@ -31,7 +31,7 @@ DIGEST_FILE = LIB + ".digest"
 
 
 def _deps():
-    return [os.path.join(CSRC, f) for f in SOURCES + ["common.h", "trsv_ml.h"]] + [os.path.join(ROOT, "include", "nepmi355.h")]
+    return [os.path.join(CSRC, f) for f in SOURCES + ["common.h", "trsv_ml.h", "devprims.h"]] + [os.path.join(ROOT, "include", "nepmi355.h")]
 
 
 def source_digest():

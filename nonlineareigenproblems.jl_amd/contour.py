@@ -329,6 +329,14 @@ def _beyn_tail_device(S, n, k, rank_drop_tol):
             return None
         R[:j, j] = oh[j, :j]
         R[j, j] = oh[j, j].real
+    # svd(R) = svd(A0) and V = Q U_R hold for an ORTHONORMAL Q only.  A column whose last enqueued DGKS pass still met the
+    # re-orthogonalisation criterion (flag bit 0) is not known to be orthogonal to its predecessors: harmless for a noise column (A0 is
+    # rank deficient by design: R[j, j] at round-off of R[0, 0]), not for one that carries weight -- the host route then (svd of the
+    # downloaded block, as the reference does it)
+    r00 = abs(R[0, 0]) if k else 0.0
+    for j in range(k):
+        if (int(oh[j, j + 1].imag) & 1) and abs(R[j, j]) > 1e-10 * r00:
+            return None
     c = 1.0 / (2j * np.pi)
     Ur, Sv, Wh = sla.svd(R * c)                             # A0 = Q (R / (2 pi i)): same singular values, V = Q U_R
     p = int(np.sum(Sv / Sv[0] > rank_drop_tol))

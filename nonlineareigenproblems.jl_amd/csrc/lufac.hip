@@ -25,11 +25,11 @@
 #include <algorithm>
 #include <chrono>
 #include <thread>
-#include <hipcub/hipcub.hpp>
+#include "devprims.h"
 #include <atomic>
-// (hipCUB -- header-only device primitives, compiled into this library; no run-time dependency -- serves the ONE-OFF enumeration
-// of a pattern's plan: an exclusive scan and a radix sort over its products.  Nothing on a solve / factorisation path uses it;
-// it is the one vendor component besides RCCL, named in tests/test_host_logic.py::test_no_vendor_blas_or_fft_behind_the_abi.)
+// (the ONE-OFF enumeration of a pattern's plan needs an exclusive scan and a radix sort over its products: this library's own,
+// csrc/devprims.h -- hipCUB / rocPRIM served here until round 5; tests/test_host_logic.py::test_no_vendor_blas_or_fft_behind_the_abi
+// now asserts that NO vendor primitive is compiled in.)
 static std::atomic<int> g_plan_threads{0};     // host enumeration threads (0: default 6); set by the host language, not via putenv
 extern "C" int32_t nep_lu_set_plan_threads(int32_t n) { g_plan_threads.store(n < 0 ? 0 : (n > 32 ? 32 : n)); return NEP_OK; }
 #include <cstring>
@@ -418,9 +418,10 @@ __global__ void k_lu_enum_classify(LuEnumArgs A, uint32_t* __restrict__ code, in
     else { kind = 1u; atomicAdd(&tot[gd], 1); }
     code[t] = gd | (kind << LU_KIND_SHIFT);
 }
-struct LuFlagOp {
-    __host__ __device__ __forceinline__ unsigned long long operator()(uint32_t c) const {
-        const uint32_t kind = c >> LU_KIND_SHIFT;
+struct LuFlagIn {                      // scan input: internal products counted in the low word, wide ones in the high word
+    const uint32_t* code;
+    __device__ __forceinline__ unsigned long long operator()(int64_t i) const {
+        const uint32_t kind = code[i] >> LU_KIND_SHIFT;
         return kind == 0u ? 1ull : (kind == 2u ? (1ull << 32) : 0ull);
     }
 };
@@ -549,12 +550,9 @@ struct LuGpuEnum {
         HIPCHK(hipMemcpyAsync(d_code + nprod, &endcode, sizeof(uint32_t), hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL(k_lu_enum_classify, dim3((unsigned)((nprod + 255) / 256)), dim3(256), 0, st, A, d_code, d_tot, d_err);
         LAUNCHCHK();
-        hipcub::TransformInputIterator<unsigned long long, LuFlagOp, const uint32_t*> flags((const uint32_t*)d_code, LuFlagOp());
-        size_t tb = 0;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(nullptr, tb, flags, d_scan, (int)(nprod + 1), st));
         char* d_tmp = nullptr;
-        if ((rc = dev(&d_tmp, tb))) return rc;
-        HIPCHK(hipcub::DeviceScan::ExclusiveSum(d_tmp, tb, flags, d_scan, (int)(nprod + 1), st));
+        if ((rc = dev(&d_tmp, nepprim::scan_temp_bytes(nprod + 1)))) return rc;
+        if ((rc = nepprim::exclusive_sum_u64(LuFlagIn{(const uint32_t*)d_code}, d_scan, nprod + 1, d_tmp, st))) return rc;
         hipLaunchKernelGGL(k_lu_enum_counts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (int32_t)n, A.pbase, d_scan, d_ci, d_cw);
         LAUNCHCHK();
         int32_t herr = 0;
@@ -585,13 +583,13 @@ struct LuGpuEnum {
         LAUNCHCHK();
         if (r->next_ > 0) {
             int segbits = 1; while (((int64_t)1 << segbits) < (int64_t)r->nseg + 1 && segbits < 31) ++segbits;
-            size_t tb = 0;
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(nullptr, tb, d_kin, d_kout, d_vin, (unsigned long long*)r->d_ext_src,
-                                                      (int)r->next_, 0, 32 + segbits, st));
+            // stable sort of the (destination segment | slot, source pair) records by key: the sorted VALUES are the plan's array
             char* d_tmp = nullptr;
-            if ((rc = dev(&d_tmp, tb))) return rc;
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(d_tmp, tb, d_kin, d_kout, d_vin, (unsigned long long*)r->d_ext_src,
-                                                      (int)r->next_, 0, 32 + segbits, st));
+            if ((rc = dev(&d_tmp, nepprim::sort_temp_bytes(r->next_)))) return rc;
+            int in0 = 1;
+            if ((rc = nepprim::radix_sort_pairs_u64(d_kin, d_vin, d_kout, (unsigned long long*)r->d_ext_src, r->next_, 32 + segbits, d_tmp, st, &in0)))
+                return rc;
+            if (in0) HIPCHK(hipMemcpyAsync(r->d_ext_src, d_vin, (size_t)r->next_ * sizeof(unsigned long long), hipMemcpyDeviceToDevice, st));
         }
         HIPCHK(hipStreamSynchronize(st));
         return NEP_OK;
@@ -600,7 +598,40 @@ struct LuGpuEnum {
 
 }  // namespace
 
+struct U64In { const unsigned long long* p; __device__ __forceinline__ unsigned long long operator()(int64_t i) const { return p[i]; } };
+
 extern "C" {
+
+// the library's own device-wide primitives (csrc/devprims.h) behind two plain entry points: tests and diagnostics
+int32_t nep_devprim_exclusive_sum(const uint64_t* d_in, uint64_t* d_out, int64_t n, nep_stream stream) {
+    ARGCHK(n >= 0 && (n == 0 || (d_in && d_out)));
+    if (n == 0) return NEP_OK;
+    void* tmp = nullptr;
+    int rc = nep_pool_alloc(&tmp, nepprim::scan_temp_bytes(n)); if (rc) return rc;
+    rc = nepprim::exclusive_sum_u64(U64In{(const unsigned long long*)d_in}, (unsigned long long*)d_out, n, tmp, as_stream(stream));
+    nep_pool_free_on(tmp, as_stream(stream), true);
+    return rc;
+}
+int32_t nep_devprim_sort_pairs(uint64_t* d_keys, uint64_t* d_vals, int64_t n, int32_t nbits, nep_stream stream) {
+    ARGCHK(n >= 0 && nbits >= 0 && nbits <= 64 && (n == 0 || (d_keys && d_vals)));
+    if (n <= 1) return NEP_OK;
+    hipStream_t st = as_stream(stream);
+    void *tmp = nullptr, *k1 = nullptr, *v1 = nullptr;
+    int rc = nep_pool_alloc(&tmp, nepprim::sort_temp_bytes(n));
+    if (!rc) rc = nep_pool_alloc(&k1, (size_t)n * 8);
+    if (!rc) rc = nep_pool_alloc(&v1, (size_t)n * 8);
+    int in0 = 1;
+    if (!rc) rc = nepprim::radix_sort_pairs_u64((unsigned long long*)d_keys, (unsigned long long*)d_vals, (unsigned long long*)k1,
+                                                (unsigned long long*)v1, n, nbits, tmp, st, &in0);
+    if (!rc && !in0) {
+        if (hipMemcpyAsync(d_keys, k1, (size_t)n * 8, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(d_vals, v1, (size_t)n * 8, hipMemcpyDeviceToDevice, st) != hipSuccess) { (void)hipGetLastError(); rc = NEP_ERR_HIP; }
+    }
+    if (tmp) nep_pool_free_on(tmp, st, true);
+    if (k1) nep_pool_free_on(k1, st, true);
+    if (v1) nep_pool_free_on(v1, st, true);
+    return rc;
+}
 
 int32_t nep_lu_refac_destroy(nep_lu_refac* r) {
     if (!r) return NEP_OK;

@@ -59,12 +59,13 @@ def to_dev(A):
 def to_host(T):
     """device (k, n) tensor -> host n x k ndarray"""
     if not T.is_cuda:
-        return T.numpy().T
+        return T.numpy().T.copy()          # a fresh array, as on the device branch (never a view that aliases the tensor)
     # through a pinned block (torch's caching host allocator hands the same pages out again once the caller has dropped the array):
     # a pageable `T.cpu()` of the 7 MB gun block runs at ~10 GB/s, the pinned copy at the link's rate
     h = torch.empty(T.shape, dtype=T.dtype, pin_memory=True)
-    h.copy_(T, non_blocking=True)
-    torch.cuda.current_stream().synchronize()
+    with torch.cuda.device(T.device):
+        h.copy_(T, non_blocking=True)
+        torch.cuda.current_stream(T.device).synchronize()      # the copy was enqueued on T's device's current stream
     return h.numpy().T.copy()
 
 

@@ -56,11 +56,18 @@ def nleigs(nep, *args, **kw):
     ctl = _nep_hostlu.blas_controller() if os.environ.get("NEP_NLEIGS_BLAS_GUARD", "1") != "0" else None
 
     def run():
+        miss = False
+        held = []                      # the run's LinSolverCache: closed on EVERY way out of it (its factors and prefetch pool are device memory)
         try:
-            return _nleigs(nep, *args, **kw)
+            return _nleigs(nep, *args, _cache_holder=held, **kw)
         except _OrthPassMiss:          # "twice is enough" failed for a step of the asynchronous Gram-Schmidt: exact DGKS through the synchronous calls
-            nleigs.orth_misses += 1
-            return _nleigs(nep, *args, _sync_orth=True, **kw)
+            miss = True                # (the re-run starts AFTER this block: a live exception keeps the aborted run's frame -- basis, H, the
+        finally:                       # cached factorisations -- alive, which would double the peak device memory of the fallback)
+            for c_ in held:
+                c_.close()
+        assert miss
+        nleigs.orth_misses += 1
+        return _nleigs(nep, *args, _sync_orth=True, **kw)
     if ctl is None:
         return run()
     with ctl.limit(limits=1, user_api="blas"):
@@ -76,7 +83,8 @@ nleigs.orth_misses = 0
 
 def _nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logger=0, maxdgr=100, minit=20, maxit=200,
             linsolvercreator=None, tol=1e-10, tollin=None, v=None, errmeasure=None, isfunm=True, static=False, leja=1,
-            nodes=(), reusefact=1, blksize=20, return_details=False, check_error_every=5, info=None, _sync_orth=False):
+            nodes=(), reusefact=1, blksize=20, return_details=False, check_error_every=5, info=None, _sync_orth=False,
+            _cache_holder=None):
     import warnings
     if tollin is None:
         tollin = max(tol / 10, 100 * EPS)
@@ -114,6 +122,8 @@ def _nleigs(nep, Sigma=(-1.0 - 1j, -1 + 1j, 1 + 1j, 1 - 1j), Xi=(np.inf,), logge
     if v is None:
         v = np.random.randn(n) + 0j
     cache = LinSolverCache(nep, linsolvercreator)
+    if _cache_holder is not None:
+        _cache_holder.append(cache)
 
     # ---- interpolation nodes, poles, scaling (method_nleigs.jl:121-146)
     if leja == 0:

@@ -1499,3 +1499,29 @@ def test_hess_eig_dev_reads_the_iar_row_layout(na):
     assert np.abs(np.sort_complex(wh[:k]) - np.sort_complex(ref)).max() <= 1e-11 * np.abs(ref).max()
     with pytest.raises(na.NepError):
         dense.hess_eig_worksize(129)                                         # LDS-resident limit: the caller keeps LAPACK there
+
+
+@pytest.mark.parametrize("n", [1, 63, 2048, 2049, 100003, 3000017])
+def test_own_scan_and_radix_sort(na, n):
+    """csrc/devprims.h (the library's own exclusive scan and stable radix sort, which replaced hipCUB in the plan enumeration of the
+    device LU): against NumPy, sizes around the tile boundaries, 64-bit sums that carry into the high word (the enumeration packs two
+    counters into one item), keys with many duplicates (stability: values of equal keys keep their input order), bitwise repeatable"""
+    import torch
+    from nep_amd._lib import lib, check, c_vp
+    rng = np.random.default_rng(n)
+    x = rng.integers(0, 3, n).astype(np.uint64) + (rng.integers(0, 2, n).astype(np.uint64) << np.uint64(32))
+    xd = torch.from_numpy(x.view(np.int64)).to("cuda"); od = torch.empty_like(xd)
+    check(lib.nep_devprim_exclusive_sum(c_vp(xd.data_ptr()), c_vp(od.data_ptr()), n, None))
+    want = np.concatenate([[0], np.cumsum(x)[:-1]]).astype(np.uint64)
+    assert np.array_equal(od.cpu().numpy().view(np.uint64), want)
+    for nbits, hi in ((9, 1 << 9), (40, 1 << 40), (47, 37)):            # few distinct keys in the last case
+        keys = rng.integers(0, hi, n, dtype=np.int64).astype(np.uint64)
+        vals = np.arange(n, dtype=np.uint64) * np.uint64(3)
+        out = []
+        for rep in range(2):
+            kd = torch.from_numpy(keys.view(np.int64).copy()).to("cuda"); vd = torch.from_numpy(vals.view(np.int64).copy()).to("cuda")
+            check(lib.nep_devprim_sort_pairs(c_vp(kd.data_ptr()), c_vp(vd.data_ptr()), n, nbits, None))
+            out.append((kd.cpu().numpy().view(np.uint64), vd.cpu().numpy().view(np.uint64)))
+        order = np.argsort(keys, kind="stable")
+        assert np.array_equal(out[0][0], keys[order]) and np.array_equal(out[0][1], vals[order])
+        assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])

@@ -720,16 +720,15 @@ def test_no_vendor_blas_or_fft_behind_the_abi():
     rocBLAS for the dense-transform fallback of the waveguide preconditioner): every GEMM / DFT behind the C ABI is this
     library's own kernel.  (RCCL is the one vendor library it loads: the collective of the sharded contour integrators.)"""
     blob = open(na.LIB_PATH, "rb").read().lower()
-    for name in (b"rocblas", b"hipblas", b"rocfft", b"hipfft", b"rocsparse", b"rocsolver", b"librocprim", b"libhipcub"):
-        assert name not in blob, name
+    for name in (b"rocblas", b"hipblas", b"rocfft", b"hipfft", b"rocsparse", b"rocsolver", b"librocprim", b"libhipcub", b"rocprim", b"hipcub"):
+        assert name not in blob, name           # (header-only rocPRIM / hipCUB kernels would show up by their mangled names)
     assert b"rccl" in blob
-    # the other vendor component, stated here so that it cannot spread unnoticed: hipCUB's header-only scan and radix sort,
-    # compiled into csrc/lufac.hip for the ONE-OFF enumeration of a device-LU plan (nep_lu_refac_create) -- no run-time library,
-    # nothing of it on a solve, factorisation or SpMV path; no other source includes a vendor primitive header
+    # no source includes a vendor primitive header: until round 5 csrc/lufac.hip compiled hipCUB's scan and radix sort in for the
+    # ONE-OFF enumeration of a device-LU plan (nep_lu_refac_create); round 6 replaced them by csrc/devprims.h
     csrc = os.path.join(ROOT, "nonlineareigenproblems.jl_amd", "csrc")
     users = sorted(f for f in os.listdir(csrc) if f.endswith((".hip", ".h"))
-                   and re.search(r"#include\s*<(hipcub|rocprim|rocblas|hipblas|rocfft|hipfft|rocsparse|rocsolver|rocwmma|ck)[/_.]", open(os.path.join(csrc, f)).read()))
-    assert users == ["lufac.hip"], users
+                   and re.search(r"#include\s*<(hipcub|rocprim|rocblas|hipblas|rocfft|hipfft|rocsparse|rocsolver|rocwmma|ck|thrust)[/_.]", open(os.path.join(csrc, f)).read()))
+    assert users == [], users
 
 
 def test_discretizepolygon_native_walk_equals_the_interpreted_one(monkeypatch):
