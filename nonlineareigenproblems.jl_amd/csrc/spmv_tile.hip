@@ -763,6 +763,184 @@ __global__ __launch_bounds__(NTHR) void k_tile_resid_sp(const TileDesc* __restri
     }
 }
 
+// ---- the same kernel with a RING OF FOUR HALF-TILES (round 6; column-major Ritz blocks) -----------------------------------------
+// k_tile_resid_sp keeps ONE panel (4 columns, fpad x 64 bytes = 57 KB at 768 threads) in flight while it reduces the other: per panel it
+// pays max(arithmetic, memory latency), and the arithmetic of a panel (8 entries x 4 columns per row) is well under the ~2.5 us a
+// loaded HBM takes to answer -- the kernel ran latency-bound at 0.44 of the bandwidth with traffic already at 1.08 x algorithmic.
+// (That was the hypothesis; the measurement refuted it -- see the launch site.  Kept as an opt-in variant.)
+// Here the two tile buffers are cut into four half-tiles of 2 columns; three half-panels (86 KB per CU) are in flight while the
+// fourth is reduced.  A wave waits for the OLDEST of its outstanding LDS-DMA groups only: loads return in order, so
+// `s_waitcnt vmcnt(N)` with N = the DMA instructions this wave issued after that group is exact (the count is a compile-time
+// constant per wave class: waves below NIh % NW issue one instruction more per half-panel).  Same LDS, same entries in registers,
+// same fixed-order sums -> bitwise the results of k_tile_resid_sp.
+__device__ __forceinline__ double sp_wave_reduce4(const double v[4], int lane) {     // sums of v[i] over the wave on the lanes whose bits 5..4 spell i
+    double a[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const double keep = (lane & 32) ? v[2 + i] : v[i], give = (lane & 32) ? v[i] : v[2 + i];
+        a[i] = keep + shfl_xor_d(give, 32);
+    }
+    const double keep = (lane & 16) ? a[1] : a[0], give = (lane & 16) ? a[0] : a[1];
+    double c = keep + shfl_xor_d(give, 16);
+    c += shfl_xor_d(c, 8); c += shfl_xor_d(c, 4); c += shfl_xor_d(c, 2); c += shfl_xor_d(c, 1);
+    return c;
+}
+template <int N> __device__ __forceinline__ void sp_wait_vm() { __builtin_amdgcn_s_waitcnt(0x0f70 | (N & 15) | ((N >> 4) << 14)); }
+template <typename VT, int NTHR, int FM, int RING>
+__global__ __launch_bounds__(NTHR, (RING == 2 ? 2 * (NTHR / 64) / 4 : 1)) void k_tile_resid_sp4(const TileDesc* __restrict__ desc, const uint32_t* __restrict__ fp,
+                                                         const uint16_t* __restrict__ eidx, const VT* __restrict__ eval,
+                                                         const cplx* __restrict__ Q, int64_t ldq, int k, const cplx* __restrict__ F,
+                                                         int mt, int lbits, uint32_t slot_terms, cplx* __restrict__ R,
+                                                         int64_t ldr, double* __restrict__ partial, int swz, int64_t split_row) {
+    constexpr int NW = NTHR / 64;
+    constexpr int fpad = SP_FPAD(NTHR);
+    constexpr int CH = fpad >> 6;                             // 64-slot chunks of a tile column
+    constexpr int NIh = 2 * CH;                               // DMA instructions of a half-panel
+    constexpr int IPW = (NIh + NW - 1) / NW;                  // ... per wave (waves >= NIh % NW issue one less when NIh % NW != 0)
+    constexpr int REMW = NIh % NW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cplx* Qt = (cplx*)smem;                                   // [RING half-tiles][2][fpad]
+    double* wsum = (double*)(Qt + (size_t)2 * RING * fpad);   // [2 parities][NW][4]
+    uint32_t* fpl = (uint32_t*)(wsum + 2 * NW * 4);           // [fpad]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int blk = tile_block(swz);
+    const TileDesc d = desc[blk];
+    const int Fn = d.fp_cnt;
+    const uint32_t* __restrict__ fpb = fp + d.fp_off;
+    const int width = d.wrb & 0xffff, rb = d.wrb >> 16;
+    const uint32_t lmask = (1u << lbits) - 1u;
+    const uint16_t* __restrict__ ib = eidx + (int64_t)d.ent_off64 * 64;
+    const VT* __restrict__ vb = eval + (int64_t)d.ent_off64 * 64;
+    const int nh = (k + 1) >> 1;                              // half-panels
+    // instruction i of a half-panel: chunk i >> 1 of 64 footprint slots, column i & 1
+    auto issue = [&](int hp, int slot) {
+#pragma unroll
+        for (int t = 0; t < IPW; ++t) {
+            const int i = wv + t * NW;
+            if (i < NIh) {
+                const int f = (i >> 1) * 64 + lane;
+                const int c = 2 * hp + (i & 1);
+                const int64_t col = (int64_t)(fpl[f] & NEP_COL_MASK);
+                sp_dma16(Q + col + (int64_t)(c < k ? c : k - 1) * ldq, Qt + ((size_t)(2 * slot + (i & 1)) * fpad + (size_t)(i >> 1) * 64));
+            }
+        }
+    };
+    // the first RING - 1 half-panels go out at once, straight from the footprint list in global memory
+    {
+        uint32_t raw[IPW];
+#pragma unroll
+        for (int t = 0; t < IPW; ++t) {
+            const int i = wv + t * NW;
+            const int f = ((i < NIh ? i : 0) >> 1) * 64 + lane;
+            raw[t] = fpb[f < Fn ? f : Fn - 1];
+        }
+        // all of the list first: the compiler counts only its own loads, so a wait for raw[t] placed between two DMA instructions
+        // would also wait for the DMA issued before it (the half-panels would go out one memory latency apart)
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int hp = 0; hp < RING - 1; ++hp) {
+            if (hp < nh) {
+#pragma unroll
+                for (int t = 0; t < IPW; ++t) {
+                    const int i = wv + t * NW;
+                    if (i < NIh) {
+                        const int f = (i >> 1) * 64 + lane;
+                        if (hp == 0 && (i & 1) == 0) fpl[f] = raw[t];              // every footprint slot exactly once
+                        const int c = 2 * hp + (i & 1);
+                        const int64_t col = (int64_t)(raw[t] & NEP_COL_MASK);
+                        sp_dma16(Q + col + (int64_t)(c < k ? c : k - 1) * ldq, Qt + ((size_t)(2 * hp + (i & 1)) * fpad + (size_t)(i >> 1) * 64));
+                    }
+                }
+            }
+        }
+    }
+    uint32_t pid2[4]; VT pv[8];
+    sp_entries<VT, true, NTHR>(ib, vb, rb, width, tid, lmask, pid2, pv);
+    const int li = tid / d.zp, ljz = tid - li * d.zp;
+    const int64_t row = (int64_t)d.r0 + (int64_t)li * d.stride + ljz;
+    const bool rowon = tid < d.nrows;
+    const bool big = REMW == 0 || wv < REMW;                  // this wave issues IPW instructions per half-panel (else IPW - 1)
+    for (int hp = 0; hp < nh; ++hp) {
+        // half-panels hp + 1 .. hp + RING - 2 (when they exist) were issued after hp and may stay in flight
+        const int after = nh - 1 - hp < RING - 2 ? nh - 1 - hp : RING - 2;
+        if (RING >= 4 && after == 2) { if (big) sp_wait_vm<2 * IPW>(); else sp_wait_vm<2 * (IPW - 1)>(); }
+        else if (RING >= 3 && after == 1) { if (big) sp_wait_vm<IPW>(); else sp_wait_vm<IPW - 1>(); }
+        else sp_wait_vm<0>();
+        __syncthreads();                           // everybody's share has landed; every wave is done with half-tile hp - 1 and with wsum of hp - 1's parity
+        if (partial && hp > 0 && tid < 4) {
+            const int which = tid >> 1, s = tid & 1, col = 2 * (hp - 1) + s;
+            if (col < k) {
+                const double* w = wsum + (size_t)((hp - 1) & 1) * NW * 4 + which * 2 + s;
+                double a = 0.0;
+#pragma unroll
+                for (int q = 0; q < NW; ++q) a += w[q * 4];
+                partial[((int64_t)blk * 2 + which) * k + col] = a;
+            }
+        }
+        if (hp + RING - 1 < nh) issue(hp + RING - 1, (hp + RING - 1) % RING);      // into the half-tile that hp - 1 has just left
+        // ---- reduce half-panel hp (columns 2 hp, 2 hp + 1) against the row's entries: the arithmetic of sp_panel for one pair
+        const cplx* tile = Qt + (size_t)(2 * (hp % RING)) * fpad;
+        cplx acc[2], r[2];
+        const cplx* Fc[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            acc[s] = cmake(0.0, 0.0); r[s] = cmake(0.0, 0.0);
+            Fc[s] = F + (2 * hp + s < k ? 2 * hp + s : k - 1) * mt;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t o16 = (j & 1) ? (pid2[j >> 1] >> 16) : (pid2[j >> 1] & 0xffffu);
+            const bool first = j == 0 || ((FM >> (j - 1)) & 1);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const cplx q = *(const cplx*)((const char*)(tile + (size_t)s * fpad) + o16);
+                if (first) acc[s] = cscale(pv[j], q); else cfma(acc[s], pv[j], q);
+            }
+            if ((FM >> j) & 1) {
+                const int tj = (int)((slot_terms >> (4 * j)) & 15u);
+#pragma unroll
+                for (int s = 0; s < 2; ++s) cfma(r[s], Fc[s][tj], acc[s]);
+            }
+        }
+        double red[4];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int col = 2 * hp + s;
+            double r2 = 0.0;
+            if (rowon && col < k) {
+                r2 = fma(r[s].x, r[s].x, r[s].y * r[s].y);
+                if (split_row < 0) { if (R) R[row + (int64_t)col * ldr] = r[s]; }
+                else if (row >= split_row) { R[(row - split_row) + (int64_t)col * ldr] = r[s]; r2 = 0.0; }
+            }
+            red[s] = r2; red[2 + s] = 0.0;
+        }
+        if (partial) {
+            for (int f = tid; f < Fn; f += NTHR) {
+                if (fpl[f] & TILE_OWN) {
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) { const cplx q = tile[(size_t)s * fpad + f]; red[2 + s] = fma(q.x, q.x, fma(q.y, q.y, red[2 + s])); }
+                }
+            }
+            const double sum = sp_wave_reduce4(red, lane);
+            if ((lane & 15) == 0) (wsum + (size_t)(hp & 1) * NW * 4)[wv * 4 + (lane >> 4)] = sum;      // lanes 0, 16, 32, 48 hold the 4 sums
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+    if (partial && tid < 4) {
+        const int which = tid >> 1, s = tid & 1, col = 2 * (nh - 1) + s;
+        if (col < k) {
+            const double* w = wsum + (size_t)((nh - 1) & 1) * NW * 4 + which * 2 + s;
+            double a = 0.0;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) a += w[q * 4];
+            partial[((int64_t)blk * 2 + which) * k + col] = a;
+        }
+    }
+}
+
 // PERSISTENT form: one workgroup per CU walks the blocks of its XCD's range, and the (block, panel) items form ONE pipeline -- while
 // the last panel of a block is reduced, the first panel of the next block is already on its way into the other tile.  A block's own
 // start-up chain (descriptor -> footprint list -> first tile: three dependent memory latencies, ~4 us of the ~12 us a block takes at
@@ -1339,6 +1517,13 @@ int nep_tiles_resid_sp(const NepTiles* t, int k, const cplx* dF, const cplx* Q, 
     // added its address arithmetic (84.7 against 70 us per launch at k = 8): OPT-IN.  NEP_K2_SP_PERSIST = 0 (default) never,
     // 1 for 4 < k <= 12, 2 always (k > 4)
     const bool pers = k > SP_PSW && (persist == 2 || (persist == 1 && k <= 3 * SP_PSW));
+    // column-major blocks: NEP_K2_SP_RING=4 selects the ring of four half-tiles (k_tile_resid_sp4).  MEASURED (round 6, n = 1e6,
+    // k = 60): 0.361 ms against 0.311 ms of the two-tile kernel -- three half-panels in flight instead of one panel did not help,
+    // twice as many barriers / wave reductions per block cost 0.3 us each: the kernel is NOT waiting for HBM latency (see DESIGN
+    // section 7, round 6: the per-panel arithmetic + LDS time equals the panel's HBM time).  Opt-in, tested.
+    // (also tried: RING = 2 with half the LDS so that TWO 768-thread workgroups share a CU -- 24 waves leave 80 VGPRs per lane, the
+    // kernel needs 111: 36 spills, their scratch reloads drain the DMA queue inside the panel loop, 0.73 ms.  Not kept.)
+    const bool ring4 = cm && !pers && env_int("NEP_K2_SP_RING", 2) == 4;
     const int pgrid = std::min(ncu, (t->nblk + 7) / 8 * 8);
     // flush mask of the slot layout: bit j = slot j is the last of its term
     int fm = 0x80;
@@ -1357,13 +1542,24 @@ int nep_tiles_resid_sp(const NepTiles* t, int k, const cplx* dF, const cplx* Q, 
                                t->lbits, t->slot_terms, R, ldr, partial, swz, split_row);                                       \
         }                                                                                                                      \
     } while (0)
-#define SPL_F(VT, C, NT_) do { if (fm == 0xD0) SPL(VT, C, NT_, 0xD0); else if (fm == 0x80) SPL(VT, C, NT_, 0x80); else SPL(VT, C, NT_, 0xFF); } while (0)
+#define SPL4R(VT, NT_, FM_, RG_, SHM_)                                                                                           \
+    do {                                                                                                                       \
+        if ((SHM_) > 64 * 1024) { const int rc_ = nep_raise_lds((const void*)k_tile_resid_sp4<VT, NT_, FM_, RG_>, 160 * 1024); if (rc_) return rc_; } \
+        hipLaunchKernelGGL((k_tile_resid_sp4<VT, NT_, FM_, RG_>), dim3((unsigned)t->nblk), dim3(NT_), (SHM_), st, (const TileDesc*)t->d_desc, \
+                           (const uint32_t*)t->d_fp, (const uint16_t*)t->d_eidx, (const VT*)t->d_eval, Q, ldq, k, dF, t->mt,        \
+                           t->lbits, t->slot_terms, R, ldr, partial, swz, split_row);                                           \
+    } while (0)
+#define SPL4(VT, NT_, FM_) SPL4R(VT, NT_, FM_, 4, shm)
+#define SPL_F(VT, C, NT_) do { if (C && ring4) { if (fm == 0xD0) SPL4(VT, NT_, 0xD0); else if (fm == 0x80) SPL4(VT, NT_, 0x80); else SPL4(VT, NT_, 0xFF); } \
+                               else if (fm == 0xD0) SPL(VT, C, NT_, 0xD0); else if (fm == 0x80) SPL(VT, C, NT_, 0x80); else SPL(VT, C, NT_, 0xFF); } while (0)
 #define SPL_C(VT, NT_) do { if (cm) SPL_F(VT, true, NT_); else SPL_F(VT, false, NT_); } while (0)
 #define SPL_T(VT) do { if (nthr == 512) SPL_C(VT, 512); else if (nthr == 768) SPL_C(VT, 768); else SPL_C(VT, 1024); } while (0)
     if (t->valbytes == 8) SPL_T(double); else SPL_T(cplx);
 #undef SPL_T
 #undef SPL_C
 #undef SPL_F
+#undef SPL4
+#undef SPL4R
 #undef SPL
     LAUNCHCHK();
     return NEP_OK;

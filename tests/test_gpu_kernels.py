@@ -1335,6 +1335,18 @@ def test_resid_batch_super_panel_kernel(na, case, monkeypatch):
                 assert np.allclose(oc[:k], r2, rtol=1e-12) and np.allclose(oc[k:], q2, rtol=1e-12)
                 assert np.allclose(oc2[:k], np.sum(abs(R[:row0]) ** 2, axis=0), rtol=1e-12) and np.allclose(oc2[k:], q2, rtol=1e-12)
                 assert np.linalg.norm(tc.T - R[row0:]) <= 1e-13 * np.linalg.norm(R[row0:])
+            # the ring-of-four-half-tiles variant of the column-major kernel (opt-in): the same bits as the two-tile kernel
+            if k >= 9:
+                monkeypatch.setenv("NEP_K2_SP_RING", "4")
+                check(lib.nep_k2_set_sp_mode(2))
+                oc4 = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+                check(lib.nep_resid_batch_cm_dev(dev.h, k, hptr(F), c_vp(Qc.data_ptr()), n, -1, c_vp(oc4.data_ptr()), None, 0, None))
+                oc5 = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
+                tc5 = torch.full((k, n - row0), float("nan"), dtype=torch.complex128, device="cuda")
+                check(lib.nep_resid_batch_cm_dev(dev.h, k, hptr(F), c_vp(Qc.data_ptr()), n, row0, c_vp(oc5.data_ptr()), c_vp(tc5.data_ptr()), n - row0, None))
+                monkeypatch.delenv("NEP_K2_SP_RING")
+                assert np.array_equal(oc4.cpu().numpy(), got[2][4]) and np.array_equal(oc5.cpu().numpy(), got[2][5])
+                assert np.array_equal(tc5.cpu().numpy(), got[2][6])
             # the super-panel form again: the same bits
             check(lib.nep_k2_set_sp_mode(2))
             o = torch.zeros(2 * k, dtype=torch.float64, device="cuda")
