@@ -52,6 +52,20 @@ __global__ void k_iar_start(cplx* __restrict__ V, const cplx* __restrict__ v, do
     if (i < n) V[i] = cmake(v[i].x * inv, v[i].y * inv);
 }
 
+// Column j of the basis is written by its step in full over its (j + 1) n active rows; rows beyond are never part of the arithmetic, but
+// the Gram-Schmidt update kernels mask at TILE granularity (csrc/orth.hip: `r0 < act`), so the rows of the tile that straddles the
+// end of a column's active part are read and must be zero.  Instead of a zero fill of the whole (m + 1) x n (m + 1) block (1.6 GB
+// for gun at m = 100, 0.45 ms on the critical path of every call) only a slack of ZSLACK rows behind every column's active part is
+// cleared (m + 1 columns x 128 KB).  NEP_IAR_FULL_ZERO=1 restores the full fill; NEP_IAR_POISON=1 (tests) fills the block with NaN
+// patterns first, so that a kernel that read anything else would show.
+constexpr int64_t ZSLACK = 8192;
+__global__ __launch_bounds__(256) void k_iar_zero_slack(cplx* __restrict__ V, int64_t ldv, int64_t n, int m1) {
+    const int j = blockIdx.y;
+    const int64_t a = (int64_t)(j + 1) * n;
+    const int64_t r = a + (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j < m1 && r < ldv && r < a + ZSLACK) V[(int64_t)j * ldv + r] = cmake(0.0, 0.0);
+}
+
 // streams of a run, kept per device for the life of the process (a fresh stream per call costs a hardware-queue assignment, and
 // the pool allocator's event hand-off is per stream)
 struct RunStreams { hipStream_t check = nullptr, eig = nullptr; hipStream_t probed_for = (hipStream_t)-1; };
@@ -335,7 +349,12 @@ int32_t nep_iar_run(nep_spmf* spmf, nep_lu* lu, int64_t n, const nep_iar_opts* o
     for (int64_t i = 0; i < n; ++i) { a.stage[i] = hc(h_v0[i]); nrm2 += h_v0[i].re * h_v0[i].re + h_v0[i].im * h_v0[i].im; }
     ARGCHK(nrm2 > 0.0 && isfinite(nrm2));
     HIPCHK(hipMemcpyAsync(a.v0, a.stage, (size_t)n * 16, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemsetAsync(R.V, 0, (size_t)(m + 1) * R.ldv * 16, st));
+    if (getenv("NEP_IAR_FULL_ZERO") && atoi(getenv("NEP_IAR_FULL_ZERO")))
+        HIPCHK(hipMemsetAsync(R.V, 0, (size_t)(m + 1) * R.ldv * 16, st));
+    else {
+        if (getenv("NEP_IAR_POISON") && atoi(getenv("NEP_IAR_POISON"))) HIPCHK(hipMemsetAsync(R.V, 0xFF, (size_t)(m + 1) * R.ldv * 16, st));
+        hipLaunchKernelGGL(k_iar_zero_slack, dim3((unsigned)(ZSLACK / 256), (unsigned)(m + 1)), dim3(256), 0, st, R.V, R.ldv, n, m + 1);
+    }
     hipLaunchKernelGGL(k_iar_start, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, R.V, (const cplx*)a.v0, 1.0 / sqrt(nrm2), n);
     hipLaunchKernelGGL(k_iar_active, dim3((unsigned)((m + 1 + 63) / 64)), dim3(64), 0, st, a.active, n, m + 1);
     HIPCHK(hipMemsetAsync(a.Hdev, 0, (size_t)m * (m + 4) * 16, st));

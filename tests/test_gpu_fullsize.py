@@ -350,6 +350,27 @@ def test_c5_wep_tiar_m60_fullsize(na):
     assert ok, worst
 
 
+def test_c2_basis_needs_no_full_zero_fill(na, monkeypatch):
+    """nep_iar_run clears only a slack of rows behind every basis column's active part (the Gram-Schmidt kernels mask at tile
+    granularity) instead of the whole 1.6 GB block.  With the block poisoned by NaN patterns first (NEP_IAR_POISON) the run returns
+    bit for bit what it returns after a full zero fill (NEP_IAR_FULL_ZERO): no kernel of the pipeline reads a row that no step wrote"""
+    nep = na.nep_gallery("gun_spmf_scaled"); n = nep.n
+    out = {}
+    na.iar(nep, sigma=0.0, gamma=1.0, maxit=100, neigs=np.inf, v=np.ones(n), tol=1e-10)      # (the refinement count settles: same plan in both runs below)
+    for mode in ("NEP_IAR_FULL_ZERO", "NEP_IAR_POISON"):
+        monkeypatch.setenv(mode, "1")
+        r0 = na.iar.native_runs
+        hist = []
+        lam, Q, _ = na.iar(nep, sigma=0.0, gamma=1.0, maxit=100, neigs=np.inf, v=np.ones(n), tol=1e-10, errhist=hist)
+        assert na.iar.native_runs == r0 + 1
+        monkeypatch.delenv(mode)
+        out[mode] = (lam, Q, np.concatenate(hist))
+    a, b = out["NEP_IAR_FULL_ZERO"], out["NEP_IAR_POISON"]
+    assert np.all(np.isfinite(b[2])) and len(a[0]) == 46 and len(b[0]) == 46
+    assert np.array_equal(a[2], b[2]), float(np.max(np.abs(a[2] - b[2]) / a[2]))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_c2_repeated_runs_are_stable(na):
     """config C2 ten times in a row (host LU for the first call, device numeric LU once the pattern's plan exists, checks on
     their own stream next to a recurrence that runs far ahead of the device): every run returns the same eigenpairs.  Guards
