@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void k_iar_zero_slack(cplx* __restrict__ V, in
 
 // streams of a run, kept per device for the life of the process (a fresh stream per call costs a hardware-queue assignment, and
 // the pool allocator's event hand-off is per stream)
-struct RunStreams { hipStream_t check = nullptr, eig = nullptr; hipStream_t probed_for = (hipStream_t)-1; };
+struct RunStreams { hipStream_t check = nullptr, eig = nullptr; hipStream_t probed_for = (hipStream_t)-1; bool shared = false; int retries = 0; };
 std::mutex g_rs_mu;
 std::map<int, RunStreams> g_rs;
 
@@ -76,7 +76,7 @@ std::map<int, RunStreams> g_rs;
 // pair, once per process, device and caller stream); `keep` (may be NULL) is tried first.  The runtime maps streams onto a small
 // pool of hardware queues and gives no way to ask which: two streams on one queue serialise (measured: the convergence checks on
 // the recurrence's queue cost 15 ms per headline call).
-int pick_stream(hipStream_t keep, int prio, int ncand, bool probe, const std::vector<hipStream_t>& others, hipStream_t* out) {
+int pick_stream(hipStream_t keep, int prio, int ncand, bool probe, const std::vector<hipStream_t>& others, hipStream_t* out, bool* shared) {
     std::vector<hipStream_t> cand;
     if (keep) cand.push_back(keep);
     hipStream_t pick = nullptr;
@@ -93,7 +93,7 @@ int pick_stream(hipStream_t keep, int prio, int ncand, bool probe, const std::ve
         if (!clash) pick = s;
     }
     if (getenv("NEP_IAR_RUN_TRACE")) fprintf(stderr, "nep_iar_run: stream pick (prio %d): %zu candidates tried, %s\n", prio, cand.size(), pick ? "free queue found" : "none free");
-    if (!pick) pick = cand[0];                       // no free hardware queue: better a shared one than none
+    if (!pick) { pick = cand[0]; *shared = true; }   // no free hardware queue: better a shared one than none (probed again by the next run)
     for (hipStream_t s : cand) if (s != pick) (void)hipStreamDestroy(s);
     *out = pick;
     return NEP_OK;
@@ -103,15 +103,26 @@ int run_streams(hipStream_t main, RunStreams* out) {
     int dev = 0; HIPCHK(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_rs_mu);
     RunStreams& r = g_rs[dev];
-    if (!r.check || !r.eig || r.probed_for != main) {
+    // (a pick that found no free hardware queue is not final: the next runs probe again, three times at most)
+    if (!r.check || !r.eig || r.probed_for != main || (r.shared && r.retries < 3)) {
+        if (r.shared) ++r.retries;
+        r.shared = false;
         int least = 0, greatest = 0;
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         const int ncand = getenv("NEP_IAR_EIG_CANDIDATES") ? atoi(getenv("NEP_IAR_EIG_CANDIDATES")) : 8;
         const bool probe = !(getenv("NEP_IAR_EIG_PROBE") && atoi(getenv("NEP_IAR_EIG_PROBE")) == 0);
-        // the convergence checks are off the critical path: lowest priority, the dispatcher serves the recurrence first
-        int rc = pick_stream(r.check, least, ncand, probe, {main}, &r.check); if (rc) return rc;
+        // the convergence checks are off the critical path, but their stream gets NORMAL priority (NEP_IAR_CHECK_PRIO = 1: the device's
+        // lowest, -1: its highest).  MEASURED (round 6, 16 fresh processes): with a lowest-priority stream half of the processes ran
+        // the headline call in 57-69 ms instead of 32 -- both side streams then executed as if they shared the recurrence's queue,
+        // although the probe below had found them free; with normal priority 8 of 8 processes ran at 31.5-32.1 ms.  (The Python host's
+        // torch.cuda.Stream(priority=1) was clamped to normal by torch and never had a low-priority queue.)
+        const int cprio = getenv("NEP_IAR_CHECK_PRIO") ? (atoi(getenv("NEP_IAR_CHECK_PRIO")) > 0 ? least : (atoi(getenv("NEP_IAR_CHECK_PRIO")) < 0 ? greatest : 0)) : 0;
+        int rc = pick_stream(r.check, cprio, ncand, probe, {main}, &r.check, &r.shared); if (rc) return rc;
         // the decompositions are 3 ms one-workgroup kernels next to both
-        rc = pick_stream(r.eig, 0, ncand, probe, {main, r.check}, &r.eig); if (rc) return rc;
+        // (NEP_IAR_EIG_PRIO: 0 = normal (default), -1 = the device's highest: a decomposition is ONE workgroup that needs half a CU's
+        // LDS and has to find a CU between the recurrence's kernels)
+        const int eprio = getenv("NEP_IAR_EIG_PRIO") ? (atoi(getenv("NEP_IAR_EIG_PRIO")) < 0 ? greatest : (atoi(getenv("NEP_IAR_EIG_PRIO")) > 0 ? least : 0)) : 0;
+        rc = pick_stream(r.eig, eprio, ncand, probe, {main, r.check}, &r.eig, &r.shared); if (rc) return rc;
         r.probed_for = main;
     }
     *out = r;
