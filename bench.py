@@ -535,7 +535,8 @@ def wep_scale_roofline(na):
     # HBM bytes of the K2 / K7 launches from the stored PMC passes (scripts/make_profiles_r5.sh: separate --pmc FETCH_SIZE / WRITE_SIZE
     # runs of `bench.py --only wepscale`; 2*FETCH + WRITE per the gfx950 note), with the digest of the kernel source they were taken on
     try:
-        pj = json.load(open(os.path.join(ROOT, "profiles", "pmc2", "r5_wepscale_traffic.json")))
+        wfile = next(f for f in (os.path.join(ROOT, "profiles", "pmc2", "r%d_wepscale_traffic.json" % r_) for r_ in (6, 5)) if os.path.exists(f))
+        pj = json.load(open(wfile))
         cur = _file_digest(os.path.join(ROOT, "nonlineareigenproblems.jl_amd", "csrc", "spmv_tile.hip"))
         stale = bool(pj.get("_meta", {}).get("spmv_tile_hip_digest") != cur)
 
@@ -555,11 +556,13 @@ def wep_scale_roofline(na):
                 out[key]["traffic"] = t
                 out[key]["traffic_over_algorithmic"] = None if t is None else t / out[key]["algorithmic_bytes"]
                 out[key]["traffic_stale"] = stale
-        mf = json.load(open(os.path.join(ROOT, "profiles", "pmc2", "r5_mfma_counters.json")))
+                out[key]["traffic_file"] = os.path.relpath(wfile, ROOT)
+        mfile = next(f for f in (os.path.join(ROOT, "profiles", "pmc2", "r%d_mfma_counters.json" % r_) for r_ in (6, 5)) if os.path.exists(f))
+        mf = json.load(open(mfile))
         for key in ("K7 k=p=60", "K7 k=p=64"):
             if key in out:
                 out[key]["mfma_utilisation_pmc"] = {"value": mf.get("k_gemm_ts_res<8, 16, true> grid=131072", {}).get("mfma_utilisation"),
-                                                    "file": "profiles/pmc2/r5_mfma_counters.json (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), k = p = 60)",
+                                                    "file": os.path.relpath(mfile, ROOT) + " (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8), k = p = 60)",
                                                     "gemm_hip_digest_then": mf.get("_meta", {}).get("gemm_hip_digest"),
                                                     "gemm_hip_digest_now": _file_digest(os.path.join(ROOT, "nonlineareigenproblems.jl_amd", "csrc", "gemm.hip"))}
     except Exception as e:
@@ -789,6 +792,7 @@ def main():
         return r.ru_utime + r.ru_stime
 
     barrier()
+    native0 = na.iar.native_runs
     t0 = time.perf_counter(); c0 = cpu_seconds()
     pairs = 0
     for _ in range(args.steps):
@@ -798,6 +802,7 @@ def main():
         pairs += len(lam)
     barrier()
     dt = time.perf_counter() - t0
+    native_steps = na.iar.native_runs - native0
     cpu_s_per_call = (cpu_seconds() - c0) / args.steps        # host CPU of this rank, all threads, per timed step
     nres = max(2, min(5, args.steps))
     torch.cuda.synchronize(); tr0 = time.perf_counter()
@@ -872,6 +877,9 @@ def main():
             "ms_per_step_host_lu": ms_host_lu,
             "cpu_s_per_call": cpu_s_per_call,     # host CPU seconds per timed step (getrusage, all threads of this rank)
             "eig_route": os.environ.get("NEP_IAR_EIG", "dev") + " (eig(H_k) of every step: csrc/hesseig.hip on the device | LAPACK on host threads)",
+            "driver": "the whole call after the factorisation is ONE C-ABI call, nep_iar_run (csrc/iar_run.hip): %d of the %d timed steps took it (the "
+                      "rest: the step-at-a-time Python pipeline); the same entry point the Julia method iar(::DeviceSPMF) calls"
+                      % (native_steps, args.steps),
             "warmup_calls_ms": warm_ms,           # the first call carries every one-off: symbolic schedule, host LU, allocator pools
             "settle_calls_ms": settle_ms,         # extra untimed calls after the device-LU plan became ready (when W < 4)
             "plan_wait_ms": plan_wait_ms,         # time the warm-up still had to wait for the device-LU plan (background thread)
@@ -897,7 +905,7 @@ def main():
                 # HBM bytes of the two kernels from the PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of
                 # scripts/pmc_collect.sh, 2*FETCH + WRITE per the gfx950 note).  The file names the digest of csrc/orth.hip it
                 # was collected on: a kernel change makes `traffic_stale` true instead of going unnoticed.
-                tfile = next((f for f in (os.path.join(ROOT, "profiles", "pmc2", "r%d_gun_traffic.json" % r_) for r_ in (5, 4, 3, 2))
+                tfile = next((f for f in (os.path.join(ROOT, "profiles", "pmc2", "r%d_gun_traffic.json" % r_) for r_ in (6, 5, 4, 3, 2))
                               if os.path.exists(f)), None)
                 pj = json.load(open(tfile))
                 kb = 0.0

@@ -29,7 +29,10 @@ steps = [(ends[i] - ends[i - 1]) / 1e3 for i in range(1, len(ends))]
 for lo in (0, 20, 40, 60, 80, 90):
     s_ = steps[lo:lo + 10]
     if s_: print("  steps %3d..%3d: avg %.0f us per step" % (lo + 2, lo + 1 + len(s_), sum(s_) / len(s_)))
-tail = [x for x in seg if x[1] > t_rec_end]
+# the call ends where the NEXT call's factorisation begins (its first k_lu_init*): kernels from there on belong to that call
+nxt = [x[0] for x in seg if x[0] > t_rec_end and x[2].startswith("k_lu_init")]
+t_cut = min(nxt) if nxt else max(x[1] for x in seg) + 1
+tail = [x for x in seg if x[1] > t_rec_end and x[0] < t_cut and not x[2].startswith(("k_ml_inverse", "k_ml_gather", "k_gemm_general", "k_apex"))]
 t_end = max(x[1] for x in tail) if tail else t_rec_end
 print("tail: %.2f ms from the end of the recurrence to the last kernel of the call" % ((t_end - t_rec_end) / 1e6))
 byq = collections.defaultdict(list)
