@@ -94,8 +94,13 @@ def integrate_interval(ST, f, gv, a, b, N, info=None, ops=_DeviceOps):
     if nstreams > 1 and ready and torch.cuda.is_available() and all(t[i] in ready for i in mine) and len(mine) > 1:
         cur = torch.cuda.current_stream()
         sts = _SOLVE_STREAMS.setdefault(torch.cuda.current_device(), [])
-        while len(sts) < nstreams:
-            sts.append(torch.cuda.Stream())
+        if len(sts) < nstreams:
+            # side streams that share a hardware queue with neither the caller's stream nor each other (probed once per process and
+            # device, nep_stream_pair_serializes): the runtime maps streams onto a small pool of queues in creation order, and two
+            # "concurrent" solve streams on ONE queue run one after the other (round 6: 21 instead of 13 ms for the 64 node solves of
+            # C4, depending on which streams the process happened to create before)
+            from .iar import _eig_streams
+            sts[:] = list(_eig_streams(nstreams, others=(cur,)))
         for s_ in sts[:nstreams]:
             s_.wait_stream(cur)
         pend = []
@@ -209,17 +214,35 @@ class _NodeSolve:
                     pass
                 A0 = _Pattern(); A0.indptr = indptr; A0.indices = indices; A0.shape = (self.nep.n, self.nep.n)
                 plan = _DeviceRefactor.lookup(_DeviceRefactor.key(A0, (None, None, None)))
+                lu_first = None
+                if plan is None and len(ts) >= 4 and os.environ.get("NEP_BEYN_COLD_PLAN", "1") != "0":
+                    # FIRST call on this sparsity pattern: instead of sending all N nodes to the host-factorisation worker pool (gun,
+                    # N = 64: 0.67 s for the call, most of it the pool's start-up and 64 SuperLU runs) the first node is factorised on
+                    # the host in this process, its device-LU plan is built right away (enumeration on the GPU, ~25 ms) and waited
+                    # for, and the other N - 1 nodes take the batched device factorisation below like every later call
+                    from .linsolvers import DeviceLU
+                    try:
+                        lu_first = DeviceLU(self.nep.compute_Mder(self.g(ts[0]) + self.sigma), expected_solves=1)
+                        _DeviceRefactor.wait()
+                        plan = _DeviceRefactor.lookup(_DeviceRefactor.key(A0, (None, None, None)))
+                    except Exception:
+                        lu_first = None; plan = None          # (singular node, refused plan ...: the host route below handles every node)
+                    if plan is None:
+                        lu_first = None
                 if plan is None:
                     self._pattern = A0
                 if plan is not None:
                     # M(lam_b) = sum_t f_t(lam_b) A_t: only the B x m_t coefficients travel, the values are formed on the GPU
                     fv = self.nep.get_fv()
-                    Cf = np.array([[f.derivs(self.g(t) + self.sigma, 1)[0] for f in fv] for t in ts], dtype=np.complex128)
+                    tsb = list(ts[1:]) if lu_first is not None else list(ts)       # (the first node of a cold call keeps its host factors)
+                    if lu_first is not None:
+                        self.ready[ts[0]] = lu_first
+                    Cf = np.array([[f.derivs(self.g(t) + self.sigma, 1)[0] for f in fv] for t in tsb], dtype=np.complex128)
                     normA = np.sqrt(np.maximum(np.einsum("bs,st,bt->b", Cf.conj(), G, Cf).real, 0.0))
                     lus = _DeviceRefactor.factor_batch_terms(plan, self.nep.n, D_dev, Cf, normA, expected_solves=1,
                                                              growth=_DeviceRefactor.GROWTH_UNREFINED)
                     ts_host = []
-                    for t, lu in zip(ts, lus):
+                    for t, lu in zip(tsb, lus):
                         if lu is None:
                             ts_host.append(t)
                         else:

@@ -694,10 +694,11 @@ def test_beyn_device_tail_equals_host_tail(na, monkeypatch):
     assert max(oE(l1[i], V1[:, i]) for i in range(len(l1))) < 1e-6
 
 
-def test_beyn_first_call_seeds_the_device_plan(na):
-    """a process that ONLY runs contour_beyn: the first call factorises its nodes in the host workers and the first of those
-    factorisations seeds the pattern's device-factorisation plan; the second call factorises all nodes on the GPU in one
-    batch and returns the same eigenvalues"""
+def test_beyn_first_call_seeds_the_device_plan(na, monkeypatch):
+    """a process that ONLY runs contour_beyn.  Round 6: the FIRST call on a pattern factorises one node on the host, builds the
+    pattern's device-factorisation plan at once and factorises the other N - 1 nodes on the GPU in one batch (cold call of C4
+    0.47 -> 0.17 s); NEP_BEYN_COLD_PLAN=0 is the earlier route (all nodes of the first call in the host workers, the first of those
+    factorisations seeds the plan, the second call is the first batched one).  Same eigenvalues every way."""
     from nep_amd.linsolvers import _DeviceRefactor
     if not _DeviceRefactor.enabled():
         pytest.skip("device numeric factorisation switched off")
@@ -705,15 +706,24 @@ def test_beyn_first_call_seeds_the_device_plan(na):
     nep = na.nep_gallery("gun_spmf", n)
     Vh = na.probe_block(n, k)
     kw = dict(sigma=250.0 ** 2, radius=1.2e4, N=N, k=k, neigs=10 ** 6, tol=1e-6)
-    _DeviceRefactor.clear()
-    l1, V1 = na.contour_beyn(nep, Vh=Vh, **kw)
-    _DeviceRefactor.wait()
-    plans = [p for p in _DeviceRefactor.plans.values() if p["state"] == "ready"]
-    assert len(plans) == 1 and plans[0]["uses"] == 0
-    l2, V2 = na.contour_beyn(nep, Vh=Vh, **kw)
-    assert plans[0]["uses"] + plans[0]["fails"] == N and plans[0]["uses"] >= N - 2
-    assert len(l1) == len(l2) and len(l1) >= 1
-    _match(l2, l1, 1e-8)
+    ref = None
+    for cold in ("1", "0"):
+        monkeypatch.setenv("NEP_BEYN_COLD_PLAN", cold)
+        _DeviceRefactor.clear()
+        l1, V1 = na.contour_beyn(nep, Vh=Vh, **kw)
+        _DeviceRefactor.wait()
+        plans = [p for p in _DeviceRefactor.plans.values() if p["state"] == "ready"]
+        assert len(plans) == 1
+        first = plans[0]["uses"] + plans[0]["fails"]
+        assert first == (N - 1 if cold == "1" else 0), (cold, first)
+        l2, V2 = na.contour_beyn(nep, Vh=Vh, **kw)
+        assert plans[0]["uses"] + plans[0]["fails"] == first + N and plans[0]["uses"] >= first + N - 2
+        assert len(l1) == len(l2) and len(l1) >= 1
+        _match(l2, l1, 1e-8)
+        if ref is None:
+            ref = l1
+        else:
+            _match(l1, ref, 1e-8)
 
 
 def test_block_SS_dep0_kat_and_gun_twin(na):
