@@ -271,6 +271,26 @@ def test_iar_native_run_retry_routes(na, monkeypatch):
     assert len(ei.value.lam) == 12 and ei.value.v.shape == (n, 12)
 
 
+@pytest.mark.parametrize("n,m", [(1310, 30), (2000, 64), (333, 40)])
+def test_iar_native_run_poisoned_basis_small_sizes(na, monkeypatch, n, m):
+    """the slack-only clearing of the Krylov basis (nep_iar_run) at sizes whose column ends fall anywhere inside the tiles of the
+    Gram-Schmidt kernels: NaN-poisoned block + slack clear gives the bits of the fully zeroed run"""
+    nep = na.nep_gallery("gun_spmf_scaled", n)
+    kw = dict(sigma=0.0, gamma=1.0, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10)
+    na.iar(nep, **kw)
+    out = {}
+    for mode in ("NEP_IAR_FULL_ZERO", "NEP_IAR_POISON"):
+        monkeypatch.setenv(mode, "1")
+        r0 = na.iar.native_runs
+        h = []
+        lam, Q, _ = na.iar(nep, errhist=h, **kw)
+        assert na.iar.native_runs == r0 + 1
+        monkeypatch.delenv(mode)
+        out[mode] = (lam, Q, np.concatenate(h))
+    a, b = out["NEP_IAR_FULL_ZERO"], out["NEP_IAR_POISON"]
+    assert np.all(np.isfinite(b[2])) and np.array_equal(a[2], b[2]) and np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
 def test_transf_shift_and_scale_iar_qdep0(na):
     """test/transf.jl:44-52 on the device path: the recipe of config C2 (shift_and_scale + iar) on the in-tree sparse SPMF
     qdep0; residuals evaluated by the ORACLE on the original problem < sqrt(eps); eigenvalues equal the oracle's"""
