@@ -1,4 +1,5 @@
 /* Plain-C smoke program for libnepmi355.so: drives the hot path through the C ABI with no Python in the process --
+ *   nep_spmf_create -> nep_mlincomb (K1) -> nep_lu_create_csc + nep_lu_solve (K5) -> ... -> nep_iar_run (the whole iar call, with a C callback)
  *   nep_spmf_create -> nep_mlincomb (K1) -> nep_lu_create_csc + nep_lu_solve (K5) -> nep_lu_refac_create + nep_lu_factor_dev
  *   (numeric LU on the device) -> nep_orth (K6) -> nep_gemm_ts (K7)
  * and checks every result against a few lines of host arithmetic.  Built by __graft_entry__.build():
@@ -14,6 +15,17 @@
 
 static double rnd(unsigned* s) { *s = *s * 1664525u + 1013904223u; return ((*s >> 8) & 0xffff) / 65536.0 - 0.5; }
 static nep_cdouble cmul(nep_cdouble a, nep_cdouble b) { nep_cdouble r = {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re}; return r; }
+
+/* f_t(lambda) of the SPMF M(lambda) = A0 - lambda A1 for nep_iar_run: F[t + s mt], t = 0: 1, t = 1: -lambda */
+static int32_t fv_eval(void* ctx, int32_t nlam, const nep_cdouble* lam, nep_cdouble* F) {
+    int* calls = (int*)ctx;
+    ++*calls;
+    for (int s = 0; s < nlam; ++s) {
+        F[0 + 2 * s].re = 1.0; F[0 + 2 * s].im = 0.0;
+        F[1 + 2 * s].re = -lam[s].re; F[1 + 2 * s].im = -lam[s].im;
+    }
+    return 0;
+}
 
 int main(void) {
     int32_t ndev = 0;
@@ -189,6 +201,62 @@ int main(void) {
     }
     printf("K7 nep_gemm_ts           rel err %.2e\n", sqrt(err / nrm));
     if (sqrt(err / nrm) > 1e-13) return 5;
+
+    /* ---- the whole infinite Arnoldi method as ONE call (nep_iar_run; what `iar(nep::DeviceSPMF; ...)` of julia/NEPMI355X.jl is):
+     * M(lambda) = A0 - lambda A1 on the SPMF above (f_0 = 1, f_1 = -lambda), sigma = 0: the factors of M(0) = A0 = tridiag(-1, 2, -1)
+     * by the Thomas recurrence, the derivative table (only f_1' = -1 is non-zero), the four eigenvalues next to 0 */
+    {
+        const int m = 40;
+        int32_t* Lp2 = malloc((n + 1) * sizeof *Lp2); int32_t* Li2 = malloc(2 * n * sizeof *Li2); nep_cdouble* Lx2 = calloc(2 * n, sizeof *Lx2);
+        int32_t* Up2 = malloc((n + 1) * sizeof *Up2); int32_t* Ui2 = malloc(2 * n * sizeof *Ui2); nep_cdouble* Ux2 = calloc(2 * n, sizeof *Ux2);
+        double* dg = malloc(n * sizeof *dg);
+        dg[0] = 2.0; for (int i = 1; i < n; ++i) dg[i] = 2.0 - 1.0 / dg[i - 1];
+        int l2n = 0, u2n = 0;
+        for (int j = 0; j < n; ++j) {
+            Lp2[j] = l2n; Li2[l2n] = j; Lx2[l2n++].re = 1.0;
+            if (j < n - 1) { Li2[l2n] = j + 1; Lx2[l2n++].re = -1.0 / dg[j]; }
+            Up2[j] = u2n;
+            if (j > 0) { Ui2[u2n] = j - 1; Ux2[u2n++].re = -1.0; }
+            Ui2[u2n] = j; Ux2[u2n++].re = dg[j];
+        }
+        Lp2[n] = l2n; Up2[n] = u2n;
+        nep_lu* lu0 = NULL;
+        CHECK(nep_lu_create_csc(n, Lp2, Li2, Lx2, Up2, Ui2, Ux2, NULL, NULL, &lu0));
+        nep_cdouble* Ctab = calloc((size_t)m * mt, sizeof *Ctab);           /* m x mt column-major: row j-1 = gamma^j / j f_t^(j)(0) */
+        Ctab[0 + (size_t)1 * m].re = -1.0;
+        const double cabs[2] = {1.0, 0.0}; const nep_cdouble cf[2] = {{1.0, 0.0}, {0.0, 0.0}};
+        double fro[2] = {0.0, 0.0};
+        for (int e = 0; e < rp0[n]; ++e) fro[0] += v0[e] * v0[e];
+        for (int e = 0; e < n; ++e) fro[1] += v1[e] * v1[e];
+        fro[0] = sqrt(fro[0]); fro[1] = sqrt(fro[1]);
+        nep_cdouble* vs0 = malloc(n * sizeof *vs0); for (int i = 0; i < n; ++i) { vs0[i].re = 1.0; vs0[i].im = 0.0; }
+        nep_iar_opts o; memset(&o, 0, sizeof o);
+        o.maxit = m; o.check_error_every = 1; o.orth_method = 0; o.umfpack_refinements = 10; o.errmeasure = 1; o.refine_hint = -1;
+        o.tol = 1e-10; o.neigs = 4.0; o.sigma.re = 0.0; o.gamma.re = 1.0;
+        nep_iar_result res;
+        nep_cdouble* lam = calloc(m, sizeof *lam); nep_cdouble* Qh = malloc((size_t)n * m * sizeof *Qh); double* errs = malloc((size_t)m * m * sizeof *errs);
+        int calls = 0;
+        CHECK(nep_iar_run(spmf, lu0, n, &o, vs0, Ctab, mt, cabs, cf, fro, fv_eval, &calls, lam, NULL, Qh, errs, NULL, &res, NULL));
+        double worst_r = 0.0;
+        for (int s = 0; s < res.nret; ++s) {                                /* ||(A0 - lambda A1) q|| / ||q||, host arithmetic */
+            double rr = 0.0, qq = 0.0;
+            for (int i = 0; i < n; ++i) {
+                nep_cdouble acc = {0.0, 0.0};
+                for (int e = rp0[i]; e < rp0[i + 1]; ++e) { acc.re += v0[e] * Qh[ci0[e] + (size_t)s * n].re; acc.im += v0[e] * Qh[ci0[e] + (size_t)s * n].im; }
+                nep_cdouble t1 = {v1[i] * Qh[i + (size_t)s * n].re, v1[i] * Qh[i + (size_t)s * n].im};
+                nep_cdouble lt = cmul(lam[s], t1);
+                acc.re -= lt.re; acc.im -= lt.im;
+                rr += acc.re * acc.re + acc.im * acc.im;
+                qq += Qh[i + (size_t)s * n].re * Qh[i + (size_t)s * n].re + Qh[i + (size_t)s * n].im * Qh[i + (size_t)s * n].im;
+            }
+            worst_r = fmax(worst_r, sqrt(rr / qq));
+        }
+        printf("   nep_iar_run           %d pairs after %d steps (%d callbacks), lambda_1 = %.6e, max ||M(lambda) q||/||q|| %.2e\n",
+               res.nret, res.k, calls, lam[0].re, worst_r);
+        if (res.nret != 4 || res.nconv < 4 || res.k > m || calls < res.k || worst_r > 1e-8 || lam[0].re <= 0.0) return 7;
+        CHECK(nep_lu_destroy(lu0));
+        free(Lp2); free(Li2); free(Lx2); free(Up2); free(Ui2); free(Ux2); free(dg); free(Ctab); free(vs0); free(lam); free(Qh); free(errs);
+    }
 
     CHECK(nep_lu_destroy(lu)); CHECK(nep_spmf_destroy(spmf));
     CHECK(nep_dev_free(dV)); CHECK(nep_dev_free(dz)); CHECK(nep_dev_free(db)); CHECK(nep_dev_free(dx)); CHECK(nep_dev_free(dY));
