@@ -35,6 +35,8 @@ struct nep_iar {
     hipStream_t side = nullptr; hipEvent_t e_solved = nullptr, e_checked = nullptr;
     hipEvent_t e_upload = nullptr; bool upload_waited = false;      // |f_t|, f_t were uploaded on the NULL stream
     hipStream_t last = nullptr;
+    bool no_events = false;                  // nep_iar_steps_graph: the steps are being captured, their events are recorded behind the graph launch
+    std::vector<hipGraphExec_t> graphs;      // chunk graphs launched so far (destroyed with the object: a graph must outlive its execution)
     // step k's last kernel (k_orth_finish_vc) forms step k + 1's coefficient product and block shift: dWT (n x mt) holds the
     // product for step `wt_for` (0: none)
     cplx* dWT = nullptr; int32_t wt_for = 0;
@@ -97,6 +99,10 @@ int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdo
 int32_t nep_iar_destroy(nep_iar* s) {
     if (!s) return NEP_OK;
     for (hipEvent_t e : s->ev) if (e) (void)hipEventDestroy(e);
+    if (!s->graphs.empty()) {
+        if (s->last) (void)hipStreamSynchronize(s->last);          // a graph must not be destroyed while it executes
+        for (hipGraphExec_t g : s->graphs) (void)hipGraphExecDestroy(g);
+    }
     if (s->side) { (void)hipStreamSynchronize(s->side); (void)hipStreamDestroy(s->side); }
     if (s->e_solved) (void)hipEventDestroy(s->e_solved);
     if (s->e_checked) (void)hipEventDestroy(s->e_checked);
@@ -182,6 +188,7 @@ int32_t nep_iar_step(nep_iar* s, int32_t k, int32_t refine_steps, nep_stream str
     if (rc) return rc;
     if (!mirror)
         HIPCHK(hipMemcpyAsync(s->hH + (int64_t)(k - 1) * (s->m + 4), hrow, (size_t)(k + 4) * sizeof(cplx), hipMemcpyDeviceToHost, st));
+    if (s->no_events) return NEP_OK;
     if (!s->ev[k]) HIPCHK(hipEventCreateWithFlags(&s->ev[k], hipEventDisableTiming | hipEventBlockingSync));
     HIPCHK(hipEventRecord(s->ev[k], st));
     return NEP_OK;
@@ -195,6 +202,47 @@ int32_t nep_iar_steps(nep_iar* s, int32_t k0, int32_t count, int32_t refine_step
         int rc = nep_iar_step(s, k, refine_steps, stream);
         if (rc) return rc;
     }
+    return NEP_OK;
+}
+
+// The same steps as ONE hipGraph launch: the chunk's ~19 launches per step are captured (thread-local capture on the caller's
+// stream), instantiated and replayed once.  Why: a dependent kernel dispatch costs ~4.6 us through the stream path on this part and
+// ~1.5-2 us as a node of a graph (scripts/ub/ub_launch_chain.hip: 2.99 -> 1.53 us for a one-word kernel with arguments), and an
+// Arnoldi step at gun size is 19 dependent dispatches around ~100-300 us of work.  The host has the time (nep_iar_run sleeps half of a
+// call).  The steps' events are recorded behind the graph launch (an event recorded inside a capture cannot be waited for by a
+// stream outside it): every step of the chunk completes, for its waiters, when the chunk does.  Anything that cannot be captured
+// (a scratch block that has to grow: device synchronisation) ends the capture; the chunk is then issued the plain way.
+// *captured = 1 when the graph route was taken.
+int32_t nep_iar_steps_graph(nep_iar* s, int32_t k0, int32_t count, int32_t refine_steps, nep_stream stream, int32_t* captured) {
+    ARGCHK(s && count >= 1);
+    if (captured) *captured = 0;
+    hipStream_t st = as_stream(stream);
+    const int32_t wt_for0 = s->wt_for; const bool waited0 = s->upload_waited; hipStream_t last0 = s->last;
+    bool ok = false;
+    if (st != nullptr && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        s->no_events = true;
+        int rc = NEP_OK;
+        for (int32_t k = k0; k < k0 + count && !rc; ++k) rc = nep_iar_step(s, k, refine_steps, stream);
+        s->no_events = false;
+        hipGraph_t g = nullptr;
+        hipError_t e = hipStreamEndCapture(st, &g);
+        hipGraphExec_t ge = nullptr;
+        if (!rc && e == hipSuccess && g && hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) == hipSuccess && ge) {
+            if (hipGraphLaunch(ge, st) == hipSuccess) { s->graphs.push_back(ge); ok = true; }
+            else (void)hipGraphExecDestroy(ge);
+        }
+        if (g) (void)hipGraphDestroy(g);
+        if (!ok) (void)hipGetLastError();
+    } else (void)hipGetLastError();
+    if (!ok) {                              // not capturable (or the NULL stream): the plain way, from the state the chunk started with
+        s->wt_for = wt_for0; s->upload_waited = waited0; s->last = last0;
+        return nep_iar_steps(s, k0, count, refine_steps, stream);
+    }
+    for (int32_t k = k0; k < k0 + count; ++k) {
+        if (!s->ev[k]) HIPCHK(hipEventCreateWithFlags(&s->ev[k], hipEventDisableTiming | hipEventBlockingSync));
+        HIPCHK(hipEventRecord(s->ev[k], st));
+    }
+    if (captured) *captured = 1;
     return NEP_OK;
 }
 

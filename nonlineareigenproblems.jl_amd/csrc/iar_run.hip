@@ -36,6 +36,7 @@ extern "C" {
 int32_t nep_iar_create(nep_spmf* spmf, nep_lu* lu, int64_t n, int32_t m, nep_cdouble* dV, int64_t ldv, const nep_cdouble* dCtab,
                        int64_t ldc, const int64_t* d_active, nep_cdouble* dwork3n, const double* h_cabs, const nep_cdouble* h_cf,
                        int32_t mt, nep_cdouble* dH, nep_cdouble* h_pinnedH, int32_t orth_method, nep_iar** out);
+int32_t nep_iar_steps_graph(nep_iar* s, int32_t k0, int32_t count, int32_t refine_steps, nep_stream stream, int32_t* captured);
 }
 
 namespace {
@@ -403,6 +404,8 @@ int32_t nep_iar_run(nep_spmf* spmf, nep_lu* lu, int64_t n, const nep_iar_opts* o
     const int CHUNK = unthrottled ? (getenv("NEP_IAR_BATCH") ? std::max(1, atoi(getenv("NEP_IAR_BATCH"))) : 8) : 4;
     const int P = std::min(256, std::max(1, 3072 / mt));        // panel width of nep_resid_batch_dev's output layout
     int k = 1; bool done = false; int status = NEP_OK;
+    const bool use_graph = getenv("NEP_IAR_GRAPH") && atoi(getenv("NEP_IAR_GRAPH")) != 0;
+    int n_graph = 0;
     auto finished = [&]() { return R.conv >= neigs; };
 
     auto batch_ready = [&]() -> int {
@@ -527,6 +530,8 @@ int32_t nep_iar_run(nep_spmf* spmf, nep_lu* lu, int64_t n, const nep_iar_opts* o
     };
 
     // ---- the cooperative loop
+    hipEvent_t te0 = nullptr, te1 = nullptr; bool te1_rec = false;
+    if (trace) { (void)hipEventCreate(&te0); (void)hipEventCreate(&te1); (void)hipEventRecord(te0, st); }
     const double t_loop = now();
     double tt_steps = 0, tt_A = 0, tt_B = 0, tt_C = 0, tt_sleep = 0, t_enq_done = 0; double tq = 0;
     while (status == NEP_OK) {
@@ -544,7 +549,9 @@ int32_t nep_iar_run(nep_spmf* spmf, nep_lu* lu, int64_t n, const nep_iar_opts* o
                 if (nb > 0) {
                     int plan = R.ref.plan();
                     if (plan > 0 && R.ref.settled() && !getenv("NEP_IAR_RECORD_ALL")) plan |= 0x100;
-                    status = nep_iar_steps(R.step, k, nb, plan, stream);
+                    // chunks after the first as hipGraphs (NEP_IAR_GRAPH, default off for the NULL stream: it cannot be captured)
+                    if (use_graph && k > 1) { int32_t cap = 0; status = nep_iar_steps_graph(R.step, k, nb, plan, stream, &cap); n_graph += cap; }
+                    else status = nep_iar_steps(R.step, k, nb, plan, stream);
                     if (status) break;
                     for (int kk = k; kk < k + nb; ++kk) {
                         R.plans[kk] = plan;
@@ -553,7 +560,7 @@ int32_t nep_iar_run(nep_spmf* spmf, nep_lu* lu, int64_t n, const nep_iar_opts* o
                     k += nb; progressed = true;
                 }
             } else done = true;
-            if (k > m) { if (!done && trace) t_enq_done = now() - t_loop; done = true; }
+            if (k > m) { if (!done && trace) { t_enq_done = now() - t_loop; if (te1 && !te1_rec) { (void)hipEventRecord(te1, st); te1_rec = true; } } done = true; }
         }
         if (trace) { const double t = now(); tt_steps += t - tq; tq = t; }
         // (A)
@@ -600,6 +607,15 @@ int32_t nep_iar_run(nep_spmf* spmf, nep_lu* lu, int64_t n, const nep_iar_opts* o
     if (trace)
         fprintf(stderr, "nep_iar_run trace (ms): set-up %.2f | loop %.2f: steps %.2f (all enqueued at %.2f) A %.2f B %.2f (callback %.2f) C %.2f sleep %.2f\n",
                 t_loop - t_entry, now() - t_loop, tt_steps, t_enq_done, tt_A, tt_B, t_fv, tt_C, tt_sleep);
+    if (trace && use_graph) fprintf(stderr, "nep_iar_run: %d chunks went out as hipGraphs\n", n_graph);
+    if (trace && te0 && te1 && te1_rec) {
+        float ms_ = 0.0f;
+        if (hipEventSynchronize(te1) == hipSuccess && hipEventElapsedTime(&ms_, te0, te1) == hipSuccess)
+            fprintf(stderr, "nep_iar_run: the recurrence's %d steps took %.2f ms on the device\n", m, ms_);
+        (void)hipGetLastError();
+    }
+    if (te0) (void)hipEventDestroy(te0);
+    if (te1) (void)hipEventDestroy(te1);
     // whatever is still queued (a failure, or speculative work beyond convergence) must not outlive the blocks it uses
     while (!stA.empty()) { drop_batch(stA.front()); stA.pop_front(); }
     while (!stC.empty()) { drop_check(stC.front()); stC.pop_front(); }

@@ -5,11 +5,14 @@ import nep_amd as na
 import torch
 from nep_amd.linsolvers import _DeviceRefactor
 nep = na.nep_gallery("gun_spmf_scaled")
+import contextlib
+side = torch.cuda.Stream() if os.environ.get("DIAG_SIDE_STREAM") else None
 ts = []
 for r in range(int(os.environ.get("REPS", "24"))):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     creator = na.FactorizeLinSolverCreator(max_factorizations=0)
-    out = na.iar(nep, sigma=0.0, gamma=1.0, maxit=100, neigs=np.inf, v=np.ones(nep.n), tol=1e-10, linsolvercreator=creator)
+    with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+        out = na.iar(nep, sigma=0.0, gamma=1.0, maxit=100, neigs=np.inf, v=np.ones(nep.n), tol=1e-10, linsolvercreator=creator)
     torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) * 1e3)
     if r == 0:
         _DeviceRefactor.wait()

@@ -271,6 +271,31 @@ def test_iar_native_run_retry_routes(na, monkeypatch):
     assert len(ei.value.lam) == 12 and ei.value.v.shape == (n, 12)
 
 
+def test_iar_native_run_chunks_as_hipgraphs(na, monkeypatch):
+    """NEP_IAR_GRAPH=1 (opt-in; measured: no gain): the chunks of Arnoldi steps after the first are captured
+    on the caller's (non-NULL) stream and replayed as hipGraphs, their events recorded behind the launch -- same eigenpairs, same
+    error history as the plain launches; on the NULL stream, which cannot be captured, the switch changes nothing"""
+    import torch
+    n, m = 2000, 48
+    nep = na.nep_gallery("gun_spmf_scaled", n)
+    kw = dict(sigma=0.0, gamma=1.0, maxit=m, neigs=np.inf, v=np.ones(n), tol=1e-10)
+    na.iar(nep, **kw)
+    side = torch.cuda.Stream()
+    out = []
+    for g in ("0", "1"):
+        monkeypatch.setenv("NEP_IAR_GRAPH", g)
+        h = []
+        r0 = na.iar.native_runs
+        with torch.cuda.stream(side):
+            lam, Q, _ = na.iar(nep, errhist=h, **kw)
+        side.synchronize()
+        assert na.iar.native_runs == r0 + 1
+        out.append((lam, np.concatenate(h)))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    lam2, _, _ = na.iar(nep, **kw)                      # NULL stream, switch still on
+    assert np.array_equal(lam2, out[0][0])
+
+
 @pytest.mark.parametrize("n,m", [(1310, 30), (2000, 64), (333, 40)])
 def test_iar_native_run_poisoned_basis_small_sizes(na, monkeypatch, n, m):
     """the slack-only clearing of the Krylov basis (nep_iar_run) at sizes whose column ends fall anywhere inside the tiles of the
