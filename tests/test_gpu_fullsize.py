@@ -356,7 +356,10 @@ def test_c2_basis_needs_no_full_zero_fill(na, monkeypatch):
     bit for bit what it returns after a full zero fill (NEP_IAR_FULL_ZERO): no kernel of the pipeline reads a row that no step wrote"""
     nep = na.nep_gallery("gun_spmf_scaled"); n = nep.n
     out = {}
-    na.iar(nep, sigma=0.0, gamma=1.0, maxit=100, neigs=np.inf, v=np.ones(n), tol=1e-10)      # (the refinement count settles: same plan in both runs below)
+    from nep_amd.linsolvers import _DeviceRefactor
+    na.iar(nep, sigma=0.0, gamma=1.0, maxit=100, neigs=np.inf, v=np.ones(n), tol=1e-10)
+    _DeviceRefactor.wait()            # (the device-LU plan exists from here on: both runs below take the same factorisation route ...)
+    na.iar(nep, sigma=0.0, gamma=1.0, maxit=100, neigs=np.inf, v=np.ones(n), tol=1e-10)      # (... and the refinement count has settled)
     for mode in ("NEP_IAR_FULL_ZERO", "NEP_IAR_POISON"):
         monkeypatch.setenv(mode, "1")
         r0 = na.iar.native_runs
